@@ -1,0 +1,112 @@
+/*
+ * tsfresh_amd C-ABI  --  MI355X (gfx950) feature-extraction hot path.
+ *
+ * The reference (blue-yonder/tsfresh) is pure Python and has no FFI of its own.  Its plug points for
+ * this path are:
+ *   - tsfresh/feature_extraction/extraction.py:308  _do_extraction_on_chunk(chunk, fc_parameters)
+ *       one (id, kind) series  x  the FCParameters dict  ->  [(id, "kind__calc__params", value), ...]
+ *   - tsfresh/feature_extraction/extraction.py:193  _do_extraction  (adapter -> map_reduce -> pivot)
+ *   - tsfresh/utilities/distribution.py:74          DistributorBaseClass.map_reduce
+ * This header is what a ctypes binding for that path binds instead: the FCParameters dict is compiled
+ * to a flat list of "feature specs" (one per output column), the list of series is handed over as one
+ * ragged buffer (values + offsets), and the result is the dense [n_series x n_cols] float64 matrix
+ * that tsfresh/feature_extraction/data.py:86 (pivot) would otherwise assemble from tuples.
+ *
+ * Plain C, plain pointers and sizes, no torch types.  All functions return 0 on success or a
+ * negative tsfa_status; the message is available from tsfa_last_error() (thread-local).
+ */
+#ifndef TSFRESH_AMD_H
+#define TSFRESH_AMD_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define TSFA_VERSION 100 /* 0.1.0 */
+
+typedef enum tsfa_status {
+    TSFA_OK = 0,
+    TSFA_ERR_INVALID = -1,     /* bad argument */
+    TSFA_ERR_UNSUPPORTED = -2, /* calculator / parameter not implemented natively */
+    TSFA_ERR_NO_DEVICE = -3,   /* no HIP device: the library never falls back to the CPU */
+    TSFA_ERR_HIP = -4,         /* HIP runtime error */
+    TSFA_ERR_TOO_LONG = -5     /* a series exceeds the per-workgroup LDS budget */
+} tsfa_status;
+
+/* element type of the ragged value buffer */
+typedef enum tsfa_dtype { TSFA_F32 = 0, TSFA_F64 = 1 } tsfa_dtype;
+
+/* where the caller's buffers live */
+typedef enum tsfa_memspace { TSFA_HOST = 0, TSFA_DEVICE = 1 } tsfa_memspace;
+
+/*
+ * One output column: a calculator of tsfresh/feature_extraction/feature_calculators.py plus one
+ * parameter combination of the FCParameters dict (tsfresh/feature_extraction/settings.py:165-280).
+ * `calc` comes from tsfa_calc_id("<calculator name>"); the meaning of p[] per calculator is listed in
+ * tsfresh_amd/csrc/tsfa_specs.h (string-valued parameters such as attr / f_agg are enum codes).
+ */
+typedef struct tsfa_feature_spec {
+    int32_t calc;
+    int32_t reserved;
+    double p[4];
+} tsfa_feature_spec;
+
+typedef struct tsfa_plan tsfa_plan; /* opaque; owned by the library */
+
+/* ---- library / device ---- */
+int tsfa_version(void);
+/* number of visible HIP devices (0 if none; never fails) */
+int tsfa_device_count(void);
+/* thread-local message of the last failing call on this thread ("" if none) */
+const char *tsfa_last_error(void);
+
+/* ---- calculator registry ---- */
+/* id of a feature calculator by its tsfresh name (feature_calculators.py), or -1 if not native */
+int tsfa_calc_id(const char *name);
+/* inverse of tsfa_calc_id; NULL if out of range */
+const char *tsfa_calc_name(int calc);
+/* number of native calculators */
+int tsfa_calc_count(void);
+
+/* ---- plan: the compiled FCParameters dict for one kind ---- */
+/*
+ * specs[i] describes output column i.  `device` is the HIP device ordinal.  Replaces the Python loop
+ * over fc_parameters.items() in extraction.py:339-378.  Returns TSFA_ERR_UNSUPPORTED (and names the
+ * offender in tsfa_last_error) for a calculator/parameter combination that has no kernel.
+ */
+int tsfa_plan_create(const tsfa_feature_spec *specs, int32_t n_specs, int32_t device, tsfa_plan **out_plan);
+int32_t tsfa_plan_n_cols(const tsfa_plan *plan);
+void tsfa_plan_destroy(tsfa_plan *plan);
+
+/*
+ * Extract all planned features for n_series ragged series.  Replaces distributor.map_reduce(
+ * _do_extraction_on_chunk, ...) + pivot (extraction.py:294-304) for one kind.
+ *
+ *   values   concatenated samples, series s occupies [offsets[s], offsets[s+1]);  dtype per `dtype`
+ *   offsets  n_series+1 int64, offsets[0] may be non-zero (a view into a larger buffer)
+ *   out      row-major [n_series x ld_out] float64, ld_out >= n_cols; caller-allocated, caller-owned;
+ *            NaN where the reference yields NaN
+ *   space    TSFA_HOST: values/offsets/out are host pointers (the library stages them through HBM);
+ *            TSFA_DEVICE: all three are device pointers on the plan's device
+ *   stream   a hipStream_t (or NULL = the plan's own stream).  With TSFA_DEVICE and a non-NULL
+ *            stream the call returns after enqueueing; otherwise it is synchronous.
+ *
+ * One plan may be used by one host thread at a time; plans on different devices are independent.
+ */
+int tsfa_extract(tsfa_plan *plan, const void *values, int32_t dtype, const int64_t *offsets,
+                 int64_t n_series, double *out, int64_t ld_out, int32_t space, void *stream);
+
+/*
+ * Timing of the kernels of the last tsfa_extract on this plan, measured with HIP events on the
+ * stream the kernels were launched on.  names[i] / ms[i] for i < returned count (<= cap).
+ * Only recorded when tsfa_plan_set_profiling(plan, 1) was called before the extract.
+ */
+int tsfa_plan_set_profiling(tsfa_plan *plan, int32_t enable);
+int32_t tsfa_plan_last_timings(const tsfa_plan *plan, const char **names, float *ms, int32_t cap);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* TSFRESH_AMD_H */

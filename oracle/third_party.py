@@ -1,0 +1,181 @@
+"""ORACLE (test infrastructure only): restatement of the third-party numerics the reference calls but that are NOT
+importable in the main interpreter of this image.
+
+  * statsmodels >= 0.13 (setup.cfg:42; floor only, not vendored under /root/reference)
+        acf / acovf / pacf("ld") / levinson_durbin / adfuller(autolag="AIC") / mackinnonp / AutoReg(trend="c")
+        call sites: feature_calculators.py:429 (acf), :490 (pacf), :521 (adfuller), :1493-1494 (AutoReg)
+  * PyWavelets (setup.cfg:44, unpinned)
+        pywt.cwt(x, scales, "mexh")     call site: feature_calculators.py:1402
+
+Pinning: tests/golden/gen_golden_conda.py runs the REAL libraries (statsmodels 0.12.2 with two import shims,
+pywt 1.1.1) under /opt/conda/bin/python3.9 in the build container and commits their outputs under tests/golden/;
+tests/test_oracle_golden.py checks this file against those vectors and against the reference's own known-answer
+tests (tests/units/feature_extraction/test_feature_calculations.py:238-412, 1055-1127).  statsmodels 0.12.2 is
+below the reference's floor (0.13); the algorithms restated here did not change between the two, but the
+short-series error behaviour of AutoReg/adfuller is taken from 0.12.2.
+"""
+import numpy as np
+from scipy import stats
+
+
+# ------------------------------------------------------------------------------------------------
+# statsmodels.tsa.stattools
+# ------------------------------------------------------------------------------------------------
+def acovf_adjusted(x, nlags=None):
+    """acovf(x, adjusted=True, demean=True, fft=False): sum_t xo[t] xo[t+k] / (n - k)."""
+    x = np.asarray(x, dtype=np.float64)
+    n = len(x)
+    xo = x - x.mean()
+    kmax = n - 1 if nlags is None else min(nlags, n - 1)
+    out = np.empty(kmax + 1)
+    for k in range(kmax + 1):
+        out[k] = np.dot(xo[: n - k], xo[k:]) / (n - k)
+    return out
+
+
+def acf_adjusted(x, nlags):
+    """acf(x, adjusted=True, nlags=nlags): avf[:nlags + 1] / avf[0]."""
+    avf = acovf_adjusted(x, nlags)
+    return avf / avf[0]
+
+
+def levinson_durbin_pacf(acv, nlags):
+    """levinson_durbin(acv, nlags, isacov=True)[2]: the diagonal of phi with pacf[0] = 1."""
+    order = nlags
+    phi = np.zeros((order + 1, order + 1))
+    sig = np.zeros(order + 1)
+    phi[1, 1] = acv[1] / acv[0]
+    sig[1] = acv[0] - phi[1, 1] * acv[1]
+    for k in range(2, order + 1):
+        phi[k, k] = (acv[k] - np.dot(phi[1:k, k - 1], acv[1:k][::-1])) / sig[k - 1]
+        for j in range(1, k):
+            phi[j, k] = phi[j, k - 1] - phi[k, k] * phi[k - j, k - 1]
+        sig[k] = sig[k - 1] * (1 - phi[k, k] ** 2)
+    pacf = np.diag(phi).copy()
+    pacf[0] = 1.0
+    return pacf
+
+
+def pacf_ld(x, nlags):
+    """pacf(x, method="ld", nlags): adjusted autocovariance + Levinson-Durbin; ValueError as statsmodels raises."""
+    x = np.asarray(x, dtype=np.float64)
+    if nlags >= x.shape[0] // 2:
+        raise ValueError("Can only compute partial correlations for lags up to 50% of the sample size.")
+    return levinson_durbin_pacf(acovf_adjusted(x, nlags), nlags)
+
+
+_TAU_MAX_C, _TAU_MIN_C, _TAU_STAR_C = 2.74, -18.83, -1.61
+_TAU_C_SMALLP = np.array([2.1659, 1.4412, 3.8269]) * np.array([1, 1, 1e-2])
+_TAU_C_LARGEP = np.array([1.7339, 9.3202, -1.2745, -1.0368]) * np.array([1, 1e-1, 1e-1, 1e-2])
+
+
+def mackinnonp_c(teststat):
+    """adfvalues.mackinnonp(teststat, regression="c", N=1)."""
+    if teststat > _TAU_MAX_C:
+        return 1.0
+    if teststat < _TAU_MIN_C:
+        return 0.0
+    coef = _TAU_C_SMALLP if teststat <= _TAU_STAR_C else _TAU_C_LARGEP
+    return stats.norm.cdf(np.polyval(coef[::-1], teststat))
+
+
+def _ols(y, X, want_cov=False):
+    """OLS by the pseudo-inverse, as statsmodels' default fit(method="pinv"):
+    params = pinv(X) y,  normalized_cov_params = pinv(X) pinv(X)^T  (statsmodels/regression/linear_model.py)."""
+    pinv = np.linalg.pinv(X)
+    beta = pinv @ y
+    resid = y - X @ beta
+    if want_cov:
+        return beta, float(resid @ resid), pinv @ pinv.T
+    return beta, float(resid @ resid)
+
+
+def adfuller_aic(x):
+    """adfuller(x, autolag="AIC") -> (teststat, pvalue, usedlag); raises ValueError like statsmodels."""
+    x = np.asarray(x, dtype=np.float64)
+    nobs = x.shape[0]
+    ntrend = 1
+    maxlag = int(np.ceil(12.0 * np.power(nobs / 100.0, 1 / 4.0)))
+    maxlag = min(nobs // 2 - ntrend - 1, maxlag)
+    if maxlag < 0:
+        raise ValueError("sample size is too short to use selected regression component")
+    d = np.diff(x)
+
+    def design(lags):
+        rows = np.arange(lags, len(d))  # t
+        cols = [x[rows]] + [d[rows - j] for j in range(1, lags + 1)]
+        return np.column_stack(cols), d[rows]
+
+    Z, y = design(maxlag)
+    n1 = len(y)
+    full = np.column_stack([np.ones(n1), Z])  # add_trend(prepend=True)
+    best = None
+    for lag in range(2, maxlag + 3):
+        _, ssr = _ols(y, full[:, :lag])
+        llf = -n1 / 2.0 * np.log(2 * np.pi) - n1 / 2.0 * np.log(ssr / n1) - n1 / 2.0
+        aic = -2 * llf + 2 * lag
+        if best is None or (aic, lag) < best:
+            best = (aic, lag)
+    usedlag = best[1] - 2
+    Z, y = design(usedlag)
+    n2 = len(y)
+    X = np.column_stack([Z[:, : usedlag + 1], np.ones(n2)])  # add_trend appends the constant
+    beta, ssr, ncov = _ols(y, X, want_cov=True)
+    sigma2 = ssr / (n2 - X.shape[1])
+    tstat = beta[0] / np.sqrt(sigma2 * ncov[0, 0])
+    return tstat, mackinnonp_c(tstat), usedlag
+
+
+def autoreg_params(x, k):
+    """AutoReg(x, lags=k, trend="c").fit().params = conditional OLS; raises ValueError/ZeroDivisionError when
+    statsmodels (0.12.2) cannot estimate the model (n < 2k + 2)."""
+    x = np.asarray(x, dtype=np.float64)
+    n = len(x)
+    if k >= n:
+        raise ValueError("maxlag should be < nobs")
+    nobs = n - k
+    if nobs < k + 1:
+        raise ValueError("The model specification cannot be estimated.")
+    if nobs == k + 1:
+        raise ZeroDivisionError("division by zero")
+    rows = np.arange(k, n)
+    X = np.column_stack([np.ones(nobs)] + [x[rows - j] for j in range(1, k + 1)])
+    beta, _ = _ols(x[rows], X)
+    return beta
+
+
+# ------------------------------------------------------------------------------------------------
+# pywt.cwt(x, scales, "mexh")   (pywt/_cwt.py, pywt/_functions.py; PyWavelets 1.1.1)
+# ------------------------------------------------------------------------------------------------
+_MEXH_CACHE = {}
+
+
+def _mexh_int_psi():
+    if "v" not in _MEXH_CACHE:
+        x = np.linspace(-8.0, 8.0, 1024)
+        psi = (1.0 - x ** 2) * np.exp(-(x ** 2) / 2.0) * 2.0 / (np.sqrt(3.0) * np.sqrt(np.sqrt(np.pi)))
+        step = x[1] - x[0]
+        _MEXH_CACHE["v"] = (np.cumsum(psi) * step, x, step)
+    return _MEXH_CACHE["v"]
+
+
+def cwt_mexh(data, scales):
+    """-> array [len(scales), len(data)] of float64 coefficients."""
+    data = np.asarray(data, dtype=np.float64)
+    int_psi, x, step = _mexh_int_psi()
+    out = np.empty((len(scales), data.shape[0]))
+    for i, scale in enumerate(scales):
+        j = np.arange(scale * (x[-1] - x[0]) + 1) / (scale * step)
+        j = j.astype(int)
+        if j[-1] >= int_psi.size:
+            j = np.extract(j < int_psi.size, j)
+        int_psi_scale = int_psi[j][::-1]
+        conv = np.convolve(data, int_psi_scale)
+        coef = -np.sqrt(scale) * np.diff(conv)
+        d = (coef.shape[-1] - data.shape[-1]) / 2.0
+        if d > 0:
+            coef = coef[int(np.floor(d)): -int(np.ceil(d))]
+        elif d < 0:
+            raise ValueError("Selected scale of {} too small.".format(scale))
+        out[i] = coef
+    return out

@@ -1,0 +1,136 @@
+// TEST INFRASTRUCTURE ONLY -- never loaded by the tsfresh_amd package.
+//
+// Compiles the per-series kernel sources (tsfresh_amd/csrc/fam_*.h) with g++ as a single-thread (nt = 1) program so
+// that the kernel LOGIC can be checked against the oracle on a box without a GPU (this container has none; GPU
+// minutes are scarce).  It does not exercise wavefront shuffles, LDS races, barriers or the MFMA fragment layout --
+// those are covered by the `-m gpu` tests, which call the real library through the C-ABI.
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+
+#include <string>
+#include <vector>
+
+#include "../../include/tsfresh_amd.h"
+#include "../../tsfresh_amd/csrc/fam_ar.h"
+#include "../../tsfresh_amd/csrc/fam_basic.h"
+#include "../../tsfresh_amd/csrc/fam_cwt.h"
+#include "../../tsfresh_amd/csrc/fam_entropy.h"
+#include "../../tsfresh_amd/csrc/fam_seq.h"
+#include "../../tsfresh_amd/csrc/fam_sort.h"
+#include "../../tsfresh_amd/csrc/fam_spectral.h"
+#include "../../tsfresh_amd/csrc/tsfa_host_tables.h"
+#include "../../tsfresh_amd/csrc/tsfa_layout.h"
+
+extern "C" int tsfa_emul_calc_id(const char *name) {
+    for (int i = 0; i < TSFA_N_CALCS; ++i)
+        if (strcmp(tsfa_calc_table[i].name, name) == 0) return i;
+    return -1;
+}
+
+extern "C" int tsfa_emul_extract(const tsfa_feature_spec *specs, int n_specs, const double *values,
+                                 const int64_t *offsets, int64_t n_series, double *out, int64_t ld, char *err,
+                                 int errlen) {
+    std::vector<TsfaSpec> fam[TSFA_N_FAMILIES], cwt_coef;
+    for (int i = 0; i < n_specs; ++i) {
+        TsfaSpec s;
+        s.calc = specs[i].calc;
+        s.col = i;
+        for (int k = 0; k < 4; ++k) s.p[k] = specs[i].p[k];
+        if (s.calc < 0 || s.calc >= TSFA_N_CALCS) {
+            snprintf(err, errlen, "spec %d: unknown calculator", i);
+            return TSFA_ERR_UNSUPPORTED;
+        }
+        const std::string why = tsfa_validate_spec(s);
+        if (!why.empty()) {
+            snprintf(err, errlen, "spec %d (%s): %s", i, tsfa_calc_table[s.calc].name, why.c_str());
+            return TSFA_ERR_UNSUPPORTED;
+        }
+        if (s.calc == TSFA_C_CWT_COEFFICIENTS) cwt_coef.push_back(s);
+        else fam[tsfa_calc_table[s.calc].family].push_back(s);
+    }
+    TsfaCwtBank bank;
+    if (!cwt_coef.empty()) {
+        const std::string why = bank.build(cwt_coef);
+        if (!why.empty()) {
+            snprintf(err, errlen, "%s", why.c_str());
+            return TSFA_ERR_UNSUPPORTED;
+        }
+    }
+    std::vector<double> dectab, twc, tws;
+    tsfa_build_dectab(dectab);
+    tsfa_build_twiddles(twc, tws);
+
+    for (int64_t s = 0; s < n_series; ++s) {
+        const int n = (int)(offsets[s + 1] - offsets[s]);
+        const double *x = values + offsets[s];
+        double *row = out + s * ld;
+        for (int c = 0; c < n_specs; ++c) row[c] = TSFA_NAN;
+        if (n < 1) {
+            snprintf(err, errlen, "empty series");
+            return TSFA_ERR_INVALID;
+        }
+        const int maxn = n;
+        std::vector<double> red(TSFA_RED_DOUBLES);
+        NpScratch nps;
+        Blk b{0, 1, red.data(), &nps};
+        std::vector<double> xs(x, x + n);
+        xs.resize(n + 8, 0.0);
+        if (!fam[TSFA_FAM_BASIC].empty()) {
+            std::vector<double> w(maxn + 8);
+            std::vector<int> iw(512);
+            fam_basic_series(b, xs.data(), n, fam[TSFA_FAM_BASIC].data(), (int)fam[TSFA_FAM_BASIC].size(), row, w.data(),
+                             iw.data(), dectab.data());
+        }
+        if (!fam[TSFA_FAM_SORT].empty()) {
+            std::vector<double> srt(tsfa_pow2_ceil(maxn) + 8), w(768);
+            std::vector<int> iw(5040);
+            fam_sort_series(b, xs.data(), n, fam[TSFA_FAM_SORT].data(), (int)fam[TSFA_FAM_SORT].size(), row, srt.data(),
+                            w.data(), iw.data());
+        }
+        if (!fam[TSFA_FAM_SPECTRAL].empty()) {
+            const int nx = (maxn / 2 + 2 > 260) ? maxn / 2 + 2 : 260;
+            const int nd = (maxn > 256) ? maxn : 256;
+            std::vector<double> Xr(nx), Xi(nx), tc(nd), ts(nd), win(256), pxx(132);
+            std::vector<int> iw(128);
+            fam_spectral_series(b, xs.data(), n, fam[TSFA_FAM_SPECTRAL].data(), (int)fam[TSFA_FAM_SPECTRAL].size(), row,
+                                Xr.data(), Xi.data(), tc.data(), ts.data(), win.data(), pxx.data(), iw.data(),
+                                twc.data(), tws.data());
+        }
+        if (!fam[TSFA_FAM_AR].empty()) {
+            std::vector<double> xc(maxn + 8), aw(TSFA_AR_AW_DOUBLES);
+            fam_ar_series(b, xs.data(), n, fam[TSFA_FAM_AR].data(), (int)fam[TSFA_FAM_AR].size(), row, xc.data(), aw.data());
+        }
+        if (!fam[TSFA_FAM_ENTROPY].empty()) {
+            std::vector<double> thr(16);
+            fam_entropy_series(b, xs.data(), n, fam[TSFA_FAM_ENTROPY].data(), (int)fam[TSFA_FAM_ENTROPY].size(), row,
+                               thr.data());
+        }
+        if (!fam[TSFA_FAM_SEQ].empty()) {
+            const int ntab = 2;
+            const int cap = SeqLds::table_cap(maxn);
+            std::vector<unsigned char> seq((size_t)ntab * maxn + 8);
+            std::vector<uint32_t> tab((size_t)ntab * cap);
+            const double *xp = xs.data();
+            fam_seq_series(b, [=](int i) { return xp[i]; }, n, fam[TSFA_FAM_SEQ].data(), (int)fam[TSFA_FAM_SEQ].size(), row,
+                           seq.data(), tab.data(), ntab, cap);
+        }
+        if (!fam[TSFA_FAM_CWT].empty()) {
+            std::vector<unsigned char> lds(CwtPeaksLayout().carve(nullptr, maxn, 1) + 64);
+            CwtPeaksLayout L;
+            unsigned char *basep = lds.data();
+            basep += (16 - ((uintptr_t)basep & 15)) & 15;
+            L.carve(basep, maxn, 1);
+            const double *xp = xs.data();
+            fam_cwtpeaks_series(b, [=](int i) { return xp[i]; }, n, fam[TSFA_FAM_CWT].data(), (int)fam[TSFA_FAM_CWT].size(),
+                                row, L.p);
+        }
+        for (int c = 0; c < bank.C; ++c) {  // plain-loop stand-in for k_cwt_gemm
+            double acc = 0.0;
+            const int kmax = (n < bank.S4) ? n : bank.S4;
+            for (int k = 0; k < kmax; ++k) acc += x[k] * bank.W[(size_t)c * bank.S4 + k];
+            row[bank.cols[c]] = (bank.coeff_idx[c] < n) ? acc : TSFA_NAN;
+        }
+    }
+    return TSFA_OK;
+}

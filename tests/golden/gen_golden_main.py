@@ -1,0 +1,83 @@
+"""Generate tests/golden/ref_main.npz by running the REAL reference (read from /root/reference) in the main
+interpreter of the build container.
+
+`import tsfresh` fails here because pywt / statsmodels / stumpy are not installed, so those modules
+are stubbed in sys.modules with objects that RAISE if ever used; the five calculators that need them
+(cwt_coefficients, agg_autocorrelation, partial_autocorrelation, augmented_dickey_fuller, ar_coefficient) are
+removed from the FCParameters and covered by gen_golden_conda.py instead.  Everything else -- 70 calculators,
+701 columns -- is the unmodified reference code path `extraction._do_extraction_on_chunk`.
+
+    python tests/golden/gen_golden_main.py        # needs /root/reference; writes tests/golden/ref_main.npz
+"""
+import os
+import sys
+import types
+import warnings
+
+import numpy as np
+import pandas as pd
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, HERE)
+
+
+class _Raiser(types.ModuleType):
+    def __getattr__(self, item):
+        if item.startswith("__"):
+            raise AttributeError(item)
+
+        def _fail(*a, **k):
+            raise RuntimeError("stubbed third-party module %s.%s was called" % (self.__name__, item))
+        return _fail
+
+
+for mod in ("pywt", "stumpy", "statsmodels", "statsmodels.tools", "statsmodels.tools.sm_exceptions", "statsmodels.tsa",
+            "statsmodels.tsa.ar_model", "statsmodels.tsa.stattools", "statsmodels.stats", "statsmodels.stats.multitest"):
+    sys.modules[mod] = _Raiser(mod)
+sys.modules["statsmodels.tools.sm_exceptions"].MissingDataError = type("MissingDataError", (Exception,), {})
+sys.path.insert(0, "/root/reference")
+
+from tsfresh.feature_extraction import settings as ref_settings  # noqa: E402
+from tsfresh.feature_extraction.extraction import _do_extraction_on_chunk  # noqa: E402
+
+from golden_cases import golden_series, pack  # noqa: E402
+
+NEED_THIRD_PARTY = ("cwt_coefficients", "agg_autocorrelation", "partial_autocorrelation", "augmented_dickey_fuller",
+                    "ar_coefficient")
+
+
+def main():
+    cases = golden_series()
+    params = ref_settings.ComprehensiveFCParameters()
+    full_names = {}
+    for cls in ("ComprehensiveFCParameters", "EfficientFCParameters", "MinimalFCParameters"):
+        p = getattr(ref_settings, cls)()
+        res = _do_extraction_on_chunk((0, "value", pd.Series(np.arange(60.0) % 7)),
+                                      {k: v for k, v in p.items() if k not in NEED_THIRD_PARTY}, None, False)
+        full_names[cls] = [r[1] for r in res]
+        full_names[cls + "_keys"] = list(p.keys())
+    for k in NEED_THIRD_PARTY:
+        del params[k]
+    names, rows = None, []
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        for label, x in cases:
+            res = _do_extraction_on_chunk((label, "value", pd.Series(x)), params, None, False)
+            cols = [r[1] for r in res]
+            if names is None:
+                names = cols
+            assert cols == names
+            rows.append([float(r[2]) for r in res])
+    values, offsets = pack(cases)
+    out = os.path.join(HERE, "ref_main.npz")
+    np.savez_compressed(
+        out, values=values, offsets=offsets, labels=np.array([c[0] for c in cases]), names=np.array(names),
+        matrix=np.asarray(rows, dtype=np.float64),
+        **{"names_" + k: np.array(v) for k, v in full_names.items()},
+        versions=np.array(["numpy " + np.__version__, "pandas " + pd.__version__,
+                           "scipy " + __import__("scipy").__version__, "python " + sys.version.split()[0]]))
+    print("wrote", out, len(names), "columns x", len(rows), "series")
+
+
+if __name__ == "__main__":
+    main()

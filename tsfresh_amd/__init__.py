@@ -1,0 +1,14 @@
+"""tsfresh_amd: the feature-extraction hot path of tsfresh, MI355X-native.
+
+`extract_features` keeps the reference's DataFrame-in / DataFrame-out contract and FCParameters dictionaries
+(tsfresh/feature_extraction/extraction.py:30); the arithmetic runs in hand-written HIP kernels for gfx950 behind the
+C-ABI declared in include/tsfresh_amd.h.  There is no CPU compute path.
+"""
+from tsfresh_amd.feature_extraction.extraction import extract_features  # noqa: F401
+from tsfresh_amd.feature_extraction.settings import (  # noqa: F401
+    ComprehensiveFCParameters,
+    EfficientFCParameters,
+    MinimalFCParameters,
+)
+
+__version__ = "0.1.0"

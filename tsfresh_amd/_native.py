@@ -1,0 +1,155 @@
+"""ctypes binding of libtsfresh_amd.so (include/tsfresh_amd.h).
+
+The library is built in-tree by `tsfresh_amd/csrc/Makefile` (or `__graft_entry__.build()`).  Loading fails loudly
+when it is missing, and computing fails loudly when no HIP device is visible: there is no CPU fallback.
+"""
+import ctypes
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libtsfresh_amd.so")
+
+TSFA_OK = 0
+TSFA_ERR_INVALID = -1
+TSFA_ERR_UNSUPPORTED = -2
+TSFA_ERR_NO_DEVICE = -3
+TSFA_ERR_HIP = -4
+TSFA_ERR_TOO_LONG = -5
+TSFA_F32, TSFA_F64 = 0, 1
+TSFA_HOST, TSFA_DEVICE = 0, 1
+
+# every symbol include/tsfresh_amd.h declares
+EXPORTS = (
+    "tsfa_version", "tsfa_device_count", "tsfa_last_error", "tsfa_calc_id", "tsfa_calc_name", "tsfa_calc_count",
+    "tsfa_plan_create", "tsfa_plan_n_cols", "tsfa_plan_destroy", "tsfa_extract", "tsfa_plan_set_profiling",
+    "tsfa_plan_last_timings",
+)
+
+
+class FeatureSpec(ctypes.Structure):
+    _fields_ = [("calc", ctypes.c_int32), ("reserved", ctypes.c_int32), ("p", ctypes.c_double * 4)]
+
+
+class NativeError(RuntimeError):
+    def __init__(self, code, message):
+        super().__init__("tsfresh_amd native error {}: {}".format(code, message))
+        self.code = code
+
+
+_lib = None
+
+
+def load():
+    """Load (once) and return the ctypes handle; raises ImportError if the library has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            "{} is missing: build it with `make -C tsfresh_amd/csrc` (hipcc --offload-arch=gfx950). "
+            "tsfresh_amd has no CPU fallback.".format(LIB_PATH))
+    lib = ctypes.CDLL(LIB_PATH)
+    lib.tsfa_version.restype = ctypes.c_int
+    lib.tsfa_device_count.restype = ctypes.c_int
+    lib.tsfa_last_error.restype = ctypes.c_char_p
+    lib.tsfa_calc_id.argtypes = [ctypes.c_char_p]
+    lib.tsfa_calc_id.restype = ctypes.c_int
+    lib.tsfa_calc_name.argtypes = [ctypes.c_int]
+    lib.tsfa_calc_name.restype = ctypes.c_char_p
+    lib.tsfa_calc_count.restype = ctypes.c_int
+    lib.tsfa_plan_create.argtypes = [ctypes.POINTER(FeatureSpec), ctypes.c_int32, ctypes.c_int32,
+                                     ctypes.POINTER(ctypes.c_void_p)]
+    lib.tsfa_plan_create.restype = ctypes.c_int
+    lib.tsfa_plan_n_cols.argtypes = [ctypes.c_void_p]
+    lib.tsfa_plan_n_cols.restype = ctypes.c_int32
+    lib.tsfa_plan_destroy.argtypes = [ctypes.c_void_p]
+    lib.tsfa_plan_destroy.restype = None
+    lib.tsfa_extract.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int32, ctypes.c_void_p, ctypes.c_int64,
+                                 ctypes.c_void_p, ctypes.c_int64, ctypes.c_int32, ctypes.c_void_p]
+    lib.tsfa_extract.restype = ctypes.c_int
+    lib.tsfa_plan_set_profiling.argtypes = [ctypes.c_void_p, ctypes.c_int32]
+    lib.tsfa_plan_set_profiling.restype = ctypes.c_int
+    lib.tsfa_plan_last_timings.argtypes = [ctypes.c_void_p, ctypes.POINTER(ctypes.c_char_p),
+                                           ctypes.POINTER(ctypes.c_float), ctypes.c_int32]
+    lib.tsfa_plan_last_timings.restype = ctypes.c_int32
+    _lib = lib
+    return lib
+
+
+def _check(lib, rc):
+    if rc != TSFA_OK:
+        raise NativeError(rc, lib.tsfa_last_error().decode("utf-8", "replace"))
+
+
+def device_count():
+    return int(load().tsfa_device_count())
+
+
+def calc_id(name):
+    return int(load().tsfa_calc_id(name.encode("ascii")))
+
+
+class Plan:
+    """Owns a `tsfa_plan*`: the compiled list of output columns of one kind on one device."""
+
+    def __init__(self, specs, device=0):
+        """specs: iterable of (calc_id, (p0, p1, p2, p3))."""
+        lib = load()
+        specs = list(specs)
+        arr = (FeatureSpec * max(len(specs), 1))()
+        for i, (cid, p) in enumerate(specs):
+            arr[i].calc = int(cid)
+            arr[i].reserved = 0
+            for k in range(4):
+                arr[i].p[k] = float(p[k])
+        handle = ctypes.c_void_p()
+        _check(lib, lib.tsfa_plan_create(arr, len(specs), int(device), ctypes.byref(handle)))
+        self._lib = lib
+        self._h = handle
+        self.n_cols = len(specs)
+        self.device = int(device)
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._lib.tsfa_plan_destroy(self._h)
+            self._h = None
+
+    __del__ = close
+
+    def set_profiling(self, enable=True):
+        _check(self._lib, self._lib.tsfa_plan_set_profiling(self._h, 1 if enable else 0))
+
+    def last_timings(self):
+        cap = 32
+        names = (ctypes.c_char_p * cap)()
+        ms = (ctypes.c_float * cap)()
+        n = self._lib.tsfa_plan_last_timings(self._h, names, ms, cap)
+        return [(names[i].decode(), float(ms[i])) for i in range(n)]
+
+    def extract_host(self, values, offsets):
+        """values: 1-D float32/float64 ndarray; offsets: int64 ndarray (n_series + 1) -> float64 [n_series, n_cols]."""
+        values = np.ascontiguousarray(values)
+        if values.dtype == np.float32:
+            dt = TSFA_F32
+        else:
+            values = np.ascontiguousarray(values, dtype=np.float64)
+            dt = TSFA_F64
+        offsets = np.ascontiguousarray(offsets, dtype=np.int64)
+        n_series = offsets.shape[0] - 1
+        out = np.empty((n_series, self.n_cols), dtype=np.float64)
+        if n_series == 0 or self.n_cols == 0:
+            return out
+        if values.size == 0:
+            raise ValueError("every series must hold at least one sample")
+        _check(self._lib, self._lib.tsfa_extract(
+            self._h, values.ctypes.data_as(ctypes.c_void_p), dt, offsets.ctypes.data_as(ctypes.c_void_p), n_series,
+            out.ctypes.data_as(ctypes.c_void_p), self.n_cols, TSFA_HOST, None))
+        return out
+
+    def extract_device(self, values_ptr, dtype, offsets_ptr, n_series, out_ptr, ld_out, stream=None):
+        """Raw device-pointer entry (ints): used with torch tensors (`.data_ptr()`) by bench.py / the sharded path."""
+        _check(self._lib, self._lib.tsfa_extract(
+            self._h, ctypes.c_void_p(values_ptr), int(dtype), ctypes.c_void_p(offsets_ptr), int(n_series),
+            ctypes.c_void_p(out_ptr), int(ld_out), TSFA_DEVICE, ctypes.c_void_p(stream) if stream else None))

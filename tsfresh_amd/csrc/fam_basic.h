@@ -1,0 +1,440 @@
+// Family BASIC: reductions, scans and counts over the LDS-resident series.
+// Each case cites the reference calculator it restates (fc.py = tsfresh/feature_extraction/feature_calculators.py).
+#ifndef TSFA_FAM_BASIC_H
+#define TSFA_FAM_BASIC_H
+
+#include "tsfa_common.h"
+
+// decimal table for benford_correlation: dectab[(k + TSFA_DEC_KMIN_OFF) * 9 + (d - 1)] = correctly rounded
+// double of the decimal "d e k", k in [-324, 308]
+#define TSFA_DEC_KMIN (-324)
+#define TSFA_DEC_KMAX 308
+#define TSFA_DEC_ROWS (TSFA_DEC_KMAX - TSFA_DEC_KMIN + 1)
+
+// First character of np.format_float_scientific(v) for v >= 0 (fc.py:2369-2371): the leading digit of the
+// SHORTEST round-tripping decimal representation of the float64 v.  Because repr() is monotone and
+// "d e k" is itself a shortest representation, that digit is max{d : v >= RN(d * 10^k)} in the decade
+// k = max{k : v >= RN(10^k)} -- comparisons against the correctly rounded table, no arithmetic.
+TSFA_DEV int tsfa_leading_decimal_digit(double v, const double *dectab) {
+    if (!(v > 0.0)) return 0;
+    if (isinf(v)) v = 1.7976931348623157e308;  // np.nan_to_num
+    int e;
+    frexp(v, &e);  // v = m * 2^e, m in [0.5, 1)
+    int k = (int)floor((double)(e - 1) * 0.30102999566398120);
+    if (k < TSFA_DEC_KMIN) k = TSFA_DEC_KMIN;
+    if (k > TSFA_DEC_KMAX) k = TSFA_DEC_KMAX;
+    while (k > TSFA_DEC_KMIN && v < dectab[(k - TSFA_DEC_KMIN) * 9]) --k;
+    while (k < TSFA_DEC_KMAX && v >= dectab[(k + 1 - TSFA_DEC_KMIN) * 9]) ++k;
+    const double *row = dectab + (k - TSFA_DEC_KMIN) * 9;
+    int d = 1;
+    for (int c = 2; c <= 9; ++c)
+        if (v >= row[c - 1]) d = c;
+    return d;
+}
+
+struct BasicStats {
+    int n;
+    double sum, mean, var, std, vmin, vmax, sumsq;
+    int first_max, last_max, first_min, last_min, cnt_max, cnt_min;
+};
+
+TSFA_DEV void basic_stats(const Blk &b, const double *xs, int n, BasicStats &st) {
+    st.n = n;
+    st.sum = np_sum(b, n, [=](int i) { return xs[i]; });          // np.sum
+    st.mean = st.sum / (double)n;                                   // np.mean = add.reduce / n
+    const double mean = st.mean;
+    const double ssd = np_sum(b, n, [=](int i) { const double d = xs[i] - mean; return d * d; });
+    st.var = ssd / (double)n;                                       // np.var (numpy/_core/_methods.py:_var)
+    st.std = sqrt(st.var);                                          // np.std
+    double mn = TSFA_INF, mx = -TSFA_INF, sq = 0.0;
+    for (int i = b.tid; i < n; i += b.nt) {
+        const double v = xs[i];
+        mn = fmin(mn, v);
+        mx = fmax(mx, v);
+        sq += v * v;
+    }
+    st.vmin = blk_min(b, mn);
+    st.vmax = blk_max(b, mx);
+    st.sumsq = blk_sum(b, sq);
+    double fmx = (double)n, lmx = -1.0, fmn = (double)n, lmn = -1.0, cmx = 0.0, cmn = 0.0;
+    for (int i = b.tid; i < n; i += b.nt) {
+        const double v = xs[i];
+        if (v == st.vmax) {
+            fmx = fmin(fmx, (double)i);
+            lmx = fmax(lmx, (double)i);
+            cmx += 1.0;
+        }
+        if (v == st.vmin) {
+            fmn = fmin(fmn, (double)i);
+            lmn = fmax(lmn, (double)i);
+            cmn += 1.0;
+        }
+    }
+    st.first_max = (int)blk_min(b, fmx);
+    st.last_max = (int)blk_max(b, lmx);
+    st.first_min = (int)blk_min(b, fmn);
+    st.last_min = (int)blk_max(b, lmn);
+    st.cnt_max = (int)blk_sum(b, cmx);
+    st.cnt_min = (int)blk_sum(b, cmn);
+}
+
+// longest run of `true` of pred(i), i in [0, n)  (fc.py:102 _get_length_sequences_where + max)
+template <class P>
+TSFA_DEV double blk_longest_run(const Blk &b, int n, P pred, int *iw) {
+    // each thread scans a contiguous segment; segments are stitched by thread 0
+    const int chunk = (n + b.nt - 1) / b.nt;
+    const int lo = b.tid * chunk;
+    const int hi = (lo + chunk < n) ? lo + chunk : n;
+    int pre = 0, suf = 0, best = 0, all = 1, run = 0;
+    for (int i = lo; i < hi; ++i) {
+        if (pred(i)) {
+            ++run;
+            if (run > best) best = run;
+        } else {
+            if (all) pre = run;
+            all = 0;
+            run = 0;
+        }
+    }
+    suf = run;
+    if (all) pre = run;
+    blk_sync();
+    iw[4 * b.tid + 0] = pre;
+    iw[4 * b.tid + 1] = suf;
+    iw[4 * b.tid + 2] = best;
+    iw[4 * b.tid + 3] = (lo < hi) ? all : 2;  // 2 = empty segment
+    blk_sync();
+    double res = 0.0;
+    if (b.tid == 0) {
+        int carry = 0, gbest = 0;
+        for (int t = 0; t < b.nt; ++t) {
+            const int a = iw[4 * t + 3];
+            if (a == 2) continue;
+            if (a == 1) {
+                carry += iw[4 * t + 0];
+                if (carry > gbest) gbest = carry;
+            } else {
+                if (carry + iw[4 * t + 0] > gbest) gbest = carry + iw[4 * t + 0];
+                if (iw[4 * t + 2] > gbest) gbest = iw[4 * t + 2];
+                carry = iw[4 * t + 1];
+                if (carry > gbest) gbest = carry;
+            }
+        }
+        res = (double)gbest;
+    }
+    return blk_bcast0(b, res);
+}
+
+// Evaluate the BASIC specs of one series.
+//   xs   : series as float64 in LDS, length n (n >= 1)
+//   w    : LDS work array of >= n doubles
+//   iw   : LDS int array of >= max(4*nt, 128) ints
+TSFA_DEV void fam_basic_series(const Blk &b, const double *xs, int n, const TsfaSpec *specs, int nspecs,
+                               double *out_row, double *w, int *iw, const double *dectab) {
+    BasicStats st;
+    basic_stats(b, xs, n, st);
+    const double dn = (double)n;
+    const double mean = st.mean;
+
+    for (int s = 0; s < nspecs; ++s) {
+        const TsfaSpec sp = specs[s];
+        const double p0 = sp.p[0], p1 = sp.p[1], p2 = sp.p[2];
+        double v = TSFA_NAN;
+        switch (sp.calc) {
+        case TSFA_C_SUM_VALUES: v = st.sum; break;                       // fc.py:371
+        case TSFA_C_MEAN: v = st.mean; break;                            // fc.py:677
+        case TSFA_C_LENGTH: v = dn; break;                               // fc.py:691
+        case TSFA_C_STANDARD_DEVIATION: v = st.std; break;               // fc.py:705
+        case TSFA_C_VARIANCE: v = st.var; break;                         // fc.py:735
+        case TSFA_C_ROOT_MEAN_SQUARE: v = sqrt(st.sumsq / dn); break;    // fc.py:783
+        case TSFA_C_MAXIMUM: v = st.vmax; break;                         // fc.py:2003
+        case TSFA_C_ABSOLUTE_MAXIMUM: v = fmax(fabs(st.vmax), fabs(st.vmin)); break;  // fc.py:2017
+        case TSFA_C_MINIMUM: v = st.vmin; break;                         // fc.py:2031
+        case TSFA_C_ABS_ENERGY: v = st.sumsq; break;                     // fc.py:548
+        case TSFA_C_VARIATION_COEFFICIENT:                               // fc.py:718
+            v = (mean == 0.0) ? TSFA_NAN : st.std / mean;
+            break;
+        case TSFA_C_VAR_GT_STD: v = (st.var > sqrt(st.var)) ? 1.0 : 0.0; break;  // fc.py:239
+        case TSFA_C_LARGE_STD:                                           // fc.py:273
+            v = (st.std > p0 * (st.vmax - st.vmin)) ? 1.0 : 0.0;
+            break;
+        case TSFA_C_RATIO_BEYOND_R_SIGMA: {                              // fc.py:256
+            const double thr = p0 * st.std;
+            double c = 0.0;
+            for (int i = b.tid; i < n; i += b.nt) c += (fabs(xs[i] - mean) > thr) ? 1.0 : 0.0;
+            v = blk_sum(b, c) / dn;
+        } break;
+        case TSFA_C_SKEWNESS: {                                          // fc.py:749 -> pandas nanops.nanskew
+            double m2 = 0.0, m3 = 0.0;
+            for (int i = b.tid; i < n; i += b.nt) {
+                const double a = xs[i] - mean;
+                const double a2 = a * a;
+                m2 += a2;
+                m3 += a2 * a;
+            }
+            m2 = blk_sum(b, m2);
+            m3 = blk_sum(b, m3);
+            if (fabs(m2) < 1e-14) m2 = 0.0;
+            if (fabs(m3) < 1e-14) m3 = 0.0;
+            if (n < 3) v = TSFA_NAN;
+            else if (m2 == 0.0) v = 0.0;
+            else v = (dn * sqrt(dn - 1.0) / (dn - 2.0)) * (m3 / pow(m2, 1.5));
+        } break;
+        case TSFA_C_KURTOSIS: {                                          // fc.py:766 -> pandas nanops.nankurt
+            double m2 = 0.0, m4 = 0.0;
+            for (int i = b.tid; i < n; i += b.nt) {
+                const double a = xs[i] - mean;
+                const double a2 = a * a;
+                m2 += a2;
+                m4 += a2 * a2;
+            }
+            m2 = blk_sum(b, m2);
+            m4 = blk_sum(b, m4);
+            if (n < 4) {
+                v = TSFA_NAN;
+            } else {
+                const double adj = 3.0 * (dn - 1.0) * (dn - 1.0) / ((dn - 2.0) * (dn - 3.0));
+                double num = dn * (dn + 1.0) * (dn - 1.0) * m4;
+                double den = (dn - 2.0) * (dn - 3.0) * m2 * m2;
+                if (fabs(num) < 1e-14) num = 0.0;
+                if (fabs(den) < 1e-14) den = 0.0;
+                v = (den == 0.0) ? 0.0 : (num / den - adj);
+            }
+        } break;
+        case TSFA_C_MEAN_ABS_CHANGE:                                     // fc.py:604
+        case TSFA_C_ABSOLUTE_SUM_OF_CHANGES: {                           // fc.py:796
+            double a = 0.0;
+            for (int i = b.tid; i < n - 1; i += b.nt) a += fabs(xs[i + 1] - xs[i]);
+            a = blk_sum(b, a);
+            if (sp.calc == TSFA_C_MEAN_ABS_CHANGE) v = (n > 1) ? a / (double)(n - 1) : TSFA_NAN;
+            else v = a;
+        } break;
+        case TSFA_C_MEAN_CHANGE:                                         // fc.py:624
+            v = (n > 1) ? (xs[n - 1] - xs[0]) / (double)(n - 1) : TSFA_NAN;
+            break;
+        case TSFA_C_MEAN_SECOND_DERIVATIVE_CENTRAL:                      // fc.py:644
+            v = (n > 2) ? (xs[n - 1] - xs[n - 2] - xs[1] + xs[0]) / (double)(2 * (n - 2)) : TSFA_NAN;
+            break;
+        case TSFA_C_CID_CE: {                                            // fc.py:567
+            const bool normalize = (p0 != 0.0);
+            if (normalize && st.std == 0.0) {
+                v = 0.0;
+                break;
+            }
+            const double sd = st.std;
+            double a = 0.0;
+            for (int i = b.tid; i < n - 1; i += b.nt) {
+                double d;
+                if (normalize) d = (xs[i + 1] - mean) / sd - (xs[i] - mean) / sd;
+                else d = xs[i + 1] - xs[i];
+                a += d * d;
+            }
+            v = sqrt(blk_sum(b, a));
+        } break;
+        case TSFA_C_COUNT_ABOVE_MEAN:                                    // fc.py:843
+        case TSFA_C_COUNT_BELOW_MEAN: {                                  // fc.py:857
+            const bool above = (sp.calc == TSFA_C_COUNT_ABOVE_MEAN);
+            double c = 0.0;
+            for (int i = b.tid; i < n; i += b.nt) c += (above ? (xs[i] > mean) : (xs[i] < mean)) ? 1.0 : 0.0;
+            v = blk_sum(b, c);
+        } break;
+        case TSFA_C_COUNT_ABOVE:                                         // fc.py:2309
+        case TSFA_C_COUNT_BELOW: {                                       // fc.py:2325
+            const bool above = (sp.calc == TSFA_C_COUNT_ABOVE);
+            double c = 0.0;
+            for (int i = b.tid; i < n; i += b.nt) c += (above ? (xs[i] >= p0) : (xs[i] <= p0)) ? 1.0 : 0.0;
+            v = blk_sum(b, c) / dn;
+        } break;
+        case TSFA_C_VALUE_COUNT: {                                       // fc.py:2044
+            double c = 0.0;
+            for (int i = b.tid; i < n; i += b.nt) c += (p0 != p0 ? (xs[i] != xs[i]) : (xs[i] == p0)) ? 1.0 : 0.0;
+            v = blk_sum(b, c);
+        } break;
+        case TSFA_C_RANGE_COUNT: {                                       // fc.py:2065
+            double c = 0.0;
+            for (int i = b.tid; i < n; i += b.nt) c += (xs[i] >= p0 && xs[i] < p1) ? 1.0 : 0.0;
+            v = blk_sum(b, c);
+        } break;
+        case TSFA_C_NUMBER_CROSSING_M: {                                 // fc.py:1980
+            double c = 0.0;
+            for (int i = b.tid; i < n - 1; i += b.nt) c += ((xs[i] > p0) != (xs[i + 1] > p0)) ? 1.0 : 0.0;
+            v = blk_sum(b, c);
+        } break;
+        case TSFA_C_FIRST_LOCATION_OF_MAXIMUM: v = (double)st.first_max / dn; break;              // fc.py:886
+        case TSFA_C_LAST_LOCATION_OF_MAXIMUM: v = 1.0 - (double)(n - 1 - st.last_max) / dn; break; // fc.py:871
+        case TSFA_C_FIRST_LOCATION_OF_MINIMUM: v = (double)st.first_min / dn; break;              // fc.py:917
+        case TSFA_C_LAST_LOCATION_OF_MINIMUM: v = 1.0 - (double)(n - 1 - st.last_min) / dn; break; // fc.py:902
+        case TSFA_C_HAS_DUPLICATE_MAX: v = (st.cnt_max >= 2) ? 1.0 : 0.0; break;                  // fc.py:325
+        case TSFA_C_HAS_DUPLICATE_MIN: v = (st.cnt_min >= 2) ? 1.0 : 0.0; break;                  // fc.py:340
+        case TSFA_C_LONGEST_STRIKE_ABOVE_MEAN:                           // fc.py:828
+            v = blk_longest_run(b, n, [=](int i) { return xs[i] > mean; }, iw);
+            break;
+        case TSFA_C_LONGEST_STRIKE_BELOW_MEAN:                           // fc.py:813
+            v = blk_longest_run(b, n, [=](int i) { return xs[i] < mean; }, iw);
+            break;
+        case TSFA_C_NUMBER_PEAKS: {                                      // fc.py:1235
+            const int sup = (int)p0;
+            double c = 0.0;
+            if (sup >= 1) {
+                for (int i = sup + b.tid; i < n - sup; i += b.nt) {
+                    const double xi = xs[i];
+                    bool pk = true;
+                    for (int k = 1; k <= sup && pk; ++k) pk = (xi > xs[i - k]) && (xi > xs[i + k]);
+                    c += pk ? 1.0 : 0.0;
+                }
+            }
+            v = blk_sum(b, c);
+        } break;
+        case TSFA_C_INDEX_MASS_QUANTILE: {                               // fc.py:1275
+            // np.cumsum is a serial accumulation; keep its order so that the >= q comparison matches
+            const double sabs = np_sum(b, n, [=](int i) { return fabs(xs[i]); });
+            double r = TSFA_NAN;
+            if (b.tid == 0 && sabs != 0.0) {
+                double acc = 0.0;
+                int idx = 0;  // np.argmax of an all-False mask is 0
+                for (int i = 0; i < n; ++i) {
+                    acc += fabs(xs[i]);
+                    if (acc / sabs >= p0) {
+                        idx = i;
+                        break;
+                    }
+                }
+                r = (double)(idx + 1) / dn;
+            }
+            v = blk_bcast0(b, r);
+        } break;
+        case TSFA_C_ENERGY_RATIO_BY_CHUNKS: {                            // fc.py:2226 (np.array_split)
+            const int nseg = (int)p0, foc = (int)p1;
+            const int q = n / nseg, rem = n % nseg;
+            const int lo = foc * q + (foc < rem ? foc : rem);
+            const int hi = lo + q + (foc < rem ? 1 : 0);
+            double a = 0.0;
+            for (int i = lo + b.tid; i < hi; i += b.nt) a += xs[i] * xs[i];
+            a = blk_sum(b, a);
+            v = (st.sumsq == 0.0) ? TSFA_NAN : a / st.sumsq;
+        } break;
+        case TSFA_C_C3: {                                                // fc.py:1600
+            const int lag = (int)p0;
+            if (2 * lag >= n) {
+                v = 0.0;
+                break;
+            }
+            const int m = n - 2 * lag;
+            double a = 0.0;
+            for (int i = b.tid; i < m; i += b.nt) a += xs[i + 2 * lag] * xs[i + lag] * xs[i];
+            v = blk_sum(b, a) / (double)m;
+        } break;
+        case TSFA_C_TIME_REVERSAL_ASYMMETRY_STATISTIC: {                 // fc.py:1557
+            const int lag = (int)p0;
+            if (2 * lag >= n) {
+                v = 0.0;
+                break;
+            }
+            const int m = n - 2 * lag;
+            double a = 0.0;
+            for (int i = b.tid; i < m; i += b.nt) {
+                const double x0 = xs[i], x1 = xs[i + lag], x2 = xs[i + 2 * lag];
+                a += x2 * x2 * x1 - x1 * x0 * x0;
+            }
+            v = blk_sum(b, a) / (double)m;
+        } break;
+        case TSFA_C_AUTOCORRELATION: {                                   // fc.py:1919
+            const int lag = (int)p0;
+            if (n < lag) {
+                v = TSFA_NAN;
+                break;
+            }
+            double a = 0.0;
+            for (int i = b.tid; i < n - lag; i += b.nt) a += (xs[i] - mean) * (xs[i + lag] - mean);
+            a = blk_sum(b, a);
+            if (fabs(st.var) <= 1e-8) v = TSFA_NAN;  // np.isclose(v, 0)
+            else v = a / ((double)(n - lag) * st.var);
+        } break;
+        case TSFA_C_BINNED_ENTROPY:                                      // fc.py:1666
+            v = blk_binned_entropy(b, n, [=](int i) { return xs[i]; }, (int)p0, st.vmin, st.vmax, iw);
+            break;
+        case TSFA_C_BENFORD_CORRELATION: {                               // fc.py:2341
+            blk_sync();
+            for (int k = b.tid; k < 16; k += b.nt) iw[k] = 0;
+            blk_sync();
+            for (int i = b.tid; i < n; i += b.nt) {
+                const int d = tsfa_leading_decimal_digit(fabs(xs[i]), dectab);
+#if TSFA_GPU
+                atomicAdd(&iw[d], 1);
+#else
+                iw[d] += 1;
+#endif
+            }
+            blk_sync();
+            double r = TSFA_NAN;
+            if (b.tid == 0) {  // np.corrcoef(benford, data)[0, 1]
+                double bd[9], dd[9], mb = 0.0, md = 0.0;
+                for (int k = 0; k < 9; ++k) {
+                    bd[k] = log10(1.0 + 1.0 / (double)(k + 1));
+                    dd[k] = (double)iw[k + 1] / dn;
+                    mb += bd[k];
+                    md += dd[k];
+                }
+                mb /= 9.0;
+                md /= 9.0;
+                double sbb = 0.0, sdd = 0.0, sbd = 0.0;
+                for (int k = 0; k < 9; ++k) {
+                    sbb += (bd[k] - mb) * (bd[k] - mb);
+                    sdd += (dd[k] - md) * (dd[k] - md);
+                    sbd += (bd[k] - mb) * (dd[k] - md);
+                }
+                // np.corrcoef: c / sqrt(d_i) / sqrt(d_j) on the ddof=1 covariance, clipped to [-1, 1]
+                const double c01 = sbd / 8.0, c00 = sbb / 8.0, c11 = sdd / 8.0;
+                r = c01 / sqrt(c00) / sqrt(c11);
+                if (r > 1.0) r = 1.0;
+                if (r < -1.0) r = -1.0;
+            }
+            v = blk_bcast0(b, r);
+        } break;
+        case TSFA_C_LINEAR_TREND: {                                      // fc.py:1343
+            double o5[5];
+            blk_linregress_index(b, n, [=](int i) { return xs[i]; }, o5);
+            v = o5[(int)p0];
+        } break;
+        case TSFA_C_AGG_LINEAR_TREND: {                                  // fc.py:2171
+            const int attr = (int)p0, cl = (int)p1, agg = (int)p2;
+            if (cl >= n) {
+                v = TSFA_NAN;
+                break;
+            }
+            const int m = (n + cl - 1) / cl;
+            blk_sync();
+            for (int c = b.tid; c < m; c += b.nt) {  // fc.py:176 _aggregate_on_chunks
+                const int lo = c * cl;
+                const int hi = (lo + cl < n) ? lo + cl : n;
+                double r;
+                if (agg == TSFA_AGG_MAX) {
+                    r = xs[lo];
+                    for (int i = lo + 1; i < hi; ++i) r = fmax(r, xs[i]);
+                } else if (agg == TSFA_AGG_MIN) {
+                    r = xs[lo];
+                    for (int i = lo + 1; i < hi; ++i) r = fmin(r, xs[i]);
+                } else {
+                    const double cm = np_leaf_sum(lo, hi - lo, [=](int i) { return xs[i]; }) / (double)(hi - lo);
+                    if (agg == TSFA_AGG_MEAN) r = cm;
+                    else r = np_leaf_sum(lo, hi - lo, [=](int i) { const double d = xs[i] - cm; return d * d; }) /
+                             (double)(hi - lo);
+                }
+                w[c] = r;
+            }
+            blk_sync();
+            double o5[5];
+            const double *wc = w;
+            blk_linregress_index(b, m, [=](int i) { return wc[i]; }, o5);
+            v = o5[attr];
+        } break;
+        case TSFA_C_QUERY_SIMILARITY_COUNT:                              // fc.py:2475 with query=None
+            v = TSFA_NAN;
+            break;
+        default: break;
+        }
+        if (b.tid == 0) out_row[sp.col] = v;
+    }
+}
+
+#endif

@@ -1,0 +1,459 @@
+// Family SORT: features that need the order statistics of the series (in-LDS bitonic sort) plus the
+// histogram-of-ordinal-patterns and Langevin-polynomial features that reuse its scratch.
+#ifndef TSFA_FAM_SORT_H
+#define TSFA_FAM_SORT_H
+
+#include "tsfa_common.h"
+
+// np.quantile(sorted, q, method="linear")   (numpy/lib/_function_base_impl.py: _compute_virtual_index,
+// _get_indexes, _get_gamma, _lerp -- the exact expression order matters for tie-sensitive callers)
+template <class S>
+TSFA_DEV double np_quantile_sorted(S s, int n, double q) {
+    const double vi = (double)(n - 1) * q;  // _QuantileMethods["linear"]: get_virtual_index = (n - 1) * quantiles
+    int prev, next;
+    double pf = floor(vi);
+    if (vi >= (double)(n - 1)) {
+        prev = next = n - 1;
+        pf = -1.0;
+    } else if (vi < 0.0) {
+        prev = next = 0;
+        pf = 0.0;
+    } else {
+        prev = (int)pf;
+        next = prev + 1;
+    }
+    const double gamma = vi - pf;
+    const double a = s(prev), c = s(next);
+    const double diff = c - a;
+    double r = a + diff * gamma;
+    if (gamma >= 0.5) r = c - diff * (1.0 - gamma);
+    return r;
+}
+
+// pandas Series.quantile(q) as used by pd.qcut: np.percentile(values, q * 100.0) -> q' = (q*100)/100
+template <class S>
+TSFA_DEV double pd_quantile_sorted(S s, int n, double q) {
+    const double qq = (q * 100.0) / 100.0;
+    return np_quantile_sorted(s, n, qq);
+}
+
+// Minimum-norm least squares  min |A c - y|  for a small dense A (rows x cols, column-major, lda = rows)
+// by Householder QR (of A, or of A^T when rows < cols).  Serial; called by one thread.  A and y are
+// overwritten; `c` receives cols coefficients; `tmp` >= max(rows, cols) doubles.
+TSFA_DEV void small_lstsq(double *A, int rows, int cols, double *y, double *c, double *tmp) {
+    if (rows >= cols) {
+        for (int k = 0; k < cols; ++k) {
+            double nrm = 0.0;
+            for (int i = k; i < rows; ++i) nrm += A[i + k * rows] * A[i + k * rows];
+            nrm = sqrt(nrm);
+            if (nrm == 0.0) { tmp[k] = 0.0; continue; }
+            const double alpha = (A[k + k * rows] > 0.0) ? -nrm : nrm;
+            const double v0 = A[k + k * rows] - alpha;
+            // v = (v0, A[k+1..,k]);  H = I - 2 v v^T / (v^T v)
+            double vtv = v0 * v0;
+            for (int i = k + 1; i < rows; ++i) vtv += A[i + k * rows] * A[i + k * rows];
+            for (int j = k + 1; j < cols; ++j) {
+                double d = v0 * A[k + j * rows];
+                for (int i = k + 1; i < rows; ++i) d += A[i + k * rows] * A[i + j * rows];
+                d = 2.0 * d / vtv;
+                A[k + j * rows] -= d * v0;
+                for (int i = k + 1; i < rows; ++i) A[i + j * rows] -= d * A[i + k * rows];
+            }
+            double d = v0 * y[k];
+            for (int i = k + 1; i < rows; ++i) d += A[i + k * rows] * y[i];
+            d = 2.0 * d / vtv;
+            y[k] -= d * v0;
+            for (int i = k + 1; i < rows; ++i) y[i] -= d * A[i + k * rows];
+            A[k + k * rows] = alpha;
+        }
+        for (int k = cols - 1; k >= 0; --k) {
+            double sacc = y[k];
+            for (int j = k + 1; j < cols; ++j) sacc -= A[k + j * rows] * c[j];
+            c[k] = sacc / A[k + k * rows];
+        }
+    } else {
+        // underdetermined: B = A^T (cols x rows) = Q R;  A c = y  ->  R^T z = y,  c = Q [z; 0]
+        // build B column-major in place is awkward; use tmp-free access B(i, j) = A[j + i * rows]
+        // Householder vectors are stored in the strictly-lower part of B, i.e. in A[j + i*rows], i > j.
+        double v0s[8];
+        double vtvs[8];
+        for (int k = 0; k < rows; ++k) {
+            double nrm = 0.0;
+            for (int i = k; i < cols; ++i) nrm += A[k + i * rows] * A[k + i * rows];
+            nrm = sqrt(nrm);
+            const double akk = A[k + k * rows];
+            const double alpha = (akk > 0.0) ? -nrm : nrm;
+            const double v0 = akk - alpha;
+            double vtv = v0 * v0;
+            for (int i = k + 1; i < cols; ++i) vtv += A[k + i * rows] * A[k + i * rows];
+            v0s[k] = v0;
+            vtvs[k] = vtv;
+            if (vtv != 0.0) {
+                for (int j = k + 1; j < rows; ++j) {
+                    double d = v0 * A[j + k * rows];
+                    for (int i = k + 1; i < cols; ++i) d += A[k + i * rows] * A[j + i * rows];
+                    d = 2.0 * d / vtv;
+                    A[j + k * rows] -= d * v0;
+                    for (int i = k + 1; i < cols; ++i) A[j + i * rows] -= d * A[k + i * rows];
+                }
+            }
+            tmp[k] = alpha;  // R(k, k)
+        }
+        // R(k, j) for j > k is B(k, j) = A[j + k*rows];  solve R^T z = y (forward)
+        for (int k = 0; k < rows; ++k) {
+            double sacc = y[k];
+            for (int j = 0; j < k; ++j) sacc -= A[k + j * rows] * c[j];
+            c[k] = sacc / tmp[k];
+        }
+        for (int k = rows; k < cols; ++k) c[k] = 0.0;
+        // c = H_0 H_1 ... H_{rows-1} [z; 0]
+        for (int k = rows - 1; k >= 0; --k) {
+            if (vtvs[k] == 0.0) continue;
+            double d = v0s[k] * c[k];
+            for (int i = k + 1; i < cols; ++i) d += A[k + i * rows] * c[i];
+            d = 2.0 * d / vtvs[k];
+            c[k] -= d * v0s[k];
+            for (int i = k + 1; i < cols; ++i) c[i] -= d * A[k + i * rows];
+        }
+    }
+}
+
+// max(real(np.roots(c)))  for a polynomial of degree <= 3, coefficients highest power first.
+TSFA_DEV double max_real_root_deg3(const double *cin, int ncoef) {
+    for (int i = 0; i < ncoef; ++i)
+        if (cin[i] != cin[i] || isinf(cin[i])) return TSFA_NAN;  // LinAlgError in eigvals
+    int lo = 0, hi = ncoef - 1;
+    while (lo <= hi && cin[lo] == 0.0) ++lo;   // strip leading zeros
+    if (lo > hi) return TSFA_NAN;              // all zero: np.roots -> [] -> max of empty raises -> NaN
+    int tz = 0;
+    while (hi > lo && cin[hi] == 0.0) { --hi; ++tz; }  // trailing zeros are roots at 0
+    const int deg = hi - lo;
+    double best = (tz > 0) ? 0.0 : -TSFA_INF;
+    bool any = (tz > 0);
+    const double *c = cin + lo;
+    if (deg == 1) {
+        best = fmax(best, -c[1] / c[0]);
+        any = true;
+    } else if (deg == 2) {
+        const double a = c[0], bq = c[1], cc = c[2];
+        const double disc = bq * bq - 4.0 * a * cc;
+        if (disc < 0.0) {
+            best = fmax(best, -bq / (2.0 * a));
+        } else {
+            const double sq = sqrt(disc);
+            const double q = -0.5 * (bq + (bq >= 0.0 ? sq : -sq));
+            double r1 = q / a, r2 = (q != 0.0) ? cc / q : r1;
+            best = fmax(best, fmax(r1, r2));
+        }
+        any = true;
+    } else if (deg == 3) {
+        // monic: x^3 + a x^2 + b x + c
+        const double a = c[1] / c[0], bb = c[2] / c[0], cc = c[3] / c[0];
+        const double Q = (a * a - 3.0 * bb) / 9.0;
+        const double R = (2.0 * a * a * a - 9.0 * a * bb + 27.0 * cc) / 54.0;
+        double r1;
+        const double R2 = R * R, Q3 = Q * Q * Q;
+        if (R2 < Q3) {
+            const double th = acos(R / sqrt(Q3));
+            const double sq = -2.0 * sqrt(Q);
+            const double x0 = sq * cos(th / 3.0) - a / 3.0;
+            const double x1 = sq * cos((th + 2.0 * M_PI) / 3.0) - a / 3.0;
+            const double x2 = sq * cos((th - 2.0 * M_PI) / 3.0) - a / 3.0;
+            r1 = fmax(x0, fmax(x1, x2));
+            // Newton polish on the largest root
+            for (int it = 0; it < 4; ++it) {
+                const double f = ((r1 + a) * r1 + bb) * r1 + cc;
+                const double fp = (3.0 * r1 + 2.0 * a) * r1 + bb;
+                if (fp == 0.0) break;
+                r1 -= f / fp;
+            }
+            best = fmax(best, r1);
+        } else {
+            const double A = -((R >= 0.0) ? 1.0 : -1.0) * cbrt(fabs(R) + sqrt(R2 - Q3));
+            const double B = (A != 0.0) ? Q / A : 0.0;
+            r1 = (A + B) - a / 3.0;
+            for (int it = 0; it < 4; ++it) {
+                const double f = ((r1 + a) * r1 + bb) * r1 + cc;
+                const double fp = (3.0 * r1 + 2.0 * a) * r1 + bb;
+                if (fp == 0.0) break;
+                r1 -= f / fp;
+            }
+            // complex pair: sum of roots = -a
+            const double re = 0.5 * (-a - r1);
+            best = fmax(best, fmax(r1, re));
+        }
+        any = true;
+    } else if (deg == 0) {
+        // constant: no non-zero roots
+    }
+    return any ? best : TSFA_NAN;
+}
+
+#define TSFA_FRIEDRICH_MAX_R 64
+#define TSFA_FRIEDRICH_MAX_M 3
+
+// fc.py:131 _estimate_friedrich_coefficients(x, m, r) -> coeff[0..m] (highest power first), NaN on failure.
+//   srt1  : functor, the first n-1 samples sorted ascending (signal = x[:-1])
+//   fw    : LDS double scratch >= 6*r + 16 + (r)*(m+1)
+// every thread returns the coefficients in `coef`
+template <class S1>
+TSFA_DEV void friedrich_coeffs(const Blk &b, const double *xs, int n, S1 srt1, int m, int r,
+                               double *fw, double *coef) {
+    for (int k = 0; k <= m; ++k) coef[k] = TSFA_NAN;
+    const int ns = n - 1;
+    if (ns < 1 || r < 1 || r > TSFA_FRIEDRICH_MAX_R || m < 1 || m > TSFA_FRIEDRICH_MAX_M) return;
+    double *edges = fw;                 // r + 1
+    double *sx = fw + (r + 1);          // r
+    double *sy = sx + r;                // r
+    double *cnt = sy + r;               // r
+    double *flag = cnt + r;             // 1
+    double *A = flag + 1;               // r * (m+1)
+    double *yv = A + r * (m + 1);       // r
+    double *cc = yv + r;                // m + 1
+    double *tmp = cc + (m + 1);         // r
+    blk_sync();
+    // pd.qcut(signal, r): edges = signal.quantile(np.linspace(0, 1, r + 1))
+    for (int j = b.tid; j <= r; j += b.nt) {
+        const double q = np_linspace_at(0.0, 1.0, r + 1, j);
+        edges[j] = pd_quantile_sorted(srt1, ns, q);
+    }
+    for (int j = b.tid; j < r; j += b.nt) { sx[j] = 0.0; sy[j] = 0.0; cnt[j] = 0.0; }
+    if (b.tid == 0) flag[0] = 0.0;
+    blk_sync();
+    double bad = 0.0;
+    for (int j = b.tid; j < r; j += b.nt) bad += (edges[j] < edges[j + 1]) ? 0.0 : 1.0;  // "Bin edges must be unique"
+    bad = blk_sum(b, bad);
+    if (bad > 0.0) return;
+    // bin index = #{edges < x} - 1, with x == edges[0] -> bin 0  (pandas _bins_to_cuts, right=True, include_lowest)
+    for (int i = b.tid; i < ns; i += b.nt) {
+        const double x = xs[i];
+        int lo = 0, hi = r + 1;  // count of edges < x
+        while (lo < hi) {
+            const int mid = (lo + hi) >> 1;
+            if (edges[mid] < x) lo = mid + 1; else hi = mid;
+        }
+        int bin = lo - 1;
+        if (x == edges[0]) bin = 0;
+        if (bin < 0 || bin >= r) continue;
+        const double dlt = xs[i + 1] - xs[i];
+#if TSFA_GPU
+        atomicAdd(&sx[bin], x);
+        atomicAdd(&sy[bin], dlt);
+        atomicAdd(&cnt[bin], 1.0);
+#else
+        sx[bin] += x; sy[bin] += dlt; cnt[bin] += 1.0;
+#endif
+    }
+    blk_sync();
+    if (b.tid == 0) {
+        // np.polyfit(x_mean, y_mean, deg=m): scaled Vandermonde + lstsq
+        int k = 0;
+        for (int j = 0; j < r; ++j) {
+            if (cnt[j] > 0.0) {
+                tmp[k] = sx[j] / cnt[j];
+                yv[k] = sy[j] / cnt[j];
+                ++k;
+            }
+        }
+        const int cols = m + 1;
+        double scale[TSFA_FRIEDRICH_MAX_M + 1];
+        for (int c = 0; c < cols; ++c) {
+            double ss = 0.0;
+            for (int i = 0; i < k; ++i) {
+                double pw = 1.0;
+                for (int e = 0; e < m - c; ++e) pw *= tmp[i];
+                A[i + c * k] = pw;
+                ss += pw * pw;
+            }
+            scale[c] = sqrt(ss);
+            for (int i = 0; i < k; ++i) A[i + c * k] /= scale[c];
+        }
+        small_lstsq(A, k, cols, yv, cc, tmp);
+        for (int c = 0; c < cols; ++c) cc[c] = cc[c] / scale[c];
+        flag[0] = 1.0;
+    }
+    blk_sync();
+    if (flag[0] != 0.0)
+        for (int c = 0; c <= m; ++c) coef[c] = cc[c];
+    blk_sync();
+}
+
+// Evaluate the SORT specs of one series.
+//   xs   : series (LDS, n doubles)
+//   srt  : LDS, >= next_pow2(n) doubles (sorted copy)
+//   w    : LDS, >= 768 doubles (Langevin-fit scratch)
+//   iw   : LDS, >= 5040 ints (ordinal-pattern histogram)
+TSFA_DEV void fam_sort_series(const Blk &b, const double *xs, int n, const TsfaSpec *specs, int nspecs,
+                              double *out_row, double *srt, double *w, int *iw) {
+    const int np2 = next_pow2(n);
+    blk_sync();
+    for (int i = b.tid; i < np2; i += b.nt) srt[i] = (i < n) ? xs[i] : TSFA_INF;
+    blk_bitonic_sort(b, srt, np2);
+    const double dn = (double)n;
+    const double vmin = srt[0], vmax = srt[n - 1];
+
+    // run structure of the sorted array (np.unique / value_counts)
+    double n_unique = 0.0, n_multi_vals = 0.0, n_multi_pts = 0.0, sum_multi_vals = 0.0, sum_multi_pts = 0.0;
+    bool have_runs = false;
+
+    for (int s = 0; s < nspecs; ++s) {
+        const TsfaSpec sp = specs[s];
+        const double p0 = sp.p[0], p1 = sp.p[1], p2 = sp.p[2], p3 = sp.p[3];
+        double v = TSFA_NAN;
+        switch (sp.calc) {
+        case TSFA_C_MEDIAN:                                              // fc.py:663 np.median
+            v = (n & 1) ? srt[(n - 1) / 2] : (0.0 + srt[n / 2 - 1] + srt[n / 2]) / 2.0;
+            break;
+        case TSFA_C_QUANTILE:                                            // fc.py:1963
+            v = np_quantile_sorted([=](int i) { return srt[i]; }, n, p0);
+            break;
+        case TSFA_C_SYMMETRY_LOOKING: {                                  // fc.py:299
+            const double mean = np_sum(b, n, [=](int i) { return xs[i]; }) / dn;
+            const double med = (n & 1) ? srt[(n - 1) / 2] : (0.0 + srt[n / 2 - 1] + srt[n / 2]) / 2.0;
+            v = (fabs(mean - med) < p0 * (vmax - vmin)) ? 1.0 : 0.0;
+        } break;
+        case TSFA_C_MEAN_N_ABSOLUTE_MAX: {                               // fc.py:1643
+            const int k = (int)p0;
+            double r = TSFA_NAN;
+            if (b.tid == 0 && n > k) {
+                int lo = 0, hi = n - 1;
+                double acc = 0.0;
+                for (int t = 0; t < k; ++t) {  // k largest |x| sit at the two ends of the sorted array
+                    const double a = fabs(srt[lo]), c = fabs(srt[hi]);
+                    if (a > c) { acc += a; ++lo; } else { acc += c; --hi; }
+                }
+                r = acc / (double)k;
+            }
+            v = blk_bcast0(b, r);
+        } break;
+        case TSFA_C_CHANGE_QUANTILES: {                                  // fc.py:1511
+            const double ql = p0, qh = p1;
+            const bool isabs = (p2 != 0.0);
+            const int agg = (int)p3;
+            if (ql >= qh) { v = 0.0; break; }
+            // pd.qcut(x, [ql, qh], labels=False) == 0  <=>  lo <= x <= hi  (right-closed, include_lowest)
+            const double lo = pd_quantile_sorted([=](int i) { return srt[i]; }, n, ql);
+            const double hi = pd_quantile_sorted([=](int i) { return srt[i]; }, n, qh);
+            double c = 0.0, a = 0.0;
+            for (int i = b.tid; i < n - 1; i += b.nt) {
+                const double x0 = xs[i], x1 = xs[i + 1];
+                if (x0 >= lo && x0 <= hi && x1 >= lo && x1 <= hi) {
+                    double d = x1 - x0;
+                    if (isabs) d = fabs(d);
+                    c += 1.0;
+                    a += d;
+                }
+            }
+            c = blk_sum(b, c);
+            a = blk_sum(b, a);
+            if (c == 0.0) { v = 0.0; break; }
+            const double dm = a / c;
+            if (agg == TSFA_AGG_MEAN) { v = dm; break; }
+            double ss = 0.0;
+            for (int i = b.tid; i < n - 1; i += b.nt) {
+                const double x0 = xs[i], x1 = xs[i + 1];
+                if (x0 >= lo && x0 <= hi && x1 >= lo && x1 <= hi) {
+                    double d = x1 - x0;
+                    if (isabs) d = fabs(d);
+                    ss += (d - dm) * (d - dm);
+                }
+            }
+            v = blk_sum(b, ss) / c;
+        } break;
+        case TSFA_C_HAS_DUPLICATE:
+        case TSFA_C_RATIO_VALUE_NUMBER:
+        case TSFA_C_PCT_REOCC_VALUES:
+        case TSFA_C_PCT_REOCC_DATAPOINTS:
+        case TSFA_C_SUM_REOCC_VALUES:
+        case TSFA_C_SUM_REOCC_DATA_POINTS: {
+            if (!have_runs) {
+                double nu = 0.0, mv = 0.0, mp = 0.0, sv = 0.0, spn = 0.0;
+                for (int i = b.tid; i < n; i += b.nt) {
+                    const double x = srt[i];
+                    const bool eq_prev = (i > 0) && (srt[i - 1] == x);
+                    const bool eq_next = (i < n - 1) && (srt[i + 1] == x);
+                    if (!eq_prev) {
+                        nu += 1.0;
+                        if (eq_next) { mv += 1.0; sv += x; }
+                    }
+                    if (eq_prev || eq_next) { mp += 1.0; spn += x; }
+                }
+                n_unique = blk_sum(b, nu);
+                n_multi_vals = blk_sum(b, mv);
+                n_multi_pts = blk_sum(b, mp);
+                sum_multi_vals = blk_sum(b, sv);
+                sum_multi_pts = blk_sum(b, spn);
+                have_runs = true;
+            }
+            if (sp.calc == TSFA_C_HAS_DUPLICATE) v = (n_unique != dn) ? 1.0 : 0.0;             // fc.py:355
+            else if (sp.calc == TSFA_C_RATIO_VALUE_NUMBER) v = n_unique / dn;                   // fc.py:1045
+            else if (sp.calc == TSFA_C_PCT_REOCC_VALUES) v = n_multi_vals / n_unique;           // fc.py:933
+            else if (sp.calc == TSFA_C_PCT_REOCC_DATAPOINTS) v = n_multi_pts / dn;              // fc.py:961
+            else if (sp.calc == TSFA_C_SUM_REOCC_VALUES) v = sum_multi_vals;                    // fc.py:992
+            else v = sum_multi_pts;                                                              // fc.py:1020
+        } break;
+        case TSFA_C_PERMUTATION_ENTROPY: {                               // fc.py:1866
+            const int tau = (int)p0, D = (int)p1;
+            const int num = (n >= D) ? ((n - D) / tau + 1) : 0;
+            if (num <= 0) { v = TSFA_NAN; break; }
+            int fact = 1;
+            for (int k = 2; k <= D; ++k) fact *= k;
+            blk_sync();
+            for (int k = b.tid; k < fact; k += b.nt) iw[k] = 0;
+            blk_sync();
+            for (int t = b.tid; t < num; t += b.nt) {
+                const double *a = xs + t * tau;
+                // Lehmer code of the (stable) ordinal pattern: c_j = #{l > j : a[l] < a[j]}
+                int code = 0, f = fact;
+                for (int j = 0; j < D - 1; ++j) {
+                    int c = 0;
+                    for (int l = j + 1; l < D; ++l) c += (a[l] < a[j]) ? 1 : 0;
+                    f /= (D - j);
+                    code += c * f;
+                }
+#if TSFA_GPU
+                atomicAdd(&iw[code], 1);
+#else
+                iw[code] += 1;
+#endif
+            }
+            blk_sync();
+            double e = 0.0;
+            for (int k = b.tid; k < fact; k += b.nt) {
+                const int c = iw[k];
+                if (c > 0) {
+                    const double pr = (double)c / (double)num;
+                    e += pr * log(pr);
+                }
+            }
+            v = -blk_sum(b, e);
+        } break;
+        case TSFA_C_FRIEDRICH_COEFFICIENTS:                              // fc.py:2082
+        case TSFA_C_MAX_LANGEVIN_FIXED_POINT: {                          // fc.py:2134
+            int coeff, m, r;
+            if (sp.calc == TSFA_C_FRIEDRICH_COEFFICIENTS) { coeff = (int)p0; m = (int)p1; r = (int)p2; }
+            else { coeff = -1; m = (int)p0; r = (int)p1; }
+            // sorted x[:-1] = the sorted series with one occurrence of x[n-1] removed
+            int pos = 0;
+            {
+                const double xl = xs[n - 1];
+                int lo = 0, hi = n;
+                while (lo < hi) {
+                    const int mid = (lo + hi) >> 1;
+                    if (srt[mid] < xl) lo = mid + 1; else hi = mid;
+                }
+                pos = lo;
+            }
+            double coef[TSFA_FRIEDRICH_MAX_M + 1];
+            const double *sr = srt;
+            friedrich_coeffs(b, xs, n, [=](int i) { return sr[i < pos ? i : i + 1]; }, m, r, w, coef);
+            if (sp.calc == TSFA_C_FRIEDRICH_COEFFICIENTS) v = (coeff >= 0 && coeff <= m && m <= TSFA_FRIEDRICH_MAX_M) ? coef[coeff] : TSFA_NAN;
+            else v = (m >= 1 && m <= TSFA_FRIEDRICH_MAX_M) ? max_real_root_deg3(coef, m + 1) : TSFA_NAN;
+        } break;
+        default: break;
+        }
+        if (b.tid == 0) out_row[sp.col] = v;
+    }
+}
+
+#endif

@@ -1,0 +1,268 @@
+// Family SPECTRAL: np.fft.rfft based features and scipy.signal.welch based features.
+#ifndef TSFA_FAM_SPECTRAL_H
+#define TSFA_FAM_SPECTRAL_H
+
+#include "tsfa_common.h"
+
+// Global twiddle table shared by every series: twc[j] = cos(2 pi j / TSFA_TW_N), tws[j] = -sin(2 pi j / TSFA_TW_N),
+// j < TSFA_TW_N / 2, computed once per plan on the host in float64.
+#define TSFA_TW_N 65536
+
+TSFA_DEV bool is_pow2(int n) { return n > 0 && (n & (n - 1)) == 0; }
+
+// in-place radix-2 complex FFT (forward, e^{-i...}) of size M = 2^logM on LDS arrays
+TSFA_DEV void blk_fft_pow2(const Blk &b, double *re, double *im, int M, const double *twc, const double *tws) {
+    int logM = 0;
+    while ((1 << logM) < M) ++logM;
+    blk_sync();
+    for (int i = b.tid; i < M; i += b.nt) {
+        unsigned r = 0, x = (unsigned)i;
+        for (int k = 0; k < logM; ++k) {
+            r = (r << 1) | (x & 1u);
+            x >>= 1;
+        }
+        const int j = (int)r;
+        if (j > i) {
+            const double tr = re[i], ti = im[i];
+            re[i] = re[j];
+            im[i] = im[j];
+            re[j] = tr;
+            im[j] = ti;
+        }
+    }
+    for (int len = 2; len <= M; len <<= 1) {
+        const int half = len >> 1;
+        const int stride = TSFA_TW_N / len;
+        blk_sync();
+        for (int t = b.tid; t < (M >> 1); t += b.nt) {
+            const int grp = t / half, k = t - grp * half;
+            const int i0 = grp * len + k, i1 = i0 + half;
+            const double wr = twc[k * stride], wi = tws[k * stride];
+            const double xr = re[i1], xi = im[i1];
+            const double tr = xr * wr - xi * wi;
+            const double ti = xr * wi + xi * wr;
+            const double ur = re[i0], ui = im[i0];
+            re[i1] = ur - tr;
+            im[i1] = ui - ti;
+            re[i0] = ur + tr;
+            im[i0] = ui + ti;
+        }
+    }
+    blk_sync();
+}
+
+// rfft of G(i), i < n, into Xr/Xi[0 .. n/2].
+//   pow2 n >= 4 : half-size complex FFT + split (Xr/Xi need n/2 + 1 doubles)
+//   otherwise   : direct DFT with a per-series twiddle table tc/ts (n doubles each; LDS or global scratch)
+template <class G>
+TSFA_DEV void blk_rfft(const Blk &b, int n, G g, double *Xr, double *Xi, double *tc, double *ts,
+                       const double *twc, const double *tws) {
+    const int nh = n / 2;
+    if (is_pow2(n) && n >= 4 && n <= TSFA_TW_N) {
+        const int M = nh;
+        blk_sync();
+        for (int k = b.tid; k < M; k += b.nt) {
+            Xr[k] = g(2 * k);
+            Xi[k] = g(2 * k + 1);
+        }
+        blk_fft_pow2(b, Xr, Xi, M, twc, tws);
+        const int stride = TSFA_TW_N / n;
+        // in-place split: pair (k, M-k)
+        for (int k = b.tid; k <= M / 2; k += b.nt) {
+            if (k == 0) {
+                const double zr = Xr[0], zi = Xi[0];
+                Xr[0] = zr + zi;
+                Xi[0] = 0.0;
+                Xr[M] = zr - zi;
+                Xi[M] = 0.0;
+            } else {
+                const int k2 = M - k;
+                const double ar = Xr[k], ai = Xi[k], br = Xr[k2], bi = Xi[k2];
+                // X[k] = E + w^k O,  E = (Zk + conj(Zk2))/2,  O = -i (Zk - conj(Zk2))/2
+                {
+                    const double er = 0.5 * (ar + br), ei = 0.5 * (ai - bi);
+                    const double orr = 0.5 * (ai + bi), oi = -0.5 * (ar - br);
+                    const double wr = twc[k * stride], wi = tws[k * stride];
+                    Xr[k] = er + (orr * wr - oi * wi);
+                    Xi[k] = ei + (orr * wi + oi * wr);
+                }
+                if (k2 != k) {
+                    const double er = 0.5 * (br + ar), ei = 0.5 * (bi - ai);
+                    const double orr = 0.5 * (bi + ai), oi = -0.5 * (br - ar);
+                    const double wr = twc[k2 * stride], wi = tws[k2 * stride];
+                    Xr[k2] = er + (orr * wr - oi * wi);
+                    Xi[k2] = ei + (orr * wi + oi * wr);
+                }
+            }
+        }
+        blk_sync();
+        return;
+    }
+    // direct DFT
+    blk_sync();
+    for (int j = b.tid; j < n; j += b.nt) {
+        // exp(-2 pi i j / n) with the argument reduced to an octant for accuracy
+        double s, c;
+        tsfa_sincospi(2.0 * (double)j / (double)n, &s, &c);
+        tc[j] = c;
+        ts[j] = -s;
+    }
+    blk_sync();
+    for (int k = b.tid; k <= nh; k += b.nt) {
+        double ar = 0.0, ai = 0.0;
+        int idx = 0;
+        for (int j = 0; j < n; ++j) {
+            const double x = g(j);
+            ar += x * tc[idx];
+            ai += x * ts[idx];
+            idx += k;
+            if (idx >= n) idx -= n;
+        }
+        if (k == 0 || (2 * k == n)) ai = 0.0;
+        Xr[k] = ar;
+        Xi[k] = ai;
+    }
+    blk_sync();
+}
+
+// scipy.signal.welch(x, nperseg=min(n, 256)) -> pxx[0 .. nperseg/2] (fs=1, hann, 50% overlap,
+// constant detrend, density scaling, mean over segments).  fc.py:1418, fc.py:1809.
+//   win : LDS >= 256 doubles;  pxx : LDS >= 129 doubles;  Xr/Xi/tc/ts : FFT scratch (>= 256 each is enough)
+TSFA_DEV int blk_welch(const Blk &b, const double *xs, int n, double *win, double *pxx, double *Xr, double *Xi,
+                       double *tc, double *ts, const double *twc, const double *tws) {
+    const int nper = (n < 256) ? n : 256;
+    const int nover = nper / 2;
+    const int step = nper - nover;
+    const int nseg = (n - nover) / step;
+    const int nf = nper / 2 + 1;
+    blk_sync();
+    double w2 = 0.0;
+    for (int j = b.tid; j < nper; j += b.nt) {
+        // scipy.signal.windows.general_cosine(M, [0.5, 0.5], sym=False): fac = linspace(-pi, pi, M + 1)[:M]
+        const double fac = np_linspace_at(-M_PI, M_PI, nper + 1, j);
+        const double wv = (nper <= 1) ? 1.0 : (0.5 + 0.5 * cos(fac));  // _len_guards: M <= 1 -> ones
+        win[j] = wv;
+        w2 += wv * wv;
+    }
+    for (int k = b.tid; k < nf; k += b.nt) pxx[k] = 0.0;
+    w2 = blk_sum(b, w2);
+    const double scale = 1.0 / w2;
+    for (int sgi = 0; sgi < nseg; ++sgi) {
+        const double *seg = xs + sgi * step;
+        double sm = 0.0;
+        for (int j = b.tid; j < nper; j += b.nt) sm += seg[j];
+        const double mu = blk_sum(b, sm) / (double)nper;
+        const double *wn = win;
+        blk_rfft(b, nper, [=](int j) { return (seg[j] - mu) * wn[j]; }, Xr, Xi, tc, ts, twc, tws);
+        for (int k = b.tid; k < nf; k += b.nt) {
+            double pw = (Xr[k] * Xr[k] + Xi[k] * Xi[k]) * scale;
+            const bool edge = (k == 0) || ((nper % 2 == 0) && (k == nf - 1));
+            if (!edge) pw *= 2.0;
+            pxx[k] += pw;
+        }
+        blk_sync();
+    }
+    if (nseg > 0)
+        for (int k = b.tid; k < nf; k += b.nt) pxx[k] = pxx[k] / (double)nseg;
+    blk_sync();
+    return nf;
+}
+
+// Evaluate the SPECTRAL specs of one series.
+//   Xr, Xi : LDS, >= n/2 + 2 doubles each (and >= 130)
+//   tc, ts : per-series DFT twiddles, >= n doubles each when n is not a power of two (LDS or global scratch)
+//   win    : LDS >= 256;  pxx : LDS >= 132;  iw : LDS ints >= 128
+TSFA_DEV void fam_spectral_series(const Blk &b, const double *xs, int n, const TsfaSpec *specs, int nspecs,
+                                  double *out_row, double *Xr, double *Xi, double *tc, double *ts, double *win,
+                                  double *pxx, int *iw, const double *twc, const double *tws) {
+    bool need_fft = false, need_welch = false;
+    for (int s = 0; s < nspecs; ++s) {
+        const int c = specs[s].calc;
+        if (c == TSFA_C_FFT_COEFFICIENT || c == TSFA_C_FFT_AGGREGATED) need_fft = true;
+        if (c == TSFA_C_SPKT_WELCH_DENSITY || c == TSFA_C_FOURIER_ENTROPY) need_welch = true;
+    }
+    const int nf = n / 2 + 1;
+
+    // ---- Welch first (it reuses the FFT scratch), results stay in pxx ----
+    int npx = 0;
+    double pmax = 0.0, pmin = 0.0;
+    bool pnan = false;
+    if (need_welch) {
+        npx = blk_welch(b, xs, n, win, pxx, Xr, Xi, tc, ts, twc, tws);
+        double mx = -TSFA_INF, mn = TSFA_INF, nn = 0.0;
+        for (int k = b.tid; k < npx; k += b.nt) {
+            mx = fmax(mx, pxx[k]);
+            mn = fmin(mn, pxx[k]);
+            nn += (pxx[k] != pxx[k]) ? 1.0 : 0.0;
+        }
+        pmax = blk_max(b, mx);
+        pmin = blk_min(b, mn);
+        pnan = blk_sum(b, nn) > 0.0;
+    }
+    for (int s = 0; s < nspecs; ++s) {
+        const TsfaSpec sp = specs[s];
+        double v = TSFA_NAN;
+        if (sp.calc == TSFA_C_SPKT_WELCH_DENSITY) {                      // fc.py:1418
+            const int c = (int)sp.p[0];
+            v = (c >= 0 && c < npx) ? pxx[c] : TSFA_NAN;
+        } else if (sp.calc == TSFA_C_FOURIER_ENTROPY) {                  // fc.py:1809
+            const int bins = (int)sp.p[0];
+            // binned_entropy(pxx / max(pxx), bins)
+            const double *px = pxx;
+            const double pm = pmax;
+            const double lo = pmin / pmax, hi = pmax / pmax;
+            if (pnan || lo != lo || hi != hi || isinf(lo) || isinf(hi)) v = TSFA_NAN;
+            else v = blk_binned_entropy(b, npx, [=](int i) { return px[i] / pm; }, bins, lo, hi, iw);
+        } else {
+            continue;
+        }
+        if (b.tid == 0) out_row[sp.col] = v;
+    }
+    if (!need_fft) return;
+
+    // ---- full-length rfft ----
+    blk_rfft(b, n, [=](int j) { return xs[j]; }, Xr, Xi, tc, ts, twc, tws);
+    // moments of |X| over the bin index (fc.py:1123)
+    double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0, s4 = 0.0;
+    for (int k = b.tid; k < nf; k += b.nt) {
+        const double a = hypot(Xr[k], Xi[k]);
+        const double dk = (double)k;
+        s0 += a;
+        s1 += a * dk;
+        s2 += a * (dk * dk);
+        s3 += a * (dk * dk * dk);
+        s4 += a * (dk * dk * dk * dk);
+    }
+    s0 = blk_sum(b, s0);
+    s1 = blk_sum(b, s1);
+    s2 = blk_sum(b, s2);
+    s3 = blk_sum(b, s3);
+    s4 = blk_sum(b, s4);
+    const double m1 = s1 / s0, m2 = s2 / s0, m3 = s3 / s0, m4 = s4 / s0;
+    const double var = m2 - m1 * m1;
+    for (int s = b.tid; s < nspecs; s += b.nt) {
+        const TsfaSpec sp = specs[s];
+        double v = TSFA_NAN;
+        if (sp.calc == TSFA_C_FFT_COEFFICIENT) {                         // fc.py:1067
+            const int k = (int)sp.p[0], attr = (int)sp.p[1];
+            if (k >= 0 && k < nf) {
+                const double r = Xr[k], i = Xi[k];
+                if (attr == TSFA_FFT_REAL) v = r;
+                else if (attr == TSFA_FFT_IMAG) v = i;
+                else if (attr == TSFA_FFT_ABS) v = hypot(r, i);
+                else v = atan2(i, r) * (180.0 / M_PI);
+            }
+        } else if (sp.calc == TSFA_C_FFT_AGGREGATED) {
+            const int t = (int)sp.p[0];
+            if (t == TSFA_FFTAGG_CENTROID) v = m1;
+            else if (t == TSFA_FFTAGG_VARIANCE) v = var;
+            else if (t == TSFA_FFTAGG_SKEW) v = (var < 0.5) ? TSFA_NAN : (m3 - 3.0 * m1 * var - m1 * m1 * m1) / pow(var, 1.5);
+            else v = (var < 0.5) ? TSFA_NAN : (m4 - 4.0 * m1 * m3 + 6.0 * m2 * m1 * m1 - 3.0 * m1) / (var * var);
+        } else {
+            continue;
+        }
+        out_row[sp.col] = v;
+    }
+}
+
+#endif

@@ -1,0 +1,359 @@
+// C-ABI of libtsfresh_amd.so (see include/tsfresh_amd.h).  Host code: plan compilation, HBM staging, launches.
+// There is deliberately no CPU compute path here: without a HIP device every entry point that would compute
+// returns TSFA_ERR_NO_DEVICE.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <string>
+#include <vector>
+
+#include "../../include/tsfresh_amd.h"
+#include "tsfa_host_tables.h"
+#include "tsfa_launch.h"
+#include "tsfa_layout.h"
+
+static thread_local std::string g_last_error;
+
+static int fail(int code, const std::string &msg) {
+    g_last_error = msg;
+    return code;
+}
+#define HIP_TRY(expr)                                                                                    \
+    do {                                                                                                 \
+        hipError_t e_ = (expr);                                                                          \
+        if (e_ != hipSuccess) return fail(TSFA_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e_)); \
+    } while (0)
+
+struct DevBuf {
+    void *p = nullptr;
+    size_t cap = 0;
+    int ensure(size_t bytes) {
+        if (bytes <= cap) return 0;
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        cap = 0;
+        size_t want = bytes + bytes / 8 + 4096;
+        if (hipMalloc(&p, want) != hipSuccess) {
+            p = nullptr;
+            return -1;
+        }
+        cap = want;
+        return 0;
+    }
+    void release() {
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        cap = 0;
+    }
+};
+
+struct Timing {
+    std::string name;
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    float ms = 0.f;
+};
+
+struct tsfa_plan {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    int n_cols = 0;
+    std::vector<TsfaSpec> fam_specs[TSFA_N_FAMILIES];  // CWT slot: number_cwt_peaks specs only
+    TsfaSpec *d_specs[TSFA_N_FAMILIES] = {nullptr};
+    TsfaCwtBank bank;  // cwt_coefficients
+    double *d_W = nullptr;
+    int *d_cols = nullptr, *d_coeff = nullptr;
+    double *d_dectab = nullptr, *d_twc = nullptr, *d_tws = nullptr;
+    long long *d_stats = nullptr;
+    DevBuf values, offsets, out, gscratch;
+    bool profiling = false;
+    std::vector<Timing> timings;
+};
+
+static const char *fam_names[TSFA_N_FAMILIES] = {"k_basic", "k_sort", "k_spectral", "k_ar", "k_entropy", "k_cwtpeaks", "k_seq"};
+
+template <class T>
+static int upload(const std::vector<T> &h, T **d) {
+    *d = nullptr;
+    if (h.empty()) return 0;
+    if (hipMalloc((void **)d, h.size() * sizeof(T)) != hipSuccess) return -1;
+    if (hipMemcpy(*d, h.data(), h.size() * sizeof(T), hipMemcpyHostToDevice) != hipSuccess) return -1;
+    return 0;
+}
+
+static int record(tsfa_plan *plan, hipStream_t st, size_t slot, const char *name, bool begin) {
+    if (!plan->profiling) return 0;
+    if (plan->timings.size() <= slot) plan->timings.resize(slot + 1);
+    Timing &t = plan->timings[slot];
+    if (!t.e0) {
+        if (hipEventCreate(&t.e0) != hipSuccess || hipEventCreate(&t.e1) != hipSuccess) return -1;
+    }
+    t.name = name;
+    return hipEventRecord(begin ? t.e0 : t.e1, st) == hipSuccess ? 0 : -1;
+}
+
+extern "C" {
+
+int tsfa_version(void) { return TSFA_VERSION; }
+
+int tsfa_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+const char *tsfa_last_error(void) { return g_last_error.c_str(); }
+
+int tsfa_calc_id(const char *name) {
+    if (!name) return -1;
+    for (int i = 0; i < TSFA_N_CALCS; ++i)
+        if (strcmp(tsfa_calc_table[i].name, name) == 0) return i;
+    return -1;
+}
+const char *tsfa_calc_name(int calc) { return (calc >= 0 && calc < TSFA_N_CALCS) ? tsfa_calc_table[calc].name : nullptr; }
+int tsfa_calc_count(void) { return TSFA_N_CALCS; }
+
+void tsfa_plan_destroy(tsfa_plan *plan) {
+    if (!plan) return;
+    (void)hipSetDevice(plan->device);
+    for (int f = 0; f < TSFA_N_FAMILIES; ++f)
+        if (plan->d_specs[f]) (void)hipFree(plan->d_specs[f]);
+    if (plan->d_W) (void)hipFree(plan->d_W);
+    if (plan->d_cols) (void)hipFree(plan->d_cols);
+    if (plan->d_coeff) (void)hipFree(plan->d_coeff);
+    if (plan->d_dectab) (void)hipFree(plan->d_dectab);
+    if (plan->d_twc) (void)hipFree(plan->d_twc);
+    if (plan->d_tws) (void)hipFree(plan->d_tws);
+    if (plan->d_stats) (void)hipFree(plan->d_stats);
+    plan->values.release();
+    plan->offsets.release();
+    plan->out.release();
+    plan->gscratch.release();
+    for (auto &t : plan->timings) {
+        if (t.e0) (void)hipEventDestroy(t.e0);
+        if (t.e1) (void)hipEventDestroy(t.e1);
+    }
+    if (plan->stream) (void)hipStreamDestroy(plan->stream);
+    delete plan;
+}
+
+int tsfa_plan_create(const tsfa_feature_spec *specs, int32_t n_specs, int32_t device, tsfa_plan **out_plan) {
+    if (!out_plan) return fail(TSFA_ERR_INVALID, "out_plan is NULL");
+    *out_plan = nullptr;
+    if (n_specs < 0 || (n_specs > 0 && !specs)) return fail(TSFA_ERR_INVALID, "bad specs");
+    const int ndev = tsfa_device_count();
+    if (ndev <= 0) return fail(TSFA_ERR_NO_DEVICE, "no HIP device visible: tsfresh_amd has no CPU fallback");
+    if (device < 0 || device >= ndev) return fail(TSFA_ERR_INVALID, "device ordinal out of range");
+
+    tsfa_plan *plan = new tsfa_plan();
+    plan->device = device;
+    plan->n_cols = n_specs;
+    std::vector<TsfaSpec> cwt_coef;
+    for (int i = 0; i < n_specs; ++i) {
+        TsfaSpec s;
+        s.calc = specs[i].calc;
+        s.col = i;
+        for (int k = 0; k < 4; ++k) s.p[k] = specs[i].p[k];
+        if (s.calc < 0 || s.calc >= TSFA_N_CALCS) {
+            delete plan;
+            return fail(TSFA_ERR_UNSUPPORTED, "spec " + std::to_string(i) + ": unknown calculator id " + std::to_string(s.calc));
+        }
+        const std::string why = tsfa_validate_spec(s);
+        if (!why.empty()) {
+            delete plan;
+            return fail(TSFA_ERR_UNSUPPORTED, std::string("spec ") + std::to_string(i) + " (" + tsfa_calc_table[s.calc].name + "): " + why);
+        }
+        if (s.calc == TSFA_C_CWT_COEFFICIENTS) cwt_coef.push_back(s);
+        else plan->fam_specs[tsfa_calc_table[s.calc].family].push_back(s);
+    }
+    if (cwt_coef.size() > 128) {
+        delete plan;
+        return fail(TSFA_ERR_UNSUPPORTED, "more than 128 cwt_coefficients columns in one plan");
+    }
+    if (!cwt_coef.empty()) {
+        const std::string why = plan->bank.build(cwt_coef);
+        if (!why.empty()) {
+            delete plan;
+            return fail(TSFA_ERR_UNSUPPORTED, why);
+        }
+    }
+    if (hipSetDevice(device) != hipSuccess) {
+        delete plan;
+        return fail(TSFA_ERR_HIP, "hipSetDevice failed");
+    }
+    bool ok = hipStreamCreateWithFlags(&plan->stream, hipStreamNonBlocking) == hipSuccess;
+    for (int f = 0; ok && f < TSFA_N_FAMILIES; ++f) ok = upload(plan->fam_specs[f], &plan->d_specs[f]) == 0;
+    if (ok && !cwt_coef.empty()) {
+        ok = upload(plan->bank.W, &plan->d_W) == 0 && upload(plan->bank.cols, &plan->d_cols) == 0 &&
+             upload(plan->bank.coeff_idx, &plan->d_coeff) == 0;
+    }
+    if (ok) {
+        std::vector<double> dt, twc, tws;
+        tsfa_build_dectab(dt);
+        tsfa_build_twiddles(twc, tws);
+        ok = upload(dt, &plan->d_dectab) == 0 && upload(twc, &plan->d_twc) == 0 && upload(tws, &plan->d_tws) == 0;
+    }
+    if (ok) ok = hipMalloc((void **)&plan->d_stats, 4 * sizeof(long long)) == hipSuccess;
+    if (!ok) {
+        tsfa_plan_destroy(plan);
+        return fail(TSFA_ERR_HIP, "device allocation/upload failed while creating the plan");
+    }
+    *out_plan = plan;
+    return TSFA_OK;
+}
+
+int32_t tsfa_plan_n_cols(const tsfa_plan *plan) { return plan ? plan->n_cols : -1; }
+
+int tsfa_plan_set_profiling(tsfa_plan *plan, int32_t enable) {
+    if (!plan) return fail(TSFA_ERR_INVALID, "plan is NULL");
+    plan->profiling = enable != 0;
+    return TSFA_OK;
+}
+
+int32_t tsfa_plan_last_timings(const tsfa_plan *plan, const char **names, float *ms, int32_t cap) {
+    if (!plan) return 0;
+    int32_t n = 0;
+    for (const auto &t : plan->timings) {
+        if (n >= cap) break;
+        if (names) names[n] = t.name.c_str();
+        if (ms) ms[n] = t.ms;
+        ++n;
+    }
+    return n;
+}
+
+int tsfa_extract(tsfa_plan *plan, const void *values, int32_t dtype, const int64_t *offsets, int64_t n_series,
+                 double *out, int64_t ld_out, int32_t space, void *stream) {
+    if (!plan) return fail(TSFA_ERR_INVALID, "plan is NULL");
+    if (dtype != TSFA_F32 && dtype != TSFA_F64) return fail(TSFA_ERR_INVALID, "dtype must be TSFA_F32 or TSFA_F64");
+    if (space != TSFA_HOST && space != TSFA_DEVICE) return fail(TSFA_ERR_INVALID, "space must be TSFA_HOST or TSFA_DEVICE");
+    if (n_series < 0) return fail(TSFA_ERR_INVALID, "n_series < 0");
+    if (n_series == 0 || plan->n_cols == 0) return TSFA_OK;
+    if (!values || !offsets || !out) return fail(TSFA_ERR_INVALID, "NULL buffer");
+    if (ld_out < plan->n_cols) return fail(TSFA_ERR_INVALID, "ld_out < n_cols");
+    if (n_series > 2147483647LL) return fail(TSFA_ERR_INVALID, "n_series exceeds the grid limit (2^31 - 1)");
+    HIP_TRY(hipSetDevice(plan->device));
+    hipStream_t st = (space == TSFA_DEVICE && stream) ? (hipStream_t)stream : plan->stream;
+    const size_t esz = (dtype == TSFA_F32) ? 4 : 8;
+
+    const void *d_values = values;
+    const int64_t *d_offsets = offsets;
+    double *d_out = out;
+    int64_t ld = ld_out;
+    if (space == TSFA_HOST) {
+        const int64_t base = offsets[0];
+        const int64_t total = offsets[n_series] - base;
+        if (total < 0) return fail(TSFA_ERR_INVALID, "offsets are not non-decreasing");
+        std::vector<int64_t> rel((size_t)n_series + 1);
+        for (int64_t i = 0; i <= n_series; ++i) rel[(size_t)i] = offsets[i] - base;
+        if (plan->values.ensure((size_t)total * esz + 16) || plan->offsets.ensure(rel.size() * sizeof(int64_t)) ||
+            plan->out.ensure((size_t)n_series * plan->n_cols * sizeof(double)))
+            return fail(TSFA_ERR_HIP, "hipMalloc failed for the staging buffers");
+        HIP_TRY(hipMemcpyAsync(plan->values.p, (const char *)values + (size_t)base * esz, (size_t)total * esz,
+                               hipMemcpyHostToDevice, st));
+        HIP_TRY(hipMemcpyAsync(plan->offsets.p, rel.data(), rel.size() * sizeof(int64_t), hipMemcpyHostToDevice, st));
+        HIP_TRY(hipStreamSynchronize(st));  // rel goes out of scope below
+        d_values = plan->values.p;
+        d_offsets = (const int64_t *)plan->offsets.p;
+        d_out = (double *)plan->out.p;
+        ld = plan->n_cols;
+    }
+
+    // ---- batch length statistics (decides workgroup size and the LDS carve) ----
+    long long h_stats[3] = {0, (1LL << 62), 0};
+    HIP_TRY(hipMemcpyAsync(plan->d_stats, h_stats, sizeof h_stats, hipMemcpyHostToDevice, st));
+    if (tsfa_launch_len_stats(d_offsets, n_series, plan->d_stats, st)) return fail(TSFA_ERR_HIP, "len_stats launch failed");
+    HIP_TRY(hipMemcpyAsync(h_stats, plan->d_stats, sizeof h_stats, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    const long long max_len = h_stats[0], min_len = h_stats[1], max_np2 = h_stats[2];
+    if (min_len < 1) return fail(TSFA_ERR_INVALID, "every series must hold at least one sample");
+    if (max_len > 65535) return fail(TSFA_ERR_TOO_LONG, "series longer than 65535 samples are not supported");
+    const int maxn = (int)max_len;
+    const int nt = (maxn <= 2048) ? 64 : 256;
+
+    if (tsfa_launch_fill_nan(d_out, n_series * ld, st)) return fail(TSFA_ERR_HIP, "fill launch failed");
+
+    size_t slot = 0;
+    for (int f = 0; f < TSFA_N_FAMILIES; ++f) {
+        if (plan->fam_specs[f].empty()) continue;
+        TsfaLaunch a;
+        memset(&a, 0, sizeof a);
+        a.fam = f;
+        a.dtype = dtype;
+        a.values = d_values;
+        a.offsets = d_offsets;
+        a.n_series = n_series;
+        a.specs = plan->d_specs[f];
+        a.nspecs = (int)plan->fam_specs[f].size();
+        a.out = d_out;
+        a.ld = ld;
+        a.maxn = maxn;
+        a.nt = nt;
+        a.stream = st;
+        a.dectab = plan->d_dectab;
+        a.twc = plan->d_twc;
+        a.tws = plan->d_tws;
+        int aux = 0;
+        if (f == TSFA_FAM_SPECTRAL) {
+            a.dft_n = (int)max_np2;
+            if (tsfa_family_lds_bytes(f, maxn, nt, a.dft_n) > TSFA_LDS_LIMIT) {
+                // twiddles of the long non-power-of-two series go to an HBM scratch slab per series
+                a.dft_n = 0;
+                a.gscratch_n = (int)max_np2;
+                const size_t need = (size_t)n_series * 2 * (size_t)a.gscratch_n * sizeof(double);
+                if (plan->gscratch.ensure(need)) return fail(TSFA_ERR_HIP, "hipMalloc failed for the DFT twiddle scratch");
+                a.gscratch = (double *)plan->gscratch.p;
+            }
+            aux = a.dft_n;
+        } else if (f == TSFA_FAM_SEQ) {
+            int ntab = a.nspecs;
+            while (ntab > 1 && tsfa_family_lds_bytes(f, maxn, nt, ntab) > TSFA_LDS_LIMIT) --ntab;
+            a.ntab = ntab;
+            aux = ntab;
+        }
+        const size_t lds = tsfa_family_lds_bytes(f, maxn, nt, aux);
+        if (lds > TSFA_LDS_LIMIT)
+            return fail(TSFA_ERR_TOO_LONG, std::string(fam_names[f]) + ": a series of " + std::to_string(maxn) +
+                                               " samples needs " + std::to_string(lds) + " B of LDS (limit 163840)");
+        if (record(plan, st, slot, fam_names[f], true)) return fail(TSFA_ERR_HIP, "event record failed");
+        const int rc = tsfa_launch_family(a);
+        if (rc) return fail(TSFA_ERR_HIP, std::string(fam_names[f]) + " launch failed: " + hipGetErrorString((hipError_t)rc));
+        if (record(plan, st, slot, fam_names[f], false)) return fail(TSFA_ERR_HIP, "event record failed");
+        ++slot;
+    }
+    if (plan->bank.C > 0) {
+        TsfaCwtLaunch c;
+        memset(&c, 0, sizeof c);
+        c.dtype = dtype;
+        c.values = d_values;
+        c.offsets = d_offsets;
+        c.n_series = n_series;
+        c.W = plan->d_W;
+        c.S4 = plan->bank.S4;
+        c.C = plan->bank.C;
+        c.cols = plan->d_cols;
+        c.coeff_idx = plan->d_coeff;
+        c.out = d_out;
+        c.ld = ld;
+        c.stream = st;
+        if (record(plan, st, slot, "k_cwt_gemm", true)) return fail(TSFA_ERR_HIP, "event record failed");
+        const int rc = tsfa_launch_cwt(c);
+        if (rc) return fail(TSFA_ERR_HIP, "k_cwt_gemm launch failed");
+        if (record(plan, st, slot, "k_cwt_gemm", false)) return fail(TSFA_ERR_HIP, "event record failed");
+        ++slot;
+    }
+    if (plan->profiling) plan->timings.resize(slot);
+
+    if (space == TSFA_HOST) {
+        HIP_TRY(hipMemcpy2DAsync(out, (size_t)ld_out * sizeof(double), d_out, (size_t)ld * sizeof(double),
+                                 (size_t)plan->n_cols * sizeof(double), (size_t)n_series, hipMemcpyDeviceToHost, st));
+    }
+    const bool async = (space == TSFA_DEVICE && stream != nullptr);
+    if (!async || plan->profiling) {
+        HIP_TRY(hipStreamSynchronize(st));
+        if (plan->profiling)
+            for (auto &t : plan->timings) (void)hipEventElapsedTime(&t.ms, t.e0, t.e1);
+    }
+    return TSFA_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,471 @@
+// Block-cooperative primitives for the per-series feature kernels.
+//
+// Execution model: ONE workgroup (64 or 256 threads = 1 or 4 wavefronts) owns ONE series, which it
+// stages once from HBM into LDS as float64 and then sweeps repeatedly.  Every function below is
+// "block-uniform": all threads of the workgroup call it with the same control flow.
+//
+// The same source is compiled two ways:
+//   * hipcc --offload-arch=gfx950  -> the product (device code; wave64 shuffles + LDS)
+//   * g++ -DTSFA_EMUL              -> a single-thread (nt = 1) emulation used ONLY by tests/ to check
+//                                     the kernel logic against the oracle on a box without a GPU.
+//                                     It is never loaded by the tsfresh_amd package.
+#ifndef TSFA_COMMON_H
+#define TSFA_COMMON_H
+
+#include <math.h>
+#include <stdint.h>
+
+#include "tsfa_specs.h"
+
+#if defined(__HIPCC__)
+#include <hip/hip_runtime.h>
+#define TSFA_GPU 1
+#define TSFA_DEV __device__ __forceinline__
+#define TSFA_DEVN __device__ __noinline__
+#define TSFA_MEM __device__ __forceinline__
+#else
+#define TSFA_GPU 0
+#define TSFA_DEV static inline
+#define TSFA_DEVN static
+#define TSFA_MEM inline
+#endif
+
+#define TSFA_NAN (__builtin_nan(""))
+#define TSFA_INF (__builtin_inf())
+
+// LDS scratch sizes (in doubles)
+#define TSFA_RED_DOUBLES 64
+#define TSFA_NP_MAXLEAF 168
+
+struct NpScratch {  // scratch for the numpy-order pairwise sum
+    double leaf_sum[TSFA_NP_MAXLEAF];
+    double vst[32];
+    int leaf_off[TSFA_NP_MAXLEAF];
+    int leaf_len[TSFA_NP_MAXLEAF];
+    int st_o[32], st_l[32], st_v[32];
+    int nleaf;
+    int pad;
+    double result;
+};
+
+struct Blk {
+    int tid;        // thread index in the workgroup
+    int nt;         // workgroup size
+    double *red;    // LDS, TSFA_RED_DOUBLES doubles: cross-wave reduction scratch + broadcast slot
+    NpScratch *np;  // LDS
+};
+
+TSFA_DEV void blk_sync() {
+#if TSFA_GPU
+    __syncthreads();
+#endif
+}
+
+// ---------------------------------------------------------------------------------------------
+// reductions: every thread receives the result
+// ---------------------------------------------------------------------------------------------
+#if TSFA_GPU
+TSFA_DEV double wave_sum(double v) {
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+TSFA_DEV double wave_min(double v) {
+    for (int o = 32; o > 0; o >>= 1) v = fmin(v, __shfl_xor(v, o));
+    return v;
+}
+TSFA_DEV double wave_max(double v) {
+    for (int o = 32; o > 0; o >>= 1) v = fmax(v, __shfl_xor(v, o));
+    return v;
+}
+#endif
+
+TSFA_DEV double blk_sum(const Blk &b, double v) {
+#if TSFA_GPU
+    v = wave_sum(v);
+    if (b.nt > 64) {
+        const int nw = b.nt >> 6;
+        blk_sync();
+        if ((b.tid & 63) == 0) b.red[b.tid >> 6] = v;
+        blk_sync();
+        v = b.red[0];
+        for (int w = 1; w < nw; ++w) v += b.red[w];
+    }
+#endif
+    return v;
+}
+TSFA_DEV double blk_min(const Blk &b, double v) {
+#if TSFA_GPU
+    v = wave_min(v);
+    if (b.nt > 64) {
+        const int nw = b.nt >> 6;
+        blk_sync();
+        if ((b.tid & 63) == 0) b.red[b.tid >> 6] = v;
+        blk_sync();
+        v = b.red[0];
+        for (int w = 1; w < nw; ++w) v = fmin(v, b.red[w]);
+    }
+#endif
+    return v;
+}
+TSFA_DEV double blk_max(const Blk &b, double v) {
+#if TSFA_GPU
+    v = wave_max(v);
+    if (b.nt > 64) {
+        const int nw = b.nt >> 6;
+        blk_sync();
+        if ((b.tid & 63) == 0) b.red[b.tid >> 6] = v;
+        blk_sync();
+        v = b.red[0];
+        for (int w = 1; w < nw; ++w) v = fmax(v, b.red[w]);
+    }
+#endif
+    return v;
+}
+
+// broadcast a value computed by thread 0 to the whole workgroup
+TSFA_DEV double blk_bcast0(const Blk &b, double v) {
+#if TSFA_GPU
+    blk_sync();
+    if (b.tid == 0) b.red[TSFA_RED_DOUBLES - 1] = v;
+    blk_sync();
+    v = b.red[TSFA_RED_DOUBLES - 1];
+#endif
+    return v;
+}
+
+// ---------------------------------------------------------------------------------------------
+// numpy-order summation.
+//
+// np.sum / np.mean / np.var on a contiguous float64 array (numpy/_core/src/umath/loops_utils.h.src,
+// DOUBLE_pairwise_sum; verified against numpy 2.2.6 in tests/test_oracle_numpy_order.py) add in a fixed
+// order: blocks of 8192 elements are accumulated serially; inside a block the array is halved
+// recursively (left half rounded down to a multiple of 8) until <= 128 elements remain, which are
+// summed with 8 strided accumulators.  Features that COMPARE against mean/std (count_above_mean,
+// longest_strike_*, large_standard_deviation, symmetry_looking, ratio_beyond_r_sigma, ...) flip on a
+// 1-ulp difference for "nice" data (constant series of 0.1, small decimals), so mean and variance are
+// summed in exactly this order.  F(i) returns element i.
+// ---------------------------------------------------------------------------------------------
+template <class F>
+TSFA_DEV double np_leaf_sum(int o, int l, F f) {
+    if (l < 8) {
+        double r = 0.0;
+        for (int i = 0; i < l; ++i) r += f(o + i);
+        return r;
+    }
+    double r0 = f(o), r1 = f(o + 1), r2 = f(o + 2), r3 = f(o + 3);
+    double r4 = f(o + 4), r5 = f(o + 5), r6 = f(o + 6), r7 = f(o + 7);
+    int i = 8;
+    const int lim = l - (l % 8);
+    for (; i < lim; i += 8) {
+        r0 += f(o + i);
+        r1 += f(o + i + 1);
+        r2 += f(o + i + 2);
+        r3 += f(o + i + 3);
+        r4 += f(o + i + 4);
+        r5 += f(o + i + 5);
+        r6 += f(o + i + 6);
+        r7 += f(o + i + 7);
+    }
+    double res = ((r0 + r1) + (r2 + r3)) + ((r4 + r5) + (r6 + r7));
+    for (; i < l; ++i) res += f(o + i);
+    return res;
+}
+
+template <class F>
+TSFA_DEV double np_sum(const Blk &b, int n, F f) {
+    NpScratch *s = b.np;
+    double total = 0.0;
+    for (int c0 = 0; c0 < n || c0 == 0; c0 += 8192) {
+        const int clen = (n - c0 < 8192) ? (n - c0) : 8192;
+        blk_sync();
+        if (b.tid == 0) {  // enumerate the leaves of the pairwise tree, left to right
+            int sp = 0, nl = 0;
+            s->st_o[0] = c0;
+            s->st_l[0] = clen;
+            sp = 1;
+            while (sp > 0) {
+                --sp;
+                const int o = s->st_o[sp], l = s->st_l[sp];
+                if (l <= 128) {
+                    s->leaf_off[nl] = o;
+                    s->leaf_len[nl] = l;
+                    ++nl;
+                } else {
+                    int n2 = l / 2;
+                    n2 -= n2 % 8;
+                    s->st_o[sp] = o + n2;
+                    s->st_l[sp] = l - n2;
+                    ++sp;
+                    s->st_o[sp] = o;
+                    s->st_l[sp] = n2;
+                    ++sp;
+                }
+            }
+            s->nleaf = nl;
+        }
+        blk_sync();
+        const int nl = s->nleaf;
+        for (int k = b.tid; k < nl; k += b.nt) s->leaf_sum[k] = np_leaf_sum(s->leaf_off[k], s->leaf_len[k], f);
+        blk_sync();
+        if (b.tid == 0) {  // combine in recursion (post-)order
+            int sp = 0, vp = 0, li = 0;
+            s->st_l[0] = clen;
+            s->st_v[0] = 0;
+            sp = 1;
+            while (sp > 0) {
+                const int l = s->st_l[sp - 1];
+                if (l <= 128) {
+                    --sp;
+                    s->vst[vp++] = s->leaf_sum[li++];
+                } else if (s->st_v[sp - 1] == 0) {
+                    s->st_v[sp - 1] = 1;
+                    int n2 = l / 2;
+                    n2 -= n2 % 8;
+                    s->st_l[sp] = l - n2;
+                    s->st_v[sp] = 0;
+                    ++sp;
+                    s->st_l[sp] = n2;
+                    s->st_v[sp] = 0;
+                    ++sp;
+                } else {
+                    --sp;
+                    const double r = s->vst[--vp];
+                    const double lft = s->vst[--vp];
+                    s->vst[vp++] = lft + r;
+                }
+            }
+            const double chunk = s->vst[0];
+            total = (c0 == 0) ? chunk : (s->result + chunk);
+            s->result = total;
+        }
+        if (n == 0) break;
+    }
+    blk_sync();
+    total = s->result;
+    blk_sync();
+    return total;
+}
+
+// ---------------------------------------------------------------------------------------------
+// in-LDS bitonic sort (ascending) of a power-of-two padded array
+// ---------------------------------------------------------------------------------------------
+TSFA_DEV int next_pow2(int n) {
+    int p = 1;
+    while (p < n) p <<= 1;
+    return p;
+}
+
+template <typename K>
+TSFA_DEV void blk_bitonic_sort(const Blk &b, K *a, int npow2) {
+    for (int k = 2; k <= npow2; k <<= 1) {
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            blk_sync();
+            for (int t = b.tid; t < (npow2 >> 1); t += b.nt) {
+                // index of the lower element of pair t for stride j
+                const int i = ((t & ~(j - 1)) << 1) | (t & (j - 1));
+                const int l = i | j;
+                const bool up = ((i & k) == 0);
+                const K x = a[i], y = a[l];
+                if ((x > y) == up) {
+                    a[i] = y;
+                    a[l] = x;
+                }
+            }
+        }
+    }
+    blk_sync();
+}
+
+// ---------------------------------------------------------------------------------------------
+// special functions
+// ---------------------------------------------------------------------------------------------
+// sin(pi x), cos(pi x) for x in [0, 2): exact octant reduction, so table entries are symmetric
+TSFA_DEV void tsfa_sincospi(double x, double *s, double *c) {
+#if TSFA_GPU
+    sincospi(x, s, c);
+#else
+    // reduce to r in [-0.25, 0.25] around the nearest multiple of 0.5
+    const double q = floor(x * 2.0 + 0.5);
+    const double r = x - q * 0.5;
+    const int qi = ((int)q) & 3;
+    const double sr = sin(M_PI * r), cr = cos(M_PI * r);
+    switch (qi) {
+    case 0: *s = sr; *c = cr; break;
+    case 1: *s = cr; *c = -sr; break;
+    case 2: *s = -sr; *c = -cr; break;
+    default: *s = -cr; *c = sr; break;
+    }
+#endif
+}
+
+// log-gamma (Lanczos, g = 7, n = 9), |rel err| ~ 1e-15 for x > 0
+TSFA_DEV double tsfa_lgamma(double x) {
+    const double c[9] = {0.99999999999980993,  676.5203681218851,     -1259.1392167224028,
+                         771.32342877765313,   -176.61502916214059,   12.507343278686905,
+                         -0.13857109526572012, 9.9843695780195716e-6, 1.5056327351493116e-7};
+    if (x < 0.5) return log(M_PI / fabs(sin(M_PI * x))) - tsfa_lgamma(1.0 - x);
+    x -= 1.0;
+    double a = c[0];
+    const double t = x + 7.5;
+    for (int i = 1; i < 9; ++i) a += c[i] / (x + (double)i);
+    return 0.5 * log(2.0 * M_PI) + (x + 0.5) * log(t) - t + log(a);
+}
+
+// continued fraction for the regularized incomplete beta (modified Lentz)
+TSFA_DEV double tsfa_betacf(double a, double b, double x) {
+    const double FPMIN = 1e-300;
+    const double qab = a + b, qap = a + 1.0, qam = a - 1.0;
+    double c = 1.0, d = 1.0 - qab * x / qap;
+    if (fabs(d) < FPMIN) d = FPMIN;
+    d = 1.0 / d;
+    double h = d;
+    for (int m = 1; m <= 10000; ++m) {
+        const double m2 = 2.0 * m;
+        double aa = m * (b - m) * x / ((qam + m2) * (a + m2));
+        d = 1.0 + aa * d;
+        if (fabs(d) < FPMIN) d = FPMIN;
+        c = 1.0 + aa / c;
+        if (fabs(c) < FPMIN) c = FPMIN;
+        d = 1.0 / d;
+        h *= d * c;
+        aa = -(a + m) * (qab + m) * x / ((a + m2) * (qap + m2));
+        d = 1.0 + aa * d;
+        if (fabs(d) < FPMIN) d = FPMIN;
+        c = 1.0 + aa / c;
+        if (fabs(c) < FPMIN) c = FPMIN;
+        d = 1.0 / d;
+        const double del = d * c;
+        h *= del;
+        if (fabs(del - 1.0) < 1e-16) break;
+    }
+    return h;
+}
+
+// regularized incomplete beta I_x(a, b)
+TSFA_DEV double tsfa_betainc(double a, double b, double x) {
+    if (x != x) return TSFA_NAN;
+    if (x <= 0.0) return 0.0;
+    if (x >= 1.0) return 1.0;
+    const double lbt = tsfa_lgamma(a + b) - tsfa_lgamma(a) - tsfa_lgamma(b) + a * log(x) + b * log1p(-x);
+    if (x < (a + 1.0) / (a + b + 2.0)) return exp(lbt) * tsfa_betacf(a, b, x) / a;
+    return 1.0 - exp(lbt) * tsfa_betacf(b, a, 1.0 - x) / b;
+}
+
+// two-sided p-value of a Student-t statistic (scipy.stats.linregress: 2 * stdtr(df, -|t|))
+TSFA_DEV double tsfa_t_pvalue2(double t, double df) {
+    if (t != t || !(df > 0.0)) return TSFA_NAN;
+    if (isinf(t)) return 0.0;
+    return tsfa_betainc(0.5 * df, 0.5, df / (df + t * t));
+}
+
+// standard normal CDF
+TSFA_DEV double tsfa_norm_cdf(double x) { return 0.5 * erfc(-x * 0.70710678118654752440); }
+
+// ---------------------------------------------------------------------------------------------
+// scipy.stats.linregress(range(m), y) for y in LDS (or computed by G(i)); every thread gets the result
+// out[0..4] = pvalue, rvalue, intercept, slope, stderr       (scipy/stats/_stats_py.py, linregress)
+// ---------------------------------------------------------------------------------------------
+template <class G>
+TSFA_DEV void blk_linregress_index(const Blk &b, int m, G g, double *out5) {
+    const double dm = (double)m;
+    double sy = 0.0;
+    for (int i = b.tid; i < m; i += b.nt) sy += g(i);
+    sy = blk_sum(b, sy);
+    const double ymean = sy / dm;
+    const double xmean = (dm - 1.0) * 0.5;
+    double sxy = 0.0, syy = 0.0;
+    for (int i = b.tid; i < m; i += b.nt) {
+        const double dy = g(i) - ymean;
+        const double dx = (double)i - xmean;
+        sxy += dx * dy;
+        syy += dy * dy;
+    }
+    sxy = blk_sum(b, sxy);
+    syy = blk_sum(b, syy);
+    // sum_i (i - xmean)^2 = m (m^2 - 1) / 12
+    const double ssxm = (dm * (dm * dm - 1.0) / 12.0) / dm;
+    const double ssxym = sxy / dm;
+    const double ssym = syy / dm;
+    double r;
+    if (ssxm == 0.0 || ssym == 0.0) {
+        r = 0.0;
+    } else {
+        r = ssxym / sqrt(ssxm * ssym);
+        if (r > 1.0) r = 1.0;
+        else if (r < -1.0) r = -1.0;
+    }
+    const double slope = ssxym / ssxm;
+    const double intercept = ymean - slope * xmean;
+    double prob, stderr_;
+    if (m == 2) {
+        prob = (g(0) == g(1)) ? 1.0 : 0.0;
+        stderr_ = 0.0;
+    } else {
+        const double df = dm - 2.0;
+        const double TINY = 1.0e-20;
+        const double t = r * sqrt(df / ((1.0 - r + TINY) * (1.0 + r + TINY)));
+        prob = tsfa_t_pvalue2(t, df);
+        stderr_ = sqrt((1.0 - r * r) * ssym / ssxm / df);
+    }
+    out5[TSFA_ATTR_PVALUE] = prob;
+    out5[TSFA_ATTR_RVALUE] = r;
+    out5[TSFA_ATTR_INTERCEPT] = intercept;
+    out5[TSFA_ATTR_SLOPE] = slope;
+    out5[TSFA_ATTR_STDERR] = stderr_;
+}
+
+// ---------------------------------------------------------------------------------------------
+// np.histogram(v, bins) with uniform bins over [vmin, vmax] followed by the entropy of the bin
+// probabilities (feature_calculators.py:1666 binned_entropy).  `cnt` = LDS int array of >= bins ints.
+// G(i) returns element i of the histogrammed vector of length m.
+// numpy/lib/_histograms_impl.py: uniform-bin fast path incl. the edge corrections.
+// ---------------------------------------------------------------------------------------------
+TSFA_DEV double np_linspace_at(double start, double stop, int num_edges, int i) {
+    // np.linspace(start, stop, num_edges)[i]
+    const int div = num_edges - 1;
+    if (i == div && num_edges > 1) return stop;
+    const double delta = stop - start;
+    const double step = delta / (double)div;
+    if (step == 0.0) return ((double)i / (double)div) * delta + start;
+    return (double)i * step + start;
+}
+
+template <class G>
+TSFA_DEV double blk_binned_entropy(const Blk &b, int m, G g, int bins, double vmin, double vmax, int *cnt) {
+    double first = vmin, last = vmax;
+    if (first == last) {
+        first = first - 0.5;
+        last = last + 0.5;
+    }
+    blk_sync();
+    for (int k = b.tid; k < bins; k += b.nt) cnt[k] = 0;
+    blk_sync();
+    const double norm = last - first;
+    for (int i = b.tid; i < m; i += b.nt) {
+        const double v = g(i);
+        if (!(v >= first && v <= last)) continue;
+        const double fidx = ((v - first) / norm) * (double)bins;
+        int idx = (int)fidx;
+        if (idx == bins) idx -= 1;
+        if (v < np_linspace_at(first, last, bins + 1, idx)) idx -= 1;
+        if (idx != bins - 1 && v >= np_linspace_at(first, last, bins + 1, idx + 1)) idx += 1;
+#if TSFA_GPU
+        atomicAdd(&cnt[idx], 1);
+#else
+        cnt[idx] += 1;
+#endif
+    }
+    blk_sync();
+    double e = 0.0;
+    for (int k = b.tid; k < bins; k += b.nt) {
+        const int c = cnt[k];
+        if (c > 0) {
+            const double p = (double)c / (double)m;
+            e += p * log(p);
+        }
+    }
+    e = blk_sum(b, e);
+    return -e;
+}
+
+#endif  // TSFA_COMMON_H

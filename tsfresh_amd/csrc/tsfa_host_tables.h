@@ -1,0 +1,229 @@
+// Host-side constant tables and spec bookkeeping shared by the C-ABI (tsfa_api.cpp) and the test-only CPU
+// emulation (tests/emul/emul.cpp).  Plain C++17, no HIP.
+#ifndef TSFA_HOST_TABLES_H
+#define TSFA_HOST_TABLES_H
+
+#include <math.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include <string>
+#include <vector>
+
+#include "tsfa_specs.h"
+
+#define TSFA_DEC_KMIN_H (-324)
+#define TSFA_DEC_KMAX_H 308
+#define TSFA_TW_N_H 65536
+
+struct TsfaCalcInfo {
+    const char *name;
+    int family;
+};
+
+static const TsfaCalcInfo tsfa_calc_table[TSFA_N_CALCS] = {
+#define X(id, name, fam) {name, fam},
+    TSFA_CALC_LIST(X)
+#undef X
+};
+
+// correctly rounded doubles of the decimals "d e k" (strtod is correctly rounded in glibc)
+static inline void tsfa_build_dectab(std::vector<double> &tab) {
+    tab.resize((size_t)(TSFA_DEC_KMAX_H - TSFA_DEC_KMIN_H + 1) * 9);
+    char buf[32];
+    for (int k = TSFA_DEC_KMIN_H; k <= TSFA_DEC_KMAX_H; ++k)
+        for (int d = 1; d <= 9; ++d) {
+            snprintf(buf, sizeof buf, "%de%d", d, k);
+            tab[(size_t)(k - TSFA_DEC_KMIN_H) * 9 + (d - 1)] = strtod(buf, nullptr);
+        }
+}
+
+// twc[j] = cos(2 pi j / N), tws[j] = -sin(2 pi j / N), j < N/2, N = 65536; octant symmetry keeps the table exact
+// under the symmetries a radix-2 FFT relies on
+static inline void tsfa_build_twiddles(std::vector<double> &twc, std::vector<double> &tws) {
+    const int N = TSFA_TW_N_H;
+    twc.resize(N / 2);
+    tws.resize(N / 2);
+    const long double PI_L = 3.141592653589793238462643383279502884L;
+    for (int j = 0; j < N / 2; ++j) {
+        // angle = 2 pi j / N in [0, pi); reduce to [0, pi/4] by symmetry
+        int q = j;
+        long double c, s;
+        const int quarter = N / 4, eighth = N / 8;
+        bool neg_c = false;
+        if (q > quarter) {  // (pi/2, pi): cos(pi - a) = -cos(a), sin(pi - a) = sin(a)
+            q = N / 2 - q;
+            neg_c = true;
+        }
+        if (q <= eighth) {
+            const long double a = 2.0L * PI_L * (long double)q / (long double)N;
+            c = cosl(a);
+            s = sinl(a);
+        } else {  // (pi/4, pi/2]: cos(a) = sin(pi/2 - a)
+            const long double a = 2.0L * PI_L * (long double)(quarter - q) / (long double)N;
+            c = sinl(a);
+            s = cosl(a);
+        }
+        if (neg_c) c = -c;
+        twc[j] = (double)c;
+        tws[j] = (double)(-s);
+    }
+}
+
+// pywt.cwt(x, scales, "mexh") restated (pywt/_cwt.py:125-197, pywt/_functions.py:29-32,104-109; pywt 1.1.1):
+//   int_psi = cumsum(mexh(linspace(-8, 8, 1024))) * step
+//   taps(scale) = int_psi[floor(arange(scale*16 + 1) / (scale*step))][::-1]
+//   coef = -sqrt(scale) * diff(convolve(x, taps)), centre-cropped to len(x)
+// Only coef[t] for small t is consumed, which is a dot product of x[0 .. t+f+1] with one filter column:
+//   W_{scale,t}[n] = -sqrt(scale) * (taps[t+f+1-n] - taps[t+f-n]),   f = floor((T-2)/2)
+struct TsfaMexh {
+    std::vector<double> int_psi;
+    double step;
+    TsfaMexh() {
+        const int P = 1024;
+        std::vector<double> x(P), psi(P);
+        const double start = -8.0, stop = 8.0;
+        const double st = (stop - start) / (double)(P - 1);
+        for (int i = 0; i < P; ++i) x[i] = (double)i * st + start;
+        x[P - 1] = stop;
+        step = x[1] - x[0];
+        for (int i = 0; i < P; ++i)
+            psi[i] = (1.0 - x[i] * x[i]) * exp(-(x[i] * x[i]) / 2.0) * 2.0 / (sqrt(3.0) * sqrt(sqrt(M_PI)));
+        int_psi.resize(P);
+        double acc = 0.0;
+        for (int i = 0; i < P; ++i) {
+            acc += psi[i];
+            int_psi[i] = acc;
+        }
+        for (int i = 0; i < P; ++i) int_psi[i] *= step;
+    }
+    void taps(double scale, std::vector<double> &out) const {
+        const int cnt = (int)ceil(scale * 16.0 + 1.0);
+        std::vector<int> j;
+        for (int k = 0; k < cnt; ++k) {
+            const int jj = (int)((double)k / (scale * step));
+            if (jj < (int)int_psi.size()) j.push_back(jj);
+        }
+        out.resize(j.size());
+        for (size_t i = 0; i < j.size(); ++i) out[i] = int_psi[j[j.size() - 1 - i]];
+    }
+    // filter column for (scale, t): w[n], n < support;  returns the support length (t + f + 2)
+    int column(double scale, int t, std::vector<double> &w) const {
+        std::vector<double> tp;
+        taps(scale, tp);
+        const int T = (int)tp.size();
+        if (T < 2) return -1;
+        const int f = (T - 2) / 2;
+        const int sup = t + f + 2;
+        w.assign(sup, 0.0);
+        const double sq = -sqrt(scale);
+        for (int n = 0; n < sup; ++n) {
+            const int i1 = t + f + 1 - n, i0 = t + f - n;
+            const double a = (i1 >= 0 && i1 < T) ? tp[i1] : 0.0;
+            const double c = (i0 >= 0 && i0 < T) ? tp[i0] : 0.0;
+            w[n] = sq * (a - c);
+        }
+        return sup;
+    }
+};
+
+// The dense filter bank for the cwt_coefficients specs of a plan: W[c][k], c < C (padded to Cpad rows), k < S4.
+struct TsfaCwtBank {
+    std::vector<double> W;
+    std::vector<int> cols, coeff_idx;
+    int S4 = 0, C = 0, Cpad = 0;
+    // returns empty string on success
+    std::string build(const std::vector<TsfaSpec> &specs) {
+        TsfaMexh mexh;
+        C = (int)specs.size();
+        Cpad = ((C + 15) / 16) * 16;
+        std::vector<std::vector<double>> colsW(C);
+        int S = 0;
+        cols.assign(Cpad, 0);
+        coeff_idx.assign(Cpad, 0);
+        for (int c = 0; c < C; ++c) {
+            const double w = specs[c].p[0];
+            const int t = (int)specs[c].p[1];
+            if (!(w > 0.0) || t < 0) return "cwt_coefficients: width must be > 0 and coeff >= 0";
+            const int sup = mexh.column(w, t, colsW[c]);
+            if (sup < 0) return "cwt_coefficients: selected scale too small";
+            if (sup > S) S = sup;
+            cols[c] = specs[c].col;
+            coeff_idx[c] = t;
+        }
+        S4 = ((S + 3) / 4) * 4;
+        W.assign((size_t)Cpad * S4, 0.0);
+        for (int c = 0; c < C; ++c)
+            for (size_t k = 0; k < colsW[c].size(); ++k) W[(size_t)c * S4 + k] = colsW[c][k];
+        return "";
+    }
+};
+
+// validate one spec; returns "" if it can be evaluated natively, else the reason
+static inline std::string tsfa_validate_spec(const TsfaSpec &s) {
+    const double *p = s.p;
+    auto is_int = [](double v) { return v == floor(v); };
+    switch (s.calc) {
+    case TSFA_C_NUMBER_PEAKS: if (!(is_int(p[0]) && p[0] >= 1)) return "number_peaks: n must be an integer >= 1"; break;
+    case TSFA_C_BINNED_ENTROPY: if (!(is_int(p[0]) && p[0] >= 1 && p[0] <= 256)) return "binned_entropy: max_bins must be in [1, 256]"; break;
+    case TSFA_C_FOURIER_ENTROPY: if (!(is_int(p[0]) && p[0] >= 1 && p[0] <= 128)) return "fourier_entropy: bins must be in [1, 128]"; break;
+    case TSFA_C_LEMPEL_ZIV_COMPLEXITY: if (!(is_int(p[0]) && p[0] >= 1 && p[0] <= 255)) return "lempel_ziv_complexity: bins must be in [1, 255]"; break;
+    case TSFA_C_ENERGY_RATIO_BY_CHUNKS:
+        if (!(is_int(p[0]) && is_int(p[1]) && p[0] > 0 && p[1] >= 0 && p[1] < p[0])) return "energy_ratio_by_chunks: need 0 <= segment_focus < num_segments";
+        break;
+    case TSFA_C_C3: case TSFA_C_TIME_REVERSAL_ASYMMETRY_STATISTIC: case TSFA_C_AUTOCORRELATION:
+        if (!(is_int(p[0]) && p[0] >= 0)) return "lag must be a non-negative integer";
+        break;
+    case TSFA_C_LINEAR_TREND: if (!(p[0] >= 0 && p[0] <= 4)) return "linear_trend: unknown attr"; break;
+    case TSFA_C_AGG_LINEAR_TREND:
+        if (!(p[0] >= 0 && p[0] <= 4)) return "agg_linear_trend: unknown attr";
+        if (!(is_int(p[1]) && p[1] >= 1)) return "agg_linear_trend: chunk_len must be a positive integer";
+        if (!(p[2] >= 0 && p[2] <= 3)) return "agg_linear_trend: f_agg must be max/min/mean/var";
+        break;
+    case TSFA_C_MEAN_N_ABSOLUTE_MAX: if (!(is_int(p[0]) && p[0] >= 1)) return "mean_n_absolute_max: number_of_maxima must be >= 1"; break;
+    case TSFA_C_CHANGE_QUANTILES:
+        if (!(p[3] == TSFA_AGG_MEAN || p[3] == TSFA_AGG_VAR)) return "change_quantiles: f_agg must be mean or var";
+        if (!(p[0] >= 0 && p[0] <= 1 && p[1] >= 0 && p[1] <= 1)) return "change_quantiles: ql, qh must be in [0, 1]";
+        break;
+    case TSFA_C_QUANTILE: if (!(p[0] >= 0 && p[0] <= 1)) return "quantile: q must be in [0, 1]"; break;
+    case TSFA_C_PERMUTATION_ENTROPY:
+        if (!(is_int(p[0]) && p[0] >= 1)) return "permutation_entropy: tau must be >= 1";
+        if (!(is_int(p[1]) && p[1] >= 2 && p[1] <= 7)) return "permutation_entropy: dimension must be in [2, 7]";
+        break;
+    case TSFA_C_FRIEDRICH_COEFFICIENTS:
+        if (!(is_int(p[1]) && p[1] >= 1 && p[1] <= 3)) return "friedrich_coefficients: m must be in [1, 3]";
+        if (!(is_int(p[2]) && p[2] >= 1 && p[2] <= 64)) return "friedrich_coefficients: r must be in [1, 64]";
+        if (!(is_int(p[0]) && p[0] >= 0)) return "friedrich_coefficients: coeff must be >= 0";
+        break;
+    case TSFA_C_MAX_LANGEVIN_FIXED_POINT:
+        if (!(is_int(p[0]) && p[0] >= 1 && p[0] <= 3)) return "max_langevin_fixed_point: m must be in [1, 3]";
+        if (!(is_int(p[1]) && p[1] >= 1 && p[1] <= 64)) return "max_langevin_fixed_point: r must be in [1, 64]";
+        break;
+    case TSFA_C_FFT_COEFFICIENT:
+        if (!(is_int(p[0]) && p[0] >= 0)) return "fft_coefficient: coeff must be >= 0";
+        if (!(p[1] >= 0 && p[1] <= 3)) return "fft_coefficient: unknown attr";
+        break;
+    case TSFA_C_FFT_AGGREGATED: if (!(p[0] >= 0 && p[0] <= 3)) return "fft_aggregated: unknown aggtype"; break;
+    case TSFA_C_SPKT_WELCH_DENSITY: if (!(is_int(p[0]) && p[0] >= 0)) return "spkt_welch_density: coeff must be >= 0"; break;
+    case TSFA_C_AGG_AUTOCORRELATION:
+        if (!(p[0] == TSFA_AGG_MEAN || p[0] == TSFA_AGG_MEDIAN || p[0] == TSFA_AGG_VAR)) return "agg_autocorrelation: f_agg must be mean/median/var";
+        if (!(is_int(p[1]) && p[1] >= 1 && p[1] <= 60)) return "agg_autocorrelation: maxlag must be in [1, 60]";
+        break;
+    case TSFA_C_PARTIAL_AUTOCORRELATION: if (!(is_int(p[0]) && p[0] >= 0 && p[0] <= 40)) return "partial_autocorrelation: lag must be in [0, 40]"; break;
+    case TSFA_C_AR_COEFFICIENT:
+        if (!(is_int(p[0]) && p[0] >= 0)) return "ar_coefficient: coeff must be >= 0";
+        if (!(is_int(p[1]) && p[1] >= 1 && p[1] <= 31)) return "ar_coefficient: k must be in [1, 31]";
+        break;
+    case TSFA_C_AUGMENTED_DICKEY_FULLER: if (!(p[0] >= 0 && p[0] <= 2)) return "augmented_dickey_fuller: unknown attr"; break;
+    case TSFA_C_APPROXIMATE_ENTROPY:
+        if (!(is_int(p[0]) && p[0] >= 1)) return "approximate_entropy: m must be >= 1";
+        if (!(p[1] >= 0)) return "approximate_entropy: Parameter r must be positive.";
+        break;
+    case TSFA_C_NUMBER_CWT_PEAKS: if (!(is_int(p[0]) && p[0] >= 1 && p[0] <= 16)) return "number_cwt_peaks: n must be in [1, 16]"; break;
+    default: break;
+    }
+    return "";
+}
+
+#endif

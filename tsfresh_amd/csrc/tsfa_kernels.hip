@@ -1,0 +1,335 @@
+// gfx950 kernels: one workgroup per series per family + the MFMA contraction for cwt_coefficients.
+#include <hip/hip_runtime.h>
+
+#include "fam_ar.h"
+#include "fam_basic.h"
+#include "fam_cwt.h"
+#include "fam_entropy.h"
+#include "fam_seq.h"
+#include "fam_sort.h"
+#include "fam_spectral.h"
+#include "tsfa_launch.h"
+#include "tsfa_layout.h"
+
+extern __shared__ __attribute__((aligned(16))) unsigned char tsfa_smem[];
+
+template <typename T>
+__device__ __forceinline__ void stage_series(const Blk &b, const T *__restrict__ g, int n, double *xs) {
+    for (int i = b.tid; i < n; i += b.nt) xs[i] = (double)g[i];
+    blk_sync();
+}
+
+// ---------------------------------------------------------------------------------------------
+template <typename T>
+__global__ void k_basic(const T *__restrict__ values, const int64_t *__restrict__ offsets, int64_t n_series,
+                        const TsfaSpec *__restrict__ specs, int nspecs, double *__restrict__ out, int64_t ld,
+                        const double *__restrict__ dectab, int maxn) {
+    const int64_t sidx = blockIdx.x;
+    if (sidx >= n_series) return;
+    const int64_t off = offsets[sidx];
+    const int n = (int)(offsets[sidx + 1] - off);
+    BasicLds L;
+    L.carve(tsfa_smem, maxn, blockDim.x);
+    Blk b{(int)threadIdx.x, (int)blockDim.x, L.red, L.np};
+    stage_series(b, values + off, n, L.xs);
+    fam_basic_series(b, L.xs, n, specs, nspecs, out + sidx * ld, L.w, L.iw, dectab);
+}
+
+template <typename T>
+__global__ void k_sort(const T *__restrict__ values, const int64_t *__restrict__ offsets, int64_t n_series,
+                       const TsfaSpec *__restrict__ specs, int nspecs, double *__restrict__ out, int64_t ld, int maxn) {
+    const int64_t sidx = blockIdx.x;
+    if (sidx >= n_series) return;
+    const int64_t off = offsets[sidx];
+    const int n = (int)(offsets[sidx + 1] - off);
+    SortLds L;
+    L.carve(tsfa_smem, maxn, blockDim.x);
+    Blk b{(int)threadIdx.x, (int)blockDim.x, L.red, L.np};
+    stage_series(b, values + off, n, L.xs);
+    fam_sort_series(b, L.xs, n, specs, nspecs, out + sidx * ld, L.srt, L.w, L.iw);
+}
+
+template <typename T>
+__global__ void k_spectral(const T *__restrict__ values, const int64_t *__restrict__ offsets, int64_t n_series,
+                           const TsfaSpec *__restrict__ specs, int nspecs, double *__restrict__ out, int64_t ld,
+                           int maxn, int dft_n, double *__restrict__ gscratch, int gscratch_n,
+                           const double *__restrict__ twc, const double *__restrict__ tws) {
+    const int64_t sidx = blockIdx.x;
+    if (sidx >= n_series) return;
+    const int64_t off = offsets[sidx];
+    const int n = (int)(offsets[sidx + 1] - off);
+    SpectralLds L;
+    L.carve(tsfa_smem, maxn, dft_n);
+    Blk b{(int)threadIdx.x, (int)blockDim.x, L.red, nullptr};
+    stage_series(b, values + off, n, L.xs);
+    double *tc = L.tc, *ts = L.ts;
+    if (gscratch != nullptr && n > dft_n && n > 256) {  // long non-power-of-two series: twiddles in HBM scratch
+        tc = gscratch + (size_t)sidx * 2 * gscratch_n;
+        ts = tc + gscratch_n;
+    }
+    fam_spectral_series(b, L.xs, n, specs, nspecs, out + sidx * ld, L.Xr, L.Xi, tc, ts, L.win, L.pxx, L.iw, twc, tws);
+}
+
+template <typename T>
+__global__ void k_ar(const T *__restrict__ values, const int64_t *__restrict__ offsets, int64_t n_series,
+                     const TsfaSpec *__restrict__ specs, int nspecs, double *__restrict__ out, int64_t ld, int maxn) {
+    const int64_t sidx = blockIdx.x;
+    if (sidx >= n_series) return;
+    const int64_t off = offsets[sidx];
+    const int n = (int)(offsets[sidx + 1] - off);
+    ArLds L;
+    L.carve(tsfa_smem, maxn, blockDim.x);
+    Blk b{(int)threadIdx.x, (int)blockDim.x, L.red, nullptr};
+    stage_series(b, values + off, n, L.xs);
+    fam_ar_series(b, L.xs, n, specs, nspecs, out + sidx * ld, L.xc, L.aw);
+}
+
+template <typename T>
+__global__ void k_entropy(const T *__restrict__ values, const int64_t *__restrict__ offsets, int64_t n_series,
+                          const TsfaSpec *__restrict__ specs, int nspecs, double *__restrict__ out, int64_t ld,
+                          int maxn) {
+    const int64_t sidx = blockIdx.x;
+    if (sidx >= n_series) return;
+    const int64_t off = offsets[sidx];
+    const int n = (int)(offsets[sidx + 1] - off);
+    EntropyLds L;
+    L.carve(tsfa_smem, maxn, blockDim.x);
+    Blk b{(int)threadIdx.x, (int)blockDim.x, L.red, L.np};
+    stage_series(b, values + off, n, L.xs);
+    fam_entropy_series(b, L.xs, n, specs, nspecs, out + sidx * ld, L.thr);
+}
+
+template <typename T>
+__global__ void k_seq(const T *__restrict__ values, const int64_t *__restrict__ offsets, int64_t n_series,
+                      const TsfaSpec *__restrict__ specs, int nspecs, double *__restrict__ out, int64_t ld, int maxn,
+                      int ntab) {
+    const int64_t sidx = blockIdx.x;
+    if (sidx >= n_series) return;
+    const int64_t off = offsets[sidx];
+    const int n = (int)(offsets[sidx + 1] - off);
+    SeqLds L;
+    L.carve(tsfa_smem, maxn, ntab);
+    Blk b{(int)threadIdx.x, (int)blockDim.x, L.red, nullptr};
+    const T *g = values + off;
+    fam_seq_series(b, [=](int i) { return (double)g[i]; }, n, specs, nspecs, out + sidx * ld, L.seq, L.tab, ntab,
+                   SeqLds::table_cap(maxn));
+}
+
+template <typename T>
+__global__ void k_cwtpeaks(const T *__restrict__ values, const int64_t *__restrict__ offsets, int64_t n_series,
+                           const TsfaSpec *__restrict__ specs, int nspecs, double *__restrict__ out, int64_t ld,
+                           int maxn) {
+    const int64_t sidx = blockIdx.x;
+    if (sidx >= n_series) return;
+    const int64_t off = offsets[sidx];
+    const int n = (int)(offsets[sidx + 1] - off);
+    CwtPeaksLayout L;
+    L.carve(tsfa_smem, maxn, blockDim.x);
+    Blk b{(int)threadIdx.x, (int)blockDim.x, L.p.red, nullptr};
+    const T *g = values + off;
+    fam_cwtpeaks_series(b, [=](int i) { return (double)g[i]; }, n, specs, nspecs, out + sidx * ld, L.p);
+}
+
+// ---------------------------------------------------------------------------------------------
+// cwt_coefficients (fc.py:1370): pywt.cwt(x, widths, "mexh")[i, coeff] only ever reads output positions
+// coeff < ~15, i.e. a dot product of the first S samples with a fixed filter column.  For a batch that is the
+// dense contraction  X[n_series x S] . W[S x C]  -> float64 MFMA (v_mfma_f64_16x16x4_f64), one wavefront per
+// 16 series, C padded to a multiple of 16, S padded to a multiple of 4.
+//   W is stored [Cpad][S4] (column c contiguous in k).
+// ---------------------------------------------------------------------------------------------
+typedef double tsfa_d4 __attribute__((ext_vector_type(4)));
+
+template <typename T, int CT>
+__global__ void __launch_bounds__(64)
+k_cwt_gemm(const T *__restrict__ values, const int64_t *__restrict__ offsets, int64_t n_series,
+           const double *__restrict__ W, int S4, int C, const int *__restrict__ cols,
+           const int *__restrict__ coeff_idx, double *__restrict__ out, int64_t ld) {
+    __shared__ int lens[16];
+    const int lane = threadIdx.x;
+    const int r = lane & 15, kq = lane >> 4;
+    const int64_t s = (int64_t)blockIdx.x * 16 + r;
+    int64_t off = 0;
+    int len = 0;
+    if (s < n_series) {
+        off = offsets[s];
+        len = (int)(offsets[s + 1] - off);
+    }
+    if (lane < 16) lens[lane] = len;
+    __syncthreads();
+    tsfa_d4 acc[CT];
+#pragma unroll
+    for (int ct = 0; ct < CT; ++ct) acc[ct] = (tsfa_d4){0.0, 0.0, 0.0, 0.0};
+    const T *g = values + off;
+    for (int k0 = 0; k0 < S4; k0 += 4) {
+        const int k = k0 + kq;
+        const double a = (k < len) ? (double)g[k] : 0.0;  // A[i = r][k = kq]
+#pragma unroll
+        for (int ct = 0; ct < CT; ++ct) {
+            const double bv = W[(size_t)(ct * 16 + r) * S4 + k];  // B[k = kq][j = r]
+            acc[ct] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, bv, acc[ct], 0, 0, 0);
+        }
+    }
+    // D[i = 4*kq + v][j = r]
+#pragma unroll
+    for (int ct = 0; ct < CT; ++ct) {
+        const int c = ct * 16 + r;
+        if (c >= C) continue;
+        const int col = cols[c], ci = coeff_idx[c];
+#pragma unroll
+        for (int v = 0; v < 4; ++v) {
+            const int i = 4 * kq + v;
+            const int64_t srow = (int64_t)blockIdx.x * 16 + i;
+            if (srow < n_series) out[srow * ld + col] = (ci < lens[i]) ? acc[ct][v] : TSFA_NAN;
+        }
+    }
+}
+
+__global__ void k_fill_nan(double *__restrict__ out, int64_t n) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t k = i; k < n; k += stride) out[k] = TSFA_NAN;
+}
+
+// per-batch length statistics: [0] = max length, [1] = min length, [2] = max non-power-of-two length
+__global__ void k_len_stats(const int64_t *__restrict__ offsets, int64_t n_series, long long *__restrict__ stats) {
+    long long mx = 0, mn = (1LL << 62), mnp = 0;
+    for (int64_t s = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; s < n_series;
+         s += (int64_t)gridDim.x * blockDim.x) {
+        const long long l = offsets[s + 1] - offsets[s];
+        mx = l > mx ? l : mx;
+        mn = l < mn ? l : mn;
+        if (l > 0 && (l & (l - 1)) != 0) mnp = l > mnp ? l : mnp;
+    }
+    atomicMax(&stats[0], mx);
+    atomicMin(&stats[1], mn);
+    atomicMax(&stats[2], mnp);
+}
+
+// ---------------------------------------------------------------------------------------------
+// launchers
+// ---------------------------------------------------------------------------------------------
+#define TSFA_LAUNCH_CHECK()                       \
+    do {                                          \
+        hipError_t e_ = hipGetLastError();        \
+        if (e_ != hipSuccess) return (int)e_;     \
+    } while (0)
+
+template <typename K>
+static int set_lds(K kern, size_t bytes) {
+    if (bytes > 64 * 1024) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+        if (e != hipSuccess) return (int)e;
+    }
+    return 0;
+}
+
+template <typename T>
+static int launch_all_t(const TsfaLaunch &a, const T *values) {
+    hipStream_t st = (hipStream_t)a.stream;
+    const dim3 grid((unsigned)a.n_series);
+    const int nt = a.nt;
+    int rc;
+    if (a.fam == TSFA_FAM_BASIC) {
+        BasicLds L;
+        const size_t lds = L.carve(nullptr, a.maxn, nt);
+        if ((rc = set_lds(k_basic<T>, lds))) return rc;
+        k_basic<T><<<grid, nt, lds, st>>>(values, a.offsets, a.n_series, a.specs, a.nspecs, a.out, a.ld, a.dectab, a.maxn);
+    } else if (a.fam == TSFA_FAM_SORT) {
+        SortLds L;
+        const size_t lds = L.carve(nullptr, a.maxn, nt);
+        if ((rc = set_lds(k_sort<T>, lds))) return rc;
+        k_sort<T><<<grid, nt, lds, st>>>(values, a.offsets, a.n_series, a.specs, a.nspecs, a.out, a.ld, a.maxn);
+    } else if (a.fam == TSFA_FAM_SPECTRAL) {
+        SpectralLds L;
+        const size_t lds = L.carve(nullptr, a.maxn, a.dft_n);
+        if ((rc = set_lds(k_spectral<T>, lds))) return rc;
+        k_spectral<T><<<grid, nt, lds, st>>>(values, a.offsets, a.n_series, a.specs, a.nspecs, a.out, a.ld, a.maxn,
+                                             a.dft_n, a.gscratch, a.gscratch_n, a.twc, a.tws);
+    } else if (a.fam == TSFA_FAM_AR) {
+        ArLds L;
+        const size_t lds = L.carve(nullptr, a.maxn, nt);
+        if ((rc = set_lds(k_ar<T>, lds))) return rc;
+        k_ar<T><<<grid, nt, lds, st>>>(values, a.offsets, a.n_series, a.specs, a.nspecs, a.out, a.ld, a.maxn);
+    } else if (a.fam == TSFA_FAM_ENTROPY) {
+        EntropyLds L;
+        const size_t lds = L.carve(nullptr, a.maxn, nt);
+        if ((rc = set_lds(k_entropy<T>, lds))) return rc;
+        k_entropy<T><<<grid, nt, lds, st>>>(values, a.offsets, a.n_series, a.specs, a.nspecs, a.out, a.ld, a.maxn);
+    } else if (a.fam == TSFA_FAM_SEQ) {
+        SeqLds L;
+        const size_t lds = L.carve(nullptr, a.maxn, a.ntab);
+        if ((rc = set_lds(k_seq<T>, lds))) return rc;
+        k_seq<T><<<grid, nt, lds, st>>>(values, a.offsets, a.n_series, a.specs, a.nspecs, a.out, a.ld, a.maxn, a.ntab);
+    } else if (a.fam == TSFA_FAM_CWT) {  // number_cwt_peaks
+        CwtPeaksLayout L;
+        const size_t lds = L.carve(nullptr, a.maxn, nt);
+        if ((rc = set_lds(k_cwtpeaks<T>, lds))) return rc;
+        k_cwtpeaks<T><<<grid, nt, lds, st>>>(values, a.offsets, a.n_series, a.specs, a.nspecs, a.out, a.ld, a.maxn);
+    } else {
+        return -1;
+    }
+    TSFA_LAUNCH_CHECK();
+    return 0;
+}
+
+size_t tsfa_family_lds_bytes(int fam, int maxn, int nt, int aux) {
+    switch (fam) {
+    case TSFA_FAM_BASIC: { BasicLds L; return L.carve(nullptr, maxn, nt); }
+    case TSFA_FAM_SORT: { SortLds L; return L.carve(nullptr, maxn, nt); }
+    case TSFA_FAM_SPECTRAL: { SpectralLds L; return L.carve(nullptr, maxn, aux); }
+    case TSFA_FAM_AR: { ArLds L; return L.carve(nullptr, maxn, nt); }
+    case TSFA_FAM_ENTROPY: { EntropyLds L; return L.carve(nullptr, maxn, nt); }
+    case TSFA_FAM_SEQ: { SeqLds L; return L.carve(nullptr, maxn, aux); }
+    case TSFA_FAM_CWT: { CwtPeaksLayout L; return L.carve(nullptr, maxn, nt); }
+    default: return 0;
+    }
+}
+
+int tsfa_launch_family(const TsfaLaunch &a) {
+    if (a.dtype == 0) return launch_all_t<float>(a, (const float *)a.values);
+    return launch_all_t<double>(a, (const double *)a.values);
+}
+
+template <typename T>
+static int launch_cwt_t(const TsfaCwtLaunch &a, const T *values) {
+    hipStream_t st = (hipStream_t)a.stream;
+    const dim3 grid((unsigned)((a.n_series + 15) / 16));
+    const int ct = (a.C + 15) / 16;
+#define TSFA_CWT_CASE(N)                                                                                         \
+    case N:                                                                                                      \
+        k_cwt_gemm<T, N><<<grid, 64, 0, st>>>(values, a.offsets, a.n_series, a.W, a.S4, a.C, a.cols, a.coeff_idx, \
+                                              a.out, a.ld);                                                      \
+        break;
+    switch (ct) {
+        TSFA_CWT_CASE(1)
+        TSFA_CWT_CASE(2)
+        TSFA_CWT_CASE(3)
+        TSFA_CWT_CASE(4)
+        TSFA_CWT_CASE(5)
+        TSFA_CWT_CASE(6)
+        TSFA_CWT_CASE(7)
+        TSFA_CWT_CASE(8)
+    default: return -1;
+    }
+#undef TSFA_CWT_CASE
+    TSFA_LAUNCH_CHECK();
+    return 0;
+}
+
+int tsfa_launch_cwt(const TsfaCwtLaunch &a) {
+    if (a.dtype == 0) return launch_cwt_t<float>(a, (const float *)a.values);
+    return launch_cwt_t<double>(a, (const double *)a.values);
+}
+
+int tsfa_launch_fill_nan(double *out, int64_t n, void *stream) {
+    k_fill_nan<<<2048, 256, 0, (hipStream_t)stream>>>(out, n);
+    TSFA_LAUNCH_CHECK();
+    return 0;
+}
+
+int tsfa_launch_len_stats(const int64_t *offsets, int64_t n_series, long long *stats, void *stream) {
+    k_len_stats<<<256, 256, 0, (hipStream_t)stream>>>(offsets, n_series, stats);
+    TSFA_LAUNCH_CHECK();
+    return 0;
+}

@@ -1,0 +1,52 @@
+// host-side launch descriptors shared by tsfa_kernels.hip and tsfa_api.cpp
+#ifndef TSFA_LAUNCH_H
+#define TSFA_LAUNCH_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#include "tsfa_specs.h"
+
+struct TsfaLaunch {
+    int fam;
+    int dtype;  // 0 = f32, 1 = f64
+    const void *values;
+    const int64_t *offsets;
+    int64_t n_series;
+    const TsfaSpec *specs;  // device
+    int nspecs;
+    double *out;
+    int64_t ld;
+    int maxn;   // longest series of the batch (LDS is sized for it)
+    int nt;     // workgroup size
+    void *stream;
+    // family extras
+    const double *dectab;   // BASIC: decimal table for benford_correlation
+    const double *twc, *tws;  // SPECTRAL: shared FFT twiddles
+    int dft_n;              // SPECTRAL: DFT twiddle slots held in LDS
+    double *gscratch;       // SPECTRAL: HBM twiddle scratch for long non-pow2 series (or null)
+    int gscratch_n;
+    int ntab;               // SEQ: concurrent parse tables
+};
+
+struct TsfaCwtLaunch {
+    int dtype;
+    const void *values;
+    const int64_t *offsets;
+    int64_t n_series;
+    const double *W;       // [Cpad][S4]
+    int S4, C;
+    const int *cols;       // output column per filter
+    const int *coeff_idx;  // requested coefficient index per filter (NaN when >= series length)
+    double *out;
+    int64_t ld;
+    void *stream;
+};
+
+size_t tsfa_family_lds_bytes(int fam, int maxn, int nt, int aux);
+int tsfa_launch_family(const TsfaLaunch &a);
+int tsfa_launch_cwt(const TsfaCwtLaunch &a);
+int tsfa_launch_fill_nan(double *out, int64_t n, void *stream);
+int tsfa_launch_len_stats(const int64_t *offsets, int64_t n_series, long long *stats, void *stream);
+
+#endif

@@ -1,0 +1,143 @@
+// LDS layouts of the per-family kernels.  The same carve routine runs on the device (to obtain pointers) and on
+// the host with a null base (to obtain the dynamic-LDS size for the launch), so the two can never disagree.
+#ifndef TSFA_LAYOUT_H
+#define TSFA_LAYOUT_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#include "tsfa_common.h"
+#include "fam_cwt.h"
+
+#if defined(__HIPCC__)
+#define TSFA_HD __host__ __device__ inline
+#else
+#define TSFA_HD inline
+#endif
+
+#define TSFA_LDS_LIMIT (160 * 1024)
+
+struct LdsCarve {
+    unsigned char *base;
+    size_t off;
+    template <class U>
+    TSFA_HD U *take(size_t count) {
+        off = (off + 15) & ~(size_t)15;
+        U *r = (U *)(base + off);
+        off += count * sizeof(U);
+        return r;
+    }
+};
+
+TSFA_HD int tsfa_pow2_ceil(int n) {
+    int p = 1;
+    while (p < n) p <<= 1;
+    return p;
+}
+
+struct BasicLds {
+    double *red; NpScratch *np; double *xs; double *w; int *iw;
+    TSFA_HD size_t carve(unsigned char *base, int maxn, int nt) {
+        LdsCarve c{base, 0};
+        red = c.take<double>(TSFA_RED_DOUBLES);
+        np = c.take<NpScratch>(1);
+        xs = c.take<double>(maxn);
+        w = c.take<double>(maxn);
+        iw = c.take<int>((4 * nt > 256) ? 4 * nt : 256);
+        return c.off;
+    }
+};
+
+struct SortLds {
+    double *red; NpScratch *np; double *xs; double *srt; double *w; int *iw;
+    TSFA_HD size_t carve(unsigned char *base, int maxn, int nt) {
+        (void)nt;
+        LdsCarve c{base, 0};
+        red = c.take<double>(TSFA_RED_DOUBLES);
+        np = c.take<NpScratch>(1);
+        xs = c.take<double>(maxn);
+        srt = c.take<double>(tsfa_pow2_ceil(maxn));
+        w = c.take<double>(768);
+        iw = c.take<int>(5040);
+        return c.off;
+    }
+};
+
+struct SpectralLds {
+    double *red; double *xs; double *Xr; double *Xi; double *tc; double *ts; double *win; double *pxx; int *iw;
+    // dft_n: length of the longest non-power-of-two series whose DFT twiddles must live in LDS (0 = none / global)
+    TSFA_HD size_t carve(unsigned char *base, int maxn, int dft_n) {
+        LdsCarve c{base, 0};
+        red = c.take<double>(TSFA_RED_DOUBLES);
+        xs = c.take<double>(maxn);
+        const int nx = (maxn / 2 + 2 > 260) ? maxn / 2 + 2 : 260;
+        Xr = c.take<double>(nx);
+        Xi = c.take<double>(nx);
+        const int nd = (dft_n > 256) ? dft_n : 256;  // Welch segments of a short series (< 256) use the DFT
+        tc = c.take<double>(nd);
+        ts = c.take<double>(nd);
+        win = c.take<double>(256);
+        pxx = c.take<double>(132);
+        iw = c.take<int>(128);
+        return c.off;
+    }
+};
+
+#define TSFA_AR_AW_DOUBLES 2560
+struct ArLds {
+    double *red; double *xs; double *xc; double *aw;
+    TSFA_HD size_t carve(unsigned char *base, int maxn, int nt) {
+        (void)nt;
+        LdsCarve c{base, 0};
+        red = c.take<double>(TSFA_RED_DOUBLES);
+        xs = c.take<double>(maxn);
+        xc = c.take<double>(maxn);
+        aw = c.take<double>(TSFA_AR_AW_DOUBLES);
+        return c.off;
+    }
+};
+
+struct EntropyLds {
+    double *red; NpScratch *np; double *xs; double *thr;
+    TSFA_HD size_t carve(unsigned char *base, int maxn, int nt) {
+        (void)nt;
+        LdsCarve c{base, 0};
+        red = c.take<double>(TSFA_RED_DOUBLES);
+        np = c.take<NpScratch>(1);
+        xs = c.take<double>(maxn + 2);
+        thr = c.take<double>(16);
+        return c.off;
+    }
+};
+
+struct SeqLds {
+    double *red; unsigned char *seq; uint32_t *tab;
+    TSFA_HD static int table_cap(int maxn) { return tsfa_pow2_ceil(maxn + 256); }
+    TSFA_HD size_t carve(unsigned char *base, int maxn, int ntab) {
+        LdsCarve c{base, 0};
+        red = c.take<double>(TSFA_RED_DOUBLES);
+        seq = c.take<unsigned char>((size_t)ntab * maxn);
+        tab = c.take<uint32_t>((size_t)ntab * table_cap(maxn));
+        return c.off;
+    }
+};
+
+
+struct CwtPeaksLayout {
+    CwtPeaksLds p;
+    TSFA_HD size_t carve(unsigned char *base, int maxn, int nt) {
+        (void)nt;
+        LdsCarve c{base, 0};
+        p.red = c.take<double>(TSFA_RED_DOUBLES);
+        p.row0 = c.take<double>(maxn);
+        p.taps = c.take<double>(TSFA_CWTP_MAXTAPS + 16);
+        p.mask = c.take<unsigned short>(maxn);
+        p.lcol = c.take<unsigned short>(maxn);
+        p.linf = c.take<unsigned short>(maxn);
+        p.colmap = c.take<unsigned short>(maxn);
+        p.misc = c.take<int>(8);
+        return c.off;
+    }
+};
+
+#endif

@@ -1,0 +1,146 @@
+// Calculator registry shared by the HIP kernels, the C-ABI and (through tsfa_calc_id) the Python host.
+// One row per calculator of tsfresh/feature_extraction/feature_calculators.py that has a native kernel.
+//   X(enum, "tsfresh name", family)
+// Parameter slots p[0..3] of tsfa_feature_spec, per calculator (settings.py:165-280 gives the values):
+//   large_standard_deviation, symmetry_looking, ratio_beyond_r_sigma : p0 = r
+//   cid_ce                          : p0 = normalize (0/1)
+//   count_above, count_below        : p0 = t
+//   value_count                     : p0 = value
+//   range_count                     : p0 = min, p1 = max
+//   number_crossing_m               : p0 = m
+//   number_peaks, number_cwt_peaks  : p0 = n
+//   index_mass_quantile, quantile   : p0 = q
+//   energy_ratio_by_chunks          : p0 = num_segments, p1 = segment_focus
+//   c3, time_reversal_asymmetry_statistic, autocorrelation : p0 = lag
+//   binned_entropy                  : p0 = max_bins
+//   linear_trend                    : p0 = attr (TSFA_ATTR_*)
+//   agg_linear_trend                : p0 = attr, p1 = chunk_len, p2 = f_agg (TSFA_AGG_*)
+//   mean_n_absolute_max             : p0 = number_of_maxima
+//   change_quantiles                : p0 = ql, p1 = qh, p2 = isabs (0/1), p3 = f_agg (mean/var)
+//   permutation_entropy             : p0 = tau, p1 = dimension
+//   friedrich_coefficients          : p0 = coeff, p1 = m, p2 = r
+//   max_langevin_fixed_point        : p0 = m, p1 = r
+//   fft_coefficient                 : p0 = coeff, p1 = attr (TSFA_FFT_*)
+//   fft_aggregated                  : p0 = aggtype (TSFA_FFTAGG_*)
+//   spkt_welch_density              : p0 = coeff
+//   fourier_entropy, lempel_ziv_complexity : p0 = bins
+//   agg_autocorrelation             : p0 = f_agg (mean/median/var), p1 = maxlag
+//   partial_autocorrelation         : p0 = lag
+//   ar_coefficient                  : p0 = coeff, p1 = k
+//   augmented_dickey_fuller         : p0 = attr (TSFA_ADF_*)   (autolag "AIC" only)
+//   approximate_entropy             : p0 = m, p1 = r
+//   cwt_coefficients                : p0 = w (the width), p1 = coeff
+#ifndef TSFA_SPECS_H
+#define TSFA_SPECS_H
+
+#include <stdint.h>
+
+enum tsfa_family {
+    TSFA_FAM_BASIC = 0,   // single-pass reductions / scans over the LDS-resident series
+    TSFA_FAM_SORT = 1,    // in-LDS bitonic sort, then scans
+    TSFA_FAM_SPECTRAL = 2,// FFT / Welch
+    TSFA_FAM_AR = 3,      // autocovariance-based small dense linear algebra
+    TSFA_FAM_ENTROPY = 4, // O(L^2) template-pair sweep
+    TSFA_FAM_CWT = 5,     // Ricker/mexh contractions (MFMA) + ridge lines
+    TSFA_FAM_SEQ = 6,     // inherently sequential parses
+    TSFA_N_FAMILIES = 7
+};
+
+#define TSFA_CALC_LIST(X)                                                              \
+    X(SUM_VALUES, "sum_values", TSFA_FAM_BASIC)                                         \
+    X(MEAN, "mean", TSFA_FAM_BASIC)                                                     \
+    X(LENGTH, "length", TSFA_FAM_BASIC)                                                 \
+    X(STANDARD_DEVIATION, "standard_deviation", TSFA_FAM_BASIC)                         \
+    X(VARIANCE, "variance", TSFA_FAM_BASIC)                                             \
+    X(ROOT_MEAN_SQUARE, "root_mean_square", TSFA_FAM_BASIC)                             \
+    X(MAXIMUM, "maximum", TSFA_FAM_BASIC)                                               \
+    X(ABSOLUTE_MAXIMUM, "absolute_maximum", TSFA_FAM_BASIC)                             \
+    X(MINIMUM, "minimum", TSFA_FAM_BASIC)                                               \
+    X(ABS_ENERGY, "abs_energy", TSFA_FAM_BASIC)                                         \
+    X(VARIATION_COEFFICIENT, "variation_coefficient", TSFA_FAM_BASIC)                   \
+    X(VAR_GT_STD, "variance_larger_than_standard_deviation", TSFA_FAM_BASIC)            \
+    X(LARGE_STD, "large_standard_deviation", TSFA_FAM_BASIC)                            \
+    X(RATIO_BEYOND_R_SIGMA, "ratio_beyond_r_sigma", TSFA_FAM_BASIC)                     \
+    X(SKEWNESS, "skewness", TSFA_FAM_BASIC)                                             \
+    X(KURTOSIS, "kurtosis", TSFA_FAM_BASIC)                                             \
+    X(MEAN_ABS_CHANGE, "mean_abs_change", TSFA_FAM_BASIC)                               \
+    X(MEAN_CHANGE, "mean_change", TSFA_FAM_BASIC)                                       \
+    X(MEAN_SECOND_DERIVATIVE_CENTRAL, "mean_second_derivative_central", TSFA_FAM_BASIC) \
+    X(ABSOLUTE_SUM_OF_CHANGES, "absolute_sum_of_changes", TSFA_FAM_BASIC)               \
+    X(CID_CE, "cid_ce", TSFA_FAM_BASIC)                                                 \
+    X(COUNT_ABOVE_MEAN, "count_above_mean", TSFA_FAM_BASIC)                             \
+    X(COUNT_BELOW_MEAN, "count_below_mean", TSFA_FAM_BASIC)                             \
+    X(COUNT_ABOVE, "count_above", TSFA_FAM_BASIC)                                       \
+    X(COUNT_BELOW, "count_below", TSFA_FAM_BASIC)                                       \
+    X(VALUE_COUNT, "value_count", TSFA_FAM_BASIC)                                       \
+    X(RANGE_COUNT, "range_count", TSFA_FAM_BASIC)                                       \
+    X(NUMBER_CROSSING_M, "number_crossing_m", TSFA_FAM_BASIC)                           \
+    X(FIRST_LOCATION_OF_MAXIMUM, "first_location_of_maximum", TSFA_FAM_BASIC)           \
+    X(LAST_LOCATION_OF_MAXIMUM, "last_location_of_maximum", TSFA_FAM_BASIC)             \
+    X(FIRST_LOCATION_OF_MINIMUM, "first_location_of_minimum", TSFA_FAM_BASIC)           \
+    X(LAST_LOCATION_OF_MINIMUM, "last_location_of_minimum", TSFA_FAM_BASIC)             \
+    X(HAS_DUPLICATE_MAX, "has_duplicate_max", TSFA_FAM_BASIC)                           \
+    X(HAS_DUPLICATE_MIN, "has_duplicate_min", TSFA_FAM_BASIC)                           \
+    X(LONGEST_STRIKE_ABOVE_MEAN, "longest_strike_above_mean", TSFA_FAM_BASIC)           \
+    X(LONGEST_STRIKE_BELOW_MEAN, "longest_strike_below_mean", TSFA_FAM_BASIC)           \
+    X(NUMBER_PEAKS, "number_peaks", TSFA_FAM_BASIC)                                     \
+    X(INDEX_MASS_QUANTILE, "index_mass_quantile", TSFA_FAM_BASIC)                       \
+    X(ENERGY_RATIO_BY_CHUNKS, "energy_ratio_by_chunks", TSFA_FAM_BASIC)                 \
+    X(C3, "c3", TSFA_FAM_BASIC)                                                         \
+    X(TIME_REVERSAL_ASYMMETRY_STATISTIC, "time_reversal_asymmetry_statistic", TSFA_FAM_BASIC) \
+    X(AUTOCORRELATION, "autocorrelation", TSFA_FAM_BASIC)                               \
+    X(BINNED_ENTROPY, "binned_entropy", TSFA_FAM_BASIC)                                 \
+    X(BENFORD_CORRELATION, "benford_correlation", TSFA_FAM_BASIC)                       \
+    X(LINEAR_TREND, "linear_trend", TSFA_FAM_BASIC)                                     \
+    X(AGG_LINEAR_TREND, "agg_linear_trend", TSFA_FAM_BASIC)                             \
+    X(QUERY_SIMILARITY_COUNT, "query_similarity_count", TSFA_FAM_BASIC)                 \
+    X(MEDIAN, "median", TSFA_FAM_SORT)                                                  \
+    X(QUANTILE, "quantile", TSFA_FAM_SORT)                                              \
+    X(SYMMETRY_LOOKING, "symmetry_looking", TSFA_FAM_SORT)                              \
+    X(MEAN_N_ABSOLUTE_MAX, "mean_n_absolute_max", TSFA_FAM_SORT)                        \
+    X(CHANGE_QUANTILES, "change_quantiles", TSFA_FAM_SORT)                              \
+    X(HAS_DUPLICATE, "has_duplicate", TSFA_FAM_SORT)                                    \
+    X(RATIO_VALUE_NUMBER, "ratio_value_number_to_time_series_length", TSFA_FAM_SORT)    \
+    X(PCT_REOCC_VALUES, "percentage_of_reoccurring_values_to_all_values", TSFA_FAM_SORT) \
+    X(PCT_REOCC_DATAPOINTS, "percentage_of_reoccurring_datapoints_to_all_datapoints", TSFA_FAM_SORT) \
+    X(SUM_REOCC_VALUES, "sum_of_reoccurring_values", TSFA_FAM_SORT)                     \
+    X(SUM_REOCC_DATA_POINTS, "sum_of_reoccurring_data_points", TSFA_FAM_SORT)           \
+    X(PERMUTATION_ENTROPY, "permutation_entropy", TSFA_FAM_SORT)                        \
+    X(FRIEDRICH_COEFFICIENTS, "friedrich_coefficients", TSFA_FAM_SORT)                  \
+    X(MAX_LANGEVIN_FIXED_POINT, "max_langevin_fixed_point", TSFA_FAM_SORT)              \
+    X(FFT_COEFFICIENT, "fft_coefficient", TSFA_FAM_SPECTRAL)                            \
+    X(FFT_AGGREGATED, "fft_aggregated", TSFA_FAM_SPECTRAL)                              \
+    X(SPKT_WELCH_DENSITY, "spkt_welch_density", TSFA_FAM_SPECTRAL)                      \
+    X(FOURIER_ENTROPY, "fourier_entropy", TSFA_FAM_SPECTRAL)                            \
+    X(AGG_AUTOCORRELATION, "agg_autocorrelation", TSFA_FAM_AR)                          \
+    X(PARTIAL_AUTOCORRELATION, "partial_autocorrelation", TSFA_FAM_AR)                  \
+    X(AR_COEFFICIENT, "ar_coefficient", TSFA_FAM_AR)                                    \
+    X(AUGMENTED_DICKEY_FULLER, "augmented_dickey_fuller", TSFA_FAM_AR)                  \
+    X(SAMPLE_ENTROPY, "sample_entropy", TSFA_FAM_ENTROPY)                               \
+    X(APPROXIMATE_ENTROPY, "approximate_entropy", TSFA_FAM_ENTROPY)                     \
+    X(CWT_COEFFICIENTS, "cwt_coefficients", TSFA_FAM_CWT)                               \
+    X(NUMBER_CWT_PEAKS, "number_cwt_peaks", TSFA_FAM_CWT)                               \
+    X(LEMPEL_ZIV_COMPLEXITY, "lempel_ziv_complexity", TSFA_FAM_SEQ)
+
+enum tsfa_calc {
+#define X(id, name, fam) TSFA_C_##id,
+    TSFA_CALC_LIST(X)
+#undef X
+    TSFA_N_CALCS
+};
+
+// string-valued parameters as codes
+enum { TSFA_ATTR_PVALUE = 0, TSFA_ATTR_RVALUE = 1, TSFA_ATTR_INTERCEPT = 2, TSFA_ATTR_SLOPE = 3, TSFA_ATTR_STDERR = 4 };
+enum { TSFA_AGG_MAX = 0, TSFA_AGG_MIN = 1, TSFA_AGG_MEAN = 2, TSFA_AGG_VAR = 3, TSFA_AGG_MEDIAN = 4 };
+enum { TSFA_FFT_REAL = 0, TSFA_FFT_IMAG = 1, TSFA_FFT_ABS = 2, TSFA_FFT_ANGLE = 3 };
+enum { TSFA_FFTAGG_CENTROID = 0, TSFA_FFTAGG_VARIANCE = 1, TSFA_FFTAGG_SKEW = 2, TSFA_FFTAGG_KURTOSIS = 3 };
+enum { TSFA_ADF_TESTSTAT = 0, TSFA_ADF_PVALUE = 1, TSFA_ADF_USEDLAG = 2 };
+
+// device-side spec: one output column
+struct TsfaSpec {
+    int32_t calc;
+    int32_t col;  // column in the output row
+    double p[4];
+};
+
+#endif

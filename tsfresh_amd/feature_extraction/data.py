@@ -1,0 +1,129 @@
+"""Input adapters: pandas containers -> ragged buffers (one per kind) for the C-ABI.
+
+The reference wraps its three input formats in iterables of single `pd.Series`
+(tsfresh/feature_extraction/data.py: WideTsFrameAdapter :181, LongTsFrameAdapter :233, TsDictAdapter :294,
+to_tsdata :447) and then walks them one series at a time.  Here the same formats, checks and error messages
+produce, per kind, ONE contiguous value buffer plus an offsets array: the `[n_ids x n_kinds x max_len]` ragged
+layout the kernels consume.  Everything is vectorised (factorize + lexsort); no per-series Python.
+"""
+import numpy as np
+import pandas as pd
+
+
+class PackedKind:
+    """All series of one kind: `values[offsets[i]:offsets[i+1]]` is the series of `ids[i]` (ids sorted)."""
+
+    def __init__(self, kind, ids, values, offsets):
+        self.kind = kind
+        self.ids = ids
+        self.values = values
+        self.offsets = offsets
+
+    @property
+    def n_series(self):
+        return len(self.offsets) - 1
+
+
+def _check_colname(*columns):
+    # data.py:124-145
+    for col in columns:
+        if str(col).endswith("_"):
+            raise ValueError("Dict keys are not allowed to end with '_': {}".format(col))
+        if "__" in str(col):
+            raise ValueError("Dict keys are not allowed to contain '__': {}".format(col))
+
+
+def _check_nan(df, *columns):
+    # data.py:148-167
+    for col in columns:
+        if col not in df.columns:
+            raise ValueError("Column not found: {}".format(col))
+        if df[col].isnull().any():
+            raise ValueError("Column must not contain NaN values: {}".format(col))
+
+
+def _get_value_columns(df, *other_columns):
+    # data.py:170-178
+    value_columns = [col for col in df.columns if col not in other_columns]
+    if len(value_columns) == 0:
+        raise ValueError("Could not guess the value column! Please hand it to the function as an argument.")
+    return value_columns
+
+
+def _as_values(column):
+    arr = np.asarray(column)
+    if arr.dtype == np.float32:
+        return arr
+    return arr.astype(np.float64)
+
+
+def _pack(kind, ids, values, sort_values):
+    """Group `values` by `ids` (ascending), each group ordered by `sort_values` (stable)."""
+    codes, uniques = pd.factorize(np.asarray(ids), sort=True)
+    if sort_values is not None:
+        order = np.lexsort((np.asarray(sort_values), codes))
+    else:
+        order = np.argsort(codes, kind="stable")
+    counts = np.bincount(codes, minlength=len(uniques))
+    offsets = np.zeros(len(uniques) + 1, dtype=np.int64)
+    np.cumsum(counts, out=offsets[1:])
+    return PackedKind(str(kind), np.asarray(uniques), np.ascontiguousarray(_as_values(values)[order]), offsets)
+
+
+def pack_timeseries(container, column_id=None, column_kind=None, column_value=None, column_sort=None):
+    """-> (list[PackedKind] in output-column order, dtype of the id column, has_datetime_index)."""
+    if isinstance(container, pd.DataFrame):
+        df = container
+        if column_id is None:
+            raise ValueError("A value for column_id needs to be supplied")
+        if column_kind is not None:
+            # long format (data.py:233-291)
+            if column_value is None:
+                possible = _get_value_columns(df, column_id, column_sort, column_kind)
+                if len(possible) != 1:
+                    raise ValueError(
+                        "Could not guess the value column, as the number of unused columns os not equal to 1."
+                        "These columns where currently unused: {}"
+                        "Please hand it to the function as an argument.".format(",".join(map(str, possible))))
+                column_value = possible[0]
+            _check_nan(df, column_id, column_kind, column_value)
+            if column_sort is not None:
+                _check_nan(df, column_sort)
+            kinds = df[column_kind].to_numpy()
+            kcodes, kuniq = pd.factorize(kinds, sort=True)
+            packed = []
+            ids_all = df[column_id].to_numpy()
+            vals_all = df[column_value].to_numpy()
+            sort_all = df[column_sort].to_numpy() if column_sort is not None else None
+            for k, kind in enumerate(kuniq):
+                sel = np.nonzero(kcodes == k)[0]
+                packed.append(_pack(kind, ids_all[sel], vals_all[sel], None if sort_all is None else sort_all[sel]))
+            return packed, df[column_id].dtype, isinstance(df.index, pd.DatetimeIndex)
+        # wide format (data.py:181-230)
+        _check_nan(df, column_id)
+        value_columns = [column_value] if column_value is not None else _get_value_columns(df, column_id, column_sort)
+        _check_nan(df, *value_columns)
+        _check_colname(*value_columns)
+        if column_sort is not None:
+            _check_nan(df, column_sort)
+        ids_all = df[column_id].to_numpy()
+        sort_all = df[column_sort].to_numpy() if column_sort is not None else None
+        packed = [_pack(col, ids_all, df[col].to_numpy(), sort_all) for col in value_columns]
+        return packed, df[column_id].dtype, isinstance(df.index, pd.DatetimeIndex)
+    if isinstance(container, dict):
+        # dict of frames, one per kind (data.py:294-338)
+        _check_colname(*list(container.keys()))
+        for frame in container.values():
+            _check_nan(frame, column_id, column_value)
+        if column_sort is not None:
+            for frame in container.values():
+                _check_nan(frame, column_sort)
+        packed, id_dtype, has_dt = [], None, False
+        for kind, frame in container.items():
+            sort_vals = frame[column_sort].to_numpy() if column_sort is not None else None
+            packed.append(_pack(kind, frame[column_id].to_numpy(), frame[column_value].to_numpy(), sort_vals))
+            id_dtype = frame[column_id].dtype
+            has_dt = has_dt or isinstance(frame.index, pd.DatetimeIndex)
+        return packed, id_dtype, has_dt
+    raise ValueError("df must be a DataFrame or a dict of DataFrames. "
+                     "See https://tsfresh.readthedocs.io/en/latest/text/data_formats.html")

@@ -1,0 +1,149 @@
+"""`extract_features`: the reference's public entry point, with the hot path on the GPU.
+
+Signature and return contract follow tsfresh/feature_extraction/extraction.py:30-190 (`extract_features`) and
+:193-305 (`_do_extraction`): a pandas container in, a float64 DataFrame out whose index holds the ids (original
+dtype, sorted) and whose columns are named ``"{kind}__{calculator}__{parameters}"``.  What changes is the inside:
+
+    reference                                              here
+    ------------------------------------------------------------------------------------------------
+    to_tsdata -> iterable of pd.Series  (data.py:447)      pack_timeseries -> ragged buffers (data.py)
+    distributor.map_reduce(_do_extraction_on_chunk, ...)   Plan.extract_host -> tsfa_extract (C-ABI, HIP)
+    data.pivot(list of (id, name, value))  (data.py:86)    the dense matrix IS the pivot
+
+Arguments that only steer the reference's CPU distributors (`n_jobs`, `chunksize`, `disable_progressbar`,
+`show_warnings`) are accepted and ignored.  A custom `distributor` cannot be honoured and raises.
+"""
+import os
+import warnings
+
+import numpy as np
+import pandas as pd
+
+from tsfresh_amd import _native
+from tsfresh_amd.feature_extraction.data import pack_timeseries
+from tsfresh_amd.feature_extraction.plan import compile_fc_parameters
+from tsfresh_amd.feature_extraction.settings import ComprehensiveFCParameters
+
+
+def _default_device():
+    if "TSFRESH_AMD_DEVICE" in os.environ:
+        return int(os.environ["TSFRESH_AMD_DEVICE"])
+    if "LOCAL_RANK" in os.environ:  # one process per GPU under torch.distributed.run
+        return int(os.environ["LOCAL_RANK"]) % max(_native.device_count(), 1)
+    return 0
+
+
+def extract_features(
+    timeseries_container,
+    default_fc_parameters=None,
+    kind_to_fc_parameters=None,
+    column_id=None,
+    column_sort=None,
+    column_kind=None,
+    column_value=None,
+    chunksize=None,
+    n_jobs=None,
+    show_warnings=False,
+    disable_progressbar=True,
+    impute_function=None,
+    profile=False,
+    profiling_filename=None,
+    profiling_sorting=None,
+    distributor=None,
+    pivot=True,
+    device=None,
+):
+    """Extract features from a pandas container on one MI355X.
+
+    :param timeseries_container: long/wide `pd.DataFrame` or dict of DataFrames (reference data formats).
+    :param default_fc_parameters: calculator name -> list of parameter dicts (or None); default
+        `ComprehensiveFCParameters()` (extraction.py:149-152).
+    :param kind_to_fc_parameters: kind -> FCParameters overriding the default for that kind.
+    :param column_id, column_sort, column_kind, column_value: as in the reference.
+    :param impute_function: called on the result DataFrame (extraction.py:181-182).
+    :param pivot: False returns the flat list of `(id, column name, value)` tuples (extraction.py:301-302).
+    :param device: HIP device ordinal (default: $TSFRESH_AMD_DEVICE, else $LOCAL_RANK, else 0).
+    :return: `pd.DataFrame` of dtype float64.
+    """
+    if default_fc_parameters is None and kind_to_fc_parameters is None:
+        default_fc_parameters = ComprehensiveFCParameters()
+    elif default_fc_parameters is None and kind_to_fc_parameters is not None:
+        default_fc_parameters = {}
+    if distributor is not None:
+        raise ValueError("the passed distributor is not an DistributorBaseClass object "
+                         "(tsfresh_amd runs the extraction on the GPU and takes no CPU distributor)")
+    if profile:
+        warnings.warn("profile=True (cProfile of the Python calculators) has no meaning for the GPU path; "
+                      "use rocprofv3 or Plan.set_profiling instead", stacklevel=2)
+
+    packed, id_dtype, has_dt_index = pack_timeseries(
+        timeseries_container, column_id=column_id, column_kind=column_kind, column_value=column_value,
+        column_sort=column_sort)
+    if device is None:
+        device = _default_device()
+
+    with warnings.catch_warnings():
+        if not show_warnings:
+            warnings.simplefilter("ignore")
+        else:
+            warnings.simplefilter("default")
+
+        blocks = []  # (PackedKind, column names, matrix)
+        plan_cache = {}
+        for pk in packed:
+            if kind_to_fc_parameters and pk.kind in kind_to_fc_parameters:
+                fc_parameters = kind_to_fc_parameters[pk.kind]
+            else:
+                fc_parameters = default_fc_parameters
+            key = id(fc_parameters)
+            if key not in plan_cache:
+                fplan = compile_fc_parameters(fc_parameters, has_datetime_index=has_dt_index)
+                nplan = _native.Plan(fplan.native_specs(_native.calc_id), device=device) if len(fplan) else None
+                plan_cache[key] = (fplan, nplan)
+            fplan, nplan = plan_cache[key]
+            if nplan is None:
+                continue
+            matrix = nplan.extract_host(pk.values, pk.offsets)
+            blocks.append((pk, [pk.kind + "__" + name for name in fplan.names], matrix))
+        for _, nplan in plan_cache.values():
+            if nplan is not None:
+                nplan.close()
+
+    if not pivot:
+        result = []
+        for pk, names, matrix in blocks:
+            for r, sample_id in enumerate(pk.ids):
+                row = matrix[r]
+                result.extend((sample_id, name, row[c]) for c, name in enumerate(names))
+        return result
+
+    # assemble: union of ids (sorted), one column block per kind
+    if not blocks:
+        return pd.DataFrame()
+    all_ids = blocks[0][0].ids
+    same_ids = all(len(b[0].ids) == len(all_ids) and np.array_equal(b[0].ids, all_ids) for b in blocks[1:])
+    if same_ids:
+        index = pd.Index(all_ids)
+        data = np.concatenate([b[2] for b in blocks], axis=1) if len(blocks) > 1 else blocks[0][2]
+    else:
+        index = pd.Index(all_ids)
+        for b in blocks[1:]:
+            index = index.union(pd.Index(b[0].ids))
+        index = index.sort_values()
+        n_cols = sum(b[2].shape[1] for b in blocks)
+        data = np.full((len(index), n_cols), np.nan)
+        c0 = 0
+        for pk, names, matrix in blocks:
+            rows = index.get_indexer(pd.Index(pk.ids))
+            data[rows, c0:c0 + matrix.shape[1]] = matrix
+            c0 += matrix.shape[1]
+    columns = [name for b in blocks for name in b[1]]
+    result = pd.DataFrame(data, index=index, columns=columns, dtype=float)
+    try:
+        result.index = result.index.astype(id_dtype)  # data.py:115-116
+    except (TypeError, ValueError):
+        pass
+    result = result.sort_index()
+    if impute_function is not None:
+        impute_function(result)
+    return result

@@ -1,0 +1,152 @@
+"""FCParameters dictionaries: which calculators run with which parameters.
+
+Mirror of the reference's tsfresh/feature_extraction/settings.py (ComprehensiveFCParameters :133-294,
+MinimalFCParameters :297-320, EfficientFCParameters :323-343, IndexBased/TimeBased :346-377, from_columns :23).
+The dictionaries are built from the registry table instead of module introspection, but hold the same keys, in
+the same order, with the same parameter lists -- including the reference's quirks (see `mean_n_absolute_max`).
+"""
+from collections import UserDict
+from itertools import product
+
+from tsfresh_amd.feature_extraction.registry import CALCULATORS
+from tsfresh_amd.utilities.string_manipulation import get_config_from_string
+
+
+def from_columns(columns, columns_to_ignore=None):
+    """kind -> FCParameters mapping that reproduces exactly the given feature columns (settings.py:23-94)."""
+    kind_to_fc_parameters = {}
+    if columns_to_ignore is None:
+        columns_to_ignore = []
+    for col in columns:
+        if col in columns_to_ignore:
+            continue
+        if not isinstance(col, str):
+            raise TypeError("Column name {} should be a string or unicode".format(col))
+        parts = col.split("__")
+        if len(parts) < 2:
+            raise ValueError("Splitting of columnname {} resulted in only one part.".format(col))
+        kind, feature_name = parts[0], parts[1]
+        if feature_name not in CALCULATORS:
+            raise ValueError("Unknown feature name {}".format(feature_name))
+        fc = kind_to_fc_parameters.setdefault(kind, {})
+        config = get_config_from_string(parts)
+        if config:
+            if feature_name in fc:
+                if config not in fc[feature_name]:
+                    fc[feature_name].append(config)
+            else:
+                fc[feature_name] = [config]
+        else:
+            fc[feature_name] = None
+    return kind_to_fc_parameters
+
+
+class PickableSettings(UserDict):
+    """Base of the settings classes (the reference adds cloudpickle support for callable keys; plain dicts of
+    names pickle as they are)."""
+
+
+def _comprehensive_parameters():
+    name_to_param = {}
+    for name, calc in CALCULATORS.items():
+        if calc.n_args == 1:
+            name_to_param[name] = None
+    name_to_param.update({
+        "time_reversal_asymmetry_statistic": [{"lag": lag} for lag in range(1, 4)],
+        "c3": [{"lag": lag} for lag in range(1, 4)],
+        "cid_ce": [{"normalize": True}, {"normalize": False}],
+        "symmetry_looking": [{"r": r * 0.05} for r in range(20)],
+        "large_standard_deviation": [{"r": r * 0.05} for r in range(1, 20)],
+        "quantile": [{"q": q} for q in [0.1, 0.2, 0.3, 0.4, 0.6, 0.7, 0.8, 0.9]],
+        "autocorrelation": [{"lag": lag} for lag in range(10)],
+        "agg_autocorrelation": [{"f_agg": s, "maxlag": 40} for s in ["mean", "median", "var"]],
+        "partial_autocorrelation": [{"lag": lag} for lag in range(10)],
+        "number_cwt_peaks": [{"n": n} for n in [1, 5]],
+        "number_peaks": [{"n": n} for n in [1, 3, 5, 10, 50]],
+        "binned_entropy": [{"max_bins": max_bins} for max_bins in [10]],
+        "index_mass_quantile": [{"q": q} for q in [0.1, 0.2, 0.3, 0.4, 0.6, 0.7, 0.8, 0.9]],
+        "cwt_coefficients": [{"widths": width, "coeff": coeff, "w": w}
+                             for width in [(2, 5, 10, 20)] for coeff in range(15) for w in (2, 5, 10, 20)],
+        "spkt_welch_density": [{"coeff": coeff} for coeff in [2, 5, 8]],
+        "ar_coefficient": [{"coeff": coeff, "k": k} for coeff in range(10 + 1) for k in [10]],
+        "change_quantiles": [{"ql": ql, "qh": qh, "isabs": b, "f_agg": f}
+                             for ql in [0.0, 0.2, 0.4, 0.6, 0.8] for qh in [0.2, 0.4, 0.6, 0.8, 1.0]
+                             for b in [False, True] for f in ["mean", "var"] if ql < qh],
+        "fft_coefficient": [{"coeff": k, "attr": a}
+                            for a, k in product(["real", "imag", "abs", "angle"], range(100))],
+        "fft_aggregated": [{"aggtype": s} for s in ["centroid", "variance", "skew", "kurtosis"]],
+        "value_count": [{"value": value} for value in [0, 1, -1]],
+        "range_count": [{"min": -1, "max": 1}, {"min": -1e12, "max": 0}, {"min": 0, "max": 1e12}],
+        "approximate_entropy": [{"m": 2, "r": r} for r in [0.1, 0.3, 0.5, 0.7, 0.9]],
+        "friedrich_coefficients": [{"coeff": coeff, "m": 3, "r": 30} for coeff in range(3 + 1)],
+        "max_langevin_fixed_point": [{"m": 3, "r": 30}],
+        "linear_trend": [{"attr": a} for a in ["pvalue", "rvalue", "intercept", "slope", "stderr"]],
+        "agg_linear_trend": [{"attr": attr, "chunk_len": i, "f_agg": f}
+                             for attr in ["rvalue", "intercept", "slope", "stderr"]
+                             for i in [5, 10, 50] for f in ["max", "min", "mean", "var"]],
+        "augmented_dickey_fuller": [{"attr": "teststat"}, {"attr": "pvalue"}, {"attr": "usedlag"}],
+        "number_crossing_m": [{"m": 0}, {"m": -1}, {"m": 1}],
+        "energy_ratio_by_chunks": [{"num_segments": 10, "segment_focus": i} for i in range(10)],
+        "ratio_beyond_r_sigma": [{"r": x} for x in [0.5, 1, 1.5, 2, 2.5, 3, 5, 6, 7, 10]],
+        "linear_trend_timewise": [{"attr": a} for a in ["pvalue", "rvalue", "intercept", "slope", "stderr"]],
+        "count_above": [{"t": 0}],
+        "count_below": [{"t": 0}],
+        "lempel_ziv_complexity": [{"bins": x} for x in [2, 3, 5, 10, 100]],
+        "fourier_entropy": [{"bins": x} for x in [2, 3, 5, 10, 100]],
+        "permutation_entropy": [{"tau": 1, "dimension": x} for x in [3, 4, 5, 6, 7]],
+        "query_similarity_count": [{"query": None, "threshold": 0.0}],
+        # The reference writes a dict literal that repeats the key "number_of_maxima" three times
+        # (settings.py:272-278); Python keeps the last one, so exactly one column (7) is produced.
+        "mean_n_absolute_max": [{"number_of_maxima": 7}],
+    })
+    # matrix_profile needs the optional `matrixprofile` dependency; the reference drops it when that is
+    # missing (settings.py:282-292), which is the only configuration that can be reproduced here.
+    name_to_param.pop("matrix_profile", None)
+    return name_to_param
+
+
+class ComprehensiveFCParameters(PickableSettings):
+    """All calculators with the reference's default parameter grids (75 calculators, 788 columns per kind)."""
+
+    def __init__(self):
+        super().__init__(_comprehensive_parameters())
+
+
+class MinimalFCParameters(ComprehensiveFCParameters):
+    """Only the calculators flagged ``minimal`` (10 columns per kind)."""
+
+    def __init__(self):
+        super().__init__()
+        for name in list(self.keys()):
+            if not CALCULATORS[name].minimal:
+                del self[name]
+
+
+class EfficientFCParameters(ComprehensiveFCParameters):
+    """Everything except the calculators flagged ``high_comp_cost`` (sample/approximate entropy)."""
+
+    def __init__(self):
+        super().__init__()
+        for name in list(self.keys()):
+            if CALCULATORS[name].high_comp_cost:
+                del self[name]
+
+
+class IndexBasedFCParameters(ComprehensiveFCParameters):
+    """Only the calculators that take the pd.Series (``input == "pd.Series"``)."""
+
+    def __init__(self):
+        super().__init__()
+        for name in list(self.keys()):
+            if CALCULATORS[name].input != "pd.Series":
+                del self[name]
+
+
+class TimeBasedFCParameters(ComprehensiveFCParameters):
+    """Only the calculators that need a DatetimeIndex."""
+
+    def __init__(self):
+        super().__init__()
+        for name in list(self.keys()):
+            if CALCULATORS[name].index_type != "DatetimeIndex":
+                del self[name]
