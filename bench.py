@@ -1,0 +1,199 @@
+#!/usr/bin/env python
+"""Headline benchmark: series/sec of the feature-extraction hot path (BASELINE.json metric).
+
+    python bench.py --gpus 1 --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+One "step" = one pass of the hot path (tsfa_extract: every kernel of the plan) over one batch of synthetic series
+that is ALREADY RESIDENT IN HBM, writing the dense [n_series x n_cols] float64 feature matrix to HBM; with N > 1
+each rank (one process per GPU) extracts its own id-shard and the shards are reassembled on every rank with one
+RCCL all-gather (north_star), inside the timed region.  Per-GPU work is fixed -> "scaling": "weak".
+
+Workload at N = 1: BASELINE.json configs[2] -- 100k synthetic float32 series x len 1024,
+ComprehensiveFCParameters (783 columns) -- the configuration the metric/target is quoted on.
+
+The JSON line also carries
+  roofline     : dominant kernel's algorithmic HBM bytes per launch / its HIP-event duration vs 8 TB/s
+  cpu_baseline : the numpy oracle (a port of the reference's calculators) timed on a bounded sample of the same
+                 workload on the host cores -- a reported baseline, not the target.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy)
+
+
+def _cpu_baseline_worker(args):
+    values, offsets = args
+    sys.path.insert(0, ROOT)
+    from oracle.extract import oracle_matrix
+    from tsfresh_amd.feature_extraction.settings import ComprehensiveFCParameters, EfficientFCParameters  # noqa: F401
+    params = ComprehensiveFCParameters()
+    t0 = time.perf_counter()
+    oracle_matrix(values, offsets, params)
+    return time.perf_counter() - t0
+
+
+def cpu_baseline(length, seed, budget_series_per_core=3):
+    """Oracle ("port") on a bounded sample: `cores` worker processes, each `budget_series_per_core` series."""
+    import multiprocessing as mp
+    for v in ("OMP_NUM_THREADS", "MKL_NUM_THREADS", "OPENBLAS_NUM_THREADS"):
+        os.environ[v] = "1"  # the reference's own advice (docs/text/tsfresh_on_a_cluster.rst:216-231)
+    cores = os.cpu_count() or 1
+    workers = min(cores, 64)
+    rng = np.random.default_rng(seed)
+    jobs = []
+    for _ in range(workers):
+        x = rng.standard_normal((budget_series_per_core, length), dtype=np.float32).astype(np.float64)
+        jobs.append((x.reshape(-1), np.arange(budget_series_per_core + 1, dtype=np.int64) * length))
+    ctx = mp.get_context("spawn")
+    t0 = time.perf_counter()
+    with ctx.Pool(workers) as pool:
+        pool.map(_cpu_baseline_worker, jobs)
+    wall = time.perf_counter() - t0
+    n = workers * budget_series_per_core
+    return {"value": n / wall, "unit": "series/sec", "cores": workers, "kind": "port",
+            "sample": "%d series x len %d, ComprehensiveFCParameters, oracle/ (numpy port of the reference "
+                      "calculators), %d processes x %d series, wall %.1f s incl. process start" % (
+                          n, length, workers, budget_series_per_core, wall)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--n-series", type=int, default=100_000, help="series per GPU")
+    ap.add_argument("--length", type=int, default=1024)
+    ap.add_argument("--params", default="comprehensive", choices=["comprehensive", "efficient", "minimal"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    from tsfresh_amd import _native
+    from tsfresh_amd.feature_extraction import settings
+    from tsfresh_amd.feature_extraction.plan import compile_fc_parameters
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available() or _native.device_count() < 1:
+        raise SystemExit("bench.py needs a HIP device: the native path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist_mod
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist_mod.init_process_group(backend="nccl", device_id=dev)
+        dist = dist_mod
+    assert world == args.gpus, "launch with --nproc-per-node equal to --gpus"
+
+    cls = {"comprehensive": settings.ComprehensiveFCParameters, "efficient": settings.EfficientFCParameters,
+           "minimal": settings.MinimalFCParameters}[args.params]
+    import warnings
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        fplan = compile_fc_parameters(cls())
+    n_cols = len(fplan)
+    plan = _native.Plan(fplan.native_specs(_native.calc_id), device=local_rank)
+
+    n, L = args.n_series, args.length
+    gen = torch.Generator(device=dev)
+    gen.manual_seed(42 + rank)
+    values = torch.randn(n * L, device=dev, dtype=torch.float32, generator=gen)  # i.i.d. N(0,1) float32 series
+    offsets = torch.arange(0, (n + 1) * L, L, device=dev, dtype=torch.int64)
+    out = torch.empty((n, n_cols), device=dev, dtype=torch.float64)
+    gathered = torch.empty((world * n, n_cols), device=dev, dtype=torch.float64) if world > 1 else None
+    stream = torch.cuda.current_stream(dev).cuda_stream
+
+    def step():
+        plan.extract_device(values.data_ptr(), _native.TSFA_F32, offsets.data_ptr(), n, out.data_ptr(), n_cols, stream)
+        if dist is not None:
+            dist.all_gather_into_tensor(gathered, out)
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+
+    torch.cuda.synchronize(dev)  # inputs fully materialised in HBM before the first launch
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    ms_per_step = 1000.0 * elapsed / max(args.steps, 1)
+    value = world * n * args.steps / elapsed
+
+    # ---- per-kernel HIP-event timings (events recorded on the launch stream), 2 profiled passes ----
+    plan.set_profiling(True)
+    kt = {}
+    reps = 2
+    for _ in range(reps):
+        plan.extract_device(values.data_ptr(), _native.TSFA_F32, offsets.data_ptr(), n, out.data_ptr(), n_cols, stream)
+        for name, ms in plan.last_timings():
+            kt[name] = kt.get(name, 0.0) + ms / reps
+    plan.set_profiling(False)
+    finite = bool(torch.isfinite(out[:, : min(n_cols, 8)]).all().item())
+
+    if rank == 0:
+        dom = max(kt, key=kt.get) if kt else None
+        roof = None
+        if dom:
+            fam_cols = {"k_basic": 0, "k_sort": 0, "k_spectral": 0, "k_ar": 0, "k_entropy": 0, "k_cwtpeaks": 0,
+                        "k_seq": 0, "k_cwt_gemm": 0}
+            from tsfresh_amd.feature_extraction.registry import CALCULATORS  # noqa: F401
+            fam_of = {"sample_entropy": "k_entropy", "approximate_entropy": "k_entropy",
+                      "cwt_coefficients": "k_cwt_gemm", "number_cwt_peaks": "k_cwtpeaks",
+                      "lempel_ziv_complexity": "k_seq"}
+            for nm in fplan.names:
+                fam_cols[fam_of.get(nm.split("__")[0], "other")] = fam_cols.get(fam_of.get(nm.split("__")[0], "other"), 0) + 1
+            cols_dom = fam_cols.get(dom, 0) or n_cols
+            # algorithmic bytes per series = 4*L read (each sample once) + 8 bytes per column written
+            alg_bytes = n * (4 * L + 8 * cols_dom)
+            achieved = alg_bytes / (kt[dom] * 1e-3) / 1e9
+            roof = {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "frac": achieved / HBM_PEAK_GBS, "traffic": None, "kernel_ms": kt[dom],
+                    "algorithmic_bytes_per_launch": alg_bytes,
+                    "note": "O(L^2) template-pair sweep: VALU(fp64)-bound, not HBM-bound (DESIGN.md roofline section)"}
+        line = {
+            "metric": "series/sec (ComprehensiveFCParameters, len=1024)" if args.params == "comprehensive" and L == 1024
+                      else "series/sec (%s, len=%d)" % (args.params, L),
+            "value": value, "unit": "series/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f64", "data": "synthetic",
+            "config": {"workload": "%d series/GPU x len %d float32 i.i.d. N(0,1), %sFCParameters (%d columns), "
+                                   "inputs and outputs resident in HBM%s" % (
+                                       n, L, args.params.capitalize(), n_cols,
+                                       ", id-sharded + RCCL all-gather of the feature matrix" if world > 1 else ""),
+                       "n_series_per_gpu": n, "length": L, "n_cols": n_cols, "parallelism": "ids%d" % world},
+            "kernel_ms": kt, "outputs_finite": finite, "roofline": roof,
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline(L, seed=42)
+        print(json.dumps(line))
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+    plan.close()
+
+
+if __name__ == "__main__":
+    main()

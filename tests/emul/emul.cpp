@@ -8,6 +8,7 @@
 #include <stdio.h>
 #include <string.h>
 
+#include <algorithm>
 #include <string>
 #include <vector>
 
@@ -98,8 +99,15 @@ extern "C" int tsfa_emul_extract(const tsfa_feature_spec *specs, int n_specs, co
                                 twc.data(), tws.data());
         }
         if (!fam[TSFA_FAM_AR].empty()) {
-            std::vector<double> xc(maxn + 8), aw(TSFA_AR_AW_DOUBLES);
-            fam_ar_series(b, xs.data(), n, fam[TSFA_FAM_AR].data(), (int)fam[TSFA_FAM_AR].size(), row, xc.data(), aw.data());
+            int P = 8;
+            for (const auto &sp : fam[TSFA_FAM_AR]) {
+                if (sp.calc == TSFA_C_AUGMENTED_DICKEY_FULLER) P = std::max(P, adf_maxlag_for(maxn) + 3);
+                else if (sp.calc == TSFA_C_AR_COEFFICIENT) P = std::max(P, (int)sp.p[1] + 2);
+            }
+            std::vector<double> xc(maxn + 8), rbuf(maxn + 8), aw(ArLds::scratch_doubles(P));
+            const double *xp = xs.data();
+            fam_ar_series(b, [=](int i) { return xp[i]; }, n, fam[TSFA_FAM_AR].data(), (int)fam[TSFA_FAM_AR].size(), row,
+                          xc.data(), rbuf.data(), aw.data(), P);
         }
         if (!fam[TSFA_FAM_ENTROPY].empty()) {
             std::vector<double> thr(16);

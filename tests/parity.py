@@ -13,6 +13,7 @@ Documented, reference-side non-determinism that is EXCLUDED (see DESIGN.md "Know
   - permutation_entropy on a series with tied values inside a window: the reference ranks with numpy's default
     argsort, which is an unstable SIMD sort for ties, so its answer depends on the CPU the reference runs on;
   - fft_coefficient "angle" of a bin whose magnitude is round-off noise (|X_k| < 1e-9 * sum|x|);
+  - fourier_entropy / spkt_welch_density of a constant series (the detrended PSD is pure round-off noise);
   - regressions on rank-deficient designs (constant / exactly linear series): ar_coefficient,
     augmented_dickey_fuller, friedrich_coefficients, max_langevin_fixed_point fall back, in the reference, on the
     minimum-norm pseudo-inverse solution of a singular system (LAPACK round-off decides the digits).
@@ -62,6 +63,8 @@ def excluded(col, x):
         return _has_window_ties(x, dim)
     if f in ("ar_coefficient", "augmented_dickey_fuller", "friedrich_coefficients", "max_langevin_fixed_point"):
         return _rank_deficient(x)
+    if f in ("fourier_entropy", "spkt_welch_density"):
+        return np.ptp(np.asarray(x, dtype=np.float64)) == 0  # Welch PSD of a constant series is round-off noise
     return False
 
 

@@ -1,0 +1,158 @@
+"""`-m gpu`: the HIP path (through the C-ABI) against the reference golden vectors, the oracle, and -- at
+BASELINE sizes -- size-independent properties."""
+import os
+import warnings
+
+import numpy as np
+import pandas as pd
+import pytest
+
+from engines import hip_engine, oracle_engine
+from parity import compare
+from tsfresh_amd.feature_extraction import settings
+
+pytestmark = pytest.mark.gpu
+G = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def _series(values, offsets):
+    return [values[offsets[i]:offsets[i + 1]] for i in range(len(offsets) - 1)]
+
+
+def _align(names_want, names_got, got):
+    idx = [names_got.index(n) for n in names_want]
+    return got[:, idx]
+
+
+def test_hip_matches_reference_golden(gpu):
+    g1 = np.load(os.path.join(G, "ref_main.npz"))
+    g2 = np.load(os.path.join(G, "ref_conda.npz"))
+    names = list(g1["names"]) + list(g2["names"])
+    want = np.concatenate([g1["matrix"], g2["matrix"]], axis=1)
+    values, offsets = g1["values"], g1["offsets"]
+    got_names, got = hip_engine(settings.ComprehensiveFCParameters(), values, offsets)
+    assert set(got_names) == set(names)
+    bad = compare(names, _align(names, got_names, got), want, _series(values, offsets))
+    assert not bad, "%d mismatches, first: %s" % (len(bad), bad[:12])
+
+
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+def test_hip_matches_oracle_on_ragged_batch(gpu, dtype):
+    rng = np.random.default_rng(5)
+    lens = list(rng.integers(4, 700, size=28)) + [1024, 512, 256, 64, 1, 2, 3]
+    chunks = []
+    for i, n in enumerate(lens):
+        x = rng.standard_normal(n)
+        if i % 3 == 1:
+            x = np.cumsum(x)
+        chunks.append(x.astype(dtype))
+    values = np.concatenate(chunks)
+    offsets = np.zeros(len(lens) + 1, dtype=np.int64)
+    np.cumsum(lens, out=offsets[1:])
+    params = settings.ComprehensiveFCParameters()
+    names, got = hip_engine(params, values, offsets)
+    onames, want = oracle_engine(params, values.astype(np.float64), offsets)
+    bad = compare(onames, _align(onames, names, got), want, _series(values.astype(np.float64), offsets))
+    assert not bad, "%d mismatches, first: %s" % (len(bad), bad[:12])
+
+
+def test_hip_long_series_uses_four_wave_workgroups(gpu):
+    # max_len > 2048 switches every kernel to 256-thread workgroups (cross-wave reductions, barriers)
+    rng = np.random.default_rng(11)
+    lens = [3000, 2500, 4096, 100]
+    values = np.concatenate([np.cumsum(rng.standard_normal(n)) if i == 1 else rng.standard_normal(n) for i, n in enumerate(lens)])
+    offsets = np.zeros(len(lens) + 1, dtype=np.int64)
+    np.cumsum(lens, out=offsets[1:])
+    params = settings.EfficientFCParameters()
+    params["approximate_entropy"] = [{"m": 2, "r": 0.3}]
+    params["sample_entropy"] = None
+    names, got = hip_engine(params, values, offsets)
+    onames, want = oracle_engine(params, values, offsets)
+    bad = compare(onames, _align(onames, names, got), want, _series(values, offsets))
+    assert not bad, "%d mismatches, first: %s" % (len(bad), bad[:12])
+
+
+def test_extract_features_dataframe_contract(gpu):
+    from tsfresh_amd import extract_features
+    rng = np.random.default_rng(3)
+    n_ids, L = 6, 40
+    ids = np.repeat(np.array([11, 3, 7, 5, 2, 9]), L)
+    df = pd.DataFrame({"id": ids, "time": np.tile(np.arange(L), n_ids), "a": rng.standard_normal(n_ids * L),
+                       "b": rng.integers(0, 5, n_ids * L)})
+    df = df.sample(frac=1.0, random_state=1)  # shuffled rows: column_sort restores the order
+    params = settings.MinimalFCParameters()
+    feats = extract_features(df, column_id="id", column_sort="time", default_fc_parameters=params)
+    assert list(feats.index) == [2, 3, 5, 7, 9, 11] and feats.index.dtype == df["id"].dtype
+    assert feats.shape == (6, 20) and feats.dtypes.unique().tolist() == [np.dtype("float64")]
+    assert feats.columns[0].startswith("a__") and feats.columns[10].startswith("b__")
+    srt = df.sort_values(["id", "time"])
+    for i in feats.index:
+        x = srt[srt["id"] == i]["a"].to_numpy()
+        assert feats.loc[i, "a__sum_values"] == np.sum(x)
+        assert feats.loc[i, "a__maximum"] == np.max(x)
+        assert feats.loc[i, "a__median"] == np.median(x)
+        assert feats.loc[i, "a__length"] == L
+    # long format and dict format give the same matrix
+    long_df = pd.concat([df[["id", "time"]].assign(kind="a", value=df["a"]),
+                         df[["id", "time"]].assign(kind="b", value=df["b"].astype(float))])
+    f2 = extract_features(long_df, column_id="id", column_sort="time", column_kind="kind", column_value="value",
+                          default_fc_parameters=params)
+    pd.testing.assert_frame_equal(feats, f2[feats.columns])
+    f3 = extract_features({"a": df[["id", "time", "a"]].rename(columns={"a": "v"}),
+                           "b": df[["id", "time", "b"]].rename(columns={"b": "v"})},
+                          column_id="id", column_sort="time", column_value="v", default_fc_parameters=params)
+    pd.testing.assert_frame_equal(feats, f3[feats.columns])
+    # pivot=False returns (id, name, value) tuples
+    tuples = extract_features(df, column_id="id", column_sort="time", default_fc_parameters=params, pivot=False)
+    assert len(tuples) == 6 * 20 and tuples[0][1].startswith("a__")
+    # kind_to_fc_parameters overrides per kind
+    f4 = extract_features(df, column_id="id", column_sort="time", default_fc_parameters=params,
+                          kind_to_fc_parameters={"b": {"maximum": None}})
+    assert [c for c in f4.columns if c.startswith("b__")] == ["b__maximum"]
+    with pytest.raises(ValueError):
+        extract_features(df.assign(a=np.nan), column_id="id", column_sort="time", default_fc_parameters=params)
+
+
+def test_properties_at_full_length(gpu):
+    """Size-independent properties on a batch too big for the oracle: 4096 series x 1024, Comprehensive."""
+    rng = np.random.default_rng(99)
+    n, L = 4096, 1024
+    base = rng.standard_normal((n // 2, L), dtype=np.float32)
+    x = np.concatenate([base, base[::-1]])  # every series appears twice, second half in reversed batch order
+    values = x.reshape(-1)
+    offsets = np.arange(n + 1, dtype=np.int64) * L
+    params = settings.ComprehensiveFCParameters()
+    names, got = hip_engine(params, values, offsets)
+    assert got.shape == (n, 783)
+    # (1) a row depends only on its own series: duplicates give bit-identical rows wherever they sit in the batch
+    a, b = got[: n // 2], got[n // 2:][::-1]
+    assert np.array_equal(np.isnan(a), np.isnan(b)) and np.array_equal(np.nan_to_num(a), np.nan_to_num(b))
+    col = {nm: i for i, nm in enumerate(names)}
+    x64 = x.astype(np.float64)
+    # (2) closed forms that numpy evaluates exactly the same way
+    assert np.array_equal(got[:, col["value__length"]], np.full(n, L))
+    assert np.array_equal(got[:, col["value__maximum"]], x64.max(axis=1))
+    assert np.array_equal(got[:, col["value__minimum"]], x64.min(axis=1))
+    assert np.array_equal(got[:, col["value__sum_values"]], np.array([np.sum(r) for r in x64]))
+    assert np.array_equal(got[:, col["value__median"]], np.median(x64, axis=1))
+    np.testing.assert_allclose(got[:, col["value__abs_energy"]], (x64 ** 2).sum(axis=1), rtol=1e-12)
+    # (3) Parseval: sum of |rfft|^2 over the reported bins is bounded by the energy; bins 0..99 match numpy's rfft
+    spec = np.fft.rfft(x64[:64], axis=1)
+    for k in (0, 1, 17, 99):
+        np.testing.assert_allclose(got[:64, col['value__fft_coefficient__attr_"real"__coeff_%d' % k]], spec[:, k].real,
+                                   rtol=1e-6, atol=1e-9 * L)
+        np.testing.assert_allclose(got[:64, col['value__fft_coefficient__attr_"abs"__coeff_%d' % k]], np.abs(spec[:, k]),
+                                   rtol=1e-6, atol=1e-9 * L)
+    # (4) quantiles are sorted, energy ratios sum to 1, counts are integers in range
+    qs = np.stack([got[:, col["value__quantile__q_%s" % q]] for q in (0.1, 0.2, 0.3, 0.4, 0.6, 0.7, 0.8, 0.9)], axis=1)
+    assert np.all(np.diff(qs, axis=1) >= 0)
+    er = np.stack([got[:, col["value__energy_ratio_by_chunks__num_segments_10__segment_focus_%d" % i]] for i in range(10)], axis=1)
+    np.testing.assert_allclose(er.sum(axis=1), 1.0, rtol=1e-12)
+    cam = got[:, col["value__count_above_mean"]]
+    assert np.all(cam == np.round(cam)) and np.all((cam >= 0) & (cam <= L))
+    # (5) entropies are finite and ordered in r for approximate entropy's neighbour counts (monotone in tolerance)
+    se = got[:, col["value__sample_entropy"]]
+    assert np.all(np.isfinite(se)) and np.all(se > 0)
+    # (6) no column is left unwritten (NaN only where the reference yields NaN: query_similarity_count)
+    nan_cols = {names[j] for j in np.where(np.isnan(got).any(axis=0))[0]}
+    assert nan_cols <= {"value__query_similarity_count__query_None__threshold_0.0"}, nan_cols

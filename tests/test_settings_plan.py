@@ -1,0 +1,69 @@
+"""Settings dictionaries and column names must equal the reference's (golden names recorded from the real
+reference by tests/golden/gen_golden_main.py; reference tests: tests/units/feature_extraction/test_settings.py)."""
+import os
+import warnings
+
+import numpy as np
+import pytest
+
+from tsfresh_amd.feature_extraction import settings
+from tsfresh_amd.feature_extraction.plan import compile_fc_parameters
+from tsfresh_amd.feature_extraction.registry import UnsupportedFeature
+from tsfresh_amd.utilities.string_manipulation import convert_to_output_format, get_config_from_string
+
+G = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+THIRD = ("cwt_coefficients", "agg_autocorrelation", "partial_autocorrelation", "augmented_dickey_fuller", "ar_coefficient")
+
+
+@pytest.mark.parametrize("cls,n_keys,n_cols", [("ComprehensiveFCParameters", 75, 783), ("EfficientFCParameters", 73, 777),
+                                               ("MinimalFCParameters", 10, 10)])
+def test_settings_match_reference(cls, n_keys, n_cols):
+    g = np.load(os.path.join(G, "ref_main.npz"))
+    ours = getattr(settings, cls)()
+    assert list(ours.keys()) == list(g["names_%s_keys" % cls])  # same calculators, same order
+    assert len(ours) == n_keys
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        plan = compile_fc_parameters(ours)
+    assert len(plan) == n_cols
+    ref_names = list(g["names_" + cls])  # without the five third-party calculators
+    mine = ["value__" + n for n in plan.names if n.split("__")[0] not in THIRD]
+    assert mine == ref_names
+
+
+def test_mean_n_absolute_max_quirk():
+    # settings.py:272-278 repeats the dict key, so only number_of_maxima=7 survives
+    assert settings.ComprehensiveFCParameters()["mean_n_absolute_max"] == [{"number_of_maxima": 7}]
+
+
+def test_column_name_round_trip():
+    p = settings.ComprehensiveFCParameters()
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        plan = compile_fc_parameters(p)
+    cols = ["value__" + n for n in plan.names]
+    back = settings.from_columns(cols)["value"]
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        plan2 = compile_fc_parameters(back)
+    assert sorted(plan2.names) == sorted(plan.names)
+
+
+def test_param_formatting():
+    assert convert_to_output_format({"p1": '"a"', "p2": 1}) == 'p1_""a""__p2_1'
+    assert convert_to_output_format({"b": 1, "a": "x"}) == 'a_"x"__b_1'
+    assert get_config_from_string(["k", "f", "q_0.5", 'attr_"x"']) == {"q": 0.5, "attr": "x"}
+    assert get_config_from_string(["k", "f"]) is None
+
+
+def test_unsupported_features_raise_instead_of_falling_back():
+    with pytest.raises(UnsupportedFeature):
+        compile_fc_parameters({(lambda x: 1.0): None})
+    with pytest.raises(UnsupportedFeature):
+        compile_fc_parameters({"matrix_profile": [{"threshold": 0.98, "feature": "min"}]})
+    with pytest.raises(UnsupportedFeature):
+        compile_fc_parameters({"query_similarity_count": [{"query": [1.0, 2.0, 3.0], "threshold": 0.0}]})
+    with pytest.raises(UnsupportedFeature):
+        compile_fc_parameters({"augmented_dickey_fuller": [{"attr": "teststat", "autolag": "BIC"}]})
+    with pytest.raises(AttributeError):
+        compile_fc_parameters({"not_a_calculator": None})

@@ -2,15 +2,26 @@
 // adjusted autocovariance, Levinson-Durbin PACF, conditional-OLS AR(k), augmented Dickey-Fuller with AIC lag
 // selection.  Restated from statsmodels/tsa/stattools.py (acovf, acf, pacf, levinson_durbin, adfuller, _autolag),
 // statsmodels/tsa/ar_model.py (AutoReg = OLS on lagged regressors) and statsmodels/tsa/adfvalues.py (mackinnonp).
+//
+// Both regressions have LAGGED designs: every regressor (and the target) is the same sequence s shifted by j.
+// Their normal matrix T(i, j) = sum_t s[t-i] s[t-j] therefore satisfies
+//     T(i+1, j+1) = T(i, j) + s[t0-1-i] s[t0-1-j] - s[t1-1-i] s[t1-1-j]
+// so only the first column (one wavefront reduction per lag) is summed; every other entry is an O(1) update
+// along its diagonal (one lane per diagonal).  ADF needs 2*maxlag+5 reductions instead of (maxlag+3)^2/2.
 #ifndef TSFA_FAM_AR_H
 #define TSFA_FAM_AR_H
 
 #include "tsfa_common.h"
 
-#define TSFA_AR_MAXP 32  // max regressors of any OLS solved here (ADF at n = 65536 needs 63: rejected at plan time via max_len)
+// ADF regressors at series length n: const, level, maxlag lagged differences (+ the target as "lag 0")
+TSFA_DEV int adf_maxlag_for(int n) {
+    int maxlag = (int)ceil(12.0 * pow((double)n / 100.0, 0.25));
+    const int cap = n / 2 - 1 - 1;
+    if (cap < maxlag) maxlag = cap;
+    return maxlag;
+}
 
-// Cholesky factorization G = L L^T (lower, in place in the lower triangle of G, ld = p).  Serial.  Returns false
-// if a pivot is not positive.
+// Cholesky factorization G = L L^T (lower triangle, in place, leading dimension ld).  Serial.
 TSFA_DEV bool chol_factor(double *G, int p, int ld) {
     for (int j = 0; j < p; ++j) {
         double d = G[j + j * ld];
@@ -27,84 +38,45 @@ TSFA_DEV bool chol_factor(double *G, int p, int ld) {
     return true;
 }
 TSFA_DEV void chol_solve(const double *L, int p, int ld, const double *rhs, double *x) {
-    for (int i = 0; i < p; ++i) {  // L w = rhs
+    for (int i = 0; i < p; ++i) {
         double s = rhs[i];
         for (int k = 0; k < i; ++k) s -= L[i + k * ld] * x[k];
         x[i] = s / L[i + i * ld];
     }
-    for (int i = p - 1; i >= 0; --i) {  // L^T x = w
+    for (int i = p - 1; i >= 0; --i) {
         double s = x[i];
         for (int k = i + 1; k < p; ++k) s -= L[k + i * ld] * x[k];
         x[i] = s / L[i + i * ld];
     }
 }
 
-// Regressor j of row t for the two designs used here.
-//   AR   : z_0 = 1, z_j = xc[t - j] (j = 1..k), target xc[t], rows t = k .. n-1
-//   ADF  : see adf_reg
-struct ArDesign {
-    const double *xc;
-    TSFA_MEM double reg(int j, int t) const { return j == 0 ? 1.0 : xc[t - j]; }
-};
-// ADF rows are indexed by t in [lag0, n-2] with d[t] = x[t+1] - x[t]:
-//   z_0 = 1, z_1 = xc[t] (level), z_j = d[t - (j-1)] for j >= 2, target d[t]
-struct AdfDesign {
-    const double *xc;
-    TSFA_MEM double dif(int t) const { return xc[t + 1] - xc[t]; }
-    TSFA_MEM double reg(int j, int t) const { return j == 0 ? 1.0 : (j == 1 ? xc[t] : dif(t - (j - 1))); }
-};
-
-// cooperative Gram matrix: G[a + b*ld] = sum_t z_a z_b (a >= b), g[a] = sum_t z_a y, yy = sum_t y^2
-template <class D, class Y>
-TSFA_DEV double blk_gram(const Blk &b, const D &dz, Y y, int p, int t0, int t1, double *G, int ld, double *g) {
-    for (int a = 0; a < p; ++a) {
-        for (int c = 0; c <= a; ++c) {
-            double s = 0.0;
-            for (int t = t0 + b.tid; t < t1; t += b.nt) s += dz.reg(a, t) * dz.reg(c, t);
-            s = blk_sum(b, s);
-            if (b.tid == 0) G[a + c * ld] = s;
-        }
-        double s = 0.0;
-        for (int t = t0 + b.tid; t < t1; t += b.nt) s += dz.reg(a, t) * y(t);
-        s = blk_sum(b, s);
-        if (b.tid == 0) g[a] = s;
+// Lag-product matrix of sequence s over rows t in [t0, t1):  T[i + j*ld] = sum_t s(t-i) s(t-j), 0 <= j <= i <= Lg,
+// and column sums C[j] = sum_t s(t-j).  Requires t0 >= Lg.  S(u) returns s[u].
+template <class S>
+TSFA_DEV void blk_lag_products(const Blk &b, S s, int Lg, int t0, int t1, double *T, int ld, double *C) {
+    for (int j = 0; j <= Lg; ++j) {  // first column by reduction
+        double a = 0.0;
+        for (int t = t0 + b.tid; t < t1; t += b.nt) a += s(t - j) * s(t);
+        a = blk_sum(b, a);
+        if (b.tid == 0) T[j] = a;
     }
-    double s = 0.0;
-    for (int t = t0 + b.tid; t < t1; t += b.nt) s += y(t) * y(t);
-    s = blk_sum(b, s);
+    double c0 = 0.0;
+    for (int t = t0 + b.tid; t < t1; t += b.nt) c0 += s(t);
+    c0 = blk_sum(b, c0);
+    if (b.tid == 0) {
+        C[0] = c0;
+        for (int j = 0; j < Lg; ++j) C[j + 1] = C[j] + s(t0 - 1 - j) - s(t1 - 1 - j);
+    }
     blk_sync();
-    return s;
-}
-
-// one step of iterative refinement of beta for the normal equations (L = chol factor), returns SSR of the refined fit
-template <class D, class Y>
-TSFA_DEV double blk_refine(const Blk &b, const D &dz, Y y, int p, int t0, int t1, const double *L, int ld,
-                           double *beta, double *gr, double *delta, int nrefine) {
-    for (int it = 0; it < nrefine; ++it) {
-        for (int a = 0; a < p; ++a) {
-            double s = 0.0;
-            for (int t = t0 + b.tid; t < t1; t += b.nt) {
-                double r = y(t);
-                for (int c = 0; c < p; ++c) r -= dz.reg(c, t) * beta[c];
-                s += dz.reg(a, t) * r;
-            }
-            s = blk_sum(b, s);
-            if (b.tid == 0) gr[a] = s;
+    for (int dg = b.tid; dg <= Lg; dg += b.nt) {  // one lane per diagonal i - j = dg
+        double v = T[dg];
+        for (int j = 0; dg + j + 1 <= Lg; ++j) {
+            const int i = dg + j;
+            v = v + s(t0 - 1 - i) * s(t0 - 1 - j) - s(t1 - 1 - i) * s(t1 - 1 - j);
+            T[(i + 1) + (j + 1) * ld] = v;
         }
-        blk_sync();
-        if (b.tid == 0) {
-            chol_solve(L, p, ld, gr, delta);
-            for (int a = 0; a < p; ++a) beta[a] += delta[a];
-        }
-        blk_sync();
     }
-    double s = 0.0;
-    for (int t = t0 + b.tid; t < t1; t += b.nt) {
-        double r = y(t);
-        for (int c = 0; c < p; ++c) r -= dz.reg(c, t) * beta[c];
-        s += r * r;
-    }
-    return blk_sum(b, s);
+    blk_sync();
 }
 
 // statsmodels.tsa.adfvalues.mackinnonp(teststat, regression="c", N=1)
@@ -117,35 +89,44 @@ TSFA_DEV double mackinnon_p_c1(double t) {
     return tsfa_norm_cdf(z);
 }
 
+// LDS scratch of the family, carved from `aw`:  P = max regressors + 1 (leading dimension of the matrices)
+//   T (P*P) | G (P*P) | 6 vectors of P | acv 64 | res 16 | pac 48 | arres 40 | pacw 128
+TSFA_DEV int ar_scratch_doubles(int P) { return 2 * P * P + 6 * P + 64 + 16 + 48 + 40 + 128; }
+
 // Evaluate the AR specs of one series.
-//   xc : LDS, n doubles (will hold the mean-centred series)
-//   aw : LDS, >= 2*TSFA_AR_MAXP*TSFA_AR_MAXP + 8*TSFA_AR_MAXP + 128 doubles
-TSFA_DEV void fam_ar_series(const Blk &b, const double *xs, int n, const TsfaSpec *specs, int nspecs,
-                            double *out_row, double *xc, double *aw) {
+//   xv   : sample accessor
+//   xc   : LDS, n doubles   (mean-centred series)
+//   rbuf : LDS, n doubles   (regression residuals)
+//   aw   : LDS, ar_scratch_doubles(P) doubles;  P >= max(adf_maxlag_for(n) + 3, max AR order + 2)
+template <class X>
+TSFA_DEV void fam_ar_series(const Blk &b, X xv, int n, const TsfaSpec *specs, int nspecs, double *out_row, double *xc,
+                            double *rbuf, double *aw, int P) {
     const double dn = (double)n;
     double sm = 0.0;
-    for (int i = b.tid; i < n; i += b.nt) sm += xs[i];
+    for (int i = b.tid; i < n; i += b.nt) sm += xv(i);
     const double mean = blk_sum(b, sm) / dn;
     blk_sync();
-    for (int i = b.tid; i < n; i += b.nt) xc[i] = xs[i] - mean;
+    for (int i = b.tid; i < n; i += b.nt) xc[i] = xv(i) - mean;
     blk_sync();
     double v0 = 0.0;
     for (int i = b.tid; i < n; i += b.nt) v0 += xc[i] * xc[i];
-    const double ss0 = blk_sum(b, v0);
-    const double var = ss0 / dn;
+    const double var = blk_sum(b, v0) / dn;
 
-    const int P = TSFA_AR_MAXP;
-    double *G = aw;                 // P*P
-    double *G2 = G + P * P;         // P*P
-    double *g = G2 + P * P;         // P
-    double *beta = g + P;           // P
-    double *tmp1 = beta + P;        // P
-    double *tmp2 = tmp1 + P;        // P
-    double *acv = tmp2 + P;         // 64: adjusted autocovariances
-    double *res = acv + 64;         // 16: results broadcast
-    double *pac = res + 16;         // 48
+    double *T = aw;               // lag products
+    double *G = T + P * P;        // normal matrix / Cholesky factor
+    double *g = G + P * P;        // rhs
+    double *beta = g + P;
+    double *tmp1 = beta + P;
+    double *tmp2 = tmp1 + P;
+    double *C = tmp2 + P;         // column sums
+    double *V = C + P;            // level products (ADF)
+    double *acv = V + P;          // 64
+    double *res = acv + 64;       // 16
+    double *pac = res + 16;       // 48
+    double *arres = pac + 48;     // 40: cached AR solution
+    double *pacw = arres + 40;    // 128: Levinson-Durbin columns
+    const double *xcc = xc;
 
-    // which shared pieces are needed
     int max_acf_lag = -1, max_pacf_lag = -1;
     bool need_adf = false;
     for (int s = 0; s < nspecs; ++s) {
@@ -164,10 +145,8 @@ TSFA_DEV void fam_ar_series(const Blk &b, const double *xs, int n, const TsfaSpe
     if (max_pacf_lag > 40) max_pacf_lag = 40;
 
     // ---- adjusted autocovariance acv[k] = sum_t xc[t] xc[t+k] / (n - k)  (stattools.acovf, adjusted=True) ----
-    int pacf_maxlag = 0;  // lags actually computed by pacf
-    if (max_pacf_lag >= 0 && n > 1) {
-        pacf_maxlag = (max_pacf_lag >= n / 2) ? (n / 2 - 1) : max_pacf_lag;  // fc.py:472-475
-    }
+    int pacf_maxlag = 0;
+    if (max_pacf_lag >= 0 && n > 1) pacf_maxlag = (max_pacf_lag >= n / 2) ? (n / 2 - 1) : max_pacf_lag;  // fc.py:472-475
     int nacv = -1;
     if (max_acf_lag >= 0) nacv = (max_acf_lag < n - 1) ? max_acf_lag : (n - 1);
     if (pacf_maxlag > nacv) nacv = pacf_maxlag;
@@ -185,48 +164,73 @@ TSFA_DEV void fam_ar_series(const Blk &b, const double *xs, int n, const TsfaSpe
             for (int k = 0; k <= max_pacf_lag; ++k) pac[k] = TSFA_NAN;
             if (n > 1 && pacf_maxlag > 0) {
                 const int ord = pacf_maxlag;
-                double *phi = G;  // (ord+1) x (ord+1), phi[j + k*ld]
-                const int ld = ord + 1;
-                double *sig = tmp1;
-                for (int i = 0; i < ld * ld; ++i) phi[i] = 0.0;
-                phi[1 + 1 * ld] = acv[1] / acv[0];
-                sig[1] = acv[0] - phi[1 + 1 * ld] * acv[1];
+                // only the previous column of phi is ever read: keep two rolling columns
+                double *prev = pacw, *cur = pacw + 42, *sig = pacw + 84;
+                prev[1] = acv[1] / acv[0];
+                pac[1] = prev[1];
+                sig[1] = acv[0] - prev[1] * acv[1];
                 for (int k = 2; k <= ord; ++k) {
                     double dot = 0.0;
-                    for (int j = 1; j < k; ++j) dot += phi[j + (k - 1) * ld] * acv[k - j];
-                    phi[k + k * ld] = (acv[k] - dot) / sig[k - 1];
-                    for (int j = 1; j < k; ++j)
-                        phi[j + k * ld] = phi[j + (k - 1) * ld] - phi[k + k * ld] * phi[(k - j) + (k - 1) * ld];
-                    sig[k] = sig[k - 1] * (1.0 - phi[k + k * ld] * phi[k + k * ld]);
+                    for (int j = 1; j < k; ++j) dot += prev[j] * acv[k - j];
+                    const double pkk = (acv[k] - dot) / sig[k - 1];
+                    for (int j = 1; j < k; ++j) cur[j] = prev[j] - pkk * prev[k - j];
+                    cur[k] = pkk;
+                    sig[k] = sig[k - 1] * (1.0 - pkk * pkk);
+                    pac[k] = pkk;
+                    for (int j = 1; j <= k; ++j) prev[j] = cur[j];
                 }
                 pac[0] = 1.0;
-                for (int k = 1; k <= ord; ++k) pac[k] = phi[k + k * ld];
             }
         }
         blk_sync();
     }
 
     // ---- augmented Dickey-Fuller, regression="c", autolag="AIC" (stattools.adfuller) ----
+    // rows are indexed by t with d[t] = x[t+1] - x[t]; regressors: 1, x[t] (level), d[t-1..t-maxlag]; target d[t]
     double adf_stat = TSFA_NAN, adf_p = TSFA_NAN, adf_lag = TSFA_NAN;
     if (need_adf) {
-        int maxlag = (int)ceil(12.0 * pow(dn / 100.0, 0.25));
-        const int cap = n / 2 - 1 - 1;
-        if (cap < maxlag) maxlag = cap;
-        if (maxlag >= 0 && maxlag + 2 <= P) {
-            AdfDesign dz{xc};
-            const double *xcc = xc;
-            auto yv = [=](int t) { return xcc[t + 1] - xcc[t]; };
-            // step 1: all nested fits on rows t = maxlag .. n-2 from one Cholesky factorization
-            const int p1 = maxlag + 2;
+        const int maxlag = adf_maxlag_for(n);
+        if (maxlag >= 0 && maxlag + 3 <= P) {
+            auto dif = [=](int t) { return xcc[t + 1] - xcc[t]; };
             const int t0 = maxlag, t1 = n - 1;
             const double nobs = (double)(t1 - t0);
-            const double yy = blk_gram(b, dz, yv, p1, t0, t1, G, P, g);
+            // lag products of d (lag 0 = the target) and level products
+            blk_lag_products(b, dif, maxlag, t0, t1, T, P, C);
+            for (int j = 0; j <= maxlag; ++j) {
+                double a = 0.0;
+                for (int t = t0 + b.tid; t < t1; t += b.nt) a += xcc[t] * dif(t - j);
+                a = blk_sum(b, a);
+                if (b.tid == 0) V[j] = a;
+            }
+            double sx = 0.0, sxx = 0.0;
+            for (int t = t0 + b.tid; t < t1; t += b.nt) { sx += xcc[t]; sxx += xcc[t] * xcc[t]; }
+            sx = blk_sum(b, sx);
+            sxx = blk_sum(b, sxx);
+            blk_sync();
+            // assemble the normal matrix in the autolag column order [const, level, d-lag1 .. d-lag maxlag]
+            const int p1 = maxlag + 2;
+            for (int e = b.tid; e < p1 * p1; e += b.nt) {
+                const int a = e % p1, c = e / p1;
+                if (c > a) continue;
+                double v;
+                if (a == 0) v = nobs;
+                else if (a == 1) v = (c == 0) ? sx : sxx;
+                else {
+                    const int la = a - 1;
+                    if (c == 0) v = C[la];
+                    else if (c == 1) v = V[la];
+                    else v = T[la + (c - 1) * P];
+                }
+                G[a + c * P] = v;
+            }
+            for (int a = b.tid; a < p1; a += b.nt) g[a] = (a == 0) ? C[0] : (a == 1 ? V[0] : T[a - 1]);
+            blk_sync();
+            const double yy = T[0];
             if (b.tid == 0) {
                 int best = -1;
                 double best_aic = 0.0;
-                const bool ok = chol_factor(G, p1, P);
-                if (ok) {
-                    // w = L^-1 g ;  SSR_p = yy - sum_{i<p} w_i^2
+                if (chol_factor(G, p1, P)) {
+                    // all nested fits from one factorization: w = L^-1 g, SSR_p = yy - sum_{i<p} w_i^2
                     double acc = 0.0;
                     for (int i = 0; i < p1; ++i) {
                         double s = g[i];
@@ -236,13 +240,9 @@ TSFA_DEV void fam_ar_series(const Blk &b, const double *xs, int n, const TsfaSpe
                         const int pcols = i + 1;
                         if (pcols >= 2) {
                             const double ssr = yy - acc;
-                            // OLS.aic = -2 llf + 2 k,  llf = -nobs/2 (log(2 pi) + log(ssr/nobs) + 1)
                             const double llf = -0.5 * nobs * log(2.0 * M_PI) - 0.5 * nobs * log(ssr / nobs) - 0.5 * nobs;
                             const double aic = -2.0 * llf + 2.0 * (double)pcols;
-                            if (best < 0 || aic < best_aic) {
-                                best = pcols;
-                                best_aic = aic;
-                            }
+                            if (best < 0 || aic < best_aic) { best = pcols; best_aic = aic; }
                         }
                     }
                 }
@@ -253,28 +253,79 @@ TSFA_DEV void fam_ar_series(const Blk &b, const double *xs, int n, const TsfaSpe
             blk_sync();
             if (bestcols >= 2) {
                 const int usedlag = bestcols - 2;
-                // step 2: final regression on rows t = usedlag .. n-2
                 const int p2 = usedlag + 2;
-                const int u0 = usedlag, u1 = n - 1;
-                const double nobs2 = (double)(u1 - u0);
-                blk_gram(b, dz, yv, p2, u0, u1, G2, P, g);
+                const int u0 = usedlag;
+                const double nobs2 = (double)(t1 - u0);
+                // final design [level, d-lag1..usedlag, const] over rows [usedlag, n-1): the autolag matrix restricted
+                // to those columns plus the rows t in [usedlag, maxlag) that the first regression had trimmed
+                auto reg2 = [=](int a, int t) { return a == 0 ? xcc[t] : (a == p2 - 1 ? 1.0 : dif(t - a)); };
+                for (int e = b.tid; e < p2 * p2 + p2; e += b.nt) {
+                    const bool is_rhs = e >= p2 * p2;
+                    const int a = is_rhs ? e - p2 * p2 : e % p2;
+                    const int c = is_rhs ? 0 : e / p2;
+                    if (!is_rhs && c > a) continue;
+                    double v;
+                    // base value from the maxlag-row sums (same quantity, autolag ordering)
+                    auto lagidx = [=](int q) { return q == 0 ? -2 : (q == p2 - 1 ? -1 : q); };  // -2 level, -1 const
+                    const int A = lagidx(a), Cc = is_rhs ? 0 : lagidx(c);
+                    if (is_rhs) {
+                        v = (A == -2) ? V[0] : (A == -1 ? C[0] : T[A]);
+                    } else {
+                        const int hi = a, lo = c;  // a >= c in final ordering; map each unordered pair
+                        (void)hi; (void)lo;
+                        if (A == -1 && Cc == -1) v = nobs;
+                        else if ((A == -1 && Cc == -2) || (A == -2 && Cc == -1)) v = sx;
+                        else if (A == -2 && Cc == -2) v = sxx;
+                        else if (A == -1) v = C[Cc];
+                        else if (Cc == -1) v = C[A];
+                        else if (A == -2) v = V[Cc];
+                        else if (Cc == -2) v = V[A];
+                        else v = (A >= Cc) ? T[A + Cc * P] : T[Cc + A * P];
+                    }
+                    for (int t = u0; t < t0; ++t) v += reg2(a, t) * (is_rhs ? dif(t) : reg2(c, t));
+                    if (is_rhs) g[a] = v; else G[a + c * P] = v;
+                }
+                blk_sync();
                 if (b.tid == 0) {
-                    const bool ok = chol_factor(G2, p2, P);
+                    const bool ok = chol_factor(G, p2, P);
                     res[1] = ok ? 1.0 : 0.0;
-                    if (ok) chol_solve(G2, p2, P, g, beta);
+                    if (ok) chol_solve(G, p2, P, g, beta);
                 }
                 blk_sync();
                 const bool ok2 = res[1] != 0.0;
                 blk_sync();
                 if (ok2) {
-                    const double ssr = blk_refine(b, dz, yv, p2, u0, u1, G2, P, beta, tmp1, tmp2, 1);
+                    // one step of iterative refinement on the true residuals, then SSR
+                    for (int t = u0 + b.tid; t < t1; t += b.nt) {
+                        double r = dif(t);
+                        for (int c = 0; c < p2; ++c) r -= reg2(c, t) * beta[c];
+                        rbuf[t] = r;
+                    }
+                    blk_sync();
+                    for (int a = 0; a < p2; ++a) {
+                        double s = 0.0;
+                        for (int t = u0 + b.tid; t < t1; t += b.nt) s += reg2(a, t) * rbuf[t];
+                        s = blk_sum(b, s);
+                        if (b.tid == 0) tmp1[a] = s;
+                    }
+                    blk_sync();
                     if (b.tid == 0) {
-                        // (X'X)^-1 [level, level]: solve G u = e_1
-                        for (int i = 0; i < p2; ++i) tmp1[i] = (i == 1) ? 1.0 : 0.0;
-                        chol_solve(G2, p2, P, tmp1, tmp2);
+                        chol_solve(G, p2, P, tmp1, tmp2);
+                        for (int a = 0; a < p2; ++a) beta[a] += tmp2[a];
+                    }
+                    blk_sync();
+                    double ssr = 0.0;
+                    for (int t = u0 + b.tid; t < t1; t += b.nt) {
+                        double r = dif(t);
+                        for (int c = 0; c < p2; ++c) r -= reg2(c, t) * beta[c];
+                        ssr += r * r;
+                    }
+                    ssr = blk_sum(b, ssr);
+                    if (b.tid == 0) {
+                        for (int i = 0; i < p2; ++i) tmp1[i] = (i == 0) ? 1.0 : 0.0;  // (X'X)^-1 [level, level]
+                        chol_solve(G, p2, P, tmp1, tmp2);
                         const double sigma2 = ssr / (nobs2 - (double)p2);
-                        const double se = sqrt(sigma2 * tmp2[1]);
-                        const double tstat = beta[1] / se;
+                        const double tstat = beta[0] / sqrt(sigma2 * tmp2[0]);
                         res[2] = tstat;
                         res[3] = mackinnon_p_c1(tstat);
                         res[4] = (double)usedlag;
@@ -290,13 +341,15 @@ TSFA_DEV void fam_ar_series(const Blk &b, const double *xs, int n, const TsfaSpe
         }
     }
 
+    int ar_cached_k = -1;
+    bool ar_ok = false;
     for (int s = 0; s < nspecs; ++s) {
         const TsfaSpec sp = specs[s];
         double v = TSFA_NAN;
         switch (sp.calc) {
         case TSFA_C_AGG_AUTOCORRELATION: {                               // fc.py:387
             const int agg = (int)sp.p[0];
-            int ml = (int)sp.p[1];
+            const int ml = (int)sp.p[1];
             double r = TSFA_NAN;
             if (b.tid == 0) {
                 if (fabs(var) < 1e-10 || n == 1) {
@@ -304,7 +357,7 @@ TSFA_DEV void fam_ar_series(const Blk &b, const double *xs, int n, const TsfaSpe
                 } else {
                     int len = (ml < n - 1) ? ml : (n - 1);  // a = acf[1:], a[:maxlag]
                     if (len > 60) len = 60;
-                    double *a = tmp1;  // <= 60 entries spill into tmp2.. (contiguous)
+                    double *a = rbuf;
                     for (int k = 0; k < len; ++k) a[k] = acv[k + 1] / acv[0];
                     if (len <= 0) {
                         r = TSFA_NAN;
@@ -317,10 +370,7 @@ TSFA_DEV void fam_ar_series(const Blk &b, const double *xs, int n, const TsfaSpe
                         for (int i = 1; i < len; ++i) {
                             const double key = a[i];
                             int j = i - 1;
-                            while (j >= 0 && a[j] > key) {
-                                a[j + 1] = a[j];
-                                --j;
-                            }
+                            while (j >= 0 && a[j] > key) { a[j + 1] = a[j]; --j; }
                             a[j + 1] = key;
                         }
                         r = (len & 1) ? a[(len - 1) / 2] : (0.0 + a[len / 2 - 1] + a[len / 2]) / 2.0;
@@ -335,41 +385,67 @@ TSFA_DEV void fam_ar_series(const Blk &b, const double *xs, int n, const TsfaSpe
         } break;
         case TSFA_C_AUGMENTED_DICKEY_FULLER: {                           // fc.py:499
             const int attr = (int)sp.p[0];
-            v = (attr == TSFA_ADF_TESTSTAT) ? adf_stat : (attr == TSFA_ADF_PVALUE ? adf_p : adf_lag);
+            v = (attr == TSFA_ADF_TESTSTAT) ? adf_stat : (attr == TSFA_ADF_PVALUE ? adf_p : (attr == TSFA_ADF_USEDLAG ? adf_lag : TSFA_NAN));
         } break;
         case TSFA_C_AR_COEFFICIENT: {                                    // fc.py:1459
             const int coeff = (int)sp.p[0], k = (int)sp.p[1];
             if (coeff > k) { v = TSFA_NAN; break; }
             // AutoReg(x, lags=k, trend="c") can only be estimated with n >= 2k + 2; on failure the reference
             // substitutes [nan]*k, so coeff < k -> NaN and coeff == k -> IndexError -> 0
-            if (n < 2 * k + 2 || k + 1 > P || k < 1) {
+            if (n < 2 * k + 2 || k + 2 > P || k < 1 || k + 1 > 40) {
                 v = (coeff < k) ? TSFA_NAN : 0.0;
                 break;
             }
-            ArDesign dz{xc};
-            const double *xcc = xc;
-            auto yv = [=](int t) { return xcc[t]; };
-            const int p = k + 1;
-            blk_gram(b, dz, yv, p, k, n, G, P, g);
-            if (b.tid == 0) {
-                const bool ok = chol_factor(G, p, P);
-                res[1] = ok ? 1.0 : 0.0;
-                if (ok) chol_solve(G, p, P, g, beta);
+            if (ar_cached_k != k) {
+                // regressors: const, xc[t-1..t-k]; target xc[t]; rows t in [k, n)
+                auto sx = [=](int u) { return xcc[u]; };
+                blk_lag_products(b, sx, k, k, n, T, P, C);
+                const int p = k + 1;
+                for (int e = b.tid; e < p * p; e += b.nt) {
+                    const int a = e % p, c = e / p;
+                    if (c > a) continue;
+                    G[a + c * P] = (a == 0) ? (double)(n - k) : (c == 0 ? C[a] : T[a + c * P]);
+                }
+                for (int a = b.tid; a < p; a += b.nt) g[a] = (a == 0) ? C[0] : T[a];
+                blk_sync();
+                if (b.tid == 0) {
+                    const bool ok = chol_factor(G, p, P);
+                    res[1] = ok ? 1.0 : 0.0;
+                    if (ok) chol_solve(G, p, P, g, beta);
+                }
+                blk_sync();
+                ar_ok = res[1] != 0.0;
+                blk_sync();
+                if (ar_ok) {
+                    auto reg = [=](int a, int t) { return a == 0 ? 1.0 : xcc[t - a]; };
+                    for (int t = k + b.tid; t < n; t += b.nt) {
+                        double r = xcc[t];
+                        for (int c = 0; c < p; ++c) r -= reg(c, t) * beta[c];
+                        rbuf[t] = r;
+                    }
+                    blk_sync();
+                    for (int a = 0; a < p; ++a) {
+                        double sacc = 0.0;
+                        for (int t = k + b.tid; t < n; t += b.nt) sacc += reg(a, t) * rbuf[t];
+                        sacc = blk_sum(b, sacc);
+                        if (b.tid == 0) tmp1[a] = sacc;
+                    }
+                    blk_sync();
+                    if (b.tid == 0) {
+                        chol_solve(G, p, P, tmp1, tmp2);
+                        double sphi = 0.0;
+                        for (int a = 0; a < p; ++a) {
+                            beta[a] += tmp2[a];
+                            if (a > 0) sphi += beta[a];
+                        }
+                        arres[0] = beta[0] + mean * (1.0 - sphi);  // undo the centring of the constant
+                        for (int a = 1; a < p; ++a) arres[a] = beta[a];
+                    }
+                    blk_sync();
+                }
+                ar_cached_k = k;
             }
-            blk_sync();
-            const bool ok = res[1] != 0.0;
-            blk_sync();
-            if (!ok) { v = TSFA_NAN; break; }
-            blk_refine(b, dz, yv, p, k, n, G, P, beta, tmp1, tmp2, 1);
-            if (coeff == 0) {
-                // undo the centring: const = c~ + mean (1 - sum phi)
-                double sphi = 0.0;
-                for (int j = 1; j <= k; ++j) sphi += beta[j];
-                v = beta[0] + mean * (1.0 - sphi);
-            } else {
-                v = beta[coeff];
-            }
-            blk_sync();
+            v = ar_ok ? arres[coeff] : TSFA_NAN;
         } break;
         default: break;
         }

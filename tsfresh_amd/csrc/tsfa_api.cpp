@@ -304,6 +304,20 @@ int tsfa_extract(tsfa_plan *plan, const void *values, int32_t dtype, const int64
                 a.gscratch = (double *)plan->gscratch.p;
             }
             aux = a.dft_n;
+        } else if (f == TSFA_FAM_AR) {
+            // leading dimension of the normal matrices: ADF needs maxlag(n) + 3, AR(k) needs k + 2
+            int P = 8;
+            for (const auto &s : plan->fam_specs[f]) {
+                if (s.calc == TSFA_C_AUGMENTED_DICKEY_FULLER) {
+                    int ml = (int)ceil(12.0 * pow((double)maxn / 100.0, 0.25));
+                    if (maxn / 2 - 2 < ml) ml = maxn / 2 - 2;
+                    P = std::max(P, ml + 3);
+                } else if (s.calc == TSFA_C_AR_COEFFICIENT) {
+                    P = std::max(P, (int)s.p[1] + 2);
+                }
+            }
+            a.ar_P = P;
+            aux = P;
         } else if (f == TSFA_FAM_SEQ) {
             int ntab = a.nspecs;
             while (ntab > 1 && tsfa_family_lds_bytes(f, maxn, nt, ntab) > TSFA_LDS_LIMIT) --ntab;

@@ -72,16 +72,17 @@ __global__ void k_spectral(const T *__restrict__ values, const int64_t *__restri
 
 template <typename T>
 __global__ void k_ar(const T *__restrict__ values, const int64_t *__restrict__ offsets, int64_t n_series,
-                     const TsfaSpec *__restrict__ specs, int nspecs, double *__restrict__ out, int64_t ld, int maxn) {
+                     const TsfaSpec *__restrict__ specs, int nspecs, double *__restrict__ out, int64_t ld, int maxn,
+                     int P) {
     const int64_t sidx = blockIdx.x;
     if (sidx >= n_series) return;
     const int64_t off = offsets[sidx];
     const int n = (int)(offsets[sidx + 1] - off);
     ArLds L;
-    L.carve(tsfa_smem, maxn, blockDim.x);
+    L.carve(tsfa_smem, maxn, P);
     Blk b{(int)threadIdx.x, (int)blockDim.x, L.red, nullptr};
-    stage_series(b, values + off, n, L.xs);
-    fam_ar_series(b, L.xs, n, specs, nspecs, out + sidx * ld, L.xc, L.aw);
+    const T *g = values + off;
+    fam_ar_series(b, [=](int i) { return (double)g[i]; }, n, specs, nspecs, out + sidx * ld, L.xc, L.rbuf, L.aw, P);
 }
 
 template <typename T>
@@ -169,7 +170,8 @@ k_cwt_gemm(const T *__restrict__ values, const int64_t *__restrict__ offsets, in
             acc[ct] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, bv, acc[ct], 0, 0, 0);
         }
     }
-    // D[i = 4*kq + v][j = r]
+    // D[i = 4*v + kq][j = r]: the f64 16x16x4 accumulator interleaves rows across the four 16-lane groups
+    // (composable_kernel xdlops_gemm.hpp mfma_f64_16x16x4f64: group_size 1, 4 groups), unlike the f32 shapes
 #pragma unroll
     for (int ct = 0; ct < CT; ++ct) {
         const int c = ct * 16 + r;
@@ -177,7 +179,7 @@ k_cwt_gemm(const T *__restrict__ values, const int64_t *__restrict__ offsets, in
         const int col = cols[c], ci = coeff_idx[c];
 #pragma unroll
         for (int v = 0; v < 4; ++v) {
-            const int i = 4 * kq + v;
+            const int i = 4 * v + kq;
             const int64_t srow = (int64_t)blockIdx.x * 16 + i;
             if (srow < n_series) out[srow * ld + col] = (ci < lens[i]) ? acc[ct][v] : TSFA_NAN;
         }
@@ -248,9 +250,9 @@ static int launch_all_t(const TsfaLaunch &a, const T *values) {
                                              a.dft_n, a.gscratch, a.gscratch_n, a.twc, a.tws);
     } else if (a.fam == TSFA_FAM_AR) {
         ArLds L;
-        const size_t lds = L.carve(nullptr, a.maxn, nt);
+        const size_t lds = L.carve(nullptr, a.maxn, a.ar_P);
         if ((rc = set_lds(k_ar<T>, lds))) return rc;
-        k_ar<T><<<grid, nt, lds, st>>>(values, a.offsets, a.n_series, a.specs, a.nspecs, a.out, a.ld, a.maxn);
+        k_ar<T><<<grid, nt, lds, st>>>(values, a.offsets, a.n_series, a.specs, a.nspecs, a.out, a.ld, a.maxn, a.ar_P);
     } else if (a.fam == TSFA_FAM_ENTROPY) {
         EntropyLds L;
         const size_t lds = L.carve(nullptr, a.maxn, nt);
@@ -278,7 +280,7 @@ size_t tsfa_family_lds_bytes(int fam, int maxn, int nt, int aux) {
     case TSFA_FAM_BASIC: { BasicLds L; return L.carve(nullptr, maxn, nt); }
     case TSFA_FAM_SORT: { SortLds L; return L.carve(nullptr, maxn, nt); }
     case TSFA_FAM_SPECTRAL: { SpectralLds L; return L.carve(nullptr, maxn, aux); }
-    case TSFA_FAM_AR: { ArLds L; return L.carve(nullptr, maxn, nt); }
+    case TSFA_FAM_AR: { ArLds L; return L.carve(nullptr, maxn, aux); }
     case TSFA_FAM_ENTROPY: { EntropyLds L; return L.carve(nullptr, maxn, nt); }
     case TSFA_FAM_SEQ: { SeqLds L; return L.carve(nullptr, maxn, aux); }
     case TSFA_FAM_CWT: { CwtPeaksLayout L; return L.carve(nullptr, maxn, nt); }

@@ -27,6 +27,7 @@ struct TsfaLaunch {
     double *gscratch;       // SPECTRAL: HBM twiddle scratch for long non-pow2 series (or null)
     int gscratch_n;
     int ntab;               // SEQ: concurrent parse tables
+    int ar_P;               // AR: leading dimension of the normal matrices
 };
 
 struct TsfaCwtLaunch {

@@ -83,16 +83,16 @@ struct SpectralLds {
     }
 };
 
-#define TSFA_AR_AW_DOUBLES 2560
 struct ArLds {
-    double *red; double *xs; double *xc; double *aw;
-    TSFA_HD size_t carve(unsigned char *base, int maxn, int nt) {
-        (void)nt;
+    double *red; double *xc; double *rbuf; double *aw;
+    // P: leading dimension of the normal matrices = (max regressors) + 1, chosen by the host for the batch
+    TSFA_HD static int scratch_doubles(int P) { return 2 * P * P + 6 * P + 64 + 16 + 48 + 40 + 128; }
+    TSFA_HD size_t carve(unsigned char *base, int maxn, int P) {
         LdsCarve c{base, 0};
         red = c.take<double>(TSFA_RED_DOUBLES);
-        xs = c.take<double>(maxn);
-        xc = c.take<double>(maxn);
-        aw = c.take<double>(TSFA_AR_AW_DOUBLES);
+        xc = c.take<double>(maxn + 2);
+        rbuf = c.take<double>(maxn + 2);
+        aw = c.take<double>(scratch_doubles(P));
         return c.off;
     }
 };
