@@ -1,0 +1,57 @@
+"""world_size-2 gloo test of the id-sharding + all-gather path (runs on CPU; the per-shard extraction is the emulated
+kernel build, the collective code is exactly what the GPU path uses)."""
+import os
+import subprocess
+import sys
+
+import numpy as np
+
+from tsfresh_amd.distributed import shard_bounds
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+WORKER = r'''
+import os, sys, numpy as np
+sys.path.insert(0, os.path.join(%(here)r, ".."))
+sys.path.insert(0, %(here)r)
+import torch, torch.distributed as dist
+from tsfresh_amd.distributed import extract_sharded
+from tsfresh_amd.feature_extraction.settings import MinimalFCParameters
+from emul_lib import emul_extract
+dist.init_process_group(backend="gloo")
+rng = np.random.default_rng(0)
+lens = rng.integers(1, 60, size=23)
+values = rng.standard_normal(int(lens.sum()))
+offsets = np.zeros(len(lens) + 1, dtype=np.int64); np.cumsum(lens, out=offsets[1:])
+params = MinimalFCParameters()
+fn = lambda v, o: emul_extract(params, v, o)[1]
+full = extract_sharded(fn, values, offsets, 10, dist=dist)
+ref = fn(values, offsets)
+assert full.shape == ref.shape and np.array_equal(full, ref), (full.shape, ref.shape)
+if dist.get_rank() == 0:
+    print("GLOO_OK", full.shape)
+dist.destroy_process_group()
+'''
+
+
+def test_shard_bounds_balance_and_cover():
+    lens = np.array([10, 10, 10, 100, 10, 10, 10, 10])
+    b = shard_bounds(lens, 2)
+    assert b[0] == 0 and b[-1] == len(lens) and np.all(np.diff(b) >= 0)
+    # the long series dominates sum(len^2): it must not share a shard with everything else
+    cost = lens.astype(float) ** 2
+    parts = [cost[b[i]:b[i + 1]].sum() for i in range(2)]
+    assert max(parts) <= 0.999 * cost.sum()
+    assert list(shard_bounds(np.ones(8), 4)) == [0, 2, 4, 6, 8]
+    assert list(shard_bounds([], 3)) == [0, 0, 0, 0]
+
+
+def test_two_rank_gloo_all_gather_matches_single_process(tmp_path):
+    script = tmp_path / "worker.py"
+    script.write_text(WORKER % {"here": HERE})
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1")
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
+                          "--master-addr", "127.0.0.1", "--master-port", "29517", str(script)],
+                         capture_output=True, text=True, env=env, timeout=300)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
+    assert "GLOO_OK (23, 10)" in out.stdout
