@@ -78,16 +78,15 @@ extern "C" int tsfa_emul_extract(const tsfa_feature_spec *specs, int n_specs, co
         std::vector<double> xs(x, x + n);
         xs.resize(n + 8, 0.0);
         if (!fam[TSFA_FAM_BASIC].empty()) {
-            std::vector<double> w(maxn + 8);
+            std::vector<double> w(maxn + 8), cum(maxn + 8), altc(8 * 16);
             std::vector<int> iw(512);
             fam_basic_series(b, xs.data(), n, fam[TSFA_FAM_BASIC].data(), (int)fam[TSFA_FAM_BASIC].size(), row, w.data(),
-                             iw.data(), dectab.data());
+                             (s % 2) ? w.data() : cum.data(), altc.data(), iw.data(), dectab.data());
         }
         if (!fam[TSFA_FAM_SORT].empty()) {
-            std::vector<double> srt(tsfa_pow2_ceil(maxn) + 8), w(768);
-            std::vector<int> iw(5040);
+            std::vector<double> srt(tsfa_pow2_ceil(maxn) + 8), w(1280);
             fam_sort_series(b, xs.data(), n, fam[TSFA_FAM_SORT].data(), (int)fam[TSFA_FAM_SORT].size(), row, srt.data(),
-                            w.data(), iw.data());
+                            w.data(), (int *)w.data());
         }
         if (!fam[TSFA_FAM_SPECTRAL].empty()) {
             const int nx = (maxn / 2 + 2 > 260) ? maxn / 2 + 2 : 260;
@@ -115,20 +114,23 @@ extern "C" int tsfa_emul_extract(const tsfa_feature_spec *specs, int n_specs, co
                                thr.data());
         }
         if (!fam[TSFA_FAM_SEQ].empty()) {
-            const int ntab = 2;
-            const int cap = SeqLds::table_cap(maxn);
-            std::vector<unsigned char> seq((size_t)ntab * maxn + 8);
-            std::vector<uint32_t> tab((size_t)ntab * cap);
+            const int group = 2;  // exercise the multi-round path
+            int tab_entries = 0, edge_doubles = 0;
+            lz_group_budget(fam[TSFA_FAM_SEQ].data(), (int)fam[TSFA_FAM_SEQ].size(), group, maxn, &tab_entries, &edge_doubles);
+            std::vector<unsigned char> seq((size_t)group * maxn + 16);
+            std::vector<uint32_t> tab((size_t)tab_entries + 4);
+            std::vector<double> edges(edge_doubles + 4);
             const double *xp = xs.data();
             fam_seq_series(b, [=](int i) { return xp[i]; }, n, fam[TSFA_FAM_SEQ].data(), (int)fam[TSFA_FAM_SEQ].size(), row,
-                           seq.data(), tab.data(), ntab, cap);
+                           seq.data(), tab.data(), edges.data(), group, maxn);
         }
         if (!fam[TSFA_FAM_CWT].empty()) {
-            std::vector<unsigned char> lds(CwtPeaksLayout().carve(nullptr, maxn, 1) + 64);
+            const int with_rowv = (s % 2 == 0) ? 1 : 0;  // exercise both variants
+            std::vector<unsigned char> lds(CwtPeaksLayout().carve(nullptr, maxn, with_rowv) + 64);
             CwtPeaksLayout L;
             unsigned char *basep = lds.data();
             basep += (16 - ((uintptr_t)basep & 15)) & 15;
-            L.carve(basep, maxn, 1);
+            L.carve(basep, maxn, with_rowv);
             const double *xp = xs.data();
             fam_cwtpeaks_series(b, [=](int i) { return xp[i]; }, n, fam[TSFA_FAM_CWT].data(), (int)fam[TSFA_FAM_CWT].size(),
                                 row, L.p);

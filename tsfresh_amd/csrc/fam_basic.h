@@ -127,14 +127,20 @@ TSFA_DEV double blk_longest_run(const Blk &b, int n, P pred, int *iw) {
 
 // Evaluate the BASIC specs of one series.
 //   xs   : series as float64 in LDS, length n (n >= 1)
-//   w    : LDS work array of >= n doubles
+//   w    : LDS work array of >= n doubles (chunk aggregates)
+//   cum  : LDS, >= n doubles (cumulative |x| for index_mass_quantile); may alias w
+//   altc : LDS, >= 8 * TSFA_ALT_CACHE doubles (agg_linear_trend regression cache)
 //   iw   : LDS int array of >= max(4*nt, 128) ints
+#define TSFA_ALT_CACHE 16
 TSFA_DEV void fam_basic_series(const Blk &b, const double *xs, int n, const TsfaSpec *specs, int nspecs,
-                               double *out_row, double *w, int *iw, const double *dectab) {
+                               double *out_row, double *w, double *cum, double *altc, int *iw, const double *dectab) {
     BasicStats st;
     basic_stats(b, xs, n, st);
     const double dn = (double)n;
     const double mean = st.mean;
+    bool have_cumsum = false;
+    double imq_sabs = 0.0;
+    int alt_n = 0;
 
     for (int s = 0; s < nspecs; ++s) {
         const TsfaSpec sp = specs[s];
@@ -286,22 +292,28 @@ TSFA_DEV void fam_basic_series(const Blk &b, const double *xs, int n, const Tsfa
             v = blk_sum(b, c);
         } break;
         case TSFA_C_INDEX_MASS_QUANTILE: {                               // fc.py:1275
-            // np.cumsum is a serial accumulation; keep its order so that the >= q comparison matches
-            const double sabs = np_sum(b, n, [=](int i) { return fabs(xs[i]); });
-            double r = TSFA_NAN;
-            if (b.tid == 0 && sabs != 0.0) {
-                double acc = 0.0;
-                int idx = 0;  // np.argmax of an all-False mask is 0
-                for (int i = 0; i < n; ++i) {
-                    acc += fabs(xs[i]);
-                    if (acc / sabs >= p0) {
-                        idx = i;
-                        break;
+            if (!have_cumsum) {
+                // np.cumsum is a serial accumulation: one lane builds it once (in numpy's order, so that the >= q
+                // comparison is bit-identical), every q then scans it in parallel
+                imq_sabs = np_sum(b, n, [=](int i) { return fabs(xs[i]); });
+                blk_sync();
+                if (b.tid == 0) {
+                    double acc = 0.0;
+                    for (int i = 0; i < n; ++i) {
+                        acc += fabs(xs[i]);
+                        cum[i] = acc;
                     }
                 }
-                r = (double)(idx + 1) / dn;
+                blk_sync();
+                have_cumsum = true;
             }
-            v = blk_bcast0(b, r);
+            if (imq_sabs == 0.0) { v = TSFA_NAN; break; }
+            double first = (double)n;
+            for (int i = b.tid; i < n; i += b.nt)
+                if (cum[i] / imq_sabs >= p0) { first = (double)i; break; }
+            first = blk_min(b, first);
+            const int idx = (first < (double)n) ? (int)first : 0;  // np.argmax of an all-False mask is 0
+            v = (double)(idx + 1) / dn;
         } break;
         case TSFA_C_ENERGY_RATIO_BY_CHUNKS: {                            // fc.py:2226 (np.array_split)
             const int nseg = (int)p0, foc = (int)p1;
@@ -402,31 +414,47 @@ TSFA_DEV void fam_basic_series(const Blk &b, const double *xs, int n, const Tsfa
                 v = TSFA_NAN;
                 break;
             }
-            const int m = (n + cl - 1) / cl;
-            blk_sync();
-            for (int c = b.tid; c < m; c += b.nt) {  // fc.py:176 _aggregate_on_chunks
-                const int lo = c * cl;
-                const int hi = (lo + cl < n) ? lo + cl : n;
-                double r;
-                if (agg == TSFA_AGG_MAX) {
-                    r = xs[lo];
-                    for (int i = lo + 1; i < hi; ++i) r = fmax(r, xs[i]);
-                } else if (agg == TSFA_AGG_MIN) {
-                    r = xs[lo];
-                    for (int i = lo + 1; i < hi; ++i) r = fmin(r, xs[i]);
-                } else {
-                    const double cm = np_leaf_sum(lo, hi - lo, [=](int i) { return xs[i]; }) / (double)(hi - lo);
-                    if (agg == TSFA_AGG_MEAN) r = cm;
-                    else r = np_leaf_sum(lo, hi - lo, [=](int i) { const double d = xs[i] - cm; return d * d; }) /
-                             (double)(hi - lo);
+            // the regression of one (f_agg, chunk_len) pair serves all its attr columns: small LDS cache
+            int slot = -1;
+            for (int k = 0; k < alt_n; ++k)
+                if (altc[8 * k] == (double)agg && altc[8 * k + 1] == (double)cl) slot = k;
+            if (slot < 0) {
+                const int m = (n + cl - 1) / cl;
+                have_cumsum = false;  // w may alias cum
+                blk_sync();
+                for (int c = b.tid; c < m; c += b.nt) {  // fc.py:176 _aggregate_on_chunks
+                    const int lo = c * cl;
+                    const int hi = (lo + cl < n) ? lo + cl : n;
+                    double r;
+                    if (agg == TSFA_AGG_MAX) {
+                        r = xs[lo];
+                        for (int i = lo + 1; i < hi; ++i) r = fmax(r, xs[i]);
+                    } else if (agg == TSFA_AGG_MIN) {
+                        r = xs[lo];
+                        for (int i = lo + 1; i < hi; ++i) r = fmin(r, xs[i]);
+                    } else {
+                        const double cm = np_leaf_sum(lo, hi - lo, [=](int i) { return xs[i]; }) / (double)(hi - lo);
+                        if (agg == TSFA_AGG_MEAN) r = cm;
+                        else r = np_leaf_sum(lo, hi - lo, [=](int i) { const double d = xs[i] - cm; return d * d; }) /
+                                 (double)(hi - lo);
+                    }
+                    w[c] = r;
                 }
-                w[c] = r;
+                blk_sync();
+                double o5[5];
+                const double *wc = w;
+                blk_linregress_index(b, m, [=](int i) { return wc[i]; }, o5);
+                slot = (alt_n < TSFA_ALT_CACHE) ? alt_n : (TSFA_ALT_CACHE - 1);
+                blk_sync();
+                if (b.tid == 0) {
+                    altc[8 * slot] = (double)agg;
+                    altc[8 * slot + 1] = (double)cl;
+                    for (int k = 0; k < 5; ++k) altc[8 * slot + 2 + k] = o5[k];
+                }
+                blk_sync();
+                if (alt_n < TSFA_ALT_CACHE) ++alt_n;
             }
-            blk_sync();
-            double o5[5];
-            const double *wc = w;
-            blk_linregress_index(b, m, [=](int i) { return wc[i]; }, o5);
-            v = o5[attr];
+            v = altc[8 * slot + 2 + attr];
         } break;
         case TSFA_C_QUERY_SIMILARITY_COUNT:                              // fc.py:2475 with query=None
             v = TSFA_NAN;

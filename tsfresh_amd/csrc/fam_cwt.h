@@ -2,9 +2,12 @@
 //   len(scipy.signal.find_peaks_cwt(x, widths=1..n, wavelet=_ricker))
 // restated from scipy/signal/_peak_finding.py (find_peaks_cwt, _identify_ridge_lines, _filter_ridge_lines,
 // _boolrelextrema), scipy/signal/_wavelets.py (_cwt) and fc.py:1307 (_ricker).
-//   phase A (all lanes)   : CWT rows by direct convolution with the Ricker taps, relative-maximum bit mask per column
-//   phase B (one lane)    : ridge-line linking, O(rows * n) with a column -> line map (the reference is O(lines^2))
-//   phase C (lane = line) : length / signal-to-noise filter (10th percentile of the width-1 row in a window)
+//   phase A : CWT rows by direct convolution with the Ricker taps (one column per lane), relative-maximum bit mask
+//   phase B : ridge-line linking, one row at a time, every step parallel over columns / lines:
+//               snapshot of the live lines' last columns (column -> line map), each maximum looks up its nearest
+//               line in the snapshot, new lines get indices in ascending column order (ballot prefix), then every
+//               line collects the maxima that chose it.  The reference's algorithm is sequential and O(lines^2).
+//   phase C : length / signal-to-noise filter, lane = line (10th percentile of the width-1 row in a window)
 // The cwt_coefficients contraction is a separate MFMA kernel (tsfa_kernels.hip: k_cwt_gemm).
 #ifndef TSFA_FAM_CWT_H
 #define TSFA_FAM_CWT_H
@@ -31,30 +34,51 @@ TSFA_DEV double conv_same_at(X xv, int n, const double *h, int nw, int c) {
     const int m = c + (nw - 1) / 2;
     int k0 = m - (n - 1);
     if (k0 < 0) k0 = 0;
-    int k1 = (m < nw - 1) ? m : (nw - 1);
+    const int k1 = (m < nw - 1) ? m : (nw - 1);
     double acc = 0.0;
-    // numpy's correlate kernel accumulates in increasing data index: x[j] * h[m - j]
     for (int k = k1; k >= k0; --k) acc += xv(m - k) * h[k];
     return acc;
 }
 
 struct CwtPeaksLds {
-    double *red; double *row0; double *taps; unsigned short *mask; unsigned short *lcol; unsigned short *linf;
-    unsigned short *colmap; int *misc;
+    double *red; double *row0; double *rowv; double *taps; unsigned short *mask; unsigned short *lcol;
+    unsigned short *linf; unsigned short *colmap; unsigned short *mline; int *misc;
 };
 
-// linf packing
+// linf packing: length (6 bits, saturating), gap (2 bits), retired flag, last row (4 bits)
 #define TSFA_LI_LEN(v) ((v) & 63)
 #define TSFA_LI_GAP(v) (((v) >> 6) & 3)
 #define TSFA_LI_DEAD(v) (((v) >> 8) & 1)
 #define TSFA_LI_ROW(v) (((v) >> 9) & 15)
 #define TSFA_LI_PACK(len, gap, dead, row) ((unsigned short)(((len) & 63) | (((gap) & 3) << 6) | (((dead) & 1) << 8) | (((row) & 15) << 9)))
 
+// value of rank i0 and i0 + 1 (0-based, ascending) among v(0..m-1); i0 + 1 < 8: running list of the 8 smallest
+template <class V>
+TSFA_DEV void smallest8_select(V v, int m, int i0, double *s0, double *s1) {
+    double t0 = TSFA_INF, t1 = TSFA_INF, t2 = TSFA_INF, t3 = TSFA_INF, t4 = TSFA_INF, t5 = TSFA_INF, t6 = TSFA_INF,
+           t7 = TSFA_INF;
+    for (int a = 0; a < m; ++a) {
+        double e = v(a);
+        if (!(e < t7)) continue;
+        double u;
+#define TSFA_CSWAP(t) u = fmin(t, e); e = fmax(t, e); t = u;
+        TSFA_CSWAP(t0) TSFA_CSWAP(t1) TSFA_CSWAP(t2) TSFA_CSWAP(t3) TSFA_CSWAP(t4) TSFA_CSWAP(t5) TSFA_CSWAP(t6) TSFA_CSWAP(t7)
+#undef TSFA_CSWAP
+    }
+    const double arr[8] = {t0, t1, t2, t3, t4, t5, t6, t7};
+    double a0 = t0, a1 = t1;
+#pragma unroll
+    for (int k = 0; k < 7; ++k)
+        if (k == i0) { a0 = arr[k]; a1 = arr[k + 1]; }
+    *s0 = a0;
+    *s1 = a1;
+}
+
 template <class X>
 TSFA_DEV double number_cwt_peaks_one(const Blk &b, X xv, int n, int W, const CwtPeaksLds &L) {
     const int cap = n;  // line capacity
     blk_sync();
-    for (int c = b.tid; c < n; c += b.nt) { L.mask[c] = 0; L.colmap[c] = 0; }
+    for (int c = b.tid; c < n; c += b.nt) { L.mask[c] = 0; L.colmap[c] = 0; L.mline[c] = 0; }
     blk_sync();
     // ---- phase A ----
     for (int w = 1; w <= W; ++w) {
@@ -63,97 +87,107 @@ TSFA_DEV double number_cwt_peaks_one(const Blk &b, X xv, int n, int W, const Cwt
         for (int k = b.tid; k < nw; k += b.nt) L.taps[k] = ricker_tap(nw, (double)w, nw - 1 - k);  // reversed
         blk_sync();
         const double *h = L.taps;
-        for (int c = b.tid; c < n; c += b.nt) {
-            const double v = conv_same_at(xv, n, h, nw, c);
-            if (w == 1) L.row0[c] = v;
-            if (c > 0 && c < n - 1) {
-                const double vl = conv_same_at(xv, n, h, nw, c - 1);
-                const double vr = conv_same_at(xv, n, h, nw, c + 1);
-                if (v > vl && v > vr) L.mask[c] |= (unsigned short)(1u << (w - 1));
+        double *dst = (w == 1) ? L.row0 : L.rowv;
+        if (dst != nullptr) {
+            for (int c = b.tid; c < n; c += b.nt) dst[c] = conv_same_at(xv, n, h, nw, c);
+            blk_sync();
+            for (int c = 1 + b.tid; c < n - 1; c += b.nt)  // _boolrelextrema(order=1, mode="clip"): strict, never at the ends
+                if (dst[c] > dst[c - 1] && dst[c] > dst[c + 1]) L.mask[c] |= (unsigned short)(1u << (w - 1));
+        } else {  // no LDS for a second row (very long series): evaluate the neighbours in place
+            for (int c = 1 + b.tid; c < n - 1; c += b.nt) {
+                const double v = conv_same_at(xv, n, h, nw, c);
+                if (v > conv_same_at(xv, n, h, nw, c - 1) && v > conv_same_at(xv, n, h, nw, c + 1))
+                    L.mask[c] |= (unsigned short)(1u << (w - 1));
             }
         }
     }
     blk_sync();
     // ---- phase B ----
-    if (b.tid == 0) {
-        int nlines = 0, overflow = 0;
-        unsigned any = 0;
-        for (int c = 0; c < n; ++c) any |= L.mask[c];
-        if (any != 0) {
-            int start_row = 0;
-            for (int r = 0; r < W; ++r)
-                if (any & (1u << r)) start_row = r;
-            for (int c = 0; c < n; ++c) {
-                if (L.mask[c] & (1u << start_row)) {
-                    if (nlines < cap) {
-                        L.lcol[nlines] = (unsigned short)c;
-                        L.linf[nlines] = TSFA_LI_PACK(1, 0, 0, start_row);
-                        ++nlines;
-                    } else overflow = 1;
+    int start_row = -1;
+    for (int r = 0; r < W; ++r) {
+        double cnt = 0.0;
+        for (int c = b.tid; c < n; c += b.nt) cnt += (L.mask[c] >> r) & 1;
+        if (blk_sum(b, cnt) > 0.0) start_row = r;
+    }
+    int nlines = 0, overflow = 0;
+    if (start_row >= 0) {
+        const unsigned sbit = 1u << start_row;
+        for (int c0 = 0; c0 < n; c0 += b.nt) {  // initial lines, ascending column order
+            const int c = c0 + b.tid;
+            const bool f = (c < n) && (L.mask[c] & sbit);
+            int tot;
+            const int idx = nlines + blk_excl_count(b, f, &tot);
+            if (f) {
+                if (idx < cap) {
+                    L.lcol[idx] = (unsigned short)c;
+                    L.linf[idx] = TSFA_LI_PACK(1, 0, 0, start_row);
                 }
             }
-            const int gap_thresh = 1;  // ceil(widths[0])
-            for (int row = start_row - 1; row >= 0; --row) {
-                const int nprev = nlines;
-                // gap += 1 for every live line; snapshot of their last columns (earliest line wins a column)
-                for (int l = 0; l < nprev; ++l) {
-                    const unsigned short v = L.linf[l];
-                    if (TSFA_LI_DEAD(v)) continue;
-                    int g = TSFA_LI_GAP(v) + 1;
-                    if (g > 3) g = 3;
-                    L.linf[l] = TSFA_LI_PACK(TSFA_LI_LEN(v), g, 0, TSFA_LI_ROW(v));
-                    const int c = L.lcol[l];
-                    if (L.colmap[c] == 0) L.colmap[c] = (unsigned short)(l + 1);
-                }
-                // max_distances[row] = widths[row] / 4  ->  integer distance <= floor((row + 1) / 4)
-                const int D = (row + 1) / 4;
-                const unsigned bit = 1u << row;
-                // the snapshot must survive the whole row: remember matches in place, apply column updates after
-                // (a line's lcol may only change AFTER every column of this row was matched against the snapshot;
-                //  colmap holds the snapshot, so updating lcol immediately is safe)
-                for (int c = 0; c < n; ++c) {
-                    if (!(L.mask[c] & bit)) continue;
-                    int line = -1;
-                    for (int d = 0; d <= D && line < 0; ++d) {
+            nlines += tot;
+        }
+        if (nlines > cap) { overflow = 1; nlines = cap; }
+        const int gap_thresh = 1;  // ceil(widths[0])
+        for (int row = start_row - 1; row >= 0; --row) {
+            const int nprev = nlines;
+            const int D = (row + 1) / 4;  // max_distances[row] = widths[row] / 4 -> integer distance <= floor
+            const unsigned bit = 1u << row;
+            blk_sync();
+            // snapshot: column -> live line (no two live lines share a last column)
+            for (int l = b.tid; l < nprev; l += b.nt)
+                if (!TSFA_LI_DEAD(L.linf[l])) L.colmap[L.lcol[l]] = (unsigned short)(l + 1);
+            blk_sync();
+            // every maximum of this row picks the nearest live line (earliest line wins a distance tie)
+            for (int c0 = 0; c0 < n; c0 += b.nt) {
+                const int c = c0 + b.tid;
+                const bool is_max = (c < n) && (L.mask[c] & bit);
+                int line = 0;
+                if (is_max) {
+                    for (int d = 0; d <= D && line == 0; ++d) {
                         int best = 0;
                         if (c - d >= 0 && L.colmap[c - d]) best = L.colmap[c - d];
                         if (d > 0 && c + d < n && L.colmap[c + d]) {
                             const int o = L.colmap[c + d];
                             if (best == 0 || o < best) best = o;
                         }
-                        if (best) line = best - 1;
+                        line = best;
                     }
-                    if (line >= 0) {
-                        const unsigned short v = L.linf[line];
-                        int len = TSFA_LI_LEN(v) + 1;
-                        if (len > 63) len = 63;
-                        L.linf[line] = TSFA_LI_PACK(len, 0, 0, row);
-                        L.lcol[line] = (unsigned short)c;
-                    } else if (nlines < cap) {
-                        L.lcol[nlines] = (unsigned short)c;
-                        L.linf[nlines] = TSFA_LI_PACK(1, 0, 0, row);
-                        ++nlines;
-                    } else {
-                        overflow = 1;
-                    }
+                    L.mline[c] = (unsigned short)line;
                 }
-                // clear the snapshot; it was built from the columns the lines had BEFORE this row, which are gone
-                // for matched lines, so wipe by scanning (cheap: one pass over the columns)
-                for (int c = 0; c < n; ++c) L.colmap[c] = 0;
-                // retire lines whose gap exceeds the threshold (they stay in the output list)
-                for (int l = 0; l < nprev; ++l) {
-                    const unsigned short v = L.linf[l];
-                    if (!TSFA_LI_DEAD(v) && TSFA_LI_GAP(v) > gap_thresh)
-                        L.linf[l] = TSFA_LI_PACK(TSFA_LI_LEN(v), TSFA_LI_GAP(v), 1, TSFA_LI_ROW(v));
+                const bool fresh = is_max && line == 0;
+                int tot;
+                const int idx = nlines + blk_excl_count(b, fresh, &tot);
+                if (fresh && idx < cap) {
+                    L.lcol[idx] = (unsigned short)c;
+                    L.linf[idx] = TSFA_LI_PACK(1, 0, 0, row);
+                }
+                nlines += tot;
+            }
+            if (nlines > cap) { overflow = 1; nlines = cap; }
+            blk_sync();
+            // every previously live line collects the maxima that chose it (ascending: the last one is its new column)
+            for (int l = b.tid; l < nprev; l += b.nt) {
+                const unsigned short v = L.linf[l];
+                if (TSFA_LI_DEAD(v)) continue;
+                const int prev = L.lcol[l];
+                L.colmap[prev] = 0;
+                int cnt = 0, last = prev;
+                for (int c = prev - D; c <= prev + D; ++c) {
+                    if (c < 0 || c >= n) continue;
+                    if ((L.mask[c] & bit) && L.mline[c] == l + 1) { ++cnt; last = c; }
+                }
+                if (cnt > 0) {
+                    int len = TSFA_LI_LEN(v) + cnt;
+                    if (len > 63) len = 63;
+                    L.linf[l] = TSFA_LI_PACK(len, 0, 0, row);
+                    L.lcol[l] = (unsigned short)last;
+                } else {
+                    const int g = TSFA_LI_GAP(v) + 1;
+                    L.linf[l] = TSFA_LI_PACK(TSFA_LI_LEN(v), g > 3 ? 3 : g, g > gap_thresh ? 1 : 0, TSFA_LI_ROW(v));
                 }
             }
         }
-        L.misc[0] = nlines;
-        L.misc[1] = overflow;
     }
     blk_sync();
-    const int nlines = L.misc[0];
-    const int overflow = L.misc[1];
     // ---- phase C ----
     const int min_length = (W + 3) / 4;             // ceil(rows / 4)
     const int window = (n + 19) / 20;               // ceil(num_points / 20)
@@ -163,8 +197,7 @@ TSFA_DEV double number_cwt_peaks_one(const Blk &b, X xv, int n, int W, const Cwt
         const unsigned short v = L.linf[l];
         if (TSFA_LI_LEN(v) < min_length) continue;
         const int col = L.lcol[l], row = TSFA_LI_ROW(v);
-        // signal: cwt[row, col]
-        double sig;
+        double sig;  // cwt[row, col]
         if (row == 0) {
             sig = L.row0[col];
         } else {
@@ -185,15 +218,20 @@ TSFA_DEV double number_cwt_peaks_one(const Blk &b, X xv, int n, int W, const Cwt
         const double idx = 10.0 / 100.0 * (double)(m - 1);
         const int i0 = (int)idx;
         double s0 = 0.0, s1 = 0.0;
-        for (int a = 0; a < m; ++a) {
-            const double ea = L.row0[ws + a];
-            int rank = 0;
-            for (int c = 0; c < m; ++c) {
-                const double ec = L.row0[ws + c];
-                rank += (ec < ea || (ec == ea && c < a)) ? 1 : 0;
+        const double *r0 = L.row0 + ws;
+        if (i0 + 1 < 8) {
+            smallest8_select([=](int a) { return r0[a]; }, m, i0, &s0, &s1);
+        } else {
+            for (int a = 0; a < m; ++a) {
+                const double ea = r0[a];
+                int rank = 0;
+                for (int c = 0; c < m; ++c) {
+                    const double ec = r0[c];
+                    rank += (ec < ea || (ec == ea && c < a)) ? 1 : 0;
+                }
+                if (rank == i0) s0 = ea;
+                if (rank == i0 + 1) s1 = ea;
             }
-            if (rank == i0) s0 = ea;
-            if (rank == i0 + 1) s1 = ea;
         }
         double noise;
         if ((double)i0 == idx) {

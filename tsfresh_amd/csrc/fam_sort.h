@@ -282,7 +282,7 @@ TSFA_DEV void friedrich_coeffs(const Blk &b, const double *xs, int n, S1 srt1, i
 //   xs   : series (LDS, n doubles)
 //   srt  : LDS, >= next_pow2(n) doubles (sorted copy)
 //   w    : LDS, >= 768 doubles (Langevin-fit scratch)
-//   iw   : LDS, >= 5040 ints (ordinal-pattern histogram)
+//   iw   : LDS, >= 2520 ints (ordinal-pattern histogram, two 16-bit counters per word); may alias w
 TSFA_DEV void fam_sort_series(const Blk &b, const double *xs, int n, const TsfaSpec *specs, int nspecs,
                               double *out_row, double *srt, double *w, int *iw) {
     const int np2 = next_pow2(n);
@@ -291,6 +291,12 @@ TSFA_DEV void fam_sort_series(const Blk &b, const double *xs, int n, const TsfaS
     blk_bitonic_sort(b, srt, np2);
     const double dn = (double)n;
     const double vmin = srt[0], vmax = srt[n - 1];
+
+    // one-entry caches: consecutive specs of the reference's parameter grids share their expensive part
+    bool have_sym = false, cq_valid = false, fr_valid = false;
+    double sym_dist = 0.0, cq_ql = 0.0, cq_qh = 0.0, cq_cnt = 0.0, cq_mean = 0.0, cq_mean_abs = 0.0, cq_var = 0.0, cq_var_abs = 0.0;
+    int fr_m = 0, fr_r = 0;
+    double fr_coef[TSFA_FRIEDRICH_MAX_M + 1];
 
     // run structure of the sorted array (np.unique / value_counts)
     double n_unique = 0.0, n_multi_vals = 0.0, n_multi_pts = 0.0, sum_multi_vals = 0.0, sum_multi_pts = 0.0;
@@ -308,9 +314,13 @@ TSFA_DEV void fam_sort_series(const Blk &b, const double *xs, int n, const TsfaS
             v = np_quantile_sorted([=](int i) { return srt[i]; }, n, p0);
             break;
         case TSFA_C_SYMMETRY_LOOKING: {                                  // fc.py:299
-            const double mean = np_sum(b, n, [=](int i) { return xs[i]; }) / dn;
-            const double med = (n & 1) ? srt[(n - 1) / 2] : (0.0 + srt[n / 2 - 1] + srt[n / 2]) / 2.0;
-            v = (fabs(mean - med) < p0 * (vmax - vmin)) ? 1.0 : 0.0;
+            if (!have_sym) {
+                const double mean = np_sum(b, n, [=](int i) { return xs[i]; }) / dn;
+                const double med = (n & 1) ? srt[(n - 1) / 2] : (0.0 + srt[n / 2 - 1] + srt[n / 2]) / 2.0;
+                sym_dist = fabs(mean - med);
+                have_sym = true;
+            }
+            v = (sym_dist < p0 * (vmax - vmin)) ? 1.0 : 0.0;
         } break;
         case TSFA_C_MEAN_N_ABSOLUTE_MAX: {                               // fc.py:1643
             const int k = (int)p0;
@@ -331,34 +341,50 @@ TSFA_DEV void fam_sort_series(const Blk &b, const double *xs, int n, const TsfaS
             const bool isabs = (p2 != 0.0);
             const int agg = (int)p3;
             if (ql >= qh) { v = 0.0; break; }
-            // pd.qcut(x, [ql, qh], labels=False) == 0  <=>  lo <= x <= hi  (right-closed, include_lowest)
-            const double lo = pd_quantile_sorted([=](int i) { return srt[i]; }, n, ql);
-            const double hi = pd_quantile_sorted([=](int i) { return srt[i]; }, n, qh);
-            double c = 0.0, a = 0.0;
-            for (int i = b.tid; i < n - 1; i += b.nt) {
-                const double x0 = xs[i], x1 = xs[i + 1];
-                if (x0 >= lo && x0 <= hi && x1 >= lo && x1 <= hi) {
-                    double d = x1 - x0;
-                    if (isabs) d = fabs(d);
-                    c += 1.0;
-                    a += d;
+            if (!(cq_valid && cq_ql == ql && cq_qh == qh)) {
+                // one scan per corridor serves its four columns (isabs x {mean, var})
+                // pd.qcut(x, [ql, qh], labels=False) == 0  <=>  lo <= x <= hi  (right-closed, include_lowest)
+                const double lo = pd_quantile_sorted([=](int i) { return srt[i]; }, n, ql);
+                const double hi = pd_quantile_sorted([=](int i) { return srt[i]; }, n, qh);
+                double c = 0.0, a = 0.0, aa = 0.0;
+                for (int i = b.tid; i < n - 1; i += b.nt) {
+                    const double x0 = xs[i], x1 = xs[i + 1];
+                    if (x0 >= lo && x0 <= hi && x1 >= lo && x1 <= hi) {
+                        const double d = x1 - x0;
+                        c += 1.0;
+                        a += d;
+                        aa += fabs(d);
+                    }
                 }
-            }
-            c = blk_sum(b, c);
-            a = blk_sum(b, a);
-            if (c == 0.0) { v = 0.0; break; }
-            const double dm = a / c;
-            if (agg == TSFA_AGG_MEAN) { v = dm; break; }
-            double ss = 0.0;
-            for (int i = b.tid; i < n - 1; i += b.nt) {
-                const double x0 = xs[i], x1 = xs[i + 1];
-                if (x0 >= lo && x0 <= hi && x1 >= lo && x1 <= hi) {
-                    double d = x1 - x0;
-                    if (isabs) d = fabs(d);
-                    ss += (d - dm) * (d - dm);
+                c = blk_sum(b, c);
+                a = blk_sum(b, a);
+                aa = blk_sum(b, aa);
+                cq_cnt = c;
+                cq_mean = (c > 0.0) ? a / c : 0.0;
+                cq_mean_abs = (c > 0.0) ? aa / c : 0.0;
+                double ss = 0.0, ssa = 0.0;
+                if (c > 0.0) {
+                    const double m1 = cq_mean, m2 = cq_mean_abs;
+                    for (int i = b.tid; i < n - 1; i += b.nt) {
+                        const double x0 = xs[i], x1 = xs[i + 1];
+                        if (x0 >= lo && x0 <= hi && x1 >= lo && x1 <= hi) {
+                            const double d = x1 - x0;
+                            ss += (d - m1) * (d - m1);
+                            ssa += (fabs(d) - m2) * (fabs(d) - m2);
+                        }
+                    }
+                    ss = blk_sum(b, ss);
+                    ssa = blk_sum(b, ssa);
                 }
+                cq_var = (c > 0.0) ? ss / c : 0.0;
+                cq_var_abs = (c > 0.0) ? ssa / c : 0.0;
+                cq_valid = true;
+                cq_ql = ql;
+                cq_qh = qh;
             }
-            v = blk_sum(b, ss) / c;
+            if (cq_cnt == 0.0) v = 0.0;
+            else if (agg == TSFA_AGG_MEAN) v = isabs ? cq_mean_abs : cq_mean;
+            else v = isabs ? cq_var_abs : cq_var;
         } break;
         case TSFA_C_HAS_DUPLICATE:
         case TSFA_C_RATIO_VALUE_NUMBER:
@@ -398,8 +424,10 @@ TSFA_DEV void fam_sort_series(const Blk &b, const double *xs, int n, const TsfaS
             if (num <= 0) { v = TSFA_NAN; break; }
             int fact = 1;
             for (int k = 2; k <= D; ++k) fact *= k;
+            // two 16-bit counters per LDS word (at most n <= 65535 windows)
+            const int nwords = (fact + 1) >> 1;
             blk_sync();
-            for (int k = b.tid; k < fact; k += b.nt) iw[k] = 0;
+            for (int k = b.tid; k < nwords; k += b.nt) iw[k] = 0;
             blk_sync();
             for (int t = b.tid; t < num; t += b.nt) {
                 const double *a = xs + t * tau;
@@ -411,16 +439,18 @@ TSFA_DEV void fam_sort_series(const Blk &b, const double *xs, int n, const TsfaS
                     f /= (D - j);
                     code += c * f;
                 }
+                const int inc = (code & 1) ? 0x10000 : 1;
 #if TSFA_GPU
-                atomicAdd(&iw[code], 1);
+                atomicAdd(&iw[code >> 1], inc);
 #else
-                iw[code] += 1;
+                iw[code >> 1] += inc;
 #endif
             }
             blk_sync();
             double e = 0.0;
             for (int k = b.tid; k < fact; k += b.nt) {
-                const int c = iw[k];
+                const unsigned wv = (unsigned)iw[k >> 1];
+                const int c = (k & 1) ? (int)(wv >> 16) : (int)(wv & 0xffffu);
                 if (c > 0) {
                     const double pr = (double)c / (double)num;
                     e += pr * log(pr);
@@ -433,20 +463,25 @@ TSFA_DEV void fam_sort_series(const Blk &b, const double *xs, int n, const TsfaS
             int coeff, m, r;
             if (sp.calc == TSFA_C_FRIEDRICH_COEFFICIENTS) { coeff = (int)p0; m = (int)p1; r = (int)p2; }
             else { coeff = -1; m = (int)p0; r = (int)p1; }
-            // sorted x[:-1] = the sorted series with one occurrence of x[n-1] removed
-            int pos = 0;
-            {
-                const double xl = xs[n - 1];
-                int lo = 0, hi = n;
-                while (lo < hi) {
-                    const int mid = (lo + hi) >> 1;
-                    if (srt[mid] < xl) lo = mid + 1; else hi = mid;
+            if (!(fr_valid && fr_m == m && fr_r == r)) {
+                // sorted x[:-1] = the sorted series with one occurrence of x[n-1] removed
+                int pos = 0;
+                {
+                    const double xl = xs[n - 1];
+                    int lo = 0, hi = n;
+                    while (lo < hi) {
+                        const int mid = (lo + hi) >> 1;
+                        if (srt[mid] < xl) lo = mid + 1; else hi = mid;
+                    }
+                    pos = lo;
                 }
-                pos = lo;
+                const double *sr = srt;
+                friedrich_coeffs(b, xs, n, [=](int i) { return sr[i < pos ? i : i + 1]; }, m, r, w, fr_coef);
+                fr_valid = true;
+                fr_m = m;
+                fr_r = r;
             }
-            double coef[TSFA_FRIEDRICH_MAX_M + 1];
-            const double *sr = srt;
-            friedrich_coeffs(b, xs, n, [=](int i) { return sr[i < pos ? i : i + 1]; }, m, r, w, coef);
+            const double *coef = fr_coef;
             if (sp.calc == TSFA_C_FRIEDRICH_COEFFICIENTS) v = (coeff >= 0 && coeff <= m && m <= TSFA_FRIEDRICH_MAX_M) ? coef[coeff] : TSFA_NAN;
             else v = (m >= 1 && m <= TSFA_FRIEDRICH_MAX_M) ? max_real_root_deg3(coef, m + 1) : TSFA_NAN;
         } break;

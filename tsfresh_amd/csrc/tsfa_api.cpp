@@ -10,6 +10,7 @@
 #include "../../include/tsfresh_amd.h"
 #include "tsfa_host_tables.h"
 #include "tsfa_launch.h"
+#include "fam_seq.h"
 #include "tsfa_layout.h"
 
 static thread_local std::string g_last_error;
@@ -304,6 +305,9 @@ int tsfa_extract(tsfa_plan *plan, const void *values, int32_t dtype, const int64
                 a.gscratch = (double *)plan->gscratch.p;
             }
             aux = a.dft_n;
+        } else if (f == TSFA_FAM_CWT) {
+            a.cwt_rowv = tsfa_family_lds_bytes(f, maxn, nt, 1) <= 96 * 1024 ? 1 : 0;
+            aux = a.cwt_rowv;
         } else if (f == TSFA_FAM_AR) {
             // leading dimension of the normal matrices: ADF needs maxlag(n) + 3, AR(k) needs k + 2
             int P = 8;
@@ -319,12 +323,16 @@ int tsfa_extract(tsfa_plan *plan, const void *values, int32_t dtype, const int64
             a.ar_P = P;
             aux = P;
         } else if (f == TSFA_FAM_SEQ) {
-            int ntab = a.nspecs;
-            while (ntab > 1 && tsfa_family_lds_bytes(f, maxn, nt, ntab) > TSFA_LDS_LIMIT) --ntab;
-            a.ntab = ntab;
-            aux = ntab;
+            // parse as many `bins` values side by side as LDS allows
+            int group = std::min(a.nspecs, TSFA_LZ_MAX_GROUP);
+            for (;; --group) {
+                lz_group_budget(plan->fam_specs[f].data(), a.nspecs, group, maxn, &a.seq_tab_entries, &a.seq_edge_doubles);
+                if (group == 1 || tsfa_seq_lds_bytes(maxn, group, a.seq_tab_entries, a.seq_edge_doubles) <= TSFA_LDS_LIMIT) break;
+            }
+            a.ntab = group;
         }
-        const size_t lds = tsfa_family_lds_bytes(f, maxn, nt, aux);
+        const size_t lds = (f == TSFA_FAM_SEQ) ? tsfa_seq_lds_bytes(maxn, a.ntab, a.seq_tab_entries, a.seq_edge_doubles)
+                                               : tsfa_family_lds_bytes(f, maxn, nt, aux);
         if (lds > TSFA_LDS_LIMIT)
             return fail(TSFA_ERR_TOO_LONG, std::string(fam_names[f]) + ": a series of " + std::to_string(maxn) +
                                                " samples needs " + std::to_string(lds) + " B of LDS (limit 163840)");

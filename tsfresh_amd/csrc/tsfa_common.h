@@ -65,17 +65,49 @@ TSFA_DEV void blk_sync() {
 // reductions: every thread receives the result
 // ---------------------------------------------------------------------------------------------
 #if TSFA_GPU
+// Wave64 all-reduce without LDS traffic.  __shfl_xor on a double lowers to two ds_bpermute_b32 (LDS crossbar, ~64
+// cycles of latency each) per step; the first four butterfly steps stay inside a 16-lane DPP row, so they are done
+// with DPP modifiers (quad_perm / row_half_mirror / row_mirror: VALU latency), and the four row totals are then read
+// with v_readlane and added -- the result is wave-uniform (SGPR) by construction.
+template <int CTRL>
+TSFA_DEV double dpp_mov_f64(double v) {
+    union { double d; int i[2]; } a, r;
+    a.d = v;
+    r.i[0] = __builtin_amdgcn_update_dpp(a.i[0], a.i[0], CTRL, 0xf, 0xf, false);
+    r.i[1] = __builtin_amdgcn_update_dpp(a.i[1], a.i[1], CTRL, 0xf, 0xf, false);
+    return r.d;
+}
+TSFA_DEV double readlane_f64(double v, int lane) {
+    union { double d; int i[2]; } a, r;
+    a.d = v;
+    r.i[0] = __builtin_amdgcn_readlane(a.i[0], lane);
+    r.i[1] = __builtin_amdgcn_readlane(a.i[1], lane);
+    return r.d;
+}
+#define TSFA_DPP_QUAD_XOR1 0xB1       /* quad_perm:[1,0,3,2] */
+#define TSFA_DPP_QUAD_XOR2 0x4E       /* quad_perm:[2,3,0,1] */
+#define TSFA_DPP_ROW_HALF_MIRROR 0x141
+#define TSFA_DPP_ROW_MIRROR 0x140
 TSFA_DEV double wave_sum(double v) {
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
-    return v;
+    v += dpp_mov_f64<TSFA_DPP_QUAD_XOR1>(v);
+    v += dpp_mov_f64<TSFA_DPP_QUAD_XOR2>(v);
+    v += dpp_mov_f64<TSFA_DPP_ROW_HALF_MIRROR>(v);
+    v += dpp_mov_f64<TSFA_DPP_ROW_MIRROR>(v);
+    return (readlane_f64(v, 0) + readlane_f64(v, 16)) + (readlane_f64(v, 32) + readlane_f64(v, 48));
 }
 TSFA_DEV double wave_min(double v) {
-    for (int o = 32; o > 0; o >>= 1) v = fmin(v, __shfl_xor(v, o));
-    return v;
+    v = fmin(v, dpp_mov_f64<TSFA_DPP_QUAD_XOR1>(v));
+    v = fmin(v, dpp_mov_f64<TSFA_DPP_QUAD_XOR2>(v));
+    v = fmin(v, dpp_mov_f64<TSFA_DPP_ROW_HALF_MIRROR>(v));
+    v = fmin(v, dpp_mov_f64<TSFA_DPP_ROW_MIRROR>(v));
+    return fmin(fmin(readlane_f64(v, 0), readlane_f64(v, 16)), fmin(readlane_f64(v, 32), readlane_f64(v, 48)));
 }
 TSFA_DEV double wave_max(double v) {
-    for (int o = 32; o > 0; o >>= 1) v = fmax(v, __shfl_xor(v, o));
-    return v;
+    v = fmax(v, dpp_mov_f64<TSFA_DPP_QUAD_XOR1>(v));
+    v = fmax(v, dpp_mov_f64<TSFA_DPP_QUAD_XOR2>(v));
+    v = fmax(v, dpp_mov_f64<TSFA_DPP_ROW_HALF_MIRROR>(v));
+    v = fmax(v, dpp_mov_f64<TSFA_DPP_ROW_MIRROR>(v));
+    return fmax(fmax(readlane_f64(v, 0), readlane_f64(v, 16)), fmax(readlane_f64(v, 32), readlane_f64(v, 48)));
 }
 #endif
 
@@ -122,9 +154,40 @@ TSFA_DEV double blk_max(const Blk &b, double v) {
     return v;
 }
 
+// Exclusive count of `flag` over the lower-numbered threads of the workgroup, and the workgroup total.
+// (thread order = ascending tid; used to hand out indices in a deterministic order)
+TSFA_DEV int blk_excl_count(const Blk &b, bool flag, int *total) {
+#if TSFA_GPU
+    const unsigned long long m = __ballot(flag);
+    const int lane = b.tid & 63;
+    int pre = __popcll(m & ((1ull << lane) - 1ull));
+    int tot = __popcll(m);
+    if (b.nt > 64) {
+        const int nw = b.nt >> 6, w = b.tid >> 6;
+        int *ir = (int *)(b.red + 32);
+        blk_sync();
+        if (lane == 0) ir[w] = tot;
+        blk_sync();
+        int base = 0, all = 0;
+        for (int k = 0; k < nw; ++k) {
+            if (k < w) base += ir[k];
+            all += ir[k];
+        }
+        pre += base;
+        tot = all;
+    }
+    *total = tot;
+    return pre;
+#else
+    *total = flag ? 1 : 0;
+    return 0;
+#endif
+}
+
 // broadcast a value computed by thread 0 to the whole workgroup
 TSFA_DEV double blk_bcast0(const Blk &b, double v) {
 #if TSFA_GPU
+    if (b.nt == 64) return readlane_f64(v, 0);
     blk_sync();
     if (b.tid == 0) b.red[TSFA_RED_DOUBLES - 1] = v;
     blk_sync();
@@ -175,7 +238,8 @@ template <class F>
 TSFA_DEV double np_sum(const Blk &b, int n, F f) {
     NpScratch *s = b.np;
     double total = 0.0;
-    for (int c0 = 0; c0 < n || c0 == 0; c0 += 8192) {
+    if (n <= 0) return 0.0;
+    for (int c0 = 0; c0 < n; c0 += 8192) {
         const int clen = (n - c0 < 8192) ? (n - c0) : 8192;
         blk_sync();
         if (b.tid == 0) {  // enumerate the leaves of the pairwise tree, left to right
@@ -205,7 +269,36 @@ TSFA_DEV double np_sum(const Blk &b, int n, F f) {
         }
         blk_sync();
         const int nl = s->nleaf;
+#if TSFA_GPU
+        // 8 lanes per leaf: lane k of a group owns numpy's accumulator r[k]; the fixed combination tree
+        // ((r0+r1)+(r2+r3))+((r4+r5)+(r6+r7)) is three DPP butterfly steps inside the 8-lane group
+        for (int u0 = 0; u0 < nl * 8; u0 += b.nt) {
+            const int u = u0 + b.tid;
+            const int leaf = u >> 3, k = u & 7;
+            const bool live = leaf < nl;
+            const int o = live ? s->leaf_off[leaf] : 0, l = live ? s->leaf_len[leaf] : 0;
+            double r = 0.0;
+            if (l >= 8) {
+                const int lim = l - (l % 8);
+                r = f(o + k);
+                for (int i = 8; i < lim; i += 8) r += f(o + i + k);
+            }
+            r += dpp_mov_f64<TSFA_DPP_QUAD_XOR1>(r);
+            r += dpp_mov_f64<TSFA_DPP_QUAD_XOR2>(r);
+            r += dpp_mov_f64<TSFA_DPP_ROW_HALF_MIRROR>(r);
+            if (live && k == 0) {
+                if (l < 8) {
+                    r = 0.0;
+                    for (int i = 0; i < l; ++i) r += f(o + i);
+                } else {
+                    for (int i = l - (l % 8); i < l; ++i) r += f(o + i);
+                }
+                s->leaf_sum[leaf] = r;
+            }
+        }
+#else
         for (int k = b.tid; k < nl; k += b.nt) s->leaf_sum[k] = np_leaf_sum(s->leaf_off[k], s->leaf_len[k], f);
+#endif
         blk_sync();
         if (b.tid == 0) {  // combine in recursion (post-)order
             int sp = 0, vp = 0, li = 0;
@@ -238,7 +331,6 @@ TSFA_DEV double np_sum(const Blk &b, int n, F f) {
             total = (c0 == 0) ? chunk : (s->result + chunk);
             s->result = total;
         }
-        if (n == 0) break;
     }
     blk_sync();
     total = s->result;

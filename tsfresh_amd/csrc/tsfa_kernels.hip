@@ -32,7 +32,7 @@ __global__ void k_basic(const T *__restrict__ values, const int64_t *__restrict_
     L.carve(tsfa_smem, maxn, blockDim.x);
     Blk b{(int)threadIdx.x, (int)blockDim.x, L.red, L.np};
     stage_series(b, values + off, n, L.xs);
-    fam_basic_series(b, L.xs, n, specs, nspecs, out + sidx * ld, L.w, L.iw, dectab);
+    fam_basic_series(b, L.xs, n, specs, nspecs, out + sidx * ld, L.w, L.cum, L.altc, L.iw, dectab);
 }
 
 template <typename T>
@@ -103,29 +103,29 @@ __global__ void k_entropy(const T *__restrict__ values, const int64_t *__restric
 template <typename T>
 __global__ void k_seq(const T *__restrict__ values, const int64_t *__restrict__ offsets, int64_t n_series,
                       const TsfaSpec *__restrict__ specs, int nspecs, double *__restrict__ out, int64_t ld, int maxn,
-                      int ntab) {
+                      int group, int tab_entries, int edge_doubles) {
     const int64_t sidx = blockIdx.x;
     if (sidx >= n_series) return;
     const int64_t off = offsets[sidx];
     const int n = (int)(offsets[sidx + 1] - off);
     SeqLds L;
-    L.carve(tsfa_smem, maxn, ntab);
+    L.carve(tsfa_smem, maxn, group, tab_entries, edge_doubles);
     Blk b{(int)threadIdx.x, (int)blockDim.x, L.red, nullptr};
     const T *g = values + off;
-    fam_seq_series(b, [=](int i) { return (double)g[i]; }, n, specs, nspecs, out + sidx * ld, L.seq, L.tab, ntab,
-                   SeqLds::table_cap(maxn));
+    fam_seq_series(b, [=](int i) { return (double)g[i]; }, n, specs, nspecs, out + sidx * ld, L.seq, L.tab, L.edges,
+                   group, maxn);
 }
 
 template <typename T>
 __global__ void k_cwtpeaks(const T *__restrict__ values, const int64_t *__restrict__ offsets, int64_t n_series,
                            const TsfaSpec *__restrict__ specs, int nspecs, double *__restrict__ out, int64_t ld,
-                           int maxn) {
+                           int maxn, int with_rowv) {
     const int64_t sidx = blockIdx.x;
     if (sidx >= n_series) return;
     const int64_t off = offsets[sidx];
     const int n = (int)(offsets[sidx + 1] - off);
     CwtPeaksLayout L;
-    L.carve(tsfa_smem, maxn, blockDim.x);
+    L.carve(tsfa_smem, maxn, with_rowv);
     Blk b{(int)threadIdx.x, (int)blockDim.x, L.p.red, nullptr};
     const T *g = values + off;
     fam_cwtpeaks_series(b, [=](int i) { return (double)g[i]; }, n, specs, nspecs, out + sidx * ld, L.p);
@@ -260,19 +260,26 @@ static int launch_all_t(const TsfaLaunch &a, const T *values) {
         k_entropy<T><<<grid, nt, lds, st>>>(values, a.offsets, a.n_series, a.specs, a.nspecs, a.out, a.ld, a.maxn);
     } else if (a.fam == TSFA_FAM_SEQ) {
         SeqLds L;
-        const size_t lds = L.carve(nullptr, a.maxn, a.ntab);
+        const size_t lds = L.carve(nullptr, a.maxn, a.ntab, a.seq_tab_entries, a.seq_edge_doubles);
         if ((rc = set_lds(k_seq<T>, lds))) return rc;
-        k_seq<T><<<grid, nt, lds, st>>>(values, a.offsets, a.n_series, a.specs, a.nspecs, a.out, a.ld, a.maxn, a.ntab);
+        k_seq<T><<<grid, nt, lds, st>>>(values, a.offsets, a.n_series, a.specs, a.nspecs, a.out, a.ld, a.maxn, a.ntab,
+                                        a.seq_tab_entries, a.seq_edge_doubles);
     } else if (a.fam == TSFA_FAM_CWT) {  // number_cwt_peaks
         CwtPeaksLayout L;
-        const size_t lds = L.carve(nullptr, a.maxn, nt);
+        const size_t lds = L.carve(nullptr, a.maxn, a.cwt_rowv);
         if ((rc = set_lds(k_cwtpeaks<T>, lds))) return rc;
-        k_cwtpeaks<T><<<grid, nt, lds, st>>>(values, a.offsets, a.n_series, a.specs, a.nspecs, a.out, a.ld, a.maxn);
+        k_cwtpeaks<T><<<grid, nt, lds, st>>>(values, a.offsets, a.n_series, a.specs, a.nspecs, a.out, a.ld, a.maxn,
+                                             a.cwt_rowv);
     } else {
         return -1;
     }
     TSFA_LAUNCH_CHECK();
     return 0;
+}
+
+size_t tsfa_seq_lds_bytes(int maxn, int group, int tab_entries, int edge_doubles) {
+    SeqLds L;
+    return L.carve(nullptr, maxn, group, tab_entries, edge_doubles);
 }
 
 size_t tsfa_family_lds_bytes(int fam, int maxn, int nt, int aux) {
@@ -282,8 +289,7 @@ size_t tsfa_family_lds_bytes(int fam, int maxn, int nt, int aux) {
     case TSFA_FAM_SPECTRAL: { SpectralLds L; return L.carve(nullptr, maxn, aux); }
     case TSFA_FAM_AR: { ArLds L; return L.carve(nullptr, maxn, aux); }
     case TSFA_FAM_ENTROPY: { EntropyLds L; return L.carve(nullptr, maxn, nt); }
-    case TSFA_FAM_SEQ: { SeqLds L; return L.carve(nullptr, maxn, aux); }
-    case TSFA_FAM_CWT: { CwtPeaksLayout L; return L.carve(nullptr, maxn, nt); }
+    case TSFA_FAM_CWT: { CwtPeaksLayout L; return L.carve(nullptr, maxn, aux); }
     default: return 0;
     }
 }

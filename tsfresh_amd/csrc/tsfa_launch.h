@@ -26,8 +26,11 @@ struct TsfaLaunch {
     int dft_n;              // SPECTRAL: DFT twiddle slots held in LDS
     double *gscratch;       // SPECTRAL: HBM twiddle scratch for long non-pow2 series (or null)
     int gscratch_n;
-    int ntab;               // SEQ: concurrent parse tables
+    int ntab;               // SEQ: specs parsed side by side (group size)
+    int seq_tab_entries;    // SEQ: hash-table slots of the largest group
+    int seq_edge_doubles;   // SEQ: bin edges of the largest group
     int ar_P;               // AR: leading dimension of the normal matrices
+    int cwt_rowv;           // CWT peaks: second CWT row resident in LDS
 };
 
 struct TsfaCwtLaunch {
@@ -45,6 +48,7 @@ struct TsfaCwtLaunch {
 };
 
 size_t tsfa_family_lds_bytes(int fam, int maxn, int nt, int aux);
+size_t tsfa_seq_lds_bytes(int maxn, int group, int tab_entries, int edge_doubles);
 int tsfa_launch_family(const TsfaLaunch &a);
 int tsfa_launch_cwt(const TsfaCwtLaunch &a);
 int tsfa_launch_fill_nan(double *out, int64_t n, void *stream);

@@ -36,13 +36,15 @@ TSFA_HD int tsfa_pow2_ceil(int n) {
 }
 
 struct BasicLds {
-    double *red; NpScratch *np; double *xs; double *w; int *iw;
+    double *red; NpScratch *np; double *xs; double *w; double *cum; double *altc; int *iw;
     TSFA_HD size_t carve(unsigned char *base, int maxn, int nt) {
         LdsCarve c{base, 0};
         red = c.take<double>(TSFA_RED_DOUBLES);
         np = c.take<NpScratch>(1);
         xs = c.take<double>(maxn);
-        w = c.take<double>(maxn);
+        w = c.take<double>(maxn);  // chunk aggregates (agg_linear_trend) ...
+        cum = w;                   // ... aliased with the cumulative |x| of index_mass_quantile (the cache is invalidated)
+        altc = c.take<double>(8 * 16);
         iw = c.take<int>((4 * nt > 256) ? 4 * nt : 256);
         return c.off;
     }
@@ -57,8 +59,8 @@ struct SortLds {
         np = c.take<NpScratch>(1);
         xs = c.take<double>(maxn);
         srt = c.take<double>(tsfa_pow2_ceil(maxn));
-        w = c.take<double>(768);
-        iw = c.take<int>(5040);
+        w = c.take<double>(1280);   // Langevin-fit scratch (<= 768 doubles) ...
+        iw = (int *)w;              // ... aliased with the ordinal-pattern histogram (2520 ints): never live together
         return c.off;
     }
 };
@@ -111,13 +113,13 @@ struct EntropyLds {
 };
 
 struct SeqLds {
-    double *red; unsigned char *seq; uint32_t *tab;
-    TSFA_HD static int table_cap(int maxn) { return tsfa_pow2_ceil(maxn + 256); }
-    TSFA_HD size_t carve(unsigned char *base, int maxn, int ntab) {
+    double *red; unsigned char *seq; uint32_t *tab; double *edges;
+    TSFA_HD size_t carve(unsigned char *base, int maxn, int group, int tab_entries, int edge_doubles) {
         LdsCarve c{base, 0};
         red = c.take<double>(TSFA_RED_DOUBLES);
-        seq = c.take<unsigned char>((size_t)ntab * maxn);
-        tab = c.take<uint32_t>((size_t)ntab * table_cap(maxn));
+        edges = c.take<double>(edge_doubles + 2);
+        tab = c.take<uint32_t>((size_t)tab_entries);
+        seq = c.take<unsigned char>((size_t)group * maxn + 16);
         return c.off;
     }
 };
@@ -125,16 +127,18 @@ struct SeqLds {
 
 struct CwtPeaksLayout {
     CwtPeaksLds p;
-    TSFA_HD size_t carve(unsigned char *base, int maxn, int nt) {
-        (void)nt;
+    // with_rowv: keep a second float64 row in LDS (each CWT row is then convolved once instead of three times)
+    TSFA_HD size_t carve(unsigned char *base, int maxn, int with_rowv) {
         LdsCarve c{base, 0};
         p.red = c.take<double>(TSFA_RED_DOUBLES);
         p.row0 = c.take<double>(maxn);
+        p.rowv = with_rowv ? c.take<double>(maxn) : nullptr;
         p.taps = c.take<double>(TSFA_CWTP_MAXTAPS + 16);
         p.mask = c.take<unsigned short>(maxn);
         p.lcol = c.take<unsigned short>(maxn);
         p.linf = c.take<unsigned short>(maxn);
         p.colmap = c.take<unsigned short>(maxn);
+        p.mline = c.take<unsigned short>(maxn);
         p.misc = c.take<int>(8);
         return c.off;
     }
