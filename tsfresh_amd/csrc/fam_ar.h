@@ -102,9 +102,9 @@ template <class X>
 TSFA_DEV void fam_ar_series(const Blk &b, X xv, int n, const TsfaSpec *specs, int nspecs, double *out_row, double *xc,
                             double *rbuf, double *aw, int P) {
     const double dn = (double)n;
-    double sm = 0.0;
-    for (int i = b.tid; i < n; i += b.nt) sm += xv(i);
-    const double mean = blk_sum(b, sm) / dn;
+    // x.mean() in numpy's summation order: statsmodels demeans with it, and on (near-)constant series the
+    // autocovariances are pure round-off of x - x.mean(), so the order decides what comes out
+    const double mean = np_sum(b, n, [=](int i) { return xv(i); }) / dn;
     blk_sync();
     for (int i = b.tid; i < n; i += b.nt) xc[i] = xv(i) - mean;
     blk_sync();

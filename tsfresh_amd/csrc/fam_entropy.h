@@ -21,13 +21,21 @@ struct EntAcc {          // per-threshold accumulators of one sweep (template le
 };
 
 // One sweep for template length m = 2 with NK thresholds thr[0..NK).  Every thread returns the block totals.
+//
+// Pruning (exact): a pair can only match if |x_i - x_j| <= r_max, so the length-2 templates are sorted by their first
+// sample (perm[], bitonic sort in LDS) and each pass of nt rows -- a narrow band of values -- only visits the columns
+// whose first sample lies within r_max of that band (two binary searches).  For N(0,1) data and r_max = 0.9 sigma
+// this skips ~45% of the pairs.  xs[n] and xs[n+1] must hold +inf (the length-3 extension of the last templates then
+// never matches).
 template <int NK>
-TSFA_DEV void entropy_sweep_m2(const Blk &b, const double *xs, int n, const double *thr, EntAcc *acc) {
+TSFA_DEV void entropy_sweep_m2(const Blk &b, const double *xs, int n, const double *thr, const unsigned short *perm,
+                               EntAcc *acc) {
     const int nrow_m = n - 1;   // templates of length 2: i in [0, n-2]
     const int nrow_m1 = n - 2;  // templates of length 3: i in [0, n-3]
     double r[NK];
+    double rmax = 0.0;
 #pragma unroll
-    for (int k = 0; k < NK; ++k) r[k] = thr[k];
+    for (int k = 0; k < NK; ++k) { r[k] = thr[k]; rmax = fmax(rmax, r[k]); }
     double slm[NK], slm1[NK], scm[NK], scm1[NK];
 #pragma unroll
     for (int k = 0; k < NK; ++k) { slm[k] = 0.0; slm1[k] = 0.0; scm[k] = 0.0; scm1[k] = 0.0; }
@@ -35,18 +43,32 @@ TSFA_DEV void entropy_sweep_m2(const Blk &b, const double *xs, int n, const doub
 
     const int npass = (nrow_m + b.nt - 1) / b.nt;
     for (int pass = 0; pass < npass; ++pass) {
-        const int i = pass * b.nt + b.tid;
-        const bool row_m = (i < nrow_m), row_m1 = (i < nrow_m1);
-        const double xi0 = row_m ? xs[i] : 0.0;
-        const double xi1 = row_m ? xs[i + 1] : 0.0;
-        const double xi2 = row_m1 ? xs[i + 2] : 0.0;
+        const int q0 = pass * b.nt;
+        const int q1 = (q0 + b.nt < nrow_m) ? (q0 + b.nt) : nrow_m;  // rows [q0, q1) of the sorted order
+        const int qi = q0 + b.tid;
+        const bool row_m = (qi < nrow_m);
+        const int ri = row_m ? (int)perm[qi] : 0;
+        const bool row_m1 = row_m && (ri < nrow_m1);
+        const double xi0 = xs[ri], xi1 = xs[ri + 1], xi2 = xs[ri + 2];
+        // column window: first samples within r_max of [band_lo, band_hi], widened by a rounding margin
+        const double band_lo = xs[perm[q0]], band_hi = xs[perm[q1 - 1]];
+        const double margin = 1e-9 * (fabs(band_lo) + fabs(band_hi) + rmax);
+        const double key_lo = band_lo - rmax - margin, key_hi = band_hi + rmax + margin;
+        int jlo, jhi;
+        {
+            int lo = 0, hi = nrow_m;
+            while (lo < hi) { const int mid = (lo + hi) >> 1; if (xs[perm[mid]] < key_lo) lo = mid + 1; else hi = mid; }
+            jlo = lo;
+            lo = jlo; hi = nrow_m;
+            while (lo < hi) { const int mid = (lo + hi) >> 1; if (xs[perm[mid]] <= key_hi) lo = mid + 1; else hi = mid; }
+            jhi = lo;
+        }
         int c2[NK], c3[NK];
 #pragma unroll
         for (int k = 0; k < NK; ++k) { c2[k] = 0; c3[k] = 0; }
-        double xj0 = xs[0], xj1 = xs[1];
-        // columns valid for both template lengths
-        for (int j = 0; j < nrow_m1; ++j) {
-            const double xj2 = xs[j + 2];
+        for (int q = jlo; q < jhi; ++q) {
+            const int c = perm[q];
+            const double xj0 = xs[c], xj1 = xs[c + 1], xj2 = xs[c + 2];  // xs[n] = +inf: no length-3 template there
             const double d0 = fabs(xi0 - xj0), d1 = fabs(xi1 - xj1), d2 = fabs(xi2 - xj2);
             const double m2 = fmax(d0, d1);
             const double m3 = fmax(m2, d2);
@@ -55,14 +77,6 @@ TSFA_DEV void entropy_sweep_m2(const Blk &b, const double *xs, int n, const doub
                 c2[k] += (m2 <= r[k]) ? 1 : 0;
                 c3[k] += (m3 <= r[k]) ? 1 : 0;
             }
-            xj0 = xj1;
-            xj1 = xj2;
-        }
-        {   // last column j = n-2: only a length-2 template
-            const double d0 = fabs(xi0 - xj0), d1 = fabs(xi1 - xj1);
-            const double m2 = fmax(d0, d1);
-#pragma unroll
-            for (int k = 0; k < NK; ++k) c2[k] += (m2 <= r[k]) ? 1 : 0;
         }
 #pragma unroll
         for (int k = 0; k < NK; ++k) {
@@ -83,6 +97,31 @@ TSFA_DEV void entropy_sweep_m2(const Blk &b, const double *xs, int n, const doub
         acc[k].sum_cnt_m = blk_sum(b, scm[k]);
         acc[k].sum_cnt_m1 = blk_sum(b, scm1[k]);
     }
+}
+
+// perm[0 .. n-2] = indices of the length-2 templates sorted by their first sample (ties by index); np2 = padded size
+TSFA_DEV void entropy_sort_templates(const Blk &b, const double *xs, int n, unsigned short *perm, int np2) {
+    const int nrow_m = n - 1;
+    blk_sync();
+    for (int i = b.tid; i < np2; i += b.nt) perm[i] = (unsigned short)((i < nrow_m) ? i : 0xFFFF);
+    for (int k = 2; k <= np2; k <<= 1) {
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            blk_sync();
+            for (int t = b.tid; t < (np2 >> 1); t += b.nt) {
+                const int i = ((t & ~(j - 1)) << 1) | (t & (j - 1));
+                const int l = i | j;
+                const bool up = ((i & k) == 0);
+                const unsigned short a = perm[i], c = perm[l];
+                const double ka = (a == 0xFFFF) ? TSFA_INF : xs[a], kc = (c == 0xFFFF) ? TSFA_INF : xs[c];
+                const bool gt = (ka > kc) || (ka == kc && a > c);
+                if (gt == up) {
+                    perm[i] = c;
+                    perm[l] = a;
+                }
+            }
+        }
+    }
+    blk_sync();
 }
 
 // generic template length m (slow path; settings.py only uses m = 2)
@@ -126,14 +165,19 @@ TSFA_DEV double sampen_from_acc(const EntAcc &a, int n, int m) {
     return -log(A / B);
 }
 
-// Evaluate the ENTROPY specs of one series.   thr : LDS scratch >= TSFA_ENT_MAXK doubles
-TSFA_DEV void fam_entropy_series(const Blk &b, const double *xs, int n, const TsfaSpec *specs, int nspecs,
-                                 double *out_row, double *thr) {
+// Evaluate the ENTROPY specs of one series.
+//   xs   : LDS, n + 2 doubles (xs[n], xs[n+1] are overwritten with +inf sentinels)
+//   thr  : LDS scratch >= TSFA_ENT_MAXK doubles;   perm : LDS, next_pow2(n) unsigned shorts
+TSFA_DEV void fam_entropy_series(const Blk &b, double *xs, int n, const TsfaSpec *specs, int nspecs,
+                                 double *out_row, double *thr, unsigned short *perm) {
     // np.std(x), numpy summation order (the tolerances are c * np.std(x))
     const double dn = (double)n;
     const double mean = np_sum(b, n, [=](int i) { return xs[i]; }) / dn;
     const double var = np_sum(b, n, [=](int i) { const double d = xs[i] - mean; return d * d; }) / dn;
     const double sd = sqrt(var);
+    blk_sync();
+    if (b.tid == 0) { xs[n] = TSFA_INF; xs[n + 1] = TSFA_INF; }
+    bool sorted = false;
 
     // m = 2 specs are batched TSFA_ENT_MAXK at a time
     int done = 0;
@@ -159,11 +203,15 @@ TSFA_DEV void fam_entropy_series(const Blk &b, const double *xs, int n, const Ts
         blk_sync();
         EntAcc acc[TSFA_ENT_MAXK];
         if (n >= 3) {
-            if (nk <= 1) entropy_sweep_m2<1>(b, xs, n, thr, acc);
-            else if (nk <= 2) entropy_sweep_m2<2>(b, xs, n, thr, acc);
-            else if (nk <= 4) entropy_sweep_m2<4>(b, xs, n, thr, acc);
-            else if (nk <= 6) entropy_sweep_m2<6>(b, xs, n, thr, acc);
-            else entropy_sweep_m2<8>(b, xs, n, thr, acc);
+            if (!sorted) {
+                entropy_sort_templates(b, xs, n, perm, next_pow2(n - 1));
+                sorted = true;
+            }
+            if (nk <= 1) entropy_sweep_m2<1>(b, xs, n, thr, perm, acc);
+            else if (nk <= 2) entropy_sweep_m2<2>(b, xs, n, thr, perm, acc);
+            else if (nk <= 4) entropy_sweep_m2<4>(b, xs, n, thr, perm, acc);
+            else if (nk <= 6) entropy_sweep_m2<6>(b, xs, n, thr, perm, acc);
+            else entropy_sweep_m2<8>(b, xs, n, thr, perm, acc);
         }
         for (int k = 0; k < nk; ++k) {
             const TsfaSpec sp = specs[idx[k]];

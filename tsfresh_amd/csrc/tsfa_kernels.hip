@@ -80,7 +80,7 @@ __global__ void k_ar(const T *__restrict__ values, const int64_t *__restrict__ o
     const int n = (int)(offsets[sidx + 1] - off);
     ArLds L;
     L.carve(tsfa_smem, maxn, P);
-    Blk b{(int)threadIdx.x, (int)blockDim.x, L.red, nullptr};
+    Blk b{(int)threadIdx.x, (int)blockDim.x, L.red, L.np};
     const T *g = values + off;
     fam_ar_series(b, [=](int i) { return (double)g[i]; }, n, specs, nspecs, out + sidx * ld, L.xc, L.rbuf, L.aw, P);
 }
@@ -97,7 +97,7 @@ __global__ void k_entropy(const T *__restrict__ values, const int64_t *__restric
     L.carve(tsfa_smem, maxn, blockDim.x);
     Blk b{(int)threadIdx.x, (int)blockDim.x, L.red, L.np};
     stage_series(b, values + off, n, L.xs);
-    fam_entropy_series(b, L.xs, n, specs, nspecs, out + sidx * ld, L.thr);
+    fam_entropy_series(b, L.xs, n, specs, nspecs, out + sidx * ld, L.thr, L.perm);
 }
 
 template <typename T>

@@ -86,12 +86,13 @@ struct SpectralLds {
 };
 
 struct ArLds {
-    double *red; double *xc; double *rbuf; double *aw;
+    double *red; NpScratch *np; double *xc; double *rbuf; double *aw;
     // P: leading dimension of the normal matrices = (max regressors) + 1, chosen by the host for the batch
     TSFA_HD static int scratch_doubles(int P) { return 2 * P * P + 6 * P + 64 + 16 + 48 + 40 + 128; }
     TSFA_HD size_t carve(unsigned char *base, int maxn, int P) {
         LdsCarve c{base, 0};
         red = c.take<double>(TSFA_RED_DOUBLES);
+        np = c.take<NpScratch>(1);
         xc = c.take<double>(maxn + 2);
         rbuf = c.take<double>(maxn + 2);
         aw = c.take<double>(scratch_doubles(P));
@@ -100,7 +101,7 @@ struct ArLds {
 };
 
 struct EntropyLds {
-    double *red; NpScratch *np; double *xs; double *thr;
+    double *red; NpScratch *np; double *xs; double *thr; unsigned short *perm;
     TSFA_HD size_t carve(unsigned char *base, int maxn, int nt) {
         (void)nt;
         LdsCarve c{base, 0};
@@ -108,6 +109,7 @@ struct EntropyLds {
         np = c.take<NpScratch>(1);
         xs = c.take<double>(maxn + 2);
         thr = c.take<double>(16);
+        perm = c.take<unsigned short>(tsfa_pow2_ceil(maxn));
         return c.off;
     }
 };
