@@ -1,17 +1,21 @@
 // Family ENTROPY: sample_entropy (fc.py:1701) and approximate_entropy (fc.py:1759).
 //
 // Both count, for every template i of length m (and m+1), the templates j whose Chebyshev distance is within a
-// tolerance r = c * np.std(x).  All requested tolerances (5 approximate-entropy r's + the sample-entropy 0.2)
-// share ONE sweep over the (i, j) template pairs: thread (lane) = row i, the loop runs over columns j, x[j..j+m]
-// is a wave-uniform broadcast read, and per-row counters live in registers.  Distances and comparisons are done in
-// float64 on the exact sample values so the counts are bit-identical to the reference's float64 arithmetic
-// (a float32 subtraction would mis-round |x_i - x_j| next to a threshold; see DESIGN.md "entropy exactness").
+// tolerance r = c * np.std(x).  Distances and comparisons are done in float64 on the exact sample values so the
+// counts are bit-identical to the reference's float64 arithmetic (a float32 subtraction would mis-round
+// |x_i - x_j| next to a threshold; see DESIGN.md "entropy exactness").  The series itself is kept in LDS in its
+// input precision (XT = float or double; float -> double is exact) to halve the footprint of float32 batches.
+//
+// Two sweeps are implemented for m = 2:
+//   entropy_sweep_sym  : every unordered pair once, per-template counters in LDS (the fast path)
+//   entropy_sweep_m2   : every ordered pair, counters in registers (no LDS counters; very long series)
 #ifndef TSFA_FAM_ENTROPY_H
 #define TSFA_FAM_ENTROPY_H
 
 #include "tsfa_common.h"
 
 #define TSFA_ENT_MAXK 8
+#define TSFA_ENT_GROUP 3   // thresholds per symmetric sweep (LDS holds one packed word per template per threshold)
 
 struct EntAcc {          // per-threshold accumulators of one sweep (template length m)
     double sum_log_m;    // sum_i log(C_m[i] / (N - m + 1))
@@ -20,15 +24,206 @@ struct EntAcc {          // per-threshold accumulators of one sweep (template le
     double sum_cnt_m1;   // sum_i C_{m+1}[i]
 };
 
-// One sweep for template length m = 2 with NK thresholds thr[0..NK).  Every thread returns the block totals.
-//
-// Pruning (exact): a pair can only match if |x_i - x_j| <= r_max, so the length-2 templates are sorted by their first
-// sample (perm[], bitonic sort in LDS) and each pass of nt rows -- a narrow band of values -- only visits the columns
-// whose first sample lies within r_max of that band (two binary searches).  For N(0,1) data and r_max = 0.9 sigma
-// this skips ~45% of the pairs.  xs[n] and xs[n+1] must hold +inf (the length-3 extension of the last templates then
-// never matches).
-template <int NK>
-TSFA_DEV void entropy_sweep_m2(const Blk &b, const double *xs, int n, const double *thr, const unsigned short *perm,
+#if TSFA_GPU
+#define TSFA_ENT_WAVE 64
+#define TSFA_ENT_G 4
+#else
+#define TSFA_ENT_WAVE 1
+#define TSFA_ENT_G 1
+#endif
+
+// number of lanes of the calling wavefront for which p holds (scalar ALU: s_bcnt1 of the compare mask)
+TSFA_DEV int wave_count(bool p) {
+#if TSFA_GPU
+    return __popcll(__ballot(p));
+#else
+    return p ? 1 : 0;
+#endif
+}
+
+TSFA_DEV void ent_lds_add(unsigned int *p, unsigned int v) {
+#if TSFA_GPU
+    __hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);  // ds_add_u32, no return
+#else
+    *p += v;
+#endif
+}
+
+struct EntCol { double x0, x1, x2; };
+struct EntIdx { int c[TSFA_ENT_G]; };
+
+TSFA_DEV EntIdx ent_load_idx(const unsigned short *perm, int q) {
+    EntIdx r;
+#if TSFA_GPU
+    const uint2 w = *reinterpret_cast<const uint2 *>(perm + q);  // q is a multiple of 4, perm is 16-byte aligned
+    r.c[0] = (int)(w.x & 0xFFFFu);
+    r.c[1] = (int)(w.x >> 16);
+    r.c[2] = (int)(w.y & 0xFFFFu);
+    r.c[3] = (int)(w.y >> 16);
+#else
+    for (int g = 0; g < TSFA_ENT_G; ++g) r.c[g] = perm[q + g];
+#endif
+    return r;
+}
+
+template <typename XT>
+TSFA_DEV void ent_load_cols(const XT *xs, const EntIdx &ix, EntCol *c) {
+#pragma unroll
+    for (int g = 0; g < TSFA_ENT_G; ++g) {
+        c[g].x0 = (double)xs[ix.c[g]];
+        c[g].x1 = (double)xs[ix.c[g] + 1];
+        c[g].x2 = (double)xs[ix.c[g] + 2];
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// Symmetric sweep.  The match relation is symmetric, so every unordered pair of templates is evaluated once.  Rows
+// and columns are both taken in the sorted order perm[] (templates sorted by their first sample).  A wavefront owns
+// a row block [q0, q0 + 64) of that order (blocks are dealt round-robin to the wavefronts of the workgroup):
+//   * diagonal block  -- columns [q0, q0 + 64): every lane counts its own row (all 64 columns, self included);
+//   * later columns   -- q in [q0 + 64, jhi), jhi = end of the r_max window of the block: lane i adds the pair to its
+//                        row counter, and the number of matching LANES (popcount of the compare mask, scalar ALU) is
+//                        what the COLUMN's template gains; the packed counts (c2 | c3 << 16) of four columns x NK
+//                        thresholds are placed in lanes 0..4NK-1 (v_writelane) and added to the LDS counters with
+//                        one ds_add_u32.
+// Earlier columns are never visited (their blocks visit us).  At the end of a pass the lanes add their row
+// counters to the same LDS counters; after a workgroup barrier cnt[q] holds the complete C_m / C_{m+1} of template
+// perm[q].  Column data of group g+1 is loaded while group g is evaluated and the perm[] indices one group further
+// ahead, so LDS latency is off the critical path.
+// Requirements: xs[n .. n+3] = +inf, perm[] padded with the index n up to roundup(n-1, 64) + 16 entries,
+// cnt[] holds (n + 8) * NK words.
+// ---------------------------------------------------------------------------------------------------------------
+template <int NK, typename XT>
+TSFA_DEV void entropy_sweep_sym(const Blk &b, const XT *xs, int n, const double *thr, const unsigned short *perm,
+                                unsigned int *cnt, EntAcc *acc) {
+    const int W = TSFA_ENT_WAVE;
+    const int nrow_m = n - 1;   // templates of length 2
+    const int nrow_m1 = n - 2;  // templates of length 3
+    const int lane = b.tid % W, wave = b.tid / W, nwave = b.nt / W;
+    double r[NK];
+    double rmax = 0.0;
+#pragma unroll
+    for (int k = 0; k < NK; ++k) { r[k] = thr[k]; rmax = fmax(rmax, r[k]); }
+    blk_sync();
+    for (int i = b.tid; i < (nrow_m + 8) * NK; i += b.nt) cnt[i] = 0u;
+    blk_sync();
+
+    const int npass = (nrow_m + W - 1) / W;
+    for (int pass = wave; pass < npass; pass += nwave) {
+        const int q0 = pass * W;
+        const int qi = q0 + lane;
+        const bool row_m = (qi < nrow_m);
+        const int ri = row_m ? (int)perm[qi] : n;  // xs[n ..] = +inf: an absent row never matches
+        const double xi0 = (double)xs[ri], xi1 = (double)xs[ri + 1], xi2 = (double)xs[ri + 2];
+        const int qlast = ((q0 + W < nrow_m) ? (q0 + W) : nrow_m) - 1;
+        const double band_hi = (double)xs[perm[qlast]];
+        const double key_hi = band_hi + rmax + 1e-9 * (fabs(band_hi) + rmax);
+        int jhi;
+        {
+            int lo = qlast + 1, hi = nrow_m;
+            while (lo < hi) { const int mid = (lo + hi) >> 1; if ((double)xs[perm[mid]] <= key_hi) lo = mid + 1; else hi = mid; }
+            jhi = lo;
+        }
+        const int qdiag_end = q0 + W;
+        int c2[NK], c3[NK];
+#pragma unroll
+        for (int k = 0; k < NK; ++k) { c2[k] = 0; c3[k] = 0; }
+
+        // ---- diagonal block: row counters only ----
+        int q = q0;
+        EntIdx ix = ent_load_idx(perm, q);
+        EntCol cur[TSFA_ENT_G];
+        ent_load_cols(xs, ix, cur);
+        ix = ent_load_idx(perm, q + TSFA_ENT_G);
+        for (; q < qdiag_end; q += TSFA_ENT_G) {
+            EntCol nxt[TSFA_ENT_G];
+            ent_load_cols(xs, ix, nxt);
+            ix = ent_load_idx(perm, q + 2 * TSFA_ENT_G);
+#pragma unroll
+            for (int g = 0; g < TSFA_ENT_G; ++g) {
+                const double d0 = fabs(xi0 - cur[g].x0), d1 = fabs(xi1 - cur[g].x1), d2 = fabs(xi2 - cur[g].x2);
+                const double m2 = fmax(d0, d1);
+                const double m3 = fmax(m2, d2);
+#pragma unroll
+                for (int k = 0; k < NK; ++k) {
+                    c2[k] += (m2 <= r[k]) ? 1 : 0;
+                    c3[k] += (m3 <= r[k]) ? 1 : 0;
+                }
+            }
+#pragma unroll
+            for (int g = 0; g < TSFA_ENT_G; ++g) cur[g] = nxt[g];
+        }
+        // ---- later columns: row counters + column counters (the first group's loads are already in flight) ----
+        for (; q < jhi; q += TSFA_ENT_G) {
+            EntCol nxt[TSFA_ENT_G];
+            ent_load_cols(xs, ix, nxt);
+            ix = ent_load_idx(perm, q + 2 * TSFA_ENT_G);
+            unsigned int colv = 0u;  // lane g * NK + k <- c2 | c3 << 16 of column q + g, threshold k
+#pragma unroll
+            for (int g = 0; g < TSFA_ENT_G; ++g) {
+                const double d0 = fabs(xi0 - cur[g].x0), d1 = fabs(xi1 - cur[g].x1), d2 = fabs(xi2 - cur[g].x2);
+                const double m2 = fmax(d0, d1);
+                const double m3 = fmax(m2, d2);
+#pragma unroll
+                for (int k = 0; k < NK; ++k) {
+                    const bool p2 = (m2 <= r[k]), p3 = (m3 <= r[k]);
+                    c2[k] += p2 ? 1 : 0;
+                    c3[k] += p3 ? 1 : 0;
+                    const unsigned int pk = (unsigned int)wave_count(p2) | ((unsigned int)wave_count(p3) << 16);
+#if TSFA_GPU
+                    asm("v_writelane_b32 %0, %1, %2" : "+v"(colv) : "s"(pk), "n"(g * NK + k));
+#else
+                    cnt[(q + g) * NK + k] += pk;
+#endif
+                }
+            }
+#if TSFA_GPU
+            if (lane < TSFA_ENT_G * NK) ent_lds_add(&cnt[q * NK + lane], colv);
+#endif
+#pragma unroll
+            for (int g = 0; g < TSFA_ENT_G; ++g) cur[g] = nxt[g];
+        }
+        if (row_m) {
+#pragma unroll
+            for (int k = 0; k < NK; ++k) ent_lds_add(&cnt[qi * NK + k], (unsigned int)c2[k] | ((unsigned int)c3[k] << 16));
+        }
+    }
+    blk_sync();
+    // ---- totals: cnt[q] is now complete for every template ----
+    double slm[NK], slm1[NK], scm[NK], scm1[NK];
+#pragma unroll
+    for (int k = 0; k < NK; ++k) { slm[k] = 0.0; slm1[k] = 0.0; scm[k] = 0.0; scm1[k] = 0.0; }
+    const double dm = (double)nrow_m, dm1 = (double)nrow_m1;
+    for (int q = b.tid; q < nrow_m; q += b.nt) {
+        const bool row_m1 = ((int)perm[q] < nrow_m1);
+#pragma unroll
+        for (int k = 0; k < NK; ++k) {
+            const unsigned int cc = cnt[q * NK + k];
+            const int t2 = (int)(cc & 0xFFFFu), t3 = (int)(cc >> 16);
+            scm[k] += (double)t2;
+            slm[k] += log((double)t2 / dm);
+            if (row_m1) {
+                scm1[k] += (double)t3;
+                slm1[k] += log((double)t3 / dm1);
+            }
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < NK; ++k) {
+        acc[k].sum_log_m = blk_sum(b, slm[k]);
+        acc[k].sum_log_m1 = blk_sum(b, slm1[k]);
+        acc[k].sum_cnt_m = blk_sum(b, scm[k]);
+        acc[k].sum_cnt_m1 = blk_sum(b, scm1[k]);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// Ordered-pair sweep (no LDS counters): thread = row i, the loop runs over the columns j of the row block's r_max
+// window, x[j..j+2] is a wave-uniform broadcast read, per-row counters live in registers.
+// xs[n], xs[n+1] must hold +inf (the length-3 extension of the last templates then never matches).
+// ---------------------------------------------------------------------------------------------------------------
+template <int NK, typename XT>
+TSFA_DEV void entropy_sweep_m2(const Blk &b, const XT *xs, int n, const double *thr, const unsigned short *perm,
                                EntAcc *acc) {
     const int nrow_m = n - 1;   // templates of length 2: i in [0, n-2]
     const int nrow_m1 = n - 2;  // templates of length 3: i in [0, n-3]
@@ -49,18 +244,18 @@ TSFA_DEV void entropy_sweep_m2(const Blk &b, const double *xs, int n, const doub
         const bool row_m = (qi < nrow_m);
         const int ri = row_m ? (int)perm[qi] : 0;
         const bool row_m1 = row_m && (ri < nrow_m1);
-        const double xi0 = xs[ri], xi1 = xs[ri + 1], xi2 = xs[ri + 2];
+        const double xi0 = (double)xs[ri], xi1 = (double)xs[ri + 1], xi2 = (double)xs[ri + 2];
         // column window: first samples within r_max of [band_lo, band_hi], widened by a rounding margin
-        const double band_lo = xs[perm[q0]], band_hi = xs[perm[q1 - 1]];
+        const double band_lo = (double)xs[perm[q0]], band_hi = (double)xs[perm[q1 - 1]];
         const double margin = 1e-9 * (fabs(band_lo) + fabs(band_hi) + rmax);
         const double key_lo = band_lo - rmax - margin, key_hi = band_hi + rmax + margin;
         int jlo, jhi;
         {
             int lo = 0, hi = nrow_m;
-            while (lo < hi) { const int mid = (lo + hi) >> 1; if (xs[perm[mid]] < key_lo) lo = mid + 1; else hi = mid; }
+            while (lo < hi) { const int mid = (lo + hi) >> 1; if ((double)xs[perm[mid]] < key_lo) lo = mid + 1; else hi = mid; }
             jlo = lo;
             lo = jlo; hi = nrow_m;
-            while (lo < hi) { const int mid = (lo + hi) >> 1; if (xs[perm[mid]] <= key_hi) lo = mid + 1; else hi = mid; }
+            while (lo < hi) { const int mid = (lo + hi) >> 1; if ((double)xs[perm[mid]] <= key_hi) lo = mid + 1; else hi = mid; }
             jhi = lo;
         }
         int c2[NK], c3[NK];
@@ -68,7 +263,7 @@ TSFA_DEV void entropy_sweep_m2(const Blk &b, const double *xs, int n, const doub
         for (int k = 0; k < NK; ++k) { c2[k] = 0; c3[k] = 0; }
         for (int q = jlo; q < jhi; ++q) {
             const int c = perm[q];
-            const double xj0 = xs[c], xj1 = xs[c + 1], xj2 = xs[c + 2];  // xs[n] = +inf: no length-3 template there
+            const double xj0 = (double)xs[c], xj1 = (double)xs[c + 1], xj2 = (double)xs[c + 2];
             const double d0 = fabs(xi0 - xj0), d1 = fabs(xi1 - xj1), d2 = fabs(xi2 - xj2);
             const double m2 = fmax(d0, d1);
             const double m3 = fmax(m2, d2);
@@ -100,7 +295,8 @@ TSFA_DEV void entropy_sweep_m2(const Blk &b, const double *xs, int n, const doub
 }
 
 // perm[0 .. n-2] = indices of the length-2 templates sorted by their first sample (ties by index); np2 = padded size
-TSFA_DEV void entropy_sort_templates(const Blk &b, const double *xs, int n, unsigned short *perm, int np2) {
+template <typename XT>
+TSFA_DEV void entropy_sort_templates(const Blk &b, const XT *xs, int n, unsigned short *perm, int np2) {
     const int nrow_m = n - 1;
     blk_sync();
     for (int i = b.tid; i < np2; i += b.nt) perm[i] = (unsigned short)((i < nrow_m) ? i : 0xFFFF);
@@ -112,7 +308,7 @@ TSFA_DEV void entropy_sort_templates(const Blk &b, const double *xs, int n, unsi
                 const int l = i | j;
                 const bool up = ((i & k) == 0);
                 const unsigned short a = perm[i], c = perm[l];
-                const double ka = (a == 0xFFFF) ? TSFA_INF : xs[a], kc = (c == 0xFFFF) ? TSFA_INF : xs[c];
+                const double ka = (a == 0xFFFF) ? TSFA_INF : (double)xs[a], kc = (c == 0xFFFF) ? TSFA_INF : (double)xs[c];
                 const bool gt = (ka > kc) || (ka == kc && a > c);
                 if (gt == up) {
                     perm[i] = c;
@@ -125,17 +321,18 @@ TSFA_DEV void entropy_sort_templates(const Blk &b, const double *xs, int n, unsi
 }
 
 // generic template length m (slow path; settings.py only uses m = 2)
-TSFA_DEV void entropy_sweep_generic(const Blk &b, const double *xs, int n, int m, double thr, EntAcc *acc) {
+template <typename XT>
+TSFA_DEV void entropy_sweep_generic(const Blk &b, const XT *xs, int n, int m, double thr, EntAcc *acc) {
     const int nrow_m = n - m + 1, nrow_m1 = n - m;
     double slm = 0.0, slm1 = 0.0, scm = 0.0, scm1 = 0.0;
     for (int i = b.tid; i < nrow_m; i += b.nt) {
         int cm = 0, cm1 = 0;
         for (int j = 0; j < nrow_m; ++j) {
             double d = 0.0;
-            for (int t = 0; t < m; ++t) d = fmax(d, fabs(xs[i + t] - xs[j + t]));
+            for (int t = 0; t < m; ++t) d = fmax(d, fabs((double)xs[i + t] - (double)xs[j + t]));
             cm += (d <= thr) ? 1 : 0;
             if (i < nrow_m1 && j < nrow_m1) {
-                d = fmax(d, fabs(xs[i + m] - xs[j + m]));
+                d = fmax(d, fabs((double)xs[i + m] - (double)xs[j + m]));
                 cm1 += (d <= thr) ? 1 : 0;
             }
         }
@@ -166,23 +363,26 @@ TSFA_DEV double sampen_from_acc(const EntAcc &a, int n, int m) {
 }
 
 // Evaluate the ENTROPY specs of one series.
-//   xs   : LDS, n + 2 doubles (xs[n], xs[n+1] are overwritten with +inf sentinels)
-//   thr  : LDS scratch >= TSFA_ENT_MAXK doubles;   perm : LDS, next_pow2(n) unsigned shorts
-TSFA_DEV void fam_entropy_series(const Blk &b, double *xs, int n, const TsfaSpec *specs, int nspecs,
-                                 double *out_row, double *thr, unsigned short *perm) {
+//   xs   : LDS, n + 4 elements in the input precision (xs[n .. n+3] are overwritten with +inf sentinels)
+//   thr  : LDS scratch >= 2 * TSFA_ENT_MAXK doubles
+//   perm : LDS, max(next_pow2(n), roundup(n, 64)) + 16 unsigned shorts
+//   cnt  : LDS, (n + 8) * TSFA_ENT_GROUP words, or null (-> ordered-pair sweep).  May alias b.np: the numpy-order
+//          sums are finished before the first sweep.
+template <typename XT>
+TSFA_DEV void fam_entropy_series(const Blk &b, XT *xs, int n, const TsfaSpec *specs, int nspecs, double *out_row,
+                                 double *thr, unsigned short *perm, unsigned int *cnt) {
     // np.std(x), numpy summation order (the tolerances are c * np.std(x))
     const double dn = (double)n;
-    const double mean = np_sum(b, n, [=](int i) { return xs[i]; }) / dn;
-    const double var = np_sum(b, n, [=](int i) { const double d = xs[i] - mean; return d * d; }) / dn;
+    const double mean = np_sum(b, n, [=](int i) { return (double)xs[i]; }) / dn;
+    const double var = np_sum(b, n, [=](int i) { const double d = (double)xs[i] - mean; return d * d; }) / dn;
     const double sd = sqrt(var);
     blk_sync();
-    if (b.tid == 0) { xs[n] = TSFA_INF; xs[n + 1] = TSFA_INF; }
+    if (b.tid == 0) { xs[n] = (XT)TSFA_INF; xs[n + 1] = (XT)TSFA_INF; xs[n + 2] = (XT)TSFA_INF; xs[n + 3] = (XT)TSFA_INF; }
     bool sorted = false;
 
     // m = 2 specs are batched TSFA_ENT_MAXK at a time
     int done = 0;
     while (done < nspecs) {
-        int idx[TSFA_ENT_MAXK];
         int nk = 0;
         int s = done;
         for (; s < nspecs && nk < TSFA_ENT_MAXK; ++s) {
@@ -190,40 +390,82 @@ TSFA_DEV void fam_entropy_series(const Blk &b, double *xs, int n, const TsfaSpec
             const bool is_m2 = (sp.calc == TSFA_C_SAMPLE_ENTROPY) ||
                                (sp.calc == TSFA_C_APPROXIMATE_ENTROPY && (int)sp.p[0] == 2);
             if (!is_m2) continue;
-            idx[nk] = s;
             blk_sync();
             if (b.tid == 0) thr[nk] = (sp.calc == TSFA_C_SAMPLE_ENTROPY) ? 0.2 * sd : sp.p[1] * sd;
             ++nk;
         }
+        const int first = done;
         done = s;
         if (nk == 0) break;
         blk_sync();
         if (b.tid == 0)
             for (int k = nk; k < TSFA_ENT_MAXK; ++k) thr[k] = -1.0;  // never matches
         blk_sync();
-        EntAcc acc[TSFA_ENT_MAXK];
-        if (n >= 3) {
-            if (!sorted) {
-                entropy_sort_templates(b, xs, n, perm, next_pow2(n - 1));
-                sorted = true;
-            }
-            if (nk <= 1) entropy_sweep_m2<1>(b, xs, n, thr, perm, acc);
-            else if (nk <= 2) entropy_sweep_m2<2>(b, xs, n, thr, perm, acc);
-            else if (nk <= 4) entropy_sweep_m2<4>(b, xs, n, thr, perm, acc);
-            else if (nk <= 6) entropy_sweep_m2<6>(b, xs, n, thr, perm, acc);
-            else entropy_sweep_m2<8>(b, xs, n, thr, perm, acc);
+        if (n >= 3 && !sorted) {
+            entropy_sort_templates(b, xs, n, perm, next_pow2(n - 1));
+            // pad: absent templates point at the +inf sentinels
+            const int padded = ((n - 1 + 63) / 64) * 64 + 16;
+            for (int i = n - 1 + b.tid; i < padded; i += b.nt) perm[i] = (unsigned short)n;
+            blk_sync();
+            sorted = true;
         }
-        for (int k = 0; k < nk; ++k) {
-            const TsfaSpec sp = specs[idx[k]];
-            double v;
-            if (sp.calc == TSFA_C_APPROXIMATE_ENTROPY) {
-                if (n <= 3) v = 0.0;  // N <= m + 1
-                else v = apen_from_acc(acc[k], n, 2);
-            } else {
-                if (n < 3) v = TSFA_NAN;  // no length-3 template: A = 0, B = 0 -> -log(0/0)
-                else v = sampen_from_acc(acc[k], n, 2);
+        // Thresholds are swept in ascending order in groups of <= TSFA_ENT_GROUP neighbours (a group of small
+        // tolerances only visits the narrow window of ITS largest one); rank[k] = position of threshold k.
+        double *gthr = thr + TSFA_ENT_MAXK;
+        const int gcap = (cnt != nullptr) ? TSFA_ENT_GROUP : TSFA_ENT_MAXK;
+        const int ngroups = (nk + gcap - 1) / gcap;
+        const int gsize = (nk + ngroups - 1) / ngroups;
+        for (int g0 = 0; g0 < nk; g0 += gsize) {
+            const int gn = (nk - g0 < gsize) ? (nk - g0) : gsize;
+            EntAcc ga[TSFA_ENT_MAXK];
+            if (n >= 3) {
+                blk_sync();
+                if (b.tid == 0) {
+                    for (int k = 0; k < TSFA_ENT_MAXK; ++k) gthr[k] = -1.0;
+                    for (int k = 0; k < nk; ++k) {  // rank of thr[k] among the batch (ties by index)
+                        int rk = 0;
+                        for (int o = 0; o < nk; ++o) rk += (thr[o] < thr[k] || (thr[o] == thr[k] && o < k)) ? 1 : 0;
+                        if (rk >= g0 && rk < g0 + gn) gthr[rk - g0] = thr[k];
+                    }
+                }
+                blk_sync();
+                if (cnt != nullptr) {
+                    if (gn <= 1) entropy_sweep_sym<1>(b, xs, n, gthr, perm, cnt, ga);
+                    else if (gn == 2) entropy_sweep_sym<2>(b, xs, n, gthr, perm, cnt, ga);
+                    else entropy_sweep_sym<3>(b, xs, n, gthr, perm, cnt, ga);
+                } else {
+                    if (gn <= 1) entropy_sweep_m2<1>(b, xs, n, gthr, perm, ga);
+                    else if (gn <= 2) entropy_sweep_m2<2>(b, xs, n, gthr, perm, ga);
+                    else if (gn <= 4) entropy_sweep_m2<4>(b, xs, n, gthr, perm, ga);
+                    else if (gn <= 6) entropy_sweep_m2<6>(b, xs, n, gthr, perm, ga);
+                    else entropy_sweep_m2<8>(b, xs, n, gthr, perm, ga);
+                }
             }
-            if (b.tid == 0) out_row[sp.col] = v;
+            // write the columns whose threshold belongs to this group
+            int k = 0;
+            for (int t = first; t < done; ++t) {
+                const TsfaSpec sp = specs[t];
+                const bool is_m2 = (sp.calc == TSFA_C_SAMPLE_ENTROPY) ||
+                                   (sp.calc == TSFA_C_APPROXIMATE_ENTROPY && (int)sp.p[0] == 2);
+                if (!is_m2) continue;
+                int rk = 0;
+                for (int o = 0; o < nk; ++o) rk += (thr[o] < thr[k] || (thr[o] == thr[k] && o < k)) ? 1 : 0;
+                ++k;
+                if (rk < g0 || rk >= g0 + gn) continue;
+                EntAcc a = ga[0];
+#pragma unroll
+                for (int u = 1; u < TSFA_ENT_MAXK; ++u)
+                    if (u == rk - g0) a = ga[u];
+                double v;
+                if (sp.calc == TSFA_C_APPROXIMATE_ENTROPY) {
+                    if (n <= 3) v = 0.0;  // N <= m + 1
+                    else v = apen_from_acc(a, n, 2);
+                } else {
+                    if (n < 3) v = TSFA_NAN;  // no length-3 template: A = 0, B = 0 -> -log(0/0)
+                    else v = sampen_from_acc(a, n, 2);
+                }
+                if (b.tid == 0) out_row[sp.col] = v;
+            }
         }
     }
     // generic m

@@ -322,6 +322,12 @@ int tsfa_extract(tsfa_plan *plan, const void *values, int32_t dtype, const int64
             }
             a.ar_P = P;
             aux = P;
+        } else if (f == TSFA_FAM_ENTROPY) {
+            // one wavefront per 64-template row block, up to four per series; the symmetric sweep needs 12 B of
+            // LDS counters per sample
+            const int waves = std::min(4, std::max(1, (maxn - 1 + 63) / 64));
+            a.nt = std::max(nt, 64 * waves);
+            a.ent_cnt = tsfa_entropy_lds_bytes(maxn, (int)esz, 1) <= TSFA_LDS_LIMIT ? 1 : 0;
         } else if (f == TSFA_FAM_SEQ) {
             // parse as many `bins` values side by side as LDS allows
             int group = std::min(a.nspecs, TSFA_LZ_MAX_GROUP);
@@ -332,7 +338,8 @@ int tsfa_extract(tsfa_plan *plan, const void *values, int32_t dtype, const int64
             a.ntab = group;
         }
         const size_t lds = (f == TSFA_FAM_SEQ) ? tsfa_seq_lds_bytes(maxn, a.ntab, a.seq_tab_entries, a.seq_edge_doubles)
-                                               : tsfa_family_lds_bytes(f, maxn, nt, aux);
+                           : (f == TSFA_FAM_ENTROPY) ? tsfa_entropy_lds_bytes(maxn, (int)esz, a.ent_cnt)
+                                                     : tsfa_family_lds_bytes(f, maxn, nt, aux);
         if (lds > TSFA_LDS_LIMIT)
             return fail(TSFA_ERR_TOO_LONG, std::string(fam_names[f]) + ": a series of " + std::to_string(maxn) +
                                                " samples needs " + std::to_string(lds) + " B of LDS (limit 163840)");

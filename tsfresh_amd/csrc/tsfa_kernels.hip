@@ -88,16 +88,19 @@ __global__ void k_ar(const T *__restrict__ values, const int64_t *__restrict__ o
 template <typename T>
 __global__ void k_entropy(const T *__restrict__ values, const int64_t *__restrict__ offsets, int64_t n_series,
                           const TsfaSpec *__restrict__ specs, int nspecs, double *__restrict__ out, int64_t ld,
-                          int maxn) {
+                          int maxn, int with_cnt) {
     const int64_t sidx = blockIdx.x;
     if (sidx >= n_series) return;
     const int64_t off = offsets[sidx];
     const int n = (int)(offsets[sidx + 1] - off);
     EntropyLds L;
-    L.carve(tsfa_smem, maxn, blockDim.x);
+    L.carve(tsfa_smem, maxn, (int)sizeof(T), with_cnt);
     Blk b{(int)threadIdx.x, (int)blockDim.x, L.red, L.np};
-    stage_series(b, values + off, n, L.xs);
-    fam_entropy_series(b, L.xs, n, specs, nspecs, out + sidx * ld, L.thr, L.perm);
+    T *xs = (T *)L.xs;  // staged in the input precision (float -> double is exact, converted at use)
+    const T *g = values + off;
+    for (int i = b.tid; i < n; i += b.nt) xs[i] = g[i];
+    blk_sync();
+    fam_entropy_series<T>(b, xs, n, specs, nspecs, out + sidx * ld, L.thr, L.perm, L.cnt);
 }
 
 template <typename T>
@@ -255,9 +258,10 @@ static int launch_all_t(const TsfaLaunch &a, const T *values) {
         k_ar<T><<<grid, nt, lds, st>>>(values, a.offsets, a.n_series, a.specs, a.nspecs, a.out, a.ld, a.maxn, a.ar_P);
     } else if (a.fam == TSFA_FAM_ENTROPY) {
         EntropyLds L;
-        const size_t lds = L.carve(nullptr, a.maxn, nt);
+        const size_t lds = L.carve(nullptr, a.maxn, (int)sizeof(T), a.ent_cnt);
         if ((rc = set_lds(k_entropy<T>, lds))) return rc;
-        k_entropy<T><<<grid, nt, lds, st>>>(values, a.offsets, a.n_series, a.specs, a.nspecs, a.out, a.ld, a.maxn);
+        k_entropy<T><<<grid, nt, lds, st>>>(values, a.offsets, a.n_series, a.specs, a.nspecs, a.out, a.ld, a.maxn,
+                                            a.ent_cnt);
     } else if (a.fam == TSFA_FAM_SEQ) {
         SeqLds L;
         const size_t lds = L.carve(nullptr, a.maxn, a.ntab, a.seq_tab_entries, a.seq_edge_doubles);
@@ -277,6 +281,11 @@ static int launch_all_t(const TsfaLaunch &a, const T *values) {
     return 0;
 }
 
+size_t tsfa_entropy_lds_bytes(int maxn, int elem, int with_cnt) {
+    EntropyLds L;
+    return L.carve(nullptr, maxn, elem, with_cnt);
+}
+
 size_t tsfa_seq_lds_bytes(int maxn, int group, int tab_entries, int edge_doubles) {
     SeqLds L;
     return L.carve(nullptr, maxn, group, tab_entries, edge_doubles);
@@ -288,7 +297,6 @@ size_t tsfa_family_lds_bytes(int fam, int maxn, int nt, int aux) {
     case TSFA_FAM_SORT: { SortLds L; return L.carve(nullptr, maxn, nt); }
     case TSFA_FAM_SPECTRAL: { SpectralLds L; return L.carve(nullptr, maxn, aux); }
     case TSFA_FAM_AR: { ArLds L; return L.carve(nullptr, maxn, aux); }
-    case TSFA_FAM_ENTROPY: { EntropyLds L; return L.carve(nullptr, maxn, nt); }
     case TSFA_FAM_CWT: { CwtPeaksLayout L; return L.carve(nullptr, maxn, aux); }
     default: return 0;
     }

@@ -31,6 +31,7 @@ struct TsfaLaunch {
     int seq_edge_doubles;   // SEQ: bin edges of the largest group
     int ar_P;               // AR: leading dimension of the normal matrices
     int cwt_rowv;           // CWT peaks: second CWT row resident in LDS
+    int ent_cnt;            // ENTROPY: per-template LDS counters (symmetric sweep)
 };
 
 struct TsfaCwtLaunch {
@@ -48,6 +49,7 @@ struct TsfaCwtLaunch {
 };
 
 size_t tsfa_family_lds_bytes(int fam, int maxn, int nt, int aux);
+size_t tsfa_entropy_lds_bytes(int maxn, int elem, int with_cnt);
 size_t tsfa_seq_lds_bytes(int maxn, int group, int tab_entries, int edge_doubles);
 int tsfa_launch_family(const TsfaLaunch &a);
 int tsfa_launch_cwt(const TsfaCwtLaunch &a);

@@ -101,15 +101,24 @@ struct ArLds {
 };
 
 struct EntropyLds {
-    double *red; NpScratch *np; double *xs; double *thr; unsigned short *perm;
-    TSFA_HD size_t carve(unsigned char *base, int maxn, int nt) {
-        (void)nt;
+    double *red; NpScratch *np; void *xs; double *thr; unsigned short *perm; unsigned int *cnt;
+    // elem: bytes per staged sample (4 = float32 input, 8 = float64); with_cnt: LDS counters of the symmetric sweep
+    TSFA_HD size_t carve(unsigned char *base, int maxn, int elem, int with_cnt) {
         LdsCarve c{base, 0};
         red = c.take<double>(TSFA_RED_DOUBLES);
-        np = c.take<NpScratch>(1);
-        xs = c.take<double>(maxn + 2);
         thr = c.take<double>(16);
-        perm = c.take<unsigned short>(tsfa_pow2_ceil(maxn));
+        xs = c.take<unsigned char>((size_t)(maxn + 4) * elem);
+        const int np2 = tsfa_pow2_ceil(maxn);
+        perm = c.take<unsigned short>(((np2 > 64) ? np2 : 64) + 16);
+        if (with_cnt) {  // the numpy-order scratch is dead before the first sweep: share its storage
+            const size_t cb = (size_t)(maxn + 8) * 3 * sizeof(unsigned int);
+            unsigned char *u = c.take<unsigned char>(cb > sizeof(NpScratch) ? cb : sizeof(NpScratch));
+            np = (NpScratch *)u;
+            cnt = (unsigned int *)u;
+        } else {
+            np = c.take<NpScratch>(1);
+            cnt = nullptr;
+        }
         return c.off;
     }
 };
