@@ -112,10 +112,10 @@ extern "C" int tsfa_emul_extract(const tsfa_feature_spec *specs, int n_specs, co
             std::vector<double> thr(16), xe(xs.begin(), xs.begin() + n);
             xe.resize(n + 8, 0.0);
             std::vector<unsigned short> perm(tsfa_pow2_ceil(maxn) + 96);
-            std::vector<unsigned int> cnt((size_t)(maxn + 8) * 3);
+            std::vector<unsigned int> cnt((size_t)(maxn + 16) * 3), refs(perm.size());
             // odd series exercise the ordered-pair sweep (no LDS counters)
             fam_entropy_series<double>(b, xe.data(), n, fam[TSFA_FAM_ENTROPY].data(), (int)fam[TSFA_FAM_ENTROPY].size(),
-                                       row, thr.data(), perm.data(), (s % 2) ? nullptr : cnt.data());
+                                       row, thr.data(), perm.data(), refs.data(), (s % 2) ? nullptr : cnt.data());
         }
         if (!fam[TSFA_FAM_SEQ].empty()) {
             const int group = 2;  // exercise the multi-round path

@@ -3,8 +3,7 @@
 // Both count, for every template i of length m (and m+1), the templates j whose Chebyshev distance is within a
 // tolerance r = c * np.std(x).  Distances and comparisons are done in float64 on the exact sample values so the
 // counts are bit-identical to the reference's float64 arithmetic (a float32 subtraction would mis-round
-// |x_i - x_j| next to a threshold; see DESIGN.md "entropy exactness").  The series itself is kept in LDS in its
-// input precision (XT = float or double; float -> double is exact) to halve the footprint of float32 batches.
+// |x_i - x_j| next to a threshold; see DESIGN.md "entropy exactness").
 //
 // Two sweeps are implemented for m = 2:
 //   entropy_sweep_sym  : every unordered pair once, per-template counters in LDS (the fast path)
@@ -50,29 +49,58 @@ TSFA_DEV void ent_lds_add(unsigned int *p, unsigned int v) {
 }
 
 struct EntCol { double x0, x1, x2; };
-struct EntIdx { int c[TSFA_ENT_G]; };
 
-TSFA_DEV EntIdx ent_load_idx(const unsigned short *perm, int q) {
-    EntIdx r;
+// Reference to the first sample of a template: on the GPU the absolute LDS byte address of xs[idx] (a ds_read
+// address register as it stands: no scaling, no base add), in the emulation the index itself.
+typedef unsigned int ent_ref;
 #if TSFA_GPU
-    const uint2 w = *reinterpret_cast<const uint2 *>(perm + q);  // q is a multiple of 4, perm is 16-byte aligned
-    r.c[0] = (int)(w.x & 0xFFFFu);
-    r.c[1] = (int)(w.x >> 16);
-    r.c[2] = (int)(w.y & 0xFFFFu);
-    r.c[3] = (int)(w.y >> 16);
-#else
-    for (int g = 0; g < TSFA_ENT_G; ++g) r.c[g] = perm[q + g];
-#endif
-    return r;
+typedef __attribute__((address_space(3))) const double *ent_lds_cdp;
+TSFA_DEV ent_ref ent_make_ref(const double *xs, int idx) {
+    return (ent_ref)(uintptr_t)(__attribute__((address_space(3))) const void *)(xs + idx);
 }
+TSFA_DEV void ent_load_group(const double *, const ent_ref *refs, int q, EntCol *c) {
+    const uint4 a = *reinterpret_cast<const uint4 *>(refs + q);  // ds_read_b128: q is a multiple of 4, refs 16-B aligned
+    const ent_lds_cdp p0 = (ent_lds_cdp)a.x, p1 = (ent_lds_cdp)a.y, p2 = (ent_lds_cdp)a.z, p3 = (ent_lds_cdp)a.w;
+    c[0].x0 = p0[0]; c[0].x1 = p0[1]; c[0].x2 = p0[2];
+    c[1].x0 = p1[0]; c[1].x1 = p1[1]; c[1].x2 = p1[2];
+    c[2].x0 = p2[0]; c[2].x1 = p2[1]; c[2].x2 = p2[2];
+    c[3].x0 = p3[0]; c[3].x1 = p3[1]; c[3].x2 = p3[2];
+}
+#else
+TSFA_DEV ent_ref ent_make_ref(const double *, int idx) { return (ent_ref)idx; }
+TSFA_DEV void ent_load_group(const double *xs, const ent_ref *refs, int q, EntCol *c) {
+    for (int g = 0; g < TSFA_ENT_G; ++g) { c[g].x0 = xs[refs[q + g]]; c[g].x1 = xs[refs[q + g] + 1]; c[g].x2 = xs[refs[q + g] + 2]; }
+}
+#endif
 
-template <typename XT>
-TSFA_DEV void ent_load_cols(const XT *xs, const EntIdx &ix, EntCol *c) {
+// One group of TSFA_ENT_G columns against the lane's row.  COL: also hand the per-column match counts of the
+// wavefront (popcount of the compare masks) to lanes 0 .. G*NK-1 of colv (c2 | c3 << 16).
+template <int NK, bool COL>
+TSFA_DEV void ent_eval_group(double xi0, double xi1, double xi2, const EntCol *c, const double *r, int *c2, int *c3,
+                             unsigned int &colv, unsigned int *cnt_emul) {
 #pragma unroll
     for (int g = 0; g < TSFA_ENT_G; ++g) {
-        c[g].x0 = (double)xs[ix.c[g]];
-        c[g].x1 = (double)xs[ix.c[g] + 1];
-        c[g].x2 = (double)xs[ix.c[g] + 2];
+        const double d0 = fabs(xi0 - c[g].x0), d1 = fabs(xi1 - c[g].x1), d2 = fabs(xi2 - c[g].x2);
+        const double m2 = fmax(d0, d1);
+        const double m3 = fmax(m2, d2);
+#pragma unroll
+        for (int k = 0; k < NK; ++k) {
+#if TSFA_GPU
+            // v_cmp -> SGPR-pair mask; the row counter takes the mask as carry-in (one VALU op per predicate)
+            const unsigned long long k2 = __ballot(m2 <= r[k]), k3 = __ballot(m3 <= r[k]);
+            asm("v_addc_co_u32_e64 %0, vcc, 0, %0, %1" : "+v"(c2[k]) : "s"(k2) : "vcc");
+            asm("v_addc_co_u32_e64 %0, vcc, 0, %0, %1" : "+v"(c3[k]) : "s"(k3) : "vcc");
+            if (COL) {
+                const unsigned int pk = (unsigned int)__popcll(k2) | ((unsigned int)__popcll(k3) << 16);
+                asm("v_writelane_b32 %0, %1, %2" : "+v"(colv) : "s"(pk), "n"(g * NK + k));
+            }
+#else
+            const bool p2 = (m2 <= r[k]), p3 = (m3 <= r[k]);
+            c2[k] += p2 ? 1 : 0;
+            c3[k] += p3 ? 1 : 0;
+            if (COL) cnt_emul[g * NK + k] += (p2 ? 1u : 0u) | ((p3 ? 1u : 0u) << 16);
+#endif
+        }
     }
 }
 
@@ -88,15 +116,16 @@ TSFA_DEV void ent_load_cols(const XT *xs, const EntIdx &ix, EntCol *c) {
 //                        one ds_add_u32.
 // Earlier columns are never visited (their blocks visit us).  At the end of a pass the lanes add their row
 // counters to the same LDS counters; after a workgroup barrier cnt[q] holds the complete C_m / C_{m+1} of template
-// perm[q].  Column data of group g+1 is loaded while group g is evaluated and the perm[] indices one group further
-// ahead, so LDS latency is off the critical path.
-// Requirements: xs[n .. n+3] = +inf, perm[] padded with the index n up to roundup(n-1, 64) + 16 entries,
-// cnt[] holds (n + 8) * NK words.
+// perm[q].  Column groups are double-buffered in registers (the loads of the next group are issued before the
+// current one is evaluated) and addressed through refs[] = absolute LDS addresses, so the inner loop carries no
+// address arithmetic and no LDS latency.
+// Requirements: xs[n .. n+3] = +inf; perm[] / refs[] padded with the template n (the sentinels) up to
+// roundup(n-1, 64) + 32 entries; cnt[] holds (n + 16) * NK words.
 // ---------------------------------------------------------------------------------------------------------------
-template <int NK, typename XT>
-TSFA_DEV void entropy_sweep_sym(const Blk &b, const XT *xs, int n, const double *thr, const unsigned short *perm,
-                                unsigned int *cnt, EntAcc *acc) {
-    const int W = TSFA_ENT_WAVE;
+template <int NK>
+TSFA_DEV void entropy_sweep_sym(const Blk &b, const double *xs, int n, const double *thr, const unsigned short *perm,
+                                const ent_ref *refs, unsigned int *cnt, EntAcc *acc) {
+    const int W = TSFA_ENT_WAVE, G = TSFA_ENT_G;
     const int nrow_m = n - 1;   // templates of length 2
     const int nrow_m1 = n - 2;  // templates of length 3
     const int lane = b.tid % W, wave = b.tid / W, nwave = b.nt / W;
@@ -105,7 +134,7 @@ TSFA_DEV void entropy_sweep_sym(const Blk &b, const XT *xs, int n, const double 
 #pragma unroll
     for (int k = 0; k < NK; ++k) { r[k] = thr[k]; rmax = fmax(rmax, r[k]); }
     blk_sync();
-    for (int i = b.tid; i < (nrow_m + 8) * NK; i += b.nt) cnt[i] = 0u;
+    for (int i = b.tid; i < (nrow_m + 16) * NK; i += b.nt) cnt[i] = 0u;
     blk_sync();
 
     const int npass = (nrow_m + W - 1) / W;
@@ -114,75 +143,56 @@ TSFA_DEV void entropy_sweep_sym(const Blk &b, const XT *xs, int n, const double 
         const int qi = q0 + lane;
         const bool row_m = (qi < nrow_m);
         const int ri = row_m ? (int)perm[qi] : n;  // xs[n ..] = +inf: an absent row never matches
-        const double xi0 = (double)xs[ri], xi1 = (double)xs[ri + 1], xi2 = (double)xs[ri + 2];
+        const double xi0 = xs[ri], xi1 = xs[ri + 1], xi2 = xs[ri + 2];
         const int qlast = ((q0 + W < nrow_m) ? (q0 + W) : nrow_m) - 1;
-        const double band_hi = (double)xs[perm[qlast]];
+        const double band_hi = xs[perm[qlast]];
         const double key_hi = band_hi + rmax + 1e-9 * (fabs(band_hi) + rmax);
         int jhi;
         {
             int lo = qlast + 1, hi = nrow_m;
-            while (lo < hi) { const int mid = (lo + hi) >> 1; if ((double)xs[perm[mid]] <= key_hi) lo = mid + 1; else hi = mid; }
+            while (lo < hi) { const int mid = (lo + hi) >> 1; if (xs[perm[mid]] <= key_hi) lo = mid + 1; else hi = mid; }
             jhi = lo;
         }
         const int qdiag_end = q0 + W;
         int c2[NK], c3[NK];
 #pragma unroll
         for (int k = 0; k < NK; ++k) { c2[k] = 0; c3[k] = 0; }
+        unsigned int colv = 0u;
 
-        // ---- diagonal block: row counters only ----
+        // ---- diagonal block: row counters only (W / G groups: an even number on the GPU) ----
+        EntCol ca[TSFA_ENT_G], cb[TSFA_ENT_G];
         int q = q0;
-        EntIdx ix = ent_load_idx(perm, q);
-        EntCol cur[TSFA_ENT_G];
-        ent_load_cols(xs, ix, cur);
-        ix = ent_load_idx(perm, q + TSFA_ENT_G);
-        for (; q < qdiag_end; q += TSFA_ENT_G) {
-            EntCol nxt[TSFA_ENT_G];
-            ent_load_cols(xs, ix, nxt);
-            ix = ent_load_idx(perm, q + 2 * TSFA_ENT_G);
-#pragma unroll
-            for (int g = 0; g < TSFA_ENT_G; ++g) {
-                const double d0 = fabs(xi0 - cur[g].x0), d1 = fabs(xi1 - cur[g].x1), d2 = fabs(xi2 - cur[g].x2);
-                const double m2 = fmax(d0, d1);
-                const double m3 = fmax(m2, d2);
-#pragma unroll
-                for (int k = 0; k < NK; ++k) {
-                    c2[k] += (m2 <= r[k]) ? 1 : 0;
-                    c3[k] += (m3 <= r[k]) ? 1 : 0;
-                }
-            }
-#pragma unroll
-            for (int g = 0; g < TSFA_ENT_G; ++g) cur[g] = nxt[g];
-        }
-        // ---- later columns: row counters + column counters (the first group's loads are already in flight) ----
-        for (; q < jhi; q += TSFA_ENT_G) {
-            EntCol nxt[TSFA_ENT_G];
-            ent_load_cols(xs, ix, nxt);
-            ix = ent_load_idx(perm, q + 2 * TSFA_ENT_G);
-            unsigned int colv = 0u;  // lane g * NK + k <- c2 | c3 << 16 of column q + g, threshold k
-#pragma unroll
-            for (int g = 0; g < TSFA_ENT_G; ++g) {
-                const double d0 = fabs(xi0 - cur[g].x0), d1 = fabs(xi1 - cur[g].x1), d2 = fabs(xi2 - cur[g].x2);
-                const double m2 = fmax(d0, d1);
-                const double m3 = fmax(m2, d2);
-#pragma unroll
-                for (int k = 0; k < NK; ++k) {
-                    const bool p2 = (m2 <= r[k]), p3 = (m3 <= r[k]);
-                    c2[k] += p2 ? 1 : 0;
-                    c3[k] += p3 ? 1 : 0;
-                    const unsigned int pk = (unsigned int)wave_count(p2) | ((unsigned int)wave_count(p3) << 16);
+        ent_load_group(xs, refs, q, ca);
 #if TSFA_GPU
-                    asm("v_writelane_b32 %0, %1, %2" : "+v"(colv) : "s"(pk), "n"(g * NK + k));
+        for (; q < qdiag_end; q += 2 * G) {
+            ent_load_group(xs, refs, q + G, cb);
+            ent_eval_group<NK, false>(xi0, xi1, xi2, ca, r, c2, c3, colv, nullptr);
+            ent_load_group(xs, refs, q + 2 * G, ca);
+            ent_eval_group<NK, false>(xi0, xi1, xi2, cb, r, c2, c3, colv, nullptr);
+        }
+        // ---- later columns: row counters + column counters; a trailing odd group lies beyond the window and
+        //      matches nothing (it adds zeros) ----
+        for (; q < jhi; q += 2 * G) {
+            ent_load_group(xs, refs, q + G, cb);
+            colv = 0u;
+            ent_eval_group<NK, true>(xi0, xi1, xi2, ca, r, c2, c3, colv, nullptr);
+            if (lane < G * NK) ent_lds_add(&cnt[q * NK + lane], colv);
+            ent_load_group(xs, refs, q + 2 * G, ca);
+            colv = 0u;
+            ent_eval_group<NK, true>(xi0, xi1, xi2, cb, r, c2, c3, colv, nullptr);
+            if (lane < G * NK) ent_lds_add(&cnt[(q + G) * NK + lane], colv);
+        }
 #else
-                    cnt[(q + g) * NK + k] += pk;
-#endif
-                }
-            }
-#if TSFA_GPU
-            if (lane < TSFA_ENT_G * NK) ent_lds_add(&cnt[q * NK + lane], colv);
-#endif
-#pragma unroll
-            for (int g = 0; g < TSFA_ENT_G; ++g) cur[g] = nxt[g];
+        (void)cb;
+        for (; q < qdiag_end; q += G) {
+            ent_eval_group<NK, false>(xi0, xi1, xi2, ca, r, c2, c3, colv, nullptr);
+            ent_load_group(xs, refs, q + G, ca);
         }
+        for (; q < jhi; q += G) {
+            ent_eval_group<NK, true>(xi0, xi1, xi2, ca, r, c2, c3, colv, &cnt[q * NK]);
+            ent_load_group(xs, refs, q + G, ca);
+        }
+#endif
         if (row_m) {
 #pragma unroll
             for (int k = 0; k < NK; ++k) ent_lds_add(&cnt[qi * NK + k], (unsigned int)c2[k] | ((unsigned int)c3[k] << 16));
@@ -365,12 +375,13 @@ TSFA_DEV double sampen_from_acc(const EntAcc &a, int n, int m) {
 // Evaluate the ENTROPY specs of one series.
 //   xs   : LDS, n + 4 elements in the input precision (xs[n .. n+3] are overwritten with +inf sentinels)
 //   thr  : LDS scratch >= 2 * TSFA_ENT_MAXK doubles
-//   perm : LDS, max(next_pow2(n), roundup(n, 64)) + 16 unsigned shorts
-//   cnt  : LDS, (n + 8) * TSFA_ENT_GROUP words, or null (-> ordered-pair sweep).  May alias b.np: the numpy-order
-//          sums are finished before the first sweep.
+//   perm : LDS, max(next_pow2(n), 64) + 32 unsigned shorts
+//   refs : LDS, as many ent_ref as perm (symmetric sweep only)
+//   cnt  : LDS, (n + 16) * TSFA_ENT_GROUP words, or null (-> ordered-pair sweep).  May alias b.np: the numpy-order
+//          sums are finished before the first sweep.  The symmetric sweep needs XT = double.
 template <typename XT>
 TSFA_DEV void fam_entropy_series(const Blk &b, XT *xs, int n, const TsfaSpec *specs, int nspecs, double *out_row,
-                                 double *thr, unsigned short *perm, unsigned int *cnt) {
+                                 double *thr, unsigned short *perm, ent_ref *refs, unsigned int *cnt) {
     // np.std(x), numpy summation order (the tolerances are c * np.std(x))
     const double dn = (double)n;
     const double mean = np_sum(b, n, [=](int i) { return (double)xs[i]; }) / dn;
@@ -404,9 +415,13 @@ TSFA_DEV void fam_entropy_series(const Blk &b, XT *xs, int n, const TsfaSpec *sp
         if (n >= 3 && !sorted) {
             entropy_sort_templates(b, xs, n, perm, next_pow2(n - 1));
             // pad: absent templates point at the +inf sentinels
-            const int padded = ((n - 1 + 63) / 64) * 64 + 16;
+            const int padded = ((n - 1 + 63) / 64) * 64 + 32;
             for (int i = n - 1 + b.tid; i < padded; i += b.nt) perm[i] = (unsigned short)n;
             blk_sync();
+            if (cnt != nullptr) {
+                for (int i = b.tid; i < padded; i += b.nt) refs[i] = ent_make_ref((const double *)(const void *)xs, (int)perm[i]);
+                blk_sync();
+            }
             sorted = true;
         }
         // Thresholds are swept in ascending order in groups of <= TSFA_ENT_GROUP neighbours (a group of small
@@ -430,9 +445,10 @@ TSFA_DEV void fam_entropy_series(const Blk &b, XT *xs, int n, const TsfaSpec *sp
                 }
                 blk_sync();
                 if (cnt != nullptr) {
-                    if (gn <= 1) entropy_sweep_sym<1>(b, xs, n, gthr, perm, cnt, ga);
-                    else if (gn == 2) entropy_sweep_sym<2>(b, xs, n, gthr, perm, cnt, ga);
-                    else entropy_sweep_sym<3>(b, xs, n, gthr, perm, cnt, ga);
+                    const double *xd = (const double *)(const void *)xs;  // cnt != null implies XT = double
+                    if (gn <= 1) entropy_sweep_sym<1>(b, xd, n, gthr, perm, refs, cnt, ga);
+                    else if (gn == 2) entropy_sweep_sym<2>(b, xd, n, gthr, perm, refs, cnt, ga);
+                    else entropy_sweep_sym<3>(b, xd, n, gthr, perm, refs, cnt, ga);
                 } else {
                     if (gn <= 1) entropy_sweep_m2<1>(b, xs, n, gthr, perm, ga);
                     else if (gn <= 2) entropy_sweep_m2<2>(b, xs, n, gthr, perm, ga);

@@ -327,7 +327,7 @@ int tsfa_extract(tsfa_plan *plan, const void *values, int32_t dtype, const int64
             // LDS counters per sample
             const int waves = std::min(4, std::max(1, (maxn - 1 + 63) / 64));
             a.nt = std::max(nt, 64 * waves);
-            a.ent_cnt = tsfa_entropy_lds_bytes(maxn, (int)esz, 1) <= TSFA_LDS_LIMIT ? 1 : 0;
+            a.ent_cnt = tsfa_entropy_lds_bytes(maxn, 1) <= TSFA_LDS_LIMIT ? 1 : 0;
         } else if (f == TSFA_FAM_SEQ) {
             // parse as many `bins` values side by side as LDS allows
             int group = std::min(a.nspecs, TSFA_LZ_MAX_GROUP);
@@ -338,7 +338,7 @@ int tsfa_extract(tsfa_plan *plan, const void *values, int32_t dtype, const int64
             a.ntab = group;
         }
         const size_t lds = (f == TSFA_FAM_SEQ) ? tsfa_seq_lds_bytes(maxn, a.ntab, a.seq_tab_entries, a.seq_edge_doubles)
-                           : (f == TSFA_FAM_ENTROPY) ? tsfa_entropy_lds_bytes(maxn, (int)esz, a.ent_cnt)
+                           : (f == TSFA_FAM_ENTROPY) ? tsfa_entropy_lds_bytes(maxn, a.ent_cnt)
                                                      : tsfa_family_lds_bytes(f, maxn, nt, aux);
         if (lds > TSFA_LDS_LIMIT)
             return fail(TSFA_ERR_TOO_LONG, std::string(fam_names[f]) + ": a series of " + std::to_string(maxn) +

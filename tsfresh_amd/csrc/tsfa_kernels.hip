@@ -94,13 +94,10 @@ __global__ void k_entropy(const T *__restrict__ values, const int64_t *__restric
     const int64_t off = offsets[sidx];
     const int n = (int)(offsets[sidx + 1] - off);
     EntropyLds L;
-    L.carve(tsfa_smem, maxn, (int)sizeof(T), with_cnt);
+    L.carve(tsfa_smem, maxn, with_cnt);
     Blk b{(int)threadIdx.x, (int)blockDim.x, L.red, L.np};
-    T *xs = (T *)L.xs;  // staged in the input precision (float -> double is exact, converted at use)
-    const T *g = values + off;
-    for (int i = b.tid; i < n; i += b.nt) xs[i] = g[i];
-    blk_sync();
-    fam_entropy_series<T>(b, xs, n, specs, nspecs, out + sidx * ld, L.thr, L.perm, L.cnt);
+    stage_series(b, values + off, n, L.xs);
+    fam_entropy_series<double>(b, L.xs, n, specs, nspecs, out + sidx * ld, L.thr, L.perm, L.refs, L.cnt);
 }
 
 template <typename T>
@@ -258,7 +255,7 @@ static int launch_all_t(const TsfaLaunch &a, const T *values) {
         k_ar<T><<<grid, nt, lds, st>>>(values, a.offsets, a.n_series, a.specs, a.nspecs, a.out, a.ld, a.maxn, a.ar_P);
     } else if (a.fam == TSFA_FAM_ENTROPY) {
         EntropyLds L;
-        const size_t lds = L.carve(nullptr, a.maxn, (int)sizeof(T), a.ent_cnt);
+        const size_t lds = L.carve(nullptr, a.maxn, a.ent_cnt);
         if ((rc = set_lds(k_entropy<T>, lds))) return rc;
         k_entropy<T><<<grid, nt, lds, st>>>(values, a.offsets, a.n_series, a.specs, a.nspecs, a.out, a.ld, a.maxn,
                                             a.ent_cnt);
@@ -281,9 +278,9 @@ static int launch_all_t(const TsfaLaunch &a, const T *values) {
     return 0;
 }
 
-size_t tsfa_entropy_lds_bytes(int maxn, int elem, int with_cnt) {
+size_t tsfa_entropy_lds_bytes(int maxn, int with_cnt) {
     EntropyLds L;
-    return L.carve(nullptr, maxn, elem, with_cnt);
+    return L.carve(nullptr, maxn, with_cnt);
 }
 
 size_t tsfa_seq_lds_bytes(int maxn, int group, int tab_entries, int edge_doubles) {

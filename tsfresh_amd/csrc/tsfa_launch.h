@@ -49,7 +49,7 @@ struct TsfaCwtLaunch {
 };
 
 size_t tsfa_family_lds_bytes(int fam, int maxn, int nt, int aux);
-size_t tsfa_entropy_lds_bytes(int maxn, int elem, int with_cnt);
+size_t tsfa_entropy_lds_bytes(int maxn, int with_cnt);
 size_t tsfa_seq_lds_bytes(int maxn, int group, int tab_entries, int edge_doubles);
 int tsfa_launch_family(const TsfaLaunch &a);
 int tsfa_launch_cwt(const TsfaCwtLaunch &a);

@@ -101,22 +101,25 @@ struct ArLds {
 };
 
 struct EntropyLds {
-    double *red; NpScratch *np; void *xs; double *thr; unsigned short *perm; unsigned int *cnt;
-    // elem: bytes per staged sample (4 = float32 input, 8 = float64); with_cnt: LDS counters of the symmetric sweep
-    TSFA_HD size_t carve(unsigned char *base, int maxn, int elem, int with_cnt) {
+    double *red; NpScratch *np; double *xs; double *thr; unsigned short *perm; unsigned int *refs; unsigned int *cnt;
+    // with_cnt: per-template LDS counters + template references of the symmetric sweep (fam_entropy.h)
+    TSFA_HD size_t carve(unsigned char *base, int maxn, int with_cnt) {
         LdsCarve c{base, 0};
         red = c.take<double>(TSFA_RED_DOUBLES);
         thr = c.take<double>(16);
-        xs = c.take<unsigned char>((size_t)(maxn + 4) * elem);
+        xs = c.take<double>(maxn + 4);
         const int np2 = tsfa_pow2_ceil(maxn);
-        perm = c.take<unsigned short>(((np2 > 64) ? np2 : 64) + 16);
+        const int nperm = ((np2 > 64) ? np2 : 64) + 32;
+        perm = c.take<unsigned short>(nperm);
         if (with_cnt) {  // the numpy-order scratch is dead before the first sweep: share its storage
-            const size_t cb = (size_t)(maxn + 8) * 3 * sizeof(unsigned int);
+            refs = c.take<unsigned int>(nperm);
+            const size_t cb = (size_t)(maxn + 16) * 3 * sizeof(unsigned int);
             unsigned char *u = c.take<unsigned char>(cb > sizeof(NpScratch) ? cb : sizeof(NpScratch));
             np = (NpScratch *)u;
             cnt = (unsigned int *)u;
         } else {
             np = c.take<NpScratch>(1);
+            refs = nullptr;
             cnt = nullptr;
         }
         return c.off;
