@@ -50,6 +50,42 @@ TSFA_DEV void chol_solve(const double *L, int p, int ld, const double *rhs, doub
     }
 }
 
+// Workgroup-cooperative Cholesky (right-looking): after step j, column j holds L(:, j) and the trailing block has had
+// L(:, j) L(:, j)^T subtracted.  Every entry receives exactly the subtractions of the serial left-looking loop, in the
+// same order (k ascending), so the factor is bit-identical to chol_factor's; only the p-1 dependent steps remain
+// serial.  Returns false (uniformly) on a non-positive pivot.
+TSFA_DEV bool blk_chol_factor(const Blk &b, double *G, int p, int ld) {
+    for (int j = 0; j < p; ++j) {
+        blk_sync();
+        const double d = G[j + j * ld];
+        if (!(d > 0.0)) return false;
+        const double sd = sqrt(d);
+        blk_sync();
+        for (int i = j + b.tid; i < p; i += b.nt) G[i + j * ld] = (i == j) ? sd : G[i + j * ld] / sd;
+        blk_sync();
+        const int m = p - j - 1;
+        for (int e = b.tid; e < m * m; e += b.nt) {
+            const int i = j + 1 + e % m, k = j + 1 + e / m;
+            if (k > i) continue;
+            G[i + k * ld] = G[i + k * ld] - G[i + j * ld] * G[k + j * ld];
+        }
+    }
+    blk_sync();
+    return true;
+}
+// w = L^-1 rhs by column-oriented forward substitution (same subtraction order as the serial row loop).
+// `w` is overwritten in place: pass a copy of rhs.
+TSFA_DEV void blk_chol_forward(const Blk &b, const double *L, int p, int ld, double *w) {
+    for (int i = 0; i < p; ++i) {
+        blk_sync();
+        const double wi = w[i] / L[i + i * ld];
+        blk_sync();
+        if (b.tid == 0) w[i] = wi;
+        for (int k = i + 1 + b.tid; k < p; k += b.nt) w[k] = w[k] - L[k + i * ld] * wi;
+    }
+    blk_sync();
+}
+
 // Lag-product matrix of sequence s over rows t in [t0, t1):  T[i + j*ld] = sum_t s(t-i) s(t-j), 0 <= j <= i <= Lg,
 // and column sums C[j] = sum_t s(t-j).  Requires t0 >= Lg.  S(u) returns s[u].
 template <class S>
@@ -226,27 +262,35 @@ TSFA_DEV void fam_ar_series(const Blk &b, X xv, int n, const TsfaSpec *specs, in
             for (int a = b.tid; a < p1; a += b.nt) g[a] = (a == 0) ? C[0] : (a == 1 ? V[0] : T[a - 1]);
             blk_sync();
             const double yy = T[0];
-            if (b.tid == 0) {
-                int best = -1;
-                double best_aic = 0.0;
-                if (chol_factor(G, p1, P)) {
-                    // all nested fits from one factorization: w = L^-1 g, SSR_p = yy - sum_{i<p} w_i^2
-                    double acc = 0.0;
-                    for (int i = 0; i < p1; ++i) {
-                        double s = g[i];
-                        for (int k = 0; k < i; ++k) s -= G[i + k * P] * tmp1[k];
-                        tmp1[i] = s / G[i + i * P];
-                        acc += tmp1[i] * tmp1[i];
-                        const int pcols = i + 1;
-                        if (pcols >= 2) {
-                            const double ssr = yy - acc;
-                            const double llf = -0.5 * nobs * log(2.0 * M_PI) - 0.5 * nobs * log(ssr / nobs) - 0.5 * nobs;
-                            const double aic = -2.0 * llf + 2.0 * (double)pcols;
-                            if (best < 0 || aic < best_aic) { best = pcols; best_aic = aic; }
-                        }
+            {
+                // all nested fits from one factorization: w = L^-1 g, SSR_p = yy - sum_{i<p} w_i^2
+                const bool okf = blk_chol_factor(b, G, p1, P);
+                if (okf) {
+                    for (int a = b.tid; a < p1; a += b.nt) tmp1[a] = g[a];
+                    blk_chol_forward(b, G, p1, P, tmp1);
+                    if (b.tid == 0) {  // running sum of squares in the serial order
+                        double acc = 0.0;
+                        for (int i = 0; i < p1; ++i) { acc += tmp1[i] * tmp1[i]; tmp2[i] = acc; }
                     }
+                    blk_sync();
+                    for (int i = b.tid; i < p1; i += b.nt) {  // AIC of the fit with i + 1 columns
+                        const int pcols = i + 1;
+                        const double ssr = yy - tmp2[i];
+                        const double llf = -0.5 * nobs * log(2.0 * M_PI) - 0.5 * nobs * log(ssr / nobs) - 0.5 * nobs;
+                        tmp1[i] = -2.0 * llf + 2.0 * (double)pcols;
+                    }
+                    blk_sync();
                 }
-                res[0] = (double)best;
+                if (b.tid == 0) {
+                    int best = -1;
+                    double best_aic = 0.0;
+                    if (okf)
+                        for (int i = 1; i < p1; ++i) {
+                            const double aic = tmp1[i];
+                            if (best < 0 || aic < best_aic) { best = i + 1; best_aic = aic; }
+                        }
+                    res[0] = (double)best;
+                }
             }
             blk_sync();
             const int bestcols = (int)res[0];
@@ -286,13 +330,8 @@ TSFA_DEV void fam_ar_series(const Blk &b, X xv, int n, const TsfaSpec *specs, in
                     if (is_rhs) g[a] = v; else G[a + c * P] = v;
                 }
                 blk_sync();
-                if (b.tid == 0) {
-                    const bool ok = chol_factor(G, p2, P);
-                    res[1] = ok ? 1.0 : 0.0;
-                    if (ok) chol_solve(G, p2, P, g, beta);
-                }
-                blk_sync();
-                const bool ok2 = res[1] != 0.0;
+                const bool ok2 = blk_chol_factor(b, G, p2, P);
+                if (b.tid == 0 && ok2) chol_solve(G, p2, P, g, beta);
                 blk_sync();
                 if (ok2) {
                     // one step of iterative refinement on the true residuals, then SSR
@@ -408,13 +447,8 @@ TSFA_DEV void fam_ar_series(const Blk &b, X xv, int n, const TsfaSpec *specs, in
                 }
                 for (int a = b.tid; a < p; a += b.nt) g[a] = (a == 0) ? C[0] : T[a];
                 blk_sync();
-                if (b.tid == 0) {
-                    const bool ok = chol_factor(G, p, P);
-                    res[1] = ok ? 1.0 : 0.0;
-                    if (ok) chol_solve(G, p, P, g, beta);
-                }
-                blk_sync();
-                ar_ok = res[1] != 0.0;
+                ar_ok = blk_chol_factor(b, G, p, P);
+                if (b.tid == 0 && ar_ok) chol_solve(G, p, P, g, beta);
                 blk_sync();
                 if (ar_ok) {
                     auto reg = [=](int a, int t) { return a == 0 ? 1.0 : xcc[t - a]; };

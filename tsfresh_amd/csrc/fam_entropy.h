@@ -200,26 +200,40 @@ TSFA_DEV void entropy_sweep_sym(const Blk &b, const double *xs, int n, const dou
     }
     blk_sync();
     // ---- totals: cnt[q] is now complete for every template ----
-    double slm[NK], slm1[NK], scm[NK], scm1[NK];
+    // sum_i log(C_i / N) = log(prod_i C_i) - (#rows) * log(N): the counts are integers <= 2^16, so a thread multiplies
+    // up to 16 of them into one double (< 2^1024, relative error 1e-16 per factor) and takes ONE logarithm.  Rows
+    // with C_i == N contribute exactly 0, as in the reference (log(1.0)).
+    double slm[NK], slm1[NK], scm[NK], scm1[NK], pm[NK], pm1[NK];
+    int nm[NK], nm1[NK];
 #pragma unroll
-    for (int k = 0; k < NK; ++k) { slm[k] = 0.0; slm1[k] = 0.0; scm[k] = 0.0; scm1[k] = 0.0; }
-    const double dm = (double)nrow_m, dm1 = (double)nrow_m1;
-    for (int q = b.tid; q < nrow_m; q += b.nt) {
-        const bool row_m1 = ((int)perm[q] < nrow_m1);
+    for (int k = 0; k < NK; ++k) { slm[k] = 0.0; slm1[k] = 0.0; scm[k] = 0.0; scm1[k] = 0.0; pm[k] = 1.0; pm1[k] = 1.0; nm[k] = 0; nm1[k] = 0; }
+    int it = 0;
+    for (int q0 = 0; q0 < nrow_m; q0 += b.nt, ++it) {
+        const int q = q0 + b.tid;
+        if (q < nrow_m) {
+            const bool row_m1 = ((int)perm[q] < nrow_m1);
 #pragma unroll
-        for (int k = 0; k < NK; ++k) {
-            const unsigned int cc = cnt[q * NK + k];
-            const int t2 = (int)(cc & 0xFFFFu), t3 = (int)(cc >> 16);
-            scm[k] += (double)t2;
-            slm[k] += log((double)t2 / dm);
-            if (row_m1) {
-                scm1[k] += (double)t3;
-                slm1[k] += log((double)t3 / dm1);
+            for (int k = 0; k < NK; ++k) {
+                const unsigned int cc = cnt[q * NK + k];
+                const int t2 = (int)(cc & 0xFFFFu), t3 = (int)(cc >> 16);
+                scm[k] += (double)t2;
+                if (t2 != nrow_m) { pm[k] *= (double)t2; ++nm[k]; }
+                if (row_m1) {
+                    scm1[k] += (double)t3;
+                    if (t3 != nrow_m1) { pm1[k] *= (double)t3; ++nm1[k]; }
+                }
             }
         }
+        if ((it & 15) == 15) {
+#pragma unroll
+            for (int k = 0; k < NK; ++k) { slm[k] += log(pm[k]); slm1[k] += log(pm1[k]); pm[k] = 1.0; pm1[k] = 1.0; }
+        }
     }
+    const double ldm = log((double)nrow_m), ldm1 = log((double)nrow_m1);
 #pragma unroll
     for (int k = 0; k < NK; ++k) {
+        slm[k] += log(pm[k]) - (double)nm[k] * ldm;
+        slm1[k] += log(pm1[k]) - (double)nm1[k] * ldm1;
         acc[k].sum_log_m = blk_sum(b, slm[k]);
         acc[k].sum_log_m1 = blk_sum(b, slm1[k]);
         acc[k].sum_cnt_m = blk_sum(b, scm[k]);

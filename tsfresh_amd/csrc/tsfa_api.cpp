@@ -3,6 +3,9 @@
 // returns TSFA_ERR_NO_DEVICE.
 #include <hip/hip_runtime.h>
 
+#include <stdio.h>
+#include <stdlib.h>
+
 #include <algorithm>
 #include <string>
 #include <vector>
@@ -289,6 +292,20 @@ int tsfa_extract(tsfa_plan *plan, const void *values, int32_t dtype, const int64
         a.ld = ld;
         a.maxn = maxn;
         a.nt = nt;
+        if (maxn <= 2048) {
+            // Wavefronts per series, measured on MI355X at n = 1024 (profiles/r01_*): the LDS footprint of a series
+            // caps the workgroups per CU, so the latency-bound families gain from more wavefronts per workgroup,
+            // while k_basic's many short reductions lose to the extra barriers.  At least 4 samples per thread.
+            static const int pref[TSFA_N_FAMILIES] = {64, 128, 64, 256, 256, 256, 256};
+            const int cap = std::max(64, ((maxn / 4 + 63) / 64) * 64);
+            a.nt = std::min(pref[f], cap);
+        }
+        {   // experiment hook: TSFA_NT_<family index>=<threads>
+            char key[32];
+            snprintf(key, sizeof key, "TSFA_NT_%d", f);
+            const char *e = getenv(key);
+            if (e && atoi(e) >= 64) a.nt = atoi(e);
+        }
         a.stream = st;
         a.dectab = plan->d_dectab;
         a.twc = plan->d_twc;
@@ -296,7 +313,7 @@ int tsfa_extract(tsfa_plan *plan, const void *values, int32_t dtype, const int64
         int aux = 0;
         if (f == TSFA_FAM_SPECTRAL) {
             a.dft_n = (int)max_np2;
-            if (tsfa_family_lds_bytes(f, maxn, nt, a.dft_n) > TSFA_LDS_LIMIT) {
+            if (tsfa_family_lds_bytes(f, maxn, a.nt, a.dft_n) > TSFA_LDS_LIMIT) {
                 // twiddles of the long non-power-of-two series go to an HBM scratch slab per series
                 a.dft_n = 0;
                 a.gscratch_n = (int)max_np2;
@@ -306,7 +323,7 @@ int tsfa_extract(tsfa_plan *plan, const void *values, int32_t dtype, const int64
             }
             aux = a.dft_n;
         } else if (f == TSFA_FAM_CWT) {
-            a.cwt_rowv = tsfa_family_lds_bytes(f, maxn, nt, 1) <= 96 * 1024 ? 1 : 0;
+            a.cwt_rowv = tsfa_family_lds_bytes(f, maxn, a.nt, 1) <= 96 * 1024 ? 1 : 0;
             aux = a.cwt_rowv;
         } else if (f == TSFA_FAM_AR) {
             // leading dimension of the normal matrices: ADF needs maxlag(n) + 3, AR(k) needs k + 2
@@ -326,7 +343,7 @@ int tsfa_extract(tsfa_plan *plan, const void *values, int32_t dtype, const int64
             // one wavefront per 64-template row block, up to four per series; the symmetric sweep needs 12 B of
             // LDS counters per sample
             const int waves = std::min(4, std::max(1, (maxn - 1 + 63) / 64));
-            a.nt = std::max(nt, 64 * waves);
+            a.nt = std::max(a.nt, 64 * waves);
             a.ent_cnt = tsfa_entropy_lds_bytes(maxn, 1) <= TSFA_LDS_LIMIT ? 1 : 0;
         } else if (f == TSFA_FAM_SEQ) {
             // parse as many `bins` values side by side as LDS allows
@@ -339,7 +356,7 @@ int tsfa_extract(tsfa_plan *plan, const void *values, int32_t dtype, const int64
         }
         const size_t lds = (f == TSFA_FAM_SEQ) ? tsfa_seq_lds_bytes(maxn, a.ntab, a.seq_tab_entries, a.seq_edge_doubles)
                            : (f == TSFA_FAM_ENTROPY) ? tsfa_entropy_lds_bytes(maxn, a.ent_cnt)
-                                                     : tsfa_family_lds_bytes(f, maxn, nt, aux);
+                                                     : tsfa_family_lds_bytes(f, maxn, a.nt, aux);
         if (lds > TSFA_LDS_LIMIT)
             return fail(TSFA_ERR_TOO_LONG, std::string(fam_names[f]) + ": a series of " + std::to_string(maxn) +
                                                " samples needs " + std::to_string(lds) + " B of LDS (limit 163840)");
