@@ -50,6 +50,8 @@ extern "C" int tsfa_emul_extract(const tsfa_feature_spec *specs, int n_specs, co
         if (s.calc == TSFA_C_CWT_COEFFICIENTS) cwt_coef.push_back(s);
         else fam[tsfa_calc_table[s.calc].family].push_back(s);
     }
+    TsfaFamHints hints[TSFA_N_FAMILIES];
+    for (int f = 0; f < TSFA_N_FAMILIES; ++f) tsfa_prepare_family(f, fam[f], hints[f]);
     TsfaCwtBank bank;
     if (!cwt_coef.empty()) {
         const std::string why = bank.build(cwt_coef);
@@ -81,7 +83,8 @@ extern "C" int tsfa_emul_extract(const tsfa_feature_spec *specs, int n_specs, co
             std::vector<double> w(maxn + 8), cum(maxn + 8), altc(8 * 16);
             std::vector<int> iw(512);
             fam_basic_series(b, xs.data(), n, fam[TSFA_FAM_BASIC].data(), (int)fam[TSFA_FAM_BASIC].size(), row, w.data(),
-                             (s % 2) ? w.data() : cum.data(), altc.data(), iw.data(), dectab.data());
+                             (s % 2) ? w.data() : cum.data(), altc.data(), iw.data(), dectab.data(),
+                             hints[TSFA_FAM_BASIC].a, hints[TSFA_FAM_BASIC].b);
         }
         if (!fam[TSFA_FAM_SORT].empty()) {
             std::vector<double> srt(tsfa_pow2_ceil(maxn) + 8), w(1280);
@@ -95,7 +98,7 @@ extern "C" int tsfa_emul_extract(const tsfa_feature_spec *specs, int n_specs, co
             std::vector<int> iw(128);
             fam_spectral_series(b, xs.data(), n, fam[TSFA_FAM_SPECTRAL].data(), (int)fam[TSFA_FAM_SPECTRAL].size(), row,
                                 Xr.data(), Xi.data(), tc.data(), ts.data(), win.data(), pxx.data(), iw.data(),
-                                twc.data(), tws.data());
+                                twc.data(), tws.data(), hints[TSFA_FAM_SPECTRAL].a, hints[TSFA_FAM_SPECTRAL].b);
         }
         if (!fam[TSFA_FAM_AR].empty()) {
             int P = 8;

@@ -132,18 +132,29 @@ TSFA_DEV double blk_longest_run(const Blk &b, int n, P pred, int *iw) {
 //   altc : LDS, >= 8 * TSFA_ALT_CACHE doubles (agg_linear_trend regression cache)
 //   iw   : LDS int array of >= max(4*nt, 128) ints
 #define TSFA_ALT_CACHE 16
+#define TSFA_PEAK_NEAR 10
+#define TSFA_DEV_UNUSED
 TSFA_DEV void fam_basic_series(const Blk &b, const double *xs, int n, const TsfaSpec *specs, int nspecs,
-                               double *out_row, double *w, double *cum, double *altc, int *iw, const double *dectab) {
+                               double *out_row, double *w, double *cum, double *altc, int *iw, const double *dectab,
+                               int peaks_maxsup, int alt_want_p) {
     BasicStats st;
     basic_stats(b, xs, n, st);
     const double dn = (double)n;
     const double mean = st.mean;
-    bool have_cumsum = false;
+    bool have_cumsum = false, have_lt = false;
+    double lt5[5] = {0.0, 0.0, 0.0, 0.0, 0.0};
     double imq_sabs = 0.0;
     int alt_n = 0;
 
+    TSFA_DEV_UNUSED int alt_key[TSFA_ALT_CACHE];  // (f_agg << 20 | chunk_len) of the cached regressions: registers
+#pragma unroll
+    for (int k = 0; k < TSFA_ALT_CACHE; ++k) alt_key[k] = -1;
+    bool have_peaks = false;
+
+    TsfaSpec nxt = specs[0];
     for (int s = 0; s < nspecs; ++s) {
-        const TsfaSpec sp = specs[s];
+        const TsfaSpec sp = nxt;
+        nxt = specs[(s + 1 < nspecs) ? s + 1 : s];  // scalar load in flight while this column is evaluated
         const double p0 = sp.p[0], p1 = sp.p[1], p2 = sp.p[2];
         double v = TSFA_NAN;
         switch (sp.calc) {
@@ -279,15 +290,76 @@ TSFA_DEV void fam_basic_series(const Blk &b, const double *xs, int n, const Tsfa
             v = blk_longest_run(b, n, [=](int i) { return xs[i] < mean; }, iw);
             break;
         case TSFA_C_NUMBER_PEAKS: {                                      // fc.py:1235
+            // x[i] is a peak of support s iff no sample within s positions on either side is >= x[i], i.e. iff the
+            // distances L[i], R[i] to the nearest such sample both exceed s.  One pass finds L and R up to
+            // TSFA_PEAK_NEAR for every sample; the few samples still unblocked (1 in 2 * NEAR + 1 on i.i.d. data)
+            // are compacted and scanned on to the largest support of the plan.  All supports then read (L, R).
             const int sup = (int)p0;
-            double c = 0.0;
-            if (sup >= 1) {
+            if (sup < 1) { v = 0.0; break; }
+            if (sup > 254) {  // beyond the 8-bit distance code: direct evaluation
+                double c = 0.0;
                 for (int i = sup + b.tid; i < n - sup; i += b.nt) {
                     const double xi = xs[i];
                     bool pk = true;
                     for (int k = 1; k <= sup && pk; ++k) pk = (xi > xs[i - k]) && (xi > xs[i + k]);
                     c += pk ? 1.0 : 0.0;
                 }
+                v = blk_sum(b, c);
+                break;
+            }
+            unsigned short *lr = (unsigned short *)w;  // L | R << 8, distances capped at 255 (= "none found")
+            if (!have_peaks) {
+                const int maxsup = (peaks_maxsup > 1) ? peaks_maxsup : 1;  // tsfa_prepare_family (host)
+                have_cumsum = false;  // w aliases cum
+                const int near = (maxsup < TSFA_PEAK_NEAR) ? maxsup : TSFA_PEAK_NEAR;
+                int *cand = iw;       // candidate indices (<= 4 * nt or 256 of them; the rest is scanned in place)
+                const int cand_cap = (4 * b.nt > 256) ? 4 * b.nt : 256;
+                blk_sync();
+                int ncand = 0;
+                for (int i0 = 0; i0 < n; i0 += b.nt) {
+                    const int i = i0 + b.tid;
+                    int L = 255, R = 255;
+                    if (i < n) {
+                        const double xi = xs[i];
+                        for (int k = 1; k <= near && (L == 255 || R == 255); ++k) {
+                            if (L == 255 && i - k >= 0 && !(xi > xs[i - k])) L = k;
+                            if (R == 255 && i + k < n && !(xi > xs[i + k])) R = k;
+                        }
+                    }
+                    const bool open = (i < n) && (maxsup > near) && (L == 255) && (R == 255);
+                    int tot;
+                    const int pos = ncand + blk_excl_count(b, open, &tot);
+                    bool parked = false;
+                    if (open && pos < cand_cap) { cand[pos] = i; parked = true; }
+                    if (open && !parked) {  // candidate list full: finish this sample here
+                        const double xi = xs[i];
+                        for (int k = near + 1; k <= maxsup && (L == 255 || R == 255); ++k) {
+                            if (L == 255 && i - k >= 0 && !(xi > xs[i - k])) L = k;
+                            if (R == 255 && i + k < n && !(xi > xs[i + k])) R = k;
+                        }
+                    }
+                    if (i < n) lr[i] = (unsigned short)(L | (R << 8));
+                    ncand += tot;
+                }
+                if (ncand > cand_cap) ncand = cand_cap;
+                blk_sync();
+                for (int c = b.tid; c < ncand; c += b.nt) {
+                    const int i = cand[c];
+                    const double xi = xs[i];
+                    int L = 255, R = 255;
+                    for (int k = near + 1; k <= maxsup && (L == 255 || R == 255); ++k) {
+                        if (L == 255 && i - k >= 0 && !(xi > xs[i - k])) L = k;
+                        if (R == 255 && i + k < n && !(xi > xs[i + k])) R = k;
+                    }
+                    lr[i] = (unsigned short)(L | (R << 8));
+                }
+                blk_sync();
+                have_peaks = true;
+            }
+            double c = 0.0;
+            for (int i = sup + b.tid; i < n - sup; i += b.nt) {
+                const int e = lr[i];
+                c += ((e & 255) > sup && (e >> 8) > sup) ? 1.0 : 0.0;
             }
             v = blk_sum(b, c);
         } break;
@@ -295,11 +367,20 @@ TSFA_DEV void fam_basic_series(const Blk &b, const double *xs, int n, const Tsfa
             if (!have_cumsum) {
                 // np.cumsum is a serial accumulation: one lane builds it once (in numpy's order, so that the >= q
                 // comparison is bit-identical), every q then scans it in parallel
+                have_peaks = false;  // cum may alias the peak distances
                 imq_sabs = np_sum(b, n, [=](int i) { return fabs(xs[i]); });
                 blk_sync();
                 if (b.tid == 0) {
                     double acc = 0.0;
-                    for (int i = 0; i < n; ++i) {
+                    int i = 0;
+                    for (; i + 16 <= n; i += 16) {  // loads batched ahead of the dependent add chain
+                        double v[16];
+#pragma unroll
+                        for (int u = 0; u < 16; ++u) v[u] = fabs(xs[i + u]);
+#pragma unroll
+                        for (int u = 0; u < 16; ++u) { acc += v[u]; cum[i + u] = acc; }
+                    }
+                    for (; i < n; ++i) {
                         acc += fabs(xs[i]);
                         cum[i] = acc;
                     }
@@ -404,9 +485,14 @@ TSFA_DEV void fam_basic_series(const Blk &b, const double *xs, int n, const Tsfa
             v = blk_bcast0(b, r);
         } break;
         case TSFA_C_LINEAR_TREND: {                                      // fc.py:1343
-            double o5[5];
-            blk_linregress_index(b, n, [=](int i) { return xs[i]; }, o5);
-            v = o5[(int)p0];
+            if (!have_lt) {  // one regression serves all five attributes
+                blk_linregress_index(b, n, [=](int i) { return xs[i]; }, lt5);
+                have_lt = true;
+            }
+            v = lt5[0];
+#pragma unroll
+            for (int k = 1; k < 5; ++k)
+                if (k == (int)p0) v = lt5[k];
         } break;
         case TSFA_C_AGG_LINEAR_TREND: {                                  // fc.py:2171
             const int attr = (int)p0, cl = (int)p1, agg = (int)p2;
@@ -416,11 +502,14 @@ TSFA_DEV void fam_basic_series(const Blk &b, const double *xs, int n, const Tsfa
             }
             // the regression of one (f_agg, chunk_len) pair serves all its attr columns: small LDS cache
             int slot = -1;
-            for (int k = 0; k < alt_n; ++k)
-                if (altc[8 * k] == (double)agg && altc[8 * k + 1] == (double)cl) slot = k;
+            const int key = (agg << 20) | cl;
+#pragma unroll
+            for (int k = 0; k < TSFA_ALT_CACHE; ++k)
+                if (alt_key[k] == key) slot = k;
             if (slot < 0) {
                 const int m = (n + cl - 1) / cl;
-                have_cumsum = false;  // w may alias cum
+                have_cumsum = false;  // w may alias cum ...
+                have_peaks = false;   // ... and holds the peak distances
                 blk_sync();
                 for (int c = b.tid; c < m; c += b.nt) {  // fc.py:176 _aggregate_on_chunks
                     const int lo = c * cl;
@@ -443,12 +532,13 @@ TSFA_DEV void fam_basic_series(const Blk &b, const double *xs, int n, const Tsfa
                 blk_sync();
                 double o5[5];
                 const double *wc = w;
-                blk_linregress_index(b, m, [=](int i) { return wc[i]; }, o5);
+                blk_linregress_index(b, m, [=](int i) { return wc[i]; }, o5, alt_want_p != 0);
                 slot = (alt_n < TSFA_ALT_CACHE) ? alt_n : (TSFA_ALT_CACHE - 1);
+#pragma unroll
+                for (int k = 0; k < TSFA_ALT_CACHE; ++k)
+                    if (k == slot) alt_key[k] = key;
                 blk_sync();
                 if (b.tid == 0) {
-                    altc[8 * slot] = (double)agg;
-                    altc[8 * slot + 1] = (double)cl;
                     for (int k = 0; k < 5; ++k) altc[8 * slot + 2 + k] = o5[k];
                 }
                 blk_sync();

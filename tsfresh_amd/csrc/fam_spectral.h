@@ -107,7 +107,7 @@ TSFA_DEV void blk_rfft(const Blk &b, int n, G g, double *Xr, double *Xi, double 
         tc[j] = c;
         ts[j] = -s;
     }
-    blk_sync();
+    blk_sync_all();  // tc / ts may live in the HBM scratch slab (long non-power-of-two series)
     for (int k = b.tid; k <= nh; k += b.nt) {
         double ar = 0.0, ai = 0.0;
         int idx = 0;
@@ -174,13 +174,9 @@ TSFA_DEV int blk_welch(const Blk &b, const double *xs, int n, double *win, doubl
 //   win    : LDS >= 256;  pxx : LDS >= 132;  iw : LDS ints >= 128
 TSFA_DEV void fam_spectral_series(const Blk &b, const double *xs, int n, const TsfaSpec *specs, int nspecs,
                                   double *out_row, double *Xr, double *Xi, double *tc, double *ts, double *win,
-                                  double *pxx, int *iw, const double *twc, const double *tws) {
-    bool need_fft = false, need_welch = false;
-    for (int s = 0; s < nspecs; ++s) {
-        const int c = specs[s].calc;
-        if (c == TSFA_C_FFT_COEFFICIENT || c == TSFA_C_FFT_AGGREGATED) need_fft = true;
-        if (c == TSFA_C_SPKT_WELCH_DENSITY || c == TSFA_C_FOURIER_ENTROPY) need_welch = true;
-    }
+                                  double *pxx, int *iw, const double *twc, const double *tws, int flags, int nlead) {
+    // flags / nlead come from tsfa_prepare_family (host): the Welch-based specs are the first nlead of the list
+    const bool need_fft = (flags & 1) != 0, need_welch = (flags & 2) != 0;
     const int nf = n / 2 + 1;
 
     // ---- Welch first (it reuses the FFT scratch), results stay in pxx ----
@@ -199,7 +195,7 @@ TSFA_DEV void fam_spectral_series(const Blk &b, const double *xs, int n, const T
         pmin = blk_min(b, mn);
         pnan = blk_sum(b, nn) > 0.0;
     }
-    for (int s = 0; s < nspecs; ++s) {
+    for (int s = 0; s < nlead; ++s) {
         const TsfaSpec sp = specs[s];
         double v = TSFA_NAN;
         if (sp.calc == TSFA_C_SPKT_WELCH_DENSITY) {                      // fc.py:1418
@@ -240,7 +236,7 @@ TSFA_DEV void fam_spectral_series(const Blk &b, const double *xs, int n, const T
     s4 = blk_sum(b, s4);
     const double m1 = s1 / s0, m2 = s2 / s0, m3 = s3 / s0, m4 = s4 / s0;
     const double var = m2 - m1 * m1;
-    for (int s = b.tid; s < nspecs; s += b.nt) {
+    for (int s = nlead + b.tid; s < nspecs; s += b.nt) {  // one lane per column
         const TsfaSpec sp = specs[s];
         double v = TSFA_NAN;
         if (sp.calc == TSFA_C_FFT_COEFFICIENT) {                         // fc.py:1067

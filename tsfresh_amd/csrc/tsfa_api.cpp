@@ -63,6 +63,7 @@ struct tsfa_plan {
     int n_cols = 0;
     std::vector<TsfaSpec> fam_specs[TSFA_N_FAMILIES];  // CWT slot: number_cwt_peaks specs only
     TsfaSpec *d_specs[TSFA_N_FAMILIES] = {nullptr};
+    TsfaFamHints hints[TSFA_N_FAMILIES];
     TsfaCwtBank bank;  // cwt_coefficients
     double *d_W = nullptr;
     int *d_cols = nullptr, *d_coeff = nullptr;
@@ -184,6 +185,7 @@ int tsfa_plan_create(const tsfa_feature_spec *specs, int32_t n_specs, int32_t de
         delete plan;
         return fail(TSFA_ERR_HIP, "hipSetDevice failed");
     }
+    for (int f = 0; f < TSFA_N_FAMILIES; ++f) tsfa_prepare_family(f, plan->fam_specs[f], plan->hints[f]);
     bool ok = hipStreamCreateWithFlags(&plan->stream, hipStreamNonBlocking) == hipSuccess;
     for (int f = 0; ok && f < TSFA_N_FAMILIES; ++f) ok = upload(plan->fam_specs[f], &plan->d_specs[f]) == 0;
     if (ok && !cwt_coef.empty()) {
@@ -310,6 +312,8 @@ int tsfa_extract(tsfa_plan *plan, const void *values, int32_t dtype, const int64
         a.dectab = plan->d_dectab;
         a.twc = plan->d_twc;
         a.tws = plan->d_tws;
+        a.hint_a = plan->hints[f].a;
+        a.hint_b = plan->hints[f].b;
         int aux = 0;
         if (f == TSFA_FAM_SPECTRAL) {
             a.dft_n = (int)max_np2;

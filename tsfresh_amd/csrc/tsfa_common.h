@@ -55,7 +55,16 @@ struct Blk {
     NpScratch *np;  // LDS
 };
 
+// Workgroup barrier for data exchanged through LDS.  __syncthreads() also drains the wave's outstanding GLOBAL
+// stores (s_waitcnt vmcnt(0)): every feature ends with a store of its value to the HBM output row, so the next
+// barrier would expose that store's round trip (~600 cycles per column, measured).  LDS traffic only needs lgkmcnt.
 TSFA_DEV void blk_sync() {
+#if TSFA_GPU
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+#endif
+}
+// Barrier that also orders global memory within the workgroup (scratch in HBM).
+TSFA_DEV void blk_sync_all() {
 #if TSFA_GPU
     __syncthreads();
 #endif
@@ -457,8 +466,9 @@ TSFA_DEV double tsfa_norm_cdf(double x) { return 0.5 * erfc(-x * 0.7071067811865
 // scipy.stats.linregress(range(m), y) for y in LDS (or computed by G(i)); every thread gets the result
 // out[0..4] = pvalue, rvalue, intercept, slope, stderr       (scipy/stats/_stats_py.py, linregress)
 // ---------------------------------------------------------------------------------------------
+// want_p: the p-value costs a continued fraction (incomplete beta); agg_linear_trend never asks for it
 template <class G>
-TSFA_DEV void blk_linregress_index(const Blk &b, int m, G g, double *out5) {
+TSFA_DEV void blk_linregress_index(const Blk &b, int m, G g, double *out5, bool want_p = true) {
     const double dm = (double)m;
     double sy = 0.0;
     for (int i = b.tid; i < m; i += b.nt) sy += g(i);
@@ -496,7 +506,7 @@ TSFA_DEV void blk_linregress_index(const Blk &b, int m, G g, double *out5) {
         const double df = dm - 2.0;
         const double TINY = 1.0e-20;
         const double t = r * sqrt(df / ((1.0 - r + TINY) * (1.0 + r + TINY)));
-        prob = tsfa_t_pvalue2(t, df);
+        prob = want_p ? tsfa_t_pvalue2(t, df) : TSFA_NAN;
         stderr_ = sqrt((1.0 - r * r) * ssym / ssxm / df);
     }
     out5[TSFA_ATTR_PVALUE] = prob;

@@ -71,6 +71,34 @@ static inline void tsfa_build_twiddles(std::vector<double> &twc, std::vector<dou
     }
 }
 
+// Per-family facts about a plan's spec list that the kernels would otherwise have to find by scanning the list
+// (a serial scan costs one scalar-memory round trip per spec on the device).  May reorder `specs` (each spec
+// carries its output column, so the order on the device is free).
+struct TsfaFamHints {
+    int a = 0, b = 0;
+};
+static inline void tsfa_prepare_family(int fam, std::vector<TsfaSpec> &specs, TsfaFamHints &h) {
+    h = TsfaFamHints();
+    if (fam == TSFA_FAM_SPECTRAL) {
+        // a: bit 0 = full-length rfft needed, bit 1 = Welch PSD needed;  b: number of leading Welch-based specs
+        std::vector<TsfaSpec> lead, rest;
+        for (const auto &s : specs) {
+            if (s.calc == TSFA_C_SPKT_WELCH_DENSITY || s.calc == TSFA_C_FOURIER_ENTROPY) lead.push_back(s);
+            else rest.push_back(s);
+        }
+        h.a = (rest.empty() ? 0 : 1) | (lead.empty() ? 0 : 2);
+        h.b = (int)lead.size();
+        specs = lead;
+        specs.insert(specs.end(), rest.begin(), rest.end());
+    } else if (fam == TSFA_FAM_BASIC) {
+        // a: largest number_peaks support <= 254;  b: 1 if any agg_linear_trend column asks for the p-value
+        for (const auto &s : specs) {
+            if (s.calc == TSFA_C_NUMBER_PEAKS && (int)s.p[0] <= 254 && (int)s.p[0] > h.a) h.a = (int)s.p[0];
+            if (s.calc == TSFA_C_AGG_LINEAR_TREND && (int)s.p[0] == TSFA_ATTR_PVALUE) h.b = 1;
+        }
+    }
+}
+
 // pywt.cwt(x, scales, "mexh") restated (pywt/_cwt.py:125-197, pywt/_functions.py:29-32,104-109; pywt 1.1.1):
 //   int_psi = cumsum(mexh(linspace(-8, 8, 1024))) * step
 //   taps(scale) = int_psi[floor(arange(scale*16 + 1) / (scale*step))][::-1]

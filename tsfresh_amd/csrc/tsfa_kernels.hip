@@ -23,7 +23,7 @@ __device__ __forceinline__ void stage_series(const Blk &b, const T *__restrict__
 template <typename T>
 __global__ void k_basic(const T *__restrict__ values, const int64_t *__restrict__ offsets, int64_t n_series,
                         const TsfaSpec *__restrict__ specs, int nspecs, double *__restrict__ out, int64_t ld,
-                        const double *__restrict__ dectab, int maxn) {
+                        const double *__restrict__ dectab, int maxn, int hint_a, int hint_b) {
     const int64_t sidx = blockIdx.x;
     if (sidx >= n_series) return;
     const int64_t off = offsets[sidx];
@@ -32,7 +32,7 @@ __global__ void k_basic(const T *__restrict__ values, const int64_t *__restrict_
     L.carve(tsfa_smem, maxn, blockDim.x);
     Blk b{(int)threadIdx.x, (int)blockDim.x, L.red, L.np};
     stage_series(b, values + off, n, L.xs);
-    fam_basic_series(b, L.xs, n, specs, nspecs, out + sidx * ld, L.w, L.cum, L.altc, L.iw, dectab);
+    fam_basic_series(b, L.xs, n, specs, nspecs, out + sidx * ld, L.w, L.cum, L.altc, L.iw, dectab, hint_a, hint_b);
 }
 
 template <typename T>
@@ -53,7 +53,7 @@ template <typename T>
 __global__ void k_spectral(const T *__restrict__ values, const int64_t *__restrict__ offsets, int64_t n_series,
                            const TsfaSpec *__restrict__ specs, int nspecs, double *__restrict__ out, int64_t ld,
                            int maxn, int dft_n, double *__restrict__ gscratch, int gscratch_n,
-                           const double *__restrict__ twc, const double *__restrict__ tws) {
+                           const double *__restrict__ twc, const double *__restrict__ tws, int hint_a, int hint_b) {
     const int64_t sidx = blockIdx.x;
     if (sidx >= n_series) return;
     const int64_t off = offsets[sidx];
@@ -67,7 +67,8 @@ __global__ void k_spectral(const T *__restrict__ values, const int64_t *__restri
         tc = gscratch + (size_t)sidx * 2 * gscratch_n;
         ts = tc + gscratch_n;
     }
-    fam_spectral_series(b, L.xs, n, specs, nspecs, out + sidx * ld, L.Xr, L.Xi, tc, ts, L.win, L.pxx, L.iw, twc, tws);
+    fam_spectral_series(b, L.xs, n, specs, nspecs, out + sidx * ld, L.Xr, L.Xi, tc, ts, L.win, L.pxx, L.iw, twc, tws,
+                        hint_a, hint_b);
 }
 
 template <typename T>
@@ -236,7 +237,8 @@ static int launch_all_t(const TsfaLaunch &a, const T *values) {
         BasicLds L;
         const size_t lds = L.carve(nullptr, a.maxn, nt);
         if ((rc = set_lds(k_basic<T>, lds))) return rc;
-        k_basic<T><<<grid, nt, lds, st>>>(values, a.offsets, a.n_series, a.specs, a.nspecs, a.out, a.ld, a.dectab, a.maxn);
+        k_basic<T><<<grid, nt, lds, st>>>(values, a.offsets, a.n_series, a.specs, a.nspecs, a.out, a.ld, a.dectab, a.maxn,
+                                          a.hint_a, a.hint_b);
     } else if (a.fam == TSFA_FAM_SORT) {
         SortLds L;
         const size_t lds = L.carve(nullptr, a.maxn, nt);
@@ -247,7 +249,7 @@ static int launch_all_t(const TsfaLaunch &a, const T *values) {
         const size_t lds = L.carve(nullptr, a.maxn, a.dft_n);
         if ((rc = set_lds(k_spectral<T>, lds))) return rc;
         k_spectral<T><<<grid, nt, lds, st>>>(values, a.offsets, a.n_series, a.specs, a.nspecs, a.out, a.ld, a.maxn,
-                                             a.dft_n, a.gscratch, a.gscratch_n, a.twc, a.tws);
+                                             a.dft_n, a.gscratch, a.gscratch_n, a.twc, a.tws, a.hint_a, a.hint_b);
     } else if (a.fam == TSFA_FAM_AR) {
         ArLds L;
         const size_t lds = L.carve(nullptr, a.maxn, a.ar_P);

@@ -31,6 +31,7 @@ struct TsfaLaunch {
     int seq_edge_doubles;   // SEQ: bin edges of the largest group
     int ar_P;               // AR: leading dimension of the normal matrices
     int cwt_rowv;           // CWT peaks: second CWT row resident in LDS
+    int hint_a, hint_b;     // tsfa_prepare_family (BASIC, SPECTRAL)
     int ent_cnt;            // ENTROPY: per-template LDS counters (symmetric sweep)
 };
 
