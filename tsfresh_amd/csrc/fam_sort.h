@@ -189,6 +189,44 @@ TSFA_DEV double max_real_root_deg3(const double *cin, int ncoef) {
     return any ? best : TSFA_NAN;
 }
 
+// Lehmer code of the (stable) ordinal pattern of a[0..D-1]: c_j = #{l > j : a[l] < a[j]}, mixed radix D!/(D-j)!...
+// The window is read into registers once for the usual embedding dimensions.
+template <int DD>
+TSFA_DEV int perm_code_fixed(const double *a, int fact) {
+    double r[DD];
+#pragma unroll
+    for (int j = 0; j < DD; ++j) r[j] = a[j];
+    int code = 0, f = fact;
+#pragma unroll
+    for (int j = 0; j < DD - 1; ++j) {
+        int c = 0;
+#pragma unroll
+        for (int l = j + 1; l < DD; ++l) c += (r[l] < r[j]) ? 1 : 0;
+        f /= (DD - j);
+        code += c * f;
+    }
+    return code;
+}
+TSFA_DEV int perm_code(const double *a, int D, int fact) {
+    switch (D) {
+    case 2: return perm_code_fixed<2>(a, fact);
+    case 3: return perm_code_fixed<3>(a, fact);
+    case 4: return perm_code_fixed<4>(a, fact);
+    case 5: return perm_code_fixed<5>(a, fact);
+    case 6: return perm_code_fixed<6>(a, fact);
+    case 7: return perm_code_fixed<7>(a, fact);
+    default: break;
+    }
+    int code = 0, f = fact;
+    for (int j = 0; j < D - 1; ++j) {
+        int c = 0;
+        for (int l = j + 1; l < D; ++l) c += (a[l] < a[j]) ? 1 : 0;
+        f /= (D - j);
+        code += c * f;
+    }
+    return code;
+}
+
 #define TSFA_FRIEDRICH_MAX_R 64
 #define TSFA_FRIEDRICH_MAX_M 3
 
@@ -245,7 +283,91 @@ TSFA_DEV void friedrich_coeffs(const Blk &b, const double *xs, int n, S1 srt1, i
 #endif
     }
     blk_sync();
+#if TSFA_GPU
+    // np.polyfit(x_mean, y_mean, deg=m): scaled Vandermonde + least squares.  The r <= 64 bins are the lanes of
+    // wavefront 0: every lane keeps its row of the design in registers and the Householder reflections are
+    // wavefront reductions (the serial LDS version below costs ~1500 dependent LDS round trips).
+    bool wave_done = false;
+    if (b.tid < 64) {
+        const int lane = b.tid;
+        const bool has = (lane < r) && (cnt[lane < r ? lane : 0] > 0.0);
+        const unsigned long long mask = __ballot(has);
+        const int k = __popcll(mask);
+        const int cols = m + 1;
+        if (k >= cols) {
+            const int row = has ? __popcll(mask & ((1ull << lane) - 1ull)) : 1000;
+            const double xm = has ? sx[lane] / cnt[lane] : 0.0;
+            double yrow = has ? sy[lane] / cnt[lane] : 0.0;
+            double a[TSFA_FRIEDRICH_MAX_M + 1], scale[TSFA_FRIEDRICH_MAX_M + 1], R[TSFA_FRIEDRICH_MAX_M + 1][TSFA_FRIEDRICH_MAX_M + 1],
+                qy[TSFA_FRIEDRICH_MAX_M + 1];
+#pragma unroll
+            for (int c = 0; c <= TSFA_FRIEDRICH_MAX_M; ++c) {
+                a[c] = 0.0;
+                scale[c] = 1.0;
+                if (c < cols) {
+                    double pw = 1.0;
+                    for (int e = 0; e < m - c; ++e) pw *= xm;
+                    pw = has ? pw : 0.0;
+                    scale[c] = sqrt(wave_sum(pw * pw));
+                    a[c] = pw / scale[c];
+                    if (!has) a[c] = 0.0;
+                }
+            }
+#pragma unroll
+            for (int kk = 0; kk <= TSFA_FRIEDRICH_MAX_M; ++kk) {
+                if (kk < cols) {
+                    const bool below = has && (row >= kk);
+                    const double nrm = sqrt(wave_sum(below ? a[kk] * a[kk] : 0.0));
+                    const double akk = wave_sum((row == kk) ? a[kk] : 0.0);
+                    if (nrm != 0.0) {
+                        const double alpha = (akk > 0.0) ? -nrm : nrm;
+                        const double v0 = akk - alpha;
+                        const double vi = (row == kk) ? v0 : ((has && row > kk) ? a[kk] : 0.0);
+                        const double vtv = wave_sum(vi * vi);
+#pragma unroll
+                        for (int j = 0; j <= TSFA_FRIEDRICH_MAX_M; ++j) {
+                            if (j > kk && j < cols) {
+                                const double d = 2.0 * wave_sum(vi * a[j]) / vtv;
+                                a[j] -= d * vi;
+                            }
+                        }
+                        const double d = 2.0 * wave_sum(vi * yrow) / vtv;
+                        yrow -= d * vi;
+                        R[kk][kk] = alpha;
+                    } else {
+                        R[kk][kk] = akk;
+                    }
+#pragma unroll
+                    for (int j = 0; j <= TSFA_FRIEDRICH_MAX_M; ++j)
+                        if (j > kk && j < cols) R[kk][j] = wave_sum((row == kk) ? a[j] : 0.0);
+                    qy[kk] = wave_sum((row == kk) ? yrow : 0.0);
+                }
+            }
+            double sol[TSFA_FRIEDRICH_MAX_M + 1];
+#pragma unroll
+            for (int kk = TSFA_FRIEDRICH_MAX_M; kk >= 0; --kk) {
+                sol[kk] = 0.0;
+                if (kk < cols) {
+                    double sacc = qy[kk];
+#pragma unroll
+                    for (int j = 0; j <= TSFA_FRIEDRICH_MAX_M; ++j)
+                        if (j > kk && j < cols) sacc -= R[kk][j] * sol[j];
+                    sol[kk] = sacc / R[kk][kk];
+                }
+            }
+            if (lane == 0) {
+#pragma unroll
+                for (int c = 0; c <= TSFA_FRIEDRICH_MAX_M; ++c)
+                    if (c < cols) cc[c] = sol[c] / scale[c];
+                flag[0] = 1.0;
+            }
+            wave_done = true;
+        }
+    }
+    if (b.tid == 0 && !wave_done) {
+#else
     if (b.tid == 0) {
+#endif
         // np.polyfit(x_mean, y_mean, deg=m): scaled Vandermonde + lstsq
         int k = 0;
         for (int j = 0; j < r; ++j) {
@@ -430,15 +552,7 @@ TSFA_DEV void fam_sort_series(const Blk &b, const double *xs, int n, const TsfaS
             for (int k = b.tid; k < nwords; k += b.nt) iw[k] = 0;
             blk_sync();
             for (int t = b.tid; t < num; t += b.nt) {
-                const double *a = xs + t * tau;
-                // Lehmer code of the (stable) ordinal pattern: c_j = #{l > j : a[l] < a[j]}
-                int code = 0, f = fact;
-                for (int j = 0; j < D - 1; ++j) {
-                    int c = 0;
-                    for (int l = j + 1; l < D; ++l) c += (a[l] < a[j]) ? 1 : 0;
-                    f /= (D - j);
-                    code += c * f;
-                }
+                const int code = perm_code(xs + t * tau, D, fact);
                 const int inc = (code & 1) ? 0x10000 : 1;
 #if TSFA_GPU
                 atomicAdd(&iw[code >> 1], inc);
@@ -448,13 +562,24 @@ TSFA_DEV void fam_sort_series(const Blk &b, const double *xs, int n, const TsfaS
             }
             blk_sync();
             double e = 0.0;
-            for (int k = b.tid; k < fact; k += b.nt) {
-                const unsigned wv = (unsigned)iw[k >> 1];
-                const int c = (k & 1) ? (int)(wv >> 16) : (int)(wv & 0xffffu);
-                if (c > 0) {
-                    const double pr = (double)c / (double)num;
-                    e += pr * log(pr);
+            if (fact <= num) {  // sum over the patterns
+                for (int k = b.tid; k < fact; k += b.nt) {
+                    const unsigned wv = (unsigned)iw[k >> 1];
+                    const int c = (k & 1) ? (int)(wv >> 16) : (int)(wv & 0xffffu);
+                    if (c > 0) {
+                        const double pr = (double)c / (double)num;
+                        e += pr * log(pr);
+                    }
                 }
+            } else {  // more patterns than windows: sum_k c_k log(c_k / num) = sum over windows of log(c(window) / num)
+                double acc = 0.0;
+                for (int t = b.tid; t < num; t += b.nt) {
+                    const int code = perm_code(xs + t * tau, D, fact);
+                    const unsigned wv = (unsigned)iw[code >> 1];
+                    const int c = (code & 1) ? (int)(wv >> 16) : (int)(wv & 0xffffu);
+                    acc += log((double)c / (double)num);
+                }
+                e = acc / (double)num;
             }
             v = -blk_sum(b, e);
         } break;
