@@ -156,3 +156,83 @@ def test_properties_at_full_length(gpu):
     # (6) no column is left unwritten (NaN only where the reference yields NaN: query_similarity_count)
     nan_cols = {names[j] for j in np.where(np.isnan(got).any(axis=0))[0]}
     assert nan_cols <= {"value__query_similarity_count__query_None__threshold_0.0"}, nan_cols
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# BASELINE.json configs: parity against the oracle on a seeded sample, size-independent properties on the batch
+# ---------------------------------------------------------------------------------------------------------------
+def _dup_rows_equal(got, half):
+    a, b = got[:half], got[half:][::-1]
+    return np.array_equal(np.isnan(a), np.isnan(b)) and np.array_equal(np.nan_to_num(a), np.nan_to_num(b))
+
+
+def _sample_parity(params, x, rows, dtype64=True):
+    vals = np.concatenate([x[i] for i in rows]).astype(np.float64)
+    lens = [len(x[i]) for i in rows]
+    offs = np.zeros(len(rows) + 1, dtype=np.int64)
+    np.cumsum(lens, out=offs[1:])
+    return oracle_engine(params, vals, offs)
+
+
+def test_config2_efficient_10k_x_1024(gpu):
+    """configs[1]: 10k synthetic float32 series x len 1024, EfficientFCParameters."""
+    rng = np.random.default_rng(42)
+    n, L = 10_000, 1024
+    base = rng.standard_normal((n // 2, L), dtype=np.float32)
+    base[1::2] = np.cumsum(base[1::2], axis=1)  # tests/benchmark.py's randn().cumsum() variant on every other id
+    x = np.concatenate([base, base[::-1]])
+    offsets = np.arange(n + 1, dtype=np.int64) * L
+    params = settings.EfficientFCParameters()
+    names, got = hip_engine(params, x.reshape(-1), offsets)
+    assert got.shape == (n, 777)
+    assert _dup_rows_equal(got, n // 2)
+    rows = [0, 1, 2, 3, 4998, 4999]
+    onames, want = _sample_parity(params, x, rows)
+    bad = compare(onames, _align(onames, names, got[rows]), want, [x[i].astype(np.float64) for i in rows])
+    assert not bad, "%d mismatches, first: %s" % (len(bad), bad[:12])
+
+
+def test_config4_comprehensive_len_256(gpu):
+    """configs[3] shape (1M x 256 sharded over 8 GPUs = 125k per GPU): one GPU's shard, ComprehensiveFCParameters."""
+    rng = np.random.default_rng(43)
+    n, L = 125_000, 256
+    base = rng.standard_normal((n // 2, L), dtype=np.float32)
+    x = np.concatenate([base, base[::-1]])
+    offsets = np.arange(n + 1, dtype=np.int64) * L
+    params = settings.ComprehensiveFCParameters()
+    names, got = hip_engine(params, x.reshape(-1), offsets)
+    assert got.shape == (n, 783)
+    assert _dup_rows_equal(got, n // 2)
+    rows = list(range(12)) + [n // 2 - 1]
+    onames, want = _sample_parity(params, x, rows)
+    bad = compare(onames, _align(onames, names, got[rows]), want, [x[i].astype(np.float64) for i in rows])
+    assert not bad, "%d mismatches, first: %s" % (len(bad), bad[:12])
+    col = {nm: i for i, nm in enumerate(names)}
+    assert np.array_equal(got[:, col["value__length"]], np.full(n, L))
+    assert np.array_equal(got[:, col["value__maximum"]], x.astype(np.float64).max(axis=1))
+
+
+def test_config5_ragged_8192_efficient(gpu):
+    """configs[4] shape: ragged rolled windows, lengths uniform on [4096, 8192], EfficientFCParameters.
+    The longest series switches every kernel to multi-wavefront workgroups with the LDS carved for 8192 samples."""
+    rng = np.random.default_rng(44)
+    n = 96
+    lens = rng.integers(4096, 8193, size=n)
+    lens[0], lens[1] = 8192, 4096
+    walk = np.cumsum(rng.standard_normal(int(lens.max()) + n, dtype=np.float32)).astype(np.float32)
+    series = [walk[i:i + lens[i]].copy() for i in range(n)]  # rolled windows over one random walk
+    series[2] = rng.standard_normal(lens[2], dtype=np.float32)
+    values = np.concatenate(series)
+    offsets = np.zeros(n + 1, dtype=np.int64)
+    np.cumsum(lens, out=offsets[1:])
+    params = settings.EfficientFCParameters()
+    names, got = hip_engine(params, values, offsets)
+    assert got.shape == (n, 777)
+    rows = [0, 1, 2, 3]
+    onames, want = _sample_parity(params, series, rows)
+    bad = compare(onames, _align(onames, names, got[rows]), want, [series[i].astype(np.float64) for i in rows])
+    assert not bad, "%d mismatches, first: %s" % (len(bad), bad[:12])
+    col = {nm: i for i, nm in enumerate(names)}
+    assert np.array_equal(got[:, col["value__length"]], lens.astype(np.float64))
+    assert np.array_equal(got[:, col["value__median"]], np.array([np.median(s.astype(np.float64)) for s in series]))
+    assert np.array_equal(got[:, col["value__sum_values"]], np.array([np.sum(s.astype(np.float64)) for s in series]))

@@ -92,10 +92,13 @@ struct ArLds {
     TSFA_HD size_t carve(unsigned char *base, int maxn, int P) {
         LdsCarve c{base, 0};
         red = c.take<double>(TSFA_RED_DOUBLES);
-        np = c.take<NpScratch>(1);
         xc = c.take<double>(maxn + 2);
         rbuf = c.take<double>(maxn + 2);
-        aw = c.take<double>(scratch_doubles(P));
+        // the numpy-order scratch is only used for x.mean(), before the matrices exist: it shares their storage
+        const size_t ab = (size_t)scratch_doubles(P) * sizeof(double);
+        unsigned char *u = c.take<unsigned char>(ab > sizeof(NpScratch) ? ab : sizeof(NpScratch));
+        aw = (double *)u;
+        np = (NpScratch *)u;
         return c.off;
     }
 };
