@@ -75,6 +75,8 @@ def main():
     ap.add_argument("--n-series", type=int, default=100_000, help="series per GPU")
     ap.add_argument("--length", type=int, default=1024)
     ap.add_argument("--params", default="comprehensive", choices=["comprehensive", "efficient", "minimal"])
+    ap.add_argument("--ragged", default="", help="LO:HI -> series lengths uniform on [LO, HI] (configs[4] shape); "
+                                                 "--length is ignored")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -110,8 +112,17 @@ def main():
     n, L = args.n_series, args.length
     gen = torch.Generator(device=dev)
     gen.manual_seed(42 + rank)
-    values = torch.randn(n * L, device=dev, dtype=torch.float32, generator=gen)  # i.i.d. N(0,1) float32 series
-    offsets = torch.arange(0, (n + 1) * L, L, device=dev, dtype=torch.int64)
+    if args.ragged:
+        lo, hi = (int(t) for t in args.ragged.split(":"))
+        lens = torch.randint(lo, hi + 1, (n,), device=dev, generator=gen, dtype=torch.int64)
+        offsets = torch.zeros(n + 1, device=dev, dtype=torch.int64)
+        offsets[1:] = torch.cumsum(lens, 0)
+        total = int(offsets[-1].item())
+        L = total // n  # mean length, for the byte accounting below
+        values = torch.randn(total, device=dev, dtype=torch.float32, generator=gen)
+    else:
+        values = torch.randn(n * L, device=dev, dtype=torch.float32, generator=gen)  # i.i.d. N(0,1) float32 series
+        offsets = torch.arange(0, (n + 1) * L, L, device=dev, dtype=torch.int64)
     out = torch.empty((n, n_cols), device=dev, dtype=torch.float64)
     gathered = torch.empty((world * n, n_cols), device=dev, dtype=torch.float64) if world > 1 else None
     stream = torch.cuda.current_stream(dev).cuda_stream
@@ -175,7 +186,7 @@ def main():
                     "note": "O(L^2) template-pair sweep: VALU(fp64)-bound, not HBM-bound (DESIGN.md roofline section)"}
         line = {
             "metric": "series/sec (ComprehensiveFCParameters, len=1024)" if args.params == "comprehensive" and L == 1024
-                      else "series/sec (%s, len=%d)" % (args.params, L),
+                      else "series/sec (%s, %s)" % (args.params, ("ragged len %s" % args.ragged) if args.ragged else "len=%d" % L),
             "value": value, "unit": "series/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f64", "data": "synthetic",

@@ -112,7 +112,7 @@ extern "C" int tsfa_emul_extract(const tsfa_feature_spec *specs, int n_specs, co
                           xc.data(), rbuf.data(), aw.data(), P);
         }
         if (!fam[TSFA_FAM_ENTROPY].empty()) {
-            std::vector<double> thr(16), xe(xs.begin(), xs.begin() + n);
+            std::vector<double> thr(56), xe(xs.begin(), xs.begin() + n);
             xe.resize(n + 8, 0.0);
             std::vector<unsigned short> perm(tsfa_pow2_ceil(maxn) + 96);
             std::vector<unsigned int> cnt((size_t)(maxn + 16) * 3), refs(perm.size());

@@ -144,11 +144,7 @@ TSFA_DEV void fam_basic_series(const Blk &b, const double *xs, int n, const Tsfa
     bool have_cumsum = false, have_lt = false;
     double lt5[5] = {0.0, 0.0, 0.0, 0.0, 0.0};
     double imq_sabs = 0.0;
-    int alt_n = 0;
 
-    TSFA_DEV_UNUSED int alt_key[TSFA_ALT_CACHE];  // (f_agg << 20 | chunk_len) of the cached regressions: registers
-#pragma unroll
-    for (int k = 0; k < TSFA_ALT_CACHE; ++k) alt_key[k] = -1;
     bool have_peaks = false;
 
     TsfaSpec nxt = specs[0];
@@ -500,13 +496,10 @@ TSFA_DEV void fam_basic_series(const Blk &b, const double *xs, int n, const Tsfa
                 v = TSFA_NAN;
                 break;
             }
-            // the regression of one (f_agg, chunk_len) pair serves all its attr columns: small LDS cache
-            int slot = -1;
-            const int key = (agg << 20) | cl;
-#pragma unroll
-            for (int k = 0; k < TSFA_ALT_CACHE; ++k)
-                if (alt_key[k] == key) slot = k;
-            if (slot < 0) {
+            // the regression of one (f_agg, chunk_len) pair serves all its attr columns: the host (tsfa_prepare_family)
+            // assigned every column its slot of the LDS cache and marked the column that fills it
+            const int slot = ((int)sp.p[3]) & 63;
+            if (((int)sp.p[3]) >= 64) {
                 const int m = (n + cl - 1) / cl;
                 have_cumsum = false;  // w may alias cum ...
                 have_peaks = false;   // ... and holds the peak distances
@@ -533,16 +526,11 @@ TSFA_DEV void fam_basic_series(const Blk &b, const double *xs, int n, const Tsfa
                 double o5[5];
                 const double *wc = w;
                 blk_linregress_index(b, m, [=](int i) { return wc[i]; }, o5, alt_want_p != 0);
-                slot = (alt_n < TSFA_ALT_CACHE) ? alt_n : (TSFA_ALT_CACHE - 1);
-#pragma unroll
-                for (int k = 0; k < TSFA_ALT_CACHE; ++k)
-                    if (k == slot) alt_key[k] = key;
                 blk_sync();
                 if (b.tid == 0) {
                     for (int k = 0; k < 5; ++k) altc[8 * slot + 2 + k] = o5[k];
                 }
                 blk_sync();
-                if (alt_n < TSFA_ALT_CACHE) ++alt_n;
             }
             v = altc[8 * slot + 2 + attr];
         } break;

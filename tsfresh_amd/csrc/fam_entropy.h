@@ -388,7 +388,7 @@ TSFA_DEV double sampen_from_acc(const EntAcc &a, int n, int m) {
 
 // Evaluate the ENTROPY specs of one series.
 //   xs   : LDS, n + 4 elements in the input precision (xs[n .. n+3] are overwritten with +inf sentinels)
-//   thr  : LDS scratch >= 2 * TSFA_ENT_MAXK doubles
+//   thr  : LDS scratch >= 7 * TSFA_ENT_MAXK doubles (batch thresholds, group thresholds, totals, group index)
 //   perm : LDS, max(next_pow2(n), 64) + 32 unsigned shorts
 //   refs : LDS, as many ent_ref as perm (symmetric sweep only)
 //   cnt  : LDS, (n + 16) * TSFA_ENT_GROUP words, or null (-> ordered-pair sweep).  May alias b.np: the numpy-order
@@ -439,53 +439,67 @@ TSFA_DEV void fam_entropy_series(const Blk &b, XT *xs, int n, const TsfaSpec *sp
             sorted = true;
         }
         // Thresholds are swept in ascending order in groups of <= TSFA_ENT_GROUP neighbours (a group of small
-        // tolerances only visits the narrow window of ITS largest one); rank[k] = position of threshold k.
+        // tolerances only visits the narrow window of ITS largest one).  gthr = the group's thresholds; racc = the
+        // four totals of every threshold of the batch, indexed by its position in the batch (LDS: no dynamically
+        // indexed register arrays).
         double *gthr = thr + TSFA_ENT_MAXK;
+        double *racc = thr + 2 * TSFA_ENT_MAXK;  // [TSFA_ENT_MAXK][4]
         const int gcap = (cnt != nullptr) ? TSFA_ENT_GROUP : TSFA_ENT_MAXK;
         const int ngroups = (nk + gcap - 1) / gcap;
         const int gsize = (nk + ngroups - 1) / ngroups;
-        for (int g0 = 0; g0 < nk; g0 += gsize) {
+        for (int g0 = 0; n >= 3 && g0 < nk; g0 += gsize) {
             const int gn = (nk - g0 < gsize) ? (nk - g0) : gsize;
-            EntAcc ga[TSFA_ENT_MAXK];
-            if (n >= 3) {
-                blk_sync();
-                if (b.tid == 0) {
-                    for (int k = 0; k < TSFA_ENT_MAXK; ++k) gthr[k] = -1.0;
-                    for (int k = 0; k < nk; ++k) {  // rank of thr[k] among the batch (ties by index)
-                        int rk = 0;
-                        for (int o = 0; o < nk; ++o) rk += (thr[o] < thr[k] || (thr[o] == thr[k] && o < k)) ? 1 : 0;
-                        if (rk >= g0 && rk < g0 + gn) gthr[rk - g0] = thr[k];
-                    }
-                }
-                blk_sync();
-                if (cnt != nullptr) {
-                    const double *xd = (const double *)(const void *)xs;  // cnt != null implies XT = double
-                    if (gn <= 1) entropy_sweep_sym<1>(b, xd, n, gthr, perm, refs, cnt, ga);
-                    else if (gn == 2) entropy_sweep_sym<2>(b, xd, n, gthr, perm, refs, cnt, ga);
-                    else entropy_sweep_sym<3>(b, xd, n, gthr, perm, refs, cnt, ga);
-                } else {
-                    if (gn <= 1) entropy_sweep_m2<1>(b, xs, n, gthr, perm, ga);
-                    else if (gn <= 2) entropy_sweep_m2<2>(b, xs, n, gthr, perm, ga);
-                    else if (gn <= 4) entropy_sweep_m2<4>(b, xs, n, gthr, perm, ga);
-                    else if (gn <= 6) entropy_sweep_m2<6>(b, xs, n, gthr, perm, ga);
-                    else entropy_sweep_m2<8>(b, xs, n, gthr, perm, ga);
+            int *gidx = (int *)(racc + 4 * TSFA_ENT_MAXK);  // batch position of the group's k-th threshold
+            blk_sync();
+            if (b.tid == 0) {
+                for (int k = 0; k < TSFA_ENT_MAXK; ++k) { gthr[k] = -1.0; gidx[k] = -1; }
+                for (int k = 0; k < nk; ++k) {  // rank of thr[k] among the batch (ties by index)
+                    int rk = 0;
+                    for (int o = 0; o < nk; ++o) rk += (thr[o] < thr[k] || (thr[o] == thr[k] && o < k)) ? 1 : 0;
+                    if (rk >= g0 && rk < g0 + gn) { gthr[rk - g0] = thr[k]; gidx[rk - g0] = k; }
                 }
             }
-            // write the columns whose threshold belongs to this group
+            blk_sync();
+            EntAcc ga[TSFA_ENT_MAXK];
+            if (cnt != nullptr) {
+                const double *xd = (const double *)(const void *)xs;  // cnt != null implies XT = double
+                if (gn <= 1) entropy_sweep_sym<1>(b, xd, n, gthr, perm, refs, cnt, ga);
+                else if (gn == 2) entropy_sweep_sym<2>(b, xd, n, gthr, perm, refs, cnt, ga);
+                else entropy_sweep_sym<3>(b, xd, n, gthr, perm, refs, cnt, ga);
+            } else {
+                if (gn <= 1) entropy_sweep_m2<1>(b, xs, n, gthr, perm, ga);
+                else if (gn <= 2) entropy_sweep_m2<2>(b, xs, n, gthr, perm, ga);
+                else if (gn <= 4) entropy_sweep_m2<4>(b, xs, n, gthr, perm, ga);
+                else if (gn <= 6) entropy_sweep_m2<6>(b, xs, n, gthr, perm, ga);
+                else entropy_sweep_m2<8>(b, xs, n, gthr, perm, ga);
+            }
+            if (b.tid == 0) {
+#pragma unroll
+                for (int k = 0; k < TSFA_ENT_MAXK; ++k) {
+                    if (k < gn) {
+                        const int pos = gidx[k];
+                        racc[4 * pos + 0] = ga[k].sum_log_m;
+                        racc[4 * pos + 1] = ga[k].sum_log_m1;
+                        racc[4 * pos + 2] = ga[k].sum_cnt_m;
+                        racc[4 * pos + 3] = ga[k].sum_cnt_m1;
+                    }
+                }
+            }
+        }
+        blk_sync();
+        {
             int k = 0;
             for (int t = first; t < done; ++t) {
                 const TsfaSpec sp = specs[t];
                 const bool is_m2 = (sp.calc == TSFA_C_SAMPLE_ENTROPY) ||
                                    (sp.calc == TSFA_C_APPROXIMATE_ENTROPY && (int)sp.p[0] == 2);
                 if (!is_m2) continue;
-                int rk = 0;
-                for (int o = 0; o < nk; ++o) rk += (thr[o] < thr[k] || (thr[o] == thr[k] && o < k)) ? 1 : 0;
+                EntAcc a;
+                a.sum_log_m = racc[4 * k + 0];
+                a.sum_log_m1 = racc[4 * k + 1];
+                a.sum_cnt_m = racc[4 * k + 2];
+                a.sum_cnt_m1 = racc[4 * k + 3];
                 ++k;
-                if (rk < g0 || rk >= g0 + gn) continue;
-                EntAcc a = ga[0];
-#pragma unroll
-                for (int u = 1; u < TSFA_ENT_MAXK; ++u)
-                    if (u == rk - g0) a = ga[u];
                 double v;
                 if (sp.calc == TSFA_C_APPROXIMATE_ENTROPY) {
                     if (n <= 3) v = 0.0;  // N <= m + 1
@@ -497,6 +511,7 @@ TSFA_DEV void fam_entropy_series(const Blk &b, XT *xs, int n, const TsfaSpec *sp
                 if (b.tid == 0) out_row[sp.col] = v;
             }
         }
+        blk_sync();
     }
     // generic m
     for (int s = 0; s < nspecs; ++s) {

@@ -74,6 +74,7 @@ static inline void tsfa_build_twiddles(std::vector<double> &twc, std::vector<dou
 // Per-family facts about a plan's spec list that the kernels would otherwise have to find by scanning the list
 // (a serial scan costs one scalar-memory round trip per spec on the device).  May reorder `specs` (each spec
 // carries its output column, so the order on the device is free).
+#define TSFA_ALT_SLOTS 16
 struct TsfaFamHints {
     int a = 0, b = 0;
 };
@@ -92,9 +93,27 @@ static inline void tsfa_prepare_family(int fam, std::vector<TsfaSpec> &specs, Ts
         specs.insert(specs.end(), rest.begin(), rest.end());
     } else if (fam == TSFA_FAM_BASIC) {
         // a: largest number_peaks support <= 254;  b: 1 if any agg_linear_trend column asks for the p-value
-        for (const auto &s : specs) {
+        // agg_linear_trend: p[3] = cache slot of the column's (f_agg, chunk_len) regression, + 64 if this column is
+        // the one that has to compute it (the slots are simulated here, round-robin over TSFA_ALT_SLOTS)
+        int slot_key[TSFA_ALT_SLOTS], next = 0;
+        for (int k = 0; k < TSFA_ALT_SLOTS; ++k) slot_key[k] = -1;
+        for (auto &s : specs) {
             if (s.calc == TSFA_C_NUMBER_PEAKS && (int)s.p[0] <= 254 && (int)s.p[0] > h.a) h.a = (int)s.p[0];
-            if (s.calc == TSFA_C_AGG_LINEAR_TREND && (int)s.p[0] == TSFA_ATTR_PVALUE) h.b = 1;
+            if (s.calc == TSFA_C_AGG_LINEAR_TREND) {
+                if ((int)s.p[0] == TSFA_ATTR_PVALUE) h.b = 1;
+                const int key = ((int)s.p[2] << 20) | (int)s.p[1];
+                int slot = -1;
+                for (int k = 0; k < TSFA_ALT_SLOTS; ++k)
+                    if (slot_key[k] == key) slot = k;
+                if (slot >= 0) {
+                    s.p[3] = (double)slot;
+                } else {
+                    slot = next;
+                    next = (next + 1) % TSFA_ALT_SLOTS;
+                    slot_key[slot] = key;
+                    s.p[3] = (double)(slot + 64);
+                }
+            }
         }
     }
 }

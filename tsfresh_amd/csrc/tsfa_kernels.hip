@@ -21,7 +21,7 @@ __device__ __forceinline__ void stage_series(const Blk &b, const T *__restrict__
 
 // ---------------------------------------------------------------------------------------------
 template <typename T>
-__global__ void k_basic(const T *__restrict__ values, const int64_t *__restrict__ offsets, int64_t n_series,
+__global__ void __launch_bounds__(256, 2) k_basic(const T *__restrict__ values, const int64_t *__restrict__ offsets, int64_t n_series,
                         const TsfaSpec *__restrict__ specs, int nspecs, double *__restrict__ out, int64_t ld,
                         const double *__restrict__ dectab, int maxn, int hint_a, int hint_b) {
     const int64_t sidx = blockIdx.x;
@@ -36,7 +36,7 @@ __global__ void k_basic(const T *__restrict__ values, const int64_t *__restrict_
 }
 
 template <typename T>
-__global__ void k_sort(const T *__restrict__ values, const int64_t *__restrict__ offsets, int64_t n_series,
+__global__ void __launch_bounds__(256) k_sort(const T *__restrict__ values, const int64_t *__restrict__ offsets, int64_t n_series,
                        const TsfaSpec *__restrict__ specs, int nspecs, double *__restrict__ out, int64_t ld, int maxn) {
     const int64_t sidx = blockIdx.x;
     if (sidx >= n_series) return;

@@ -109,7 +109,7 @@ struct EntropyLds {
     TSFA_HD size_t carve(unsigned char *base, int maxn, int with_cnt) {
         LdsCarve c{base, 0};
         red = c.take<double>(TSFA_RED_DOUBLES);
-        thr = c.take<double>(16);
+        thr = c.take<double>(56);
         xs = c.take<double>(maxn + 4);
         const int np2 = tsfa_pow2_ceil(maxn);
         const int nperm = ((np2 > 64) ? np2 : 64) + 32;
