@@ -43,7 +43,22 @@ def _cpu_baseline_worker(args):
     return time.perf_counter() - t0
 
 
-def cpu_baseline(length, seed, budget_series_per_core=3):
+def measured_hbm_traffic(kernel, cfg):
+    """HBM bytes per launch of `kernel` from the committed PMC pass (profiles/pmc_hbm.sh -> profiles/hbm_traffic.json:
+    rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate runs of this same command, FETCH_SIZE doubled as
+    MI355X_MICROARCH.md prescribes for gfx950).  None when the file is absent or was taken on another workload."""
+    path = os.path.join(ROOT, "profiles", "hbm_traffic.json")
+    try:
+        doc = json.load(open(path))
+    except (OSError, ValueError):
+        return None
+    w = doc.get("workload", {})
+    if any(w.get(k) != cfg.get(k) for k in ("n_series_per_gpu", "length", "n_cols")):
+        return None
+    return doc.get("kernels", {}).get(kernel, {}).get("hbm_bytes_per_launch")
+
+
+def cpu_baseline(length, seed, budget_series_per_core=4):
     """Oracle ("port") on a bounded sample: `cores` worker processes, each `budget_series_per_core` series."""
     import multiprocessing as mp
     for v in ("OMP_NUM_THREADS", "MKL_NUM_THREADS", "OPENBLAS_NUM_THREADS"):
@@ -181,7 +196,9 @@ def main():
             alg_bytes = n * (4 * L + 8 * cols_dom)
             achieved = alg_bytes / (kt[dom] * 1e-3) / 1e9
             roof = {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                    "frac": achieved / HBM_PEAK_GBS, "traffic": None, "kernel_ms": kt[dom],
+                    "frac": achieved / HBM_PEAK_GBS,
+                    "traffic": measured_hbm_traffic(dom, {"n_series_per_gpu": n, "length": L, "n_cols": n_cols}),
+                    "kernel_ms": kt[dom],
                     "algorithmic_bytes_per_launch": alg_bytes,
                     "note": "O(L^2) template-pair sweep: VALU(fp64)-bound, not HBM-bound (DESIGN.md roofline section)"}
         line = {

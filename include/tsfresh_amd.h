@@ -99,6 +99,18 @@ int tsfa_extract(tsfa_plan *plan, const void *values, int32_t dtype, const int64
                  int64_t n_series, double *out, int64_t ld_out, int32_t space, void *stream);
 
 /*
+ * tsfa_extract plus the per-sample abscissa that linear_trend_timewise regresses on
+ * (feature_calculators.py:2274: hours since the series' first timestamp, taken from the DatetimeIndex
+ * the reference hands the calculator as x.index, extraction.py:345-360).
+ *
+ *   times    float64, laid out exactly like `values` (same offsets, same memory space); NULL is allowed
+ *            only for plans without linear_trend_timewise columns (TSFA_ERR_INVALID otherwise).
+ */
+int tsfa_extract_timed(tsfa_plan *plan, const void *values, int32_t dtype, const double *times,
+                       const int64_t *offsets, int64_t n_series, double *out, int64_t ld_out,
+                       int32_t space, void *stream);
+
+/*
  * Timing of the kernels of the last tsfa_extract on this plan, measured with HIP events on the
  * stream the kernels were launched on.  names[i] / ms[i] for i < returned count (<= cap).
  * Only recorded when tsfa_plan_set_profiling(plan, 1) was called before the extract.

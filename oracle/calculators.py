@@ -48,9 +48,11 @@ def _runs_of_true(mask):  # fc.py:102
 class SeriesOracle:
     """All calculators for one series; `x` is converted to float64."""
 
-    def __init__(self, x):
+    def __init__(self, x, times=None):
         self.x = np.asarray(x, dtype=np.float64)
         self.n = len(self.x)
+        # hours since the first timestamp, as fc.py:2291-2296 derives them from a DatetimeIndex (or None)
+        self.times = None if times is None else np.asarray(times, dtype=np.float64)
         self._langevin = {}
 
     # ---- parameter-less ----
@@ -450,6 +452,15 @@ class SeriesOracle:
             reg = linregress(range(self.n), self.x)
         return [('attr_"{}"'.format(p["attr"]), getattr(reg, p["attr"])) for p in param]
 
+    def linear_trend_timewise(self, param):  # fc.py:2274
+        try:
+            with warnings.catch_warnings(), np.errstate(all="ignore"):
+                warnings.simplefilter("ignore")
+                reg = linregress(self.times, self.x)
+            return [('attr_"{}"'.format(p["attr"]), getattr(reg, p["attr"])) for p in param]
+        except ValueError:  # scipy: all x identical / fewer than two points -- the reference would raise here
+            return [('attr_"{}"'.format(p["attr"]), np.nan) for p in param]
+
     def cwt_coefficients(self, param):  # fc.py:1370
         cache, out = {}, []
         for p in param:
@@ -548,5 +559,5 @@ COMBINERS = {
     "symmetry_looking", "agg_autocorrelation", "partial_autocorrelation", "augmented_dickey_fuller",
     "fft_coefficient", "fft_aggregated", "index_mass_quantile", "linear_trend", "cwt_coefficients",
     "spkt_welch_density", "ar_coefficient", "friedrich_coefficients", "agg_linear_trend",
-    "energy_ratio_by_chunks", "query_similarity_count",
+    "energy_ratio_by_chunks", "query_similarity_count", "linear_trend_timewise",
 }

@@ -18,9 +18,11 @@ def _param_suffix(param):
         for k in sorted(param.keys()))
 
 
-def oracle_series(x, fc_parameters, kind="value", skip=("linear_trend_timewise",)):
-    """-> list[(column name, float value)] for one series, in the reference's emission order."""
-    so = SeriesOracle(x)
+def oracle_series(x, fc_parameters, kind="value", times=None):
+    """-> list[(column name, float value)] for one series, in the reference's emission order.
+    times: hours since the series' first timestamp when the data has a DatetimeIndex, else None."""
+    so = SeriesOracle(x, times)
+    skip = () if times is not None else ("linear_trend_timewise",)
     out = []
     with warnings.catch_warnings(), np.errstate(all="ignore"):
         warnings.simplefilter("ignore")
@@ -40,11 +42,12 @@ def oracle_series(x, fc_parameters, kind="value", skip=("linear_trend_timewise",
     return out
 
 
-def oracle_matrix(values, offsets, fc_parameters, kind="value"):
+def oracle_matrix(values, offsets, fc_parameters, kind="value", times=None):
     """-> (column names, float64 matrix [n_series, n_cols]) for a ragged batch."""
     names, rows = None, []
     for s in range(len(offsets) - 1):
-        items = oracle_series(values[offsets[s]:offsets[s + 1]], fc_parameters, kind=kind)
+        items = oracle_series(values[offsets[s]:offsets[s + 1]], fc_parameters, kind=kind,
+                              times=None if times is None else times[offsets[s]:offsets[s + 1]])
         cols, seen, vals = [], {}, []
         for c, v in items:
             if c in seen:

@@ -10,6 +10,6 @@ timeout 600 rocprofv3 --kernel-trace --stats -d $O/prof -o p -- python bench.py 
 DB=$(ls $O/prof/*/*.db $O/prof/*.db 2>/dev/null | head -1)
 [ -n "$DB" ] && python profiles/summarize_rocpd.py $DB "$TAG: rocprofv3 --kernel-trace --stats -- python bench.py --no-cpu-baseline" > $O/kernel_stats.md && rm -f $DB
 cat $O/kernel_stats.md
-if [ -z "$SKIP_PMC" ]; then bash profiles/pmc_hbm.sh > $O/pmc_hbm.log 2>&1; cp gpurun_out/hbm/traffic.json $O/ 2>/dev/null; tail -12 $O/pmc_hbm.log; fi
+if [ -z "$SKIP_PMC" ]; then bash profiles/pmc_hbm.sh > $O/pmc_hbm.log 2>&1; cp gpurun_out/hbm/traffic.json $O/hbm_traffic.json 2>/dev/null; tail -12 $O/pmc_hbm.log; fi
 if [ -z "$SKIP_E2E" ]; then timeout 600 python profiles/e2e_timing.py > $O/e2e.json 2> $O/e2e.err; tail -3 $O/e2e.json; fi
 rm -rf $O/prof gpurun_out/hbm/*/

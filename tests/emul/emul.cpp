@@ -29,9 +29,19 @@ extern "C" int tsfa_emul_calc_id(const char *name) {
     return -1;
 }
 
+extern "C" int tsfa_emul_extract_timed(const tsfa_feature_spec *specs, int n_specs, const double *values,
+                                       const double *times, const int64_t *offsets, int64_t n_series, double *out,
+                                       int64_t ld, char *err, int errlen);
+
 extern "C" int tsfa_emul_extract(const tsfa_feature_spec *specs, int n_specs, const double *values,
                                  const int64_t *offsets, int64_t n_series, double *out, int64_t ld, char *err,
                                  int errlen) {
+    return tsfa_emul_extract_timed(specs, n_specs, values, nullptr, offsets, n_series, out, ld, err, errlen);
+}
+
+extern "C" int tsfa_emul_extract_timed(const tsfa_feature_spec *specs, int n_specs, const double *values,
+                                       const double *times, const int64_t *offsets, int64_t n_series, double *out,
+                                       int64_t ld, char *err, int errlen) {
     std::vector<TsfaSpec> fam[TSFA_N_FAMILIES], cwt_coef;
     for (int i = 0; i < n_specs; ++i) {
         TsfaSpec s;
@@ -84,7 +94,7 @@ extern "C" int tsfa_emul_extract(const tsfa_feature_spec *specs, int n_specs, co
             std::vector<int> iw(512);
             fam_basic_series(b, xs.data(), n, fam[TSFA_FAM_BASIC].data(), (int)fam[TSFA_FAM_BASIC].size(), row, w.data(),
                              (s % 2) ? w.data() : cum.data(), altc.data(), iw.data(), dectab.data(),
-                             hints[TSFA_FAM_BASIC].a, hints[TSFA_FAM_BASIC].b);
+                             hints[TSFA_FAM_BASIC].a, hints[TSFA_FAM_BASIC].b, times ? times + offsets[s] : nullptr);
         }
         if (!fam[TSFA_FAM_SORT].empty()) {
             std::vector<double> srt(tsfa_pow2_ceil(maxn) + 8), w(1280);
@@ -121,15 +131,17 @@ extern "C" int tsfa_emul_extract(const tsfa_feature_spec *specs, int n_specs, co
                                        row, thr.data(), perm.data(), refs.data(), (s % 2) ? nullptr : cnt.data());
         }
         if (!fam[TSFA_FAM_SEQ].empty()) {
-            const int group = 2;  // exercise the multi-round path
-            int tab_entries = 0, edge_doubles = 0;
-            lz_group_budget(fam[TSFA_FAM_SEQ].data(), (int)fam[TSFA_FAM_SEQ].size(), group, maxn, &tab_entries, &edge_doubles);
-            std::vector<unsigned char> seq((size_t)group * maxn + 16);
-            std::vector<uint32_t> tab((size_t)tab_entries + 4);
-            std::vector<double> edges(edge_doubles + 4);
+            const int group = 2;  // exercise the multi-launch path
+            const int nsq = (int)fam[TSFA_FAM_SEQ].size();
             const double *xp = xs.data();
-            fam_seq_series(b, [=](int i) { return xp[i]; }, n, fam[TSFA_FAM_SEQ].data(), (int)fam[TSFA_FAM_SEQ].size(), row,
-                           seq.data(), tab.data(), edges.data(), group, maxn);
+            for (int s0 = 0; s0 < nsq; s0 += group) {
+                TsfaSeqGroup g;
+                lz_build_group(fam[TSFA_FAM_SEQ].data() + s0, std::min(group, nsq - s0), maxn, &g);
+                std::vector<uint32_t> seqw(((size_t)g.nb * g.stride + 16) / 4 + 1), tab((size_t)g.ttotal + 4);
+                std::vector<double> edges(g.etotal + 4);
+                fam_seq_series(b, [=](int i) { return xp[i]; }, n, g, row, (unsigned char *)seqw.data(), tab.data(),
+                               edges.data());
+            }
         }
         if (!fam[TSFA_FAM_CWT].empty()) {
             const int with_rowv = (s % 2 == 0) ? 1 : 0;  // exercise both variants

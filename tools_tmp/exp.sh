@@ -1,2 +1,12 @@
-run() { timeout 200 python bench.py --steps 2 --warmup 1 --no-cpu-baseline 2>&1 | tail -1 | python -c "import json,sys; d=json.loads(sys.stdin.read()); print({k: round(v,1) for k,v in d['kernel_ms'].items()})"; }
-for nt in 64 128 256; do echo nt=$nt; TSFA_NT_0=$nt TSFA_NT_1=$nt TSFA_NT_2=$nt TSFA_NT_3=$nt TSFA_NT_5=$nt TSFA_NT_6=$nt run; done
+#!/bin/bash
+export TMPDIR=/tmp
+mkdir -p gpurun_out/exp
+run() { timeout 300 python bench.py --steps 3 --warmup 1 --no-cpu-baseline "$@" 2>&1 | tail -1 | python -c "import json,sys; d=json.loads(sys.stdin.read()); print(round(d['ms_per_step'],2), {k: round(v,1) for k,v in d['kernel_ms'].items()})"; }
+{
+timeout 900 python -m pytest tests -m gpu -x -q 2>&1 | tail -3
+echo default; run
+echo ENT_SLOW; TSFA_ENT_SLOW=1 run
+for nt in 64 128; do echo "seq nt=$nt"; TSFA_NT_6=$nt run; done
+echo efficient; run --params efficient --n-series 10000
+echo len256; run --length 256 --n-series 125000
+} > gpurun_out/exp/log2.txt 2>&1

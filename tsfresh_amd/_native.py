@@ -23,7 +23,8 @@ TSFA_HOST, TSFA_DEVICE = 0, 1
 # every symbol include/tsfresh_amd.h declares
 EXPORTS = (
     "tsfa_version", "tsfa_device_count", "tsfa_last_error", "tsfa_calc_id", "tsfa_calc_name", "tsfa_calc_count",
-    "tsfa_plan_create", "tsfa_plan_n_cols", "tsfa_plan_destroy", "tsfa_extract", "tsfa_plan_set_profiling",
+    "tsfa_plan_create", "tsfa_plan_n_cols", "tsfa_plan_destroy", "tsfa_extract", "tsfa_extract_timed",
+    "tsfa_plan_set_profiling",
     "tsfa_plan_last_timings",
 )
 
@@ -69,6 +70,10 @@ def load():
     lib.tsfa_extract.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int32, ctypes.c_void_p, ctypes.c_int64,
                                  ctypes.c_void_p, ctypes.c_int64, ctypes.c_int32, ctypes.c_void_p]
     lib.tsfa_extract.restype = ctypes.c_int
+    lib.tsfa_extract_timed.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int32, ctypes.c_void_p,
+                                       ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p, ctypes.c_int64, ctypes.c_int32,
+                                       ctypes.c_void_p]
+    lib.tsfa_extract_timed.restype = ctypes.c_int
     lib.tsfa_plan_set_profiling.argtypes = [ctypes.c_void_p, ctypes.c_int32]
     lib.tsfa_plan_set_profiling.restype = ctypes.c_int
     lib.tsfa_plan_last_timings.argtypes = [ctypes.c_void_p, ctypes.POINTER(ctypes.c_char_p),
@@ -128,8 +133,10 @@ class Plan:
         n = self._lib.tsfa_plan_last_timings(self._h, names, ms, cap)
         return [(names[i].decode(), float(ms[i])) for i in range(n)]
 
-    def extract_host(self, values, offsets):
-        """values: 1-D float32/float64 ndarray; offsets: int64 ndarray (n_series + 1) -> float64 [n_series, n_cols]."""
+    def extract_host(self, values, offsets, times=None):
+        """values: 1-D float32/float64 ndarray; offsets: int64 ndarray (n_series + 1) -> float64 [n_series, n_cols].
+        times: float64 ndarray laid out like `values` (hours since each series' first timestamp) for plans that
+        hold linear_trend_timewise columns."""
         values = np.ascontiguousarray(values)
         if values.dtype == np.float32:
             dt = TSFA_F32
@@ -143,9 +150,15 @@ class Plan:
             return out
         if values.size == 0:
             raise ValueError("every series must hold at least one sample")
-        _check(self._lib, self._lib.tsfa_extract(
-            self._h, values.ctypes.data_as(ctypes.c_void_p), dt, offsets.ctypes.data_as(ctypes.c_void_p), n_series,
-            out.ctypes.data_as(ctypes.c_void_p), self.n_cols, TSFA_HOST, None))
+        tptr = None
+        if times is not None:
+            times = np.ascontiguousarray(times, dtype=np.float64)
+            if times.shape != values.shape:
+                raise ValueError("times must have one entry per sample")
+            tptr = times.ctypes.data_as(ctypes.c_void_p)
+        _check(self._lib, self._lib.tsfa_extract_timed(
+            self._h, values.ctypes.data_as(ctypes.c_void_p), dt, tptr, offsets.ctypes.data_as(ctypes.c_void_p),
+            n_series, out.ctypes.data_as(ctypes.c_void_p), self.n_cols, TSFA_HOST, None))
         return out
 
     def extract_device(self, values_ptr, dtype, offsets_ptr, n_series, out_ptr, ld_out, stream=None):

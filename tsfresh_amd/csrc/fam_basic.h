@@ -134,15 +134,17 @@ TSFA_DEV double blk_longest_run(const Blk &b, int n, P pred, int *iw) {
 #define TSFA_ALT_CACHE 16
 #define TSFA_PEAK_NEAR 10
 #define TSFA_DEV_UNUSED
+//   times: HBM, the series' timestamps as float64 hours since its first sample (linear_trend_timewise), or null
 TSFA_DEV void fam_basic_series(const Blk &b, const double *xs, int n, const TsfaSpec *specs, int nspecs,
                                double *out_row, double *w, double *cum, double *altc, int *iw, const double *dectab,
-                               int peaks_maxsup, int alt_want_p) {
+                               int peaks_maxsup, int alt_want_p, const double *times = nullptr) {
     BasicStats st;
     basic_stats(b, xs, n, st);
     const double dn = (double)n;
     const double mean = st.mean;
-    bool have_cumsum = false, have_lt = false;
+    bool have_cumsum = false, have_lt = false, have_ltt = false;
     double lt5[5] = {0.0, 0.0, 0.0, 0.0, 0.0};
+    double ltt5[5] = {TSFA_NAN, TSFA_NAN, TSFA_NAN, TSFA_NAN, TSFA_NAN};
     double imq_sabs = 0.0;
 
     bool have_peaks = false;
@@ -489,6 +491,16 @@ TSFA_DEV void fam_basic_series(const Blk &b, const double *xs, int n, const Tsfa
 #pragma unroll
             for (int k = 1; k < 5; ++k)
                 if (k == (int)p0) v = lt5[k];
+        } break;
+        case TSFA_C_LINEAR_TREND_TIMEWISE: {                             // fc.py:2274
+            if (!have_ltt) {
+                if (times != nullptr && n >= 2) blk_linregress_xy(b, n, [=](int i) { return times[i]; }, [=](int i) { return xs[i]; }, ltt5);
+                have_ltt = true;
+            }
+            v = ltt5[0];
+#pragma unroll
+            for (int k = 1; k < 5; ++k)
+                if (k == (int)p0) v = ltt5[k];
         } break;
         case TSFA_C_AGG_LINEAR_TREND: {                                  // fc.py:2171
             const int attr = (int)p0, cl = (int)p1, agg = (int)p2;

@@ -50,6 +50,19 @@ TSFA_DEV void ent_lds_add(unsigned int *p, unsigned int v) {
 
 struct EntCol { double x0, x1, x2; };
 
+// The four totals of the group's k-th threshold go straight to the batch table in LDS (racc[4 * batch position]):
+// no per-thread result arrays, hence no scratch memory.
+TSFA_DEV void ent_store_acc(const Blk &b, double *racc, const int *gidx, int gn, int k, double slm, double slm1,
+                            double scm, double scm1) {
+    if (b.tid == 0 && k < gn) {
+        double *d = racc + 4 * gidx[k];
+        d[0] = slm;
+        d[1] = slm1;
+        d[2] = scm;
+        d[3] = scm1;
+    }
+}
+
 // Reference to the first sample of a template: on the GPU the absolute LDS byte address of xs[idx] (a ds_read
 // address register as it stands: no scaling, no base add), in the emulation the index itself.
 typedef unsigned int ent_ref;
@@ -124,7 +137,7 @@ TSFA_DEV void ent_eval_group(double xi0, double xi1, double xi2, const EntCol *c
 // ---------------------------------------------------------------------------------------------------------------
 template <int NK>
 TSFA_DEV void entropy_sweep_sym(const Blk &b, const double *xs, int n, const double *thr, const unsigned short *perm,
-                                const ent_ref *refs, unsigned int *cnt, EntAcc *acc) {
+                                const ent_ref *refs, unsigned int *cnt, double *racc, const int *gidx, int gn) {
     const int W = TSFA_ENT_WAVE, G = TSFA_ENT_G;
     const int nrow_m = n - 1;   // templates of length 2
     const int nrow_m1 = n - 2;  // templates of length 3
@@ -234,10 +247,7 @@ TSFA_DEV void entropy_sweep_sym(const Blk &b, const double *xs, int n, const dou
     for (int k = 0; k < NK; ++k) {
         slm[k] += log(pm[k]) - (double)nm[k] * ldm;
         slm1[k] += log(pm1[k]) - (double)nm1[k] * ldm1;
-        acc[k].sum_log_m = blk_sum(b, slm[k]);
-        acc[k].sum_log_m1 = blk_sum(b, slm1[k]);
-        acc[k].sum_cnt_m = blk_sum(b, scm[k]);
-        acc[k].sum_cnt_m1 = blk_sum(b, scm1[k]);
+        ent_store_acc(b, racc, gidx, gn, k, blk_sum(b, slm[k]), blk_sum(b, slm1[k]), blk_sum(b, scm[k]), blk_sum(b, scm1[k]));
     }
 }
 
@@ -248,7 +258,7 @@ TSFA_DEV void entropy_sweep_sym(const Blk &b, const double *xs, int n, const dou
 // ---------------------------------------------------------------------------------------------------------------
 template <int NK, typename XT>
 TSFA_DEV void entropy_sweep_m2(const Blk &b, const XT *xs, int n, const double *thr, const unsigned short *perm,
-                               EntAcc *acc) {
+                               double *racc, const int *gidx, int gn) {
     const int nrow_m = n - 1;   // templates of length 2: i in [0, n-2]
     const int nrow_m1 = n - 2;  // templates of length 3: i in [0, n-3]
     double r[NK];
@@ -310,12 +320,8 @@ TSFA_DEV void entropy_sweep_m2(const Blk &b, const XT *xs, int n, const double *
         }
     }
 #pragma unroll
-    for (int k = 0; k < NK; ++k) {
-        acc[k].sum_log_m = blk_sum(b, slm[k]);
-        acc[k].sum_log_m1 = blk_sum(b, slm1[k]);
-        acc[k].sum_cnt_m = blk_sum(b, scm[k]);
-        acc[k].sum_cnt_m1 = blk_sum(b, scm1[k]);
-    }
+    for (int k = 0; k < NK; ++k)
+        ent_store_acc(b, racc, gidx, gn, k, blk_sum(b, slm[k]), blk_sum(b, slm1[k]), blk_sum(b, scm[k]), blk_sum(b, scm1[k]));
 }
 
 // perm[0 .. n-2] = indices of the length-2 templates sorted by their first sample (ties by index); np2 = padded size
@@ -393,7 +399,9 @@ TSFA_DEV double sampen_from_acc(const EntAcc &a, int n, int m) {
 //   refs : LDS, as many ent_ref as perm (symmetric sweep only)
 //   cnt  : LDS, (n + 16) * TSFA_ENT_GROUP words, or null (-> ordered-pair sweep).  May alias b.np: the numpy-order
 //          sums are finished before the first sweep.  The symmetric sweep needs XT = double.
-template <typename XT>
+//   FAST : the plan holds only m = 2 specs and cnt != null (decided on the host): the ordered-pair and generic
+//          sweeps are compiled out, which keeps the register allocation of the hot kernel free of spills.
+template <typename XT, bool FAST = false>
 TSFA_DEV void fam_entropy_series(const Blk &b, XT *xs, int n, const TsfaSpec *specs, int nspecs, double *out_row,
                                  double *thr, unsigned short *perm, ent_ref *refs, unsigned int *cnt) {
     // np.std(x), numpy summation order (the tolerances are c * np.std(x))
@@ -432,7 +440,7 @@ TSFA_DEV void fam_entropy_series(const Blk &b, XT *xs, int n, const TsfaSpec *sp
             const int padded = ((n - 1 + 63) / 64) * 64 + 32;
             for (int i = n - 1 + b.tid; i < padded; i += b.nt) perm[i] = (unsigned short)n;
             blk_sync();
-            if (cnt != nullptr) {
+            if (FAST || cnt != nullptr) {
                 for (int i = b.tid; i < padded; i += b.nt) refs[i] = ent_make_ref((const double *)(const void *)xs, (int)perm[i]);
                 blk_sync();
             }
@@ -444,7 +452,7 @@ TSFA_DEV void fam_entropy_series(const Blk &b, XT *xs, int n, const TsfaSpec *sp
         // indexed register arrays).
         double *gthr = thr + TSFA_ENT_MAXK;
         double *racc = thr + 2 * TSFA_ENT_MAXK;  // [TSFA_ENT_MAXK][4]
-        const int gcap = (cnt != nullptr) ? TSFA_ENT_GROUP : TSFA_ENT_MAXK;
+        const int gcap = (FAST || cnt != nullptr) ? TSFA_ENT_GROUP : TSFA_ENT_MAXK;
         const int ngroups = (nk + gcap - 1) / gcap;
         const int gsize = (nk + ngroups - 1) / ngroups;
         for (int g0 = 0; n >= 3 && g0 < nk; g0 += gsize) {
@@ -460,30 +468,17 @@ TSFA_DEV void fam_entropy_series(const Blk &b, XT *xs, int n, const TsfaSpec *sp
                 }
             }
             blk_sync();
-            EntAcc ga[TSFA_ENT_MAXK];
-            if (cnt != nullptr) {
+            if (FAST || cnt != nullptr) {
                 const double *xd = (const double *)(const void *)xs;  // cnt != null implies XT = double
-                if (gn <= 1) entropy_sweep_sym<1>(b, xd, n, gthr, perm, refs, cnt, ga);
-                else if (gn == 2) entropy_sweep_sym<2>(b, xd, n, gthr, perm, refs, cnt, ga);
-                else entropy_sweep_sym<3>(b, xd, n, gthr, perm, refs, cnt, ga);
-            } else {
-                if (gn <= 1) entropy_sweep_m2<1>(b, xs, n, gthr, perm, ga);
-                else if (gn <= 2) entropy_sweep_m2<2>(b, xs, n, gthr, perm, ga);
-                else if (gn <= 4) entropy_sweep_m2<4>(b, xs, n, gthr, perm, ga);
-                else if (gn <= 6) entropy_sweep_m2<6>(b, xs, n, gthr, perm, ga);
-                else entropy_sweep_m2<8>(b, xs, n, gthr, perm, ga);
-            }
-            if (b.tid == 0) {
-#pragma unroll
-                for (int k = 0; k < TSFA_ENT_MAXK; ++k) {
-                    if (k < gn) {
-                        const int pos = gidx[k];
-                        racc[4 * pos + 0] = ga[k].sum_log_m;
-                        racc[4 * pos + 1] = ga[k].sum_log_m1;
-                        racc[4 * pos + 2] = ga[k].sum_cnt_m;
-                        racc[4 * pos + 3] = ga[k].sum_cnt_m1;
-                    }
-                }
+                if (gn <= 1) entropy_sweep_sym<1>(b, xd, n, gthr, perm, refs, cnt, racc, gidx, gn);
+                else if (gn == 2) entropy_sweep_sym<2>(b, xd, n, gthr, perm, refs, cnt, racc, gidx, gn);
+                else entropy_sweep_sym<3>(b, xd, n, gthr, perm, refs, cnt, racc, gidx, gn);
+            } else if (!FAST) {
+                if (gn <= 1) entropy_sweep_m2<1>(b, xs, n, gthr, perm, racc, gidx, gn);
+                else if (gn <= 2) entropy_sweep_m2<2>(b, xs, n, gthr, perm, racc, gidx, gn);
+                else if (gn <= 4) entropy_sweep_m2<4>(b, xs, n, gthr, perm, racc, gidx, gn);
+                else if (gn <= 6) entropy_sweep_m2<6>(b, xs, n, gthr, perm, racc, gidx, gn);
+                else entropy_sweep_m2<8>(b, xs, n, gthr, perm, racc, gidx, gn);
             }
         }
         blk_sync();
@@ -514,7 +509,7 @@ TSFA_DEV void fam_entropy_series(const Blk &b, XT *xs, int n, const TsfaSpec *sp
         blk_sync();
     }
     // generic m
-    for (int s = 0; s < nspecs; ++s) {
+    for (int s = 0; !FAST && s < nspecs; ++s) {
         const TsfaSpec sp = specs[s];
         if (sp.calc != TSFA_C_APPROXIMATE_ENTROPY || (int)sp.p[0] == 2) continue;
         const int m = (int)sp.p[0];

@@ -51,6 +51,9 @@ struct DevBuf {
     }
 };
 
+#define TSFA_MAX_AUX 3
+#define TSFA_DEFAULT_STREAMS 1
+
 struct Timing {
     std::string name;
     hipEvent_t e0 = nullptr, e1 = nullptr;
@@ -69,7 +72,12 @@ struct tsfa_plan {
     int *d_cols = nullptr, *d_coeff = nullptr;
     double *d_dectab = nullptr, *d_twc = nullptr, *d_tws = nullptr;
     long long *d_stats = nullptr;
-    DevBuf values, offsets, out, gscratch;
+    DevBuf values, offsets, out, gscratch, times;
+    bool needs_times = false;  // the plan holds linear_trend_timewise columns
+    // side streams: the family kernels are independent (each writes its own columns), so they may overlap
+    int n_streams = 1;
+    hipStream_t aux[TSFA_MAX_AUX] = {nullptr};
+    hipEvent_t ev_fork = nullptr, ev_join[TSFA_MAX_AUX] = {nullptr};
     bool profiling = false;
     std::vector<Timing> timings;
 };
@@ -129,6 +137,7 @@ void tsfa_plan_destroy(tsfa_plan *plan) {
     if (plan->d_twc) (void)hipFree(plan->d_twc);
     if (plan->d_tws) (void)hipFree(plan->d_tws);
     if (plan->d_stats) (void)hipFree(plan->d_stats);
+    plan->times.release();
     plan->values.release();
     plan->offsets.release();
     plan->out.release();
@@ -137,6 +146,11 @@ void tsfa_plan_destroy(tsfa_plan *plan) {
         if (t.e0) (void)hipEventDestroy(t.e0);
         if (t.e1) (void)hipEventDestroy(t.e1);
     }
+    for (int i = 0; i < TSFA_MAX_AUX; ++i) {
+        if (plan->aux[i]) (void)hipStreamDestroy(plan->aux[i]);
+        if (plan->ev_join[i]) (void)hipEventDestroy(plan->ev_join[i]);
+    }
+    if (plan->ev_fork) (void)hipEventDestroy(plan->ev_fork);
     if (plan->stream) (void)hipStreamDestroy(plan->stream);
     delete plan;
 }
@@ -167,6 +181,7 @@ int tsfa_plan_create(const tsfa_feature_spec *specs, int32_t n_specs, int32_t de
             delete plan;
             return fail(TSFA_ERR_UNSUPPORTED, std::string("spec ") + std::to_string(i) + " (" + tsfa_calc_table[s.calc].name + "): " + why);
         }
+        if (s.calc == TSFA_C_LINEAR_TREND_TIMEWISE) plan->needs_times = true;
         if (s.calc == TSFA_C_CWT_COEFFICIENTS) cwt_coef.push_back(s);
         else plan->fam_specs[tsfa_calc_table[s.calc].family].push_back(s);
     }
@@ -199,6 +214,14 @@ int tsfa_plan_create(const tsfa_feature_spec *specs, int32_t n_specs, int32_t de
         ok = upload(dt, &plan->d_dectab) == 0 && upload(twc, &plan->d_twc) == 0 && upload(tws, &plan->d_tws) == 0;
     }
     if (ok) ok = hipMalloc((void **)&plan->d_stats, 4 * sizeof(long long)) == hipSuccess;
+    {
+        const char *e = getenv("TSFA_STREAMS");
+        plan->n_streams = e ? std::min(std::max(atoi(e), 1), TSFA_MAX_AUX + 1) : TSFA_DEFAULT_STREAMS;
+        for (int i = 0; ok && i + 1 < plan->n_streams; ++i)
+            ok = hipStreamCreateWithFlags(&plan->aux[i], hipStreamNonBlocking) == hipSuccess &&
+                 hipEventCreateWithFlags(&plan->ev_join[i], hipEventDisableTiming) == hipSuccess;
+        if (ok && plan->n_streams > 1) ok = hipEventCreateWithFlags(&plan->ev_fork, hipEventDisableTiming) == hipSuccess;
+    }
     if (!ok) {
         tsfa_plan_destroy(plan);
         return fail(TSFA_ERR_HIP, "device allocation/upload failed while creating the plan");
@@ -229,7 +252,15 @@ int32_t tsfa_plan_last_timings(const tsfa_plan *plan, const char **names, float 
 
 int tsfa_extract(tsfa_plan *plan, const void *values, int32_t dtype, const int64_t *offsets, int64_t n_series,
                  double *out, int64_t ld_out, int32_t space, void *stream) {
+    return tsfa_extract_timed(plan, values, dtype, nullptr, offsets, n_series, out, ld_out, space, stream);
+}
+
+int tsfa_extract_timed(tsfa_plan *plan, const void *values, int32_t dtype, const double *times, const int64_t *offsets,
+                       int64_t n_series, double *out, int64_t ld_out, int32_t space, void *stream) {
     if (!plan) return fail(TSFA_ERR_INVALID, "plan is NULL");
+    if (plan->needs_times && !times)
+        return fail(TSFA_ERR_INVALID, "the plan holds linear_trend_timewise columns: call tsfa_extract_timed with the "
+                                      "per-sample times (the reference skips the calculator without a DatetimeIndex)");
     if (dtype != TSFA_F32 && dtype != TSFA_F64) return fail(TSFA_ERR_INVALID, "dtype must be TSFA_F32 or TSFA_F64");
     if (space != TSFA_HOST && space != TSFA_DEVICE) return fail(TSFA_ERR_INVALID, "space must be TSFA_HOST or TSFA_DEVICE");
     if (n_series < 0) return fail(TSFA_ERR_INVALID, "n_series < 0");
@@ -242,6 +273,7 @@ int tsfa_extract(tsfa_plan *plan, const void *values, int32_t dtype, const int64
     const size_t esz = (dtype == TSFA_F32) ? 4 : 8;
 
     const void *d_values = values;
+    const double *d_times = plan->needs_times ? times : nullptr;
     const int64_t *d_offsets = offsets;
     double *d_out = out;
     int64_t ld = ld_out;
@@ -257,6 +289,11 @@ int tsfa_extract(tsfa_plan *plan, const void *values, int32_t dtype, const int64
         HIP_TRY(hipMemcpyAsync(plan->values.p, (const char *)values + (size_t)base * esz, (size_t)total * esz,
                                hipMemcpyHostToDevice, st));
         HIP_TRY(hipMemcpyAsync(plan->offsets.p, rel.data(), rel.size() * sizeof(int64_t), hipMemcpyHostToDevice, st));
+        if (d_times) {
+            if (plan->times.ensure((size_t)total * sizeof(double) + 16)) return fail(TSFA_ERR_HIP, "hipMalloc failed for the times buffer");
+            HIP_TRY(hipMemcpyAsync(plan->times.p, times + base, (size_t)total * sizeof(double), hipMemcpyHostToDevice, st));
+            d_times = (const double *)plan->times.p;
+        }
         HIP_TRY(hipStreamSynchronize(st));  // rel goes out of scope below
         d_values = plan->values.p;
         d_offsets = (const int64_t *)plan->offsets.p;
@@ -278,9 +315,25 @@ int tsfa_extract(tsfa_plan *plan, const void *values, int32_t dtype, const int64
 
     if (tsfa_launch_fill_nan(d_out, n_series * ld, st)) return fail(TSFA_ERR_HIP, "fill launch failed");
 
+    // Launch order: longest kernels first.  With side streams (and no per-kernel timing requested) the families are
+    // dealt round-robin over the streams after a fork event; the join events bring them back to `st`.
+    static const int order[TSFA_N_FAMILIES] = {TSFA_FAM_ENTROPY, TSFA_FAM_BASIC, TSFA_FAM_AR, TSFA_FAM_SORT,
+                                               TSFA_FAM_SEQ, TSFA_FAM_CWT, TSFA_FAM_SPECTRAL};
+    const bool overlap = plan->n_streams > 1 && !plan->profiling;
+    if (overlap) {
+        HIP_TRY(hipEventRecord(plan->ev_fork, st));
+        for (int i = 0; i + 1 < plan->n_streams; ++i) HIP_TRY(hipStreamWaitEvent(plan->aux[i], plan->ev_fork, 0));
+    }
     size_t slot = 0;
-    for (int f = 0; f < TSFA_N_FAMILIES; ++f) {
+    int dealt = 0;
+    for (int fi = 0; fi < TSFA_N_FAMILIES; ++fi) {
+        const int f = order[fi];
         if (plan->fam_specs[f].empty()) continue;
+        hipStream_t fst = st;
+        if (overlap) {
+            const int k = dealt++ % plan->n_streams;
+            if (k > 0) fst = plan->aux[k - 1];
+        }
         TsfaLaunch a;
         memset(&a, 0, sizeof a);
         a.fam = f;
@@ -308,8 +361,9 @@ int tsfa_extract(tsfa_plan *plan, const void *values, int32_t dtype, const int64
             const char *e = getenv(key);
             if (e && atoi(e) >= 64) a.nt = atoi(e);
         }
-        a.stream = st;
+        a.stream = fst;
         a.dectab = plan->d_dectab;
+        a.times = d_times;
         a.twc = plan->d_twc;
         a.tws = plan->d_tws;
         a.hint_a = plan->hints[f].a;
@@ -349,26 +403,51 @@ int tsfa_extract(tsfa_plan *plan, const void *values, int32_t dtype, const int64
             const int waves = std::min(4, std::max(1, (maxn - 1 + 63) / 64));
             a.nt = std::max(a.nt, 64 * waves);
             a.ent_cnt = tsfa_entropy_lds_bytes(maxn, 1) <= TSFA_LDS_LIMIT ? 1 : 0;
-        } else if (f == TSFA_FAM_SEQ) {
-            // parse as many `bins` values side by side as LDS allows
-            int group = std::min(a.nspecs, TSFA_LZ_MAX_GROUP);
-            for (;; --group) {
-                lz_group_budget(plan->fam_specs[f].data(), a.nspecs, group, maxn, &a.seq_tab_entries, &a.seq_edge_doubles);
-                if (group == 1 || tsfa_seq_lds_bytes(maxn, group, a.seq_tab_entries, a.seq_edge_doubles) <= TSFA_LDS_LIMIT) break;
-            }
-            a.ntab = group;
+            a.ent_fast = a.ent_cnt;
+            for (const auto &s : plan->fam_specs[f])
+                if (s.calc == TSFA_C_APPROXIMATE_ENTROPY && (int)s.p[0] != 2) a.ent_fast = 0;
+            if (getenv("TSFA_ENT_SLOW")) a.ent_fast = 0;  // experiment / test hook: the general kernel
         }
-        const size_t lds = (f == TSFA_FAM_SEQ) ? tsfa_seq_lds_bytes(maxn, a.ntab, a.seq_tab_entries, a.seq_edge_doubles)
+        // SEQ: one launch parses up to TSFA_LZ_MAX_GROUP `bins` values side by side -- as many as LDS allows
+        int seq_group = 0;
+        if (f == TSFA_FAM_SEQ) {
+            for (seq_group = std::min(a.nspecs, TSFA_LZ_MAX_GROUP); seq_group > 1; --seq_group) {
+                bool fits = true;
+                for (int s0 = 0; fits && s0 < a.nspecs; s0 += seq_group) {
+                    lz_build_group(plan->fam_specs[f].data() + s0, std::min(seq_group, a.nspecs - s0), maxn, &a.seq);
+                    fits = tsfa_seq_lds_bytes(a.seq) <= TSFA_LDS_LIMIT;
+                }
+                if (fits) break;
+            }
+            lz_build_group(plan->fam_specs[f].data(), std::min(seq_group, a.nspecs), maxn, &a.seq);
+        }
+        const size_t lds = (f == TSFA_FAM_SEQ) ? tsfa_seq_lds_bytes(a.seq)
                            : (f == TSFA_FAM_ENTROPY) ? tsfa_entropy_lds_bytes(maxn, a.ent_cnt)
                                                      : tsfa_family_lds_bytes(f, maxn, a.nt, aux);
         if (lds > TSFA_LDS_LIMIT)
             return fail(TSFA_ERR_TOO_LONG, std::string(fam_names[f]) + ": a series of " + std::to_string(maxn) +
                                                " samples needs " + std::to_string(lds) + " B of LDS (limit 163840)");
-        if (record(plan, st, slot, fam_names[f], true)) return fail(TSFA_ERR_HIP, "event record failed");
-        const int rc = tsfa_launch_family(a);
+        if (record(plan, fst, slot, fam_names[f], true)) return fail(TSFA_ERR_HIP, "event record failed");
+        int rc = 0;
+        if (f == TSFA_FAM_SEQ) {
+            for (int s0 = 0; rc == 0 && s0 < a.nspecs; s0 += seq_group) {
+                lz_build_group(plan->fam_specs[f].data() + s0, std::min(seq_group, a.nspecs - s0), maxn, &a.seq);
+                if (tsfa_seq_lds_bytes(a.seq) > TSFA_LDS_LIMIT)
+                    return fail(TSFA_ERR_TOO_LONG, "k_seq: a series of " + std::to_string(maxn) + " samples does not fit LDS");
+                rc = tsfa_launch_family(a);
+            }
+        } else {
+            rc = tsfa_launch_family(a);
+        }
         if (rc) return fail(TSFA_ERR_HIP, std::string(fam_names[f]) + " launch failed: " + hipGetErrorString((hipError_t)rc));
-        if (record(plan, st, slot, fam_names[f], false)) return fail(TSFA_ERR_HIP, "event record failed");
+        if (record(plan, fst, slot, fam_names[f], false)) return fail(TSFA_ERR_HIP, "event record failed");
         ++slot;
+    }
+    if (overlap) {
+        for (int i = 0; i + 1 < plan->n_streams; ++i) {
+            HIP_TRY(hipEventRecord(plan->ev_join[i], plan->aux[i]));
+            HIP_TRY(hipStreamWaitEvent(st, plan->ev_join[i], 0));
+        }
     }
     if (plan->bank.C > 0) {
         TsfaCwtLaunch c;

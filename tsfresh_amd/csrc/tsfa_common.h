@@ -516,6 +516,61 @@ TSFA_DEV void blk_linregress_index(const Blk &b, int m, G g, double *out5, bool 
     out5[TSFA_ATTR_STDERR] = stderr_;
 }
 
+// scipy.stats.linregress(x, y) for an arbitrary abscissa (fc.py:2274 linear_trend_timewise: x = hours since the
+// first timestamp).  Centred sums as np.cov(x, y, bias=1) forms them.  All x identical: scipy raises ValueError
+// ("Cannot calculate a linear regression if all x values are identical"); here every attribute is NaN.
+template <class GX, class GY>
+TSFA_DEV void blk_linregress_xy(const Blk &b, int m, GX gx, GY gy, double *out5) {
+    const double dm = (double)m;
+    double sx = 0.0, sy = 0.0;
+    for (int i = b.tid; i < m; i += b.nt) { sx += gx(i); sy += gy(i); }
+    sx = blk_sum(b, sx);
+    sy = blk_sum(b, sy);
+    const double xmean = sx / dm, ymean = sy / dm;
+    double sxx = 0.0, sxy = 0.0, syy = 0.0;
+    for (int i = b.tid; i < m; i += b.nt) {
+        const double dx = gx(i) - xmean, dy = gy(i) - ymean;
+        sxx += dx * dx;
+        sxy += dx * dy;
+        syy += dy * dy;
+    }
+    sxx = blk_sum(b, sxx);
+    sxy = blk_sum(b, sxy);
+    syy = blk_sum(b, syy);
+    const double ssxm = sxx / dm, ssxym = sxy / dm, ssym = syy / dm;
+    if (ssxm == 0.0) {
+#pragma unroll
+        for (int k = 0; k < 5; ++k) out5[k] = TSFA_NAN;
+        return;
+    }
+    double r;
+    if (ssym == 0.0) {
+        r = 0.0;
+    } else {
+        r = ssxym / sqrt(ssxm * ssym);
+        if (r > 1.0) r = 1.0;
+        else if (r < -1.0) r = -1.0;
+    }
+    const double slope = ssxym / ssxm;
+    const double intercept = ymean - slope * xmean;
+    double prob, stderr_;
+    if (m == 2) {
+        prob = (gy(0) == gy(1)) ? 1.0 : 0.0;
+        stderr_ = 0.0;
+    } else {
+        const double df = dm - 2.0;
+        const double TINY = 1.0e-20;
+        const double t = r * sqrt(df / ((1.0 - r + TINY) * (1.0 + r + TINY)));
+        prob = tsfa_t_pvalue2(t, df);
+        stderr_ = sqrt((1.0 - r * r) * ssym / ssxm / df);
+    }
+    out5[TSFA_ATTR_PVALUE] = prob;
+    out5[TSFA_ATTR_RVALUE] = r;
+    out5[TSFA_ATTR_INTERCEPT] = intercept;
+    out5[TSFA_ATTR_SLOPE] = slope;
+    out5[TSFA_ATTR_STDERR] = stderr_;
+}
+
 // ---------------------------------------------------------------------------------------------
 // np.histogram(v, bins) with uniform bins over [vmin, vmax] followed by the entropy of the bin
 // probabilities (feature_calculators.py:1666 binned_entropy).  `cnt` = LDS int array of >= bins ints.

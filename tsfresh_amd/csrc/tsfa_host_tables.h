@@ -223,6 +223,7 @@ static inline std::string tsfa_validate_spec(const TsfaSpec &s) {
         if (!(is_int(p[0]) && p[0] >= 0)) return "lag must be a non-negative integer";
         break;
     case TSFA_C_LINEAR_TREND: if (!(p[0] >= 0 && p[0] <= 4)) return "linear_trend: unknown attr"; break;
+    case TSFA_C_LINEAR_TREND_TIMEWISE: if (!(p[0] >= 0 && p[0] <= 4)) return "linear_trend_timewise: unknown attr"; break;
     case TSFA_C_AGG_LINEAR_TREND:
         if (!(p[0] >= 0 && p[0] <= 4)) return "agg_linear_trend: unknown attr";
         if (!(is_int(p[1]) && p[1] >= 1)) return "agg_linear_trend: chunk_len must be a positive integer";

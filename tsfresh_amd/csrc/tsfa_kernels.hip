@@ -23,7 +23,8 @@ __device__ __forceinline__ void stage_series(const Blk &b, const T *__restrict__
 template <typename T>
 __global__ void __launch_bounds__(256, 2) k_basic(const T *__restrict__ values, const int64_t *__restrict__ offsets, int64_t n_series,
                         const TsfaSpec *__restrict__ specs, int nspecs, double *__restrict__ out, int64_t ld,
-                        const double *__restrict__ dectab, int maxn, int hint_a, int hint_b) {
+                        const double *__restrict__ dectab, int maxn, int hint_a, int hint_b,
+                        const double *__restrict__ times) {
     const int64_t sidx = blockIdx.x;
     if (sidx >= n_series) return;
     const int64_t off = offsets[sidx];
@@ -32,7 +33,8 @@ __global__ void __launch_bounds__(256, 2) k_basic(const T *__restrict__ values, 
     L.carve(tsfa_smem, maxn, blockDim.x);
     Blk b{(int)threadIdx.x, (int)blockDim.x, L.red, L.np};
     stage_series(b, values + off, n, L.xs);
-    fam_basic_series(b, L.xs, n, specs, nspecs, out + sidx * ld, L.w, L.cum, L.altc, L.iw, dectab, hint_a, hint_b);
+    fam_basic_series(b, L.xs, n, specs, nspecs, out + sidx * ld, L.w, L.cum, L.altc, L.iw, dectab, hint_a, hint_b,
+                     times ? times + off : nullptr);
 }
 
 template <typename T>
@@ -50,7 +52,7 @@ __global__ void __launch_bounds__(256) k_sort(const T *__restrict__ values, cons
 }
 
 template <typename T>
-__global__ void k_spectral(const T *__restrict__ values, const int64_t *__restrict__ offsets, int64_t n_series,
+__global__ void __launch_bounds__(256) k_spectral(const T *__restrict__ values, const int64_t *__restrict__ offsets, int64_t n_series,
                            const TsfaSpec *__restrict__ specs, int nspecs, double *__restrict__ out, int64_t ld,
                            int maxn, int dft_n, double *__restrict__ gscratch, int gscratch_n,
                            const double *__restrict__ twc, const double *__restrict__ tws, int hint_a, int hint_b) {
@@ -72,7 +74,7 @@ __global__ void k_spectral(const T *__restrict__ values, const int64_t *__restri
 }
 
 template <typename T>
-__global__ void k_ar(const T *__restrict__ values, const int64_t *__restrict__ offsets, int64_t n_series,
+__global__ void __launch_bounds__(256) k_ar(const T *__restrict__ values, const int64_t *__restrict__ offsets, int64_t n_series,
                      const TsfaSpec *__restrict__ specs, int nspecs, double *__restrict__ out, int64_t ld, int maxn,
                      int P) {
     const int64_t sidx = blockIdx.x;
@@ -86,8 +88,9 @@ __global__ void k_ar(const T *__restrict__ values, const int64_t *__restrict__ o
     fam_ar_series(b, [=](int i) { return (double)g[i]; }, n, specs, nspecs, out + sidx * ld, L.xc, L.rbuf, L.aw, P);
 }
 
-template <typename T>
-__global__ void k_entropy(const T *__restrict__ values, const int64_t *__restrict__ offsets, int64_t n_series,
+// FAST: symmetric sweep only (m = 2 specs, LDS counters fit) -- see fam_entropy_series
+template <typename T, bool FAST>
+__global__ void __launch_bounds__(256, 4) k_entropy(const T *__restrict__ values, const int64_t *__restrict__ offsets, int64_t n_series,
                           const TsfaSpec *__restrict__ specs, int nspecs, double *__restrict__ out, int64_t ld,
                           int maxn, int with_cnt) {
     const int64_t sidx = blockIdx.x;
@@ -98,27 +101,25 @@ __global__ void k_entropy(const T *__restrict__ values, const int64_t *__restric
     L.carve(tsfa_smem, maxn, with_cnt);
     Blk b{(int)threadIdx.x, (int)blockDim.x, L.red, L.np};
     stage_series(b, values + off, n, L.xs);
-    fam_entropy_series<double>(b, L.xs, n, specs, nspecs, out + sidx * ld, L.thr, L.perm, L.refs, L.cnt);
+    fam_entropy_series<double, FAST>(b, L.xs, n, specs, nspecs, out + sidx * ld, L.thr, L.perm, L.refs, L.cnt);
 }
 
 template <typename T>
-__global__ void k_seq(const T *__restrict__ values, const int64_t *__restrict__ offsets, int64_t n_series,
-                      const TsfaSpec *__restrict__ specs, int nspecs, double *__restrict__ out, int64_t ld, int maxn,
-                      int group, int tab_entries, int edge_doubles) {
+__global__ void __launch_bounds__(256) k_seq(const T *__restrict__ values, const int64_t *__restrict__ offsets, int64_t n_series,
+                      double *__restrict__ out, int64_t ld, const TsfaSeqGroup g) {
     const int64_t sidx = blockIdx.x;
     if (sidx >= n_series) return;
     const int64_t off = offsets[sidx];
     const int n = (int)(offsets[sidx + 1] - off);
     SeqLds L;
-    L.carve(tsfa_smem, maxn, group, tab_entries, edge_doubles);
+    L.carve(tsfa_smem, g.nb, g.stride, g.ttotal, g.etotal);
     Blk b{(int)threadIdx.x, (int)blockDim.x, L.red, nullptr};
-    const T *g = values + off;
-    fam_seq_series(b, [=](int i) { return (double)g[i]; }, n, specs, nspecs, out + sidx * ld, L.seq, L.tab, L.edges,
-                   group, maxn);
+    const T *gv = values + off;
+    fam_seq_series(b, [=](int i) { return (double)gv[i]; }, n, g, out + sidx * ld, L.seq, L.tab, L.edges);
 }
 
 template <typename T>
-__global__ void k_cwtpeaks(const T *__restrict__ values, const int64_t *__restrict__ offsets, int64_t n_series,
+__global__ void __launch_bounds__(256) k_cwtpeaks(const T *__restrict__ values, const int64_t *__restrict__ offsets, int64_t n_series,
                            const TsfaSpec *__restrict__ specs, int nspecs, double *__restrict__ out, int64_t ld,
                            int maxn, int with_rowv) {
     const int64_t sidx = blockIdx.x;
@@ -194,7 +195,7 @@ __global__ void k_fill_nan(double *__restrict__ out, int64_t n) {
 }
 
 // per-batch length statistics: [0] = max length, [1] = min length, [2] = max non-power-of-two length
-__global__ void k_len_stats(const int64_t *__restrict__ offsets, int64_t n_series, long long *__restrict__ stats) {
+__global__ void __launch_bounds__(256) k_len_stats(const int64_t *__restrict__ offsets, int64_t n_series, long long *__restrict__ stats) {
     long long mx = 0, mn = (1LL << 62), mnp = 0;
     for (int64_t s = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; s < n_series;
          s += (int64_t)gridDim.x * blockDim.x) {
@@ -203,9 +204,28 @@ __global__ void k_len_stats(const int64_t *__restrict__ offsets, int64_t n_serie
         mn = l < mn ? l : mn;
         if (l > 0 && (l & (l - 1)) != 0) mnp = l > mnp ? l : mnp;
     }
-    atomicMax(&stats[0], mx);
-    atomicMin(&stats[1], mn);
-    atomicMax(&stats[2], mnp);
+    // one atomic per workgroup (256 contended 64-bit atomics per counter, not 65536)
+    __shared__ long long red[3][4];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const long long a = __shfl_xor(mx, o), c = __shfl_xor(mn, o), d = __shfl_xor(mnp, o);
+        mx = a > mx ? a : mx;
+        mn = c < mn ? c : mn;
+        mnp = d > mnp ? d : mnp;
+    }
+    const int wave = threadIdx.x >> 6;
+    if ((threadIdx.x & 63) == 0) { red[0][wave] = mx; red[1][wave] = mn; red[2][wave] = mnp; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int w = 1; w < (int)(blockDim.x >> 6); ++w) {
+            mx = red[0][w] > mx ? red[0][w] : mx;
+            mn = red[1][w] < mn ? red[1][w] : mn;
+            mnp = red[2][w] > mnp ? red[2][w] : mnp;
+        }
+        atomicMax(&stats[0], mx);
+        atomicMin(&stats[1], mn);
+        atomicMax(&stats[2], mnp);
+    }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -238,7 +258,7 @@ static int launch_all_t(const TsfaLaunch &a, const T *values) {
         const size_t lds = L.carve(nullptr, a.maxn, nt);
         if ((rc = set_lds(k_basic<T>, lds))) return rc;
         k_basic<T><<<grid, nt, lds, st>>>(values, a.offsets, a.n_series, a.specs, a.nspecs, a.out, a.ld, a.dectab, a.maxn,
-                                          a.hint_a, a.hint_b);
+                                          a.hint_a, a.hint_b, a.times);
     } else if (a.fam == TSFA_FAM_SORT) {
         SortLds L;
         const size_t lds = L.carve(nullptr, a.maxn, nt);
@@ -258,15 +278,20 @@ static int launch_all_t(const TsfaLaunch &a, const T *values) {
     } else if (a.fam == TSFA_FAM_ENTROPY) {
         EntropyLds L;
         const size_t lds = L.carve(nullptr, a.maxn, a.ent_cnt);
-        if ((rc = set_lds(k_entropy<T>, lds))) return rc;
-        k_entropy<T><<<grid, nt, lds, st>>>(values, a.offsets, a.n_series, a.specs, a.nspecs, a.out, a.ld, a.maxn,
-                                            a.ent_cnt);
+if (a.ent_fast) {
+            if ((rc = set_lds(k_entropy<T, true>, lds))) return rc;
+            k_entropy<T, true><<<grid, nt, lds, st>>>(values, a.offsets, a.n_series, a.specs, a.nspecs, a.out, a.ld, a.maxn,
+                                                      a.ent_cnt);
+        } else {
+            if ((rc = set_lds(k_entropy<T, false>, lds))) return rc;
+            k_entropy<T, false><<<grid, nt, lds, st>>>(values, a.offsets, a.n_series, a.specs, a.nspecs, a.out, a.ld, a.maxn,
+                                                       a.ent_cnt);
+        }
     } else if (a.fam == TSFA_FAM_SEQ) {
         SeqLds L;
-        const size_t lds = L.carve(nullptr, a.maxn, a.ntab, a.seq_tab_entries, a.seq_edge_doubles);
+        const size_t lds = L.carve(nullptr, a.seq.nb, a.seq.stride, a.seq.ttotal, a.seq.etotal);
         if ((rc = set_lds(k_seq<T>, lds))) return rc;
-        k_seq<T><<<grid, nt, lds, st>>>(values, a.offsets, a.n_series, a.specs, a.nspecs, a.out, a.ld, a.maxn, a.ntab,
-                                        a.seq_tab_entries, a.seq_edge_doubles);
+        k_seq<T><<<grid, nt, lds, st>>>(values, a.offsets, a.n_series, a.out, a.ld, a.seq);
     } else if (a.fam == TSFA_FAM_CWT) {  // number_cwt_peaks
         CwtPeaksLayout L;
         const size_t lds = L.carve(nullptr, a.maxn, a.cwt_rowv);
@@ -285,9 +310,9 @@ size_t tsfa_entropy_lds_bytes(int maxn, int with_cnt) {
     return L.carve(nullptr, maxn, with_cnt);
 }
 
-size_t tsfa_seq_lds_bytes(int maxn, int group, int tab_entries, int edge_doubles) {
+size_t tsfa_seq_lds_bytes(const TsfaSeqGroup &g) {
     SeqLds L;
-    return L.carve(nullptr, maxn, group, tab_entries, edge_doubles);
+    return L.carve(nullptr, g.nb, g.stride, g.ttotal, g.etotal);
 }
 
 size_t tsfa_family_lds_bytes(int fam, int maxn, int nt, int aux) {

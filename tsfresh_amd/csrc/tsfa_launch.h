@@ -6,6 +6,7 @@
 #include <stdint.h>
 
 #include "tsfa_specs.h"
+#include "fam_seq.h"
 
 struct TsfaLaunch {
     int fam;
@@ -22,17 +23,17 @@ struct TsfaLaunch {
     void *stream;
     // family extras
     const double *dectab;   // BASIC: decimal table for benford_correlation
+    const double *times;    // BASIC: per-sample hours since the series' first timestamp (linear_trend_timewise) or null
     const double *twc, *tws;  // SPECTRAL: shared FFT twiddles
     int dft_n;              // SPECTRAL: DFT twiddle slots held in LDS
     double *gscratch;       // SPECTRAL: HBM twiddle scratch for long non-pow2 series (or null)
     int gscratch_n;
-    int ntab;               // SEQ: specs parsed side by side (group size)
-    int seq_tab_entries;    // SEQ: hash-table slots of the largest group
-    int seq_edge_doubles;   // SEQ: bin edges of the largest group
+    TsfaSeqGroup seq;       // SEQ: the (<= TSFA_LZ_MAX_GROUP) specs this launch parses side by side
     int ar_P;               // AR: leading dimension of the normal matrices
     int cwt_rowv;           // CWT peaks: second CWT row resident in LDS
     int hint_a, hint_b;     // tsfa_prepare_family (BASIC, SPECTRAL)
     int ent_cnt;            // ENTROPY: per-template LDS counters (symmetric sweep)
+    int ent_fast;           // ENTROPY: only m = 2 specs and ent_cnt: the kernel variant without the fallback sweeps
 };
 
 struct TsfaCwtLaunch {
@@ -51,7 +52,7 @@ struct TsfaCwtLaunch {
 
 size_t tsfa_family_lds_bytes(int fam, int maxn, int nt, int aux);
 size_t tsfa_entropy_lds_bytes(int maxn, int with_cnt);
-size_t tsfa_seq_lds_bytes(int maxn, int group, int tab_entries, int edge_doubles);
+size_t tsfa_seq_lds_bytes(const TsfaSeqGroup &g);
 int tsfa_launch_family(const TsfaLaunch &a);
 int tsfa_launch_cwt(const TsfaCwtLaunch &a);
 int tsfa_launch_fill_nan(double *out, int64_t n, void *stream);

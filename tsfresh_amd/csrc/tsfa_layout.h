@@ -8,6 +8,7 @@
 
 #include "tsfa_common.h"
 #include "fam_cwt.h"
+#include "fam_seq.h"
 
 #if defined(__HIPCC__)
 #define TSFA_HD __host__ __device__ inline
@@ -131,12 +132,13 @@ struct EntropyLds {
 
 struct SeqLds {
     double *red; unsigned char *seq; uint32_t *tab; double *edges;
-    TSFA_HD size_t carve(unsigned char *base, int maxn, int group, int tab_entries, int edge_doubles) {
+    // group: chains parsed side by side; stride: bytes per symbol row; tab_words / edge_doubles: TsfaSeqGroup totals
+    TSFA_HD size_t carve(unsigned char *base, int group, int stride, int tab_words, int edge_doubles) {
         LdsCarve c{base, 0};
         red = c.take<double>(TSFA_RED_DOUBLES);
         edges = c.take<double>(edge_doubles + 2);
-        tab = c.take<uint32_t>((size_t)tab_entries);
-        seq = c.take<unsigned char>((size_t)group * maxn + 16);
+        tab = c.take<uint32_t>((size_t)tab_words);
+        seq = c.take<unsigned char>((size_t)group * stride + 16);
         return c.off;
     }
 };

@@ -120,7 +120,8 @@ enum tsfa_family {
     X(APPROXIMATE_ENTROPY, "approximate_entropy", TSFA_FAM_ENTROPY)                     \
     X(CWT_COEFFICIENTS, "cwt_coefficients", TSFA_FAM_CWT)                               \
     X(NUMBER_CWT_PEAKS, "number_cwt_peaks", TSFA_FAM_CWT)                               \
-    X(LEMPEL_ZIV_COMPLEXITY, "lempel_ziv_complexity", TSFA_FAM_SEQ)
+    X(LEMPEL_ZIV_COMPLEXITY, "lempel_ziv_complexity", TSFA_FAM_SEQ)                     \
+    X(LINEAR_TREND_TIMEWISE, "linear_trend_timewise", TSFA_FAM_BASIC)
 
 enum tsfa_calc {
 #define X(id, name, fam) TSFA_C_##id,

@@ -13,11 +13,12 @@ import pandas as pd
 class PackedKind:
     """All series of one kind: `values[offsets[i]:offsets[i+1]]` is the series of `ids[i]` (ids sorted)."""
 
-    def __init__(self, kind, ids, values, offsets):
+    def __init__(self, kind, ids, values, offsets, times=None):
         self.kind = kind
         self.ids = ids
         self.values = values
         self.offsets = offsets
+        self.times = times  # float64 hours since each series' first timestamp (DatetimeIndex input only)
 
     @property
     def n_series(self):
@@ -57,8 +58,18 @@ def _as_values(column):
     return arr.astype(np.float64)
 
 
-def _pack(kind, ids, values, sort_values):
-    """Group `values` by `ids` (ascending), each group ordered by `sort_values` (stable)."""
+def _hours_since_first(index, order, offsets):
+    """Per sample: hours since the first timestamp of its series, with the arithmetic of the reference's
+    linear_trend_timewise (feature_calculators.py:2291-2296): (ix - ix[0]).total_seconds() / 3600.0."""
+    ix = index[order]
+    counts = np.diff(offsets)
+    first = ix[np.repeat(offsets[:-1], counts)]
+    return np.ascontiguousarray(np.asarray((ix - first).total_seconds() / float(3600)), dtype=np.float64)
+
+
+def _pack(kind, ids, values, sort_values, index=None):
+    """Group `values` by `ids` (ascending), each group ordered by `sort_values` (stable).  `index`: the frame's
+    DatetimeIndex (row-aligned with `values`) or None."""
     codes, uniques = pd.factorize(np.asarray(ids), sort=True)
     if sort_values is not None:
         order = np.lexsort((np.asarray(sort_values), codes))
@@ -67,7 +78,8 @@ def _pack(kind, ids, values, sort_values):
     counts = np.bincount(codes, minlength=len(uniques))
     offsets = np.zeros(len(uniques) + 1, dtype=np.int64)
     np.cumsum(counts, out=offsets[1:])
-    return PackedKind(str(kind), np.asarray(uniques), np.ascontiguousarray(_as_values(values)[order]), offsets)
+    times = _hours_since_first(index, order, offsets) if index is not None and len(order) else None
+    return PackedKind(str(kind), np.asarray(uniques), np.ascontiguousarray(_as_values(values)[order]), offsets, times)
 
 
 def pack_timeseries(container, column_id=None, column_kind=None, column_value=None, column_sort=None):
@@ -90,6 +102,7 @@ def pack_timeseries(container, column_id=None, column_kind=None, column_value=No
             if column_sort is not None:
                 _check_nan(df, column_sort)
             kinds = df[column_kind].to_numpy()
+            dt_index = df.index if isinstance(df.index, pd.DatetimeIndex) else None
             kcodes, kuniq = pd.factorize(kinds, sort=True)
             packed = []
             ids_all = df[column_id].to_numpy()
@@ -97,7 +110,8 @@ def pack_timeseries(container, column_id=None, column_kind=None, column_value=No
             sort_all = df[column_sort].to_numpy() if column_sort is not None else None
             for k, kind in enumerate(kuniq):
                 sel = np.nonzero(kcodes == k)[0]
-                packed.append(_pack(kind, ids_all[sel], vals_all[sel], None if sort_all is None else sort_all[sel]))
+                packed.append(_pack(kind, ids_all[sel], vals_all[sel], None if sort_all is None else sort_all[sel],
+                                    None if dt_index is None else dt_index[sel]))
             return packed, df[column_id].dtype, isinstance(df.index, pd.DatetimeIndex)
         # wide format (data.py:181-230)
         _check_nan(df, column_id)
@@ -108,7 +122,8 @@ def pack_timeseries(container, column_id=None, column_kind=None, column_value=No
             _check_nan(df, column_sort)
         ids_all = df[column_id].to_numpy()
         sort_all = df[column_sort].to_numpy() if column_sort is not None else None
-        packed = [_pack(col, ids_all, df[col].to_numpy(), sort_all) for col in value_columns]
+        dt_index = df.index if isinstance(df.index, pd.DatetimeIndex) else None
+        packed = [_pack(col, ids_all, df[col].to_numpy(), sort_all, dt_index) for col in value_columns]
         return packed, df[column_id].dtype, isinstance(df.index, pd.DatetimeIndex)
     if isinstance(container, dict):
         # dict of frames, one per kind (data.py:294-338)
@@ -121,7 +136,8 @@ def pack_timeseries(container, column_id=None, column_kind=None, column_value=No
         packed, id_dtype, has_dt = [], None, False
         for kind, frame in container.items():
             sort_vals = frame[column_sort].to_numpy() if column_sort is not None else None
-            packed.append(_pack(kind, frame[column_id].to_numpy(), frame[column_value].to_numpy(), sort_vals))
+            packed.append(_pack(kind, frame[column_id].to_numpy(), frame[column_value].to_numpy(), sort_vals,
+                                frame.index if isinstance(frame.index, pd.DatetimeIndex) else None))
             id_dtype = frame[column_id].dtype
             has_dt = has_dt or isinstance(frame.index, pd.DatetimeIndex)
         return packed, id_dtype, has_dt

@@ -95,15 +95,16 @@ def extract_features(
                 fc_parameters = kind_to_fc_parameters[pk.kind]
             else:
                 fc_parameters = default_fc_parameters
-            key = id(fc_parameters)
+            kind_has_dt = pk.times is not None  # extraction.py:349-358 checks the index of each series
+            key = (id(fc_parameters), kind_has_dt)
             if key not in plan_cache:
-                fplan = compile_fc_parameters(fc_parameters, has_datetime_index=has_dt_index)
+                fplan = compile_fc_parameters(fc_parameters, has_datetime_index=kind_has_dt)
                 nplan = _native.Plan(fplan.native_specs(_native.calc_id), device=device) if len(fplan) else None
                 plan_cache[key] = (fplan, nplan)
             fplan, nplan = plan_cache[key]
             if nplan is None:
                 continue
-            matrix = nplan.extract_host(pk.values, pk.offsets)
+            matrix = nplan.extract_host(pk.values, pk.offsets, times=pk.times)
             blocks.append((pk, [pk.kind + "__" + name for name in fplan.names], matrix))
         for _, nplan in plan_cache.values():
             if nplan is not None:

@@ -36,7 +36,7 @@ def compile_fc_parameters(fc_parameters, has_datetime_index=False):
 
     Column order follows the reference: calculators in dict order, parameter sets in list order
     (extraction.py:339-378).  Raises UnsupportedFeature for anything that has no native kernel -- custom
-    callables, matrix_profile, query_similarity_count with a query, linear_trend_timewise on a DatetimeIndex --
+    callables, matrix_profile, query_similarity_count with a query --
     instead of silently computing it on the CPU.
     """
     names, specs, seen = [], [], set()
@@ -54,7 +54,6 @@ def compile_fc_parameters(fc_parameters, has_datetime_index=False):
                 warnings.warn("{} requires the data to have a index of type {}. Results will "
                               "not be calculated".format(key, "<class 'pandas.core.indexes.datetimes.DatetimeIndex'>"))
                 continue
-            raise UnsupportedFeature("{} on a DatetimeIndex has no native kernel yet".format(key))
         if not calc.native:
             raise UnsupportedFeature("{} has no native kernel".format(key))
         params = param_list if param_list else [None]

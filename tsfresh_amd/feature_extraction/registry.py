@@ -169,7 +169,8 @@ _CALCS = [
     Calc("energy_ratio_by_chunks", "combiner", encode=lambda p: (p["num_segments"], p["segment_focus"]),
          key=lambda p: "num_segments_{}__segment_focus_{}".format(p["num_segments"], p["segment_focus"])),
     # needs a DatetimeIndex; on any other index the reference skips it with a warning (extraction.py:349-358)
-    Calc("linear_trend_timewise", "combiner", input="pd.Series", index_type="DatetimeIndex", native=False,
+    Calc("linear_trend_timewise", "combiner", input="pd.Series", index_type="DatetimeIndex",
+         encode=lambda p: (_code(ATTR_LINREG, p["attr"], "linear_trend_timewise attr"),),
          key=lambda p: 'attr_"{}"'.format(p["attr"])),
     Calc("count_above", "simple", encode=lambda p: (p["t"],)),
     Calc("count_below", "simple", encode=lambda p: (p["t"],)),
