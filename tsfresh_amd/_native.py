@@ -9,7 +9,8 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libtsfresh_amd.so")
+# TSFA_LIB: diagnostics override (the phase-clock build of profiles/phase_ticks.py); the default is the in-tree library
+LIB_PATH = os.environ.get("TSFA_LIB") or os.path.join(_HERE, "libtsfresh_amd.so")
 
 TSFA_OK = 0
 TSFA_ERR_INVALID = -1

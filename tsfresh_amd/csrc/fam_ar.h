@@ -138,6 +138,7 @@ template <class X>
 TSFA_DEV void fam_ar_series(const Blk &b, X xv, int n, const TsfaSpec *specs, int nspecs, double *out_row, double *xc,
                             double *rbuf, double *aw, int P) {
     const double dn = (double)n;
+    TSFA_TICKER(tk, 0);
     // x.mean() in numpy's summation order: statsmodels demeans with it, and on (near-)constant series the
     // autocovariances are pure round-off of x - x.mean(), so the order decides what comes out
     const double mean = np_sum(b, n, [=](int i) { return xv(i); }) / dn;
@@ -382,6 +383,7 @@ TSFA_DEV void fam_ar_series(const Blk &b, X xv, int n, const TsfaSpec *specs, in
 
     int ar_cached_k = -1;
     bool ar_ok = false;
+    TSFA_TICK(tk, b, 120);
     for (int s = 0; s < nspecs; ++s) {
         const TsfaSpec sp = specs[s];
         double v = TSFA_NAN;
@@ -484,6 +486,7 @@ TSFA_DEV void fam_ar_series(const Blk &b, X xv, int n, const TsfaSpec *specs, in
         default: break;
         }
         if (b.tid == 0) out_row[sp.col] = v;
+        TSFA_TICK(tk, b, sp.calc);
     }
 }
 

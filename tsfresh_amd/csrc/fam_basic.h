@@ -125,6 +125,146 @@ TSFA_DEV double blk_longest_run(const Blk &b, int n, P pred, int *iw) {
     return blk_bcast0(b, res);
 }
 
+// agg_linear_trend (fc.py:2171), all distinct (chunk_len, f_agg) regressions of the plan at once:
+//   * one sweep per chunk_len computes every requested aggregate of a chunk together (lane = chunk),
+//   * the regression sums of the aggregates of one chunk_len are accumulated side by side (independent chains) and
+//     reduced back to back,
+//   * the scalar tail of linregress (a dozen dependent float64 divisions / square roots, ~4k cycles) runs ONCE with
+//     lane = regression instead of once per regression on every lane.
+// raw: LDS, 6 doubles per key (m, mean, sxy, syy, y0, y1); w: LDS, >= n doubles; altc[8 * key + 2 + attr] = results.
+TSFA_DEV void alt_fill_all(const Blk &b, const double *xs, int n, const TsfaAltPlan &alt, double *w, double *raw,
+                           double *altc) {
+    const int nkeys = alt.nkeys;
+    int k0 = 0;
+    TSFA_TICKER(tka, 0);
+    while (k0 < nkeys) {
+        const int cl = alt.cl[k0];
+        int k1 = k0 + 1;
+        while (k1 < nkeys && alt.cl[k1] == cl && k1 - k0 < 4) ++k1;
+        const int m = (n + cl - 1) / cl;
+        if (cl >= n || (k1 - k0) * m > n) k1 = k0 + 1;  // no room for several aggregate rows: one key at a time
+        const int ng = k1 - k0;
+        if (cl >= n) {  // fc.py: chunk_len >= len(x) -> NaN
+            blk_sync();
+            if (b.tid == 0) raw[6 * k0] = 0.0;
+            k0 = k1;
+            continue;
+        }
+        int ag[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) ag[j] = (j < ng) ? alt.agg[k0 + j] : -1;
+        blk_sync();
+        for (int c = b.tid; c < m; c += b.nt) {  // fc.py:176 _aggregate_on_chunks
+            const int lo = c * cl;
+            const int hi = (lo + cl < n) ? lo + cl : n;
+            bool need_max = false, need_min = false, need_mean = false, need_var = false;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                need_max |= (ag[j] == TSFA_AGG_MAX);
+                need_min |= (ag[j] == TSFA_AGG_MIN);
+                need_mean |= (ag[j] == TSFA_AGG_MEAN) || (ag[j] == TSFA_AGG_VAR);
+                need_var |= (ag[j] == TSFA_AGG_VAR);
+            }
+            double vmx = xs[lo], vmn = xs[lo], vmean = 0.0, vvar = 0.0;
+            if (need_max || need_min)
+                for (int i = lo + 1; i < hi; ++i) { const double x = xs[i]; vmx = fmax(vmx, x); vmn = fmin(vmn, x); }
+            if (need_mean) vmean = np_leaf_sum(lo, hi - lo, [=](int i) { return xs[i]; }) / (double)(hi - lo);
+            if (need_var)
+                vvar = np_leaf_sum(lo, hi - lo, [=](int i) { const double d = xs[i] - vmean; return d * d; }) / (double)(hi - lo);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                if (j >= ng) continue;
+                const double r = (ag[j] == TSFA_AGG_MAX) ? vmx : (ag[j] == TSFA_AGG_MIN) ? vmn : (ag[j] == TSFA_AGG_MEAN) ? vmean : vvar;
+                w[j * m + c] = r;
+            }
+        }
+        blk_sync();
+        TSFA_TICK(tka, b, 200);
+        const double dm = (double)m;
+        const double xmean = (dm - 1.0) * 0.5;
+        double sy[4] = {0.0, 0.0, 0.0, 0.0};
+        for (int i = b.tid; i < m; i += b.nt) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                if (j < ng) sy[j] += w[j * m + i];
+        }
+        double ym[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) ym[j] = (j < ng) ? blk_sum(b, sy[j]) / dm : 0.0;
+        double sxy[4] = {0.0, 0.0, 0.0, 0.0}, syy[4] = {0.0, 0.0, 0.0, 0.0};
+        for (int i = b.tid; i < m; i += b.nt) {
+            const double dx = (double)i - xmean;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                if (j < ng) {
+                    const double dy = w[j * m + i] - ym[j];
+                    sxy[j] += dx * dy;
+                    syy[j] += dy * dy;
+                }
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            if (j < ng) {
+                const double a = blk_sum(b, sxy[j]), c2 = blk_sum(b, syy[j]);
+                if (b.tid == 0) {
+                    double *r = raw + 6 * (k0 + j);
+                    r[0] = dm;
+                    r[1] = ym[j];
+                    r[2] = a;
+                    r[3] = c2;
+                    r[4] = w[j * m];
+                    r[5] = (m > 1) ? w[j * m + 1] : 0.0;
+                }
+            }
+        }
+        k0 = k1;
+        TSFA_TICK(tka, b, 201);
+    }
+    blk_sync();
+    // scalar tail of scipy.stats.linregress(range(m), y), lane = regression (blk_linregress_index restated)
+    for (int k = b.tid; k < nkeys; k += b.nt) {
+        const double *r = raw + 6 * k;
+        double *o = altc + 8 * k + 2;
+        const double dm = r[0];
+        if (dm == 0.0) {
+            for (int a = 0; a < 5; ++a) o[a] = TSFA_NAN;
+            continue;
+        }
+        const double ymean = r[1], xmean = (dm - 1.0) * 0.5;
+        const double ssxm = (dm * (dm * dm - 1.0) / 12.0) / dm;
+        const double ssxym = r[2] / dm, ssym = r[3] / dm;
+        double rr;
+        if (ssxm == 0.0 || ssym == 0.0) {
+            rr = 0.0;
+        } else {
+            rr = ssxym / sqrt(ssxm * ssym);
+            if (rr > 1.0) rr = 1.0;
+            else if (rr < -1.0) rr = -1.0;
+        }
+        const double slope = ssxym / ssxm;
+        const double intercept = ymean - slope * xmean;
+        double prob, stderr_;
+        if (dm == 2.0) {
+            prob = (r[4] == r[5]) ? 1.0 : 0.0;
+            stderr_ = 0.0;
+        } else {
+            const double df = dm - 2.0;
+            const double TINY = 1.0e-20;
+            const double t = rr * sqrt(df / ((1.0 - rr + TINY) * (1.0 + rr + TINY)));
+            prob = alt.want_p ? tsfa_t_pvalue2(t, df) : TSFA_NAN;
+            stderr_ = sqrt((1.0 - rr * rr) * ssym / ssxm / df);
+        }
+        o[TSFA_ATTR_PVALUE] = prob;
+        o[TSFA_ATTR_RVALUE] = rr;
+        o[TSFA_ATTR_INTERCEPT] = intercept;
+        o[TSFA_ATTR_SLOPE] = slope;
+        o[TSFA_ATTR_STDERR] = stderr_;
+    }
+    blk_sync();
+    TSFA_TICK(tka, b, 202);
+}
+
 // Evaluate the BASIC specs of one series.
 //   xs   : series as float64 in LDS, length n (n >= 1)
 //   w    : LDS work array of >= n doubles (chunk aggregates)
@@ -137,9 +277,11 @@ TSFA_DEV double blk_longest_run(const Blk &b, int n, P pred, int *iw) {
 //   times: HBM, the series' timestamps as float64 hours since its first sample (linear_trend_timewise), or null
 TSFA_DEV void fam_basic_series(const Blk &b, const double *xs, int n, const TsfaSpec *specs, int nspecs,
                                double *out_row, double *w, double *cum, double *altc, int *iw, const double *dectab,
-                               int peaks_maxsup, int alt_want_p, const double *times = nullptr) {
+                               int peaks_maxsup, int alt_want_p, const TsfaAltPlan &alt, const double *times = nullptr) {
+    TSFA_TICKER(tk, 0);
     BasicStats st;
     basic_stats(b, xs, n, st);
+    TSFA_TICK(tk, b, 100);
     const double dn = (double)n;
     const double mean = st.mean;
     bool have_cumsum = false, have_lt = false, have_ltt = false;
@@ -504,6 +646,15 @@ TSFA_DEV void fam_basic_series(const Blk &b, const double *xs, int n, const Tsfa
         } break;
         case TSFA_C_AGG_LINEAR_TREND: {                                  // fc.py:2171
             const int attr = (int)p0, cl = (int)p1, agg = (int)p2;
+            if (alt.nkeys > 0) {  // all regressions of the plan are computed by the first column
+                if (((int)sp.p[3]) >= 128) {
+                    have_cumsum = false;  // w may alias cum ...
+                    have_peaks = false;   // ... and holds the peak distances
+                    alt_fill_all(b, xs, n, alt, w, (double *)(void *)iw, altc);
+                }
+                v = altc[8 * (((int)sp.p[3]) & 127) + 2 + attr];
+                break;
+            }
             if (cl >= n) {
                 v = TSFA_NAN;
                 break;
@@ -552,6 +703,7 @@ TSFA_DEV void fam_basic_series(const Blk &b, const double *xs, int n, const Tsfa
         default: break;
         }
         if (b.tid == 0) out_row[sp.col] = v;
+        TSFA_TICK(tk, b, sp.calc);
     }
 }
 

@@ -77,6 +77,7 @@ TSFA_DEV void smallest8_select(V v, int m, int i0, double *s0, double *s1) {
 template <class X>
 TSFA_DEV double number_cwt_peaks_one(const Blk &b, X xv, int n, int W, const CwtPeaksLds &L) {
     const int cap = n;  // line capacity
+    TSFA_TICKER(tk, 0);
     blk_sync();
     for (int c = b.tid; c < n; c += b.nt) { L.mask[c] = 0; L.colmap[c] = 0; L.mline[c] = 0; }
     blk_sync();
@@ -102,6 +103,7 @@ TSFA_DEV double number_cwt_peaks_one(const Blk &b, X xv, int n, int W, const Cwt
         }
     }
     blk_sync();
+    TSFA_TICK(tk, b, 151);
     // ---- phase B ----
     int start_row = -1;
     for (int r = 0; r < W; ++r) {
@@ -188,6 +190,7 @@ TSFA_DEV double number_cwt_peaks_one(const Blk &b, X xv, int n, int W, const Cwt
         }
     }
     blk_sync();
+    TSFA_TICK(tk, b, 152);
     // ---- phase C ----
     const int min_length = (W + 3) / 4;             // ceil(rows / 4)
     const int window = (n + 19) / 20;               // ceil(num_points / 20)
@@ -245,6 +248,7 @@ TSFA_DEV double number_cwt_peaks_one(const Blk &b, X xv, int n, int W, const Cwt
         if (!(snr < 1.0)) kept += 1.0;
     }
     kept = blk_sum(b, kept);
+    TSFA_TICK(tk, b, 153);
     return overflow ? TSFA_NAN : kept;
 }
 

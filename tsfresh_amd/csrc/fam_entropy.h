@@ -150,6 +150,7 @@ TSFA_DEV void entropy_sweep_sym(const Blk &b, const double *xs, int n, const dou
     for (int i = b.tid; i < (nrow_m + 16) * NK; i += b.nt) cnt[i] = 0u;
     blk_sync();
 
+    TSFA_TICKER(tks, 0);
     const int npass = (nrow_m + W - 1) / W;
     for (int pass = wave; pass < npass; pass += nwave) {
         const int q0 = pass * W;
@@ -211,7 +212,9 @@ TSFA_DEV void entropy_sweep_sym(const Blk &b, const double *xs, int n, const dou
             for (int k = 0; k < NK; ++k) ent_lds_add(&cnt[qi * NK + k], (unsigned int)c2[k] | ((unsigned int)c3[k] << 16));
         }
     }
+    TSFA_TICK(tks, b, 136);
     blk_sync();
+    TSFA_TICK(tks, b, 137);
     // ---- totals: cnt[q] is now complete for every template ----
     // sum_i log(C_i / N) = log(prod_i C_i) - (#rows) * log(N): the counts are integers <= 2^16, so a thread multiplies
     // up to 16 of them into one double (< 2^1024, relative error 1e-16 per factor) and takes ONE logarithm.  Rows
@@ -405,6 +408,7 @@ template <typename XT, bool FAST = false>
 TSFA_DEV void fam_entropy_series(const Blk &b, XT *xs, int n, const TsfaSpec *specs, int nspecs, double *out_row,
                                  double *thr, unsigned short *perm, ent_ref *refs, unsigned int *cnt) {
     // np.std(x), numpy summation order (the tolerances are c * np.std(x))
+    TSFA_TICKER(tk, 0);
     const double dn = (double)n;
     const double mean = np_sum(b, n, [=](int i) { return (double)xs[i]; }) / dn;
     const double var = np_sum(b, n, [=](int i) { const double d = (double)xs[i] - mean; return d * d; }) / dn;
@@ -412,6 +416,7 @@ TSFA_DEV void fam_entropy_series(const Blk &b, XT *xs, int n, const TsfaSpec *sp
     blk_sync();
     if (b.tid == 0) { xs[n] = (XT)TSFA_INF; xs[n + 1] = (XT)TSFA_INF; xs[n + 2] = (XT)TSFA_INF; xs[n + 3] = (XT)TSFA_INF; }
     bool sorted = false;
+    TSFA_TICK(tk, b, 130);
 
     // m = 2 specs are batched TSFA_ENT_MAXK at a time
     int done = 0;
@@ -445,6 +450,7 @@ TSFA_DEV void fam_entropy_series(const Blk &b, XT *xs, int n, const TsfaSpec *sp
                 blk_sync();
             }
             sorted = true;
+            TSFA_TICK(tk, b, 131);
         }
         // Thresholds are swept in ascending order in groups of <= TSFA_ENT_GROUP neighbours (a group of small
         // tolerances only visits the narrow window of ITS largest one).  gthr = the group's thresholds; racc = the
@@ -468,6 +474,7 @@ TSFA_DEV void fam_entropy_series(const Blk &b, XT *xs, int n, const TsfaSpec *sp
                 }
             }
             blk_sync();
+            TSFA_TICK(tk, b, 132);
             if (FAST || cnt != nullptr) {
                 const double *xd = (const double *)(const void *)xs;  // cnt != null implies XT = double
                 if (gn <= 1) entropy_sweep_sym<1>(b, xd, n, gthr, perm, refs, cnt, racc, gidx, gn);
@@ -480,6 +487,7 @@ TSFA_DEV void fam_entropy_series(const Blk &b, XT *xs, int n, const TsfaSpec *sp
                 else if (gn <= 6) entropy_sweep_m2<6>(b, xs, n, gthr, perm, racc, gidx, gn);
                 else entropy_sweep_m2<8>(b, xs, n, gthr, perm, racc, gidx, gn);
             }
+            TSFA_TICK(tk, b, 133 + (g0 > 0 ? 1 : 0));
         }
         blk_sync();
         {

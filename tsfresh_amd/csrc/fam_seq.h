@@ -4,15 +4,15 @@
 // set is a previously entered phrase plus one symbol (all its proper prefixes starting at the same position were
 // found in the set), so the set is prefix-closed: a trie, held in LDS in the cheapest form that fits:
 //   DIRECT16 : child[node * bins + symbol] (uint16 node ids) -- one dependent LDS read per symbol; small alphabets
-//   HASH16   : open addressing keyed by (parent slot, symbol) packed in 16 bits, the slot index is the node id
-//   HASH32   : the same with 32-bit keys (large alphabets)
+//   HASH32   : open addressing keyed by (parent slot, symbol), the slot index is the node id (large alphabets)
 //
 // The parse is inherently sequential (one dependent table lookup per symbol), so the kernel's throughput is
 // (series resident per CU) / (latency of one step): the tables are sized tightly from the largest possible phrase
 // count so that more workgroups fit in the 160 KB of LDS, each requested `bins` value gets its own lane and table,
-// and the chains of one series are dealt over the wavefronts of the workgroup so that they step concurrently.
-// Every loop iteration consumes exactly ONE symbol whether the phrase is extended or closed; symbols are fetched
-// four at a time (one ds_read_b32) ahead of the dependent chain.
+// and the two table kinds run on different wavefronts of the workgroup (lane = chain), each in lockstep and without
+// per-symbol branches: a step is load -> compare -> select, the table entry is stored unconditionally (a known phrase
+// re-stores its own value).  Every step consumes exactly ONE symbol whether the phrase is extended or closed;
+// symbols are fetched four at a time (one ds_read_b32) ahead of the dependent chain.
 #ifndef TSFA_FAM_SEQ_H
 #define TSFA_FAM_SEQ_H
 
@@ -27,7 +27,7 @@
 #define TSFA_LZ_MAX_GROUP 8
 #define TSFA_LZ_DIRECT_MAX_BYTES 4096
 
-enum { TSFA_LZ_DIRECT16 = 0, TSFA_LZ_HASH16 = 1, TSFA_LZ_HASH32 = 2 };
+enum { TSFA_LZ_DIRECT16 = 0, TSFA_LZ_HASH32 = 2 };
 
 // Most phrases a parse of n symbols over an alphabet of b symbols can produce: all phrases are distinct strings, so
 // the count is maximised by taking every string of length 1, then every string of length 2, ...
@@ -50,17 +50,16 @@ TSFA_SEQ_HD int lz_max_phrases(int b, int n) {
 
 struct LzTable {
     int mode;   // TSFA_LZ_*
-    int cap;    // hash modes: slots (power of two, load factor <= 0.6); direct: (max phrases + 1) * bins entries
-    int lg;     // hash modes: log2(cap)
+    int cap;    // hash: slots (power of two, load factor <= 0.6); direct: (max phrases + 1) * bins entries
+    int lg;     // hash: log2(cap)
     int words;  // uint32 words of LDS
 };
-// Table of the parse of <= n symbols over `bins` symbols.  Shared by the host (LDS sizing), the device and the
-// emulation, so they can never disagree.
+// Table of the parse of <= n symbols over `bins` symbols.  Shared by the host (LDS sizing) and the emulation.
 TSFA_SEQ_HD LzTable lz_table_plan(int bins, int n) {
     LzTable t;
     const int P = lz_max_phrases(bins, n);
     const long long direct_bytes = 2LL * (P + 1) * bins;
-    if (direct_bytes <= TSFA_LZ_DIRECT_MAX_BYTES) {
+    if (direct_bytes <= TSFA_LZ_DIRECT_MAX_BYTES && P < 65535) {
         t.mode = TSFA_LZ_DIRECT16;
         t.cap = (P + 1) * bins;
         t.lg = 0;
@@ -68,28 +67,24 @@ TSFA_SEQ_HD LzTable lz_table_plan(int bins, int n) {
     } else {
         int cap = 16, lg = 4;
         while (3LL * cap < 5LL * P + 5) { cap <<= 1; ++lg; }  // cap >= (P + 1) / 0.6
+        t.mode = TSFA_LZ_HASH32;
         t.cap = cap;
         t.lg = lg;
-        if ((long long)(cap + 1) * bins <= 65535) {
-            t.mode = TSFA_LZ_HASH16;
-            t.words = cap / 2;
-        } else {
-            t.mode = TSFA_LZ_HASH32;
-            t.words = cap;
-        }
+        t.words = cap;
     }
     t.words = (t.words + 3) & ~3;  // 16-byte granules
     return t;
 }
 
 // bytes between the symbol rows of two chains (rows are read one 32-bit word = four symbols at a time)
-TSFA_SEQ_HD int lz_seq_stride(int maxn) { return ((maxn + 3) & ~3) + 4; }
+TSFA_SEQ_HD int lz_seq_stride(int maxn) { return ((maxn + 3) & ~3) + 8; }
 
 // One launch of the kernel parses up to TSFA_LZ_MAX_GROUP `bins` values side by side.  Everything that depends on
 // (bins, longest series of the batch) is worked out ONCE on the host -- lz_max_phrases divides 64-bit integers, far
 // too slow to repeat in every thread -- and handed to the kernel by value.
 struct TsfaSeqGroup {
     int nb;                           // chains of this group
+    int ndirect;                      // the first ndirect chains use direct tables, the rest hashed ones
     int ttotal;                       // uint32 words of table storage
     int etotal;                       // bin edges (doubles)
     int stride;                       // bytes between the symbol rows of two chains
@@ -104,97 +99,90 @@ struct TsfaSeqGroup {
 inline void lz_build_group(const TsfaSpec *specs, int nb, int maxn, TsfaSeqGroup *g) {
     g->nb = nb;
     g->stride = lz_seq_stride(maxn);
+    // chains with direct tables first: they share a wavefront (lane = chain), the hashed ones share another
+    int order[TSFA_LZ_MAX_GROUP], no = 0;
+    for (int pass = 0; pass < 2; ++pass)
+        for (int k = 0; k < nb; ++k)
+            if ((lz_table_plan((int)specs[k].p[0], maxn).mode == TSFA_LZ_DIRECT16) == (pass == 0)) order[no++] = k;
+    g->ndirect = 0;
     int t = 0, e = 0;
     for (int k = 0; k < TSFA_LZ_MAX_GROUP; ++k) {
-        const int bins = (k < nb) ? (int)specs[k].p[0] : 1;
+        const TsfaSpec *sp = (k < nb) ? &specs[order[k]] : nullptr;
+        const int bins = sp ? (int)sp->p[0] : 1;
         const LzTable lt = lz_table_plan(bins, maxn);
+        if (sp && lt.mode == TSFA_LZ_DIRECT16) g->ndirect = k + 1;
         g->bins[k] = bins;
         g->mode[k] = lt.mode;
         g->cap[k] = lt.cap;
         g->lg[k] = lt.lg;
         g->toff[k] = t;
         g->eoff[k] = e;
-        g->col[k] = (k < nb) ? specs[k].col : 0;
+        g->col[k] = sp ? sp->col : 0;
         if (k < nb) { t += lt.words; e += bins; }
     }
     g->ttotal = t;
     g->etotal = e;
 }
 
-// One parse.  sq: the chain's symbols (4-byte aligned, readable up to the next multiple of 4); tb: its table (zeroed).
-TSFA_DEV int lz_parse(const unsigned char *sq, int n, int bins, const LzTable &lt, uint32_t *tb) {
+// Lockstep parse of the calling lane's chain with a DIRECT16 table.  All lanes of the wavefront that call this walk the
+// same positions (one series, one length); `active` masks the lanes that own a chain.
+TSFA_DEV int lz_parse_direct(const unsigned char *sq, int n, int bins, unsigned short *t16) {
     int count = 0;
     uint32_t node = 0u;  // 0 = root
     const uint32_t *sw = (const uint32_t *)(const void *)sq;
-    if (lt.mode == TSFA_LZ_DIRECT16) {
-        unsigned short *t16 = (unsigned short *)(void *)tb;
-        for (int pos = 0; pos < n; pos += 4) {
-            uint32_t w = sw[pos >> 2];
-            const int lim = (n - pos < 4) ? (n - pos) : 4;
-            for (int k = 0; k < lim; ++k, w >>= 8) {
-                const uint32_t idx = node * (uint32_t)bins + (w & 255u);
+    const uint32_t ub = (uint32_t)bins;
+    uint32_t wnext = sw[0];
+    for (int pos = 0; pos < n; pos += 4) {
+        uint32_t w = wnext;
+        wnext = sw[(pos >> 2) + 1];  // the row is padded by one word
+        const int lim = (n - pos < 4) ? (n - pos) : 4;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            if (k < lim) {  // wave-uniform
+                const uint32_t idx = node * ub + (w & 255u);
+                w >>= 8;
                 const uint32_t c = t16[idx];
-                if (c != 0u) {
-                    node = c;  // known phrase: extend it with the next symbol
-                } else {
-                    t16[idx] = (unsigned short)(++count);  // new phrase: record it and restart at the root
-                    node = 0u;
-                }
-            }
-        }
-    } else if (lt.mode == TSFA_LZ_HASH16) {
-        unsigned short *t16 = (unsigned short *)(void *)tb;
-        const uint32_t mask = (uint32_t)lt.cap - 1u;
-        const int sh = 32 - lt.lg;
-        for (int pos = 0; pos < n; pos += 4) {
-            uint32_t w = sw[pos >> 2];
-            const int lim = (n - pos < 4) ? (n - pos) : 4;
-            for (int k = 0; k < lim; ++k, w >>= 8) {
-                const uint32_t key = node * (uint32_t)bins + (w & 255u) + 1u;  // non-zero, <= (cap + 1) * bins
-                uint32_t h = (key * 2654435761u) >> sh;
-                bool found = false;
-                for (;;) {
-                    const uint32_t cur = t16[h];
-                    if (cur == key) { found = true; break; }
-                    if (cur == 0u) break;
-                    h = (h + 1u) & mask;
-                }
-                if (found) {
-                    node = h + 1u;
-                } else {
-                    t16[h] = (unsigned short)key;
-                    ++count;
-                    node = 0u;
-                }
-            }
-        }
-    } else {
-        const uint32_t mask = (uint32_t)lt.cap - 1u;
-        const int sh = 32 - lt.lg;
-        for (int pos = 0; pos < n; pos += 4) {
-            uint32_t w = sw[pos >> 2];
-            const int lim = (n - pos < 4) ? (n - pos) : 4;
-            for (int k = 0; k < lim; ++k, w >>= 8) {
-                const uint32_t key = ((node << 8) | (w & 255u)) + 1u;  // non-zero
-                uint32_t h = (key * 2654435761u) >> sh;
-                bool found = false;
-                for (;;) {
-                    const uint32_t cur = tb[h];
-                    if (cur == key) { found = true; break; }
-                    if (cur == 0u) break;
-                    h = (h + 1u) & mask;
-                }
-                if (found) {
-                    node = h + 1u;
-                } else {
-                    tb[h] = key;
-                    ++count;
-                    node = 0u;
-                }
+                const bool fresh = (c == 0u);
+                count += fresh ? 1 : 0;
+                t16[idx] = (unsigned short)(fresh ? (uint32_t)count : c);  // new phrase: record it; known: unchanged
+                node = fresh ? 0u : c;                                     // ... and restart at the root / extend
             }
         }
     }
     // a trailing, already-known phrase is not added (the reference's while loop ends first)
+    return count;
+}
+
+// Lockstep parse with an open-addressing table keyed by (parent slot + 1, symbol); the slot index is the node id.
+TSFA_DEV int lz_parse_hash(const unsigned char *sq, int n, int cap, int lg, uint32_t *tb) {
+    int count = 0;
+    uint32_t node = 0u;
+    const uint32_t *sw = (const uint32_t *)(const void *)sq;
+    const uint32_t mask = (uint32_t)cap - 1u;
+    const int sh = 32 - lg;
+    uint32_t wnext = sw[0];
+    for (int pos = 0; pos < n; pos += 4) {
+        uint32_t w = wnext;
+        wnext = sw[(pos >> 2) + 1];
+        const int lim = (n - pos < 4) ? (n - pos) : 4;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            if (k < lim) {
+                const uint32_t key = ((node << 8) | (w & 255u)) + 1u;  // non-zero
+                w >>= 8;
+                uint32_t h = (key * 2654435761u) >> sh;
+                uint32_t cur = tb[h];
+                while (cur != key && cur != 0u) {  // collisions are rare (load factor <= 0.6)
+                    h = (h + 1u) & mask;
+                    cur = tb[h];
+                }
+                const bool fresh = (cur == 0u);
+                tb[h] = key;
+                count += fresh ? 1 : 0;
+                node = fresh ? 0u : (h + 1u);
+            }
+        }
+    }
     return count;
 }
 
@@ -206,6 +194,7 @@ TSFA_DEV int lz_parse(const unsigned char *sq, int n, int bins, const LzTable &l
 template <class X>
 TSFA_DEV void fam_seq_series(const Blk &b, X xv, int n, const TsfaSeqGroup &g, double *out_row, unsigned char *seq,
                              uint32_t *tab, double *edges) {
+    TSFA_TICKER(tk, 0);
     double mn = TSFA_INF, mx = -TSFA_INF;
     for (int i = b.tid; i < n; i += b.nt) {
         const double x = xv(i);
@@ -215,6 +204,7 @@ TSFA_DEV void fam_seq_series(const Blk &b, X xv, int n, const TsfaSeqGroup &g, d
     const double vmin = blk_min(b, mn), vmax = blk_max(b, mx);
     const int nb = g.nb, stride = g.stride;
     blk_sync();
+    TSFA_TICK(tk, b, 160);
     // bin edges: np.linspace(min, max, bins + 1)[1:]
 #pragma unroll
     for (int t = 0; t < TSFA_LZ_MAX_GROUP; ++t) {
@@ -224,6 +214,7 @@ TSFA_DEV void fam_seq_series(const Blk &b, X xv, int n, const TsfaSeqGroup &g, d
     }
     for (int k = b.tid; k < g.ttotal; k += b.nt) tab[k] = 0u;
     blk_sync();
+    TSFA_TICK(tk, b, 161);
     // symbols: np.searchsorted(edges, x, side="left") = #{edges < x}
     for (int i = b.tid; i < n; i += b.nt) {
         const double x = xv(i);
@@ -241,23 +232,47 @@ TSFA_DEV void fam_seq_series(const Blk &b, X xv, int n, const TsfaSeqGroup &g, d
         }
     }
     blk_sync();
+    TSFA_TICK(tk, b, 162);
+    // lane = chain: the direct chains on wavefront 0, the hashed ones on wavefront 1 (if the workgroup has one)
+    {
 #if TSFA_GPU
-    // chains are dealt over the wavefronts (chain t -> wave t % nw, lane t / nw) so that they step concurrently
-    const int nw = b.nt >> 6;
-    for (int t = (b.tid & 63) * nw + (b.tid >> 6); t < nb; t += b.nt) {
+        // direct chains: wavefront 0, lane = chain.  Hashed chains: dealt over the remaining wavefronts (a probe loop
+        // stalls only the chains that share its wavefront).
+        const int lane = b.tid & 63, wave = b.tid >> 6, nw = b.nt >> 6;
+        const int nhw = (nw > 1) ? nw - 1 : 1;                 // wavefronts that take hashed chains
+        const int hw = (nw > 1) ? wave - 1 : 0;                // this wavefront's index among them (-1: none)
+        const int hidx = lane * nhw + hw;                      // hashed chain of this lane
+        const bool do_direct = (wave == 0) && (lane < g.ndirect);
+        const bool do_hash = (hw >= 0) && (hidx < nb - g.ndirect);
+        const int td = lane, th = g.ndirect + hidx;
 #else
-    for (int t = b.tid; t < nb; t += b.nt) {
+        for (int t = 0; t < nb; ++t) {
+        const bool do_direct = (t < g.ndirect), do_hash = !do_direct;
+        const int td = t, th = t;
 #endif
-        LzTable lt;
-        int off = 0, bins = 1, col = 0;
-        lt.mode = 0; lt.cap = 0; lt.lg = 0; lt.words = 0;
+        if (do_direct) {
+            int off = 0, bins = 1, col = 0;
 #pragma unroll
-        for (int q = 0; q < TSFA_LZ_MAX_GROUP; ++q)
-            if (q == t) { off = g.toff[q]; bins = g.bins[q]; col = g.col[q]; lt.mode = g.mode[q]; lt.cap = g.cap[q]; lt.lg = g.lg[q]; }
-        const int count = lz_parse(seq + (size_t)t * stride, n, bins, lt, tab + off);
-        out_row[col] = (double)count / (double)n;
+            for (int q = 0; q < TSFA_LZ_MAX_GROUP; ++q)
+                if (q == td) { off = g.toff[q]; bins = g.bins[q]; col = g.col[q]; }
+            const int count = lz_parse_direct(seq + (size_t)td * stride, n, bins, (unsigned short *)(void *)(tab + off));
+            out_row[col] = (double)count / (double)n;
+        }
+        if (do_hash) {
+            int off = 0, cap = 16, lg = 4, col = 0;
+#pragma unroll
+            for (int q = 0; q < TSFA_LZ_MAX_GROUP; ++q)
+                if (q == th) { off = g.toff[q]; cap = g.cap[q]; lg = g.lg[q]; col = g.col[q]; }
+            const int count = lz_parse_hash(seq + (size_t)th * stride, n, cap, lg, tab + off);
+            out_row[col] = (double)count / (double)n;
+        }
+#if !TSFA_GPU
+        }
+#endif
     }
+    TSFA_TICK(tk, b, 163);
     blk_sync();
+    TSFA_TICK(tk, b, 164);
 }
 
 #endif

@@ -405,12 +405,83 @@ TSFA_DEV void friedrich_coeffs(const Blk &b, const double *xs, int n, S1 srt1, i
 //   srt  : LDS, >= next_pow2(n) doubles (sorted copy)
 //   w    : LDS, >= 768 doubles (Langevin-fit scratch)
 //   iw   : LDS, >= 2520 ints (ordinal-pattern histogram, two 16-bit counters per word); may alias w
+// change_quantiles (fc.py:1511), every corridor of the plan, four per sweep: the samples are read once per sweep and
+// the 12 + 8 partial sums of a sweep are reduced together (blk_sum_multi).  cq[5 * k ..] = count, mean, mean |.|,
+// var, var |.| of corridor k.
+TSFA_DEV void cq_fill_all(const Blk &b, const double *xs, const double *srt, int n, const TsfaCqPlan &plan, double *cq) {
+    for (int k0 = 0; k0 < plan.n; k0 += 4) {
+        const int ng = (plan.n - k0 < 4) ? (plan.n - k0) : 4;
+        double lo[4], hi[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            // pd.qcut(x, [ql, qh], labels=False) == 0  <=>  lo <= x <= hi  (right-closed, include_lowest)
+            lo[j] = (j < ng) ? pd_quantile_sorted([=](int i) { return srt[i]; }, n, plan.ql[k0 + j]) : TSFA_INF;
+            hi[j] = (j < ng) ? pd_quantile_sorted([=](int i) { return srt[i]; }, n, plan.qh[k0 + j]) : -TSFA_INF;
+        }
+        double s1[12];
+#pragma unroll
+        for (int k = 0; k < 12; ++k) s1[k] = 0.0;
+        for (int i = b.tid; i < n - 1; i += b.nt) {
+            const double x0 = xs[i], x1 = xs[i + 1];
+            const double d = x1 - x0, ad = fabs(d);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                if (x0 >= lo[j] && x0 <= hi[j] && x1 >= lo[j] && x1 <= hi[j]) {
+                    s1[3 * j] += 1.0;
+                    s1[3 * j + 1] += d;
+                    s1[3 * j + 2] += ad;
+                }
+            }
+        }
+        blk_sum_multi<12>(b, s1);
+        double m1[4], m2[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            m1[j] = (s1[3 * j] > 0.0) ? s1[3 * j + 1] / s1[3 * j] : 0.0;
+            m2[j] = (s1[3 * j] > 0.0) ? s1[3 * j + 2] / s1[3 * j] : 0.0;
+        }
+        double s2[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) s2[k] = 0.0;
+        for (int i = b.tid; i < n - 1; i += b.nt) {
+            const double x0 = xs[i], x1 = xs[i + 1];
+            const double d = x1 - x0, ad = fabs(d);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                if (x0 >= lo[j] && x0 <= hi[j] && x1 >= lo[j] && x1 <= hi[j]) {
+                    s2[2 * j] += (d - m1[j]) * (d - m1[j]);
+                    s2[2 * j + 1] += (ad - m2[j]) * (ad - m2[j]);
+                }
+            }
+        }
+        blk_sum_multi<8>(b, s2);
+        blk_sync();
+        if (b.tid == 0) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                if (j < ng) {
+                    double *o = cq + 5 * (k0 + j);
+                    const double c = s1[3 * j];
+                    o[0] = c;
+                    o[1] = m1[j];
+                    o[2] = m2[j];
+                    o[3] = (c > 0.0) ? s2[2 * j] / c : 0.0;
+                    o[4] = (c > 0.0) ? s2[2 * j + 1] / c : 0.0;
+                }
+            }
+        }
+    }
+    blk_sync();
+}
+
 TSFA_DEV void fam_sort_series(const Blk &b, const double *xs, int n, const TsfaSpec *specs, int nspecs,
-                              double *out_row, double *srt, double *w, int *iw) {
+                              double *out_row, double *srt, double *w, int *iw, const TsfaCqPlan &cqplan, double *cq) {
     const int np2 = next_pow2(n);
+    TSFA_TICKER(tk, 0);
     blk_sync();
     for (int i = b.tid; i < np2; i += b.nt) srt[i] = (i < n) ? xs[i] : TSFA_INF;
     blk_bitonic_sort(b, srt, np2);
+    TSFA_TICK(tk, b, 104);
     const double dn = (double)n;
     const double vmin = srt[0], vmax = srt[n - 1];
 
@@ -462,6 +533,14 @@ TSFA_DEV void fam_sort_series(const Blk &b, const double *xs, int n, const TsfaS
             const double ql = p0, qh = p1;
             const bool isabs = (p2 != 0.0);
             const int agg = (int)p3;
+            if (cqplan.n > 0 && p1 == -2.0) {  // indexed corridor: the first such column evaluates them all
+                if ((int)p0 >= 128) cq_fill_all(b, xs, srt, n, cqplan, cq);
+                const double *o = cq + 5 * (((int)p0) & 127);
+                if (o[0] == 0.0) v = 0.0;
+                else if (agg == TSFA_AGG_MEAN) v = isabs ? o[2] : o[1];
+                else v = isabs ? o[4] : o[3];
+                break;
+            }
             if (ql >= qh) { v = 0.0; break; }
             if (!(cq_valid && cq_ql == ql && cq_qh == qh)) {
                 // one scan per corridor serves its four columns (isabs x {mean, var})
@@ -613,6 +692,7 @@ TSFA_DEV void fam_sort_series(const Blk &b, const double *xs, int n, const TsfaS
         default: break;
         }
         if (b.tid == 0) out_row[sp.col] = v;
+        TSFA_TICK(tk, b, sp.calc);
     }
 }
 

@@ -55,6 +55,42 @@ struct Blk {
     NpScratch *np;  // LDS
 };
 
+// Phase clocks (diagnostics build only: make ticks -> libtsfresh_amd_ticks.so, read with tsfa_debug_ticks).
+// Thread 0 of every workgroup adds the shader-clock cycles since its previous mark to a global counter per phase id,
+// so one bench pass yields the per-phase latency breakdown of every kernel (rocprofv3 only sees whole kernels).
+#if TSFA_GPU && defined(TSFA_TICKS)
+static __device__ unsigned long long tsfa_ticks[256];
+static __shared__ unsigned long long tsfa_ticks_lds[256];  // per-workgroup accumulation; flushed once at kernel end
+struct Ticker {
+    unsigned long long t;
+    int base;
+    __device__ __forceinline__ explicit Ticker(int base_) : t(__builtin_readcyclecounter()), base(base_) {}
+    __device__ __forceinline__ void mark(int tid, int id) {
+        const unsigned long long now = __builtin_readcyclecounter();
+        if (tid == 0) tsfa_ticks_lds[base + id] += now - t;
+        t = __builtin_readcyclecounter();
+    }
+};
+#define TSFA_TICKER(name, base) Ticker name(base)
+#define TSFA_TICK(name, b, id) name.mark((b).tid, id)
+#define TSFA_TICKS_BEGIN()                                                                  \
+    do {                                                                                    \
+        for (int i_ = threadIdx.x; i_ < 256; i_ += blockDim.x) tsfa_ticks_lds[i_] = 0ull;   \
+        __syncthreads();                                                                    \
+    } while (0)
+#define TSFA_TICKS_END()                                                                    \
+    do {                                                                                    \
+        __syncthreads();                                                                    \
+        for (int i_ = threadIdx.x; i_ < 256; i_ += blockDim.x)                              \
+            if (tsfa_ticks_lds[i_]) atomicAdd(&tsfa_ticks[i_], tsfa_ticks_lds[i_]);         \
+    } while (0)
+#else
+#define TSFA_TICKER(name, base)
+#define TSFA_TICK(name, b, id)
+#define TSFA_TICKS_BEGIN()
+#define TSFA_TICKS_END()
+#endif
+
 // Workgroup barrier for data exchanged through LDS.  __syncthreads() also drains the wave's outstanding GLOBAL
 // stores (s_waitcnt vmcnt(0)): every feature ends with a store of its value to the HBM output row, so the next
 // barrier would expose that store's round trip (~600 cycles per column, measured).  LDS traffic only needs lgkmcnt.
@@ -134,6 +170,31 @@ TSFA_DEV double blk_sum(const Blk &b, double v) {
 #endif
     return v;
 }
+// N sums at once: the wave reductions are independent chains (they overlap), and the cross-wave exchange costs one
+// barrier pair for all N instead of one per value.  Same summation order as N calls of blk_sum.  N * waves <= 64.
+template <int N>
+TSFA_DEV void blk_sum_multi(const Blk &b, double *v) {
+#if TSFA_GPU
+#pragma unroll
+    for (int k = 0; k < N; ++k) v[k] = wave_sum(v[k]);
+    if (b.nt > 64) {
+        const int nw = b.nt >> 6;
+        blk_sync();
+        if ((b.tid & 63) == 0) {
+#pragma unroll
+            for (int k = 0; k < N; ++k) b.red[(b.tid >> 6) * N + k] = v[k];
+        }
+        blk_sync();
+#pragma unroll
+        for (int k = 0; k < N; ++k) {
+            double t = b.red[k];
+            for (int w = 1; w < nw; ++w) t += b.red[w * N + k];
+            v[k] = t;
+        }
+    }
+#endif
+}
+
 TSFA_DEV double blk_min(const Blk &b, double v) {
 #if TSFA_GPU
     v = wave_min(v);

@@ -8,6 +8,7 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <algorithm>
 #include <string>
 #include <vector>
 
@@ -77,9 +78,34 @@ static inline void tsfa_build_twiddles(std::vector<double> &twc, std::vector<dou
 #define TSFA_ALT_SLOTS 16
 struct TsfaFamHints {
     int a = 0, b = 0;
+    TsfaAltPlan alt;  // BASIC
+    TsfaCqPlan cq;    // SORT
 };
 static inline void tsfa_prepare_family(int fam, std::vector<TsfaSpec> &specs, TsfaFamHints &h) {
     h = TsfaFamHints();
+    memset(&h.alt, 0, sizeof h.alt);
+    memset(&h.cq, 0, sizeof h.cq);
+    if (fam == TSFA_FAM_SORT) {
+        std::vector<std::pair<double, double>> cor;
+        for (const auto &s : specs)
+            if (s.calc == TSFA_C_CHANGE_QUANTILES && s.p[0] < s.p[1]) {
+                const std::pair<double, double> k(s.p[0], s.p[1]);
+                if (std::find(cor.begin(), cor.end(), k) == cor.end()) cor.push_back(k);
+            }
+        if (!cor.empty() && cor.size() <= TSFA_CQ_MAX) {
+            h.cq.n = (int)cor.size();
+            for (size_t k = 0; k < cor.size(); ++k) { h.cq.ql[k] = cor[k].first; h.cq.qh[k] = cor[k].second; }
+            bool first = true;
+            for (auto &s : specs) {
+                if (s.calc != TSFA_C_CHANGE_QUANTILES || !(s.p[0] < s.p[1])) continue;
+                const std::pair<double, double> k(s.p[0], s.p[1]);
+                const int idx = (int)(std::find(cor.begin(), cor.end(), k) - cor.begin());
+                s.p[0] = (double)(idx + (first ? 128 : 0));
+                s.p[1] = -2.0;
+                first = false;
+            }
+        }
+    }
     if (fam == TSFA_FAM_SPECTRAL) {
         // a: bit 0 = full-length rfft needed, bit 1 = Welch PSD needed;  b: number of leading Welch-based specs
         std::vector<TsfaSpec> lead, rest;
@@ -95,6 +121,33 @@ static inline void tsfa_prepare_family(int fam, std::vector<TsfaSpec> &specs, Ts
         // a: largest number_peaks support <= 254;  b: 1 if any agg_linear_trend column asks for the p-value
         // agg_linear_trend: p[3] = cache slot of the column's (f_agg, chunk_len) regression, + 64 if this column is
         // the one that has to compute it (the slots are simulated here, round-robin over TSFA_ALT_SLOTS)
+        // preferred: all distinct (chunk_len, f_agg) keys at once (TsfaAltPlan); p[3] = key index, + 128 on the first
+        // agg_linear_trend column, which computes them all
+        {
+            std::vector<std::pair<int, int>> keys;
+            for (const auto &s : specs)
+                if (s.calc == TSFA_C_AGG_LINEAR_TREND) {
+                    const std::pair<int, int> k((int)s.p[1], (int)s.p[2]);
+                    if (std::find(keys.begin(), keys.end(), k) == keys.end()) keys.push_back(k);
+                    if ((int)s.p[0] == TSFA_ATTR_PVALUE) h.alt.want_p = 1;
+                }
+            std::sort(keys.begin(), keys.end());
+            if (!keys.empty() && keys.size() <= TSFA_ALT_MAXKEYS) {
+                h.alt.nkeys = (int)keys.size();
+                for (size_t k = 0; k < keys.size(); ++k) { h.alt.cl[k] = keys[k].first; h.alt.agg[k] = keys[k].second; }
+                bool first = true;
+                for (auto &s : specs) {
+                    if (s.calc == TSFA_C_NUMBER_PEAKS && (int)s.p[0] <= 254 && (int)s.p[0] > h.a) h.a = (int)s.p[0];
+                    if (s.calc != TSFA_C_AGG_LINEAR_TREND) continue;
+                    const std::pair<int, int> k((int)s.p[1], (int)s.p[2]);
+                    const int idx = (int)(std::find(keys.begin(), keys.end(), k) - keys.begin());
+                    s.p[3] = (double)(idx + (first ? 128 : 0));
+                    first = false;
+                }
+                h.b = h.alt.want_p;
+                return;
+            }
+        }
         int slot_key[TSFA_ALT_SLOTS], next = 0;
         for (int k = 0; k < TSFA_ALT_SLOTS; ++k) slot_key[k] = -1;
         for (auto &s : specs) {

@@ -24,31 +24,36 @@ template <typename T>
 __global__ void __launch_bounds__(256, 2) k_basic(const T *__restrict__ values, const int64_t *__restrict__ offsets, int64_t n_series,
                         const TsfaSpec *__restrict__ specs, int nspecs, double *__restrict__ out, int64_t ld,
                         const double *__restrict__ dectab, int maxn, int hint_a, int hint_b,
-                        const double *__restrict__ times) {
+                        const double *__restrict__ times, const TsfaAltPlan alt) {
     const int64_t sidx = blockIdx.x;
     if (sidx >= n_series) return;
     const int64_t off = offsets[sidx];
     const int n = (int)(offsets[sidx + 1] - off);
     BasicLds L;
     L.carve(tsfa_smem, maxn, blockDim.x);
+    TSFA_TICKS_BEGIN();
     Blk b{(int)threadIdx.x, (int)blockDim.x, L.red, L.np};
     stage_series(b, values + off, n, L.xs);
     fam_basic_series(b, L.xs, n, specs, nspecs, out + sidx * ld, L.w, L.cum, L.altc, L.iw, dectab, hint_a, hint_b,
-                     times ? times + off : nullptr);
+                     alt, times ? times + off : nullptr);
+    TSFA_TICKS_END();
 }
 
 template <typename T>
 __global__ void __launch_bounds__(256) k_sort(const T *__restrict__ values, const int64_t *__restrict__ offsets, int64_t n_series,
-                       const TsfaSpec *__restrict__ specs, int nspecs, double *__restrict__ out, int64_t ld, int maxn) {
+                       const TsfaSpec *__restrict__ specs, int nspecs, double *__restrict__ out, int64_t ld, int maxn,
+                       const TsfaCqPlan cqplan) {
     const int64_t sidx = blockIdx.x;
     if (sidx >= n_series) return;
     const int64_t off = offsets[sidx];
     const int n = (int)(offsets[sidx + 1] - off);
     SortLds L;
     L.carve(tsfa_smem, maxn, blockDim.x);
+    TSFA_TICKS_BEGIN();
     Blk b{(int)threadIdx.x, (int)blockDim.x, L.red, L.np};
     stage_series(b, values + off, n, L.xs);
-    fam_sort_series(b, L.xs, n, specs, nspecs, out + sidx * ld, L.srt, L.w, L.iw);
+    fam_sort_series(b, L.xs, n, specs, nspecs, out + sidx * ld, L.srt, L.w, L.iw, cqplan, L.cq);
+    TSFA_TICKS_END();
 }
 
 template <typename T>
@@ -62,6 +67,7 @@ __global__ void __launch_bounds__(256) k_spectral(const T *__restrict__ values, 
     const int n = (int)(offsets[sidx + 1] - off);
     SpectralLds L;
     L.carve(tsfa_smem, maxn, dft_n);
+    TSFA_TICKS_BEGIN();
     Blk b{(int)threadIdx.x, (int)blockDim.x, L.red, nullptr};
     stage_series(b, values + off, n, L.xs);
     double *tc = L.tc, *ts = L.ts;
@@ -71,6 +77,7 @@ __global__ void __launch_bounds__(256) k_spectral(const T *__restrict__ values, 
     }
     fam_spectral_series(b, L.xs, n, specs, nspecs, out + sidx * ld, L.Xr, L.Xi, tc, ts, L.win, L.pxx, L.iw, twc, tws,
                         hint_a, hint_b);
+    TSFA_TICKS_END();
 }
 
 template <typename T>
@@ -83,9 +90,11 @@ __global__ void __launch_bounds__(256) k_ar(const T *__restrict__ values, const 
     const int n = (int)(offsets[sidx + 1] - off);
     ArLds L;
     L.carve(tsfa_smem, maxn, P);
+    TSFA_TICKS_BEGIN();
     Blk b{(int)threadIdx.x, (int)blockDim.x, L.red, L.np};
     const T *g = values + off;
     fam_ar_series(b, [=](int i) { return (double)g[i]; }, n, specs, nspecs, out + sidx * ld, L.xc, L.rbuf, L.aw, P);
+    TSFA_TICKS_END();
 }
 
 // FAST: symmetric sweep only (m = 2 specs, LDS counters fit) -- see fam_entropy_series
@@ -99,9 +108,11 @@ __global__ void __launch_bounds__(256, 4) k_entropy(const T *__restrict__ values
     const int n = (int)(offsets[sidx + 1] - off);
     EntropyLds L;
     L.carve(tsfa_smem, maxn, with_cnt);
+    TSFA_TICKS_BEGIN();
     Blk b{(int)threadIdx.x, (int)blockDim.x, L.red, L.np};
     stage_series(b, values + off, n, L.xs);
     fam_entropy_series<double, FAST>(b, L.xs, n, specs, nspecs, out + sidx * ld, L.thr, L.perm, L.refs, L.cnt);
+    TSFA_TICKS_END();
 }
 
 template <typename T>
@@ -113,9 +124,11 @@ __global__ void __launch_bounds__(256) k_seq(const T *__restrict__ values, const
     const int n = (int)(offsets[sidx + 1] - off);
     SeqLds L;
     L.carve(tsfa_smem, g.nb, g.stride, g.ttotal, g.etotal);
+    TSFA_TICKS_BEGIN();
     Blk b{(int)threadIdx.x, (int)blockDim.x, L.red, nullptr};
     const T *gv = values + off;
     fam_seq_series(b, [=](int i) { return (double)gv[i]; }, n, g, out + sidx * ld, L.seq, L.tab, L.edges);
+    TSFA_TICKS_END();
 }
 
 template <typename T>
@@ -128,9 +141,11 @@ __global__ void __launch_bounds__(256) k_cwtpeaks(const T *__restrict__ values, 
     const int n = (int)(offsets[sidx + 1] - off);
     CwtPeaksLayout L;
     L.carve(tsfa_smem, maxn, with_rowv);
+    TSFA_TICKS_BEGIN();
     Blk b{(int)threadIdx.x, (int)blockDim.x, L.p.red, nullptr};
     const T *g = values + off;
     fam_cwtpeaks_series(b, [=](int i) { return (double)g[i]; }, n, specs, nspecs, out + sidx * ld, L.p);
+    TSFA_TICKS_END();
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -258,12 +273,12 @@ static int launch_all_t(const TsfaLaunch &a, const T *values) {
         const size_t lds = L.carve(nullptr, a.maxn, nt);
         if ((rc = set_lds(k_basic<T>, lds))) return rc;
         k_basic<T><<<grid, nt, lds, st>>>(values, a.offsets, a.n_series, a.specs, a.nspecs, a.out, a.ld, a.dectab, a.maxn,
-                                          a.hint_a, a.hint_b, a.times);
+                                          a.hint_a, a.hint_b, a.times, a.alt);
     } else if (a.fam == TSFA_FAM_SORT) {
         SortLds L;
         const size_t lds = L.carve(nullptr, a.maxn, nt);
         if ((rc = set_lds(k_sort<T>, lds))) return rc;
-        k_sort<T><<<grid, nt, lds, st>>>(values, a.offsets, a.n_series, a.specs, a.nspecs, a.out, a.ld, a.maxn);
+        k_sort<T><<<grid, nt, lds, st>>>(values, a.offsets, a.n_series, a.specs, a.nspecs, a.out, a.ld, a.maxn, a.cq);
     } else if (a.fam == TSFA_FAM_SPECTRAL) {
         SpectralLds L;
         const size_t lds = L.carve(nullptr, a.maxn, a.dft_n);
@@ -373,3 +388,16 @@ int tsfa_launch_len_stats(const int64_t *offsets, int64_t n_series, long long *s
     TSFA_LAUNCH_CHECK();
     return 0;
 }
+
+#ifdef TSFA_TICKS
+// diagnostics build only: read (and optionally clear) the phase clocks
+extern "C" int tsfa_debug_ticks(unsigned long long *out, int n, int reset) {
+    if (n > 256) n = 256;
+    if (out && hipMemcpyFromSymbol(out, HIP_SYMBOL(tsfa_ticks), (size_t)n * sizeof(unsigned long long)) != hipSuccess) return -1;
+    if (reset) {
+        static unsigned long long zeros[256];
+        if (hipMemcpyToSymbol(HIP_SYMBOL(tsfa_ticks), zeros, sizeof zeros) != hipSuccess) return -1;
+    }
+    return 0;
+}
+#endif

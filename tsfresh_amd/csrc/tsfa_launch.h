@@ -23,6 +23,8 @@ struct TsfaLaunch {
     void *stream;
     // family extras
     const double *dectab;   // BASIC: decimal table for benford_correlation
+    TsfaCqPlan cq;          // SORT: the plan's change_quantiles corridors (tsfa_prepare_family)
+    TsfaAltPlan alt;        // BASIC: the plan's agg_linear_trend regressions (tsfa_prepare_family)
     const double *times;    // BASIC: per-sample hours since the series' first timestamp (linear_trend_timewise) or null
     const double *twc, *tws;  // SPECTRAL: shared FFT twiddles
     int dft_n;              // SPECTRAL: DFT twiddle slots held in LDS

@@ -52,7 +52,7 @@ struct BasicLds {
 };
 
 struct SortLds {
-    double *red; NpScratch *np; double *xs; double *srt; double *w; int *iw;
+    double *red; NpScratch *np; double *xs; double *srt; double *w; int *iw; double *cq;
     TSFA_HD size_t carve(unsigned char *base, int maxn, int nt) {
         (void)nt;
         LdsCarve c{base, 0};
@@ -62,6 +62,7 @@ struct SortLds {
         srt = c.take<double>(tsfa_pow2_ceil(maxn));
         w = c.take<double>(1280);   // Langevin-fit scratch (<= 768 doubles) ...
         iw = (int *)w;              // ... aliased with the ordinal-pattern histogram (2520 ints): never live together
+        cq = c.take<double>(5 * TSFA_CQ_MAX);  // change_quantiles results per corridor
         return c.off;
     }
 };

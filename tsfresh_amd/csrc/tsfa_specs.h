@@ -137,6 +137,28 @@ enum { TSFA_FFT_REAL = 0, TSFA_FFT_IMAG = 1, TSFA_FFT_ABS = 2, TSFA_FFT_ANGLE = 
 enum { TSFA_FFTAGG_CENTROID = 0, TSFA_FFTAGG_VARIANCE = 1, TSFA_FFTAGG_SKEW = 2, TSFA_FFTAGG_KURTOSIS = 3 };
 enum { TSFA_ADF_TESTSTAT = 0, TSFA_ADF_PVALUE = 1, TSFA_ADF_USEDLAG = 2 };
 
+// agg_linear_trend (fc.py:2171): the distinct (chunk_len, f_agg) regressions of a plan, sorted by chunk_len, worked
+// out on the host.  All of them are computed in one go by the first agg_linear_trend column (fam_basic.h); column
+// specs carry their key's index in p[3].  nkeys == 0: more than TSFA_ALT_MAXKEYS keys -> per-column evaluation.
+#define TSFA_ALT_MAXKEYS 16
+struct TsfaAltPlan {
+    int nkeys;
+    int want_p;  // some column asks for the p-value
+    int cl[TSFA_ALT_MAXKEYS];
+    int agg[TSFA_ALT_MAXKEYS];
+};
+
+// change_quantiles (fc.py:1511): the distinct valid corridors (ql < qh) of a plan.  All of them are evaluated by the
+// first change_quantiles column, four corridors per sweep (fam_sort.h); an indexed column spec has p[1] == -2 and
+// its corridor's index in p[0].  n == 0: more than TSFA_CQ_MAX corridors -> per-column evaluation.
+#define TSFA_CQ_MAX 24
+struct TsfaCqPlan {
+    int n;
+    int pad;
+    double ql[TSFA_CQ_MAX];
+    double qh[TSFA_CQ_MAX];
+};
+
 // device-side spec: one output column
 struct TsfaSpec {
     int32_t calc;
