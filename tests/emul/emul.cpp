@@ -94,13 +94,13 @@ extern "C" int tsfa_emul_extract_timed(const tsfa_feature_spec *specs, int n_spe
             std::vector<int> iw(512);
             fam_basic_series(b, xs.data(), n, fam[TSFA_FAM_BASIC].data(), (int)fam[TSFA_FAM_BASIC].size(), row, w.data(),
                              (s % 2) ? w.data() : cum.data(), altc.data(), iw.data(), dectab.data(),
-                             hints[TSFA_FAM_BASIC].a, hints[TSFA_FAM_BASIC].b, hints[TSFA_FAM_BASIC].alt,
+                             hints[TSFA_FAM_BASIC].a, hints[TSFA_FAM_BASIC].b, hints[TSFA_FAM_BASIC].alt, nullptr,
                              times ? times + offsets[s] : nullptr);
         }
         if (!fam[TSFA_FAM_SORT].empty()) {
             std::vector<double> srt(tsfa_pow2_ceil(maxn) + 8), w(1280), cq(5 * TSFA_CQ_MAX);
             fam_sort_series(b, xs.data(), n, fam[TSFA_FAM_SORT].data(), (int)fam[TSFA_FAM_SORT].size(), row, srt.data(),
-                            w.data(), (int *)w.data(), hints[TSFA_FAM_SORT].cq, cq.data());
+                            w.data(), (int *)w.data(), hints[TSFA_FAM_SORT].cq, cq.data(), nullptr);
         }
         if (!fam[TSFA_FAM_SPECTRAL].empty()) {
             const int nx = (maxn / 2 + 2 > 260) ? maxn / 2 + 2 : 260;

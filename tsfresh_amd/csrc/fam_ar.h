@@ -90,11 +90,22 @@ TSFA_DEV void blk_chol_forward(const Blk &b, const double *L, int p, int ld, dou
 // and column sums C[j] = sum_t s(t-j).  Requires t0 >= Lg.  S(u) returns s[u].
 template <class S>
 TSFA_DEV void blk_lag_products(const Blk &b, S s, int Lg, int t0, int t1, double *T, int ld, double *C) {
-    for (int j = 0; j <= Lg; ++j) {  // first column by reduction
-        double a = 0.0;
-        for (int t = t0 + b.tid; t < t1; t += b.nt) a += s(t - j) * s(t);
-        a = blk_sum(b, a);
-        if (b.tid == 0) T[j] = a;
+    for (int j0 = 0; j0 <= Lg; j0 += 8) {  // first column by reduction, eight lags per sweep
+        double a8[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) a8[j] = 0.0;
+        for (int t = t0 + b.tid; t < t1; t += b.nt) {
+            const double st = s(t);
+#pragma unroll
+            for (int j = 0; j < 8; ++j)
+                if (j0 + j <= Lg) a8[j] += s(t - j0 - j) * st;
+        }
+        blk_sum_multi<8>(b, a8);
+        if (b.tid == 0) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j)
+                if (j0 + j <= Lg) T[j0 + j] = a8[j];
+        }
     }
     double c0 = 0.0;
     for (int t = t0 + b.tid; t < t1; t += b.nt) c0 += s(t);
@@ -187,11 +198,22 @@ TSFA_DEV void fam_ar_series(const Blk &b, X xv, int n, const TsfaSpec *specs, in
     int nacv = -1;
     if (max_acf_lag >= 0) nacv = (max_acf_lag < n - 1) ? max_acf_lag : (n - 1);
     if (pacf_maxlag > nacv) nacv = pacf_maxlag;
-    for (int k = 0; k <= nacv; ++k) {
-        double s = 0.0;
-        for (int t = b.tid; t < n - k; t += b.nt) s += xc[t] * xc[t + k];
-        s = blk_sum(b, s);
-        if (b.tid == 0) acv[k] = s / (double)(n - k);
+    for (int k0 = 0; k0 <= nacv; k0 += 8) {  // eight lags per sweep: x[t] is read once, the sums are reduced together
+        double s8[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) s8[j] = 0.0;
+        for (int t = b.tid; t < n - k0; t += b.nt) {
+            const double xt = xcc[t];
+#pragma unroll
+            for (int j = 0; j < 8; ++j)
+                if (t + k0 + j < n) s8[j] += xt * xcc[t + k0 + j];
+        }
+        blk_sum_multi<8>(b, s8);
+        if (b.tid == 0) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j)
+                if (k0 + j <= nacv) acv[k0 + j] = s8[j] / (double)(n - k0 - j);
+        }
     }
     blk_sync();
 
@@ -233,16 +255,27 @@ TSFA_DEV void fam_ar_series(const Blk &b, X xv, int n, const TsfaSpec *specs, in
             const double nobs = (double)(t1 - t0);
             // lag products of d (lag 0 = the target) and level products
             blk_lag_products(b, dif, maxlag, t0, t1, T, P, C);
-            for (int j = 0; j <= maxlag; ++j) {
-                double a = 0.0;
-                for (int t = t0 + b.tid; t < t1; t += b.nt) a += xcc[t] * dif(t - j);
-                a = blk_sum(b, a);
-                if (b.tid == 0) V[j] = a;
+            for (int j0 = 0; j0 <= maxlag; j0 += 8) {  // eight lags per sweep, reduced together
+                double a8[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) a8[j] = 0.0;
+                for (int t = t0 + b.tid; t < t1; t += b.nt) {
+                    const double xt = xcc[t];
+#pragma unroll
+                    for (int j = 0; j < 8; ++j)
+                        if (j0 + j <= maxlag) a8[j] += xt * dif(t - j0 - j);
+                }
+                blk_sum_multi<8>(b, a8);
+                if (b.tid == 0) {
+#pragma unroll
+                    for (int j = 0; j < 8; ++j)
+                        if (j0 + j <= maxlag) V[j0 + j] = a8[j];
+                }
             }
-            double sx = 0.0, sxx = 0.0;
-            for (int t = t0 + b.tid; t < t1; t += b.nt) { sx += xcc[t]; sxx += xcc[t] * xcc[t]; }
-            sx = blk_sum(b, sx);
-            sxx = blk_sum(b, sxx);
+            double sxs[2] = {0.0, 0.0};
+            for (int t = t0 + b.tid; t < t1; t += b.nt) { sxs[0] += xcc[t]; sxs[1] += xcc[t] * xcc[t]; }
+            blk_sum_multi<2>(b, sxs);
+            const double sx = sxs[0], sxx = sxs[1];
             blk_sync();
             // assemble the normal matrix in the autolag column order [const, level, d-lag1 .. d-lag maxlag]
             const int p1 = maxlag + 2;

@@ -277,7 +277,8 @@ TSFA_DEV void alt_fill_all(const Blk &b, const double *xs, int n, const TsfaAltP
 //   times: HBM, the series' timestamps as float64 hours since its first sample (linear_trend_timewise), or null
 TSFA_DEV void fam_basic_series(const Blk &b, const double *xs, int n, const TsfaSpec *specs, int nspecs,
                                double *out_row, double *w, double *cum, double *altc, int *iw, const double *dectab,
-                               int peaks_maxsup, int alt_want_p, const TsfaAltPlan &alt, const double *times = nullptr) {
+                               int peaks_maxsup, int alt_want_p, const TsfaAltPlan &alt, TsfaSpec *stage,
+                               const double *times = nullptr) {
     TSFA_TICKER(tk, 0);
     BasicStats st;
     basic_stats(b, xs, n, st);
@@ -291,10 +292,16 @@ TSFA_DEV void fam_basic_series(const Blk &b, const double *xs, int n, const Tsfa
 
     bool have_peaks = false;
 
-    TsfaSpec nxt = specs[0];
+    TsfaSpec nxt = spec_fetch(b, specs, nspecs, 0, stage);
     for (int s = 0; s < nspecs; ++s) {
+        TSFA_TICKER(tkc, 0);
         const TsfaSpec sp = nxt;
+#if !defined(TSFA_SPEC_LDS)
         nxt = specs[(s + 1 < nspecs) ? s + 1 : s];  // scalar load in flight while this column is evaluated
+#else
+        if (s + 1 < nspecs) nxt = spec_fetch(b, specs, nspecs, s + 1, stage);
+#endif
+        TSFA_TICK(tkc, b, 210);
         const double p0 = sp.p[0], p1 = sp.p[1], p2 = sp.p[2];
         double v = TSFA_NAN;
         switch (sp.calc) {
@@ -313,7 +320,9 @@ TSFA_DEV void fam_basic_series(const Blk &b, const double *xs, int n, const Tsfa
             break;
         case TSFA_C_VAR_GT_STD: v = (st.var > sqrt(st.var)) ? 1.0 : 0.0; break;  // fc.py:239
         case TSFA_C_LARGE_STD:                                           // fc.py:273
+            TSFA_TICK(tkc, b, 213);
             v = (st.std > p0 * (st.vmax - st.vmin)) ? 1.0 : 0.0;
+            TSFA_TICK(tkc, b, 214);
             break;
         case TSFA_C_RATIO_BEYOND_R_SIGMA: {                              // fc.py:256
             const double thr = p0 * st.std;
@@ -702,7 +711,9 @@ TSFA_DEV void fam_basic_series(const Blk &b, const double *xs, int n, const Tsfa
             break;
         default: break;
         }
+        TSFA_TICK(tkc, b, 211);
         if (b.tid == 0) out_row[sp.col] = v;
+        TSFA_TICK(tkc, b, 212);
         TSFA_TICK(tk, b, sp.calc);
     }
 }

@@ -328,9 +328,35 @@ TSFA_DEV void entropy_sweep_m2(const Blk &b, const XT *xs, int n, const double *
 }
 
 // perm[0 .. n-2] = indices of the length-2 templates sorted by their first sample (ties by index); np2 = padded size
+#if TSFA_GPU
+template <int E, typename XT>
+TSFA_DEVN void entropy_sort_templates_regs(const Blk &b, const XT *xs, int n, unsigned short *perm) {
+    const int nrow_m = n - 1;
+    double key[E];
+    int idx[E];
+#pragma unroll
+    for (int e = 0; e < E; ++e) {
+        const int g = b.tid * E + e;
+        idx[e] = (g < nrow_m) ? g : 0xFFFF;
+        key[e] = (g < nrow_m) ? (double)xs[g] : TSFA_INF;
+    }
+    blk_sort_pairs_regs<E>(b, key, idx, perm, [=](int i) { return (i == 0xFFFF) ? TSFA_INF : (double)xs[i]; });
+    blk_sync();
+#pragma unroll
+    for (int e = 0; e < E; ++e) perm[b.tid * E + e] = (unsigned short)idx[e];
+    blk_sync();
+}
+#endif
+
 template <typename XT>
 TSFA_DEV void entropy_sort_templates(const Blk &b, const XT *xs, int n, unsigned short *perm, int np2) {
     const int nrow_m = n - 1;
+#if TSFA_GPU
+    // register-blocked sort when every thread gets 1, 2 or 4 templates (np2 = E * nt)
+    if (np2 == b.nt) { entropy_sort_templates_regs<1>(b, xs, n, perm); return; }
+    if (np2 == 2 * b.nt) { entropy_sort_templates_regs<2>(b, xs, n, perm); return; }
+    if (np2 == 4 * b.nt) { entropy_sort_templates_regs<4>(b, xs, n, perm); return; }
+#endif
     blk_sync();
     for (int i = b.tid; i < np2; i += b.nt) perm[i] = (unsigned short)((i < nrow_m) ? i : 0xFFFF);
     for (int k = 2; k <= np2; k <<= 1) {

@@ -475,7 +475,8 @@ TSFA_DEV void cq_fill_all(const Blk &b, const double *xs, const double *srt, int
 }
 
 TSFA_DEV void fam_sort_series(const Blk &b, const double *xs, int n, const TsfaSpec *specs, int nspecs,
-                              double *out_row, double *srt, double *w, int *iw, const TsfaCqPlan &cqplan, double *cq) {
+                              double *out_row, double *srt, double *w, int *iw, const TsfaCqPlan &cqplan, double *cq,
+                              TsfaSpec *stage) {
     const int np2 = next_pow2(n);
     TSFA_TICKER(tk, 0);
     blk_sync();
@@ -496,7 +497,7 @@ TSFA_DEV void fam_sort_series(const Blk &b, const double *xs, int n, const TsfaS
     bool have_runs = false;
 
     for (int s = 0; s < nspecs; ++s) {
-        const TsfaSpec sp = specs[s];
+        const TsfaSpec sp = spec_fetch(b, specs, nspecs, s, stage);
         const double p0 = sp.p[0], p1 = sp.p[1], p2 = sp.p[2], p3 = sp.p[3];
         double v = TSFA_NAN;
         switch (sp.calc) {

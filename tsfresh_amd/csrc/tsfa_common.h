@@ -170,6 +170,33 @@ TSFA_DEV double blk_sum(const Blk &b, double v) {
 #endif
     return v;
 }
+// Column specs: a scalar (SMEM) load per column, or -- with TSFA_SPEC_LDS -- staged through LDS TSFA_SPEC_BATCH at a
+// time.  Measured on MI355X (profiles/phase_ticks.py): the staged variant is ~20% slower per column (two barriers per
+// batch, ten readfirstlanes per column), so the scalar load is the default.  Block-uniform: every thread calls it.
+#define TSFA_SPEC_BATCH 16
+TSFA_DEV TsfaSpec spec_fetch(const Blk &b, const TsfaSpec *specs, int nspecs, int s, TsfaSpec *stage) {
+#if TSFA_GPU && defined(TSFA_SPEC_LDS)
+    if ((s % TSFA_SPEC_BATCH) == 0) {
+        blk_sync();  // every thread is done with the previous batch
+        const int cnt = (nspecs - s < TSFA_SPEC_BATCH) ? (nspecs - s) : TSFA_SPEC_BATCH;
+        const double *src = (const double *)(const void *)(specs + s);
+        double *dst = (double *)(void *)stage;
+        for (int i = b.tid; i < cnt * (int)(sizeof(TsfaSpec) / sizeof(double)); i += b.nt) dst[i] = src[i];
+        blk_sync();
+    }
+    const TsfaSpec *e = stage + (s % TSFA_SPEC_BATCH);
+    TsfaSpec r;
+    r.calc = __builtin_amdgcn_readfirstlane(e->calc);  // wave-uniform by construction: keep the dispatch scalar
+    r.col = __builtin_amdgcn_readfirstlane(e->col);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) r.p[k] = readlane_f64(e->p[k], 0);
+    return r;
+#else
+    (void)b; (void)nspecs; (void)stage;
+    return specs[s];
+#endif
+}
+
 // N sums at once: the wave reductions are independent chains (they overlap), and the cross-wave exchange costs one
 // barrier pair for all N instead of one per value.  Same summation order as N calls of blk_sum.  N * waves <= 64.
 template <int N>
@@ -437,6 +464,81 @@ TSFA_DEV void blk_bitonic_sort(const Blk &b, K *a, int npow2) {
     }
     blk_sync();
 }
+
+#if TSFA_GPU
+// ---------------------------------------------------------------------------------------------
+// Register-blocked bitonic sort of np2 = E * nt (key, index) pairs, ascending by key, ties by index.
+// Thread t holds elements [t*E, (t+1)*E).  Of the log2(np2)(log2(np2)+1)/2 compare-exchange stages
+//   * stride < E        : both elements live in this thread's registers,
+//   * stride < 64 * E   : the partner lives in another lane of the wavefront -> ds_bpermute (no LDS memory, no barrier),
+//   * stride >= 64 * E  : the partner lives in another wavefront -> exchanged through LDS with a barrier pair.
+// For 1024 elements on 256 threads that is 19 + 33 + 3 stages: three barrier pairs instead of 55.
+// xchg_idx: LDS exchange buffer of np2 indices, only touched by the cross-wavefront stages; the partner's key is
+// looked up again from its index (keyof), so no second buffer is needed.
+// ---------------------------------------------------------------------------------------------
+TSFA_DEV bool sort_pair_gt(double ka, int ia, double kb, int ib) { return (ka > kb) || (ka == kb && ia > ib); }
+
+template <int E, int J>
+TSFA_DEV void sort_stage_regs(double (&key)[E], int (&idx)[E], int g0, int k) {
+#pragma unroll
+    for (int e = 0; e < E; ++e) {
+        if ((e & J) != 0) continue;
+        const int f = e | J;
+        const bool up = (((g0 + e) & k) == 0);
+        const bool gt = sort_pair_gt(key[e], idx[e], key[f], idx[f]);
+        if (gt == up) {
+            const double tk = key[e]; key[e] = key[f]; key[f] = tk;
+            const int ti = idx[e]; idx[e] = idx[f]; idx[f] = ti;
+        }
+    }
+}
+
+template <int E, class KF>
+TSFA_DEV void blk_sort_pairs_regs(const Blk &b, double (&key)[E], int (&idx)[E], unsigned short *xchg_idx, KF keyof) {
+    const int np2 = E * b.nt;
+    const int g0 = b.tid * E;
+    for (int k = 2; k <= np2; k <<= 1) {
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            if (j < E) {
+                switch (j) {
+                case 1: if (E > 1) sort_stage_regs<E, (E > 1 ? 1 : 0)>(key, idx, g0, k); break;
+                case 2: if (E > 2) sort_stage_regs<E, (E > 2 ? 2 : 0)>(key, idx, g0, k); break;
+                case 4: if (E > 4) sort_stage_regs<E, (E > 4 ? 4 : 0)>(key, idx, g0, k); break;
+                default: break;
+                }
+            } else if (j < 64 * E) {
+                const int lane_xor = j / E;
+                const bool lower = ((g0 & j) == 0);  // this thread holds the lower index of each pair
+#pragma unroll
+                for (int e = 0; e < E; ++e) {
+                    const double pk = __shfl_xor(key[e], lane_xor);
+                    const int pi = __shfl_xor(idx[e], lane_xor);
+                    const bool up = (((g0 + e) & k) == 0);
+                    const bool gt = sort_pair_gt(key[e], idx[e], pk, pi);
+                    // keep the minimum when (lower == up), the maximum otherwise
+                    const bool take = (lower == up) ? gt : !gt;
+                    if (take) { key[e] = pk; idx[e] = pi; }
+                }
+            } else {
+                blk_sync();
+#pragma unroll
+                for (int e = 0; e < E; ++e) xchg_idx[g0 + e] = (unsigned short)idx[e];
+                blk_sync();
+                const bool lower = ((g0 & j) == 0);
+#pragma unroll
+                for (int e = 0; e < E; ++e) {
+                    const int pi = xchg_idx[(g0 + e) ^ j];
+                    const double pk = keyof(pi);
+                    const bool up = (((g0 + e) & k) == 0);
+                    const bool gt = sort_pair_gt(key[e], idx[e], pk, pi);
+                    const bool take = (lower == up) ? gt : !gt;
+                    if (take) { key[e] = pk; idx[e] = pi; }
+                }
+            }
+        }
+    }
+}
+#endif
 
 // ---------------------------------------------------------------------------------------------
 // special functions

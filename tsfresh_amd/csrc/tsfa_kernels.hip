@@ -35,7 +35,7 @@ __global__ void __launch_bounds__(256, 2) k_basic(const T *__restrict__ values, 
     Blk b{(int)threadIdx.x, (int)blockDim.x, L.red, L.np};
     stage_series(b, values + off, n, L.xs);
     fam_basic_series(b, L.xs, n, specs, nspecs, out + sidx * ld, L.w, L.cum, L.altc, L.iw, dectab, hint_a, hint_b,
-                     alt, times ? times + off : nullptr);
+                     alt, L.stage, times ? times + off : nullptr);
     TSFA_TICKS_END();
 }
 
@@ -52,7 +52,7 @@ __global__ void __launch_bounds__(256) k_sort(const T *__restrict__ values, cons
     TSFA_TICKS_BEGIN();
     Blk b{(int)threadIdx.x, (int)blockDim.x, L.red, L.np};
     stage_series(b, values + off, n, L.xs);
-    fam_sort_series(b, L.xs, n, specs, nspecs, out + sidx * ld, L.srt, L.w, L.iw, cqplan, L.cq);
+    fam_sort_series(b, L.xs, n, specs, nspecs, out + sidx * ld, L.srt, L.w, L.iw, cqplan, L.cq, L.stage);
     TSFA_TICKS_END();
 }
 

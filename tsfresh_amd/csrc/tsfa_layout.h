@@ -37,7 +37,7 @@ TSFA_HD int tsfa_pow2_ceil(int n) {
 }
 
 struct BasicLds {
-    double *red; NpScratch *np; double *xs; double *w; double *cum; double *altc; int *iw;
+    double *red; NpScratch *np; double *xs; double *w; double *cum; double *altc; int *iw; TsfaSpec *stage;
     TSFA_HD size_t carve(unsigned char *base, int maxn, int nt) {
         LdsCarve c{base, 0};
         red = c.take<double>(TSFA_RED_DOUBLES);
@@ -47,12 +47,13 @@ struct BasicLds {
         cum = w;                   // ... aliased with the cumulative |x| of index_mass_quantile (the cache is invalidated)
         altc = c.take<double>(8 * 16);
         iw = c.take<int>((4 * nt > 256) ? 4 * nt : 256);
+        stage = c.take<TsfaSpec>(TSFA_SPEC_BATCH);
         return c.off;
     }
 };
 
 struct SortLds {
-    double *red; NpScratch *np; double *xs; double *srt; double *w; int *iw; double *cq;
+    double *red; NpScratch *np; double *xs; double *srt; double *w; int *iw; double *cq; TsfaSpec *stage;
     TSFA_HD size_t carve(unsigned char *base, int maxn, int nt) {
         (void)nt;
         LdsCarve c{base, 0};
@@ -63,6 +64,7 @@ struct SortLds {
         w = c.take<double>(1280);   // Langevin-fit scratch (<= 768 doubles) ...
         iw = (int *)w;              // ... aliased with the ordinal-pattern histogram (2520 ints): never live together
         cq = c.take<double>(5 * TSFA_CQ_MAX);  // change_quantiles results per corridor
+        stage = c.take<TsfaSpec>(TSFA_SPEC_BATCH);
         return c.off;
     }
 };
