@@ -111,6 +111,21 @@ int tsfa_extract_timed(tsfa_plan *plan, const void *values, int32_t dtype, const
                        int32_t space, void *stream);
 
 /*
+ * The window form: series s is the view values[starts[s] .. ends[s]) of one shared buffer; views may overlap.
+ * This is what tsfresh/utilities/dataframe_functions.py:340-372 (_roll_out_time_series, called by
+ * roll_time_series :377) produces by COPYING every window into a new DataFrame before extract_features is
+ * called on it (the forecasting workflow, BASELINE configs[4]); here the windows stay views.
+ * tsfa_extract / tsfa_extract_timed are the special case ends = starts + 1 (a ragged batch).
+ *
+ *   starts, ends   n_series int64 each (same memory space as values); 1 <= ends[s] - starts[s] <= 65535
+ *   times          as in tsfa_extract_timed, indexed like values; the kernel regresses on
+ *                  times[i] - times[starts[s]], i.e. hours since the window's own first stamp
+ */
+int tsfa_extract_windows(tsfa_plan *plan, const void *values, int32_t dtype, const double *times,
+                         const int64_t *starts, const int64_t *ends, int64_t n_series, double *out,
+                         int64_t ld_out, int32_t space, void *stream);
+
+/*
  * Timing of the kernels of the last tsfa_extract on this plan, measured with HIP events on the
  * stream the kernels were launched on.  names[i] / ms[i] for i < returned count (<= cap).
  * Only recorded when tsfa_plan_set_profiling(plan, 1) was called before the extract.

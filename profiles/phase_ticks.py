@@ -15,7 +15,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 os.environ.setdefault("TSFA_LIB", os.path.join(ROOT, "tsfresh_amd", "libtsfresh_amd_ticks.so"))
 
-NAMED = {213: "basic: switch dispatch of the 19 large_standard_deviation columns", 214: "basic: their bodies", 210: "basic: spec fetch (all columns)", 211: "basic: column bodies (all columns)",
+NAMED = {210: "basic: spec fetch (all columns)", 211: "basic: column bodies (all columns)",
          212: "basic: output stores (all columns)", 200: "basic/agg_linear_trend: chunk aggregates", 201: "basic/agg_linear_trend: regression sums",
          202: "basic/agg_linear_trend: linregress tails (lane = regression)", 100: "basic: stage + stats", 104: "sort: stage + bitonic sort", 120: "ar: mean/demean/var + scan",
          130: "entropy: std + sentinels", 131: "entropy: template sort + refs", 132: "entropy: group setup",

@@ -22,7 +22,7 @@ for f in sorted(glob.glob("gpurun_out/hbm/*/*counter_collection.csv")):
 for k, v in out.items():
     if "FETCH_SIZE" in v and "WRITE_SIZE" in v:
         v["hbm_bytes_per_launch"] = 2.0 * v["FETCH_SIZE"]["mean"] * 1024.0 + v["WRITE_SIZE"]["mean"] * 1024.0
-line = json.loads(open("gpurun_out/hbm/FETCH_SIZE.log").read().strip().splitlines()[-1])
+line = json.loads([l for l in open("gpurun_out/hbm/FETCH_SIZE.log") if l.startswith('{"metric"')][-1])
 doc = {"workload": line["config"], "units": "FETCH_SIZE / WRITE_SIZE means in KiB per launch as rocprofv3 reports them; "
        "hbm_bytes_per_launch = 2 * FETCH_SIZE + WRITE_SIZE in bytes (gfx950 read correction)", "kernels": out}
 json.dump(doc, open("gpurun_out/hbm/traffic.json", "w"), indent=1)

@@ -1,0 +1,103 @@
+"""Rolling windows: `roll_time_series` against the REAL reference's output
+(tests/golden/ref_roll.json, gen_golden_roll.py), the window views against the materialised frame, and -- on the GPU --
+`extract_rolled_features` (views, `tsfa_extract_windows`) against `extract_features(roll_time_series(...))`."""
+import json
+import os
+import sys
+import warnings
+
+import numpy as np
+import pandas as pd
+import pytest
+
+G = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+sys.path.insert(0, G)
+from gen_golden_roll_cases import roll_cases  # noqa: E402
+
+from tsfresh_amd.utilities.dataframe_functions import roll_time_series, roll_views  # noqa: E402
+
+
+def _as_json(df):
+    d = df.copy()
+    d["id"] = [list(map(lambda v: v.item() if hasattr(v, "item") else v, t)) for t in d["id"]]
+    return {"index": [int(i) for i in d.index], "columns": list(map(str, d.columns)),
+            "rows": json.loads(d.to_json(orient="values"))}
+
+
+@pytest.mark.parametrize("case", [c[0] for c in roll_cases()])
+def test_roll_time_series_matches_the_reference(case):
+    golden = json.load(open(os.path.join(G, "ref_roll.json")))
+    name, df, kw = [c for c in roll_cases() if c[0] == case][0]
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        got = _as_json(roll_time_series(df.copy(), **kw))
+    want = golden[name]
+    assert got["columns"] == want["columns"]
+    assert got["rows"] == want["rows"]
+    assert got["index"] == want["index"]
+
+
+def test_roll_argument_errors_are_the_reference_errors():
+    df = pd.DataFrame({"id": [1, 1], "time": [0, 1], "x": [1.0, 2.0]})
+    with pytest.raises(ValueError, match="Rolling direction of 0"):
+        roll_time_series(df, "id", "time", rolling_direction=0)
+    with pytest.raises(ValueError, match="max_timeshift needs to be positive"):
+        roll_time_series(df, "id", "time", max_timeshift=0)
+    with pytest.raises(ValueError, match="min_timeshift needs to be positive or zero"):
+        roll_time_series(df, "id", "time", min_timeshift=-1)
+    with pytest.raises(ValueError, match="zero or one rows"):
+        roll_time_series(df.iloc[:1], "id", "time")
+    with pytest.raises(AttributeError):
+        roll_time_series(df, "nope", "time")
+    with pytest.raises(ValueError, match="dictionary and gave a column name for the kind"):
+        roll_time_series({"a": df}, "id", "time", column_kind="k")
+
+
+def test_roll_views_cover_the_same_rows_as_the_materialised_frame():
+    rng = np.random.default_rng(1)
+    lengths = rng.integers(1, 40, size=30)
+    for direction, mts, mn in [(1, None, 0), (1, 7, 2), (-1, 5, 0), (3, 10, 1), (-2, None, 3)]:
+        gi, frm, until, ts = roll_views(lengths, direction, mts, mn)
+        assert np.all(frm >= 0) and np.all(until <= lengths[gi]) and np.all(until - frm >= mn + 1)
+        if mts is not None:
+            assert np.all(until - frm <= mts + 1)
+        # brute force per series, shift by shift (dataframe_functions.py:340-358)
+        want = []
+        steps = lengths.max()
+        shifts = list(reversed(range(steps, 0, -abs(direction)))) if direction > 0 else range(1, steps + 1, abs(direction))
+        m = mts or steps
+        for s, L in enumerate(lengths):
+            for t in shifts:
+                if direction > 0:
+                    u = t
+                    f = max(u - m - 1, 0)
+                    if u > L:
+                        continue
+                else:
+                    f = max(t - 1, 0)
+                    u = min(f + m + 1, L)
+                if u - f < mn + 1:
+                    continue
+                want.append((s, f, u, t))
+        assert list(zip(gi.tolist(), frm.tolist(), until.tolist(), ts.tolist())) == want
+
+
+@pytest.mark.gpu
+def test_extract_rolled_features_equals_extraction_on_the_rolled_frame(gpu):
+    from tsfresh_amd import EfficientFCParameters, extract_features, extract_rolled_features
+    rng = np.random.default_rng(5)
+    rows = []
+    for sid, L in enumerate([60, 45, 80, 12]):
+        rows.append(pd.DataFrame({"id": sid, "time": np.arange(L), "a": rng.standard_normal(L),
+                                  "b": np.cumsum(rng.standard_normal(L))}))
+    df = pd.concat(rows, ignore_index=True).sample(frac=1.0, random_state=2)
+    params = EfficientFCParameters()
+    for kw in (dict(max_timeshift=30, min_timeshift=9), dict(rolling_direction=-3, max_timeshift=25, min_timeshift=5)):
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            rolled = roll_time_series(df, "id", "time", **kw)
+            want = extract_features(rolled, column_id="id", column_sort="time", default_fc_parameters=params)
+            got = extract_rolled_features(df, column_id="id", column_sort="time", default_fc_parameters=params, **kw)
+        assert list(got.index) == list(want.index) and list(got.columns) == list(want.columns)
+        a, b = got.to_numpy(), want.to_numpy()
+        assert np.array_equal(np.isnan(a), np.isnan(b)) and np.array_equal(np.nan_to_num(a), np.nan_to_num(b))

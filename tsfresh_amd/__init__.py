@@ -4,7 +4,7 @@
 (tsfresh/feature_extraction/extraction.py:30); the arithmetic runs in hand-written HIP kernels for gfx950 behind the
 C-ABI declared in include/tsfresh_amd.h.  There is no CPU compute path.
 """
-from tsfresh_amd.feature_extraction.extraction import extract_features  # noqa: F401
+from tsfresh_amd.feature_extraction.extraction import extract_features, extract_rolled_features  # noqa: F401
 from tsfresh_amd.feature_extraction.settings import (  # noqa: F401
     ComprehensiveFCParameters,
     EfficientFCParameters,

@@ -25,6 +25,7 @@ TSFA_HOST, TSFA_DEVICE = 0, 1
 EXPORTS = (
     "tsfa_version", "tsfa_device_count", "tsfa_last_error", "tsfa_calc_id", "tsfa_calc_name", "tsfa_calc_count",
     "tsfa_plan_create", "tsfa_plan_n_cols", "tsfa_plan_destroy", "tsfa_extract", "tsfa_extract_timed",
+    "tsfa_extract_windows",
     "tsfa_plan_set_profiling",
     "tsfa_plan_last_timings",
 )
@@ -75,6 +76,10 @@ def load():
                                        ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p, ctypes.c_int64, ctypes.c_int32,
                                        ctypes.c_void_p]
     lib.tsfa_extract_timed.restype = ctypes.c_int
+    lib.tsfa_extract_windows.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int32, ctypes.c_void_p,
+                                         ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p,
+                                         ctypes.c_int64, ctypes.c_int32, ctypes.c_void_p]
+    lib.tsfa_extract_windows.restype = ctypes.c_int
     lib.tsfa_plan_set_profiling.argtypes = [ctypes.c_void_p, ctypes.c_int32]
     lib.tsfa_plan_set_profiling.restype = ctypes.c_int
     lib.tsfa_plan_last_timings.argtypes = [ctypes.c_void_p, ctypes.POINTER(ctypes.c_char_p),
@@ -160,6 +165,34 @@ class Plan:
         _check(self._lib, self._lib.tsfa_extract_timed(
             self._h, values.ctypes.data_as(ctypes.c_void_p), dt, tptr, offsets.ctypes.data_as(ctypes.c_void_p),
             n_series, out.ctypes.data_as(ctypes.c_void_p), self.n_cols, TSFA_HOST, None))
+        return out
+
+    def extract_windows_host(self, values, starts, ends, times=None):
+        """Window views of one shared buffer: series s = values[starts[s]:ends[s]] (views may overlap) ->
+        float64 [n_windows, n_cols].  The rolled (forecasting) layout without materialising the windows."""
+        values = np.ascontiguousarray(values)
+        if values.dtype == np.float32:
+            dt = TSFA_F32
+        else:
+            values = np.ascontiguousarray(values, dtype=np.float64)
+            dt = TSFA_F64
+        starts = np.ascontiguousarray(starts, dtype=np.int64)
+        ends = np.ascontiguousarray(ends, dtype=np.int64)
+        if starts.shape != ends.shape or starts.ndim != 1:
+            raise ValueError("starts and ends must be 1-D arrays of the same length")
+        n = starts.shape[0]
+        out = np.empty((n, self.n_cols), dtype=np.float64)
+        if n == 0 or self.n_cols == 0:
+            return out
+        if starts.min() < 0 or ends.max() > values.shape[0]:
+            raise ValueError("a window reaches outside the value buffer")
+        tptr = None
+        if times is not None:
+            times = np.ascontiguousarray(times, dtype=np.float64)
+            tptr = times.ctypes.data_as(ctypes.c_void_p)
+        _check(self._lib, self._lib.tsfa_extract_windows(
+            self._h, values.ctypes.data_as(ctypes.c_void_p), dt, tptr, starts.ctypes.data_as(ctypes.c_void_p),
+            ends.ctypes.data_as(ctypes.c_void_p), n, out.ctypes.data_as(ctypes.c_void_p), self.n_cols, TSFA_HOST, None))
         return out
 
     def extract_device(self, values_ptr, dtype, offsets_ptr, n_series, out_ptr, ld_out, stream=None):

@@ -320,9 +320,7 @@ TSFA_DEV void fam_basic_series(const Blk &b, const double *xs, int n, const Tsfa
             break;
         case TSFA_C_VAR_GT_STD: v = (st.var > sqrt(st.var)) ? 1.0 : 0.0; break;  // fc.py:239
         case TSFA_C_LARGE_STD:                                           // fc.py:273
-            TSFA_TICK(tkc, b, 213);
             v = (st.std > p0 * (st.vmax - st.vmin)) ? 1.0 : 0.0;
-            TSFA_TICK(tkc, b, 214);
             break;
         case TSFA_C_RATIO_BEYOND_R_SIGMA: {                              // fc.py:256
             const double thr = p0 * st.std;
@@ -645,7 +643,11 @@ TSFA_DEV void fam_basic_series(const Blk &b, const double *xs, int n, const Tsfa
         } break;
         case TSFA_C_LINEAR_TREND_TIMEWISE: {                             // fc.py:2274
             if (!have_ltt) {
-                if (times != nullptr && n >= 2) blk_linregress_xy(b, n, [=](int i) { return times[i]; }, [=](int i) { return xs[i]; }, ltt5);
+                // hours since the first stamp OF THIS SERIES: a no-op (x - 0.0) for a whole series, the rebase for a
+                // window view into a longer one (tsfa_extract_windows)
+                const double t_first = (times != nullptr) ? times[0] : 0.0;
+                if (times != nullptr && n >= 2)
+                    blk_linregress_xy(b, n, [=](int i) { return times[i] - t_first; }, [=](int i) { return xs[i]; }, ltt5);
                 have_ltt = true;
             }
             v = ltt5[0];

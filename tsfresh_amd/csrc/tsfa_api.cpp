@@ -257,6 +257,14 @@ int tsfa_extract(tsfa_plan *plan, const void *values, int32_t dtype, const int64
 
 int tsfa_extract_timed(tsfa_plan *plan, const void *values, int32_t dtype, const double *times, const int64_t *offsets,
                        int64_t n_series, double *out, int64_t ld_out, int32_t space, void *stream) {
+    // a ragged batch is the special case ends = starts + 1 of the window form
+    return tsfa_extract_windows(plan, values, dtype, times, offsets, offsets ? offsets + 1 : nullptr, n_series, out,
+                                ld_out, space, stream);
+}
+
+int tsfa_extract_windows(tsfa_plan *plan, const void *values, int32_t dtype, const double *times, const int64_t *starts,
+                         const int64_t *ends, int64_t n_series, double *out, int64_t ld_out, int32_t space,
+                         void *stream) {
     if (!plan) return fail(TSFA_ERR_INVALID, "plan is NULL");
     if (plan->needs_times && !times)
         return fail(TSFA_ERR_INVALID, "the plan holds linear_trend_timewise columns: call tsfa_extract_timed with the "
@@ -265,7 +273,7 @@ int tsfa_extract_timed(tsfa_plan *plan, const void *values, int32_t dtype, const
     if (space != TSFA_HOST && space != TSFA_DEVICE) return fail(TSFA_ERR_INVALID, "space must be TSFA_HOST or TSFA_DEVICE");
     if (n_series < 0) return fail(TSFA_ERR_INVALID, "n_series < 0");
     if (n_series == 0 || plan->n_cols == 0) return TSFA_OK;
-    if (!values || !offsets || !out) return fail(TSFA_ERR_INVALID, "NULL buffer");
+    if (!values || !starts || !ends || !out) return fail(TSFA_ERR_INVALID, "NULL buffer");
     if (ld_out < plan->n_cols) return fail(TSFA_ERR_INVALID, "ld_out < n_cols");
     if (n_series > 2147483647LL) return fail(TSFA_ERR_INVALID, "n_series exceeds the grid limit (2^31 - 1)");
     HIP_TRY(hipSetDevice(plan->device));
@@ -274,15 +282,30 @@ int tsfa_extract_timed(tsfa_plan *plan, const void *values, int32_t dtype, const
 
     const void *d_values = values;
     const double *d_times = plan->needs_times ? times : nullptr;
-    const int64_t *d_offsets = offsets;
+    const int64_t *d_starts = starts, *d_ends = ends;
     double *d_out = out;
     int64_t ld = ld_out;
     if (space == TSFA_HOST) {
-        const int64_t base = offsets[0];
-        const int64_t total = offsets[n_series] - base;
-        if (total < 0) return fail(TSFA_ERR_INVALID, "offsets are not non-decreasing");
-        std::vector<int64_t> rel((size_t)n_series + 1);
-        for (int64_t i = 0; i <= n_series; ++i) rel[(size_t)i] = offsets[i] - base;
+        // stage the span of `values` the windows touch; window bounds become relative to its first sample
+        const bool ragged = (ends == starts + 1);
+        int64_t base = starts[0], top = ends[0];
+        for (int64_t i = 0; i < n_series; ++i) {
+            if (ends[i] < starts[i]) return fail(TSFA_ERR_INVALID, "a series ends before it starts (offsets must be non-decreasing)");
+            base = std::min(base, starts[i]);
+            top = std::max(top, ends[i]);
+        }
+        const int64_t total = top - base;
+        std::vector<int64_t> rel;
+        if (ragged) {
+            rel.resize((size_t)n_series + 1);
+            for (int64_t i = 0; i <= n_series; ++i) rel[(size_t)i] = starts[i] - base;
+        } else {
+            rel.resize(2 * (size_t)n_series);
+            for (int64_t i = 0; i < n_series; ++i) {
+                rel[(size_t)i] = starts[i] - base;
+                rel[(size_t)(n_series + i)] = ends[i] - base;
+            }
+        }
         if (plan->values.ensure((size_t)total * esz + 16) || plan->offsets.ensure(rel.size() * sizeof(int64_t)) ||
             plan->out.ensure((size_t)n_series * plan->n_cols * sizeof(double)))
             return fail(TSFA_ERR_HIP, "hipMalloc failed for the staging buffers");
@@ -296,7 +319,8 @@ int tsfa_extract_timed(tsfa_plan *plan, const void *values, int32_t dtype, const
         }
         HIP_TRY(hipStreamSynchronize(st));  // rel goes out of scope below
         d_values = plan->values.p;
-        d_offsets = (const int64_t *)plan->offsets.p;
+        d_starts = (const int64_t *)plan->offsets.p;
+        d_ends = d_starts + (ragged ? 1 : n_series);
         d_out = (double *)plan->out.p;
         ld = plan->n_cols;
     }
@@ -304,7 +328,7 @@ int tsfa_extract_timed(tsfa_plan *plan, const void *values, int32_t dtype, const
     // ---- batch length statistics (decides workgroup size and the LDS carve) ----
     long long h_stats[3] = {0, (1LL << 62), 0};
     HIP_TRY(hipMemcpyAsync(plan->d_stats, h_stats, sizeof h_stats, hipMemcpyHostToDevice, st));
-    if (tsfa_launch_len_stats(d_offsets, n_series, plan->d_stats, st)) return fail(TSFA_ERR_HIP, "len_stats launch failed");
+    if (tsfa_launch_len_stats(d_starts, d_ends, n_series, plan->d_stats, st)) return fail(TSFA_ERR_HIP, "len_stats launch failed");
     HIP_TRY(hipMemcpyAsync(h_stats, plan->d_stats, sizeof h_stats, hipMemcpyDeviceToHost, st));
     HIP_TRY(hipStreamSynchronize(st));
     const long long max_len = h_stats[0], min_len = h_stats[1], max_np2 = h_stats[2];
@@ -339,7 +363,8 @@ int tsfa_extract_timed(tsfa_plan *plan, const void *values, int32_t dtype, const
         a.fam = f;
         a.dtype = dtype;
         a.values = d_values;
-        a.offsets = d_offsets;
+        a.starts = d_starts;
+        a.ends = d_ends;
         a.n_series = n_series;
         a.specs = plan->d_specs[f];
         a.nspecs = (int)plan->fam_specs[f].size();
@@ -456,7 +481,8 @@ int tsfa_extract_timed(tsfa_plan *plan, const void *values, int32_t dtype, const
         memset(&c, 0, sizeof c);
         c.dtype = dtype;
         c.values = d_values;
-        c.offsets = d_offsets;
+        c.starts = d_starts;
+        c.ends = d_ends;
         c.n_series = n_series;
         c.W = plan->d_W;
         c.S4 = plan->bank.S4;

@@ -21,14 +21,14 @@ __device__ __forceinline__ void stage_series(const Blk &b, const T *__restrict__
 
 // ---------------------------------------------------------------------------------------------
 template <typename T>
-__global__ void __launch_bounds__(256, 2) k_basic(const T *__restrict__ values, const int64_t *__restrict__ offsets, int64_t n_series,
+__global__ void __launch_bounds__(256, 2) k_basic(const T *__restrict__ values, const int64_t *__restrict__ starts, const int64_t *__restrict__ ends, int64_t n_series,
                         const TsfaSpec *__restrict__ specs, int nspecs, double *__restrict__ out, int64_t ld,
                         const double *__restrict__ dectab, int maxn, int hint_a, int hint_b,
                         const double *__restrict__ times, const TsfaAltPlan alt) {
     const int64_t sidx = blockIdx.x;
     if (sidx >= n_series) return;
-    const int64_t off = offsets[sidx];
-    const int n = (int)(offsets[sidx + 1] - off);
+    const int64_t off = starts[sidx];
+    const int n = (int)(ends[sidx] - off);
     BasicLds L;
     L.carve(tsfa_smem, maxn, blockDim.x);
     TSFA_TICKS_BEGIN();
@@ -40,13 +40,13 @@ __global__ void __launch_bounds__(256, 2) k_basic(const T *__restrict__ values, 
 }
 
 template <typename T>
-__global__ void __launch_bounds__(256) k_sort(const T *__restrict__ values, const int64_t *__restrict__ offsets, int64_t n_series,
+__global__ void __launch_bounds__(256) k_sort(const T *__restrict__ values, const int64_t *__restrict__ starts, const int64_t *__restrict__ ends, int64_t n_series,
                        const TsfaSpec *__restrict__ specs, int nspecs, double *__restrict__ out, int64_t ld, int maxn,
                        const TsfaCqPlan cqplan) {
     const int64_t sidx = blockIdx.x;
     if (sidx >= n_series) return;
-    const int64_t off = offsets[sidx];
-    const int n = (int)(offsets[sidx + 1] - off);
+    const int64_t off = starts[sidx];
+    const int n = (int)(ends[sidx] - off);
     SortLds L;
     L.carve(tsfa_smem, maxn, blockDim.x);
     TSFA_TICKS_BEGIN();
@@ -57,14 +57,14 @@ __global__ void __launch_bounds__(256) k_sort(const T *__restrict__ values, cons
 }
 
 template <typename T>
-__global__ void __launch_bounds__(256) k_spectral(const T *__restrict__ values, const int64_t *__restrict__ offsets, int64_t n_series,
+__global__ void __launch_bounds__(256) k_spectral(const T *__restrict__ values, const int64_t *__restrict__ starts, const int64_t *__restrict__ ends, int64_t n_series,
                            const TsfaSpec *__restrict__ specs, int nspecs, double *__restrict__ out, int64_t ld,
                            int maxn, int dft_n, double *__restrict__ gscratch, int gscratch_n,
                            const double *__restrict__ twc, const double *__restrict__ tws, int hint_a, int hint_b) {
     const int64_t sidx = blockIdx.x;
     if (sidx >= n_series) return;
-    const int64_t off = offsets[sidx];
-    const int n = (int)(offsets[sidx + 1] - off);
+    const int64_t off = starts[sidx];
+    const int n = (int)(ends[sidx] - off);
     SpectralLds L;
     L.carve(tsfa_smem, maxn, dft_n);
     TSFA_TICKS_BEGIN();
@@ -81,13 +81,13 @@ __global__ void __launch_bounds__(256) k_spectral(const T *__restrict__ values, 
 }
 
 template <typename T>
-__global__ void __launch_bounds__(256) k_ar(const T *__restrict__ values, const int64_t *__restrict__ offsets, int64_t n_series,
+__global__ void __launch_bounds__(256) k_ar(const T *__restrict__ values, const int64_t *__restrict__ starts, const int64_t *__restrict__ ends, int64_t n_series,
                      const TsfaSpec *__restrict__ specs, int nspecs, double *__restrict__ out, int64_t ld, int maxn,
                      int P) {
     const int64_t sidx = blockIdx.x;
     if (sidx >= n_series) return;
-    const int64_t off = offsets[sidx];
-    const int n = (int)(offsets[sidx + 1] - off);
+    const int64_t off = starts[sidx];
+    const int n = (int)(ends[sidx] - off);
     ArLds L;
     L.carve(tsfa_smem, maxn, P);
     TSFA_TICKS_BEGIN();
@@ -99,13 +99,13 @@ __global__ void __launch_bounds__(256) k_ar(const T *__restrict__ values, const 
 
 // FAST: symmetric sweep only (m = 2 specs, LDS counters fit) -- see fam_entropy_series
 template <typename T, bool FAST>
-__global__ void __launch_bounds__(256, 4) k_entropy(const T *__restrict__ values, const int64_t *__restrict__ offsets, int64_t n_series,
+__global__ void __launch_bounds__(256, 4) k_entropy(const T *__restrict__ values, const int64_t *__restrict__ starts, const int64_t *__restrict__ ends, int64_t n_series,
                           const TsfaSpec *__restrict__ specs, int nspecs, double *__restrict__ out, int64_t ld,
                           int maxn, int with_cnt) {
     const int64_t sidx = blockIdx.x;
     if (sidx >= n_series) return;
-    const int64_t off = offsets[sidx];
-    const int n = (int)(offsets[sidx + 1] - off);
+    const int64_t off = starts[sidx];
+    const int n = (int)(ends[sidx] - off);
     EntropyLds L;
     L.carve(tsfa_smem, maxn, with_cnt);
     TSFA_TICKS_BEGIN();
@@ -116,12 +116,12 @@ __global__ void __launch_bounds__(256, 4) k_entropy(const T *__restrict__ values
 }
 
 template <typename T>
-__global__ void __launch_bounds__(256) k_seq(const T *__restrict__ values, const int64_t *__restrict__ offsets, int64_t n_series,
+__global__ void __launch_bounds__(256) k_seq(const T *__restrict__ values, const int64_t *__restrict__ starts, const int64_t *__restrict__ ends, int64_t n_series,
                       double *__restrict__ out, int64_t ld, const TsfaSeqGroup g) {
     const int64_t sidx = blockIdx.x;
     if (sidx >= n_series) return;
-    const int64_t off = offsets[sidx];
-    const int n = (int)(offsets[sidx + 1] - off);
+    const int64_t off = starts[sidx];
+    const int n = (int)(ends[sidx] - off);
     SeqLds L;
     L.carve(tsfa_smem, g.nb, g.stride, g.ttotal, g.etotal);
     TSFA_TICKS_BEGIN();
@@ -132,13 +132,13 @@ __global__ void __launch_bounds__(256) k_seq(const T *__restrict__ values, const
 }
 
 template <typename T>
-__global__ void __launch_bounds__(256) k_cwtpeaks(const T *__restrict__ values, const int64_t *__restrict__ offsets, int64_t n_series,
+__global__ void __launch_bounds__(256) k_cwtpeaks(const T *__restrict__ values, const int64_t *__restrict__ starts, const int64_t *__restrict__ ends, int64_t n_series,
                            const TsfaSpec *__restrict__ specs, int nspecs, double *__restrict__ out, int64_t ld,
                            int maxn, int with_rowv) {
     const int64_t sidx = blockIdx.x;
     if (sidx >= n_series) return;
-    const int64_t off = offsets[sidx];
-    const int n = (int)(offsets[sidx + 1] - off);
+    const int64_t off = starts[sidx];
+    const int n = (int)(ends[sidx] - off);
     CwtPeaksLayout L;
     L.carve(tsfa_smem, maxn, with_rowv);
     TSFA_TICKS_BEGIN();
@@ -159,7 +159,7 @@ typedef double tsfa_d4 __attribute__((ext_vector_type(4)));
 
 template <typename T, int CT>
 __global__ void __launch_bounds__(64)
-k_cwt_gemm(const T *__restrict__ values, const int64_t *__restrict__ offsets, int64_t n_series,
+k_cwt_gemm(const T *__restrict__ values, const int64_t *__restrict__ starts, const int64_t *__restrict__ ends, int64_t n_series,
            const double *__restrict__ W, int S4, int C, const int *__restrict__ cols,
            const int *__restrict__ coeff_idx, double *__restrict__ out, int64_t ld) {
     __shared__ int lens[16];
@@ -169,8 +169,8 @@ k_cwt_gemm(const T *__restrict__ values, const int64_t *__restrict__ offsets, in
     int64_t off = 0;
     int len = 0;
     if (s < n_series) {
-        off = offsets[s];
-        len = (int)(offsets[s + 1] - off);
+        off = starts[s];
+        len = (int)(ends[s] - off);
     }
     if (lane < 16) lens[lane] = len;
     __syncthreads();
@@ -210,11 +210,11 @@ __global__ void k_fill_nan(double *__restrict__ out, int64_t n) {
 }
 
 // per-batch length statistics: [0] = max length, [1] = min length, [2] = max non-power-of-two length
-__global__ void __launch_bounds__(256) k_len_stats(const int64_t *__restrict__ offsets, int64_t n_series, long long *__restrict__ stats) {
+__global__ void __launch_bounds__(256) k_len_stats(const int64_t *__restrict__ starts, const int64_t *__restrict__ ends, int64_t n_series, long long *__restrict__ stats) {
     long long mx = 0, mn = (1LL << 62), mnp = 0;
     for (int64_t s = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; s < n_series;
          s += (int64_t)gridDim.x * blockDim.x) {
-        const long long l = offsets[s + 1] - offsets[s];
+        const long long l = ends[s] - starts[s];
         mx = l > mx ? l : mx;
         mn = l < mn ? l : mn;
         if (l > 0 && (l & (l - 1)) != 0) mnp = l > mnp ? l : mnp;
@@ -272,46 +272,46 @@ static int launch_all_t(const TsfaLaunch &a, const T *values) {
         BasicLds L;
         const size_t lds = L.carve(nullptr, a.maxn, nt);
         if ((rc = set_lds(k_basic<T>, lds))) return rc;
-        k_basic<T><<<grid, nt, lds, st>>>(values, a.offsets, a.n_series, a.specs, a.nspecs, a.out, a.ld, a.dectab, a.maxn,
+        k_basic<T><<<grid, nt, lds, st>>>(values, a.starts, a.ends, a.n_series, a.specs, a.nspecs, a.out, a.ld, a.dectab, a.maxn,
                                           a.hint_a, a.hint_b, a.times, a.alt);
     } else if (a.fam == TSFA_FAM_SORT) {
         SortLds L;
         const size_t lds = L.carve(nullptr, a.maxn, nt);
         if ((rc = set_lds(k_sort<T>, lds))) return rc;
-        k_sort<T><<<grid, nt, lds, st>>>(values, a.offsets, a.n_series, a.specs, a.nspecs, a.out, a.ld, a.maxn, a.cq);
+        k_sort<T><<<grid, nt, lds, st>>>(values, a.starts, a.ends, a.n_series, a.specs, a.nspecs, a.out, a.ld, a.maxn, a.cq);
     } else if (a.fam == TSFA_FAM_SPECTRAL) {
         SpectralLds L;
         const size_t lds = L.carve(nullptr, a.maxn, a.dft_n);
         if ((rc = set_lds(k_spectral<T>, lds))) return rc;
-        k_spectral<T><<<grid, nt, lds, st>>>(values, a.offsets, a.n_series, a.specs, a.nspecs, a.out, a.ld, a.maxn,
+        k_spectral<T><<<grid, nt, lds, st>>>(values, a.starts, a.ends, a.n_series, a.specs, a.nspecs, a.out, a.ld, a.maxn,
                                              a.dft_n, a.gscratch, a.gscratch_n, a.twc, a.tws, a.hint_a, a.hint_b);
     } else if (a.fam == TSFA_FAM_AR) {
         ArLds L;
         const size_t lds = L.carve(nullptr, a.maxn, a.ar_P);
         if ((rc = set_lds(k_ar<T>, lds))) return rc;
-        k_ar<T><<<grid, nt, lds, st>>>(values, a.offsets, a.n_series, a.specs, a.nspecs, a.out, a.ld, a.maxn, a.ar_P);
+        k_ar<T><<<grid, nt, lds, st>>>(values, a.starts, a.ends, a.n_series, a.specs, a.nspecs, a.out, a.ld, a.maxn, a.ar_P);
     } else if (a.fam == TSFA_FAM_ENTROPY) {
         EntropyLds L;
         const size_t lds = L.carve(nullptr, a.maxn, a.ent_cnt);
 if (a.ent_fast) {
             if ((rc = set_lds(k_entropy<T, true>, lds))) return rc;
-            k_entropy<T, true><<<grid, nt, lds, st>>>(values, a.offsets, a.n_series, a.specs, a.nspecs, a.out, a.ld, a.maxn,
+            k_entropy<T, true><<<grid, nt, lds, st>>>(values, a.starts, a.ends, a.n_series, a.specs, a.nspecs, a.out, a.ld, a.maxn,
                                                       a.ent_cnt);
         } else {
             if ((rc = set_lds(k_entropy<T, false>, lds))) return rc;
-            k_entropy<T, false><<<grid, nt, lds, st>>>(values, a.offsets, a.n_series, a.specs, a.nspecs, a.out, a.ld, a.maxn,
+            k_entropy<T, false><<<grid, nt, lds, st>>>(values, a.starts, a.ends, a.n_series, a.specs, a.nspecs, a.out, a.ld, a.maxn,
                                                        a.ent_cnt);
         }
     } else if (a.fam == TSFA_FAM_SEQ) {
         SeqLds L;
         const size_t lds = L.carve(nullptr, a.seq.nb, a.seq.stride, a.seq.ttotal, a.seq.etotal);
         if ((rc = set_lds(k_seq<T>, lds))) return rc;
-        k_seq<T><<<grid, nt, lds, st>>>(values, a.offsets, a.n_series, a.out, a.ld, a.seq);
+        k_seq<T><<<grid, nt, lds, st>>>(values, a.starts, a.ends, a.n_series, a.out, a.ld, a.seq);
     } else if (a.fam == TSFA_FAM_CWT) {  // number_cwt_peaks
         CwtPeaksLayout L;
         const size_t lds = L.carve(nullptr, a.maxn, a.cwt_rowv);
         if ((rc = set_lds(k_cwtpeaks<T>, lds))) return rc;
-        k_cwtpeaks<T><<<grid, nt, lds, st>>>(values, a.offsets, a.n_series, a.specs, a.nspecs, a.out, a.ld, a.maxn,
+        k_cwtpeaks<T><<<grid, nt, lds, st>>>(values, a.starts, a.ends, a.n_series, a.specs, a.nspecs, a.out, a.ld, a.maxn,
                                              a.cwt_rowv);
     } else {
         return -1;
@@ -353,7 +353,7 @@ static int launch_cwt_t(const TsfaCwtLaunch &a, const T *values) {
     const int ct = (a.C + 15) / 16;
 #define TSFA_CWT_CASE(N)                                                                                         \
     case N:                                                                                                      \
-        k_cwt_gemm<T, N><<<grid, 64, 0, st>>>(values, a.offsets, a.n_series, a.W, a.S4, a.C, a.cols, a.coeff_idx, \
+        k_cwt_gemm<T, N><<<grid, 64, 0, st>>>(values, a.starts, a.ends, a.n_series, a.W, a.S4, a.C, a.cols, a.coeff_idx, \
                                               a.out, a.ld);                                                      \
         break;
     switch (ct) {
@@ -383,8 +383,8 @@ int tsfa_launch_fill_nan(double *out, int64_t n, void *stream) {
     return 0;
 }
 
-int tsfa_launch_len_stats(const int64_t *offsets, int64_t n_series, long long *stats, void *stream) {
-    k_len_stats<<<256, 256, 0, (hipStream_t)stream>>>(offsets, n_series, stats);
+int tsfa_launch_len_stats(const int64_t *starts, const int64_t *ends, int64_t n_series, long long *stats, void *stream) {
+    k_len_stats<<<256, 256, 0, (hipStream_t)stream>>>(starts, ends, n_series, stats);
     TSFA_LAUNCH_CHECK();
     return 0;
 }

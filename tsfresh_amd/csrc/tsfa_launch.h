@@ -12,7 +12,8 @@ struct TsfaLaunch {
     int fam;
     int dtype;  // 0 = f32, 1 = f64
     const void *values;
-    const int64_t *offsets;
+    const int64_t *starts;  // series s occupies values[starts[s] .. ends[s]); for a ragged batch ends = starts + 1
+    const int64_t *ends;
     int64_t n_series;
     const TsfaSpec *specs;  // device
     int nspecs;
@@ -41,7 +42,7 @@ struct TsfaLaunch {
 struct TsfaCwtLaunch {
     int dtype;
     const void *values;
-    const int64_t *offsets;
+    const int64_t *starts, *ends;
     int64_t n_series;
     const double *W;       // [Cpad][S4]
     int S4, C;
@@ -58,6 +59,6 @@ size_t tsfa_seq_lds_bytes(const TsfaSeqGroup &g);
 int tsfa_launch_family(const TsfaLaunch &a);
 int tsfa_launch_cwt(const TsfaCwtLaunch &a);
 int tsfa_launch_fill_nan(double *out, int64_t n, void *stream);
-int tsfa_launch_len_stats(const int64_t *offsets, int64_t n_series, long long *stats, void *stream);
+int tsfa_launch_len_stats(const int64_t *starts, const int64_t *ends, int64_t n_series, long long *stats, void *stream);
 
 #endif

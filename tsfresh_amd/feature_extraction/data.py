@@ -13,12 +13,13 @@ import pandas as pd
 class PackedKind:
     """All series of one kind: `values[offsets[i]:offsets[i+1]]` is the series of `ids[i]` (ids sorted)."""
 
-    def __init__(self, kind, ids, values, offsets, times=None):
+    def __init__(self, kind, ids, values, offsets, times=None, sort=None):
         self.kind = kind
         self.ids = ids
         self.values = values
         self.offsets = offsets
         self.times = times  # float64 hours since each series' first timestamp (DatetimeIndex input only)
+        self.sort = sort    # the sort column in packed order (None without column_sort); names rolled windows
 
     @property
     def n_series(self):
@@ -79,7 +80,8 @@ def _pack(kind, ids, values, sort_values, index=None):
     offsets = np.zeros(len(uniques) + 1, dtype=np.int64)
     np.cumsum(counts, out=offsets[1:])
     times = _hours_since_first(index, order, offsets) if index is not None and len(order) else None
-    return PackedKind(str(kind), np.asarray(uniques), np.ascontiguousarray(_as_values(values)[order]), offsets, times)
+    return PackedKind(str(kind), np.asarray(uniques), np.ascontiguousarray(_as_values(values)[order]), offsets, times,
+                      None if sort_values is None else np.asarray(sort_values)[order])
 
 
 def pack_timeseries(container, column_id=None, column_kind=None, column_value=None, column_sort=None):

@@ -110,6 +110,12 @@ def extract_features(
             if nplan is not None:
                 nplan.close()
 
+    return _assemble(blocks, id_dtype, pivot, impute_function)
+
+
+def _assemble(blocks, id_dtype, pivot, impute_function):
+    """(PackedKind-like with .ids, column names, matrix) blocks -> the reference's result container
+    (data.py:86-121 pivot / extraction.py:301-302 tuples)."""
     if not pivot:
         result = []
         for pk, names, matrix in blocks:
@@ -148,3 +154,71 @@ def extract_features(
     if impute_function is not None:
         impute_function(result)
     return result
+
+
+class _WindowBlock:
+    def __init__(self, kind, ids):
+        self.kind = kind
+        self.ids = ids
+
+
+def extract_rolled_features(timeseries_container, column_id=None, column_sort=None, column_kind=None, column_value=None,
+                            rolling_direction=1, max_timeshift=None, min_timeshift=0, default_fc_parameters=None,
+                            kind_to_fc_parameters=None, impute_function=None, show_warnings=False, pivot=True,
+                            device=None):
+    """`extract_features(roll_time_series(container, ...), column_id="id", ...)` without building the rolled frame.
+
+    The reference's forecasting workflow first copies every window into a new DataFrame
+    (tsfresh/utilities/dataframe_functions.py:340-372, :601) and then extracts features from it.  Here every series is
+    packed and uploaded ONCE; the windows are `(start, end)` views into that buffer
+    (`tsfresh_amd.utilities.dataframe_functions.roll_views` restates the reference's index arithmetic) and go to the
+    kernels through `tsfa_extract_windows`.  Same rows, same ``(id, shift)`` index, same columns as the two-step form.
+    """
+    from tsfresh_amd.utilities.dataframe_functions import roll_views
+    if default_fc_parameters is None and kind_to_fc_parameters is None:
+        default_fc_parameters = ComprehensiveFCParameters()
+    elif default_fc_parameters is None:
+        default_fc_parameters = {}
+    if isinstance(timeseries_container, pd.DataFrame) and len(timeseries_container) <= 1:
+        raise ValueError("Your time series container has zero or one rows!. Can not perform rolling.")
+    packed, id_dtype, _ = pack_timeseries(timeseries_container, column_id=column_id, column_kind=column_kind,
+                                          column_value=column_value, column_sort=column_sort)
+    if device is None:
+        device = _default_device()
+    # prediction_steps is the longest series over ALL ids and kinds (dataframe_functions.py:546)
+    steps = max(int(np.diff(pk.offsets).max()) for pk in packed if pk.n_series)
+    blocks, plan_cache = [], {}
+    with warnings.catch_warnings():
+        warnings.simplefilter("default" if show_warnings else "ignore")
+        for pk in packed:
+            fc_parameters = kind_to_fc_parameters[pk.kind] if kind_to_fc_parameters and pk.kind in kind_to_fc_parameters \
+                else default_fc_parameters
+            kind_has_dt = pk.times is not None
+            key = (id(fc_parameters), kind_has_dt)
+            if key not in plan_cache:
+                fplan = compile_fc_parameters(fc_parameters, has_datetime_index=kind_has_dt)
+                plan_cache[key] = (fplan, _native.Plan(fplan.native_specs(_native.calc_id), device=device) if len(fplan) else None)
+            fplan, nplan = plan_cache[key]
+            if nplan is None:
+                continue
+            lengths = np.diff(pk.offsets)
+            # roll_views sizes its shifts from the longest series it is given: append a phantom of `steps` samples
+            gi, frm, until, ts = roll_views(np.concatenate([lengths, [steps]]), rolling_direction, max_timeshift, min_timeshift)
+            keep = gi < len(lengths)
+            gi, frm, until, ts = gi[keep], frm[keep], until[keep], ts[keep]
+            starts, ends = pk.offsets[gi] + frm, pk.offsets[gi] + until
+            if pk.sort is not None:
+                shift_val = pk.sort[ends - 1] if rolling_direction > 0 else pk.sort[starts]
+            else:
+                shift_val = ts - 1
+            ids = np.empty(len(gi), dtype=object)
+            base_ids = pk.ids[gi]
+            for i in range(len(gi)):
+                ids[i] = (base_ids[i], shift_val[i])
+            matrix = nplan.extract_windows_host(pk.values, starts, ends, times=pk.times)
+            order = sorted(range(len(ids)), key=lambda i: ids[i])
+            blocks.append((_WindowBlock(pk.kind, ids[order]), [pk.kind + "__" + n for n in fplan.names], matrix[order]))
+        for _, nplan in plan_cache.values():
+            if nplan is not None:
+                nplan.close()
+    return _assemble(blocks, np.dtype(object), pivot, impute_function)

@@ -1,0 +1,144 @@
+"""Rolling ("forecasting") windows.
+
+`roll_time_series` keeps the reference's contract (tsfresh/utilities/dataframe_functions.py:377-603): every id is cut
+into sub-windows, each of which becomes a new time series with the id ``(id, shift)``.  The reference builds the
+result by copying every window into a new DataFrame (`_roll_out_time_series` :294-372, one `groupby.apply` per
+shift); here the windows are first described as `(series, first row, end row)` views (`roll_views`), and
+
+  * `roll_time_series` materialises them with one vectorised gather -- same rows, same order, same ``id`` tuples;
+  * `tsfresh_amd.extract_rolled_features` hands the views straight to the GPU (`tsfa_extract_windows`): the samples
+    are uploaded once and every window is a `(start, end)` pair into that one buffer, which removes the O(windows x
+    length) host memory of the forecasting workflow (BASELINE.json configs[4]).
+"""
+import warnings
+
+import numpy as np
+import pandas as pd
+
+
+def roll_views(lengths, rolling_direction=1, max_timeshift=None, min_timeshift=0):
+    """Window views of series with the given lengths.
+
+    Restates the index arithmetic of `_roll_out_time_series` (dataframe_functions.py:340-358) for all shifts at once.
+    -> (series index, first row, end row (exclusive), timeshift) as int64 arrays, ordered by (series, timeshift).
+    """
+    if rolling_direction == 0:
+        raise ValueError("Rolling direction of 0 is not possible")
+    if max_timeshift is not None and max_timeshift <= 0:
+        raise ValueError("max_timeshift needs to be positive!")
+    if min_timeshift < 0:
+        raise ValueError("min_timeshift needs to be positive or zero!")
+    lengths = np.asarray(lengths, dtype=np.int64)
+    if lengths.size == 0:
+        z = np.zeros(0, dtype=np.int64)
+        return z, z, z, z
+    amount = abs(int(rolling_direction))
+    steps = int(lengths.max())                       # prediction_steps (:546)
+    mts = int(max_timeshift or steps)                # :548
+    if rolling_direction > 0:
+        shifts = np.arange(steps, 0, -amount, dtype=np.int64)[::-1]   # :550-551
+    else:
+        shifts = np.arange(1, steps + 1, amount, dtype=np.int64)      # :553
+    sidx = np.repeat(np.arange(lengths.size, dtype=np.int64), shifts.size)
+    ts = np.tile(shifts, lengths.size)
+    ln = lengths[sidx]
+    if rolling_direction > 0:
+        until = ts                                   # :343
+        frm = np.maximum(until - mts - 1, 0)         # :344
+        ok = until <= ln                             # :346
+    else:
+        frm = np.maximum(ts - 1, 0)                  # :349
+        until = np.minimum(frm + mts + 1, ln)        # :350-352 (iloc clips)
+        ok = frm < ln
+    ok &= (until - frm) >= (min_timeshift + 1)       # :354
+    return sidx[ok], frm[ok], until[ok], ts[ok]
+
+
+def _sorted_groups(df, column_id, column_sort, column_kind):
+    """Row order of `df.sort_values(column_sort)` grouped by (kind, id) -> (row order, group starts, group lengths,
+    group keys as a list of arrays)."""
+    n = len(df)
+    order = np.arange(n)
+    if column_sort is not None:
+        order = np.argsort(df[column_sort].to_numpy(), kind="stable")
+    keys = []
+    if column_kind is not None:
+        keys.append(pd.factorize(df[column_kind].to_numpy()[order], sort=True)[0])
+    keys.append(pd.factorize(df[column_id].to_numpy()[order], sort=True)[0])
+    grp = np.lexsort(tuple(reversed(keys)))          # stable: keeps the sort order inside a group
+    order = order[grp]
+    code = np.zeros(n, dtype=np.int64)
+    for k in keys:
+        code = code * (int(k.max()) + 1 if n else 1) + k[grp]
+    change = np.nonzero(np.diff(code))[0] + 1
+    starts = np.concatenate([[0], change]).astype(np.int64)
+    lengths = np.diff(np.concatenate([starts, [n]])).astype(np.int64)
+    return order, starts, lengths
+
+
+def roll_time_series(df_or_dict, column_id, column_sort=None, column_kind=None, rolling_direction=1,
+                     max_timeshift=None, min_timeshift=0, chunksize=None, n_jobs=None, show_warnings=False,
+                     disable_progressbar=True, distributor=None):
+    """Reference-compatible `roll_time_series` (dataframe_functions.py:377): returns the rolled DataFrame (or dict of
+    DataFrames) with the new ``id`` column of ``(id, shift)`` tuples, sorted by ``["id", column_sort or "sort"]``.
+    `chunksize`, `n_jobs`, `disable_progressbar`, `distributor` only steer the reference's CPU distributors and are
+    ignored."""
+    if rolling_direction == 0:
+        raise ValueError("Rolling direction of 0 is not possible")
+    if max_timeshift is not None and max_timeshift <= 0:
+        raise ValueError("max_timeshift needs to be positive!")
+    if min_timeshift < 0:
+        raise ValueError("min_timeshift needs to be positive or zero!")
+    if isinstance(df_or_dict, dict):
+        if column_kind is not None:
+            raise ValueError("You passed in a dictionary and gave a column name for the kind. Both are not possible.")
+        return {key: roll_time_series(df_or_dict[key], column_id=column_id, column_sort=column_sort,
+                                      column_kind=column_kind, rolling_direction=rolling_direction,
+                                      max_timeshift=max_timeshift, min_timeshift=min_timeshift)
+                for key in df_or_dict}
+    df = df_or_dict
+    if len(df) <= 1:
+        raise ValueError("Your time series container has zero or one rows!. Can not perform rolling.")
+    if column_id is None:
+        raise ValueError("You have to set the column_id which contains the ids of the different time series")
+    if column_id not in df:
+        raise AttributeError("The given column for the id is not present in the data.")
+    if column_sort is not None:
+        if df[column_sort].isnull().any():
+            raise ValueError("You have NaN values in your sort column.")
+    else:
+        df = df.copy()
+        df["sort"] = range(df.shape[0])             # :543
+    order, starts, lengths = _sorted_groups(df, column_id, column_sort, column_kind)
+    if column_sort is not None and df[column_sort].dtype != object:
+        sv = df[column_sort].to_numpy()[order]
+        d = sv[:-1] - sv[1:]
+        inner = np.ones(len(sv) - 1, dtype=bool)
+        inner[starts[1:] - 1] = False               # differences across group borders do not count
+        if inner.any() and d[inner].min() != d[inner].max():
+            warnings.warn("Your time stamps are not uniformly sampled, which makes rolling "
+                          "nonsensical in some domains.")
+    gi, frm, until, ts = roll_views(lengths, rolling_direction, max_timeshift, min_timeshift)
+    wlen = until - frm
+    # rows of all windows: group start + first row + 0..len-1
+    first = starts[gi] + frm
+    rows = np.repeat(first, wlen) + (np.arange(int(wlen.sum())) - np.repeat(np.cumsum(wlen) - wlen, wlen))
+    out = df.iloc[order[rows]].copy()
+    sort_col = column_sort or "sort"
+    if column_sort is not None:
+        sv = df[column_sort].to_numpy()[order]
+        shift_val = sv[first + wlen - 1] if rolling_direction > 0 else sv[first]   # :363-366
+    else:
+        shift_val = ts - 1                           # :368
+    ids = df[column_id].to_numpy()[order][first]
+    new_ids = np.empty(len(first), dtype=object)
+    for i in range(len(first)):
+        new_ids[i] = (ids[i], shift_val[i])
+    out["id"] = np.repeat(new_ids, wlen)            # :370
+    # the reference concatenates shift by shift (pd.concat(..., ignore_index=True) :601): give every row the position
+    # it has there, so that even the index of the result is the reference's
+    by_shift = np.lexsort((gi, ts))
+    base = np.empty(len(first), dtype=np.int64)
+    base[by_shift] = np.cumsum(wlen[by_shift]) - wlen[by_shift]
+    out.index = np.repeat(base, wlen) + (np.arange(int(wlen.sum())) - np.repeat(np.cumsum(wlen) - wlen, wlen))
+    return out.sort_values(by=["id", sort_col])
