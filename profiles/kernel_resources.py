@@ -8,7 +8,7 @@ import sys
 
 csrc = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "tsfresh_amd", "csrc")
 cmd = ["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off",
-       "-Wno-unused-function", "-mllvm", "-amdgpu-atomic-optimizer-strategy=None",
+       "-Wno-unused-function", "-mllvm", "-amdgpu-atomic-optimizer-strategy=None", "-mllvm", "-disable-machine-licm",
        "-Rpass-analysis=kernel-resource-usage", "-c", "tsfa_kernels.hip", "-o", "/tmp/tsfa_k.o"]
 txt = subprocess.run(cmd, cwd=csrc, capture_output=True, text=True).stderr
 rows, cur = [], None
