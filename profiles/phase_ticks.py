@@ -17,7 +17,8 @@ os.environ.setdefault("TSFA_LIB", os.path.join(ROOT, "tsfresh_amd", "libtsfresh_
 
 NAMED = {210: "basic: spec fetch (all columns)", 211: "basic: column bodies (all columns)",
          212: "basic: output stores (all columns)", 200: "basic/agg_linear_trend: chunk aggregates", 201: "basic/agg_linear_trend: regression sums",
-         202: "basic/agg_linear_trend: linregress tails (lane = regression)", 100: "basic: stage + stats", 104: "sort: stage + bitonic sort", 120: "ar: mean/demean/var + scan",
+         202: "basic/agg_linear_trend: linregress tails (lane = regression)", 100: "basic: stage + stats", 104: "sort: stage + bitonic sort", 120: "ar: mean / demean / var", 121: "ar: spec scan + autocovariances", 122: "ar: Levinson-Durbin (pacf)",
+         123: "ar/adf: lag products + normal matrix", 124: "ar/adf: Cholesky + nested AIC", 125: "ar/adf: final regression",
          130: "entropy: std + sentinels", 131: "entropy: template sort + refs", 132: "entropy: group setup",
          133: "entropy: sweep group 0 (incl. totals)", 134: "entropy: sweep groups 1+ (incl. totals)",
          136: "entropy: pair sweep (thread 0's wave)", 137: "entropy: wait for the other waves",

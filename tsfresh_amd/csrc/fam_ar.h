@@ -147,7 +147,7 @@ TSFA_DEV int ar_scratch_doubles(int P) { return 2 * P * P + 6 * P + 64 + 16 + 48
 //   aw   : LDS, ar_scratch_doubles(P) doubles;  P >= max(adf_maxlag_for(n) + 3, max AR order + 2)
 template <class X>
 TSFA_DEV void fam_ar_series(const Blk &b, X xv, int n, const TsfaSpec *specs, int nspecs, double *out_row, double *xc,
-                            double *rbuf, double *aw, int P) {
+                            double *rbuf, double *aw, int P, int hint_acf, int hint_pacf, int hint_adf) {
     const double dn = (double)n;
     TSFA_TICKER(tk, 0);
     // x.mean() in numpy's summation order: statsmodels demeans with it, and on (near-)constant series the
@@ -175,20 +175,11 @@ TSFA_DEV void fam_ar_series(const Blk &b, X xv, int n, const TsfaSpec *specs, in
     double *pacw = arres + 40;    // 128: Levinson-Durbin columns
     const double *xcc = xc;
 
-    int max_acf_lag = -1, max_pacf_lag = -1;
-    bool need_adf = false;
-    for (int s = 0; s < nspecs; ++s) {
-        const int c = specs[s].calc;
-        if (c == TSFA_C_AGG_AUTOCORRELATION) {
-            const int ml = (int)specs[s].p[1];
-            if (ml > max_acf_lag) max_acf_lag = ml;
-        } else if (c == TSFA_C_PARTIAL_AUTOCORRELATION) {
-            const int l = (int)specs[s].p[0];
-            if (l > max_pacf_lag) max_pacf_lag = l;
-        } else if (c == TSFA_C_AUGMENTED_DICKEY_FULLER) {
-            need_adf = true;
-        }
-    }
+    TSFA_TICK(tk, b, 120);
+    // largest agg_autocorrelation maxlag / partial_autocorrelation lag of the plan (-1: none) and whether ADF is
+    // requested: tsfa_prepare_family on the host (a scan of the spec list here costs a scalar-load round trip per spec)
+    int max_acf_lag = hint_acf, max_pacf_lag = hint_pacf;
+    const bool need_adf = (hint_adf != 0);
     if (max_acf_lag > 60) max_acf_lag = 60;
     if (max_pacf_lag > 40) max_pacf_lag = 40;
 
@@ -217,6 +208,7 @@ TSFA_DEV void fam_ar_series(const Blk &b, X xv, int n, const TsfaSpec *specs, in
     }
     blk_sync();
 
+    TSFA_TICK(tk, b, 121);
     // ---- PACF by Levinson-Durbin (stattools.levinson_durbin, isacov=True) ----
     if (max_pacf_lag >= 0) {
         if (b.tid == 0) {
@@ -244,6 +236,7 @@ TSFA_DEV void fam_ar_series(const Blk &b, X xv, int n, const TsfaSpec *specs, in
         blk_sync();
     }
 
+    TSFA_TICK(tk, b, 122);
     // ---- augmented Dickey-Fuller, regression="c", autolag="AIC" (stattools.adfuller) ----
     // rows are indexed by t with d[t] = x[t+1] - x[t]; regressors: 1, x[t] (level), d[t-1..t-maxlag]; target d[t]
     double adf_stat = TSFA_NAN, adf_p = TSFA_NAN, adf_lag = TSFA_NAN;
@@ -296,6 +289,7 @@ TSFA_DEV void fam_ar_series(const Blk &b, X xv, int n, const TsfaSpec *specs, in
             for (int a = b.tid; a < p1; a += b.nt) g[a] = (a == 0) ? C[0] : (a == 1 ? V[0] : T[a - 1]);
             blk_sync();
             const double yy = T[0];
+            TSFA_TICK(tk, b, 123);
             {
                 // all nested fits from one factorization: w = L^-1 g, SSR_p = yy - sum_{i<p} w_i^2
                 const bool okf = blk_chol_factor(b, G, p1, P);
@@ -329,6 +323,7 @@ TSFA_DEV void fam_ar_series(const Blk &b, X xv, int n, const TsfaSpec *specs, in
             blk_sync();
             const int bestcols = (int)res[0];
             blk_sync();
+            TSFA_TICK(tk, b, 124);
             if (bestcols >= 2) {
                 const int usedlag = bestcols - 2;
                 const int p2 = usedlag + 2;
@@ -416,7 +411,7 @@ TSFA_DEV void fam_ar_series(const Blk &b, X xv, int n, const TsfaSpec *specs, in
 
     int ar_cached_k = -1;
     bool ar_ok = false;
-    TSFA_TICK(tk, b, 120);
+    TSFA_TICK(tk, b, 125);
     for (int s = 0; s < nspecs; ++s) {
         const TsfaSpec sp = specs[s];
         double v = TSFA_NAN;

@@ -40,8 +40,10 @@ TSFA_DEV double conv_same_at(X xv, int n, const double *h, int nw, int c) {
     return acc;
 }
 
+#define TSFA_CWTP_HALO ((TSFA_CWTP_MAXTAPS + 1) / 2 + 2)   // zero padding of the staged series on either side
+
 struct CwtPeaksLds {
-    double *red; double *row0; double *rowv; double *taps; unsigned short *mask; unsigned short *lcol;
+    double *red; double *row0; double *rowv; double *taps; double *xpad; unsigned short *mask; unsigned short *lcol;
     unsigned short *linf; unsigned short *colmap; unsigned short *mline; int *misc;
 };
 
@@ -82,7 +84,51 @@ TSFA_DEV double number_cwt_peaks_one(const Blk &b, X xv, int n, int W, const Cwt
     for (int c = b.tid; c < n; c += b.nt) { L.mask[c] = 0; L.colmap[c] = 0; L.mline[c] = 0; }
     blk_sync();
     // ---- phase A ----
-    for (int w = 1; w <= W; ++w) {
+    // The series sits in LDS between two zero halos (xpad[TSFA_CWTP_HALO + i] = x[i]), so every output runs the full
+    // tap range without bounds (the padded products are exact zeros).  A thread owns four consecutive columns plus one
+    // neighbour on either side: the six running sums share each sample it reads (a sliding window in registers), and
+    // the relative-maximum test needs no stored row.  Same accumulation order as conv_same_at (ascending sample).
+    if (L.xpad != nullptr) {
+        blk_sync();
+        for (int i = b.tid; i < n + 2 * TSFA_CWTP_HALO + 8; i += b.nt) {
+            const int j = i - TSFA_CWTP_HALO;
+            L.xpad[i] = (j >= 0 && j < n) ? xv(j) : 0.0;
+        }
+    }
+    for (int w = 1; w <= W && L.xpad != nullptr; ++w) {
+        const int nw = (10 * w < n) ? 10 * w : n;
+        blk_sync();
+        for (int k = b.tid; k < nw; k += b.nt) L.taps[k] = ricker_tap(nw, (double)w, nw - 1 - k);  // reversed
+        blk_sync();
+        const double *h = L.taps;
+        const int half = (nw - 1) / 2;
+        for (int c0 = 4 * b.tid; c0 < n; c0 += 4 * b.nt) {
+            // outputs c0-1 .. c0+4;  out[c] = sum_k h[k] x[c + half - k]: with u = c0 - 1 + half - k (sample of the
+            // first output), output j reads sample u + j.  k runs nw-1 .. 0, i.e. u ascends.
+            double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0, a4 = 0.0, a5 = 0.0;
+            const double *xp = L.xpad + TSFA_CWTP_HALO + (c0 - 1 + half - (nw - 1));
+            double x0 = xp[0], x1 = xp[1], x2 = xp[2], x3 = xp[3], x4 = xp[4];
+            for (int t = 0; t < nw; ++t) {  // k = nw - 1 - t
+                const double hk = h[nw - 1 - t];
+                const double x5 = xp[t + 5];
+                a0 += x0 * hk; a1 += x1 * hk; a2 += x2 * hk; a3 += x3 * hk; a4 += x4 * hk; a5 += x5 * hk;
+                x0 = x1; x1 = x2; x2 = x3; x3 = x4; x4 = x5;
+            }
+            // _boolrelextrema(order=1, mode="clip"): strict, never at the ends
+            unsigned short bit = (unsigned short)(1u << (w - 1));
+            if (c0 >= 1 && c0 < n - 1 && a1 > a0 && a1 > a2) L.mask[c0] |= bit;
+            if (c0 + 1 < n - 1 && a2 > a1 && a2 > a3) L.mask[c0 + 1] |= bit;
+            if (c0 + 2 < n - 1 && a3 > a2 && a3 > a4) L.mask[c0 + 2] |= bit;
+            if (c0 + 3 < n - 1 && a4 > a3 && a4 > a5) L.mask[c0 + 3] |= bit;
+            if (w == 1) {
+                L.row0[c0] = a1;
+                if (c0 + 1 < n) L.row0[c0 + 1] = a2;
+                if (c0 + 2 < n) L.row0[c0 + 2] = a3;
+                if (c0 + 3 < n) L.row0[c0 + 3] = a4;
+            }
+        }
+    }
+    for (int w = 1; w <= W && L.xpad == nullptr; ++w) {  // no room for the padded copy (very long series)
         const int nw = (10 * w < n) ? 10 * w : n;
         blk_sync();
         for (int k = b.tid; k < nw; k += b.nt) L.taps[k] = ricker_tap(nw, (double)w, nw - 1 - k);  // reversed

@@ -339,6 +339,67 @@ TSFA_DEV double np_sum(const Blk &b, int n, F f) {
     for (int c0 = 0; c0 < n; c0 += 8192) {
         const int clen = (n - c0 < 8192) ? (n - c0) : 8192;
         blk_sync();
+#if TSFA_GPU
+        {
+            // Fast path (every length whose pairwise tree is COMPLETE, e.g. 1024 = 8 leaves of 128): lane j of every
+            // wavefront walks from the root to leaf j with index arithmetic only -- no LDS stack, no serial thread --
+            // and the leaf sums are combined by log2(leaves) butterfly steps, which is the recursion's own order
+            // (sum(left half) + sum(right half) at every level).  All wavefronts do this redundantly, so the result
+            // is uniform without a broadcast.  Incomplete trees (leaf depths differ) take the general path below.
+            int dl = 0, dr = 0;
+            for (int l = clen; l > 128; ++dl) { int n2 = l / 2; n2 -= n2 % 8; l = n2; }
+            for (int l = clen; l > 128; ++dr) { int n2 = l / 2; n2 -= n2 % 8; l = l - n2; }
+            bool complete = (dl == dr) && (dl <= 6);
+            const int d = dl, nl = 1 << d, lane = b.tid & 63;
+            int lo = c0, ll = clen, lp = 1 << 30;  // my leaf's offset / length, its parent's length
+            if (complete) {
+                for (int lev = d - 1; lev >= 0; --lev) {
+                    int n2 = ll / 2;
+                    n2 -= n2 % 8;
+                    lp = ll;
+                    if ((lane >> lev) & 1) { lo += n2; ll -= n2; } else { ll = n2; }
+                }
+                const bool ok = (lane >= nl) || (ll <= 128 && (d == 0 || lp > 128));
+                complete = (__ballot(ok) == ~0ull);
+            }
+            if (complete) {
+                for (int u0 = 0; u0 < nl * 8; u0 += b.nt) {
+                    const int u = u0 + b.tid;
+                    const int leaf = u >> 3, k = u & 7;
+                    const bool live = leaf < nl;
+                    const int o = __shfl(lo, leaf & 63), l = live ? __shfl(ll, leaf & 63) : 0;
+                    double r = 0.0;
+                    if (l >= 8) {
+                        const int lim = l - (l % 8);
+                        r = f(o + k);
+                        for (int i = 8; i < lim; i += 8) r += f(o + i + k);
+                    }
+                    r += dpp_mov_f64<TSFA_DPP_QUAD_XOR1>(r);
+                    r += dpp_mov_f64<TSFA_DPP_QUAD_XOR2>(r);
+                    r += dpp_mov_f64<TSFA_DPP_ROW_HALF_MIRROR>(r);
+                    if (live && k == 0) {
+                        if (l < 8) {
+                            r = 0.0;
+                            for (int i = 0; i < l; ++i) r += f(o + i);
+                        } else {
+                            for (int i = l - (l % 8); i < l; ++i) r += f(o + i);
+                        }
+                        s->leaf_sum[leaf] = r;
+                    }
+                }
+                blk_sync();
+                double v = (lane < nl) ? s->leaf_sum[lane] : 0.0;
+                for (int bit = 1; bit < nl; bit <<= 1) v = v + __shfl_xor(v, bit);
+                const double chunk = readlane_f64(v, 0);
+                total = (c0 == 0) ? chunk : (total + chunk);
+                if (c0 + 8192 >= n) {
+                    blk_sync();  // leaf_sum may be reused by the next call
+                    return total;
+                }
+                continue;
+            }
+        }
+#endif
         if (b.tid == 0) {  // enumerate the leaves of the pairwise tree, left to right
             int sp = 0, nl = 0;
             s->st_o[0] = c0;
@@ -425,12 +486,11 @@ TSFA_DEV double np_sum(const Blk &b, int n, F f) {
                 }
             }
             const double chunk = s->vst[0];
-            total = (c0 == 0) ? chunk : (s->result + chunk);
-            s->result = total;
+            s->result = chunk;
         }
+        blk_sync();
+        total = (c0 == 0) ? s->result : (total + s->result);
     }
-    blk_sync();
-    total = s->result;
     blk_sync();
     return total;
 }

@@ -77,7 +77,7 @@ static inline void tsfa_build_twiddles(std::vector<double> &twc, std::vector<dou
 // carries its output column, so the order on the device is free).
 #define TSFA_ALT_SLOTS 16
 struct TsfaFamHints {
-    int a = 0, b = 0;
+    int a = 0, b = 0, c = 0;
     TsfaAltPlan alt;  // BASIC
     TsfaCqPlan cq;    // SORT
 };
@@ -85,6 +85,16 @@ static inline void tsfa_prepare_family(int fam, std::vector<TsfaSpec> &specs, Ts
     h = TsfaFamHints();
     memset(&h.alt, 0, sizeof h.alt);
     memset(&h.cq, 0, sizeof h.cq);
+    if (fam == TSFA_FAM_AR) {
+        // a: largest agg_autocorrelation maxlag, b: largest partial_autocorrelation lag (-1: none), c: ADF requested
+        h.a = -1;
+        h.b = -1;
+        for (const auto &s : specs) {
+            if (s.calc == TSFA_C_AGG_AUTOCORRELATION && (int)s.p[1] > h.a) h.a = (int)s.p[1];
+            if (s.calc == TSFA_C_PARTIAL_AUTOCORRELATION && (int)s.p[0] > h.b) h.b = (int)s.p[0];
+            if (s.calc == TSFA_C_AUGMENTED_DICKEY_FULLER) h.c = 1;
+        }
+    }
     if (fam == TSFA_FAM_SORT) {
         std::vector<std::pair<double, double>> cor;
         for (const auto &s : specs)

@@ -149,12 +149,14 @@ struct SeqLds {
 
 struct CwtPeaksLayout {
     CwtPeaksLds p;
-    // with_rowv: keep a second float64 row in LDS (each CWT row is then convolved once instead of three times)
-    TSFA_HD size_t carve(unsigned char *base, int maxn, int with_rowv) {
+    // mode 1: the series is staged between zero halos (register-tiled convolutions, no second row needed);
+    // mode 0: no staging (very long series): the CWT rows are evaluated column by column from HBM
+    TSFA_HD size_t carve(unsigned char *base, int maxn, int mode) {
         LdsCarve c{base, 0};
         p.red = c.take<double>(TSFA_RED_DOUBLES);
-        p.row0 = c.take<double>(maxn);
-        p.rowv = with_rowv ? c.take<double>(maxn) : nullptr;
+        p.row0 = c.take<double>(maxn + 4);
+        p.rowv = nullptr;
+        p.xpad = mode ? c.take<double>(maxn + 2 * TSFA_CWTP_HALO + 8) : nullptr;
         p.taps = c.take<double>(TSFA_CWTP_MAXTAPS + 16);
         p.mask = c.take<unsigned short>(maxn);
         p.lcol = c.take<unsigned short>(maxn);
