@@ -76,26 +76,14 @@ TSFA_DEV void smallest8_select(V v, int m, int i0, double *s0, double *s1) {
     *s1 = a1;
 }
 
-template <class X>
-TSFA_DEV double number_cwt_peaks_one(const Blk &b, X xv, int n, int W, const CwtPeaksLds &L) {
-    const int cap = n;  // line capacity
-    TSFA_TICKER(tk, 0);
-    blk_sync();
-    for (int c = b.tid; c < n; c += b.nt) { L.mask[c] = 0; L.colmap[c] = 0; L.mline[c] = 0; }
-    blk_sync();
-    // ---- phase A ----
-    // The series sits in LDS between two zero halos (xpad[TSFA_CWTP_HALO + i] = x[i]), so every output runs the full
-    // tap range without bounds (the padded products are exact zeros).  A thread owns four consecutive columns plus one
-    // neighbour on either side: the six running sums share each sample it reads (a sliding window in registers), and
-    // the relative-maximum test needs no stored row.  Same accumulation order as conv_same_at (ascending sample).
-    if (L.xpad != nullptr) {
-        blk_sync();
-        for (int i = b.tid; i < n + 2 * TSFA_CWTP_HALO + 8; i += b.nt) {
-            const int j = i - TSFA_CWTP_HALO;
-            L.xpad[i] = (j >= 0 && j < n) ? xv(j) : 0.0;
-        }
-    }
-    for (int w = 1; w <= W && L.xpad != nullptr; ++w) {
+// CWT rows for widths 1..W by direct convolution with the Ricker taps, relative-maximum bit mask, row 0 kept.
+// xat(i) = sample i, 0 outside [0, n): every output runs the full tap range without bounds (the padded products are
+// exact zeros).  A thread owns four consecutive columns plus one neighbour on either side: the six running sums share
+// each sample it reads (a sliding window in registers), and the relative-maximum test needs no stored row.  Same
+// accumulation order as conv_same_at (ascending sample).
+template <class XA>
+TSFA_DEV void cwt_rows_tiled(const Blk &b, XA xat, int n, int W, const CwtPeaksLds &L) {
+    for (int w = 1; w <= W; ++w) {
         const int nw = (10 * w < n) ? 10 * w : n;
         blk_sync();
         for (int k = b.tid; k < nw; k += b.nt) L.taps[k] = ricker_tap(nw, (double)w, nw - 1 - k);  // reversed
@@ -106,16 +94,16 @@ TSFA_DEV double number_cwt_peaks_one(const Blk &b, X xv, int n, int W, const Cwt
             // outputs c0-1 .. c0+4;  out[c] = sum_k h[k] x[c + half - k]: with u = c0 - 1 + half - k (sample of the
             // first output), output j reads sample u + j.  k runs nw-1 .. 0, i.e. u ascends.
             double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0, a4 = 0.0, a5 = 0.0;
-            const double *xp = L.xpad + TSFA_CWTP_HALO + (c0 - 1 + half - (nw - 1));
-            double x0 = xp[0], x1 = xp[1], x2 = xp[2], x3 = xp[3], x4 = xp[4];
+            const int u0 = c0 - 1 + half - (nw - 1);
+            double x0 = xat(u0), x1 = xat(u0 + 1), x2 = xat(u0 + 2), x3 = xat(u0 + 3), x4 = xat(u0 + 4);
             for (int t = 0; t < nw; ++t) {  // k = nw - 1 - t
                 const double hk = h[nw - 1 - t];
-                const double x5 = xp[t + 5];
+                const double x5 = xat(u0 + t + 5);
                 a0 += x0 * hk; a1 += x1 * hk; a2 += x2 * hk; a3 += x3 * hk; a4 += x4 * hk; a5 += x5 * hk;
                 x0 = x1; x1 = x2; x2 = x3; x3 = x4; x4 = x5;
             }
             // _boolrelextrema(order=1, mode="clip"): strict, never at the ends
-            unsigned short bit = (unsigned short)(1u << (w - 1));
+            const unsigned short bit = (unsigned short)(1u << (w - 1));
             if (c0 >= 1 && c0 < n - 1 && a1 > a0 && a1 > a2) L.mask[c0] |= bit;
             if (c0 + 1 < n - 1 && a2 > a1 && a2 > a3) L.mask[c0 + 1] |= bit;
             if (c0 + 2 < n - 1 && a3 > a2 && a3 > a4) L.mask[c0 + 2] |= bit;
@@ -128,25 +116,26 @@ TSFA_DEV double number_cwt_peaks_one(const Blk &b, X xv, int n, int W, const Cwt
             }
         }
     }
-    for (int w = 1; w <= W && L.xpad == nullptr; ++w) {  // no room for the padded copy (very long series)
-        const int nw = (10 * w < n) ? 10 * w : n;
+}
+
+template <class X>
+TSFA_DEV double number_cwt_peaks_one(const Blk &b, X xv, int n, int W, const CwtPeaksLds &L) {
+    const int cap = n;  // line capacity
+    TSFA_TICKER(tk, 0);
+    blk_sync();
+    for (int c = b.tid; c < n; c += b.nt) { L.mask[c] = 0; L.colmap[c] = 0; L.mline[c] = 0; }
+    blk_sync();
+    // ---- phase A: the series goes to LDS between two zero halos (xpad[TSFA_CWTP_HALO + i] = x[i]) when it fits ----
+    if (L.xpad != nullptr) {
         blk_sync();
-        for (int k = b.tid; k < nw; k += b.nt) L.taps[k] = ricker_tap(nw, (double)w, nw - 1 - k);  // reversed
-        blk_sync();
-        const double *h = L.taps;
-        double *dst = (w == 1) ? L.row0 : L.rowv;
-        if (dst != nullptr) {
-            for (int c = b.tid; c < n; c += b.nt) dst[c] = conv_same_at(xv, n, h, nw, c);
-            blk_sync();
-            for (int c = 1 + b.tid; c < n - 1; c += b.nt)  // _boolrelextrema(order=1, mode="clip"): strict, never at the ends
-                if (dst[c] > dst[c - 1] && dst[c] > dst[c + 1]) L.mask[c] |= (unsigned short)(1u << (w - 1));
-        } else {  // no LDS for a second row (very long series): evaluate the neighbours in place
-            for (int c = 1 + b.tid; c < n - 1; c += b.nt) {
-                const double v = conv_same_at(xv, n, h, nw, c);
-                if (v > conv_same_at(xv, n, h, nw, c - 1) && v > conv_same_at(xv, n, h, nw, c + 1))
-                    L.mask[c] |= (unsigned short)(1u << (w - 1));
-            }
+        for (int i = b.tid; i < n + 2 * TSFA_CWTP_HALO + 8; i += b.nt) {
+            const int j = i - TSFA_CWTP_HALO;
+            L.xpad[i] = (j >= 0 && j < n) ? xv(j) : 0.0;
         }
+        const double *xp0 = L.xpad + TSFA_CWTP_HALO;
+        cwt_rows_tiled(b, [=](int i) { return xp0[i]; }, n, W, L);
+    } else {  // no room for the padded copy (very long series): the same tiles, samples straight from HBM / L2
+        cwt_rows_tiled(b, [=](int i) { return (i >= 0 && i < n) ? xv(i) : 0.0; }, n, W, L);
     }
     blk_sync();
     TSFA_TICK(tk, b, 151);

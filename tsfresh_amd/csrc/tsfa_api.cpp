@@ -398,15 +398,8 @@ int tsfa_extract_windows(tsfa_plan *plan, const void *values, int32_t dtype, con
         a.cq = plan->hints[f].cq;
         int aux = 0;
         if (f == TSFA_FAM_SPECTRAL) {
-            a.dft_n = (int)max_np2;
-            if (tsfa_family_lds_bytes(f, maxn, a.nt, a.dft_n) > TSFA_LDS_LIMIT) {
-                // twiddles of the long non-power-of-two series go to an HBM scratch slab per series
-                a.dft_n = 0;
-                a.gscratch_n = (int)max_np2;
-                const size_t need = (size_t)n_series * 2 * (size_t)a.gscratch_n * sizeof(double);
-                if (plan->gscratch.ensure(need)) return fail(TSFA_ERR_HIP, "hipMalloc failed for the DFT twiddle scratch");
-                a.gscratch = (double *)plan->gscratch.p;
-            }
+            // only non-power-of-two lengths <= 256 use the table-driven DFT (longer ones: Goertzel, no table)
+            a.dft_n = (int)std::min<long long>(max_np2, 256);
             aux = a.dft_n;
         } else if (f == TSFA_FAM_CWT) {
             a.cwt_rowv = tsfa_family_lds_bytes(f, maxn, a.nt, 1) <= 96 * 1024 ? 1 : 0;
