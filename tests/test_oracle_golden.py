@@ -50,3 +50,17 @@ def test_emul_column_order_is_the_reference_order():
     names, _ = emul_engine(ComprehensiveFCParameters(), values, offsets)
     ours = [n for n in names if n in set(ref_order)]
     assert ours == ref_order
+
+
+def test_emul_number_cwt_peaks_long_windows_match_oracle():
+    """Series long enough (n > ~1400) that the SNR filter's noise percentile takes the argsort-scan path."""
+    rng = np.random.default_rng(123)
+    lens = [1500, 3000, 2049]
+    chunks = [rng.standard_normal(lens[0]), np.cumsum(rng.standard_normal(lens[1])), rng.standard_normal(lens[2])]
+    values = np.concatenate(chunks)
+    offsets = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
+    params = {"number_cwt_peaks": [{"n": 1}, {"n": 5}]}
+    names, got = emul_engine(params, values, offsets)
+    onames, want = oracle_engine(params, values, offsets)
+    assert names == onames
+    assert np.array_equal(got, want), (got, want)

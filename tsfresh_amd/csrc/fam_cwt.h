@@ -40,6 +40,11 @@ TSFA_DEV double conv_same_at(X xv, int n, const double *h, int nw, int c) {
     return acc;
 }
 
+#if TSFA_GPU
+#define TSFA_ENT_WAVE_C 64
+#else
+#define TSFA_ENT_WAVE_C 1
+#endif
 #define TSFA_CWTP_HALO ((TSFA_CWTP_MAXTAPS + 1) / 2 + 2)   // zero padding of the staged series on either side
 
 struct CwtPeaksLds {
@@ -231,6 +236,83 @@ TSFA_DEV double number_cwt_peaks_one(const Blk &b, X xv, int n, int W, const Cwt
     const int window = (n + 19) / 20;               // ceil(num_points / 20)
     const int hf = window / 2, odd = window % 2;
     double kept = 0.0;
+    // Long series: the noise window holds hundreds of samples and its 10th percentile is no longer among the eight
+    // smallest.  Ranking a window against itself costs window^2 per ridge line (n^3 / 1200 per series).  Instead the
+    // width-1 row is argsorted ONCE; a line's percentile is then found by walking that global order from the smallest
+    // value and counting the entries whose column falls into the line's window (64 entries per step: ballot +
+    // popcount) -- about 0.1 * n entries per line.  One wavefront per line.
+    const bool long_windows = ((int)(0.1 * (double)(window - 1)) + 1 >= 8);
+    if (long_windows) {
+        unsigned short *order = L.colmap;  // colmap and mline are contiguous and dead by now: 2 * maxn >= pow2(n)
+        int np2 = 1;
+        while (np2 < n) np2 <<= 1;
+        blk_argsort_u16(b, L.row0, n, order, np2);
+#if TSFA_GPU
+        const int lane = b.tid & 63, wave = b.tid >> 6, nwv = b.nt >> 6;
+#else
+        const int lane = 0, wave = 0, nwv = 1;
+#endif
+        for (int l = wave; l < nlines; l += nwv) {  // wave-uniform
+            const unsigned short v = L.linf[l];
+            if (TSFA_LI_LEN(v) < min_length) continue;
+            const int col = L.lcol[l], row = TSFA_LI_ROW(v);
+            double sig;
+            if (row == 0) {
+                sig = L.row0[col];
+            } else {
+                const int w = row + 1;
+                const int nw = (10 * w < n) ? 10 * w : n;
+                const int m2 = col + (nw - 1) / 2;
+                int k0 = m2 - (n - 1);
+                if (k0 < 0) k0 = 0;
+                const int k1 = (m2 < nw - 1) ? m2 : (nw - 1);
+                double acc = 0.0;
+                for (int k = k1; k >= k0; --k) acc += xv(m2 - k) * ricker_tap(nw, (double)w, nw - 1 - k);
+                sig = acc;
+            }
+            const int ws = (col - hf > 0) ? col - hf : 0;
+            const int we = (col + hf + odd < n) ? col + hf + odd : n;
+            const int m = we - ws;
+            const double idx = 10.0 / 100.0 * (double)(m - 1);
+            const int i0 = (int)idx;
+            double s0 = 0.0, s1 = 0.0;
+            int count = 0;
+            for (int base = 0; base < n && count <= i0 + 1; base += TSFA_ENT_WAVE_C) {
+#if TSFA_GPU
+                const int e = base + lane;
+                const int p = (e < n) ? (int)order[e] : 0xFFFF;
+                const bool in = (p >= ws && p < we);
+                const unsigned long long mk = __ballot(in);
+                const int before = count + __popcll(mk & ((1ull << lane) - 1ull));
+                const double val = in ? L.row0[p] : 0.0;
+                const unsigned long long h0 = __ballot(in && before == i0), h1 = __ballot(in && before == i0 + 1);
+                if (h0) s0 = readlane_f64(val, __ffsll((long long)h0) - 1);
+                if (h1) s1 = readlane_f64(val, __ffsll((long long)h1) - 1);
+                count += __popcll(mk);
+#else
+                const int p = order[base];
+                if (p >= ws && p < we) {
+                    if (count == i0) s0 = L.row0[p];
+                    if (count == i0 + 1) s1 = L.row0[p];
+                    ++count;
+                }
+#endif
+            }
+            double noise;
+            if ((double)i0 == idx) {
+                noise = s0;
+            } else {
+                const double j = (double)(i0 + 1);
+                const double w0 = j - idx, w1 = idx - (double)i0;
+                noise = (s0 * w0 + s1 * w1) / (w0 + w1);
+            }
+            const double snr = fabs(sig / noise);
+            if (!(snr < 1.0) && lane == 0) kept += 1.0;
+        }
+        kept = blk_sum(b, kept);
+        TSFA_TICK(tk, b, 153);
+        return overflow ? TSFA_NAN : kept;
+    }
     for (int l = b.tid; l < nlines; l += b.nt) {
         const unsigned short v = L.linf[l];
         if (TSFA_LI_LEN(v) < min_length) continue;

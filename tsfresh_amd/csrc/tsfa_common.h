@@ -525,6 +525,31 @@ TSFA_DEV void blk_bitonic_sort(const Blk &b, K *a, int npow2) {
     blk_sync();
 }
 
+// perm[0 .. np2) = indices 0 .. n-1 sorted ascending by key[index] (ties by index), padded with 0xFFFF (key +inf).
+// In-LDS bitonic network on the indices; np2 = power of two >= n.
+TSFA_DEV void blk_argsort_u16(const Blk &b, const double *key, int n, unsigned short *perm, int np2) {
+    blk_sync();
+    for (int i = b.tid; i < np2; i += b.nt) perm[i] = (unsigned short)((i < n) ? i : 0xFFFF);
+    for (int k = 2; k <= np2; k <<= 1) {
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            blk_sync();
+            for (int t = b.tid; t < (np2 >> 1); t += b.nt) {
+                const int i = ((t & ~(j - 1)) << 1) | (t & (j - 1));
+                const int l = i | j;
+                const bool up = ((i & k) == 0);
+                const unsigned short a = perm[i], c = perm[l];
+                const double ka = (a == 0xFFFF) ? TSFA_INF : key[a], kc = (c == 0xFFFF) ? TSFA_INF : key[c];
+                const bool gt = (ka > kc) || (ka == kc && a > c);
+                if (gt == up) {
+                    perm[i] = c;
+                    perm[l] = a;
+                }
+            }
+        }
+    }
+    blk_sync();
+}
+
 #if TSFA_GPU
 // ---------------------------------------------------------------------------------------------
 // Register-blocked bitonic sort of np2 = E * nt (key, index) pairs, ascending by key, ties by index.

@@ -161,8 +161,8 @@ struct CwtPeaksLayout {
         p.mask = c.take<unsigned short>(maxn);
         p.lcol = c.take<unsigned short>(maxn);
         p.linf = c.take<unsigned short>(maxn);
-        p.colmap = c.take<unsigned short>(maxn);
-        p.mline = c.take<unsigned short>(maxn);
+        p.colmap = c.take<unsigned short>(2 * (size_t)maxn);  // colmap | mline, contiguous: phase C argsorts into both
+        p.mline = p.colmap + maxn;
         p.misc = c.take<int>(8);
         return c.off;
     }
