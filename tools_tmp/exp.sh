@@ -5,7 +5,5 @@ run() { timeout 300 python bench.py --steps 3 --warmup 1 --no-cpu-baseline "$@" 
 {
 timeout 900 python -m pytest tests -m gpu -x -q 2>&1 | tail -3
 echo default; run
-echo efficient; run --params efficient --n-series 10000
 echo len256; run --length 256 --n-series 125000
-echo ragged; run --params efficient --n-series 5000 --ragged 4096:8192
-} > gpurun_out/exp/log13.txt 2>&1
+} > gpurun_out/exp/log20.txt 2>&1

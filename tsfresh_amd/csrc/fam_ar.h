@@ -420,6 +420,43 @@ TSFA_DEV void fam_ar_series(const Blk &b, X xv, int n, const TsfaSpec *specs, in
             const int agg = (int)sp.p[0];
             const int ml = (int)sp.p[1];
             double r = TSFA_NAN;
+#if TSFA_GPU
+            {
+                // lane = lag (at most 60 of them): one division per lane, mean / var by wave reductions, the median by
+                // ranking every lag against the others with readlane broadcasts -- registers only, every wavefront
+                // computes the same value.  (Serial on one lane this was ~100k cycles per series for the 3 columns.)
+                int len = (ml < n - 1) ? ml : (n - 1);
+                if (len > 60) len = 60;
+                const int lane = b.tid & 63;
+                const bool live = lane < len;
+                if (fabs(var) < 1e-10 || n == 1) {
+                    r = 0.0;
+                } else if (len > 0) {
+                    const double a0 = acv[0];
+                    const double ak = live ? acv[lane + 1] / a0 : 0.0;
+                    if (agg == TSFA_AGG_MEAN) {
+                        r = wave_sum(ak) / (double)len;
+                    } else if (agg == TSFA_AGG_VAR) {
+                        const double m = wave_sum(ak) / (double)len;
+                        const double d = live ? ak - m : 0.0;
+                        r = wave_sum(d * d) / (double)len;
+                    } else {
+                        int rank = 0;
+                        for (int j = 0; j < len; ++j) {
+                            const double aj = readlane_f64(ak, j);
+                            rank += (aj < ak || (aj == ak && j < lane)) ? 1 : 0;
+                        }
+                        const unsigned long long mlo = __ballot(live && rank == (len - 1) / 2);
+                        const unsigned long long mhi = __ballot(live && rank == len / 2);
+                        const double lo = readlane_f64(ak, __ffsll((long long)mlo) - 1);
+                        const double hi = readlane_f64(ak, __ffsll((long long)mhi) - 1);
+                        r = (len & 1) ? lo : (0.0 + lo + hi) / 2.0;
+                    }
+                }
+            }
+            v = r;
+            break;
+#endif
             if (b.tid == 0) {
                 if (fabs(var) < 1e-10 || n == 1) {
                     r = 0.0;  // f_agg over zeros

@@ -511,6 +511,11 @@ TSFA_DEV void fam_basic_series(const Blk &b, const double *xs, int n, const Tsfa
             v = blk_sum(b, c);
         } break;
         case TSFA_C_INDEX_MASS_QUANTILE: {                               // fc.py:1275
+            const bool imq_indexed = (alt.nq > 0 && p2 == 1.0);
+            if (imq_indexed && (int)p1 < 128) {  // evaluated by the plan's first index_mass_quantile column
+                v = altc[8 * ((int)p1 & 127) + 7];
+                break;
+            }
             if (!have_cumsum) {
                 // np.cumsum is a serial accumulation: one lane builds it once (in numpy's order, so that the >= q
                 // comparison is bit-identical), every q then scans it in parallel
@@ -534,6 +539,33 @@ TSFA_DEV void fam_basic_series(const Blk &b, const double *xs, int n, const Tsfa
                 }
                 blk_sync();
                 have_cumsum = true;
+            }
+            if (imq_indexed) {
+                // lane = q: cum / S is non-decreasing (a correctly rounded division is monotone), so the first index
+                // with cum[i] / S >= q is found by bisection with the reference's own expression -- ~10 dependent
+                // divisions for ALL q together instead of n / 64 divisions per lane for every q
+                blk_sync();
+                for (int k = b.tid; k < alt.nq; k += b.nt) {
+                    double q = 0.0;
+#pragma unroll
+                    for (int u = 0; u < TSFA_ALT_MAXKEYS; ++u)
+                        if (u == k) q = alt.q[u];
+                    double res = TSFA_NAN;
+                    if (imq_sabs != 0.0) {
+                        int lo = 0, hi = n;  // first i in [0, n) with the predicate true, n if none
+                        while (lo < hi) {
+                            const int mid = (lo + hi) >> 1;
+                            if (cum[mid] / imq_sabs >= q) hi = mid;
+                            else lo = mid + 1;
+                        }
+                        const int idx = (lo < n) ? lo : 0;  // np.argmax of an all-False mask is 0
+                        res = (double)(idx + 1) / dn;
+                    }
+                    altc[8 * k + 7] = res;
+                }
+                blk_sync();
+                v = altc[8 * ((int)p1 & 127) + 7];
+                break;
             }
             if (imq_sabs == 0.0) { v = TSFA_NAN; break; }
             double first = (double)n;

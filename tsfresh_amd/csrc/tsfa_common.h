@@ -578,6 +578,46 @@ TSFA_DEV void sort_stage_regs(double (&key)[E], int (&idx)[E], int g0, int k) {
     }
 }
 
+// value held by lane (lane ^ LX).  LX = 1, 2: DPP quad_perm (VALU rate, no LDS pipe); LX = 16, 32: the gfx950 row /
+// half swaps v_permlane16_swap / v_permlane32_swap; LX = 4, 8: ds_bpermute through __shfl_xor.
+template <int LX>
+TSFA_DEV int lane_xor_i32(int v) {
+    if (LX == 1) return __builtin_amdgcn_update_dpp(v, v, TSFA_DPP_QUAD_XOR1, 0xf, 0xf, false);
+    if (LX == 2) return __builtin_amdgcn_update_dpp(v, v, TSFA_DPP_QUAD_XOR2, 0xf, 0xf, false);
+    if (LX == 16) {
+        const auto r = __builtin_amdgcn_permlane16_swap(v, v, false, false);
+        return ((threadIdx.x >> 4) & 1) ? (int)r[0] : (int)r[1];  // odd rows got their partner in vdst, even rows in vsrc
+    }
+    if (LX == 32) {
+        const auto r = __builtin_amdgcn_permlane32_swap(v, v, false, false);
+        return ((threadIdx.x >> 5) & 1) ? (int)r[0] : (int)r[1];
+    }
+    return __shfl_xor(v, LX);
+}
+template <int LX>
+TSFA_DEV double lane_xor_f64(double v) {
+    union { double d; int i[2]; } a, r;
+    a.d = v;
+    r.i[0] = lane_xor_i32<LX>(a.i[0]);
+    r.i[1] = lane_xor_i32<LX>(a.i[1]);
+    return r.d;
+}
+
+template <int E, int LX>
+TSFA_DEV void sort_stage_lanes(double (&key)[E], int (&idx)[E], int g0, int k, int j) {
+    const bool lower = ((g0 & j) == 0);  // this thread holds the lower index of each pair
+#pragma unroll
+    for (int e = 0; e < E; ++e) {
+        const double pk = lane_xor_f64<LX>(key[e]);
+        const int pi = lane_xor_i32<LX>(idx[e]);
+        const bool up = (((g0 + e) & k) == 0);
+        const bool gt = sort_pair_gt(key[e], idx[e], pk, pi);
+        // keep the minimum when (lower == up), the maximum otherwise
+        const bool take = (lower == up) ? gt : !gt;
+        if (take) { key[e] = pk; idx[e] = pi; }
+    }
+}
+
 template <int E, class KF>
 TSFA_DEV void blk_sort_pairs_regs(const Blk &b, double (&key)[E], int (&idx)[E], unsigned short *xchg_idx, KF keyof) {
     const int np2 = E * b.nt;
@@ -592,17 +632,13 @@ TSFA_DEV void blk_sort_pairs_regs(const Blk &b, double (&key)[E], int (&idx)[E],
                 default: break;
                 }
             } else if (j < 64 * E) {
-                const int lane_xor = j / E;
-                const bool lower = ((g0 & j) == 0);  // this thread holds the lower index of each pair
-#pragma unroll
-                for (int e = 0; e < E; ++e) {
-                    const double pk = __shfl_xor(key[e], lane_xor);
-                    const int pi = __shfl_xor(idx[e], lane_xor);
-                    const bool up = (((g0 + e) & k) == 0);
-                    const bool gt = sort_pair_gt(key[e], idx[e], pk, pi);
-                    // keep the minimum when (lower == up), the maximum otherwise
-                    const bool take = (lower == up) ? gt : !gt;
-                    if (take) { key[e] = pk; idx[e] = pi; }
+                switch (j / E) {
+                case 1: sort_stage_lanes<E, 1>(key, idx, g0, k, j); break;
+                case 2: sort_stage_lanes<E, 2>(key, idx, g0, k, j); break;
+                case 4: sort_stage_lanes<E, 4>(key, idx, g0, k, j); break;
+                case 8: sort_stage_lanes<E, 8>(key, idx, g0, k, j); break;
+                case 16: sort_stage_lanes<E, 16>(key, idx, g0, k, j); break;
+                default: sort_stage_lanes<E, 32>(key, idx, g0, k, j); break;
                 }
             } else {
                 blk_sync();

@@ -131,6 +131,24 @@ static inline void tsfa_prepare_family(int fam, std::vector<TsfaSpec> &specs, Ts
         // a: largest number_peaks support <= 254;  b: 1 if any agg_linear_trend column asks for the p-value
         // agg_linear_trend: p[3] = cache slot of the column's (f_agg, chunk_len) regression, + 64 if this column is
         // the one that has to compute it (the slots are simulated here, round-robin over TSFA_ALT_SLOTS)
+        // index_mass_quantile: all distinct q at once (lane = q)
+        {
+            std::vector<double> qs;
+            for (const auto &s : specs)
+                if (s.calc == TSFA_C_INDEX_MASS_QUANTILE && std::find(qs.begin(), qs.end(), s.p[0]) == qs.end()) qs.push_back(s.p[0]);
+            if (!qs.empty() && qs.size() <= TSFA_ALT_MAXKEYS) {
+                h.alt.nq = (int)qs.size();
+                for (size_t k = 0; k < qs.size(); ++k) h.alt.q[k] = qs[k];
+                bool first = true;
+                for (auto &s : specs) {
+                    if (s.calc != TSFA_C_INDEX_MASS_QUANTILE) continue;
+                    const int idx = (int)(std::find(qs.begin(), qs.end(), s.p[0]) - qs.begin());
+                    s.p[1] = (double)(idx + (first ? 128 : 0));
+                    s.p[2] = 1.0;
+                    first = false;
+                }
+            }
+        }
         // preferred: all distinct (chunk_len, f_agg) keys at once (TsfaAltPlan); p[3] = key index, + 128 on the first
         // agg_linear_trend column, which computes them all
         {

@@ -146,6 +146,11 @@ struct TsfaAltPlan {
     int want_p;  // some column asks for the p-value
     int cl[TSFA_ALT_MAXKEYS];
     int agg[TSFA_ALT_MAXKEYS];
+    // index_mass_quantile (fc.py:1275): the distinct q of the plan; an indexed column has p[2] == 1 and its q's index
+    // in p[1] (+ 128 on the column that evaluates them all).  nq == 0: more than TSFA_ALT_MAXKEYS -> per column.
+    int nq;
+    int pad;
+    double q[TSFA_ALT_MAXKEYS];
 };
 
 // change_quantiles (fc.py:1511): the distinct valid corridors (ql < qh) of a plan.  All of them are evaluated by the
