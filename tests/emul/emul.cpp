@@ -153,7 +153,7 @@ extern "C" int tsfa_emul_extract_timed(const tsfa_feature_spec *specs, int n_spe
             basep += (16 - ((uintptr_t)basep & 15)) & 15;
             L.carve(basep, maxn, with_rowv);
             const double *xp = xs.data();
-            fam_cwtpeaks_series(b, [=](int i) { return xp[i]; }, n, fam[TSFA_FAM_CWT].data(), (int)fam[TSFA_FAM_CWT].size(),
+            fam_cwtpeaks_series<double>(b, [=](int i) { return xp[i]; }, n, fam[TSFA_FAM_CWT].data(), (int)fam[TSFA_FAM_CWT].size(),
                                 row, L.p);
         }
         for (int c = 0; c < bank.C; ++c) {  // plain-loop stand-in for k_cwt_gemm

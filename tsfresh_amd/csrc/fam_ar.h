@@ -50,6 +50,32 @@ TSFA_DEV void chol_solve(const double *L, int p, int ld, const double *rhs, doub
     }
 }
 
+// x = (L L^T)^-1 rhs for p <= 64, called by every thread.  GPU: lane i of every wavefront holds entry i; the two
+// triangular solves are column-oriented (x_k is broadcast with readlane, every lane below / above subtracts its
+// L entry times x_k), so a solve costs 2p dependent steps instead of p^2 dependent LDS reads on one thread; all
+// wavefronts compute the same result, thread 0 stores it.  The caller provides the barriers around it.
+TSFA_DEV void blk_chol_solve(const Blk &b, const double *L, int p, int ld, const double *rhs, double *x) {
+#if TSFA_GPU
+    const int lane = b.tid & 63;
+    const bool live = lane < p;
+    double s = live ? rhs[lane] : 0.0;
+    const double dg = live ? L[lane + lane * ld] : 1.0;
+    for (int k = 0; k < p; ++k) {  // forward: L w = rhs
+        const double wk = readlane_f64(s, k) / readlane_f64(dg, k);
+        if (lane == k) s = wk;
+        else if (live && lane > k) s -= L[lane + k * ld] * wk;
+    }
+    for (int k = p - 1; k >= 0; --k) {  // backward: L^T x = w
+        const double xk = readlane_f64(s, k) / readlane_f64(dg, k);
+        if (lane == k) s = xk;
+        else if (live && lane < k) s -= L[k + lane * ld] * xk;
+    }
+    if (b.tid < p) x[b.tid] = s;
+#else
+    if (b.tid == 0) chol_solve(L, p, ld, rhs, x);
+#endif
+}
+
 // Workgroup-cooperative Cholesky (right-looking): after step j, column j holds L(:, j) and the trailing block has had
 // L(:, j) L(:, j)^T subtracted.  Every entry receives exactly the subtractions of the serial left-looking loop, in the
 // same order (k ascending), so the factor is bit-identical to chol_factor's; only the p-1 dependent steps remain
@@ -360,7 +386,7 @@ TSFA_DEV void fam_ar_series(const Blk &b, X xv, int n, const TsfaSpec *specs, in
                 }
                 blk_sync();
                 const bool ok2 = blk_chol_factor(b, G, p2, P);
-                if (b.tid == 0 && ok2) chol_solve(G, p2, P, g, beta);
+                if (ok2) blk_chol_solve(b, G, p2, P, g, beta);
                 blk_sync();
                 if (ok2) {
                     // one step of iterative refinement on the true residuals, then SSR
@@ -370,17 +396,27 @@ TSFA_DEV void fam_ar_series(const Blk &b, X xv, int n, const TsfaSpec *specs, in
                         rbuf[t] = r;
                     }
                     blk_sync();
-                    for (int a = 0; a < p2; ++a) {
-                        double s = 0.0;
-                        for (int t = u0 + b.tid; t < t1; t += b.nt) s += reg2(a, t) * rbuf[t];
-                        s = blk_sum(b, s);
-                        if (b.tid == 0) tmp1[a] = s;
+                    for (int a0 = 0; a0 < p2; a0 += 8) {  // X^T r, eight regressors per sweep
+                        double s8[8];
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) s8[j] = 0.0;
+                        for (int t = u0 + b.tid; t < t1; t += b.nt) {
+                            const double rt = rbuf[t];
+#pragma unroll
+                            for (int j = 0; j < 8; ++j)
+                                if (a0 + j < p2) s8[j] += reg2(a0 + j, t) * rt;
+                        }
+                        blk_sum_multi<8>(b, s8);
+                        if (b.tid == 0) {
+#pragma unroll
+                            for (int j = 0; j < 8; ++j)
+                                if (a0 + j < p2) tmp1[a0 + j] = s8[j];
+                        }
                     }
                     blk_sync();
-                    if (b.tid == 0) {
-                        chol_solve(G, p2, P, tmp1, tmp2);
-                        for (int a = 0; a < p2; ++a) beta[a] += tmp2[a];
-                    }
+                    blk_chol_solve(b, G, p2, P, tmp1, tmp2);
+                    blk_sync();
+                    for (int a = b.tid; a < p2; a += b.nt) beta[a] += tmp2[a];
                     blk_sync();
                     double ssr = 0.0;
                     for (int t = u0 + b.tid; t < t1; t += b.nt) {
@@ -389,9 +425,11 @@ TSFA_DEV void fam_ar_series(const Blk &b, X xv, int n, const TsfaSpec *specs, in
                         ssr += r * r;
                     }
                     ssr = blk_sum(b, ssr);
+                    for (int i = b.tid; i < p2; i += b.nt) tmp1[i] = (i == 0) ? 1.0 : 0.0;  // (X'X)^-1 [level, level]
+                    blk_sync();
+                    blk_chol_solve(b, G, p2, P, tmp1, tmp2);
+                    blk_sync();
                     if (b.tid == 0) {
-                        for (int i = 0; i < p2; ++i) tmp1[i] = (i == 0) ? 1.0 : 0.0;  // (X'X)^-1 [level, level]
-                        chol_solve(G, p2, P, tmp1, tmp2);
                         const double sigma2 = ssr / (nobs2 - (double)p2);
                         const double tstat = beta[0] / sqrt(sigma2 * tmp2[0]);
                         res[2] = tstat;
@@ -515,7 +553,7 @@ TSFA_DEV void fam_ar_series(const Blk &b, X xv, int n, const TsfaSpec *specs, in
                 for (int a = b.tid; a < p; a += b.nt) g[a] = (a == 0) ? C[0] : T[a];
                 blk_sync();
                 ar_ok = blk_chol_factor(b, G, p, P);
-                if (b.tid == 0 && ar_ok) chol_solve(G, p, P, g, beta);
+                if (ar_ok) blk_chol_solve(b, G, p, P, g, beta);
                 blk_sync();
                 if (ar_ok) {
                     auto reg = [=](int a, int t) { return a == 0 ? 1.0 : xcc[t - a]; };
@@ -525,15 +563,27 @@ TSFA_DEV void fam_ar_series(const Blk &b, X xv, int n, const TsfaSpec *specs, in
                         rbuf[t] = r;
                     }
                     blk_sync();
-                    for (int a = 0; a < p; ++a) {
-                        double sacc = 0.0;
-                        for (int t = k + b.tid; t < n; t += b.nt) sacc += reg(a, t) * rbuf[t];
-                        sacc = blk_sum(b, sacc);
-                        if (b.tid == 0) tmp1[a] = sacc;
+                    for (int a0 = 0; a0 < p; a0 += 8) {  // X^T r, eight regressors per sweep
+                        double s8[8];
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) s8[j] = 0.0;
+                        for (int t = k + b.tid; t < n; t += b.nt) {
+                            const double rt = rbuf[t];
+#pragma unroll
+                            for (int j = 0; j < 8; ++j)
+                                if (a0 + j < p) s8[j] += reg(a0 + j, t) * rt;
+                        }
+                        blk_sum_multi<8>(b, s8);
+                        if (b.tid == 0) {
+#pragma unroll
+                            for (int j = 0; j < 8; ++j)
+                                if (a0 + j < p) tmp1[a0 + j] = s8[j];
+                        }
                     }
                     blk_sync();
+                    blk_chol_solve(b, G, p, P, tmp1, tmp2);
+                    blk_sync();
                     if (b.tid == 0) {
-                        chol_solve(G, p, P, tmp1, tmp2);
                         double sphi = 0.0;
                         for (int a = 0; a < p; ++a) {
                             beta[a] += tmp2[a];

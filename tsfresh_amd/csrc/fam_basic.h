@@ -38,7 +38,8 @@ struct BasicStats {
     int first_max, last_max, first_min, last_min, cnt_max, cnt_min;
 };
 
-TSFA_DEV void basic_stats(const Blk &b, const double *xs, int n, BasicStats &st) {
+template <class XS>
+TSFA_DEV void basic_stats(const Blk &b, XS xs, int n, BasicStats &st) {
     st.n = n;
     st.sum = np_sum(b, n, [=](int i) { return xs[i]; });          // np.sum
     st.mean = st.sum / (double)n;                                   // np.mean = add.reduce / n
@@ -132,7 +133,8 @@ TSFA_DEV double blk_longest_run(const Blk &b, int n, P pred, int *iw) {
 //   * the scalar tail of linregress (a dozen dependent float64 divisions / square roots, ~4k cycles) runs ONCE with
 //     lane = regression instead of once per regression on every lane.
 // raw: LDS, 6 doubles per key (m, mean, sxy, syy, y0, y1); w: LDS, >= n doubles; altc[8 * key + 2 + attr] = results.
-TSFA_DEV void alt_fill_all(const Blk &b, const double *xs, int n, const TsfaAltPlan &alt, double *w, double *raw,
+template <class XS>
+TSFA_DEV void alt_fill_all(const Blk &b, XS xs, int n, const TsfaAltPlan &alt, double *w, double *raw,
                            double *altc) {
     const int nkeys = alt.nkeys;
     int k0 = 0;
@@ -275,7 +277,8 @@ TSFA_DEV void alt_fill_all(const Blk &b, const double *xs, int n, const TsfaAltP
 #define TSFA_PEAK_NEAR 10
 #define TSFA_DEV_UNUSED
 //   times: HBM, the series' timestamps as float64 hours since its first sample (linear_trend_timewise), or null
-TSFA_DEV void fam_basic_series(const Blk &b, const double *xs, int n, const TsfaSpec *specs, int nspecs,
+template <class XS>
+TSFA_DEV void fam_basic_series(const Blk &b, XS xs, int n, const TsfaSpec *specs, int nspecs,
                                double *out_row, double *w, double *cum, double *altc, int *iw, const double *dectab,
                                int peaks_maxsup, int alt_want_p, const TsfaAltPlan &alt, TsfaSpec *stage,
                                const double *times = nullptr) {

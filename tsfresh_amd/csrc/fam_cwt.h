@@ -48,7 +48,7 @@ TSFA_DEV double conv_same_at(X xv, int n, const double *h, int nw, int c) {
 #define TSFA_CWTP_HALO ((TSFA_CWTP_MAXTAPS + 1) / 2 + 2)   // zero padding of the staged series on either side
 
 struct CwtPeaksLds {
-    double *red; double *row0; double *rowv; double *taps; double *xpad; unsigned short *mask; unsigned short *lcol;
+    double *red; double *row0; double *rowv; double *taps; void *xpad; unsigned short *mask; unsigned short *lcol;
     unsigned short *linf; unsigned short *colmap; unsigned short *mline; int *misc;
 };
 
@@ -123,7 +123,8 @@ TSFA_DEV void cwt_rows_tiled(const Blk &b, XA xat, int n, int W, const CwtPeaksL
     }
 }
 
-template <class X>
+// ST: element type of the padded LDS copy of the series (the input precision: float32 samples stay float32)
+template <class ST, class X>
 TSFA_DEV double number_cwt_peaks_one(const Blk &b, X xv, int n, int W, const CwtPeaksLds &L) {
     const int cap = n;  // line capacity
     TSFA_TICKER(tk, 0);
@@ -133,12 +134,13 @@ TSFA_DEV double number_cwt_peaks_one(const Blk &b, X xv, int n, int W, const Cwt
     // ---- phase A: the series goes to LDS between two zero halos (xpad[TSFA_CWTP_HALO + i] = x[i]) when it fits ----
     if (L.xpad != nullptr) {
         blk_sync();
+        ST *xpad = (ST *)L.xpad;
         for (int i = b.tid; i < n + 2 * TSFA_CWTP_HALO + 8; i += b.nt) {
             const int j = i - TSFA_CWTP_HALO;
-            L.xpad[i] = (j >= 0 && j < n) ? xv(j) : 0.0;
+            xpad[i] = (j >= 0 && j < n) ? (ST)xv(j) : (ST)0;
         }
-        const double *xp0 = L.xpad + TSFA_CWTP_HALO;
-        cwt_rows_tiled(b, [=](int i) { return xp0[i]; }, n, W, L);
+        const ST *xp0 = xpad + TSFA_CWTP_HALO;
+        cwt_rows_tiled(b, [=](int i) { return (double)xp0[i]; }, n, W, L);
     } else {  // no room for the padded copy (very long series): the same tiles, samples straight from HBM / L2
         cwt_rows_tiled(b, [=](int i) { return (i >= 0 && i < n) ? xv(i) : 0.0; }, n, W, L);
     }
@@ -369,13 +371,13 @@ TSFA_DEV double number_cwt_peaks_one(const Blk &b, X xv, int n, int W, const Cwt
     return overflow ? TSFA_NAN : kept;
 }
 
-template <class X>
+template <class ST, class X>
 TSFA_DEV void fam_cwtpeaks_series(const Blk &b, X xv, int n, const TsfaSpec *specs, int nspecs, double *out_row,
                                   const CwtPeaksLds &L) {
     for (int s = 0; s < nspecs; ++s) {
         const TsfaSpec sp = specs[s];
         if (sp.calc != TSFA_C_NUMBER_CWT_PEAKS) continue;
-        const double v = number_cwt_peaks_one(b, xv, n, (int)sp.p[0], L);
+        const double v = number_cwt_peaks_one<ST>(b, xv, n, (int)sp.p[0], L);
         if (b.tid == 0) out_row[sp.col] = v;
     }
 }

@@ -48,6 +48,15 @@ struct NpScratch {  // scratch for the numpy-order pairwise sum
     double result;
 };
 
+// The series as the kernels see it: LDS-resident in its INPUT precision (float32 samples take half the LDS of their
+// float64 image, and LDS capacity is what limits the resident series per CU), read as float64 -- the conversion is
+// exact, so every expression downstream is the float64 arithmetic of the reference on x.astype(float64).
+template <typename ST>
+struct XsView {
+    const ST *p;
+    TSFA_MEM double operator[](int i) const { return (double)p[i]; }
+};
+
 struct Blk {
     int tid;        // thread index in the workgroup
     int nt;         // workgroup size

@@ -30,12 +30,17 @@ __global__ void __launch_bounds__(256, 2) k_basic(const T *__restrict__ values, 
     const int64_t off = starts[sidx];
     const int n = (int)(ends[sidx] - off);
     BasicLds L;
-    L.carve(tsfa_smem, maxn, blockDim.x);
+    L.carve(tsfa_smem, maxn, blockDim.x, (int)sizeof(T));
     TSFA_TICKS_BEGIN();
     Blk b{(int)threadIdx.x, (int)blockDim.x, L.red, L.np};
-    stage_series(b, values + off, n, L.xs);
-    fam_basic_series(b, L.xs, n, specs, nspecs, out + sidx * ld, L.w, L.cum, L.altc, L.iw, dectab, hint_a, hint_b,
-                     alt, L.stage, times ? times + off : nullptr);
+    T *xs = (T *)L.xs;  // resident in the input precision (half the LDS for float32), read as float64
+    {
+        const T *__restrict__ g = values + off;
+        for (int i = b.tid; i < n; i += b.nt) xs[i] = g[i];
+        blk_sync();
+    }
+    fam_basic_series(b, XsView<T>{xs}, n, specs, nspecs, out + sidx * ld, L.w, L.cum, L.altc, L.iw, dectab, hint_a,
+                     hint_b, alt, L.stage, times ? times + off : nullptr);
     TSFA_TICKS_END();
 }
 
@@ -141,11 +146,11 @@ __global__ void __launch_bounds__(256) k_cwtpeaks(const T *__restrict__ values, 
     const int64_t off = starts[sidx];
     const int n = (int)(ends[sidx] - off);
     CwtPeaksLayout L;
-    L.carve(tsfa_smem, maxn, with_rowv);
+    L.carve(tsfa_smem, maxn, with_rowv, (int)sizeof(T));
     TSFA_TICKS_BEGIN();
     Blk b{(int)threadIdx.x, (int)blockDim.x, L.p.red, nullptr};
     const T *g = values + off;
-    fam_cwtpeaks_series(b, [=](int i) { return (double)g[i]; }, n, specs, nspecs, out + sidx * ld, L.p);
+    fam_cwtpeaks_series<T>(b, [=](int i) { return (double)g[i]; }, n, specs, nspecs, out + sidx * ld, L.p);
     TSFA_TICKS_END();
 }
 
@@ -271,7 +276,7 @@ static int launch_all_t(const TsfaLaunch &a, const T *values) {
     int rc;
     if (a.fam == TSFA_FAM_BASIC) {
         BasicLds L;
-        const size_t lds = L.carve(nullptr, a.maxn, nt);
+        const size_t lds = L.carve(nullptr, a.maxn, nt, (int)sizeof(T));
         if ((rc = set_lds(k_basic<T>, lds))) return rc;
         k_basic<T><<<grid, nt, lds, st>>>(values, a.starts, a.ends, a.n_series, a.specs, a.nspecs, a.out, a.ld, a.dectab, a.maxn,
                                           a.hint_a, a.hint_b, a.times, a.alt);
@@ -311,7 +316,7 @@ if (a.ent_fast) {
         k_seq<T><<<grid, nt, lds, st>>>(values, a.starts, a.ends, a.n_series, a.out, a.ld, a.seq);
     } else if (a.fam == TSFA_FAM_CWT) {  // number_cwt_peaks
         CwtPeaksLayout L;
-        const size_t lds = L.carve(nullptr, a.maxn, a.cwt_rowv);
+        const size_t lds = L.carve(nullptr, a.maxn, a.cwt_rowv, (int)sizeof(T));
         if ((rc = set_lds(k_cwtpeaks<T>, lds))) return rc;
         k_cwtpeaks<T><<<grid, nt, lds, st>>>(values, a.starts, a.ends, a.n_series, a.specs, a.nspecs, a.out, a.ld, a.maxn,
                                              a.cwt_rowv);

@@ -37,17 +37,22 @@ TSFA_HD int tsfa_pow2_ceil(int n) {
 }
 
 struct BasicLds {
-    double *red; NpScratch *np; double *xs; double *w; double *cum; double *altc; int *iw; TsfaSpec *stage;
-    TSFA_HD size_t carve(unsigned char *base, int maxn, int nt) {
+    double *red; NpScratch *np; void *xs; double *w; double *cum; double *altc; int *iw; TsfaSpec *stage;
+    // xs_bytes: element size of the LDS-resident series (4: float32 input kept as float32, 8: float64)
+    TSFA_HD size_t carve(unsigned char *base, int maxn, int nt, int xs_bytes = 8) {
         LdsCarve c{base, 0};
         red = c.take<double>(TSFA_RED_DOUBLES);
         np = c.take<NpScratch>(1);
-        xs = c.take<double>(maxn);
+        xs = c.take<unsigned char>((size_t)maxn * xs_bytes);
         w = c.take<double>(maxn);  // chunk aggregates (agg_linear_trend) ...
         cum = w;                   // ... aliased with the cumulative |x| of index_mass_quantile (the cache is invalidated)
         altc = c.take<double>(8 * 16);
         iw = c.take<int>((4 * nt > 256) ? 4 * nt : 256);
+#if defined(TSFA_SPEC_LDS)
         stage = c.take<TsfaSpec>(TSFA_SPEC_BATCH);
+#else
+        stage = nullptr;
+#endif
         return c.off;
     }
 };
@@ -151,12 +156,13 @@ struct CwtPeaksLayout {
     CwtPeaksLds p;
     // mode 1: the series is staged between zero halos (register-tiled convolutions, no second row needed);
     // mode 0: no staging (very long series): the CWT rows are evaluated column by column from HBM
-    TSFA_HD size_t carve(unsigned char *base, int maxn, int mode) {
+    // xs_bytes: element size of the padded copy (4: float32 input kept as float32, 8: float64)
+    TSFA_HD size_t carve(unsigned char *base, int maxn, int mode, int xs_bytes = 8) {
         LdsCarve c{base, 0};
         p.red = c.take<double>(TSFA_RED_DOUBLES);
         p.row0 = c.take<double>(maxn + 4);
         p.rowv = nullptr;
-        p.xpad = mode ? c.take<double>(maxn + 2 * TSFA_CWTP_HALO + 8) : nullptr;
+        p.xpad = mode ? (void *)c.take<unsigned char>((size_t)(maxn + 2 * TSFA_CWTP_HALO + 8) * xs_bytes) : nullptr;
         p.taps = c.take<double>(TSFA_CWTP_MAXTAPS + 16);
         p.mask = c.take<unsigned short>(maxn);
         p.lcol = c.take<unsigned short>(maxn);
