@@ -191,11 +191,11 @@ TSFA_DEV double max_real_root_deg3(const double *cin, int ncoef) {
 
 // Lehmer code of the (stable) ordinal pattern of a[0..D-1]: c_j = #{l > j : a[l] < a[j]}, mixed radix D!/(D-j)!...
 // The window is read into registers once for the usual embedding dimensions.
-template <int DD>
-TSFA_DEV int perm_code_fixed(const double *a, int fact) {
+template <int DD, class AT>
+TSFA_DEV int perm_code_fixed(const AT *a, int fact) {
     double r[DD];
 #pragma unroll
-    for (int j = 0; j < DD; ++j) r[j] = a[j];
+    for (int j = 0; j < DD; ++j) r[j] = (double)a[j];
     int code = 0, f = fact;
 #pragma unroll
     for (int j = 0; j < DD - 1; ++j) {
@@ -207,7 +207,8 @@ TSFA_DEV int perm_code_fixed(const double *a, int fact) {
     }
     return code;
 }
-TSFA_DEV int perm_code(const double *a, int D, int fact) {
+template <class AT>
+TSFA_DEV int perm_code(const AT *a, int D, int fact) {
     switch (D) {
     case 2: return perm_code_fixed<2>(a, fact);
     case 3: return perm_code_fixed<3>(a, fact);
@@ -220,7 +221,7 @@ TSFA_DEV int perm_code(const double *a, int D, int fact) {
     int code = 0, f = fact;
     for (int j = 0; j < D - 1; ++j) {
         int c = 0;
-        for (int l = j + 1; l < D; ++l) c += (a[l] < a[j]) ? 1 : 0;
+        for (int l = j + 1; l < D; ++l) c += ((double)a[l] < (double)a[j]) ? 1 : 0;
         f /= (D - j);
         code += c * f;
     }
@@ -234,8 +235,8 @@ TSFA_DEV int perm_code(const double *a, int D, int fact) {
 //   srt1  : functor, the first n-1 samples sorted ascending (signal = x[:-1])
 //   fw    : LDS double scratch >= 6*r + 16 + (r)*(m+1)
 // every thread returns the coefficients in `coef`
-template <class S1>
-TSFA_DEV void friedrich_coeffs(const Blk &b, const double *xs, int n, S1 srt1, int m, int r,
+template <class XS, class S1>
+TSFA_DEV void friedrich_coeffs(const Blk &b, XS xs, int n, S1 srt1, int m, int r,
                                double *fw, double *coef) {
     for (int k = 0; k <= m; ++k) coef[k] = TSFA_NAN;
     const int ns = n - 1;
@@ -408,7 +409,8 @@ TSFA_DEV void friedrich_coeffs(const Blk &b, const double *xs, int n, S1 srt1, i
 // change_quantiles (fc.py:1511), every corridor of the plan, four per sweep: the samples are read once per sweep and
 // the 12 + 8 partial sums of a sweep are reduced together (blk_sum_multi).  cq[5 * k ..] = count, mean, mean |.|,
 // var, var |.| of corridor k.
-TSFA_DEV void cq_fill_all(const Blk &b, const double *xs, const double *srt, int n, const TsfaCqPlan &plan, double *cq) {
+template <class XS, class SS>
+TSFA_DEV void cq_fill_all(const Blk &b, XS xs, SS srt, int n, const TsfaCqPlan &plan, double *cq) {
     for (int k0 = 0; k0 < plan.n; k0 += 4) {
         const int ng = (plan.n - k0 < 4) ? (plan.n - k0) : 4;
         double lo[4], hi[4];
@@ -476,14 +478,18 @@ TSFA_DEV void cq_fill_all(const Blk &b, const double *xs, const double *srt, int
     blk_sync();
 }
 
-TSFA_DEV void fam_sort_series(const Blk &b, const double *xs, int n, const TsfaSpec *specs, int nspecs,
-                              double *out_row, double *srt, double *w, int *iw, const TsfaCqPlan &cqplan, double *cq,
+// ST: element type of the LDS-resident series and of its sorted copy (the input precision; read as float64)
+template <class ST>
+TSFA_DEV void fam_sort_series(const Blk &b, const ST *xs_raw, int n, const TsfaSpec *specs, int nspecs,
+                              double *out_row, ST *srt_raw, double *w, int *iw, const TsfaCqPlan &cqplan, double *cq,
                               TsfaSpec *stage) {
+    const XsView<ST> xs{xs_raw};
+    const XsView<ST> srt{srt_raw};
     const int np2 = next_pow2(n);
     TSFA_TICKER(tk, 0);
     blk_sync();
-    for (int i = b.tid; i < np2; i += b.nt) srt[i] = (i < n) ? xs[i] : TSFA_INF;
-    blk_bitonic_sort(b, srt, np2);
+    for (int i = b.tid; i < np2; i += b.nt) srt_raw[i] = (i < n) ? xs_raw[i] : (ST)TSFA_INF;
+    blk_bitonic_sort(b, srt_raw, np2);
     TSFA_TICK(tk, b, 104);
     const double dn = (double)n;
     const double vmin = srt[0], vmax = srt[n - 1];
@@ -634,7 +640,7 @@ TSFA_DEV void fam_sort_series(const Blk &b, const double *xs, int n, const TsfaS
             for (int k = b.tid; k < nwords; k += b.nt) iw[k] = 0;
             blk_sync();
             for (int t = b.tid; t < num; t += b.nt) {
-                const int code = perm_code(xs + t * tau, D, fact);
+                const int code = perm_code(xs_raw + t * tau, D, fact);
                 const int inc = (code & 1) ? 0x10000 : 1;
 #if TSFA_GPU
                 atomicAdd(&iw[code >> 1], inc);
@@ -656,7 +662,7 @@ TSFA_DEV void fam_sort_series(const Blk &b, const double *xs, int n, const TsfaS
             } else {  // more patterns than windows: sum_k c_k log(c_k / num) = sum over windows of log(c(window) / num)
                 double acc = 0.0;
                 for (int t = b.tid; t < num; t += b.nt) {
-                    const int code = perm_code(xs + t * tau, D, fact);
+                    const int code = perm_code(xs_raw + t * tau, D, fact);
                     const unsigned wv = (unsigned)iw[code >> 1];
                     const int c = (code & 1) ? (int)(wv >> 16) : (int)(wv & 0xffffu);
                     acc += log((double)c / (double)num);
@@ -682,7 +688,7 @@ TSFA_DEV void fam_sort_series(const Blk &b, const double *xs, int n, const TsfaS
                     }
                     pos = lo;
                 }
-                const double *sr = srt;
+                const XsView<ST> sr = srt;
                 friedrich_coeffs(b, xs, n, [=](int i) { return sr[i < pos ? i : i + 1]; }, m, r, w, fr_coef);
                 fr_valid = true;
                 fr_m = m;

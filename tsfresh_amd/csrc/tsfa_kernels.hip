@@ -53,11 +53,16 @@ __global__ void __launch_bounds__(256) k_sort(const T *__restrict__ values, cons
     const int64_t off = starts[sidx];
     const int n = (int)(ends[sidx] - off);
     SortLds L;
-    L.carve(tsfa_smem, maxn, blockDim.x);
+    L.carve(tsfa_smem, maxn, blockDim.x, (int)sizeof(T));
     TSFA_TICKS_BEGIN();
     Blk b{(int)threadIdx.x, (int)blockDim.x, L.red, L.np};
-    stage_series(b, values + off, n, L.xs);
-    fam_sort_series(b, L.xs, n, specs, nspecs, out + sidx * ld, L.srt, L.w, L.iw, cqplan, L.cq, L.stage);
+    T *xs = (T *)L.xs;  // resident in the input precision, like its sorted copy
+    {
+        const T *__restrict__ g = values + off;
+        for (int i = b.tid; i < n; i += b.nt) xs[i] = g[i];
+        blk_sync();
+    }
+    fam_sort_series<T>(b, xs, n, specs, nspecs, out + sidx * ld, (T *)L.srt, L.w, L.iw, cqplan, L.cq, L.stage);
     TSFA_TICKS_END();
 }
 
@@ -282,7 +287,7 @@ static int launch_all_t(const TsfaLaunch &a, const T *values) {
                                           a.hint_a, a.hint_b, a.times, a.alt);
     } else if (a.fam == TSFA_FAM_SORT) {
         SortLds L;
-        const size_t lds = L.carve(nullptr, a.maxn, nt);
+        const size_t lds = L.carve(nullptr, a.maxn, nt, (int)sizeof(T));
         if ((rc = set_lds(k_sort<T>, lds))) return rc;
         k_sort<T><<<grid, nt, lds, st>>>(values, a.starts, a.ends, a.n_series, a.specs, a.nspecs, a.out, a.ld, a.maxn, a.cq);
     } else if (a.fam == TSFA_FAM_SPECTRAL) {

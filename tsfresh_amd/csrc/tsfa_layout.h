@@ -58,18 +58,23 @@ struct BasicLds {
 };
 
 struct SortLds {
-    double *red; NpScratch *np; double *xs; double *srt; double *w; int *iw; double *cq; TsfaSpec *stage;
-    TSFA_HD size_t carve(unsigned char *base, int maxn, int nt) {
+    double *red; NpScratch *np; void *xs; void *srt; double *w; int *iw; double *cq; TsfaSpec *stage;
+    // xs_bytes: element size of the resident series and its sorted copy (4: float32 input kept as float32, 8: float64)
+    TSFA_HD size_t carve(unsigned char *base, int maxn, int nt, int xs_bytes = 8) {
         (void)nt;
         LdsCarve c{base, 0};
         red = c.take<double>(TSFA_RED_DOUBLES);
         np = c.take<NpScratch>(1);
-        xs = c.take<double>(maxn);
-        srt = c.take<double>(tsfa_pow2_ceil(maxn));
+        xs = c.take<unsigned char>((size_t)maxn * xs_bytes);
+        srt = c.take<unsigned char>((size_t)tsfa_pow2_ceil(maxn) * xs_bytes);
         w = c.take<double>(1280);   // Langevin-fit scratch (<= 768 doubles) ...
         iw = (int *)w;              // ... aliased with the ordinal-pattern histogram (2520 ints): never live together
         cq = c.take<double>(5 * TSFA_CQ_MAX);  // change_quantiles results per corridor
+#if defined(TSFA_SPEC_LDS)
         stage = c.take<TsfaSpec>(TSFA_SPEC_BATCH);
+#else
+        stage = nullptr;
+#endif
         return c.off;
     }
 };
