@@ -3,5 +3,6 @@ export TMPDIR=/tmp
 mkdir -p gpurun_out/exp
 run() { timeout 300 python bench.py --steps 3 --warmup 1 --no-cpu-baseline "$@" 2>&1 | tail -1 | python -c "import json,sys; d=json.loads(sys.stdin.read()); print(round(d['ms_per_step'],2), {k: round(v,1) for k,v in d['kernel_ms'].items()})"; }
 {
-echo "basic launch_bounds(256,3)"; run
-} > gpurun_out/exp/log25.txt 2>&1
+timeout 900 python -m pytest tests -m gpu -x -q 2>&1 | tail -3
+echo default; run
+} > gpurun_out/exp/log26.txt 2>&1

@@ -238,6 +238,18 @@ TSFA_DEV double number_cwt_peaks_one(const Blk &b, X xv, int n, int W, const Cwt
     const int window = (n + 19) / 20;               // ceil(num_points / 20)
     const int hf = window / 2, odd = window % 2;
     double kept = 0.0;
+    // cwt[row, col] of a line that ended above row 0 is re-evaluated here; its Ricker taps (exp / pow / sqrt each) are
+    // tabulated once per width instead of once per tap per line:  taps[5 (w-2)(w+1) + k] = reversed tap k of width w
+    const bool taps_cached = (W >= 2) && (10 * W < n) && (5 * (W - 1) * (W + 2) <= TSFA_CWTP_MAXTAPS + 16);
+    if (taps_cached) {
+        blk_sync();
+        for (int w = 2; w <= W; ++w) {
+            const int nw = 10 * w;
+            double *tw = L.taps + 5 * (w - 2) * (w + 1);
+            for (int k = b.tid; k < nw; k += b.nt) tw[k] = ricker_tap(nw, (double)w, nw - 1 - k);
+        }
+        blk_sync();
+    }
     // Long series: the noise window holds hundreds of samples and its 10th percentile is no longer among the eight
     // smallest.  Ranking a window against itself costs window^2 per ridge line (n^3 / 1200 per series).  Instead the
     // width-1 row is argsorted ONCE; a line's percentile is then found by walking that global order from the smallest
@@ -269,7 +281,12 @@ TSFA_DEV double number_cwt_peaks_one(const Blk &b, X xv, int n, int W, const Cwt
                 if (k0 < 0) k0 = 0;
                 const int k1 = (m2 < nw - 1) ? m2 : (nw - 1);
                 double acc = 0.0;
+                if (taps_cached) {
+                const double *tw = L.taps + 5 * (w - 2) * (w + 1);  // sum_{v=2}^{w-1} 10 v
+                for (int k = k1; k >= k0; --k) acc += xv(m2 - k) * tw[k];
+            } else {
                 for (int k = k1; k >= k0; --k) acc += xv(m2 - k) * ricker_tap(nw, (double)w, nw - 1 - k);
+            }
                 sig = acc;
             }
             const int ws = (col - hf > 0) ? col - hf : 0;
@@ -330,7 +347,12 @@ TSFA_DEV double number_cwt_peaks_one(const Blk &b, X xv, int n, int W, const Cwt
             if (k0 < 0) k0 = 0;
             const int k1 = (m < nw - 1) ? m : (nw - 1);
             double acc = 0.0;
-            for (int k = k1; k >= k0; --k) acc += xv(m - k) * ricker_tap(nw, (double)w, nw - 1 - k);
+            if (taps_cached) {
+                const double *tw = L.taps + 5 * (w - 2) * (w + 1);  // sum_{v=2}^{w-1} 10 v
+                for (int k = k1; k >= k0; --k) acc += xv(m - k) * tw[k];
+            } else {
+                for (int k = k1; k >= k0; --k) acc += xv(m - k) * ricker_tap(nw, (double)w, nw - 1 - k);
+            }
             sig = acc;
         }
         // noise: scipy.stats.scoreatpercentile(row0[ws:we], 10)
