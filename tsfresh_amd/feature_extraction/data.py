@@ -72,14 +72,28 @@ def _pack(kind, ids, values, sort_values, index=None):
     """Group `values` by `ids` (ascending), each group ordered by `sort_values` (stable).  `index`: the frame's
     DatetimeIndex (row-aligned with `values`) or None."""
     codes, uniques = pd.factorize(np.asarray(ids), sort=True)
-    if sort_values is not None:
-        order = np.lexsort((np.asarray(sort_values), codes))
-    else:
-        order = np.argsort(codes, kind="stable")
+    order = None
+    if len(codes) > 1 and np.all(codes[1:] >= codes[:-1]):
+        # already grouped by id in ascending order (the usual layout of a long frame): if every group is also in sort
+        # order the permutation is the identity, and the 20M-row lexsort (90 % of the packing time) is skipped
+        if sort_values is None:
+            order = slice(None)
+        else:
+            try:
+                sv = np.asarray(sort_values)
+                if np.all((sv[1:] >= sv[:-1]) | (codes[1:] != codes[:-1])):
+                    order = slice(None)
+            except TypeError:  # sort values that do not compare element-wise
+                order = None
+    if order is None:
+        if sort_values is not None:
+            order = np.lexsort((np.asarray(sort_values), codes))
+        else:
+            order = np.argsort(codes, kind="stable")
     counts = np.bincount(codes, minlength=len(uniques))
     offsets = np.zeros(len(uniques) + 1, dtype=np.int64)
     np.cumsum(counts, out=offsets[1:])
-    times = _hours_since_first(index, order, offsets) if index is not None and len(order) else None
+    times = _hours_since_first(index, order, offsets) if index is not None and len(codes) else None
     return PackedKind(str(kind), np.asarray(uniques), np.ascontiguousarray(_as_values(values)[order]), offsets, times,
                       None if sort_values is None else np.asarray(sort_values)[order])
 

@@ -11,7 +11,8 @@ dtype, sorted) and whose columns are named ``"{kind}__{calculator}__{parameters}
     data.pivot(list of (id, name, value))  (data.py:86)    the dense matrix IS the pivot
 
 Arguments that only steer the reference's CPU distributors (`n_jobs`, `chunksize`, `disable_progressbar`,
-`show_warnings`) are accepted and ignored.  A custom `distributor` cannot be honoured and raises.
+`show_warnings`) are accepted and ignored.  `distributor` may be a `tsfresh_amd.utilities.distribution.GPUDistributor`
+(only its device is used); any other distributor raises the reference's ValueError.
 """
 import os
 import warnings
@@ -70,8 +71,12 @@ def extract_features(
     elif default_fc_parameters is None and kind_to_fc_parameters is not None:
         default_fc_parameters = {}
     if distributor is not None:
-        raise ValueError("the passed distributor is not an DistributorBaseClass object "
-                         "(tsfresh_amd runs the extraction on the GPU and takes no CPU distributor)")
+        from tsfresh_amd.utilities.distribution import GPUDistributor
+        if not isinstance(distributor, GPUDistributor):
+            raise ValueError("the passed distributor is not an DistributorBaseClass object "
+                             "(tsfresh_amd runs the extraction on the GPU: pass a GPUDistributor or None)")
+        if device is None:
+            device = distributor.device
     if profile:
         warnings.warn("profile=True (cProfile of the Python calculators) has no meaning for the GPU path; "
                       "use rocprofv3 or Plan.set_profiling instead", stacklevel=2)
