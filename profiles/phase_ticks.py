@@ -15,7 +15,9 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 os.environ.setdefault("TSFA_LIB", os.path.join(ROOT, "tsfresh_amd", "libtsfresh_amd_ticks.so"))
 
-NAMED = {210: "basic: spec fetch (all columns)", 211: "basic: column bodies (all columns)",
+NAMED = {220: "sort/change_quantiles: corridor edges (quantiles)", 221: "sort/change_quantiles: pass 1",
+         222: "sort/change_quantiles: reduce 12", 223: "sort/change_quantiles: pass 2", 224: "sort/change_quantiles: reduce 8",
+         225: "basic/number_peaks: near pass (L/R up to 10)", 226: "basic/number_peaks: far candidates", 210: "basic: spec fetch (all columns)", 211: "basic: column bodies (all columns)",
          212: "basic: output stores (all columns)", 200: "basic/agg_linear_trend: chunk aggregates", 201: "basic/agg_linear_trend: regression sums",
          202: "basic/agg_linear_trend: linregress tails (lane = regression)", 100: "basic: stage + stats", 104: "sort: stage + bitonic sort", 120: "ar: mean / demean / var", 121: "ar: spec scan + autocovariances", 122: "ar: Levinson-Durbin (pacf)",
          123: "ar/adf: lag products + normal matrix", 124: "ar/adf: Cholesky + nested AIC", 125: "ar/adf: final regression",

@@ -458,6 +458,7 @@ TSFA_DEV void fam_basic_series(const Blk &b, XS xs, int n, const TsfaSpec *specs
                 break;
             }
             unsigned short *lr = (unsigned short *)w;  // L | R << 8, distances capped at 255 (= "none found")
+            TSFA_TICKER(tkp, 0);
             if (!have_peaks) {
                 const int maxsup = (peaks_maxsup > 1) ? peaks_maxsup : 1;  // tsfa_prepare_family (host)
                 have_cumsum = false;  // w aliases cum
@@ -470,10 +471,20 @@ TSFA_DEV void fam_basic_series(const Blk &b, XS xs, int n, const TsfaSpec *specs
                     const int i = i0 + b.tid;
                     int L = 255, R = 255;
                     if (i < n) {
+                        // all 2 * TSFA_PEAK_NEAR neighbours are fetched up front (independent LDS reads in flight
+                        // together) and the nearest blocker on either side is picked by a branch-free descending
+                        // scan, instead of a data-dependent loop that waits for a read in every iteration
                         const double xi = xs[i];
-                        for (int k = 1; k <= near && (L == 255 || R == 255); ++k) {
-                            if (L == 255 && i - k >= 0 && !(xi > xs[i - k])) L = k;
-                            if (R == 255 && i + k < n && !(xi > xs[i + k])) R = k;
+                        double xl[TSFA_PEAK_NEAR], xr[TSFA_PEAK_NEAR];
+#pragma unroll
+                        for (int k = 1; k <= TSFA_PEAK_NEAR; ++k) {
+                            xl[k - 1] = (k <= near && i - k >= 0) ? xs[i - k] : 0.0;
+                            xr[k - 1] = (k <= near && i + k < n) ? xs[i + k] : 0.0;
+                        }
+#pragma unroll
+                        for (int k = TSFA_PEAK_NEAR; k >= 1; --k) {  // a neighbour outside the series never blocks
+                            if (k <= near && i - k >= 0 && !(xi > xl[k - 1])) L = k;
+                            if (k <= near && i + k < n && !(xi > xr[k - 1])) R = k;
                         }
                     }
                     const bool open = (i < n) && (maxsup > near) && (L == 255) && (R == 255);
@@ -493,6 +504,7 @@ TSFA_DEV void fam_basic_series(const Blk &b, XS xs, int n, const TsfaSpec *specs
                 }
                 if (ncand > cand_cap) ncand = cand_cap;
                 blk_sync();
+                TSFA_TICK(tkp, b, 225);
                 for (int c = b.tid; c < ncand; c += b.nt) {
                     const int i = cand[c];
                     const double xi = xs[i];
@@ -505,6 +517,7 @@ TSFA_DEV void fam_basic_series(const Blk &b, XS xs, int n, const TsfaSpec *specs
                 }
                 blk_sync();
                 have_peaks = true;
+                TSFA_TICK(tkp, b, 226);
             }
             double c = 0.0;
             for (int i = sup + b.tid; i < n - sup; i += b.nt) {

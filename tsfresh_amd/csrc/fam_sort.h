@@ -411,6 +411,7 @@ TSFA_DEV void friedrich_coeffs(const Blk &b, XS xs, int n, S1 srt1, int m, int r
 // var, var |.| of corridor k.
 template <class XS, class SS>
 TSFA_DEV void cq_fill_all(const Blk &b, XS xs, SS srt, int n, const TsfaCqPlan &plan, double *cq) {
+    TSFA_TICKER(tkq, 0);
     for (int k0 = 0; k0 < plan.n; k0 += 4) {
         const int ng = (plan.n - k0 < 4) ? (plan.n - k0) : 4;
         double lo[4], hi[4];
@@ -422,6 +423,7 @@ TSFA_DEV void cq_fill_all(const Blk &b, XS xs, SS srt, int n, const TsfaCqPlan &
             lo[j] = (j < ng) ? pd_quantile_sorted([=](int i) { return srt[i]; }, n, plan.ql[k0 + j]) : TSFA_INF;
             hi[j] = (j < ng) ? pd_quantile_sorted([=](int i) { return srt[i]; }, n, plan.qh[k0 + j]) : -TSFA_INF;
         }
+        TSFA_TICK(tkq, b, 220);
         double s1[12];
 #pragma unroll
         for (int k = 0; k < 12; ++k) s1[k] = 0.0;
@@ -437,7 +439,9 @@ TSFA_DEV void cq_fill_all(const Blk &b, XS xs, SS srt, int n, const TsfaCqPlan &
                 }
             }
         }
+        TSFA_TICK(tkq, b, 221);
         blk_sum_multi<12>(b, s1);
+        TSFA_TICK(tkq, b, 222);
         double m1[4], m2[4];
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
@@ -458,7 +462,9 @@ TSFA_DEV void cq_fill_all(const Blk &b, XS xs, SS srt, int n, const TsfaCqPlan &
                 }
             }
         }
+        TSFA_TICK(tkq, b, 223);
         blk_sum_multi<8>(b, s2);
+        TSFA_TICK(tkq, b, 224);
         blk_sync();
         if (b.tid == 0) {
 #pragma unroll
