@@ -20,11 +20,11 @@ cols = ["GRBM_GUI_ACTIVE", "SQ_WAVES", "SQ_WAVE_CYCLES", "SQ_BUSY_CYCLES", "SQ_I
         "SQ_ACTIVE_INST_SCA", "SQ_INSTS_LDS", "SQ_ACTIVE_INST_LDS", "SQ_WAIT_INST_LDS", "SQ_LDS_BANK_CONFLICT", "SQ_WAIT_ANY",
         "SQ_WAIT_INST_ANY", "SQ_ACTIVE_INST_ANY", "SQ_INSTS_SMEM"]
 print("per-launch means (rocprofv3 --pmc, bench.py default workload); SQ_* cycle counters are summed over all SIMDs/waves in quad-cycles\n")
-print("| kernel | " + " | ".join(cols) + " | VALU busy (ACTIVE_INST_VALU*4 / (GUI_ACTIVE*1024 SIMDs)) |")
+print("| kernel | " + " | ".join(cols) + " | VALU busy = ACTIVE_INST_VALU*4 / (GUI_ACTIVE/8 XCDs * 1024 SIMDs) |")
 print("|---|" + "---|" * (len(cols) + 1))
 for k, v in agg.items():
     m = {c: (sum(v[c]) / len(v[c]) if v.get(c) else float("nan")) for c in cols}
-    busy = m["SQ_ACTIVE_INST_VALU"] * 4.0 / (m["GRBM_GUI_ACTIVE"] * 1024.0) if m["GRBM_GUI_ACTIVE"] == m["GRBM_GUI_ACTIVE"] else float("nan")
+    busy = m["SQ_ACTIVE_INST_VALU"] * 4.0 / (m["GRBM_GUI_ACTIVE"] / 8.0 * 1024.0)  # GUI_ACTIVE is summed over the 8 XCDs if m["GRBM_GUI_ACTIVE"] == m["GRBM_GUI_ACTIVE"] else float("nan")
     print("| %s | " % k + " | ".join("%.4g" % m[c] for c in cols) + " | %.3f |" % busy)
 PY
 cat gpurun_out/pmc_issue/summary.md

@@ -29,8 +29,10 @@ def _stale():
 
 def load():
     if _stale():
+        tmp = "%s.%d.tmp" % (LIB, os.getpid())  # atomic: several processes (the gloo test's ranks) may build at once
         subprocess.check_call(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off", "-DTSFA_EMUL",
-                               SRC, "-o", LIB])
+                               SRC, "-o", tmp])
+        os.replace(tmp, LIB)
     lib = ctypes.CDLL(LIB)
     lib.tsfa_emul_calc_id.argtypes = [ctypes.c_char_p]
     lib.tsfa_emul_calc_id.restype = ctypes.c_int

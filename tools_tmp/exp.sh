@@ -5,5 +5,5 @@ run() { timeout 300 python bench.py --steps 3 --warmup 1 --no-cpu-baseline "$@" 
 {
 timeout 900 python -m pytest tests -m gpu -x -q 2>&1 | tail -3
 echo default; run
-for nt in 128; do echo "seq nt=$nt"; TSFA_NT_6=$nt run; done
-} > gpurun_out/exp/log28.txt 2>&1
+echo len256; run --length 256 --n-series 125000
+} > gpurun_out/exp/log29.txt 2>&1

@@ -89,11 +89,13 @@ TSFA_DEV bool blk_chol_factor(const Blk &b, double *G, int p, int ld) {
         blk_sync();
         for (int i = j + b.tid; i < p; i += b.nt) G[i + j * ld] = (i == j) ? sd : G[i + j * ld] / sd;
         blk_sync();
-        const int m = p - j - 1;
-        for (int e = b.tid; e < m * m; e += b.nt) {
-            const int i = j + 1 + e % m, k = j + 1 + e / m;
-            if (k > i) continue;
-            G[i + k * ld] = G[i + k * ld] - G[i + j * ld] * G[k + j * ld];
+        // trailing update, (row, column) = (tid % 32, tid / 32) strides: shifts instead of an integer division and a
+        // modulo per element (the family is VALU-issue bound, and those two cost ~80 instructions)
+        const int rsh = (b.nt >= 32) ? 5 : 0;  // nt is 1 (emulation) or a multiple of 64
+        for (int i = j + 1 + (b.tid & ((1 << rsh) - 1)); i < p; i += (1 << rsh)) {
+            const double lij = G[i + j * ld];
+            for (int k = j + 1 + (b.tid >> rsh); k <= i; k += (b.nt >> rsh))
+                G[i + k * ld] = G[i + k * ld] - lij * G[k + j * ld];
         }
     }
     blk_sync();
@@ -298,9 +300,9 @@ TSFA_DEV void fam_ar_series(const Blk &b, X xv, int n, const TsfaSpec *specs, in
             blk_sync();
             // assemble the normal matrix in the autolag column order [const, level, d-lag1 .. d-lag maxlag]
             const int p1 = maxlag + 2;
-            for (int e = b.tid; e < p1 * p1; e += b.nt) {
-                const int a = e % p1, c = e / p1;
-                if (c > a) continue;
+            for (int e = b.tid; e < 64 * p1; e += b.nt) {  // (a, c) = (e % 64, e / 64): p1 <= 63 for n <= 65535
+                const int a = e & 63, c = e >> 6;
+                if (a >= p1 || c > a) continue;
                 double v;
                 if (a == 0) v = nobs;
                 else if (a == 1) v = (c == 0) ? sx : sxx;

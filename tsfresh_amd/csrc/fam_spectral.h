@@ -16,12 +16,16 @@ TSFA_DEV void blk_fft_pow2(const Blk &b, double *re, double *im, int M, const do
     while ((1 << logM) < M) ++logM;
     blk_sync();
     for (int i = b.tid; i < M; i += b.nt) {
+#if TSFA_GPU
+        const int j = (logM > 0) ? (int)(__builtin_bitreverse32((unsigned)i) >> (32 - logM)) : 0;  // v_bfrev_b32
+#else
         unsigned r = 0, x = (unsigned)i;
         for (int k = 0; k < logM; ++k) {
             r = (r << 1) | (x & 1u);
             x >>= 1;
         }
         const int j = (int)r;
+#endif
         if (j > i) {
             const double tr = re[i], ti = im[i];
             re[i] = re[j];
@@ -30,12 +34,13 @@ TSFA_DEV void blk_fft_pow2(const Blk &b, double *re, double *im, int M, const do
             im[j] = ti;
         }
     }
-    for (int len = 2; len <= M; len <<= 1) {
+    int lh = 0;  // log2(half): the butterfly index splits by shifts, not by an integer division per butterfly
+    for (int len = 2; len <= M; len <<= 1, ++lh) {
         const int half = len >> 1;
         const int stride = TSFA_TW_N / len;
         blk_sync();
         for (int t = b.tid; t < (M >> 1); t += b.nt) {
-            const int grp = t / half, k = t - grp * half;
+            const int grp = t >> lh, k = t & (half - 1);
             const int i0 = grp * len + k, i1 = i0 + half;
             const double wr = twc[k * stride], wi = tws[k * stride];
             const double xr = re[i1], xi = im[i1];
