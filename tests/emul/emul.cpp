@@ -117,10 +117,10 @@ extern "C" int tsfa_emul_extract_timed(const tsfa_feature_spec *specs, int n_spe
                 if (sp.calc == TSFA_C_AUGMENTED_DICKEY_FULLER) P = std::max(P, adf_maxlag_for(maxn) + 3);
                 else if (sp.calc == TSFA_C_AR_COEFFICIENT) P = std::max(P, (int)sp.p[1] + 2);
             }
-            std::vector<double> xc(maxn + 8), rbuf(maxn + 8), aw(ArLds::scratch_doubles(P));
+            std::vector<double> xc(maxn + 8), aw(ArLds::scratch_doubles(P));
             const double *xp = xs.data();
             fam_ar_series(b, [=](int i) { return xp[i]; }, n, fam[TSFA_FAM_AR].data(), (int)fam[TSFA_FAM_AR].size(), row,
-                          xc.data(), rbuf.data(), aw.data(), P, hints[TSFA_FAM_AR].a, hints[TSFA_FAM_AR].b,
+                          xc.data(), aw.data(), P, hints[TSFA_FAM_AR].a, hints[TSFA_FAM_AR].b,
                           hints[TSFA_FAM_AR].c);
         }
         if (!fam[TSFA_FAM_ENTROPY].empty()) {

@@ -171,11 +171,10 @@ TSFA_DEV int ar_scratch_doubles(int P) { return 2 * P * P + 6 * P + 64 + 16 + 48
 // Evaluate the AR specs of one series.
 //   xv   : sample accessor
 //   xc   : LDS, n doubles   (mean-centred series)
-//   rbuf : LDS, n doubles   (regression residuals)
 //   aw   : LDS, ar_scratch_doubles(P) doubles;  P >= max(adf_maxlag_for(n) + 3, max AR order + 2)
 template <class X>
 TSFA_DEV void fam_ar_series(const Blk &b, X xv, int n, const TsfaSpec *specs, int nspecs, double *out_row, double *xc,
-                            double *rbuf, double *aw, int P, int hint_acf, int hint_pacf, int hint_adf) {
+                            double *aw, int P, int hint_acf, int hint_pacf, int hint_adf) {
     const double dn = (double)n;
     TSFA_TICKER(tk, 0);
     // x.mean() in numpy's summation order: statsmodels demeans with it, and on (near-)constant series the
@@ -392,18 +391,19 @@ TSFA_DEV void fam_ar_series(const Blk &b, X xv, int n, const TsfaSpec *specs, in
                 blk_sync();
                 if (ok2) {
                     // one step of iterative refinement on the true residuals, then SSR
-                    for (int t = u0 + b.tid; t < t1; t += b.nt) {
+                    // (the residual of a row is recomputed where it is used: a few multiply-adds instead of an
+                    // n-double LDS buffer, which would cost the family two resident series per CU)
+                    auto resid2 = [=](int t) {
                         double r = dif(t);
                         for (int c = 0; c < p2; ++c) r -= reg2(c, t) * beta[c];
-                        rbuf[t] = r;
-                    }
-                    blk_sync();
+                        return r;
+                    };
                     for (int a0 = 0; a0 < p2; a0 += 8) {  // X^T r, eight regressors per sweep
                         double s8[8];
 #pragma unroll
                         for (int j = 0; j < 8; ++j) s8[j] = 0.0;
                         for (int t = u0 + b.tid; t < t1; t += b.nt) {
-                            const double rt = rbuf[t];
+                            const double rt = resid2(t);
 #pragma unroll
                             for (int j = 0; j < 8; ++j)
                                 if (a0 + j < p2) s8[j] += reg2(a0 + j, t) * rt;
@@ -503,7 +503,8 @@ TSFA_DEV void fam_ar_series(const Blk &b, X xv, int n, const TsfaSpec *specs, in
                 } else {
                     int len = (ml < n - 1) ? ml : (n - 1);  // a = acf[1:], a[:maxlag]
                     if (len > 60) len = 60;
-                    double *a = rbuf;
+                    double abuf[64];
+                    double *a = abuf;
                     for (int k = 0; k < len; ++k) a[k] = acv[k + 1] / acv[0];
                     if (len <= 0) {
                         r = TSFA_NAN;
@@ -559,18 +560,17 @@ TSFA_DEV void fam_ar_series(const Blk &b, X xv, int n, const TsfaSpec *specs, in
                 blk_sync();
                 if (ar_ok) {
                     auto reg = [=](int a, int t) { return a == 0 ? 1.0 : xcc[t - a]; };
-                    for (int t = k + b.tid; t < n; t += b.nt) {
+                    auto resid = [=](int t) {
                         double r = xcc[t];
                         for (int c = 0; c < p; ++c) r -= reg(c, t) * beta[c];
-                        rbuf[t] = r;
-                    }
-                    blk_sync();
+                        return r;
+                    };
                     for (int a0 = 0; a0 < p; a0 += 8) {  // X^T r, eight regressors per sweep
                         double s8[8];
 #pragma unroll
                         for (int j = 0; j < 8; ++j) s8[j] = 0.0;
                         for (int t = k + b.tid; t < n; t += b.nt) {
-                            const double rt = rbuf[t];
+                            const double rt = resid(t);
 #pragma unroll
                             for (int j = 0; j < 8; ++j)
                                 if (a0 + j < p) s8[j] += reg(a0 + j, t) * rt;

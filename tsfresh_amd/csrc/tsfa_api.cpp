@@ -376,7 +376,7 @@ int tsfa_extract_windows(tsfa_plan *plan, const void *values, int32_t dtype, con
             // Wavefronts per series, measured on MI355X at n = 1024 (profiles/r01_*): the LDS footprint of a series
             // caps the workgroups per CU, so the latency-bound families gain from more wavefronts per workgroup,
             // while k_basic's many short reductions lose to the extra barriers.  At least 4 samples per thread.
-            static const int pref[TSFA_N_FAMILIES] = {64, 128, 128, 256, 256, 256, 128};
+            static const int pref[TSFA_N_FAMILIES] = {64, 128, 128, 128, 256, 256, 128};
             const int cap = std::max(64, ((maxn / 4 + 63) / 64) * 64);
             a.nt = std::min(pref[f], cap);
         }

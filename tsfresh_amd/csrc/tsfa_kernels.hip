@@ -103,7 +103,7 @@ __global__ void __launch_bounds__(256) k_ar(const T *__restrict__ values, const 
     TSFA_TICKS_BEGIN();
     Blk b{(int)threadIdx.x, (int)blockDim.x, L.red, L.np};
     const T *g = values + off;
-    fam_ar_series(b, [=](int i) { return (double)g[i]; }, n, specs, nspecs, out + sidx * ld, L.xc, L.rbuf, L.aw, P,
+    fam_ar_series(b, [=](int i) { return (double)g[i]; }, n, specs, nspecs, out + sidx * ld, L.xc, L.aw, P,
                   hint_acf, hint_pacf, hint_adf);
     TSFA_TICKS_END();
 }
