@@ -171,7 +171,8 @@ TSFA_DEV void blk_rfft(const Blk &b, int n, G g, double *Xr, double *Xi, double 
 // scipy.signal.welch(x, nperseg=min(n, 256)) -> pxx[0 .. nperseg/2] (fs=1, hann, 50% overlap,
 // constant detrend, density scaling, mean over segments).  fc.py:1418, fc.py:1809.
 //   win : LDS >= 256 doubles;  pxx : LDS >= 129 doubles;  Xr/Xi/tc/ts : FFT scratch (>= 256 each is enough)
-TSFA_DEV int blk_welch(const Blk &b, const double *xs, int n, double *win, double *pxx, double *Xr, double *Xi,
+template <class ST>
+TSFA_DEV int blk_welch(const Blk &b, const ST *xs, int n, double *win, double *pxx, double *Xr, double *Xi,
                        double *tc, double *ts, const double *twc, const double *tws) {
     const int nper = (n < 256) ? n : 256;
     const int nover = nper / 2;
@@ -191,7 +192,7 @@ TSFA_DEV int blk_welch(const Blk &b, const double *xs, int n, double *win, doubl
     w2 = blk_sum(b, w2);
     const double scale = 1.0 / w2;
     for (int sgi = 0; sgi < nseg; ++sgi) {
-        const double *seg = xs + sgi * step;
+        const XsView<ST> seg{xs + sgi * step};
         double sm = 0.0;
         for (int j = b.tid; j < nper; j += b.nt) sm += seg[j];
         const double mu = blk_sum(b, sm) / (double)nper;
@@ -215,9 +216,12 @@ TSFA_DEV int blk_welch(const Blk &b, const double *xs, int n, double *win, doubl
 //   Xr, Xi : LDS, >= n/2 + 2 doubles each (and >= 130)
 //   tc, ts : per-series DFT twiddles, >= n doubles each when n is not a power of two (LDS or global scratch)
 //   win    : LDS >= 256;  pxx : LDS >= 132;  iw : LDS ints >= 128
-TSFA_DEV void fam_spectral_series(const Blk &b, const double *xs, int n, const TsfaSpec *specs, int nspecs,
+// ST: element type of the LDS-resident series (the input precision; read as float64)
+template <class ST>
+TSFA_DEV void fam_spectral_series(const Blk &b, const ST *xs_raw, int n, const TsfaSpec *specs, int nspecs,
                                   double *out_row, double *Xr, double *Xi, double *tc, double *ts, double *win,
                                   double *pxx, int *iw, const double *twc, const double *tws, int flags, int nlead) {
+    const XsView<ST> xs{xs_raw};
     // flags / nlead come from tsfa_prepare_family (host): the Welch-based specs are the first nlead of the list
     const bool need_fft = (flags & 1) != 0, need_welch = (flags & 2) != 0;
     const int nf = n / 2 + 1;
@@ -227,7 +231,7 @@ TSFA_DEV void fam_spectral_series(const Blk &b, const double *xs, int n, const T
     double pmax = 0.0, pmin = 0.0;
     bool pnan = false;
     if (need_welch) {
-        npx = blk_welch(b, xs, n, win, pxx, Xr, Xi, tc, ts, twc, tws);
+        npx = blk_welch(b, xs_raw, n, win, pxx, Xr, Xi, tc, ts, twc, tws);
         double mx = -TSFA_INF, mn = TSFA_INF, nn = 0.0;
         for (int k = b.tid; k < npx; k += b.nt) {
             mx = fmax(mx, pxx[k]);

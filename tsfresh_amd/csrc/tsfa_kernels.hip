@@ -76,16 +76,21 @@ __global__ void __launch_bounds__(256) k_spectral(const T *__restrict__ values, 
     const int64_t off = starts[sidx];
     const int n = (int)(ends[sidx] - off);
     SpectralLds L;
-    L.carve(tsfa_smem, maxn, dft_n);
+    L.carve(tsfa_smem, maxn, dft_n, (int)sizeof(T));
     TSFA_TICKS_BEGIN();
     Blk b{(int)threadIdx.x, (int)blockDim.x, L.red, nullptr};
-    stage_series(b, values + off, n, L.xs);
+    T *xs = (T *)L.xs;  // resident in the input precision
+    {
+        const T *__restrict__ g = values + off;
+        for (int i = b.tid; i < n; i += b.nt) xs[i] = g[i];
+        blk_sync();
+    }
     double *tc = L.tc, *ts = L.ts;
     if (gscratch != nullptr && n > dft_n && n > 256) {  // long non-power-of-two series: twiddles in HBM scratch
         tc = gscratch + (size_t)sidx * 2 * gscratch_n;
         ts = tc + gscratch_n;
     }
-    fam_spectral_series(b, L.xs, n, specs, nspecs, out + sidx * ld, L.Xr, L.Xi, tc, ts, L.win, L.pxx, L.iw, twc, tws,
+    fam_spectral_series<T>(b, xs, n, specs, nspecs, out + sidx * ld, L.Xr, L.Xi, tc, ts, L.win, L.pxx, L.iw, twc, tws,
                         hint_a, hint_b);
     TSFA_TICKS_END();
 }
@@ -292,7 +297,7 @@ static int launch_all_t(const TsfaLaunch &a, const T *values) {
         k_sort<T><<<grid, nt, lds, st>>>(values, a.starts, a.ends, a.n_series, a.specs, a.nspecs, a.out, a.ld, a.maxn, a.cq);
     } else if (a.fam == TSFA_FAM_SPECTRAL) {
         SpectralLds L;
-        const size_t lds = L.carve(nullptr, a.maxn, a.dft_n);
+        const size_t lds = L.carve(nullptr, a.maxn, a.dft_n, (int)sizeof(T));
         if ((rc = set_lds(k_spectral<T>, lds))) return rc;
         k_spectral<T><<<grid, nt, lds, st>>>(values, a.starts, a.ends, a.n_series, a.specs, a.nspecs, a.out, a.ld, a.maxn,
                                              a.dft_n, a.gscratch, a.gscratch_n, a.twc, a.tws, a.hint_a, a.hint_b);

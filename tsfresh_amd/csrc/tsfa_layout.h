@@ -80,12 +80,13 @@ struct SortLds {
 };
 
 struct SpectralLds {
-    double *red; double *xs; double *Xr; double *Xi; double *tc; double *ts; double *win; double *pxx; int *iw;
+    double *red; void *xs; double *Xr; double *Xi; double *tc; double *ts; double *win; double *pxx; int *iw;
     // dft_n: length of the longest non-power-of-two series whose DFT twiddles must live in LDS (0 = none / global)
-    TSFA_HD size_t carve(unsigned char *base, int maxn, int dft_n) {
+    // xs_bytes: element size of the resident series (4: float32 input kept as float32, 8: float64)
+    TSFA_HD size_t carve(unsigned char *base, int maxn, int dft_n, int xs_bytes = 8) {
         LdsCarve c{base, 0};
         red = c.take<double>(TSFA_RED_DOUBLES);
-        xs = c.take<double>(maxn);
+        xs = c.take<unsigned char>((size_t)maxn * xs_bytes);
         const int nx = (maxn / 2 + 2 > 260) ? maxn / 2 + 2 : 260;
         Xr = c.take<double>(nx);
         Xi = c.take<double>(nx);
