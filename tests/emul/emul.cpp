@@ -90,12 +90,12 @@ extern "C" int tsfa_emul_extract_timed(const tsfa_feature_spec *specs, int n_spe
         std::vector<double> xs(x, x + n);
         xs.resize(n + 8, 0.0);
         if (!fam[TSFA_FAM_BASIC].empty()) {
-            std::vector<double> w(maxn + 8), cum(maxn + 8), altc(8 * 16);
+            std::vector<double> w(maxn + 8), cum(maxn + 8), altc(8 * 16), ctx(32);
             std::vector<int> iw(512);
             fam_basic_series(b, xs.data(), n, fam[TSFA_FAM_BASIC].data(), (int)fam[TSFA_FAM_BASIC].size(), row, w.data(),
                              (s % 2) ? w.data() : cum.data(), altc.data(), iw.data(), dectab.data(),
                              hints[TSFA_FAM_BASIC].a, hints[TSFA_FAM_BASIC].b, hints[TSFA_FAM_BASIC].alt, nullptr,
-                             times ? times + offsets[s] : nullptr);
+                             times ? times + offsets[s] : nullptr, (s % 2) ? -1 : hints[TSFA_FAM_BASIC].c, ctx.data());
         }
         if (!fam[TSFA_FAM_SORT].empty()) {
             std::vector<double> srt(tsfa_pow2_ceil(maxn) + 8), w(1280), cq(5 * TSFA_CQ_MAX);

@@ -267,6 +267,52 @@ TSFA_DEV void alt_fill_all(const Blk &b, XS xs, int n, const TsfaAltPlan &alt, d
     TSFA_TICK(tka, b, 202);
 }
 
+// Per-series values the epilogue columns read (LDS, TSFA_BASIC_CTX doubles)
+enum { TSFA_CTX_SUM = 0, TSFA_CTX_MEAN, TSFA_CTX_VAR, TSFA_CTX_STD, TSFA_CTX_VMIN, TSFA_CTX_VMAX, TSFA_CTX_SUMSQ,
+       TSFA_CTX_FIRST_MAX, TSFA_CTX_LAST_MAX, TSFA_CTX_FIRST_MIN, TSFA_CTX_LAST_MIN, TSFA_CTX_CNT_MAX, TSFA_CTX_CNT_MIN,
+       TSFA_CTX_X0, TSFA_CTX_X1, TSFA_CTX_XN2, TSFA_CTX_XN1, TSFA_CTX_LT = 20, TSFA_CTX_LTT = 25, TSFA_BASIC_CTX = 32 };
+
+// Columns [first, nspecs): closed forms of the statistics in ctx and reads of the caches (altc, ctx), lane = column.
+// Every lane fetches its own spec (one coalesced vector load for the whole group instead of a scalar-load round trip
+// per column) and stores its own value.
+TSFA_DEV void basic_epilogue(const Blk &b, const TsfaSpec *specs, int first, int nspecs, int n, const double *ctx,
+                             const double *altc, double *out_row) {
+    const double dn = (double)n;
+    for (int s = first + b.tid; s < nspecs; s += b.nt) {
+        const TsfaSpec sp = specs[s];
+        const double p0 = sp.p[0];
+        double v = TSFA_NAN;
+        switch (sp.calc) {
+        case TSFA_C_SUM_VALUES: v = ctx[TSFA_CTX_SUM]; break;
+        case TSFA_C_MEAN: v = ctx[TSFA_CTX_MEAN]; break;
+        case TSFA_C_LENGTH: v = dn; break;
+        case TSFA_C_STANDARD_DEVIATION: v = ctx[TSFA_CTX_STD]; break;
+        case TSFA_C_VARIANCE: v = ctx[TSFA_CTX_VAR]; break;
+        case TSFA_C_ROOT_MEAN_SQUARE: v = sqrt(ctx[TSFA_CTX_SUMSQ] / dn); break;
+        case TSFA_C_MAXIMUM: v = ctx[TSFA_CTX_VMAX]; break;
+        case TSFA_C_ABSOLUTE_MAXIMUM: v = fmax(fabs(ctx[TSFA_CTX_VMAX]), fabs(ctx[TSFA_CTX_VMIN])); break;
+        case TSFA_C_MINIMUM: v = ctx[TSFA_CTX_VMIN]; break;
+        case TSFA_C_ABS_ENERGY: v = ctx[TSFA_CTX_SUMSQ]; break;
+        case TSFA_C_VARIATION_COEFFICIENT: v = (ctx[TSFA_CTX_MEAN] == 0.0) ? TSFA_NAN : ctx[TSFA_CTX_STD] / ctx[TSFA_CTX_MEAN]; break;
+        case TSFA_C_VAR_GT_STD: v = (ctx[TSFA_CTX_VAR] > sqrt(ctx[TSFA_CTX_VAR])) ? 1.0 : 0.0; break;
+        case TSFA_C_LARGE_STD: v = (ctx[TSFA_CTX_STD] > p0 * (ctx[TSFA_CTX_VMAX] - ctx[TSFA_CTX_VMIN])) ? 1.0 : 0.0; break;
+        case TSFA_C_FIRST_LOCATION_OF_MAXIMUM: v = ctx[TSFA_CTX_FIRST_MAX] / dn; break;
+        case TSFA_C_LAST_LOCATION_OF_MAXIMUM: v = 1.0 - ((double)(n - 1) - ctx[TSFA_CTX_LAST_MAX]) / dn; break;
+        case TSFA_C_FIRST_LOCATION_OF_MINIMUM: v = ctx[TSFA_CTX_FIRST_MIN] / dn; break;
+        case TSFA_C_LAST_LOCATION_OF_MINIMUM: v = 1.0 - ((double)(n - 1) - ctx[TSFA_CTX_LAST_MIN]) / dn; break;
+        case TSFA_C_HAS_DUPLICATE_MAX: v = (ctx[TSFA_CTX_CNT_MAX] >= 2.0) ? 1.0 : 0.0; break;
+        case TSFA_C_HAS_DUPLICATE_MIN: v = (ctx[TSFA_CTX_CNT_MIN] >= 2.0) ? 1.0 : 0.0; break;
+        case TSFA_C_QUERY_SIMILARITY_COUNT: v = TSFA_NAN; break;
+        case TSFA_C_AGG_LINEAR_TREND: v = ((int)sp.p[1] >= n) ? TSFA_NAN : altc[8 * (((int)sp.p[3]) & 127) + 2 + (int)p0]; break;
+        case TSFA_C_INDEX_MASS_QUANTILE: v = altc[8 * (((int)sp.p[1]) & 127) + 7]; break;
+        case TSFA_C_LINEAR_TREND: v = ctx[TSFA_CTX_LT + (int)p0]; break;
+        case TSFA_C_LINEAR_TREND_TIMEWISE: v = ctx[TSFA_CTX_LTT + (int)p0]; break;
+        default: break;
+        }
+        out_row[sp.col] = v;
+    }
+}
+
 // Evaluate the BASIC specs of one series.
 //   xs   : series as float64 in LDS, length n (n >= 1)
 //   w    : LDS work array of >= n doubles (chunk aggregates)
@@ -281,11 +327,24 @@ template <class XS>
 TSFA_DEV void fam_basic_series(const Blk &b, XS xs, int n, const TsfaSpec *specs, int nspecs,
                                double *out_row, double *w, double *cum, double *altc, int *iw, const double *dectab,
                                int peaks_maxsup, int alt_want_p, const TsfaAltPlan &alt, TsfaSpec *stage,
-                               const double *times = nullptr) {
+                               const double *times = nullptr, int n_loop = -1, double *ctx = nullptr) {
     TSFA_TICKER(tk, 0);
     BasicStats st;
     basic_stats(b, xs, n, st);
     TSFA_TICK(tk, b, 100);
+    // n_loop columns go through the column loop; the rest are evaluated by basic_epilogue (lane = column) from ctx
+    const int nloop = (n_loop >= 0 && ctx != nullptr) ? n_loop : nspecs;
+    if (nloop < nspecs) {
+        blk_sync();
+        if (b.tid == 0) {
+            ctx[TSFA_CTX_SUM] = st.sum; ctx[TSFA_CTX_MEAN] = st.mean; ctx[TSFA_CTX_VAR] = st.var; ctx[TSFA_CTX_STD] = st.std;
+            ctx[TSFA_CTX_VMIN] = st.vmin; ctx[TSFA_CTX_VMAX] = st.vmax; ctx[TSFA_CTX_SUMSQ] = st.sumsq;
+            ctx[TSFA_CTX_FIRST_MAX] = (double)st.first_max; ctx[TSFA_CTX_LAST_MAX] = (double)st.last_max;
+            ctx[TSFA_CTX_FIRST_MIN] = (double)st.first_min; ctx[TSFA_CTX_LAST_MIN] = (double)st.last_min;
+            ctx[TSFA_CTX_CNT_MAX] = (double)st.cnt_max; ctx[TSFA_CTX_CNT_MIN] = (double)st.cnt_min;
+            for (int k = 0; k < 5; ++k) { ctx[TSFA_CTX_LT + k] = TSFA_NAN; ctx[TSFA_CTX_LTT + k] = TSFA_NAN; }
+        }
+    }
     const double dn = (double)n;
     const double mean = st.mean;
     bool have_cumsum = false, have_lt = false, have_ltt = false;
@@ -296,11 +355,11 @@ TSFA_DEV void fam_basic_series(const Blk &b, XS xs, int n, const TsfaSpec *specs
     bool have_peaks = false;
 
     TsfaSpec nxt = spec_fetch(b, specs, nspecs, 0, stage);
-    for (int s = 0; s < nspecs; ++s) {
+    for (int s = 0; s < nloop; ++s) {
         TSFA_TICKER(tkc, 0);
         const TsfaSpec sp = nxt;
 #if !defined(TSFA_SPEC_LDS)
-        nxt = specs[(s + 1 < nspecs) ? s + 1 : s];  // scalar load in flight while this column is evaluated
+        nxt = specs[(s + 1 < nloop) ? s + 1 : s];  // scalar load in flight while this column is evaluated
 #else
         if (s + 1 < nspecs) nxt = spec_fetch(b, specs, nspecs, s + 1, stage);
 #endif
@@ -683,6 +742,8 @@ TSFA_DEV void fam_basic_series(const Blk &b, XS xs, int n, const TsfaSpec *specs
             if (!have_lt) {  // one regression serves all five attributes
                 blk_linregress_index(b, n, [=](int i) { return xs[i]; }, lt5);
                 have_lt = true;
+                if (nloop < nspecs && b.tid == 0)
+                    for (int k = 0; k < 5; ++k) ctx[TSFA_CTX_LT + k] = lt5[k];
             }
             v = lt5[0];
 #pragma unroll
@@ -697,6 +758,8 @@ TSFA_DEV void fam_basic_series(const Blk &b, XS xs, int n, const TsfaSpec *specs
                 if (times != nullptr && n >= 2)
                     blk_linregress_xy(b, n, [=](int i) { return times[i] - t_first; }, [=](int i) { return xs[i]; }, ltt5);
                 have_ltt = true;
+                if (nloop < nspecs && b.tid == 0)
+                    for (int k = 0; k < 5; ++k) ctx[TSFA_CTX_LTT + k] = ltt5[k];
             }
             v = ltt5[0];
 #pragma unroll
@@ -765,6 +828,10 @@ TSFA_DEV void fam_basic_series(const Blk &b, XS xs, int n, const TsfaSpec *specs
         if (b.tid == 0) out_row[sp.col] = v;
         TSFA_TICK(tkc, b, 212);
         TSFA_TICK(tk, b, sp.calc);
+    }
+    if (nloop < nspecs) {
+        blk_sync();
+        basic_epilogue(b, specs, nloop, nspecs, n, ctx, altc, out_row);
     }
 }
 

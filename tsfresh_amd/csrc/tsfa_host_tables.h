@@ -81,7 +81,46 @@ struct TsfaFamHints {
     TsfaAltPlan alt;  // BASIC
     TsfaCqPlan cq;    // SORT
 };
+// BASIC columns whose value is a closed form of the per-series statistics or a read of a cached result: they are
+// moved behind the other columns and evaluated with lane = column (fam_basic.h: basic_epilogue) instead of one
+// ~450-cycle trip through the column loop each.
+static inline bool tsfa_basic_is_closed_form(int calc) {
+    switch (calc) {
+    case TSFA_C_SUM_VALUES: case TSFA_C_MEAN: case TSFA_C_LENGTH: case TSFA_C_STANDARD_DEVIATION: case TSFA_C_VARIANCE:
+    case TSFA_C_ROOT_MEAN_SQUARE: case TSFA_C_MAXIMUM: case TSFA_C_ABSOLUTE_MAXIMUM: case TSFA_C_MINIMUM:
+    case TSFA_C_ABS_ENERGY: case TSFA_C_VARIATION_COEFFICIENT: case TSFA_C_VAR_GT_STD: case TSFA_C_LARGE_STD:
+    case TSFA_C_FIRST_LOCATION_OF_MAXIMUM: case TSFA_C_LAST_LOCATION_OF_MAXIMUM: case TSFA_C_FIRST_LOCATION_OF_MINIMUM:
+    case TSFA_C_LAST_LOCATION_OF_MINIMUM: case TSFA_C_HAS_DUPLICATE_MAX: case TSFA_C_HAS_DUPLICATE_MIN:
+    case TSFA_C_QUERY_SIMILARITY_COUNT:
+        return true;
+    default:
+        return false;
+    }
+}
+
+static inline void tsfa_prepare_family_impl(int fam, std::vector<TsfaSpec> &specs, TsfaFamHints &h);
+
 static inline void tsfa_prepare_family(int fam, std::vector<TsfaSpec> &specs, TsfaFamHints &h) {
+    tsfa_prepare_family_impl(fam, specs, h);
+    if (fam != TSFA_FAM_BASIC) return;
+    // c = number of columns that stay in the column loop; the rest (closed forms, reads of the agg_linear_trend /
+    // linear_trend / index_mass_quantile caches that an earlier loop column fills) follow and go to the epilogue
+    std::vector<TsfaSpec> loop, epi;
+    bool seen_lt = false, seen_ltt = false;
+    for (const auto &s : specs) {
+        bool e = tsfa_basic_is_closed_form(s.calc);
+        if (s.calc == TSFA_C_AGG_LINEAR_TREND) e = (h.alt.nkeys > 0) && ((int)s.p[3] < 128);
+        if (s.calc == TSFA_C_INDEX_MASS_QUANTILE) e = (h.alt.nq > 0) && (s.p[2] == 1.0) && ((int)s.p[1] < 128);
+        if (s.calc == TSFA_C_LINEAR_TREND) { e = seen_lt; seen_lt = true; }
+        if (s.calc == TSFA_C_LINEAR_TREND_TIMEWISE) { e = seen_ltt; seen_ltt = true; }
+        (e ? epi : loop).push_back(s);
+    }
+    h.c = (int)loop.size();
+    specs = loop;
+    specs.insert(specs.end(), epi.begin(), epi.end());
+}
+
+static inline void tsfa_prepare_family_impl(int fam, std::vector<TsfaSpec> &specs, TsfaFamHints &h) {
     h = TsfaFamHints();
     memset(&h.alt, 0, sizeof h.alt);
     memset(&h.cq, 0, sizeof h.cq);

@@ -37,7 +37,7 @@ TSFA_HD int tsfa_pow2_ceil(int n) {
 }
 
 struct BasicLds {
-    double *red; NpScratch *np; void *xs; double *w; double *cum; double *altc; int *iw; TsfaSpec *stage;
+    double *red; NpScratch *np; void *xs; double *w; double *cum; double *altc; int *iw; TsfaSpec *stage; double *ctx;
     // xs_bytes: element size of the LDS-resident series (4: float32 input kept as float32, 8: float64)
     TSFA_HD size_t carve(unsigned char *base, int maxn, int nt, int xs_bytes = 8) {
         LdsCarve c{base, 0};
@@ -47,6 +47,7 @@ struct BasicLds {
         w = c.take<double>(maxn);  // chunk aggregates (agg_linear_trend) ...
         cum = w;                   // ... aliased with the cumulative |x| of index_mass_quantile (the cache is invalidated)
         altc = c.take<double>(8 * 16);
+        ctx = c.take<double>(32);  // TSFA_BASIC_CTX: per-series values read by the epilogue columns
         iw = c.take<int>((4 * nt > 256) ? 4 * nt : 256);
 #if defined(TSFA_SPEC_LDS)
         stage = c.take<TsfaSpec>(TSFA_SPEC_BATCH);
