@@ -484,11 +484,51 @@ TSFA_DEV void cq_fill_all(const Blk &b, XS xs, SS srt, int n, const TsfaCqPlan &
     blk_sync();
 }
 
+// Per-series values the epilogue columns of the family read (LDS, TSFA_SORT_CTX doubles)
+enum { TSFA_SCTX_SYM = 0, TSFA_SCTX_NUNIQUE, TSFA_SCTX_MULTI_VALS, TSFA_SCTX_MULTI_PTS, TSFA_SCTX_SUM_VALS, TSFA_SCTX_SUM_PTS,
+       TSFA_SORT_CTX = 8 };
+
+// Columns [first, nspecs) with lane = column: order statistics of the sorted copy and reads of the caches.
+template <class SS>
+TSFA_DEV void sort_epilogue(const Blk &b, const TsfaSpec *specs, int first, int nspecs, int n, SS srt, const double *ctx,
+                            const double *cq, double *out_row) {
+    const double dn = (double)n;
+    const double vmin = srt[0], vmax = srt[n - 1];
+    for (int s = first + b.tid; s < nspecs; s += b.nt) {
+        const TsfaSpec sp = specs[s];
+        const double p0 = sp.p[0];
+        double v = TSFA_NAN;
+        switch (sp.calc) {
+        case TSFA_C_MEDIAN: v = (n & 1) ? srt[(n - 1) / 2] : (0.0 + srt[n / 2 - 1] + srt[n / 2]) / 2.0; break;
+        case TSFA_C_QUANTILE: v = np_quantile_sorted([=](int i) { return srt[i]; }, n, p0); break;
+        case TSFA_C_SYMMETRY_LOOKING: v = (ctx[TSFA_SCTX_SYM] < p0 * (vmax - vmin)) ? 1.0 : 0.0; break;
+        case TSFA_C_CHANGE_QUANTILES: {
+            if (sp.p[1] != -2.0) { v = 0.0; break; }  // ql >= qh
+            const double *o = cq + 5 * (((int)p0) & 127);
+            const bool isabs = (sp.p[2] != 0.0);
+            if (o[0] == 0.0) v = 0.0;
+            else if ((int)sp.p[3] == TSFA_AGG_MEAN) v = isabs ? o[2] : o[1];
+            else v = isabs ? o[4] : o[3];
+        } break;
+        case TSFA_C_HAS_DUPLICATE: v = (ctx[TSFA_SCTX_NUNIQUE] != dn) ? 1.0 : 0.0; break;
+        case TSFA_C_RATIO_VALUE_NUMBER: v = ctx[TSFA_SCTX_NUNIQUE] / dn; break;
+        case TSFA_C_PCT_REOCC_VALUES: v = ctx[TSFA_SCTX_MULTI_VALS] / ctx[TSFA_SCTX_NUNIQUE]; break;
+        case TSFA_C_PCT_REOCC_DATAPOINTS: v = ctx[TSFA_SCTX_MULTI_PTS] / dn; break;
+        case TSFA_C_SUM_REOCC_VALUES: v = ctx[TSFA_SCTX_SUM_VALS]; break;
+        case TSFA_C_SUM_REOCC_DATA_POINTS: v = ctx[TSFA_SCTX_SUM_PTS]; break;
+        default: break;
+        }
+        out_row[sp.col] = v;
+    }
+}
+
 // ST: element type of the LDS-resident series and of its sorted copy (the input precision; read as float64)
 template <class ST>
 TSFA_DEV void fam_sort_series(const Blk &b, const ST *xs_raw, int n, const TsfaSpec *specs, int nspecs,
                               double *out_row, ST *srt_raw, double *w, int *iw, const TsfaCqPlan &cqplan, double *cq,
-                              TsfaSpec *stage) {
+                              TsfaSpec *stage, int n_loop = -1, double *ctx = nullptr) {
+    // n_loop columns go through the column loop; the rest are evaluated by sort_epilogue (lane = column)
+    const int nloop = (n_loop >= 0 && ctx != nullptr) ? n_loop : nspecs;
     const XsView<ST> xs{xs_raw};
     const XsView<ST> srt{srt_raw};
     const int np2 = next_pow2(n);
@@ -510,7 +550,7 @@ TSFA_DEV void fam_sort_series(const Blk &b, const ST *xs_raw, int n, const TsfaS
     double n_unique = 0.0, n_multi_vals = 0.0, n_multi_pts = 0.0, sum_multi_vals = 0.0, sum_multi_pts = 0.0;
     bool have_runs = false;
 
-    for (int s = 0; s < nspecs; ++s) {
+    for (int s = 0; s < nloop; ++s) {
         const TsfaSpec sp = spec_fetch(b, specs, nspecs, s, stage);
         const double p0 = sp.p[0], p1 = sp.p[1], p2 = sp.p[2], p3 = sp.p[3];
         double v = TSFA_NAN;
@@ -527,6 +567,7 @@ TSFA_DEV void fam_sort_series(const Blk &b, const ST *xs_raw, int n, const TsfaS
                 const double med = (n & 1) ? srt[(n - 1) / 2] : (0.0 + srt[n / 2 - 1] + srt[n / 2]) / 2.0;
                 sym_dist = fabs(mean - med);
                 have_sym = true;
+                if (nloop < nspecs && b.tid == 0) ctx[TSFA_SCTX_SYM] = sym_dist;
             }
             v = (sym_dist < p0 * (vmax - vmin)) ? 1.0 : 0.0;
         } break;
@@ -626,6 +667,11 @@ TSFA_DEV void fam_sort_series(const Blk &b, const ST *xs_raw, int n, const TsfaS
                 sum_multi_vals = blk_sum(b, sv);
                 sum_multi_pts = blk_sum(b, spn);
                 have_runs = true;
+                if (nloop < nspecs && b.tid == 0) {
+                    ctx[TSFA_SCTX_NUNIQUE] = n_unique; ctx[TSFA_SCTX_MULTI_VALS] = n_multi_vals;
+                    ctx[TSFA_SCTX_MULTI_PTS] = n_multi_pts; ctx[TSFA_SCTX_SUM_VALS] = sum_multi_vals;
+                    ctx[TSFA_SCTX_SUM_PTS] = sum_multi_pts;
+                }
             }
             if (sp.calc == TSFA_C_HAS_DUPLICATE) v = (n_unique != dn) ? 1.0 : 0.0;             // fc.py:355
             else if (sp.calc == TSFA_C_RATIO_VALUE_NUMBER) v = n_unique / dn;                   // fc.py:1045
@@ -708,6 +754,10 @@ TSFA_DEV void fam_sort_series(const Blk &b, const ST *xs_raw, int n, const TsfaS
         }
         if (b.tid == 0) out_row[sp.col] = v;
         TSFA_TICK(tk, b, sp.calc);
+    }
+    if (nloop < nspecs) {
+        blk_sync();
+        sort_epilogue(b, specs, nloop, nspecs, n, srt, ctx, cq, out_row);
     }
 }
 

@@ -102,6 +102,27 @@ static inline void tsfa_prepare_family_impl(int fam, std::vector<TsfaSpec> &spec
 
 static inline void tsfa_prepare_family(int fam, std::vector<TsfaSpec> &specs, TsfaFamHints &h) {
     tsfa_prepare_family_impl(fam, specs, h);
+    if (fam == TSFA_FAM_SORT) {
+        // c = columns of the column loop; behind them the ones basic_epilogue's sibling sort_epilogue evaluates with
+        // lane = column: order statistics read straight from the sorted copy, and reads of the corridor / run /
+        // symmetry caches that an earlier loop column fills
+        std::vector<TsfaSpec> loop, epi;
+        bool seen_sym = false, seen_runs = false;
+        for (const auto &s : specs) {
+            bool e = (s.calc == TSFA_C_MEDIAN || s.calc == TSFA_C_QUANTILE);
+            if (s.calc == TSFA_C_CHANGE_QUANTILES)
+                e = (s.p[1] == -2.0) ? ((int)s.p[0] < 128) : (h.cq.n > 0 && s.p[0] >= s.p[1]);
+            if (s.calc == TSFA_C_SYMMETRY_LOOKING) { e = seen_sym; seen_sym = true; }
+            if (s.calc == TSFA_C_HAS_DUPLICATE || s.calc == TSFA_C_RATIO_VALUE_NUMBER || s.calc == TSFA_C_PCT_REOCC_VALUES ||
+                s.calc == TSFA_C_PCT_REOCC_DATAPOINTS || s.calc == TSFA_C_SUM_REOCC_VALUES ||
+                s.calc == TSFA_C_SUM_REOCC_DATA_POINTS) { e = seen_runs; seen_runs = true; }
+            (e ? epi : loop).push_back(s);
+        }
+        h.c = (int)loop.size();
+        specs = loop;
+        specs.insert(specs.end(), epi.begin(), epi.end());
+        return;
+    }
     if (fam != TSFA_FAM_BASIC) return;
     // c = number of columns that stay in the column loop; the rest (closed forms, reads of the agg_linear_trend /
     // linear_trend / index_mass_quantile caches that an earlier loop column fills) follow and go to the epilogue

@@ -47,7 +47,7 @@ __global__ void __launch_bounds__(256, 2) k_basic(const T *__restrict__ values, 
 template <typename T>
 __global__ void __launch_bounds__(256) k_sort(const T *__restrict__ values, const int64_t *__restrict__ starts, const int64_t *__restrict__ ends, int64_t n_series,
                        const TsfaSpec *__restrict__ specs, int nspecs, double *__restrict__ out, int64_t ld, int maxn,
-                       const TsfaCqPlan cqplan) {
+                       const TsfaCqPlan cqplan, int n_loop) {
     const int64_t sidx = blockIdx.x;
     if (sidx >= n_series) return;
     const int64_t off = starts[sidx];
@@ -62,7 +62,8 @@ __global__ void __launch_bounds__(256) k_sort(const T *__restrict__ values, cons
         for (int i = b.tid; i < n; i += b.nt) xs[i] = g[i];
         blk_sync();
     }
-    fam_sort_series<T>(b, xs, n, specs, nspecs, out + sidx * ld, (T *)L.srt, L.w, L.iw, cqplan, L.cq, L.stage);
+    fam_sort_series<T>(b, xs, n, specs, nspecs, out + sidx * ld, (T *)L.srt, L.w, L.iw, cqplan, L.cq, L.stage,
+                       n_loop, L.ctx);
     TSFA_TICKS_END();
 }
 
@@ -294,7 +295,8 @@ static int launch_all_t(const TsfaLaunch &a, const T *values) {
         SortLds L;
         const size_t lds = L.carve(nullptr, a.maxn, nt, (int)sizeof(T));
         if ((rc = set_lds(k_sort<T>, lds))) return rc;
-        k_sort<T><<<grid, nt, lds, st>>>(values, a.starts, a.ends, a.n_series, a.specs, a.nspecs, a.out, a.ld, a.maxn, a.cq);
+        k_sort<T><<<grid, nt, lds, st>>>(values, a.starts, a.ends, a.n_series, a.specs, a.nspecs, a.out, a.ld, a.maxn, a.cq,
+                                         a.hint_c);
     } else if (a.fam == TSFA_FAM_SPECTRAL) {
         SpectralLds L;
         const size_t lds = L.carve(nullptr, a.maxn, a.dft_n, (int)sizeof(T));

@@ -59,7 +59,7 @@ struct BasicLds {
 };
 
 struct SortLds {
-    double *red; NpScratch *np; void *xs; void *srt; double *w; int *iw; double *cq; TsfaSpec *stage;
+    double *red; NpScratch *np; void *xs; void *srt; double *w; int *iw; double *cq; TsfaSpec *stage; double *ctx;
     // xs_bytes: element size of the resident series and its sorted copy (4: float32 input kept as float32, 8: float64)
     TSFA_HD size_t carve(unsigned char *base, int maxn, int nt, int xs_bytes = 8) {
         (void)nt;
@@ -71,6 +71,7 @@ struct SortLds {
         w = c.take<double>(1280);   // Langevin-fit scratch (<= 768 doubles) ...
         iw = (int *)w;              // ... aliased with the ordinal-pattern histogram (2520 ints): never live together
         cq = c.take<double>(5 * TSFA_CQ_MAX);  // change_quantiles results per corridor
+        ctx = c.take<double>(8);               // TSFA_SORT_CTX: values read by the epilogue columns
 #if defined(TSFA_SPEC_LDS)
         stage = c.take<TsfaSpec>(TSFA_SPEC_BATCH);
 #else
