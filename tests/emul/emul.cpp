@@ -122,7 +122,7 @@ extern "C" int tsfa_emul_extract_timed(const tsfa_feature_spec *specs, int n_spe
             const double *xp = xs.data();
             fam_ar_series(b, [=](int i) { return xp[i]; }, n, fam[TSFA_FAM_AR].data(), (int)fam[TSFA_FAM_AR].size(), row,
                           xc.data(), aw.data(), P, hints[TSFA_FAM_AR].a, hints[TSFA_FAM_AR].b,
-                          hints[TSFA_FAM_AR].c);
+                          hints[TSFA_FAM_AR].c, (s % 2) ? -1 : hints[TSFA_FAM_AR].d);
         }
         if (!fam[TSFA_FAM_ENTROPY].empty()) {
             std::vector<double> thr(56), xe(xs.begin(), xs.begin() + n);

@@ -174,7 +174,8 @@ TSFA_DEV int ar_scratch_doubles(int P) { return 2 * P * P + 6 * P + 64 + 16 + 48
 //   aw   : LDS, ar_scratch_doubles(P) doubles;  P >= max(adf_maxlag_for(n) + 3, max AR order + 2)
 template <class X>
 TSFA_DEV void fam_ar_series(const Blk &b, X xv, int n, const TsfaSpec *specs, int nspecs, double *out_row, double *xc,
-                            double *aw, int P, int hint_acf, int hint_pacf, int hint_adf) {
+                            double *aw, int P, int hint_acf, int hint_pacf, int hint_adf, int n_loop = -1) {
+    const int nloop = (n_loop >= 0) ? n_loop : nspecs;  // columns [nloop, nspecs): lane = column epilogue
     const double dn = (double)n;
     TSFA_TICKER(tk, 0);
     // x.mean() in numpy's summation order: statsmodels demeans with it, and on (near-)constant series the
@@ -452,7 +453,7 @@ TSFA_DEV void fam_ar_series(const Blk &b, X xv, int n, const TsfaSpec *specs, in
     int ar_cached_k = -1;
     bool ar_ok = false;
     TSFA_TICK(tk, b, 125);
-    for (int s = 0; s < nspecs; ++s) {
+    for (int s = 0; s < nloop; ++s) {
         const TsfaSpec sp = specs[s];
         double v = TSFA_NAN;
         switch (sp.calc) {
@@ -604,6 +605,27 @@ TSFA_DEV void fam_ar_series(const Blk &b, X xv, int n, const TsfaSpec *specs, in
         }
         if (b.tid == 0) out_row[sp.col] = v;
         TSFA_TICK(tk, b, sp.calc);
+    }
+    if (nloop < nspecs) {
+        // lane = column: reads of pac[], the ADF outputs and the cached AR fit (all resident in LDS / uniform)
+        blk_sync();
+        for (int s = nloop + b.tid; s < nspecs; s += b.nt) {
+            const TsfaSpec sp = specs[s];
+            double v = TSFA_NAN;
+            if (sp.calc == TSFA_C_PARTIAL_AUTOCORRELATION) {
+                const int l = (int)sp.p[0];
+                v = (l >= 0 && l <= max_pacf_lag) ? pac[l] : TSFA_NAN;
+            } else if (sp.calc == TSFA_C_AUGMENTED_DICKEY_FULLER) {
+                const int attr = (int)sp.p[0];
+                v = (attr == TSFA_ADF_TESTSTAT) ? adf_stat : (attr == TSFA_ADF_PVALUE ? adf_p : (attr == TSFA_ADF_USEDLAG ? adf_lag : TSFA_NAN));
+            } else if (sp.calc == TSFA_C_AR_COEFFICIENT) {
+                const int coeff = (int)sp.p[0], k = (int)sp.p[1];
+                if (coeff > k) v = TSFA_NAN;
+                else if (n < 2 * k + 2 || k + 2 > P || k < 1 || k + 1 > 40) v = (coeff < k) ? TSFA_NAN : 0.0;
+                else v = (ar_cached_k == k && ar_ok) ? arres[coeff] : TSFA_NAN;
+            }
+            out_row[sp.col] = v;
+        }
     }
 }
 

@@ -77,7 +77,7 @@ static inline void tsfa_build_twiddles(std::vector<double> &twc, std::vector<dou
 // carries its output column, so the order on the device is free).
 #define TSFA_ALT_SLOTS 16
 struct TsfaFamHints {
-    int a = 0, b = 0, c = 0;
+    int a = 0, b = 0, c = 0, d = -1;
     TsfaAltPlan alt;  // BASIC
     TsfaCqPlan cq;    // SORT
 };
@@ -102,6 +102,29 @@ static inline void tsfa_prepare_family_impl(int fam, std::vector<TsfaSpec> &spec
 
 static inline void tsfa_prepare_family(int fam, std::vector<TsfaSpec> &specs, TsfaFamHints &h) {
     tsfa_prepare_family_impl(fam, specs, h);
+    if (fam == TSFA_FAM_AR) {
+        // d = columns of the column loop; behind them the reads of results the prologue / an earlier column left in
+        // LDS (pacf lags, the three ADF outputs, the other coefficients of an AR fit), evaluated with lane = column.
+        // AR coefficients only when the plan fits a single order k (the cache holds one fit).
+        int ar_k = -1;
+        bool one_k = true;
+        for (const auto &s : specs)
+            if (s.calc == TSFA_C_AR_COEFFICIENT) {
+                if (ar_k >= 0 && (int)s.p[1] != ar_k) one_k = false;
+                ar_k = (int)s.p[1];
+            }
+        std::vector<TsfaSpec> loop, epi;
+        bool seen_ar = false;
+        for (const auto &s : specs) {
+            bool e = (s.calc == TSFA_C_PARTIAL_AUTOCORRELATION || s.calc == TSFA_C_AUGMENTED_DICKEY_FULLER);
+            if (s.calc == TSFA_C_AR_COEFFICIENT) { e = one_k && seen_ar; seen_ar = true; }
+            (e ? epi : loop).push_back(s);
+        }
+        h.d = (int)loop.size();
+        specs = loop;
+        specs.insert(specs.end(), epi.begin(), epi.end());
+        return;
+    }
     if (fam == TSFA_FAM_SORT) {
         // c = columns of the column loop; behind them the ones basic_epilogue's sibling sort_epilogue evaluates with
         // lane = column: order statistics read straight from the sorted copy, and reads of the corridor / run /

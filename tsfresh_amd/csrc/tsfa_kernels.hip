@@ -99,7 +99,7 @@ __global__ void __launch_bounds__(256) k_spectral(const T *__restrict__ values, 
 template <typename T>
 __global__ void __launch_bounds__(256) k_ar(const T *__restrict__ values, const int64_t *__restrict__ starts, const int64_t *__restrict__ ends, int64_t n_series,
                      const TsfaSpec *__restrict__ specs, int nspecs, double *__restrict__ out, int64_t ld, int maxn,
-                     int P, int hint_acf, int hint_pacf, int hint_adf) {
+                     int P, int hint_acf, int hint_pacf, int hint_adf, int n_loop) {
     const int64_t sidx = blockIdx.x;
     if (sidx >= n_series) return;
     const int64_t off = starts[sidx];
@@ -110,7 +110,7 @@ __global__ void __launch_bounds__(256) k_ar(const T *__restrict__ values, const 
     Blk b{(int)threadIdx.x, (int)blockDim.x, L.red, L.np};
     const T *g = values + off;
     fam_ar_series(b, [=](int i) { return (double)g[i]; }, n, specs, nspecs, out + sidx * ld, L.xc, L.aw, P,
-                  hint_acf, hint_pacf, hint_adf);
+                  hint_acf, hint_pacf, hint_adf, n_loop);
     TSFA_TICKS_END();
 }
 
@@ -308,7 +308,7 @@ static int launch_all_t(const TsfaLaunch &a, const T *values) {
         const size_t lds = L.carve(nullptr, a.maxn, a.ar_P);
         if ((rc = set_lds(k_ar<T>, lds))) return rc;
         k_ar<T><<<grid, nt, lds, st>>>(values, a.starts, a.ends, a.n_series, a.specs, a.nspecs, a.out, a.ld, a.maxn, a.ar_P,
-                                       a.hint_a, a.hint_b, a.hint_c);
+                                       a.hint_a, a.hint_b, a.hint_c, a.hint_d);
     } else if (a.fam == TSFA_FAM_ENTROPY) {
         EntropyLds L;
         const size_t lds = L.carve(nullptr, a.maxn, a.ent_cnt);
