@@ -128,10 +128,12 @@ extern "C" int tsfa_emul_extract_timed(const tsfa_feature_spec *specs, int n_spe
             std::vector<double> thr(56), xe(xs.begin(), xs.begin() + n);
             xe.resize(n + 8, 0.0);
             std::vector<unsigned short> perm(tsfa_pow2_ceil(maxn) + 96);
-            std::vector<unsigned int> cnt((size_t)(maxn + 16) * 3), refs(perm.size());
-            // odd series exercise the ordered-pair sweep (no LDS counters)
+            std::vector<unsigned int> cnt((size_t)(maxn + 16) * 4), refs(perm.size());
+            // odd series exercise the ordered-pair sweep (no LDS counters), every fourth the grouped symmetric sweep
+            // instead of the staged one
             fam_entropy_series<double>(b, xe.data(), n, fam[TSFA_FAM_ENTROPY].data(), (int)fam[TSFA_FAM_ENTROPY].size(),
-                                       row, thr.data(), perm.data(), refs.data(), (s % 2) ? nullptr : cnt.data());
+                                       row, thr.data(), perm.data(), refs.data(), (s % 2) ? nullptr : cnt.data(),
+                                       (s % 4 == 0) ? 1 : 0);
         }
         if (!fam[TSFA_FAM_SEQ].empty()) {
             const int group = 2;  // exercise the multi-launch path

@@ -132,7 +132,7 @@ struct EntropyLds {
         perm = c.take<unsigned short>(nperm);
         if (with_cnt) {  // the numpy-order scratch is dead before the first sweep: share its storage
             refs = c.take<unsigned int>(nperm);
-            const size_t cb = (size_t)(maxn + 16) * 3 * sizeof(unsigned int);
+            const size_t cb = (size_t)(maxn + 16) * ((maxn <= 1024) ? 4 : 3) * sizeof(unsigned int);  // staged sweep: 4 words / template
             unsigned char *u = c.take<unsigned char>(cb > sizeof(NpScratch) ? cb : sizeof(NpScratch));
             np = (NpScratch *)u;
             cnt = (unsigned int *)u;
