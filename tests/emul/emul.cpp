@@ -95,7 +95,8 @@ extern "C" int tsfa_emul_extract_timed(const tsfa_feature_spec *specs, int n_spe
             fam_basic_series(b, xs.data(), n, fam[TSFA_FAM_BASIC].data(), (int)fam[TSFA_FAM_BASIC].size(), row, w.data(),
                              (s % 2) ? w.data() : cum.data(), altc.data(), iw.data(), dectab.data(),
                              hints[TSFA_FAM_BASIC].a, hints[TSFA_FAM_BASIC].b, hints[TSFA_FAM_BASIC].alt, nullptr,
-                             times ? times + offsets[s] : nullptr, (s % 2) ? -1 : hints[TSFA_FAM_BASIC].c, ctx.data());
+                             times ? times + offsets[s] : nullptr, (s % 2) ? -1 : hints[TSFA_FAM_BASIC].c, ctx.data(),
+                             (s % 4 == 1) ? 0 : hints[TSFA_FAM_BASIC].d);
         }
         if (!fam[TSFA_FAM_SORT].empty()) {
             std::vector<double> srt(tsfa_pow2_ceil(maxn) + 8), w(1280), cq(5 * TSFA_CQ_MAX), sctx(8);

@@ -99,31 +99,42 @@ TSFA_DEV double blk_longest_run(const Blk &b, int n, P pred, int *iw) {
     }
     suf = run;
     if (all) pre = run;
-    blk_sync();
-    iw[4 * b.tid + 0] = pre;
-    iw[4 * b.tid + 1] = suf;
-    iw[4 * b.tid + 2] = best;
-    iw[4 * b.tid + 3] = (lo < hi) ? all : 2;  // 2 = empty segment
-    blk_sync();
-    double res = 0.0;
-    if (b.tid == 0) {
-        int carry = 0, gbest = 0;
-        for (int t = 0; t < b.nt; ++t) {
-            const int a = iw[4 * t + 3];
-            if (a == 2) continue;
-            if (a == 1) {
-                carry += iw[4 * t + 0];
-                if (carry > gbest) gbest = carry;
-            } else {
-                if (carry + iw[4 * t + 0] > gbest) gbest = carry + iw[4 * t + 0];
-                if (iw[4 * t + 2] > gbest) gbest = iw[4 * t + 2];
-                carry = iw[4 * t + 1];
-                if (carry > gbest) gbest = carry;
-            }
-        }
-        res = (double)gbest;
+#if TSFA_GPU
+    // (pre, suf, best, len) of adjacent segments combine associatively ("all true" <=> pre == len), so the wavefront
+    // stitches its 64 segments with an ordered butterfly (6 shuffle steps) instead of a serial walk by thread 0
+    int len = (hi > lo) ? (hi - lo) : 0;
+    const int lane = b.tid & 63;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const int opre = __shfl_xor(pre, d), osuf = __shfl_xor(suf, d), obest = __shfl_xor(best, d), olen = __shfl_xor(len, d);
+        const bool left = ((lane & d) == 0);  // this lane's aggregate lies to the left of its partner's
+        const int Lpre = left ? pre : opre, Lsuf = left ? suf : osuf, Lbest = left ? best : obest, Llen = left ? len : olen;
+        const int Rpre = left ? opre : pre, Rsuf = left ? osuf : suf, Rbest = left ? obest : best, Rlen = left ? olen : len;
+        int nb = (Lbest > Rbest) ? Lbest : Rbest;
+        if (Lsuf + Rpre > nb) nb = Lsuf + Rpre;
+        pre = (Lpre == Llen) ? Llen + Rpre : Lpre;
+        suf = (Rsuf == Rlen) ? Rlen + Lsuf : Rsuf;
+        best = nb;
+        len = Llen + Rlen;
     }
-    return blk_bcast0(b, res);
+    if (b.nt == 64) return (double)best;
+    const int nw = b.nt >> 6, wv = b.tid >> 6;
+    blk_sync();
+    if (lane == 0) { iw[4 * wv + 0] = pre; iw[4 * wv + 1] = suf; iw[4 * wv + 2] = best; iw[4 * wv + 3] = len; }
+    blk_sync();
+    int carry = 0, gbest = 0;  // every thread walks the (<= 16) wave aggregates
+    for (int t = 0; t < nw; ++t) {
+        const int tp = iw[4 * t + 0], ts = iw[4 * t + 1], tb = iw[4 * t + 2], tl = iw[4 * t + 3];
+        if (carry + tp > gbest) gbest = carry + tp;
+        if (tb > gbest) gbest = tb;
+        carry = (tp == tl) ? carry + tl : ts;
+    }
+    blk_sync();
+    return (double)gbest;
+#else
+    (void)iw;
+    return (double)best;  // nt = 1: one segment
+#endif
 }
 
 // agg_linear_trend (fc.py:2171), all distinct (chunk_len, f_agg) regressions of the plan at once:
@@ -313,6 +324,105 @@ TSFA_DEV void basic_epilogue(const Blk &b, const TsfaSpec *specs, int first, int
     }
 }
 
+// Count-type columns (ratio_beyond_r_sigma, count_above/below(_mean), value_count, range_count, number_crossing_m):
+// the host moves them to the front of the spec list (tsfa_prepare_family, hint d = their number) and they are
+// evaluated together here.  A wavefront keeps 1024 samples in registers (16 per lane); a predicate then costs one
+// v_cmp per register, its count is the popcount of the compare mask (scalar ALU) -- no per-lane accumulators, no
+// cross-lane reduction, no second trip to LDS.  Sign changes (number_crossing_m) are bit operations on the masks.
+// iw: LDS, >= ncount ints.  Results are integers, identical to the column loop's.
+TSFA_DEV bool basic_count_scaled(int calc) {  // count / n instead of the count
+    return calc == TSFA_C_RATIO_BEYOND_R_SIGMA || calc == TSFA_C_COUNT_ABOVE || calc == TSFA_C_COUNT_BELOW;
+}
+template <class XS>
+TSFA_DEV void basic_count_pass(const Blk &b, XS xs, int n, const TsfaSpec *specs, int ncount, const BasicStats &st,
+                               double *out_row, int *iw) {
+    const double mean = st.mean, dn = (double)n;
+#if TSFA_GPU
+    const int lane = b.tid & 63, wave = b.tid >> 6, nwave = b.nt >> 6;
+    blk_sync();
+    for (int e = b.tid; e < ncount; e += b.nt) iw[e] = 0;
+    blk_sync();
+    for (int base = wave * 1024; base < n; base += nwave * 1024) {
+        double xr[16];
+#pragma unroll
+        for (int u = 0; u < 16; ++u) {
+            const int i = base + u * 64 + lane;
+            xr[u] = (i < n) ? xs[i] : TSFA_NAN;  // NaN: every ordered comparison below is false
+        }
+        const double xnext = (base + 1024 < n) ? xs[base + 1024] : TSFA_NAN;
+        TsfaSpec nxt = specs[0];
+        for (int e = 0; e < ncount; ++e) {
+            const TsfaSpec sp = nxt;
+            nxt = specs[(e + 1 < ncount) ? e + 1 : e];
+            const double p0 = sp.p[0], p1 = sp.p[1];
+            int c = 0;
+#define TSFA_COUNT_LOOP(PRED)                                                         \
+    _Pragma("unroll") for (int u = 0; u < 16; ++u) { const double x = xr[u]; c += __popcll(__ballot(PRED)); }
+            switch (sp.calc) {
+            case TSFA_C_RATIO_BEYOND_R_SIGMA: { const double thr = p0 * st.std; TSFA_COUNT_LOOP(fabs(x - mean) > thr) } break;
+            case TSFA_C_COUNT_ABOVE_MEAN: TSFA_COUNT_LOOP(x > mean) break;
+            case TSFA_C_COUNT_BELOW_MEAN: TSFA_COUNT_LOOP(x < mean) break;
+            case TSFA_C_COUNT_ABOVE: TSFA_COUNT_LOOP(x >= p0) break;
+            case TSFA_C_COUNT_BELOW: TSFA_COUNT_LOOP(x <= p0) break;
+            case TSFA_C_RANGE_COUNT: TSFA_COUNT_LOOP(x >= p0 && x < p1) break;
+            case TSFA_C_VALUE_COUNT:
+                if (p0 != p0) {
+#pragma unroll
+                    for (int u = 0; u < 16; ++u) { const double x = xr[u]; c += __popcll(__ballot(base + u * 64 + lane < n && x != x)); }
+                } else {
+                    TSFA_COUNT_LOOP(x == p0)
+                }
+                break;
+            case TSFA_C_NUMBER_CROSSING_M: {
+                unsigned long long nb = (xnext > p0) ? 1ull : 0ull;  // (x[i + 1] > m) of the lane 63 element
+#pragma unroll
+                for (int u = 15; u >= 0; --u) {
+                    const unsigned long long m = __ballot(xr[u] > p0);
+                    const unsigned long long pv = __ballot(base + u * 64 + lane + 1 < n);  // pairs (i, i + 1) inside the series
+                    c += __popcll((m ^ ((m >> 1) | (nb << 63))) & pv);
+                    nb = m & 1ull;
+                }
+            } break;
+            default: break;
+            }
+#undef TSFA_COUNT_LOOP
+            if (lane == 0) __hip_atomic_fetch_add(&iw[e], c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        }
+    }
+    blk_sync();
+    for (int e = b.tid; e < ncount; e += b.nt) {
+        const TsfaSpec sp = specs[e];
+        const double c = (double)iw[e];
+        out_row[sp.col] = basic_count_scaled(sp.calc) ? c / dn : c;
+    }
+    blk_sync();
+#else
+    (void)iw; (void)b;
+    for (int e = 0; e < ncount; ++e) {
+        const TsfaSpec sp = specs[e];
+        const double p0 = sp.p[0], p1 = sp.p[1], thr = p0 * st.std;
+        double c = 0.0;
+        for (int i = 0; i < n; ++i) {
+            const double x = xs[i];
+            bool p = false;
+            switch (sp.calc) {
+            case TSFA_C_RATIO_BEYOND_R_SIGMA: p = fabs(x - mean) > thr; break;
+            case TSFA_C_COUNT_ABOVE_MEAN: p = x > mean; break;
+            case TSFA_C_COUNT_BELOW_MEAN: p = x < mean; break;
+            case TSFA_C_COUNT_ABOVE: p = x >= p0; break;
+            case TSFA_C_COUNT_BELOW: p = x <= p0; break;
+            case TSFA_C_RANGE_COUNT: p = (x >= p0 && x < p1); break;
+            case TSFA_C_VALUE_COUNT: p = (p0 != p0) ? (x != x) : (x == p0); break;
+            case TSFA_C_NUMBER_CROSSING_M: p = (i + 1 < n) && ((x > p0) != (xs[i + 1] > p0)); break;
+            default: break;
+            }
+            c += p ? 1.0 : 0.0;
+        }
+        out_row[sp.col] = basic_count_scaled(sp.calc) ? c / dn : c;
+    }
+#endif
+}
+
 // Evaluate the BASIC specs of one series.
 //   xs   : series as float64 in LDS, length n (n >= 1)
 //   w    : LDS work array of >= n doubles (chunk aggregates)
@@ -327,7 +437,8 @@ template <class XS>
 TSFA_DEV void fam_basic_series(const Blk &b, XS xs, int n, const TsfaSpec *specs, int nspecs,
                                double *out_row, double *w, double *cum, double *altc, int *iw, const double *dectab,
                                int peaks_maxsup, int alt_want_p, const TsfaAltPlan &alt, TsfaSpec *stage,
-                               const double *times = nullptr, int n_loop = -1, double *ctx = nullptr) {
+                               const double *times = nullptr, int n_loop = -1, double *ctx = nullptr,
+                               int n_count = 0) {
     TSFA_TICKER(tk, 0);
     BasicStats st;
     basic_stats(b, xs, n, st);
@@ -354,8 +465,11 @@ TSFA_DEV void fam_basic_series(const Blk &b, XS xs, int n, const TsfaSpec *specs
 
     bool have_peaks = false;
 
-    TsfaSpec nxt = spec_fetch(b, specs, nspecs, 0, stage);
-    for (int s = 0; s < nloop; ++s) {
+    // the count-type columns at the front of the list (host hint) are evaluated together from registers
+    const int ncnt = (n_count > 0 && n_count <= nloop) ? n_count : 0;
+    if (ncnt > 0) basic_count_pass(b, xs, n, specs, ncnt, st, out_row, iw);
+    TsfaSpec nxt = spec_fetch(b, specs, nspecs, ncnt, stage);
+    for (int s = ncnt; s < nloop; ++s) {
         TSFA_TICKER(tkc, 0);
         const TsfaSpec sp = nxt;
 #if !defined(TSFA_SPEC_LDS)

@@ -159,6 +159,20 @@ static inline void tsfa_prepare_family(int fam, std::vector<TsfaSpec> &specs, Ts
         if (s.calc == TSFA_C_LINEAR_TREND_TIMEWISE) { e = seen_ltt; seen_ltt = true; }
         (e ? epi : loop).push_back(s);
     }
+    // d = count-type columns, moved to the front of the column loop: fam_basic.h (basic_count_pass) evaluates them
+    // together from registers (at most 256: one LDS counter each)
+    {
+        std::vector<TsfaSpec> cnt, rest;
+        for (const auto &s : loop) {
+            const bool c = (s.calc == TSFA_C_RATIO_BEYOND_R_SIGMA || s.calc == TSFA_C_COUNT_ABOVE_MEAN ||
+                            s.calc == TSFA_C_COUNT_BELOW_MEAN || s.calc == TSFA_C_COUNT_ABOVE || s.calc == TSFA_C_COUNT_BELOW ||
+                            s.calc == TSFA_C_VALUE_COUNT || s.calc == TSFA_C_RANGE_COUNT || s.calc == TSFA_C_NUMBER_CROSSING_M);
+            ((c && cnt.size() < 256) ? cnt : rest).push_back(s);
+        }
+        h.d = (int)cnt.size();
+        loop = cnt;
+        loop.insert(loop.end(), rest.begin(), rest.end());
+    }
     h.c = (int)loop.size();
     specs = loop;
     specs.insert(specs.end(), epi.begin(), epi.end());
