@@ -15,7 +15,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 os.environ.setdefault("TSFA_LIB", os.path.join(ROOT, "tsfresh_amd", "libtsfresh_amd_ticks.so"))
 
-NAMED = {220: "sort/change_quantiles: corridor edges (quantiles)", 221: "sort/change_quantiles: pass 1",
+NAMED = {213: "basic: count pass (all count-type columns)", 214: "basic: sum pass (all sum-type columns)", 220: "sort/change_quantiles: corridor edges (quantiles)", 221: "sort/change_quantiles: pass 1",
          222: "sort/change_quantiles: reduce 12", 223: "sort/change_quantiles: pass 2", 224: "sort/change_quantiles: reduce 8",
          225: "basic/number_peaks: near pass (L/R up to 10)", 226: "basic/number_peaks: far candidates", 210: "basic: spec fetch (all columns)", 211: "basic: column bodies (all columns)",
          212: "basic: output stores (all columns)", 200: "basic/agg_linear_trend: chunk aggregates", 201: "basic/agg_linear_trend: regression sums",

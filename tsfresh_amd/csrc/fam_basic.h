@@ -356,6 +356,12 @@ TSFA_DEV void basic_count_pass(const Blk &b, XS xs, int n, const TsfaSpec *specs
             nxt = specs[(e + 1 < ncount) ? e + 1 : e];
             const double p0 = sp.p[0], p1 = sp.p[1];
             int c = 0;
+            // keep the compares inside this iteration: hoisted out of the entry loop, their 64-bit masks (and the
+            // validity masks) would have to live in scalar registers for the whole loop and get spilled
+            int ln = lane;
+            asm volatile("" : "+v"(ln));
+#pragma unroll
+            for (int u = 0; u < 16; ++u) asm volatile("" : "+v"(xr[u]));
 #define TSFA_COUNT_LOOP(PRED)                                                         \
     _Pragma("unroll") for (int u = 0; u < 16; ++u) { const double x = xr[u]; c += __popcll(__ballot(PRED)); }
             switch (sp.calc) {
@@ -368,7 +374,7 @@ TSFA_DEV void basic_count_pass(const Blk &b, XS xs, int n, const TsfaSpec *specs
             case TSFA_C_VALUE_COUNT:
                 if (p0 != p0) {
 #pragma unroll
-                    for (int u = 0; u < 16; ++u) { const double x = xr[u]; c += __popcll(__ballot(base + u * 64 + lane < n && x != x)); }
+                    for (int u = 0; u < 16; ++u) { const double x = xr[u]; c += __popcll(__ballot(base + u * 64 + ln < n && x != x)); }
                 } else {
                     TSFA_COUNT_LOOP(x == p0)
                 }
@@ -378,7 +384,7 @@ TSFA_DEV void basic_count_pass(const Blk &b, XS xs, int n, const TsfaSpec *specs
 #pragma unroll
                 for (int u = 15; u >= 0; --u) {
                     const unsigned long long m = __ballot(xr[u] > p0);
-                    const unsigned long long pv = __ballot(base + u * 64 + lane + 1 < n);  // pairs (i, i + 1) inside the series
+                    const unsigned long long pv = __ballot(base + u * 64 + ln + 1 < n);  // pairs (i, i + 1) inside the series
                     c += __popcll((m ^ ((m >> 1) | (nb << 63))) & pv);
                     nb = m & 1ull;
                 }
@@ -423,6 +429,149 @@ TSFA_DEV void basic_count_pass(const Blk &b, XS xs, int n, const TsfaSpec *specs
 #endif
 }
 
+// Sum-type columns (autocorrelation, c3, time_reversal_asymmetry_statistic, energy_ratio_by_chunks, cid_ce,
+// mean_abs_change, absolute_sum_of_changes, skewness, kurtosis): the host places them behind the count-type ones
+// (hint e = their number).  For a series of <= 1024 samples owned by ONE wavefront the samples stay in registers (16
+// per lane), the lagged operands of a column are fetched from LDS all at once (16 independent reads in flight instead
+// of a read -> multiply -> add round trip per loop iteration) and the lane sums run in the same order as the column
+// loop's (identical results).  Other shapes leave these columns to the column loop.
+template <class XS>
+TSFA_DEV bool basic_sum_pass(const Blk &b, XS xs, int n, const TsfaSpec *specs, int first, int nsum, const BasicStats &st,
+                             double *out_row) {
+#if TSFA_GPU
+    if (b.nt != 64 || n > 1024 || nsum <= 0) return false;
+    const int lane = b.tid;
+    const double mean = st.mean, dn = (double)n;
+    double xr[16];
+#pragma unroll
+    for (int u = 0; u < 16; ++u) {
+        const int i = u * 64 + lane;
+        xr[u] = xs[(i < n) ? i : (n - 1)];  // unconditional reads (clamped index): every use below is masked
+    }
+#define TSFA_LOAD_LAG(Y, LAG)                                                                         \
+    double Y[16];                                                                                     \
+    _Pragma("unroll") for (int u = 0; u < 16; ++u) {                                                  \
+        const int i = u * 64 + lane + (LAG);                                                          \
+        Y[u] = xs[(i < n) ? i : (n - 1)];                                                             \
+    }
+    TsfaSpec nxt = specs[first];
+    for (int e = 0; e < nsum; ++e) {
+        const TsfaSpec sp = nxt;
+        nxt = specs[first + ((e + 1 < nsum) ? e + 1 : e)];
+        const double p0 = sp.p[0], p1 = sp.p[1];
+        double v = TSFA_NAN;
+        // nothing of a column is hoisted out of the entry loop (centred copies, masks: they would be spilled)
+#pragma unroll
+        for (int u = 0; u < 16; ++u) asm volatile("" : "+v"(xr[u]));
+        switch (sp.calc) {
+        case TSFA_C_AUTOCORRELATION: {                                   // fc.py:1919
+            const int lag = (int)p0;
+            if (n < lag) break;
+            TSFA_LOAD_LAG(y, lag)
+            double a = 0.0;
+#pragma unroll
+            for (int u = 0; u < 16; ++u) {
+                const double t = (xr[u] - mean) * (y[u] - mean);
+                a += (u * 64 + lane < n - lag) ? t : 0.0;
+            }
+            a = blk_sum(b, a);
+            if (!(fabs(st.var) <= 1e-8)) v = a / ((double)(n - lag) * st.var);  // np.isclose(v, 0) -> NaN
+        } break;
+        case TSFA_C_C3:                                                  // fc.py:1600
+        case TSFA_C_TIME_REVERSAL_ASYMMETRY_STATISTIC: {                 // fc.py:1557
+            const int lag = (int)p0;
+            if (2 * lag >= n) { v = 0.0; break; }
+            const int m = n - 2 * lag;
+            TSFA_LOAD_LAG(y1, lag)
+            TSFA_LOAD_LAG(y2, 2 * lag)
+            double a = 0.0;
+            if (sp.calc == TSFA_C_C3) {
+#pragma unroll
+                for (int u = 0; u < 16; ++u) { const double t = y2[u] * y1[u] * xr[u]; a += (u * 64 + lane < m) ? t : 0.0; }
+            } else {
+#pragma unroll
+                for (int u = 0; u < 16; ++u) {
+                    const double t = y2[u] * y2[u] * y1[u] - y1[u] * xr[u] * xr[u];
+                    a += (u * 64 + lane < m) ? t : 0.0;
+                }
+            }
+            v = blk_sum(b, a) / (double)m;
+        } break;
+        case TSFA_C_ENERGY_RATIO_BY_CHUNKS: {                            // fc.py:2226 (np.array_split)
+            const int nseg = (int)p0, foc = (int)p1;
+            const int q = n / nseg, rem = n % nseg;
+            const int lo = foc * q + (foc < rem ? foc : rem);
+            const int hi = lo + q + (foc < rem ? 1 : 0);
+            double a = 0.0;
+#pragma unroll
+            for (int u = 0; u < 16; ++u) { const int i = u * 64 + lane; a += (i >= lo && i < hi) ? xr[u] * xr[u] : 0.0; }
+            a = blk_sum(b, a);
+            v = (st.sumsq == 0.0) ? TSFA_NAN : a / st.sumsq;
+        } break;
+        case TSFA_C_CID_CE: {                                            // fc.py:567
+            const bool normalize = (p0 != 0.0);
+            if (normalize && st.std == 0.0) { v = 0.0; break; }
+            const double sd = st.std;
+            TSFA_LOAD_LAG(y, 1)
+            double a = 0.0;
+#pragma unroll
+            for (int u = 0; u < 16; ++u) {
+                const double d = normalize ? ((y[u] - mean) / sd - (xr[u] - mean) / sd) : (y[u] - xr[u]);
+                a += (u * 64 + lane < n - 1) ? d * d : 0.0;
+            }
+            v = sqrt(blk_sum(b, a));
+        } break;
+        case TSFA_C_MEAN_ABS_CHANGE:                                     // fc.py:604
+        case TSFA_C_ABSOLUTE_SUM_OF_CHANGES: {                           // fc.py:796
+            TSFA_LOAD_LAG(y, 1)
+            double a = 0.0;
+#pragma unroll
+            for (int u = 0; u < 16; ++u) a += (u * 64 + lane < n - 1) ? fabs(y[u] - xr[u]) : 0.0;
+            a = blk_sum(b, a);
+            if (sp.calc == TSFA_C_MEAN_ABS_CHANGE) v = (n > 1) ? a / (double)(n - 1) : TSFA_NAN;
+            else v = a;
+        } break;
+        case TSFA_C_SKEWNESS:                                            // fc.py:749 -> pandas nanops.nanskew
+        case TSFA_C_KURTOSIS: {                                          // fc.py:766 -> pandas nanops.nankurt
+            const bool skew = (sp.calc == TSFA_C_SKEWNESS);
+            double m2 = 0.0, mh = 0.0;
+#pragma unroll
+            for (int u = 0; u < 16; ++u) {
+                const double a = xr[u] - mean;
+                const double a2 = a * a;
+                const bool in = (u * 64 + lane < n);
+                m2 += in ? a2 : 0.0;
+                mh += in ? (skew ? a2 * a : a2 * a2) : 0.0;
+            }
+            m2 = blk_sum(b, m2);
+            mh = blk_sum(b, mh);
+            if (skew) {
+                if (fabs(m2) < 1e-14) m2 = 0.0;
+                if (fabs(mh) < 1e-14) mh = 0.0;
+                if (n < 3) v = TSFA_NAN;
+                else if (m2 == 0.0) v = 0.0;
+                else v = (dn * sqrt(dn - 1.0) / (dn - 2.0)) * (mh / pow(m2, 1.5));
+            } else if (n >= 4) {
+                const double adj = 3.0 * (dn - 1.0) * (dn - 1.0) / ((dn - 2.0) * (dn - 3.0));
+                double num = dn * (dn + 1.0) * (dn - 1.0) * mh;
+                double den = (dn - 2.0) * (dn - 3.0) * m2 * m2;
+                if (fabs(num) < 1e-14) num = 0.0;
+                if (fabs(den) < 1e-14) den = 0.0;
+                v = (den == 0.0) ? 0.0 : (num / den - adj);
+            }
+        } break;
+        default: break;
+        }
+        if (lane == 0) out_row[sp.col] = v;
+    }
+#undef TSFA_LOAD_LAG
+    return true;
+#else
+    (void)b; (void)xs; (void)n; (void)specs; (void)first; (void)nsum; (void)st; (void)out_row;
+    return false;
+#endif
+}
+
 // Evaluate the BASIC specs of one series.
 //   xs   : series as float64 in LDS, length n (n >= 1)
 //   w    : LDS work array of >= n doubles (chunk aggregates)
@@ -438,7 +587,7 @@ TSFA_DEV void fam_basic_series(const Blk &b, XS xs, int n, const TsfaSpec *specs
                                double *out_row, double *w, double *cum, double *altc, int *iw, const double *dectab,
                                int peaks_maxsup, int alt_want_p, const TsfaAltPlan &alt, TsfaSpec *stage,
                                const double *times = nullptr, int n_loop = -1, double *ctx = nullptr,
-                               int n_count = 0) {
+                               int n_count = 0, int n_sum = 0) {
     TSFA_TICKER(tk, 0);
     BasicStats st;
     basic_stats(b, xs, n, st);
@@ -464,12 +613,19 @@ TSFA_DEV void fam_basic_series(const Blk &b, XS xs, int n, const TsfaSpec *specs
     double imq_sabs = 0.0;
 
     bool have_peaks = false;
+    int peaks_p = 0;  // window length of the sliding maxima currently held in w (number_peaks fast path), 0 = none
 
     // the count-type columns at the front of the list (host hint) are evaluated together from registers
     const int ncnt = (n_count > 0 && n_count <= nloop) ? n_count : 0;
     if (ncnt > 0) basic_count_pass(b, xs, n, specs, ncnt, st, out_row, iw);
-    TsfaSpec nxt = spec_fetch(b, specs, nspecs, ncnt, stage);
-    for (int s = ncnt; s < nloop; ++s) {
+    TSFA_TICK(tk, b, 213);
+    // ... and behind them the sum-type columns (single-wavefront series of <= 1024 samples; else the column loop)
+    int sbeg = ncnt;
+    if (ncnt == n_count && n_sum > 0 && ncnt + n_sum <= nloop && basic_sum_pass(b, xs, n, specs, ncnt, n_sum, st, out_row))
+        sbeg = ncnt + n_sum;
+    TSFA_TICK(tk, b, 214);
+    TsfaSpec nxt = spec_fetch(b, specs, nspecs, (sbeg < nspecs) ? sbeg : 0, stage);
+    for (int s = sbeg; s < nloop; ++s) {
         TSFA_TICKER(tkc, 0);
         const TsfaSpec sp = nxt;
 #if !defined(TSFA_SPEC_LDS)
@@ -619,6 +775,69 @@ TSFA_DEV void fam_basic_series(const Blk &b, XS xs, int n, const TsfaSpec *specs
             // are compacted and scanned on to the largest support of the plan.  All supports then read (L, R).
             const int sup = (int)p0;
             if (sup < 1) { v = 0.0; break; }
+#if TSFA_GPU
+            if (n <= 16 * b.nt) {
+                if (n <= 2 * sup) { v = 0.0; break; }
+                // Sliding-window maxima by doubling: M_p[i] = max(x[i .. i + p - 1]), M_2p[i] = max(M_p[i], M_p[i + p]).
+                // With p the largest power of two <= s, the s samples left of i are covered by M_p[i - s] and
+                // M_p[i - p], the s samples right of it by M_p[i + 1] and M_p[i + 1 + s - p]: a peak test is four
+                // reads, two maxima, two compares -- instead of 2 s compares (or the distance scan below).  The
+                // maxima are kept in w in the input precision (exact) and doubled in place as the supports grow
+                // (every thread holds its <= 16 new values in registers across the barrier).
+                typedef typename XS::elem ST;
+                ST *mb = (ST *)(void *)w;
+                int tp = 1;
+                while (2 * tp <= sup) tp *= 2;
+                if (peaks_p == 0 || peaks_p > tp) peaks_p = 1;
+                have_peaks = false;   // w no longer holds the distance codes ...
+                have_cumsum = false;  // ... nor the cumulative sums
+                while (peaks_p < tp) {
+                    const ST *src = (peaks_p == 1) ? xs.p : (const ST *)mb;
+                    ST r[16];
+#pragma unroll
+                    for (int u = 0; u < 16; ++u) {
+                        const int i = u * b.nt + b.tid;
+                        const int i0 = (i < n) ? i : (n - 1), i1 = (i + peaks_p < n) ? (i + peaks_p) : (n - 1);
+                        const ST a0 = src[i0], a1 = src[i1];
+                        r[u] = (a0 > a1) ? a0 : a1;
+                    }
+                    blk_sync();
+#pragma unroll
+                    for (int u = 0; u < 16; ++u) {
+                        const int i = u * b.nt + b.tid;
+                        if (i < n) mb[i] = r[u];
+                    }
+                    blk_sync();
+                    peaks_p *= 2;
+                }
+                const ST *src = (tp == 1) ? xs.p : (const ST *)mb;
+                // all reads of all 16 positions are issued unconditionally (clamped index, bitwise predicate): a
+                // short-circuit here turns into a chain of dependent LDS round trips
+                int ci = 0;
+#pragma unroll 1
+                for (int h = 0; h < 16; h += 8) {  // eight positions at a time: 40 reads in flight, no spills
+                    ST xi[8], l0[8], l1[8], r0[8], r1[8];
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) {
+                        const int i = (h + u) * b.nt + b.tid;
+                        const int ic = ((i >= sup) & (i < n - sup)) ? i : sup;  // any in-range position (n > 2 sup here)
+                        xi[u] = xs.p[ic];
+                        l0[u] = src[ic - sup];
+                        l1[u] = src[ic - tp];
+                        r0[u] = src[ic + 1];
+                        r1[u] = src[ic + 1 + sup - tp];
+                    }
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) {
+                        const int i = (h + u) * b.nt + b.tid;
+                        const ST lm = (l0[u] > l1[u]) ? l0[u] : l1[u], rm = (r0[u] > r1[u]) ? r0[u] : r1[u];
+                        ci += (int)(i >= sup) & (int)(i < n - sup) & (int)(xi[u] > lm) & (int)(xi[u] > rm);
+                    }
+                }
+                v = blk_sum(b, (double)ci);
+                break;
+            }
+#endif
             if (sup > 254) {  // beyond the 8-bit distance code: direct evaluation
                 double c = 0.0;
                 for (int i = sup + b.tid; i < n - sup; i += b.nt) {
@@ -709,6 +928,7 @@ TSFA_DEV void fam_basic_series(const Blk &b, XS xs, int n, const TsfaSpec *specs
                 // np.cumsum is a serial accumulation: one lane builds it once (in numpy's order, so that the >= q
                 // comparison is bit-identical), every q then scans it in parallel
                 have_peaks = false;  // cum may alias the peak distances
+                peaks_p = 0;
                 imq_sabs = np_sum(b, n, [=](int i) { return fabs(xs[i]); });
                 blk_sync();
                 if (b.tid == 0) {
@@ -886,6 +1106,8 @@ TSFA_DEV void fam_basic_series(const Blk &b, XS xs, int n, const TsfaSpec *specs
                 if (((int)sp.p[3]) >= 128) {
                     have_cumsum = false;  // w may alias cum ...
                     have_peaks = false;   // ... and holds the peak distances
+                peaks_p = 0;
+                    peaks_p = 0;
                     alt_fill_all(b, xs, n, alt, w, (double *)(void *)iw, altc);
                 }
                 v = altc[8 * (((int)sp.p[3]) & 127) + 2 + attr];
@@ -902,6 +1124,7 @@ TSFA_DEV void fam_basic_series(const Blk &b, XS xs, int n, const TsfaSpec *specs
                 const int m = (n + cl - 1) / cl;
                 have_cumsum = false;  // w may alias cum ...
                 have_peaks = false;   // ... and holds the peak distances
+                peaks_p = 0;
                 blk_sync();
                 for (int c = b.tid; c < m; c += b.nt) {  // fc.py:176 _aggregate_on_chunks
                     const int lo = c * cl;

@@ -395,6 +395,7 @@ int tsfa_extract_windows(tsfa_plan *plan, const void *values, int32_t dtype, con
         a.hint_b = plan->hints[f].b;
         a.hint_c = plan->hints[f].c;
         a.hint_d = plan->hints[f].d;
+        a.hint_e = plan->hints[f].e;
         a.alt = plan->hints[f].alt;
         a.cq = plan->hints[f].cq;
         int aux = 0;

@@ -53,6 +53,7 @@ struct NpScratch {  // scratch for the numpy-order pairwise sum
 // exact, so every expression downstream is the float64 arithmetic of the reference on x.astype(float64).
 template <typename ST>
 struct XsView {
+    typedef ST elem;
     const ST *p;
     TSFA_MEM double operator[](int i) const { return (double)p[i]; }
 };

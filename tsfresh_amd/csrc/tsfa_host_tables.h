@@ -77,7 +77,7 @@ static inline void tsfa_build_twiddles(std::vector<double> &twc, std::vector<dou
 // carries its output column, so the order on the device is free).
 #define TSFA_ALT_SLOTS 16
 struct TsfaFamHints {
-    int a = 0, b = 0, c = 0, d = -1;
+    int a = 0, b = 0, c = 0, d = -1, e = 0;
     TsfaAltPlan alt;  // BASIC
     TsfaCqPlan cq;    // SORT
 };
@@ -170,8 +170,19 @@ static inline void tsfa_prepare_family(int fam, std::vector<TsfaSpec> &specs, Ts
             ((c && cnt.size() < 256) ? cnt : rest).push_back(s);
         }
         h.d = (int)cnt.size();
+        // e = sum-type columns, next in line (basic_sum_pass)
+        std::vector<TsfaSpec> sums, rest2;
+        for (const auto &s : rest) {
+            const bool c = (s.calc == TSFA_C_AUTOCORRELATION || s.calc == TSFA_C_C3 ||
+                            s.calc == TSFA_C_TIME_REVERSAL_ASYMMETRY_STATISTIC || s.calc == TSFA_C_ENERGY_RATIO_BY_CHUNKS ||
+                            s.calc == TSFA_C_CID_CE || s.calc == TSFA_C_MEAN_ABS_CHANGE ||
+                            s.calc == TSFA_C_ABSOLUTE_SUM_OF_CHANGES || s.calc == TSFA_C_SKEWNESS || s.calc == TSFA_C_KURTOSIS);
+            (c ? sums : rest2).push_back(s);
+        }
+        h.e = (int)sums.size();
         loop = cnt;
-        loop.insert(loop.end(), rest.begin(), rest.end());
+        loop.insert(loop.end(), sums.begin(), sums.end());
+        loop.insert(loop.end(), rest2.begin(), rest2.end());
     }
     h.c = (int)loop.size();
     specs = loop;

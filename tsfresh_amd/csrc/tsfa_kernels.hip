@@ -24,7 +24,7 @@ template <typename T>
 __global__ void __launch_bounds__(256, 2) k_basic(const T *__restrict__ values, const int64_t *__restrict__ starts, const int64_t *__restrict__ ends, int64_t n_series,
                         const TsfaSpec *__restrict__ specs, int nspecs, double *__restrict__ out, int64_t ld,
                         const double *__restrict__ dectab, int maxn, int hint_a, int hint_b,
-                        const double *__restrict__ times, const TsfaAltPlan alt, int n_loop, int n_count) {
+                        const double *__restrict__ times, const TsfaAltPlan alt, int n_loop, int n_count, int n_sum) {
     const int64_t sidx = blockIdx.x;
     if (sidx >= n_series) return;
     const int64_t off = starts[sidx];
@@ -40,7 +40,7 @@ __global__ void __launch_bounds__(256, 2) k_basic(const T *__restrict__ values, 
         blk_sync();
     }
     fam_basic_series(b, XsView<T>{xs}, n, specs, nspecs, out + sidx * ld, L.w, L.cum, L.altc, L.iw, dectab, hint_a,
-                     hint_b, alt, L.stage, times ? times + off : nullptr, n_loop, L.ctx, n_count);
+                     hint_b, alt, L.stage, times ? times + off : nullptr, n_loop, L.ctx, n_count, n_sum);
     TSFA_TICKS_END();
 }
 
@@ -290,7 +290,7 @@ static int launch_all_t(const TsfaLaunch &a, const T *values) {
         const size_t lds = L.carve(nullptr, a.maxn, nt, (int)sizeof(T));
         if ((rc = set_lds(k_basic<T>, lds))) return rc;
         k_basic<T><<<grid, nt, lds, st>>>(values, a.starts, a.ends, a.n_series, a.specs, a.nspecs, a.out, a.ld, a.dectab, a.maxn,
-                                          a.hint_a, a.hint_b, a.times, a.alt, a.hint_c, a.hint_d);
+                                          a.hint_a, a.hint_b, a.times, a.alt, a.hint_c, a.hint_d, a.hint_e);
     } else if (a.fam == TSFA_FAM_SORT) {
         SortLds L;
         const size_t lds = L.carve(nullptr, a.maxn, nt, (int)sizeof(T));

@@ -34,7 +34,7 @@ struct TsfaLaunch {
     TsfaSeqGroup seq;       // SEQ: the (<= TSFA_LZ_MAX_GROUP) specs this launch parses side by side
     int ar_P;               // AR: leading dimension of the normal matrices
     int cwt_rowv;           // CWT peaks: second CWT row resident in LDS
-    int hint_a, hint_b, hint_c, hint_d;  // tsfa_prepare_family (BASIC, SORT, SPECTRAL, AR)
+    int hint_a, hint_b, hint_c, hint_d, hint_e;  // tsfa_prepare_family (BASIC, SORT, SPECTRAL, AR)
     int ent_cnt;            // ENTROPY: per-template LDS counters (symmetric sweep)
     int ent_fast;           // ENTROPY: only m = 2 specs and ent_cnt: the kernel variant without the fallback sweeps
 };
