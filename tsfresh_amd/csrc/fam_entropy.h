@@ -540,6 +540,23 @@ TSFA_DEV void entropy_sweep_m2(const Blk &b, const XT *xs, int n, const double *
 
 // perm[0 .. n-2] = indices of the length-2 templates sorted by their first sample (ties by index); np2 = padded size
 #if TSFA_GPU
+// F32: the samples are exact float32 values (float32 input staged as float64): one packed 64-bit sort key
+template <int E, typename XT>
+TSFA_DEVN void entropy_sort_templates_packed(const Blk &b, const XT *xs, int n, unsigned short *perm) {
+    const int nrow_m = n - 1;
+    unsigned long long pk[E];
+#pragma unroll
+    for (int e = 0; e < E; ++e) {
+        const int g = b.tid * E + e;
+        pk[e] = (g < nrow_m) ? sort_pack_f32((float)xs[g], g) : sort_pack_f32((float)TSFA_INF, 0xFFFF);
+    }
+    blk_sort_packed_regs<E>(b, pk, perm, [=](int i) { return (i == 0xFFFF) ? (float)TSFA_INF : (float)xs[i]; });
+    blk_sync();
+#pragma unroll
+    for (int e = 0; e < E; ++e) perm[b.tid * E + e] = (unsigned short)(pk[e] & 0xFFFFull);
+    blk_sync();
+}
+
 template <int E, typename XT>
 TSFA_DEVN void entropy_sort_templates_regs(const Blk &b, const XT *xs, int n, unsigned short *perm) {
     const int nrow_m = n - 1;
@@ -560,9 +577,14 @@ TSFA_DEVN void entropy_sort_templates_regs(const Blk &b, const XT *xs, int n, un
 #endif
 
 template <typename XT>
-TSFA_DEV void entropy_sort_templates(const Blk &b, const XT *xs, int n, unsigned short *perm, int np2) {
+TSFA_DEV void entropy_sort_templates(const Blk &b, const XT *xs, int n, unsigned short *perm, int np2, bool f32 = false) {
     const int nrow_m = n - 1;
 #if TSFA_GPU
+    if (f32) {
+        if (np2 == b.nt) { entropy_sort_templates_packed<1>(b, xs, n, perm); return; }
+        if (np2 == 2 * b.nt) { entropy_sort_templates_packed<2>(b, xs, n, perm); return; }
+        if (np2 == 4 * b.nt) { entropy_sort_templates_packed<4>(b, xs, n, perm); return; }
+    }
     // register-blocked sort when every thread gets 1, 2 or 4 templates (np2 = E * nt)
     if (np2 == b.nt) { entropy_sort_templates_regs<1>(b, xs, n, perm); return; }
     if (np2 == 2 * b.nt) { entropy_sort_templates_regs<2>(b, xs, n, perm); return; }
@@ -641,7 +663,7 @@ TSFA_DEV double sampen_from_acc(const EntAcc &a, int n, int m) {
 //          sums are finished before the first sweep.  The symmetric sweep needs XT = double.
 //   FAST : the plan holds only m = 2 specs and cnt != null (decided on the host): the ordered-pair and generic
 //          sweeps are compiled out, which keeps the register allocation of the hot kernel free of spills.
-template <typename XT, bool FAST = false>
+template <typename XT, bool FAST = false, bool F32 = false>
 TSFA_DEV void fam_entropy_series(const Blk &b, XT *xs, int n, const TsfaSpec *specs, int nspecs, double *out_row,
                                  double *thr, unsigned short *perm, ent_ref *refs, unsigned int *cnt,
                                  int staged_ok = 1) {
@@ -678,7 +700,7 @@ TSFA_DEV void fam_entropy_series(const Blk &b, XT *xs, int n, const TsfaSpec *sp
             for (int k = nk; k < TSFA_ENT_MAXK; ++k) thr[k] = -1.0;  // never matches
         blk_sync();
         if (n >= 3 && !sorted) {
-            entropy_sort_templates(b, xs, n, perm, next_pow2(n - 1));
+            entropy_sort_templates(b, xs, n, perm, next_pow2(n - 1), F32);
             // pad: absent templates point at the +inf sentinels
             const int padded = ((n - 1 + 63) / 64) * 64 + 32;
             for (int i = n - 1 + b.tid; i < padded; i += b.nt) perm[i] = (unsigned short)n;

@@ -128,7 +128,7 @@ __global__ void __launch_bounds__(256, 4) k_entropy(const T *__restrict__ values
     TSFA_TICKS_BEGIN();
     Blk b{(int)threadIdx.x, (int)blockDim.x, L.red, L.np};
     stage_series(b, values + off, n, L.xs);
-    fam_entropy_series<double, FAST>(b, L.xs, n, specs, nspecs, out + sidx * ld, L.thr, L.perm, L.refs, L.cnt);
+    fam_entropy_series<double, FAST, sizeof(T) == 4>(b, L.xs, n, specs, nspecs, out + sidx * ld, L.thr, L.perm, L.refs, L.cnt);
     TSFA_TICKS_END();
 }
 
