@@ -534,8 +534,13 @@ TSFA_DEV void fam_sort_series(const Blk &b, const ST *xs_raw, int n, const TsfaS
     const int np2 = next_pow2(n);
     TSFA_TICKER(tk, 0);
     blk_sync();
-    for (int i = b.tid; i < np2; i += b.nt) srt_raw[i] = (i < n) ? xs_raw[i] : (ST)TSFA_INF;
-    blk_bitonic_sort(b, srt_raw, np2);
+#if TSFA_GPU
+    if (!blk_sorted_copy_regs(b, xs_raw, n, srt_raw, np2))
+#endif
+    {
+        for (int i = b.tid; i < np2; i += b.nt) srt_raw[i] = (i < n) ? xs_raw[i] : (ST)TSFA_INF;
+        blk_bitonic_sort(b, srt_raw, np2);
+    }
     TSFA_TICK(tk, b, 104);
     const double dn = (double)n;
     const double vmin = srt[0], vmax = srt[n - 1];

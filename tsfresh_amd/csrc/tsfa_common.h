@@ -749,6 +749,107 @@ TSFA_DEV void blk_sort_packed_regs(const Blk &b, unsigned long long (&pk)[E], un
         }
     }
 }
+
+// ---------------------------------------------------------------------------------------------
+// Keys only (float or double), E = np2 / nt of them per thread: a compare-exchange is v_min + v_max (+ a select on
+// the direction); only the strides >= 64 * E go through LDS (xchg, np2 keys -- the destination array itself).
+// For 1024 float keys on 128 threads: 27 in-register + 27 cross-lane stages and ONE barrier pair instead of 55.
+// ---------------------------------------------------------------------------------------------
+TSFA_DEV float sort_min(float a, float b) { return __builtin_fminf(a, b); }
+TSFA_DEV float sort_max(float a, float b) { return __builtin_fmaxf(a, b); }
+TSFA_DEV double sort_min(double a, double b) { return __builtin_fmin(a, b); }
+TSFA_DEV double sort_max(double a, double b) { return __builtin_fmax(a, b); }
+template <int LX>
+TSFA_DEV float lane_xor_key(float v) { return __int_as_float(lane_xor_i32<LX>(__float_as_int(v))); }
+template <int LX>
+TSFA_DEV double lane_xor_key(double v) { return lane_xor_f64<LX>(v); }
+
+template <int E, int J, typename K>
+TSFA_DEV void sortk_stage_regs(K (&key)[E], int g0, int k) {
+#pragma unroll
+    for (int e = 0; e < E; ++e) {
+        if ((e & J) != 0) continue;
+        const int f = e | J;
+        const bool up = (((g0 + e) & k) == 0);
+        const K lo = sort_min(key[e], key[f]), hi = sort_max(key[e], key[f]);
+        key[e] = up ? lo : hi;
+        key[f] = up ? hi : lo;
+    }
+}
+template <int E, int LX, typename K>
+TSFA_DEV void sortk_stage_lanes(K (&key)[E], int g0, int k, int j) {
+    const bool lower = ((g0 & j) == 0);
+#pragma unroll
+    for (int e = 0; e < E; ++e) {
+        const K o = lane_xor_key<LX>(key[e]);
+        const bool up = (((g0 + e) & k) == 0);
+        const K lo = sort_min(key[e], o), hi = sort_max(key[e], o);
+        key[e] = (lower == up) ? lo : hi;
+    }
+}
+template <int E, typename K>
+TSFA_DEV void blk_sort_keys_regs(const Blk &b, K (&key)[E], K *xchg) {
+    const int np2 = E * b.nt;
+    const int g0 = b.tid * E;
+    for (int k = 2; k <= np2; k <<= 1) {
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            if (j < E) {
+                switch (j) {
+                case 1: if (E > 1) sortk_stage_regs<E, (E > 1 ? 1 : 0)>(key, g0, k); break;
+                case 2: if (E > 2) sortk_stage_regs<E, (E > 2 ? 2 : 0)>(key, g0, k); break;
+                case 4: if (E > 4) sortk_stage_regs<E, (E > 4 ? 4 : 0)>(key, g0, k); break;
+                case 8: if (E > 8) sortk_stage_regs<E, (E > 8 ? 8 : 0)>(key, g0, k); break;
+                default: break;
+                }
+            } else if (j < 64 * E) {
+                switch (j / E) {
+                case 1: sortk_stage_lanes<E, 1>(key, g0, k, j); break;
+                case 2: sortk_stage_lanes<E, 2>(key, g0, k, j); break;
+                case 4: sortk_stage_lanes<E, 4>(key, g0, k, j); break;
+                case 8: sortk_stage_lanes<E, 8>(key, g0, k, j); break;
+                case 16: sortk_stage_lanes<E, 16>(key, g0, k, j); break;
+                default: sortk_stage_lanes<E, 32>(key, g0, k, j); break;
+                }
+            } else {
+                blk_sync();
+#pragma unroll
+                for (int e = 0; e < E; ++e) xchg[g0 + e] = key[e];
+                blk_sync();
+                const bool lower = ((g0 & j) == 0);
+#pragma unroll
+                for (int e = 0; e < E; ++e) {
+                    const K o = xchg[(g0 + e) ^ j];
+                    const bool up = (((g0 + e) & k) == 0);
+                    const K lo = sort_min(key[e], o), hi = sort_max(key[e], o);
+                    key[e] = (lower == up) ? lo : hi;
+                }
+            }
+        }
+    }
+}
+// dst[0 .. np2) = src[0 .. n) sorted ascending, padded with +inf; false if the shape has no register-blocked variant
+template <int E, typename K>
+TSFA_DEVN void blk_sorted_copy_regs_e(const Blk &b, const K *src, int n, K *dst) {
+    K key[E];
+#pragma unroll
+    for (int e = 0; e < E; ++e) {
+        const int g = b.tid * E + e;
+        key[e] = (g < n) ? src[g] : (K)TSFA_INF;
+    }
+    blk_sort_keys_regs<E>(b, key, dst);
+    blk_sync();
+#pragma unroll
+    for (int e = 0; e < E; ++e) dst[b.tid * E + e] = key[e];
+    blk_sync();
+}
+template <typename K>
+TSFA_DEV bool blk_sorted_copy_regs(const Blk &b, const K *src, int n, K *dst, int np2) {
+    if (np2 == 2 * b.nt) { blk_sorted_copy_regs_e<2>(b, src, n, dst); return true; }
+    if (np2 == 4 * b.nt) { blk_sorted_copy_regs_e<4>(b, src, n, dst); return true; }
+    if (np2 == 8 * b.nt) { blk_sorted_copy_regs_e<8>(b, src, n, dst); return true; }
+    if (np2 == 16 * b.nt) { blk_sorted_copy_regs_e<16>(b, src, n, dst); return true; }
+    return false;
+}
 #endif
 
 // ---------------------------------------------------------------------------------------------
