@@ -143,7 +143,7 @@ extern "C" int tsfa_emul_extract_timed(const tsfa_feature_spec *specs, int n_spe
             for (int s0 = 0; s0 < nsq; s0 += group) {
                 TsfaSeqGroup g;
                 lz_build_group(fam[TSFA_FAM_SEQ].data() + s0, std::min(group, nsq - s0), maxn, &g);
-                std::vector<uint32_t> seqw(((size_t)g.nb * g.stride + 16) / 4 + 1), tab((size_t)g.ttotal + 4);
+                std::vector<uint32_t> seqw(((size_t)g.stride + 16) / 4 + 1), tab((size_t)g.ttotal + 4);
                 std::vector<double> edges(g.etotal + 4);
                 fam_seq_series(b, [=](int i) { return xp[i]; }, n, g, row, (unsigned char *)seqw.data(), tab.data(),
                                edges.data());

@@ -27,7 +27,8 @@
 #define TSFA_LZ_MAX_GROUP 8
 #define TSFA_LZ_DIRECT_MAX_BYTES 4096
 
-enum { TSFA_LZ_DIRECT16 = 0, TSFA_LZ_HASH32 = 2 };
+enum { TSFA_LZ_DIRECT16 = 0, TSFA_LZ_HASH32 = 2, TSFA_LZ_BITS = 3 };
+#define TSFA_LZ_BITS_MAX 16384  // bits of the implicit-trie table of a TSFA_LZ_BITS chain
 
 // Most phrases a parse of n symbols over an alphabet of b symbols can produce: all phrases are distinct strings, so
 // the count is maximised by taking every string of length 1, then every string of length 2, ...
@@ -53,17 +54,37 @@ struct LzTable {
     int cap;    // hash: slots (power of two, load factor <= 0.6); direct: (max phrases + 1) * bins entries
     int lg;     // hash: log2(cap)
     int words;  // uint32 words of LDS
+    int nbt;    // TSFA_LZ_BITS: nodes of the implicit trie (ids 0 .. nbt-1 own a row of `bins` child bits)
 };
 // Table of the parse of <= n symbols over `bins` symbols.  Shared by the host (LDS sizing) and the emulation.
 TSFA_SEQ_HD LzTable lz_table_plan(int bins, int n) {
     LzTable t;
+    t.nbt = 0;
     const int P = lz_max_phrases(bins, n);
     const long long direct_bytes = 2LL * (P + 1) * bins;
-    if (direct_bytes <= TSFA_LZ_DIRECT_MAX_BYTES && P < 65535) {
+    // chains of one launch run in the lanes of ONE wavefront when they share a code path, so the implicit-trie
+    // form is preferred for every alphabet it covers (direct child tables remain for larger alphabets that fit)
+    if (bins > 255 && direct_bytes <= TSFA_LZ_DIRECT_MAX_BYTES && P < 65535) {
         t.mode = TSFA_LZ_DIRECT16;
         t.cap = (P + 1) * bins;
         t.lg = 0;
         t.words = (t.cap + 1) / 2;
+    } else if (bins <= 255) {
+        // TSFA_LZ_BITS: the shallow levels of the trie are IMPLICIT -- a node of depth < D is numbered like a heap
+        // (child of node id by symbol s: id * bins + 1 + s), so "does this child exist" is one bit of a table indexed
+        // by id * bins + s: no keys, no probing, a third of the LDS.  D is the largest depth whose bit table fits
+        // TSFA_LZ_BITS_MAX; only phrases longer than D (at most n / (D + 1) of them) go to a small hash table.
+        long long nodes = 1, pw = 1;  // nodes of depth < D, bins^(D-1)
+        int D = 1;
+        while ((nodes + pw * bins) * bins <= TSFA_LZ_BITS_MAX) { pw *= bins; nodes += pw; ++D; }
+        const int deep = n / (D + 1);
+        int cap = 16, lg = 4;
+        while (17LL * cap < 20LL * deep + 20) { cap <<= 1; ++lg; }  // load factor <= 0.85: probing only costs the rare deep steps
+        t.mode = TSFA_LZ_BITS;
+        t.nbt = (int)nodes;
+        t.cap = cap;
+        t.lg = lg;
+        t.words = (int)((nodes * bins + 31) / 32) + 1 + cap;  // + one dummy word (lanes that are in the hashed part)
     } else {
         int cap = 16, lg = 4;
         while (3LL * cap < 5LL * P + 5) { cap <<= 1; ++lg; }  // cap >= (P + 1) / 0.6
@@ -87,9 +108,12 @@ struct TsfaSeqGroup {
     int ndirect;                      // the first ndirect chains use direct tables, the rest hashed ones
     int ttotal;                       // uint32 words of table storage
     int etotal;                       // bin edges (doubles)
-    int stride;                       // bytes between the symbol rows of two chains
+    int stride;                       // total bytes of the symbol rows (SeqLds: one 'row' of this size)
+    int soff[TSFA_LZ_MAX_GROUP];      // byte offset of a chain's symbol row
+    int sbits[TSFA_LZ_MAX_GROUP];     // bits per stored symbol: 4 (two per byte; TSFA_LZ_BITS chains of <= 16 bins) or 8
     int bins[TSFA_LZ_MAX_GROUP];
     int mode[TSFA_LZ_MAX_GROUP];      // TSFA_LZ_*
+    int nbt[TSFA_LZ_MAX_GROUP];       // TSFA_LZ_BITS: implicit-trie nodes
     int cap[TSFA_LZ_MAX_GROUP];
     int lg[TSFA_LZ_MAX_GROUP];
     int toff[TSFA_LZ_MAX_GROUP];      // table offset in uint32 words
@@ -98,7 +122,7 @@ struct TsfaSeqGroup {
 };
 inline void lz_build_group(const TsfaSpec *specs, int nb, int maxn, TsfaSeqGroup *g) {
     g->nb = nb;
-    g->stride = lz_seq_stride(maxn);
+    int sbytes = 0;
     // chains with direct tables first: they share a wavefront (lane = chain), the hashed ones share another
     int order[TSFA_LZ_MAX_GROUP], no = 0;
     for (int pass = 0; pass < 2; ++pass)
@@ -113,13 +137,17 @@ inline void lz_build_group(const TsfaSpec *specs, int nb, int maxn, TsfaSeqGroup
         if (sp && lt.mode == TSFA_LZ_DIRECT16) g->ndirect = k + 1;
         g->bins[k] = bins;
         g->mode[k] = lt.mode;
+        g->nbt[k] = lt.nbt;
         g->cap[k] = lt.cap;
         g->lg[k] = lt.lg;
         g->toff[k] = t;
         g->eoff[k] = e;
         g->col[k] = sp ? sp->col : 0;
-        if (k < nb) { t += lt.words; e += bins; }
+        g->sbits[k] = (lt.mode == TSFA_LZ_BITS && bins <= 16) ? 4 : 8;
+        g->soff[k] = sbytes;
+        if (k < nb) { t += lt.words; e += bins; sbytes += (g->sbits[k] == 4) ? lz_seq_stride((maxn + 1) / 2) : lz_seq_stride(maxn); }
     }
+    g->stride = sbytes;
     g->ttotal = t;
     g->etotal = e;
 }
@@ -186,9 +214,71 @@ TSFA_DEV int lz_parse_hash(const unsigned char *sq, int n, int cap, int lg, uint
     return count;
 }
 
+// Parse with the implicit shallow trie (bit table) + a hash table for the deep phrases (TSFA_LZ_BITS).
+// tb: [ceil(nbt * bins / 32) words of child bits][cap hash slots]
+TSFA_DEV int lz_parse_bits(const unsigned char *sq, int n, int bins, int nbt, int cap, int lg, uint32_t *tb, int sbits) {
+    int count = 0;
+    uint32_t node = 0u;
+    const uint32_t *sw = (const uint32_t *)(const void *)sq;
+    const bool packed = (sbits == 4);            // eight symbols per word instead of four
+    const uint32_t smask = packed ? 15u : 255u;
+    const int wstep = packed ? 1 : 2;            // words per eight symbols
+    const uint32_t ub = (uint32_t)bins, unb = (uint32_t)nbt;
+    const uint32_t nbw = (unb * ub + 31u) >> 5;  // tb[nbw] is a dummy word
+    uint32_t *hb = tb + nbw + 1u;
+    const uint32_t hbase = unb * ub + 1u;  // ids of hashed nodes start above every implicit id
+    const uint32_t mask = (uint32_t)cap - 1u;
+    const int sh = 32 - lg;
+    uint32_t wa = sw[0], wb = sw[1];
+    for (int pos = 0; pos < n; pos += 8) {
+        uint32_t w = wa;
+        const uint32_t w2 = wb;
+        const int nx = ((pos >> 3) + 1) * wstep;  // rows are padded: the look-ahead stays inside
+        wa = sw[nx];
+        wb = sw[nx + 1];
+        const int lim = (n - pos < 8) ? (n - pos) : 8;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            if (k < lim) {
+                if (k == 4) w = packed ? w : w2;
+                const uint32_t sym = w & smask;
+                w >>= sbits;
+                // shallow part: branch-free for every lane (a lane that is in the hashed part hits the dummy word);
+                // the hashed part runs only when some chain of the wavefront is that deep (rare)
+                const bool deep = (node >= unb);
+                const uint32_t p = deep ? (nbw << 5) : (node * ub + sym);
+                const uint32_t word = tb[p >> 5], bit = 1u << (p & 31u);
+                bool fresh = ((word & bit) == 0u);
+                tb[p >> 5] = word | bit;
+                uint32_t child = p + 1u;
+#if TSFA_GPU
+                if (__any(deep))
+#endif
+                {
+                    if (deep) {
+                        const uint32_t key = ((node << 8) | sym) + 1u;  // non-zero
+                        uint32_t h = (key * 2654435761u) >> sh;
+                        uint32_t cur = hb[h];
+                        while (cur != key && cur != 0u) {
+                            h = (h + 1u) & mask;
+                            cur = hb[h];
+                        }
+                        fresh = (cur == 0u);
+                        hb[h] = key;
+                        child = hbase + h;
+                    }
+                }
+                count += fresh ? 1 : 0;
+                node = fresh ? 0u : child;
+            }
+        }
+    }
+    return count;
+}
+
 // Evaluate one group of SEQ specs for one series.
 //   x(i)   : sample accessor (the kernel reads HBM directly: the series is only touched twice)
-//   seq    : LDS bytes,   >= nb * g.stride, 4-byte aligned
+//   seq    : LDS bytes,   >= g.stride, 4-byte aligned
 //   tab    : LDS uint32,  >= g.ttotal
 //   edges  : LDS doubles, >= g.etotal
 template <class X>
@@ -202,7 +292,7 @@ TSFA_DEV void fam_seq_series(const Blk &b, X xv, int n, const TsfaSeqGroup &g, d
         mx = fmax(mx, x);
     }
     const double vmin = blk_min(b, mn), vmax = blk_max(b, mx);
-    const int nb = g.nb, stride = g.stride;
+    const int nb = g.nb;
     blk_sync();
     TSFA_TICK(tk, b, 160);
     // bin edges: np.linspace(min, max, bins + 1)[1:]
@@ -216,19 +306,26 @@ TSFA_DEV void fam_seq_series(const Blk &b, X xv, int n, const TsfaSeqGroup &g, d
     blk_sync();
     TSFA_TICK(tk, b, 161);
     // symbols: np.searchsorted(edges, x, side="left") = #{edges < x}
-    for (int i = b.tid; i < n; i += b.nt) {
-        const double x = xv(i);
+    // a thread bins two neighbouring samples (a 4-bit row packs them into one byte)
+    for (int i = 2 * b.tid; i < n; i += 2 * b.nt) {
+        const bool two = (i + 1 < n);
+        const double x0 = xv(i), x1 = two ? xv(i + 1) : x0;
 #pragma unroll
         for (int t = 0; t < TSFA_LZ_MAX_GROUP; ++t) {
             if (t >= nb) continue;
             const double *ed = edges + g.eoff[t];
-            int lo = 0, hi = g.bins[t];
-            while (lo < hi) {
-                const int mid = (lo + hi) >> 1;
-                if (ed[mid] < x) lo = mid + 1;
-                else hi = mid;
+            int lo0 = 0, hi0 = g.bins[t], lo1 = 0, hi1 = g.bins[t];
+            while (lo0 < hi0 || lo1 < hi1) {
+                if (lo0 < hi0) { const int mid = (lo0 + hi0) >> 1; if (ed[mid] < x0) lo0 = mid + 1; else hi0 = mid; }
+                if (lo1 < hi1) { const int mid = (lo1 + hi1) >> 1; if (ed[mid] < x1) lo1 = mid + 1; else hi1 = mid; }
             }
-            seq[(size_t)t * stride + i] = (unsigned char)lo;
+            unsigned char *row = seq + g.soff[t];
+            if (g.sbits[t] == 4) {
+                row[i >> 1] = (unsigned char)(lo0 | (two ? (lo1 << 4) : 0));
+            } else {
+                row[i] = (unsigned char)lo0;
+                if (two) row[i + 1] = (unsigned char)lo1;
+            }
         }
     }
     blk_sync();
@@ -251,19 +348,20 @@ TSFA_DEV void fam_seq_series(const Blk &b, X xv, int n, const TsfaSeqGroup &g, d
         const int td = t, th = t;
 #endif
         if (do_direct) {
-            int off = 0, bins = 1, col = 0;
+            int off = 0, bins = 1, col = 0, so = 0;
 #pragma unroll
             for (int q = 0; q < TSFA_LZ_MAX_GROUP; ++q)
-                if (q == td) { off = g.toff[q]; bins = g.bins[q]; col = g.col[q]; }
-            const int count = lz_parse_direct(seq + (size_t)td * stride, n, bins, (unsigned short *)(void *)(tab + off));
+                if (q == td) { off = g.toff[q]; bins = g.bins[q]; col = g.col[q]; so = g.soff[q]; }
+            const int count = lz_parse_direct(seq + so, n, bins, (unsigned short *)(void *)(tab + off));
             out_row[col] = (double)count / (double)n;
         }
         if (do_hash) {
-            int off = 0, cap = 16, lg = 4, col = 0;
+            int off = 0, cap = 16, lg = 4, col = 0, mode = TSFA_LZ_HASH32, nbt = 0, hbins = 1, so = 0, sb = 8;
 #pragma unroll
             for (int q = 0; q < TSFA_LZ_MAX_GROUP; ++q)
-                if (q == th) { off = g.toff[q]; cap = g.cap[q]; lg = g.lg[q]; col = g.col[q]; }
-            const int count = lz_parse_hash(seq + (size_t)th * stride, n, cap, lg, tab + off);
+                if (q == th) { off = g.toff[q]; cap = g.cap[q]; lg = g.lg[q]; col = g.col[q]; mode = g.mode[q]; nbt = g.nbt[q]; hbins = g.bins[q]; so = g.soff[q]; sb = g.sbits[q]; }
+            const int count = (mode == TSFA_LZ_BITS) ? lz_parse_bits(seq + so, n, hbins, nbt, cap, lg, tab + off, sb)
+                                                     : lz_parse_hash(seq + so, n, cap, lg, tab + off);
             out_row[col] = (double)count / (double)n;
         }
 #if !TSFA_GPU

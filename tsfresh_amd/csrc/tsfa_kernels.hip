@@ -140,7 +140,7 @@ __global__ void __launch_bounds__(256) k_seq(const T *__restrict__ values, const
     const int64_t off = starts[sidx];
     const int n = (int)(ends[sidx] - off);
     SeqLds L;
-    L.carve(tsfa_smem, g.nb, g.stride, g.ttotal, g.etotal);
+    L.carve(tsfa_smem, 1, g.stride, g.ttotal, g.etotal);
     TSFA_TICKS_BEGIN();
     Blk b{(int)threadIdx.x, (int)blockDim.x, L.red, nullptr};
     const T *gv = values + off;
@@ -323,7 +323,7 @@ if (a.ent_fast) {
         }
     } else if (a.fam == TSFA_FAM_SEQ) {
         SeqLds L;
-        const size_t lds = L.carve(nullptr, a.seq.nb, a.seq.stride, a.seq.ttotal, a.seq.etotal);
+        const size_t lds = L.carve(nullptr, 1, a.seq.stride, a.seq.ttotal, a.seq.etotal);
         if ((rc = set_lds(k_seq<T>, lds))) return rc;
         k_seq<T><<<grid, nt, lds, st>>>(values, a.starts, a.ends, a.n_series, a.out, a.ld, a.seq);
     } else if (a.fam == TSFA_FAM_CWT) {  // number_cwt_peaks
@@ -346,7 +346,7 @@ size_t tsfa_entropy_lds_bytes(int maxn, int with_cnt) {
 
 size_t tsfa_seq_lds_bytes(const TsfaSeqGroup &g) {
     SeqLds L;
-    return L.carve(nullptr, g.nb, g.stride, g.ttotal, g.etotal);
+    return L.carve(nullptr, 1, g.stride, g.ttotal, g.etotal);
 }
 
 size_t tsfa_family_lds_bytes(int fam, int maxn, int nt, int aux) {
