@@ -216,6 +216,55 @@ TSFA_DEV int lz_parse_hash(const unsigned char *sq, int n, int cap, int lg, uint
 
 // Parse with the implicit shallow trie (bit table) + a hash table for the deep phrases (TSFA_LZ_BITS).
 // tb: [ceil(nbt * bins / 32) words of child bits][cap hash slots]
+#if TSFA_GPU
+TSFA_DEV uint32_t lz_mad24(uint32_t a, uint32_t b, uint32_t c) { return __umul24(a, b) + c; }  // v_mad_u32_u24 (full rate)
+TSFA_DEV uint32_t lz_bit(uint32_t word, uint32_t pos) { return __builtin_amdgcn_ubfe(word, pos, 1u); }
+#else
+TSFA_DEV uint32_t lz_mad24(uint32_t a, uint32_t b, uint32_t c) { return a * b + c; }
+TSFA_DEV uint32_t lz_bit(uint32_t word, uint32_t pos) { return (word >> pos) & 1u; }
+#endif
+
+// One symbol of a TSFA_LZ_BITS chain.  The dependent chain per symbol is what bounds the kernel (one lane per chain,
+// ~1000 strictly sequential steps), so the shallow step is kept to mad24 -> min -> shift -> address -> LDS read ->
+// bit extract -> mul24: a lane that is in the hashed part is clamped onto the dummy word (no select, no branch), and
+// the next node is child * seen instead of compare + select.
+struct LzBits {
+    uint32_t *tb, *hb;
+    uint32_t ub, unb, dummy, hbase, mask;
+    int sh;
+};
+TSFA_DEV void lz_bits_step(const LzBits &L, uint32_t sym, uint32_t &node, int &count) {
+    const bool deep = (node >= L.unb);
+    uint32_t p = lz_mad24(node, L.ub, sym);
+    p = (p < L.dummy) ? p : L.dummy;  // v_min_u32: hashed nodes have ids above every table index
+    uint32_t *wp = L.tb + (p >> 5);
+    const uint32_t word = *wp;
+    uint32_t seen = lz_bit(word, p & 31u);
+    *wp = word | (1u << (p & 31u));
+    uint32_t child = p + 1u;
+#if TSFA_GPU
+    if (__any(deep))
+#endif
+    {
+        if (deep) {
+            const uint32_t key = ((node << 8) | sym) + 1u;  // non-zero
+            uint32_t h = (key * 2654435761u) >> L.sh;
+            uint32_t cur = L.hb[h];
+            while (cur != key && cur != 0u) {
+                h = (h + 1u) & L.mask;
+                cur = L.hb[h];
+            }
+            seen = (cur == 0u) ? 0u : 1u;
+            L.hb[h] = key;
+            child = L.hbase + h;
+        }
+    }
+    count += (int)(1u - seen);
+    node = lz_mad24(child, seen, 0u);  // fresh phrase: back to the root (0)
+}
+
+// Parse with the implicit shallow trie (bit table) + a hash table for the deep phrases (TSFA_LZ_BITS).
+// tb: [ceil(nbt * bins / 32) words of child bits][dummy word][cap hash slots]
 TSFA_DEV int lz_parse_bits(const unsigned char *sq, int n, int bins, int nbt, int cap, int lg, uint32_t *tb, int sbits) {
     int count = 0;
     uint32_t node = 0u;
@@ -223,54 +272,39 @@ TSFA_DEV int lz_parse_bits(const unsigned char *sq, int n, int bins, int nbt, in
     const bool packed = (sbits == 4);            // eight symbols per word instead of four
     const uint32_t smask = packed ? 15u : 255u;
     const int wstep = packed ? 1 : 2;            // words per eight symbols
-    const uint32_t ub = (uint32_t)bins, unb = (uint32_t)nbt;
-    const uint32_t nbw = (unb * ub + 31u) >> 5;  // tb[nbw] is a dummy word
-    uint32_t *hb = tb + nbw + 1u;
-    const uint32_t hbase = unb * ub + 1u;  // ids of hashed nodes start above every implicit id
-    const uint32_t mask = (uint32_t)cap - 1u;
-    const int sh = 32 - lg;
+    LzBits L;
+    L.ub = (uint32_t)bins;
+    L.unb = (uint32_t)nbt;
+    const uint32_t nbw = (L.unb * L.ub + 31u) >> 5;  // tb[nbw] is the dummy word
+    L.tb = tb;
+    L.hb = tb + nbw + 1u;
+    L.dummy = nbw << 5;
+    L.hbase = L.dummy + 32u;  // ids of hashed nodes start above every table index (and above the dummy's)
+    L.mask = (uint32_t)cap - 1u;
+    L.sh = 32 - lg;
     uint32_t wa = sw[0], wb = sw[1];
-    for (int pos = 0; pos < n; pos += 8) {
+    int pos = 0;
+    for (; pos + 8 <= n; pos += 8) {  // full groups: no per-symbol bounds
         uint32_t w = wa;
         const uint32_t w2 = wb;
         const int nx = ((pos >> 3) + 1) * wstep;  // rows are padded: the look-ahead stays inside
         wa = sw[nx];
         wb = sw[nx + 1];
-        const int lim = (n - pos < 8) ? (n - pos) : 8;
 #pragma unroll
         for (int k = 0; k < 8; ++k) {
-            if (k < lim) {
-                if (k == 4) w = packed ? w : w2;
-                const uint32_t sym = w & smask;
-                w >>= sbits;
-                // shallow part: branch-free for every lane (a lane that is in the hashed part hits the dummy word);
-                // the hashed part runs only when some chain of the wavefront is that deep (rare)
-                const bool deep = (node >= unb);
-                const uint32_t p = deep ? (nbw << 5) : (node * ub + sym);
-                const uint32_t word = tb[p >> 5], bit = 1u << (p & 31u);
-                bool fresh = ((word & bit) == 0u);
-                tb[p >> 5] = word | bit;
-                uint32_t child = p + 1u;
-#if TSFA_GPU
-                if (__any(deep))
-#endif
-                {
-                    if (deep) {
-                        const uint32_t key = ((node << 8) | sym) + 1u;  // non-zero
-                        uint32_t h = (key * 2654435761u) >> sh;
-                        uint32_t cur = hb[h];
-                        while (cur != key && cur != 0u) {
-                            h = (h + 1u) & mask;
-                            cur = hb[h];
-                        }
-                        fresh = (cur == 0u);
-                        hb[h] = key;
-                        child = hbase + h;
-                    }
-                }
-                count += fresh ? 1 : 0;
-                node = fresh ? 0u : child;
-            }
+            if (k == 4) w = packed ? w : w2;
+            const uint32_t sym = w & smask;
+            w >>= sbits;
+            lz_bits_step(L, sym, node, count);
+        }
+    }
+    if (pos < n) {
+        uint32_t w = wa;
+        for (int k = 0; pos + k < n; ++k) {
+            if (k == 4) w = packed ? w : wb;
+            const uint32_t sym = w & smask;
+            w >>= sbits;
+            lz_bits_step(L, sym, node, count);
         }
     }
     return count;
