@@ -92,11 +92,19 @@ extern "C" int tsfa_emul_extract_timed(const tsfa_feature_spec *specs, int n_spe
         if (!fam[TSFA_FAM_BASIC].empty()) {
             std::vector<double> w(maxn + 8), cum(maxn + 8), altc(8 * 16), ctx(32);
             std::vector<int> iw(512);
-            fam_basic_series(b, xs.data(), n, fam[TSFA_FAM_BASIC].data(), (int)fam[TSFA_FAM_BASIC].size(), row, w.data(),
-                             (s % 2) ? w.data() : cum.data(), altc.data(), iw.data(), dectab.data(),
-                             hints[TSFA_FAM_BASIC].a, hints[TSFA_FAM_BASIC].b, hints[TSFA_FAM_BASIC].alt, nullptr,
-                             times ? times + offsets[s] : nullptr, (s % 2) ? -1 : hints[TSFA_FAM_BASIC].c, ctx.data(),
-                             (s % 4 == 1) ? 0 : hints[TSFA_FAM_BASIC].d);
+            fam_basic_series<1>(b, xs.data(), n, fam[TSFA_FAM_BASIC].data(), (int)fam[TSFA_FAM_BASIC].size(), row, w.data(),
+                                (s % 2) ? w.data() : cum.data(), altc.data(), iw.data(), dectab.data(),
+                                hints[TSFA_FAM_BASIC].a, 0, hints[TSFA_FAM_BASIC].alt, nullptr, nullptr,
+                                (s % 2) ? -1 : hints[TSFA_FAM_BASIC].c, ctx.data(),
+                                (s % 4 == 1) ? 0 : hints[TSFA_FAM_BASIC].d);
+        }
+        if (!fam[TSFA_FAM_TREND].empty()) {
+            std::vector<double> w(maxn + 8), cum(maxn + 8), altc(8 * 16), ctx(32);
+            std::vector<int> iw(512);
+            fam_basic_series<2>(b, xs.data(), n, fam[TSFA_FAM_TREND].data(), (int)fam[TSFA_FAM_TREND].size(), row, w.data(),
+                                (s % 2) ? w.data() : cum.data(), altc.data(), iw.data(), dectab.data(), 0,
+                                hints[TSFA_FAM_TREND].b, hints[TSFA_FAM_TREND].alt, nullptr,
+                                times ? times + offsets[s] : nullptr, (s % 2) ? -1 : hints[TSFA_FAM_TREND].c, ctx.data());
         }
         if (!fam[TSFA_FAM_SORT].empty()) {
             std::vector<double> srt(tsfa_pow2_ceil(maxn) + 8), w(1280), cq(5 * TSFA_CQ_MAX), sctx(8);

@@ -582,7 +582,11 @@ TSFA_DEV bool basic_sum_pass(const Blk &b, XS xs, int n, const TsfaSpec *specs, 
 #define TSFA_PEAK_NEAR 10
 #define TSFA_DEV_UNUSED
 //   times: HBM, the series' timestamps as float64 hours since its first sample (linear_trend_timewise), or null
-template <class XS>
+// PART: 1 = the BASIC family (k_basic), 2 = the TREND family (k_trend: index_mass_quantile, linear_trend(_timewise),
+// agg_linear_trend -- the calculators that need a float64 work array of n entries), 3 = both.  Two kernels instead
+// of one: each half needs far fewer registers and less LDS than the union, and both are latency-bound (the resident
+// wavefronts per CU are what they gain from).
+template <int PART, class XS>
 TSFA_DEV void fam_basic_series(const Blk &b, XS xs, int n, const TsfaSpec *specs, int nspecs,
                                double *out_row, double *w, double *cum, double *altc, int *iw, const double *dectab,
                                int peaks_maxsup, int alt_want_p, const TsfaAltPlan &alt, TsfaSpec *stage,
@@ -590,7 +594,12 @@ TSFA_DEV void fam_basic_series(const Blk &b, XS xs, int n, const TsfaSpec *specs
                                int n_count = 0, int n_sum = 0) {
     TSFA_TICKER(tk, 0);
     BasicStats st;
-    basic_stats(b, xs, n, st);
+    if (PART & 1) {
+        basic_stats(b, xs, n, st);
+    } else {
+        st.n = n; st.sum = 0.0; st.mean = 0.0; st.var = 0.0; st.std = 0.0; st.vmin = 0.0; st.vmax = 0.0; st.sumsq = 0.0;
+        st.first_max = 0; st.last_max = 0; st.first_min = 0; st.last_min = 0; st.cnt_max = 0; st.cnt_min = 0;
+    }
     TSFA_TICK(tk, b, 100);
     // n_loop columns go through the column loop; the rest are evaluated by basic_epilogue (lane = column) from ctx
     const int nloop = (n_loop >= 0 && ctx != nullptr) ? n_loop : nspecs;
@@ -616,12 +625,12 @@ TSFA_DEV void fam_basic_series(const Blk &b, XS xs, int n, const TsfaSpec *specs
     int peaks_p = 0;  // window length of the sliding maxima currently held in w (number_peaks fast path), 0 = none
 
     // the count-type columns at the front of the list (host hint) are evaluated together from registers
-    const int ncnt = (n_count > 0 && n_count <= nloop) ? n_count : 0;
-    if (ncnt > 0) basic_count_pass(b, xs, n, specs, ncnt, st, out_row, iw);
+    const int ncnt = ((PART & 1) && n_count > 0 && n_count <= nloop) ? n_count : 0;
+    if ((PART & 1) && ncnt > 0) basic_count_pass(b, xs, n, specs, ncnt, st, out_row, iw);
     TSFA_TICK(tk, b, 213);
     // ... and behind them the sum-type columns (single-wavefront series of <= 1024 samples; else the column loop)
     int sbeg = ncnt;
-    if (ncnt == n_count && n_sum > 0 && ncnt + n_sum <= nloop && basic_sum_pass(b, xs, n, specs, ncnt, n_sum, st, out_row))
+    if ((PART & 1) && ncnt == n_count && n_sum > 0 && ncnt + n_sum <= nloop && basic_sum_pass(b, xs, n, specs, ncnt, n_sum, st, out_row))
         sbeg = ncnt + n_sum;
     TSFA_TICK(tk, b, 214);
     TsfaSpec nxt = spec_fetch(b, specs, nspecs, (sbeg < nspecs) ? sbeg : 0, stage);
@@ -636,6 +645,7 @@ TSFA_DEV void fam_basic_series(const Blk &b, XS xs, int n, const TsfaSpec *specs
         TSFA_TICK(tkc, b, 210);
         const double p0 = sp.p[0], p1 = sp.p[1], p2 = sp.p[2];
         double v = TSFA_NAN;
+        if (PART & 1) {  // k_basic proper
         switch (sp.calc) {
         case TSFA_C_SUM_VALUES: v = st.sum; break;                       // fc.py:371
         case TSFA_C_MEAN: v = st.mean; break;                            // fc.py:677
@@ -918,72 +928,6 @@ TSFA_DEV void fam_basic_series(const Blk &b, XS xs, int n, const TsfaSpec *specs
             }
             v = blk_sum(b, c);
         } break;
-        case TSFA_C_INDEX_MASS_QUANTILE: {                               // fc.py:1275
-            const bool imq_indexed = (alt.nq > 0 && p2 == 1.0);
-            if (imq_indexed && (int)p1 < 128) {  // evaluated by the plan's first index_mass_quantile column
-                v = altc[8 * ((int)p1 & 127) + 7];
-                break;
-            }
-            if (!have_cumsum) {
-                // np.cumsum is a serial accumulation: one lane builds it once (in numpy's order, so that the >= q
-                // comparison is bit-identical), every q then scans it in parallel
-                have_peaks = false;  // cum may alias the peak distances
-                peaks_p = 0;
-                imq_sabs = np_sum(b, n, [=](int i) { return fabs(xs[i]); });
-                blk_sync();
-                if (b.tid == 0) {
-                    double acc = 0.0;
-                    int i = 0;
-                    for (; i + 16 <= n; i += 16) {  // loads batched ahead of the dependent add chain
-                        double v[16];
-#pragma unroll
-                        for (int u = 0; u < 16; ++u) v[u] = fabs(xs[i + u]);
-#pragma unroll
-                        for (int u = 0; u < 16; ++u) { acc += v[u]; cum[i + u] = acc; }
-                    }
-                    for (; i < n; ++i) {
-                        acc += fabs(xs[i]);
-                        cum[i] = acc;
-                    }
-                }
-                blk_sync();
-                have_cumsum = true;
-            }
-            if (imq_indexed) {
-                // lane = q: cum / S is non-decreasing (a correctly rounded division is monotone), so the first index
-                // with cum[i] / S >= q is found by bisection with the reference's own expression -- ~10 dependent
-                // divisions for ALL q together instead of n / 64 divisions per lane for every q
-                blk_sync();
-                for (int k = b.tid; k < alt.nq; k += b.nt) {
-                    double q = 0.0;
-#pragma unroll
-                    for (int u = 0; u < TSFA_ALT_MAXKEYS; ++u)
-                        if (u == k) q = alt.q[u];
-                    double res = TSFA_NAN;
-                    if (imq_sabs != 0.0) {
-                        int lo = 0, hi = n;  // first i in [0, n) with the predicate true, n if none
-                        while (lo < hi) {
-                            const int mid = (lo + hi) >> 1;
-                            if (cum[mid] / imq_sabs >= q) hi = mid;
-                            else lo = mid + 1;
-                        }
-                        const int idx = (lo < n) ? lo : 0;  // np.argmax of an all-False mask is 0
-                        res = (double)(idx + 1) / dn;
-                    }
-                    altc[8 * k + 7] = res;
-                }
-                blk_sync();
-                v = altc[8 * ((int)p1 & 127) + 7];
-                break;
-            }
-            if (imq_sabs == 0.0) { v = TSFA_NAN; break; }
-            double first = (double)n;
-            for (int i = b.tid; i < n; i += b.nt)
-                if (cum[i] / imq_sabs >= p0) { first = (double)i; break; }
-            first = blk_min(b, first);
-            const int idx = (first < (double)n) ? (int)first : 0;  // np.argmax of an all-False mask is 0
-            v = (double)(idx + 1) / dn;
-        } break;
         case TSFA_C_ENERGY_RATIO_BY_CHUNKS: {                            // fc.py:2226 (np.array_split)
             const int nseg = (int)p0, foc = (int)p1;
             const int q = n / nseg, rem = n % nseg;
@@ -1072,6 +1016,80 @@ TSFA_DEV void fam_basic_series(const Blk &b, XS xs, int n, const TsfaSpec *specs
             }
             v = blk_bcast0(b, r);
         } break;
+        case TSFA_C_QUERY_SIMILARITY_COUNT:                              // fc.py:2475 with query=None
+            v = TSFA_NAN;
+            break;
+        default: break;
+        }
+        }
+        if (PART & 2) {  // the trend calculators (k_trend): cumulative sums, chunk aggregates, regressions
+        switch (sp.calc) {
+        case TSFA_C_INDEX_MASS_QUANTILE: {                               // fc.py:1275
+            const bool imq_indexed = (alt.nq > 0 && p2 == 1.0);
+            if (imq_indexed && (int)p1 < 128) {  // evaluated by the plan's first index_mass_quantile column
+                v = altc[8 * ((int)p1 & 127) + 7];
+                break;
+            }
+            if (!have_cumsum) {
+                // np.cumsum is a serial accumulation: one lane builds it once (in numpy's order, so that the >= q
+                // comparison is bit-identical), every q then scans it in parallel
+                have_peaks = false;  // cum may alias the peak distances
+                peaks_p = 0;
+                imq_sabs = np_sum(b, n, [=](int i) { return fabs(xs[i]); });
+                blk_sync();
+                if (b.tid == 0) {
+                    double acc = 0.0;
+                    int i = 0;
+                    for (; i + 16 <= n; i += 16) {  // loads batched ahead of the dependent add chain
+                        double v[16];
+#pragma unroll
+                        for (int u = 0; u < 16; ++u) v[u] = fabs(xs[i + u]);
+#pragma unroll
+                        for (int u = 0; u < 16; ++u) { acc += v[u]; cum[i + u] = acc; }
+                    }
+                    for (; i < n; ++i) {
+                        acc += fabs(xs[i]);
+                        cum[i] = acc;
+                    }
+                }
+                blk_sync();
+                have_cumsum = true;
+            }
+            if (imq_indexed) {
+                // lane = q: cum / S is non-decreasing (a correctly rounded division is monotone), so the first index
+                // with cum[i] / S >= q is found by bisection with the reference's own expression -- ~10 dependent
+                // divisions for ALL q together instead of n / 64 divisions per lane for every q
+                blk_sync();
+                for (int k = b.tid; k < alt.nq; k += b.nt) {
+                    double q = 0.0;
+#pragma unroll
+                    for (int u = 0; u < TSFA_ALT_MAXKEYS; ++u)
+                        if (u == k) q = alt.q[u];
+                    double res = TSFA_NAN;
+                    if (imq_sabs != 0.0) {
+                        int lo = 0, hi = n;  // first i in [0, n) with the predicate true, n if none
+                        while (lo < hi) {
+                            const int mid = (lo + hi) >> 1;
+                            if (cum[mid] / imq_sabs >= q) hi = mid;
+                            else lo = mid + 1;
+                        }
+                        const int idx = (lo < n) ? lo : 0;  // np.argmax of an all-False mask is 0
+                        res = (double)(idx + 1) / dn;
+                    }
+                    altc[8 * k + 7] = res;
+                }
+                blk_sync();
+                v = altc[8 * ((int)p1 & 127) + 7];
+                break;
+            }
+            if (imq_sabs == 0.0) { v = TSFA_NAN; break; }
+            double first = (double)n;
+            for (int i = b.tid; i < n; i += b.nt)
+                if (cum[i] / imq_sabs >= p0) { first = (double)i; break; }
+            first = blk_min(b, first);
+            const int idx = (first < (double)n) ? (int)first : 0;  // np.argmax of an all-False mask is 0
+            v = (double)(idx + 1) / dn;
+        } break;
         case TSFA_C_LINEAR_TREND: {                                      // fc.py:1343
             if (!have_lt) {  // one regression serves all five attributes
                 blk_linregress_index(b, n, [=](int i) { return xs[i]; }, lt5);
@@ -1156,10 +1174,8 @@ TSFA_DEV void fam_basic_series(const Blk &b, XS xs, int n, const TsfaSpec *specs
             }
             v = altc[8 * slot + 2 + attr];
         } break;
-        case TSFA_C_QUERY_SIMILARITY_COUNT:                              // fc.py:2475 with query=None
-            v = TSFA_NAN;
-            break;
         default: break;
+        }
         }
         TSFA_TICK(tkc, b, 211);
         if (b.tid == 0) out_row[sp.col] = v;

@@ -82,7 +82,7 @@ struct tsfa_plan {
     std::vector<Timing> timings;
 };
 
-static const char *fam_names[TSFA_N_FAMILIES] = {"k_basic", "k_sort", "k_spectral", "k_ar", "k_entropy", "k_cwtpeaks", "k_seq"};
+static const char *fam_names[TSFA_N_FAMILIES] = {"k_basic", "k_sort", "k_spectral", "k_ar", "k_entropy", "k_cwtpeaks", "k_seq", "k_trend"};
 
 template <class T>
 static int upload(const std::vector<T> &h, T **d) {
@@ -341,8 +341,8 @@ int tsfa_extract_windows(tsfa_plan *plan, const void *values, int32_t dtype, con
 
     // Launch order: longest kernels first.  With side streams (and no per-kernel timing requested) the families are
     // dealt round-robin over the streams after a fork event; the join events bring them back to `st`.
-    static const int order[TSFA_N_FAMILIES] = {TSFA_FAM_ENTROPY, TSFA_FAM_BASIC, TSFA_FAM_AR, TSFA_FAM_SORT,
-                                               TSFA_FAM_SEQ, TSFA_FAM_CWT, TSFA_FAM_SPECTRAL};
+    static const int order[TSFA_N_FAMILIES] = {TSFA_FAM_ENTROPY, TSFA_FAM_AR, TSFA_FAM_SORT, TSFA_FAM_CWT, TSFA_FAM_BASIC,
+                                               TSFA_FAM_SEQ, TSFA_FAM_SPECTRAL, TSFA_FAM_TREND};
     const bool overlap = plan->n_streams > 1 && !plan->profiling;
     if (overlap) {
         HIP_TRY(hipEventRecord(plan->ev_fork, st));
@@ -376,7 +376,7 @@ int tsfa_extract_windows(tsfa_plan *plan, const void *values, int32_t dtype, con
             // Wavefronts per series, measured on MI355X at n = 1024 (profiles/r01_*): the LDS footprint of a series
             // caps the workgroups per CU, so the latency-bound families gain from more wavefronts per workgroup,
             // while k_basic's many short reductions lose to the extra barriers.  At least 4 samples per thread.
-            static const int pref[TSFA_N_FAMILIES] = {64, 128, 128, 128, 256, 256, 128};
+            static const int pref[TSFA_N_FAMILIES] = {64, 128, 128, 128, 256, 256, 128, 64};
             const int cap = std::max(64, ((maxn / 4 + 63) / 64) * 64);
             a.nt = std::min(pref[f], cap);
         }

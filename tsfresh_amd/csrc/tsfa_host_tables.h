@@ -146,7 +146,7 @@ static inline void tsfa_prepare_family(int fam, std::vector<TsfaSpec> &specs, Ts
         specs.insert(specs.end(), epi.begin(), epi.end());
         return;
     }
-    if (fam != TSFA_FAM_BASIC) return;
+    if (fam != TSFA_FAM_BASIC && fam != TSFA_FAM_TREND) return;
     // c = number of columns that stay in the column loop; the rest (closed forms, reads of the agg_linear_trend /
     // linear_trend / index_mass_quantile caches that an earlier loop column fills) follow and go to the epilogue
     std::vector<TsfaSpec> loop, epi;
@@ -235,7 +235,7 @@ static inline void tsfa_prepare_family_impl(int fam, std::vector<TsfaSpec> &spec
         h.b = (int)lead.size();
         specs = lead;
         specs.insert(specs.end(), rest.begin(), rest.end());
-    } else if (fam == TSFA_FAM_BASIC) {
+    } else if (fam == TSFA_FAM_BASIC || fam == TSFA_FAM_TREND) {  // BASIC: a;  TREND: b, alt
         // a: largest number_peaks support <= 254;  b: 1 if any agg_linear_trend column asks for the p-value
         // agg_linear_trend: p[3] = cache slot of the column's (f_agg, chunk_len) regression, + 64 if this column is
         // the one that has to compute it (the slots are simulated here, round-robin over TSFA_ALT_SLOTS)

@@ -20,17 +20,19 @@ __device__ __forceinline__ void stage_series(const Blk &b, const T *__restrict__
 }
 
 // ---------------------------------------------------------------------------------------------
-template <typename T>
-__global__ void __launch_bounds__(256, 2) k_basic(const T *__restrict__ values, const int64_t *__restrict__ starts, const int64_t *__restrict__ ends, int64_t n_series,
+// PART 1: the BASIC family; PART 2 (k_trend below): the TREND family -- same series staging, separate register
+// and LDS budgets (fam_basic.h)
+template <typename T, int PART>
+__device__ __forceinline__ void basic_body(const T *__restrict__ values, const int64_t *__restrict__ starts, const int64_t *__restrict__ ends, int64_t n_series,
                         const TsfaSpec *__restrict__ specs, int nspecs, double *__restrict__ out, int64_t ld,
                         const double *__restrict__ dectab, int maxn, int hint_a, int hint_b,
-                        const double *__restrict__ times, const TsfaAltPlan alt, int n_loop, int n_count, int n_sum) {
+                        const double *__restrict__ times, const TsfaAltPlan &alt, int n_loop, int n_count, int n_sum) {
     const int64_t sidx = blockIdx.x;
     if (sidx >= n_series) return;
     const int64_t off = starts[sidx];
     const int n = (int)(ends[sidx] - off);
     BasicLds L;
-    L.carve(tsfa_smem, maxn, blockDim.x, (int)sizeof(T));
+    L.carve(tsfa_smem, maxn, blockDim.x, (int)sizeof(T), PART);
     TSFA_TICKS_BEGIN();
     Blk b{(int)threadIdx.x, (int)blockDim.x, L.red, L.np};
     T *xs = (T *)L.xs;  // resident in the input precision (half the LDS for float32), read as float64
@@ -39,9 +41,26 @@ __global__ void __launch_bounds__(256, 2) k_basic(const T *__restrict__ values, 
         for (int i = b.tid; i < n; i += b.nt) xs[i] = g[i];
         blk_sync();
     }
-    fam_basic_series(b, XsView<T>{xs}, n, specs, nspecs, out + sidx * ld, L.w, L.cum, L.altc, L.iw, dectab, hint_a,
-                     hint_b, alt, L.stage, times ? times + off : nullptr, n_loop, L.ctx, n_count, n_sum);
+    fam_basic_series<PART>(b, XsView<T>{xs}, n, specs, nspecs, out + sidx * ld, L.w, L.cum, L.altc, L.iw, dectab, hint_a,
+                           hint_b, alt, L.stage, times ? times + off : nullptr, n_loop, L.ctx, n_count, n_sum);
     TSFA_TICKS_END();
+}
+
+template <typename T>
+__global__ void __launch_bounds__(256, 3) k_basic(const T *__restrict__ values, const int64_t *__restrict__ starts, const int64_t *__restrict__ ends, int64_t n_series,
+                        const TsfaSpec *__restrict__ specs, int nspecs, double *__restrict__ out, int64_t ld,
+                        const double *__restrict__ dectab, int maxn, int hint_a, int n_loop, int n_count, int n_sum) {
+    TsfaAltPlan alt;
+    alt.nkeys = 0; alt.want_p = 0; alt.nq = 0;
+    basic_body<T, 1>(values, starts, ends, n_series, specs, nspecs, out, ld, dectab, maxn, hint_a, 0, nullptr, alt, n_loop,
+                     n_count, n_sum);
+}
+
+template <typename T>
+__global__ void __launch_bounds__(256, 2) k_trend(const T *__restrict__ values, const int64_t *__restrict__ starts, const int64_t *__restrict__ ends, int64_t n_series,
+                        const TsfaSpec *__restrict__ specs, int nspecs, double *__restrict__ out, int64_t ld, int maxn,
+                        int hint_b, const double *__restrict__ times, const TsfaAltPlan alt, int n_loop) {
+    basic_body<T, 2>(values, starts, ends, n_series, specs, nspecs, out, ld, nullptr, maxn, 0, hint_b, times, alt, n_loop, 0, 0);
 }
 
 template <typename T>
@@ -287,10 +306,16 @@ static int launch_all_t(const TsfaLaunch &a, const T *values) {
     int rc;
     if (a.fam == TSFA_FAM_BASIC) {
         BasicLds L;
-        const size_t lds = L.carve(nullptr, a.maxn, nt, (int)sizeof(T));
+        const size_t lds = L.carve(nullptr, a.maxn, nt, (int)sizeof(T), 1);
         if ((rc = set_lds(k_basic<T>, lds))) return rc;
         k_basic<T><<<grid, nt, lds, st>>>(values, a.starts, a.ends, a.n_series, a.specs, a.nspecs, a.out, a.ld, a.dectab, a.maxn,
-                                          a.hint_a, a.hint_b, a.times, a.alt, a.hint_c, a.hint_d, a.hint_e);
+                                          a.hint_a, a.hint_c, a.hint_d, a.hint_e);
+    } else if (a.fam == TSFA_FAM_TREND) {
+        BasicLds L;
+        const size_t lds = L.carve(nullptr, a.maxn, nt, (int)sizeof(T), 2);
+        if ((rc = set_lds(k_trend<T>, lds))) return rc;
+        k_trend<T><<<grid, nt, lds, st>>>(values, a.starts, a.ends, a.n_series, a.specs, a.nspecs, a.out, a.ld, a.maxn, a.hint_b,
+                                          a.times, a.alt, a.hint_c);
     } else if (a.fam == TSFA_FAM_SORT) {
         SortLds L;
         const size_t lds = L.carve(nullptr, a.maxn, nt, (int)sizeof(T));
@@ -351,7 +376,8 @@ size_t tsfa_seq_lds_bytes(const TsfaSeqGroup &g) {
 
 size_t tsfa_family_lds_bytes(int fam, int maxn, int nt, int aux) {
     switch (fam) {
-    case TSFA_FAM_BASIC: { BasicLds L; return L.carve(nullptr, maxn, nt); }
+    case TSFA_FAM_BASIC: { BasicLds L; return L.carve(nullptr, maxn, nt, 8, 1); }
+    case TSFA_FAM_TREND: { BasicLds L; return L.carve(nullptr, maxn, nt, 8, 2); }
     case TSFA_FAM_SORT: { SortLds L; return L.carve(nullptr, maxn, nt); }
     case TSFA_FAM_SPECTRAL: { SpectralLds L; return L.carve(nullptr, maxn, aux); }
     case TSFA_FAM_AR: { ArLds L; return L.carve(nullptr, maxn, aux); }

@@ -39,14 +39,20 @@ TSFA_HD int tsfa_pow2_ceil(int n) {
 struct BasicLds {
     double *red; NpScratch *np; void *xs; double *w; double *cum; double *altc; int *iw; TsfaSpec *stage; double *ctx;
     // xs_bytes: element size of the LDS-resident series (4: float32 input kept as float32, 8: float64)
-    TSFA_HD size_t carve(unsigned char *base, int maxn, int nt, int xs_bytes = 8) {
+    // part: 1 = k_basic (w holds the sliding maxima of number_peaks / the distance codes: maxn elements of the input
+    //       precision, at least maxn shorts), 2 = k_trend (w = maxn float64: cumulative |x|, chunk aggregates), 3 = both
+    // The numpy-order scratch (np_sum: the statistics / sum |x|, always finished before w is written) shares w.
+    TSFA_HD size_t carve(unsigned char *base, int maxn, int nt, int xs_bytes = 8, int part = 3) {
         LdsCarve c{base, 0};
         red = c.take<double>(TSFA_RED_DOUBLES);
-        np = c.take<NpScratch>(1);
         xs = c.take<unsigned char>((size_t)maxn * xs_bytes);
-        w = c.take<double>(maxn);  // chunk aggregates (agg_linear_trend) ...
-        cum = w;                   // ... aliased with the cumulative |x| of index_mass_quantile (the cache is invalidated)
-        altc = c.take<double>(8 * 16);
+        size_t wb = (part & 2) ? (size_t)maxn * sizeof(double) : (size_t)maxn * xs_bytes;
+        if (wb < sizeof(NpScratch)) wb = sizeof(NpScratch);
+        unsigned char *u = c.take<unsigned char>(wb);
+        w = (double *)u;   // chunk aggregates (agg_linear_trend) ...
+        cum = w;           // ... aliased with the cumulative |x| of index_mass_quantile (the cache is invalidated)
+        np = (NpScratch *)u;
+        altc = (part & 2) ? c.take<double>(8 * 16) : nullptr;
         ctx = c.take<double>(32);  // TSFA_BASIC_CTX: per-series values read by the epilogue columns
         iw = c.take<int>((4 * nt > 256) ? 4 * nt : 256);
 #if defined(TSFA_SPEC_LDS)

@@ -43,7 +43,8 @@ enum tsfa_family {
     TSFA_FAM_ENTROPY = 4, // O(L^2) template-pair sweep
     TSFA_FAM_CWT = 5,     // Ricker/mexh contractions (MFMA) + ridge lines
     TSFA_FAM_SEQ = 6,     // inherently sequential parses
-    TSFA_N_FAMILIES = 7
+    TSFA_FAM_TREND = 7,   // cumulative sums / chunk aggregates / regressions over the series (float64 work array)
+    TSFA_N_FAMILIES = 8
 };
 
 #define TSFA_CALC_LIST(X)                                                              \
@@ -84,15 +85,15 @@ enum tsfa_family {
     X(LONGEST_STRIKE_ABOVE_MEAN, "longest_strike_above_mean", TSFA_FAM_BASIC)           \
     X(LONGEST_STRIKE_BELOW_MEAN, "longest_strike_below_mean", TSFA_FAM_BASIC)           \
     X(NUMBER_PEAKS, "number_peaks", TSFA_FAM_BASIC)                                     \
-    X(INDEX_MASS_QUANTILE, "index_mass_quantile", TSFA_FAM_BASIC)                       \
+    X(INDEX_MASS_QUANTILE, "index_mass_quantile", TSFA_FAM_TREND)                       \
     X(ENERGY_RATIO_BY_CHUNKS, "energy_ratio_by_chunks", TSFA_FAM_BASIC)                 \
     X(C3, "c3", TSFA_FAM_BASIC)                                                         \
     X(TIME_REVERSAL_ASYMMETRY_STATISTIC, "time_reversal_asymmetry_statistic", TSFA_FAM_BASIC) \
     X(AUTOCORRELATION, "autocorrelation", TSFA_FAM_BASIC)                               \
     X(BINNED_ENTROPY, "binned_entropy", TSFA_FAM_BASIC)                                 \
     X(BENFORD_CORRELATION, "benford_correlation", TSFA_FAM_BASIC)                       \
-    X(LINEAR_TREND, "linear_trend", TSFA_FAM_BASIC)                                     \
-    X(AGG_LINEAR_TREND, "agg_linear_trend", TSFA_FAM_BASIC)                             \
+    X(LINEAR_TREND, "linear_trend", TSFA_FAM_TREND)                                     \
+    X(AGG_LINEAR_TREND, "agg_linear_trend", TSFA_FAM_TREND)                             \
     X(QUERY_SIMILARITY_COUNT, "query_similarity_count", TSFA_FAM_BASIC)                 \
     X(MEDIAN, "median", TSFA_FAM_SORT)                                                  \
     X(QUANTILE, "quantile", TSFA_FAM_SORT)                                              \
@@ -121,7 +122,7 @@ enum tsfa_family {
     X(CWT_COEFFICIENTS, "cwt_coefficients", TSFA_FAM_CWT)                               \
     X(NUMBER_CWT_PEAKS, "number_cwt_peaks", TSFA_FAM_CWT)                               \
     X(LEMPEL_ZIV_COMPLEXITY, "lempel_ziv_complexity", TSFA_FAM_SEQ)                     \
-    X(LINEAR_TREND_TIMEWISE, "linear_trend_timewise", TSFA_FAM_BASIC)
+    X(LINEAR_TREND_TIMEWISE, "linear_trend_timewise", TSFA_FAM_TREND)
 
 enum tsfa_calc {
 #define X(id, name, fam) TSFA_C_##id,
