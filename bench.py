@@ -184,7 +184,7 @@ def main():
         roof = None
         if dom:
             fam_cols = {"k_basic": 0, "k_sort": 0, "k_spectral": 0, "k_ar": 0, "k_entropy": 0, "k_cwtpeaks": 0,
-                        "k_seq": 0, "k_cwt_gemm": 0}
+                        "k_seq": 0, "k_trend": 0, "k_cwt_gemm": 0}
             from tsfresh_amd.feature_extraction.registry import CALCULATORS  # noqa: F401
             fam_of = {"sample_entropy": "k_entropy", "approximate_entropy": "k_entropy",
                       "cwt_coefficients": "k_cwt_gemm", "number_cwt_peaks": "k_cwtpeaks",

@@ -47,7 +47,7 @@ __device__ __forceinline__ void basic_body(const T *__restrict__ values, const i
 }
 
 template <typename T>
-__global__ void __launch_bounds__(256, 3) k_basic(const T *__restrict__ values, const int64_t *__restrict__ starts, const int64_t *__restrict__ ends, int64_t n_series,
+__global__ void __launch_bounds__(256, 4) k_basic(const T *__restrict__ values, const int64_t *__restrict__ starts, const int64_t *__restrict__ ends, int64_t n_series,
                         const TsfaSpec *__restrict__ specs, int nspecs, double *__restrict__ out, int64_t ld,
                         const double *__restrict__ dectab, int maxn, int hint_a, int n_loop, int n_count, int n_sum) {
     TsfaAltPlan alt;
