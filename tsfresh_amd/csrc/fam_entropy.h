@@ -542,7 +542,7 @@ TSFA_DEV void entropy_sweep_m2(const Blk &b, const XT *xs, int n, const double *
 #if TSFA_GPU
 // F32: the samples are exact float32 values (float32 input staged as float64): one packed 64-bit sort key
 template <int E, typename XT>
-TSFA_DEVN void entropy_sort_templates_packed(const Blk &b, const XT *xs, int n, unsigned short *perm) {
+TSFA_DEVN void entropy_sort_templates_packed(const Blk b, const XT *xs, int n, unsigned short *perm) {
     const int nrow_m = n - 1;
     unsigned long long pk[E];
 #pragma unroll
@@ -558,7 +558,7 @@ TSFA_DEVN void entropy_sort_templates_packed(const Blk &b, const XT *xs, int n, 
 }
 
 template <int E, typename XT>
-TSFA_DEVN void entropy_sort_templates_regs(const Blk &b, const XT *xs, int n, unsigned short *perm) {
+TSFA_DEVN void entropy_sort_templates_regs(const Blk b, const XT *xs, int n, unsigned short *perm) {
     const int nrow_m = n - 1;
     double key[E];
     int idx[E];
@@ -664,9 +664,10 @@ TSFA_DEV double sampen_from_acc(const EntAcc &a, int n, int m) {
 //   FAST : the plan holds only m = 2 specs and cnt != null (decided on the host): the ordered-pair and generic
 //          sweeps are compiled out, which keeps the register allocation of the hot kernel free of spills.
 template <typename XT, bool FAST = false, bool F32 = false>
-TSFA_DEV void fam_entropy_series(const Blk &b, XT *xs, int n, const TsfaSpec *specs, int nspecs, double *out_row,
+TSFA_DEV void fam_entropy_series(const Blk &b0, XT *xs, int n, const TsfaSpec *specs, int nspecs, double *out_row,
                                  double *thr, unsigned short *perm, ent_ref *refs, unsigned int *cnt,
                                  int staged_ok = 1) {
+    const Blk &b = b0;
     // np.std(x), numpy summation order (the tolerances are c * np.std(x))
     TSFA_TICKER(tk, 0);
     const double dn = (double)n;
@@ -681,6 +682,14 @@ TSFA_DEV void fam_entropy_series(const Blk &b, XT *xs, int n, const TsfaSpec *sp
     // m = 2 specs are batched TSFA_ENT_MAXK at a time
     int done = 0;
     while (done < nspecs) {
+#if TSFA_GPU
+        // the thread index is made opaque per batch: everything derived from it inside the sweeps (addresses, lane
+        // predicates) is then computed where it is used instead of being hoisted to the kernel's top, kept live over
+        // the whole loop and spilled (scratch traffic was 10x the algorithmic HBM bytes of this kernel)
+        int tid_opaque = b0.tid;
+        asm volatile("" : "+v"(tid_opaque));
+        const Blk b{tid_opaque, b0.nt, b0.red, b0.np};  // shadows the function-level alias of b0
+#endif
         int nk = 0;
         int s = done;
         for (; s < nspecs && nk < TSFA_ENT_MAXK; ++s) {
