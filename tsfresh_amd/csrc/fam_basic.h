@@ -440,12 +440,12 @@ TSFA_DEV bool basic_sum_pass(const Blk &b, XS xs, int n, const TsfaSpec *specs, 
                              double *out_row) {
 #if TSFA_GPU
     if (b.nt != 64 || n > 1024 || nsum <= 0) return false;
-    const int lane = b.tid;
+    const int lane0 = b.tid;
     const double mean = st.mean, dn = (double)n;
     double xr[16];
 #pragma unroll
     for (int u = 0; u < 16; ++u) {
-        const int i = u * 64 + lane;
+        const int i = u * 64 + lane0;
         xr[u] = xs[(i < n) ? i : (n - 1)];  // unconditional reads (clamped index): every use below is masked
     }
 #define TSFA_LOAD_LAG(Y, LAG)                                                                         \
@@ -460,9 +460,11 @@ TSFA_DEV bool basic_sum_pass(const Blk &b, XS xs, int n, const TsfaSpec *specs, 
         nxt = specs[first + ((e + 1 < nsum) ? e + 1 : e)];
         const double p0 = sp.p[0], p1 = sp.p[1];
         double v = TSFA_NAN;
-        // nothing of a column is hoisted out of the entry loop (centred copies, masks: they would be spilled)
+        // nothing of a column is hoisted out of the entry loop (centred copies, masks, addresses: they would be spilled)
 #pragma unroll
         for (int u = 0; u < 16; ++u) asm volatile("" : "+v"(xr[u]));
+        int lane = lane0;
+        asm volatile("" : "+v"(lane));
         switch (sp.calc) {
         case TSFA_C_AUTOCORRELATION: {                                   // fc.py:1919
             const int lag = (int)p0;
@@ -587,11 +589,12 @@ TSFA_DEV bool basic_sum_pass(const Blk &b, XS xs, int n, const TsfaSpec *specs, 
 // of one: each half needs far fewer registers and less LDS than the union, and both are latency-bound (the resident
 // wavefronts per CU are what they gain from).
 template <int PART, class XS>
-TSFA_DEV void fam_basic_series(const Blk &b, XS xs, int n, const TsfaSpec *specs, int nspecs,
+TSFA_DEV void fam_basic_series(const Blk &b0, XS xs, int n, const TsfaSpec *specs, int nspecs,
                                double *out_row, double *w, double *cum, double *altc, int *iw, const double *dectab,
                                int peaks_maxsup, int alt_want_p, const TsfaAltPlan &alt, TsfaSpec *stage,
                                const double *times = nullptr, int n_loop = -1, double *ctx = nullptr,
                                int n_count = 0, int n_sum = 0) {
+    const Blk &b = b0;
     TSFA_TICKER(tk, 0);
     BasicStats st;
     if (PART & 1) {
@@ -635,6 +638,13 @@ TSFA_DEV void fam_basic_series(const Blk &b, XS xs, int n, const TsfaSpec *specs
     TSFA_TICK(tk, b, 214);
     TsfaSpec nxt = spec_fetch(b, specs, nspecs, (sbeg < nspecs) ? sbeg : 0, stage);
     for (int s = sbeg; s < nloop; ++s) {
+#if TSFA_GPU
+        // opaque thread index per column: nothing derived from it is hoisted out of the column loop, kept live across
+        // all the other columns and spilled
+        int tid_opaque = b0.tid;
+        asm volatile("" : "+v"(tid_opaque));
+        const Blk b{tid_opaque, b0.nt, b0.red, b0.np};
+#endif
         TSFA_TICKER(tkc, 0);
         const TsfaSpec sp = nxt;
 #if !defined(TSFA_SPEC_LDS)
