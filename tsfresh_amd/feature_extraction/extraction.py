@@ -14,7 +14,9 @@ Arguments that only steer the reference's CPU distributors (`n_jobs`, `chunksize
 `show_warnings`) are accepted and ignored.  `distributor` may be a `tsfresh_amd.utilities.distribution.GPUDistributor`
 (only its device is used); any other distributor raises the reference's ValueError.
 """
+import collections
 import os
+import threading
 import warnings
 
 import numpy as np
@@ -32,6 +34,34 @@ def _default_device():
     if "LOCAL_RANK" in os.environ:  # one process per GPU under torch.distributed.run
         return int(os.environ["LOCAL_RANK"]) % max(_native.device_count(), 1)
     return 0
+
+
+# Native plans (device-side spec tables, twiddles, staging buffers) are kept across calls: creating one costs ~8 ms,
+# a 20 000-series extraction ~25 ms.  One plan may be driven by one host thread at a time, so the key holds the thread.
+_PLAN_CACHE = collections.OrderedDict()
+_PLAN_CACHE_SIZE = 6
+
+
+def _acquire_plan(fplan, device):
+    specs = fplan.native_specs(_native.calc_id)
+    key = (threading.get_ident(), int(device), tuple((cid, tuple(float(v) for v in p)) for cid, p in specs))
+    plan = _PLAN_CACHE.get(key)
+    if plan is not None:
+        _PLAN_CACHE.move_to_end(key)
+        return plan
+    plan = _native.Plan(specs, device=device)
+    _PLAN_CACHE[key] = plan
+    while len(_PLAN_CACHE) > _PLAN_CACHE_SIZE:
+        _, old = _PLAN_CACHE.popitem(last=False)
+        old.close()
+    return plan
+
+
+def clear_plan_cache():
+    """Release the cached native plans (and the device memory they hold)."""
+    while _PLAN_CACHE:
+        _, old = _PLAN_CACHE.popitem(last=False)
+        old.close()
 
 
 def extract_features(
@@ -104,16 +134,13 @@ def extract_features(
             key = (id(fc_parameters), kind_has_dt)
             if key not in plan_cache:
                 fplan = compile_fc_parameters(fc_parameters, has_datetime_index=kind_has_dt)
-                nplan = _native.Plan(fplan.native_specs(_native.calc_id), device=device) if len(fplan) else None
+                nplan = _acquire_plan(fplan, device) if len(fplan) else None
                 plan_cache[key] = (fplan, nplan)
             fplan, nplan = plan_cache[key]
             if nplan is None:
                 continue
             matrix = nplan.extract_host(pk.values, pk.offsets, times=pk.times)
             blocks.append((pk, [pk.kind + "__" + name for name in fplan.names], matrix))
-        for _, nplan in plan_cache.values():
-            if nplan is not None:
-                nplan.close()
 
     return _assemble(blocks, id_dtype, pivot, impute_function)
 
@@ -155,7 +182,8 @@ def _assemble(blocks, id_dtype, pivot, impute_function):
         result.index = result.index.astype(id_dtype)  # data.py:115-116
     except (TypeError, ValueError):
         pass
-    result = result.sort_index()
+    if not result.index.is_monotonic_increasing:  # ids come out of the packer sorted: no 125 MB copy per 20 k rows
+        result = result.sort_index()
     if impute_function is not None:
         impute_function(result)
     return result
@@ -202,7 +230,7 @@ def extract_rolled_features(timeseries_container, column_id=None, column_sort=No
             key = (id(fc_parameters), kind_has_dt)
             if key not in plan_cache:
                 fplan = compile_fc_parameters(fc_parameters, has_datetime_index=kind_has_dt)
-                plan_cache[key] = (fplan, _native.Plan(fplan.native_specs(_native.calc_id), device=device) if len(fplan) else None)
+                plan_cache[key] = (fplan, _acquire_plan(fplan, device) if len(fplan) else None)
             fplan, nplan = plan_cache[key]
             if nplan is None:
                 continue
@@ -223,7 +251,4 @@ def extract_rolled_features(timeseries_container, column_id=None, column_sort=No
             matrix = nplan.extract_windows_host(pk.values, starts, ends, times=pk.times)
             order = sorted(range(len(ids)), key=lambda i: ids[i])
             blocks.append((_WindowBlock(pk.kind, ids[order]), [pk.kind + "__" + n for n in fplan.names], matrix[order]))
-        for _, nplan in plan_cache.values():
-            if nplan is not None:
-                nplan.close()
     return _assemble(blocks, np.dtype(object), pivot, impute_function)
