@@ -133,6 +133,27 @@ int tsfa_extract_windows(tsfa_plan *plan, const void *values, int32_t dtype, con
 int tsfa_plan_set_profiling(tsfa_plan *plan, int32_t enable);
 int32_t tsfa_plan_last_timings(const tsfa_plan *plan, const char **names, float *ms, int32_t cap);
 
+/* ---- feature selection: relevance statistics of the extracted matrix ----
+ * Replaces the per-feature loop of tsfresh/feature_selection/relevance.py:214-322 (calculate_relevance_table ->
+ * _calculate_relevance_table_for_implicit_target) for classification targets: one call yields, for EVERY column of
+ * X, what the reference's univariate tests need
+ *   significance_tests.py:84  target_binary_feature_real_test  (scipy.stats.mannwhitneyu): the mid-rank sum of the
+ *                             rows of each class and the tie term sum(t^3 - t) of the normal approximation,
+ *   significance_tests.py:43  target_binary_feature_binary_test (scipy.stats.fisher_exact): for a column with two
+ *                             distinct values, the rows of each class that hold the larger one,
+ *   relevance.py:396          get_feature_type: the number of distinct values (1 constant, 2 binary, more: real).
+ * X: row-major float64 [n_rows x n_cols], leading dimension ld, host or device memory (`space`), no NaNs.
+ * y_codes: host int32[n_rows], class codes 0 .. n_classes-1 (<= 256).  Outputs are host arrays:
+ * cols[n_cols], rank_sums[n_cols * n_classes], hi_counts[n_cols * n_classes].  Synchronous. */
+typedef struct tsfa_relevance_col {
+    int64_t n_unique;  /* distinct values of the column */
+    double v_lo, v_hi; /* smallest / largest value */
+    double tie_term;   /* sum over tie groups of t^3 - t */
+} tsfa_relevance_col;
+int tsfa_relevance_classes(const double *X, int64_t n_rows, int64_t n_cols, int64_t ld, int32_t space,
+                           const int32_t *y_codes, int32_t n_classes, int32_t device, tsfa_relevance_col *cols,
+                           double *rank_sums, int64_t *hi_counts);
+
 #ifdef __cplusplus
 }
 #endif

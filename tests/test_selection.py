@@ -1,0 +1,151 @@
+"""Feature selection.  CPU: the oracle and the host-side p-value tails against the golden tables of
+the real reference and against scipy.  GPU: `calculate_relevance_table` / `select_features` through the C-ABI against
+the same golden tables and against the oracle on larger matrices."""
+import json
+import math
+import os
+import sys
+
+import numpy as np
+import pandas as pd
+import pytest
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(HERE, "golden"))
+sys.path.insert(0, os.path.dirname(HERE))
+
+from selection_cases import CASES, make_case  # noqa: E402
+
+GOLD = {r["name"]: r for r in json.load(open(os.path.join(HERE, "golden", "ref_selection.json")))}
+
+
+def _frames(rec):
+    X = pd.DataFrame({c: v for c, v in rec["X"].items()}, index=rec["index"])
+    y = pd.Series(rec["y"], index=rec["y_index"])
+    return X, y
+
+
+def _check_against_golden(rec, got_rows):
+    """got_rows: feature -> dict of column values."""
+    cols = [c for c in rec["columns"] if c != "feature"]
+    assert sorted(got_rows) == sorted(rec["table_index"])
+    for r, feat in enumerate(rec["table_index"]):
+        for c in cols:
+            want = rec["table"][c][r]
+            got = got_rows[feat].get(c)
+            if isinstance(want, bool):
+                assert bool(got) == want, (rec["name"], feat, c, got, want)
+            elif want is None:
+                assert got is None or (isinstance(got, float) and math.isnan(got)), (rec["name"], feat, c, got)
+            elif isinstance(want, float):
+                assert got == pytest.approx(want, rel=1e-9, abs=1e-300), (rec["name"], feat, c, got, want)
+            else:
+                assert str(got) == want, (rec["name"], feat, c, got, want)
+
+
+@pytest.mark.parametrize("name", CASES)
+def test_case_inputs_are_reproducible(name):
+    X, y, _ = make_case(name)
+    gX, gy = _frames(GOLD[name])
+    assert list(X.index) == list(gX.index) and list(y.index) == list(gy.index)
+    assert np.array_equal(X.to_numpy(dtype=float), gX[list(X.columns)].to_numpy(dtype=float))
+    assert [str(v) for v in y] == [str(v) for v in gy]
+
+
+@pytest.mark.parametrize("name", CASES)
+def test_oracle_matches_the_reference_tables(name):
+    from oracle.selection import relevance_table
+    rec = GOLD[name]
+    X, y = _frames(rec)
+    _check_against_golden(rec, relevance_table(X, y, **rec["kwargs"]))
+
+
+def test_host_tails_match_scipy():
+    from scipy import stats
+    from tsfresh_amd.feature_selection.significance_tests import fdr_reject, fisher_exact_pvalue, mannwhitney_pvalue
+    from oracle.selection import fdr
+    rng = np.random.default_rng(1)
+    for trial in range(200):
+        n1, n2 = int(rng.integers(1, 40)), int(rng.integers(1, 40))
+        x, z = rng.standard_normal(n1), rng.standard_normal(n2)
+        if trial % 2:
+            x, z = np.round(x, 0), np.round(z, 0)
+        allv = np.concatenate([x, z])
+        _, cnt = np.unique(allv, return_counts=True)
+        p = mannwhitney_pvalue(stats.rankdata(allv)[:n1].sum(), n1, n2, float(np.sum(cnt.astype(float) ** 3 - cnt)))
+        q = stats.mannwhitneyu(x, z, use_continuity=True, alternative="two-sided").pvalue
+        assert (math.isnan(p) and math.isnan(q)) or p == pytest.approx(q, rel=1e-12, abs=1e-300)
+        a, b, c, d = [int(v) for v in rng.integers(0, 50, 4)]
+        if trial % 5 == 0:
+            a, c = b, d
+        assert fisher_exact_pvalue(a, b, c, d) == pytest.approx(stats.fisher_exact([[a, b], [c, d]])[1], rel=1e-10)
+        pv = rng.random(int(rng.integers(1, 30))) ** 3
+        for ind in (True, False):
+            assert np.array_equal(fdr_reject(pv, 0.1, ind), fdr(pv, 0.1, ind))
+
+
+def test_regression_targets_fail_loudly():
+    from tsfresh_amd.feature_extraction.plan import UnsupportedFeature
+    from tsfresh_amd.feature_selection import calculate_relevance_table
+    X = pd.DataFrame({"a": [1.0, 2.0, 3.0, 4.0]})
+    with pytest.raises(UnsupportedFeature):
+        calculate_relevance_table(X, pd.Series([0.1, 0.2, 0.3, 0.4]))
+    with pytest.raises(UnsupportedFeature):
+        calculate_relevance_table(X, pd.Series([0, 1, 0, 1]), test_for_binary_target_real_feature="smir")
+    with pytest.raises(ValueError):
+        calculate_relevance_table(X, pd.Series([0, 1, 0, 1]), ml_task="ranking")
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", CASES)
+def test_gpu_relevance_table_matches_the_reference(name):
+    from tsfresh_amd.feature_selection import calculate_relevance_table, select_features
+    rec = GOLD[name]
+    X, y = _frames(rec)
+    tab = calculate_relevance_table(X, y, **rec["kwargs"])
+    assert list(tab.columns) == rec["columns"]
+    rows = {str(f): {c: (None if (isinstance(v, float) and math.isnan(v)) else v) for c, v in row.items()}
+            for f, row in tab.set_index(tab.index.astype(str)).iterrows()}
+    _check_against_golden(rec, rows)
+    # row order: ascending p-value inside the tested block (ties may permute), constants last
+    if "p_value" in tab.columns and name != "all_constant":
+        p = tab["p_value"].to_numpy()
+        k = int(np.sum(~np.isnan(p)))
+        assert np.all(np.diff(p[:k]) >= 0) and np.all(np.isnan(p[k:]))
+    if name != "all_constant":
+        kw = {k: v for k, v in rec["kwargs"].items()}
+        sel = select_features(X, y, **kw)
+        want = [f for f, r in zip(rec["table_index"], rec["table"]["relevant"]) if r]
+        assert sorted(sel.columns) == sorted(want)
+        assert sel.index.equals(X.index)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n,m,classes", [(5000, 40, 2), (20000, 25, 5), (70000, 12, 3)])
+def test_gpu_relevance_table_matches_the_oracle_at_scale(n, m, classes):
+    from oracle.selection import relevance_table
+    from tsfresh_amd.feature_selection import calculate_relevance_table
+    rng = np.random.default_rng(n)
+    yv = rng.integers(0, classes, n)
+    X = pd.DataFrame(rng.standard_normal((n, m)), columns=["f%d" % i for i in range(m)])
+    X["f0"] += 0.05 * yv
+    X["f1"] = np.round(X["f1"] + 0.1 * yv, 1)          # ties
+    X["f2"] = (rng.random(n) < 0.3 + 0.02 * yv) * 1.0   # binary
+    X["f3"] = 2.0                                       # constant
+    X["f4"] = rng.integers(0, 4, n).astype(float)       # four values
+    y = pd.Series(yv)
+    kw = {"multiclass": classes > 2, "n_significant": 2} if classes > 2 else {}
+    tab = calculate_relevance_table(X, y, **kw)
+    want = relevance_table(X, y, **kw)
+    for f in X.columns:
+        row = tab.loc[f]
+        for c, w in want[f].items():
+            g = row[c]
+            if isinstance(w, (bool, np.bool_)):
+                assert bool(g) == bool(w), (f, c, g, w)
+            elif isinstance(w, str):
+                assert g == w
+            elif isinstance(w, float) and math.isnan(w):
+                assert math.isnan(g)
+            else:
+                assert g == pytest.approx(w, rel=1e-9, abs=1e-300), (f, c, g, w)

@@ -28,11 +28,17 @@ EXPORTS = (
     "tsfa_extract_windows",
     "tsfa_plan_set_profiling",
     "tsfa_plan_last_timings",
+    "tsfa_relevance_classes",
 )
 
 
 class FeatureSpec(ctypes.Structure):
     _fields_ = [("calc", ctypes.c_int32), ("reserved", ctypes.c_int32), ("p", ctypes.c_double * 4)]
+
+
+class RelevanceCol(ctypes.Structure):
+    _fields_ = [("n_unique", ctypes.c_int64), ("v_lo", ctypes.c_double), ("v_hi", ctypes.c_double),
+                ("tie_term", ctypes.c_double)]
 
 
 class NativeError(RuntimeError):
@@ -200,3 +206,29 @@ class Plan:
         _check(self._lib, self._lib.tsfa_extract(
             self._h, ctypes.c_void_p(values_ptr), int(dtype), ctypes.c_void_p(offsets_ptr), int(n_series),
             ctypes.c_void_p(out_ptr), int(ld_out), TSFA_DEVICE, ctypes.c_void_p(stream) if stream else None))
+
+
+def relevance_classes(X, y_codes, n_classes, device=0):
+    """Per-column relevance statistics of the row-major float64 matrix X against class codes (tsfa_relevance_classes).
+    -> (n_unique int64[m], v_lo[m], v_hi[m], tie_term[m], rank_sums[m, C], hi_counts[m, C])."""
+    lib = load()
+    X = np.ascontiguousarray(X, dtype=np.float64)
+    if X.ndim != 2:
+        raise ValueError("X must be two-dimensional")
+    n, m = X.shape
+    y_codes = np.ascontiguousarray(y_codes, dtype=np.int32)
+    if y_codes.shape != (n,):
+        raise ValueError("one class code per row")
+    cols = (RelevanceCol * max(m, 1))()
+    rank_sums = np.zeros((m, n_classes), dtype=np.float64)
+    hi_counts = np.zeros((m, n_classes), dtype=np.int64)
+    lib.tsfa_relevance_classes.restype = ctypes.c_int32
+    lib.tsfa_relevance_classes.argtypes = [ctypes.c_void_p, ctypes.c_int64, ctypes.c_int64, ctypes.c_int64, ctypes.c_int32,
+                                           ctypes.c_void_p, ctypes.c_int32, ctypes.c_int32, ctypes.c_void_p,
+                                           ctypes.c_void_p, ctypes.c_void_p]
+    _check(lib, lib.tsfa_relevance_classes(X.ctypes.data_as(ctypes.c_void_p), n, m, m, TSFA_HOST,
+                                           y_codes.ctypes.data_as(ctypes.c_void_p), int(n_classes), int(device),
+                                           ctypes.cast(cols, ctypes.c_void_p), rank_sums.ctypes.data_as(ctypes.c_void_p),
+                                           hi_counts.ctypes.data_as(ctypes.c_void_p)))
+    rec = np.frombuffer(cols, dtype=[("n_unique", "<i8"), ("v_lo", "<f8"), ("v_hi", "<f8"), ("tie_term", "<f8")], count=m)
+    return (rec["n_unique"].copy(), rec["v_lo"].copy(), rec["v_hi"].copy(), rec["tie_term"].copy(), rank_sums, hi_counts)

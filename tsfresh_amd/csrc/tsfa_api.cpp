@@ -22,6 +22,9 @@ static int fail(int code, const std::string &msg) {
     g_last_error = msg;
     return code;
 }
+
+// for the other translation units of the library (tsfa_relevance.hip)
+int tsfa_fail(int code, const char *msg) { return fail(code, std::string(msg ? msg : "")); }
 #define HIP_TRY(expr)                                                                                    \
     do {                                                                                                 \
         hipError_t e_ = (expr);                                                                          \
