@@ -149,3 +149,29 @@ def test_gpu_relevance_table_matches_the_oracle_at_scale(n, m, classes):
                 assert math.isnan(g)
             else:
                 assert g == pytest.approx(w, rel=1e-9, abs=1e-300), (f, c, g, w)
+
+
+@pytest.mark.gpu
+def test_gpu_extract_relevant_features_end_to_end():
+    """extract -> impute -> select on series whose level depends on the class: the level features must survive, and
+    the selected frame must equal select_features(extract_features(...))."""
+    from tsfresh_amd import MinimalFCParameters, extract_features, extract_relevant_features, select_features
+    from tsfresh_amd.utilities.dataframe_functions import impute
+    rng = np.random.default_rng(4)
+    n_ids, L = 60, 40
+    y = pd.Series(rng.integers(0, 2, n_ids), index=np.arange(n_ids) + 100)
+    rows = []
+    for i, sid in enumerate(y.index):
+        rows.append(pd.DataFrame({"id": sid, "time": np.arange(L), "a": rng.standard_normal(L) + 2.0 * y.iloc[i],
+                                  "b": rng.standard_normal(L)}))
+    df = pd.concat(rows, ignore_index=True)
+    Xr = extract_relevant_features(df, y, column_id="id", column_sort="time", default_fc_parameters=MinimalFCParameters())
+    Xe = extract_features(df, column_id="id", column_sort="time", default_fc_parameters=MinimalFCParameters(),
+                          impute_function=impute)
+    Xs = select_features(Xe, y)
+    assert list(Xr.columns) == list(Xs.columns) and Xr.equals(Xs)
+    assert "a__mean" in Xr.columns and "a__median" in Xr.columns
+    assert not any(c.startswith("b__") for c in Xr.columns if c not in ("b__length",))
+    with pytest.raises(ValueError):
+        extract_relevant_features(df, y.iloc[:-1], column_id="id", column_sort="time",
+                                  default_fc_parameters=MinimalFCParameters())

@@ -11,4 +11,7 @@ from tsfresh_amd.feature_extraction.settings import (  # noqa: F401
     MinimalFCParameters,
 )
 
+from tsfresh_amd.feature_selection import calculate_relevance_table, select_features  # noqa: F401,E402
+from tsfresh_amd.convenience import extract_relevant_features  # noqa: F401,E402
+
 __version__ = "0.1.0"
