@@ -1,5 +1,6 @@
 #!/bin/bash
-# quick GPU check: entropy-focused parity test + bench kernel times
+# quick GPU check while optimising: (TESTS=1: the gpu parity tests) + per-kernel times of the default bench workload
+#   gpurun -- 'TESTS=1 bash profiles/quick_bench.sh'
 export TMPDIR=/tmp
 mkdir -p gpurun_out/exp
 {

@@ -1,4 +1,5 @@
 #!/bin/bash
+# the other BASELINE shapes (Efficient 10k x 1024, Comprehensive 125k x 256, ragged 4096..8192, Minimal): DESIGN.md section 5
 export TMPDIR=/tmp
 mkdir -p gpurun_out/exp
 run() { timeout 300 python bench.py --steps 3 --warmup 1 --no-cpu-baseline "$@" 2>&1 | tail -1 | python -c "import json,sys; d=json.loads(sys.stdin.read()); print(round(d['ms_per_step'],2), round(d['value']), {k: round(v,2) for k,v in d['kernel_ms'].items()})"; }
