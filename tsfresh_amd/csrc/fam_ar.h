@@ -114,20 +114,51 @@ TSFA_DEV void blk_chol_forward(const Blk &b, const double *L, int p, int ld, dou
     blk_sync();
 }
 
+// s8[j] = sum over t in [t0, t1) of fa(t) * fb(t, j), j < nj <= 8 (the caller reduces s8 over the workgroup).
+// With <= 8 time points per thread they stay in registers, every operand read of the 8 x nj products is issued
+// unconditionally on an in-range index (fb must accept any t in [t0, t1) and j < 8), and the lane sums run in the same
+// order as the plain loop: the loop form waits for an LDS round trip in each of its iterations.
+template <class FA, class FB>
+TSFA_DEV void blk_dots8(const Blk &b, int t0, int t1, int nj, FA fa, FB fb, double (&s8)[8]) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) s8[j] = 0.0;
+    if (t1 <= t0) return;
+#if TSFA_GPU
+    if (t1 - t0 <= 8 * b.nt) {
+        double a[8];
+        int tc[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int t = t0 + b.tid + u * b.nt;
+            tc[u] = (t < t1) ? t : t0;
+            const double av = fa(tc[u]);
+            a[u] = (t < t1) ? av : 0.0;
+        }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            if (j < nj) {
+#pragma unroll
+                for (int u = 0; u < 8; ++u) s8[j] += a[u] * fb(tc[u], j);
+            }
+        }
+        return;
+    }
+#endif
+    for (int t = t0 + b.tid; t < t1; t += b.nt) {
+        const double at = fa(t);
+#pragma unroll
+        for (int j = 0; j < 8; ++j)
+            if (j < nj) s8[j] += at * fb(t, j);
+    }
+}
+
 // Lag-product matrix of sequence s over rows t in [t0, t1):  T[i + j*ld] = sum_t s(t-i) s(t-j), 0 <= j <= i <= Lg,
 // and column sums C[j] = sum_t s(t-j).  Requires t0 >= Lg.  S(u) returns s[u].
 template <class S>
 TSFA_DEV void blk_lag_products(const Blk &b, S s, int Lg, int t0, int t1, double *T, int ld, double *C) {
     for (int j0 = 0; j0 <= Lg; j0 += 8) {  // first column by reduction, eight lags per sweep
         double a8[8];
-#pragma unroll
-        for (int j = 0; j < 8; ++j) a8[j] = 0.0;
-        for (int t = t0 + b.tid; t < t1; t += b.nt) {
-            const double st = s(t);
-#pragma unroll
-            for (int j = 0; j < 8; ++j)
-                if (j0 + j <= Lg) a8[j] += s(t - j0 - j) * st;
-        }
+        blk_dots8(b, t0, t1, Lg - j0 + 1, [=](int t) { return s(t); }, [=](int t, int j) { return s(t - j0 - j); }, a8);
         blk_sum_multi<8>(b, a8);
         if (b.tid == 0) {
 #pragma unroll
@@ -219,14 +250,12 @@ TSFA_DEV void fam_ar_series(const Blk &b, X xv, int n, const TsfaSpec *specs, in
     if (pacf_maxlag > nacv) nacv = pacf_maxlag;
     for (int k0 = 0; k0 <= nacv; k0 += 8) {  // eight lags per sweep: x[t] is read once, the sums are reduced together
         double s8[8];
-#pragma unroll
-        for (int j = 0; j < 8; ++j) s8[j] = 0.0;
-        for (int t = b.tid; t < n - k0; t += b.nt) {
-            const double xt = xcc[t];
-#pragma unroll
-            for (int j = 0; j < 8; ++j)
-                if (t + k0 + j < n) s8[j] += xt * xcc[t + k0 + j];
-        }
+        blk_dots8(b, 0, n - k0, 8, [=](int t) { return xcc[t]; },
+                  [=](int t, int j) {
+                      const int i = t + k0 + j;
+                      const double v = xcc[(i < n) ? i : (n - 1)];
+                      return (i < n) ? v : 0.0;
+                  }, s8);
         blk_sum_multi<8>(b, s8);
         if (b.tid == 0) {
 #pragma unroll
@@ -278,14 +307,8 @@ TSFA_DEV void fam_ar_series(const Blk &b, X xv, int n, const TsfaSpec *specs, in
             blk_lag_products(b, dif, maxlag, t0, t1, T, P, C);
             for (int j0 = 0; j0 <= maxlag; j0 += 8) {  // eight lags per sweep, reduced together
                 double a8[8];
-#pragma unroll
-                for (int j = 0; j < 8; ++j) a8[j] = 0.0;
-                for (int t = t0 + b.tid; t < t1; t += b.nt) {
-                    const double xt = xcc[t];
-#pragma unroll
-                    for (int j = 0; j < 8; ++j)
-                        if (j0 + j <= maxlag) a8[j] += xt * dif(t - j0 - j);
-                }
+                blk_dots8(b, t0, t1, maxlag - j0 + 1, [=](int t) { return xcc[t]; },
+                          [=](int t, int j) { return dif(t - j0 - j); }, a8);
                 blk_sum_multi<8>(b, a8);
                 if (b.tid == 0) {
 #pragma unroll
