@@ -129,8 +129,8 @@ extern "C" int tsfa_emul_extract_timed(const tsfa_feature_spec *specs, int n_spe
             }
             std::vector<double> xc(maxn + 8), aw(ArLds::scratch_doubles(P));
             const double *xp = xs.data();
-            fam_ar_series(b, [=](int i) { return xp[i]; }, n, fam[TSFA_FAM_AR].data(), (int)fam[TSFA_FAM_AR].size(), row,
-                          xc.data(), aw.data(), P, hints[TSFA_FAM_AR].a, hints[TSFA_FAM_AR].b,
+            fam_ar_series<double>(b, [=](int i) { return xp[i]; }, n, fam[TSFA_FAM_AR].data(), (int)fam[TSFA_FAM_AR].size(), row,
+                          (void *)xc.data(), aw.data(), P, hints[TSFA_FAM_AR].a, hints[TSFA_FAM_AR].b,
                           hints[TSFA_FAM_AR].c, (s % 2) ? -1 : hints[TSFA_FAM_AR].d);
         }
         if (!fam[TSFA_FAM_ENTROPY].empty()) {

@@ -201,10 +201,18 @@ TSFA_DEV int ar_scratch_doubles(int P) { return 2 * P * P + 6 * P + 64 + 16 + 48
 
 // Evaluate the AR specs of one series.
 //   xv   : sample accessor
-//   xc   : LDS, n doubles   (mean-centred series)
+//   xc_raw : LDS, n + 2 elements of ST (the series in its input precision)
 //   aw   : LDS, ar_scratch_doubles(P) doubles;  P >= max(adf_maxlag_for(n) + 3, max AR order + 2)
-template <class X>
-TSFA_DEV void fam_ar_series(const Blk &b, X xv, int n, const TsfaSpec *specs, int nspecs, double *out_row, double *xc,
+// The series stays in LDS in its INPUT precision ST (float32 samples: half the LDS, one more resident series per CU);
+// the mean-centred value is formed where it is read -- (double)x - mean is the very expression that used to be stored.
+template <class ST>
+struct ArCentred {
+    const ST *p;
+    double mean;
+    TSFA_MEM double operator[](int i) const { return (double)p[i] - mean; }
+};
+template <class ST, class X>
+TSFA_DEV void fam_ar_series(const Blk &b, X xv, int n, const TsfaSpec *specs, int nspecs, double *out_row, void *xc_raw,
                             double *aw, int P, int hint_acf, int hint_pacf, int hint_adf, int n_loop = -1) {
     const int nloop = (n_loop >= 0) ? n_loop : nspecs;  // columns [nloop, nspecs): lane = column epilogue
     const double dn = (double)n;
@@ -213,7 +221,9 @@ TSFA_DEV void fam_ar_series(const Blk &b, X xv, int n, const TsfaSpec *specs, in
     // autocovariances are pure round-off of x - x.mean(), so the order decides what comes out
     const double mean = np_sum(b, n, [=](int i) { return xv(i); }) / dn;
     blk_sync();
-    for (int i = b.tid; i < n; i += b.nt) xc[i] = xv(i) - mean;
+    ST *xs_lds = (ST *)xc_raw;
+    for (int i = b.tid; i < n; i += b.nt) xs_lds[i] = (ST)xv(i);
+    const ArCentred<ST> xc{xs_lds, mean};
     blk_sync();
     double v0 = 0.0;
     for (int i = b.tid; i < n; i += b.nt) v0 += xc[i] * xc[i];
@@ -232,7 +242,7 @@ TSFA_DEV void fam_ar_series(const Blk &b, X xv, int n, const TsfaSpec *specs, in
     double *pac = res + 16;       // 48
     double *arres = pac + 48;     // 40: cached AR solution
     double *pacw = arres + 40;    // 128: Levinson-Durbin columns
-    const double *xcc = xc;
+    const ArCentred<ST> xcc = xc;
 
     TSFA_TICK(tk, b, 120);
     // largest agg_autocorrelation maxlag / partial_autocorrelation lag of the plan (-1: none) and whether ADF is

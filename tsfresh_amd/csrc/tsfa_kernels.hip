@@ -124,11 +124,11 @@ __global__ void __launch_bounds__(256) k_ar(const T *__restrict__ values, const 
     const int64_t off = starts[sidx];
     const int n = (int)(ends[sidx] - off);
     ArLds L;
-    L.carve(tsfa_smem, maxn, P);
+    L.carve(tsfa_smem, maxn, P, (int)sizeof(T));
     TSFA_TICKS_BEGIN();
     Blk b{(int)threadIdx.x, (int)blockDim.x, L.red, L.np};
     const T *g = values + off;
-    fam_ar_series(b, [=](int i) { return (double)g[i]; }, n, specs, nspecs, out + sidx * ld, L.xc, L.aw, P,
+    fam_ar_series<T>(b, [=](int i) { return (double)g[i]; }, n, specs, nspecs, out + sidx * ld, (void *)L.xc, L.aw, P,
                   hint_acf, hint_pacf, hint_adf, n_loop);
     TSFA_TICKS_END();
 }
@@ -330,7 +330,7 @@ static int launch_all_t(const TsfaLaunch &a, const T *values) {
                                              a.dft_n, a.gscratch, a.gscratch_n, a.twc, a.tws, a.hint_a, a.hint_b);
     } else if (a.fam == TSFA_FAM_AR) {
         ArLds L;
-        const size_t lds = L.carve(nullptr, a.maxn, a.ar_P);
+        const size_t lds = L.carve(nullptr, a.maxn, a.ar_P, (int)sizeof(T));
         if ((rc = set_lds(k_ar<T>, lds))) return rc;
         k_ar<T><<<grid, nt, lds, st>>>(values, a.starts, a.ends, a.n_series, a.specs, a.nspecs, a.out, a.ld, a.maxn, a.ar_P,
                                        a.hint_a, a.hint_b, a.hint_c, a.hint_d);

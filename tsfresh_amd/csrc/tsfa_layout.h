@@ -112,10 +112,11 @@ struct ArLds {
     double *red; NpScratch *np; double *xc; double *aw;
     // P: leading dimension of the normal matrices = (max regressors) + 1, chosen by the host for the batch
     TSFA_HD static int scratch_doubles(int P) { return 2 * P * P + 6 * P + 64 + 16 + 48 + 40 + 128; }
-    TSFA_HD size_t carve(unsigned char *base, int maxn, int P) {
+    // xs_bytes: element size of the resident series (4: float32 input kept as float32, 8: float64)
+    TSFA_HD size_t carve(unsigned char *base, int maxn, int P, int xs_bytes = 8) {
         LdsCarve c{base, 0};
         red = c.take<double>(TSFA_RED_DOUBLES);
-        xc = c.take<double>(maxn + 2);
+        xc = (double *)(void *)c.take<unsigned char>((size_t)(maxn + 2) * xs_bytes);
         // the numpy-order scratch is only used for x.mean(), before the matrices exist: it shares their storage
         const size_t ab = (size_t)scratch_doubles(P) * sizeof(double);
         unsigned char *u = c.take<unsigned char>(ab > sizeof(NpScratch) ? ab : sizeof(NpScratch));
