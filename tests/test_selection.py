@@ -175,3 +175,28 @@ def test_gpu_extract_relevant_features_end_to_end():
     with pytest.raises(ValueError):
         extract_relevant_features(df, y.iloc[:-1], column_id="id", column_sort="time",
                                   default_fc_parameters=MinimalFCParameters())
+
+
+@pytest.mark.gpu
+def test_gpu_relevance_statistics_are_exact_with_infinities_and_ties():
+    """The C-ABI statistics against scipy.stats.rankdata / np.unique: heavy ties, +-inf values (which tie with the
+    padding of the device sort), one row, non-power-of-two row counts."""
+    from scipy.stats import rankdata
+    from tsfresh_amd import _native
+    rng = np.random.default_rng(9)
+    for n, m, C in [(1, 2, 1), (7, 3, 2), (2049, 6, 3), (5000, 5, 2), (33000, 4, 4)]:
+        X = rng.standard_normal((n, m))
+        X[:, 0] = np.round(X[:, 0], 0)
+        if n > 4:
+            X[rng.choice(n, max(1, n // 10), replace=False), 1] = np.inf
+            X[rng.choice(n, max(1, n // 10), replace=False), 1] = -np.inf
+        y = rng.integers(0, C, n).astype(np.int32)
+        nu, lo, hi, tie, rs, hc = _native.relevance_classes(X, y, C)
+        for c in range(m):
+            r = rankdata(X[:, c])
+            u, cnt = np.unique(X[:, c], return_counts=True)
+            assert nu[c] == len(u) and lo[c] == u[0] and hi[c] == u[-1]
+            assert tie[c] == float(np.sum(cnt.astype(float) ** 3 - cnt))
+            for k in range(C):
+                assert rs[c, k] == r[y == k].sum()
+                assert hc[c, k] == np.sum((X[:, c] == u[-1]) & (y == k))

@@ -45,9 +45,11 @@ __device__ __forceinline__ void rel_lds_stages(double *sk, uint32_t *si, int til
             const int l = i | j;
             const bool up = (((base + i) & k) == 0);
             const double a = sk[i], b = sk[l];
-            if ((a > b) == up) {
+            const uint32_t ia = si[i], ib = si[l];
+            // ties by row: a total order, so the +inf pads (rows >= n) stay behind real +inf values
+            if (((a > b) || (a == b && ia > ib)) == up) {
                 sk[i] = b; sk[l] = a;
-                const uint32_t ia = si[i]; si[i] = si[l]; si[l] = ia;
+                si[i] = ib; si[l] = ia;
             }
         }
     }
@@ -76,9 +78,10 @@ __global__ void __launch_bounds__(REL_NT) k_rel_sort(double *__restrict__ keys, 
                 const int64_t l = i | j;
                 const bool up = ((i & k) == 0);
                 const double a = K[i], b = K[l];
-                if ((a > b) == up) {
+                const uint32_t ia = I[i], ib = I[l];
+                if (((a > b) || (a == b && ia > ib)) == up) {
                     K[i] = b; K[l] = a;
-                    const uint32_t ia = I[i]; I[i] = I[l]; I[l] = ia;
+                    I[i] = ib; I[l] = ia;
                 }
             }
         }
