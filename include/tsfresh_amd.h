@@ -154,6 +154,29 @@ int tsfa_relevance_classes(const double *X, int64_t n_rows, int64_t n_cols, int6
                            const int32_t *y_codes, int32_t n_classes, int32_t device, tsfa_relevance_col *cols,
                            double *rank_sums, int64_t *hi_counts);
 
+/* The same for real-valued targets (relevance.py:303-316):
+ *   significance_tests.py:170 target_real_feature_real_test   (scipy.stats.kendalltau, asymptotic): discordant pairs
+ *                             and the tie statistics of the column and of the (column, target) pairs,
+ *   significance_tests.py:135 target_real_feature_binary_test (scipy.stats.ks_2samp): for a two-valued column the
+ *                             Kolmogorov-Smirnov distance of the target split by the column.
+ * y_rank: host int32[n_rows], dense ranks of the target (equal targets share a rank); y_perm: host int32[n_rows], the
+ * rows in ascending target order; y_end: host uint8[n_rows], 1 where position p of that order ends a tie group.
+ * cols: host array [n_cols].  Synchronous. */
+typedef struct tsfa_relevance_real_col {
+    int64_t n_unique;   /* distinct values of the column */
+    double v_lo, v_hi;  /* smallest / largest value */
+    int64_t dis;        /* discordant pairs */
+    int64_t xtie, ntie; /* tied pairs of the column / of (column, target) */
+    double x0, x1;      /* sum t(t-1)(t-2), sum t(t-1)(2t+5) over the column's tie groups */
+    int64_t n_hi;       /* two-valued column: rows holding v_hi */
+    double ks_d;        /* two-valued column: sup |F_hi - F_lo| of the target */
+} tsfa_relevance_real_col;
+int tsfa_relevance_real(const double *X, int64_t n_rows, int64_t n_cols, int64_t ld, int32_t space, const int32_t *y_rank,
+                        const int32_t *y_perm, const unsigned char *y_end, int32_t device, tsfa_relevance_real_col *cols);
+/* Pr(D >= h / lcm(m, n)), two-sided two-sample Kolmogorov-Smirnov, m != n, g = gcd(m, n): the exact lattice-path tail of
+ * scipy.stats.ks_2samp(method="exact") -- a scalar function of four integers (host arithmetic, no device needed). */
+double tsfa_ks_outer_prob(int64_t m, int64_t n, int64_t g, int64_t h);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,7 +1,7 @@
 """TEST INFRASTRUCTURE ONLY (imported by tests/ only; the product never imports oracle/).
 
-CPU restatement of the reference's relevance table for classification targets
-(tsfresh/feature_selection/relevance.py:31-350, significance_tests.py:43-132): one scipy call per feature and label,
+CPU restatement of the reference's relevance table
+(tsfresh/feature_selection/relevance.py:31-350, significance_tests.py:43-188): one scipy call per feature and label,
 exactly like the reference, plus statsmodels' FDR procedures (stats/multitest.py: fdrcorrection, "indep" / "negcorr")
 restated in numpy.  Pinned by tests/golden/ref_selection.json, which the REAL reference produced
 (tests/golden/gen_golden_selection.py).
@@ -27,10 +27,41 @@ def fdr(pvals, alpha, independent):
     return out
 
 
-def relevance_table(X, y, multiclass=False, n_significant=1, fdr_level=0.05, hypotheses_independent=False, **_):
+def _regression_table(X, y, types, fdr_level, hypotheses_independent):
+    # relevance.py:303-316 with significance_tests.py:135 (ks_2samp) and :170 (kendalltau, asymptotic)
+    tested = [f for f in X.columns if types[f] == "real"] + [f for f in X.columns if types[f] == "binary"]
+    pv = []
+    for f in tested:
+        x = X[f]
+        if types[f] == "real":
+            pv.append(stats.kendalltau(x, y, method="asymptotic")[1])
+        else:
+            x0, x1 = np.unique(x.values)
+            pv.append(stats.ks_2samp(y[x == x1], y[x == x0])[1])
+    rej = fdr(pv, fdr_level, hypotheses_independent) if tested else []
+    out = {f: {"type": types[f]} for f in X.columns}
+    for i, f in enumerate(tested):
+        out[f]["p_value"] = float(pv[i])
+        out[f]["relevant"] = bool(rej[i])
+    for f in X.columns:
+        if types[f] == "constant":
+            out[f]["p_value"] = np.nan
+            out[f]["relevant"] = False
+    return out
+
+
+def relevance_table(X, y, multiclass=False, n_significant=1, fdr_level=0.05, hypotheses_independent=False, ml_task="auto", **_):
     """-> dict feature -> dict(type, p_value..., relevant...) with the reference's column names."""
     y = y.sort_index()
     X = X.sort_index()
+    if ml_task == "auto":
+        ml_task = "classification" if (y.dtype.kind in "iub" or y.dtype == object) else "regression"
+    if ml_task == "regression":
+        types = {}
+        for f in X.columns:
+            nu = len(set(X[f].values))
+            types[f] = "constant" if nu == 1 else ("binary" if nu == 2 else "real")
+        return _regression_table(X, y, types, fdr_level, hypotheses_independent)
     labels = list(y.unique())
     if multiclass and len(labels) <= 2:
         multiclass = False

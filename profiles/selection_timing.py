@@ -52,6 +52,25 @@ def main():
     res["cpu_oracle_s_scaled"] = cpu / sub.shape[1] * m
     res["cpu_sample"] = "%d of %d columns, 1 core (scipy.stats.mannwhitneyu per feature)" % (sub.shape[1], m)
     res["bytes_matrix"] = int(vals.nbytes)
+    # regression target: Kendall's tau / Kolmogorov-Smirnov (tsfa_relevance_real)
+    yr = pd.Series(np.round(rng.standard_normal(n), 3))
+    Xr = X.copy()
+    Xr.iloc[:, 0] = (yr.to_numpy() > 0.3) * 1.0
+    valsr = np.ascontiguousarray(Xr.to_numpy())
+    for rep in range(3):
+        t0 = time.perf_counter()
+        _native.relevance_real(valsr, yr.to_numpy())
+        res["regression_device_call_s"] = time.perf_counter() - t0
+    for rep in range(2):
+        t0 = time.perf_counter()
+        tabr = calculate_relevance_table(Xr, yr)
+        res["regression_relevance_table_s"] = time.perf_counter() - t0
+    subr = Xr.iloc[:, :: max(1, m // max(2, args.cpu_cols // 4))]
+    t0 = time.perf_counter()
+    relevance_table(subr, yr)
+    cpu = time.perf_counter() - t0
+    res["regression_cpu_oracle_s_per_feature"] = cpu / subr.shape[1]
+    res["regression_cpu_oracle_s_scaled"] = cpu / subr.shape[1] * m
     print(json.dumps(res))
 
 

@@ -47,7 +47,7 @@ for name in CASES:
     X, y, kw = make_case(name)
     tab = calculate_relevance_table(X, y, n_jobs=0, **kw)
     rec = {"name": name, "kwargs": kw, "X": {c: [float(v) for v in X[c]] for c in X.columns}, "index": [int(i) for i in X.index],
-           "y": [(int(v) if not isinstance(v, str) else v) for v in y], "y_index": [int(i) for i in y.index],
+           "y": [(v if isinstance(v, str) else (float(v) if y.dtype.kind == "f" else int(v))) for v in y], "y_index": [int(i) for i in y.index],
            "table_index": [str(i) for i in tab.index], "columns": list(tab.columns), "table": {}}
     for c in tab.columns:
         col = tab[c]

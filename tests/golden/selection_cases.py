@@ -3,7 +3,8 @@ import numpy as np
 import pandas as pd
 
 CASES = ["binary_basic", "binary_ties", "binary_small_class_exact", "binary_independent_fdr", "multiclass3",
-         "multiclass_strings", "all_constant", "shuffled_index"]
+         "multiclass_strings", "all_constant", "shuffled_index", "regression_basic", "regression_ties",
+         "regression_equal_halves"]
 
 
 def _features(rng, n, y_signal):
@@ -67,6 +68,26 @@ def make_case(name):
         perm = rng.permutation(n)
         X = X.iloc[perm]
         y = y.iloc[rng.permutation(n)]
+    elif name == "regression_basic":
+        n = 250
+        yv = rng.standard_normal(n)
+        y = pd.Series(yv)
+        X = _features(rng, n, yv)
+    elif name == "regression_ties":
+        n = 400
+        yv = np.round(rng.standard_normal(n), 1)
+        y = pd.Series(yv)
+        X = _features(rng, n, yv)
+        X["rel_real"] = np.round(X["rel_real"], 1)
+    elif name == "regression_equal_halves":
+        n = 300
+        yv = rng.standard_normal(n)
+        y = pd.Series(yv)
+        X = _features(rng, n, yv)
+        half = np.zeros(n)
+        half[rng.choice(n, n // 2, replace=False)] = 1.0   # n1 == n2: the square formula of ks_2samp
+        X["half_binary"] = half
+        X["rel_half"] = (yv > np.median(yv)).astype(float)
     else:
         raise KeyError(name)
     return X, y, kw

@@ -29,6 +29,8 @@ EXPORTS = (
     "tsfa_plan_set_profiling",
     "tsfa_plan_last_timings",
     "tsfa_relevance_classes",
+    "tsfa_relevance_real",
+    "tsfa_ks_outer_prob",
 )
 
 
@@ -232,3 +234,42 @@ def relevance_classes(X, y_codes, n_classes, device=0):
                                            hi_counts.ctypes.data_as(ctypes.c_void_p)))
     rec = np.frombuffer(cols, dtype=[("n_unique", "<i8"), ("v_lo", "<f8"), ("v_hi", "<f8"), ("tie_term", "<f8")], count=m)
     return (rec["n_unique"].copy(), rec["v_lo"].copy(), rec["v_hi"].copy(), rec["tie_term"].copy(), rank_sums, hi_counts)
+
+
+_REAL_COL_DTYPE = [("n_unique", "<i8"), ("v_lo", "<f8"), ("v_hi", "<f8"), ("dis", "<i8"), ("xtie", "<i8"), ("ntie", "<i8"),
+                   ("x0", "<f8"), ("x1", "<f8"), ("n_hi", "<i8"), ("ks_d", "<f8")]
+
+
+def relevance_real(X, y, device=0):
+    """Per-column statistics of the row-major float64 matrix X against a real-valued target (tsfa_relevance_real).
+    -> (structured array with the fields of tsfa_relevance_real_col, dense ranks of y)."""
+    lib = load()
+    X = np.ascontiguousarray(X, dtype=np.float64)
+    n, m = X.shape
+    y = np.ascontiguousarray(y, dtype=np.float64)
+    if y.shape != (n,):
+        raise ValueError("one target value per row")
+    # the target is one vector: its dense ranks / sorted order are prepared here once for all columns
+    uniq, inverse = np.unique(y, return_inverse=True)
+    y_rank = np.ascontiguousarray(inverse, dtype=np.int32)
+    y_perm = np.ascontiguousarray(np.argsort(y, kind="stable"), dtype=np.int32)
+    ys = y[y_perm]
+    y_end = np.ones(n, dtype=np.uint8)
+    if n > 1:
+        y_end[:-1] = ys[1:] != ys[:-1]
+    cols = np.zeros(max(m, 1), dtype=_REAL_COL_DTYPE)
+    lib.tsfa_relevance_real.restype = ctypes.c_int32
+    lib.tsfa_relevance_real.argtypes = [ctypes.c_void_p, ctypes.c_int64, ctypes.c_int64, ctypes.c_int64, ctypes.c_int32,
+                                        ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int32, ctypes.c_void_p]
+    _check(lib, lib.tsfa_relevance_real(X.ctypes.data_as(ctypes.c_void_p), n, m, m, TSFA_HOST,
+                                        y_rank.ctypes.data_as(ctypes.c_void_p), y_perm.ctypes.data_as(ctypes.c_void_p),
+                                        y_end.ctypes.data_as(ctypes.c_void_p), int(device),
+                                        cols.ctypes.data_as(ctypes.c_void_p)))
+    return cols[:m], y_rank
+
+
+def ks_outer_prob(m, n, g, h):
+    lib = load()
+    lib.tsfa_ks_outer_prob.restype = ctypes.c_double
+    lib.tsfa_ks_outer_prob.argtypes = [ctypes.c_int64] * 4
+    return float(lib.tsfa_ks_outer_prob(int(m), int(n), int(g), int(h)))

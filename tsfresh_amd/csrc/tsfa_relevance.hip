@@ -152,6 +152,192 @@ __global__ void __launch_bounds__(REL_NT) k_rel_stats(const double *__restrict__
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// Real-valued targets (significance_tests.py:170 target_real_feature_real_test = scipy.stats.kendalltau, :135
+// target_real_feature_binary_test = scipy.stats.ks_2samp).  The column is sorted by (value, dense rank of y) -- the
+// payload of the sort is the y rank instead of the row -- which is the order scipy's kendalltau establishes; then
+//   k_rel_xties       tie statistics of x and of the (x, y) pairs (group ends by binary search),
+//   k_rel_inversions  discordant pairs = strict inversions of the y-rank sequence: bottom-up merge sort, runs up to 4096
+//                     in LDS (rank of every element in the sibling run by binary search), longer runs by merge-path
+//                     segments in HBM scratch (each thread merges one contiguous output segment and counts, for every
+//                     element taken from the right run, the left elements still waiting),
+//   k_rel_ks          for two-valued columns: the two-sample Kolmogorov-Smirnov distance of y split by the column,
+//                     walked in y order (prefix counts by a block scan, evaluated where a y tie group ends).
+// ---------------------------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(REL_NT) k_rel_stage_real(const double *__restrict__ X, int64_t n, int64_t ld, int64_t c0,
+                                                            const int32_t *__restrict__ yrank, double *__restrict__ keys,
+                                                            uint32_t *__restrict__ idx, int64_t np2) {
+    const int64_t c = blockIdx.x;
+    double *K = keys + c * np2;
+    uint32_t *I = idx + c * np2;
+    const double *col = X + c0 + c;
+    for (int64_t r = threadIdx.x; r < np2; r += REL_NT) {
+        K[r] = (r < n) ? col[r * ld] : __builtin_inf();
+        I[r] = (r < n) ? (uint32_t)yrank[r] : 0xFFFFFFFFu;
+    }
+}
+
+__global__ void __launch_bounds__(REL_NT) k_rel_xties(const double *__restrict__ keys, const uint32_t *__restrict__ idx, int64_t np2, int64_t n,
+                                                       int64_t c0, tsfa_relevance_real_col *__restrict__ cols) {
+    __shared__ unsigned long long s_xtie, s_ntie, s_uniq;
+    __shared__ double s_x0, s_x1;
+    const double *K = keys + (int64_t)blockIdx.x * np2;
+    const uint32_t *I = idx + (int64_t)blockIdx.x * np2;
+    if (threadIdx.x == 0) { s_xtie = 0ull; s_ntie = 0ull; s_uniq = 0ull; s_x0 = 0.0; s_x1 = 0.0; }
+    __syncthreads();
+    unsigned long long xtie = 0ull, ntie = 0ull, uniq = 0ull;
+    double x0 = 0.0, x1 = 0.0;
+    for (int64_t i = threadIdx.x; i < n; i += REL_NT) {
+        const double key = K[i];
+        const uint32_t yr = I[i];
+        const bool xstart = (i == 0) || (K[i - 1] != key);
+        const bool jstart = xstart || (I[i - 1] != yr);
+        if (xstart) {
+            ++uniq;
+            if (i + 1 < n && K[i + 1] == key) {  // a tie group of x starts here: its end by binary search
+                int64_t lo = i + 1, hi = n;
+                while (lo < hi) { const int64_t mid = (lo + hi) >> 1; if (K[mid] <= key) lo = mid + 1; else hi = mid; }
+                const unsigned long long t = (unsigned long long)(lo - i);
+                xtie += t * (t - 1ull) / 2ull;
+                const double td = (double)t;
+                x0 += td * (td - 1.0) * (td - 2.0);
+                x1 += td * (td - 1.0) * (2.0 * td + 5.0);
+            }
+        }
+        if (jstart && i + 1 < n && K[i + 1] == key && I[i + 1] == yr) {  // joint tie group of (x, y)
+            int64_t lo = i + 1, hi = n;
+            while (lo < hi) {
+                const int64_t mid = (lo + hi) >> 1;
+                const double km = K[mid];
+                if (km < key || (km == key && I[mid] <= yr)) lo = mid + 1; else hi = mid;
+            }
+            const unsigned long long t = (unsigned long long)(lo - i);
+            ntie += t * (t - 1ull) / 2ull;
+        }
+    }
+    atomicAdd(&s_xtie, xtie); atomicAdd(&s_ntie, ntie); atomicAdd(&s_uniq, uniq);
+    atomicAdd(&s_x0, x0); atomicAdd(&s_x1, x1);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        tsfa_relevance_real_col &o = cols[c0 + blockIdx.x];
+        o.n_unique = (int64_t)s_uniq;
+        o.v_lo = K[0];
+        o.v_hi = K[n - 1];
+        o.xtie = (int64_t)s_xtie;
+        o.ntie = (int64_t)s_ntie;
+        o.x0 = s_x0;
+        o.x1 = s_x1;
+        o.dis = 0;
+        o.n_hi = 0;
+        o.ks_d = 0.0;
+    }
+}
+
+// strict inversions of seq[0 .. np2) (padded with 0xFFFFFFFF); tmp: a second buffer of np2 words; both are clobbered
+__global__ void __launch_bounds__(REL_NT) k_rel_inversions(uint32_t *__restrict__ idx, uint32_t *__restrict__ tmpbuf, int64_t np2, int tile,
+                                                            int64_t c0, tsfa_relevance_real_col *__restrict__ cols) {
+    extern __shared__ unsigned char rel_smem[];
+    uint32_t *sa = (uint32_t *)rel_smem, *sb = sa + tile;
+    __shared__ unsigned long long s_inv;
+    uint32_t *A = idx + (int64_t)blockIdx.x * np2;
+    uint32_t *B = tmpbuf + (int64_t)blockIdx.x * np2;
+    if (threadIdx.x == 0) s_inv = 0ull;
+    unsigned long long inv = 0ull;
+    for (int64_t base = 0; base < np2; base += tile) {
+        __syncthreads();
+        for (int t = threadIdx.x; t < tile; t += REL_NT) sa[t] = A[base + t];
+        uint32_t *src = sa, *dst = sb;
+        for (int run = 1; run < tile; run <<= 1) {
+            __syncthreads();
+            for (int t = threadIdx.x; t < tile; t += REL_NT) {
+                const int off = t & (2 * run - 1), lbase = t - off, rbase = lbase + run;
+                const uint32_t v = src[t];
+                int pos;
+                if (off < run) {  // left run: elements of the right run that are smaller go first
+                    int lo = 0, hi = run;
+                    while (lo < hi) { const int mid = (lo + hi) >> 1; if (src[rbase + mid] < v) lo = mid + 1; else hi = mid; }
+                    pos = off + lo;
+                } else {          // right run: elements of the left run that are <= v go first; the others are inversions
+                    int lo = 0, hi = run;
+                    while (lo < hi) { const int mid = (lo + hi) >> 1; if (src[lbase + mid] <= v) lo = mid + 1; else hi = mid; }
+                    pos = (off - run) + lo;
+                    inv += (unsigned long long)(run - lo);
+                }
+                dst[lbase + pos] = v;
+            }
+            uint32_t *sw = src; src = dst; dst = sw;
+        }
+        __syncthreads();
+        for (int t = threadIdx.x; t < tile; t += REL_NT) A[base + t] = src[t];
+    }
+    // merge levels above the tile: one contiguous output segment per thread (merge path), ping-pong A <-> B
+    const int64_t seg = np2 / REL_NT;  // np2 >= 2048: >= 2
+    uint32_t *src = A, *dst = B;
+    for (int64_t run = tile; run < np2; run <<= 1) {
+        __syncthreads();
+        const int64_t o0 = (int64_t)threadIdx.x * seg;
+        const int64_t pbase = o0 & ~(2 * run - 1), diag = o0 - pbase;
+        const uint32_t *L = src + pbase, *R = src + pbase + run;
+        int64_t lo = (diag > run) ? diag - run : 0, hi = (diag < run) ? diag : run;
+        while (lo < hi) {  // smallest li with L[li] > R[diag - li - 1]  (ties: the left element goes first)
+            const int64_t mid = (lo + hi) >> 1;
+            if (L[mid] <= R[diag - mid - 1]) lo = mid + 1; else hi = mid;
+        }
+        int64_t li = lo, ri = diag - lo;
+        for (int64_t k = 0; k < seg; ++k) {
+            const bool take_left = (li < run) && (ri >= run || L[li] <= R[ri]);
+            if (take_left) { dst[o0 + k] = L[li]; ++li; }
+            else { dst[o0 + k] = R[ri]; ++ri; inv += (unsigned long long)(run - li); }
+        }
+        uint32_t *sw = src; src = dst; dst = sw;
+    }
+    atomicAdd(&s_inv, inv);
+    __syncthreads();
+    if (threadIdx.x == 0) cols[c0 + blockIdx.x].dis = (int64_t)s_inv;
+}
+
+// two-valued columns: sup |F_hi - F_lo| of y over the rows with the larger / the smaller value of the column
+__global__ void __launch_bounds__(REL_NT) k_rel_ks(const double *__restrict__ X, int64_t n, int64_t ld, const int32_t *__restrict__ yperm,
+                                                    const unsigned char *__restrict__ yend, tsfa_relevance_real_col *__restrict__ cols) {
+    __shared__ long long s_cnt[REL_NT];
+    __shared__ double s_max[REL_NT], s_min[REL_NT];
+    tsfa_relevance_real_col &o = cols[blockIdx.x];
+    if (o.n_unique != 2) return;
+    const double vhi = o.v_hi;
+    const double *col = X + blockIdx.x;
+    const int64_t chunk = (n + REL_NT - 1) / REL_NT;
+    const int64_t p0 = (int64_t)threadIdx.x * chunk, p1 = (p0 + chunk < n) ? p0 + chunk : n;
+    long long c = 0;
+    for (int64_t p = p0; p < p1; ++p) c += (col[(int64_t)yperm[p] * ld] == vhi) ? 1 : 0;
+    s_cnt[threadIdx.x] = c;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        long long acc = 0;
+        for (int t = 0; t < REL_NT; ++t) { const long long v = s_cnt[t]; s_cnt[t] = acc; acc += v; }
+        o.n_hi = acc;
+    }
+    __syncthreads();
+    const double n1 = (double)o.n_hi, n0 = (double)(n - o.n_hi);
+    long long k1 = s_cnt[threadIdx.x];
+    double mx = -__builtin_inf(), mn = __builtin_inf();
+    for (int64_t p = p0; p < p1; ++p) {
+        k1 += (col[(int64_t)yperm[p] * ld] == vhi) ? 1 : 0;
+        if (yend[p]) {
+            const double d = (double)k1 / n1 - (double)(p + 1 - k1) / n0;  // searchsorted(side="right") / n, as scipy
+            mx = fmax(mx, d);
+            mn = fmin(mn, d);
+        }
+    }
+    s_max[threadIdx.x] = mx; s_min[threadIdx.x] = mn;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int t = 1; t < REL_NT; ++t) { mx = fmax(mx, s_max[t]); mn = fmin(mn, s_min[t]); }
+        double mins = -mn;
+        mins = (mins < 0.0) ? 0.0 : ((mins > 1.0) ? 1.0 : mins);
+        o.ks_d = (mins > mx) ? mins : mx;
+    }
+}
+
 #define REL_HIP(call)                                                                          \
     do {                                                                                       \
         hipError_t e_ = (call);                                                                \
@@ -215,4 +401,105 @@ extern "C" int tsfa_relevance_classes(const double *X, int64_t n_rows, int64_t n
 done:
     (void)hipFree(dX); (void)hipFree(dkeys); (void)hipFree(didx); (void)hipFree(dy); (void)hipFree(drs); (void)hipFree(dhc); (void)hipFree(dcols);
     return rc;
+}
+
+extern "C" int tsfa_relevance_real(const double *X, int64_t n_rows, int64_t n_cols, int64_t ld, int32_t space,
+                                   const int32_t *y_rank, const int32_t *y_perm, const unsigned char *y_end, int32_t device,
+                                   tsfa_relevance_real_col *cols) {
+    if (!X || !y_rank || !y_perm || !y_end || !cols || n_rows < 1 || n_cols < 0 || ld < n_cols)
+        return tsfa_fail(TSFA_ERR_INVALID, "tsfa_relevance_real: null pointer or bad shape");
+    if (n_rows >= (1ll << 31)) return tsfa_fail(TSFA_ERR_TOO_LONG, "tsfa_relevance_real: more than 2^31 rows");
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1 || device < 0 || device >= ndev)
+        return tsfa_fail(TSFA_ERR_NO_DEVICE, "tsfa_relevance_real: no such HIP device (there is no CPU path)");
+    if (n_cols == 0) return TSFA_OK;
+    int rc = TSFA_OK;
+    int64_t np2 = 2048;
+    while (np2 < n_rows) np2 <<= 1;
+    const int tile = (int)((np2 < REL_TILE) ? np2 : REL_TILE);
+    int64_t batch = (int64_t)(4.0e9 / (12.0 * (double)np2));
+    if (batch < 1) batch = 1;
+    if (batch > n_cols) batch = n_cols;
+    double *dX = nullptr, *dkeys = nullptr;
+    uint32_t *didx = nullptr;
+    int32_t *dyr = nullptr, *dyp = nullptr;
+    unsigned char *dye = nullptr;
+    tsfa_relevance_real_col *dcols = nullptr;
+    const double *Xd = X;
+    REL_HIP(hipSetDevice(device));
+    if (space == TSFA_HOST) {
+        REL_HIP(hipMalloc((void **)&dX, (size_t)n_rows * ld * sizeof(double)));
+        REL_HIP(hipMemcpy(dX, X, (size_t)n_rows * ld * sizeof(double), hipMemcpyHostToDevice));
+        Xd = dX;
+    }
+    REL_HIP(hipMalloc((void **)&dkeys, (size_t)batch * np2 * sizeof(double)));
+    REL_HIP(hipMalloc((void **)&didx, (size_t)batch * np2 * sizeof(uint32_t)));
+    REL_HIP(hipMalloc((void **)&dyr, (size_t)n_rows * sizeof(int32_t)));
+    REL_HIP(hipMalloc((void **)&dyp, (size_t)n_rows * sizeof(int32_t)));
+    REL_HIP(hipMalloc((void **)&dye, (size_t)n_rows));
+    REL_HIP(hipMalloc((void **)&dcols, (size_t)n_cols * sizeof(tsfa_relevance_real_col)));
+    REL_HIP(hipMemcpy(dyr, y_rank, (size_t)n_rows * sizeof(int32_t), hipMemcpyHostToDevice));
+    REL_HIP(hipMemcpy(dyp, y_perm, (size_t)n_rows * sizeof(int32_t), hipMemcpyHostToDevice));
+    REL_HIP(hipMemcpy(dye, y_end, (size_t)n_rows, hipMemcpyHostToDevice));
+    {
+        const size_t lds_sort = (size_t)tile * (sizeof(double) + sizeof(uint32_t));
+        const size_t lds_inv = (size_t)tile * 2 * sizeof(uint32_t);
+        REL_HIP(hipFuncSetAttribute((const void *)k_rel_sort, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_sort));
+        REL_HIP(hipFuncSetAttribute((const void *)k_rel_inversions, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_inv));
+        for (int64_t c0 = 0; c0 < n_cols; c0 += batch) {
+            const int64_t nb = (n_cols - c0 < batch) ? (n_cols - c0) : batch;
+            k_rel_stage_real<<<dim3((unsigned)nb), REL_NT, 0, 0>>>(Xd, n_rows, ld, c0, dyr, dkeys, didx, np2);
+            k_rel_sort<<<dim3((unsigned)nb), REL_NT, lds_sort, 0>>>(dkeys, didx, np2, tile);
+            k_rel_xties<<<dim3((unsigned)nb), REL_NT, 0, 0>>>(dkeys, didx, np2, n_rows, c0, dcols);
+            // the sorted values are dead now: their storage is the second buffer of the merge sort (np2 words per column
+            // out of the np2 doubles)
+            k_rel_inversions<<<dim3((unsigned)nb), REL_NT, lds_inv, 0>>>(didx, (uint32_t *)dkeys, np2, tile, c0, dcols);
+            REL_HIP(hipGetLastError());
+        }
+        k_rel_ks<<<dim3((unsigned)n_cols), REL_NT, 0, 0>>>(Xd, n_rows, ld, dyp, dye, dcols);
+        REL_HIP(hipGetLastError());
+    }
+    REL_HIP(hipMemcpy(cols, dcols, (size_t)n_cols * sizeof(tsfa_relevance_real_col), hipMemcpyDeviceToHost));
+done:
+    (void)hipFree(dX); (void)hipFree(dkeys); (void)hipFree(didx); (void)hipFree(dyr); (void)hipFree(dyp); (void)hipFree(dye); (void)hipFree(dcols);
+    return rc;
+}
+
+// Pr(D >= h / lcm(m, n)) for the two-sided two-sample Kolmogorov-Smirnov statistic, m != n: the proportion of lattice
+// paths (0,0) -> (m,n) that do not stay strictly inside |x/m - y/n| < h/lcm (Hodges 1958; the column recurrence scipy
+// uses in ks_2samp(method="exact"), computed on the complement so small probabilities keep their relative accuracy).
+// A scalar function of four integers: no data passes through it.
+extern "C" double tsfa_ks_outer_prob(int64_t m, int64_t n, int64_t g, int64_t h) {
+    if (m < n) { const int64_t t = m; m = n; n = t; }
+    const int64_t mg = m / g, ng = n / g;
+    int64_t minj = 0, maxj = (h + mg - 1) / mg;
+    if (maxj > n + 1) maxj = n + 1;
+    int64_t curlen = maxj - minj;
+    int64_t lenA = 2 * maxj + 2;
+    if (lenA > n + 1) lenA = n + 1;
+    std::vector<double> A((size_t)lenA + 2, 1.0);
+    for (int64_t j = minj; j < maxj; ++j) A[(size_t)j] = 0.0;
+    for (int64_t i = 1; i <= m; ++i) {
+        const int64_t lastminj = minj, lastlen = curlen;
+        // floor((ng * i - h) / mg) + 1 and ceil((ng * i + h) / mg) in exact integer arithmetic
+        const int64_t num = ng * i - h;
+        int64_t fl = num / mg;
+        if (num % mg != 0 && num < 0) --fl;
+        minj = fl + 1;
+        if (minj < 0) minj = 0;
+        if (minj > n) minj = n;
+        maxj = (ng * i + h + mg - 1) / mg;
+        if (maxj > n + 1) maxj = n + 1;
+        if (maxj <= minj) return 1.0;
+        double val = (minj == 0) ? 0.0 : 1.0;
+        for (int64_t jj = 0; jj < maxj - minj; ++jj) {
+            const int64_t j = jj + minj;
+            val = (A[(size_t)(jj + minj - lastminj)] * (double)i + val * (double)j) / (double)(i + j);
+            A[(size_t)jj] = val;
+        }
+        curlen = maxj - minj;
+        if (lastlen > curlen)
+            for (int64_t q = maxj - minj; q < maxj - minj + (lastlen - curlen); ++q) A[(size_t)q] = 1.0;
+    }
+    return A[(size_t)(maxj - minj - 1)];
 }

@@ -1,4 +1,4 @@
-"""`calculate_relevance_table` (tsfresh/feature_selection/relevance.py:31) on the GPU, classification targets.
+"""`calculate_relevance_table` (tsfresh/feature_selection/relevance.py:31) on the GPU.
 
 The reference maps a scipy test over the columns of X (`_calculate_relevance_table_for_implicit_target`,
 relevance.py:325) once per class label.  Here ONE call of `tsfa_relevance_classes` yields, for all columns and all
@@ -14,7 +14,8 @@ import pandas as pd
 
 from tsfresh_amd import _native
 from tsfresh_amd.feature_extraction.plan import UnsupportedFeature
-from tsfresh_amd.feature_selection.significance_tests import fdr_reject, fisher_exact_pvalue, mannwhitney_pvalue
+from tsfresh_amd.feature_selection.significance_tests import (fdr_reject, fisher_exact_pvalue, kendall_pvalue,
+                                                             ks_2samp_pvalue, mannwhitney_pvalue, target_tie_statistics)
 
 
 def infer_ml_task(y):
@@ -65,10 +66,7 @@ def calculate_relevance_table(X, y, ml_task="auto", multiclass=False, n_signific
         if len(y.unique()) <= 2:
             warnings.warn("Two or fewer classes, binary feature selection will be used (multiclass = False)")
             multiclass = False
-    if ml_task == "regression":
-        raise UnsupportedFeature("regression targets (Kendall's tau / Kolmogorov-Smirnov) have no kernel yet: "
-                                 "tsfresh_amd.feature_selection covers classification targets")
-    if test_for_binary_target_real_feature != "mann":
+    if ml_task == "classification" and test_for_binary_target_real_feature != "mann":
         if test_for_binary_target_real_feature == "smir":
             raise UnsupportedFeature("the Kolmogorov-Smirnov test has no kernel yet (use 'mann')")
         raise ValueError("Please use a valid entry for test_for_binary_target_real_feature. "
@@ -80,14 +78,19 @@ def calculate_relevance_table(X, y, ml_task="auto", multiclass=False, n_signific
         raise ValueError("Feature {} contains NaN values".format(bad))
     if y.dtype.kind == "f" and np.isnan(y.to_numpy()).any():
         raise ValueError("Target contains NaN values")
-    labels = list(y.unique())  # order of first appearance, as the reference iterates
-    codes = pd.Categorical(y, categories=labels).codes.astype(np.int32)
     if device is None:
         device = _default_device()
-    n_unique, _, _, tie_term, rank_sums, hi_counts = _native.relevance_classes(values, codes, len(labels), device=device)
-    class_n = np.bincount(codes, minlength=len(labels))
-    n = len(codes)
-    hi_total = hi_counts.sum(axis=1)
+    n = len(y)
+    if ml_task == "classification":
+        labels = list(y.unique())  # order of first appearance, as the reference iterates
+        codes = pd.Categorical(y, categories=labels).codes.astype(np.int32)
+        n_unique, _, _, tie_term, rank_sums, hi_counts = _native.relevance_classes(values, codes, len(labels), device=device)
+        class_n = np.bincount(codes, minlength=len(labels))
+        hi_total = hi_counts.sum(axis=1)
+    else:
+        real_cols, y_rank = _native.relevance_real(values, y.to_numpy(dtype=np.float64), device=device)
+        n_unique = real_cols["n_unique"]
+        ytie, y0, y1 = target_tie_statistics(y_rank)
 
     with warnings.catch_warnings():
         warnings.simplefilter("default" if show_warnings else "ignore")
@@ -107,6 +110,21 @@ def calculate_relevance_table(X, y, ml_task="auto", multiclass=False, n_signific
         if len(table_const) == len(relevance_table):
             return table_const
 
+        if ml_task == "regression":
+            # relevance.py:303-316: Kendall's tau for the real features, Kolmogorov-Smirnov of the target split by a
+            # binary feature; one table
+            t_real, t_bin = table_real.copy(), table_binary.copy()
+            t_real["p_value"] = pd.Series(
+                [kendall_pvalue(n, real_cols["dis"][pos[f]], real_cols["xtie"][pos[f]], real_cols["ntie"][pos[f]],
+                                real_cols["x0"][pos[f]], real_cols["x1"][pos[f]], ytie, y0, y1) for f in t_real.index],
+                index=t_real.index, dtype=float)
+            t_bin["p_value"] = pd.Series(
+                [ks_2samp_pvalue(real_cols["n_hi"][pos[f]], n - real_cols["n_hi"][pos[f]], real_cols["ks_d"][pos[f]])
+                 for f in t_bin.index], index=t_bin.index, dtype=float)
+            relevance_table = pd.concat([t_real, t_bin])
+            relevance_table["relevant"] = fdr_reject(relevance_table.p_value.to_numpy(), fdr_level, hypotheses_independent)
+            relevance_table = relevance_table.sort_values("p_value")
+            labels = []
         tables = []
         for k, label in enumerate(labels):
             n1, n0 = int(class_n[k]), int(n - class_n[k])
@@ -127,7 +145,9 @@ def calculate_relevance_table(X, y, ml_task="auto", multiclass=False, n_signific
                 tmp.columns = tmp.columns.map(lambda c: c + "_" + str(label) if c != "feature" and c != "type" else c)
             tables.append(tmp)
 
-        if multiclass:
+        if ml_task == "regression":
+            pass
+        elif multiclass:
             relevance_table = functools.reduce(
                 lambda left, right: pd.merge(left, right, on=["feature", "type"], how="outer"), tables)
             relevance_table["n_significant"] = relevance_table.filter(regex="^relevant_", axis=1).sum(axis=1)

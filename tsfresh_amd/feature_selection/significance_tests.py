@@ -78,6 +78,60 @@ def fisher_exact_pvalue(a, b, c, d):
     return float(min(pm[pm <= pobs * (1.0 + 1e-7)].sum(), 1.0))
 
 
+def kendall_pvalue(n, dis, xtie, ntie, x0, x1, ytie, y0, y1):
+    """Two-sided p-value of scipy.stats.kendalltau(x, y, method="asymptotic") (tau-b) from the discordant pairs and
+    the tie statistics: con - dis is approximately normal with the variance of Kendall (1970), as scipy evaluates it."""
+    n = int(n)
+    tot = n * (n - 1) // 2
+    if xtie == tot or ytie == tot:
+        return math.nan
+    con_minus_dis = tot - int(xtie) - int(ytie) + int(ntie) - 2 * int(dis)
+    m = n * (n - 1.0)
+    var = ((m * (2 * n + 5) - float(x1) - float(y1)) / 18.0 + (2.0 * int(xtie) * int(ytie)) / m
+           + float(x0) * float(y0) / (9.0 * m * (n - 2)))
+    z = con_minus_dis / math.sqrt(var)
+    return math.erfc(abs(z) / math.sqrt(2.0))
+
+
+def target_tie_statistics(y_rank):
+    """(ytie, y0, y1) of scipy's count_rank_tie for the dense ranks of the target."""
+    cnt = np.bincount(np.asarray(y_rank)).astype(np.int64)
+    cnt = cnt[cnt > 1]
+    return (int((cnt * (cnt - 1) // 2).sum()), int((cnt * (cnt - 1.0) * (cnt - 2)).sum()),
+            int((cnt * (cnt - 1.0) * (2 * cnt + 5)).sum()))
+
+
+def ks_2samp_pvalue(n1, n2, d):
+    """Two-sided p-value of scipy.stats.ks_2samp(method="auto") from the sample sizes and the statistic: the exact
+    lattice-path probability for samples of <= 10 000, the one-sample Kolmogorov distribution at n1 n2 / (n1 + n2)
+    (scipy.stats.kstwo) beyond."""
+    n1, n2 = int(n1), int(n2)
+    if max(n1, n2) <= 10000:
+        g = math.gcd(n1, n2)
+        lcm = (n1 // g) * n2
+        h = int(round(d * lcm))
+        if h == 0:
+            return 1.0
+        if n1 == n2:
+            prob, k = 0.0, n1 // h
+            while k >= 0:  # Horner form of 2 * sum (-1)^(k-1) binom(2n, n - k h) / binom(2n, n)
+                p1 = 1.0
+                for j in range(h):
+                    p1 = (n1 - k * h - j) * p1 / (n1 + k * h + j + 1)
+                prob = p1 * (1.0 - prob)
+                k -= 1
+            prob = 2.0 * prob
+        else:
+            from tsfresh_amd import _native
+            prob = _native.ks_outer_prob(n1, n2, g, h)
+        if 0.0 <= prob <= 1.0:
+            return prob
+    from scipy.stats import kstwo  # a special function of two scalars (the reference's own dependency)
+    big, small = max(float(n1), float(n2)), min(float(n1), float(n2))
+    en = big * small / (big + small)
+    return float(min(max(kstwo.sf(d, np.round(en)), 0.0), 1.0))
+
+
 def fdr_reject(pvalues, alpha, independent):
     """statsmodels.stats.multitest.multipletests(pvalues, alpha, "fdr_bh" if independent else "fdr_by")[0]."""
     p = np.asarray(pvalues, dtype=np.float64)
