@@ -154,6 +154,12 @@ int tsfa_relevance_classes(const double *X, int64_t n_rows, int64_t n_cols, int6
                            const int32_t *y_codes, int32_t n_classes, int32_t device, tsfa_relevance_col *cols,
                            double *rank_sums, int64_t *hi_counts);
 
+/* ... plus, for the 'smir' option (significance_tests.py:121, scipy.stats.ks_2samp of the column split by the label),
+ * ks_d[n_cols * n_classes]: the Kolmogorov-Smirnov distance of every column for every label against the rest. */
+int tsfa_relevance_classes_ks(const double *X, int64_t n_rows, int64_t n_cols, int64_t ld, int32_t space,
+                              const int32_t *y_codes, int32_t n_classes, int32_t device, tsfa_relevance_col *cols,
+                              double *rank_sums, int64_t *hi_counts, double *ks_d);
+
 /* The same for real-valued targets (relevance.py:303-316):
  *   significance_tests.py:170 target_real_feature_real_test   (scipy.stats.kendalltau, asymptotic): discordant pairs
  *                             and the tie statistics of the column and of the (column, target) pairs,

@@ -50,7 +50,8 @@ def _regression_table(X, y, types, fdr_level, hypotheses_independent):
     return out
 
 
-def relevance_table(X, y, multiclass=False, n_significant=1, fdr_level=0.05, hypotheses_independent=False, ml_task="auto", **_):
+def relevance_table(X, y, multiclass=False, n_significant=1, fdr_level=0.05, hypotheses_independent=False, ml_task="auto",
+                    test_for_binary_target_real_feature="mann", **_):
     """-> dict feature -> dict(type, p_value..., relevant...) with the reference's column names."""
     y = y.sort_index()
     X = X.sort_index()
@@ -78,7 +79,10 @@ def relevance_table(X, y, multiclass=False, n_significant=1, fdr_level=0.05, hyp
         for f in tested:
             x = X[f]
             if types[f] == "real":
-                pv.append(stats.mannwhitneyu(x[yb], x[~yb], use_continuity=True, alternative="two-sided").pvalue)
+                if test_for_binary_target_real_feature == "smir":
+                    pv.append(stats.ks_2samp(x[yb], x[~yb])[1])
+                else:
+                    pv.append(stats.mannwhitneyu(x[yb], x[~yb], use_continuity=True, alternative="two-sided").pvalue)
             else:
                 x0, x1 = np.unique(x.values)
                 a = int(np.sum(yb[x == x1])); b = int(np.sum(yb[x == x0]))

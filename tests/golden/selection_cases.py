@@ -4,7 +4,7 @@ import pandas as pd
 
 CASES = ["binary_basic", "binary_ties", "binary_small_class_exact", "binary_independent_fdr", "multiclass3",
          "multiclass_strings", "all_constant", "shuffled_index", "regression_basic", "regression_ties",
-         "regression_equal_halves"]
+         "regression_equal_halves", "binary_smir", "multiclass_smir"]
 
 
 def _features(rng, n, y_signal):
@@ -88,6 +88,16 @@ def make_case(name):
         half[rng.choice(n, n // 2, replace=False)] = 1.0   # n1 == n2: the square formula of ks_2samp
         X["half_binary"] = half
         X["rel_half"] = (yv > np.median(yv)).astype(float)
+    elif name == "binary_smir":
+        n = 260
+        y = pd.Series(rng.integers(0, 2, n))
+        X = _features(rng, n, 0.5 * y.to_numpy().astype(float))
+        kw = {"test_for_binary_target_real_feature": "smir"}
+    elif name == "multiclass_smir":
+        n = 280
+        y = pd.Series(rng.integers(0, 3, n))
+        X = _features(rng, n, 0.4 * y.to_numpy().astype(float))
+        kw = {"multiclass": True, "n_significant": 1, "test_for_binary_target_real_feature": "smir"}
     else:
         raise KeyError(name)
     return X, y, kw

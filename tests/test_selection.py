@@ -38,12 +38,13 @@ def _check_against_golden(rec, got_rows):
             elif want is None:
                 assert got is None or (isinstance(got, float) and math.isnan(got)), (rec["name"], feat, c, got)
             elif isinstance(want, float):
-                if c.startswith("p_value") and rec["table"]["type"][r] == "binary" and rec["name"].startswith("regression") \
-                        and want < 1e-6:
-                    # the golden tables come from scipy 1.7.1, whose exact Kolmogorov-Smirnov tail is 1 - P(inside):
-                    # below ~1e-10 it is rounding noise of that subtraction (scipy >= 1.9 and this package compute the
-                    # complement directly); both must agree that the value is negligible
-                    assert got < 1e-6, (rec["name"], feat, c, got, want)
+                ks_col = (rec["table"]["type"][r] == "binary" and rec["name"].startswith("regression")) or \
+                         (rec["table"]["type"][r] == "real" and rec["name"].endswith("smir"))
+                if c.startswith("p_value") and ks_col:
+                    # the golden tables come from scipy 1.7.1, whose exact Kolmogorov-Smirnov tail is 1 - P(inside): an
+                    # absolute rounding error of a few 1e-16 (scipy >= 1.9 and this package compute the complement
+                    # directly and keep the relative accuracy of small tails)
+                    assert abs(got - want) <= 1e-9 * want + 5e-15, (rec["name"], feat, c, got, want)
                 else:
                     assert got == pytest.approx(want, rel=1e-9, abs=1e-300), (rec["name"], feat, c, got, want)
             else:
@@ -122,12 +123,11 @@ def test_ks_tail_matches_scipy():
         assert (math.isnan(want) and math.isnan(got)) or got == pytest.approx(want, rel=1e-12)
 
 
-def test_unsupported_options_fail_loudly():
-    from tsfresh_amd.feature_extraction.plan import UnsupportedFeature
+def test_invalid_options_raise_the_reference_errors():
     from tsfresh_amd.feature_selection import calculate_relevance_table
     X = pd.DataFrame({"a": [1.0, 2.0, 3.0, 4.0]})
-    with pytest.raises(UnsupportedFeature):
-        calculate_relevance_table(X, pd.Series([0, 1, 0, 1]), test_for_binary_target_real_feature="smir")
+    with pytest.raises(ValueError):
+        calculate_relevance_table(X, pd.Series([0, 1, 0, 1]), test_for_binary_target_real_feature="other")
     with pytest.raises(ValueError):
         calculate_relevance_table(X, pd.Series([0, 1, 0, 1]), ml_task="ranking")
 

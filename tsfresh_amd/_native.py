@@ -29,6 +29,7 @@ EXPORTS = (
     "tsfa_plan_set_profiling",
     "tsfa_plan_last_timings",
     "tsfa_relevance_classes",
+    "tsfa_relevance_classes_ks",
     "tsfa_relevance_real",
     "tsfa_ks_outer_prob",
 )
@@ -210,9 +211,9 @@ class Plan:
             ctypes.c_void_p(out_ptr), int(ld_out), TSFA_DEVICE, ctypes.c_void_p(stream) if stream else None))
 
 
-def relevance_classes(X, y_codes, n_classes, device=0):
+def relevance_classes(X, y_codes, n_classes, device=0, with_ks=False):
     """Per-column relevance statistics of the row-major float64 matrix X against class codes (tsfa_relevance_classes).
-    -> (n_unique int64[m], v_lo[m], v_hi[m], tie_term[m], rank_sums[m, C], hi_counts[m, C])."""
+    -> (n_unique int64[m], v_lo[m], v_hi[m], tie_term[m], rank_sums[m, C], hi_counts[m, C]) (+ ks_d[m, C] with_ks)."""
     lib = load()
     X = np.ascontiguousarray(X, dtype=np.float64)
     if X.ndim != 2:
@@ -228,12 +229,22 @@ def relevance_classes(X, y_codes, n_classes, device=0):
     lib.tsfa_relevance_classes.argtypes = [ctypes.c_void_p, ctypes.c_int64, ctypes.c_int64, ctypes.c_int64, ctypes.c_int32,
                                            ctypes.c_void_p, ctypes.c_int32, ctypes.c_int32, ctypes.c_void_p,
                                            ctypes.c_void_p, ctypes.c_void_p]
-    _check(lib, lib.tsfa_relevance_classes(X.ctypes.data_as(ctypes.c_void_p), n, m, m, TSFA_HOST,
-                                           y_codes.ctypes.data_as(ctypes.c_void_p), int(n_classes), int(device),
-                                           ctypes.cast(cols, ctypes.c_void_p), rank_sums.ctypes.data_as(ctypes.c_void_p),
-                                           hi_counts.ctypes.data_as(ctypes.c_void_p)))
+    if with_ks:
+        ks_d = np.zeros((m, n_classes), dtype=np.float64)
+        lib.tsfa_relevance_classes_ks.restype = ctypes.c_int32
+        lib.tsfa_relevance_classes_ks.argtypes = lib.tsfa_relevance_classes.argtypes + [ctypes.c_void_p]
+        _check(lib, lib.tsfa_relevance_classes_ks(X.ctypes.data_as(ctypes.c_void_p), n, m, m, TSFA_HOST,
+                                                  y_codes.ctypes.data_as(ctypes.c_void_p), int(n_classes), int(device),
+                                                  ctypes.cast(cols, ctypes.c_void_p), rank_sums.ctypes.data_as(ctypes.c_void_p),
+                                                  hi_counts.ctypes.data_as(ctypes.c_void_p), ks_d.ctypes.data_as(ctypes.c_void_p)))
+    else:
+        _check(lib, lib.tsfa_relevance_classes(X.ctypes.data_as(ctypes.c_void_p), n, m, m, TSFA_HOST,
+                                               y_codes.ctypes.data_as(ctypes.c_void_p), int(n_classes), int(device),
+                                               ctypes.cast(cols, ctypes.c_void_p), rank_sums.ctypes.data_as(ctypes.c_void_p),
+                                               hi_counts.ctypes.data_as(ctypes.c_void_p)))
     rec = np.frombuffer(cols, dtype=[("n_unique", "<i8"), ("v_lo", "<f8"), ("v_hi", "<f8"), ("tie_term", "<f8")], count=m)
-    return (rec["n_unique"].copy(), rec["v_lo"].copy(), rec["v_hi"].copy(), rec["tie_term"].copy(), rank_sums, hi_counts)
+    res = (rec["n_unique"].copy(), rec["v_lo"].copy(), rec["v_hi"].copy(), rec["tie_term"].copy(), rank_sums, hi_counts)
+    return res + (ks_d,) if with_ks else res
 
 
 _REAL_COL_DTYPE = [("n_unique", "<i8"), ("v_lo", "<f8"), ("v_hi", "<f8"), ("dis", "<i8"), ("xtie", "<i8"), ("ntie", "<i8"),

@@ -152,6 +152,53 @@ __global__ void __launch_bounds__(REL_NT) k_rel_stats(const double *__restrict__
     }
 }
 
+// 'smir' option (significance_tests.py:121: scipy.stats.ks_2samp(x[y == label], x[y != label])): the Kolmogorov-Smirnov
+// distance of the column split by each class label, walked along the sorted column (prefix counts by a block scan,
+// evaluated where a tie group of the column ends).
+__global__ void __launch_bounds__(REL_NT) k_rel_ks_classes(const double *__restrict__ keys, const uint32_t *__restrict__ idx, int64_t np2, int64_t n,
+                                                            const int32_t *__restrict__ y, int n_classes, int64_t c0,
+                                                            double *__restrict__ ks_d) {
+    __shared__ long long s_cnt[REL_NT];
+    __shared__ double s_max[REL_NT], s_min[REL_NT];
+    __shared__ long long s_total;
+    const double *K = keys + (int64_t)blockIdx.x * np2;
+    const uint32_t *I = idx + (int64_t)blockIdx.x * np2;
+    const int64_t chunk = (n + REL_NT - 1) / REL_NT;
+    const int64_t p0 = (int64_t)threadIdx.x * chunk, p1 = (p0 + chunk < n) ? p0 + chunk : n;
+    for (int k = 0; k < n_classes; ++k) {
+        long long c = 0;
+        for (int64_t p = p0; p < p1; ++p) c += (y[I[p]] == k) ? 1 : 0;
+        __syncthreads();
+        s_cnt[threadIdx.x] = c;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            long long acc = 0;
+            for (int t = 0; t < REL_NT; ++t) { const long long v = s_cnt[t]; s_cnt[t] = acc; acc += v; }
+            s_total = acc;
+        }
+        __syncthreads();
+        const double n1 = (double)s_total, n0 = (double)(n - s_total);
+        long long k1 = s_cnt[threadIdx.x];
+        double mx = -__builtin_inf(), mn = __builtin_inf();
+        for (int64_t p = p0; p < p1; ++p) {
+            k1 += (y[I[p]] == k) ? 1 : 0;
+            if (p == n - 1 || K[p + 1] != K[p]) {
+                const double d = (double)k1 / n1 - (double)(p + 1 - k1) / n0;
+                mx = fmax(mx, d);
+                mn = fmin(mn, d);
+            }
+        }
+        s_max[threadIdx.x] = mx; s_min[threadIdx.x] = mn;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            for (int t = 1; t < REL_NT; ++t) { mx = fmax(mx, s_max[t]); mn = fmin(mn, s_min[t]); }
+            double mins = -mn;
+            mins = (mins < 0.0) ? 0.0 : ((mins > 1.0) ? 1.0 : mins);
+            ks_d[(c0 + blockIdx.x) * n_classes + k] = (mins > mx) ? mins : mx;
+        }
+    }
+}
+
 // ---------------------------------------------------------------------------------------------------------------------
 // Real-valued targets (significance_tests.py:170 target_real_feature_real_test = scipy.stats.kendalltau, :135
 // target_real_feature_binary_test = scipy.stats.ks_2samp).  The column is sorted by (value, dense rank of y) -- the
@@ -344,9 +391,26 @@ __global__ void __launch_bounds__(REL_NT) k_rel_ks(const double *__restrict__ X,
         if (e_ != hipSuccess) { rc = tsfa_fail(TSFA_ERR_HIP, (std::string(#call) + ": " + hipGetErrorString(e_)).c_str()); goto done; } \
     } while (0)
 
+static int relevance_classes_impl(const double *X, int64_t n_rows, int64_t n_cols, int64_t ld, int32_t space,
+                                  const int32_t *y_codes, int32_t n_classes, int32_t device, tsfa_relevance_col *cols,
+                                  double *rank_sums, int64_t *hi_counts, double *ks_d);
+
 extern "C" int tsfa_relevance_classes(const double *X, int64_t n_rows, int64_t n_cols, int64_t ld, int32_t space,
                                       const int32_t *y_codes, int32_t n_classes, int32_t device, tsfa_relevance_col *cols,
                                       double *rank_sums, int64_t *hi_counts) {
+    return relevance_classes_impl(X, n_rows, n_cols, ld, space, y_codes, n_classes, device, cols, rank_sums, hi_counts, nullptr);
+}
+
+extern "C" int tsfa_relevance_classes_ks(const double *X, int64_t n_rows, int64_t n_cols, int64_t ld, int32_t space,
+                                         const int32_t *y_codes, int32_t n_classes, int32_t device, tsfa_relevance_col *cols,
+                                         double *rank_sums, int64_t *hi_counts, double *ks_d) {
+    if (!ks_d) return tsfa_fail(TSFA_ERR_INVALID, "tsfa_relevance_classes_ks: null ks_d");
+    return relevance_classes_impl(X, n_rows, n_cols, ld, space, y_codes, n_classes, device, cols, rank_sums, hi_counts, ks_d);
+}
+
+static int relevance_classes_impl(const double *X, int64_t n_rows, int64_t n_cols, int64_t ld, int32_t space,
+                                  const int32_t *y_codes, int32_t n_classes, int32_t device, tsfa_relevance_col *cols,
+                                  double *rank_sums, int64_t *hi_counts, double *ks_d) {
     if (!X || !y_codes || !cols || !rank_sums || !hi_counts || n_rows < 1 || n_cols < 0 || ld < n_cols)
         return tsfa_fail(TSFA_ERR_INVALID, "tsfa_relevance_classes: null pointer or bad shape");
     if (n_classes < 1 || n_classes > REL_MAXC) return tsfa_fail(TSFA_ERR_UNSUPPORTED, "tsfa_relevance_classes: 1 .. 256 classes");
@@ -365,7 +429,7 @@ extern "C" int tsfa_relevance_classes(const double *X, int64_t n_rows, int64_t n
     int64_t batch = (int64_t)(4.0e9 / (12.0 * (double)np2));
     if (batch < 1) batch = 1;
     if (batch > n_cols) batch = n_cols;
-    double *dX = nullptr, *dkeys = nullptr, *drs = nullptr;
+    double *dX = nullptr, *dkeys = nullptr, *drs = nullptr, *dks = nullptr;
     uint32_t *didx = nullptr;
     int32_t *dy = nullptr;
     int64_t *dhc = nullptr;
@@ -383,6 +447,7 @@ extern "C" int tsfa_relevance_classes(const double *X, int64_t n_rows, int64_t n
     REL_HIP(hipMalloc((void **)&drs, (size_t)n_cols * n_classes * sizeof(double)));
     REL_HIP(hipMalloc((void **)&dhc, (size_t)n_cols * n_classes * sizeof(int64_t)));
     REL_HIP(hipMalloc((void **)&dcols, (size_t)n_cols * sizeof(tsfa_relevance_col)));
+    if (ks_d) REL_HIP(hipMalloc((void **)&dks, (size_t)n_cols * n_classes * sizeof(double)));
     REL_HIP(hipMemcpy(dy, y_codes, (size_t)n_rows * sizeof(int32_t), hipMemcpyHostToDevice));
     {
         const size_t lds = (size_t)tile * (sizeof(double) + sizeof(uint32_t));
@@ -392,14 +457,17 @@ extern "C" int tsfa_relevance_classes(const double *X, int64_t n_rows, int64_t n
             k_rel_stage<<<dim3((unsigned)nb), REL_NT, 0, 0>>>(Xd, n_rows, ld, c0, dkeys, didx, np2);
             k_rel_sort<<<dim3((unsigned)nb), REL_NT, lds, 0>>>(dkeys, didx, np2, tile);
             k_rel_stats<<<dim3((unsigned)nb), REL_NT, 0, 0>>>(dkeys, didx, np2, n_rows, dy, n_classes, c0, dcols, drs, dhc);
+            if (ks_d) k_rel_ks_classes<<<dim3((unsigned)nb), REL_NT, 0, 0>>>(dkeys, didx, np2, n_rows, dy, n_classes, c0, dks);
             REL_HIP(hipGetLastError());
         }
     }
     REL_HIP(hipMemcpy(cols, dcols, (size_t)n_cols * sizeof(tsfa_relevance_col), hipMemcpyDeviceToHost));
     REL_HIP(hipMemcpy(rank_sums, drs, (size_t)n_cols * n_classes * sizeof(double), hipMemcpyDeviceToHost));
     REL_HIP(hipMemcpy(hi_counts, dhc, (size_t)n_cols * n_classes * sizeof(int64_t), hipMemcpyDeviceToHost));
+    if (ks_d) REL_HIP(hipMemcpy(ks_d, dks, (size_t)n_cols * n_classes * sizeof(double), hipMemcpyDeviceToHost));
 done:
     (void)hipFree(dX); (void)hipFree(dkeys); (void)hipFree(didx); (void)hipFree(dy); (void)hipFree(drs); (void)hipFree(dhc); (void)hipFree(dcols);
+    (void)hipFree(dks);
     return rc;
 }
 

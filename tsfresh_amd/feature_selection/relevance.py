@@ -13,7 +13,6 @@ import numpy as np
 import pandas as pd
 
 from tsfresh_amd import _native
-from tsfresh_amd.feature_extraction.plan import UnsupportedFeature
 from tsfresh_amd.feature_selection.significance_tests import (fdr_reject, fisher_exact_pvalue, kendall_pvalue,
                                                              ks_2samp_pvalue, mannwhitney_pvalue, target_tie_statistics)
 
@@ -66,11 +65,10 @@ def calculate_relevance_table(X, y, ml_task="auto", multiclass=False, n_signific
         if len(y.unique()) <= 2:
             warnings.warn("Two or fewer classes, binary feature selection will be used (multiclass = False)")
             multiclass = False
-    if ml_task == "classification" and test_for_binary_target_real_feature != "mann":
-        if test_for_binary_target_real_feature == "smir":
-            raise UnsupportedFeature("the Kolmogorov-Smirnov test has no kernel yet (use 'mann')")
+    if ml_task == "classification" and test_for_binary_target_real_feature not in ("mann", "smir"):
         raise ValueError("Please use a valid entry for test_for_binary_target_real_feature. "
                          "Valid entries are 'mann' and 'smir'.")
+    smir = (test_for_binary_target_real_feature == "smir")
 
     values = np.ascontiguousarray(X.to_numpy(dtype=np.float64))
     if np.isnan(values).any():
@@ -84,7 +82,9 @@ def calculate_relevance_table(X, y, ml_task="auto", multiclass=False, n_signific
     if ml_task == "classification":
         labels = list(y.unique())  # order of first appearance, as the reference iterates
         codes = pd.Categorical(y, categories=labels).codes.astype(np.int32)
-        n_unique, _, _, tie_term, rank_sums, hi_counts = _native.relevance_classes(values, codes, len(labels), device=device)
+        stats_ = _native.relevance_classes(values, codes, len(labels), device=device, with_ks=smir)
+        n_unique, _, _, tie_term, rank_sums, hi_counts = stats_[:6]
+        ks_d = stats_[6] if smir else None
         class_n = np.bincount(codes, minlength=len(labels))
         hi_total = hi_counts.sum(axis=1)
     else:
@@ -129,9 +129,13 @@ def calculate_relevance_table(X, y, ml_task="auto", multiclass=False, n_signific
         for k, label in enumerate(labels):
             n1, n0 = int(class_n[k]), int(n - class_n[k])
             t_real, t_bin = table_real.copy(), table_binary.copy()
-            t_real["p_value"] = pd.Series(
-                [mannwhitney_pvalue(rank_sums[pos[f], k], n1, n0, tie_term[pos[f]]) for f in t_real.index],
-                index=t_real.index, dtype=float)
+            if smir:  # significance_tests.py:121: ks_2samp(x[y == label], x[y != label])
+                t_real["p_value"] = pd.Series([ks_2samp_pvalue(n1, n0, ks_d[pos[f], k]) for f in t_real.index],
+                                              index=t_real.index, dtype=float)
+            else:
+                t_real["p_value"] = pd.Series(
+                    [mannwhitney_pvalue(rank_sums[pos[f], k], n1, n0, tie_term[pos[f]]) for f in t_real.index],
+                    index=t_real.index, dtype=float)
             # [[y1 & x1, y1 & x0], [y0 & x1, y0 & x0]], x1 = the larger of the feature's two values (np.unique order)
             t_bin["p_value"] = pd.Series(
                 [fisher_exact_pvalue(hi_counts[pos[f], k], n1 - hi_counts[pos[f], k], hi_total[pos[f]] - hi_counts[pos[f], k],
