@@ -93,6 +93,9 @@ def main():
     ap.add_argument("--ragged", default="", help="LO:HI -> series lengths uniform on [LO, HI] (configs[4] shape); "
                                                  "--length is ignored")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--chunks", type=int, default=0,
+                    help="N > 1: row chunks per step; the all-gather of chunk c runs on RCCL's stream while chunk c + 1 is "
+                         "being extracted (0 = 8 when N > 1, else 1)")
     args = ap.parse_args()
 
     import torch
@@ -108,7 +111,7 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     dist = None
-    if world > 1:
+    if world > 1 or os.environ.get("TSFA_BENCH_FORCE_DIST"):  # the env var exercises the N > 1 code path on one GPU
         import torch.distributed as dist_mod
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         dist_mod.init_process_group(backend="nccl", device_id=dev)
@@ -139,13 +142,28 @@ def main():
         values = torch.randn(n * L, device=dev, dtype=torch.float32, generator=gen)  # i.i.d. N(0,1) float32 series
         offsets = torch.arange(0, (n + 1) * L, L, device=dev, dtype=torch.int64)
     out = torch.empty((n, n_cols), device=dev, dtype=torch.float64)
-    gathered = torch.empty((world * n, n_cols), device=dev, dtype=torch.float64) if world > 1 else None
     stream = torch.cuda.current_stream(dev).cuda_stream
+    # N > 1: the shard is extracted in row chunks; the all-gather of a finished chunk is enqueued asynchronously (RCCL's
+    # own stream waits for the chunk's kernels, the launch stream goes straight on to the next chunk), so only the last
+    # chunk's exchange is exposed.  Every rank ends up with all rows: gathered[c] = [world x rows_c, n_cols], the rows of
+    # chunk c of every rank in rank order.
+    n_chunks = args.chunks if args.chunks > 0 else (8 if dist is not None else 1)
+    n_chunks = max(1, min(n_chunks, n))
+    cuts = [int(round(i * n / n_chunks)) for i in range(n_chunks + 1)]
+    gathered = [torch.empty((world * (cuts[c + 1] - cuts[c]), n_cols), device=dev, dtype=torch.float64)
+                for c in range(n_chunks)] if dist is not None else None
 
     def step():
-        plan.extract_device(values.data_ptr(), _native.TSFA_F32, offsets.data_ptr(), n, out.data_ptr(), n_cols, stream)
-        if dist is not None:
-            dist.all_gather_into_tensor(gathered, out)
+        works = []
+        for c in range(n_chunks):
+            c0, c1 = cuts[c], cuts[c + 1]
+            # offsets stay relative to the start of `values`: a chunk is the same buffer with a later offsets pointer
+            plan.extract_device(values.data_ptr(), _native.TSFA_F32, offsets.data_ptr() + 8 * c0, c1 - c0,
+                                out.data_ptr() + 8 * n_cols * c0, n_cols, stream)
+            if dist is not None:
+                works.append(dist.all_gather_into_tensor(gathered[c], out[c0:c1], async_op=True))
+        for w in works:
+            w.wait()
 
     def barrier():
         if dist is not None:
@@ -167,6 +185,12 @@ def main():
         elapsed = float(t.item())
     ms_per_step = 1000.0 * elapsed / max(args.steps, 1)
     value = world * n * args.steps / elapsed
+    if dist is not None:  # every rank holds every rank's rows: its own block must be where its rank puts it
+        for c in range(n_chunks):
+            rows = cuts[c + 1] - cuts[c]
+            mine = gathered[c][rank * rows:(rank + 1) * rows]
+            ref = out[cuts[c]:cuts[c + 1]]
+            assert bool(((mine == ref) | (torch.isnan(mine) & torch.isnan(ref))).all().item()), "all-gather layout"
 
     # ---- per-kernel HIP-event timings (events recorded on the launch stream), 2 profiled passes ----
     plan.set_profiling(True)
