@@ -7,8 +7,9 @@
 
 One "step" = one pass of the hot path (tsfa_extract: every kernel of the plan) over one batch of synthetic series
 that is ALREADY RESIDENT IN HBM, writing the dense [n_series x n_cols] float64 feature matrix to HBM; with N > 1
-each rank (one process per GPU) extracts its own id-shard and the shards are reassembled on every rank with one
-RCCL all-gather (north_star), inside the timed region.  Per-GPU work is fixed -> "scaling": "weak".
+each rank (one process per GPU) extracts its own id-shard in row chunks and the shards are reassembled on every rank
+with RCCL all-gathers (north_star) -- one per chunk, overlapped with the extraction of the next chunk -- inside the
+timed region.  Per-GPU work is fixed -> "scaling": "weak".
 
 Workload at N = 1: BASELINE.json configs[2] -- 100k synthetic float32 series x len 1024,
 ComprehensiveFCParameters (783 columns) -- the configuration the metric/target is quoted on.
