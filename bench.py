@@ -148,6 +148,8 @@ def main():
     # own stream waits for the chunk's kernels, the launch stream goes straight on to the next chunk), so only the last
     # chunk's exchange is exposed.  Every rank ends up with all rows: gathered[c] = [world x rows_c, n_cols], the rows of
     # chunk c of every rank in rank order.
+    if not args.ragged:
+        plan.set_length_hint(L, L)  # equal lengths, known up front: chunk launches need no length scan / host sync
     n_chunks = args.chunks if args.chunks > 0 else (8 if dist is not None else 1)
     n_chunks = max(1, min(n_chunks, n))
     cuts = [int(round(i * n / n_chunks)) for i in range(n_chunks + 1)]

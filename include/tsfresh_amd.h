@@ -133,6 +133,13 @@ int tsfa_extract_windows(tsfa_plan *plan, const void *values, int32_t dtype, con
 int tsfa_plan_set_profiling(tsfa_plan *plan, int32_t enable);
 int32_t tsfa_plan_last_timings(const tsfa_plan *plan, const char **names, float *ms, int32_t cap);
 
+/* Optional: promise that every series of the following tsfa_extract* calls on this plan has min_len <= length <=
+ * max_len.  The calls then skip their length scan and the host synchronisation it needs, so device-pointer calls on one
+ * stream (e.g. the row chunks of a shard whose results are exchanged chunk by chunk) are enqueued back to back.  A batch
+ * outside the promised range is undefined behaviour.  (0, 0) withdraws the promise.  The reference has no counterpart:
+ * its per-series dispatch (extraction.py:308) sizes nothing ahead. */
+int tsfa_plan_set_length_hint(tsfa_plan *plan, int64_t min_len, int64_t max_len);
+
 /* ---- feature selection: relevance statistics of the extracted matrix ----
  * Replaces the per-feature loop of tsfresh/feature_selection/relevance.py:214-322 (calculate_relevance_table ->
  * _calculate_relevance_table_for_implicit_target) for classification targets: one call yields, for EVERY column of

@@ -236,3 +236,30 @@ def test_config5_ragged_8192_efficient(gpu):
     assert np.array_equal(got[:, col["value__length"]], lens.astype(np.float64))
     assert np.array_equal(got[:, col["value__median"]], np.array([np.median(s.astype(np.float64)) for s in series]))
     assert np.array_equal(got[:, col["value__sum_values"]], np.array([np.sum(s.astype(np.float64)) for s in series]))
+
+
+@pytest.mark.gpu
+def test_length_hint_gives_identical_results():
+    """tsfa_plan_set_length_hint only removes the length scan: the matrix must not change (equal and ragged lengths
+    inside the promised range), and the hint can be withdrawn."""
+    import warnings
+    from tsfresh_amd import _native
+    from tsfresh_amd.feature_extraction import settings
+    from tsfresh_amd.feature_extraction.plan import compile_fc_parameters
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        fplan = compile_fc_parameters(settings.ComprehensiveFCParameters())
+    plan = _native.Plan(fplan.native_specs(_native.calc_id), device=0)
+    rng = np.random.default_rng(21)
+    for lens in (np.full(40, 256), rng.integers(100, 257, size=40)):
+        offsets = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
+        x = rng.standard_normal(int(offsets[-1])).astype(np.float32)
+        plan.set_length_hint(0, 0)
+        a = plan.extract_host(x, offsets)
+        plan.set_length_hint(int(lens.min()), int(lens.max()))
+        b = plan.extract_host(x, offsets)
+        assert np.array_equal(np.isnan(a), np.isnan(b)) and np.array_equal(np.nan_to_num(a), np.nan_to_num(b))
+    plan.set_length_hint(0, 0)
+    with pytest.raises(_native.NativeError):
+        plan.set_length_hint(5, 3)
+    plan.close()

@@ -28,6 +28,7 @@ EXPORTS = (
     "tsfa_extract_windows",
     "tsfa_plan_set_profiling",
     "tsfa_plan_last_timings",
+    "tsfa_plan_set_length_hint",
     "tsfa_relevance_classes",
     "tsfa_relevance_classes_ks",
     "tsfa_relevance_real",
@@ -140,6 +141,12 @@ class Plan:
 
     def set_profiling(self, enable=True):
         _check(self._lib, self._lib.tsfa_plan_set_profiling(self._h, 1 if enable else 0))
+
+    def set_length_hint(self, min_len, max_len):
+        """Promise the length range of every following batch (skips the per-call length scan and its host sync)."""
+        self._lib.tsfa_plan_set_length_hint.restype = ctypes.c_int32
+        self._lib.tsfa_plan_set_length_hint.argtypes = [ctypes.c_void_p, ctypes.c_int64, ctypes.c_int64]
+        _check(self._lib, self._lib.tsfa_plan_set_length_hint(self._h, int(min_len), int(max_len)))
 
     def last_timings(self):
         cap = 32

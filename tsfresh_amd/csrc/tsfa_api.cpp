@@ -83,6 +83,7 @@ struct tsfa_plan {
     hipEvent_t ev_fork = nullptr, ev_join[TSFA_MAX_AUX] = {nullptr};
     bool profiling = false;
     std::vector<Timing> timings;
+    long long hint_min_len = 0, hint_max_len = 0;  // tsfa_plan_set_length_hint: skip the length scan (and its host sync)
 };
 
 static const char *fam_names[TSFA_N_FAMILIES] = {"k_basic", "k_sort", "k_spectral", "k_ar", "k_entropy", "k_cwtpeaks", "k_seq", "k_trend"};
@@ -235,6 +236,15 @@ int tsfa_plan_create(const tsfa_feature_spec *specs, int32_t n_specs, int32_t de
 
 int32_t tsfa_plan_n_cols(const tsfa_plan *plan) { return plan ? plan->n_cols : -1; }
 
+int tsfa_plan_set_length_hint(tsfa_plan *plan, int64_t min_len, int64_t max_len) {
+    if (!plan) return fail(TSFA_ERR_INVALID, "null plan");
+    if (max_len == 0 && min_len == 0) { plan->hint_min_len = plan->hint_max_len = 0; return TSFA_OK; }
+    if (min_len < 1 || max_len < min_len || max_len > 65535) return fail(TSFA_ERR_INVALID, "length hint must satisfy 1 <= min <= max <= 65535");
+    plan->hint_min_len = min_len;
+    plan->hint_max_len = max_len;
+    return TSFA_OK;
+}
+
 int tsfa_plan_set_profiling(tsfa_plan *plan, int32_t enable) {
     if (!plan) return fail(TSFA_ERR_INVALID, "plan is NULL");
     plan->profiling = enable != 0;
@@ -330,10 +340,19 @@ int tsfa_extract_windows(tsfa_plan *plan, const void *values, int32_t dtype, con
 
     // ---- batch length statistics (decides workgroup size and the LDS carve) ----
     long long h_stats[3] = {0, (1LL << 62), 0};
-    HIP_TRY(hipMemcpyAsync(plan->d_stats, h_stats, sizeof h_stats, hipMemcpyHostToDevice, st));
-    if (tsfa_launch_len_stats(d_starts, d_ends, n_series, plan->d_stats, st)) return fail(TSFA_ERR_HIP, "len_stats launch failed");
-    HIP_TRY(hipMemcpyAsync(h_stats, plan->d_stats, sizeof h_stats, hipMemcpyDeviceToHost, st));
-    HIP_TRY(hipStreamSynchronize(st));
+    if (plan->hint_max_len > 0) {
+        // the caller vouches for the length range of every batch (tsfa_plan_set_length_hint): no scan, no host sync --
+        // back-to-back calls on one stream (chunks of a shard) are enqueued without waiting for each other
+        h_stats[0] = plan->hint_max_len;
+        h_stats[1] = plan->hint_min_len;
+        h_stats[2] = (plan->hint_min_len == plan->hint_max_len && (plan->hint_max_len & (plan->hint_max_len - 1)) == 0)
+                         ? 0 : plan->hint_max_len;  // longest length that may not be a power of two
+    } else {
+        HIP_TRY(hipMemcpyAsync(plan->d_stats, h_stats, sizeof h_stats, hipMemcpyHostToDevice, st));
+        if (tsfa_launch_len_stats(d_starts, d_ends, n_series, plan->d_stats, st)) return fail(TSFA_ERR_HIP, "len_stats launch failed");
+        HIP_TRY(hipMemcpyAsync(h_stats, plan->d_stats, sizeof h_stats, hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipStreamSynchronize(st));
+    }
     const long long max_len = h_stats[0], min_len = h_stats[1], max_np2 = h_stats[2];
     if (min_len < 1) return fail(TSFA_ERR_INVALID, "every series must hold at least one sample");
     if (max_len > 65535) return fail(TSFA_ERR_TOO_LONG, "series longer than 65535 samples are not supported");
