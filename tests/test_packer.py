@@ -62,3 +62,17 @@ def test_presorted_declines_other_layouts():
     assert D._pack_presorted("v", ids, np.zeros(4), np.array([0, 1, 1, 0]), None) is None  # descent inside a group
     assert D._pack_presorted("v", ids, np.zeros(4), np.array([0, 1, 0, 1]), None) is not None
     assert D._pack_presorted("v", np.array(["a", "a", "b"]), np.zeros(3), None, None) is None
+
+
+def test_arrow_tables_pack_like_frames():
+    pa = pytest.importorskip("pyarrow")
+    rng = np.random.default_rng(8)
+    lens = rng.integers(1, 7, size=11)
+    df = pd.DataFrame({"id": np.repeat(np.arange(11), lens), "time": np.concatenate([np.arange(m) for m in lens]),
+                       "value": rng.standard_normal(int(lens.sum())).astype(np.float32)})
+    want, _, _ = D.pack_timeseries(df, column_id="id", column_sort="time")
+    for container in (pa.Table.from_pandas(df, preserve_index=False),
+                      pa.Table.from_pandas(df, preserve_index=False).to_batches()[0]):
+        got, id_dtype, has_dt = D.pack_timeseries(container, column_id="id", column_sort="time")
+        _same(got, want)
+        assert id_dtype == df["id"].dtype and not has_dt

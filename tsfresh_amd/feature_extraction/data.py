@@ -130,8 +130,26 @@ def _pack(kind, ids, values, sort_values, index=None):
                       None if sort_values is None else np.asarray(sort_values)[order])
 
 
+def _arrow_to_frame(table):
+    """A pyarrow Table / RecordBatch as a DataFrame, column by column through numpy (no Python objects for primitive
+    columns; pandas still consolidates the columns into its own blocks): the checks and the packing below then see an
+    ordinary long / wide frame."""
+    cols = {}
+    for name in table.schema.names:
+        col = table.column(name)
+        if hasattr(col, "combine_chunks"):
+            col = col.combine_chunks()
+        try:
+            cols[name] = col.to_numpy(zero_copy_only=True)
+        except Exception:  # strings, nulls, chunk boundaries: Arrow has to materialise a copy
+            cols[name] = col.to_numpy(zero_copy_only=False)
+    return pd.DataFrame(cols, copy=False)
+
+
 def pack_timeseries(container, column_id=None, column_kind=None, column_value=None, column_sort=None):
     """-> (list[PackedKind] in output-column order, dtype of the id column, has_datetime_index)."""
+    if type(container).__module__.startswith("pyarrow") and hasattr(container, "schema"):
+        container = _arrow_to_frame(container)
     if isinstance(container, pd.DataFrame):
         df = container
         if column_id is None:
