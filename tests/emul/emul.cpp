@@ -110,7 +110,8 @@ extern "C" int tsfa_emul_extract_timed(const tsfa_feature_spec *specs, int n_spe
             std::vector<double> srt(tsfa_pow2_ceil(maxn) + 8), w(1280), cq(5 * TSFA_CQ_MAX), sctx(8);
             fam_sort_series(b, xs.data(), n, fam[TSFA_FAM_SORT].data(), (int)fam[TSFA_FAM_SORT].size(), row, srt.data(),
                             w.data(), (int *)w.data(), hints[TSFA_FAM_SORT].cq, cq.data(), nullptr,
-                            (s % 2) ? -1 : hints[TSFA_FAM_SORT].c, sctx.data());
+                            (s % 2) ? -1 : hints[TSFA_FAM_SORT].c, sctx.data(),
+                            (s % 4 >= 2) ? hints[TSFA_FAM_SORT].a : 1280);  // plan-sized scratch: multi-pass pattern histogram
         }
         if (!fam[TSFA_FAM_SPECTRAL].empty()) {
             const int nx = (maxn / 2 + 2 > 260) ? maxn / 2 + 2 : 260;

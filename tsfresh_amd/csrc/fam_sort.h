@@ -526,7 +526,8 @@ TSFA_DEV void sort_epilogue(const Blk &b, const TsfaSpec *specs, int first, int 
 template <class ST>
 TSFA_DEV void fam_sort_series(const Blk &b, const ST *xs_raw, int n, const TsfaSpec *specs, int nspecs,
                               double *out_row, ST *srt_raw, double *w, int *iw, const TsfaCqPlan &cqplan, double *cq,
-                              TsfaSpec *stage, int n_loop = -1, double *ctx = nullptr) {
+                              TsfaSpec *stage, int n_loop = -1, double *ctx = nullptr, int w_doubles = 1280) {
+    const int hist_words = 2 * w_doubles;  // iw aliases w: 32-bit words of the ordinal-pattern histogram
     // n_loop columns go through the column loop; the rest are evaluated by sort_epilogue (lane = column)
     const int nloop = (n_loop >= 0 && ctx != nullptr) ? n_loop : nspecs;
     const XsView<ST> xs{xs_raw};
@@ -691,40 +692,84 @@ TSFA_DEV void fam_sort_series(const Blk &b, const ST *xs_raw, int n, const TsfaS
             if (num <= 0) { v = TSFA_NAN; break; }
             int fact = 1;
             for (int k = 2; k <= D; ++k) fact *= k;
-            // two 16-bit counters per LDS word (at most n <= 65535 windows)
-            const int nwords = (fact + 1) >> 1;
-            blk_sync();
-            for (int k = b.tid; k < nwords; k += b.nt) iw[k] = 0;
-            blk_sync();
-            for (int t = b.tid; t < num; t += b.nt) {
-                const int code = perm_code(xs_raw + t * tau, D, fact);
-                const int inc = (code & 1) ? 0x10000 : 1;
-#if TSFA_GPU
-                atomicAdd(&iw[code >> 1], inc);
-#else
-                iw[code >> 1] += inc;
-#endif
+            // Two 16-bit counters per LDS word (at most n <= 65535 windows).  The histogram only has room for
+            // 2 * hist_words patterns: the pattern space is swept in ranges of that size (one pass for D <= 6 at the
+            // usual sizes, four for D = 7 with a 2.5 KB scratch).  With <= 8 windows per thread their codes are
+            // computed ONCE and stay in registers for all passes (the code of a D = 7 window is 21 compares).
+            const int per_pass = 2 * hist_words;
+            const bool in_regs = (num <= 8 * b.nt);
+            int codes[8];
+            if (in_regs) {
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const int t = b.tid + u * b.nt;
+                    codes[u] = (t < num) ? perm_code(xs_raw + t * tau, D, fact) : -1;
+                }
             }
-            blk_sync();
             double e = 0.0;
-            if (fact <= num) {  // sum over the patterns
-                for (int k = b.tid; k < fact; k += b.nt) {
-                    const unsigned wv = (unsigned)iw[k >> 1];
-                    const int c = (k & 1) ? (int)(wv >> 16) : (int)(wv & 0xffffu);
-                    if (c > 0) {
-                        const double pr = (double)c / (double)num;
-                        e += pr * log(pr);
+            for (int base = 0; base < fact; base += per_pass) {
+                const int top = (fact - base < per_pass) ? (fact - base) : per_pass;  // patterns of this pass
+                blk_sync();
+                for (int k = b.tid; k < (top + 1) >> 1; k += b.nt) iw[k] = 0;
+                blk_sync();
+                if (in_regs) {
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) {
+                        const int c = codes[u] - base;
+                        if (codes[u] >= 0 && c >= 0 && c < top) {
+#if TSFA_GPU
+                            atomicAdd(&iw[c >> 1], (c & 1) ? 0x10000 : 1);
+#else
+                            iw[c >> 1] += (c & 1) ? 0x10000 : 1;
+#endif
+                        }
+                    }
+                } else {
+                    for (int t = b.tid; t < num; t += b.nt) {
+                        const int c = perm_code(xs_raw + t * tau, D, fact) - base;
+                        if (c >= 0 && c < top) {
+#if TSFA_GPU
+                            atomicAdd(&iw[c >> 1], (c & 1) ? 0x10000 : 1);
+#else
+                            iw[c >> 1] += (c & 1) ? 0x10000 : 1;
+#endif
+                        }
                     }
                 }
-            } else {  // more patterns than windows: sum_k c_k log(c_k / num) = sum over windows of log(c(window) / num)
-                double acc = 0.0;
-                for (int t = b.tid; t < num; t += b.nt) {
-                    const int code = perm_code(xs_raw + t * tau, D, fact);
-                    const unsigned wv = (unsigned)iw[code >> 1];
-                    const int c = (code & 1) ? (int)(wv >> 16) : (int)(wv & 0xffffu);
-                    acc += log((double)c / (double)num);
+                blk_sync();
+                if (fact <= num) {  // sum over the patterns
+                    for (int k = b.tid; k < top; k += b.nt) {
+                        const unsigned wv = (unsigned)iw[k >> 1];
+                        const int c = (k & 1) ? (int)(wv >> 16) : (int)(wv & 0xffffu);
+                        if (c > 0) {
+                            const double pr = (double)c / (double)num;
+                            e += pr * log(pr);
+                        }
+                    }
+                } else {  // more patterns than windows: sum_k c_k log(c_k / num) = sum over windows of log(c(window) / num)
+                    double acc = 0.0;
+                    if (in_regs) {
+#pragma unroll
+                        for (int u = 0; u < 8; ++u) {
+                            const int c = codes[u] - base;
+                            if (codes[u] >= 0 && c >= 0 && c < top) {
+                                const unsigned wv = (unsigned)iw[c >> 1];
+                                const int cc = (c & 1) ? (int)(wv >> 16) : (int)(wv & 0xffffu);
+                                acc += log((double)cc / (double)num);
+                            }
+                        }
+                    } else {
+                        for (int t = b.tid; t < num; t += b.nt) {
+                            const int c = perm_code(xs_raw + t * tau, D, fact) - base;
+                            if (c >= 0 && c < top) {
+                                const unsigned wv = (unsigned)iw[c >> 1];
+                                const int cc = (c & 1) ? (int)(wv >> 16) : (int)(wv & 0xffffu);
+                                acc += log((double)cc / (double)num);
+                            }
+                        }
+                    }
+                    e += acc / (double)num;
                 }
-                e = acc / (double)num;
             }
             v = -blk_sum(b, e);
         } break;

@@ -142,6 +142,15 @@ static inline void tsfa_prepare_family(int fam, std::vector<TsfaSpec> &specs, Ts
             (e ? epi : loop).push_back(s);
         }
         h.c = (int)loop.size();
+        // a = doubles of LDS scratch the plan needs (fam_sort.h friedrich_coeffs: 6 r + 16 + r (m + 1)), at least 320:
+        // the ordinal-pattern histogram adapts to it
+        h.a = 320;
+        for (const auto &s : loop) {
+            int m = 0, r = 0;
+            if (s.calc == TSFA_C_FRIEDRICH_COEFFICIENTS) { m = (int)s.p[1]; r = (int)s.p[2]; }
+            else if (s.calc == TSFA_C_MAX_LANGEVIN_FIXED_POINT) { m = (int)s.p[0]; r = (int)s.p[1]; }
+            if (r > 0 && r <= 64 && m >= 1 && m <= 3) h.a = std::max(h.a, 6 * r + 16 + r * (m + 1) + 8);
+        }
         specs = loop;
         specs.insert(specs.end(), epi.begin(), epi.end());
         return;

@@ -64,15 +64,15 @@ __global__ void __launch_bounds__(256, 2) k_trend(const T *__restrict__ values, 
 }
 
 template <typename T>
-__global__ void __launch_bounds__(256) k_sort(const T *__restrict__ values, const int64_t *__restrict__ starts, const int64_t *__restrict__ ends, int64_t n_series,
+__global__ void __launch_bounds__(256, 4) k_sort(const T *__restrict__ values, const int64_t *__restrict__ starts, const int64_t *__restrict__ ends, int64_t n_series,
                        const TsfaSpec *__restrict__ specs, int nspecs, double *__restrict__ out, int64_t ld, int maxn,
-                       const TsfaCqPlan cqplan, int n_loop) {
+                       const TsfaCqPlan cqplan, int n_loop, int w_doubles) {
     const int64_t sidx = blockIdx.x;
     if (sidx >= n_series) return;
     const int64_t off = starts[sidx];
     const int n = (int)(ends[sidx] - off);
     SortLds L;
-    L.carve(tsfa_smem, maxn, blockDim.x, (int)sizeof(T));
+    L.carve(tsfa_smem, maxn, blockDim.x, (int)sizeof(T), w_doubles);
     TSFA_TICKS_BEGIN();
     Blk b{(int)threadIdx.x, (int)blockDim.x, L.red, L.np};
     T *xs = (T *)L.xs;  // resident in the input precision, like its sorted copy
@@ -82,7 +82,7 @@ __global__ void __launch_bounds__(256) k_sort(const T *__restrict__ values, cons
         blk_sync();
     }
     fam_sort_series<T>(b, xs, n, specs, nspecs, out + sidx * ld, (T *)L.srt, L.w, L.iw, cqplan, L.cq, L.stage,
-                       n_loop, L.ctx);
+                       n_loop, L.ctx, w_doubles);
     TSFA_TICKS_END();
 }
 
@@ -318,10 +318,11 @@ static int launch_all_t(const TsfaLaunch &a, const T *values) {
                                           a.times, a.alt, a.hint_c);
     } else if (a.fam == TSFA_FAM_SORT) {
         SortLds L;
-        const size_t lds = L.carve(nullptr, a.maxn, nt, (int)sizeof(T));
+        const int wd = (a.hint_a >= 320) ? a.hint_a : 1280;
+        const size_t lds = L.carve(nullptr, a.maxn, nt, (int)sizeof(T), wd);
         if ((rc = set_lds(k_sort<T>, lds))) return rc;
         k_sort<T><<<grid, nt, lds, st>>>(values, a.starts, a.ends, a.n_series, a.specs, a.nspecs, a.out, a.ld, a.maxn, a.cq,
-                                         a.hint_c);
+                                         a.hint_c, wd);
     } else if (a.fam == TSFA_FAM_SPECTRAL) {
         SpectralLds L;
         const size_t lds = L.carve(nullptr, a.maxn, a.dft_n, (int)sizeof(T));

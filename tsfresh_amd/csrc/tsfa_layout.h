@@ -67,15 +67,18 @@ struct BasicLds {
 struct SortLds {
     double *red; NpScratch *np; void *xs; void *srt; double *w; int *iw; double *cq; TsfaSpec *stage; double *ctx;
     // xs_bytes: element size of the resident series and its sorted copy (4: float32 input kept as float32, 8: float64)
-    TSFA_HD size_t carve(unsigned char *base, int maxn, int nt, int xs_bytes = 8) {
+    // w_doubles: scratch of the Langevin fit (6 r + 16 + r (m + 1) doubles for the plan's largest (m, r): tsfa_prepare_family),
+    //            at least 320; the ordinal-pattern histogram of permutation_entropy takes what is there and sweeps the
+    //            pattern space in as many passes as it needs (fam_sort.h)
+    TSFA_HD size_t carve(unsigned char *base, int maxn, int nt, int xs_bytes = 8, int w_doubles = 1280) {
         (void)nt;
         LdsCarve c{base, 0};
         red = c.take<double>(TSFA_RED_DOUBLES);
         np = c.take<NpScratch>(1);
         xs = c.take<unsigned char>((size_t)maxn * xs_bytes);
         srt = c.take<unsigned char>((size_t)tsfa_pow2_ceil(maxn) * xs_bytes);
-        w = c.take<double>(1280);   // Langevin-fit scratch (<= 768 doubles) ...
-        iw = (int *)w;              // ... aliased with the ordinal-pattern histogram (2520 ints): never live together
+        w = c.take<double>(w_doubles);
+        iw = (int *)w;              // ... aliased with the ordinal-pattern histogram: never live together
         cq = c.take<double>(5 * TSFA_CQ_MAX);  // change_quantiles results per corridor
         ctx = c.take<double>(8);               // TSFA_SORT_CTX: values read by the epilogue columns
 #if defined(TSFA_SPEC_LDS)
