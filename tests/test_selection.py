@@ -266,3 +266,27 @@ def test_gpu_regression_table_matches_the_oracle_at_scale(n, m):
                 assert math.isnan(g)
             else:
                 assert g == pytest.approx(w, rel=1e-9, abs=1e-300), (f, c, g, w)
+
+
+@pytest.mark.gpu
+def test_gpu_relevance_column_batches(monkeypatch):
+    """The column loop of the C-ABI calls (sort scratch bounded to a few GB): forced to batches of 3 columns, every
+    statistic must equal the single-batch result."""
+    from tsfresh_amd import _native
+    rng = np.random.default_rng(12)
+    n, m = 3000, 11
+    X = rng.standard_normal((n, m))
+    X[:, 4] = (X[:, 4] > 0) * 1.0
+    X[:, 7] = np.round(X[:, 7], 1)
+    yc = rng.integers(0, 3, n).astype(np.int32)
+    yr = np.round(rng.standard_normal(n), 2)
+    monkeypatch.delenv("TSFA_REL_BATCH", raising=False)
+    a = _native.relevance_classes(X, yc, 3, with_ks=True)
+    ar, _ = _native.relevance_real(X, yr)
+    monkeypatch.setenv("TSFA_REL_BATCH", "3")
+    b = _native.relevance_classes(X, yc, 3, with_ks=True)
+    br, _ = _native.relevance_real(X, yr)
+    for u, v in zip(a, b):
+        assert np.array_equal(u, v)
+    for f in ar.dtype.names:
+        assert np.array_equal(ar[f], br[f]), f

@@ -12,6 +12,7 @@
 #include <hip/hip_runtime.h>
 #include <math.h>
 #include <stdint.h>
+#include <stdlib.h>
 
 #include <string>
 #include <vector>
@@ -385,6 +386,16 @@ __global__ void __launch_bounds__(REL_NT) k_rel_ks(const double *__restrict__ X,
     }
 }
 
+// columns per batch: bound the sort scratch (12 B per padded row and column) to ~4 GB; TSFA_REL_BATCH overrides (tests)
+static int64_t rel_batch_columns(int64_t np2, int64_t n_cols) {
+    int64_t batch = (int64_t)(4.0e9 / (12.0 * (double)np2));
+    const char *e = getenv("TSFA_REL_BATCH");
+    if (e && atoll(e) > 0) batch = atoll(e);
+    if (batch < 1) batch = 1;
+    if (batch > n_cols) batch = n_cols;
+    return batch;
+}
+
 #define REL_HIP(call)                                                                          \
     do {                                                                                       \
         hipError_t e_ = (call);                                                                \
@@ -425,10 +436,7 @@ static int relevance_classes_impl(const double *X, int64_t n_rows, int64_t n_col
     int64_t np2 = 2048;
     while (np2 < n_rows) np2 <<= 1;
     const int tile = (int)((np2 < REL_TILE) ? np2 : REL_TILE);
-    // columns per batch: bound the sort scratch (12 B per padded row and column) to ~4 GB
-    int64_t batch = (int64_t)(4.0e9 / (12.0 * (double)np2));
-    if (batch < 1) batch = 1;
-    if (batch > n_cols) batch = n_cols;
+    int64_t batch = rel_batch_columns(np2, n_cols);
     double *dX = nullptr, *dkeys = nullptr, *drs = nullptr, *dks = nullptr;
     uint32_t *didx = nullptr;
     int32_t *dy = nullptr;
@@ -485,9 +493,7 @@ extern "C" int tsfa_relevance_real(const double *X, int64_t n_rows, int64_t n_co
     int64_t np2 = 2048;
     while (np2 < n_rows) np2 <<= 1;
     const int tile = (int)((np2 < REL_TILE) ? np2 : REL_TILE);
-    int64_t batch = (int64_t)(4.0e9 / (12.0 * (double)np2));
-    if (batch < 1) batch = 1;
-    if (batch > n_cols) batch = n_cols;
+    int64_t batch = rel_batch_columns(np2, n_cols);
     double *dX = nullptr, *dkeys = nullptr;
     uint32_t *didx = nullptr;
     int32_t *dyr = nullptr, *dyp = nullptr;
