@@ -101,7 +101,9 @@ struct SpectralLds {
         const int nx = (maxn / 2 + 2 > 260) ? maxn / 2 + 2 : 260;
         Xr = c.take<double>(nx);
         Xi = c.take<double>(nx);
-        const int nd = (dft_n > 256) ? dft_n : 256;  // Welch segments of a short series (< 256) use the DFT
+        // the table-driven DFT serves non-power-of-two lengths <= 256 (short series and their Welch segments); a batch
+        // without any non-power-of-two length (dft_n == 0) needs no table: 4 KB of LDS, two more resident series per CU
+        const int nd = (dft_n > 256) ? dft_n : (dft_n > 0 ? 256 : 2);
         tc = c.take<double>(nd);
         ts = c.take<double>(nd);
         win = c.take<double>(256);
