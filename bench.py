@@ -238,7 +238,8 @@ def main():
                                    "inputs and outputs resident in HBM%s" % (
                                        n, L, args.params.capitalize(), n_cols,
                                        ", id-sharded + RCCL all-gather of the feature matrix" if world > 1 else ""),
-                       "n_series_per_gpu": n, "length": L, "n_cols": n_cols, "parallelism": "ids%d" % world},
+                       "n_series_per_gpu": n, "length": L, "n_cols": n_cols, "parallelism": "ids%d" % world,
+                       "row_chunks_per_step": n_chunks},
             "kernel_ms": kt, "outputs_finite": finite, "roofline": roof,
         }
         if world == 1 and not args.no_cpu_baseline:
