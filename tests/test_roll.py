@@ -101,3 +101,21 @@ def test_extract_rolled_features_equals_extraction_on_the_rolled_frame(gpu):
         assert list(got.index) == list(want.index) and list(got.columns) == list(want.columns)
         a, b = got.to_numpy(), want.to_numpy()
         assert np.array_equal(np.isnan(a), np.isnan(b)) and np.array_equal(np.nan_to_num(a), np.nan_to_num(b))
+
+
+def test_make_forecasting_frame_matches_the_reference():
+    from forecasting_cases import forecasting_cases
+    from tsfresh_amd.utilities.dataframe_functions import make_forecasting_frame
+    golden = json.load(open(os.path.join(G, "ref_forecasting.json")))
+    for name, x, kw in forecasting_cases():
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            df, y = make_forecasting_frame(x, **kw)
+        d = df.copy()
+        d["id"] = [list(map(lambda v: v.item() if hasattr(v, "item") else str(v), t)) for t in d["id"]]
+        d["time"] = [str(v) for v in d["time"]]
+        want = golden[name]
+        assert list(map(str, d.columns)) == want["columns"], name
+        assert json.loads(d.to_json(orient="values")) == want["rows"], name
+        assert [[str(a) for a in t] for t in y.index] == want["y_index"], name
+        assert [float(v) for v in y] == want["y"], name

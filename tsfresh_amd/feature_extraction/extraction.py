@@ -242,6 +242,8 @@ def extract_rolled_features(timeseries_container, column_id=None, column_sort=No
             starts, ends = pk.offsets[gi] + frm, pk.offsets[gi] + until
             if pk.sort is not None:
                 shift_val = pk.sort[ends - 1] if rolling_direction > 0 else pk.sort[starts]
+                if shift_val.dtype.kind in "mM":  # as roll_time_series: pandas Timestamps in the window ids
+                    shift_val = pd.Series(shift_val).tolist()
             else:
                 shift_val = ts - 1
             ids = np.empty(len(gi), dtype=object)

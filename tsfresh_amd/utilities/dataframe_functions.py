@@ -128,9 +128,13 @@ def roll_time_series(df_or_dict, column_id, column_sort=None, column_kind=None, 
     if column_sort is not None:
         sv = df[column_sort].to_numpy()[order]
         shift_val = sv[first + wlen - 1] if rolling_direction > 0 else sv[first]   # :363-366
+        if shift_val.dtype.kind in "mM":             # pandas hands out Timestamps / Timedeltas, not numpy scalars
+            shift_val = pd.Series(shift_val).tolist()
     else:
         shift_val = ts - 1                           # :368
     ids = df[column_id].to_numpy()[order][first]
+    if ids.dtype.kind in "mM":
+        ids = pd.Series(ids).tolist()
     new_ids = np.empty(len(first), dtype=object)
     for i in range(len(first)):
         new_ids[i] = (ids[i], shift_val[i])
@@ -218,3 +222,25 @@ def impute(df_impute):
         return df_impute
     col_to_max, col_to_min, col_to_median = get_range_values_per_column(df_impute)
     return impute_dataframe_range(df_impute, col_to_max, col_to_min, col_to_median)
+
+
+def make_forecasting_frame(x, kind, max_timeshift, rolling_direction, min_timeshift=0):
+    """The reference's forecasting container (tsfresh/utilities/dataframe_functions.py:606): every time stamp of the
+    single series `x` gets the window of its last `max_timeshift` predecessors as a series of its own (id = ("id",
+    time stamp)), and `y` holds the value to predict for each of them.  Built on `roll_time_series` of this package;
+    for extraction the windows need not be materialised at all -- see `extract_rolled_features`."""
+    n = len(x)
+    t = x.index if isinstance(x, pd.Series) else range(n)
+    df = pd.DataFrame({"id": ["id"] * n, "time": t, "value": x, "kind": kind})
+    df_shift = roll_time_series(df, column_id="id", column_sort="time", column_kind="kind",
+                                rolling_direction=rolling_direction, max_timeshift=max_timeshift,
+                                min_timeshift=min_timeshift)
+    # drop, in every window, the row that is to be predicted (its last one)
+    last_of_window = ~df_shift.duplicated(subset=["id"], keep="last") if len(df_shift) else pd.Series([], dtype=bool)
+    df_shift = df_shift[~last_of_window]
+    # targets: every value but the first, named like the windows, restricted to the windows that exist
+    y = df["value"][1:]
+    y.index = map(lambda i: ("id", i), y.index)
+    valid_ids = set(df_shift["id"].unique())
+    y = y[y.index.isin(valid_ids)]
+    return df_shift, y
