@@ -263,3 +263,40 @@ def test_length_hint_gives_identical_results():
     with pytest.raises(_native.NativeError):
         plan.set_length_hint(5, 3)
     plan.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+def test_hip_matches_oracle_on_structured_series(gpu, dtype):
+    """Series that stress the paths evaluated from registers / bit masks / tables: constants, few distinct values (heavy
+    ties), alternating and monotone runs, spikes; lengths around the register-tile and wavefront boundaries."""
+    rng = np.random.default_rng(77)
+    series = []
+    for n in (1, 2, 3, 4, 5, 7, 8, 9, 15, 16, 17, 31, 33, 63, 64, 65, 127, 129, 255, 256, 257, 511, 513, 1000, 1023, 1024):
+        kind = n % 6
+        if kind == 0:
+            x = np.full(n, 0.1)
+        elif kind == 1:
+            x = rng.integers(-2, 3, n).astype(float)
+        elif kind == 2:
+            # alternating signs with irregular amplitudes (an exactly regular zig-zag makes the lagged differences of
+            # the ADF / AR regressions collinear to ~1e-9: DESIGN.md 4.3, normal equations vs the reference's pinv)
+            x = np.where(np.arange(n) % 2 == 0, 1.0, -1.0) * (1 + 0.3 * rng.random(n))
+        elif kind == 3:
+            x = np.arange(n, dtype=float) * 0.5 - 3.0
+        elif kind == 4:
+            x = rng.standard_normal(n)
+            x[rng.integers(0, n)] = 50.0
+        else:
+            x = np.round(rng.standard_normal(n), 1)
+        series.append(x.astype(dtype))
+    values = np.concatenate(series)
+    offsets = np.concatenate([[0], np.cumsum([len(s) for s in series])]).astype(np.int64)
+    params = settings.ComprehensiveFCParameters()
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        names, got = hip_engine(params, values, offsets)
+        names_o, want = oracle_engine(params, values.astype(np.float64), offsets)
+    assert names == names_o
+    bad = compare(names, got, want, [values[offsets[i]:offsets[i + 1]].astype(np.float64) for i in range(len(series))])
+    assert not bad, bad[:20]
