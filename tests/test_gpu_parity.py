@@ -300,3 +300,32 @@ def test_hip_matches_oracle_on_structured_series(gpu, dtype):
     assert names == names_o
     bad = compare(names, got, want, [values[offsets[i]:offsets[i + 1]].astype(np.float64) for i in range(len(series))])
     assert not bad, bad[:20]
+
+
+@pytest.mark.gpu
+def test_hip_matches_oracle_on_structured_long_series(gpu):
+    """The > 1024-sample code paths (multi-wavefront workgroups, chunked register tiles, column-loop fallbacks, hashed LZ
+    tables) on series with heavy ties / constants / ramps."""
+    rng = np.random.default_rng(78)
+    series = []
+    for n in (1025, 1500, 2048, 2049, 3000, 4096, 4100):
+        kind = n % 4
+        if kind == 0:
+            x = np.round(rng.standard_normal(n), 1)
+        elif kind == 1:
+            x = rng.integers(0, 4, n).astype(float)
+        elif kind == 2:
+            x = np.cumsum(rng.standard_normal(n))
+        else:
+            x = np.full(n, -2.5)
+        series.append(x.astype(np.float32))
+    values = np.concatenate(series)
+    offsets = np.concatenate([[0], np.cumsum([len(s) for s in series])]).astype(np.int64)
+    params = settings.EfficientFCParameters()
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        names, got = hip_engine(params, values, offsets)
+        names_o, want = oracle_engine(params, values.astype(np.float64), offsets)
+    assert names == names_o
+    bad = compare(names, got, want, [values[offsets[i]:offsets[i + 1]].astype(np.float64) for i in range(len(series))])
+    assert not bad, bad[:20]
