@@ -1,0 +1,73 @@
+#!/usr/bin/env python
+"""Ad-hoc parity fuzz on the GPU box: random subsets of ComprehensiveFCParameters (random parameter sub-lists, random
+order of appearance is the reference's dict order) on random ragged batches of mixed structured / random series, HIP
+path against the oracle.    python profiles/fuzz_parity.py [rounds] [seed]"""
+import os
+import sys
+import warnings
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+from engines import hip_engine, oracle_engine  # noqa: E402
+from parity import compare  # noqa: E402
+from tsfresh_amd.feature_extraction import settings  # noqa: E402
+
+
+def make_series(rng, n):
+    k = rng.integers(0, 7)
+    if k == 0:
+        return np.full(n, float(rng.integers(-3, 4)) * 0.25)
+    if k == 1:
+        return rng.integers(-3, 4, n).astype(float)
+    if k == 2:
+        return np.cumsum(rng.standard_normal(n))
+    if k == 3:
+        return np.round(rng.standard_normal(n), 1)
+    if k == 4:
+        x = rng.standard_normal(n)
+        x[rng.integers(0, n, max(1, n // 50))] *= 30
+        return x
+    if k == 5:
+        return np.sin(np.arange(n) * rng.uniform(0.01, 1.0)) + 0.05 * rng.standard_normal(n)
+    return rng.standard_normal(n) * 10.0 ** float(rng.integers(-3, 4))
+
+
+def main():
+    rounds = int(sys.argv[1]) if len(sys.argv) > 1 else 12
+    rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
+    full = settings.ComprehensiveFCParameters()
+    names_all = list(full.keys())
+    total_bad = 0
+    for r in range(rounds):
+        pick = [nm for nm in names_all if rng.random() < 0.45]
+        params = {}
+        for nm in pick:
+            pl = full[nm]
+            if pl is None:
+                params[nm] = None
+            else:
+                sub = [p for p in pl if rng.random() < 0.6] or [pl[0]]
+                params[nm] = sub
+        maxlen = int(rng.choice([40, 300, 1024, 1024, 2500]))
+        lens = rng.integers(1, maxlen + 1, size=int(rng.integers(3, 14)))
+        dtype = np.float32 if rng.random() < 0.6 else np.float64
+        series = [make_series(rng, int(n)).astype(dtype) for n in lens]
+        values = np.concatenate(series)
+        offsets = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            names, got = hip_engine(params, values, offsets)
+            names_o, want = oracle_engine(params, values.astype(np.float64), offsets)
+        assert names == names_o, (names[:3], names_o[:3])
+        bad = compare(names, got, want, [values[offsets[i]:offsets[i + 1]].astype(np.float64) for i in range(len(series))])
+        total_bad += len(bad)
+        print("round", r, "calcs", len(pick), "cols", len(names), "series", len(lens), "maxlen", maxlen, dtype.__name__,
+              "mismatches", len(bad), bad[:4])
+    print("TOTAL mismatches", total_bad)
+
+
+if __name__ == "__main__":
+    main()
