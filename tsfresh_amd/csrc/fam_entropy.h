@@ -451,15 +451,21 @@ TSFA_DEV void entropy_sweep_staged(const Blk &b, const double *xs, int n, const 
                 for (int k = 0; k < 3; ++k) { slm[k] += log(pm[k]); slm1[k] += log(pm1[k]); pm[k] = 1.0; pm1[k] = 1.0; }
             }
         }
+        double tot[12];  // the twelve totals of this half reduced together: one barrier pair instead of twelve
 #pragma unroll
         for (int k = 0; k < 3; ++k) {
-            slm[k] += log(pm[k]) - (double)nm[k] * ldm;
-            slm1[k] += log(pm1[k]) - (double)nm1[k] * ldm1;
-            const double a0 = blk_sum(b, slm[k]), a1 = blk_sum(b, slm1[k]), a2 = blk_sum(b, scm[k]), a3 = blk_sum(b, scm1[k]);
+            tot[4 * k + 0] = slm[k] + (log(pm[k]) - (double)nm[k] * ldm);
+            tot[4 * k + 1] = slm1[k] + (log(pm1[k]) - (double)nm1[k] * ldm1);
+            tot[4 * k + 2] = scm[k];
+            tot[4 * k + 3] = scm1[k];
+        }
+        blk_sum_multi<12>(b, tot);
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
             const int pos = gidx[3 * h + k];
             if (b.tid == 0 && pos >= 0) {
                 double *d = racc + 4 * pos;
-                d[0] = a0; d[1] = a1; d[2] = a2; d[3] = a3;
+                d[0] = tot[4 * k + 0]; d[1] = tot[4 * k + 1]; d[2] = tot[4 * k + 2]; d[3] = tot[4 * k + 3];
             }
         }
     }
