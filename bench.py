@@ -156,17 +156,37 @@ def main():
     gathered = [torch.empty((world * (cuts[c + 1] - cuts[c]), n_cols), device=dev, dtype=torch.float64)
                 for c in range(n_chunks)] if dist is not None else None
 
+    # chunks alternate between two launch streams (each with its own plan: a plan's device scratch belongs to one
+    # stream at a time), so the thinning tail of one chunk's kernels overlaps the start of the next chunk's
+    main_stream = torch.cuda.current_stream(dev)
+    if n_chunks > 1:
+        plan_b = _native.Plan(fplan.native_specs(_native.calc_id), device=local_rank)
+        if not args.ragged:
+            plan_b.set_length_hint(L, L)
+        lanes = [(plan, torch.cuda.Stream(device=dev)), (plan_b, torch.cuda.Stream(device=dev))]
+    else:
+        plan_b = None
+        lanes = [(plan, main_stream)]
+
     def step():
         works = []
+        for pl, st in lanes:
+            if st is not main_stream:
+                st.wait_stream(main_stream)
         for c in range(n_chunks):
             c0, c1 = cuts[c], cuts[c + 1]
+            pl, st = lanes[c % len(lanes)]
             # offsets stay relative to the start of `values`: a chunk is the same buffer with a later offsets pointer
-            plan.extract_device(values.data_ptr(), _native.TSFA_F32, offsets.data_ptr() + 8 * c0, c1 - c0,
-                                out.data_ptr() + 8 * n_cols * c0, n_cols, stream)
+            pl.extract_device(values.data_ptr(), _native.TSFA_F32, offsets.data_ptr() + 8 * c0, c1 - c0,
+                              out.data_ptr() + 8 * n_cols * c0, n_cols, st.cuda_stream)
             if dist is not None:
-                works.append(dist.all_gather_into_tensor(gathered[c], out[c0:c1], async_op=True))
+                with torch.cuda.stream(st):  # the collective orders itself after this chunk's kernels only
+                    works.append(dist.all_gather_into_tensor(gathered[c], out[c0:c1], async_op=True))
         for w in works:
             w.wait()
+        for pl, st in lanes:
+            if st is not main_stream:
+                main_stream.wait_stream(st)
 
     def barrier():
         if dist is not None:
@@ -249,6 +269,8 @@ def main():
         dist.barrier()
         dist.destroy_process_group()
     plan.close()
+    if plan_b is not None:
+        plan_b.close()
 
 
 if __name__ == "__main__":
