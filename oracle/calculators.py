@@ -45,6 +45,12 @@ def _runs_of_true(mask):  # fc.py:102
     return best
 
 
+def friedrich_coefficients_of(x, m, r):
+    """The polynomial fitted by _estimate_friedrich_coefficients (fc.py:131-173) as an array, highest power first
+    (tests/parity.py uses it to recognise cubics whose leading coefficient is round-off)."""
+    return np.asarray(SeriesOracle(x)._friedrich(int(m), r), dtype=np.float64)
+
+
 class SeriesOracle:
     """All calculators for one series; `x` is converted to float64."""
 

@@ -79,19 +79,40 @@ def mackinnonp_c(teststat):
     return stats.norm.cdf(np.polyval(coef[::-1], teststat))
 
 
-def _ols(y, X, want_cov=False):
-    """OLS by the pseudo-inverse, as statsmodels' default fit(method="pinv"):
-    params = pinv(X) y,  normalized_cov_params = pinv(X) pinv(X)^T  (statsmodels/regression/linear_model.py)."""
-    pinv = np.linalg.pinv(X)
+def _ols(y, X):
+    """statsmodels OLS(y, X).fit(method="pinv") (regression/linear_model.py:300-338, tools/tools.py:398 pinv_extended):
+    params = pinv(X) y with singular values <= 1e-15 * s_max zeroed; rank = matrix_rank(diag(s)) (tolerance
+    s_max * p * eps); normalized_cov_params = pinv(X) pinv(X)^T; ssr from the residuals.
+    -> (params, ssr, rank, normalized_cov_params)"""
+    X = np.asarray(X, dtype=np.float64)
+    if X.shape[1] == 0:
+        return np.zeros(0), float(y @ y), 0, np.zeros((0, 0))
+    u, s, vt = np.linalg.svd(X, False)
+    s_orig = s.copy()
+    cutoff = 1e-15 * s.max()
+    sinv = np.where(s > cutoff, 1.0 / np.where(s > cutoff, s, 1.0), 0.0)
+    pinv = vt.T @ (sinv[:, None] * u.T)
+    rank = int(np.linalg.matrix_rank(np.diag(s_orig)))
     beta = pinv @ y
     resid = y - X @ beta
-    if want_cov:
-        return beta, float(resid @ resid), pinv @ pinv.T
-    return beta, float(resid @ resid)
+    return beta, float(resid @ resid), rank, pinv @ pinv.T
+
+
+def _add_const(X, prepend):
+    """tsatools.add_trend(X, "c", prepend, has_constant="skip"): the constant column is NOT added when X already holds
+    an exactly constant, non-zero column (tsatools.py:112-136)."""
+    if X.shape[1]:
+        ptp0 = np.ptp(X, axis=0)
+        if np.any((ptp0 == 0) & (X[0] != 0)):
+            return X
+    ones = np.ones((X.shape[0], 1))
+    return np.column_stack([ones, X]) if prepend else np.column_stack([X, ones])
 
 
 def adfuller_aic(x):
-    """adfuller(x, autolag="AIC") -> (teststat, pvalue, usedlag); raises ValueError like statsmodels."""
+    """adfuller(x, autolag="AIC") -> (teststat, pvalue, usedlag); raises ValueError like statsmodels
+    (stattools.py:160-380, _autolag :63-147).  AIC = -2 llf + 2 rank (linear_model.py:1827 with df_model = rank -
+    k_constant), llf of OLS.loglike (:896-903), t value = params[0] / sqrt(ssr / (nobs - rank) * ncov[0, 0])."""
     x = np.asarray(x, dtype=np.float64)
     nobs = x.shape[0]
     ntrend = 1
@@ -108,21 +129,23 @@ def adfuller_aic(x):
 
     Z, y = design(maxlag)
     n1 = len(y)
-    full = np.column_stack([np.ones(n1), Z])  # add_trend(prepend=True)
+    full = _add_const(Z, prepend=True)
+    startlag = full.shape[1] - Z.shape[1] + 1
     best = None
-    for lag in range(2, maxlag + 3):
-        _, ssr = _ols(y, full[:, :lag])
-        llf = -n1 / 2.0 * np.log(2 * np.pi) - n1 / 2.0 * np.log(ssr / n1) - n1 / 2.0
-        aic = -2 * llf + 2 * lag
-        if best is None or (aic, lag) < best:
-            best = (aic, lag)
-    usedlag = best[1] - 2
-    Z, y = design(usedlag)
-    n2 = len(y)
-    X = np.column_stack([Z[:, : usedlag + 1], np.ones(n2)])  # add_trend appends the constant
-    beta, ssr, ncov = _ols(y, X, want_cov=True)
-    sigma2 = ssr / (n2 - X.shape[1])
-    tstat = beta[0] / np.sqrt(sigma2 * ncov[0, 0])
+    with np.errstate(divide="ignore", invalid="ignore"):
+        for lag in range(startlag, startlag + maxlag + 1):
+            _, ssr, rank, _ = _ols(y, full[:, :lag])
+            llf = -n1 / 2.0 * np.log(2 * np.pi) - n1 / 2.0 * np.log(ssr / n1) - n1 / 2.0
+            aic = -2 * llf + 2 * rank
+            if best is None or (aic, lag) < best:
+                best = (aic, lag)
+        usedlag = best[1] - startlag
+        Z, y = design(usedlag)
+        n2 = len(y)
+        X = _add_const(Z[:, : usedlag + 1], prepend=False)
+        beta, ssr, rank, ncov = _ols(y, X)
+        sigma2 = ssr / (n2 - rank)
+        tstat = beta[0] / np.sqrt(sigma2 * ncov[0, 0])
     return tstat, mackinnonp_c(tstat), usedlag
 
 
@@ -140,8 +163,7 @@ def autoreg_params(x, k):
         raise ZeroDivisionError("division by zero")
     rows = np.arange(k, n)
     X = np.column_stack([np.ones(nobs)] + [x[rows - j] for j in range(1, k + 1)])
-    beta, _ = _ols(x[rows], X)
-    return beta
+    return _ols(x[rows], X)[0]
 
 
 # ------------------------------------------------------------------------------------------------

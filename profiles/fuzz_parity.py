@@ -1,7 +1,8 @@
 #!/usr/bin/env python
 """Ad-hoc parity fuzz on the GPU box: random subsets of ComprehensiveFCParameters (random parameter sub-lists, random
 order of appearance is the reference's dict order) on random ragged batches of mixed structured / random series, HIP
-path against the oracle.    python profiles/fuzz_parity.py [rounds] [seed]"""
+path against the oracle.    python profiles/fuzz_parity.py [rounds] [seed]
+TSFA_FUZZ_ENGINE=emul runs the g++ build of the kernel sources instead (no GPU needed)."""
 import os
 import sys
 import warnings
@@ -11,13 +12,25 @@ import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
-from engines import hip_engine, oracle_engine  # noqa: E402
+from engines import emul_engine, hip_engine, oracle_engine  # noqa: E402
 from parity import compare  # noqa: E402
 from tsfresh_amd.feature_extraction import settings  # noqa: E402
 
 
 def make_series(rng, n):
-    k = rng.integers(0, 7)
+    k = rng.integers(0, 12)
+    if k == 7:  # ramp (rank-deficient regressions)
+        return rng.uniform(-5, 5) + rng.uniform(-2, 2) * np.arange(n)
+    if k == 8:  # exactly periodic
+        return np.resize(rng.integers(-2, 3, int(rng.integers(2, 6))).astype(float), n)
+    if k == 9:  # noiseless sine, float32-rounded (ill-conditioned but resolvable)
+        return np.sin(np.arange(n) * rng.uniform(0.02, 0.5)).astype(np.float32).astype(float)
+    if k == 10:  # stuck sensor after a noisy start
+        x = rng.standard_normal(n)
+        x[n // 3:] = x[n // 3] if n >= 3 else x[-1]
+        return x
+    if k == 11:  # ramp + small noise
+        return np.arange(n) * 0.5 + 10.0 ** float(rng.integers(-7, -1)) * rng.standard_normal(n)
     if k == 0:
         return np.full(n, float(rng.integers(-3, 4)) * 0.25)
     if k == 1:
@@ -59,11 +72,15 @@ def main():
         offsets = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
         with warnings.catch_warnings():
             warnings.simplefilter("ignore")
-            names, got = hip_engine(params, values, offsets)
+            engine = emul_engine if os.environ.get("TSFA_FUZZ_ENGINE") == "emul" else hip_engine
+            names, got = engine(params, values, offsets)
             names_o, want = oracle_engine(params, values.astype(np.float64), offsets)
         assert names == names_o, (names[:3], names_o[:3])
         bad = compare(names, got, want, [values[offsets[i]:offsets[i + 1]].astype(np.float64) for i in range(len(series))])
         total_bad += len(bad)
+        for bmsg in bad[:3]:
+            si = int(bmsg.split()[1])
+            print("   offending series", si, repr(values[offsets[si]:offsets[si + 1]].astype(np.float64).tolist()[:60]))
         print("round", r, "calcs", len(pick), "cols", len(names), "series", len(lens), "maxlen", maxlen, dtype.__name__,
               "mismatches", len(bad), bad[:4])
     print("TOTAL mismatches", total_bad)

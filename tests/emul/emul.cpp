@@ -14,6 +14,7 @@
 
 #include "../../include/tsfresh_amd.h"
 #include "../../tsfresh_amd/csrc/fam_ar.h"
+#include "../../tsfresh_amd/csrc/fam_ar_dd.h"
 #include "../../tsfresh_amd/csrc/fam_basic.h"
 #include "../../tsfresh_amd/csrc/fam_cwt.h"
 #include "../../tsfresh_amd/csrc/fam_entropy.h"
@@ -130,9 +131,14 @@ extern "C" int tsfa_emul_extract_timed(const tsfa_feature_spec *specs, int n_spe
             }
             std::vector<double> xc(maxn + 8), aw(ArLds::scratch_doubles(P));
             const double *xp = xs.data();
-            fam_ar_series<double>(b, [=](int i) { return xp[i]; }, n, fam[TSFA_FAM_AR].data(), (int)fam[TSFA_FAM_AR].size(), row,
-                          (void *)xc.data(), aw.data(), P, hints[TSFA_FAM_AR].a, hints[TSFA_FAM_AR].b,
-                          hints[TSFA_FAM_AR].c, (s % 2) ? -1 : hints[TSFA_FAM_AR].d);
+            const int flags = fam_ar_series<double>(b, [=](int i) { return xp[i]; }, n, fam[TSFA_FAM_AR].data(),
+                          (int)fam[TSFA_FAM_AR].size(), row, (void *)xc.data(), aw.data(), P, hints[TSFA_FAM_AR].a,
+                          hints[TSFA_FAM_AR].b, hints[TSFA_FAM_AR].c, (s % 2) ? -1 : hints[TSFA_FAM_AR].d);
+            if (flags) {  // the second pass of the family (k_ar_degenerate)
+                std::vector<double> sc(ArDdLds::scratch_doubles(P));
+                fam_ar_degenerate_series(b, [=](int i) { return xp[i]; }, n, fam[TSFA_FAM_AR].data(),
+                                         (int)fam[TSFA_FAM_AR].size(), row, sc.data(), P, flags);
+            }
         }
         if (!fam[TSFA_FAM_ENTROPY].empty()) {
             std::vector<double> thr(56), xe(xs.begin(), xs.begin() + n);

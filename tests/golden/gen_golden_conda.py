@@ -46,13 +46,14 @@ import statsmodels  # noqa: E402
 from tsfresh.feature_extraction import settings as ref_settings  # noqa: E402
 from tsfresh.feature_extraction.extraction import _do_extraction_on_chunk  # noqa: E402
 
-from golden_cases import golden_series, pack  # noqa: E402
+from golden_cases import CASE_SETS, pack  # noqa: E402
 
 CALCS = ("cwt_coefficients", "agg_autocorrelation", "partial_autocorrelation", "augmented_dickey_fuller", "ar_coefficient")
 
 
 def main():
-    cases = golden_series()
+    case_set = sys.argv[sys.argv.index("--set") + 1] if "--set" in sys.argv else "main"
+    cases = CASE_SETS[case_set]()
     full = ref_settings.ComprehensiveFCParameters()
     params = {k: full[k] for k in CALCS}
     names, rows = None, []
@@ -64,7 +65,7 @@ def main():
         assert cols == names
         rows.append([float(r[2]) for r in res])
     values, offsets = pack(cases)
-    out = os.path.join(HERE, "ref_conda.npz")
+    out = os.path.join(HERE, "ref_conda.npz" if case_set == "main" else "ref_conda_%s.npz" % case_set)
     np.savez_compressed(out, values=values, offsets=offsets, labels=np.array([c[0] for c in cases]),
                         names=np.array(names), matrix=np.asarray(rows, dtype=np.float64),
                         versions=np.array(["numpy " + np.__version__, "pandas " + pd.__version__,

@@ -8,9 +8,24 @@ removed from the FCParameters and covered by gen_golden_conda.py instead.  Every
 701 columns -- is the unmodified reference code path `extraction._do_extraction_on_chunk`.
 
     python tests/golden/gen_golden_main.py        # needs /root/reference; writes tests/golden/ref_main.npz
+    python tests/golden/gen_golden_main.py --set degenerate             # ref_main_degenerate.npz
+    python tests/golden/gen_golden_main.py [--set S] --nosimd           # ref_main[_S]_nosimd.npz
+
+--nosimd re-executes the interpreter with NPY_DISABLE_CPU_FEATURES set, so numpy's runtime dispatch falls back to its
+scalar loops.  It exists for ONE calculator: permutation_entropy ranks every window with np.argsort's default kind
+(fc.py:1866-1916), which on AVX-512 / AVX2 machines is an unstable vectorised sort, so windows holding tied values
+get CPU-dependent ranks; numpy's scalar path sorts such short rows by insertion (stable), the ranking the kernels
+and the oracle use.  The two fixtures differ in the permutation_entropy cells of tie-holding series and otherwise
+by <= 5e-14 relative (libm-vs-SIMD rounding).
 """
 import os
 import sys
+
+NOSIMD = "--nosimd" in sys.argv
+_SIMD_FEATURES = "AVX512F AVX512CD AVX512_SKX AVX512_CLX AVX512_CNL AVX512_ICL AVX2 FMA3"
+if NOSIMD and os.environ.get("NPY_DISABLE_CPU_FEATURES") != _SIMD_FEATURES:
+    os.environ["NPY_DISABLE_CPU_FEATURES"] = _SIMD_FEATURES
+    os.execv(sys.executable, [sys.executable] + sys.argv)
 import types
 import warnings
 
@@ -40,14 +55,15 @@ sys.path.insert(0, "/root/reference")
 from tsfresh.feature_extraction import settings as ref_settings  # noqa: E402
 from tsfresh.feature_extraction.extraction import _do_extraction_on_chunk  # noqa: E402
 
-from golden_cases import golden_series, pack  # noqa: E402
+from golden_cases import CASE_SETS, pack  # noqa: E402
 
 NEED_THIRD_PARTY = ("cwt_coefficients", "agg_autocorrelation", "partial_autocorrelation", "augmented_dickey_fuller",
                     "ar_coefficient")
 
 
 def main():
-    cases = golden_series()
+    case_set = sys.argv[sys.argv.index("--set") + 1] if "--set" in sys.argv else "main"
+    cases = CASE_SETS[case_set]()
     params = ref_settings.ComprehensiveFCParameters()
     full_names = {}
     for cls in ("ComprehensiveFCParameters", "EfficientFCParameters", "MinimalFCParameters"):
@@ -69,7 +85,8 @@ def main():
             assert cols == names
             rows.append([float(r[2]) for r in res])
     values, offsets = pack(cases)
-    out = os.path.join(HERE, "ref_main.npz")
+    suffix = ("" if case_set == "main" else "_" + case_set) + ("_nosimd" if NOSIMD else "")
+    out = os.path.join(HERE, "ref_main%s.npz" % suffix)
     np.savez_compressed(
         out, values=values, offsets=offsets, labels=np.array([c[0] for c in cases]), names=np.array(names),
         matrix=np.asarray(rows, dtype=np.float64),

@@ -24,6 +24,41 @@ def golden_series():
     return cases
 
 
+def degenerate_series():
+    """Series on which the regressions of the path are rank-deficient or nearly so (stuck sensors, ramps, periodic
+    signals, noiseless float32 sines): the reference answers with the pseudo-inverse's minimum-norm solution
+    (statsmodels OLS pinv, np.polyfit's lstsq), and these vectors pin that behaviour."""
+    rng = np.random.default_rng(20260923)
+    t = np.arange(1024, dtype=np.float64)
+    cases = [
+        ("const_3_100", np.full(100, 3.0)),
+        ("const_f32_64", np.full(64, np.float32(-1.7)).astype(np.float64)),
+        ("const_big_1024", np.full(1024, 1.0e6 + 0.25)),
+        ("zeros_100", np.zeros(100)),
+        ("ramp_neg_100", 5.0 - 0.5 * t[:100]),
+        ("ramp_f32_1000", (t[:1000] * 0.25 + 3.0).astype(np.float32).astype(np.float64)),
+        ("alt_pm1_80", np.where(np.arange(80) % 2 == 0, 1.0, -1.0)),
+        ("period4_120", np.tile([0.0, 1.0, 2.0, 1.0], 30)),
+        ("period3_99", np.tile([1.0, 2.0, 4.0], 33)),
+        ("step_60", np.concatenate([np.zeros(30), np.ones(30)])),
+        ("sat_ramp_90", np.minimum(t[:90], 50.0)),
+        ("glitch_ramp_70", np.concatenate([[5.0], t[1:70]])),
+        ("quad_200", t[:200] ** 2),
+        ("geom_40", 2.0 ** t[:40]),
+        ("const_then_noise_100", np.concatenate([np.full(50, 2.0), rng.standard_normal(50)])),
+        ("noise_then_const_100", np.concatenate([rng.standard_normal(50), np.full(50, 2.0)])),
+        ("sine_f32_512", np.sin(t[:512] * 0.1).astype(np.float32).astype(np.float64)),
+        ("sine_2dec_400", np.round(np.sin(t[:400] * 0.05), 2)),
+        ("two_valued_1024", rng.integers(0, 2, size=1024).astype(np.float64)),
+        ("const_1024", np.full(1024, 0.1)),
+        ("tiny_noise_ramp_300", t[:300] + 1e-9 * rng.standard_normal(300)),
+    ]
+    return cases
+
+
+CASE_SETS = {"main": golden_series, "degenerate": degenerate_series}
+
+
 def pack(cases):
     values = np.concatenate([c[1] for c in cases])
     offsets = np.zeros(len(cases) + 1, dtype=np.int64)

@@ -1,0 +1,51 @@
+"""The golden fixtures (outputs of the REAL reference, tests/golden/gen_golden_*.py) as (names, matrix, values,
+offsets, series, labels) tuples.
+
+  pair            reference run                                   compare(..., simd_golden=)
+  main            ref_main.npz + ref_conda.npz                    True  (numpy's SIMD argsort ranked the windows)
+  main_nosimd     ref_main_nosimd.npz + ref_conda.npz             False (stable ranks: permutation_entropy ties pinned)
+  degenerate      ref_main_degenerate.npz + ref_conda_degenerate  True
+  degenerate_nosimd  ref_main_degenerate_nosimd.npz + ...         False
+"""
+import os
+
+import numpy as np
+
+G = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+PAIRS = {
+    "main": ("ref_main.npz", "ref_conda.npz", True),
+    "main_nosimd": ("ref_main_nosimd.npz", "ref_conda.npz", False),
+    "degenerate": ("ref_main_degenerate.npz", "ref_conda_degenerate.npz", True),
+    "degenerate_nosimd": ("ref_main_degenerate_nosimd.npz", "ref_conda_degenerate.npz", False),
+}
+
+
+def load(pair):
+    f1, f2, simd = PAIRS[pair]
+    g1 = np.load(os.path.join(G, f1))
+    g2 = np.load(os.path.join(G, f2))
+    assert np.array_equal(g1["values"], g2["values"]) and np.array_equal(g1["offsets"], g2["offsets"])
+    names = list(g1["names"]) + list(g2["names"])
+    matrix = np.concatenate([g1["matrix"], g2["matrix"]], axis=1)
+    values, offsets = g1["values"], g1["offsets"]
+    series = [values[offsets[i]:offsets[i + 1]] for i in range(len(offsets) - 1)]
+    return dict(names=names, matrix=matrix, values=values, offsets=offsets, series=series,
+                labels=[str(l) for l in g1["labels"]], simd=simd)
+
+
+def align(names_want, names_got, got):
+    assert set(names_want) == set(names_got), (set(names_want) ^ set(names_got))
+    idx = [names_got.index(n) for n in names_want]
+    return got[:, idx]
+
+
+def check_engine(engine, pair, fc_parameters):
+    """-> (mismatches, skipped cells, total cells) of `engine` against the fixture pair."""
+    from parity import compare
+    g = load(pair)
+    got_names, got = engine(fc_parameters, g["values"], g["offsets"])
+    skipped = []
+    bad = compare(g["names"], align(g["names"], got_names, got), g["matrix"], g["series"], simd_golden=g["simd"],
+                  skipped=skipped)
+    return bad, skipped, g["matrix"].size

@@ -79,12 +79,18 @@ TSFA_DEV void blk_chol_solve(const Blk &b, const double *L, int p, int ld, const
 // Workgroup-cooperative Cholesky (right-looking): after step j, column j holds L(:, j) and the trailing block has had
 // L(:, j) L(:, j)^T subtracted.  Every entry receives exactly the subtractions of the serial left-looking loop, in the
 // same order (k ascending), so the factor is bit-identical to chol_factor's; only the p-1 dependent steps remain
-// serial.  Returns false (uniformly) on a non-positive pivot.
-TSFA_DEV bool blk_chol_factor(const Blk &b, double *G, int p, int ld) {
+// serial.
+// Returns false (uniformly) when a pivot keeps less than TSFA_AR_PIVOT_TOL of its column's squared norm (diag0
+// receives the diagonal of G): the design is rank-deficient (constant / linear / periodic series) or conditioned
+// worse than ~3e4, where float64 normal equations lose the digits the reference's SVD still has.  Such series are
+// listed for the double-double second pass (fam_ar_dd.h); an absolute `d > 0` test lets round-off pass for a pivot.
+#define TSFA_AR_PIVOT_TOL 1e-9
+TSFA_DEV bool blk_chol_factor(const Blk &b, double *G, int p, int ld, double *diag0) {
+    for (int a = b.tid; a < p; a += b.nt) diag0[a] = G[a + a * ld];
     for (int j = 0; j < p; ++j) {
         blk_sync();
         const double d = G[j + j * ld];
-        if (!(d > 0.0)) return false;
+        if (!(d > TSFA_AR_PIVOT_TOL * diag0[j])) return false;
         const double sd = sqrt(d);
         blk_sync();
         for (int i = j + b.tid; i < p; i += b.nt) G[i + j * ld] = (i == j) ? sd : G[i + j * ld] / sd;
@@ -196,8 +202,8 @@ TSFA_DEV double mackinnon_p_c1(double t) {
 }
 
 // LDS scratch of the family, carved from `aw`:  P = max regressors + 1 (leading dimension of the matrices)
-//   T (P*P) | G (P*P) | 6 vectors of P | acv 64 | res 16 | pac 48 | arres 40 | pacw 128
-TSFA_DEV int ar_scratch_doubles(int P) { return 2 * P * P + 6 * P + 64 + 16 + 48 + 40 + 128; }
+//   T (P*P) | G (P*P) | 7 vectors of P | acv 64 | res 16 | pac 48 | arres 40 | pacw 128
+TSFA_DEV int ar_scratch_doubles(int P) { return 2 * P * P + 7 * P + 64 + 16 + 48 + 40 + 128; }
 
 // Evaluate the AR specs of one series.
 //   xv   : sample accessor
@@ -211,8 +217,10 @@ struct ArCentred {
     double mean;
     TSFA_MEM double operator[](int i) const { return (double)p[i] - mean; }
 };
+// Returns the calculators the float64 normal equations could not serve (bit 0: ar_coefficient, bit 1:
+// augmented_dickey_fuller); their columns are left NaN for the second pass (fam_ar_dd.h).
 template <class ST, class X>
-TSFA_DEV void fam_ar_series(const Blk &b, X xv, int n, const TsfaSpec *specs, int nspecs, double *out_row, void *xc_raw,
+TSFA_DEV int fam_ar_series(const Blk &b, X xv, int n, const TsfaSpec *specs, int nspecs, double *out_row, void *xc_raw,
                             double *aw, int P, int hint_acf, int hint_pacf, int hint_adf, int n_loop = -1) {
     const int nloop = (n_loop >= 0) ? n_loop : nspecs;  // columns [nloop, nspecs): lane = column epilogue
     const double dn = (double)n;
@@ -237,12 +245,14 @@ TSFA_DEV void fam_ar_series(const Blk &b, X xv, int n, const TsfaSpec *specs, in
     double *tmp2 = tmp1 + P;
     double *C = tmp2 + P;         // column sums
     double *V = C + P;            // level products (ADF)
-    double *acv = V + P;          // 64
+    double *diag0 = V + P;        // diagonal of the matrix being factored (relative pivot test)
+    double *acv = diag0 + P;      // 64
     double *res = acv + 64;       // 16
     double *pac = res + 16;       // 48
     double *arres = pac + 48;     // 40: cached AR solution
     double *pacw = arres + 40;    // 128: Levinson-Durbin columns
     const ArCentred<ST> xcc = xc;
+    int degenerate = 0;
 
     TSFA_TICK(tk, b, 120);
     // largest agg_autocorrelation maxlag / partial_autocorrelation lag of the plan (-1: none) and whether ADF is
@@ -353,7 +363,8 @@ TSFA_DEV void fam_ar_series(const Blk &b, X xv, int n, const TsfaSpec *specs, in
             TSFA_TICK(tk, b, 123);
             {
                 // all nested fits from one factorization: w = L^-1 g, SSR_p = yy - sum_{i<p} w_i^2
-                const bool okf = blk_chol_factor(b, G, p1, P);
+                const bool okf = blk_chol_factor(b, G, p1, P, diag0);
+                if (!okf) degenerate |= 2;
                 if (okf) {
                     for (int a = b.tid; a < p1; a += b.nt) tmp1[a] = g[a];
                     blk_chol_forward(b, G, p1, P, tmp1);
@@ -420,7 +431,8 @@ TSFA_DEV void fam_ar_series(const Blk &b, X xv, int n, const TsfaSpec *specs, in
                     if (is_rhs) g[a] = v; else G[a + c * P] = v;
                 }
                 blk_sync();
-                const bool ok2 = blk_chol_factor(b, G, p2, P);
+                const bool ok2 = blk_chol_factor(b, G, p2, P, diag0);
+                if (!ok2) degenerate |= 2;
                 if (ok2) blk_chol_solve(b, G, p2, P, g, beta);
                 blk_sync();
                 if (ok2) {
@@ -589,7 +601,8 @@ TSFA_DEV void fam_ar_series(const Blk &b, X xv, int n, const TsfaSpec *specs, in
                 }
                 for (int a = b.tid; a < p; a += b.nt) g[a] = (a == 0) ? C[0] : T[a];
                 blk_sync();
-                ar_ok = blk_chol_factor(b, G, p, P);
+                ar_ok = blk_chol_factor(b, G, p, P, diag0);
+                if (!ar_ok) degenerate |= 1;
                 if (ar_ok) blk_chol_solve(b, G, p, P, g, beta);
                 blk_sync();
                 if (ar_ok) {
@@ -660,6 +673,7 @@ TSFA_DEV void fam_ar_series(const Blk &b, X xv, int n, const TsfaSpec *specs, in
             out_row[sp.col] = v;
         }
     }
+    return degenerate;
 }
 
 #endif

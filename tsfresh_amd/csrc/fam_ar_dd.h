@@ -1,0 +1,440 @@
+// Family AR, second pass: rank-deficient and ill-conditioned regressions.
+//
+// statsmodels fits AutoReg (fc.py:1459-1508) and every OLS inside adfuller (fc.py:499-545) with the pseudo-inverse
+// (regression/linear_model.py:300-338, tools/tools.py:398 pinv_extended, rcond = 1e-15): on a constant, linear,
+// periodic, ... series the design is rank-deficient and the reference returns the MINIMUM-NORM solution, uses the
+// RANK (not the column count) in the AIC and in the residual degrees of freedom, and -- tsatools.add_trend(...,
+// has_constant="skip"), tsatools.py:112-136 -- leaves the constant out when the design already holds an exactly
+// constant non-zero column.  k_ar solves the normal equations by Cholesky in float64, which is only trustworthy while
+// every pivot keeps a fair share of its column (fam_ar.h: TSFA_AR_PIVOT_TOL); series that fail the test are listed and
+// handled here, one workgroup per listed series, in double-double arithmetic (~32 digits):
+//   * the Gram matrix of the RAW (uncentred) design from exact products (the minimum-norm solution is not invariant
+//     under centring), lag products by the same diagonal recurrence as the first pass;
+//   * a Cholesky factorization in natural column order that SKIPS dependent columns (pivot <= 1e-26 of its column:
+//     the square of a singular-value ratio of 1e-13, the double-double image of pinv's 1e-15 cut-off): the kept
+//     columns give X = Q R with R = L_kept^T of full row rank, every nested prefix fit (adfuller's lag search)
+//     reads its rank and its residual sum from the same factor;
+//   * minimum norm:  beta = R^T (R R^T)^-1 Q^T y,  (X^T X)^+ [0,0] = | (R R^T)^-1 R e_0 |^2.
+// With 32 digits the normal equations resolve designs up to cond(X) ~ 1e12, so near-degenerate but full-rank series
+// (a noiseless float32 sine, a ramp with 1e-9 noise) also agree with the reference's SVD.
+// A residual sum that is zero in exact arithmetic (a perfect fit) gives AIC = -inf and a 0/0 or x/0 test statistic
+// here; the reference divides two round-off numbers there (tests/parity.py documents that exclusion).
+#ifndef TSFA_FAM_AR_DD_H
+#define TSFA_FAM_AR_DD_H
+
+#include "fam_ar.h"
+
+struct dd {
+    double hi, lo;
+};
+TSFA_DEV dd dd_from(double a) { return dd{a, 0.0}; }
+TSFA_DEV dd dd_quick_two_sum(double a, double b) {
+    const double s = a + b;
+    return dd{s, b - (s - a)};
+}
+TSFA_DEV dd dd_two_sum(double a, double b) {
+    const double s = a + b;
+    const double bb = s - a;
+    return dd{s, (a - (s - bb)) + (b - bb)};
+}
+TSFA_DEV dd dd_two_prod(double a, double b) {
+    const double p = a * b;
+    return dd{p, __builtin_fma(a, b, -p)};
+}
+TSFA_DEV dd dd_add(dd a, dd b) {
+    dd s = dd_two_sum(a.hi, b.hi);
+    const dd t = dd_two_sum(a.lo, b.lo);
+    s.lo += t.hi;
+    s = dd_quick_two_sum(s.hi, s.lo);
+    s.lo += t.lo;
+    return dd_quick_two_sum(s.hi, s.lo);
+}
+TSFA_DEV dd dd_neg(dd a) { return dd{-a.hi, -a.lo}; }
+TSFA_DEV dd dd_sub(dd a, dd b) { return dd_add(a, dd_neg(b)); }
+TSFA_DEV dd dd_mul(dd a, dd b) {
+    dd p = dd_two_prod(a.hi, b.hi);
+    p.lo += a.hi * b.lo + a.lo * b.hi;
+    return dd_quick_two_sum(p.hi, p.lo);
+}
+TSFA_DEV dd dd_mul_d(dd a, double b) {
+    dd p = dd_two_prod(a.hi, b);
+    p.lo += a.lo * b;
+    return dd_quick_two_sum(p.hi, p.lo);
+}
+TSFA_DEV dd dd_add_prod(dd acc, double a, double b) { return dd_add(acc, dd_two_prod(a, b)); }  // acc + a * b
+TSFA_DEV dd dd_div(dd a, dd b) {
+    const double q1 = a.hi / b.hi;
+    dd r = dd_sub(a, dd_mul_d(b, q1));
+    const double q2 = r.hi / b.hi;
+    r = dd_sub(r, dd_mul_d(b, q2));
+    const double q3 = r.hi / b.hi;
+    return dd_add(dd_quick_two_sum(q1, q2), dd_from(q3));
+}
+TSFA_DEV dd dd_sqrt(dd a) {
+    if (!(a.hi > 0.0)) return dd_from(0.0);
+    const double x = 1.0 / sqrt(a.hi);
+    const double ax = a.hi * x;
+    const dd t = dd_sub(a, dd_two_prod(ax, ax));
+    return dd_two_sum(ax, t.hi * (x * 0.5));
+}
+
+// all-reduce of a double-double over the workgroup (every thread receives the same bits: dd_add is symmetric)
+TSFA_DEV dd blk_sum_dd(const Blk &b, dd v) {
+#if TSFA_GPU
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const dd u{__shfl_xor(v.hi, o), __shfl_xor(v.lo, o)};
+        v = dd_add(v, u);
+    }
+    if (b.nt > 64) {
+        const int nw = b.nt >> 6;
+        blk_sync();
+        if ((b.tid & 63) == 0) {
+            b.red[2 * (b.tid >> 6)] = v.hi;
+            b.red[2 * (b.tid >> 6) + 1] = v.lo;
+        }
+        blk_sync();
+        v = dd{b.red[0], b.red[1]};
+        for (int w = 1; w < nw; ++w) v = dd_add(v, dd{b.red[2 * w], b.red[2 * w + 1]});
+    }
+#endif
+    return v;
+}
+
+#define TSFA_DD_SKIP_TOL 1e-26   // pivot / column norm^2 below which a column is dependent
+#define TSFA_DD_ZERO_SSR 1e-24   // ssr / yy below which a fit is perfect (ssr = 0 in exact arithmetic)
+
+// Cholesky in natural column order, skipping dependent columns (right-looking; rows of a column are dealt over the
+// threads).  On exit kept[j] tells whether column j entered the factor; for a kept j, G[i + j*ld] (i >= j) = L(i, j)
+// for EVERY row i (dependent rows included: they are the columns of R beyond its triangle).  `mask` (optional)
+// pre-excludes columns.  Returns the rank, or -1 if a non-masked pivot is not positive although tol == 0.
+TSFA_DEV int dd_chol_skip(const Blk &b, dd *G, int p, int ld, int *kept, const int *mask, double tol, dd *diag0) {
+    blk_sync();
+    for (int a = b.tid; a < p; a += b.nt) diag0[a] = G[a + a * ld];
+    int rank = 0;
+    bool bad = false;
+    for (int j = 0; j < p; ++j) {
+        blk_sync();
+        const dd d = G[j + j * ld];
+        const double d0 = diag0[j].hi;
+        bool keep = !(mask && !mask[j]);
+        if (keep) {
+            if (tol > 0.0) keep = (d0 > 0.0) && (d.hi > tol * d0);
+            else if (!(d.hi > 0.0)) { keep = false; bad = true; }
+        }
+        if (b.tid == 0) kept[j] = keep ? 1 : 0;
+        if (!keep) continue;
+        ++rank;
+        const dd sd = dd_sqrt(d);
+        blk_sync();
+        for (int i = j + b.tid; i < p; i += b.nt) G[i + j * ld] = (i == j) ? sd : dd_div(G[i + j * ld], sd);
+        blk_sync();
+        // trailing update: G(i, k) -= L(i, j) L(k, j), j < k <= i
+        const int m = p - j - 1;
+        for (int e = b.tid; e < m * m; e += b.nt) {
+            const int i = j + 1 + e / m, k = j + 1 + e % m;
+            if (k > i) continue;
+            G[i + k * ld] = dd_sub(G[i + k * ld], dd_mul(G[i + j * ld], G[k + j * ld]));
+        }
+    }
+    blk_sync();
+    return bad ? -1 : rank;
+}
+
+// w = (L_kept)^-1 g over the kept columns, in place (w[j] = 0 for skipped columns)
+TSFA_DEV void dd_forward_kept(const Blk &b, const dd *L, int p, int ld, const int *kept, dd *w) {
+    for (int j = 0; j < p; ++j) {
+        blk_sync();
+        if (!kept[j]) {
+            if (b.tid == 0) w[j] = dd_from(0.0);
+            continue;
+        }
+        const dd wj = dd_div(w[j], L[j + j * ld]);
+        blk_sync();
+        if (b.tid == 0) w[j] = wj;
+        for (int i = j + 1 + b.tid; i < p; i += b.nt) w[i] = dd_sub(w[i], dd_mul(L[i + j * ld], wj));
+    }
+    blk_sync();
+}
+
+// Minimum-norm least squares from the skipping factor:  beta = R^T (R R^T)^-1 w  with R = L_kept^T.
+//   S: p x p scratch (receives R R^T and its factor); z, diag0: p scratch; kept2: p ints.
+// If want_cov0, *cov0 = ((X^T X)^+)[0, 0].  Returns false if R R^T fails to factor (never for a consistent factor).
+TSFA_DEV bool dd_min_norm(const Blk &b, const dd *L, int p, int ld, const int *kept, const dd *w, dd *S, dd *z, dd *diag0,
+                          int *kept2, dd *beta, bool want_cov0, double *cov0) {
+    blk_sync();
+    for (int e = b.tid; e < p * p; e += b.nt) {
+        const int a = e / p, c = e % p;
+        if (c > a) continue;
+        dd s = dd_from(0.0);
+        if (kept[a] && kept[c])
+            for (int i = a; i < p; ++i) s = dd_add(s, dd_mul(L[i + a * ld], L[i + c * ld]));
+        S[a + c * ld] = s;
+    }
+    const int r2 = dd_chol_skip(b, S, p, ld, kept2, kept, 0.0, diag0);
+    if (r2 < 0) return false;
+    for (int pass = 0; pass < (want_cov0 ? 2 : 1); ++pass) {
+        blk_sync();
+        if (b.tid == 0) {
+            // rhs: pass 0 = w, pass 1 = R e_0 (only its first entry, L(0, 0), is non-zero)
+            for (int a = 0; a < p; ++a) z[a] = (pass == 0) ? w[a] : dd_from(0.0);
+            if (pass == 1 && kept[0]) z[0] = L[0];
+            for (int a = 0; a < p; ++a) {  // S = F F^T:  F y = rhs
+                if (!kept[a]) continue;
+                dd s = z[a];
+                for (int c = 0; c < a; ++c)
+                    if (kept[c]) s = dd_sub(s, dd_mul(S[a + c * ld], z[c]));
+                z[a] = dd_div(s, S[a + a * ld]);
+            }
+            for (int a = p - 1; a >= 0; --a) {  // F^T x = y
+                if (!kept[a]) continue;
+                dd s = z[a];
+                for (int c = a + 1; c < p; ++c)
+                    if (kept[c]) s = dd_sub(s, dd_mul(S[c + a * ld], z[c]));
+                z[a] = dd_div(s, S[a + a * ld]);
+            }
+            if (pass == 1) {
+                dd s = dd_from(0.0);
+                for (int a = 0; a < p; ++a)
+                    if (kept[a]) s = dd_add(s, dd_mul(z[a], z[a]));
+                diag0[0] = s;
+            }
+        }
+        blk_sync();
+        if (pass == 0) {
+            for (int c = b.tid; c < p; c += b.nt) {
+                dd s = dd_from(0.0);
+                for (int a = 0; a <= c; ++a)
+                    if (kept[a]) s = dd_add(s, dd_mul(L[c + a * ld], z[a]));
+                beta[c] = s;
+            }
+        } else {
+            *cov0 = diag0[0].hi;
+        }
+    }
+    blk_sync();
+    return true;
+}
+
+// Lag products of sequence s over rows t in [t0, t1) in double-double: T[i + j*ld] = sum_t s(t-i) s(t-j) (lower
+// triangle, 0 <= j <= i <= Lg) and C[j] = sum_t s(t-j).  Requires t0 >= Lg.
+template <class S>
+TSFA_DEV void dd_lag_products(const Blk &b, S s, int Lg, int t0, int t1, dd *T, int ld, dd *C) {
+    for (int j = 0; j <= Lg; ++j) {
+        dd a = dd_from(0.0);
+        for (int t = t0 + b.tid; t < t1; t += b.nt) a = dd_add_prod(a, s(t), s(t - j));
+        a = blk_sum_dd(b, a);
+        if (b.tid == 0) T[j] = a;
+    }
+    dd c0 = dd_from(0.0);
+    for (int t = t0 + b.tid; t < t1; t += b.nt) c0 = dd_add(c0, dd_from(s(t)));
+    c0 = blk_sum_dd(b, c0);
+    if (b.tid == 0) {
+        C[0] = c0;
+        for (int j = 0; j < Lg; ++j) C[j + 1] = dd_add(dd_add(C[j], dd_from(s(t0 - 1 - j))), dd_from(-s(t1 - 1 - j)));
+    }
+    blk_sync();
+    for (int dg = b.tid; dg <= Lg; dg += b.nt) {  // one lane per diagonal i - j = dg
+        dd v = T[dg];
+        for (int j = 0; dg + j + 1 <= Lg; ++j) {
+            const int i = dg + j;
+            v = dd_add_prod(v, s(t0 - 1 - i), s(t0 - 1 - j));
+            v = dd_add_prod(v, -s(t1 - 1 - i), s(t1 - 1 - j));
+            T[(i + 1) + (j + 1) * ld] = v;
+        }
+    }
+    blk_sync();
+}
+
+// LDS scratch of the second pass, in doubles (ArDdLds::scratch_doubles): 2 matrices of P*P dd + 7 vectors of (P+1) dd
+// + 2 P ints, rounded up
+
+// flags: bit 0 = ar_coefficient, bit 1 = augmented_dickey_fuller (which calculators the first pass gave up on)
+template <class X>
+TSFA_DEV void fam_ar_degenerate_series(const Blk &b, X xv, int n, const TsfaSpec *specs, int nspecs, double *out_row,
+                                       double *scratch, int P, int flags) {
+    dd *T = (dd *)(void *)scratch;        // lag products, later R R^T
+    dd *G = T + P * P;                    // Gram matrix -> skipping factor
+    dd *C = G + P * P;                    // column sums
+    dd *V = C + (P + 1);                  // level products (ADF)
+    dd *g = V + (P + 1);                  // rhs -> w
+    dd *z = g + (P + 1);
+    dd *beta = z + (P + 1);
+    dd *diag0 = beta + (P + 1);
+    dd *misc = diag0 + (P + 1);           // P + 1
+    int *kept = (int *)(void *)(misc + (P + 1));
+    int *kept2 = kept + P;
+
+    // ---------------------------------------------------------------------------------------------------------
+    // augmented Dickey-Fuller, regression="c", autolag="AIC" (stattools.adfuller)
+    // ---------------------------------------------------------------------------------------------------------
+    if (flags & 2) {
+        double r_stat = TSFA_NAN, r_p = TSFA_NAN, r_lag = TSFA_NAN;
+        const int M = adf_maxlag_for(n);
+        if (M >= 0 && M + 3 <= P) {
+            auto dif = [=](int t) { return xv(t + 1) - xv(t); };  // np.diff(x) in float64
+            const int t0 = M, t1 = n - 1;
+            const int nobs = t1 - t0;
+            // add_trend(..., has_constant="skip"): a column of [level, lag 1..U] over rows [r0, t1) that is exactly
+            // constant and non-zero suppresses the constant.  Counts the offending columns.
+            auto const_cols = [&](int U, int r0) {
+                double cnt = 0.0;
+                for (int c = b.tid; c <= U; c += b.nt) {  // c = 0: level; c >= 1: lag c
+                    const double first = (c == 0) ? xv(r0) : dif(r0 - c);
+                    bool same = (first != 0.0);
+                    for (int t = r0 + 1; same && t < t1; ++t) same = (((c == 0) ? xv(t) : dif(t - c)) == first);
+                    cnt += same ? 1.0 : 0.0;
+                }
+                return blk_sum(b, cnt) > 0.0;
+            };
+            const int hasc = const_cols(M, t0) ? 0 : 1;
+            dd_lag_products(b, dif, M, t0, t1, T, P, C);
+            for (int j = 0; j <= M; ++j) {
+                dd a = dd_from(0.0);
+                for (int t = t0 + b.tid; t < t1; t += b.nt) a = dd_add_prod(a, xv(t), dif(t - j));
+                a = blk_sum_dd(b, a);
+                if (b.tid == 0) V[j] = a;
+            }
+            dd sx = dd_from(0.0), sxx = dd_from(0.0);
+            for (int t = t0 + b.tid; t < t1; t += b.nt) {
+                sx = dd_add(sx, dd_from(xv(t)));
+                sxx = dd_add_prod(sxx, xv(t), xv(t));
+            }
+            sx = blk_sum_dd(b, sx);
+            sxx = blk_sum_dd(b, sxx);
+            blk_sync();
+            // column kinds of the lag-search design: -1 const, 0 level, j >= 1 lag j
+            const int p1 = M + 1 + hasc;
+            auto kind1 = [=](int a) { return hasc ? (a == 0 ? -1 : a - 1) : a; };
+            auto gram = [&](int ka, int kc) -> dd {  // inner product of two column kinds over rows [t0, t1)
+                if (ka < kc) { const int t = ka; ka = kc; kc = t; }
+                if (ka == -1) return dd_from((double)nobs);
+                if (kc == -1) return (ka == 0) ? sx : C[ka];
+                if (ka == 0) return sxx;
+                if (kc == 0) return V[ka];
+                return T[ka + kc * P];
+            };
+            for (int e = b.tid; e < p1 * p1; e += b.nt) {
+                const int a = e / p1, c = e % p1;
+                if (c > a) continue;
+                G[a + c * P] = gram(kind1(a), kind1(c));
+            }
+            for (int a = b.tid; a < p1; a += b.nt) {
+                const int ka = kind1(a);
+                g[a] = (ka == -1) ? C[0] : (ka == 0 ? V[0] : T[ka]);
+            }
+            const dd yy = T[0];
+            blk_sync();
+            dd_chol_skip(b, G, p1, P, kept, nullptr, TSFA_DD_SKIP_TOL, diag0);
+            dd_forward_kept(b, G, p1, P, kept, g);
+            if (b.tid == 0) {
+                // nested fits: `lag` leading columns, lag = startlag .. startlag + M (stattools._autolag)
+                const int startlag = hasc + 1;
+                dd acc = dd_from(0.0);
+                int rank = 0, best = -1;
+                double best_aic = 0.0;
+                const double dn = (double)nobs;
+                for (int m = 1; m <= p1; ++m) {
+                    if (kept[m - 1]) { acc = dd_add(acc, dd_mul(g[m - 1], g[m - 1])); ++rank; }
+                    if (m < startlag) continue;
+                    double ssr = dd_sub(yy, acc).hi;
+                    if (!(ssr > TSFA_DD_ZERO_SSR * yy.hi)) ssr = 0.0;
+                    const double llf = -0.5 * dn * log(2.0 * M_PI) - 0.5 * dn * log(ssr / dn) - 0.5 * dn;
+                    const double aic = -2.0 * llf + 2.0 * (double)rank;
+                    if (best < 0 || aic < best_aic) { best = m; best_aic = aic; }
+                }
+                misc[0] = dd_from((double)(best - startlag));
+            }
+            blk_sync();
+            const int U = (int)misc[0].hi;
+            blk_sync();
+            // final regression: [level, lag 1..U] (+ const) over rows [U, n-1)
+            const int u0 = U;
+            const int nobs2 = t1 - u0;
+            const int hasc2 = const_cols(U, u0) ? 0 : 1;
+            const int p2 = U + 1 + hasc2;
+            auto kind2 = [=](int a) { return (a <= U) ? a : -1; };
+            auto colv = [=](int k, int t) { return k == -1 ? 1.0 : (k == 0 ? xv(t) : dif(t - k)); };
+            for (int e = b.tid; e < p2 * p2 + p2 + 1; e += b.nt) {
+                const bool is_yy = (e == p2 * p2 + p2), is_rhs = (e >= p2 * p2) && !is_yy;
+                const int a = is_yy ? 0 : (is_rhs ? e - p2 * p2 : e / p2);
+                const int c = (is_rhs || is_yy) ? 0 : e % p2;
+                if (!is_rhs && !is_yy && c > a) continue;
+                const int ka = kind2(a), kc = kind2(c);
+                dd v;
+                if (is_yy) v = yy;
+                else if (is_rhs) v = (ka == -1) ? C[0] : (ka == 0 ? V[0] : T[ka]);
+                else v = gram(ka, kc);
+                for (int t = u0; t < t0; ++t) {  // the rows the lag search had trimmed
+                    const double l = is_yy ? dif(t) : colv(ka, t);
+                    const double r = (is_rhs || is_yy) ? dif(t) : colv(kc, t);
+                    v = dd_add_prod(v, l, r);
+                }
+                if (is_yy) misc[1] = v;
+                else if (is_rhs) g[a] = v;
+                else G[a + c * P] = v;
+            }
+            blk_sync();
+            const dd yy2 = misc[1];
+            const double lev2 = G[0].hi;  // squared norm of the level column
+            const int rank2 = dd_chol_skip(b, G, p2, P, kept, nullptr, TSFA_DD_SKIP_TOL, diag0);
+            dd_forward_kept(b, G, p2, P, kept, g);
+            double cov0 = 0.0;
+            const bool ok = dd_min_norm(b, G, p2, P, kept, g, T, z, diag0, kept2, beta, true, &cov0);
+            if (ok) {
+                dd acc = dd_from(0.0);
+                for (int a = 0; a < p2; ++a)
+                    if (kept[a]) acc = dd_add(acc, dd_mul(g[a], g[a]));
+                double ssr = dd_sub(yy2, acc).hi;
+                if (!(ssr > TSFA_DD_ZERO_SSR * yy2.hi)) ssr = 0.0;
+                const double sigma2 = ssr / ((double)nobs2 - (double)rank2);
+                double b0 = beta[0].hi;
+                // a perfect fit whose level coefficient is zero in exact arithmetic: 0 / 0, not (round-off) / 0
+                if (ssr == 0.0 && fabs(b0) * sqrt(lev2) <= 1e-12 * sqrt(yy2.hi)) b0 = 0.0;
+                r_stat = b0 / sqrt(sigma2 * cov0);
+                r_p = (r_stat != r_stat) ? TSFA_NAN : mackinnon_p_c1(r_stat);
+                r_lag = (double)U;
+            }
+        }
+        for (int s = b.tid; s < nspecs; s += b.nt) {
+            const TsfaSpec sp = specs[s];
+            if (sp.calc != TSFA_C_AUGMENTED_DICKEY_FULLER) continue;
+            const int attr = (int)sp.p[0];
+            out_row[sp.col] = (attr == TSFA_ADF_TESTSTAT) ? r_stat : (attr == TSFA_ADF_PVALUE ? r_p : (attr == TSFA_ADF_USEDLAG ? r_lag : TSFA_NAN));
+        }
+        blk_sync();
+    }
+
+    // ---------------------------------------------------------------------------------------------------------
+    // AutoReg(x, lags=k, trend="c").fit().params  (ar_model.py: OLS on [1, x[t-1..t-k]], rows t in [k, n))
+    // ---------------------------------------------------------------------------------------------------------
+    if (flags & 1) {
+        int done_k = -1;
+        bool ok = false;
+        for (int s = 0; s < nspecs; ++s) {
+            const TsfaSpec sp = specs[s];
+            if (sp.calc != TSFA_C_AR_COEFFICIENT) continue;
+            const int coeff = (int)sp.p[0], k = (int)sp.p[1];
+            if (coeff > k || n < 2 * k + 2 || k + 2 > P || k < 1 || k + 1 > 40) continue;  // the first pass's answer stands
+            if (done_k != k) {
+                dd_lag_products(b, [=](int u) { return xv(u); }, k, k, n, T, P, C);
+                const int p = k + 1;
+                for (int e = b.tid; e < p * p; e += b.nt) {
+                    const int a = e / p, c = e % p;
+                    if (c > a) continue;
+                    G[a + c * P] = (a == 0) ? dd_from((double)(n - k)) : (c == 0 ? C[a] : T[a + c * P]);
+                }
+                for (int a = b.tid; a < p; a += b.nt) g[a] = (a == 0) ? C[0] : T[a];
+                blk_sync();
+                dd_chol_skip(b, G, p, P, kept, nullptr, TSFA_DD_SKIP_TOL, diag0);
+                dd_forward_kept(b, G, p, P, kept, g);
+                double unused = 0.0;
+                ok = dd_min_norm(b, G, p, P, kept, g, T, z, diag0, kept2, beta, false, &unused);
+                done_k = k;
+            }
+            if (b.tid == 0) out_row[sp.col] = ok ? beta[coeff].hi : TSFA_NAN;
+        }
+    }
+}
+
+#endif

@@ -75,7 +75,8 @@ struct tsfa_plan {
     int *d_cols = nullptr, *d_coeff = nullptr;
     double *d_dectab = nullptr, *d_twc = nullptr, *d_tws = nullptr;
     long long *d_stats = nullptr;
-    DevBuf values, offsets, out, gscratch, times;
+    DevBuf values, offsets, out, gscratch, times, deg_list;
+    int *d_deg_count = nullptr;
     bool needs_times = false;  // the plan holds linear_trend_timewise columns
     // side streams: the family kernels are independent (each writes its own columns), so they may overlap
     int n_streams = 1;
@@ -141,6 +142,8 @@ void tsfa_plan_destroy(tsfa_plan *plan) {
     if (plan->d_twc) (void)hipFree(plan->d_twc);
     if (plan->d_tws) (void)hipFree(plan->d_tws);
     if (plan->d_stats) (void)hipFree(plan->d_stats);
+    if (plan->d_deg_count) (void)hipFree(plan->d_deg_count);
+    plan->deg_list.release();
     plan->times.release();
     plan->values.release();
     plan->offsets.release();
@@ -218,6 +221,7 @@ int tsfa_plan_create(const tsfa_feature_spec *specs, int32_t n_specs, int32_t de
         ok = upload(dt, &plan->d_dectab) == 0 && upload(twc, &plan->d_twc) == 0 && upload(tws, &plan->d_tws) == 0;
     }
     if (ok) ok = hipMalloc((void **)&plan->d_stats, 4 * sizeof(long long)) == hipSuccess;
+    if (ok) ok = hipMalloc((void **)&plan->d_deg_count, sizeof(int)) == hipSuccess;
     {
         const char *e = getenv("TSFA_STREAMS");
         plan->n_streams = e ? std::min(std::max(atoi(e), 1), TSFA_MAX_AUX + 1) : TSFA_DEFAULT_STREAMS;
@@ -442,6 +446,12 @@ int tsfa_extract_windows(tsfa_plan *plan, const void *values, int32_t dtype, con
             }
             a.ar_P = P;
             aux = P;
+            for (const auto &s : plan->fam_specs[f])
+                if (s.calc == TSFA_C_AR_COEFFICIENT) a.ar_has_coef = 1;
+            if (plan->deg_list.ensure((size_t)n_series * sizeof(long long))) return fail(TSFA_ERR_HIP, "hipMalloc failed for the k_ar_degenerate list");
+            a.deg_list = (long long *)plan->deg_list.p;
+            a.deg_count = plan->d_deg_count;
+            HIP_TRY(hipMemsetAsync(plan->d_deg_count, 0, sizeof(int), fst));
         } else if (f == TSFA_FAM_ENTROPY) {
             // one wavefront per 64-template row block, up to four per series; the symmetric sweep needs 12 B of
             // LDS counters per sample

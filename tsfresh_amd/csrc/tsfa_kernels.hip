@@ -2,6 +2,7 @@
 #include <hip/hip_runtime.h>
 
 #include "fam_ar.h"
+#include "fam_ar_dd.h"
 #include "fam_basic.h"
 #include "fam_cwt.h"
 #include "fam_entropy.h"
@@ -10,6 +11,8 @@
 #include "fam_spectral.h"
 #include "tsfa_launch.h"
 #include "tsfa_layout.h"
+
+#include <algorithm>
 
 extern __shared__ __attribute__((aligned(16))) unsigned char tsfa_smem[];
 
@@ -118,7 +121,8 @@ __global__ void __launch_bounds__(256) k_spectral(const T *__restrict__ values, 
 template <typename T>
 __global__ void __launch_bounds__(256) k_ar(const T *__restrict__ values, const int64_t *__restrict__ starts, const int64_t *__restrict__ ends, int64_t n_series,
                      const TsfaSpec *__restrict__ specs, int nspecs, double *__restrict__ out, int64_t ld, int maxn,
-                     int P, int hint_acf, int hint_pacf, int hint_adf, int n_loop) {
+                     int P, int hint_acf, int hint_pacf, int hint_adf, int n_loop, long long *__restrict__ deg_list,
+                     int *__restrict__ deg_count) {
     const int64_t sidx = blockIdx.x;
     if (sidx >= n_series) return;
     const int64_t off = starts[sidx];
@@ -128,9 +132,33 @@ __global__ void __launch_bounds__(256) k_ar(const T *__restrict__ values, const 
     TSFA_TICKS_BEGIN();
     Blk b{(int)threadIdx.x, (int)blockDim.x, L.red, L.np};
     const T *g = values + off;
-    fam_ar_series<T>(b, [=](int i) { return (double)g[i]; }, n, specs, nspecs, out + sidx * ld, (void *)L.xc, L.aw, P,
-                  hint_acf, hint_pacf, hint_adf, n_loop);
+    const int flags = fam_ar_series<T>(b, [=](int i) { return (double)g[i]; }, n, specs, nspecs, out + sidx * ld,
+                                       (void *)L.xc, L.aw, P, hint_acf, hint_pacf, hint_adf, n_loop);
+    // rank-deficient / ill-conditioned regressions: list the series for k_ar_degenerate
+    if (flags && threadIdx.x == 0) deg_list[atomicAdd(deg_count, 1)] = ((long long)sidx << 2) | flags;
     TSFA_TICKS_END();
+}
+
+// second pass of the AR family (fam_ar_dd.h): the listed series, one workgroup each, double-double normal equations.
+// The list order is arbitrary (atomics); every listed series writes only its own row, so the result is not.
+template <typename T>
+__global__ void __launch_bounds__(64) k_ar_degenerate(const T *__restrict__ values, const int64_t *__restrict__ starts, const int64_t *__restrict__ ends,
+                     const TsfaSpec *__restrict__ specs, int nspecs, double *__restrict__ out, int64_t ld, int P,
+                     const long long *__restrict__ deg_list, const int *__restrict__ deg_count) {
+    ArDdLds L;
+    L.carve(tsfa_smem, P);
+    Blk b{(int)threadIdx.x, (int)blockDim.x, L.red, nullptr};
+    const int cnt = *deg_count;
+    for (int i = blockIdx.x; i < cnt; i += gridDim.x) {
+        const long long e = deg_list[i];
+        const int64_t sidx = e >> 2;
+        const int64_t off = starts[sidx];
+        const int n = (int)(ends[sidx] - off);
+        const T *g = values + off;
+        fam_ar_degenerate_series(b, [=](int k) { return (double)g[k]; }, n, specs, nspecs, out + sidx * ld, L.scratch, P,
+                                 (int)(e & 3));
+        blk_sync();
+    }
 }
 
 // FAST: symmetric sweep only (m = 2 specs, LDS counters fit) -- see fam_entropy_series
@@ -334,7 +362,16 @@ static int launch_all_t(const TsfaLaunch &a, const T *values) {
         const size_t lds = L.carve(nullptr, a.maxn, a.ar_P, (int)sizeof(T));
         if ((rc = set_lds(k_ar<T>, lds))) return rc;
         k_ar<T><<<grid, nt, lds, st>>>(values, a.starts, a.ends, a.n_series, a.specs, a.nspecs, a.out, a.ld, a.maxn, a.ar_P,
-                                       a.hint_a, a.hint_b, a.hint_c, a.hint_d);
+                                       a.hint_a, a.hint_b, a.hint_c, a.hint_d, a.deg_list, a.deg_count);
+        TSFA_LAUNCH_CHECK();
+        if (a.hint_c || a.ar_has_coef) {  // ADF / ar_coefficient columns: the regressions that can degenerate
+            ArDdLds D;
+            const size_t dlds = D.carve(nullptr, a.ar_P);
+            if ((rc = set_lds(k_ar_degenerate<T>, dlds))) return rc;
+            const unsigned dgrid = (unsigned)std::min<int64_t>(a.n_series, 4096);
+            k_ar_degenerate<T><<<dgrid, 64, dlds, st>>>(values, a.starts, a.ends, a.specs, a.nspecs, a.out, a.ld, a.ar_P,
+                                                        a.deg_list, a.deg_count);
+        }
     } else if (a.fam == TSFA_FAM_ENTROPY) {
         EntropyLds L;
         const size_t lds = L.carve(nullptr, a.maxn, a.ent_cnt);

@@ -33,6 +33,9 @@ struct TsfaLaunch {
     int gscratch_n;
     TsfaSeqGroup seq;       // SEQ: the (<= TSFA_LZ_MAX_GROUP) specs this launch parses side by side
     int ar_P;               // AR: leading dimension of the normal matrices
+    int ar_has_coef;        // AR: the plan holds ar_coefficient columns
+    long long *deg_list;    // AR: series listed for the double-double second pass ((index << 2) | calculator bits) ...
+    int *deg_count;         // ... and their number (device; zeroed before the launch)
     int cwt_rowv;           // CWT peaks: second CWT row resident in LDS
     int hint_a, hint_b, hint_c, hint_d, hint_e;  // tsfa_prepare_family (BASIC, SORT, SPECTRAL, AR)
     int ent_cnt;            // ENTROPY: per-template LDS counters (symmetric sweep)

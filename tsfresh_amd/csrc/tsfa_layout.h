@@ -116,7 +116,7 @@ struct SpectralLds {
 struct ArLds {
     double *red; NpScratch *np; double *xc; double *aw;
     // P: leading dimension of the normal matrices = (max regressors) + 1, chosen by the host for the batch
-    TSFA_HD static int scratch_doubles(int P) { return 2 * P * P + 6 * P + 64 + 16 + 48 + 40 + 128; }
+    TSFA_HD static int scratch_doubles(int P) { return 2 * P * P + 7 * P + 64 + 16 + 48 + 40 + 128; }
     // xs_bytes: element size of the resident series (4: float32 input kept as float32, 8: float64)
     TSFA_HD size_t carve(unsigned char *base, int maxn, int P, int xs_bytes = 8) {
         LdsCarve c{base, 0};
@@ -127,6 +127,18 @@ struct ArLds {
         unsigned char *u = c.take<unsigned char>(ab > sizeof(NpScratch) ? ab : sizeof(NpScratch));
         aw = (double *)u;
         np = (NpScratch *)u;
+        return c.off;
+    }
+};
+
+// second pass of the AR family (fam_ar_dd.h): one workgroup per listed series, matrices in double-double
+struct ArDdLds {
+    double *red; double *scratch;
+    TSFA_HD static int scratch_doubles(int P) { return 4 * P * P + 16 * (P + 1) + P + 8; }
+    TSFA_HD size_t carve(unsigned char *base, int P) {
+        LdsCarve c{base, 0};
+        red = c.take<double>(TSFA_RED_DOUBLES);
+        scratch = c.take<double>((size_t)scratch_doubles(P));
         return c.off;
     }
 };
