@@ -38,8 +38,9 @@ can bound it.
       (scipy's sqrt((1 - r^2) ...) cancels).
   R9  partial_autocorrelation from the lag at which the Levinson-Durbin innovation variance has dropped below
       1e-9 * acov[0] (an exactly predictable series: periodic, linear): the next coefficient divides by round-off.
-  R8  number_cwt_peaks on an exactly periodic series: ridge lines start from relative maxima of CWT rows whose
-      neighbouring values are equal up to round-off.
+  R8  number_cwt_peaks when a CWT row has two neighbouring values on top of a hump that are equal up to round-off
+      (1e-12 of the row's magnitude; symmetric integer-valued or periodic data): which one is the STRICT relative
+      maximum that starts a ridge line depends on the summation order of scipy's convolution.
 """
 import numpy as np
 
@@ -129,13 +130,22 @@ def _chunk_aggs(x, f_agg, chunk_len):
     return np.array([getattr(x[i * chunk_len:(i + 1) * chunk_len], f_agg)() for i in range(int(np.ceil(len(x) / chunk_len)))])
 
 
-def _is_periodic(x):
-    x = np.asarray(x)
-    n = len(x)
-    if n < 3 or np.ptp(x) == 0:
+def _cwt_peaks_ambiguous(x, n):
+    """A CWT row (scipy.signal.find_peaks_cwt's convolution with the Ricker wavelet) holds two neighbouring values that
+    are equal up to round-off on top of a hump: which of them -- or neither -- is the strict relative maximum that
+    starts a ridge line depends on the summation order of the convolution."""
+    from scipy.signal._wavelets import _cwt
+    from oracle.calculators import _ricker
+    x = np.asarray(x, dtype=np.float64)
+    if len(x) < 4 or np.ptp(x) == 0:
         return False
-    for p in range(1, min(n // 3, 64) + 1):
-        if np.array_equal(x[p:], x[:-p]):
+    rows = _cwt(x, _ricker, np.arange(1, n + 1))
+    for c in rows:
+        tol = 1e-12 * np.max(np.abs(c))
+        near = np.abs(c[1:] - c[:-1]) <= tol                       # c[i] ~ c[i+1]
+        left = np.concatenate([[True], c[1:-1] >= c[:-2] - tol])   # c[i] >= c[i-1]
+        right = np.concatenate([c[1:-1] >= c[2:] - tol, [True]])   # c[i+1] >= c[i+2]
+        if np.any(near & left & right):
             return True
     return False
 
@@ -215,7 +225,8 @@ def excluded(col, x, simd_golden=False, facts=None, rvalue=None):
     if f == "partial_autocorrelation":
         return _param(col, "lag", int) >= facts.get("pacf", lambda: _pacf_noise_lag(xv))                   # R9
     if f == "number_cwt_peaks":
-        return facts.get("periodic", lambda: _is_periodic(xv))                                           # R8
+        nn = _param(col, "n", int)
+        return facts.get(("cwtp", nn), lambda: _cwt_peaks_ambiguous(xv, nn))                             # R8
     return False
 
 

