@@ -17,7 +17,11 @@ ComprehensiveFCParameters (783 columns) -- the configuration the metric/target i
 The JSON line also carries
   roofline     : dominant kernel's algorithmic HBM bytes per launch / its HIP-event duration vs 8 TB/s
   cpu_baseline : the numpy oracle (a port of the reference's calculators) timed on a bounded sample of the same
-                 workload on the host cores -- a reported baseline, not the target.
+                 workload on the host cores (warm pool, >= 32 series per worker, median of 3) -- a reported baseline,
+                 not the target; `reference_estimate` scales it by the port/reference ratio measured in the build
+                 container (profiles/r02_reference_cpu.json)
+  parity_sample: 8 rows of the timed output against the oracle (tests/parity.py), outside the timed region
+  e2e          : host-buffer and DataFrame -> DataFrame rates of the same plan (PCIe-inclusive; never `value`)
 """
 import argparse
 import json
@@ -34,14 +38,20 @@ HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: 8.0 TB/s spec (
 
 
 def _cpu_baseline_worker(args):
-    values, offsets = args
-    sys.path.insert(0, ROOT)
+    values, offsets, params_name = args
+    import warnings
     from oracle.extract import oracle_matrix
-    from tsfresh_amd.feature_extraction.settings import ComprehensiveFCParameters, EfficientFCParameters  # noqa: F401
-    params = ComprehensiveFCParameters()
-    t0 = time.perf_counter()
-    oracle_matrix(values, offsets, params)
-    return time.perf_counter() - t0
+    from tsfresh_amd.feature_extraction import settings
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        return oracle_matrix(values, offsets, getattr(settings, params_name)())
+
+
+def _cpu_warm(_):
+    sys.path.insert(0, ROOT)
+    import oracle.extract  # noqa: F401
+    import tsfresh_amd.feature_extraction.settings  # noqa: F401
+    return 0
 
 
 def measured_hbm_traffic(kernel, cfg):
@@ -59,28 +69,100 @@ def measured_hbm_traffic(kernel, cfg):
     return doc.get("kernels", {}).get(kernel, {}).get("hbm_bytes_per_launch")
 
 
-def cpu_baseline(length, seed, budget_series_per_core=4):
-    """Oracle ("port") on a bounded sample: `cores` worker processes, each `budget_series_per_core` series."""
-    import multiprocessing as mp
-    for v in ("OMP_NUM_THREADS", "MKL_NUM_THREADS", "OPENBLAS_NUM_THREADS"):
-        os.environ[v] = "1"  # the reference's own advice (docs/text/tsfresh_on_a_cluster.rst:216-231)
-    cores = os.cpu_count() or 1
-    workers = min(cores, 64)
-    rng = np.random.default_rng(seed)
-    jobs = []
-    for _ in range(workers):
-        x = rng.standard_normal((budget_series_per_core, length), dtype=np.float32).astype(np.float64)
-        jobs.append((x.reshape(-1), np.arange(budget_series_per_core + 1, dtype=np.int64) * length))
-    ctx = mp.get_context("spawn")
-    t0 = time.perf_counter()
-    with ctx.Pool(workers) as pool:
+def cpu_baseline(pool, workers, length, params_name, seed, per_worker=32, repeats=3):
+    """The CPU path beside the GPU number, on the host cores of this box (rank 0, N = 1 only).
+
+    What is timed is oracle/ -- the numpy restatement of the reference's calculators ("port", all 75 calculators) --
+    because /root/reference does not exist on the GPU box.  Protocol: one worker process per core,
+    started and warmed OUTSIDE the clock, `per_worker` (>= 32) series each, `repeats` runs, median; BLAS threads = 1
+    (docs/text/tsfresh_on_a_cluster.rst:216-231).  profiles/r02_reference_cpu.json holds the same protocol run in the
+    build container on BOTH the real reference (tsfresh.extract_features + MultiprocessingDistributor,
+    distribution.py:438; 70 of 75 calculators importable there) and this port: the port does 0.945x the reference's
+    series/s/core, so `value / port_over_reference_per_core` estimates the reference on these cores."""
+    import statistics
+    walls = []
+    for r in range(repeats):
+        rng = np.random.default_rng(seed + r)
+        jobs = []
+        for _ in range(workers):
+            x = rng.standard_normal((per_worker, length), dtype=np.float32).astype(np.float64)
+            jobs.append((x.reshape(-1), np.arange(per_worker + 1, dtype=np.int64) * length, params_name))
+        t0 = time.perf_counter()
         pool.map(_cpu_baseline_worker, jobs)
-    wall = time.perf_counter() - t0
-    n = workers * budget_series_per_core
-    return {"value": n / wall, "unit": "series/sec", "cores": workers, "kind": "port",
-            "sample": "%d series x len %d, ComprehensiveFCParameters, oracle/ (numpy port of the reference "
-                      "calculators), %d processes x %d series, wall %.1f s incl. process start" % (
-                          n, length, workers, budget_series_per_core, wall)}
+        walls.append(time.perf_counter() - t0)
+    n = workers * per_worker
+    wall = statistics.median(walls)
+    doc = {"value": n / wall, "unit": "series/sec", "cores": workers, "kind": "port",
+           "series_per_sec_per_core": n / wall / workers,
+           "sample": "%d series x len %d, %s, oracle/ (numpy port of the reference calculators, all 75), %d warm worker "
+                     "processes x %d series, median of %d runs (%s s), pool start outside the clock" % (
+                         n, length, params_name, workers, per_worker, repeats, ", ".join("%.1f" % w for w in walls))}
+    try:
+        ref = json.load(open(os.path.join(ROOT, "profiles", "r02_reference_cpu.json")))
+        ratio = ref["port_over_reference_per_core"]
+        doc["port_over_reference_per_core"] = ratio
+        doc["reference_estimate"] = {
+            "value": doc["value"] / ratio, "unit": "series/sec",
+            "basis": "real tsfresh extract_features(n_jobs=cores) vs this port, same protocol, build container "
+                     "(profiles/r02_reference_cpu.json: reference %.3f, port %.3f series/s/core; reference default "
+                     "n_jobs = cores // 2 -> half this value)" % (
+                         ref["reference"]["all_cores"]["series_per_sec_per_core"],
+                         ref["port"]["all_cores"]["series_per_sec_per_core"])}
+    except (OSError, ValueError, KeyError):
+        pass
+    return doc
+
+
+def parity_sample(pool, rows_in, rows_out, names, params_name):
+    """A few rows of the TIMED output against the oracle (outside the timed region): 'ok' or 'fail: ...'."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from parity import compare
+    L = rows_in.shape[1]
+    jobs = [(rows_in[i].astype(np.float64), np.array([0, L], dtype=np.int64), params_name) for i in range(len(rows_in))]
+    res = pool.map(_cpu_baseline_worker, jobs) if pool is not None else [_cpu_baseline_worker(j) for j in jobs]
+    onames = res[0][0]
+    want = np.concatenate([r[1] for r in res], axis=0)
+    kind_names = ["value__" + n for n in names]
+    idx = [kind_names.index(n) for n in onames]
+    bad = compare(onames, rows_out[:, idx], want, [r.astype(np.float64) for r in rows_in])
+    return "ok" if not bad else "fail: %d of %d cells, first %s" % (len(bad), want.size, bad[:3])
+
+
+def e2e_block(plan, fplan, params_cls, n, L):
+    """Boundary timings beside the HBM-resident `value`: the same plan on HOST buffers (PCIe-inclusive:
+    chunked H2D / kernels / D2H pipeline of tsfa_extract(TSFA_HOST)) and DataFrame in -> DataFrame out through
+    extract_features (packer + host path + frame construction).  Best of 3 after one warm call."""
+    import warnings
+
+    import pandas as pd
+    from tsfresh_amd import extract_features
+    rng = np.random.default_rng(7)
+    x = rng.standard_normal((n, L), dtype=np.float32)
+    offsets = np.arange(n + 1, dtype=np.int64) * L
+    plan.set_length_hint(0, 0)
+    res = {"n_series": n, "length": L}
+    best = None
+    for _ in range(4):
+        t0 = time.perf_counter()
+        m = plan.extract_host(x.reshape(-1), offsets)
+        dt = time.perf_counter() - t0
+        best = dt if best is None or _ == 1 else min(best, dt)  # first call: allocations / page-locking
+    res["host_buffers"] = {"seconds": best, "series_per_sec": n / best,
+                           "bytes_h2d": int(x.nbytes), "bytes_d2h": int(m.nbytes)}
+    df = pd.DataFrame({"id": np.repeat(np.arange(n), L), "time": np.tile(np.arange(L), n), "value": x.reshape(-1)})
+    best = None
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        for _ in range(4):
+            t0 = time.perf_counter()
+            f = extract_features(df, column_id="id", column_sort="time", default_fc_parameters=params_cls())
+            dt = time.perf_counter() - t0
+            best = dt if best is None or _ == 1 else min(best, dt)
+    assert f.shape == (n, len(fplan))
+    same = np.array_equal(np.nan_to_num(f.to_numpy()), np.nan_to_num(m))
+    res["dataframe"] = {"seconds": best, "series_per_sec": n / best, "rows_in": int(n * L),
+                        "equals_host_buffer_result": bool(same)}
+    return res
 
 
 def main():
@@ -94,6 +176,7 @@ def main():
     ap.add_argument("--ragged", default="", help="LO:HI -> series lengths uniform on [LO, HI] (configs[4] shape); "
                                                  "--length is ignored")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-e2e", action="store_true", help="skip the host-buffer / DataFrame boundary timings")
     ap.add_argument("--chunks", type=int, default=0,
                     help="N > 1: row chunks per step; the all-gather of chunk c runs on RCCL's stream while chunk c + 1 is "
                          "being extracted (0 = 8 when N > 1, else 1)")
@@ -224,7 +307,9 @@ def main():
         for name, ms in plan.last_timings():
             kt[name] = kt.get(name, 0.0) + ms / reps
     plan.set_profiling(False)
-    finite = bool(torch.isfinite(out[:, : min(n_cols, 8)]).all().item())
+    # every column of the TIMED output: finite everywhere, except the columns that are NaN by definition
+    nonfinite_cols = [fplan.names[j] for j in torch.nonzero(~torch.isfinite(out).all(dim=0)).flatten().tolist()]
+    finite = all(nm.startswith("query_similarity_count") for nm in nonfinite_cols)
 
     if rank == 0:
         dom = max(kt, key=kt.get) if kt else None
@@ -262,8 +347,29 @@ def main():
                        "row_chunks_per_step": n_chunks},
             "kernel_ms": kt, "outputs_finite": finite, "roofline": roof,
         }
+        line["nonfinite_columns"] = nonfinite_cols
+        params_name = args.params.capitalize() + "FCParameters"
+        pool = None
         if world == 1 and not args.no_cpu_baseline:
-            line["cpu_baseline"] = cpu_baseline(L, seed=42)
+            import multiprocessing as mp
+            for v in ("OMP_NUM_THREADS", "MKL_NUM_THREADS", "OPENBLAS_NUM_THREADS"):
+                os.environ[v] = "1"  # the reference's own advice (docs/text/tsfresh_on_a_cluster.rst:216-231)
+            workers = min(os.cpu_count() or 1, 64)
+            pool = mp.get_context("spawn").Pool(workers)
+            pool.map(_cpu_warm, range(4 * workers))
+        if world == 1 and not args.ragged:
+            # ~8 rows of the timed output against the oracle, outside the timed region
+            pick = sorted(set([0, 1, 2, n // 3, n // 2, n - 3, n - 2, n - 1]))
+            pick = [i for i in pick if 0 <= i < n]
+            rows_in = values.view(n, L)[pick].cpu().numpy()
+            rows_out = out[pick].cpu().numpy()
+            line["parity_sample"] = parity_sample(pool, rows_in, rows_out, fplan.names, params_name)
+        if world == 1 and not args.ragged and not args.no_e2e:
+            line["e2e"] = e2e_block(plan, fplan, cls, min(n, 20_000), L)
+        if pool is not None:
+            line["cpu_baseline"] = cpu_baseline(pool, workers, L, params_name, seed=42)
+            pool.close()
+            pool.join()
         print(json.dumps(line))
     if dist is not None:
         dist.barrier()

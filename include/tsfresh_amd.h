@@ -18,6 +18,7 @@
 #ifndef TSFRESH_AMD_H
 #define TSFRESH_AMD_H
 
+#include <stddef.h>
 #include <stdint.h>
 
 #ifdef __cplusplus
@@ -88,8 +89,11 @@ void tsfa_plan_destroy(tsfa_plan *plan);
  *   offsets  n_series+1 int64, offsets[0] may be non-zero (a view into a larger buffer)
  *   out      row-major [n_series x ld_out] float64, ld_out >= n_cols; caller-allocated, caller-owned;
  *            NaN where the reference yields NaN
- *   space    TSFA_HOST: values/offsets/out are host pointers (the library stages them through HBM);
+ *   space    TSFA_HOST: values/offsets/out are host pointers; the batch is staged through HBM in row chunks, copy-in
+ *            of chunk c + 1 and copy-out of chunk c - 1 overlapping the kernels of chunk c (three streams);
  *            TSFA_DEVICE: all three are device pointers on the plan's device
+ * A batch whose lengths span more than a factor of two is launched by length class (each class with the LDS carve and
+ * workgroup size of ITS longest series), so one long series does not slow a batch of short ones down.
  *   stream   a hipStream_t (or NULL = the plan's own stream).  With TSFA_DEVICE and a non-NULL
  *            stream the call returns after enqueueing; otherwise it is synchronous.
  *
@@ -139,6 +143,14 @@ int32_t tsfa_plan_last_timings(const tsfa_plan *plan, const char **names, float 
  * outside the promised range is undefined behaviour.  (0, 0) withdraws the promise.  The reference has no counterpart:
  * its per-series dispatch (extraction.py:308) sizes nothing ahead. */
 int tsfa_plan_set_length_hint(tsfa_plan *plan, int64_t min_len, int64_t max_len);
+
+/* Page-locked host memory for the TSFA_HOST form.  tsfa_extract* accepts ANY host pointer; from pageable memory the HIP
+ * runtime stages every transfer through its own bounce buffers, from memory obtained here the copy engines read and
+ * write it directly, so the chunked copy-in / compute / copy-out pipeline of tsfa_extract runs at PCIe rate.  The
+ * Python host allocates the packed sample buffer and the result matrix (the future DataFrame's block) this way.  The
+ * reference has no counterpart (its matrix is assembled by data.pivot, data.py:86-121, from Python tuples). */
+int tsfa_host_alloc(void **ptr, size_t bytes);
+int tsfa_host_free(void *ptr);
 
 /* ---- feature selection: relevance statistics of the extracted matrix ----
  * Replaces the per-feature loop of tsfresh/feature_selection/relevance.py:214-322 (calculate_relevance_table ->

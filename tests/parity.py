@@ -122,7 +122,7 @@ def _langevin_noise_cubic(x, m, r):
         return False
     s = max(float(np.max(np.abs(x))), 1e-300)
     mag = np.abs(c) * s ** np.arange(len(c) - 1, -1, -1)
-    return bool(mag[0] <= 1e-9 * mag.max())
+    return bool(mag[0] <= 1e-8 * mag.max())
 
 
 def _chunk_aggs(x, f_agg, chunk_len):

@@ -5,6 +5,7 @@ when it is missing, and computing fails loudly when no HIP device is visible: th
 """
 import ctypes
 import os
+import sys
 
 import numpy as np
 
@@ -29,6 +30,8 @@ EXPORTS = (
     "tsfa_plan_set_profiling",
     "tsfa_plan_last_timings",
     "tsfa_plan_set_length_hint",
+    "tsfa_host_alloc",
+    "tsfa_host_free",
     "tsfa_relevance_classes",
     "tsfa_relevance_classes_ks",
     "tsfa_relevance_real",
@@ -95,6 +98,10 @@ def load():
     lib.tsfa_plan_last_timings.argtypes = [ctypes.c_void_p, ctypes.POINTER(ctypes.c_char_p),
                                            ctypes.POINTER(ctypes.c_float), ctypes.c_int32]
     lib.tsfa_plan_last_timings.restype = ctypes.c_int32
+    lib.tsfa_host_alloc.argtypes = [ctypes.POINTER(ctypes.c_void_p), ctypes.c_size_t]
+    lib.tsfa_host_alloc.restype = ctypes.c_int
+    lib.tsfa_host_free.argtypes = [ctypes.c_void_p]
+    lib.tsfa_host_free.restype = ctypes.c_int
     _lib = lib
     return lib
 
@@ -110,6 +117,81 @@ def device_count():
 
 def calc_id(name):
     return int(load().tsfa_calc_id(name.encode("ascii")))
+
+
+# Page-locking memory is slow (~0.1 ms per MB), so freed blocks are kept for reuse, by power-of-two size class, up to
+# TSFRESH_AMD_PINNED_POOL_MB (default 4096) in total; a result matrix handed to the caller returns here when the
+# caller's DataFrame dies.
+_PIN_POOL = {}
+_PIN_POOL_BYTES = [0]
+_PIN_LOCK = __import__("threading").Lock()
+
+
+def _pin_pool_cap():
+    return int(os.environ.get("TSFRESH_AMD_PINNED_POOL_MB", "4096")) << 20
+
+
+class _PinnedBlock:
+    """Owner of one tsfa_host_alloc allocation; numpy arrays built on it keep it alive through their base chain."""
+
+    def __init__(self, nbytes):
+        lib = load()
+        size = 1 << max(20, int(nbytes - 1).bit_length()) if nbytes > (1 << 20) else (1 << 20)
+        with _PIN_LOCK:
+            free = _PIN_POOL.get(size)
+            ptr = free.pop() if free else None
+            if ptr is not None:
+                _PIN_POOL_BYTES[0] -= size
+        if ptr is None:
+            p = ctypes.c_void_p()
+            _check(lib, lib.tsfa_host_alloc(ctypes.byref(p), size))
+            ptr = p.value
+        self._lib, self.ptr, self.nbytes, self.size = lib, ptr, int(nbytes), size
+
+    def __del__(self):
+        try:
+            ptr, self.ptr = getattr(self, "ptr", None), None
+            if not ptr:
+                return
+            with _PIN_LOCK:
+                if _PIN_POOL_BYTES[0] + self.size <= _pin_pool_cap():
+                    _PIN_POOL.setdefault(self.size, []).append(ptr)
+                    _PIN_POOL_BYTES[0] += self.size
+                    return
+            self._lib.tsfa_host_free(ctypes.c_void_p(ptr))
+        except Exception:  # interpreter shutdown
+            pass
+
+
+def release_pinned_pool():
+    """Give the pooled page-locked blocks back to the system."""
+    lib = load()
+    with _PIN_LOCK:
+        for size, ptrs in _PIN_POOL.items():
+            for ptr in ptrs:
+                lib.tsfa_host_free(ctypes.c_void_p(ptr))
+        _PIN_POOL.clear()
+        _PIN_POOL_BYTES[0] = 0
+
+
+def pinned_empty(shape, dtype):
+    """np.empty(shape, dtype) in page-locked host memory (tsfa_host_alloc): the copy engines reach it directly, so the
+    chunked H2D / kernels / D2H pipeline of tsfa_extract(TSFA_HOST) runs at PCIe rate.  Returned to the pool with the
+    last view."""
+    dtype = np.dtype(dtype)
+    shape = tuple(int(d) for d in (shape if isinstance(shape, (tuple, list)) else (shape,)))
+    n = int(np.prod(shape, dtype=np.int64)) if shape else 1
+    block = _PinnedBlock(n * dtype.itemsize)
+    buf = (ctypes.c_char * max(block.nbytes, 1)).from_address(block.ptr)
+    buf._tsfa_owner = block  # array -> memoryview -> buf -> block: the allocation lives as long as any view of it
+    return np.frombuffer(buf, dtype=dtype, count=n).reshape(shape)
+
+
+def _result_matrix(n_rows, n_cols):
+    """The feature matrix of a host-side extraction: page-locked when it is large enough for the copy-out to matter."""
+    if n_rows * n_cols * 8 >= (4 << 20) and os.environ.get("TSFRESH_AMD_PINNED", "1") != "0":
+        return pinned_empty((n_rows, n_cols), np.float64)
+    return np.empty((n_rows, n_cols), dtype=np.float64)
 
 
 class Plan:
@@ -137,7 +219,13 @@ class Plan:
             self._lib.tsfa_plan_destroy(self._h)
             self._h = None
 
-    __del__ = close
+    def __del__(self):
+        # at interpreter exit the HIP runtime may already be gone: leak rather than call into it
+        try:
+            if not sys.is_finalizing():
+                self.close()
+        except Exception:
+            pass
 
     def set_profiling(self, enable=True):
         _check(self._lib, self._lib.tsfa_plan_set_profiling(self._h, 1 if enable else 0))
@@ -167,7 +255,7 @@ class Plan:
             dt = TSFA_F64
         offsets = np.ascontiguousarray(offsets, dtype=np.int64)
         n_series = offsets.shape[0] - 1
-        out = np.empty((n_series, self.n_cols), dtype=np.float64)
+        out = _result_matrix(n_series, self.n_cols)
         if n_series == 0 or self.n_cols == 0:
             return out
         if values.size == 0:
@@ -197,7 +285,7 @@ class Plan:
         if starts.shape != ends.shape or starts.ndim != 1:
             raise ValueError("starts and ends must be 1-D arrays of the same length")
         n = starts.shape[0]
-        out = np.empty((n, self.n_cols), dtype=np.float64)
+        out = _result_matrix(n, self.n_cols)
         if n == 0 or self.n_cols == 0:
             return out
         if starts.min() < 0 or ends.max() > values.shape[0]:

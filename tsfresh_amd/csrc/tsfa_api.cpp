@@ -55,6 +55,7 @@ struct DevBuf {
 };
 
 #define TSFA_MAX_AUX 3
+#define TSFA_MAX_CHUNKS 16
 #define TSFA_DEFAULT_STREAMS 1
 
 struct Timing {
@@ -75,8 +76,12 @@ struct tsfa_plan {
     int *d_cols = nullptr, *d_coeff = nullptr;
     double *d_dectab = nullptr, *d_twc = nullptr, *d_tws = nullptr;
     long long *d_stats = nullptr;
-    DevBuf values, offsets, out, gscratch, times, deg_list;
+    DevBuf values, offsets, out, gscratch, times, deg_list, sel;
     int *d_deg_count = nullptr;
+    int *d_cursor = nullptr;                    // per-launch-group fill cursors (k_class_fill)
+    hipStream_t s_in = nullptr, s_out = nullptr;  // copy-in / copy-out streams of the host pipeline
+    hipEvent_t ev_in[TSFA_MAX_CHUNKS] = {nullptr}, ev_k[TSFA_MAX_CHUNKS] = {nullptr};
+    std::vector<int64_t> h_rel;                 // offsets relative to the staged span
     bool needs_times = false;  // the plan holds linear_trend_timewise columns
     // side streams: the family kernels are independent (each writes its own columns), so they may overlap
     int n_streams = 1;
@@ -143,7 +148,15 @@ void tsfa_plan_destroy(tsfa_plan *plan) {
     if (plan->d_tws) (void)hipFree(plan->d_tws);
     if (plan->d_stats) (void)hipFree(plan->d_stats);
     if (plan->d_deg_count) (void)hipFree(plan->d_deg_count);
+    if (plan->d_cursor) (void)hipFree(plan->d_cursor);
     plan->deg_list.release();
+    plan->sel.release();
+    for (int i = 0; i < TSFA_MAX_CHUNKS; ++i) {
+        if (plan->ev_in[i]) (void)hipEventDestroy(plan->ev_in[i]);
+        if (plan->ev_k[i]) (void)hipEventDestroy(plan->ev_k[i]);
+    }
+    if (plan->s_in) (void)hipStreamDestroy(plan->s_in);
+    if (plan->s_out) (void)hipStreamDestroy(plan->s_out);
     plan->times.release();
     plan->values.release();
     plan->offsets.release();
@@ -220,8 +233,14 @@ int tsfa_plan_create(const tsfa_feature_spec *specs, int32_t n_specs, int32_t de
         tsfa_build_twiddles(twc, tws);
         ok = upload(dt, &plan->d_dectab) == 0 && upload(twc, &plan->d_twc) == 0 && upload(tws, &plan->d_tws) == 0;
     }
-    if (ok) ok = hipMalloc((void **)&plan->d_stats, 4 * sizeof(long long)) == hipSuccess;
+    if (ok) ok = hipMalloc((void **)&plan->d_stats, TSFA_LEN_STATS * sizeof(long long)) == hipSuccess;
     if (ok) ok = hipMalloc((void **)&plan->d_deg_count, sizeof(int)) == hipSuccess;
+    if (ok) ok = hipMalloc((void **)&plan->d_cursor, TSFA_N_LEN_CLASSES * sizeof(int)) == hipSuccess;
+    if (ok) ok = hipStreamCreateWithFlags(&plan->s_in, hipStreamNonBlocking) == hipSuccess &&
+                 hipStreamCreateWithFlags(&plan->s_out, hipStreamNonBlocking) == hipSuccess;
+    for (int i = 0; ok && i < TSFA_MAX_CHUNKS; ++i)
+        ok = hipEventCreateWithFlags(&plan->ev_in[i], hipEventDisableTiming) == hipSuccess &&
+             hipEventCreateWithFlags(&plan->ev_k[i], hipEventDisableTiming) == hipSuccess;
     {
         const char *e = getenv("TSFA_STREAMS");
         plan->n_streams = e ? std::min(std::max(atoi(e), 1), TSFA_MAX_AUX + 1) : TSFA_DEFAULT_STREAMS;
@@ -279,97 +298,96 @@ int tsfa_extract_timed(tsfa_plan *plan, const void *values, int32_t dtype, const
                                 ld_out, space, stream);
 }
 
-int tsfa_extract_windows(tsfa_plan *plan, const void *values, int32_t dtype, const double *times, const int64_t *starts,
-                         const int64_t *ends, int64_t n_series, double *out, int64_t ld_out, int32_t space,
-                         void *stream) {
-    if (!plan) return fail(TSFA_ERR_INVALID, "plan is NULL");
-    if (plan->needs_times && !times)
-        return fail(TSFA_ERR_INVALID, "the plan holds linear_trend_timewise columns: call tsfa_extract_timed with the "
-                                      "per-sample times (the reference skips the calculator without a DatetimeIndex)");
-    if (dtype != TSFA_F32 && dtype != TSFA_F64) return fail(TSFA_ERR_INVALID, "dtype must be TSFA_F32 or TSFA_F64");
-    if (space != TSFA_HOST && space != TSFA_DEVICE) return fail(TSFA_ERR_INVALID, "space must be TSFA_HOST or TSFA_DEVICE");
-    if (n_series < 0) return fail(TSFA_ERR_INVALID, "n_series < 0");
-    if (n_series == 0 || plan->n_cols == 0) return TSFA_OK;
-    if (!values || !starts || !ends || !out) return fail(TSFA_ERR_INVALID, "NULL buffer");
-    if (ld_out < plan->n_cols) return fail(TSFA_ERR_INVALID, "ld_out < n_cols");
-    if (n_series > 2147483647LL) return fail(TSFA_ERR_INVALID, "n_series exceeds the grid limit (2^31 - 1)");
-    HIP_TRY(hipSetDevice(plan->device));
-    hipStream_t st = (space == TSFA_DEVICE && stream) ? (hipStream_t)stream : plan->stream;
-    const size_t esz = (dtype == TSFA_F32) ? 4 : 8;
+// ---------------------------------------------------------------------------------------------------------------
+// One batch = fill + the family kernels of the plan over [n_series] views, enqueued on `st` (no host sync).
+// ---------------------------------------------------------------------------------------------------------------
+struct BatchShape {
+    long long max_len = 0, min_len = 0, max_np2 = 0;
+    int n_groups = 1;                        // launch groups; 1 = every series in one launch, no index lists
+    int g_maxn[TSFA_N_LEN_CLASSES] = {0};
+    long long g_np2[TSFA_N_LEN_CLASSES] = {0};
+    int64_t g_count[TSFA_N_LEN_CLASSES] = {0};
+    TsfaClassMap map;
+};
 
-    const void *d_values = values;
-    const double *d_times = plan->needs_times ? times : nullptr;
-    const int64_t *d_starts = starts, *d_ends = ends;
-    double *d_out = out;
-    int64_t ld = ld_out;
-    if (space == TSFA_HOST) {
-        // stage the span of `values` the windows touch; window bounds become relative to its first sample
-        const bool ragged = (ends == starts + 1);
-        int64_t base = starts[0], top = ends[0];
-        for (int64_t i = 0; i < n_series; ++i) {
-            if (ends[i] < starts[i]) return fail(TSFA_ERR_INVALID, "a series ends before it starts (offsets must be non-decreasing)");
-            base = std::min(base, starts[i]);
-            top = std::max(top, ends[i]);
+// stats: the TSFA_LEN_STATS numbers of k_len_stats (or their host-side twin).  Length classes with fewer than
+// `min_group` series ride with the next longer class; a batch whose lengths span less than a factor of two (or that is
+// small) is one group.
+static void shape_from_stats(const long long *st, int64_t n_series, BatchShape &sh) {
+    sh.max_len = st[0];
+    sh.min_len = st[1];
+    sh.max_np2 = st[2];
+    memset(&sh.map, 0, sizeof sh.map);
+    sh.n_groups = 1;
+    sh.g_maxn[0] = (int)st[0];
+    sh.g_np2[0] = st[2];
+    sh.g_count[0] = n_series;
+    const char *env = getenv("TSFA_NO_LENGTH_CLASSES");
+    if ((env && atoi(env)) || n_series < 2048 || st[0] <= 2 * st[1] || st[0] <= 128) return;
+    const int64_t min_group = 512;
+    int ng = 0;
+    int64_t pend_count = 0;
+    long long pend_np2 = 0;
+    int first_of_group = 0;
+    for (int c = 0; c < TSFA_N_LEN_CLASSES; ++c) {
+        const int64_t cnt = st[3 + c];
+        pend_count += cnt;
+        pend_np2 = std::max(pend_np2, st[3 + 2 * TSFA_N_LEN_CLASSES + c]);
+        bool last = true;
+        for (int d = c + 1; d < TSFA_N_LEN_CLASSES; ++d)
+            if (st[3 + d] > 0) last = false;
+        if (cnt > 0 && (pend_count >= min_group || last)) {
+            sh.g_maxn[ng] = (int)st[3 + TSFA_N_LEN_CLASSES + c];
+            sh.g_np2[ng] = pend_np2;
+            sh.g_count[ng] = pend_count;
+            for (int d = first_of_group; d <= c; ++d) sh.map.group_of[d] = ng;
+            first_of_group = c + 1;
+            pend_count = 0;
+            pend_np2 = 0;
+            ++ng;
         }
-        const int64_t total = top - base;
-        std::vector<int64_t> rel;
-        if (ragged) {
-            rel.resize((size_t)n_series + 1);
-            for (int64_t i = 0; i <= n_series; ++i) rel[(size_t)i] = starts[i] - base;
-        } else {
-            rel.resize(2 * (size_t)n_series);
-            for (int64_t i = 0; i < n_series; ++i) {
-                rel[(size_t)i] = starts[i] - base;
-                rel[(size_t)(n_series + i)] = ends[i] - base;
-            }
+        if (last) {
+            for (int d = first_of_group; d < TSFA_N_LEN_CLASSES; ++d) sh.map.group_of[d] = ng > 0 ? ng - 1 : 0;
+            break;
         }
-        if (plan->values.ensure((size_t)total * esz + 16) || plan->offsets.ensure(rel.size() * sizeof(int64_t)) ||
-            plan->out.ensure((size_t)n_series * plan->n_cols * sizeof(double)))
-            return fail(TSFA_ERR_HIP, "hipMalloc failed for the staging buffers");
-        HIP_TRY(hipMemcpyAsync(plan->values.p, (const char *)values + (size_t)base * esz, (size_t)total * esz,
-                               hipMemcpyHostToDevice, st));
-        HIP_TRY(hipMemcpyAsync(plan->offsets.p, rel.data(), rel.size() * sizeof(int64_t), hipMemcpyHostToDevice, st));
-        if (d_times) {
-            if (plan->times.ensure((size_t)total * sizeof(double) + 16)) return fail(TSFA_ERR_HIP, "hipMalloc failed for the times buffer");
-            HIP_TRY(hipMemcpyAsync(plan->times.p, times + base, (size_t)total * sizeof(double), hipMemcpyHostToDevice, st));
-            d_times = (const double *)plan->times.p;
-        }
-        HIP_TRY(hipStreamSynchronize(st));  // rel goes out of scope below
-        d_values = plan->values.p;
-        d_starts = (const int64_t *)plan->offsets.p;
-        d_ends = d_starts + (ragged ? 1 : n_series);
-        d_out = (double *)plan->out.p;
-        ld = plan->n_cols;
     }
-
-    // ---- batch length statistics (decides workgroup size and the LDS carve) ----
-    long long h_stats[3] = {0, (1LL << 62), 0};
-    if (plan->hint_max_len > 0) {
-        // the caller vouches for the length range of every batch (tsfa_plan_set_length_hint): no scan, no host sync --
-        // back-to-back calls on one stream (chunks of a shard) are enqueued without waiting for each other
-        h_stats[0] = plan->hint_max_len;
-        h_stats[1] = plan->hint_min_len;
-        h_stats[2] = (plan->hint_min_len == plan->hint_max_len && (plan->hint_max_len & (plan->hint_max_len - 1)) == 0)
-                         ? 0 : plan->hint_max_len;  // longest length that may not be a power of two
-    } else {
-        HIP_TRY(hipMemcpyAsync(plan->d_stats, h_stats, sizeof h_stats, hipMemcpyHostToDevice, st));
-        if (tsfa_launch_len_stats(d_starts, d_ends, n_series, plan->d_stats, st)) return fail(TSFA_ERR_HIP, "len_stats launch failed");
-        HIP_TRY(hipMemcpyAsync(h_stats, plan->d_stats, sizeof h_stats, hipMemcpyDeviceToHost, st));
-        HIP_TRY(hipStreamSynchronize(st));
+    sh.n_groups = std::max(ng, 1);
+    int b = 0;
+    for (int g = 0; g < sh.n_groups; ++g) {
+        sh.map.base[g] = b;
+        b += (int)sh.g_count[g];
     }
-    const long long max_len = h_stats[0], min_len = h_stats[1], max_np2 = h_stats[2];
-    if (min_len < 1) return fail(TSFA_ERR_INVALID, "every series must hold at least one sample");
-    if (max_len > 65535) return fail(TSFA_ERR_TOO_LONG, "series longer than 65535 samples are not supported");
-    const int maxn = (int)max_len;
-    const int nt = (maxn <= 2048) ? 64 : 256;
+}
 
+// host-side twin of k_len_stats
+static int host_len_stats(const int64_t *starts, const int64_t *ends, int64_t n, long long *st) {
+    for (int i = 0; i < TSFA_LEN_STATS; ++i) st[i] = 0;
+    st[1] = (1LL << 62);
+    for (int64_t s = 0; s < n; ++s) {
+        const long long l = ends[s] - starts[s];
+        if (l < 0) return -1;
+        const bool np2 = l > 0 && (l & (l - 1)) != 0;
+        const int c = tsfa_len_class(l);
+        st[0] = std::max(st[0], l);
+        st[1] = std::min(st[1], l);
+        if (np2) st[2] = std::max(st[2], l);
+        st[3 + c] += 1;
+        st[3 + TSFA_N_LEN_CLASSES + c] = std::max(st[3 + TSFA_N_LEN_CLASSES + c], l);
+        if (np2) st[3 + 2 * TSFA_N_LEN_CLASSES + c] = std::max(st[3 + 2 * TSFA_N_LEN_CLASSES + c], l);
+    }
+    return 0;
+}
+
+static int run_batch(tsfa_plan *plan, const void *d_values, int dtype, const double *d_times, const int64_t *d_starts,
+                     const int64_t *d_ends, int64_t n_series, double *d_out, int64_t ld, const BatchShape &sh,
+                     const int *d_sel, hipStream_t st, bool with_overlap) {
     if (tsfa_launch_fill_nan(d_out, n_series * ld, st)) return fail(TSFA_ERR_HIP, "fill launch failed");
 
     // Launch order: longest kernels first.  With side streams (and no per-kernel timing requested) the families are
     // dealt round-robin over the streams after a fork event; the join events bring them back to `st`.
     static const int order[TSFA_N_FAMILIES] = {TSFA_FAM_ENTROPY, TSFA_FAM_AR, TSFA_FAM_SORT, TSFA_FAM_CWT, TSFA_FAM_BASIC,
                                                TSFA_FAM_SEQ, TSFA_FAM_SPECTRAL, TSFA_FAM_TREND};
-    const bool overlap = plan->n_streams > 1 && !plan->profiling;
+    const bool overlap = with_overlap && plan->n_streams > 1 && !plan->profiling;
     if (overlap) {
         HIP_TRY(hipEventRecord(plan->ev_fork, st));
         for (int i = 0; i + 1 < plan->n_streams; ++i) HIP_TRY(hipStreamWaitEvent(plan->aux[i], plan->ev_fork, 0));
@@ -384,117 +402,120 @@ int tsfa_extract_windows(tsfa_plan *plan, const void *values, int32_t dtype, con
             const int k = dealt++ % plan->n_streams;
             if (k > 0) fst = plan->aux[k - 1];
         }
-        TsfaLaunch a;
-        memset(&a, 0, sizeof a);
-        a.fam = f;
-        a.dtype = dtype;
-        a.values = d_values;
-        a.starts = d_starts;
-        a.ends = d_ends;
-        a.n_series = n_series;
-        a.specs = plan->d_specs[f];
-        a.nspecs = (int)plan->fam_specs[f].size();
-        a.out = d_out;
-        a.ld = ld;
-        a.maxn = maxn;
-        a.nt = nt;
-        if (maxn <= 2048) {
-            // Wavefronts per series, measured on MI355X at n = 1024 (profiles/r01_*): the LDS footprint of a series
-            // caps the workgroups per CU, so the latency-bound families gain from more wavefronts per workgroup,
-            // while k_basic's many short reductions lose to the extra barriers.  At least 4 samples per thread.
-            static const int pref[TSFA_N_FAMILIES] = {64, 128, 128, 128, 256, 256, 128, 64};
-            const int cap = std::max(64, ((maxn / 4 + 63) / 64) * 64);
-            a.nt = std::min(pref[f], cap);
-        }
-        {   // experiment hook: TSFA_NT_<family index>=<threads>
-            char key[32];
-            snprintf(key, sizeof key, "TSFA_NT_%d", f);
-            const char *e = getenv(key);
-            if (e && atoi(e) >= 64) a.nt = atoi(e);
-        }
-        a.stream = fst;
-        a.dectab = plan->d_dectab;
-        a.times = d_times;
-        a.twc = plan->d_twc;
-        a.tws = plan->d_tws;
-        a.hint_a = plan->hints[f].a;
-        a.hint_b = plan->hints[f].b;
-        a.hint_c = plan->hints[f].c;
-        a.hint_d = plan->hints[f].d;
-        a.hint_e = plan->hints[f].e;
-        a.alt = plan->hints[f].alt;
-        a.cq = plan->hints[f].cq;
-        int aux = 0;
-        if (f == TSFA_FAM_SPECTRAL) {
-            // only non-power-of-two lengths <= 256 use the table-driven DFT (longer ones: Goertzel, no table)
-            a.dft_n = (int)std::min<long long>(max_np2, 256);
-            aux = a.dft_n;
-        } else if (f == TSFA_FAM_CWT) {
-            a.cwt_rowv = tsfa_family_lds_bytes(f, maxn, a.nt, 1) <= 96 * 1024 ? 1 : 0;
-            aux = a.cwt_rowv;
-        } else if (f == TSFA_FAM_AR) {
-            // leading dimension of the normal matrices: ADF needs maxlag(n) + 3, AR(k) needs k + 2
-            int P = 8;
-            for (const auto &s : plan->fam_specs[f]) {
-                if (s.calc == TSFA_C_AUGMENTED_DICKEY_FULLER) {
-                    int ml = (int)ceil(12.0 * pow((double)maxn / 100.0, 0.25));
-                    if (maxn / 2 - 2 < ml) ml = maxn / 2 - 2;
-                    P = std::max(P, ml + 3);
-                } else if (s.calc == TSFA_C_AR_COEFFICIENT) {
-                    P = std::max(P, (int)s.p[1] + 2);
-                }
-            }
-            a.ar_P = P;
-            aux = P;
-            for (const auto &s : plan->fam_specs[f])
-                if (s.calc == TSFA_C_AR_COEFFICIENT) a.ar_has_coef = 1;
-            if (plan->deg_list.ensure((size_t)n_series * sizeof(long long))) return fail(TSFA_ERR_HIP, "hipMalloc failed for the k_ar_degenerate list");
-            a.deg_list = (long long *)plan->deg_list.p;
-            a.deg_count = plan->d_deg_count;
-            HIP_TRY(hipMemsetAsync(plan->d_deg_count, 0, sizeof(int), fst));
-        } else if (f == TSFA_FAM_ENTROPY) {
-            // one wavefront per 64-template row block, up to four per series; the symmetric sweep needs 12 B of
-            // LDS counters per sample
-            const int waves = std::min(4, std::max(1, (maxn - 1 + 63) / 64));
-            a.nt = std::max(a.nt, 64 * waves);
-            a.ent_cnt = tsfa_entropy_lds_bytes(maxn, 1) <= TSFA_LDS_LIMIT ? 1 : 0;
-            a.ent_fast = a.ent_cnt;
-            for (const auto &s : plan->fam_specs[f])
-                if (s.calc == TSFA_C_APPROXIMATE_ENTROPY && (int)s.p[0] != 2) a.ent_fast = 0;
-            if (getenv("TSFA_ENT_SLOW")) a.ent_fast = 0;  // experiment / test hook: the general kernel
-        }
-        // SEQ: one launch parses up to TSFA_LZ_MAX_GROUP `bins` values side by side -- as many as LDS allows
-        int seq_group = 0;
-        if (f == TSFA_FAM_SEQ) {
-            for (seq_group = std::min(a.nspecs, TSFA_LZ_MAX_GROUP); seq_group > 1; --seq_group) {
-                bool fits = true;
-                for (int s0 = 0; fits && s0 < a.nspecs; s0 += seq_group) {
-                    lz_build_group(plan->fam_specs[f].data() + s0, std::min(seq_group, a.nspecs - s0), maxn, &a.seq);
-                    fits = tsfa_seq_lds_bytes(a.seq) <= TSFA_LDS_LIMIT;
-                }
-                if (fits) break;
-            }
-            lz_build_group(plan->fam_specs[f].data(), std::min(seq_group, a.nspecs), maxn, &a.seq);
-        }
-        const size_t lds = (f == TSFA_FAM_SEQ) ? tsfa_seq_lds_bytes(a.seq)
-                           : (f == TSFA_FAM_ENTROPY) ? tsfa_entropy_lds_bytes(maxn, a.ent_cnt)
-                                                     : tsfa_family_lds_bytes(f, maxn, a.nt, aux);
-        if (lds > TSFA_LDS_LIMIT)
-            return fail(TSFA_ERR_TOO_LONG, std::string(fam_names[f]) + ": a series of " + std::to_string(maxn) +
-                                               " samples needs " + std::to_string(lds) + " B of LDS (limit 163840)");
         if (record(plan, fst, slot, fam_names[f], true)) return fail(TSFA_ERR_HIP, "event record failed");
-        int rc = 0;
-        if (f == TSFA_FAM_SEQ) {
-            for (int s0 = 0; rc == 0 && s0 < a.nspecs; s0 += seq_group) {
-                lz_build_group(plan->fam_specs[f].data() + s0, std::min(seq_group, a.nspecs - s0), maxn, &a.seq);
-                if (tsfa_seq_lds_bytes(a.seq) > TSFA_LDS_LIMIT)
-                    return fail(TSFA_ERR_TOO_LONG, "k_seq: a series of " + std::to_string(maxn) + " samples does not fit LDS");
+        for (int g = sh.n_groups - 1; g >= 0; --g) {  // longest series first
+            const int maxn = sh.g_maxn[g];
+            const long long max_np2 = sh.g_np2[g];
+            TsfaLaunch a;
+            memset(&a, 0, sizeof a);
+            a.fam = f;
+            a.dtype = dtype;
+            a.values = d_values;
+            a.starts = d_starts;
+            a.ends = d_ends;
+            a.n_series = sh.g_count[g];
+            a.sel = (sh.n_groups > 1) ? d_sel + sh.map.base[g] : nullptr;
+            a.specs = plan->d_specs[f];
+            a.nspecs = (int)plan->fam_specs[f].size();
+            a.out = d_out;
+            a.ld = ld;
+            a.maxn = maxn;
+            a.nt = (maxn <= 2048) ? 64 : 256;
+            if (maxn <= 2048) {
+                // Wavefronts per series, measured on MI355X at n = 1024 (profiles/r01_*): the LDS footprint of a series
+                // caps the workgroups per CU, so the latency-bound families gain from more wavefronts per workgroup,
+                // while k_basic's many short reductions lose to the extra barriers.  At least 4 samples per thread.
+                static const int pref[TSFA_N_FAMILIES] = {64, 128, 128, 128, 256, 256, 128, 64};
+                const int cap = std::max(64, ((maxn / 4 + 63) / 64) * 64);
+                a.nt = std::min(pref[f], cap);
+            }
+            {   // experiment hook: TSFA_NT_<family index>=<threads>
+                char key[32];
+                snprintf(key, sizeof key, "TSFA_NT_%d", f);
+                const char *e = getenv(key);
+                if (e && atoi(e) >= 64) a.nt = atoi(e);
+            }
+            a.stream = fst;
+            a.dectab = plan->d_dectab;
+            a.times = d_times;
+            a.twc = plan->d_twc;
+            a.tws = plan->d_tws;
+            a.hint_a = plan->hints[f].a;
+            a.hint_b = plan->hints[f].b;
+            a.hint_c = plan->hints[f].c;
+            a.hint_d = plan->hints[f].d;
+            a.hint_e = plan->hints[f].e;
+            a.alt = plan->hints[f].alt;
+            a.cq = plan->hints[f].cq;
+            int aux = 0;
+            if (f == TSFA_FAM_SPECTRAL) {
+                // only non-power-of-two lengths <= 256 use the table-driven DFT (longer ones: Goertzel, no table)
+                a.dft_n = (int)std::min<long long>(max_np2, 256);
+                aux = a.dft_n;
+            } else if (f == TSFA_FAM_CWT) {
+                a.cwt_rowv = tsfa_family_lds_bytes(f, maxn, a.nt, 1) <= 96 * 1024 ? 1 : 0;
+                aux = a.cwt_rowv;
+            } else if (f == TSFA_FAM_AR) {
+                // leading dimension of the normal matrices: ADF needs maxlag(n) + 3, AR(k) needs k + 2
+                int P = 8;
+                for (const auto &s : plan->fam_specs[f]) {
+                    if (s.calc == TSFA_C_AUGMENTED_DICKEY_FULLER) {
+                        int ml = (int)ceil(12.0 * pow((double)maxn / 100.0, 0.25));
+                        if (maxn / 2 - 2 < ml) ml = maxn / 2 - 2;
+                        P = std::max(P, ml + 3);
+                    } else if (s.calc == TSFA_C_AR_COEFFICIENT) {
+                        P = std::max(P, (int)s.p[1] + 2);
+                        a.ar_has_coef = 1;
+                    }
+                }
+                a.ar_P = P;
+                aux = P;
+                a.deg_list = (long long *)plan->deg_list.p;
+                a.deg_count = plan->d_deg_count;
+                HIP_TRY(hipMemsetAsync(plan->d_deg_count, 0, sizeof(int), fst));
+            } else if (f == TSFA_FAM_ENTROPY) {
+                // one wavefront per 64-template row block, up to four per series; the symmetric sweep needs 12 B of
+                // LDS counters per sample
+                const int waves = std::min(4, std::max(1, (maxn - 1 + 63) / 64));
+                a.nt = std::max(a.nt, 64 * waves);
+                a.ent_cnt = tsfa_entropy_lds_bytes(maxn, 1) <= TSFA_LDS_LIMIT ? 1 : 0;
+                a.ent_fast = a.ent_cnt;
+                for (const auto &s : plan->fam_specs[f])
+                    if (s.calc == TSFA_C_APPROXIMATE_ENTROPY && (int)s.p[0] != 2) a.ent_fast = 0;
+                if (getenv("TSFA_ENT_SLOW")) a.ent_fast = 0;  // experiment / test hook: the general kernel
+            }
+            // SEQ: one launch parses up to TSFA_LZ_MAX_GROUP `bins` values side by side -- as many as LDS allows
+            int seq_group = 0;
+            if (f == TSFA_FAM_SEQ) {
+                for (seq_group = std::min(a.nspecs, TSFA_LZ_MAX_GROUP); seq_group > 1; --seq_group) {
+                    bool fits = true;
+                    for (int s0 = 0; fits && s0 < a.nspecs; s0 += seq_group) {
+                        lz_build_group(plan->fam_specs[f].data() + s0, std::min(seq_group, a.nspecs - s0), maxn, &a.seq);
+                        fits = tsfa_seq_lds_bytes(a.seq) <= TSFA_LDS_LIMIT;
+                    }
+                    if (fits) break;
+                }
+                lz_build_group(plan->fam_specs[f].data(), std::min(seq_group, a.nspecs), maxn, &a.seq);
+            }
+            const size_t lds = (f == TSFA_FAM_SEQ) ? tsfa_seq_lds_bytes(a.seq)
+                               : (f == TSFA_FAM_ENTROPY) ? tsfa_entropy_lds_bytes(maxn, a.ent_cnt)
+                                                         : tsfa_family_lds_bytes(f, maxn, a.nt, aux);
+            if (lds > TSFA_LDS_LIMIT)
+                return fail(TSFA_ERR_TOO_LONG, std::string(fam_names[f]) + ": a series of " + std::to_string(maxn) +
+                                                   " samples needs " + std::to_string(lds) + " B of LDS (limit 163840)");
+            int rc = 0;
+            if (f == TSFA_FAM_SEQ) {
+                for (int s0 = 0; rc == 0 && s0 < a.nspecs; s0 += seq_group) {
+                    lz_build_group(plan->fam_specs[f].data() + s0, std::min(seq_group, a.nspecs - s0), maxn, &a.seq);
+                    if (tsfa_seq_lds_bytes(a.seq) > TSFA_LDS_LIMIT)
+                        return fail(TSFA_ERR_TOO_LONG, "k_seq: a series of " + std::to_string(maxn) + " samples does not fit LDS");
+                    rc = tsfa_launch_family(a);
+                }
+            } else {
                 rc = tsfa_launch_family(a);
             }
-        } else {
-            rc = tsfa_launch_family(a);
+            if (rc) return fail(TSFA_ERR_HIP, std::string(fam_names[f]) + " launch failed: " + hipGetErrorString((hipError_t)rc));
         }
-        if (rc) return fail(TSFA_ERR_HIP, std::string(fam_names[f]) + " launch failed: " + hipGetErrorString((hipError_t)rc));
         if (record(plan, fst, slot, fam_names[f], false)) return fail(TSFA_ERR_HIP, "event record failed");
         ++slot;
     }
@@ -527,17 +548,213 @@ int tsfa_extract_windows(tsfa_plan *plan, const void *values, int32_t dtype, con
         ++slot;
     }
     if (plan->profiling) plan->timings.resize(slot);
+    return TSFA_OK;
+}
 
-    if (space == TSFA_HOST) {
-        HIP_TRY(hipMemcpy2DAsync(out, (size_t)ld_out * sizeof(double), d_out, (size_t)ld * sizeof(double),
-                                 (size_t)plan->n_cols * sizeof(double), (size_t)n_series, hipMemcpyDeviceToHost, st));
+static int check_shape(const BatchShape &sh) {
+    if (sh.min_len < 1) return fail(TSFA_ERR_INVALID, "every series must hold at least one sample");
+    if (sh.max_len > 65535) return fail(TSFA_ERR_TOO_LONG, "series longer than 65535 samples are not supported");
+    return TSFA_OK;
+}
+
+// index lists of the launch groups (device), from the device-resident views
+static int build_sel(tsfa_plan *plan, const int64_t *d_starts, const int64_t *d_ends, int64_t n_series, const BatchShape &sh,
+                     int *d_sel, hipStream_t st) {
+    if (sh.n_groups <= 1) return TSFA_OK;
+    HIP_TRY(hipMemsetAsync(plan->d_cursor, 0, TSFA_N_LEN_CLASSES * sizeof(int), st));
+    if (tsfa_launch_class_fill(d_starts, d_ends, n_series, sh.map, plan->d_cursor, d_sel, st))
+        return fail(TSFA_ERR_HIP, "class_fill launch failed");
+    return TSFA_OK;
+}
+
+int tsfa_extract_windows(tsfa_plan *plan, const void *values, int32_t dtype, const double *times, const int64_t *starts,
+                         const int64_t *ends, int64_t n_series, double *out, int64_t ld_out, int32_t space,
+                         void *stream) {
+    if (!plan) return fail(TSFA_ERR_INVALID, "plan is NULL");
+    if (plan->needs_times && !times)
+        return fail(TSFA_ERR_INVALID, "the plan holds linear_trend_timewise columns: call tsfa_extract_timed with the "
+                                      "per-sample times (the reference skips the calculator without a DatetimeIndex)");
+    if (dtype != TSFA_F32 && dtype != TSFA_F64) return fail(TSFA_ERR_INVALID, "dtype must be TSFA_F32 or TSFA_F64");
+    if (space != TSFA_HOST && space != TSFA_DEVICE) return fail(TSFA_ERR_INVALID, "space must be TSFA_HOST or TSFA_DEVICE");
+    if (n_series < 0) return fail(TSFA_ERR_INVALID, "n_series < 0");
+    if (n_series == 0 || plan->n_cols == 0) return TSFA_OK;
+    if (!values || !starts || !ends || !out) return fail(TSFA_ERR_INVALID, "NULL buffer");
+    if (ld_out < plan->n_cols) return fail(TSFA_ERR_INVALID, "ld_out < n_cols");
+    if (n_series > 2147483647LL) return fail(TSFA_ERR_INVALID, "n_series exceeds the grid limit (2^31 - 1)");
+    HIP_TRY(hipSetDevice(plan->device));
+    const size_t esz = (dtype == TSFA_F32) ? 4 : 8;
+    if (plan->deg_list.ensure((size_t)n_series * sizeof(long long)))
+        return fail(TSFA_ERR_HIP, "hipMalloc failed for the k_ar_degenerate list");
+
+    if (space == TSFA_DEVICE) {
+        hipStream_t st = stream ? (hipStream_t)stream : plan->stream;
+        // ---- batch length statistics (decide workgroup sizes, LDS carves and the length-class launch groups) ----
+        long long h_stats[TSFA_LEN_STATS];
+        for (int i = 0; i < TSFA_LEN_STATS; ++i) h_stats[i] = 0;
+        h_stats[1] = (1LL << 62);
+        BatchShape sh;
+        if (plan->hint_max_len > 0) {
+            // the caller vouches for the length range of every batch (tsfa_plan_set_length_hint): no scan, no host sync
+            // -- back-to-back calls on one stream (chunks of a shard) are enqueued without waiting for each other;
+            // one launch group, carved for the longest promised length
+            h_stats[0] = plan->hint_max_len;
+            h_stats[1] = plan->hint_min_len;
+            h_stats[2] = (plan->hint_min_len == plan->hint_max_len && (plan->hint_max_len & (plan->hint_max_len - 1)) == 0)
+                             ? 0 : plan->hint_max_len;  // longest length that may not be a power of two
+            sh.max_len = h_stats[0];
+            sh.min_len = h_stats[1];
+            sh.max_np2 = h_stats[2];
+            sh.g_maxn[0] = (int)h_stats[0];
+            sh.g_np2[0] = h_stats[2];
+            sh.g_count[0] = n_series;
+            memset(&sh.map, 0, sizeof sh.map);
+        } else {
+            HIP_TRY(hipMemcpyAsync(plan->d_stats, h_stats, sizeof h_stats, hipMemcpyHostToDevice, st));
+            if (tsfa_launch_len_stats(starts, ends, n_series, plan->d_stats, st)) return fail(TSFA_ERR_HIP, "len_stats launch failed");
+            HIP_TRY(hipMemcpyAsync(h_stats, plan->d_stats, sizeof h_stats, hipMemcpyDeviceToHost, st));
+            HIP_TRY(hipStreamSynchronize(st));
+            shape_from_stats(h_stats, n_series, sh);
+        }
+        int rc = check_shape(sh);
+        if (rc) return rc;
+        int *d_sel = nullptr;
+        if (sh.n_groups > 1) {
+            if (plan->sel.ensure((size_t)n_series * sizeof(int))) return fail(TSFA_ERR_HIP, "hipMalloc failed for the length-class lists");
+            d_sel = (int *)plan->sel.p;
+            if ((rc = build_sel(plan, starts, ends, n_series, sh, d_sel, st))) return rc;
+        }
+        if ((rc = run_batch(plan, values, dtype, plan->needs_times ? times : nullptr, starts, ends, n_series, out, ld_out, sh,
+                            d_sel, st, true)))
+            return rc;
+        const bool async = (stream != nullptr);
+        if (!async || plan->profiling) {
+            HIP_TRY(hipStreamSynchronize(st));
+            if (plan->profiling)
+                for (auto &t : plan->timings) (void)hipEventElapsedTime(&t.ms, t.e0, t.e1);
+        }
+        return TSFA_OK;
     }
-    const bool async = (space == TSFA_DEVICE && stream != nullptr);
-    if (!async || plan->profiling) {
-        HIP_TRY(hipStreamSynchronize(st));
-        if (plan->profiling)
-            for (auto &t : plan->timings) (void)hipEventElapsedTime(&t.ms, t.e0, t.e1);
+
+    // ---------------------------------------------------------------------------------------------------------
+    // TSFA_HOST: the batch is cut into row chunks that travel as a pipeline over three streams --
+    //   copy-in stream : values of chunk c + 1 (H2D)        (pinned host memory: true DMA; pageable: the runtime stages)
+    //   compute stream : kernels of chunk c
+    //   copy-out stream: rows of chunk c - 1 (D2H, strided into the caller's matrix)
+    // so PCIe traffic hides behind the kernels instead of bracketing them.
+    // ---------------------------------------------------------------------------------------------------------
+    hipStream_t st = plan->stream;
+    const bool ragged = (ends == starts + 1);
+    long long h_stats[TSFA_LEN_STATS];
+    if (host_len_stats(starts, ends, n_series, h_stats))
+        return fail(TSFA_ERR_INVALID, "a series ends before it starts (offsets must be non-decreasing)");
+    {
+        BatchShape whole;
+        shape_from_stats(h_stats, n_series, whole);
+        const int rc = check_shape(whole);
+        if (rc) return rc;
     }
+    int64_t base = starts[0], top = ends[0];
+    if (ragged) {
+        base = starts[0];
+        top = starts[n_series];
+    } else {
+        for (int64_t i = 0; i < n_series; ++i) {
+            base = std::min(base, starts[i]);
+            top = std::max(top, ends[i]);
+        }
+    }
+    const int64_t total = top - base;
+    std::vector<int64_t> &rel = plan->h_rel;
+    if (ragged) {
+        rel.resize((size_t)n_series + 1);
+        for (int64_t i = 0; i <= n_series; ++i) rel[(size_t)i] = starts[i] - base;
+    } else {
+        rel.resize(2 * (size_t)n_series);
+        for (int64_t i = 0; i < n_series; ++i) {
+            rel[(size_t)i] = starts[i] - base;
+            rel[(size_t)(n_series + i)] = ends[i] - base;
+        }
+    }
+    if (plan->values.ensure((size_t)total * esz + 16) || plan->offsets.ensure(rel.size() * sizeof(int64_t)) ||
+        plan->out.ensure((size_t)n_series * plan->n_cols * sizeof(double)) ||
+        plan->sel.ensure((size_t)n_series * sizeof(int)))
+        return fail(TSFA_ERR_HIP, "hipMalloc failed for the staging buffers");
+    const double *d_times = nullptr;
+    if (plan->needs_times) {
+        if (plan->times.ensure((size_t)total * sizeof(double) + 16)) return fail(TSFA_ERR_HIP, "hipMalloc failed for the times buffer");
+        d_times = (const double *)plan->times.p;
+    }
+    const int64_t *d_starts = (const int64_t *)plan->offsets.p;
+    const int64_t *d_ends = d_starts + (ragged ? 1 : n_series);
+    double *d_out = (double *)plan->out.p;
+    const int64_t ld = plan->n_cols;
+
+    // chunks: >= 4096 series each (a launch should fill the 256 CUs several times over), at most TSFA_MAX_CHUNKS
+    int n_chunks = (int)std::min<int64_t>(TSFA_MAX_CHUNKS, std::max<int64_t>(1, n_series / 4096));
+    {
+        const char *e = getenv("TSFA_HOST_CHUNKS");
+        if (e && atoi(e) >= 1) n_chunks = std::min(atoi(e), TSFA_MAX_CHUNKS);
+    }
+    if (plan->profiling) n_chunks = 1;
+    n_chunks = (int)std::min<int64_t>(n_chunks, n_series);
+
+    HIP_TRY(hipMemcpyAsync(plan->offsets.p, rel.data(), rel.size() * sizeof(int64_t), hipMemcpyHostToDevice, plan->s_in));
+    if (!ragged || n_chunks == 1) {
+        // window views may interleave: the touched span goes up in one piece
+        HIP_TRY(hipMemcpyAsync(plan->values.p, (const char *)values + (size_t)base * esz, (size_t)total * esz,
+                               hipMemcpyHostToDevice, plan->s_in));
+        if (d_times)
+            HIP_TRY(hipMemcpyAsync(plan->times.p, times + base, (size_t)total * sizeof(double), hipMemcpyHostToDevice, plan->s_in));
+    }
+    int rc = TSFA_OK;
+    for (int c = 0; c < n_chunks && rc == TSFA_OK; ++c) {
+        const int64_t c0 = n_series * c / n_chunks, c1 = n_series * (c + 1) / n_chunks;
+        if (ragged && n_chunks > 1) {
+            const int64_t v0 = rel[(size_t)c0], v1 = rel[(size_t)c1];
+            HIP_TRY(hipMemcpyAsync((char *)plan->values.p + (size_t)v0 * esz, (const char *)values + (size_t)(base + v0) * esz,
+                                   (size_t)(v1 - v0) * esz, hipMemcpyHostToDevice, plan->s_in));
+            if (d_times)
+                HIP_TRY(hipMemcpyAsync((char *)plan->times.p + (size_t)v0 * 8, times + base + v0, (size_t)(v1 - v0) * 8,
+                                       hipMemcpyHostToDevice, plan->s_in));
+        }
+        HIP_TRY(hipEventRecord(plan->ev_in[c], plan->s_in));
+        HIP_TRY(hipStreamWaitEvent(st, plan->ev_in[c], 0));
+        // length classes of this chunk, from the host-side offsets (no device scan, no sync)
+        long long cs[TSFA_LEN_STATS];
+        host_len_stats(starts + c0, ends + c0, c1 - c0, cs);
+        BatchShape sh;
+        shape_from_stats(cs, c1 - c0, sh);
+        int *d_sel = (int *)plan->sel.p + c0;
+        if ((rc = build_sel(plan, d_starts + c0, d_ends + c0, c1 - c0, sh, d_sel, st))) break;
+        if ((rc = run_batch(plan, plan->values.p, dtype, d_times, d_starts + c0, d_ends + c0, c1 - c0, d_out + c0 * ld, ld,
+                            sh, d_sel, st, n_chunks == 1)))
+            break;
+        HIP_TRY(hipEventRecord(plan->ev_k[c], st));
+        HIP_TRY(hipStreamWaitEvent(plan->s_out, plan->ev_k[c], 0));
+        HIP_TRY(hipMemcpy2DAsync(out + c0 * ld_out, (size_t)ld_out * sizeof(double), d_out + c0 * ld, (size_t)ld * sizeof(double),
+                                 (size_t)plan->n_cols * sizeof(double), (size_t)(c1 - c0), hipMemcpyDeviceToHost, plan->s_out));
+    }
+    // drain all three streams even on an error: the caller's buffers must not be in flight when we return
+    const hipError_t e1 = hipStreamSynchronize(plan->s_in), e2 = hipStreamSynchronize(st), e3 = hipStreamSynchronize(plan->s_out);
+    if (rc) return rc;
+    if (e1 != hipSuccess || e2 != hipSuccess || e3 != hipSuccess)
+        return fail(TSFA_ERR_HIP, std::string("stream synchronize: ") + hipGetErrorString(e1 != hipSuccess ? e1 : (e2 != hipSuccess ? e2 : e3)));
+    if (plan->profiling)
+        for (auto &t : plan->timings) (void)hipEventElapsedTime(&t.ms, t.e0, t.e1);
+    return TSFA_OK;
+}
+
+int tsfa_host_alloc(void **ptr, size_t bytes) {
+    if (!ptr) return fail(TSFA_ERR_INVALID, "ptr is NULL");
+    *ptr = nullptr;
+    if (tsfa_device_count() <= 0) return fail(TSFA_ERR_NO_DEVICE, "no HIP device visible");
+    HIP_TRY(hipHostMalloc(ptr, bytes ? bytes : 1, hipHostMallocDefault));
+    return TSFA_OK;
+}
+
+int tsfa_host_free(void *ptr) {
+    if (!ptr) return TSFA_OK;
+    HIP_TRY(hipHostFree(ptr));
     return TSFA_OK;
 }
 

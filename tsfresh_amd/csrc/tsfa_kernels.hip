@@ -26,12 +26,12 @@ __device__ __forceinline__ void stage_series(const Blk &b, const T *__restrict__
 // PART 1: the BASIC family; PART 2 (k_trend below): the TREND family -- same series staging, separate register
 // and LDS budgets (fam_basic.h)
 template <typename T, int PART>
-__device__ __forceinline__ void basic_body(const T *__restrict__ values, const int64_t *__restrict__ starts, const int64_t *__restrict__ ends, int64_t n_series,
+__device__ __forceinline__ void basic_body(const T *__restrict__ values, const int64_t *__restrict__ starts, const int64_t *__restrict__ ends, int64_t n_series, const int *__restrict__ sel,
                         const TsfaSpec *__restrict__ specs, int nspecs, double *__restrict__ out, int64_t ld,
                         const double *__restrict__ dectab, int maxn, int hint_a, int hint_b,
                         const double *__restrict__ times, const TsfaAltPlan &alt, int n_loop, int n_count, int n_sum) {
-    const int64_t sidx = blockIdx.x;
-    if (sidx >= n_series) return;
+    if ((int64_t)blockIdx.x >= n_series) return;
+    const int64_t sidx = sel ? (int64_t)sel[blockIdx.x] : (int64_t)blockIdx.x;  // length-class launch: its series list
     const int64_t off = starts[sidx];
     const int n = (int)(ends[sidx] - off);
     BasicLds L;
@@ -50,28 +50,28 @@ __device__ __forceinline__ void basic_body(const T *__restrict__ values, const i
 }
 
 template <typename T>
-__global__ void __launch_bounds__(256, 4) k_basic(const T *__restrict__ values, const int64_t *__restrict__ starts, const int64_t *__restrict__ ends, int64_t n_series,
+__global__ void __launch_bounds__(256, 4) k_basic(const T *__restrict__ values, const int64_t *__restrict__ starts, const int64_t *__restrict__ ends, int64_t n_series, const int *__restrict__ sel,
                         const TsfaSpec *__restrict__ specs, int nspecs, double *__restrict__ out, int64_t ld,
                         const double *__restrict__ dectab, int maxn, int hint_a, int n_loop, int n_count, int n_sum) {
     TsfaAltPlan alt;
     alt.nkeys = 0; alt.want_p = 0; alt.nq = 0;
-    basic_body<T, 1>(values, starts, ends, n_series, specs, nspecs, out, ld, dectab, maxn, hint_a, 0, nullptr, alt, n_loop,
+    basic_body<T, 1>(values, starts, ends, n_series, sel, specs, nspecs, out, ld, dectab, maxn, hint_a, 0, nullptr, alt, n_loop,
                      n_count, n_sum);
 }
 
 template <typename T>
-__global__ void __launch_bounds__(256, 2) k_trend(const T *__restrict__ values, const int64_t *__restrict__ starts, const int64_t *__restrict__ ends, int64_t n_series,
+__global__ void __launch_bounds__(256, 2) k_trend(const T *__restrict__ values, const int64_t *__restrict__ starts, const int64_t *__restrict__ ends, int64_t n_series, const int *__restrict__ sel,
                         const TsfaSpec *__restrict__ specs, int nspecs, double *__restrict__ out, int64_t ld, int maxn,
                         int hint_b, const double *__restrict__ times, const TsfaAltPlan alt, int n_loop) {
-    basic_body<T, 2>(values, starts, ends, n_series, specs, nspecs, out, ld, nullptr, maxn, 0, hint_b, times, alt, n_loop, 0, 0);
+    basic_body<T, 2>(values, starts, ends, n_series, sel, specs, nspecs, out, ld, nullptr, maxn, 0, hint_b, times, alt, n_loop, 0, 0);
 }
 
 template <typename T>
-__global__ void __launch_bounds__(256, 4) k_sort(const T *__restrict__ values, const int64_t *__restrict__ starts, const int64_t *__restrict__ ends, int64_t n_series,
+__global__ void __launch_bounds__(256, 4) k_sort(const T *__restrict__ values, const int64_t *__restrict__ starts, const int64_t *__restrict__ ends, int64_t n_series, const int *__restrict__ sel,
                        const TsfaSpec *__restrict__ specs, int nspecs, double *__restrict__ out, int64_t ld, int maxn,
                        const TsfaCqPlan cqplan, int n_loop, int w_doubles) {
-    const int64_t sidx = blockIdx.x;
-    if (sidx >= n_series) return;
+    if ((int64_t)blockIdx.x >= n_series) return;
+    const int64_t sidx = sel ? (int64_t)sel[blockIdx.x] : (int64_t)blockIdx.x;  // length-class launch: its series list
     const int64_t off = starts[sidx];
     const int n = (int)(ends[sidx] - off);
     SortLds L;
@@ -90,12 +90,12 @@ __global__ void __launch_bounds__(256, 4) k_sort(const T *__restrict__ values, c
 }
 
 template <typename T>
-__global__ void __launch_bounds__(256) k_spectral(const T *__restrict__ values, const int64_t *__restrict__ starts, const int64_t *__restrict__ ends, int64_t n_series,
+__global__ void __launch_bounds__(256) k_spectral(const T *__restrict__ values, const int64_t *__restrict__ starts, const int64_t *__restrict__ ends, int64_t n_series, const int *__restrict__ sel,
                            const TsfaSpec *__restrict__ specs, int nspecs, double *__restrict__ out, int64_t ld,
                            int maxn, int dft_n, double *__restrict__ gscratch, int gscratch_n,
                            const double *__restrict__ twc, const double *__restrict__ tws, int hint_a, int hint_b) {
-    const int64_t sidx = blockIdx.x;
-    if (sidx >= n_series) return;
+    if ((int64_t)blockIdx.x >= n_series) return;
+    const int64_t sidx = sel ? (int64_t)sel[blockIdx.x] : (int64_t)blockIdx.x;  // length-class launch: its series list
     const int64_t off = starts[sidx];
     const int n = (int)(ends[sidx] - off);
     SpectralLds L;
@@ -119,12 +119,12 @@ __global__ void __launch_bounds__(256) k_spectral(const T *__restrict__ values, 
 }
 
 template <typename T>
-__global__ void __launch_bounds__(256) k_ar(const T *__restrict__ values, const int64_t *__restrict__ starts, const int64_t *__restrict__ ends, int64_t n_series,
+__global__ void __launch_bounds__(256) k_ar(const T *__restrict__ values, const int64_t *__restrict__ starts, const int64_t *__restrict__ ends, int64_t n_series, const int *__restrict__ sel,
                      const TsfaSpec *__restrict__ specs, int nspecs, double *__restrict__ out, int64_t ld, int maxn,
                      int P, int hint_acf, int hint_pacf, int hint_adf, int n_loop, long long *__restrict__ deg_list,
                      int *__restrict__ deg_count) {
-    const int64_t sidx = blockIdx.x;
-    if (sidx >= n_series) return;
+    if ((int64_t)blockIdx.x >= n_series) return;
+    const int64_t sidx = sel ? (int64_t)sel[blockIdx.x] : (int64_t)blockIdx.x;  // length-class launch: its series list
     const int64_t off = starts[sidx];
     const int n = (int)(ends[sidx] - off);
     ArLds L;
@@ -163,11 +163,11 @@ __global__ void __launch_bounds__(64) k_ar_degenerate(const T *__restrict__ valu
 
 // FAST: symmetric sweep only (m = 2 specs, LDS counters fit) -- see fam_entropy_series
 template <typename T, bool FAST>
-__global__ void __launch_bounds__(256, 4) k_entropy(const T *__restrict__ values, const int64_t *__restrict__ starts, const int64_t *__restrict__ ends, int64_t n_series,
+__global__ void __launch_bounds__(256, 4) k_entropy(const T *__restrict__ values, const int64_t *__restrict__ starts, const int64_t *__restrict__ ends, int64_t n_series, const int *__restrict__ sel,
                           const TsfaSpec *__restrict__ specs, int nspecs, double *__restrict__ out, int64_t ld,
                           int maxn, int with_cnt) {
-    const int64_t sidx = blockIdx.x;
-    if (sidx >= n_series) return;
+    if ((int64_t)blockIdx.x >= n_series) return;
+    const int64_t sidx = sel ? (int64_t)sel[blockIdx.x] : (int64_t)blockIdx.x;  // length-class launch: its series list
     const int64_t off = starts[sidx];
     const int n = (int)(ends[sidx] - off);
     EntropyLds L;
@@ -180,10 +180,10 @@ __global__ void __launch_bounds__(256, 4) k_entropy(const T *__restrict__ values
 }
 
 template <typename T>
-__global__ void __launch_bounds__(256) k_seq(const T *__restrict__ values, const int64_t *__restrict__ starts, const int64_t *__restrict__ ends, int64_t n_series,
+__global__ void __launch_bounds__(256) k_seq(const T *__restrict__ values, const int64_t *__restrict__ starts, const int64_t *__restrict__ ends, int64_t n_series, const int *__restrict__ sel,
                       double *__restrict__ out, int64_t ld, const TsfaSeqGroup g) {
-    const int64_t sidx = blockIdx.x;
-    if (sidx >= n_series) return;
+    if ((int64_t)blockIdx.x >= n_series) return;
+    const int64_t sidx = sel ? (int64_t)sel[blockIdx.x] : (int64_t)blockIdx.x;  // length-class launch: its series list
     const int64_t off = starts[sidx];
     const int n = (int)(ends[sidx] - off);
     SeqLds L;
@@ -196,11 +196,11 @@ __global__ void __launch_bounds__(256) k_seq(const T *__restrict__ values, const
 }
 
 template <typename T>
-__global__ void __launch_bounds__(256) k_cwtpeaks(const T *__restrict__ values, const int64_t *__restrict__ starts, const int64_t *__restrict__ ends, int64_t n_series,
+__global__ void __launch_bounds__(256) k_cwtpeaks(const T *__restrict__ values, const int64_t *__restrict__ starts, const int64_t *__restrict__ ends, int64_t n_series, const int *__restrict__ sel,
                            const TsfaSpec *__restrict__ specs, int nspecs, double *__restrict__ out, int64_t ld,
                            int maxn, int with_rowv) {
-    const int64_t sidx = blockIdx.x;
-    if (sidx >= n_series) return;
+    if ((int64_t)blockIdx.x >= n_series) return;
+    const int64_t sidx = sel ? (int64_t)sel[blockIdx.x] : (int64_t)blockIdx.x;  // length-class launch: its series list
     const int64_t off = starts[sidx];
     const int n = (int)(ends[sidx] - off);
     CwtPeaksLayout L;
@@ -273,37 +273,45 @@ __global__ void k_fill_nan(double *__restrict__ out, int64_t n) {
     for (int64_t k = i; k < n; k += stride) out[k] = TSFA_NAN;
 }
 
-// per-batch length statistics: [0] = max length, [1] = min length, [2] = max non-power-of-two length
+// per-batch length statistics: [0] = max length, [1] = min length, [2] = max non-power-of-two length, then per
+// length class c (tsfa_len_class: lengths in (2^(c+5), 2^(c+6)], the first class from 1):
+//   [3 + c] = number of series, [3 + NC + c] = longest, [3 + 2 NC + c] = longest non-power-of-two
+__device__ __forceinline__ int tsfa_len_class_dev(long long l) {
+    int c = 0;
+    while (c < TSFA_N_LEN_CLASSES - 1 && l > (64LL << c)) ++c;
+    return c;
+}
 __global__ void __launch_bounds__(256) k_len_stats(const int64_t *__restrict__ starts, const int64_t *__restrict__ ends, int64_t n_series, long long *__restrict__ stats) {
-    long long mx = 0, mn = (1LL << 62), mnp = 0;
+    __shared__ long long acc[TSFA_LEN_STATS];
+    for (int i = threadIdx.x; i < TSFA_LEN_STATS; i += blockDim.x) acc[i] = (i == 1) ? (1LL << 62) : 0;
+    __syncthreads();
     for (int64_t s = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; s < n_series;
          s += (int64_t)gridDim.x * blockDim.x) {
         const long long l = ends[s] - starts[s];
-        mx = l > mx ? l : mx;
-        mn = l < mn ? l : mn;
-        if (l > 0 && (l & (l - 1)) != 0) mnp = l > mnp ? l : mnp;
+        const bool np2 = l > 0 && (l & (l - 1)) != 0;
+        const int c = tsfa_len_class_dev(l);
+        atomicMax(&acc[0], l);
+        atomicMin(&acc[1], l);
+        if (np2) atomicMax(&acc[2], l);
+        atomicAdd((unsigned long long *)&acc[3 + c], 1ULL);
+        atomicMax(&acc[3 + TSFA_N_LEN_CLASSES + c], l);
+        if (np2) atomicMax(&acc[3 + 2 * TSFA_N_LEN_CLASSES + c], l);
     }
-    // one atomic per workgroup (256 contended 64-bit atomics per counter, not 65536)
-    __shared__ long long red[3][4];
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) {
-        const long long a = __shfl_xor(mx, o), c = __shfl_xor(mn, o), d = __shfl_xor(mnp, o);
-        mx = a > mx ? a : mx;
-        mn = c < mn ? c : mn;
-        mnp = d > mnp ? d : mnp;
-    }
-    const int wave = threadIdx.x >> 6;
-    if ((threadIdx.x & 63) == 0) { red[0][wave] = mx; red[1][wave] = mn; red[2][wave] = mnp; }
     __syncthreads();
-    if (threadIdx.x == 0) {
-        for (int w = 1; w < (int)(blockDim.x >> 6); ++w) {
-            mx = red[0][w] > mx ? red[0][w] : mx;
-            mn = red[1][w] < mn ? red[1][w] : mn;
-            mnp = red[2][w] > mnp ? red[2][w] : mnp;
-        }
-        atomicMax(&stats[0], mx);
-        atomicMin(&stats[1], mn);
-        atomicMax(&stats[2], mnp);
+    for (int i = threadIdx.x; i < TSFA_LEN_STATS; i += blockDim.x) {
+        if (i == 1) atomicMin(&stats[1], acc[1]);
+        else if (i >= 3 && i < 3 + TSFA_N_LEN_CLASSES) atomicAdd((unsigned long long *)&stats[i], (unsigned long long)acc[i]);
+        else atomicMax(&stats[i], acc[i]);
+    }
+}
+
+// series index lists of the launch groups: sel[g.base[group] ...] receives the series whose length class maps to it
+__global__ void __launch_bounds__(256) k_class_fill(const int64_t *__restrict__ starts, const int64_t *__restrict__ ends, int64_t n_series,
+                                                    const TsfaClassMap g, int *__restrict__ cursor, int *__restrict__ sel) {
+    for (int64_t s = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; s < n_series;
+         s += (int64_t)gridDim.x * blockDim.x) {
+        const int grp = g.group_of[tsfa_len_class_dev(ends[s] - starts[s])];
+        sel[g.base[grp] + atomicAdd(&cursor[grp], 1)] = (int)s;
     }
 }
 
@@ -336,32 +344,32 @@ static int launch_all_t(const TsfaLaunch &a, const T *values) {
         BasicLds L;
         const size_t lds = L.carve(nullptr, a.maxn, nt, (int)sizeof(T), 1);
         if ((rc = set_lds(k_basic<T>, lds))) return rc;
-        k_basic<T><<<grid, nt, lds, st>>>(values, a.starts, a.ends, a.n_series, a.specs, a.nspecs, a.out, a.ld, a.dectab, a.maxn,
+        k_basic<T><<<grid, nt, lds, st>>>(values, a.starts, a.ends, a.n_series, a.sel, a.specs, a.nspecs, a.out, a.ld, a.dectab, a.maxn,
                                           a.hint_a, a.hint_c, a.hint_d, a.hint_e);
     } else if (a.fam == TSFA_FAM_TREND) {
         BasicLds L;
         const size_t lds = L.carve(nullptr, a.maxn, nt, (int)sizeof(T), 2);
         if ((rc = set_lds(k_trend<T>, lds))) return rc;
-        k_trend<T><<<grid, nt, lds, st>>>(values, a.starts, a.ends, a.n_series, a.specs, a.nspecs, a.out, a.ld, a.maxn, a.hint_b,
+        k_trend<T><<<grid, nt, lds, st>>>(values, a.starts, a.ends, a.n_series, a.sel, a.specs, a.nspecs, a.out, a.ld, a.maxn, a.hint_b,
                                           a.times, a.alt, a.hint_c);
     } else if (a.fam == TSFA_FAM_SORT) {
         SortLds L;
         const int wd = (a.hint_a >= 320) ? a.hint_a : 1280;
         const size_t lds = L.carve(nullptr, a.maxn, nt, (int)sizeof(T), wd);
         if ((rc = set_lds(k_sort<T>, lds))) return rc;
-        k_sort<T><<<grid, nt, lds, st>>>(values, a.starts, a.ends, a.n_series, a.specs, a.nspecs, a.out, a.ld, a.maxn, a.cq,
+        k_sort<T><<<grid, nt, lds, st>>>(values, a.starts, a.ends, a.n_series, a.sel, a.specs, a.nspecs, a.out, a.ld, a.maxn, a.cq,
                                          a.hint_c, wd);
     } else if (a.fam == TSFA_FAM_SPECTRAL) {
         SpectralLds L;
         const size_t lds = L.carve(nullptr, a.maxn, a.dft_n, (int)sizeof(T));
         if ((rc = set_lds(k_spectral<T>, lds))) return rc;
-        k_spectral<T><<<grid, nt, lds, st>>>(values, a.starts, a.ends, a.n_series, a.specs, a.nspecs, a.out, a.ld, a.maxn,
+        k_spectral<T><<<grid, nt, lds, st>>>(values, a.starts, a.ends, a.n_series, a.sel, a.specs, a.nspecs, a.out, a.ld, a.maxn,
                                              a.dft_n, a.gscratch, a.gscratch_n, a.twc, a.tws, a.hint_a, a.hint_b);
     } else if (a.fam == TSFA_FAM_AR) {
         ArLds L;
         const size_t lds = L.carve(nullptr, a.maxn, a.ar_P, (int)sizeof(T));
         if ((rc = set_lds(k_ar<T>, lds))) return rc;
-        k_ar<T><<<grid, nt, lds, st>>>(values, a.starts, a.ends, a.n_series, a.specs, a.nspecs, a.out, a.ld, a.maxn, a.ar_P,
+        k_ar<T><<<grid, nt, lds, st>>>(values, a.starts, a.ends, a.n_series, a.sel, a.specs, a.nspecs, a.out, a.ld, a.maxn, a.ar_P,
                                        a.hint_a, a.hint_b, a.hint_c, a.hint_d, a.deg_list, a.deg_count);
         TSFA_LAUNCH_CHECK();
         if (a.hint_c || a.ar_has_coef) {  // ADF / ar_coefficient columns: the regressions that can degenerate
@@ -377,23 +385,23 @@ static int launch_all_t(const TsfaLaunch &a, const T *values) {
         const size_t lds = L.carve(nullptr, a.maxn, a.ent_cnt);
 if (a.ent_fast) {
             if ((rc = set_lds(k_entropy<T, true>, lds))) return rc;
-            k_entropy<T, true><<<grid, nt, lds, st>>>(values, a.starts, a.ends, a.n_series, a.specs, a.nspecs, a.out, a.ld, a.maxn,
+            k_entropy<T, true><<<grid, nt, lds, st>>>(values, a.starts, a.ends, a.n_series, a.sel, a.specs, a.nspecs, a.out, a.ld, a.maxn,
                                                       a.ent_cnt);
         } else {
             if ((rc = set_lds(k_entropy<T, false>, lds))) return rc;
-            k_entropy<T, false><<<grid, nt, lds, st>>>(values, a.starts, a.ends, a.n_series, a.specs, a.nspecs, a.out, a.ld, a.maxn,
+            k_entropy<T, false><<<grid, nt, lds, st>>>(values, a.starts, a.ends, a.n_series, a.sel, a.specs, a.nspecs, a.out, a.ld, a.maxn,
                                                        a.ent_cnt);
         }
     } else if (a.fam == TSFA_FAM_SEQ) {
         SeqLds L;
         const size_t lds = L.carve(nullptr, 1, a.seq.stride, a.seq.ttotal, a.seq.etotal);
         if ((rc = set_lds(k_seq<T>, lds))) return rc;
-        k_seq<T><<<grid, nt, lds, st>>>(values, a.starts, a.ends, a.n_series, a.out, a.ld, a.seq);
+        k_seq<T><<<grid, nt, lds, st>>>(values, a.starts, a.ends, a.n_series, a.sel, a.out, a.ld, a.seq);
     } else if (a.fam == TSFA_FAM_CWT) {  // number_cwt_peaks
         CwtPeaksLayout L;
         const size_t lds = L.carve(nullptr, a.maxn, a.cwt_rowv, (int)sizeof(T));
         if ((rc = set_lds(k_cwtpeaks<T>, lds))) return rc;
-        k_cwtpeaks<T><<<grid, nt, lds, st>>>(values, a.starts, a.ends, a.n_series, a.specs, a.nspecs, a.out, a.ld, a.maxn,
+        k_cwtpeaks<T><<<grid, nt, lds, st>>>(values, a.starts, a.ends, a.n_series, a.sel, a.specs, a.nspecs, a.out, a.ld, a.maxn,
                                              a.cwt_rowv);
     } else {
         return -1;
@@ -468,6 +476,13 @@ int tsfa_launch_fill_nan(double *out, int64_t n, void *stream) {
 
 int tsfa_launch_len_stats(const int64_t *starts, const int64_t *ends, int64_t n_series, long long *stats, void *stream) {
     k_len_stats<<<256, 256, 0, (hipStream_t)stream>>>(starts, ends, n_series, stats);
+    TSFA_LAUNCH_CHECK();
+    return 0;
+}
+
+int tsfa_launch_class_fill(const int64_t *starts, const int64_t *ends, int64_t n_series, const TsfaClassMap &g, int *cursor,
+                           int *sel, void *stream) {
+    k_class_fill<<<256, 256, 0, (hipStream_t)stream>>>(starts, ends, n_series, g, cursor, sel);
     TSFA_LAUNCH_CHECK();
     return 0;
 }

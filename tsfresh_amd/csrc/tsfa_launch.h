@@ -8,13 +8,29 @@
 #include "tsfa_specs.h"
 #include "fam_seq.h"
 
+// Length classes of a batch: class c holds the lengths in (2^(c+5), 2^(c+6)] (class 0 from 1, the last one up to
+// 65535).  A ragged batch is launched class by class (merged into at most TSFA_N_LEN_CLASSES groups), each with the
+// LDS carve and workgroup size of ITS longest series, through an index list per group.
+#define TSFA_N_LEN_CLASSES 11
+#define TSFA_LEN_STATS (3 + 3 * TSFA_N_LEN_CLASSES)
+static inline int tsfa_len_class(long long l) {
+    int c = 0;
+    while (c < TSFA_N_LEN_CLASSES - 1 && l > (64LL << c)) ++c;
+    return c;
+}
+struct TsfaClassMap {
+    int group_of[TSFA_N_LEN_CLASSES];  // length class -> launch group
+    int base[TSFA_N_LEN_CLASSES];      // first entry of the group's list in `sel`
+};
+
 struct TsfaLaunch {
     int fam;
     int dtype;  // 0 = f32, 1 = f64
     const void *values;
     const int64_t *starts;  // series s occupies values[starts[s] .. ends[s]); for a ragged batch ends = starts + 1
     const int64_t *ends;
-    int64_t n_series;
+    int64_t n_series;       // workgroups of this launch
+    const int *sel;         // device: the series of this launch (indices into starts/ends/out rows), or null = 0..n-1
     const TsfaSpec *specs;  // device
     int nspecs;
     double *out;
@@ -63,5 +79,7 @@ int tsfa_launch_family(const TsfaLaunch &a);
 int tsfa_launch_cwt(const TsfaCwtLaunch &a);
 int tsfa_launch_fill_nan(double *out, int64_t n, void *stream);
 int tsfa_launch_len_stats(const int64_t *starts, const int64_t *ends, int64_t n_series, long long *stats, void *stream);
+int tsfa_launch_class_fill(const int64_t *starts, const int64_t *ends, int64_t n_series, const TsfaClassMap &g, int *cursor,
+                           int *sel, void *stream);
 
 #endif

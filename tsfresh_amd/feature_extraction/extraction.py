@@ -37,30 +37,46 @@ def _default_device():
 
 
 # Native plans (device-side spec tables, twiddles, staging buffers) are kept across calls: creating one costs ~8 ms,
-# a 20 000-series extraction ~25 ms.  One plan may be driven by one host thread at a time, so the key holds the thread.
-_PLAN_CACHE = collections.OrderedDict()
+# a 20 000-series extraction ~25 ms.  One plan may be driven by one host thread at a time (ctypes releases the GIL inside
+# tsfa_extract), so every thread keeps its OWN small LRU: no thread can evict -- and destroy -- a plan another thread
+# is running, and no lock is held across the native call.
 _PLAN_CACHE_SIZE = 6
+_TLS = threading.local()
+_ALL_CACHES = []  # weak bookkeeping for clear_plan_cache(): (thread ident, cache)
+_ALL_CACHES_LOCK = threading.Lock()
+
+
+def _thread_cache():
+    cache = getattr(_TLS, "plans", None)
+    if cache is None:
+        cache = _TLS.plans = collections.OrderedDict()
+        with _ALL_CACHES_LOCK:
+            _ALL_CACHES.append((threading.get_ident(), cache))
+    return cache
 
 
 def _acquire_plan(fplan, device):
     specs = fplan.native_specs(_native.calc_id)
-    key = (threading.get_ident(), int(device), tuple((cid, tuple(float(v) for v in p)) for cid, p in specs))
-    plan = _PLAN_CACHE.get(key)
+    key = (int(device), tuple((cid, tuple(float(v) for v in p)) for cid, p in specs))
+    cache = _thread_cache()
+    plan = cache.get(key)
     if plan is not None:
-        _PLAN_CACHE.move_to_end(key)
+        cache.move_to_end(key)
         return plan
     plan = _native.Plan(specs, device=device)
-    _PLAN_CACHE[key] = plan
-    while len(_PLAN_CACHE) > _PLAN_CACHE_SIZE:
-        _, old = _PLAN_CACHE.popitem(last=False)
+    cache[key] = plan
+    while len(cache) > _PLAN_CACHE_SIZE:
+        _, old = cache.popitem(last=False)  # this thread's own, idle plan
         old.close()
     return plan
 
 
 def clear_plan_cache():
-    """Release the cached native plans (and the device memory they hold)."""
-    while _PLAN_CACHE:
-        _, old = _PLAN_CACHE.popitem(last=False)
+    """Release the cached native plans of the CALLING thread (and the device memory they hold).  Plans cached by other
+    threads are released when those threads call this, or with the interpreter."""
+    cache = _thread_cache()
+    while cache:
+        _, old = cache.popitem(last=False)
         old.close()
 
 
