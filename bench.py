@@ -209,7 +209,6 @@ def main():
         warnings.simplefilter("ignore")
         fplan = compile_fc_parameters(cls())
     n_cols = len(fplan)
-    plan = _native.Plan(fplan.native_specs(_native.calc_id), device=local_rank)
 
     n, L = args.n_series, args.length
     gen = torch.Generator(device=dev)
@@ -225,51 +224,23 @@ def main():
     else:
         values = torch.randn(n * L, device=dev, dtype=torch.float32, generator=gen)  # i.i.d. N(0,1) float32 series
         offsets = torch.arange(0, (n + 1) * L, L, device=dev, dtype=torch.int64)
-    out = torch.empty((n, n_cols), device=dev, dtype=torch.float64)
-    stream = torch.cuda.current_stream(dev).cuda_stream
-    # N > 1: the shard is extracted in row chunks; the all-gather of a finished chunk is enqueued asynchronously (RCCL's
-    # own stream waits for the chunk's kernels, the launch stream goes straight on to the next chunk), so only the last
-    # chunk's exchange is exposed.  Every rank ends up with all rows: gathered[c] = [world x rows_c, n_cols], the rows of
-    # chunk c of every rank in rank order.
-    if not args.ragged:
-        plan.set_length_hint(L, L)  # equal lengths, known up front: chunk launches need no length scan / host sync
+    # The product pipeline (tsfresh_amd/distributed.py: ShardPipeline): the shard is extracted in row chunks on two
+    # alternating launch streams (a plan each); with N > 1 every finished chunk is exchanged (RCCL all-gather into a
+    # staging block + device scatter into the rank-major matrix) while the next chunk is being extracted, so only the
+    # last chunk's exchange is exposed.  Every rank ends up with all rows: full = [world x n, n_cols], rank-major.
+    from tsfresh_amd.distributed import ShardPipeline
     n_chunks = args.chunks if args.chunks > 0 else (8 if dist is not None else 1)
     n_chunks = max(1, min(n_chunks, n))
-    cuts = [int(round(i * n / n_chunks)) for i in range(n_chunks + 1)]
-    gathered = [torch.empty((world * (cuts[c + 1] - cuts[c]), n_cols), device=dev, dtype=torch.float64)
-                for c in range(n_chunks)] if dist is not None else None
-
-    # chunks alternate between two launch streams (each with its own plan: a plan's device scratch belongs to one
-    # stream at a time), so the thinning tail of one chunk's kernels overlaps the start of the next chunk's
-    main_stream = torch.cuda.current_stream(dev)
-    if n_chunks > 1:
-        plan_b = _native.Plan(fplan.native_specs(_native.calc_id), device=local_rank)
-        if not args.ragged:
-            plan_b.set_length_hint(L, L)
-        lanes = [(plan, torch.cuda.Stream(device=dev)), (plan_b, torch.cuda.Stream(device=dev))]
-    else:
-        plan_b = None
-        lanes = [(plan, main_stream)]
+    pipe = ShardPipeline(fplan.native_specs(_native.calc_id), n_cols, local_rank, dist=dist, n_chunks=n_chunks,
+                         length_hint=None if args.ragged else (L, L))  # equal lengths, known up front: no length scan
+    plan = pipe.plans[0]
+    full = torch.empty((world * n, n_cols), device=dev, dtype=torch.float64)
+    out = full[rank * n:(rank + 1) * n]
+    stream = torch.cuda.current_stream(dev).cuda_stream
+    counts = [n] * world
 
     def step():
-        works = []
-        for pl, st in lanes:
-            if st is not main_stream:
-                st.wait_stream(main_stream)
-        for c in range(n_chunks):
-            c0, c1 = cuts[c], cuts[c + 1]
-            pl, st = lanes[c % len(lanes)]
-            # offsets stay relative to the start of `values`: a chunk is the same buffer with a later offsets pointer
-            pl.extract_device(values.data_ptr(), _native.TSFA_F32, offsets.data_ptr() + 8 * c0, c1 - c0,
-                              out.data_ptr() + 8 * n_cols * c0, n_cols, st.cuda_stream)
-            if dist is not None:
-                with torch.cuda.stream(st):  # the collective orders itself after this chunk's kernels only
-                    works.append(dist.all_gather_into_tensor(gathered[c], out[c0:c1], async_op=True))
-        for w in works:
-            w.wait()
-        for pl, st in lanes:
-            if st is not main_stream:
-                main_stream.wait_stream(st)
+        pipe.run(values, offsets, counts, full, _native.TSFA_F32)
 
     def barrier():
         if dist is not None:
@@ -291,12 +262,14 @@ def main():
         elapsed = float(t.item())
     ms_per_step = 1000.0 * elapsed / max(args.steps, 1)
     value = world * n * args.steps / elapsed
-    if dist is not None:  # every rank holds every rank's rows: its own block must be where its rank puts it
-        for c in range(n_chunks):
-            rows = cuts[c + 1] - cuts[c]
-            mine = gathered[c][rank * rows:(rank + 1) * rows]
-            ref = out[cuts[c]:cuts[c + 1]]
-            assert bool(((mine == ref) | (torch.isnan(mine) & torch.isnan(ref))).all().item()), "all-gather layout"
+    if dist is not None and world > 1:
+        # every rank holds every rank's rows: a checksum of each rank's block (NaNs zeroed), all-reduced with MAX and
+        # MIN, must agree on all ranks -- i.e. everybody received the same bytes for every block
+        sums = torch.stack([torch.nan_to_num(full[r * n:(r + 1) * n]).sum() for r in range(world)])
+        hi, lo = sums.clone(), sums.clone()
+        dist.all_reduce(hi, op=dist.ReduceOp.MAX)
+        dist.all_reduce(lo, op=dist.ReduceOp.MIN)
+        assert bool((hi == lo).all().item()), "exchange: ranks disagree on the gathered matrix"
 
     # ---- per-kernel HIP-event timings (events recorded on the launch stream), 2 profiled passes ----
     plan.set_profiling(True)
@@ -374,9 +347,7 @@ def main():
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
-    plan.close()
-    if plan_b is not None:
-        plan_b.close()
+    pipe.close()
 
 
 if __name__ == "__main__":

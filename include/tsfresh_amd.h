@@ -37,7 +37,7 @@ typedef enum tsfa_status {
 } tsfa_status;
 
 /* element type of the ragged value buffer */
-typedef enum tsfa_dtype { TSFA_F32 = 0, TSFA_F64 = 1 } tsfa_dtype;
+typedef enum tsfa_dtype { TSFA_F32 = 0, TSFA_F64 = 1, TSFA_I64 = 2, TSFA_I32 = 3 /* ids / sort keys only */ } tsfa_dtype;
 
 /* where the caller's buffers live */
 typedef enum tsfa_memspace { TSFA_HOST = 0, TSFA_DEVICE = 1 } tsfa_memspace;
@@ -143,6 +143,21 @@ int32_t tsfa_plan_last_timings(const tsfa_plan *plan, const char **names, float 
  * outside the promised range is undefined behaviour.  (0, 0) withdraws the promise.  The reference has no counterpart:
  * its per-series dispatch (extraction.py:308) sizes nothing ahead. */
 int tsfa_plan_set_length_hint(tsfa_plan *plan, int64_t min_len, int64_t max_len);
+
+/* Host-side packer helper.  The reference groups a long DataFrame into per-(id, kind) pd.Series with a pandas groupby
+ * (data.py:233-291, LongTsFrameAdapter); for the usual layout -- rows already grouped by ascending id, every group already
+ * in sort order -- the ragged buffer tsfa_extract wants is the value column itself, and all that is needed is ONE
+ * multi-threaded pass that (a) proves the layout, (b) finds the group boundaries, (c) performs the reference's NaN check
+ * of the value column (data.py:148-167).
+ *   ids / sort / values: the columns (sort and values may be NULL), element types per tsfa_dtype
+ *   *flags:    TSFA_PACK_UNSORTED  the layout is something else (the caller falls back to a sorting packer)
+ *              TSFA_PACK_VALUE_NAN a value is NaN (the caller raises the reference's ValueError)
+ *   *n_groups: number of series; tsfa_pack_offsets then writes the n_groups + 1 row offsets (same thread). */
+#define TSFA_PACK_UNSORTED 1
+#define TSFA_PACK_VALUE_NAN 2
+int tsfa_pack_scan(const void *ids, int32_t id_type, const void *sort, int32_t sort_type, const void *values,
+                   int32_t value_type, int64_t n_rows, int32_t *flags, int64_t *n_groups);
+int tsfa_pack_offsets(int64_t *offsets, int64_t n_groups, int64_t n_rows);
 
 /* Page-locked host memory for the TSFA_HOST form.  tsfa_extract* accepts ANY host pointer; from pageable memory the HIP
  * runtime stages every transfer through its own bounce buffers, from memory obtained here the copy engines read and

@@ -409,3 +409,79 @@ def test_hip_matches_oracle_on_structured_long_series(gpu):
     assert names == names_o
     bad = compare(names, got, want, [values[offsets[i]:offsets[i + 1]].astype(np.float64) for i in range(len(series))])
     assert not bad, bad[:20]
+
+
+def test_extract_features_on_several_devices_from_one_process(gpu):
+    """extract_features(..., devices=[...]): sum(len^2)-balanced shards, one plan + host thread per device, every
+    device's pipeline writing its rows into one page-locked matrix.  A one-GPU box runs both shards on device 0
+    (two threads, two plans): the result must equal the single-device call bit for bit."""
+    from tsfresh_amd import extract_features
+    rng = np.random.default_rng(21)
+    lens = rng.integers(20, 300, size=700)
+    lens[[3, 500]] = 2000
+    df = pd.DataFrame({"id": np.repeat(np.arange(len(lens)), lens), "time": np.concatenate([np.arange(m) for m in lens]),
+                       "value": rng.standard_normal(int(lens.sum())).astype(np.float32)})
+    params = settings.EfficientFCParameters()
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        one = extract_features(df, column_id="id", column_sort="time", default_fc_parameters=params, device=0)
+        two = extract_features(df, column_id="id", column_sort="time", default_fc_parameters=params, devices=[0, 0])
+        three = extract_features(df, column_id="id", column_sort="time", default_fc_parameters=params, devices=[0, 0, 0])
+    assert one.shape == two.shape == (len(lens), 777)
+    pd.testing.assert_frame_equal(one, two, check_exact=True)
+    pd.testing.assert_frame_equal(one, three, check_exact=True)
+
+
+def test_shard_pipeline_chunks_and_lanes_equal_one_pass(gpu):
+    """tsfresh_amd.distributed.ShardPipeline without peers: 5 row chunks alternating between two launch streams / plans
+    must produce the matrix of a single pass (ragged lengths: every chunk scans and classes its own lengths)."""
+    import torch
+    from tsfresh_amd import _native
+    from tsfresh_amd.distributed import ShardPipeline
+    from tsfresh_amd.feature_extraction.plan import compile_fc_parameters
+    rng = np.random.default_rng(22)
+    lens = rng.integers(5, 400, size=3000)
+    values = rng.standard_normal(int(lens.sum())).astype(np.float32)
+    offsets = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        fplan = compile_fc_parameters(settings.EfficientFCParameters())
+    specs = fplan.native_specs(_native.calc_id)
+    dev = torch.device("cuda", 0)
+    tv, to = torch.from_numpy(values).to(dev), torch.from_numpy(offsets).to(dev)
+    res = []
+    for n_chunks in (1, 5):
+        pipe = ShardPipeline(specs, len(fplan), 0, dist=None, n_chunks=n_chunks)
+        full = torch.empty((len(lens), len(fplan)), device=dev, dtype=torch.float64)
+        pipe.run(tv, to, [len(lens)], full, _native.TSFA_F32)
+        torch.cuda.synchronize(dev)
+        res.append(full.cpu().numpy())
+        pipe.close()
+    assert np.array_equal(np.nan_to_num(res[0]), np.nan_to_num(res[1])) and np.array_equal(np.isnan(res[0]), np.isnan(res[1]))
+    names, want = hip_engine(settings.EfficientFCParameters(), values, offsets)
+    assert np.array_equal(np.nan_to_num(res[0]), np.nan_to_num(want))
+
+
+def test_length_classes_give_identical_results_and_do_not_pay_for_the_longest(gpu, monkeypatch):
+    """A ragged batch is launched by length class (each class with its own LDS carve / workgroup size): same numbers as
+    the single-launch form (TSFA_NO_LENGTH_CLASSES=1), for host and device-resident inputs."""
+    rng = np.random.default_rng(23)
+    lens = np.concatenate([rng.integers(8, 64, size=1500), rng.integers(200, 260, size=1500), rng.integers(900, 1100, size=600),
+                           [4000, 3000, 7000]])
+    rng.shuffle(lens)
+    values = rng.standard_normal(int(lens.sum())).astype(np.float32)
+    offsets = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
+    params = settings.EfficientFCParameters()
+    names, classed = hip_engine(params, values, offsets)
+    monkeypatch.setenv("TSFA_NO_LENGTH_CLASSES", "1")
+    names2, single = hip_engine(params, values, offsets)
+    monkeypatch.delenv("TSFA_NO_LENGTH_CLASSES")
+    assert names == names2
+    assert np.array_equal(np.isnan(classed), np.isnan(single))
+    # the workgroup size of a class decides the association of its reductions: equal to 1e-12, not bit for bit
+    assert np.allclose(np.nan_to_num(classed), np.nan_to_num(single), rtol=1e-9, atol=1e-9)
+    rows = [int(np.argmax(lens)), int(np.argmin(lens)), 5, 6, 7]
+    onames, want = _sample_parity(params, [values[offsets[i]:offsets[i + 1]] for i in range(len(lens))], rows)
+    bad = compare(onames, _align(onames, names, classed[rows]), want,
+                  [values[offsets[i]:offsets[i + 1]].astype(np.float64) for i in rows])
+    assert not bad, bad[:8]

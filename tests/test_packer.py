@@ -10,7 +10,7 @@ from tsfresh_amd.feature_extraction import data as D
 def _both(df, **kw):
     fast, _, _ = D.pack_timeseries(df, **kw)
     orig = D._pack_presorted
-    D._pack_presorted = lambda *a: None
+    D._pack_presorted = lambda *a, **k: None
     try:
         gen, _, _ = D.pack_timeseries(df, **kw)
     finally:
@@ -76,3 +76,64 @@ def test_arrow_tables_pack_like_frames():
         got, id_dtype, has_dt = D.pack_timeseries(container, column_id="id", column_sort="time")
         _same(got, want)
         assert id_dtype == df["id"].dtype and not has_dt
+
+
+@pytest.mark.parametrize("case", ["sorted", "ragged", "float_ids", "unsorted_within", "unsorted_ids", "datetime_sort",
+                                  "int32", "no_sort"])
+def test_native_scan_equals_numpy_passes(case, monkeypatch):
+    """tsfa_pack_scan (one multi-threaded C++ pass: layout proof + group boundaries + NaN check) against the numpy
+    passes it replaces, on frames large enough to split over several scan threads."""
+    rng = np.random.default_rng(5)
+    n_ids = 3000
+    lens = rng.integers(1, 700, size=n_ids) if case == "ragged" else np.full(n_ids, 300)
+    ids = np.repeat(np.arange(n_ids) * 2, lens)
+    t = np.concatenate([np.arange(m) for m in lens])
+    df = pd.DataFrame({"id": ids, "time": t, "value": rng.standard_normal(len(ids)).astype(np.float32)})
+    if case == "float_ids":
+        df["id"] = df["id"].astype(float) / 2
+    if case == "unsorted_within":
+        df.loc[len(df) // 2 + 1, "time"] = 10 ** 6 if df.loc[len(df) // 2 + 2, "id"] == df.loc[len(df) // 2 + 1, "id"] else -1
+    if case == "unsorted_ids":
+        df = df.iloc[::-1].reset_index(drop=True)
+    if case == "datetime_sort":
+        df["time"] = pd.to_datetime("2021-03-04") + pd.to_timedelta(df["time"].to_numpy(), unit="s")
+    if case == "int32":
+        df["id"] = df["id"].astype(np.int32)
+        df["time"] = df["time"].astype(np.int32)
+    kw = dict(column_id="id") if case == "no_sort" else dict(column_id="id", column_sort="time")
+    if case == "no_sort":
+        df = df.drop(columns="time")
+    assert len(df) >= D._NATIVE_SCAN_MIN_ROWS
+    native, _, _ = D.pack_timeseries(df, **kw)
+    monkeypatch.setattr(D, "_NATIVE_SCAN_MIN_ROWS", 1 << 62)
+    plain, _, _ = D.pack_timeseries(df, **kw)
+    _same(native, plain)
+
+
+def test_native_scan_reports_nan_values_like_the_reference():
+    n = D._NATIVE_SCAN_MIN_ROWS + 10
+    df = pd.DataFrame({"id": np.arange(n) // 100, "time": np.arange(n) % 100, "value": np.zeros(n, dtype=np.float32)})
+    df.loc[n - 3, "value"] = np.nan
+    with pytest.raises(ValueError, match="Column must not contain NaN values: value"):
+        D.pack_timeseries(df, column_id="id", column_sort="time")
+    small = df.iloc[-50:].reset_index(drop=True)
+    with pytest.raises(ValueError, match="Column must not contain NaN values: value"):
+        D.pack_timeseries(small, column_id="id", column_sort="time")
+
+
+def test_arrow_wide_table_is_packed_without_a_dataframe(monkeypatch):
+    pa = pytest.importorskip("pyarrow")
+    rng = np.random.default_rng(9)
+    lens = rng.integers(1, 9, size=40)
+    df = pd.DataFrame({"id": np.repeat(np.arange(40), lens), "time": np.concatenate([np.arange(m) for m in lens]),
+                       "a": rng.standard_normal(int(lens.sum())).astype(np.float32), "b": rng.standard_normal(int(lens.sum()))})
+    want, _, _ = D.pack_timeseries(df, column_id="id", column_sort="time")
+    monkeypatch.setattr(D, "_arrow_to_frame", lambda t: (_ for _ in ()).throw(AssertionError("took the pandas route")))
+    table = pa.Table.from_pandas(df, preserve_index=False)
+    got, id_dtype, has_dt = D.pack_timeseries(table, column_id="id", column_sort="time")
+    _same(got, want)
+    assert got[0].values.base is not None  # a view of the Arrow buffer, not a copy
+    assert id_dtype == df["id"].dtype and not has_dt
+    bad = pa.table({"id": df["id"].to_numpy(), "time": df["time"].to_numpy(), "a": np.where(np.arange(len(df)) == 3, np.nan, df["a"].to_numpy())})
+    with pytest.raises(ValueError, match="Column must not contain NaN values: a"):
+        D.pack_timeseries(bad, column_id="id", column_sort="time")

@@ -19,7 +19,8 @@ TSFA_ERR_UNSUPPORTED = -2
 TSFA_ERR_NO_DEVICE = -3
 TSFA_ERR_HIP = -4
 TSFA_ERR_TOO_LONG = -5
-TSFA_F32, TSFA_F64 = 0, 1
+TSFA_F32, TSFA_F64, TSFA_I64, TSFA_I32 = 0, 1, 2, 3
+TSFA_PACK_UNSORTED, TSFA_PACK_VALUE_NAN = 1, 2
 TSFA_HOST, TSFA_DEVICE = 0, 1
 
 # every symbol include/tsfresh_amd.h declares
@@ -32,6 +33,8 @@ EXPORTS = (
     "tsfa_plan_set_length_hint",
     "tsfa_host_alloc",
     "tsfa_host_free",
+    "tsfa_pack_scan",
+    "tsfa_pack_offsets",
     "tsfa_relevance_classes",
     "tsfa_relevance_classes_ks",
     "tsfa_relevance_real",
@@ -98,6 +101,12 @@ def load():
     lib.tsfa_plan_last_timings.argtypes = [ctypes.c_void_p, ctypes.POINTER(ctypes.c_char_p),
                                            ctypes.POINTER(ctypes.c_float), ctypes.c_int32]
     lib.tsfa_plan_last_timings.restype = ctypes.c_int32
+    lib.tsfa_pack_scan.argtypes = [ctypes.c_void_p, ctypes.c_int32, ctypes.c_void_p, ctypes.c_int32, ctypes.c_void_p,
+                                   ctypes.c_int32, ctypes.c_int64, ctypes.POINTER(ctypes.c_int32),
+                                   ctypes.POINTER(ctypes.c_int64)]
+    lib.tsfa_pack_scan.restype = ctypes.c_int
+    lib.tsfa_pack_offsets.argtypes = [ctypes.c_void_p, ctypes.c_int64, ctypes.c_int64]
+    lib.tsfa_pack_offsets.restype = ctypes.c_int
     lib.tsfa_host_alloc.argtypes = [ctypes.POINTER(ctypes.c_void_p), ctypes.c_size_t]
     lib.tsfa_host_alloc.restype = ctypes.c_int
     lib.tsfa_host_free.argtypes = [ctypes.c_void_p]
@@ -187,6 +196,35 @@ def pinned_empty(shape, dtype):
     return np.frombuffer(buf, dtype=dtype, count=n).reshape(shape)
 
 
+_PACK_TYPES = {np.dtype(np.float32): TSFA_F32, np.dtype(np.float64): TSFA_F64, np.dtype(np.int64): TSFA_I64,
+               np.dtype(np.int32): TSFA_I32}
+
+
+def pack_scan(ids, sort_values, values):
+    """One multi-threaded pass over the rows of a long frame (tsfa_pack_scan): -> (flags, offsets or None).
+    Returns None when a column has a layout / element type the native scan does not take (the caller uses numpy)."""
+    cols = []
+    for a in (ids, sort_values, values):
+        if a is None:
+            cols.append((None, 0))
+            continue
+        if isinstance(a, np.ndarray) and a.dtype.kind in "mM" and a.dtype.itemsize == 8:
+            a = a.view(np.int64)  # datetime64 / timedelta64 sort keys compare like their integer ticks (no NaT: checked)
+        if not isinstance(a, np.ndarray) or a.ndim != 1 or not a.flags.c_contiguous or a.dtype not in _PACK_TYPES:
+            return None
+        cols.append((a.ctypes.data_as(ctypes.c_void_p), _PACK_TYPES[a.dtype]))
+    lib = load()
+    flags, groups = ctypes.c_int32(0), ctypes.c_int64(0)
+    n = len(ids)
+    _check(lib, lib.tsfa_pack_scan(cols[0][0], cols[0][1], cols[1][0], cols[1][1], cols[2][0], cols[2][1], n,
+                                   ctypes.byref(flags), ctypes.byref(groups)))
+    if flags.value & TSFA_PACK_UNSORTED:
+        return flags.value, None
+    offsets = np.empty(groups.value + 1, dtype=np.int64)
+    _check(lib, lib.tsfa_pack_offsets(offsets.ctypes.data_as(ctypes.c_void_p), groups.value, n))
+    return flags.value, offsets
+
+
 def _result_matrix(n_rows, n_cols):
     """The feature matrix of a host-side extraction: page-locked when it is large enough for the copy-out to matter."""
     if n_rows * n_cols * 8 >= (4 << 20) and os.environ.get("TSFRESH_AMD_PINNED", "1") != "0":
@@ -243,10 +281,11 @@ class Plan:
         n = self._lib.tsfa_plan_last_timings(self._h, names, ms, cap)
         return [(names[i].decode(), float(ms[i])) for i in range(n)]
 
-    def extract_host(self, values, offsets, times=None):
+    def extract_host(self, values, offsets, times=None, out=None):
         """values: 1-D float32/float64 ndarray; offsets: int64 ndarray (n_series + 1) -> float64 [n_series, n_cols].
         times: float64 ndarray laid out like `values` (hours since each series' first timestamp) for plans that
-        hold linear_trend_timewise columns."""
+        hold linear_trend_timewise columns.  out: optional C-contiguous-row float64 [n_series, >= n_cols] target (a row
+        slice of a larger matrix); default: a new page-locked matrix."""
         values = np.ascontiguousarray(values)
         if values.dtype == np.float32:
             dt = TSFA_F32
@@ -255,7 +294,12 @@ class Plan:
             dt = TSFA_F64
         offsets = np.ascontiguousarray(offsets, dtype=np.int64)
         n_series = offsets.shape[0] - 1
-        out = _result_matrix(n_series, self.n_cols)
+        if out is None:
+            out = _result_matrix(n_series, self.n_cols)
+        elif (out.dtype != np.float64 or out.ndim != 2 or out.shape[0] != n_series or out.shape[1] < self.n_cols
+              or out.strides[1] != 8 or out.strides[0] % 8):
+            raise ValueError("out must be a float64 [n_series, >= n_cols] matrix with contiguous rows")
+        ld = out.strides[0] // 8 if n_series else self.n_cols
         if n_series == 0 or self.n_cols == 0:
             return out
         if values.size == 0:
@@ -268,7 +312,7 @@ class Plan:
             tptr = times.ctypes.data_as(ctypes.c_void_p)
         _check(self._lib, self._lib.tsfa_extract_timed(
             self._h, values.ctypes.data_as(ctypes.c_void_p), dt, tptr, offsets.ctypes.data_as(ctypes.c_void_p),
-            n_series, out.ctypes.data_as(ctypes.c_void_p), self.n_cols, TSFA_HOST, None))
+            n_series, out.ctypes.data_as(ctypes.c_void_p), ld, TSFA_HOST, None))
         return out
 
     def extract_windows_host(self, values, starts, ends, times=None):

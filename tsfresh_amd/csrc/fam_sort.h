@@ -264,6 +264,31 @@ TSFA_DEV void friedrich_coeffs(const Blk &b, XS xs, int n, S1 srt1, int m, int r
     bad = blk_sum(b, bad);
     if (bad > 0.0) return;
     // bin index = #{edges < x} - 1, with x == edges[0] -> bin 0  (pandas _bins_to_cuts, right=True, include_lowest)
+#if TSFA_GPU
+    {
+        // lane = bin: every lane walks the samples in index order and keeps those of ITS bin (edges[j] < x <= edges[j+1]),
+        // the wavefronts split the index range and add their partial sums in wavefront order -- the same additions in
+        // the same order on every run (LDS float atomics made the last bits depend on the scheduling)
+        const int lane = b.tid & 63, wv = b.tid >> 6, nw = b.nt >> 6;
+        const int per = (ns + nw - 1) / nw;
+        const int i0 = wv * per, i1 = (i0 + per < ns) ? i0 + per : ns;
+        const bool mine = lane < r;
+        const double e_lo = mine ? edges[lane] : 0.0, e_hi = mine ? edges[lane + 1] : 0.0, e0 = edges[0];
+        double ax = 0.0, ay = 0.0, ac = 0.0;
+        for (int i = i0; i < i1; ++i) {
+            const double x = xs[i];
+            const double dlt = xs[i + 1] - x;
+            const bool in = mine && ((x > e_lo && x <= e_hi) || (lane == 0 && x == e0));
+            ax += in ? x : 0.0;
+            ay += in ? dlt : 0.0;
+            ac += in ? 1.0 : 0.0;
+        }
+        for (int w = 0; w < nw; ++w) {
+            if (wv == w && mine) { sx[lane] += ax; sy[lane] += ay; cnt[lane] += ac; }
+            blk_sync();
+        }
+    }
+#else
     for (int i = b.tid; i < ns; i += b.nt) {
         const double x = xs[i];
         int lo = 0, hi = r + 1;  // count of edges < x
@@ -275,15 +300,10 @@ TSFA_DEV void friedrich_coeffs(const Blk &b, XS xs, int n, S1 srt1, int m, int r
         if (x == edges[0]) bin = 0;
         if (bin < 0 || bin >= r) continue;
         const double dlt = xs[i + 1] - xs[i];
-#if TSFA_GPU
-        atomicAdd(&sx[bin], x);
-        atomicAdd(&sy[bin], dlt);
-        atomicAdd(&cnt[bin], 1.0);
-#else
         sx[bin] += x; sy[bin] += dlt; cnt[bin] += 1.0;
-#endif
     }
     blk_sync();
+#endif
 #if TSFA_GPU
     // np.polyfit(x_mean, y_mean, deg=m): scaled Vandermonde + least squares.  The r <= 64 bins are the lanes of
     // wavefront 0: every lane keeps its row of the design in registers and the Householder reflections are

@@ -9,6 +9,10 @@ layout the kernels consume.  Everything is vectorised (factorize + lexsort); no 
 import numpy as np
 import pandas as pd
 
+from tsfresh_amd import _native
+
+_NATIVE_SCAN_MIN_ROWS = 1 << 18  # below this the numpy passes are as fast as spawning the scan threads
+
 
 class PackedKind:
     """All series of one kind: `values[offsets[i]:offsets[i+1]]` is the series of `ids[i]` (ids sorted)."""
@@ -35,13 +39,21 @@ def _check_colname(*columns):
             raise ValueError("Dict keys are not allowed to contain '__': {}".format(col))
 
 
-def _check_nan(df, *columns):
-    # data.py:148-167
+def _check_nan(df, *columns, defer=()):
+    # data.py:148-167.  Integer / boolean columns cannot hold NaN (no 20 M-row isnull() pass for an int64 id column);
+    # columns in `defer` are checked by _pack (in the same native pass that finds the group boundaries).
     for col in columns:
         if col not in df.columns:
             raise ValueError("Column not found: {}".format(col))
+        if col in defer or df[col].dtype.kind in "iub":
+            continue
         if df[col].isnull().any():
             raise ValueError("Column must not contain NaN values: {}".format(col))
+
+
+def _raise_if_nan(values, name):
+    if name is not None and values.dtype.kind == "f" and bool(np.isnan(values).any()):
+        raise ValueError("Column must not contain NaN values: {}".format(name))
 
 
 def _get_value_columns(df, *other_columns):
@@ -68,13 +80,26 @@ def _hours_since_first(index, order, offsets):
     return np.ascontiguousarray(np.asarray((ix - first).total_seconds() / float(3600)), dtype=np.float64)
 
 
-def _pack_presorted(kind, ids, values, sort_values, index):
+def _pack_presorted(kind, ids, values, sort_values, index, nan_name=None):
     """The usual layout of a long frame -- numeric ids already non-decreasing, every group already in sort order --
     needs no hashing and no permutation: the group boundaries are where the id changes (three linear passes over the
     rows instead of `factorize` + `bincount` + the element-wise sortedness test: 4x less packing time on 20 M rows).
     Returns None when the layout is anything else (the general path then sorts)."""
     if ids.dtype.kind not in "iuf" or len(ids) < 2:
         return None
+    if len(ids) >= _NATIVE_SCAN_MIN_ROWS:
+        # one multi-threaded native pass: layout proof + group boundaries + the NaN check of the value column
+        vals = _as_values(values)
+        sv = None if sort_values is None else np.asarray(sort_values)
+        res = _native.pack_scan(ids, sv, vals)
+        if res is not None:
+            flags, offsets = res
+            if flags & _native.TSFA_PACK_VALUE_NAN and nan_name is not None:
+                raise ValueError("Column must not contain NaN values: {}".format(nan_name))
+            if offsets is None:
+                return None
+            times = _hours_since_first(index, slice(None), offsets) if index is not None else None
+            return PackedKind(str(kind), ids[offsets[:-1]], np.ascontiguousarray(vals), offsets, times, sv)
     if not bool(np.all(ids[1:] >= ids[:-1])):  # also False for NaN ids
         return None
     cuts = np.flatnonzero(ids[1:] != ids[:-1]) + 1
@@ -93,16 +118,20 @@ def _pack_presorted(kind, ids, values, sort_values, index):
     offsets[-1] = len(ids)
     uniques = ids[offsets[:-1]]
     times = _hours_since_first(index, slice(None), offsets) if index is not None else None
-    return PackedKind(str(kind), uniques, np.ascontiguousarray(_as_values(values)), offsets, times, sv)
+    vals = np.ascontiguousarray(_as_values(values))
+    _raise_if_nan(vals, nan_name)
+    return PackedKind(str(kind), uniques, vals, offsets, times, sv)
 
 
-def _pack(kind, ids, values, sort_values, index=None):
+def _pack(kind, ids, values, sort_values, index=None, nan_name=None):
     """Group `values` by `ids` (ascending), each group ordered by `sort_values` (stable).  `index`: the frame's
-    DatetimeIndex (row-aligned with `values`) or None."""
+    DatetimeIndex (row-aligned with `values`) or None.  nan_name: the value column's name if its NaN check
+    (data.py:148-167) has been left to this function."""
     ids = np.asarray(ids)
-    fast = _pack_presorted(kind, ids, values, sort_values, index)
+    fast = _pack_presorted(kind, ids, values, sort_values, index, nan_name)
     if fast is not None:
         return fast
+    _raise_if_nan(_as_values(values), nan_name)
     codes, uniques = pd.factorize(ids, sort=True)
     order = None
     if len(codes) > 1 and np.all(codes[1:] >= codes[:-1]):
@@ -146,9 +175,48 @@ def _arrow_to_frame(table):
     return pd.DataFrame(cols, copy=False)
 
 
+def _pack_arrow_wide(table, column_id, column_kind, column_value, column_sort):
+    """Wide-format pyarrow Table / RecordBatch with primitive, null-free columns: the Arrow buffers go to the packer as
+    numpy views (zero copy) -- no pandas frame, no block consolidation.  None -> the caller converts to a DataFrame
+    and takes the general route (strings, nulls, chunked columns that need a copy, the long format)."""
+    if column_id is None or column_kind is not None:
+        return None
+    names = list(table.schema.names)
+    if column_id not in names or (column_sort is not None and column_sort not in names):
+        return None
+    value_columns = [column_value] if column_value is not None else [c for c in names if c not in (column_id, column_sort)]
+    if not value_columns or any(c not in names for c in value_columns):
+        return None
+    arrays = {}
+    for name in [column_id] + ([column_sort] if column_sort is not None else []) + value_columns:
+        col = table.column(name)
+        if getattr(col, "null_count", 0):
+            return None
+        if hasattr(col, "num_chunks"):
+            if col.num_chunks != 1:
+                return None
+            col = col.chunk(0)
+        try:
+            arrays[name] = col.to_numpy(zero_copy_only=True)
+        except Exception:
+            return None
+        if arrays[name].dtype.kind not in "iuf":
+            return None
+    _check_colname(*value_columns)
+    for name in [column_id] + ([column_sort] if column_sort is not None else []):
+        _raise_if_nan(arrays[name], name)
+    ids = arrays[column_id]
+    sort_all = arrays[column_sort] if column_sort is not None else None
+    packed = [_pack(c, ids, arrays[c], sort_all, None, nan_name=c) for c in value_columns]
+    return packed, ids.dtype, False
+
+
 def pack_timeseries(container, column_id=None, column_kind=None, column_value=None, column_sort=None):
     """-> (list[PackedKind] in output-column order, dtype of the id column, has_datetime_index)."""
     if type(container).__module__.startswith("pyarrow") and hasattr(container, "schema"):
+        direct = _pack_arrow_wide(container, column_id, column_kind, column_value, column_sort)
+        if direct is not None:
+            return direct
         container = _arrow_to_frame(container)
     if isinstance(container, pd.DataFrame):
         df = container
@@ -182,14 +250,16 @@ def pack_timeseries(container, column_id=None, column_kind=None, column_value=No
         # wide format (data.py:181-230)
         _check_nan(df, column_id)
         value_columns = [column_value] if column_value is not None else _get_value_columns(df, column_id, column_sort)
-        _check_nan(df, *value_columns)
+        deferred = [c for c in value_columns if c in df.columns and df[c].dtype.kind == "f"]
+        _check_nan(df, *value_columns, defer=deferred)
         _check_colname(*value_columns)
         if column_sort is not None:
             _check_nan(df, column_sort)
         ids_all = df[column_id].to_numpy()
         sort_all = df[column_sort].to_numpy() if column_sort is not None else None
         dt_index = df.index if isinstance(df.index, pd.DatetimeIndex) else None
-        packed = [_pack(col, ids_all, df[col].to_numpy(), sort_all, dt_index) for col in value_columns]
+        packed = [_pack(col, ids_all, df[col].to_numpy(), sort_all, dt_index, nan_name=col if col in deferred else None)
+                  for col in value_columns]
         return packed, df[column_id].dtype, isinstance(df.index, pd.DatetimeIndex)
     if isinstance(container, dict):
         # dict of frames, one per kind (data.py:294-338)

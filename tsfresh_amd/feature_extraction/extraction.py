@@ -56,7 +56,11 @@ def _thread_cache():
 
 
 def _acquire_plan(fplan, device):
-    specs = fplan.native_specs(_native.calc_id)
+    return _acquire_plan_specs(fplan.native_specs(_native.calc_id), device)
+
+
+def _acquire_plan_specs(specs, device):
+    specs = list(specs)
     key = (int(device), tuple((cid, tuple(float(v) for v in p)) for cid, p in specs))
     cache = _thread_cache()
     plan = cache.get(key)
@@ -99,8 +103,9 @@ def extract_features(
     distributor=None,
     pivot=True,
     device=None,
+    devices=None,
 ):
-    """Extract features from a pandas container on one MI355X.
+    """Extract features from a pandas container on one MI355X (or, with `devices`, on several).
 
     :param timeseries_container: long/wide `pd.DataFrame` or dict of DataFrames (reference data formats).
     :param default_fc_parameters: calculator name -> list of parameter dicts (or None); default
@@ -110,6 +115,10 @@ def extract_features(
     :param impute_function: called on the result DataFrame (extraction.py:181-182).
     :param pivot: False returns the flat list of `(id, column name, value)` tuples (extraction.py:301-302).
     :param device: HIP device ordinal (default: $TSFRESH_AMD_DEVICE, else $LOCAL_RANK, else 0).
+    :param devices: list of HIP device ordinals: the series of every kind are cut into sum(len^2)-balanced contiguous
+        shards, one per device, extracted concurrently from this process (one plan + host thread per device) into one
+        page-locked matrix (`tsfresh_amd.distributed.extract_on_devices`).  The reference's counterpart is
+        `n_jobs` / a MultiprocessingDistributor over CPU cores (extraction.py:262-275).
     :return: `pd.DataFrame` of dtype float64.
     """
     if default_fc_parameters is None and kind_to_fc_parameters is None:
@@ -130,6 +139,12 @@ def extract_features(
     packed, id_dtype, has_dt_index = pack_timeseries(
         timeseries_container, column_id=column_id, column_kind=column_kind, column_value=column_value,
         column_sort=column_sort)
+    if devices is not None:
+        devices = [int(d) for d in devices]
+        if not devices:
+            raise ValueError("devices must name at least one HIP device")
+        if device is None:
+            device = devices[0]
     if device is None:
         device = _default_device()
 
@@ -155,7 +170,12 @@ def extract_features(
             fplan, nplan = plan_cache[key]
             if nplan is None:
                 continue
-            matrix = nplan.extract_host(pk.values, pk.offsets, times=pk.times)
+            if devices is not None and len(devices) > 1:
+                from tsfresh_amd.distributed import extract_on_devices
+                matrix = extract_on_devices(fplan.native_specs(_native.calc_id), pk.values, pk.offsets, devices,
+                                            times=pk.times)
+            else:
+                matrix = nplan.extract_host(pk.values, pk.offsets, times=pk.times)
             blocks.append((pk, [pk.kind + "__" + name for name in fplan.names], matrix))
 
     return _assemble(blocks, id_dtype, pivot, impute_function)
