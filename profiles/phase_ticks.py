@@ -34,6 +34,7 @@ def main():
     ap.add_argument("--n-series", type=int, default=20000)
     ap.add_argument("--length", type=int, default=1024)
     ap.add_argument("--params", default="comprehensive")
+    ap.add_argument("--ragged", default="", help="LO:HI -> lengths uniform on [LO, HI]")
     args = ap.parse_args()
     import torch
     from tsfresh_amd import _native
@@ -45,9 +46,17 @@ def main():
     n, L = args.n_series, args.length
     gen = torch.Generator(device=dev)
     gen.manual_seed(42)
-    values = torch.randn(n * L, device=dev, dtype=torch.float32, generator=gen)
-    offsets = torch.arange(0, (n + 1) * L, L, device=dev, dtype=torch.int64)
-    cls = {"comprehensive": settings.ComprehensiveFCParameters, "efficient": settings.EfficientFCParameters}[args.params]
+    if args.ragged:
+        lo, hi = (int(t) for t in args.ragged.split(":"))
+        lens = torch.randint(lo, hi + 1, (n,), device=dev, generator=gen, dtype=torch.int64)
+        offsets = torch.zeros(n + 1, device=dev, dtype=torch.int64)
+        offsets[1:] = torch.cumsum(lens, 0)
+        values = torch.randn(int(offsets[-1].item()), device=dev, dtype=torch.float32, generator=gen)
+    else:
+        values = torch.randn(n * L, device=dev, dtype=torch.float32, generator=gen)
+        offsets = torch.arange(0, (n + 1) * L, L, device=dev, dtype=torch.int64)
+    cls = {"comprehensive": settings.ComprehensiveFCParameters, "efficient": settings.EfficientFCParameters,
+           "minimal": settings.MinimalFCParameters}[args.params]
     with warnings.catch_warnings():
         warnings.simplefilter("ignore")
         fplan = compile_fc_parameters(cls())

@@ -432,34 +432,56 @@ def test_extract_features_on_several_devices_from_one_process(gpu):
     pd.testing.assert_frame_equal(one, three, check_exact=True)
 
 
+_SHARD_PIPELINE_SCRIPT = r"""
+import sys, warnings
+import numpy as np
+import torch   # first: torch ships its own HIP runtime and must be the one that opens the device in this process
+torch.cuda.init()
+sys.path.insert(0, %(root)r); sys.path.insert(0, %(tests)r)
+from tsfresh_amd import _native
+from tsfresh_amd.distributed import ShardPipeline
+from tsfresh_amd.feature_extraction import settings
+from tsfresh_amd.feature_extraction.plan import compile_fc_parameters
+from engines import hip_engine
+rng = np.random.default_rng(22)
+lens = rng.integers(5, 400, size=3000)
+values = rng.standard_normal(int(lens.sum())).astype(np.float32)
+offsets = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
+with warnings.catch_warnings():
+    warnings.simplefilter("ignore")
+    fplan = compile_fc_parameters(settings.EfficientFCParameters())
+specs = fplan.native_specs(_native.calc_id)
+dev = torch.device("cuda", 0)
+tv, to = torch.from_numpy(values).to(dev), torch.from_numpy(offsets).to(dev)
+res = []
+for n_chunks in (1, 5):
+    pipe = ShardPipeline(specs, len(fplan), 0, dist=None, n_chunks=n_chunks)
+    full = torch.empty((len(lens), len(fplan)), device=dev, dtype=torch.float64)
+    pipe.run(tv, to, [len(lens)], full, _native.TSFA_F32)
+    torch.cuda.synchronize(dev)
+    res.append(full.cpu().numpy())
+    pipe.close()
+assert np.array_equal(np.isnan(res[0]), np.isnan(res[1]))
+# a chunk is carved and sized for ITS longest series: reductions associate differently -> equal to 1e-9, not bitwise
+assert np.allclose(np.nan_to_num(res[0]), np.nan_to_num(res[1]), rtol=1e-9, atol=1e-9)
+with warnings.catch_warnings():
+    warnings.simplefilter("ignore")
+    names, want = hip_engine(settings.EfficientFCParameters(), values, offsets)
+assert np.allclose(np.nan_to_num(res[0]), np.nan_to_num(want), rtol=1e-9, atol=1e-9)
+print("PIPELINE_OK", res[0].shape)
+"""
+
+
 def test_shard_pipeline_chunks_and_lanes_equal_one_pass(gpu):
     """tsfresh_amd.distributed.ShardPipeline without peers: 5 row chunks alternating between two launch streams / plans
-    must produce the matrix of a single pass (ragged lengths: every chunk scans and classes its own lengths)."""
-    import torch
-    from tsfresh_amd import _native
-    from tsfresh_amd.distributed import ShardPipeline
-    from tsfresh_amd.feature_extraction.plan import compile_fc_parameters
-    rng = np.random.default_rng(22)
-    lens = rng.integers(5, 400, size=3000)
-    values = rng.standard_normal(int(lens.sum())).astype(np.float32)
-    offsets = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
-    with warnings.catch_warnings():
-        warnings.simplefilter("ignore")
-        fplan = compile_fc_parameters(settings.EfficientFCParameters())
-    specs = fplan.native_specs(_native.calc_id)
-    dev = torch.device("cuda", 0)
-    tv, to = torch.from_numpy(values).to(dev), torch.from_numpy(offsets).to(dev)
-    res = []
-    for n_chunks in (1, 5):
-        pipe = ShardPipeline(specs, len(fplan), 0, dist=None, n_chunks=n_chunks)
-        full = torch.empty((len(lens), len(fplan)), device=dev, dtype=torch.float64)
-        pipe.run(tv, to, [len(lens)], full, _native.TSFA_F32)
-        torch.cuda.synchronize(dev)
-        res.append(full.cpu().numpy())
-        pipe.close()
-    assert np.array_equal(np.nan_to_num(res[0]), np.nan_to_num(res[1])) and np.array_equal(np.isnan(res[0]), np.isnan(res[1]))
-    names, want = hip_engine(settings.EfficientFCParameters(), values, offsets)
-    assert np.array_equal(np.nan_to_num(res[0]), np.nan_to_num(want))
+    must produce the matrix of a single pass (ragged lengths: every chunk scans and classes its own lengths), which in
+    turn equals the host-buffer path.  In a process of its own, with torch initialised before the library."""
+    import subprocess
+    import sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    out = subprocess.run([sys.executable, "-c", _SHARD_PIPELINE_SCRIPT % {"root": os.path.dirname(here), "tests": here}],
+                         capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0 and "PIPELINE_OK (3000, 777)" in out.stdout, out.stdout[-1500:] + out.stderr[-3000:]
 
 
 def test_length_classes_give_identical_results_and_do_not_pay_for_the_longest(gpu, monkeypatch):
@@ -485,3 +507,26 @@ def test_length_classes_give_identical_results_and_do_not_pay_for_the_longest(gp
     bad = compare(onames, _align(onames, names, classed[rows]), want,
                   [values[offsets[i]:offsets[i + 1]].astype(np.float64) for i in rows])
     assert not bad, bad[:8]
+
+
+def test_number_cwt_peaks_on_long_series_matches_oracle(gpu):
+    """n > ~1400: the SNR filter's noise percentile comes from the sliding rank bitmap (fam_cwt.h phase C).  Lengths
+    around the workgroup / bitmap-word boundaries, powers of two, walks and noise, float32 and float64."""
+    rng = np.random.default_rng(31)
+    lens = [1500, 2048, 2049, 3000, 4095, 4096, 4097, 5000, 6143, 7777, 8191, 8192]
+    params = {"number_cwt_peaks": [{"n": 1}, {"n": 5}]}
+    for dtype in (np.float32, np.float64):
+        chunks = []
+        for i, n in enumerate(lens):
+            x = rng.standard_normal(n)
+            if i % 3 == 1:
+                x = np.cumsum(x)
+            if i % 3 == 2:
+                x = np.sin(np.arange(n) * 0.01) + 0.3 * x
+            chunks.append(x.astype(dtype))
+        values = np.concatenate(chunks)
+        offsets = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
+        names, got = hip_engine(params, values, offsets)
+        onames, want = oracle_engine(params, values.astype(np.float64), offsets)
+        assert names == onames
+        assert np.array_equal(got, want), (dtype.__name__, got.T, want.T)

@@ -266,27 +266,41 @@ TSFA_DEV void friedrich_coeffs(const Blk &b, XS xs, int n, S1 srt1, int m, int r
     // bin index = #{edges < x} - 1, with x == edges[0] -> bin 0  (pandas _bins_to_cuts, right=True, include_lowest)
 #if TSFA_GPU
     {
-        // lane = bin: every lane walks the samples in index order and keeps those of ITS bin (edges[j] < x <= edges[j+1]),
-        // the wavefronts split the index range and add their partial sums in wavefront order -- the same additions in
-        // the same order on every run (LDS float atomics made the last bits depend on the scheduling)
-        const int lane = b.tid & 63, wv = b.tid >> 6, nw = b.nt >> 6;
-        const int per = (ns + nw - 1) / nw;
-        const int i0 = wv * per, i1 = (i0 + per < ns) ? i0 + per : ns;
-        const bool mine = lane < r;
-        const double e_lo = mine ? edges[lane] : 0.0, e_hi = mine ? edges[lane + 1] : 0.0, e0 = edges[0];
-        double ax = 0.0, ay = 0.0, ac = 0.0;
-        for (int i = i0; i < i1; ++i) {
+        // Bin sums by LDS atomics, made independent of the order in which the threads arrive: the addends are converted
+        // to 64-bit fixed point (a power-of-two scale chosen so that even the sum of all |values| stays below 2^61) and
+        // added as integers -- exact, hence associative.  The quantum is 2^-(61 - log2 n) of max|x| (1e-15 at n = 1024),
+        // the precision a float64 sum of these values has anyway; float atomics made the last bits of the Friedrich
+        // coefficients differ from run to run.
+        double amax = fmax(fabs(srt1(0)), fabs(srt1(ns - 1)));
+        amax = fmax(amax, fabs(xs[n - 1]));
+        int e2 = 0, bits = 1;
+        (void)frexp(amax, &e2);              // amax < 2^e2, |delta| < 2^(e2 + 1)
+        while ((1 << bits) < n) ++bits;
+        const double scale = ldexp(1.0, 60 - bits - e2), inv_scale = ldexp(1.0, -(60 - bits - e2));
+        unsigned long long *isx = (unsigned long long *)(void *)sx, *isy = (unsigned long long *)(void *)sy,
+                           *icnt = (unsigned long long *)(void *)cnt;
+        for (int i = b.tid; i < ns; i += b.nt) {
             const double x = xs[i];
-            const double dlt = xs[i + 1] - x;
-            const bool in = mine && ((x > e_lo && x <= e_hi) || (lane == 0 && x == e0));
-            ax += in ? x : 0.0;
-            ay += in ? dlt : 0.0;
-            ac += in ? 1.0 : 0.0;
+            int lo = 0, hi = r + 1;  // count of edges < x
+            while (lo < hi) {
+                const int mid = (lo + hi) >> 1;
+                if (edges[mid] < x) lo = mid + 1; else hi = mid;
+            }
+            int bin = lo - 1;
+            if (x == edges[0]) bin = 0;
+            if (bin < 0 || bin >= r) continue;
+            const double dlt = xs[i + 1] - xs[i];
+            atomicAdd(&isx[bin], (unsigned long long)(long long)rint(x * scale));
+            atomicAdd(&isy[bin], (unsigned long long)(long long)rint(dlt * scale));
+            atomicAdd(&icnt[bin], 1ULL);
         }
-        for (int w = 0; w < nw; ++w) {
-            if (wv == w && mine) { sx[lane] += ax; sy[lane] += ay; cnt[lane] += ac; }
-            blk_sync();
+        blk_sync();
+        for (int j = b.tid; j < r; j += b.nt) {  // back to float64 sums (0.0 bit pattern == integer 0: empty bins stay 0)
+            const double vx = (double)(long long)isx[j] * inv_scale, vy = (double)(long long)isy[j] * inv_scale;
+            const double vc = (double)icnt[j];
+            sx[j] = vx; sy[j] = vy; cnt[j] = vc;
         }
+        blk_sync();
     }
 #else
     for (int i = b.tid; i < ns; i += b.nt) {
