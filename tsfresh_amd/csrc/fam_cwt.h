@@ -265,139 +265,73 @@ TSFA_DEV double number_cwt_peaks_one(const Blk &b, X xv, int n, int W, const Cwt
         int np2 = 1;
         while (np2 < n) np2 <<= 1;
         blk_argsort_u16(b, L.row0, n, order, np2);
+        TSFA_TICK(tk, b, 154);
 #if TSFA_GPU
         {
-            // Sliding rank bitmap.  What the filter needs of a ridge line is (column, row) of its end point, so the lines
-            // are first summarised as need[c] = set of rows of the qualifying lines that end in column c (`mask` is dead
-            // after phase B; lcol / linf are dead once need[] is built).  Every wavefront then walks ITS quarter of the
-            // columns from left to right keeping a bitmap over RANK space (bit r set <=> the column of rank r lies in the
-            // current noise window): moving the window costs one LDS atomic per entering / leaving column, and the
-            // percentile is the i0-th set bit -- popcounts, one wavefront prefix sum, a 6-step bit select -- instead of a
-            // walk over ~0.1 n entries of the global order per line (5.5 M -> 0.7 M cycles per 8192-sample series).
+            // lane = line.  All lanes walk the SAME global order from the smallest value (64 entries per load, handed
+            // round with v_readlane: the entry is wave-uniform, the window test is per lane) and count the entries whose
+            // column falls into their own line's window until they have seen the i0-th and (i0 + 1)-th: ~0.1 n entries
+            // for 64 lines at once.  (One wavefront per line with a ballot per 64 entries -- the first version -- spent
+            // 5.5 M cycles per 8192-sample series here; this is 7 compares / adds per entry for 64 lines.)
             const int lane = b.tid & 63, wave = b.tid >> 6, nwv = b.nt >> 6;
-            unsigned short *need = L.mask;
-            unsigned int *need32 = (unsigned int *)(void *)L.mask;
-            blk_sync();
-            for (int c = b.tid; c < (n + 1) / 2; c += b.nt) need32[c] = 0u;
-            blk_sync();
-            for (int l = b.tid; l < nlines; l += b.nt) {
-                const unsigned short v = L.linf[l];
-                if (TSFA_LI_LEN(v) < min_length) continue;
-                const int col = L.lcol[l];
-                atomicOr(&need32[col >> 1], (1u << TSFA_LI_ROW(v)) << ((col & 1) * 16));
-            }
-            blk_sync();
-            unsigned short *rank = L.lcol;  // rank[c] = position of column c in the ascending order of row 0
-            for (int e = b.tid; e < n; e += b.nt) rank[order[e]] = (unsigned short)e;
-            const int nwords = (n + 63) >> 6;
-            const int WPL = (nwords + 63) >> 6;  // bitmap words per lane
-            unsigned long long *bm = (unsigned long long *)(void *)L.linf + (size_t)wave * nwords;  // nwv * n / 8 <= 2 n bytes
-            blk_sync();
-            for (int j = lane; j < nwords; j += 64) bm[j] = 0ull;
-            const int cs = (int)((long long)n * wave / nwv), ce = (int)((long long)n * (wave + 1) / nwv);
-            int ws_cur = 0, we_cur = 0;
-            for (int cb = cs; cb < ce; cb += 64) {
-                const int cc = cb + lane;
-                unsigned long long todo = __ballot(cc < ce && need[cc < n ? cc : 0] != 0);
-                while (todo) {
-                    const int col = cb + __ffsll((long long)todo) - 1;
-                    todo &= todo - 1;
-                    const unsigned rows = need[col];
-                    const int ws = (col - hf > 0) ? col - hf : 0;
-                    const int we = (col + hf + odd < n) ? col + hf + odd : n;
-                    if (ws >= we_cur) {  // disjoint from the previous window: start over
-                        for (int j = lane; j < nwords; j += 64) bm[j] = 0ull;
-                        ws_cur = we_cur = ws;
+            for (int l0 = wave * 64; l0 < nlines; l0 += nwv * 64) {  // wave-uniform
+                const int l = l0 + lane;
+                const unsigned short v = (l < nlines) ? L.linf[l] : 0;
+                const bool live = (l < nlines) && (TSFA_LI_LEN(v) >= min_length);
+                const int col = live ? (int)L.lcol[l] : 0, row = TSFA_LI_ROW(v);
+                const int ws = (col - hf > 0) ? col - hf : 0;
+                const int we = (col + hf + odd < n) ? col + hf + odd : n;
+                const int m = we - ws;
+                const double idx = 10.0 / 100.0 * (double)(m - 1);
+                const int i0 = (int)idx;
+                int count = live ? 0 : (1 << 30), p0 = 0, p1 = 0;
+                for (int base = 0; base < n; base += 64) {
+                    if (!__ballot(count <= i0 + 1)) break;
+                    const int e = base + lane;
+                    const int pe = (e < n) ? (int)order[e] : 0xFFFF;
+                    const int lim = (n - base < 64) ? n - base : 64;
+                    for (int j = 0; j < lim; ++j) {
+                        const int p = __builtin_amdgcn_readlane(pe, j);
+                        const bool in = (p >= ws) & (p < we);
+                        p0 = (in & (count == i0)) ? p : p0;
+                        p1 = (in & (count == i0 + 1)) ? p : p1;
+                        count += in ? 1 : 0;
                     }
-                    for (int base = ws_cur; base < ws; base += 64) {
-                        const int p = base + lane;
-                        if (p < ws) { const unsigned r = rank[p]; atomicAnd(&bm[r >> 6], ~(1ull << (r & 63))); }
-                    }
-                    for (int base = we_cur; base < we; base += 64) {
-                        const int p = base + lane;
-                        if (p < we) { const unsigned r = rank[p]; atomicOr(&bm[r >> 6], 1ull << (r & 63)); }
-                    }
-                    ws_cur = ws;
-                    we_cur = we;
-                    const int m = we - ws;
-                    const double idx = 10.0 / 100.0 * (double)(m - 1);
-                    const int i0 = (int)idx;
-                    // the i0-th and (i0 + 1)-th set bits
-                    int pc = 0;
-                    for (int j = 0; j < WPL; ++j) {
-                        const int wi = lane * WPL + j;
-                        pc += (wi < nwords) ? __popcll(bm[wi]) : 0;
-                    }
-                    int incl = pc;
-#pragma unroll
-                    for (int o = 1; o < 64; o <<= 1) {
-                        const int t = __shfl_up(incl, o);
-                        if (lane >= o) incl += t;
-                    }
-                    const int excl = incl - pc;
-                    double sq[2] = {0.0, 0.0};
-#pragma unroll
-                    for (int q = 0; q < 2; ++q) {
-                        const int k = i0 + q;
-                        const unsigned long long hit = __ballot(excl <= k && k < incl);
-                        if (!hit) continue;
-                        const int src = __ffsll((long long)hit) - 1;
-                        int r = 0;
-                        if (lane == src) {
-                            int kk = k - excl;
-                            for (int j = 0; j < WPL; ++j) {
-                                const int wi = lane * WPL + j;
-                                const unsigned long long w = (wi < nwords) ? bm[wi] : 0ull;
-                                const int c = __popcll(w);
-                                if (kk < c) {
-                                    int pos = 0;
-#pragma unroll
-                                    for (int sft = 32; sft > 0; sft >>= 1) {
-                                        const int cl = __popcll(w & (((1ull << sft) - 1ull) << pos));
-                                        if (kk >= cl) { kk -= cl; pos += sft; }
-                                    }
-                                    r = wi * 64 + pos;
-                                    break;
-                                }
-                                kk -= c;
-                            }
-                        }
-                        r = __shfl(r, src);
-                        sq[q] = L.row0[order[r]];
-                    }
+                }
+                TSFA_TICK(tk, b, 155);
+                if (live) {
+                    const double s0 = L.row0[p0], s1 = L.row0[p1];
                     double noise;
                     if ((double)i0 == idx) {
-                        noise = sq[0];
+                        noise = s0;
                     } else {
                         const double j = (double)(i0 + 1);
                         const double w0 = j - idx, w1 = idx - (double)i0;
-                        noise = (sq[0] * w0 + sq[1] * w1) / (w0 + w1);
+                        noise = (s0 * w0 + s1 * w1) / (w0 + w1);
                     }
-                    for (unsigned rb = rows; rb; rb &= rb - 1) {
-                        const int row = __ffs((int)rb) - 1;
-                        double sig;
-                        if (row == 0) {
-                            sig = L.row0[col];
+                    double sig;
+                    if (row == 0) {
+                        sig = L.row0[col];
+                    } else {
+                        const int w = row + 1;
+                        const int nw = (10 * w < n) ? 10 * w : n;
+                        const int m2 = col + (nw - 1) / 2;
+                        int k0 = m2 - (n - 1);
+                        if (k0 < 0) k0 = 0;
+                        const int k1 = (m2 < nw - 1) ? m2 : (nw - 1);
+                        double acc = 0.0;
+                        if (taps_cached) {
+                            const double *tw = L.taps + 5 * (w - 2) * (w + 1);
+                            for (int k = k1; k >= k0; --k) acc += xv(m2 - k) * tw[k];
                         } else {
-                            const int w = row + 1;
-                            const int nw = (10 * w < n) ? 10 * w : n;
-                            const int m2 = col + (nw - 1) / 2;
-                            int k0 = m2 - (n - 1);
-                            if (k0 < 0) k0 = 0;
-                            const int k1 = (m2 < nw - 1) ? m2 : (nw - 1);
-                            double acc = 0.0;
-                            if (taps_cached) {
-                                const double *tw = L.taps + 5 * (w - 2) * (w + 1);
-                                for (int k = k1; k >= k0; --k) acc += xv(m2 - k) * tw[k];
-                            } else {
-                                for (int k = k1; k >= k0; --k) acc += xv(m2 - k) * ricker_tap(nw, (double)w, nw - 1 - k);
-                            }
-                            sig = acc;
+                            for (int k = k1; k >= k0; --k) acc += xv(m2 - k) * ricker_tap(nw, (double)w, nw - 1 - k);
                         }
-                        const double snr = fabs(sig / noise);
-                        if (!(snr < 1.0) && lane == 0) kept += 1.0;
+                        sig = acc;
                     }
+                    const double snr = fabs(sig / noise);
+                    if (!(snr < 1.0)) kept += 1.0;
                 }
+                TSFA_TICK(tk, b, 156);
             }
             kept = blk_sum(b, kept);
             TSFA_TICK(tk, b, 153);

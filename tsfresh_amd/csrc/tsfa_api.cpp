@@ -421,6 +421,15 @@ static int run_batch(tsfa_plan *plan, const void *d_values, int dtype, const dou
             a.ld = ld;
             a.maxn = maxn;
             a.nt = (maxn <= 2048) ? 64 : 256;
+            if (maxn > 2048) {
+                // Long series: the LDS footprint leaves ONE workgroup per CU, so the wavefronts of that workgroup are all
+                // the latency hiding there is.  Measured (profiles/nt_sweep.sh, 5 000 series, lengths 4096..8192 /
+                // 2049..4096): number_cwt_peaks gains up to 1024 threads (31.6 -> 12.3 ms), the others peak at 512
+                // beyond 4096 samples and at 256 below (more barriers than work).
+                static const int nt_8k[TSFA_N_FAMILIES] = {512, 512, 512, 512, 256, 1024, 256, 256};
+                static const int nt_4k[TSFA_N_FAMILIES] = {256, 256, 256, 256, 256, 512, 256, 256};
+                a.nt = (maxn > 4096) ? nt_8k[f] : nt_4k[f];
+            }
             if (maxn <= 2048) {
                 // Wavefronts per series, measured on MI355X at n = 1024 (profiles/r01_*): the LDS footprint of a series
                 // caps the workgroups per CU, so the latency-bound families gain from more wavefronts per workgroup,

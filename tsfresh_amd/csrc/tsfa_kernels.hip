@@ -50,7 +50,7 @@ __device__ __forceinline__ void basic_body(const T *__restrict__ values, const i
 }
 
 template <typename T>
-__global__ void __launch_bounds__(256, 4) k_basic(const T *__restrict__ values, const int64_t *__restrict__ starts, const int64_t *__restrict__ ends, int64_t n_series, const int *__restrict__ sel,
+__global__ void __launch_bounds__(1024) k_basic(const T *__restrict__ values, const int64_t *__restrict__ starts, const int64_t *__restrict__ ends, int64_t n_series, const int *__restrict__ sel,
                         const TsfaSpec *__restrict__ specs, int nspecs, double *__restrict__ out, int64_t ld,
                         const double *__restrict__ dectab, int maxn, int hint_a, int n_loop, int n_count, int n_sum) {
     TsfaAltPlan alt;
@@ -60,14 +60,14 @@ __global__ void __launch_bounds__(256, 4) k_basic(const T *__restrict__ values, 
 }
 
 template <typename T>
-__global__ void __launch_bounds__(256, 2) k_trend(const T *__restrict__ values, const int64_t *__restrict__ starts, const int64_t *__restrict__ ends, int64_t n_series, const int *__restrict__ sel,
+__global__ void __launch_bounds__(512) k_trend(const T *__restrict__ values, const int64_t *__restrict__ starts, const int64_t *__restrict__ ends, int64_t n_series, const int *__restrict__ sel,
                         const TsfaSpec *__restrict__ specs, int nspecs, double *__restrict__ out, int64_t ld, int maxn,
                         int hint_b, const double *__restrict__ times, const TsfaAltPlan alt, int n_loop) {
     basic_body<T, 2>(values, starts, ends, n_series, sel, specs, nspecs, out, ld, nullptr, maxn, 0, hint_b, times, alt, n_loop, 0, 0);
 }
 
 template <typename T>
-__global__ void __launch_bounds__(256, 4) k_sort(const T *__restrict__ values, const int64_t *__restrict__ starts, const int64_t *__restrict__ ends, int64_t n_series, const int *__restrict__ sel,
+__global__ void __launch_bounds__(1024) k_sort(const T *__restrict__ values, const int64_t *__restrict__ starts, const int64_t *__restrict__ ends, int64_t n_series, const int *__restrict__ sel,
                        const TsfaSpec *__restrict__ specs, int nspecs, double *__restrict__ out, int64_t ld, int maxn,
                        const TsfaCqPlan cqplan, int n_loop, int w_doubles) {
     if ((int64_t)blockIdx.x >= n_series) return;
@@ -90,7 +90,7 @@ __global__ void __launch_bounds__(256, 4) k_sort(const T *__restrict__ values, c
 }
 
 template <typename T>
-__global__ void __launch_bounds__(256) k_spectral(const T *__restrict__ values, const int64_t *__restrict__ starts, const int64_t *__restrict__ ends, int64_t n_series, const int *__restrict__ sel,
+__global__ void __launch_bounds__(1024) k_spectral(const T *__restrict__ values, const int64_t *__restrict__ starts, const int64_t *__restrict__ ends, int64_t n_series, const int *__restrict__ sel,
                            const TsfaSpec *__restrict__ specs, int nspecs, double *__restrict__ out, int64_t ld,
                            int maxn, int dft_n, double *__restrict__ gscratch, int gscratch_n,
                            const double *__restrict__ twc, const double *__restrict__ tws, int hint_a, int hint_b) {
@@ -119,7 +119,7 @@ __global__ void __launch_bounds__(256) k_spectral(const T *__restrict__ values, 
 }
 
 template <typename T>
-__global__ void __launch_bounds__(256) k_ar(const T *__restrict__ values, const int64_t *__restrict__ starts, const int64_t *__restrict__ ends, int64_t n_series, const int *__restrict__ sel,
+__global__ void __launch_bounds__(1024) k_ar(const T *__restrict__ values, const int64_t *__restrict__ starts, const int64_t *__restrict__ ends, int64_t n_series, const int *__restrict__ sel,
                      const TsfaSpec *__restrict__ specs, int nspecs, double *__restrict__ out, int64_t ld, int maxn,
                      int P, int hint_acf, int hint_pacf, int hint_adf, int n_loop, long long *__restrict__ deg_list,
                      int *__restrict__ deg_count) {
@@ -163,7 +163,7 @@ __global__ void __launch_bounds__(64) k_ar_degenerate(const T *__restrict__ valu
 
 // FAST: symmetric sweep only (m = 2 specs, LDS counters fit) -- see fam_entropy_series
 template <typename T, bool FAST>
-__global__ void __launch_bounds__(256, 4) k_entropy(const T *__restrict__ values, const int64_t *__restrict__ starts, const int64_t *__restrict__ ends, int64_t n_series, const int *__restrict__ sel,
+__global__ void __launch_bounds__(1024) k_entropy(const T *__restrict__ values, const int64_t *__restrict__ starts, const int64_t *__restrict__ ends, int64_t n_series, const int *__restrict__ sel,
                           const TsfaSpec *__restrict__ specs, int nspecs, double *__restrict__ out, int64_t ld,
                           int maxn, int with_cnt) {
     if ((int64_t)blockIdx.x >= n_series) return;
@@ -196,7 +196,7 @@ __global__ void __launch_bounds__(256) k_seq(const T *__restrict__ values, const
 }
 
 template <typename T>
-__global__ void __launch_bounds__(256) k_cwtpeaks(const T *__restrict__ values, const int64_t *__restrict__ starts, const int64_t *__restrict__ ends, int64_t n_series, const int *__restrict__ sel,
+__global__ void __launch_bounds__(1024) k_cwtpeaks(const T *__restrict__ values, const int64_t *__restrict__ starts, const int64_t *__restrict__ ends, int64_t n_series, const int *__restrict__ sel,
                            const TsfaSpec *__restrict__ specs, int nspecs, double *__restrict__ out, int64_t ld,
                            int maxn, int with_rowv) {
     if ((int64_t)blockIdx.x >= n_series) return;
