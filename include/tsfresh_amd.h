@@ -217,6 +217,15 @@ int tsfa_relevance_real(const double *X, int64_t n_rows, int64_t n_cols, int64_t
  * scipy.stats.ks_2samp(method="exact") -- a scalar function of four integers (host arithmetic, no device needed). */
 double tsfa_ks_outer_prob(int64_t m, int64_t n, int64_t g, int64_t h);
 
+/* ---- impute: tsfresh/utilities/dataframe_functions.py:49-214 on the feature matrix ----
+ * Per column: the largest / smallest / median FINITE value (get_range_values_per_column :142-180; a column without a
+ * finite value counts as zeros); then, in place, +inf -> max, -inf -> min, NaN -> median (impute_dataframe_range
+ * :96-139).  X: row-major float64 [n_rows x n_cols], leading dimension ld, host or device memory (`space`).
+ * col_max / col_min / col_median / finite_count: optional host arrays [n_cols] receiving the statistics and the number
+ * of finite cells per column (0: the reference warns and fills with zeros).  Synchronous. */
+int tsfa_impute(double *X, int64_t n_rows, int64_t n_cols, int64_t ld, int32_t space, int32_t device, double *col_max,
+                double *col_min, double *col_median, int32_t *finite_count);
+
 #ifdef __cplusplus
 }
 #endif

@@ -52,3 +52,86 @@ def test_map_reduce_returns_the_reference_tuples(gpu):
                              distributor=GPUDistributor(device=0))
     for (sid, name), v in got.items():
         assert feats.loc[sid, name] == v
+
+
+def _load_real_tsfresh():
+    """Stub-load /root/reference as tests/golden/gen_golden_main.py does (pywt / statsmodels / stumpy are missing in the
+    main interpreter); None when the reference tree is absent (the GPU box)."""
+    import os
+    import sys
+    import types
+    if not os.path.isdir("/root/reference/tsfresh"):
+        return None
+
+    class _Raiser(types.ModuleType):
+        def __getattr__(self, item):
+            if item.startswith("__"):
+                raise AttributeError(item)
+
+            def _fail(*a, **k):
+                raise RuntimeError("stubbed third-party module %s.%s was called" % (self.__name__, item))
+            return _fail
+    for mod in ("pywt", "stumpy", "statsmodels", "statsmodels.tools", "statsmodels.tools.sm_exceptions", "statsmodels.tsa",
+                "statsmodels.tsa.ar_model", "statsmodels.tsa.stattools", "statsmodels.stats", "statsmodels.stats.multitest"):
+        sys.modules.setdefault(mod, _Raiser(mod))
+    sys.modules["statsmodels.tools.sm_exceptions"].MissingDataError = type("MissingDataError", (Exception,), {})
+    if "/root/reference" not in sys.path:
+        sys.path.insert(0, "/root/reference")
+    import tsfresh
+    return tsfresh
+
+
+def test_the_real_reference_pipeline_drives_the_distributor():
+    """tsfresh.extract_features(distributor=...) -- the REFERENCE's own to_tsdata / _do_extraction / pivot
+    (extraction.py:193-305, data.py:86-121) -- with a GPUDistributor whose matrix comes from the g++ build of the kernel
+    sources (no GPU in this container; the class under test is the product's, only `_extract_matrix` is swapped).  The
+    frame must carry the reference's columns and index, and the oracle's numbers, by column name
+    (tests/units/feature_extraction/test_extraction.py:292-318 style).  Build container only."""
+    tsfresh = _load_real_tsfresh()
+    if tsfresh is None:
+        pytest.skip("/root/reference is not present on this box")
+    import importlib
+    import warnings
+
+    import tsfresh_amd.utilities.distribution as dmod
+    importlib.reload(dmod)  # pick up tsfresh's DistributorBaseClass now that tsfresh is importable
+    from tsfresh.feature_extraction import extract_features as ref_extract_features
+    from tsfresh.feature_extraction import settings as ref_settings
+    from tsfresh.utilities.distribution import DistributorBaseClass
+
+    from emul_lib import emul_extract
+    from engines import oracle_engine
+    from parity import compare
+
+    class EmulDistributor(dmod.GPUDistributor):
+        def _extract_matrix(self, fc_parameters, values, offsets, times, has_dt):
+            names, matrix = emul_extract(fc_parameters, values, offsets, kind="k", times=times)
+            return [n[len("k__"):] for n in names], matrix
+
+    assert issubclass(dmod.GPUDistributor, DistributorBaseClass)
+    rng = np.random.default_rng(12)
+    lens = [60, 75, 64, 90, 128]
+    ids = [11, 3, 7, 5, 9]
+    frames = []
+    for sid, n in zip(ids, lens):
+        frames.append(pd.DataFrame({"id": sid, "time": np.arange(n), "a": rng.standard_normal(n),
+                                    "b": np.cumsum(rng.standard_normal(n))}))
+    df = pd.concat(frames, ignore_index=True)
+    params = ref_settings.ComprehensiveFCParameters()
+    for k in ("cwt_coefficients", "agg_autocorrelation", "partial_autocorrelation", "augmented_dickey_fuller", "ar_coefficient"):
+        del params[k]  # their third-party modules are stubs here; the oracle comparison below does not need them
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        got = ref_extract_features(df, column_id="id", column_sort="time", default_fc_parameters=params,
+                                   distributor=EmulDistributor(), disable_progressbar=True)
+        want_ref = ref_extract_features(df, column_id="id", column_sort="time", default_fc_parameters=params, n_jobs=0,
+                                        disable_progressbar=True)
+    assert list(got.index) == sorted(ids) and got.index.dtype == want_ref.index.dtype
+    assert set(got.columns) == set(want_ref.columns) and got.shape == want_ref.shape
+    # the numbers: against the reference's own serial run, column by column
+    for kind in ("a", "b"):
+        cols = [c for c in want_ref.columns if c.startswith(kind + "__")]
+        series = [df.loc[df.id == sid, kind].to_numpy() for sid in sorted(ids)]
+        names = ["value__" + c[len(kind) + 2:] for c in cols]
+        bad = compare(names, got[cols].to_numpy(), want_ref[cols].to_numpy(), series, simd_golden=True)
+        assert not bad, (kind, bad[:6])

@@ -52,3 +52,39 @@ def test_impute_errors():
     with pytest.raises(ValueError, match="must not contain NaN"):
         ours.check_for_nans_in_columns(df)
     assert len(ours.impute(df.iloc[:0])) == 0
+
+
+@pytest.mark.gpu
+def test_device_impute_matches_the_reference_and_the_numpy_path(gpu):
+    """tsfa_impute (column sort in HBM: max / min / median of the finite values, in-place patch) against the real
+    reference's output (ref_impute.json) and, on a matrix large enough to take the device route through impute(),
+    against the numpy restatement."""
+    from tsfresh_amd import _native
+    golden = json.load(open(os.path.join(G, "ref_impute.json")))
+    x = np.ascontiguousarray(_frame().to_numpy())
+    mx, mn, med, cnt = _native.impute_matrix(x, device=0)
+    cols = list("abcdef")
+    assert dict(zip(cols, mx.tolist())) == golden["range"]["max"]
+    assert dict(zip(cols, mn.tolist())) == golden["range"]["min"]
+    assert dict(zip(cols, med.tolist())) == golden["range"]["median"]
+    assert x.tolist() == golden["impute"] and cnt.tolist()[1] == 0
+    rng = np.random.default_rng(5)
+    big = rng.standard_normal((5000, 40))
+    big[rng.random(big.shape) < 0.02] = np.nan
+    big[rng.random(big.shape) < 0.01] = np.inf
+    big[rng.random(big.shape) < 0.01] = -np.inf
+    big[:, 7] = np.nan
+    big[:, 9] = 3.0
+    df_dev = pd.DataFrame(big.copy(), columns=["c%d" % i for i in range(40)])
+    df_cpu = df_dev.copy()
+    assert df_dev.size >= ours._DEVICE_IMPUTE_MIN_CELLS
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter("always")
+        ours.impute(df_dev)
+    assert any("did not have any finite values" in str(m.message) for m in w)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        mx, mn, med = ours.get_range_values_per_column(df_cpu)
+        ours.impute_dataframe_range(df_cpu, mx, mn, med)
+    assert np.isfinite(df_dev.to_numpy()).all()
+    assert np.array_equal(df_dev.to_numpy(), df_cpu.to_numpy())

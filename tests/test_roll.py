@@ -103,6 +103,29 @@ def test_extract_rolled_features_equals_extraction_on_the_rolled_frame(gpu):
         assert np.array_equal(np.isnan(a), np.isnan(b)) and np.array_equal(np.nan_to_num(a), np.nan_to_num(b))
 
 
+@pytest.mark.gpu
+def test_extract_rolled_features_rolls_every_dict_entry_with_its_own_steps(gpu):
+    """A dict container is rolled entry by entry (dataframe_functions.py:430-445), each with the longest series of ITS
+    frame as prediction_steps: with a positive direction of 3 the shift sets differ between the two entries."""
+    from tsfresh_amd import MinimalFCParameters, extract_features, extract_rolled_features
+    rng = np.random.default_rng(6)
+    frames = {}
+    for kind, lens in (("a", [31, 20]), ("b", [47, 40])):
+        frames[kind] = pd.concat([pd.DataFrame({"id": sid, "time": np.arange(L), "value": rng.standard_normal(L)})
+                                  for sid, L in enumerate(lens)], ignore_index=True)
+    params = MinimalFCParameters()
+    kw = dict(rolling_direction=3, max_timeshift=12, min_timeshift=2)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        rolled = roll_time_series(frames, "id", "time", **kw)
+        want = extract_features(rolled, column_id="id", column_sort="time", column_value="value", default_fc_parameters=params)
+        got = extract_rolled_features(frames, column_id="id", column_sort="time", column_value="value",
+                                      default_fc_parameters=params, **kw)
+    assert list(got.index) == list(want.index) and list(got.columns) == list(want.columns)
+    a, b = got.to_numpy(), want.to_numpy()
+    assert np.array_equal(np.isnan(a), np.isnan(b)) and np.array_equal(np.nan_to_num(a), np.nan_to_num(b))
+
+
 def test_make_forecasting_frame_matches_the_reference():
     from forecasting_cases import forecasting_cases
     from tsfresh_amd.utilities.dataframe_functions import make_forecasting_frame

@@ -35,6 +35,7 @@ EXPORTS = (
     "tsfa_host_free",
     "tsfa_pack_scan",
     "tsfa_pack_offsets",
+    "tsfa_impute",
     "tsfa_relevance_classes",
     "tsfa_relevance_classes_ks",
     "tsfa_relevance_real",
@@ -416,6 +417,25 @@ def relevance_real(X, y, device=0):
                                         y_end.ctypes.data_as(ctypes.c_void_p), int(device),
                                         cols.ctypes.data_as(ctypes.c_void_p)))
     return cols[:m], y_rank
+
+
+def impute_matrix(X, device=0):
+    """In-place impute of the C-contiguous-row float64 matrix X on the device (tsfa_impute).
+    -> (col_max, col_min, col_median of the finite values, number of finite cells per column)."""
+    lib = load()
+    if not (isinstance(X, np.ndarray) and X.dtype == np.float64 and X.ndim == 2 and X.flags.writeable
+            and (X.shape[1] == 0 or X.strides[1] == 8) and X.strides[0] % 8 == 0 and X.strides[0] >= 8 * X.shape[1]):
+        raise ValueError("impute_matrix needs a writeable float64 matrix with contiguous rows")
+    n, m = X.shape
+    cmax, cmin, cmed = (np.zeros(m) for _ in range(3))
+    cnt = np.zeros(m, dtype=np.int32)
+    lib.tsfa_impute.restype = ctypes.c_int32
+    lib.tsfa_impute.argtypes = [ctypes.c_void_p, ctypes.c_int64, ctypes.c_int64, ctypes.c_int64, ctypes.c_int32, ctypes.c_int32,
+                                ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]
+    _check(lib, lib.tsfa_impute(X.ctypes.data_as(ctypes.c_void_p), n, m, X.strides[0] // 8 if n else m, TSFA_HOST, int(device),
+                                cmax.ctypes.data_as(ctypes.c_void_p), cmin.ctypes.data_as(ctypes.c_void_p),
+                                cmed.ctypes.data_as(ctypes.c_void_p), cnt.ctypes.data_as(ctypes.c_void_p)))
+    return cmax, cmin, cmed, cnt
 
 
 def ks_outer_prob(m, n, g, h):

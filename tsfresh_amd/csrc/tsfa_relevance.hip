@@ -539,6 +539,122 @@ done:
     return rc;
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// impute (tsfresh/utilities/dataframe_functions.py:49-214): per column the largest / smallest / median FINITE value
+// (get_range_values_per_column :142-180: np.ma.masked_invalid + np.max / np.min / np.ma.median; a column without any
+// finite value counts as all zeros), then +inf -> max, -inf -> min, NaN -> median (impute_dataframe_range :96-139).
+// The column statistics come from the same staged HBM sort as the relevance tests: non-finite cells are staged as +inf
+// and therefore sort behind the `cnt` finite ones.
+// ---------------------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(REL_NT) k_imp_stage(const double *__restrict__ X, int64_t n, int64_t ld, int64_t c0,
+                                                       double *__restrict__ keys, uint32_t *__restrict__ idx, int64_t np2,
+                                                       int *__restrict__ finite_cnt) {
+    const int64_t c = blockIdx.x;
+    double *K = keys + c * np2;
+    uint32_t *I = idx + c * np2;
+    const double *col = X + c0 + c;
+    int cnt = 0;
+    for (int64_t r = threadIdx.x; r < np2; r += REL_NT) {
+        double v = __builtin_inf();
+        if (r < n) {
+            const double x = col[r * ld];
+            if (x == x && x != __builtin_inf() && x != -__builtin_inf()) { v = x; ++cnt; }
+        }
+        K[r] = v;
+        I[r] = (uint32_t)r;
+    }
+    __shared__ int red[REL_NT / 64];
+    for (int o = 32; o > 0; o >>= 1) cnt += __shfl_xor(cnt, o);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = cnt;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        int t = 0;
+        for (int w = 0; w < REL_NT / 64; ++w) t += red[w];
+        finite_cnt[c0 + c] = t;
+    }
+}
+
+__global__ void k_imp_stats(const double *__restrict__ keys, int64_t np2, const int *__restrict__ finite_cnt, int64_t c0, int64_t nb,
+                            double *__restrict__ cmax, double *__restrict__ cmin, double *__restrict__ cmed) {
+    const int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= nb) return;
+    const double *K = keys + c * np2;
+    const int cnt = finite_cnt[c0 + c];
+    double mx = 0.0, mn = 0.0, md = 0.0;
+    if (cnt > 0) {
+        mn = K[0];
+        mx = K[cnt - 1];
+        md = (cnt & 1) ? K[cnt / 2] : (K[cnt / 2 - 1] + K[cnt / 2]) / 2.0;  // np.ma.median: mean of the two middle values
+    }
+    cmax[c0 + c] = mx;
+    cmin[c0 + c] = mn;
+    cmed[c0 + c] = md;
+}
+
+__global__ void __launch_bounds__(256) k_imp_apply(double *__restrict__ X, int64_t n, int64_t ld, int64_t n_cols,
+                                                   const double *__restrict__ cmax, const double *__restrict__ cmin,
+                                                   const double *__restrict__ cmed) {
+    const int64_t total = n * n_cols;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t r = i / n_cols, c = i - r * n_cols;
+        const double v = X[r * ld + c];
+        if (v != v) X[r * ld + c] = cmed[c];
+        else if (v == __builtin_inf()) X[r * ld + c] = cmax[c];
+        else if (v == -__builtin_inf()) X[r * ld + c] = cmin[c];
+    }
+}
+
+extern "C" int tsfa_impute(double *X, int64_t n_rows, int64_t n_cols, int64_t ld, int32_t space, int32_t device,
+                           double *col_max, double *col_min, double *col_median, int32_t *finite_count) {
+    if (!X || n_rows < 0 || n_cols < 0 || ld < n_cols) return tsfa_fail(TSFA_ERR_INVALID, "tsfa_impute: null pointer or bad shape");
+    if (n_rows >= (1ll << 31)) return tsfa_fail(TSFA_ERR_TOO_LONG, "tsfa_impute: more than 2^31 rows");
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1 || device < 0 || device >= ndev)
+        return tsfa_fail(TSFA_ERR_NO_DEVICE, "tsfa_impute: no such HIP device (there is no CPU path)");
+    if (n_cols == 0 || n_rows == 0) return TSFA_OK;
+    int rc = TSFA_OK;
+    int64_t np2 = 2048;
+    while (np2 < n_rows) np2 <<= 1;
+    const int tile = (int)((np2 < REL_TILE) ? np2 : REL_TILE);
+    const int64_t batch = rel_batch_columns(np2, n_cols);
+    double *dX = nullptr, *dkeys = nullptr, *dstat = nullptr;
+    uint32_t *didx = nullptr;
+    int *dcnt = nullptr;
+    double *Xd = X;
+    REL_HIP(hipSetDevice(device));
+    if (space == TSFA_HOST) {
+        REL_HIP(hipMalloc((void **)&dX, (size_t)n_rows * ld * sizeof(double)));
+        REL_HIP(hipMemcpy(dX, X, (size_t)n_rows * ld * sizeof(double), hipMemcpyHostToDevice));
+        Xd = dX;
+    }
+    REL_HIP(hipMalloc((void **)&dkeys, (size_t)batch * np2 * sizeof(double)));
+    REL_HIP(hipMalloc((void **)&didx, (size_t)batch * np2 * sizeof(uint32_t)));
+    REL_HIP(hipMalloc((void **)&dcnt, (size_t)n_cols * sizeof(int)));
+    REL_HIP(hipMalloc((void **)&dstat, (size_t)3 * n_cols * sizeof(double)));
+    {
+        const size_t lds = (size_t)tile * (sizeof(double) + sizeof(uint32_t));
+        REL_HIP(hipFuncSetAttribute((const void *)k_rel_sort, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        for (int64_t c0 = 0; c0 < n_cols; c0 += batch) {
+            const int64_t nb = (n_cols - c0 < batch) ? (n_cols - c0) : batch;
+            k_imp_stage<<<dim3((unsigned)nb), REL_NT, 0, 0>>>(Xd, n_rows, ld, c0, dkeys, didx, np2, dcnt);
+            k_rel_sort<<<dim3((unsigned)nb), REL_NT, lds, 0>>>(dkeys, didx, np2, tile);
+            k_imp_stats<<<dim3((unsigned)((nb + 63) / 64)), 64, 0, 0>>>(dkeys, np2, dcnt, c0, nb, dstat, dstat + n_cols, dstat + 2 * n_cols);
+            REL_HIP(hipGetLastError());
+        }
+        k_imp_apply<<<2048, 256, 0, 0>>>(Xd, n_rows, ld, n_cols, dstat, dstat + n_cols, dstat + 2 * n_cols);
+        REL_HIP(hipGetLastError());
+    }
+    if (col_max) REL_HIP(hipMemcpy(col_max, dstat, (size_t)n_cols * sizeof(double), hipMemcpyDeviceToHost));
+    if (col_min) REL_HIP(hipMemcpy(col_min, dstat + n_cols, (size_t)n_cols * sizeof(double), hipMemcpyDeviceToHost));
+    if (col_median) REL_HIP(hipMemcpy(col_median, dstat + 2 * n_cols, (size_t)n_cols * sizeof(double), hipMemcpyDeviceToHost));
+    if (finite_count) REL_HIP(hipMemcpy(finite_count, dcnt, (size_t)n_cols * sizeof(int), hipMemcpyDeviceToHost));
+    if (space == TSFA_HOST) REL_HIP(hipMemcpy(X, dX, (size_t)n_rows * ld * sizeof(double), hipMemcpyDeviceToHost));
+    REL_HIP(hipDeviceSynchronize());
+done:
+    (void)hipFree(dX); (void)hipFree(dkeys); (void)hipFree(didx); (void)hipFree(dcnt); (void)hipFree(dstat);
+    return rc;
+}
+
 // Pr(D >= h / lcm(m, n)) for the two-sided two-sample Kolmogorov-Smirnov statistic, m != n: the proportion of lattice
 // paths (0,0) -> (m,n) that do not stay strictly inside |x/m - y/n| < h/lcm (Hodges 1958; the column recurrence scipy
 // uses in ks_2samp(method="exact"), computed on the complement so small probabilities keep their relative accuracy).

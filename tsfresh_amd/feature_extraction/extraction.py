@@ -254,8 +254,10 @@ def extract_rolled_features(timeseries_container, column_id=None, column_sort=No
                                           column_value=column_value, column_sort=column_sort)
     if device is None:
         device = _default_device()
-    # prediction_steps is the longest series over ALL ids and kinds (dataframe_functions.py:546)
-    steps = max(int(np.diff(pk.offsets).max()) for pk in packed if pk.n_series)
+    # prediction_steps is the longest series over ALL ids and kinds of ONE frame (dataframe_functions.py:546); a dict
+    # container is rolled entry by entry (:430-445), each entry with the longest series of its own frame
+    per_kind_steps = isinstance(timeseries_container, dict)
+    steps_all = max(int(np.diff(pk.offsets).max()) for pk in packed if pk.n_series)
     blocks, plan_cache = [], {}
     with warnings.catch_warnings():
         warnings.simplefilter("default" if show_warnings else "ignore")
@@ -271,6 +273,7 @@ def extract_rolled_features(timeseries_container, column_id=None, column_sort=No
             if nplan is None:
                 continue
             lengths = np.diff(pk.offsets)
+            steps = int(lengths.max()) if per_kind_steps else steps_all
             # roll_views sizes its shifts from the longest series it is given: append a phantom of `steps` samples
             gi, frm, until, ts = roll_views(np.concatenate([lengths, [steps]]), rolling_direction, max_timeshift, min_timeshift)
             keep = gi < len(lengths)

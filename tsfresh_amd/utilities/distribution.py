@@ -27,49 +27,59 @@ class GPUDistributor(_Base):
     def __init__(self, device=None):
         self.device = device
 
-    def map_reduce(self, map_function=None, data=None, function_kwargs=None, chunk_size=None, data_length=None):
-        from tsfresh_amd import _native
-        from tsfresh_amd.feature_extraction.extraction import _default_device
+    def _extract_matrix(self, fc_parameters, values, offsets, times, has_dt):
+        """-> (column names without the kind prefix, float64 [n_series, n_cols]) through the native plan cache."""
+        from tsfresh_amd import _native  # noqa: F401  (fails loudly without the library: there is no CPU path)
+        from tsfresh_amd.feature_extraction.extraction import _acquire_plan, _default_device
         from tsfresh_amd.feature_extraction.plan import compile_fc_parameters
+        fplan = compile_fc_parameters(fc_parameters, has_datetime_index=has_dt)
+        if len(fplan) == 0:
+            return [], np.empty((len(offsets) - 1, 0))
+        device = self.device if self.device is not None else _default_device()
+        plan = _acquire_plan(fplan, device)  # cached per thread: no 8 ms plan build per call
+        return list(fplan.names), plan.extract_host(values, offsets, times=times)
+
+    def map_reduce(self, map_function=None, data=None, function_kwargs=None, chunk_size=None, data_length=None):
         kwargs = function_kwargs or {}
         default_fc = kwargs.get("default_fc_parameters")
         kind_to_fc = kwargs.get("kind_to_fc_parameters")
         show_warnings = kwargs.get("show_warnings", False)
-        device = self.device if self.device is not None else _default_device()
-        # group the chunks by kind, keeping the order in which kinds and ids arrive
+        # group the chunks by kind (the ORIGINAL key: kind_to_fc_parameters is looked up with it, extraction.py:333-336)
+        # and, within a kind, by whether the series carries a DatetimeIndex -- the reference decides per series whether
+        # linear_trend_timewise can be computed (extraction.py:349-358), so a kind with mixed indices gets the timewise
+        # columns for the series that have timestamps and not for the others
         by_kind = {}
         for chunk in data:
             sample_id, kind, series = chunk[0], chunk[1], chunk[2]
-            by_kind.setdefault(str(kind), []).append((sample_id, series))
+            has_dt = isinstance(series, pd.Series) and isinstance(series.index, pd.DatetimeIndex)
+            by_kind.setdefault(kind, {}).setdefault(has_dt, []).append((sample_id, series))
         result = []
         with warnings.catch_warnings():
             warnings.simplefilter("default" if show_warnings else "ignore")
-            for kind, items in by_kind.items():
-                fc_parameters = kind_to_fc[kind] if kind_to_fc and kind in kind_to_fc else default_fc
-                arrays = [np.asarray(s) for _, s in items]
-                if any(len(a) == 0 for a in arrays):
-                    raise ValueError("every series must hold at least one sample")
-                dtype = np.float32 if all(a.dtype == np.float32 for a in arrays) else np.float64
-                values = np.concatenate([a.astype(dtype, copy=False) for a in arrays])
-                offsets = np.zeros(len(arrays) + 1, dtype=np.int64)
-                np.cumsum([len(a) for a in arrays], out=offsets[1:])
-                has_dt = all(isinstance(s, pd.Series) and isinstance(s.index, pd.DatetimeIndex) for _, s in items)
-                times = None
-                if has_dt:  # feature_calculators.py:2291-2296
-                    times = np.concatenate([np.asarray((s.index - s.index[0]).total_seconds() / float(3600))
-                                            for _, s in items]).astype(np.float64)
-                fplan = compile_fc_parameters(fc_parameters, has_datetime_index=has_dt)
-                if len(fplan) == 0:
-                    continue
-                plan = _native.Plan(fplan.native_specs(_native.calc_id), device=device)
-                try:
-                    matrix = plan.extract_host(values, offsets, times=times)
-                finally:
-                    plan.close()
-                names = [kind + "__" + n for n in fplan.names]
-                for r, (sample_id, _) in enumerate(items):
-                    row = matrix[r]
-                    result.extend((sample_id, name, row[c]) for c, name in enumerate(names))
+            for kind, groups in by_kind.items():
+                if kind_to_fc and kind in kind_to_fc:
+                    fc_parameters = kind_to_fc[kind]
+                elif kind_to_fc and str(kind) in kind_to_fc:
+                    fc_parameters = kind_to_fc[str(kind)]
+                else:
+                    fc_parameters = default_fc
+                for has_dt, items in groups.items():
+                    arrays = [np.asarray(s) for _, s in items]
+                    if any(len(a) == 0 for a in arrays):
+                        raise ValueError("every series must hold at least one sample")
+                    dtype = np.float32 if all(a.dtype == np.float32 for a in arrays) else np.float64
+                    values = np.concatenate([a.astype(dtype, copy=False) for a in arrays])
+                    offsets = np.zeros(len(arrays) + 1, dtype=np.int64)
+                    np.cumsum([len(a) for a in arrays], out=offsets[1:])
+                    times = None
+                    if has_dt:  # feature_calculators.py:2291-2296
+                        times = np.concatenate([np.asarray((s.index - s.index[0]).total_seconds() / float(3600))
+                                                for _, s in items]).astype(np.float64)
+                    names, matrix = self._extract_matrix(fc_parameters, values, offsets, times, has_dt)
+                    names = [str(kind) + "__" + n for n in names]
+                    for r, (sample_id, _) in enumerate(items):
+                        row = matrix[r]
+                        result.extend((sample_id, name, row[c]) for c, name in enumerate(names))
         return result
 
     def close(self):
