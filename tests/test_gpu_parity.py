@@ -530,3 +530,44 @@ def test_number_cwt_peaks_on_long_series_matches_oracle(gpu):
         onames, want = oracle_engine(params, values.astype(np.float64), offsets)
         assert names == onames
         assert np.array_equal(got, want), (dtype.__name__, got.T, want.T)
+
+
+def test_series_longer_than_lds_match_oracle(gpu):
+    """Series whose working set does not fit a CU's LDS (beyond ~8.9 k samples) run from the long-series build of the
+    kernels (tsfa_kernels_long.hip: working set in HBM scratch).  Lengths up to the documented cap of 65 535, mixed with
+    short series in one batch (length classes), EfficientFCParameters against the oracle."""
+    rng = np.random.default_rng(41)
+    lens = [9001, 300, 12345, 20000, 1024, 40000, 65535, 64]
+    chunks = []
+    for i, n in enumerate(lens):
+        x = rng.standard_normal(n)
+        if i % 2 == 1:
+            x = np.cumsum(x)
+        chunks.append(x.astype(np.float32))
+    values = np.concatenate(chunks)
+    offsets = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
+    params = settings.EfficientFCParameters()
+    names, got = hip_engine(params, values, offsets)
+    onames, want = oracle_engine(params, values.astype(np.float64), offsets)
+    bad = compare(onames, _align(onames, names, got), want, _series(values.astype(np.float64), offsets))
+    assert not bad, "%d mismatches, first: %s" % (len(bad), bad[:12])
+
+
+def test_forced_long_build_equals_the_lds_build(gpu, monkeypatch):
+    """TSFA_FORCE_LONG=1 sends every family through the HBM-scratch build, also for ordinary lengths: all 783
+    Comprehensive columns (the general entropy sweep included) must agree with the LDS build and with the oracle."""
+    rng = np.random.default_rng(42)
+    lens = list(rng.integers(4, 600, size=40)) + [1024, 700, 64, 1, 2, 3]
+    chunks = [(np.cumsum(rng.standard_normal(n)) if i % 3 == 0 else rng.standard_normal(n)).astype(np.float32)
+              for i, n in enumerate(lens)]
+    values = np.concatenate(chunks)
+    offsets = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
+    params = settings.ComprehensiveFCParameters()
+    names, lds_build = hip_engine(params, values, offsets)
+    monkeypatch.setenv("TSFA_FORCE_LONG", "1")
+    names2, long_build = hip_engine(params, values, offsets)
+    monkeypatch.delenv("TSFA_FORCE_LONG")
+    assert names == names2 and np.array_equal(np.isnan(lds_build), np.isnan(long_build))
+    onames, want = oracle_engine(params, values.astype(np.float64), offsets)
+    bad = compare(onames, _align(onames, names2, long_build), want, _series(values.astype(np.float64), offsets))
+    assert not bad, "%d mismatches, first: %s" % (len(bad), bad[:12])

@@ -76,7 +76,7 @@ struct tsfa_plan {
     int *d_cols = nullptr, *d_coeff = nullptr;
     double *d_dectab = nullptr, *d_twc = nullptr, *d_tws = nullptr;
     long long *d_stats = nullptr;
-    DevBuf values, offsets, out, gscratch, times, deg_list, sel;
+    DevBuf values, offsets, out, gscratch, times, deg_list, sel, long_scratch;
     int *d_deg_count = nullptr;
     int *d_cursor = nullptr;                    // per-launch-group fill cursors (k_class_fill)
     hipStream_t s_in = nullptr, s_out = nullptr;  // copy-in / copy-out streams of the host pipeline
@@ -151,6 +151,7 @@ void tsfa_plan_destroy(tsfa_plan *plan) {
     if (plan->d_cursor) (void)hipFree(plan->d_cursor);
     plan->deg_list.release();
     plan->sel.release();
+    plan->long_scratch.release();
     for (int i = 0; i < TSFA_MAX_CHUNKS; ++i) {
         if (plan->ev_in[i]) (void)hipEventDestroy(plan->ev_in[i]);
         if (plan->ev_k[i]) (void)hipEventDestroy(plan->ev_k[i]);
@@ -506,24 +507,57 @@ static int run_batch(tsfa_plan *plan, const void *d_values, int dtype, const dou
                 }
                 lz_build_group(plan->fam_specs[f].data(), std::min(seq_group, a.nspecs), maxn, &a.seq);
             }
-            const size_t lds = (f == TSFA_FAM_SEQ) ? tsfa_seq_lds_bytes(a.seq)
-                               : (f == TSFA_FAM_ENTROPY) ? tsfa_entropy_lds_bytes(maxn, a.ent_cnt)
-                                                         : tsfa_family_lds_bytes(f, maxn, a.nt, aux);
-            if (lds > TSFA_LDS_LIMIT)
-                return fail(TSFA_ERR_TOO_LONG, std::string(fam_names[f]) + ": a series of " + std::to_string(maxn) +
-                                                   " samples needs " + std::to_string(lds) + " B of LDS (limit 163840)");
+            size_t seq_lds = 0;  // the largest launch of the family at this group size
+            if (f == TSFA_FAM_SEQ) {
+                TsfaSeqGroup g;
+                for (int s0 = 0; s0 < a.nspecs; s0 += seq_group) {
+                    lz_build_group(plan->fam_specs[f].data() + s0, std::min(seq_group, a.nspecs - s0), maxn, &g);
+                    seq_lds = std::max(seq_lds, tsfa_seq_lds_bytes(g));
+                }
+            }
+            size_t lds = (f == TSFA_FAM_SEQ) ? seq_lds
+                         : (f == TSFA_FAM_ENTROPY) ? tsfa_entropy_lds_bytes(maxn, a.ent_cnt)
+                                                   : tsfa_family_lds_bytes(f, maxn, a.nt, aux);
+            // A series whose working set does not fit a CU's LDS runs from the long-series build of the same kernels
+            // (tsfa_kernels_long.hip): the working set in a slot of HBM scratch per resident workgroup, a persistent
+            // grid walking the group's series.  Slower per sample, but every length up to 65 535 extracts.
+            const bool use_long = lds > TSFA_LDS_LIMIT || (getenv("TSFA_FORCE_LONG") && atoi(getenv("TSFA_FORCE_LONG")));
+            if (use_long) {
+                a.nt = 256;
+                if (f == TSFA_FAM_ENTROPY) { a.ent_cnt = 0; a.ent_fast = 0; lds = tsfa_entropy_lds_bytes(maxn, 0); }
+                if (f == TSFA_FAM_CWT) { a.cwt_rowv = 0; lds = tsfa_family_lds_bytes(f, maxn, a.nt, 0); }
+                if (f == TSFA_FAM_SEQ) {
+                    seq_group = std::min(a.nspecs, TSFA_LZ_MAX_GROUP);
+                    lds = 0;
+                    for (int s0 = 0; s0 < a.nspecs; s0 += seq_group) {
+                        lz_build_group(plan->fam_specs[f].data() + s0, std::min(seq_group, a.nspecs - s0), maxn, &a.seq);
+                        lds = std::max(lds, tsfa_seq_lds_bytes(a.seq));
+                    }
+                } else if (f != TSFA_FAM_ENTROPY && f != TSFA_FAM_CWT) {
+                    lds = tsfa_family_lds_bytes(f, maxn, a.nt, aux);
+                }
+                const size_t slot_bytes = (lds + 255) & ~(size_t)255;
+                const int64_t n_slots = std::max<int64_t>(1, std::min<int64_t>(std::min<int64_t>(a.n_series, 512),
+                                                                               (int64_t)((4ull << 30) / slot_bytes)));
+                if (plan->long_scratch.ensure((size_t)n_slots * slot_bytes))
+                    return fail(TSFA_ERR_HIP, "hipMalloc failed for the long-series scratch");
+                a.long_scratch = (unsigned char *)plan->long_scratch.p;
+                a.long_bytes = (size_t)n_slots * slot_bytes;
+            }
             int rc = 0;
             if (f == TSFA_FAM_SEQ) {
                 for (int s0 = 0; rc == 0 && s0 < a.nspecs; s0 += seq_group) {
                     lz_build_group(plan->fam_specs[f].data() + s0, std::min(seq_group, a.nspecs - s0), maxn, &a.seq);
-                    if (tsfa_seq_lds_bytes(a.seq) > TSFA_LDS_LIMIT)
+                    if (!use_long && tsfa_seq_lds_bytes(a.seq) > TSFA_LDS_LIMIT)
                         return fail(TSFA_ERR_TOO_LONG, "k_seq: a series of " + std::to_string(maxn) + " samples does not fit LDS");
-                    rc = tsfa_launch_family(a);
+                    rc = use_long ? tsfa_launch_family_long(a) : tsfa_launch_family(a);
                 }
             } else {
-                rc = tsfa_launch_family(a);
+                rc = use_long ? tsfa_launch_family_long(a) : tsfa_launch_family(a);
             }
-            if (rc) return fail(TSFA_ERR_HIP, std::string(fam_names[f]) + " launch failed: " + hipGetErrorString((hipError_t)rc));
+            if (rc == 0 && f == TSFA_FAM_AR) rc = tsfa_launch_ar_degenerate(a);
+            if (rc) return fail(TSFA_ERR_HIP, std::string(fam_names[f]) + " launch failed: " +
+                                                  (rc == -2 ? "no scratch slot" : hipGetErrorString((hipError_t)rc)));
         }
         if (record(plan, fst, slot, fam_names[f], false)) return fail(TSFA_ERR_HIP, "event record failed");
         ++slot;

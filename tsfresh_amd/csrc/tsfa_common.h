@@ -106,7 +106,11 @@ struct Ticker {
 // barrier would expose that store's round trip (~600 cycles per column, measured).  LDS traffic only needs lgkmcnt.
 TSFA_DEV void blk_sync() {
 #if TSFA_GPU
+#if defined(TSFA_LONG)
+    __syncthreads();  // the working set lives in HBM scratch: the barrier must order global memory too
+#else
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+#endif
 #endif
 }
 // Barrier that also orders global memory within the workgroup (scratch in HBM).

@@ -14,7 +14,32 @@
 
 #include <algorithm>
 
+// This file is compiled twice.  tsfa_kernels.o: one workgroup per series, the working set carved from LDS.
+// tsfa_kernels_long.o (tsfa_kernels_long.hip defines TSFA_LONG and renames the kernels): series too long for a CU's
+// LDS -- the SAME per-series code with its working set carved from a per-workgroup slot of HBM scratch (L2 / Infinity
+// Cache resident), a persistent grid that walks the series list, and workgroup barriers that also order global
+// memory (tsfa_common.h: blk_sync).  Slower per sample, but no length limit below 65 535.
+#if defined(TSFA_LONG)
+#define TSFA_GS_PARAMS , unsigned char *__restrict__ gsc, size_t gslot
+#define TSFA_GS_ARGS , gsc, gslot
+#define TSFA_SERIES_BEGIN                                                           \
+    unsigned char *const tsfa_base = gsc + (size_t)blockIdx.x * gslot;             \
+    for (int64_t wi_ = blockIdx.x; wi_ < n_series; wi_ += gridDim.x) {             \
+        const int64_t sidx = sel ? (int64_t)sel[wi_] : wi_;
+#define TSFA_SERIES_END \
+        __syncthreads(); \
+    }
+#else
 extern __shared__ __attribute__((aligned(16))) unsigned char tsfa_smem[];
+#define TSFA_GS_PARAMS
+#define TSFA_GS_ARGS
+#define TSFA_SERIES_BEGIN                                                                                                   \
+    if ((int64_t)blockIdx.x >= n_series) return;                                                                            \
+    unsigned char *const tsfa_base = tsfa_smem;                                                                             \
+    {                                                                                                                       \
+        const int64_t sidx = sel ? (int64_t)sel[blockIdx.x] : (int64_t)blockIdx.x; /* length-class launch: its series list */
+#define TSFA_SERIES_END }
+#endif
 
 template <typename T>
 __device__ __forceinline__ void stage_series(const Blk &b, const T *__restrict__ g, int n, double *xs) {
@@ -29,13 +54,12 @@ template <typename T, int PART>
 __device__ __forceinline__ void basic_body(const T *__restrict__ values, const int64_t *__restrict__ starts, const int64_t *__restrict__ ends, int64_t n_series, const int *__restrict__ sel,
                         const TsfaSpec *__restrict__ specs, int nspecs, double *__restrict__ out, int64_t ld,
                         const double *__restrict__ dectab, int maxn, int hint_a, int hint_b,
-                        const double *__restrict__ times, const TsfaAltPlan &alt, int n_loop, int n_count, int n_sum) {
-    if ((int64_t)blockIdx.x >= n_series) return;
-    const int64_t sidx = sel ? (int64_t)sel[blockIdx.x] : (int64_t)blockIdx.x;  // length-class launch: its series list
+                        const double *__restrict__ times, const TsfaAltPlan &alt, int n_loop, int n_count, int n_sum TSFA_GS_PARAMS) {
+    TSFA_SERIES_BEGIN
     const int64_t off = starts[sidx];
     const int n = (int)(ends[sidx] - off);
     BasicLds L;
-    L.carve(tsfa_smem, maxn, blockDim.x, (int)sizeof(T), PART);
+    L.carve(tsfa_base, maxn, blockDim.x, (int)sizeof(T), PART);
     TSFA_TICKS_BEGIN();
     Blk b{(int)threadIdx.x, (int)blockDim.x, L.red, L.np};
     T *xs = (T *)L.xs;  // resident in the input precision (half the LDS for float32), read as float64
@@ -47,35 +71,35 @@ __device__ __forceinline__ void basic_body(const T *__restrict__ values, const i
     fam_basic_series<PART>(b, XsView<T>{xs}, n, specs, nspecs, out + sidx * ld, L.w, L.cum, L.altc, L.iw, dectab, hint_a,
                            hint_b, alt, L.stage, times ? times + off : nullptr, n_loop, L.ctx, n_count, n_sum);
     TSFA_TICKS_END();
+    TSFA_SERIES_END
 }
 
 template <typename T>
 __global__ void __launch_bounds__(1024) k_basic(const T *__restrict__ values, const int64_t *__restrict__ starts, const int64_t *__restrict__ ends, int64_t n_series, const int *__restrict__ sel,
                         const TsfaSpec *__restrict__ specs, int nspecs, double *__restrict__ out, int64_t ld,
-                        const double *__restrict__ dectab, int maxn, int hint_a, int n_loop, int n_count, int n_sum) {
+                        const double *__restrict__ dectab, int maxn, int hint_a, int n_loop, int n_count, int n_sum TSFA_GS_PARAMS) {
     TsfaAltPlan alt;
     alt.nkeys = 0; alt.want_p = 0; alt.nq = 0;
     basic_body<T, 1>(values, starts, ends, n_series, sel, specs, nspecs, out, ld, dectab, maxn, hint_a, 0, nullptr, alt, n_loop,
-                     n_count, n_sum);
+                     n_count, n_sum TSFA_GS_ARGS);
 }
 
 template <typename T>
 __global__ void __launch_bounds__(512) k_trend(const T *__restrict__ values, const int64_t *__restrict__ starts, const int64_t *__restrict__ ends, int64_t n_series, const int *__restrict__ sel,
                         const TsfaSpec *__restrict__ specs, int nspecs, double *__restrict__ out, int64_t ld, int maxn,
-                        int hint_b, const double *__restrict__ times, const TsfaAltPlan alt, int n_loop) {
-    basic_body<T, 2>(values, starts, ends, n_series, sel, specs, nspecs, out, ld, nullptr, maxn, 0, hint_b, times, alt, n_loop, 0, 0);
+                        int hint_b, const double *__restrict__ times, const TsfaAltPlan alt, int n_loop TSFA_GS_PARAMS) {
+    basic_body<T, 2>(values, starts, ends, n_series, sel, specs, nspecs, out, ld, nullptr, maxn, 0, hint_b, times, alt, n_loop, 0, 0 TSFA_GS_ARGS);
 }
 
 template <typename T>
 __global__ void __launch_bounds__(1024) k_sort(const T *__restrict__ values, const int64_t *__restrict__ starts, const int64_t *__restrict__ ends, int64_t n_series, const int *__restrict__ sel,
                        const TsfaSpec *__restrict__ specs, int nspecs, double *__restrict__ out, int64_t ld, int maxn,
-                       const TsfaCqPlan cqplan, int n_loop, int w_doubles) {
-    if ((int64_t)blockIdx.x >= n_series) return;
-    const int64_t sidx = sel ? (int64_t)sel[blockIdx.x] : (int64_t)blockIdx.x;  // length-class launch: its series list
+                       const TsfaCqPlan cqplan, int n_loop, int w_doubles TSFA_GS_PARAMS) {
+    TSFA_SERIES_BEGIN
     const int64_t off = starts[sidx];
     const int n = (int)(ends[sidx] - off);
     SortLds L;
-    L.carve(tsfa_smem, maxn, blockDim.x, (int)sizeof(T), w_doubles);
+    L.carve(tsfa_base, maxn, blockDim.x, (int)sizeof(T), w_doubles);
     TSFA_TICKS_BEGIN();
     Blk b{(int)threadIdx.x, (int)blockDim.x, L.red, L.np};
     T *xs = (T *)L.xs;  // resident in the input precision, like its sorted copy
@@ -87,19 +111,19 @@ __global__ void __launch_bounds__(1024) k_sort(const T *__restrict__ values, con
     fam_sort_series<T>(b, xs, n, specs, nspecs, out + sidx * ld, (T *)L.srt, L.w, L.iw, cqplan, L.cq, L.stage,
                        n_loop, L.ctx, w_doubles);
     TSFA_TICKS_END();
+    TSFA_SERIES_END
 }
 
 template <typename T>
 __global__ void __launch_bounds__(1024) k_spectral(const T *__restrict__ values, const int64_t *__restrict__ starts, const int64_t *__restrict__ ends, int64_t n_series, const int *__restrict__ sel,
                            const TsfaSpec *__restrict__ specs, int nspecs, double *__restrict__ out, int64_t ld,
                            int maxn, int dft_n, double *__restrict__ gscratch, int gscratch_n,
-                           const double *__restrict__ twc, const double *__restrict__ tws, int hint_a, int hint_b) {
-    if ((int64_t)blockIdx.x >= n_series) return;
-    const int64_t sidx = sel ? (int64_t)sel[blockIdx.x] : (int64_t)blockIdx.x;  // length-class launch: its series list
+                           const double *__restrict__ twc, const double *__restrict__ tws, int hint_a, int hint_b TSFA_GS_PARAMS) {
+    TSFA_SERIES_BEGIN
     const int64_t off = starts[sidx];
     const int n = (int)(ends[sidx] - off);
     SpectralLds L;
-    L.carve(tsfa_smem, maxn, dft_n, (int)sizeof(T));
+    L.carve(tsfa_base, maxn, dft_n, (int)sizeof(T));
     TSFA_TICKS_BEGIN();
     Blk b{(int)threadIdx.x, (int)blockDim.x, L.red, nullptr};
     T *xs = (T *)L.xs;  // resident in the input precision
@@ -116,19 +140,19 @@ __global__ void __launch_bounds__(1024) k_spectral(const T *__restrict__ values,
     fam_spectral_series<T>(b, xs, n, specs, nspecs, out + sidx * ld, L.Xr, L.Xi, tc, ts, L.win, L.pxx, L.iw, twc, tws,
                         hint_a, hint_b);
     TSFA_TICKS_END();
+    TSFA_SERIES_END
 }
 
 template <typename T>
 __global__ void __launch_bounds__(1024) k_ar(const T *__restrict__ values, const int64_t *__restrict__ starts, const int64_t *__restrict__ ends, int64_t n_series, const int *__restrict__ sel,
                      const TsfaSpec *__restrict__ specs, int nspecs, double *__restrict__ out, int64_t ld, int maxn,
                      int P, int hint_acf, int hint_pacf, int hint_adf, int n_loop, long long *__restrict__ deg_list,
-                     int *__restrict__ deg_count) {
-    if ((int64_t)blockIdx.x >= n_series) return;
-    const int64_t sidx = sel ? (int64_t)sel[blockIdx.x] : (int64_t)blockIdx.x;  // length-class launch: its series list
+                     int *__restrict__ deg_count TSFA_GS_PARAMS) {
+    TSFA_SERIES_BEGIN
     const int64_t off = starts[sidx];
     const int n = (int)(ends[sidx] - off);
     ArLds L;
-    L.carve(tsfa_smem, maxn, P, (int)sizeof(T));
+    L.carve(tsfa_base, maxn, P, (int)sizeof(T));
     TSFA_TICKS_BEGIN();
     Blk b{(int)threadIdx.x, (int)blockDim.x, L.red, L.np};
     const T *g = values + off;
@@ -137,8 +161,10 @@ __global__ void __launch_bounds__(1024) k_ar(const T *__restrict__ values, const
     // rank-deficient / ill-conditioned regressions: list the series for k_ar_degenerate
     if (flags && threadIdx.x == 0) deg_list[atomicAdd(deg_count, 1)] = ((long long)sidx << 2) | flags;
     TSFA_TICKS_END();
+    TSFA_SERIES_END
 }
 
+#if !defined(TSFA_LONG)
 // second pass of the AR family (fam_ar_dd.h): the listed series, one workgroup each, double-double normal equations.
 // The list order is arbitrary (atomics); every listed series writes only its own row, so the result is not.
 template <typename T>
@@ -161,57 +187,60 @@ __global__ void __launch_bounds__(64) k_ar_degenerate(const T *__restrict__ valu
     }
 }
 
+#endif  // !TSFA_LONG
+
 // FAST: symmetric sweep only (m = 2 specs, LDS counters fit) -- see fam_entropy_series
 template <typename T, bool FAST>
 __global__ void __launch_bounds__(1024) k_entropy(const T *__restrict__ values, const int64_t *__restrict__ starts, const int64_t *__restrict__ ends, int64_t n_series, const int *__restrict__ sel,
                           const TsfaSpec *__restrict__ specs, int nspecs, double *__restrict__ out, int64_t ld,
-                          int maxn, int with_cnt) {
-    if ((int64_t)blockIdx.x >= n_series) return;
-    const int64_t sidx = sel ? (int64_t)sel[blockIdx.x] : (int64_t)blockIdx.x;  // length-class launch: its series list
+                          int maxn, int with_cnt TSFA_GS_PARAMS) {
+    TSFA_SERIES_BEGIN
     const int64_t off = starts[sidx];
     const int n = (int)(ends[sidx] - off);
     EntropyLds L;
-    L.carve(tsfa_smem, maxn, with_cnt);
+    L.carve(tsfa_base, maxn, with_cnt);
     TSFA_TICKS_BEGIN();
     Blk b{(int)threadIdx.x, (int)blockDim.x, L.red, L.np};
     stage_series(b, values + off, n, L.xs);
     fam_entropy_series<double, FAST, sizeof(T) == 4>(b, L.xs, n, specs, nspecs, out + sidx * ld, L.thr, L.perm, L.refs, L.cnt);
     TSFA_TICKS_END();
+    TSFA_SERIES_END
 }
 
 template <typename T>
 __global__ void __launch_bounds__(256) k_seq(const T *__restrict__ values, const int64_t *__restrict__ starts, const int64_t *__restrict__ ends, int64_t n_series, const int *__restrict__ sel,
-                      double *__restrict__ out, int64_t ld, const TsfaSeqGroup g) {
-    if ((int64_t)blockIdx.x >= n_series) return;
-    const int64_t sidx = sel ? (int64_t)sel[blockIdx.x] : (int64_t)blockIdx.x;  // length-class launch: its series list
+                      double *__restrict__ out, int64_t ld, const TsfaSeqGroup g TSFA_GS_PARAMS) {
+    TSFA_SERIES_BEGIN
     const int64_t off = starts[sidx];
     const int n = (int)(ends[sidx] - off);
     SeqLds L;
-    L.carve(tsfa_smem, 1, g.stride, g.ttotal, g.etotal);
+    L.carve(tsfa_base, 1, g.stride, g.ttotal, g.etotal);
     TSFA_TICKS_BEGIN();
     Blk b{(int)threadIdx.x, (int)blockDim.x, L.red, nullptr};
     const T *gv = values + off;
     fam_seq_series(b, [=](int i) { return (double)gv[i]; }, n, g, out + sidx * ld, L.seq, L.tab, L.edges);
     TSFA_TICKS_END();
+    TSFA_SERIES_END
 }
 
 template <typename T>
 __global__ void __launch_bounds__(1024) k_cwtpeaks(const T *__restrict__ values, const int64_t *__restrict__ starts, const int64_t *__restrict__ ends, int64_t n_series, const int *__restrict__ sel,
                            const TsfaSpec *__restrict__ specs, int nspecs, double *__restrict__ out, int64_t ld,
-                           int maxn, int with_rowv) {
-    if ((int64_t)blockIdx.x >= n_series) return;
-    const int64_t sidx = sel ? (int64_t)sel[blockIdx.x] : (int64_t)blockIdx.x;  // length-class launch: its series list
+                           int maxn, int with_rowv TSFA_GS_PARAMS) {
+    TSFA_SERIES_BEGIN
     const int64_t off = starts[sidx];
     const int n = (int)(ends[sidx] - off);
     CwtPeaksLayout L;
-    L.carve(tsfa_smem, maxn, with_rowv, (int)sizeof(T));
+    L.carve(tsfa_base, maxn, with_rowv, (int)sizeof(T));
     TSFA_TICKS_BEGIN();
     Blk b{(int)threadIdx.x, (int)blockDim.x, L.p.red, nullptr};
     const T *g = values + off;
     fam_cwtpeaks_series<T>(b, [=](int i) { return (double)g[i]; }, n, specs, nspecs, out + sidx * ld, L.p);
     TSFA_TICKS_END();
+    TSFA_SERIES_END
 }
 
+#if !defined(TSFA_LONG)
 // ---------------------------------------------------------------------------------------------
 // cwt_coefficients (fc.py:1370): pywt.cwt(x, widths, "mexh")[i, coeff] only ever reads output positions
 // coeff < ~15, i.e. a dot product of the first S samples with a fixed filter column.  For a batch that is the
@@ -315,6 +344,8 @@ __global__ void __launch_bounds__(256) k_class_fill(const int64_t *__restrict__ 
     }
 }
 
+#endif  // !TSFA_LONG
+
 // ---------------------------------------------------------------------------------------------
 // launchers
 // ---------------------------------------------------------------------------------------------
@@ -334,80 +365,108 @@ static int set_lds(K kern, size_t bytes) {
     return 0;
 }
 
+// One family launch.  LDS build: a workgroup per series, `lds` bytes of dynamic LDS.  TSFA_LONG build: a persistent grid
+// of as many workgroups as the scratch holds slots of `lds` bytes (a.long_scratch / a.long_bytes), no dynamic LDS.
+#if defined(TSFA_LONG)
+#define TSFA_KLAUNCH(kern, lds, ...)                                                                       \
+    do {                                                                                                   \
+        const size_t slot_ = ((size_t)(lds) + 255) & ~(size_t)255;                                          \
+        const int64_t slots_ = (int64_t)(a.long_bytes / slot_);                                            \
+        if (!a.long_scratch || slots_ < 1) return -2;                                                      \
+        const dim3 lgrid_((unsigned)std::min<int64_t>(a.n_series, std::min<int64_t>(slots_, 2048)));       \
+        kern<<<lgrid_, nt, 0, st>>>(__VA_ARGS__, a.long_scratch, slot_);                                   \
+    } while (0)
+#else
+#define TSFA_KLAUNCH(kern, lds, ...)                           \
+    do {                                                       \
+        if ((rc = set_lds(kern, lds))) return rc;              \
+        kern<<<grid, nt, lds, st>>>(__VA_ARGS__);              \
+    } while (0)
+#endif
+
 template <typename T>
 static int launch_all_t(const TsfaLaunch &a, const T *values) {
     hipStream_t st = (hipStream_t)a.stream;
     const dim3 grid((unsigned)a.n_series);
     const int nt = a.nt;
-    int rc;
+    int rc = 0;
+    (void)grid; (void)rc;
     if (a.fam == TSFA_FAM_BASIC) {
         BasicLds L;
         const size_t lds = L.carve(nullptr, a.maxn, nt, (int)sizeof(T), 1);
-        if ((rc = set_lds(k_basic<T>, lds))) return rc;
-        k_basic<T><<<grid, nt, lds, st>>>(values, a.starts, a.ends, a.n_series, a.sel, a.specs, a.nspecs, a.out, a.ld, a.dectab, a.maxn,
-                                          a.hint_a, a.hint_c, a.hint_d, a.hint_e);
+        TSFA_KLAUNCH(k_basic<T>, lds, values, a.starts, a.ends, a.n_series, a.sel, a.specs, a.nspecs, a.out, a.ld, a.dectab,
+                     a.maxn, a.hint_a, a.hint_c, a.hint_d, a.hint_e);
     } else if (a.fam == TSFA_FAM_TREND) {
         BasicLds L;
         const size_t lds = L.carve(nullptr, a.maxn, nt, (int)sizeof(T), 2);
-        if ((rc = set_lds(k_trend<T>, lds))) return rc;
-        k_trend<T><<<grid, nt, lds, st>>>(values, a.starts, a.ends, a.n_series, a.sel, a.specs, a.nspecs, a.out, a.ld, a.maxn, a.hint_b,
-                                          a.times, a.alt, a.hint_c);
+        TSFA_KLAUNCH(k_trend<T>, lds, values, a.starts, a.ends, a.n_series, a.sel, a.specs, a.nspecs, a.out, a.ld, a.maxn,
+                     a.hint_b, a.times, a.alt, a.hint_c);
     } else if (a.fam == TSFA_FAM_SORT) {
         SortLds L;
         const int wd = (a.hint_a >= 320) ? a.hint_a : 1280;
         const size_t lds = L.carve(nullptr, a.maxn, nt, (int)sizeof(T), wd);
-        if ((rc = set_lds(k_sort<T>, lds))) return rc;
-        k_sort<T><<<grid, nt, lds, st>>>(values, a.starts, a.ends, a.n_series, a.sel, a.specs, a.nspecs, a.out, a.ld, a.maxn, a.cq,
-                                         a.hint_c, wd);
+        TSFA_KLAUNCH(k_sort<T>, lds, values, a.starts, a.ends, a.n_series, a.sel, a.specs, a.nspecs, a.out, a.ld, a.maxn, a.cq,
+                     a.hint_c, wd);
     } else if (a.fam == TSFA_FAM_SPECTRAL) {
         SpectralLds L;
         const size_t lds = L.carve(nullptr, a.maxn, a.dft_n, (int)sizeof(T));
-        if ((rc = set_lds(k_spectral<T>, lds))) return rc;
-        k_spectral<T><<<grid, nt, lds, st>>>(values, a.starts, a.ends, a.n_series, a.sel, a.specs, a.nspecs, a.out, a.ld, a.maxn,
-                                             a.dft_n, a.gscratch, a.gscratch_n, a.twc, a.tws, a.hint_a, a.hint_b);
+        TSFA_KLAUNCH(k_spectral<T>, lds, values, a.starts, a.ends, a.n_series, a.sel, a.specs, a.nspecs, a.out, a.ld, a.maxn,
+                     a.dft_n, a.gscratch, a.gscratch_n, a.twc, a.tws, a.hint_a, a.hint_b);
     } else if (a.fam == TSFA_FAM_AR) {
         ArLds L;
         const size_t lds = L.carve(nullptr, a.maxn, a.ar_P, (int)sizeof(T));
-        if ((rc = set_lds(k_ar<T>, lds))) return rc;
-        k_ar<T><<<grid, nt, lds, st>>>(values, a.starts, a.ends, a.n_series, a.sel, a.specs, a.nspecs, a.out, a.ld, a.maxn, a.ar_P,
-                                       a.hint_a, a.hint_b, a.hint_c, a.hint_d, a.deg_list, a.deg_count);
-        TSFA_LAUNCH_CHECK();
-        if (a.hint_c || a.ar_has_coef) {  // ADF / ar_coefficient columns: the regressions that can degenerate
-            ArDdLds D;
-            const size_t dlds = D.carve(nullptr, a.ar_P);
-            if ((rc = set_lds(k_ar_degenerate<T>, dlds))) return rc;
-            const unsigned dgrid = (unsigned)std::min<int64_t>(a.n_series, 4096);
-            k_ar_degenerate<T><<<dgrid, 64, dlds, st>>>(values, a.starts, a.ends, a.specs, a.nspecs, a.out, a.ld, a.ar_P,
-                                                        a.deg_list, a.deg_count);
-        }
+        TSFA_KLAUNCH(k_ar<T>, lds, values, a.starts, a.ends, a.n_series, a.sel, a.specs, a.nspecs, a.out, a.ld, a.maxn, a.ar_P,
+                     a.hint_a, a.hint_b, a.hint_c, a.hint_d, a.deg_list, a.deg_count);
     } else if (a.fam == TSFA_FAM_ENTROPY) {
         EntropyLds L;
         const size_t lds = L.carve(nullptr, a.maxn, a.ent_cnt);
-if (a.ent_fast) {
-            if ((rc = set_lds(k_entropy<T, true>, lds))) return rc;
-            k_entropy<T, true><<<grid, nt, lds, st>>>(values, a.starts, a.ends, a.n_series, a.sel, a.specs, a.nspecs, a.out, a.ld, a.maxn,
-                                                      a.ent_cnt);
+        if (a.ent_fast) {
+            auto kfn = k_entropy<T, true>;
+            TSFA_KLAUNCH(kfn, lds, values, a.starts, a.ends, a.n_series, a.sel, a.specs, a.nspecs, a.out, a.ld, a.maxn, a.ent_cnt);
         } else {
-            if ((rc = set_lds(k_entropy<T, false>, lds))) return rc;
-            k_entropy<T, false><<<grid, nt, lds, st>>>(values, a.starts, a.ends, a.n_series, a.sel, a.specs, a.nspecs, a.out, a.ld, a.maxn,
-                                                       a.ent_cnt);
+            auto kfn = k_entropy<T, false>;
+            TSFA_KLAUNCH(kfn, lds, values, a.starts, a.ends, a.n_series, a.sel, a.specs, a.nspecs, a.out, a.ld, a.maxn, a.ent_cnt);
         }
     } else if (a.fam == TSFA_FAM_SEQ) {
         SeqLds L;
         const size_t lds = L.carve(nullptr, 1, a.seq.stride, a.seq.ttotal, a.seq.etotal);
-        if ((rc = set_lds(k_seq<T>, lds))) return rc;
-        k_seq<T><<<grid, nt, lds, st>>>(values, a.starts, a.ends, a.n_series, a.sel, a.out, a.ld, a.seq);
+        TSFA_KLAUNCH(k_seq<T>, lds, values, a.starts, a.ends, a.n_series, a.sel, a.out, a.ld, a.seq);
     } else if (a.fam == TSFA_FAM_CWT) {  // number_cwt_peaks
         CwtPeaksLayout L;
         const size_t lds = L.carve(nullptr, a.maxn, a.cwt_rowv, (int)sizeof(T));
-        if ((rc = set_lds(k_cwtpeaks<T>, lds))) return rc;
-        k_cwtpeaks<T><<<grid, nt, lds, st>>>(values, a.starts, a.ends, a.n_series, a.sel, a.specs, a.nspecs, a.out, a.ld, a.maxn,
-                                             a.cwt_rowv);
+        TSFA_KLAUNCH(k_cwtpeaks<T>, lds, values, a.starts, a.ends, a.n_series, a.sel, a.specs, a.nspecs, a.out, a.ld, a.maxn,
+                     a.cwt_rowv);
     } else {
         return -1;
     }
     TSFA_LAUNCH_CHECK();
     return 0;
+}
+
+#if defined(TSFA_LONG)
+int tsfa_launch_family_long(const TsfaLaunch &a) {
+    if (a.dtype == 0) return launch_all_t<float>(a, (const float *)a.values);
+    return launch_all_t<double>(a, (const double *)a.values);
+}
+#else
+// second pass of the AR family over the series k_ar listed (after tsfa_launch_family / _long of TSFA_FAM_AR)
+template <typename T>
+static int launch_ar_degenerate_t(const TsfaLaunch &a, const T *values) {
+    hipStream_t st = (hipStream_t)a.stream;
+    int rc;
+    ArDdLds D;
+    const size_t dlds = D.carve(nullptr, a.ar_P);
+    if ((rc = set_lds(k_ar_degenerate<T>, dlds))) return rc;
+    const unsigned dgrid = (unsigned)std::min<int64_t>(a.n_series, 4096);
+    k_ar_degenerate<T><<<dgrid, 64, dlds, st>>>(values, a.starts, a.ends, a.specs, a.nspecs, a.out, a.ld, a.ar_P, a.deg_list,
+                                                a.deg_count);
+    TSFA_LAUNCH_CHECK();
+    return 0;
+}
+int tsfa_launch_ar_degenerate(const TsfaLaunch &a) {
+    if (!(a.hint_c || a.ar_has_coef)) return 0;  // no ADF / ar_coefficient column: nothing can degenerate
+    if (a.dtype == 0) return launch_ar_degenerate_t<float>(a, (const float *)a.values);
+    return launch_ar_degenerate_t<double>(a, (const double *)a.values);
 }
 
 size_t tsfa_entropy_lds_bytes(int maxn, int with_cnt) {
@@ -499,3 +558,4 @@ extern "C" int tsfa_debug_ticks(unsigned long long *out, int n, int reset) {
     return 0;
 }
 #endif
+#endif  // !TSFA_LONG

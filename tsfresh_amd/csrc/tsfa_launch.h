@@ -54,6 +54,8 @@ struct TsfaLaunch {
     int *deg_count;         // ... and their number (device; zeroed before the launch)
     int cwt_rowv;           // CWT peaks: second CWT row resident in LDS
     int hint_a, hint_b, hint_c, hint_d, hint_e;  // tsfa_prepare_family (BASIC, SORT, SPECTRAL, AR)
+    unsigned char *long_scratch;  // HBM scratch of the long-series build (tsfa_launch_family_long) ...
+    size_t long_bytes;            // ... and its size: slots of one working set each, one per resident workgroup
     int ent_cnt;            // ENTROPY: per-template LDS counters (symmetric sweep)
     int ent_fast;           // ENTROPY: only m = 2 specs and ent_cnt: the kernel variant without the fallback sweeps
 };
@@ -76,6 +78,8 @@ size_t tsfa_family_lds_bytes(int fam, int maxn, int nt, int aux);
 size_t tsfa_entropy_lds_bytes(int maxn, int with_cnt);
 size_t tsfa_seq_lds_bytes(const TsfaSeqGroup &g);
 int tsfa_launch_family(const TsfaLaunch &a);
+int tsfa_launch_family_long(const TsfaLaunch &a);   // working set in a.long_scratch instead of LDS (any length <= 65535)
+int tsfa_launch_ar_degenerate(const TsfaLaunch &a);  // second pass of TSFA_FAM_AR over the series the first listed
 int tsfa_launch_cwt(const TsfaCwtLaunch &a);
 int tsfa_launch_fill_nan(double *out, int64_t n, void *stream);
 int tsfa_launch_len_stats(const int64_t *starts, const int64_t *ends, int64_t n_series, long long *stats, void *stream);
