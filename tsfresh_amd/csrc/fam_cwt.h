@@ -260,7 +260,7 @@ TSFA_DEV double number_cwt_peaks_one(const Blk &b, X xv, int n, int W, const Cwt
     // value and counting the entries whose column falls into the line's window (64 entries per step: ballot +
     // popcount) -- about 0.1 * n entries per line.  One wavefront per line.
     const bool long_windows = ((int)(0.1 * (double)(window - 1)) + 1 >= 8);
-    if (long_windows) {
+    if (__builtin_expect(long_windows, 0)) {
         unsigned short *order = L.colmap;  // colmap and mline are contiguous and dead by now: 2 * maxn >= pow2(n)
         int np2 = 1;
         while (np2 < n) np2 <<= 1;

@@ -223,8 +223,9 @@ __global__ void __launch_bounds__(256) k_seq(const T *__restrict__ values, const
     TSFA_SERIES_END
 }
 
-template <typename T>
-__global__ void __launch_bounds__(1024) k_cwtpeaks(const T *__restrict__ values, const int64_t *__restrict__ starts, const int64_t *__restrict__ ends, int64_t n_series, const int *__restrict__ sel,
+// MAXT: 256 for series up to 2048 samples (register allocation for 4-wave workgroups), 1024 beyond
+template <typename T, int MAXT>
+__global__ void __launch_bounds__(MAXT) k_cwtpeaks(const T *__restrict__ values, const int64_t *__restrict__ starts, const int64_t *__restrict__ ends, int64_t n_series, const int *__restrict__ sel,
                            const TsfaSpec *__restrict__ specs, int nspecs, double *__restrict__ out, int64_t ld,
                            int maxn, int with_rowv TSFA_GS_PARAMS) {
     TSFA_SERIES_BEGIN
@@ -434,8 +435,13 @@ static int launch_all_t(const TsfaLaunch &a, const T *values) {
     } else if (a.fam == TSFA_FAM_CWT) {  // number_cwt_peaks
         CwtPeaksLayout L;
         const size_t lds = L.carve(nullptr, a.maxn, a.cwt_rowv, (int)sizeof(T));
-        TSFA_KLAUNCH(k_cwtpeaks<T>, lds, values, a.starts, a.ends, a.n_series, a.sel, a.specs, a.nspecs, a.out, a.ld, a.maxn,
-                     a.cwt_rowv);
+        if (nt <= 256) {
+            auto kfn = k_cwtpeaks<T, 256>;
+            TSFA_KLAUNCH(kfn, lds, values, a.starts, a.ends, a.n_series, a.sel, a.specs, a.nspecs, a.out, a.ld, a.maxn, a.cwt_rowv);
+        } else {
+            auto kfn = k_cwtpeaks<T, 1024>;
+            TSFA_KLAUNCH(kfn, lds, values, a.starts, a.ends, a.n_series, a.sel, a.specs, a.nspecs, a.out, a.ld, a.maxn, a.cwt_rowv);
+        }
     } else {
         return -1;
     }
