@@ -571,3 +571,16 @@ def test_forced_long_build_equals_the_lds_build(gpu, monkeypatch):
     onames, want = oracle_engine(params, values.astype(np.float64), offsets)
     bad = compare(onames, _align(onames, names2, long_build), want, _series(values.astype(np.float64), offsets))
     assert not bad, "%d mismatches, first: %s" % (len(bad), bad[:12])
+
+
+def test_custom_callable_calculator_next_to_native_ones(gpu):
+    from tsfresh_amd import extract_features
+
+    def spread(x):
+        return float(np.max(x) - np.min(x))
+
+    rng = np.random.default_rng(3)
+    df = pd.DataFrame({"id": np.repeat(np.arange(5), 40), "time": np.tile(np.arange(40), 5), "value": rng.standard_normal(200)})
+    got = extract_features(df, column_id="id", column_sort="time", default_fc_parameters={"maximum": None, spread: None, "minimum": None})
+    assert list(got.columns) == ["value__maximum", "value__spread", "value__minimum"]
+    assert np.allclose(got["value__spread"], got["value__maximum"] - got["value__minimum"], rtol=0, atol=1e-15)

@@ -58,8 +58,6 @@ def test_param_formatting():
 
 def test_unsupported_features_raise_instead_of_falling_back():
     with pytest.raises(UnsupportedFeature):
-        compile_fc_parameters({(lambda x: 1.0): None})
-    with pytest.raises(UnsupportedFeature):
         compile_fc_parameters({"matrix_profile": [{"threshold": 0.98, "feature": "min"}]})
     with pytest.raises(UnsupportedFeature):
         compile_fc_parameters({"query_similarity_count": [{"query": [1.0, 2.0, 3.0], "threshold": 0.0}]})
@@ -67,3 +65,35 @@ def test_unsupported_features_raise_instead_of_falling_back():
         compile_fc_parameters({"augmented_dickey_fuller": [{"attr": "teststat", "autolag": "BIC"}]})
     with pytest.raises(AttributeError):
         compile_fc_parameters({"not_a_calculator": None})
+
+
+def test_custom_callable_calculators_are_spliced_in_at_their_dict_position():
+    """Callable keys of the FCParameters dict (extraction.py:340-343, docs/text/how_to_add_custom_feature.rst): evaluated
+    per series on the host with the reference's call shapes (simple with / without parameters, combiner) and column
+    names, between the native columns in dict order."""
+    import numpy as np
+
+    from tsfresh_amd.feature_extraction.plan import compile_fc_parameters
+
+    def spread(x):
+        return float(np.max(x) - np.min(x))
+
+    def above(x, t):
+        return int(np.sum(x > t))
+
+    def ends(x, param):
+        return [("which_%s" % p["which"], x[0] if p["which"] == "first" else x[-1]) for p in param]
+    ends.fctype = "combiner"
+
+    fc = {"maximum": None, spread: None, "minimum": None, above: [{"t": 0.5}, {"t": -1}],
+          ends: [{"which": "first"}, {"which": "last"}], "mean": None}
+    fplan = compile_fc_parameters(fc)
+    assert fplan.names == ["maximum", "minimum", "mean"] and len(fplan) == 6
+    rows = [np.array([1.0, -2.0, 3.0]), np.array([0.25, 0.75])]
+    native = np.array([[3.0, -2.0, 2 / 3], [0.75, 0.25, 0.5]])
+    names, matrix = fplan.finish(native, lambda i: rows[i], 2)
+    assert names == ["maximum", "spread", "minimum", "above__t_0.5", "above__t_-1", "ends__which_first", "ends__which_last", "mean"]
+    assert matrix.tolist() == [[3.0, 5.0, -2.0, 2.0, 2.0, 1.0, 3.0, 2 / 3], [0.75, 0.5, 0.25, 1.0, 2.0, 0.25, 0.75, 0.5]]
+    only_host = compile_fc_parameters({spread: None})
+    names, matrix = only_host.finish(np.empty((2, 0)), lambda i: rows[i], 2)
+    assert names == ["spread"] and matrix.tolist() == [[5.0], [0.5]]

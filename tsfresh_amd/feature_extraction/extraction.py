@@ -165,18 +165,22 @@ def extract_features(
             key = (id(fc_parameters), kind_has_dt)
             if key not in plan_cache:
                 fplan = compile_fc_parameters(fc_parameters, has_datetime_index=kind_has_dt)
-                nplan = _acquire_plan(fplan, device) if len(fplan) else None
+                nplan = _acquire_plan(fplan, device) if fplan.names else None
                 plan_cache[key] = (fplan, nplan)
             fplan, nplan = plan_cache[key]
-            if nplan is None:
+            if len(fplan) == 0:
                 continue
-            if devices is not None and len(devices) > 1:
+            if not fplan.names:
+                matrix = np.empty((pk.n_series, 0))
+            elif devices is not None and len(devices) > 1:
                 from tsfresh_amd.distributed import extract_on_devices
                 matrix = extract_on_devices(fplan.native_specs(_native.calc_id), pk.values, pk.offsets, devices,
                                             times=pk.times)
             else:
                 matrix = nplan.extract_host(pk.values, pk.offsets, times=pk.times)
-            blocks.append((pk, [pk.kind + "__" + name for name in fplan.names], matrix))
+            # user-defined calculators (callable keys): per series on the host, spliced in at their dict position
+            names, matrix = fplan.finish(matrix, lambda i, pk=pk: pk.values[pk.offsets[i]:pk.offsets[i + 1]], pk.n_series)
+            blocks.append((pk, [pk.kind + "__" + name for name in names], matrix))
 
     return _assemble(blocks, id_dtype, pivot, impute_function)
 
@@ -268,6 +272,10 @@ def extract_rolled_features(timeseries_container, column_id=None, column_sort=No
             key = (id(fc_parameters), kind_has_dt)
             if key not in plan_cache:
                 fplan = compile_fc_parameters(fc_parameters, has_datetime_index=kind_has_dt)
+                if fplan.host_calls:
+                    from tsfresh_amd.feature_extraction.registry import UnsupportedFeature
+                    raise UnsupportedFeature("custom (callable) calculators are evaluated per series on the host: roll the "
+                                             "frame with roll_time_series and call extract_features on it")
                 plan_cache[key] = (fplan, _acquire_plan(fplan, device) if len(fplan) else None)
             fplan, nplan = plan_cache[key]
             if nplan is None:

@@ -11,14 +11,62 @@ from tsfresh_amd.feature_extraction.registry import CALCULATORS, UnsupportedFeat
 
 
 class FeaturePlan:
-    """Column names (without the kind prefix) and native specs of one FCParameters mapping."""
+    """Column names (without the kind prefix) and native specs of one FCParameters mapping.
 
-    def __init__(self, names, specs):
-        self.names = names    # list[str]  "<calculator>[__<params>]"
+    `host_calls`: user-defined calculators (callable keys of the FCParameters dict, extraction.py:340-343 /
+    docs/text/how_to_add_custom_feature.rst).  A user's Python function has no kernel; it is evaluated per series on
+    the host exactly as the reference's dispatcher would (extraction.py:345-378) and its columns are spliced into the
+    native matrix at the position the dict order gives them (`finish`)."""
+
+    def __init__(self, names, specs, host_calls=(), layout=None):
+        self.names = names    # list[str]  "<calculator>[__<params>]" of the NATIVE columns
         self.specs = specs    # list[(calculator name, (p0, p1, p2, p3))], aligned with names
+        self.host_calls = list(host_calls)  # [(func, parameter_list)]
+        self.layout = layout  # [("native", first, end) | ("host", k)] in reference order; None = native only
 
     def __len__(self):
-        return len(self.names)
+        return len(self.names) + len(self.host_calls)
+
+    def finish(self, matrix, series_of, n_series):
+        """-> (column names, matrix) with the host-evaluated custom calculators spliced in.
+        series_of(i) -> 1-D ndarray of series i (the dtype of the input column, as the reference hands data.values)."""
+        if not self.host_calls:
+            return self.names, matrix
+        import numpy as np
+        import pandas as pd
+
+        from tsfresh_amd.utilities.string_manipulation import convert_to_output_format
+        blocks = []
+        for func, parameter_list in self.host_calls:
+            cols, names = None, None
+            for i in range(n_series):
+                x = series_of(i)
+                if getattr(func, "input", None) == "pd.Series":
+                    x = pd.Series(x)
+                if getattr(func, "fctype", None) == "combiner":
+                    result = list(func(x, param=parameter_list))
+                elif parameter_list:
+                    result = [(convert_to_output_format(param), func(x, **param)) for param in parameter_list]
+                else:
+                    result = [("", func(x))]
+                row_names = [func.__name__ + ("__" + str(k) if k else "") for k, _ in result]
+                if names is None:
+                    names = row_names
+                    cols = np.full((n_series, len(names)), np.nan)
+                    pos = {nm: j for j, nm in enumerate(names)}
+                for nm, (_, v) in zip(row_names, result):
+                    if nm in pos:
+                        cols[i, pos[nm]] = v
+            blocks.append((names or [], cols if cols is not None else np.empty((n_series, 0))))
+        out_names, parts = [], []
+        for seg in self.layout:
+            if seg[0] == "native":
+                out_names.extend(self.names[seg[1]:seg[2]])
+                parts.append(matrix[:, seg[1]:seg[2]])
+            else:
+                out_names.extend(blocks[seg[1]][0])
+                parts.append(blocks[seg[1]][1])
+        return out_names, np.concatenate(parts, axis=1) if parts else matrix
 
     def native_specs(self, calc_id):
         """[(id, p)] with ids resolved through the C library's registry (tsfa_calc_id)."""
@@ -35,16 +83,23 @@ def compile_fc_parameters(fc_parameters, has_datetime_index=False):
     """Compile one FCParameters mapping (settings.py) to a :class:`FeaturePlan`.
 
     Column order follows the reference: calculators in dict order, parameter sets in list order
-    (extraction.py:339-378).  Raises UnsupportedFeature for anything that has no native kernel -- custom
-    callables, matrix_profile, query_similarity_count with a query --
-    instead of silently computing it on the CPU.
+    (extraction.py:339-378).  Raises UnsupportedFeature for a LIBRARY calculator that has no native kernel
+    (matrix_profile, query_similarity_count with a query) instead of silently computing it on the CPU; a user's own
+    callable key is the user's code and runs on the host (FeaturePlan.finish).
     """
     names, specs, seen = [], [], set()
+    host_calls, layout, seg_start = [], [], 0
     for key, param_list in fc_parameters.items():
         if callable(key):
-            raise UnsupportedFeature(
-                "custom calculator {!r}: user-defined Python calculators cannot run in the native path".format(
+            if getattr(key, "index_type", None) is not None:
+                raise UnsupportedFeature("custom calculator {!r} requires an index type: not supported".format(
                     getattr(key, "__name__", key)))
+            if len(names) > seg_start:
+                layout.append(("native", seg_start, len(names)))
+            seg_start = len(names)
+            layout.append(("host", len(host_calls)))
+            host_calls.append((key, param_list))
+            continue
         if key not in CALCULATORS:
             raise AttributeError("module 'feature_calculators' has no attribute {!r}".format(key))
         calc = CALCULATORS[key]
@@ -65,4 +120,6 @@ def compile_fc_parameters(fc_parameters, has_datetime_index=False):
             seen.add(name)
             names.append(name)
             specs.append((key, calc.encode(param) if param is not None else (0.0, 0.0, 0.0, 0.0)))
-    return FeaturePlan(names, specs)
+    if host_calls and len(names) > seg_start:
+        layout.append(("native", seg_start, len(names)))
+    return FeaturePlan(names, specs, host_calls, layout if host_calls else None)

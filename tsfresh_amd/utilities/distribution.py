@@ -33,11 +33,17 @@ class GPUDistributor(_Base):
         from tsfresh_amd.feature_extraction.extraction import _acquire_plan, _default_device
         from tsfresh_amd.feature_extraction.plan import compile_fc_parameters
         fplan = compile_fc_parameters(fc_parameters, has_datetime_index=has_dt)
+        n_series = len(offsets) - 1
         if len(fplan) == 0:
-            return [], np.empty((len(offsets) - 1, 0))
-        device = self.device if self.device is not None else _default_device()
-        plan = _acquire_plan(fplan, device)  # cached per thread: no 8 ms plan build per call
-        return list(fplan.names), plan.extract_host(values, offsets, times=times)
+            return [], np.empty((n_series, 0))
+        if fplan.names:
+            device = self.device if self.device is not None else _default_device()
+            plan = _acquire_plan(fplan, device)  # cached per thread: no 8 ms plan build per call
+            matrix = plan.extract_host(values, offsets, times=times)
+        else:
+            matrix = np.empty((n_series, 0))
+        names, matrix = fplan.finish(matrix, lambda i: values[offsets[i]:offsets[i + 1]], n_series)
+        return list(names), matrix
 
     def map_reduce(self, map_function=None, data=None, function_kwargs=None, chunk_size=None, data_length=None):
         kwargs = function_kwargs or {}
