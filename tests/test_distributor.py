@@ -135,3 +135,28 @@ def test_the_real_reference_pipeline_drives_the_distributor():
         names = ["value__" + c[len(kind) + 2:] for c in cols]
         bad = compare(names, got[cols].to_numpy(), want_ref[cols].to_numpy(), series, simd_golden=True)
         assert not bad, (kind, bad[:6])
+
+
+@pytest.mark.gpu
+def test_partition_binding_returns_the_reference_long_rows(gpu):
+    """tsfresh_amd.convenience.bindings.feature_extraction_on_partition: one pandas partition in, the long
+    (id, variable, value) frame of the reference's dask helper out (bindings.py:9-60), equal to the pivoted call."""
+    from tsfresh_amd import MinimalFCParameters, extract_features
+    from tsfresh_amd.convenience.bindings import dask_feature_extraction_on_chunk, feature_extraction_on_partition
+    chunks = _chunks()
+    df = pd.concat([pd.DataFrame({"id": c.id, "kind": c.kind, "t": np.arange(len(c.data)), "v": c.data.to_numpy()})
+                    for c in chunks], ignore_index=True)
+    long = feature_extraction_on_partition(df, column_id="id", column_kind="kind", column_value="v", column_sort="t",
+                                           default_fc_parameters=MinimalFCParameters())
+    assert list(long.columns) == ["id", "variable", "value"] and long["value"].dtype == np.float64
+    wide = long.pivot_table(index="id", columns="variable", values="value", aggfunc="mean")
+    want = extract_features(df, column_id="id", column_sort="t", column_kind="kind", column_value="v",
+                            default_fc_parameters=MinimalFCParameters())
+    assert sorted(wide.columns) == sorted(want.columns)
+    assert np.array_equal(wide[want.columns].to_numpy(), want.to_numpy())
+    assert len(feature_extraction_on_partition(df.iloc[:0], "id", "kind", "v", "t", MinimalFCParameters())) == 0
+    try:
+        import dask  # noqa: F401
+    except ImportError:
+        with pytest.raises(ImportError, match="needs dask"):
+            dask_feature_extraction_on_chunk(df, "id", "kind", "v", "t", MinimalFCParameters())

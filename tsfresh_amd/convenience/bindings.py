@@ -1,0 +1,63 @@
+"""dask-partition binding (reference: tsfresh/convenience/bindings.py:9-60, :62-178).
+
+The reference hands dask one `(id, kind)` group at a time: `df.groupby([id, kind]).apply(_feature_extraction_on_chunk_
+helper)` runs the Python dispatcher per series and returns long `(id, variable, value)` rows.  One series per call is
+the wrong grain for a GPU: here the unit of work is a whole PARTITION -- `feature_extraction_on_partition` packs every
+(id, kind) series of a pandas frame into one ragged batch per kind, extracts it in one pass and returns the same long
+rows; `dask_feature_extraction_on_chunk` maps it over the partitions of a dask DataFrame (which must be partitioned
+so that no id is split across partitions, e.g. `df.set_index(column_id)` or `shuffle(on=column_id)`).
+
+dask is not a dependency of this package: the dask entry point imports it lazily and says so when it is missing.
+"""
+import numpy as np
+import pandas as pd
+
+from tsfresh_amd.feature_extraction.extraction import extract_features
+from tsfresh_amd.feature_extraction.settings import ComprehensiveFCParameters
+
+
+def feature_extraction_on_partition(df, column_id, column_kind, column_value, column_sort=None,
+                                    default_fc_parameters=None, kind_to_fc_parameters=None, device=None):
+    """All series of one pandas frame (a dask partition) -> long DataFrame `[column_id, "variable", "value"]` with the
+    rows `_feature_extraction_on_chunk_helper` (bindings.py:9-60) would produce for every (id, kind) group: `variable` is
+    the reference's column name `"{kind}__{calculator}__{params}"`, `value` a float64."""
+    if default_fc_parameters is None and kind_to_fc_parameters is None:
+        default_fc_parameters = ComprehensiveFCParameters()
+    elif default_fc_parameters is None and kind_to_fc_parameters is not None:
+        default_fc_parameters = {}
+    empty = pd.DataFrame({column_id: pd.Series([], dtype=df[column_id].dtype if column_id in df else "int64"),
+                          "variable": pd.Series([], dtype=object), "value": pd.Series([], dtype="float64")})
+    if len(df) == 0:
+        return empty
+    tuples = extract_features(df, column_id=column_id, column_kind=column_kind, column_value=column_value,
+                              column_sort=column_sort, default_fc_parameters=default_fc_parameters,
+                              kind_to_fc_parameters=kind_to_fc_parameters, pivot=False, device=device)
+    if not tuples:
+        return empty
+    ids, variables, values = zip(*tuples)
+    out = pd.DataFrame({column_id: np.asarray(ids), "variable": np.asarray(variables, dtype=object),
+                        "value": np.asarray(values, dtype=np.float64)})
+    return out[[column_id, "variable", "value"]]
+
+
+def dask_feature_extraction_on_chunk(df, column_id, column_kind, column_value, column_sort=None,
+                                     default_fc_parameters=None, kind_to_fc_parameters=None, device=None):
+    """The reference's dask entry point (bindings.py:62) at partition grain.
+
+    :param df: a dask DataFrame in long format with the columns `column_id`, `column_kind`, `column_value` (and
+        `column_sort`), partitioned so that every id lives in ONE partition.  (The reference takes the frame already
+        grouped by (id, kind); a `DataFrameGroupBy` is accepted too and its underlying frame is used.)
+    :return: a dask DataFrame with the columns `[column_id, "variable", "value"]`, as the reference returns; pivot it
+        with `pivot_table(index=column_id, columns="variable", values="value")`."""
+    try:
+        import dask.dataframe as dd  # noqa: F401
+    except ImportError as e:  # pragma: no cover - dask is not installed in the build image
+        raise ImportError("dask_feature_extraction_on_chunk needs dask[dataframe]; for a pandas frame call "
+                          "feature_extraction_on_partition directly") from e
+    frame = getattr(df, "obj", df)  # a groupby object carries its frame as .obj
+    meta = pd.DataFrame({column_id: pd.Series([], dtype=frame[column_id].dtype), "variable": pd.Series([], dtype=object),
+                         "value": pd.Series([], dtype="float64")})
+    return frame.map_partitions(feature_extraction_on_partition, column_id=column_id, column_kind=column_kind,
+                                column_value=column_value, column_sort=column_sort,
+                                default_fc_parameters=default_fc_parameters, kind_to_fc_parameters=kind_to_fc_parameters,
+                                device=device, meta=meta)
