@@ -584,3 +584,33 @@ def test_custom_callable_calculator_next_to_native_ones(gpu):
     got = extract_features(df, column_id="id", column_sort="time", default_fc_parameters={"maximum": None, spread: None, "minimum": None})
     assert list(got.columns) == ["value__maximum", "value__spread", "value__minimum"]
     assert np.allclose(got["value__spread"], got["value__maximum"] - got["value__minimum"], rtol=0, atol=1e-15)
+
+
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+def test_order_statistics_by_selection_equal_numpy(gpu, dtype, monkeypatch):
+    """Plans whose sort family holds only median / quantile columns (MinimalFCParameters) run k_order_stats: selection
+    in registers instead of a sort.  Exactly np.median / np.quantile, and exactly what the sorting kernel returns."""
+    rng = np.random.default_rng(51)
+    lens = [1, 2, 3, 4, 63, 64, 65, 255, 256, 257, 1000, 1023, 1024, 1025, 2047, 2048] + list(rng.integers(1, 2048, size=40))
+    chunks = []
+    for i, n in enumerate(lens):
+        kind = i % 4
+        x = rng.standard_normal(n) if kind == 0 else (np.round(rng.standard_normal(n), 1) if kind == 1 else
+                                                       (rng.integers(-2, 3, n).astype(float) if kind == 2 else np.cumsum(rng.standard_normal(n))))
+        if i == 7:
+            x = np.zeros(n)
+            x[::2] = -0.0
+        chunks.append(x.astype(dtype))
+    values = np.concatenate(chunks)
+    offsets = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
+    params = {"median": None, "quantile": [{"q": q} for q in (0.1, 0.2, 0.3, 0.4, 0.6, 0.7, 0.8, 0.9, 0.0, 1.0, 0.5)]}
+    names, got = hip_engine(params, values, offsets)
+    monkeypatch.setenv("TSFA_NO_SELECT", "1")
+    names2, sorted_path = hip_engine(params, values, offsets)
+    monkeypatch.delenv("TSFA_NO_SELECT")
+    assert names == names2 and np.array_equal(got, sorted_path)
+    for i in range(len(lens)):
+        x = values[offsets[i]:offsets[i + 1]].astype(np.float64)
+        assert got[i, names.index("value__median")] == np.median(x)
+        for q in (0.1, 0.4, 0.9, 0.0, 1.0, 0.5):
+            assert got[i, names.index("value__quantile__q_%s" % q)] == np.quantile(x, q), (i, len(x), q)

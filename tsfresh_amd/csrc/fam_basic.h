@@ -38,8 +38,10 @@ struct BasicStats {
     int first_max, last_max, first_min, last_min, cnt_max, cnt_min;
 };
 
+// want_loc: some column needs the positions / multiplicities of the extrema (first / last_location_of_*,
+// has_duplicate_*); a plan without them (MinimalFCParameters) skips that sweep and its six reductions
 template <class XS>
-TSFA_DEV void basic_stats(const Blk &b, XS xs, int n, BasicStats &st) {
+TSFA_DEV void basic_stats(const Blk &b, XS xs, int n, BasicStats &st, bool want_loc = true) {
     st.n = n;
     st.sum = np_sum(b, n, [=](int i) { return xs[i]; });          // np.sum
     st.mean = st.sum / (double)n;                                   // np.mean = add.reduce / n
@@ -57,6 +59,8 @@ TSFA_DEV void basic_stats(const Blk &b, XS xs, int n, BasicStats &st) {
     st.vmin = blk_min(b, mn);
     st.vmax = blk_max(b, mx);
     st.sumsq = blk_sum(b, sq);
+    st.first_max = 0; st.last_max = 0; st.first_min = 0; st.last_min = 0; st.cnt_max = 0; st.cnt_min = 0;
+    if (!want_loc) return;
     double fmx = (double)n, lmx = -1.0, fmn = (double)n, lmn = -1.0, cmx = 0.0, cmn = 0.0;
     for (int i = b.tid; i < n; i += b.nt) {
         const double v = xs[i];
@@ -591,14 +595,16 @@ TSFA_DEV bool basic_sum_pass(const Blk &b, XS xs, int n, const TsfaSpec *specs, 
 template <int PART, class XS>
 TSFA_DEV void fam_basic_series(const Blk &b0, XS xs, int n, const TsfaSpec *specs, int nspecs,
                                double *out_row, double *w, double *cum, double *altc, int *iw, const double *dectab,
-                               int peaks_maxsup, int alt_want_p, const TsfaAltPlan &alt, TsfaSpec *stage,
+                               int peaks_hint, int alt_want_p, const TsfaAltPlan &alt, TsfaSpec *stage,
                                const double *times = nullptr, int n_loop = -1, double *ctx = nullptr,
                                int n_count = 0, int n_sum = 0) {
     const Blk &b = b0;
     TSFA_TICKER(tk, 0);
     BasicStats st;
+    const int peaks_maxsup = peaks_hint & 0xFFFF;         // tsfa_prepare_family: largest number_peaks support
+    const bool want_loc = ((peaks_hint >> 16) & 1) == 0;  // ... and bit 16: no column reads the extrema's positions
     if (PART & 1) {
-        basic_stats(b, xs, n, st);
+        basic_stats(b, xs, n, st, want_loc);
     } else {
         st.n = n; st.sum = 0.0; st.mean = 0.0; st.var = 0.0; st.std = 0.0; st.vmin = 0.0; st.vmax = 0.0; st.sumsq = 0.0;
         st.first_max = 0; st.last_max = 0; st.first_min = 0; st.last_min = 0; st.cnt_max = 0; st.cnt_min = 0;

@@ -83,6 +83,7 @@ struct tsfa_plan {
     hipEvent_t ev_in[TSFA_MAX_CHUNKS] = {nullptr}, ev_k[TSFA_MAX_CHUNKS] = {nullptr};
     std::vector<int64_t> h_rel;                 // offsets relative to the staged span
     bool needs_times = false;  // the plan holds linear_trend_timewise columns
+    bool sort_only_order_stats = false;  // the SORT family holds only median / quantile columns
     // side streams: the family kernels are independent (each writes its own columns), so they may overlap
     int n_streams = 1;
     hipStream_t aux[TSFA_MAX_AUX] = {nullptr};
@@ -222,6 +223,9 @@ int tsfa_plan_create(const tsfa_feature_spec *specs, int32_t n_specs, int32_t de
         return fail(TSFA_ERR_HIP, "hipSetDevice failed");
     }
     for (int f = 0; f < TSFA_N_FAMILIES; ++f) tsfa_prepare_family(f, plan->fam_specs[f], plan->hints[f]);
+    plan->sort_only_order_stats = !plan->fam_specs[TSFA_FAM_SORT].empty();
+    for (const auto &sp : plan->fam_specs[TSFA_FAM_SORT])
+        if (sp.calc != TSFA_C_MEDIAN && sp.calc != TSFA_C_QUANTILE) plan->sort_only_order_stats = false;
     bool ok = hipStreamCreateWithFlags(&plan->stream, hipStreamNonBlocking) == hipSuccess;
     for (int f = 0; ok && f < TSFA_N_FAMILIES; ++f) ok = upload(plan->fam_specs[f], &plan->d_specs[f]) == 0;
     if (ok && !cwt_coef.empty()) {
@@ -545,7 +549,12 @@ static int run_batch(tsfa_plan *plan, const void *d_values, int dtype, const dou
                 a.long_bytes = (size_t)n_slots * slot_bytes;
             }
             int rc = 0;
-            if (f == TSFA_FAM_SEQ) {
+            if (f == TSFA_FAM_SORT && plan->sort_only_order_stats && maxn <= 2048 && !use_long &&
+                !(getenv("TSFA_NO_SELECT") && atoi(getenv("TSFA_NO_SELECT")))) {
+                // a plan that only asks the sort family for median / quantile columns (MinimalFCParameters): selection
+                // in registers, one wavefront per series, no sorted copy (tsfa_kernels.hip: k_order_stats)
+                rc = tsfa_launch_order_stats(a);
+            } else if (f == TSFA_FAM_SEQ) {
                 for (int s0 = 0; rc == 0 && s0 < a.nspecs; s0 += seq_group) {
                     lz_build_group(plan->fam_specs[f].data() + s0, std::min(seq_group, a.nspecs - s0), maxn, &a.seq);
                     if (!use_long && tsfa_seq_lds_bytes(a.seq) > TSFA_LDS_LIMIT)

@@ -102,6 +102,15 @@ static inline void tsfa_prepare_family_impl(int fam, std::vector<TsfaSpec> &spec
 
 static inline void tsfa_prepare_family(int fam, std::vector<TsfaSpec> &specs, TsfaFamHints &h) {
     tsfa_prepare_family_impl(fam, specs, h);
+    if (fam == TSFA_FAM_BASIC) {  // bit 16 of a: no column reads the positions / multiplicities of the extrema
+        bool want_loc = false;
+        for (const auto &s : specs)
+            if (s.calc == TSFA_C_FIRST_LOCATION_OF_MAXIMUM || s.calc == TSFA_C_LAST_LOCATION_OF_MAXIMUM ||
+                s.calc == TSFA_C_FIRST_LOCATION_OF_MINIMUM || s.calc == TSFA_C_LAST_LOCATION_OF_MINIMUM ||
+                s.calc == TSFA_C_HAS_DUPLICATE_MAX || s.calc == TSFA_C_HAS_DUPLICATE_MIN)
+                want_loc = true;
+        if (!want_loc) h.a |= (1 << 16);
+    }
     if (fam == TSFA_FAM_AR) {
         // d = columns of the column loop; behind them the reads of results the prologue / an earlier column left in
         // LDS (pacf lags, the three ADF outputs, the other coefficients of an AR fit), evaluated with lane = column.

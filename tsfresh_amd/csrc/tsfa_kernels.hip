@@ -243,6 +243,127 @@ __global__ void __launch_bounds__(MAXT) k_cwtpeaks(const T *__restrict__ values,
 
 #if !defined(TSFA_LONG)
 // ---------------------------------------------------------------------------------------------
+// Order statistics by selection: the SORT family of a plan that only asks for median / quantile columns (the
+// streaming configurations, MinimalFCParameters: one median) does not need the sorted copy -- and with it the LDS
+// residency, the barriers and 43 k cycles of latency per series.  One WAVEFRONT per series, the series in registers
+// (E keys per lane, E = 16 at n = 1024) as order-preserving unsigned integers; the k-th smallest is found bit by bit
+// from the top (#{key < prefix | bit} <= k decides the bit: E compares + one wavefront sum per bit), its successor by
+// one more pass.  No LDS, no barrier, four series per 256-thread workgroup.  np.median / np.quantile("linear") then
+// take their usual expressions on the (at most two) order statistics each needs.
+// ---------------------------------------------------------------------------------------------
+template <typename T> struct OsKey;
+template <> struct OsKey<float> {
+    typedef unsigned int key_t;
+    static constexpr int BITS = 32;
+    static __device__ __forceinline__ key_t enc(float v) {
+        const unsigned int u = __float_as_uint(v);
+        return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+    }
+    static __device__ __forceinline__ double dec(key_t k) {
+        const unsigned int u = (k & 0x80000000u) ? (k & 0x7FFFFFFFu) : ~k;
+        return (double)__uint_as_float(u);
+    }
+    static __device__ __forceinline__ key_t maxkey() { return 0xFFFFFFFFu; }
+};
+template <> struct OsKey<double> {
+    typedef unsigned long long key_t;
+    static constexpr int BITS = 64;
+    static __device__ __forceinline__ key_t enc(double v) {
+        const unsigned long long u = (unsigned long long)__double_as_longlong(v);
+        return (u >> 63) ? ~u : (u | 0x8000000000000000ull);
+    }
+    static __device__ __forceinline__ double dec(key_t k) {
+        const unsigned long long u = (k >> 63) ? (k & 0x7FFFFFFFFFFFFFFFull) : ~k;
+        return __longlong_as_double((long long)u);
+    }
+    static __device__ __forceinline__ key_t maxkey() { return ~0ull; }
+};
+
+// wave64 integer sum without LDS-crossbar traffic: four DPP steps inside the 16-lane rows, then four readlanes
+__device__ __forceinline__ int wave_sum_i32(int v) {
+    v += __builtin_amdgcn_update_dpp(0, v, TSFA_DPP_QUAD_XOR1, 0xf, 0xf, false);
+    v += __builtin_amdgcn_update_dpp(0, v, TSFA_DPP_QUAD_XOR2, 0xf, 0xf, false);
+    v += __builtin_amdgcn_update_dpp(0, v, TSFA_DPP_ROW_HALF_MIRROR, 0xf, 0xf, false);
+    v += __builtin_amdgcn_update_dpp(0, v, TSFA_DPP_ROW_MIRROR, 0xf, 0xf, false);
+    return (__builtin_amdgcn_readlane(v, 0) + __builtin_amdgcn_readlane(v, 16)) +
+           (__builtin_amdgcn_readlane(v, 32) + __builtin_amdgcn_readlane(v, 48));
+}
+
+// k-th smallest (0-based) key of the wavefront's E x 64 keys
+template <typename K, int E, int BITS>
+__device__ __forceinline__ K os_select(const K (&key)[E], int k) {
+    K prefix = 0;
+#pragma unroll 1
+    for (int bit = BITS - 1; bit >= 0; --bit) {
+        const K cand = prefix | ((K)1 << bit);
+        int c = 0;
+#pragma unroll
+        for (int e = 0; e < E; ++e) c += (key[e] < cand) ? 1 : 0;
+        if (wave_sum_i32(c) <= k) prefix = cand;
+    }
+    return prefix;
+}
+
+template <typename T, int E>
+__global__ void __launch_bounds__(256) k_order_stats(const T *__restrict__ values, const int64_t *__restrict__ starts, const int64_t *__restrict__ ends, int64_t n_series,
+                                                     const int *__restrict__ sel, const TsfaSpec *__restrict__ specs, int nspecs,
+                                                     double *__restrict__ out, int64_t ld) {
+    typedef OsKey<T> KC;
+    typedef typename KC::key_t K;
+    const int lane = threadIdx.x & 63;
+    const int64_t wi = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (wi >= n_series) return;  // wave-uniform
+    const int64_t sidx = sel ? (int64_t)sel[wi] : wi;
+    const int64_t off = starts[sidx];
+    const int n = (int)(ends[sidx] - off);
+    const T *__restrict__ g = values + off;
+    K key[E];
+#pragma unroll
+    for (int e = 0; e < E; ++e) {
+        const int i = e * 64 + lane;
+        key[e] = (i < n) ? KC::enc(g[i]) : KC::maxkey();  // pads sort behind every sample (NaN-free input)
+    }
+    double *row = out + sidx * ld;
+    int have_k = -1;
+    double v_k = 0.0, v_k1 = 0.0;  // cached order statistics k and k + 1
+    // order statistic i of the series (wave-collective); np.median / np.quantile read i and i + 1 back to back
+    auto os = [&](int i) -> double {
+        if (i == have_k) return v_k;
+        if (i == have_k + 1 && have_k >= 0) return v_k1;
+        const K kk = os_select<K, E, KC::BITS>(key, i);
+        v_k = KC::dec(kk);
+        // successor: the (i + 1)-th smallest is v_k again if v_k occurs often enough, else the smallest larger key
+        int cle = 0;
+        K nxt = KC::maxkey();
+#pragma unroll
+        for (int e = 0; e < E; ++e) {
+            cle += (key[e] <= kk) ? 1 : 0;
+            if (key[e] > kk && key[e] < nxt) nxt = key[e];
+        }
+        cle = wave_sum_i32(cle);
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            const K t = (K)__shfl_xor(nxt, o);
+            nxt = (t < nxt) ? t : nxt;
+        }
+        v_k1 = (cle >= i + 2 || i + 1 >= n) ? v_k : KC::dec(nxt);
+        have_k = i;
+        return v_k;
+    };
+    for (int s = 0; s < nspecs; ++s) {
+        const TsfaSpec sp = specs[s];
+        double res;
+        if (sp.calc == TSFA_C_MEDIAN) {                                      // fc.py:663 np.median
+            if (n & 1) res = os((n - 1) / 2);
+            else { const double a0 = os(n / 2 - 1), a1 = os(n / 2); res = (0.0 + a0 + a1) / 2.0; }
+        } else {                                                             // fc.py:1963 np.quantile (TSFA_C_QUANTILE)
+            res = np_quantile_sorted(os, n, sp.p[0]);
+        }
+        if (lane == 0) row[sp.col] = res;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
 // cwt_coefficients (fc.py:1370): pywt.cwt(x, widths, "mexh")[i, coeff] only ever reads output positions
 // coeff < ~15, i.e. a dot product of the first S samples with a fixed filter column.  For a batch that is the
 // dense contraction  X[n_series x S] . W[S x C]  -> float64 MFMA (v_mfma_f64_16x16x4_f64), one wavefront per
@@ -500,6 +621,27 @@ size_t tsfa_family_lds_bytes(int fam, int maxn, int nt, int aux) {
 int tsfa_launch_family(const TsfaLaunch &a) {
     if (a.dtype == 0) return launch_all_t<float>(a, (const float *)a.values);
     return launch_all_t<double>(a, (const double *)a.values);
+}
+
+// SORT family of a plan that holds only median / quantile columns, series of at most 2048 samples: selection in registers
+template <typename T>
+static int launch_order_stats_t(const TsfaLaunch &a, const T *values) {
+    hipStream_t st = (hipStream_t)a.stream;
+    const dim3 grid((unsigned)((a.n_series + 3) / 4));
+    if (a.maxn <= 256)
+        k_order_stats<T, 4><<<grid, 256, 0, st>>>(values, a.starts, a.ends, a.n_series, a.sel, a.specs, a.nspecs, a.out, a.ld);
+    else if (a.maxn <= 1024)
+        k_order_stats<T, 16><<<grid, 256, 0, st>>>(values, a.starts, a.ends, a.n_series, a.sel, a.specs, a.nspecs, a.out, a.ld);
+    else if (a.maxn <= 2048)
+        k_order_stats<T, 32><<<grid, 256, 0, st>>>(values, a.starts, a.ends, a.n_series, a.sel, a.specs, a.nspecs, a.out, a.ld);
+    else
+        return -1;
+    TSFA_LAUNCH_CHECK();
+    return 0;
+}
+int tsfa_launch_order_stats(const TsfaLaunch &a) {
+    if (a.dtype == 0) return launch_order_stats_t<float>(a, (const float *)a.values);
+    return launch_order_stats_t<double>(a, (const double *)a.values);
 }
 
 template <typename T>
