@@ -119,9 +119,13 @@ extern "C" int tsfa_emul_extract_timed(const tsfa_feature_spec *specs, int n_spe
             const int nd = (maxn > 256) ? maxn : 256;
             std::vector<double> Xr(nx), Xi(nx), tc(nd), ts(nd), win(256), pxx(132);
             std::vector<int> iw(128);
+            // even series take the Bluestein route where it applies (HBM scratch on the device), odd ones the Goertzel sweep
+            std::vector<double> gsv((s % 2 == 0 && n >= TSFA_BLUESTEIN_MIN && bluestein_m(n) <= TSFA_BLUESTEIN_MAXM)
+                                        ? 4 * (size_t)bluestein_m(n) : 0);
             fam_spectral_series(b, xs.data(), n, fam[TSFA_FAM_SPECTRAL].data(), (int)fam[TSFA_FAM_SPECTRAL].size(), row,
                                 Xr.data(), Xi.data(), tc.data(), ts.data(), win.data(), pxx.data(), iw.data(),
-                                twc.data(), tws.data(), hints[TSFA_FAM_SPECTRAL].a, hints[TSFA_FAM_SPECTRAL].b);
+                                twc.data(), tws.data(), hints[TSFA_FAM_SPECTRAL].a, hints[TSFA_FAM_SPECTRAL].b,
+                                gsv.empty() ? nullptr : gsv.data());
         }
         if (!fam[TSFA_FAM_AR].empty()) {
             int P = 8;

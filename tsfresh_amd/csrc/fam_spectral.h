@@ -168,6 +168,144 @@ TSFA_DEV void blk_rfft(const Blk &b, int n, G g, double *Xr, double *Xi, double 
     blk_sync();
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// Long series of arbitrary length: Bluestein's chirp-z transform.  X_k = c_k sum_j (x_j c_j) conj(c_{k-j}) with
+// c_j = exp(-i pi j^2 / n) turns the length-n DFT into a circular convolution of length M = 2^ceil(log2(2n - 1)),
+// i.e. three power-of-two FFTs -- O(n log n) against the O(n^2) of the Goertzel sweep above (33 M multiply-adds at
+// n = 8192, every bin of which fft_aggregated reads).  M complex points do not fit LDS beside the series (256 KB at
+// n = 8192), so they live in a slot of HBM scratch per workgroup (L2 / Infinity Cache resident) and pass through LDS in
+// tiles: gfft_pow2 runs the first log2(T) butterfly stages on T-point tiles staged in Xr/Xi (which the transform's
+// result only occupies at the very end) and the last log2(M / T) stages in place in the scratch.  The chirp phases come
+// from j^2 mod 2n in integer arithmetic, so they stay accurate to the last bit for every n.
+// ---------------------------------------------------------------------------------------------------------------
+#define TSFA_BLUESTEIN_MIN 4097     // measured (5 000 series): 4096..8192 samples 16.7 -> 14.1 ms, 2049..4096 samples 4.1 -> 5.5 ms
+#define TSFA_BLUESTEIN_MAXM 65536   // the shared twiddle table (TSFA_TW_N) serves FFTs up to this size: n <= 32768
+
+TSFA_DEV int tsfa_bitrev(int i, int bits) {
+#if TSFA_GPU
+    return (bits > 0) ? (int)(__builtin_bitreverse32((unsigned)i) >> (32 - bits)) : 0;
+#else
+    unsigned r = 0, x = (unsigned)i;
+    for (int k = 0; k < bits; ++k) { r = (r << 1) | (x & 1u); x >>= 1; }
+    return (int)r;
+#endif
+}
+
+// dre/dim[0 .. M) (HBM scratch, natural order) = forward FFT of the M points src(j, &re, &im), j in natural order.
+// lre / lim: LDS tile buffers of T doubles each (T a power of two <= M).
+template <class SRC>
+TSFA_DEV void gfft_pow2(const Blk &b, SRC src, double *dre, double *dim, int M, double *lre, double *lim, int T,
+                        const double *twc, const double *tws) {
+    int logM = 0;
+    while ((1 << logM) < M) ++logM;
+    if (T > M) T = M;
+    for (int t0 = 0; t0 < M; t0 += T) {
+        blk_sync();
+        for (int i = b.tid; i < T; i += b.nt) {
+            double re, im;
+            src(tsfa_bitrev(t0 + i, logM), &re, &im);
+            lre[i] = re;
+            lim[i] = im;
+        }
+        int lh = 0;
+        for (int len = 2; len <= T; len <<= 1, ++lh) {
+            const int half = len >> 1, stride = TSFA_TW_N / len;
+            blk_sync();
+            for (int t = b.tid; t < (T >> 1); t += b.nt) {
+                const int grp = t >> lh, k = t & (half - 1);
+                const int i0 = grp * len + k, i1 = i0 + half;
+                const double wr = twc[k * stride], wi = tws[k * stride];
+                const double xr = lre[i1], xi = lim[i1];
+                const double tr = xr * wr - xi * wi, ti = xr * wi + xi * wr;
+                const double ur = lre[i0], ui = lim[i0];
+                lre[i1] = ur - tr;
+                lim[i1] = ui - ti;
+                lre[i0] = ur + tr;
+                lim[i0] = ui + ti;
+            }
+        }
+        blk_sync();
+        for (int i = b.tid; i < T; i += b.nt) {
+            dre[t0 + i] = lre[i];
+            dim[t0 + i] = lim[i];
+        }
+    }
+    int lh = 0;
+    while ((1 << lh) < T) ++lh;  // log2(half) of the first global stage
+    for (int len = 2 * T; len <= M; len <<= 1, ++lh) {
+        const int half = len >> 1, stride = TSFA_TW_N / len;
+        blk_sync_all();
+        for (int t = b.tid; t < (M >> 1); t += b.nt) {
+            const int grp = t >> lh, k = t & (half - 1);
+            const int i0 = grp * len + k, i1 = i0 + half;
+            const double wr = twc[k * stride], wi = tws[k * stride];
+            const double xr = dre[i1], xi = dim[i1];
+            const double tr = xr * wr - xi * wi, ti = xr * wi + xi * wr;
+            const double ur = dre[i0], ui = dim[i0];
+            dre[i1] = ur - tr;
+            dim[i1] = ui - ti;
+            dre[i0] = ur + tr;
+            dim[i0] = ui + ti;
+        }
+    }
+    blk_sync_all();
+}
+
+TSFA_DEV int bluestein_m(int n) {
+    int M = 1;
+    while (M < 2 * n - 1) M <<= 1;
+    return M;
+}
+
+// rfft of G(i), i < n, into Xr/Xi[0 .. n/2] through gs (4 * bluestein_m(n) doubles of HBM scratch)
+template <class G>
+TSFA_DEV void blk_rfft_bluestein(const Blk &b, int n, G g, double *Xr, double *Xi, double *gs, const double *twc,
+                                 const double *tws) {
+    const int M = bluestein_m(n);
+    int T = 1;
+    while (2 * T <= n / 2 + 1) T <<= 1;  // Xr / Xi hold n/2 + 2 doubles each
+    double *Are = gs, *Aim = gs + M, *Bre = gs + 2 * (size_t)M, *Bim = gs + 3 * (size_t)M;
+    const double dn = (double)n;
+    // conj(c_j) = exp(+i pi j^2 / n), phase reduced in integers: j^2 mod 2n
+    auto chirp = [=](int j, double *c, double *s) {
+        const unsigned long long jj = ((unsigned long long)j * (unsigned long long)j) % (2ull * (unsigned long long)n);
+        tsfa_sincospi((double)jj / dn, s, c);
+    };
+    gfft_pow2(b, [=](int j, double *re, double *im) {
+        const int jj = (j < n) ? j : ((M - j < n) ? M - j : -1);
+        if (jj < 0) { *re = 0.0; *im = 0.0; return; }
+        double c, s;
+        chirp(jj, &c, &s);
+        *re = c;
+        *im = s;
+    }, Bre, Bim, M, Xr, Xi, T, twc, tws);
+    gfft_pow2(b, [=](int j, double *re, double *im) {
+        if (j >= n) { *re = 0.0; *im = 0.0; return; }
+        double c, s;
+        chirp(j, &c, &s);
+        const double x = g(j);
+        *re = x * c;
+        *im = -(x * s);
+    }, Are, Aim, M, Xr, Xi, T, twc, tws);
+    for (int j = b.tid; j < M; j += b.nt) {  // A <- conj(A B): the inverse transform is conj(FFT(conj(.))) / M
+        const double ar = Are[j], ai = Aim[j], br = Bre[j], bi = Bim[j];
+        Are[j] = ar * br - ai * bi;
+        Aim[j] = -(ar * bi + ai * br);
+    }
+    blk_sync_all();
+    gfft_pow2(b, [=](int j, double *re, double *im) { *re = Are[j]; *im = Aim[j]; }, Bre, Bim, M, Xr, Xi, T, twc, tws);
+    const double inv_m = 1.0 / (double)M;
+    const int nh = n / 2;
+    for (int k = b.tid; k <= nh; k += b.nt) {
+        double c, s;
+        chirp(k, &c, &s);
+        const double cr = Bre[k] * inv_m, ci = -(Bim[k] * inv_m);
+        Xr[k] = cr * c + ci * s;  // (cr + i ci)(c - i s)
+        Xi[k] = (k == 0 || 2 * k == n) ? 0.0 : (ci * c - cr * s);
+    }
+    blk_sync();
+}
+
 // scipy.signal.welch(x, nperseg=min(n, 256)) -> pxx[0 .. nperseg/2] (fs=1, hann, 50% overlap,
 // constant detrend, density scaling, mean over segments).  fc.py:1418, fc.py:1809.
 //   win : LDS >= 256 doubles;  pxx : LDS >= 129 doubles;  Xr/Xi/tc/ts : FFT scratch (>= 256 each is enough)
@@ -220,7 +358,8 @@ TSFA_DEV int blk_welch(const Blk &b, const ST *xs, int n, double *win, double *p
 template <class ST>
 TSFA_DEV void fam_spectral_series(const Blk &b, const ST *xs_raw, int n, const TsfaSpec *specs, int nspecs,
                                   double *out_row, double *Xr, double *Xi, double *tc, double *ts, double *win,
-                                  double *pxx, int *iw, const double *twc, const double *tws, int flags, int nlead) {
+                                  double *pxx, int *iw, const double *twc, const double *tws, int flags, int nlead,
+                                  double *gs = nullptr) {
     const XsView<ST> xs{xs_raw};
     // flags / nlead come from tsfa_prepare_family (host): the Welch-based specs are the first nlead of the list
     const bool need_fft = (flags & 1) != 0, need_welch = (flags & 2) != 0;
@@ -264,7 +403,12 @@ TSFA_DEV void fam_spectral_series(const Blk &b, const ST *xs_raw, int n, const T
     if (!need_fft) return;
 
     // ---- full-length rfft ----
-    blk_rfft(b, n, [=](int j) { return xs[j]; }, Xr, Xi, tc, ts, twc, tws);
+    // gs: 4 * bluestein_m(n) doubles of HBM scratch (or null: long lengths of arbitrary factorisation fall back on the
+    // O(n^2) Goertzel sweep of blk_rfft)
+    if (gs != nullptr && n >= TSFA_BLUESTEIN_MIN && !is_pow2(n) && bluestein_m(n) <= TSFA_BLUESTEIN_MAXM)
+        blk_rfft_bluestein(b, n, [=](int j) { return xs[j]; }, Xr, Xi, gs, twc, tws);
+    else
+        blk_rfft(b, n, [=](int j) { return xs[j]; }, Xr, Xi, tc, ts, twc, tws);
     // moments of |X| over the bin index (fc.py:1123)
     double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0, s4 = 0.0;
     for (int k = b.tid; k < nf; k += b.nt) {

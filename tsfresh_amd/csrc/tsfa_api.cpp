@@ -466,6 +466,19 @@ static int run_batch(tsfa_plan *plan, const void *d_values, int dtype, const dou
                 // only non-power-of-two lengths <= 256 use the table-driven DFT (longer ones: Goertzel, no table)
                 a.dft_n = (int)std::min<long long>(max_np2, 256);
                 aux = a.dft_n;
+                // long series of non-power-of-two length: three power-of-two FFTs through HBM scratch (Bluestein,
+                // fam_spectral.h) instead of the O(n^2) Goertzel sweep; 32 M bytes per workgroup, at most 6 GB per launch
+                if (max_np2 >= 4097 && max_np2 <= 32768 && !(getenv("TSFA_NO_BLUESTEIN") && atoi(getenv("TSFA_NO_BLUESTEIN")))) {
+                    long long M = 1;
+                    while (M < 2 * max_np2 - 1) M <<= 1;
+                    const int64_t wgs = std::min<int64_t>(a.n_series, 512 * 64);
+                    const size_t bytes = (size_t)a.n_series * (size_t)(4 * M) * sizeof(double);
+                    (void)wgs;
+                    if (bytes <= (6ull << 30) && plan->gscratch.ensure(bytes) == 0) {
+                        a.gscratch = (double *)plan->gscratch.p;
+                        a.gscratch_n = (int)(4 * M);
+                    }
+                }
             } else if (f == TSFA_FAM_CWT) {
                 a.cwt_rowv = tsfa_family_lds_bytes(f, maxn, a.nt, 1) <= 96 * 1024 ? 1 : 0;
                 aux = a.cwt_rowv;

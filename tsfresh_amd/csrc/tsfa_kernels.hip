@@ -132,13 +132,10 @@ __global__ void __launch_bounds__(1024) k_spectral(const T *__restrict__ values,
         for (int i = b.tid; i < n; i += b.nt) xs[i] = g[i];
         blk_sync();
     }
-    double *tc = L.tc, *ts = L.ts;
-    if (gscratch != nullptr && n > dft_n && n > 256) {  // long non-power-of-two series: twiddles in HBM scratch
-        tc = gscratch + (size_t)sidx * 2 * gscratch_n;
-        ts = tc + gscratch_n;
-    }
-    fam_spectral_series<T>(b, xs, n, specs, nspecs, out + sidx * ld, L.Xr, L.Xi, tc, ts, L.win, L.pxx, L.iw, twc, tws,
-                        hint_a, hint_b);
+    // gscratch: one slot of gscratch_n doubles per workgroup for the Bluestein FFTs of long series (or null)
+    double *gs = gscratch ? gscratch + (size_t)blockIdx.x * (size_t)gscratch_n : nullptr;
+    fam_spectral_series<T>(b, xs, n, specs, nspecs, out + sidx * ld, L.Xr, L.Xi, L.tc, L.ts, L.win, L.pxx, L.iw, twc, tws,
+                        hint_a, hint_b, gs);
     TSFA_TICKS_END();
     TSFA_SERIES_END
 }

@@ -45,7 +45,7 @@ struct TsfaLaunch {
     const double *times;    // BASIC: per-sample hours since the series' first timestamp (linear_trend_timewise) or null
     const double *twc, *tws;  // SPECTRAL: shared FFT twiddles
     int dft_n;              // SPECTRAL: DFT twiddle slots held in LDS
-    double *gscratch;       // SPECTRAL: HBM twiddle scratch for long non-pow2 series (or null)
+    double *gscratch;       // SPECTRAL: HBM scratch of the Bluestein FFTs, one slot of gscratch_n doubles per workgroup (or null)
     int gscratch_n;
     TsfaSeqGroup seq;       // SEQ: the (<= TSFA_LZ_MAX_GROUP) specs this launch parses side by side
     int ar_P;               // AR: leading dimension of the normal matrices
