@@ -127,9 +127,125 @@ TSFA_DEV void cwt_rows_tiled(const Blk &b, XA xat, int n, int W, const CwtPeaksL
     }
 }
 
+// Length / signal-to-noise filter of scipy.signal._peak_finding._filter_ridge_lines over a list of ridge-line end points:
+// entry k = (cols[k], rows ? rows[k] : 0).  signal = cwt[row, col], noise = the 10th percentile
+// (scipy.stats.scoreatpercentile) of |...| row 0 in the window [col - hf, col + hf + odd) clipped to the series.
+// Returns the number of entries with |signal / noise| >= 1; *extra receives how many of those carry `extra_bit` in
+// mask[col] (0: none asked).
+//   order == nullptr : short windows (the percentile is among the eight smallest, or a rank count over <= 70 values),
+//                      lane = entry;
+//   order            : the argsort of row 0.  lane = entry; all lanes walk the SAME global order from the smallest value
+//                      (64 entries per load, handed round with v_readlane: the entry is wave-uniform, the window test
+//                      per lane) and count the entries whose column falls into their own window until they have seen
+//                      the i0-th and (i0 + 1)-th: ~0.1 n entries for 64 end points at once.
+template <class X>
+TSFA_DEV double cwt_filter_list(const Blk &b, X xv, int n, const CwtPeaksLds &L, const unsigned short *cols,
+                                const unsigned short *rows, int cnt, int hf, int odd, bool taps_cached,
+                                const unsigned short *order, unsigned short extra_bit, double *extra) {
+    double kept = 0.0, ext = 0.0;
+#if TSFA_GPU
+    const int lane = b.tid & 63;
+#endif
+    for (int k0 = 0; k0 < cnt; k0 += b.nt) {  // uniform over the workgroup
+        const int k = k0 + b.tid;
+        const bool live = k < cnt;
+        const int col = live ? (int)cols[k] : 0, row = (live && rows) ? (int)rows[k] : 0;
+        const int ws = (col - hf > 0) ? col - hf : 0;
+        const int we = (col + hf + odd < n) ? col + hf + odd : n;
+        const int m = we - ws;
+        const double idx = 10.0 / 100.0 * (double)(m - 1);
+        const int i0 = (int)idx;
+        double s0 = 0.0, s1 = 0.0;
+        if (order != nullptr) {
+#if TSFA_GPU
+            int count = live ? 0 : (1 << 30), p0 = 0, p1 = 0;
+            for (int base = 0; base < n; base += 64) {
+                if (!__ballot(count <= i0 + 1)) break;
+                const int e = base + lane;
+                const int pe = (e < n) ? (int)order[e] : 0xFFFF;
+                const int lim = (n - base < 64) ? n - base : 64;
+                for (int j = 0; j < lim; ++j) {
+                    const int p = __builtin_amdgcn_readlane(pe, j);
+                    const bool in = (p >= ws) & (p < we);
+                    p0 = (in & (count == i0)) ? p : p0;
+                    p1 = (in & (count == i0 + 1)) ? p : p1;
+                    count += in ? 1 : 0;
+                }
+            }
+            s0 = L.row0[p0];
+            s1 = L.row0[p1];
+#else
+            int count = 0;
+            for (int e = 0; live && e < n && count <= i0 + 1; ++e) {
+                const int p = order[e];
+                if (p >= ws && p < we) {
+                    if (count == i0) s0 = L.row0[p];
+                    if (count == i0 + 1) s1 = L.row0[p];
+                    ++count;
+                }
+            }
+#endif
+        } else if (live) {
+            const double *r0 = L.row0 + ws;
+            if (i0 + 1 < 8) {
+                smallest8_select([=](int a) { return r0[a]; }, m, i0, &s0, &s1);
+            } else {
+                for (int a = 0; a < m; ++a) {
+                    const double ea = r0[a];
+                    int rank = 0;
+                    for (int c = 0; c < m; ++c) {
+                        const double ec = r0[c];
+                        rank += (ec < ea || (ec == ea && c < a)) ? 1 : 0;
+                    }
+                    if (rank == i0) s0 = ea;
+                    if (rank == i0 + 1) s1 = ea;
+                }
+            }
+        }
+        if (!live) continue;
+        double noise;
+        if ((double)i0 == idx) {
+            noise = s0;
+        } else {
+            const double j = (double)(i0 + 1);
+            const double w0 = j - idx, w1 = idx - (double)i0;
+            noise = (s0 * w0 + s1 * w1) / (w0 + w1);
+        }
+        double sig;  // cwt[row, col]
+        if (row == 0) {
+            sig = L.row0[col];
+        } else {
+            const int w = row + 1;
+            const int nw = (10 * w < n) ? 10 * w : n;
+            const int m2 = col + (nw - 1) / 2;
+            int kk0 = m2 - (n - 1);
+            if (kk0 < 0) kk0 = 0;
+            const int kk1 = (m2 < nw - 1) ? m2 : (nw - 1);
+            double acc = 0.0;
+            if (taps_cached) {
+                const double *tw = L.taps + 5 * (w - 2) * (w + 1);  // sum_{v=2}^{w-1} 10 v
+                for (int kk = kk1; kk >= kk0; --kk) acc += xv(m2 - kk) * tw[kk];
+            } else {
+                for (int kk = kk1; kk >= kk0; --kk) acc += xv(m2 - kk) * ricker_tap(nw, (double)w, nw - 1 - kk);
+            }
+            sig = acc;
+        }
+        const double snr = fabs(sig / noise);
+        if (!(snr < 1.0)) {
+            kept += 1.0;
+            if (extra_bit && (L.mask[col] & extra_bit)) ext += 1.0;
+        }
+    }
+    kept = blk_sum(b, kept);
+    if (extra_bit) *extra = blk_sum(b, ext);
+    return kept;
+}
+
 // ST: element type of the padded LDS copy of the series (the input precision: float32 samples stay float32)
+// derive_w1 / kept_w1: also return number_cwt_peaks(n = 1) of the same series (phase C), W <= 14
 template <class ST, class X>
-TSFA_DEV double number_cwt_peaks_one(const Blk &b, X xv, int n, int W, const CwtPeaksLds &L) {
+TSFA_DEV double number_cwt_peaks_one(const Blk &b, X xv, int n, int W, const CwtPeaksLds &L, bool derive_w1 = false,
+                                     double *kept_w1 = nullptr) {
     const int cap = n;  // line capacity
     TSFA_TICKER(tk, 0);
     blk_sync();
@@ -241,7 +357,6 @@ TSFA_DEV double number_cwt_peaks_one(const Blk &b, X xv, int n, int W, const Cwt
     const int min_length = (W + 3) / 4;             // ceil(rows / 4)
     const int window = (n + 19) / 20;               // ceil(num_points / 20)
     const int hf = window / 2, odd = window % 2;
-    double kept = 0.0;
     // cwt[row, col] of a line that ended above row 0 is re-evaluated here; its Ricker taps (exp / pow / sqrt each) are
     // tabulated once per width instead of once per tap per line:  taps[5 (w-2)(w+1) + k] = reversed tap k of width w
     const bool taps_cached = (W >= 2) && (10 * W < n) && (5 * (W - 1) * (W + 2) <= TSFA_CWTP_MAXTAPS + 16);
@@ -255,212 +370,93 @@ TSFA_DEV double number_cwt_peaks_one(const Blk &b, X xv, int n, int W, const Cwt
         blk_sync();
     }
     // Long series: the noise window holds hundreds of samples and its 10th percentile is no longer among the eight
-    // smallest.  Ranking a window against itself costs window^2 per ridge line (n^3 / 1200 per series).  Instead the
-    // width-1 row is argsorted ONCE; a line's percentile is then found by walking that global order from the smallest
-    // value and counting the entries whose column falls into the line's window (64 entries per step: ballot +
-    // popcount) -- about 0.1 * n entries per line.  One wavefront per line.
+    // smallest: the width-1 row is argsorted ONCE and every entry walks that global order (cwt_filter_list).
     const bool long_windows = ((int)(0.1 * (double)(window - 1)) + 1 >= 8);
+    const unsigned short *order = nullptr;
     if (__builtin_expect(long_windows, 0)) {
-        unsigned short *order = L.colmap;  // colmap and mline are contiguous and dead by now: 2 * maxn >= pow2(n)
+        unsigned short *ord = L.colmap;  // colmap and mline are contiguous and dead by now: 2 * maxn >= pow2(n)
         int np2 = 1;
         while (np2 < n) np2 <<= 1;
-        blk_argsort_u16(b, L.row0, n, order, np2);
+        blk_argsort_u16(b, L.row0, n, ord, np2);
+        order = ord;
         TSFA_TICK(tk, b, 154);
-#if TSFA_GPU
-        {
-            // lane = line.  All lanes walk the SAME global order from the smallest value (64 entries per load, handed
-            // round with v_readlane: the entry is wave-uniform, the window test is per lane) and count the entries whose
-            // column falls into their own line's window until they have seen the i0-th and (i0 + 1)-th: ~0.1 n entries
-            // for 64 lines at once.  (One wavefront per line with a ballot per 64 entries -- the first version -- spent
-            // 5.5 M cycles per 8192-sample series here; this is 7 compares / adds per entry for 64 lines.)
-            const int lane = b.tid & 63, wave = b.tid >> 6, nwv = b.nt >> 6;
-            for (int l0 = wave * 64; l0 < nlines; l0 += nwv * 64) {  // wave-uniform
-                const int l = l0 + lane;
-                const unsigned short v = (l < nlines) ? L.linf[l] : 0;
-                const bool live = (l < nlines) && (TSFA_LI_LEN(v) >= min_length);
-                const int col = live ? (int)L.lcol[l] : 0, row = TSFA_LI_ROW(v);
-                const int ws = (col - hf > 0) ? col - hf : 0;
-                const int we = (col + hf + odd < n) ? col + hf + odd : n;
-                const int m = we - ws;
-                const double idx = 10.0 / 100.0 * (double)(m - 1);
-                const int i0 = (int)idx;
-                int count = live ? 0 : (1 << 30), p0 = 0, p1 = 0;
-                for (int base = 0; base < n; base += 64) {
-                    if (!__ballot(count <= i0 + 1)) break;
-                    const int e = base + lane;
-                    const int pe = (e < n) ? (int)order[e] : 0xFFFF;
-                    const int lim = (n - base < 64) ? n - base : 64;
-                    for (int j = 0; j < lim; ++j) {
-                        const int p = __builtin_amdgcn_readlane(pe, j);
-                        const bool in = (p >= ws) & (p < we);
-                        p0 = (in & (count == i0)) ? p : p0;
-                        p1 = (in & (count == i0 + 1)) ? p : p1;
-                        count += in ? 1 : 0;
-                    }
-                }
-                TSFA_TICK(tk, b, 155);
-                if (live) {
-                    const double s0 = L.row0[p0], s1 = L.row0[p1];
-                    double noise;
-                    if ((double)i0 == idx) {
-                        noise = s0;
-                    } else {
-                        const double j = (double)(i0 + 1);
-                        const double w0 = j - idx, w1 = idx - (double)i0;
-                        noise = (s0 * w0 + s1 * w1) / (w0 + w1);
-                    }
-                    double sig;
-                    if (row == 0) {
-                        sig = L.row0[col];
-                    } else {
-                        const int w = row + 1;
-                        const int nw = (10 * w < n) ? 10 * w : n;
-                        const int m2 = col + (nw - 1) / 2;
-                        int k0 = m2 - (n - 1);
-                        if (k0 < 0) k0 = 0;
-                        const int k1 = (m2 < nw - 1) ? m2 : (nw - 1);
-                        double acc = 0.0;
-                        if (taps_cached) {
-                            const double *tw = L.taps + 5 * (w - 2) * (w + 1);
-                            for (int k = k1; k >= k0; --k) acc += xv(m2 - k) * tw[k];
-                        } else {
-                            for (int k = k1; k >= k0; --k) acc += xv(m2 - k) * ricker_tap(nw, (double)w, nw - 1 - k);
-                        }
-                        sig = acc;
-                    }
-                    const double snr = fabs(sig / noise);
-                    if (!(snr < 1.0)) kept += 1.0;
-                }
-                TSFA_TICK(tk, b, 156);
-            }
-            kept = blk_sum(b, kept);
-            TSFA_TICK(tk, b, 153);
-            return overflow ? TSFA_NAN : kept;
-        }
-#else
-        // single-thread build (tests/emul): one line at a time, its percentile by walking the global order
-        const int lane = 0, wave = 0, nwv = 1;
-        for (int l = wave; l < nlines; l += nwv) {  // wave-uniform
-            const unsigned short v = L.linf[l];
-            if (TSFA_LI_LEN(v) < min_length) continue;
-            const int col = L.lcol[l], row = TSFA_LI_ROW(v);
-            double sig;
-            if (row == 0) {
-                sig = L.row0[col];
-            } else {
-                const int w = row + 1;
-                const int nw = (10 * w < n) ? 10 * w : n;
-                const int m2 = col + (nw - 1) / 2;
-                int k0 = m2 - (n - 1);
-                if (k0 < 0) k0 = 0;
-                const int k1 = (m2 < nw - 1) ? m2 : (nw - 1);
-                double acc = 0.0;
-                if (taps_cached) {
-                const double *tw = L.taps + 5 * (w - 2) * (w + 1);  // sum_{v=2}^{w-1} 10 v
-                for (int k = k1; k >= k0; --k) acc += xv(m2 - k) * tw[k];
-            } else {
-                for (int k = k1; k >= k0; --k) acc += xv(m2 - k) * ricker_tap(nw, (double)w, nw - 1 - k);
-            }
-                sig = acc;
-            }
-            const int ws = (col - hf > 0) ? col - hf : 0;
-            const int we = (col + hf + odd < n) ? col + hf + odd : n;
-            const int m = we - ws;
-            const double idx = 10.0 / 100.0 * (double)(m - 1);
-            const int i0 = (int)idx;
-            double s0 = 0.0, s1 = 0.0;
-            int count = 0;
-            for (int base = 0; base < n && count <= i0 + 1; base += TSFA_ENT_WAVE_C) {
-                const int p = order[base];
-                if (p >= ws && p < we) {
-                    if (count == i0) s0 = L.row0[p];
-                    if (count == i0 + 1) s1 = L.row0[p];
-                    ++count;
-                }
-            }
-            double noise;
-            if ((double)i0 == idx) {
-                noise = s0;
-            } else {
-                const double j = (double)(i0 + 1);
-                const double w0 = j - idx, w1 = idx - (double)i0;
-                noise = (s0 * w0 + s1 * w1) / (w0 + w1);
-            }
-            const double snr = fabs(sig / noise);
-            if (!(snr < 1.0) && lane == 0) kept += 1.0;
-        }
-        kept = blk_sum(b, kept);
-        TSFA_TICK(tk, b, 153);
-        return overflow ? TSFA_NAN : kept;
-#endif
     }
-    for (int l = b.tid; l < nlines; l += b.nt) {
-        const unsigned short v = L.linf[l];
-        if (TSFA_LI_LEN(v) < min_length) continue;
-        const int col = L.lcol[l], row = TSFA_LI_ROW(v);
-        double sig;  // cwt[row, col]
-        if (row == 0) {
-            sig = L.row0[col];
-        } else {
-            const int w = row + 1;
-            const int nw = (10 * w < n) ? 10 * w : n;
-            const int m = col + (nw - 1) / 2;
-            int k0 = m - (n - 1);
-            if (k0 < 0) k0 = 0;
-            const int k1 = (m < nw - 1) ? m : (nw - 1);
-            double acc = 0.0;
-            if (taps_cached) {
-                const double *tw = L.taps + 5 * (w - 2) * (w + 1);  // sum_{v=2}^{w-1} 10 v
-                for (int k = k1; k >= k0; --k) acc += xv(m - k) * tw[k];
-            } else {
-                for (int k = k1; k >= k0; --k) acc += xv(m - k) * ricker_tap(nw, (double)w, nw - 1 - k);
-            }
-            sig = acc;
+    // The filter needs (column, row) of a line's end point.  The qualifying lines are compacted to the front of
+    // (lcol, linf) -- entry k = (lcol[k], row in linf[k]) -- so every lane of the evaluation below has work.
+    // derive_w1 (the plan also asks for n = 1, whose ridge lines are exactly the maxima of row 0, each of length 1): the
+    // lines of THIS width that end on row 0 are not evaluated here but marked (bit W + 1 of mask[col]); the second list --
+    // all maxima of row 0 -- then yields the n = 1 count and, through the marks, this width's row-0 lines: one noise
+    // percentile per row-0 maximum for both columns of the plan, one argsort, one CWT.
+    const unsigned short bit_a = (unsigned short)(1u << (W + 1));
+    int cnt_a = 0;
+    blk_sync();
+    for (int base = 0; base < nlines; base += b.nt) {
+        const int l = base + b.tid;
+        const unsigned short v = (l < nlines) ? L.linf[l] : 0;
+        const bool qual = (l < nlines) && (TSFA_LI_LEN(v) >= min_length);
+        const int col = (l < nlines) ? (int)L.lcol[l] : 0, row = TSFA_LI_ROW(v);
+        const bool defer = derive_w1 && qual && row == 0;
+        if (defer) L.mask[col] |= bit_a;
+        const bool take = qual && !defer;
+        int tot;
+        const int idx = cnt_a + blk_excl_count(b, take, &tot);
+        if (take) {
+            L.lcol[idx] = (unsigned short)col;
+            L.linf[idx] = (unsigned short)row;
         }
-        // noise: scipy.stats.scoreatpercentile(row0[ws:we], 10)
-        const int ws = (col - hf > 0) ? col - hf : 0;
-        const int we = (col + hf + odd < n) ? col + hf + odd : n;
-        const int m = we - ws;
-        const double idx = 10.0 / 100.0 * (double)(m - 1);
-        const int i0 = (int)idx;
-        double s0 = 0.0, s1 = 0.0;
-        const double *r0 = L.row0 + ws;
-        if (i0 + 1 < 8) {
-            smallest8_select([=](int a) { return r0[a]; }, m, i0, &s0, &s1);
-        } else {
-            for (int a = 0; a < m; ++a) {
-                const double ea = r0[a];
-                int rank = 0;
-                for (int c = 0; c < m; ++c) {
-                    const double ec = r0[c];
-                    rank += (ec < ea || (ec == ea && c < a)) ? 1 : 0;
-                }
-                if (rank == i0) s0 = ea;
-                if (rank == i0 + 1) s1 = ea;
-            }
-        }
-        double noise;
-        if ((double)i0 == idx) {
-            noise = s0;
-        } else {
-            const double j = (double)(i0 + 1);
-            const double w0 = j - idx, w1 = idx - (double)i0;
-            noise = (s0 * w0 + s1 * w1) / (w0 + w1);
-        }
-        const double snr = fabs(sig / noise);
-        if (!(snr < 1.0)) kept += 1.0;
+        cnt_a += tot;
+        blk_sync();
     }
-    kept = blk_sum(b, kept);
+    double unused = 0.0;
+    double kept = cwt_filter_list(b, xv, n, L, L.lcol, L.linf, cnt_a, hf, odd, taps_cached, order, 0, &unused);
     TSFA_TICK(tk, b, 153);
+    if (derive_w1) {
+        int cnt_b = 0;
+        blk_sync();
+        for (int base = 0; base < n; base += b.nt) {
+            const int c = base + b.tid;
+            const bool take = (c < n) && (L.mask[c < n ? c : 0] & 1u);
+            int tot;
+            const int idx = cnt_b + blk_excl_count(b, take, &tot);
+            if (take) L.lcol[idx] = (unsigned short)c;
+            cnt_b += tot;
+            blk_sync();
+        }
+        double marked = 0.0;
+        *kept_w1 = cwt_filter_list(b, xv, n, L, L.lcol, nullptr, cnt_b, hf, odd, taps_cached, order, bit_a, &marked);
+        kept += marked;
+        TSFA_TICK(tk, b, 156);
+    }
     return overflow ? TSFA_NAN : kept;
 }
 
 template <class ST, class X>
 TSFA_DEV void fam_cwtpeaks_series(const Blk &b, X xv, int n, const TsfaSpec *specs, int nspecs, double *out_row,
                                   const CwtPeaksLds &L) {
+    // n = 1 rides along with the widest other width of the plan (<= 14): its ridge lines are the maxima of row 0, which
+    // that pass computes anyway (number_cwt_peaks_one, phase C)
+    int s_w1 = -1, s_host = -1, w_host = 0;
     for (int s = 0; s < nspecs; ++s) {
         const TsfaSpec sp = specs[s];
         if (sp.calc != TSFA_C_NUMBER_CWT_PEAKS) continue;
+        const int W = (int)sp.p[0];
+        if (W == 1 && s_w1 < 0) s_w1 = s;
+        else if (W > w_host && W <= 14) { w_host = W; s_host = s; }
+    }
+    const bool fuse = (s_w1 >= 0 && s_host >= 0);
+    for (int s = 0; s < nspecs; ++s) {
+        const TsfaSpec sp = specs[s];
+        if (sp.calc != TSFA_C_NUMBER_CWT_PEAKS) continue;
+        if (fuse && s == s_w1) continue;
+        if (fuse && s == s_host) {
+            double k1 = 0.0;
+            const double v = number_cwt_peaks_one<ST>(b, xv, n, (int)sp.p[0], L, true, &k1);
+            if (b.tid == 0) {
+                out_row[sp.col] = v;
+                out_row[specs[s_w1].col] = k1;
+            }
+            continue;
+        }
         const double v = number_cwt_peaks_one<ST>(b, xv, n, (int)sp.p[0], L);
         if (b.tid == 0) out_row[sp.col] = v;
     }
