@@ -26,7 +26,7 @@ NAMED = {213: "basic: count pass (all count-type columns)", 214: "basic: sum pas
          136: "entropy: pair sweep (thread 0's wave)", 137: "entropy: wait for the other waves",
          151: "cwtpeaks: phase A (CWT rows, maxima)", 152: "cwtpeaks: phase B (ridge lines)",
          153: "cwtpeaks: phase C (SNR filter)", 154: "cwtpeaks: phase C argsort of row 0 (long series)",
-         155: "cwtpeaks: phase C order walk (long series)", 156: "cwtpeaks: phase C signal / noise (long series)", 160: "seq: min/max", 161: "seq: edges + table clear",
+         155: "cwtpeaks: phase C order walk (long series)", 156: "cwtpeaks: phase C signal / noise (long series)", 170: "spectral: Welch periodogram", 171: "spectral: Welch columns", 172: "spectral: full-length rfft", 173: "spectral: |X| moments + fft columns", 160: "seq: min/max", 161: "seq: edges + table clear",
          162: "seq: binning", 163: "seq: parse (thread 0's chain)", 164: "seq: wait for the other chains"}
 
 

@@ -308,10 +308,11 @@ TSFA_DEV void blk_rfft_bluestein(const Blk &b, int n, G g, double *Xr, double *X
 
 // scipy.signal.welch(x, nperseg=min(n, 256)) -> pxx[0 .. nperseg/2] (fs=1, hann, 50% overlap,
 // constant detrend, density scaling, mean over segments).  fc.py:1418, fc.py:1809.
-//   win : LDS >= 256 doubles;  pxx : LDS >= 129 doubles;  Xr/Xi/tc/ts : FFT scratch (>= 256 each is enough)
+//   win : LDS >= 256 doubles;  pxx : LDS >= 129 doubles;  Xr/Xi/tc/ts : FFT scratch (>= 256 each is enough);
+//   xcap : doubles available in Xr and in Xi (the parallel form needs a 256-double slice per wavefront)
 template <class ST>
 TSFA_DEV int blk_welch(const Blk &b, const ST *xs, int n, double *win, double *pxx, double *Xr, double *Xi,
-                       double *tc, double *ts, const double *twc, const double *tws) {
+                       double *tc, double *ts, const double *twc, const double *tws, int xcap = 0) {
     const int nper = (n < 256) ? n : 256;
     const int nover = nper / 2;
     const int step = nper - nover;
@@ -329,6 +330,42 @@ TSFA_DEV int blk_welch(const Blk &b, const ST *xs, int n, double *win, double *p
     for (int k = b.tid; k < nf; k += b.nt) pxx[k] = 0.0;
     w2 = blk_sum(b, w2);
     const double scale = 1.0 / w2;
+#if TSFA_GPU
+    // Several 256-sample segments at a time, one per WAVEFRONT: the half-size FFT of a segment keeps 64 lanes busy, the
+    // other wavefronts of the workgroup used to wait at its barriers.  Every wavefront transforms its own segment in its
+    // own slice of Xr / Xi (the barriers inside blk_rfft stay workgroup barriers: all wavefronts run the same stages),
+    // leaves the segment's periodogram there, and the periodograms are added to pxx in SEGMENT order -- the additions of
+    // the sequential loop below, in the same order.
+    const int nwav = b.nt >> 6;
+    if (nper == 256 && nseg > 1 && nwav > 1 && 256 * (nwav - 1) + 130 <= xcap) {
+        const int lane = b.tid & 63, wave = b.tid >> 6;
+        const Blk wb{lane, 64, b.red, nullptr};
+        double *xr = Xr + 256 * wave, *xi = Xi + 256 * wave;
+        for (int s0 = 0; s0 < nseg; s0 += nwav) {
+            const int sgi = s0 + wave;
+            const bool act = sgi < nseg;
+            const XsView<ST> seg{xs + (act ? sgi : 0) * step};  // idle wavefronts redo segment 0 and discard it
+            double sm = 0.0;
+            for (int j = lane; j < nper; j += 64) sm += seg[j];
+            const double mu = wave_sum(sm) / (double)nper;
+            const double *wn = win;
+            blk_rfft(wb, nper, [=](int j) { return (seg[j] - mu) * wn[j]; }, xr, xi, tc, ts, twc, tws);
+            for (int k = lane; k < nf; k += 64) {
+                double pw = (xr[k] * xr[k] + xi[k] * xi[k]) * scale;
+                const bool edge = (k == 0) || (k == nf - 1);
+                if (!edge) pw *= 2.0;
+                xr[k] = act ? pw : 0.0;
+            }
+            blk_sync();
+            for (int k = b.tid; k < nf; k += b.nt) {
+                double acc = pxx[k];
+                for (int w = 0; w < nwav && s0 + w < nseg; ++w) acc += Xr[256 * w + k];
+                pxx[k] = acc;
+            }
+            blk_sync();
+        }
+    } else
+#endif
     for (int sgi = 0; sgi < nseg; ++sgi) {
         const XsView<ST> seg{xs + sgi * step};
         double sm = 0.0;
@@ -364,13 +401,14 @@ TSFA_DEV void fam_spectral_series(const Blk &b, const ST *xs_raw, int n, const T
     // flags / nlead come from tsfa_prepare_family (host): the Welch-based specs are the first nlead of the list
     const bool need_fft = (flags & 1) != 0, need_welch = (flags & 2) != 0;
     const int nf = n / 2 + 1;
+    TSFA_TICKER(tk, 0);
 
     // ---- Welch first (it reuses the FFT scratch), results stay in pxx ----
     int npx = 0;
     double pmax = 0.0, pmin = 0.0;
     bool pnan = false;
     if (need_welch) {
-        npx = blk_welch(b, xs_raw, n, win, pxx, Xr, Xi, tc, ts, twc, tws);
+        npx = blk_welch(b, xs_raw, n, win, pxx, Xr, Xi, tc, ts, twc, tws, (n / 2 + 2 > 260) ? n / 2 + 2 : 260);
         double mx = -TSFA_INF, mn = TSFA_INF, nn = 0.0;
         for (int k = b.tid; k < npx; k += b.nt) {
             mx = fmax(mx, pxx[k]);
@@ -381,6 +419,7 @@ TSFA_DEV void fam_spectral_series(const Blk &b, const ST *xs_raw, int n, const T
         pmin = blk_min(b, mn);
         pnan = blk_sum(b, nn) > 0.0;
     }
+    TSFA_TICK(tk, b, 170);
     for (int s = 0; s < nlead; ++s) {
         const TsfaSpec sp = specs[s];
         double v = TSFA_NAN;
@@ -400,6 +439,7 @@ TSFA_DEV void fam_spectral_series(const Blk &b, const ST *xs_raw, int n, const T
         }
         if (b.tid == 0) out_row[sp.col] = v;
     }
+    TSFA_TICK(tk, b, 171);
     if (!need_fft) return;
 
     // ---- full-length rfft ----
@@ -409,6 +449,7 @@ TSFA_DEV void fam_spectral_series(const Blk &b, const ST *xs_raw, int n, const T
         blk_rfft_bluestein(b, n, [=](int j) { return xs[j]; }, Xr, Xi, gs, twc, tws);
     else
         blk_rfft(b, n, [=](int j) { return xs[j]; }, Xr, Xi, tc, ts, twc, tws);
+    TSFA_TICK(tk, b, 172);
     // moments of |X| over the bin index (fc.py:1123)
     double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0, s4 = 0.0;
     for (int k = b.tid; k < nf; k += b.nt) {
@@ -450,6 +491,7 @@ TSFA_DEV void fam_spectral_series(const Blk &b, const ST *xs_raw, int n, const T
         }
         out_row[sp.col] = v;
     }
+    TSFA_TICK(tk, b, 173);
 }
 
 #endif
