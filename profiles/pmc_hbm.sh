@@ -7,7 +7,7 @@
 export TMPDIR=/tmp
 rm -rf gpurun_out/hbm; mkdir -p gpurun_out/hbm
 for c in FETCH_SIZE WRITE_SIZE; do
-  timeout 600 rocprofv3 --pmc $c -d gpurun_out/hbm/$c -o p --output-format csv -- python bench.py --steps 1 --warmup 1 --no-cpu-baseline > gpurun_out/hbm/$c.log 2>&1
+  timeout 600 rocprofv3 --pmc $c -d gpurun_out/hbm/$c -o p --output-format csv -- python bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-e2e > gpurun_out/hbm/$c.log 2>&1
 done
 python - <<'PY'
 import csv, glob, collections, json

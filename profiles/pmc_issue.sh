@@ -6,7 +6,7 @@ rm -rf gpurun_out/pmc_issue; mkdir -p gpurun_out/pmc_issue
 i=0
 for set in "GRBM_GUI_ACTIVE SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES" "SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_INSTS_SALU SQ_ACTIVE_INST_SCA" "SQ_INSTS_LDS SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT" "SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_SMEM"; do
   i=$((i+1))
-  timeout 600 rocprofv3 --pmc $set -d gpurun_out/pmc_issue/p$i -o p --output-format csv -- python bench.py --steps 1 --warmup 1 --no-cpu-baseline > gpurun_out/pmc_issue/p$i.log 2>&1
+  timeout 600 rocprofv3 --pmc $set -d gpurun_out/pmc_issue/p$i -o p --output-format csv -- python bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-e2e > gpurun_out/pmc_issue/p$i.log 2>&1
 done
 python - <<'PY' > gpurun_out/pmc_issue/summary.md
 import csv, glob, collections
