@@ -23,7 +23,8 @@ NAMED = {213: "basic: count pass (all count-type columns)", 214: "basic: sum pas
          123: "ar/adf: lag products + normal matrix", 124: "ar/adf: Cholesky + nested AIC", 125: "ar/adf: final regression",
          130: "entropy: std + sentinels", 131: "entropy: template sort + refs", 132: "entropy: group setup",
          133: "entropy: sweep group 0 (incl. totals)", 134: "entropy: sweep groups 1+ (incl. totals)",
-         136: "entropy: pair sweep (thread 0's wave)", 137: "entropy: wait for the other waves",
+         136: "entropy: pair / bit sweep (thread 0's wave)", 137: "entropy: wait for the other waves",
+         138: "entropy bits: ranges to registers", 139: "entropy bits: table build",
          151: "cwtpeaks: phase A (CWT rows, maxima)", 152: "cwtpeaks: phase B (ridge lines)",
          153: "cwtpeaks: phase C (SNR filter)", 154: "cwtpeaks: phase C argsort of row 0 (long series)",
          155: "cwtpeaks: phase C order walk (long series)", 156: "cwtpeaks: phase C signal / noise (long series)", 170: "spectral: Welch periodogram", 171: "spectral: Welch columns", 172: "spectral: full-length rfft", 173: "spectral: |X| moments + fft columns", 160: "seq: min/max", 161: "seq: edges + table clear",

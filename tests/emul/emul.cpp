@@ -151,6 +151,16 @@ extern "C" int tsfa_emul_extract_timed(const tsfa_feature_spec *specs, int n_spe
             std::vector<unsigned int> cnt((size_t)(maxn + 16) * 4), refs(perm.size());
             // odd series exercise the ordered-pair sweep (no LDS counters), every fourth the grouped symmetric sweep
             // instead of the staged one
+            bool all_m2 = true;
+            for (const auto &sp : fam[TSFA_FAM_ENTROPY])
+                if (sp.calc == TSFA_C_APPROXIMATE_ENTROPY && (int)sp.p[0] != 2) all_m2 = false;
+            const char *force = getenv("TSFA_EMUL_ENTROPY");  // "bits" / "pairs": one sweep for every series
+            const bool bits = all_m2 && n <= TSFA_ENTB_MAXN && (force ? !strcmp(force, "bits") : (s % 4 == 2));
+            if (bits) {  // the bit-matrix sweep (k_entropy_bits)
+                std::vector<unsigned int> work(entb_work_words(n) + 64);
+                fam_entropy_series_bits<false>(b, xe.data(), n, fam[TSFA_FAM_ENTROPY].data(), (int)fam[TSFA_FAM_ENTROPY].size(),
+                                               row, thr.data(), perm.data(), work.data());
+            } else
             fam_entropy_series<double>(b, xe.data(), n, fam[TSFA_FAM_ENTROPY].data(), (int)fam[TSFA_FAM_ENTROPY].size(),
                                        row, thr.data(), perm.data(), refs.data(), (s % 2) ? nullptr : cnt.data(),
                                        (s % 4 == 0) ? 1 : 0);

@@ -828,4 +828,6 @@ TSFA_DEV void fam_entropy_series(const Blk &b0, XT *xs, int n, const TsfaSpec *s
     }
 }
 
+#include "fam_entropy_bits.h"
+
 #endif

@@ -1,0 +1,479 @@
+// Family ENTROPY, bit-matrix sweep (series of 3 .. TSFA_ENTB_MAXN samples, template length m = 2).
+//
+// sample_entropy (fc.py:1701) and approximate_entropy (fc.py:1759) need, for every template i, the number of
+// templates j with max_t |x[i+t] - x[j+t]| <= r (t < m, and t < m + 1).  The pair sweeps of fam_entropy.h evaluate that
+// Chebyshev distance per PAIR: three float64 subtractions, two maxima and two compares + two counter updates per
+// tolerance.  This sweep never forms a distance:
+//
+//   * Per SAMPLE a and tolerance r, the samples within r of x[a] form one contiguous range of the sorted order,
+//     [lo, hi) -- fl(|x_a - x_b|) <= r is monotone in x_b on either side of x_a, so the range is found with the
+//     reference's own float64 predicate by bisection (lo), and hi follows from lo by symmetry of the predicate
+//     (hi(q) = #{p : lo(p) <= q}, an integer bisection).  O(n log n) float64 operations per tolerance instead of O(n^2).
+//   * With Pref(t) = the bit set {b : rank(x_b) < t} over the NATURAL sample index b, the row of the 0/1 matrix
+//     A[a, b] = (|x_a - x_b| <= r) is Pref(hi) xor Pref(lo): two table reads and one xor per 32 pairs.
+//   * Templates i, j of length 2 match iff A[i, j] & A[i+1, j+1]; of length 3 iff additionally A[i+2, j+2].  With
+//     lane = template i and the rows of i+1, i+2 shifted right by one / two bits:
+//         C_2[i] = popcount(A[i] & (A[i+1] >> 1)),   C_3[i] = popcount(A[i] & (A[i+1] >> 1) & (A[i+2] >> 2))
+//     -- per 32 pairs: 2 funnel shifts, 2 ands, 2 popcount-accumulates and the two cross-lane moves that fetch the
+//     shifted words of lanes i+1, i+2 (DPP wavefront shifts, no LDS).  The counts are exact integers: the result is
+//     bit-identical to the pair sweeps'.
+//
+// Pref is (n + 1) x n bits = 128 KB at n = 1024, so it is built in column parts of TSFA_ENTB_QW words (+ one halo
+// word for the funnel shift) by a workgroup prefix-OR over the sorted order; a wavefront sweeps strips of 62 templates
+// (lanes 62, 63 only supply their neighbours) for one tolerance per task, its ranges and counters in registers.
+//
+// Cost at n = 1024, six tolerances: ~3.0 M lane operations per series against 9.0 M for the staged pair sweep.
+#ifndef TSFA_FAM_ENTROPY_BITS_H
+#define TSFA_FAM_ENTROPY_BITS_H
+
+#include "tsfa_entb_params.h"
+
+#if TSFA_GPU
+typedef __attribute__((address_space(3))) const unsigned int *entb_lds_cup;
+TSFA_DEV unsigned int entb_lds_addr(const void *p) {
+    return (unsigned int)(uintptr_t)(__attribute__((address_space(3))) const void *)p;
+}
+// value of lane + 1 (lane 63: 0)
+TSFA_DEV unsigned int entb_from_next(unsigned int v) {
+    return (unsigned int)__builtin_amdgcn_update_dpp(0, (int)v, 0x130 /* wave_shl:1 */, 0xf, 0xf, true);
+}
+// inclusive OR-scan over the 64 lanes (the sequence LLVM's atomic optimizer emits for wave64 on gfx9)
+TSFA_DEV unsigned int entb_wave_or_scan(unsigned int v) {
+    v |= (unsigned int)__builtin_amdgcn_update_dpp(0, (int)v, 0x111 /* row_shr:1 */, 0xf, 0xf, false);
+    v |= (unsigned int)__builtin_amdgcn_update_dpp(0, (int)v, 0x112 /* row_shr:2 */, 0xf, 0xf, false);
+    v |= (unsigned int)__builtin_amdgcn_update_dpp(0, (int)v, 0x114 /* row_shr:4 */, 0xf, 0xf, false);
+    v |= (unsigned int)__builtin_amdgcn_update_dpp(0, (int)v, 0x118 /* row_shr:8 */, 0xf, 0xf, false);
+    v |= (unsigned int)__builtin_amdgcn_update_dpp(0, (int)v, 0x142 /* row_bcast:15 */, 0xa, 0xf, false);
+    v |= (unsigned int)__builtin_amdgcn_update_dpp(0, (int)v, 0x143 /* row_bcast:31 */, 0xc, 0xf, false);
+    return v;
+}
+TSFA_DEV unsigned int entb_from_prev(unsigned int v) {  // value of lane - 1 (lane 0: 0)
+    return (unsigned int)__builtin_amdgcn_update_dpp(0, (int)v, 0x138 /* wave_shr:1 */, 0xf, 0xf, true);
+}
+#endif
+
+// The thread index made opaque to the optimiser: addresses and predicates derived from it are then computed inside the
+// phase that uses them instead of being hoisted to the kernel's top, kept live across the sweep and spilled.
+TSFA_DEV Blk entb_opaque(const Blk &b0) {
+#if TSFA_GPU
+    int t = b0.tid;
+    asm volatile("" : "+v"(t));
+    return Blk{t, b0.nt, b0.red, b0.np};
+#else
+    return b0;
+#endif
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// Ranges.  perm[0 .. n) = sample indices sorted by value (ties by index).  For tolerance k and sorted position q
+// (sample a = perm[q]) the samples within thr[k] of x_a are the sorted positions [lo, hi).  Written per NATURAL sample
+// index: rng[k * n + a] = (lo * S * 4) | (hi * S * 4) << 16 -- byte offsets of the two table entries (lo == hi: empty).
+// lo16: scratch, nk * n unsigned shorts.
+// ---------------------------------------------------------------------------------------------------------------
+TSFA_DEV void entb_ranges(const Blk &b0, const double *xs, int n, const double *thr, int nk, const unsigned short *perm,
+                          double *xsrt, unsigned int *rng) {
+    const Blk b = entb_opaque(b0);
+    const int K = TSFA_ENTB_MAXK;
+    // xsrt: the sorted copy, padded with +inf to a power of two (the bisections then need no bound checks: a sample
+    // beyond the order matches nothing).  The 2 K bisections of a sample run side by side as independent chains.
+    const int P = next_pow2(n);
+    for (int q = b.tid; q < P; q += b.nt) xsrt[q] = (q < n) ? xs[perm[q]] : TSFA_INF;
+    double r[TSFA_ENTB_MAXK];
+#pragma unroll
+    for (int k = 0; k < K; ++k) r[k] = (k < nk) ? thr[k] : -1.0;
+    blk_sync();
+    const char *xb = (const char *)xsrt;
+    for (int q = b.tid; q < n; q += b.nt) {
+        const double xq = xsrt[q];
+        // lo = #{p : !(x_q - x_p <= r)} (leading samples too far below), hi = #{p : x_p - x_q <= r}: both predicates are
+        // monotone along the sorted order (rounding is monotone) and equal the reference's |x_q - x_p| <= r on their side
+        int pl[TSFA_ENTB_MAXK], ph[TSFA_ENTB_MAXK];  // byte offsets into xsrt
+#pragma unroll
+        for (int k = 0; k < K; ++k) { pl[k] = 0; ph[k] = 0; }
+        for (int step = (P >> 1) * 8; step >= 8; step >>= 1) {
+            const char *at = xb + (step - 8);
+#pragma unroll
+            for (int k = 0; k < K; ++k) {
+                const double vl = *(const double *)(at + pl[k]), vh = *(const double *)(at + ph[k]);
+                pl[k] += (xq - vl <= r[k]) ? 0 : step;
+                ph[k] += (vh - xq <= r[k]) ? step : 0;
+            }
+        }
+        const int a = (int)perm[q];
+#pragma unroll
+        for (int k = 0; k < K; ++k) {
+            ph[k] += (*(const double *)(xb + ph[k]) - xq <= r[k]) ? 8 : 0;  // the count may reach P (P - 1 after the steps)
+            // infinite sample / negative or NaN tolerance: matches nothing (not even itself)
+            const bool any = (fabs(xq - xq) <= r[k]) && pl[k] < ph[k];
+            const unsigned int lo = any ? (unsigned int)pl[k] : 0u, hi = any ? (unsigned int)ph[k] : 0u;  // 8 * rank
+            if (k < nk) rng[k * n + a] = ((lo >> 3) * (TSFA_ENTB_S * 4u)) | (((hi >> 3) * (TSFA_ENTB_S * 4u)) << 16);
+        }
+    }
+    blk_sync();
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// Table of one column part: entry t (0 .. n), word w (0 .. QW) = bits of the columns 32 (w0 + w) .. + 31 whose rank
+// is below t.  wtot: TSFA_ENTB_MAXWAVES * S words of cross-wavefront scratch.
+// ---------------------------------------------------------------------------------------------------------------
+TSFA_DEV void entb_build_table(const Blk &b0, int n, const unsigned short *perm, int w0, unsigned int *table,
+                               unsigned int *wtot) {
+    const Blk b = entb_opaque(b0);
+    const int S = TSFA_ENTB_S;
+#if TSFA_GPU
+    const int E = (n + b.nt - 1) / b.nt;
+    const int p0 = b.tid * E;
+    unsigned int tot[TSFA_ENTB_S];
+#pragma unroll
+    for (int w = 0; w < S; ++w) tot[w] = 0u;
+    for (int e = 0; e < E; ++e) {
+        const int p = p0 + e;
+        if (p < n) {
+            const int j = (int)perm[p];
+            const int wi = (j >> 5) - w0;
+            const unsigned int bit = 1u << (j & 31);
+#pragma unroll
+            for (int w = 0; w < S; ++w) tot[w] |= (wi == w) ? bit : 0u;
+        }
+    }
+    unsigned int run[TSFA_ENTB_S];
+    const int lane = b.tid & 63, wave = b.tid >> 6, nw = b.nt >> 6;
+#pragma unroll
+    for (int w = 0; w < S; ++w) {
+        const unsigned int inc = entb_wave_or_scan(tot[w]);
+        if (lane == 63) wtot[wave * S + w] = inc;
+        run[w] = entb_from_prev(inc);
+    }
+    blk_sync();
+    for (int v = 0; v < wave; ++v) {
+#pragma unroll
+        for (int w = 0; w < S; ++w) run[w] |= wtot[v * S + w];
+    }
+    for (int e = 0; e < E; ++e) {
+        const int p = p0 + e;
+        if (p < n) {
+#pragma unroll
+            for (int w = 0; w < S; ++w) table[p * S + w] = run[w];
+            const int j = (int)perm[p];
+            const int wi = (j >> 5) - w0;
+            const unsigned int bit = 1u << (j & 31);
+#pragma unroll
+            for (int w = 0; w < S; ++w) run[w] |= (wi == w) ? bit : 0u;
+        }
+    }
+    if (b.tid == b.nt - 1) {  // entry n: every column (the last thread's running value is the total: its range ends the order)
+#pragma unroll
+        for (int w = 0; w < S; ++w) table[n * S + w] = run[w];
+    }
+    (void)nw;
+#else
+    (void)b; (void)wtot;
+    unsigned int run[TSFA_ENTB_S];
+    for (int w = 0; w < S; ++w) run[w] = 0u;
+    for (int p = 0; p <= n; ++p) {
+        for (int w = 0; w < S; ++w) table[p * S + w] = run[w];
+        if (p < n) {
+            const int j = (int)perm[p];
+            const int wi = (j >> 5) - w0;
+            if (wi >= 0 && wi < S) run[wi] |= 1u << (j & 31);
+        }
+    }
+#endif
+    blk_sync();
+}
+
+// one task (strip, tolerance) over one column part: the lane's template against the 32 * QW columns of the part
+#if TSFA_GPU
+TSFA_DEV unsigned int entb_task_part(unsigned int rng_lane) {
+    const entb_lds_cup pl = (entb_lds_cup)(rng_lane & 0xFFFFu), ph = (entb_lds_cup)(rng_lane >> 16);
+    unsigned int A[TSFA_ENTB_S];
+#pragma unroll
+    for (int w = 0; w < TSFA_ENTB_S; ++w) A[w] = ph[w] ^ pl[w];
+    unsigned int c2 = 0u, c3 = 0u;
+#pragma unroll
+    for (int w = 0; w < TSFA_ENTB_QW; ++w) {
+        const unsigned int s1 = __builtin_amdgcn_alignbit(A[w + 1], A[w], 1);  // the row shifted right by one column
+        const unsigned int s2 = __builtin_amdgcn_alignbit(A[w + 1], A[w], 2);
+        const unsigned int m2 = A[w] & entb_from_next(s1);
+        const unsigned int m3 = m2 & entb_from_next(entb_from_next(s2));
+        c2 += (unsigned int)__builtin_popcount(m2);
+        c3 += (unsigned int)__builtin_popcount(m3);
+    }
+    return c2 | (c3 << 16);
+}
+#else
+TSFA_DEV void entb_row_words(unsigned int rng_lane, const unsigned int *table, unsigned int *A) {
+    const unsigned int *pl = table + (rng_lane & 0xFFFFu) / 4, *ph = table + (rng_lane >> 16) / 4;
+    for (int w = 0; w < TSFA_ENTB_S; ++w) A[w] = ph[w] ^ pl[w];
+}
+#endif
+
+// Reduction of the per-thread products / sums of one round (see entropy_bits_batch): part = LDS scratch of
+// 2 K * (nt / 16) doubles.
+TSFA_DEV void entb_totals(const Blk &b, int kn, int k0, double *pm, double *pm1, int *sc, int *sc1, int *nm, int *nm1,
+                          int nrow_m, int nrow_m1, double *part, double *racc, bool accumulate) {
+    const int K = TSFA_ENTB_MAXK;
+    const double ldm = log((double)nrow_m), ldm1 = log((double)nrow_m1);
+#if TSFA_GPU
+    const int lane = b.tid & 63, wave = b.tid >> 6, nrows = b.nt >> 4;  // DPP rows of 16 lanes
+    // products over the 16 lanes of a row (xor butterflies inside the row), sums over the wavefront
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+        if (k < kn) {
+            pm[k] *= dpp_mov_f64<TSFA_DPP_QUAD_XOR1>(pm[k]);   pm1[k] *= dpp_mov_f64<TSFA_DPP_QUAD_XOR1>(pm1[k]);
+            pm[k] *= dpp_mov_f64<TSFA_DPP_QUAD_XOR2>(pm[k]);   pm1[k] *= dpp_mov_f64<TSFA_DPP_QUAD_XOR2>(pm1[k]);
+            pm[k] *= dpp_mov_f64<TSFA_DPP_ROW_HALF_MIRROR>(pm[k]); pm1[k] *= dpp_mov_f64<TSFA_DPP_ROW_HALF_MIRROR>(pm1[k]);
+            pm[k] *= dpp_mov_f64<TSFA_DPP_ROW_MIRROR>(pm[k]);  pm1[k] *= dpp_mov_f64<TSFA_DPP_ROW_MIRROR>(pm1[k]);
+            if ((lane & 15) == 0) {
+                part[(2 * k) * nrows + (b.tid >> 4)] = pm[k];
+                part[(2 * k + 1) * nrows + (b.tid >> 4)] = pm1[k];
+            }
+        }
+    }
+    blk_sync();
+    // one logarithm per partial product (by as many lanes as there are products); then the 2 K sums of logs, the
+    // per-thread folded logs and the integer totals (exact in float64) are reduced together: wavefront sums, one slot
+    // per wavefront and value, one barrier
+    double lg = 0.0;
+    int which = -1;
+    if (b.tid < 2 * kn * nrows) {
+        which = b.tid / nrows;  // 2 k + (0: m, 1: m + 1)
+        lg = log(part[b.tid]);
+    }
+    blk_sync();
+    double *slot = part;  // [6 K][nwaves]
+    const int nw = b.nt >> 6;
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+        if (k < kn) {
+            const double v0 = wave_sum((which == 2 * k) ? lg : 0.0);
+            const double v1 = wave_sum((which == 2 * k + 1) ? lg : 0.0);
+            const double v2 = wave_sum((double)sc[k]), v3 = wave_sum((double)sc1[k]);
+            const double v4 = wave_sum((double)nm[k]), v5 = wave_sum((double)nm1[k]);
+            if (lane == 0) {
+                double *d = slot + (6 * k) * nw + wave;
+                d[0] = v0; d[nw] = v1; d[2 * nw] = v2; d[3 * nw] = v3; d[4 * nw] = v4; d[5 * nw] = v5;
+            }
+        }
+    }
+    blk_sync();
+    if (b.tid < kn) {
+        const int k = b.tid;
+        double t[6];
+        for (int j = 0; j < 6; ++j) {
+            double a = 0.0;
+            for (int w = 0; w < nw; ++w) a += slot[(6 * k + j) * nw + w];
+            t[j] = a;
+        }
+        double *d = racc + 4 * (k0 + k);
+        if (!accumulate) { d[0] = 0.0; d[1] = 0.0; d[2] = 0.0; d[3] = 0.0; }
+        d[0] += t[0] - t[4] * ldm; d[1] += t[1] - t[5] * ldm1; d[2] += t[2]; d[3] += t[3];
+    }
+    blk_sync();
+#else
+    (void)b; (void)part;
+    for (int k = 0; k < kn && k < K; ++k) {
+        double *d = racc + 4 * (k0 + k);
+        if (!accumulate) { d[0] = 0.0; d[1] = 0.0; d[2] = 0.0; d[3] = 0.0; }
+        d[0] += log(pm[k]) - (double)nm[k] * ldm;
+        d[1] += log(pm1[k]) - (double)nm1[k] * ldm1;
+        d[2] += (double)sc[k];
+        d[3] += (double)sc1[k];
+    }
+#endif
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// One batch of nk <= TSFA_ENTB_MAXK tolerances (thr[0 .. nk), any order): racc[4 k .. 4 k + 3] = sum log(C_2 / (n-1)),
+// sum log(C_3 / (n-2)), sum C_2, sum C_3 of tolerance k -- the totals the pair sweeps deliver.
+// perm: all n samples sorted; work: entb_work_words(n) words of LDS.
+// ---------------------------------------------------------------------------------------------------------------
+TSFA_DEV void entropy_bits_batch(const Blk &b_in, const double *xs, int n, const double *thr, int nk,
+                                 const unsigned short *perm, unsigned int *work, double *racc) {
+    const Blk b = entb_opaque(b_in);
+    const int S = TSFA_ENTB_S, QW = TSFA_ENTB_QW;
+    const int nrow_m = n - 1, nrow_m1 = n - 2;
+    const int nwords = (n + 31) >> 5;
+    const int nparts = (nwords + QW - 1) / QW;
+    const int nstrips = (nrow_m + TSFA_ENTB_STRIP - 1) / TSFA_ENTB_STRIP;
+    unsigned int *rng = work + 2 * (size_t)next_pow2(n);  // behind the sorted copy
+    unsigned int *table = work;
+    unsigned int *wtot = work + (size_t)(n + 1) * S;
+    unsigned int *cnt = work;
+    TSFA_TICKER(tk, 0);
+    blk_sync();
+    entb_ranges(b, xs, n, thr, nk, perm, (double *)(void *)work, rng);
+    TSFA_TICK(tk, b, 132);
+#if TSFA_GPU
+    const int lane = b.tid & 63, wave = __builtin_amdgcn_readfirstlane(b.tid >> 6), nw = b.nt >> 6;
+    const unsigned int tbase = entb_lds_addr(table);
+    // tolerances per round: all of them when the tasks fit the wavefronts' registers
+    int kround = (TSFA_ENTB_MAXT * nw) / nstrips;
+    if (kround > nk) kround = nk;
+    if (kround < 1) kround = 1;  // (the host never selects this sweep for such a shape; the counts below stay correct
+                                 //  only for nstrips <= MAXT * nw)
+    for (int k0 = 0; k0 < nk; k0 += kround) {
+        const int kn = (nk - k0 < kround) ? (nk - k0) : kround;
+        const int ntask = nstrips * kn;
+        unsigned int rg[TSFA_ENTB_MAXT], ct[TSFA_ENTB_MAXT];
+        const unsigned int kmagic = 65536u / (unsigned int)kn + 1u;  // id / kn == (id * kmagic) >> 16 for id < 10 000
+        if (k0 > 0) {  // the ranges were overwritten by the table of the previous round
+            blk_sync();
+            entb_ranges(b, xs, n, thr, nk, perm, (double *)(void *)work, rng);
+        }
+#pragma unroll
+        for (int tt = 0; tt < TSFA_ENTB_MAXT; ++tt) {
+            const int id = wave + tt * nw;
+            rg[tt] = 0u;
+            ct[tt] = 0u;
+            if (id < ntask) {
+                const int s = (int)(((unsigned int)id * kmagic) >> 16), k = k0 + (id - s * kn);
+                const int i = s * TSFA_ENTB_STRIP + lane;
+                const unsigned int r = (i < n) ? rng[k * n + i] : 0u;
+                rg[tt] = ((r & 0xFFFFu) + tbase) | (((r >> 16) + tbase) << 16);
+            }
+        }
+        blk_sync();
+        TSFA_TICK(tk, b, 138);
+        for (int part = 0; part < nparts; ++part) {
+            entb_build_table(b, n, perm, part * QW, table, wtot);
+            TSFA_TICK(tk, b, 139);
+#pragma unroll
+            for (int tt = 0; tt < TSFA_ENTB_MAXT; ++tt) {
+                if (wave + tt * nw < ntask) ct[tt] += entb_task_part(rg[tt]);
+            }
+            TSFA_TICK(tk, b, 136);
+            blk_sync();
+            TSFA_TICK(tk, b, 137);
+        }
+        // counts to LDS: cnt[k * n + i] = C_2 | C_3 << 16
+#pragma unroll
+        for (int tt = 0; tt < TSFA_ENTB_MAXT; ++tt) {
+            const int id = wave + tt * nw;
+            if (id < ntask) {
+                const int s = (int)(((unsigned int)id * kmagic) >> 16), k = k0 + (id - s * kn);
+                const int i = s * TSFA_ENTB_STRIP + lane;
+                if (lane < TSFA_ENTB_STRIP && i < nrow_m) cnt[k * n + i] = ct[tt];
+            }
+        }
+        blk_sync();
+        TSFA_TICK(tk, b, 133);
+#else
+    {
+        const int k0 = 0, kn = nk;
+        // single-thread emulation of the same strips: 64 "lanes", lanes 62 / 63 only supply their neighbours
+        static thread_local unsigned int rg[TSFA_ENTB_MAXK * (TSFA_ENTB_MAXN + 64)], ct[TSFA_ENTB_MAXK * (TSFA_ENTB_MAXN + 64)];
+        for (int k = 0; k < nk; ++k)
+            for (int i = 0; i < n + 64; ++i) { rg[k * (TSFA_ENTB_MAXN + 64) + i] = (i < n) ? rng[k * n + i] : 0u; ct[k * (TSFA_ENTB_MAXN + 64) + i] = 0u; }
+        for (int part = 0; part < nparts; ++part) {
+            entb_build_table(b, n, perm, part * QW, table, wtot);
+            for (int k = 0; k < nk; ++k) {
+                for (int s = 0; s < nstrips; ++s) {
+                    unsigned int A[64][TSFA_ENTB_S], s1[66][TSFA_ENTB_QW], s2[66][TSFA_ENTB_QW];
+                    for (int l = 0; l < 64; ++l) {
+                        entb_row_words(rg[k * (TSFA_ENTB_MAXN + 64) + s * TSFA_ENTB_STRIP + l], table, A[l]);
+                        for (int w = 0; w < QW; ++w) {
+                            s1[l][w] = (A[l][w] >> 1) | (A[l][w + 1] << 31);
+                            s2[l][w] = (A[l][w] >> 2) | (A[l][w + 1] << 30);
+                        }
+                    }
+                    for (int w = 0; w < QW; ++w) { s1[64][w] = s1[65][w] = 0u; s2[64][w] = s2[65][w] = 0u; }
+                    for (int l = 0; l < TSFA_ENTB_STRIP; ++l) {
+                        unsigned int c2 = 0u, c3 = 0u;
+                        for (int w = 0; w < QW; ++w) {
+                            const unsigned int m2 = A[l][w] & s1[l + 1][w];
+                            const unsigned int m3 = m2 & s2[l + 2][w];
+                            c2 += (unsigned int)__builtin_popcount(m2);
+                            c3 += (unsigned int)__builtin_popcount(m3);
+                        }
+                        ct[k * (TSFA_ENTB_MAXN + 64) + s * TSFA_ENTB_STRIP + l] += c2 | (c3 << 16);
+                    }
+                }
+            }
+        }
+        for (int k = 0; k < nk; ++k)
+            for (int i = 0; i < nrow_m; ++i) cnt[k * n + i] = ct[k * (TSFA_ENTB_MAXN + 64) + i];
+#endif
+        // ---- totals of the round's tolerances: sum_i log(C_i / N) = log(prod_i C_i) - (#rows) log N.  The counts are
+        //      integers <= 2^11, so a thread multiplies its rows' counts, the 16 lanes of a DPP row multiply theirs
+        //      (< 2^1024 up to 92 factors), and ONE logarithm is taken per row of lanes -- in a second step, by as many
+        //      lanes as there are partial products (a float64 log is ~150 instructions: per thread it would cost more
+        //      than the sweep of a column part).  Rows with C_i == N contribute exactly 0, as in the reference.
+        {
+            const Blk b = entb_opaque(b_in);
+            const int K = TSFA_ENTB_MAXK;
+            double pm[TSFA_ENTB_MAXK], pm1[TSFA_ENTB_MAXK];
+            int sc[TSFA_ENTB_MAXK], sc1[TSFA_ENTB_MAXK], nm[TSFA_ENTB_MAXK], nm1[TSFA_ENTB_MAXK];
+            double *part = (double *)(void *)(cnt + (((size_t)TSFA_ENTB_MAXK * n + 1) & ~(size_t)1));  // [2 K][nt / 16]
+            // (a thread multiplies at most four counts before the lanes combine theirs: longer rows go in chunks)
+            for (int c0 = 0; c0 < nrow_m; c0 += 4 * b.nt) {
+#pragma unroll
+                for (int k = 0; k < K; ++k) { pm[k] = 1.0; pm1[k] = 1.0; sc[k] = 0; sc1[k] = 0; nm[k] = 0; nm1[k] = 0; }
+                for (int ib = c0; ib < nrow_m && ib < c0 + 4 * b.nt; ib += b.nt) {
+                    const int i = ib + b.tid;
+#pragma unroll
+                    for (int k = 0; k < K; ++k) {
+                        if (k < kn && i < nrow_m) {
+                            const unsigned int cc = cnt[(k0 + k) * n + i];
+                            const int t2 = (int)(cc & 0xFFFFu), t3 = (int)(cc >> 16);
+                            sc[k] += t2;
+                            if (t2 != nrow_m) { pm[k] *= (double)t2; ++nm[k]; }
+                            if (i < nrow_m1) {
+                                sc1[k] += t3;
+                                if (t3 != nrow_m1) { pm1[k] *= (double)t3; ++nm1[k]; }
+                            }
+                        }
+                    }
+                }
+                entb_totals(b, kn, k0, pm, pm1, sc, sc1, nm, nm1, nrow_m, nrow_m1, part, racc, c0 > 0);
+            }
+        }
+        blk_sync();
+    }
+    TSFA_TICK(tk, b, 134);
+}
+
+// The ENTROPY specs of one series by the bit-matrix sweep (every spec has m = 2; 3 <= n <= TSFA_ENTB_MAXN is decided
+// on the host, shorter series take the closed forms below).  xs: n + 4 doubles; thr: >= 56 doubles; perm:
+// next_pow2(n) + 32 entries; work: entb_work_words(maxn) words (may alias b.np: the numpy-order sums finish first).
+template <bool F32>
+TSFA_DEV void fam_entropy_series_bits(const Blk &b, double *xs, int n, const TsfaSpec *specs, int nspecs, double *out_row,
+                                      double *thr, unsigned short *perm, unsigned int *work) {
+    TSFA_TICKER(tk, 0);
+    const double dn = (double)n;
+    const double mean = np_sum(b, n, [=](int i) { return xs[i]; }) / dn;
+    const double var = np_sum(b, n, [=](int i) { const double d = xs[i] - mean; return d * d; }) / dn;
+    const double sd = sqrt(var);
+    blk_sync();
+    TSFA_TICK(tk, b, 130);
+    if (n >= 3) {
+        entropy_sort_templates(b, xs, n + 1, perm, next_pow2(n), F32);  // all n samples (a "template" per sample)
+        TSFA_TICK(tk, b, 131);
+    }
+    double *racc = thr + TSFA_ENTB_MAXK;
+    for (int first = 0; first < nspecs; first += TSFA_ENTB_MAXK) {
+        const int nk = (nspecs - first < TSFA_ENTB_MAXK) ? (nspecs - first) : TSFA_ENTB_MAXK;
+        blk_sync();
+        for (int k = b.tid; k < nk; k += b.nt) {
+            const TsfaSpec sp = specs[first + k];
+            thr[k] = (sp.calc == TSFA_C_SAMPLE_ENTROPY) ? 0.2 * sd : sp.p[1] * sd;
+        }
+        blk_sync();
+        if (n >= 3) entropy_bits_batch(b, xs, n, thr, nk, perm, work, racc);
+        for (int k = 0; k < nk; ++k) {
+            const TsfaSpec sp = specs[first + k];
+            EntAcc a;
+            a.sum_log_m = racc[4 * k + 0];
+            a.sum_log_m1 = racc[4 * k + 1];
+            a.sum_cnt_m = racc[4 * k + 2];
+            a.sum_cnt_m1 = racc[4 * k + 3];
+            double v;
+            if (sp.calc == TSFA_C_APPROXIMATE_ENTROPY) v = (n <= 3) ? 0.0 : apen_from_acc(a, n, 2);
+            else v = (n < 3) ? TSFA_NAN : sampen_from_acc(a, n, 2);
+            if (b.tid == 0) out_row[sp.col] = v;
+        }
+        blk_sync();
+    }
+}
+
+#endif

@@ -510,6 +510,18 @@ static int run_batch(tsfa_plan *plan, const void *d_values, int dtype, const dou
                 for (const auto &s : plan->fam_specs[f])
                     if (s.calc == TSFA_C_APPROXIMATE_ENTROPY && (int)s.p[0] != 2) a.ent_fast = 0;
                 if (getenv("TSFA_ENT_SLOW")) a.ent_fast = 0;  // experiment / test hook: the general kernel
+                // series up to TSFA_ENTB_MAXN samples: the bit-matrix sweep (fam_entropy_bits.h) -- sorted ranges + bit
+                // rows instead of a distance per pair; one (strip, tolerance) task per wavefront register slot
+                if (a.ent_fast && maxn <= TSFA_ENTB_MAXN && maxn >= 3 &&
+                    !(getenv("TSFA_ENT_PAIRS") && atoi(getenv("TSFA_ENT_PAIRS"))) &&
+                    tsfa_entropy_lds_bytes(maxn, 2) <= 64 * 1024) {
+                    a.ent_cnt = 2;
+                    a.nt = 64 * std::min(TSFA_ENTB_MAXWAVES, entb_waves_for(maxn, a.nspecs));
+                    char key[32];
+                    snprintf(key, sizeof key, "TSFA_NT_%d", f);
+                    const char *e = getenv(key);
+                    if (e && atoi(e) >= 64) a.nt = atoi(e);
+                }
             }
             // SEQ: one launch parses up to TSFA_LZ_MAX_GROUP `bins` values side by side -- as many as LDS allows
             int seq_group = 0;

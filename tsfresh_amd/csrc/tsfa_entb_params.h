@@ -1,0 +1,42 @@
+// Shape parameters of the bit-matrix entropy sweep (fam_entropy_bits.h), shared by the kernels, the LDS layout and
+// the host's launch decisions.
+#ifndef TSFA_ENTB_PARAMS_H
+#define TSFA_ENTB_PARAMS_H
+#include <stddef.h>
+#if defined(__HIPCC__)
+#define TSFA_ENTB_HD __host__ __device__
+#else
+#define TSFA_ENTB_HD
+#endif
+
+#define TSFA_ENTB_QW 4                    // table words per column part
+#define TSFA_ENTB_S (TSFA_ENTB_QW + 1)    // words per table entry (one halo word)
+#define TSFA_ENTB_MAXT 13                 // tasks (strip x tolerance) per wavefront: register-resident ranges + counters
+#define TSFA_ENTB_MAXK 6                  // tolerances per batch
+#define TSFA_ENTB_STRIP 62                // templates per strip (64 lanes, two halo lanes)
+#define TSFA_ENTB_MAXN 1024
+#define TSFA_ENTB_MAXWAVES 16
+
+// words of the LDS work region (ranges / table / counters take turns in it)
+static inline TSFA_ENTB_HD size_t entb_work_words(int maxn) {
+    size_t p2 = 1;
+    while (p2 < (size_t)maxn) p2 <<= 1;
+    const size_t ranges = 2 * p2 + (size_t)TSFA_ENTB_MAXK * maxn;  // sorted copy (float64, padded) + packed ranges
+    const size_t table = (size_t)(maxn + 1) * TSFA_ENTB_S + (size_t)TSFA_ENTB_MAXWAVES * TSFA_ENTB_S;
+    const size_t counts = (size_t)TSFA_ENTB_MAXK * maxn + 2 * (2 * TSFA_ENTB_MAXK * TSFA_ENTB_MAXWAVES * 4) + 4;  // + partial products
+    size_t w = ranges > table ? ranges : table;
+    if (counts > w) w = counts;
+    return w + 8;
+}
+
+
+// wavefronts per workgroup for series of up to maxn samples, tolerances nk: every (strip, tolerance) task in registers
+static inline TSFA_ENTB_HD int entb_waves_for(int maxn, int nk) {
+    const int nstrips = (maxn - 1 + TSFA_ENTB_STRIP - 1) / TSFA_ENTB_STRIP;
+    if (nk > TSFA_ENTB_MAXK) nk = TSFA_ENTB_MAXK;
+    const int need = (nstrips * nk + TSFA_ENTB_MAXT - 1) / TSFA_ENTB_MAXT;
+    int w = 1;
+    while (w < need) w <<= 1;
+    return w < 1 ? 1 : w;
+}
+#endif

@@ -204,6 +204,26 @@ __global__ void __launch_bounds__(1024) k_entropy(const T *__restrict__ values, 
     TSFA_SERIES_END
 }
 
+#if !defined(TSFA_LONG)
+// Bit-matrix sweep (fam_entropy_bits.h): every spec has m = 2 and every series of the launch 3 .. TSFA_ENTB_MAXN samples
+// (shorter ones take the closed forms); workgroup = entb_waves_for(maxn, nspecs) wavefronts.
+template <typename T>
+__global__ void __launch_bounds__(1024) k_entropy_bits(const T *__restrict__ values, const int64_t *__restrict__ starts, const int64_t *__restrict__ ends, int64_t n_series, const int *__restrict__ sel,
+                          const TsfaSpec *__restrict__ specs, int nspecs, double *__restrict__ out, int64_t ld, int maxn) {
+    TSFA_SERIES_BEGIN
+    const int64_t off = starts[sidx];
+    const int n = (int)(ends[sidx] - off);
+    EntropyLds L;
+    L.carve(tsfa_base, maxn, 2);
+    TSFA_TICKS_BEGIN();
+    Blk b{(int)threadIdx.x, (int)blockDim.x, L.red, L.np};
+    stage_series(b, values + off, n, L.xs);
+    fam_entropy_series_bits<sizeof(T) == 4>(b, L.xs, n, specs, nspecs, out + sidx * ld, L.thr, L.perm, L.cnt);
+    TSFA_TICKS_END();
+    TSFA_SERIES_END
+}
+#endif
+
 template <typename T>
 __global__ void __launch_bounds__(256) k_seq(const T *__restrict__ values, const int64_t *__restrict__ starts, const int64_t *__restrict__ ends, int64_t n_series, const int *__restrict__ sel,
                       double *__restrict__ out, int64_t ld, const TsfaSeqGroup g TSFA_GS_PARAMS) {
@@ -539,6 +559,12 @@ static int launch_all_t(const TsfaLaunch &a, const T *values) {
     } else if (a.fam == TSFA_FAM_ENTROPY) {
         EntropyLds L;
         const size_t lds = L.carve(nullptr, a.maxn, a.ent_cnt);
+#if !defined(TSFA_LONG)
+        if (a.ent_cnt == 2) {
+            auto kfn = k_entropy_bits<T>;
+            TSFA_KLAUNCH(kfn, lds, values, a.starts, a.ends, a.n_series, a.sel, a.specs, a.nspecs, a.out, a.ld, a.maxn);
+        } else
+#endif
         if (a.ent_fast) {
             auto kfn = k_entropy<T, true>;
             TSFA_KLAUNCH(kfn, lds, values, a.starts, a.ends, a.n_series, a.sel, a.specs, a.nspecs, a.out, a.ld, a.maxn, a.ent_cnt);

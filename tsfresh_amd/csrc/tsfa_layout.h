@@ -9,6 +9,7 @@
 #include "tsfa_common.h"
 #include "fam_cwt.h"
 #include "fam_seq.h"
+#include "tsfa_entb_params.h"
 
 #if defined(__HIPCC__)
 #define TSFA_HD __host__ __device__ inline
@@ -145,7 +146,8 @@ struct ArDdLds {
 
 struct EntropyLds {
     double *red; NpScratch *np; double *xs; double *thr; unsigned short *perm; unsigned int *refs; unsigned int *cnt;
-    // with_cnt: per-template LDS counters + template references of the symmetric sweep (fam_entropy.h)
+    // with_cnt 1: per-template LDS counters + template references of the symmetric sweep (fam_entropy.h);
+    // with_cnt 2: the work region of the bit-matrix sweep (fam_entropy_bits.h) in `cnt`
     TSFA_HD size_t carve(unsigned char *base, int maxn, int with_cnt) {
         LdsCarve c{base, 0};
         red = c.take<double>(TSFA_RED_DOUBLES);
@@ -154,7 +156,13 @@ struct EntropyLds {
         const int np2 = tsfa_pow2_ceil(maxn);
         const int nperm = ((np2 > 64) ? np2 : 64) + 32;
         perm = c.take<unsigned short>(nperm);
-        if (with_cnt) {  // the numpy-order scratch is dead before the first sweep: share its storage
+        if (with_cnt == 2) {  // the numpy-order scratch is dead before the ranges are computed: share its storage
+            refs = nullptr;
+            const size_t cb = entb_work_words(maxn) * sizeof(unsigned int);
+            unsigned char *u = c.take<unsigned char>(cb > sizeof(NpScratch) ? cb : sizeof(NpScratch));
+            np = (NpScratch *)u;
+            cnt = (unsigned int *)u;
+        } else if (with_cnt) {  // the numpy-order scratch is dead before the first sweep: share its storage
             refs = c.take<unsigned int>(nperm);
             const size_t cb = (size_t)(maxn + 16) * ((maxn <= 1024) ? 4 : 3) * sizeof(unsigned int);  // staged sweep: 4 words / template
             unsigned char *u = c.take<unsigned char>(cb > sizeof(NpScratch) ? cb : sizeof(NpScratch));
