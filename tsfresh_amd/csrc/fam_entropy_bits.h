@@ -11,18 +11,18 @@
 //     (hi(q) = #{p : lo(p) <= q}, an integer bisection).  O(n log n) float64 operations per tolerance instead of O(n^2).
 //   * With Pref(t) = the bit set {b : rank(x_b) < t} over the NATURAL sample index b, the row of the 0/1 matrix
 //     A[a, b] = (|x_a - x_b| <= r) is Pref(hi) xor Pref(lo): two table reads and one xor per 32 pairs.
-//   * Templates i, j of length 2 match iff A[i, j] & A[i+1, j+1]; of length 3 iff additionally A[i+2, j+2].  With
-//     lane = template i and the rows of i+1, i+2 shifted right by one / two bits:
-//         C_2[i] = popcount(A[i] & (A[i+1] >> 1)),   C_3[i] = popcount(A[i] & (A[i+1] >> 1) & (A[i+2] >> 2))
-//     -- per 32 pairs: 2 funnel shifts, 2 ands, 2 popcount-accumulates and the two cross-lane moves that fetch the
-//     shifted words of lanes i+1, i+2 (DPP wavefront shifts, no LDS).  The counts are exact integers: the result is
-//     bit-identical to the pair sweeps'.
+//   * Templates i, j of length 2 match iff A[i, j] & A[i+1, j+1]; of length 3 iff additionally A[i+2, j+2]: the
+//     partners sit one step down the DIAGONAL.  Lane l of a strip (template i = strip start + l) therefore holds its row
+//     rotated left by l bits, E_l[d] = A[i, d + l] -- one funnel shift per word -- and then
+//         M2_l = E_l & E_{l+1},   M3_l = M2_l & M2_{l+1},   C_2[i] = popcount(M2_l),   C_3[i] = popcount(M3_l)
+//     with the neighbour lane's word as a DPP operand of the AND itself: per 32 pairs one xor, one funnel shift, two
+//     ANDs and two popcount-accumulates.  The counts are exact integers: the result is bit-identical to the pair
+//     sweeps'.  (Columns are taken modulo 32 * NW with NW = ceil((n + 1) / 32): at least one zero guard column, so a
+//     wrapped partner never matches.)
 //
-// Pref is (n + 1) x n bits = 128 KB at n = 1024, so it is built in column parts of TSFA_ENTB_QW words (+ one halo
-// word for the funnel shift) by a workgroup prefix-OR over the sorted order; a wavefront sweeps strips of 62 templates
+// Pref is (n + 1) x n bits = 128 KB at n = 1024, so it is built in column parts of TSFA_ENTB_QW words (+ two halo
+// words for the rotation) by a workgroup prefix-OR over the sorted order; a wavefront sweeps strips of 62 templates
 // (lanes 62, 63 only supply their neighbours) for one tolerance per task, its ranges and counters in registers.
-//
-// Cost at n = 1024, six tolerances: ~3.0 M lane operations per series against 9.0 M for the staged pair sweep.
 #ifndef TSFA_FAM_ENTROPY_BITS_H
 #define TSFA_FAM_ENTROPY_BITS_H
 
@@ -33,9 +33,9 @@ typedef __attribute__((address_space(3))) const unsigned int *entb_lds_cup;
 TSFA_DEV unsigned int entb_lds_addr(const void *p) {
     return (unsigned int)(uintptr_t)(__attribute__((address_space(3))) const void *)p;
 }
-// value of lane + 1 (lane 63: 0)
-TSFA_DEV unsigned int entb_from_next(unsigned int v) {
-    return (unsigned int)__builtin_amdgcn_update_dpp(0, (int)v, 0x130 /* wave_shl:1 */, 0xf, 0xf, true);
+// v & (v of lane + 1); lane 63: 0.  (v_and_b32_dpp wave_shl:1 -- the neighbour's word is an operand of the AND)
+TSFA_DEV unsigned int entb_and_next(unsigned int v) {
+    return v & (unsigned int)__builtin_amdgcn_update_dpp(0, (int)v, 0x130 /* wave_shl:1 */, 0xf, 0xf, true);
 }
 // inclusive OR-scan over the 64 lanes (the sequence LLVM's atomic optimizer emits for wave64 on gfx9)
 TSFA_DEV unsigned int entb_wave_or_scan(unsigned int v) {
@@ -67,7 +67,7 @@ TSFA_DEV Blk entb_opaque(const Blk &b0) {
 // ---------------------------------------------------------------------------------------------------------------
 // Ranges.  perm[0 .. n) = sample indices sorted by value (ties by index).  For tolerance k and sorted position q
 // (sample a = perm[q]) the samples within thr[k] of x_a are the sorted positions [lo, hi).  Written per NATURAL sample
-// index: rng[k * n + a] = (lo * S * 4) | (hi * S * 4) << 16 -- byte offsets of the two table entries (lo == hi: empty).
+// index: rng[k * n + a] = (lo * S) | (hi * S) << 16 -- word offsets of the two table entries (lo == hi: empty).
 // lo16: scratch, nk * n unsigned shorts.
 // ---------------------------------------------------------------------------------------------------------------
 TSFA_DEV void entb_ranges(const Blk &b0, const double *xs, int n, const double *thr, int nk, const unsigned short *perm,
@@ -106,110 +106,150 @@ TSFA_DEV void entb_ranges(const Blk &b0, const double *xs, int n, const double *
             // infinite sample / negative or NaN tolerance: matches nothing (not even itself)
             const bool any = (fabs(xq - xq) <= r[k]) && pl[k] < ph[k];
             const unsigned int lo = any ? (unsigned int)pl[k] : 0u, hi = any ? (unsigned int)ph[k] : 0u;  // 8 * rank
-            if (k < nk) rng[k * n + a] = ((lo >> 3) * (TSFA_ENTB_S * 4u)) | (((hi >> 3) * (TSFA_ENTB_S * 4u)) << 16);
+            if (k < nk) rng[k * n + a] = ((lo >> 3) * (unsigned int)TSFA_ENTB_S) | (((hi >> 3) * (unsigned int)TSFA_ENTB_S) << 16);
         }
     }
     blk_sync();
 }
 
 // ---------------------------------------------------------------------------------------------------------------
-// Table of one column part: entry t (0 .. n), word w (0 .. QW) = bits of the columns 32 (w0 + w) .. + 31 whose rank
-// is below t.  wtot: TSFA_ENTB_MAXWAVES * S words of cross-wavefront scratch.
+// Table of one column part: entry t (0 .. n), word u (0 .. S-1) = bits of the columns of word (w0 + u) mod NW whose
+// rank is below t.  wtot: TSFA_ENTB_MAXWAVES * S words of cross-wavefront scratch.
 // ---------------------------------------------------------------------------------------------------------------
-TSFA_DEV void entb_build_table(const Blk &b0, int n, const unsigned short *perm, int w0, unsigned int *table,
+TSFA_DEV void entb_build_table(const Blk &b0, int n, const unsigned short *perm, int w0, int NW, unsigned int *table,
                                unsigned int *wtot) {
     const Blk b = entb_opaque(b0);
     const int S = TSFA_ENTB_S;
+    int target[TSFA_ENTB_S];  // wave-uniform: the row word each entry word mirrors
+#pragma unroll
+    for (int u = 0; u < S; ++u) target[u] = (w0 + u) % NW;
 #if TSFA_GPU
     const int E = (n + b.nt - 1) / b.nt;
     const int p0 = b.tid * E;
     unsigned int tot[TSFA_ENTB_S];
 #pragma unroll
-    for (int w = 0; w < S; ++w) tot[w] = 0u;
+    for (int u = 0; u < S; ++u) tot[u] = 0u;
     for (int e = 0; e < E; ++e) {
         const int p = p0 + e;
         if (p < n) {
             const int j = (int)perm[p];
-            const int wi = (j >> 5) - w0;
+            const int jw = j >> 5;
             const unsigned int bit = 1u << (j & 31);
 #pragma unroll
-            for (int w = 0; w < S; ++w) tot[w] |= (wi == w) ? bit : 0u;
+            for (int u = 0; u < S; ++u) tot[u] |= (jw == target[u]) ? bit : 0u;
         }
     }
     unsigned int run[TSFA_ENTB_S];
-    const int lane = b.tid & 63, wave = b.tid >> 6, nw = b.nt >> 6;
+    const int lane = b.tid & 63, wave = b.tid >> 6;
 #pragma unroll
-    for (int w = 0; w < S; ++w) {
-        const unsigned int inc = entb_wave_or_scan(tot[w]);
-        if (lane == 63) wtot[wave * S + w] = inc;
-        run[w] = entb_from_prev(inc);
+    for (int u = 0; u < S; ++u) {
+        const unsigned int inc = entb_wave_or_scan(tot[u]);
+        if (lane == 63) wtot[wave * S + u] = inc;
+        run[u] = entb_from_prev(inc);
     }
     blk_sync();
     for (int v = 0; v < wave; ++v) {
 #pragma unroll
-        for (int w = 0; w < S; ++w) run[w] |= wtot[v * S + w];
+        for (int u = 0; u < S; ++u) run[u] |= wtot[v * S + u];
     }
     for (int e = 0; e < E; ++e) {
         const int p = p0 + e;
         if (p < n) {
 #pragma unroll
-            for (int w = 0; w < S; ++w) table[p * S + w] = run[w];
+            for (int u = 0; u < S; ++u) table[p * S + u] = run[u];
             const int j = (int)perm[p];
-            const int wi = (j >> 5) - w0;
+            const int jw = j >> 5;
             const unsigned int bit = 1u << (j & 31);
 #pragma unroll
-            for (int w = 0; w < S; ++w) run[w] |= (wi == w) ? bit : 0u;
+            for (int u = 0; u < S; ++u) run[u] |= (jw == target[u]) ? bit : 0u;
         }
     }
     if (b.tid == b.nt - 1) {  // entry n: every column (the last thread's running value is the total: its range ends the order)
 #pragma unroll
-        for (int w = 0; w < S; ++w) table[n * S + w] = run[w];
+        for (int u = 0; u < S; ++u) table[n * S + u] = run[u];
     }
-    (void)nw;
 #else
     (void)b; (void)wtot;
     unsigned int run[TSFA_ENTB_S];
-    for (int w = 0; w < S; ++w) run[w] = 0u;
+    for (int u = 0; u < S; ++u) run[u] = 0u;
     for (int p = 0; p <= n; ++p) {
-        for (int w = 0; w < S; ++w) table[p * S + w] = run[w];
+        for (int u = 0; u < S; ++u) table[p * S + u] = run[u];
         if (p < n) {
             const int j = (int)perm[p];
-            const int wi = (j >> 5) - w0;
-            if (wi >= 0 && wi < S) run[wi] |= 1u << (j & 31);
+            for (int u = 0; u < S; ++u)
+                if ((j >> 5) == target[u]) run[u] |= 1u << (j & 31);
         }
     }
 #endif
     blk_sync();
 }
 
-// one task (strip, tolerance) over one column part: the lane's template against the 32 * QW columns of the part
+// One task (strip, tolerance) over one column part.  pl / ph: LDS byte addresses of the lane's two table entries, already
+// advanced by the lane's word offset (lane >> 5); sh = lane & 31; nq = diagonal words of this part (<= QW).
 #if TSFA_GPU
-TSFA_DEV unsigned int entb_task_part(unsigned int rng_lane) {
-    const entb_lds_cup pl = (entb_lds_cup)(rng_lane & 0xFFFFu), ph = (entb_lds_cup)(rng_lane >> 16);
-    unsigned int A[TSFA_ENTB_S];
+#define TSFA_ENTB_DPP " wave_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+// FULL: all QW diagonal words of the part exist (every part of a series with NW % QW == 0, e.g. n = 1024)
+template <bool FULL>
+TSFA_DEV unsigned int entb_task_part(unsigned int pl_addr, unsigned int ph_addr, unsigned int sh, int nq) {
+    static_assert(TSFA_ENTB_QW == 11, "the DPP block below is written for eleven words");
+    const entb_lds_cup pl = (entb_lds_cup)pl_addr, ph = (entb_lds_cup)ph_addr;
+    unsigned int A[TSFA_ENTB_QW + 1];
 #pragma unroll
-    for (int w = 0; w < TSFA_ENTB_S; ++w) A[w] = ph[w] ^ pl[w];
-    unsigned int c2 = 0u, c3 = 0u;
+    for (int u = 0; u <= TSFA_ENTB_QW; ++u) A[u] = ph[u] ^ pl[u];
+    unsigned int e[TSFA_ENTB_QW];
 #pragma unroll
-    for (int w = 0; w < TSFA_ENTB_QW; ++w) {
-        const unsigned int s1 = __builtin_amdgcn_alignbit(A[w + 1], A[w], 1);  // the row shifted right by one column
-        const unsigned int s2 = __builtin_amdgcn_alignbit(A[w + 1], A[w], 2);
-        const unsigned int m2 = A[w] & entb_from_next(s1);
-        const unsigned int m3 = m2 & entb_from_next(entb_from_next(s2));
-        c2 += (unsigned int)__builtin_popcount(m2);
-        c3 += (unsigned int)__builtin_popcount(m3);
+    for (int t = 0; t < TSFA_ENTB_QW; ++t) {
+        e[t] = __builtin_amdgcn_alignbit(A[t + 1], A[t], sh);  // the row rotated left by the lane index
+        if (!FULL) e[t] = (t < nq) ? e[t] : 0u;
     }
+    // M2 = E & E(lane + 1), M3 = M2 & M2(lane + 1), the neighbour's word as the DPP operand of the AND; the eleven words
+    // are interleaved so that no DPP read follows the write of its source by less than the two required wait states
+    unsigned int c2 = 0u, c3 = 0u;
+    unsigned int m0, m1, m2, m3, m4, m5, m6, m7, m8, m9, m10;
+    asm("s_nop 1\n\t"
+        "v_and_b32_dpp %2, %13, %13" TSFA_ENTB_DPP "v_and_b32_dpp %3, %14, %14" TSFA_ENTB_DPP
+        "v_and_b32_dpp %4, %15, %15" TSFA_ENTB_DPP "v_and_b32_dpp %5, %16, %16" TSFA_ENTB_DPP
+        "v_and_b32_dpp %6, %17, %17" TSFA_ENTB_DPP "v_and_b32_dpp %7, %18, %18" TSFA_ENTB_DPP
+        "v_and_b32_dpp %8, %19, %19" TSFA_ENTB_DPP "v_and_b32_dpp %9, %20, %20" TSFA_ENTB_DPP
+        "v_and_b32_dpp %10, %21, %21" TSFA_ENTB_DPP "v_and_b32_dpp %11, %22, %22" TSFA_ENTB_DPP
+        "v_and_b32_dpp %12, %23, %23" TSFA_ENTB_DPP
+        "v_bcnt_u32_b32 %0, %2, %0\n\tv_bcnt_u32_b32 %0, %3, %0\n\tv_bcnt_u32_b32 %0, %4, %0\n\t"
+        "v_bcnt_u32_b32 %0, %5, %0\n\tv_bcnt_u32_b32 %0, %6, %0\n\tv_bcnt_u32_b32 %0, %7, %0\n\t"
+        "v_bcnt_u32_b32 %0, %8, %0\n\tv_bcnt_u32_b32 %0, %9, %0\n\tv_bcnt_u32_b32 %0, %10, %0\n\t"
+        "v_bcnt_u32_b32 %0, %11, %0\n\tv_bcnt_u32_b32 %0, %12, %0\n\t"
+        "v_and_b32_dpp %2, %2, %2" TSFA_ENTB_DPP "v_and_b32_dpp %3, %3, %3" TSFA_ENTB_DPP
+        "v_and_b32_dpp %4, %4, %4" TSFA_ENTB_DPP "v_and_b32_dpp %5, %5, %5" TSFA_ENTB_DPP
+        "v_and_b32_dpp %6, %6, %6" TSFA_ENTB_DPP "v_and_b32_dpp %7, %7, %7" TSFA_ENTB_DPP
+        "v_and_b32_dpp %8, %8, %8" TSFA_ENTB_DPP "v_and_b32_dpp %9, %9, %9" TSFA_ENTB_DPP
+        "v_and_b32_dpp %10, %10, %10" TSFA_ENTB_DPP "v_and_b32_dpp %11, %11, %11" TSFA_ENTB_DPP
+        "v_and_b32_dpp %12, %12, %12" TSFA_ENTB_DPP
+        "v_bcnt_u32_b32 %1, %2, %1\n\tv_bcnt_u32_b32 %1, %3, %1\n\tv_bcnt_u32_b32 %1, %4, %1\n\t"
+        "v_bcnt_u32_b32 %1, %5, %1\n\tv_bcnt_u32_b32 %1, %6, %1\n\tv_bcnt_u32_b32 %1, %7, %1\n\t"
+        "v_bcnt_u32_b32 %1, %8, %1\n\tv_bcnt_u32_b32 %1, %9, %1\n\tv_bcnt_u32_b32 %1, %10, %1\n\t"
+        "v_bcnt_u32_b32 %1, %11, %1\n\tv_bcnt_u32_b32 %1, %12, %1"
+        : "+v"(c2), "+v"(c3), "=&v"(m0), "=&v"(m1), "=&v"(m2), "=&v"(m3), "=&v"(m4), "=&v"(m5), "=&v"(m6), "=&v"(m7),
+          "=&v"(m8), "=&v"(m9), "=&v"(m10)
+        : "v"(e[0]), "v"(e[1]), "v"(e[2]), "v"(e[3]), "v"(e[4]), "v"(e[5]), "v"(e[6]), "v"(e[7]), "v"(e[8]), "v"(e[9]),
+          "v"(e[10]));
     return c2 | (c3 << 16);
-}
-#else
-TSFA_DEV void entb_row_words(unsigned int rng_lane, const unsigned int *table, unsigned int *A) {
-    const unsigned int *pl = table + (rng_lane & 0xFFFFu) / 4, *ph = table + (rng_lane >> 16) / 4;
-    for (int w = 0; w < TSFA_ENTB_S; ++w) A[w] = ph[w] ^ pl[w];
 }
 #endif
 
+TSFA_DEV int entb_wave_sum_i32(int v) {
+#if TSFA_GPU
+    v += __builtin_amdgcn_update_dpp(0, v, TSFA_DPP_QUAD_XOR1, 0xf, 0xf, false);
+    v += __builtin_amdgcn_update_dpp(0, v, TSFA_DPP_QUAD_XOR2, 0xf, 0xf, false);
+    v += __builtin_amdgcn_update_dpp(0, v, TSFA_DPP_ROW_HALF_MIRROR, 0xf, 0xf, false);
+    v += __builtin_amdgcn_update_dpp(0, v, TSFA_DPP_ROW_MIRROR, 0xf, 0xf, false);
+    return (__builtin_amdgcn_readlane(v, 0) + __builtin_amdgcn_readlane(v, 16)) +
+           (__builtin_amdgcn_readlane(v, 32) + __builtin_amdgcn_readlane(v, 48));
+#else
+    return v;
+#endif
+}
+
 // Reduction of the per-thread products / sums of one round (see entropy_bits_batch): part = LDS scratch of
-// 2 K * (nt / 16) doubles.
+// 2 K * (nt / 16) doubles + 2 K * (nt / 64) words.
 TSFA_DEV void entb_totals(const Blk &b, int kn, int k0, double *pm, double *pm1, int *sc, int *sc1, int *nm, int *nm1,
                           int nrow_m, int nrow_m1, double *part, double *racc, bool accumulate) {
     const int K = TSFA_ENTB_MAXK;
@@ -230,44 +270,32 @@ TSFA_DEV void entb_totals(const Blk &b, int kn, int k0, double *pm, double *pm1,
             }
         }
     }
-    blk_sync();
-    // one logarithm per partial product (by as many lanes as there are products); then the 2 K sums of logs, the
-    // per-thread folded logs and the integer totals (exact in float64) are reduced together: wavefront sums, one slot
-    // per wavefront and value, one barrier
-    double lg = 0.0;
-    int which = -1;
-    if (b.tid < 2 * kn * nrows) {
-        which = b.tid / nrows;  // 2 k + (0: m, 1: m + 1)
-        lg = log(part[b.tid]);
-    }
-    blk_sync();
-    double *slot = part;  // [6 K][nwaves]
+    // the integer totals of a tolerance packed into one word each (sum C < 2^21, #rows < 2^11): wavefront sums by DPP,
+    // one slot per wavefront
+    unsigned int *islot = (unsigned int *)(void *)(part + 2 * K * nrows);  // [nwaves][2 K]
     const int nw = b.nt >> 6;
 #pragma unroll
     for (int k = 0; k < K; ++k) {
         if (k < kn) {
-            const double v0 = wave_sum((which == 2 * k) ? lg : 0.0);
-            const double v1 = wave_sum((which == 2 * k + 1) ? lg : 0.0);
-            const double v2 = wave_sum((double)sc[k]), v3 = wave_sum((double)sc1[k]);
-            const double v4 = wave_sum((double)nm[k]), v5 = wave_sum((double)nm1[k]);
-            if (lane == 0) {
-                double *d = slot + (6 * k) * nw + wave;
-                d[0] = v0; d[nw] = v1; d[2 * nw] = v2; d[3 * nw] = v3; d[4 * nw] = v4; d[5 * nw] = v5;
-            }
+            const int s0 = entb_wave_sum_i32((int)((unsigned int)sc[k] | ((unsigned int)nm[k] << 21)));
+            const int s1 = entb_wave_sum_i32((int)((unsigned int)sc1[k] | ((unsigned int)nm1[k] << 21)));
+            if (lane == 0) { islot[wave * 2 * K + 2 * k] = (unsigned int)s0; islot[wave * 2 * K + 2 * k + 1] = (unsigned int)s1; }
         }
     }
     blk_sync();
-    if (b.tid < kn) {
-        const int k = b.tid;
-        double t[6];
-        for (int j = 0; j < 6; ++j) {
-            double a = 0.0;
-            for (int w = 0; w < nw; ++w) a += slot[(6 * k + j) * nw + w];
-            t[j] = a;
-        }
+    // one logarithm per partial product -- by as many lanes as there are products (a float64 log is ~150 instructions)
+    if (b.tid < 2 * kn * nrows) part[b.tid] = log(part[b.tid]);
+    blk_sync();
+    if (b.tid < 2 * kn) {  // value j = 2 k + (0: m, 1: m + 1)
+        const int k = b.tid >> 1, odd = b.tid & 1;
+        double a = 0.0;
+        for (int r = 0; r < nrows; ++r) a += part[b.tid * nrows + r];
+        unsigned int tot = 0u;
+        for (int w = 0; w < nw; ++w) tot += islot[w * 2 * K + b.tid];
         double *d = racc + 4 * (k0 + k);
-        if (!accumulate) { d[0] = 0.0; d[1] = 0.0; d[2] = 0.0; d[3] = 0.0; }
-        d[0] += t[0] - t[4] * ldm; d[1] += t[1] - t[5] * ldm1; d[2] += t[2]; d[3] += t[3];
+        const double v = a - (double)(tot >> 21) * (odd ? ldm1 : ldm), c = (double)(tot & 0x1FFFFFu);
+        if (accumulate) { d[odd] += v; d[2 + odd] += c; }
+        else { d[odd] = v; d[2 + odd] = c; }
     }
     blk_sync();
 #else
@@ -293,8 +321,8 @@ TSFA_DEV void entropy_bits_batch(const Blk &b_in, const double *xs, int n, const
     const Blk b = entb_opaque(b_in);
     const int S = TSFA_ENTB_S, QW = TSFA_ENTB_QW;
     const int nrow_m = n - 1, nrow_m1 = n - 2;
-    const int nwords = (n + 31) >> 5;
-    const int nparts = (nwords + QW - 1) / QW;
+    const int NW = (n + 32) >> 5;  // row words: at least one zero guard column
+    const int nparts = (NW + QW - 1) / QW;
     const int nstrips = (nrow_m + TSFA_ENTB_STRIP - 1) / TSFA_ENTB_STRIP;
     unsigned int *rng = work + 2 * (size_t)next_pow2(n);  // behind the sorted copy
     unsigned int *table = work;
@@ -315,7 +343,8 @@ TSFA_DEV void entropy_bits_batch(const Blk &b_in, const double *xs, int n, const
     for (int k0 = 0; k0 < nk; k0 += kround) {
         const int kn = (nk - k0 < kround) ? (nk - k0) : kround;
         const int ntask = nstrips * kn;
-        unsigned int rg[TSFA_ENTB_MAXT], ct[TSFA_ENTB_MAXT];
+        unsigned int rl[TSFA_ENTB_MAXT], rh[TSFA_ENTB_MAXT], ct[TSFA_ENTB_MAXT];
+        const unsigned int lane_off = tbase + 4u * (unsigned int)(lane >> 5), sh = (unsigned int)(lane & 31);
         const unsigned int kmagic = 65536u / (unsigned int)kn + 1u;  // id / kn == (id * kmagic) >> 16 for id < 10 000
         if (k0 > 0) {  // the ranges were overwritten by the table of the previous round
             blk_sync();
@@ -324,23 +353,33 @@ TSFA_DEV void entropy_bits_batch(const Blk &b_in, const double *xs, int n, const
 #pragma unroll
         for (int tt = 0; tt < TSFA_ENTB_MAXT; ++tt) {
             const int id = wave + tt * nw;
-            rg[tt] = 0u;
+            rl[tt] = lane_off;
+            rh[tt] = lane_off;
             ct[tt] = 0u;
             if (id < ntask) {
                 const int s = (int)(((unsigned int)id * kmagic) >> 16), k = k0 + (id - s * kn);
                 const int i = s * TSFA_ENTB_STRIP + lane;
                 const unsigned int r = (i < n) ? rng[k * n + i] : 0u;
-                rg[tt] = ((r & 0xFFFFu) + tbase) | (((r >> 16) + tbase) << 16);
+                rl[tt] = lane_off + 4u * (r & 0xFFFFu);
+                rh[tt] = lane_off + 4u * (r >> 16);
             }
         }
         blk_sync();
         TSFA_TICK(tk, b, 138);
         for (int part = 0; part < nparts; ++part) {
-            entb_build_table(b, n, perm, part * QW, table, wtot);
+            entb_build_table(b, n, perm, part * QW, NW, table, wtot);
             TSFA_TICK(tk, b, 139);
+            const int nq = (NW - part * QW < QW) ? (NW - part * QW) : QW;
+            if (nq == QW) {
 #pragma unroll
-            for (int tt = 0; tt < TSFA_ENTB_MAXT; ++tt) {
-                if (wave + tt * nw < ntask) ct[tt] += entb_task_part(rg[tt]);
+                for (int tt = 0; tt < TSFA_ENTB_MAXT; ++tt) {
+                    if (wave + tt * nw < ntask) ct[tt] += entb_task_part<true>(rl[tt], rh[tt], sh, nq);
+                }
+            } else {
+#pragma unroll
+                for (int tt = 0; tt < TSFA_ENTB_MAXT; ++tt) {
+                    if (wave + tt * nw < ntask) ct[tt] += entb_task_part<false>(rl[tt], rh[tt], sh, nq);
+                }
             }
             TSFA_TICK(tk, b, 136);
             blk_sync();
@@ -366,25 +405,28 @@ TSFA_DEV void entropy_bits_batch(const Blk &b_in, const double *xs, int n, const
         for (int k = 0; k < nk; ++k)
             for (int i = 0; i < n + 64; ++i) { rg[k * (TSFA_ENTB_MAXN + 64) + i] = (i < n) ? rng[k * n + i] : 0u; ct[k * (TSFA_ENTB_MAXN + 64) + i] = 0u; }
         for (int part = 0; part < nparts; ++part) {
-            entb_build_table(b, n, perm, part * QW, table, wtot);
+            entb_build_table(b, n, perm, part * QW, NW, table, wtot);
+            const int nq = (NW - part * QW < QW) ? (NW - part * QW) : QW;
             for (int k = 0; k < nk; ++k) {
                 for (int s = 0; s < nstrips; ++s) {
-                    unsigned int A[64][TSFA_ENTB_S], s1[66][TSFA_ENTB_QW], s2[66][TSFA_ENTB_QW];
+                    unsigned int e[66][TSFA_ENTB_QW], m2[66][TSFA_ENTB_QW];
                     for (int l = 0; l < 64; ++l) {
-                        entb_row_words(rg[k * (TSFA_ENTB_MAXN + 64) + s * TSFA_ENTB_STRIP + l], table, A[l]);
-                        for (int w = 0; w < QW; ++w) {
-                            s1[l][w] = (A[l][w] >> 1) | (A[l][w + 1] << 31);
-                            s2[l][w] = (A[l][w] >> 2) | (A[l][w + 1] << 30);
+                        const unsigned int r = rg[k * (TSFA_ENTB_MAXN + 64) + s * TSFA_ENTB_STRIP + l];
+                        const unsigned int *pl = table + (r & 0xFFFFu) + (l >> 5), *ph = table + (r >> 16) + (l >> 5);
+                        const unsigned int sh = (unsigned int)(l & 31);
+                        for (int t = 0; t < QW; ++t) {
+                            const unsigned long long two = ((unsigned long long)(ph[t + 1] ^ pl[t + 1]) << 32) | (ph[t] ^ pl[t]);
+                            e[l][t] = (unsigned int)(two >> sh);
                         }
                     }
-                    for (int w = 0; w < QW; ++w) { s1[64][w] = s1[65][w] = 0u; s2[64][w] = s2[65][w] = 0u; }
+                    for (int t = 0; t < QW; ++t) { e[64][t] = 0u; m2[64][t] = m2[65][t] = 0u; }
+                    for (int l = 0; l < 64; ++l)
+                        for (int t = 0; t < QW; ++t) m2[l][t] = e[l][t] & e[l + 1][t];
                     for (int l = 0; l < TSFA_ENTB_STRIP; ++l) {
                         unsigned int c2 = 0u, c3 = 0u;
-                        for (int w = 0; w < QW; ++w) {
-                            const unsigned int m2 = A[l][w] & s1[l + 1][w];
-                            const unsigned int m3 = m2 & s2[l + 2][w];
-                            c2 += (unsigned int)__builtin_popcount(m2);
-                            c3 += (unsigned int)__builtin_popcount(m3);
+                        for (int t = 0; t < nq; ++t) {
+                            c2 += (unsigned int)__builtin_popcount(m2[l][t]);
+                            c3 += (unsigned int)__builtin_popcount(m2[l][t] & m2[l + 1][t]);
                         }
                         ct[k * (TSFA_ENTB_MAXN + 64) + s * TSFA_ENTB_STRIP + l] += c2 | (c3 << 16);
                     }

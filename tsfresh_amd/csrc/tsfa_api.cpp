@@ -514,7 +514,7 @@ static int run_batch(tsfa_plan *plan, const void *d_values, int dtype, const dou
                 // rows instead of a distance per pair; one (strip, tolerance) task per wavefront register slot
                 if (a.ent_fast && maxn <= TSFA_ENTB_MAXN && maxn >= 3 &&
                     !(getenv("TSFA_ENT_PAIRS") && atoi(getenv("TSFA_ENT_PAIRS"))) &&
-                    tsfa_entropy_lds_bytes(maxn, 2) <= 64 * 1024) {
+                    tsfa_entropy_lds_bytes(maxn, 2) <= TSFA_LDS_LIMIT / 2) {
                     a.ent_cnt = 2;
                     a.nt = 64 * std::min(TSFA_ENTB_MAXWAVES, entb_waves_for(maxn, a.nspecs));
                     char key[32];

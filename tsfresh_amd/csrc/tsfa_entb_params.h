@@ -9,8 +9,8 @@
 #define TSFA_ENTB_HD
 #endif
 
-#define TSFA_ENTB_QW 4                    // table words per column part
-#define TSFA_ENTB_S (TSFA_ENTB_QW + 1)    // words per table entry (one halo word)
+#define TSFA_ENTB_QW 11                   // diagonal words per column part
+#define TSFA_ENTB_S (TSFA_ENTB_QW + 2)    // words per table entry (two halo words: the rotation by up to 63 bits)
 #define TSFA_ENTB_MAXT 13                 // tasks (strip x tolerance) per wavefront: register-resident ranges + counters
 #define TSFA_ENTB_MAXK 6                  // tolerances per batch
 #define TSFA_ENTB_STRIP 62                // templates per strip (64 lanes, two halo lanes)
@@ -23,7 +23,7 @@ static inline TSFA_ENTB_HD size_t entb_work_words(int maxn) {
     while (p2 < (size_t)maxn) p2 <<= 1;
     const size_t ranges = 2 * p2 + (size_t)TSFA_ENTB_MAXK * maxn;  // sorted copy (float64, padded) + packed ranges
     const size_t table = (size_t)(maxn + 1) * TSFA_ENTB_S + (size_t)TSFA_ENTB_MAXWAVES * TSFA_ENTB_S;
-    const size_t counts = (size_t)TSFA_ENTB_MAXK * maxn + 2 * (2 * TSFA_ENTB_MAXK * TSFA_ENTB_MAXWAVES * 4) + 4;  // + partial products
+    const size_t counts = (size_t)TSFA_ENTB_MAXK * maxn + 2 * (2 * TSFA_ENTB_MAXK * TSFA_ENTB_MAXWAVES * 4) + 2 * TSFA_ENTB_MAXK * TSFA_ENTB_MAXWAVES + 4;  // + partial products, integer slots
     size_t w = ranges > table ? ranges : table;
     if (counts > w) w = counts;
     return w + 8;
