@@ -20,9 +20,12 @@
 //     sweeps'.  (Columns are taken modulo 32 * NW with NW = ceil((n + 1) / 32): at least one zero guard column, so a
 //     wrapped partner never matches.)
 //
-// Pref is (n + 1) x n bits = 128 KB at n = 1024, so it is built in column parts of TSFA_ENTB_QW words (+ two halo
-// words for the rotation) by a workgroup prefix-OR over the sorted order; a wavefront sweeps strips of 62 templates
-// (lanes 62, 63 only supply their neighbours) for one tolerance per task, its ranges and counters in registers.
+// Pref is (n + 1) x n bits = 128 KB at n = 1024, so it is built in column parts of TSFA_ENTB_QW words (+ one halo
+// word for the rotation) by a workgroup prefix-OR over the sorted order.  A task = one tolerance x two half-strips of
+// 30 templates: lanes 0-29 and 32-61 hold templates, lanes 30, 31, 62, 63 only supply their neighbours; the rotation
+// is the lane index mod 32, so every lane reads the same 48 aligned bytes of its two entries (three ds_read_b128 each
+// -- the table gathers of random entries are what the LDS spends its cycles on).  Ranges and counters of a wavefront's
+// tasks stay in registers across the parts.
 #ifndef TSFA_FAM_ENTROPY_BITS_H
 #define TSFA_FAM_ENTROPY_BITS_H
 
@@ -188,49 +191,111 @@ TSFA_DEV void entb_build_table(const Blk &b0, int n, const unsigned short *perm,
 // advanced by the lane's word offset (lane >> 5); sh = lane & 31; nq = diagonal words of this part (<= QW).
 #if TSFA_GPU
 #define TSFA_ENTB_DPP " wave_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
-// FULL: all QW diagonal words of the part exist (every part of a series with NW % QW == 0, e.g. n = 1024)
+// FULL: all QW diagonal words of the part exist (every part of a series with NW % QW == 0)
 template <bool FULL>
 TSFA_DEV unsigned int entb_task_part(unsigned int pl_addr, unsigned int ph_addr, unsigned int sh, int nq) {
-    static_assert(TSFA_ENTB_QW == 11, "the DPP block below is written for eleven words");
-    const entb_lds_cup pl = (entb_lds_cup)pl_addr, ph = (entb_lds_cup)ph_addr;
-    unsigned int A[TSFA_ENTB_QW + 1];
+    static_assert(TSFA_ENTB_S % 4 == 0, "entries are read as 16-byte vectors");
+    typedef unsigned int entb_u4 __attribute__((ext_vector_type(4)));
+    typedef __attribute__((address_space(3))) const entb_u4 *entb_lds_cv4;
+    const entb_lds_cv4 pl = (entb_lds_cv4)pl_addr, ph = (entb_lds_cv4)ph_addr;
+    unsigned int A[TSFA_ENTB_S];
 #pragma unroll
-    for (int u = 0; u <= TSFA_ENTB_QW; ++u) A[u] = ph[u] ^ pl[u];
-    unsigned int e[TSFA_ENTB_QW];
+    for (int v = 0; v < TSFA_ENTB_S / 4; ++v) {
+        const entb_u4 l4 = pl[v], h4 = ph[v];
+        A[4 * v + 0] = h4.x ^ l4.x; A[4 * v + 1] = h4.y ^ l4.y; A[4 * v + 2] = h4.z ^ l4.z; A[4 * v + 3] = h4.w ^ l4.w;
+    }
+    unsigned int e[TSFA_ENTB_QW], m[TSFA_ENTB_QW];
 #pragma unroll
     for (int t = 0; t < TSFA_ENTB_QW; ++t) {
         e[t] = __builtin_amdgcn_alignbit(A[t + 1], A[t], sh);  // the row rotated left by the lane index
         if (!FULL) e[t] = (t < nq) ? e[t] : 0u;
     }
-    // M2 = E & E(lane + 1), M3 = M2 & M2(lane + 1), the neighbour's word as the DPP operand of the AND; the eleven words
-    // are interleaved so that no DPP read follows the write of its source by less than the two required wait states
+    // M2 = E & E(lane + 1), M3 = M2 & M2(lane + 1), the neighbour's word as the DPP operand of the AND; the words are
+    // interleaved so that no DPP read follows the write of its source by less than the two required wait states
     unsigned int c2 = 0u, c3 = 0u;
-    unsigned int m0, m1, m2, m3, m4, m5, m6, m7, m8, m9, m10;
+#if TSFA_ENTB_QW == 11
     asm("s_nop 1\n\t"
-        "v_and_b32_dpp %2, %13, %13" TSFA_ENTB_DPP "v_and_b32_dpp %3, %14, %14" TSFA_ENTB_DPP
-        "v_and_b32_dpp %4, %15, %15" TSFA_ENTB_DPP "v_and_b32_dpp %5, %16, %16" TSFA_ENTB_DPP
-        "v_and_b32_dpp %6, %17, %17" TSFA_ENTB_DPP "v_and_b32_dpp %7, %18, %18" TSFA_ENTB_DPP
-        "v_and_b32_dpp %8, %19, %19" TSFA_ENTB_DPP "v_and_b32_dpp %9, %20, %20" TSFA_ENTB_DPP
-        "v_and_b32_dpp %10, %21, %21" TSFA_ENTB_DPP "v_and_b32_dpp %11, %22, %22" TSFA_ENTB_DPP
+        "v_and_b32_dpp %2, %13, %13" TSFA_ENTB_DPP
+        "v_and_b32_dpp %3, %14, %14" TSFA_ENTB_DPP
+        "v_and_b32_dpp %4, %15, %15" TSFA_ENTB_DPP
+        "v_and_b32_dpp %5, %16, %16" TSFA_ENTB_DPP
+        "v_and_b32_dpp %6, %17, %17" TSFA_ENTB_DPP
+        "v_and_b32_dpp %7, %18, %18" TSFA_ENTB_DPP
+        "v_and_b32_dpp %8, %19, %19" TSFA_ENTB_DPP
+        "v_and_b32_dpp %9, %20, %20" TSFA_ENTB_DPP
+        "v_and_b32_dpp %10, %21, %21" TSFA_ENTB_DPP
+        "v_and_b32_dpp %11, %22, %22" TSFA_ENTB_DPP
         "v_and_b32_dpp %12, %23, %23" TSFA_ENTB_DPP
-        "v_bcnt_u32_b32 %0, %2, %0\n\tv_bcnt_u32_b32 %0, %3, %0\n\tv_bcnt_u32_b32 %0, %4, %0\n\t"
-        "v_bcnt_u32_b32 %0, %5, %0\n\tv_bcnt_u32_b32 %0, %6, %0\n\tv_bcnt_u32_b32 %0, %7, %0\n\t"
-        "v_bcnt_u32_b32 %0, %8, %0\n\tv_bcnt_u32_b32 %0, %9, %0\n\tv_bcnt_u32_b32 %0, %10, %0\n\t"
-        "v_bcnt_u32_b32 %0, %11, %0\n\tv_bcnt_u32_b32 %0, %12, %0\n\t"
-        "v_and_b32_dpp %2, %2, %2" TSFA_ENTB_DPP "v_and_b32_dpp %3, %3, %3" TSFA_ENTB_DPP
-        "v_and_b32_dpp %4, %4, %4" TSFA_ENTB_DPP "v_and_b32_dpp %5, %5, %5" TSFA_ENTB_DPP
-        "v_and_b32_dpp %6, %6, %6" TSFA_ENTB_DPP "v_and_b32_dpp %7, %7, %7" TSFA_ENTB_DPP
-        "v_and_b32_dpp %8, %8, %8" TSFA_ENTB_DPP "v_and_b32_dpp %9, %9, %9" TSFA_ENTB_DPP
-        "v_and_b32_dpp %10, %10, %10" TSFA_ENTB_DPP "v_and_b32_dpp %11, %11, %11" TSFA_ENTB_DPP
+        "v_bcnt_u32_b32 %0, %2, %0\n\t"
+        "v_bcnt_u32_b32 %0, %3, %0\n\t"
+        "v_bcnt_u32_b32 %0, %4, %0\n\t"
+        "v_bcnt_u32_b32 %0, %5, %0\n\t"
+        "v_bcnt_u32_b32 %0, %6, %0\n\t"
+        "v_bcnt_u32_b32 %0, %7, %0\n\t"
+        "v_bcnt_u32_b32 %0, %8, %0\n\t"
+        "v_bcnt_u32_b32 %0, %9, %0\n\t"
+        "v_bcnt_u32_b32 %0, %10, %0\n\t"
+        "v_bcnt_u32_b32 %0, %11, %0\n\t"
+        "v_bcnt_u32_b32 %0, %12, %0\n\t"
+        "v_and_b32_dpp %2, %2, %2" TSFA_ENTB_DPP
+        "v_and_b32_dpp %3, %3, %3" TSFA_ENTB_DPP
+        "v_and_b32_dpp %4, %4, %4" TSFA_ENTB_DPP
+        "v_and_b32_dpp %5, %5, %5" TSFA_ENTB_DPP
+        "v_and_b32_dpp %6, %6, %6" TSFA_ENTB_DPP
+        "v_and_b32_dpp %7, %7, %7" TSFA_ENTB_DPP
+        "v_and_b32_dpp %8, %8, %8" TSFA_ENTB_DPP
+        "v_and_b32_dpp %9, %9, %9" TSFA_ENTB_DPP
+        "v_and_b32_dpp %10, %10, %10" TSFA_ENTB_DPP
+        "v_and_b32_dpp %11, %11, %11" TSFA_ENTB_DPP
         "v_and_b32_dpp %12, %12, %12" TSFA_ENTB_DPP
-        "v_bcnt_u32_b32 %1, %2, %1\n\tv_bcnt_u32_b32 %1, %3, %1\n\tv_bcnt_u32_b32 %1, %4, %1\n\t"
-        "v_bcnt_u32_b32 %1, %5, %1\n\tv_bcnt_u32_b32 %1, %6, %1\n\tv_bcnt_u32_b32 %1, %7, %1\n\t"
-        "v_bcnt_u32_b32 %1, %8, %1\n\tv_bcnt_u32_b32 %1, %9, %1\n\tv_bcnt_u32_b32 %1, %10, %1\n\t"
-        "v_bcnt_u32_b32 %1, %11, %1\n\tv_bcnt_u32_b32 %1, %12, %1"
-        : "+v"(c2), "+v"(c3), "=&v"(m0), "=&v"(m1), "=&v"(m2), "=&v"(m3), "=&v"(m4), "=&v"(m5), "=&v"(m6), "=&v"(m7),
-          "=&v"(m8), "=&v"(m9), "=&v"(m10)
-        : "v"(e[0]), "v"(e[1]), "v"(e[2]), "v"(e[3]), "v"(e[4]), "v"(e[5]), "v"(e[6]), "v"(e[7]), "v"(e[8]), "v"(e[9]),
-          "v"(e[10]));
+        "v_bcnt_u32_b32 %1, %2, %1\n\t"
+        "v_bcnt_u32_b32 %1, %3, %1\n\t"
+        "v_bcnt_u32_b32 %1, %4, %1\n\t"
+        "v_bcnt_u32_b32 %1, %5, %1\n\t"
+        "v_bcnt_u32_b32 %1, %6, %1\n\t"
+        "v_bcnt_u32_b32 %1, %7, %1\n\t"
+        "v_bcnt_u32_b32 %1, %8, %1\n\t"
+        "v_bcnt_u32_b32 %1, %9, %1\n\t"
+        "v_bcnt_u32_b32 %1, %10, %1\n\t"
+        "v_bcnt_u32_b32 %1, %11, %1\n\t"
+        "v_bcnt_u32_b32 %1, %12, %1"
+        : "+v"(c2), "+v"(c3), "=&v"(m[0]), "=&v"(m[1]), "=&v"(m[2]), "=&v"(m[3]), "=&v"(m[4]), "=&v"(m[5]), "=&v"(m[6]), "=&v"(m[7]), "=&v"(m[8]), "=&v"(m[9]), "=&v"(m[10])
+        : "v"(e[0]), "v"(e[1]), "v"(e[2]), "v"(e[3]), "v"(e[4]), "v"(e[5]), "v"(e[6]), "v"(e[7]), "v"(e[8]), "v"(e[9]), "v"(e[10]));
+#elif TSFA_ENTB_QW == 7
+    asm("s_nop 1\n\t"
+        "v_and_b32_dpp %2, %9, %9" TSFA_ENTB_DPP
+        "v_and_b32_dpp %3, %10, %10" TSFA_ENTB_DPP
+        "v_and_b32_dpp %4, %11, %11" TSFA_ENTB_DPP
+        "v_and_b32_dpp %5, %12, %12" TSFA_ENTB_DPP
+        "v_and_b32_dpp %6, %13, %13" TSFA_ENTB_DPP
+        "v_and_b32_dpp %7, %14, %14" TSFA_ENTB_DPP
+        "v_and_b32_dpp %8, %15, %15" TSFA_ENTB_DPP
+        "v_bcnt_u32_b32 %0, %2, %0\n\t"
+        "v_bcnt_u32_b32 %0, %3, %0\n\t"
+        "v_bcnt_u32_b32 %0, %4, %0\n\t"
+        "v_bcnt_u32_b32 %0, %5, %0\n\t"
+        "v_bcnt_u32_b32 %0, %6, %0\n\t"
+        "v_bcnt_u32_b32 %0, %7, %0\n\t"
+        "v_bcnt_u32_b32 %0, %8, %0\n\t"
+        "v_and_b32_dpp %2, %2, %2" TSFA_ENTB_DPP
+        "v_and_b32_dpp %3, %3, %3" TSFA_ENTB_DPP
+        "v_and_b32_dpp %4, %4, %4" TSFA_ENTB_DPP
+        "v_and_b32_dpp %5, %5, %5" TSFA_ENTB_DPP
+        "v_and_b32_dpp %6, %6, %6" TSFA_ENTB_DPP
+        "v_and_b32_dpp %7, %7, %7" TSFA_ENTB_DPP
+        "v_and_b32_dpp %8, %8, %8" TSFA_ENTB_DPP
+        "v_bcnt_u32_b32 %1, %2, %1\n\t"
+        "v_bcnt_u32_b32 %1, %3, %1\n\t"
+        "v_bcnt_u32_b32 %1, %4, %1\n\t"
+        "v_bcnt_u32_b32 %1, %5, %1\n\t"
+        "v_bcnt_u32_b32 %1, %6, %1\n\t"
+        "v_bcnt_u32_b32 %1, %7, %1\n\t"
+        "v_bcnt_u32_b32 %1, %8, %1"
+        : "+v"(c2), "+v"(c3), "=&v"(m[0]), "=&v"(m[1]), "=&v"(m[2]), "=&v"(m[3]), "=&v"(m[4]), "=&v"(m[5]), "=&v"(m[6])
+        : "v"(e[0]), "v"(e[1]), "v"(e[2]), "v"(e[3]), "v"(e[4]), "v"(e[5]), "v"(e[6]));
+#else
+#error "write the DPP block for this TSFA_ENTB_QW"
+#endif
     return c2 | (c3 << 16);
 }
 #endif
@@ -323,7 +388,7 @@ TSFA_DEV void entropy_bits_batch(const Blk &b_in, const double *xs, int n, const
     const int nrow_m = n - 1, nrow_m1 = n - 2;
     const int NW = (n + 32) >> 5;  // row words: at least one zero guard column
     const int nparts = (NW + QW - 1) / QW;
-    const int nstrips = (nrow_m + TSFA_ENTB_STRIP - 1) / TSFA_ENTB_STRIP;
+    const int nstrips = ((nrow_m + TSFA_ENTB_STRIP - 1) / TSFA_ENTB_STRIP + 1) / 2;  // pairs of half-strips
     unsigned int *rng = work + 2 * (size_t)next_pow2(n);  // behind the sorted copy
     unsigned int *table = work;
     unsigned int *wtot = work + (size_t)(n + 1) * S;
@@ -344,7 +409,8 @@ TSFA_DEV void entropy_bits_batch(const Blk &b_in, const double *xs, int n, const
         const int kn = (nk - k0 < kround) ? (nk - k0) : kround;
         const int ntask = nstrips * kn;
         unsigned int rl[TSFA_ENTB_MAXT], rh[TSFA_ENTB_MAXT], ct[TSFA_ENTB_MAXT];
-        const unsigned int lane_off = tbase + 4u * (unsigned int)(lane >> 5), sh = (unsigned int)(lane & 31);
+        const unsigned int lane_off = tbase, sh = (unsigned int)(lane & 31);
+        const int lane_row = (lane >> 5) * TSFA_ENTB_STRIP + (lane & 31);  // template of the lane within its pair of half-strips
         const unsigned int kmagic = 65536u / (unsigned int)kn + 1u;  // id / kn == (id * kmagic) >> 16 for id < 10 000
         if (k0 > 0) {  // the ranges were overwritten by the table of the previous round
             blk_sync();
@@ -358,7 +424,7 @@ TSFA_DEV void entropy_bits_batch(const Blk &b_in, const double *xs, int n, const
             ct[tt] = 0u;
             if (id < ntask) {
                 const int s = (int)(((unsigned int)id * kmagic) >> 16), k = k0 + (id - s * kn);
-                const int i = s * TSFA_ENTB_STRIP + lane;
+                const int i = s * (2 * TSFA_ENTB_STRIP) + lane_row;
                 const unsigned int r = (i < n) ? rng[k * n + i] : 0u;
                 rl[tt] = lane_off + 4u * (r & 0xFFFFu);
                 rh[tt] = lane_off + 4u * (r >> 16);
@@ -391,8 +457,8 @@ TSFA_DEV void entropy_bits_batch(const Blk &b_in, const double *xs, int n, const
             const int id = wave + tt * nw;
             if (id < ntask) {
                 const int s = (int)(((unsigned int)id * kmagic) >> 16), k = k0 + (id - s * kn);
-                const int i = s * TSFA_ENTB_STRIP + lane;
-                if (lane < TSFA_ENTB_STRIP && i < nrow_m) cnt[k * n + i] = ct[tt];
+                const int i = s * (2 * TSFA_ENTB_STRIP) + lane_row;
+                if ((lane & 31) < TSFA_ENTB_STRIP && i < nrow_m) cnt[k * n + i] = ct[tt];
             }
         }
         blk_sync();
@@ -411,8 +477,9 @@ TSFA_DEV void entropy_bits_batch(const Blk &b_in, const double *xs, int n, const
                 for (int s = 0; s < nstrips; ++s) {
                     unsigned int e[66][TSFA_ENTB_QW], m2[66][TSFA_ENTB_QW];
                     for (int l = 0; l < 64; ++l) {
-                        const unsigned int r = rg[k * (TSFA_ENTB_MAXN + 64) + s * TSFA_ENTB_STRIP + l];
-                        const unsigned int *pl = table + (r & 0xFFFFu) + (l >> 5), *ph = table + (r >> 16) + (l >> 5);
+                        const int row = s * (2 * TSFA_ENTB_STRIP) + (l >> 5) * TSFA_ENTB_STRIP + (l & 31);
+                        const unsigned int r = rg[k * (TSFA_ENTB_MAXN + 64) + row];
+                        const unsigned int *pl = table + (r & 0xFFFFu), *ph = table + (r >> 16);
                         const unsigned int sh = (unsigned int)(l & 31);
                         for (int t = 0; t < QW; ++t) {
                             const unsigned long long two = ((unsigned long long)(ph[t + 1] ^ pl[t + 1]) << 32) | (ph[t] ^ pl[t]);
@@ -422,13 +489,15 @@ TSFA_DEV void entropy_bits_batch(const Blk &b_in, const double *xs, int n, const
                     for (int t = 0; t < QW; ++t) { e[64][t] = 0u; m2[64][t] = m2[65][t] = 0u; }
                     for (int l = 0; l < 64; ++l)
                         for (int t = 0; t < QW; ++t) m2[l][t] = e[l][t] & e[l + 1][t];
-                    for (int l = 0; l < TSFA_ENTB_STRIP; ++l) {
+                    for (int l = 0; l < 64; ++l) {
+                        if ((l & 31) >= TSFA_ENTB_STRIP) continue;
+                        const int row = s * (2 * TSFA_ENTB_STRIP) + (l >> 5) * TSFA_ENTB_STRIP + (l & 31);
                         unsigned int c2 = 0u, c3 = 0u;
                         for (int t = 0; t < nq; ++t) {
                             c2 += (unsigned int)__builtin_popcount(m2[l][t]);
                             c3 += (unsigned int)__builtin_popcount(m2[l][t] & m2[l + 1][t]);
                         }
-                        ct[k * (TSFA_ENTB_MAXN + 64) + s * TSFA_ENTB_STRIP + l] += c2 | (c3 << 16);
+                        ct[k * (TSFA_ENTB_MAXN + 64) + row] += c2 | (c3 << 16);
                     }
                 }
             }

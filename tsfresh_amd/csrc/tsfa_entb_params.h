@@ -10,10 +10,10 @@
 #endif
 
 #define TSFA_ENTB_QW 11                   // diagonal words per column part
-#define TSFA_ENTB_S (TSFA_ENTB_QW + 2)    // words per table entry (two halo words: the rotation by up to 63 bits)
-#define TSFA_ENTB_MAXT 13                 // tasks (strip x tolerance) per wavefront: register-resident ranges + counters
+#define TSFA_ENTB_S (TSFA_ENTB_QW + 1)    // words per table entry (one halo word: the rotation by up to 31 bits); 48 B: three ds_read_b128
+#define TSFA_ENTB_MAXT 14                 // tasks (strip x tolerance) per wavefront: register-resident ranges + counters
 #define TSFA_ENTB_MAXK 6                  // tolerances per batch
-#define TSFA_ENTB_STRIP 62                // templates per strip (64 lanes, two halo lanes)
+#define TSFA_ENTB_STRIP 30                // templates per half-strip (32 lanes, two halo lanes); a wavefront sweeps two
 #define TSFA_ENTB_MAXN 1024
 #define TSFA_ENTB_MAXWAVES 16
 
@@ -32,7 +32,7 @@ static inline TSFA_ENTB_HD size_t entb_work_words(int maxn) {
 
 // wavefronts per workgroup for series of up to maxn samples, tolerances nk: every (strip, tolerance) task in registers
 static inline TSFA_ENTB_HD int entb_waves_for(int maxn, int nk) {
-    const int nstrips = (maxn - 1 + TSFA_ENTB_STRIP - 1) / TSFA_ENTB_STRIP;
+    const int nstrips = ((maxn - 1 + TSFA_ENTB_STRIP - 1) / TSFA_ENTB_STRIP + 1) / 2;  // pairs of half-strips
     if (nk > TSFA_ENTB_MAXK) nk = TSFA_ENTB_MAXK;
     const int need = (nstrips * nk + TSFA_ENTB_MAXT - 1) / TSFA_ENTB_MAXT;
     int w = 1;
