@@ -544,6 +544,81 @@ TSFA_DEV void entropy_bits_batch(const Blk &b_in, const double *xs, int n, const
     TSFA_TICK(tk, b, 134);
 }
 
+#if TSFA_GPU
+// ---------------------------------------------------------------------------------------------------------------
+// Sort of the n samples (float32 values: one packed 48-bit key = ordered value bits | index), E = np2 / nt keys per
+// thread.  Every wavefront sorts its 64 E keys with the bitonic network in registers / across lanes (no barrier); the
+// sorted runs are then merged pairwise by RANKING: a key's position in the merged run = its offset in its own run +
+// the number of smaller keys in the sibling run (bisection in LDS; "smaller or equal" for the right-hand run, so equal
+// padding keys keep distinct places).  log2(nt / 64) barriers instead of two per cross-wavefront bitonic stage, and a
+// merge level costs log2(run) dependent LDS reads instead of log2(run) + 1 compare-exchange stages.
+// buf: 2 * np2 64-bit words of LDS.  Result: perm[0 .. np2) = indices in sorted order (0xFFFF beyond n).
+// ---------------------------------------------------------------------------------------------------------------
+template <int E>
+TSFA_DEVN void entb_sort_merge(const Blk b, const double *xs, int n, unsigned short *perm, unsigned long long *buf) {
+    const int np2 = E * b.nt;
+    const int g0 = b.tid * E;
+    unsigned long long pk[E];
+#pragma unroll
+    for (int e = 0; e < E; ++e) {
+        const int g = g0 + e;
+        pk[e] = (g < n) ? sort_pack_f32((float)xs[g], g) : sort_pack_f32((float)TSFA_INF, 0xFFFF);
+    }
+    const int W = 64 * E;  // keys per wavefront
+    for (int k = 2; k <= W; k <<= 1) {
+        const int kdir = (k == W) ? (1 << 30) : k;  // the last in-wavefront merge sorts every run ascending
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            if (j < E) {
+                switch (j) {
+                case 1: if (E > 1) sortp_stage_regs<E, (E > 1 ? 1 : 0)>(pk, g0, kdir); break;
+                case 2: if (E > 2) sortp_stage_regs<E, (E > 2 ? 2 : 0)>(pk, g0, kdir); break;
+                default: break;
+                }
+            } else {
+                switch (j / E) {
+                case 1: sortp_stage_lanes<E, 1>(pk, g0, kdir, j); break;
+                case 2: sortp_stage_lanes<E, 2>(pk, g0, kdir, j); break;
+                case 4: sortp_stage_lanes<E, 4>(pk, g0, kdir, j); break;
+                case 8: sortp_stage_lanes<E, 8>(pk, g0, kdir, j); break;
+                case 16: sortp_stage_lanes<E, 16>(pk, g0, kdir, j); break;
+                default: sortp_stage_lanes<E, 32>(pk, g0, kdir, j); break;
+                }
+            }
+        }
+    }
+    unsigned long long *src = buf, *dst = buf + np2;
+    if (np2 > W) {
+        blk_sync();
+#pragma unroll
+        for (int e = 0; e < E; ++e) src[g0 + e] = pk[e];
+        blk_sync();
+        int lr = 6;
+        while ((1 << lr) < W) ++lr;
+        for (int R = W; R < np2; R <<= 1, ++lr) {
+#pragma unroll
+            for (int e = 0; e < E; ++e) {
+                const int pos = g0 + e;
+                const int run = pos >> lr, o = pos & (R - 1);
+                const unsigned long long *sib = src + ((run ^ 1) << lr);
+                const unsigned long long key = pk[e] + (unsigned long long)(run & 1);  // right-hand run: count <=
+                int cnt = 0;
+                for (int step = R >> 1; step >= 1; step >>= 1) cnt += (sib[cnt + step - 1] < key) ? step : 0;
+                cnt += (sib[cnt] < key) ? 1 : 0;
+                dst[((run >> 1) << (lr + 1)) + o + cnt] = pk[e];
+            }
+            blk_sync();
+#pragma unroll
+            for (int e = 0; e < E; ++e) pk[e] = dst[g0 + e];
+            unsigned long long *t = src; src = dst; dst = t;
+        }
+    }
+    blk_sync();
+#pragma unroll
+    for (int e = 0; e < E; ++e) perm[g0 + e] = (unsigned short)(pk[e] & 0xFFFFull);
+    blk_sync();
+}
+#endif
+
 // The ENTROPY specs of one series by the bit-matrix sweep (every spec has m = 2; 3 <= n <= TSFA_ENTB_MAXN is decided
 // on the host, shorter series take the closed forms below).  xs: n + 4 doubles; thr: >= 56 doubles; perm:
 // next_pow2(n) + 32 entries; work: entb_work_words(maxn) words (may alias b.np: the numpy-order sums finish first).
@@ -558,7 +633,17 @@ TSFA_DEV void fam_entropy_series_bits(const Blk &b, double *xs, int n, const Tsf
     blk_sync();
     TSFA_TICK(tk, b, 130);
     if (n >= 3) {
-        entropy_sort_templates(b, xs, n + 1, perm, next_pow2(n), F32);  // all n samples (a "template" per sample)
+        const int np2 = next_pow2(n);
+        bool sorted = false;
+#if TSFA_GPU
+        if (F32 && b.nt >= 64) {  // wavefront-local bitonic sort + merge by ranking (work: 2 * np2 64-bit words)
+            unsigned long long *buf = (unsigned long long *)(void *)work;
+            if (np2 == b.nt) { entb_sort_merge<1>(b, xs, n, perm, buf); sorted = true; }
+            else if (np2 == 2 * b.nt) { entb_sort_merge<2>(b, xs, n, perm, buf); sorted = true; }
+            else if (np2 == 4 * b.nt) { entb_sort_merge<4>(b, xs, n, perm, buf); sorted = true; }
+        }
+#endif
+        if (!sorted) entropy_sort_templates(b, xs, n + 1, perm, np2, F32);  // all n samples (a "template" per sample)
         TSFA_TICK(tk, b, 131);
     }
     double *racc = thr + TSFA_ENTB_MAXK;

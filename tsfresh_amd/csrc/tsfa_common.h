@@ -593,7 +593,7 @@ TSFA_DEV void sort_stage_regs(double (&key)[E], int (&idx)[E], int g0, int k) {
 }
 
 // value held by lane (lane ^ LX).  LX = 1, 2: DPP quad_perm (VALU rate, no LDS pipe); LX = 16, 32: the gfx950 row /
-// half swaps v_permlane16_swap / v_permlane32_swap; LX = 4, 8: ds_bpermute through __shfl_xor.
+// half swaps v_permlane16_swap / v_permlane32_swap; LX = 8: row_ror:8; LX = 4: two bank-masked row shifts.
 template <int LX>
 TSFA_DEV int lane_xor_i32(int v) {
     if (LX == 1) return __builtin_amdgcn_update_dpp(v, v, TSFA_DPP_QUAD_XOR1, 0xf, 0xf, false);
@@ -605,6 +605,11 @@ TSFA_DEV int lane_xor_i32(int v) {
     if (LX == 32) {
         const auto r = __builtin_amdgcn_permlane32_swap(v, v, false, false);
         return ((threadIdx.x >> 5) & 1) ? (int)r[0] : (int)r[1];
+    }
+    if (LX == 8) return __builtin_amdgcn_update_dpp(v, v, 0x128 /* row_ror:8 */, 0xf, 0xf, false);
+    if (LX == 4) {  // lanes 0-3 / 8-11 of a row take from lane + 4, lanes 4-7 / 12-15 from lane - 4
+        const int t = __builtin_amdgcn_update_dpp(v, v, 0x104 /* row_shl:4 */, 0xf, 0x5, false);
+        return __builtin_amdgcn_update_dpp(t, v, 0x114 /* row_shr:4 */, 0xf, 0xa, false);
     }
     return __shfl_xor(v, LX);
 }
