@@ -300,12 +300,19 @@ def main():
             # algorithmic bytes per series = 4*L read (each sample once) + 8 bytes per column written
             alg_bytes = n * (4 * L + 8 * cols_dom)
             achieved = alg_bytes / (kt[dom] * 1e-3) / 1e9
-            roof = {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            # the entropy family runs as k_entropy_bits for series up to 1024 samples (fam_entropy_bits.h), as k_entropy beyond
+            kname = dom
+            if dom == "k_entropy" and L <= 1024 and not args.ragged and not os.environ.get("TSFA_ENT_PAIRS"):
+                kname = "k_entropy_bits"
+            notes = {"k_entropy_bits": "sorted ranges + bit-matrix sweep of all template pairs: VALU / LDS-issue bound, not "
+                                       "HBM-bound (DESIGN.md roofline section)",
+                     "k_entropy": "O(L^2) template-pair sweep: VALU(fp64)-bound, not HBM-bound (DESIGN.md roofline section)"}
+            roof = {"bound": "hbm", "kernel": kname, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": achieved / HBM_PEAK_GBS,
-                    "traffic": measured_hbm_traffic(dom, {"n_series_per_gpu": n, "length": L, "n_cols": n_cols}),
+                    "traffic": measured_hbm_traffic(kname, {"n_series_per_gpu": n, "length": L, "n_cols": n_cols}),
                     "kernel_ms": kt[dom],
                     "algorithmic_bytes_per_launch": alg_bytes,
-                    "note": "O(L^2) template-pair sweep: VALU(fp64)-bound, not HBM-bound (DESIGN.md roofline section)"}
+                    "note": notes.get(kname, "compute-side bound: see DESIGN.md roofline section")}
         line = {
             "metric": "series/sec (ComprehensiveFCParameters, len=1024)" if args.params == "comprehensive" and L == 1024
                       else "series/sec (%s, %s)" % (args.params, ("ragged len %s" % args.ragged) if args.ragged else "len=%d" % L),

@@ -614,3 +614,44 @@ def test_order_statistics_by_selection_equal_numpy(gpu, dtype, monkeypatch):
         assert got[i, names.index("value__median")] == np.median(x)
         for q in (0.1, 0.4, 0.9, 0.0, 1.0, 0.5):
             assert got[i, names.index("value__quantile__q_%s" % q)] == np.quantile(x, q), (i, len(x), q)
+
+
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+def test_entropy_bit_matrix_sweep_equals_the_pair_sweep_and_the_oracle(gpu, dtype, monkeypatch):
+    """k_entropy_bits (sorted ranges + prefix bit sets, fam_entropy_bits.h) counts the same neighbours as the float64
+    pair sweep of k_entropy (TSFA_ENT_PAIRS=1): the counts are integers, so the six columns agree to the rounding of the
+    log sums -- on every length 1 ... 1024 around the strip / word / part boundaries (30, 32, 60, 352, 1023, 1024 ...),
+    with ties, constant runs, two-valued and heavy-tailed series, tolerances given by the caller, and against the
+    oracle (feature_calculators.py:1701-1805)."""
+    rng = np.random.default_rng(77)
+    lens = [1, 2, 3, 4, 5, 29, 30, 31, 32, 33, 59, 60, 61, 62, 63, 64, 65, 95, 96, 97, 127, 128, 129, 255, 256, 257, 351, 352,
+            353, 383, 384, 511, 512, 513, 703, 704, 705, 1000, 1022, 1023, 1024]
+    chunks = []
+    for i, n in enumerate(lens):
+        kind = i % 6
+        if kind == 0: x = rng.standard_normal(n)
+        elif kind == 1: x = np.round(rng.standard_normal(n) * 3)                 # heavy ties
+        elif kind == 2: x = np.cumsum(rng.standard_normal(n))
+        elif kind == 3: x = rng.choice([-1.0, 2.5], size=n)                       # two-valued
+        elif kind == 4: x = rng.standard_t(1.5, size=n)                           # heavy tails
+        else: x = np.r_[np.full(n // 2, 0.25), rng.standard_normal(n - n // 2)]   # constant run + noise
+        chunks.append(x.astype(dtype))
+    for n in (1024, 1024, 1024, 777):
+        chunks.append(rng.standard_normal(n).astype(dtype))
+    chunks.append(np.zeros(100, dtype))
+    chunks.append(np.arange(1024, dtype=dtype))
+    values = np.concatenate(chunks)
+    offsets = np.concatenate([[0], np.cumsum([len(c) for c in chunks])]).astype(np.int64)
+    params = {"sample_entropy": None,
+              "approximate_entropy": [{"m": 2, "r": r} for r in (0.1, 0.3, 0.5, 0.7, 0.9, 0.05, 1.7, 0.0)]}  # 9 specs: two batches
+    names, bits = hip_engine(params, values, offsets)
+    monkeypatch.setenv("TSFA_ENT_PAIRS", "1")
+    names2, pairs = hip_engine(params, values, offsets)
+    monkeypatch.delenv("TSFA_ENT_PAIRS")
+    assert names == names2
+    assert np.array_equal(np.isnan(bits), np.isnan(pairs)) and np.array_equal(np.isinf(bits), np.isinf(pairs))
+    ok = np.isfinite(bits)
+    assert np.allclose(bits[ok], pairs[ok], rtol=1e-12, atol=1e-13), np.abs(bits[ok] - pairs[ok]).max()
+    onames, want = oracle_engine(params, values.astype(np.float64), offsets)
+    bad = compare(onames, _align(onames, names, bits), want, _series(values.astype(np.float64), offsets))
+    assert not bad, "%d mismatches, first: %s" % (len(bad), bad[:12])
