@@ -38,6 +38,8 @@ can bound it.
       (scipy's sqrt((1 - r^2) ...) cancels).
   R9  partial_autocorrelation from the lag at which the Levinson-Durbin innovation variance has dropped below
       1e-9 * acov[0] (an exactly predictable series: periodic, linear): the next coefficient divides by round-off.
+  R10 fourier_entropy when a normalised Welch density lies on an edge of np.histogram's bins up to round-off (exactly
+      periodic series: a Hann-leaked bin of exactly 1/4 of the peak sits on the edge 0.25 of 100 bins).
   R8  number_cwt_peaks when a CWT row has two neighbouring values on top of a hump that are equal up to round-off
       (1e-12 of the row's magnitude; symmetric integer-valued or periodic data): which one is the STRICT relative
       maximum that starts a ridge line depends on the summation order of scipy's convolution.
@@ -150,6 +152,30 @@ def _cwt_peaks_ambiguous(x, n):
     return False
 
 
+def _psd_on_bin_edge(x, bins):
+    """fourier_entropy (feature_calculators.py:2216): binned_entropy(pxx / max(pxx), bins) -- is a value within round-off
+    of an interior edge of np.histogram(., bins)?"""
+    from scipy.signal import welch
+    if len(x) < 2:
+        return False
+    _, pxx = welch(x, nperseg=min(len(x), 256))
+    if not np.all(np.isfinite(pxx)) or np.max(pxx) <= 0:
+        return False
+    v = pxx / np.max(pxx)
+    edges = np.histogram_bin_edges(v, bins=bins)[1:-1]
+    if len(edges) == 0:
+        return False
+    d = np.abs(v[:, None] - edges[None, :]).min()
+    return bool(d < 1e-9)
+
+
+def _r_of_chunks(agg):
+    agg = np.asarray(agg, dtype=np.float64)
+    if len(agg) < 3 or np.ptp(agg) == 0 or not np.all(np.isfinite(agg)):
+        return None
+    return float(np.corrcoef(np.arange(len(agg), dtype=np.float64), agg)[0, 1])
+
+
 def _r2_cancels(rvalue):
     # two-point fits are exact (r = +-1, stderr = 0 by scipy's special case) and stay compared
     return rvalue is not None and np.isfinite(rvalue) and 1.0 - rvalue * rvalue < 1e-9
@@ -201,7 +227,12 @@ def excluded(col, x, simd_golden=False, facts=None, rvalue=None):
     if f == "permutation_entropy":
         return simd_golden and _has_window_ties(xv, _param(col, "dimension", int))                       # R1
     if f in ("fourier_entropy", "spkt_welch_density"):
-        return len(xv) > 0 and np.ptp(xv) == 0                                                           # R3
+        if len(xv) > 0 and np.ptp(xv) == 0:
+            return True                                                                                   # R3
+        if f == "fourier_entropy":
+            bins = _param(col, "bins", int)
+            return facts.get(("fe_edge", bins), lambda: _psd_on_bin_edge(xv, bins))                      # R10
+        return False
     if f == "ar_coefficient":
         k = _param(col, "k", int)
         X = facts.get(("ar", k), lambda: _ar_design(xv, k))
@@ -219,8 +250,12 @@ def excluded(col, x, simd_golden=False, facts=None, rvalue=None):
         agg = facts.get(("agg", f_agg, cl), lambda: _chunk_aggs(xv, f_agg, cl))
         if attr != "intercept" and len(agg) > 1 and 0 < np.ptp(agg) <= 1e-12 * np.max(np.abs(agg)):
             return True                                                                                   # R7
+        if attr == "stderr" and len(agg) > 2 and rvalue is None:  # the plan does not hold the sibling column
+            rvalue = _r_of_chunks(agg)
         return attr == "stderr" and len(agg) > 2 and _r2_cancels(rvalue)
     if f == "linear_trend":
+        if 'attr_"stderr"' in col and len(xv) > 2 and rvalue is None:
+            rvalue = _r_of_chunks(xv)
         return 'attr_"stderr"' in col and len(xv) > 2 and _r2_cancels(rvalue)
     if f == "partial_autocorrelation":
         return _param(col, "lag", int) >= facts.get("pacf", lambda: _pacf_noise_lag(xv))                   # R9
