@@ -313,10 +313,12 @@ __device__ __forceinline__ K os_select(const K (&key)[E], int k) {
 #pragma unroll 1
     for (int bit = BITS - 1; bit >= 0; --bit) {
         const K cand = prefix | ((K)1 << bit);
+        // the count of a wavefront-wide predicate is the popcount of its compare mask: one v_cmp per register, the
+        // rest on the scalar ALU (no per-lane counters, no cross-lane sum)
         int c = 0;
 #pragma unroll
-        for (int e = 0; e < E; ++e) c += (key[e] < cand) ? 1 : 0;
-        if (wave_sum_i32(c) <= k) prefix = cand;
+        for (int e = 0; e < E; ++e) c += __popcll(__ballot(key[e] < cand));
+        if (c <= k) prefix = cand;
     }
     return prefix;
 }
@@ -354,10 +356,9 @@ __global__ void __launch_bounds__(256) k_order_stats(const T *__restrict__ value
         K nxt = KC::maxkey();
 #pragma unroll
         for (int e = 0; e < E; ++e) {
-            cle += (key[e] <= kk) ? 1 : 0;
+            cle += __popcll(__ballot(key[e] <= kk));
             if (key[e] > kk && key[e] < nxt) nxt = key[e];
         }
-        cle = wave_sum_i32(cle);
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) {
             const K t = (K)__shfl_xor(nxt, o);
