@@ -345,6 +345,10 @@ TSFA_DEV double np_leaf_sum(int o, int l, F f) {
     return res;
 }
 
+#if TSFA_GPU
+template <int LX>
+TSFA_DEV double lane_xor_f64(double v);  // defined with the sorting networks below
+#endif
 template <class F>
 TSFA_DEV double np_sum(const Blk &b, int n, F f) {
     NpScratch *s = b.np;
@@ -375,6 +379,40 @@ TSFA_DEV double np_sum(const Blk &b, int n, F f) {
                 }
                 const bool ok = (lane >= nl) || (ll <= 128 && (d == 0 || lp > 128));
                 complete = (__ballot(ok) == ~0ull);
+            }
+            if (complete && nl <= 8) {
+                // up to 8 leaves (n <= 1024): 8 leaves x 8 accumulators = the 64 lanes of ONE wavefront.  Every wavefront
+                // evaluates the whole tree on its own -- no LDS exchange, no barrier (three per call otherwise); the
+                // additions and their order are those of the general path.
+                const int leaf = lane >> 3, k = lane & 7;
+                const bool live = leaf < nl;
+                const int o = __shfl(lo, leaf), l = live ? __shfl(ll, leaf) : 0;
+                double r = 0.0;
+                if (l >= 8) {
+                    const int lim = l - (l % 8);
+                    r = f(o + k);
+                    for (int i = 8; i < lim; i += 8) r += f(o + i + k);
+                }
+                r += dpp_mov_f64<TSFA_DPP_QUAD_XOR1>(r);
+                r += dpp_mov_f64<TSFA_DPP_QUAD_XOR2>(r);
+                r += dpp_mov_f64<TSFA_DPP_ROW_HALF_MIRROR>(r);
+                if (live && k == 0) {
+                    if (l < 8) {
+                        r = 0.0;
+                        for (int i = 0; i < l; ++i) r += f(o + i);
+                    } else {
+                        for (int i = l - (l % 8); i < l; ++i) r += f(o + i);
+                    }
+                }
+                // leaf sums sit in lanes 0, 8, 16, ...: the recursion's pairwise order is a butterfly over lane bits 3, 4, 5
+                double v = live ? r : 0.0;
+                if (nl > 1) v = v + lane_xor_f64<8>(v);
+                if (nl > 2) v = v + lane_xor_f64<16>(v);
+                if (nl > 4) v = v + lane_xor_f64<32>(v);
+                const double chunk = readlane_f64(v, 0);
+                total = (c0 == 0) ? chunk : (total + chunk);
+                if (c0 + 8192 >= n) return total;
+                continue;
             }
             if (complete) {
                 for (int u0 = 0; u0 < nl * 8; u0 += b.nt) {
