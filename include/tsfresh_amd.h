@@ -167,6 +167,18 @@ int tsfa_pack_offsets(int64_t *offsets, int64_t n_groups, int64_t n_rows);
 int tsfa_host_alloc(void **ptr, size_t bytes);
 int tsfa_host_free(void *ptr);
 
+/* Device-resident matrices: the chain extract -> impute -> select (tsfresh/convenience/relevant_extraction.py:18,
+ * SURVEY.md 8f N3) hands a float64 [n_ids x n_features] matrix from step to step.  tsfa_extract, tsfa_impute and
+ * tsfa_relevance_* accept TSFA_DEVICE pointers; with the four entry points below a host in any language keeps that
+ * matrix in HBM for the whole chain and fetches only the selected columns (the reference's `X.loc[:, relevant]`,
+ * feature_selection/selection.py:181).  tsfa_device_copy: to_device != 0 copies host -> device, else device -> host.
+ * tsfa_gather_columns: out_host[r * n_sel + c] = X[r * ld + cols[c]]. */
+int tsfa_device_alloc(void **ptr, size_t bytes, int32_t device);
+int tsfa_device_free(void *ptr, int32_t device);
+int tsfa_device_copy(void *dst, const void *src, size_t bytes, int32_t to_device, int32_t device);
+int tsfa_gather_columns(const double *X, int64_t n_rows, int64_t ld, const int32_t *cols, int64_t n_sel, double *out_host,
+                        int32_t device);
+
 /* ---- feature selection: relevance statistics of the extracted matrix ----
  * Replaces the per-feature loop of tsfresh/feature_selection/relevance.py:214-322 (calculate_relevance_table ->
  * _calculate_relevance_table_for_implicit_target) for classification targets: one call yields, for EVERY column of

@@ -655,3 +655,34 @@ def test_entropy_bit_matrix_sweep_equals_the_pair_sweep_and_the_oracle(gpu, dtyp
     onames, want = oracle_engine(params, values.astype(np.float64), offsets)
     bad = compare(onames, _align(onames, names, bits), want, _series(values.astype(np.float64), offsets))
     assert not bad, "%d mismatches, first: %s" % (len(bad), bad[:12])
+
+
+def test_device_output_with_a_leading_dimension_leaves_the_other_cells_alone(gpu):
+    """tsfa_extract(TSFA_DEVICE, out, ld > n_cols) writes (and NaN-initialises) only its own n_cols columns of every row:
+    column blocks of several plans share one device matrix (the device-resident extract -> impute -> select chain)."""
+    import ctypes
+
+    from tsfresh_amd import _native
+    from tsfresh_amd.feature_extraction.extraction import _acquire_plan
+    from tsfresh_amd.feature_extraction.plan import compile_fc_parameters
+    rng = np.random.default_rng(3)
+    lens = [50, 64, 10, 200, 33]
+    values = rng.standard_normal(sum(lens)).astype(np.float32)
+    offsets = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
+    fplan = compile_fc_parameters(settings.MinimalFCParameters())
+    plan = _acquire_plan(fplan, 0)
+    want = plan.extract_host(values, offsets)
+    n, m = want.shape
+    dm = _native.DeviceMatrix(n, m + 5, 0)
+    try:
+        sentinel = np.full((n, m + 5), -777.0)
+        lib = _native.load()
+        _native._check(lib, lib.tsfa_device_copy(ctypes.c_void_p(dm.ptr), sentinel.ctypes.data_as(ctypes.c_void_p),
+                                                 sentinel.nbytes, 1, 0))
+        plan.extract_into(values, offsets, dm, col0=2)
+        got = dm.to_host()
+        assert np.array_equal(got[:, 2:2 + m], want)
+        assert (got[:, :2] == -777.0).all() and (got[:, 2 + m:] == -777.0).all()
+        assert np.array_equal(dm.to_host([2 + m - 1, 2, 0]), np.c_[want[:, m - 1], want[:, 0], np.full(n, -777.0)])
+    finally:
+        dm.free()

@@ -290,3 +290,37 @@ def test_gpu_relevance_column_batches(monkeypatch):
         assert np.array_equal(u, v)
     for f in ar.dtype.names:
         assert np.array_equal(ar[f], br[f]), f
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("task", ["classification", "regression"])
+def test_device_resident_chain_equals_the_host_chain(gpu, task):
+    """extract_relevant_features(device_resident=True): the feature matrix stays in HBM from tsfa_extract through
+    tsfa_impute and tsfa_relevance_* and only the selected columns come back (tsfa_gather_columns) -- same frame as the
+    default chain (relevant_extraction.py:18: extract -> impute -> select), two kinds, NaN / inf cells for impute."""
+    from tsfresh_amd import EfficientFCParameters, extract_relevant_features
+    rng = np.random.default_rng(8)
+    n_ids = 120
+    frames = []
+    label = rng.integers(0, 2, n_ids)
+    for i in range(n_ids):
+        n = int(rng.integers(3, 40)) if i % 7 == 0 else int(rng.integers(60, 160))  # short series: NaN / inf features
+        shift = 0.8 * label[i]
+        frames.append(pd.DataFrame({"id": i, "t": np.arange(n), "a": rng.standard_normal(n) + shift,
+                                    "b": np.cumsum(rng.standard_normal(n)) * (1.0 + shift)}))
+    df = pd.concat(frames, ignore_index=True)
+    if task == "classification":
+        y = pd.Series(label, index=np.arange(n_ids))
+    else:
+        y = pd.Series(label * 1.5 + 0.3 * rng.standard_normal(n_ids), index=np.arange(n_ids))
+    params = EfficientFCParameters()
+    kw = dict(column_id="id", column_sort="t", default_fc_parameters=params, fdr_level=0.2)
+    want = extract_relevant_features(df, y, **kw)
+    got = extract_relevant_features(df, y, device_resident=True, **kw)
+    assert list(got.columns) == list(want.columns) and len(want.columns) > 5
+    assert list(got.index) == list(want.index) and got.index.dtype == want.index.dtype
+    assert np.array_equal(got.to_numpy(), want.to_numpy())
+    # and through X (the merge of the reference's signature)
+    Xin = pd.DataFrame({"extra": rng.standard_normal(n_ids)}, index=np.arange(n_ids))
+    got2 = extract_relevant_features(df, y, X=Xin, device_resident=True, **kw)
+    assert list(got2.columns) == ["extra"] + list(want.columns)

@@ -40,6 +40,10 @@ EXPORTS = (
     "tsfa_relevance_classes_ks",
     "tsfa_relevance_real",
     "tsfa_ks_outer_prob",
+    "tsfa_device_alloc",
+    "tsfa_device_free",
+    "tsfa_device_copy",
+    "tsfa_gather_columns",
 )
 
 
@@ -344,6 +348,39 @@ class Plan:
             ends.ctypes.data_as(ctypes.c_void_p), n, out.ctypes.data_as(ctypes.c_void_p), self.n_cols, TSFA_HOST, None))
         return out
 
+    def extract_into(self, values, offsets, matrix, col0=0, times=None):
+        """Host arrays in, columns [col0, col0 + n_cols) of the DeviceMatrix `matrix` out: the samples are copied to the
+        device once and the feature rows stay there (tsfa_extract / tsfa_extract_timed with TSFA_DEVICE pointers)."""
+        values = np.ascontiguousarray(values)
+        if values.dtype == np.float32:
+            dt = TSFA_F32
+        else:
+            values = np.ascontiguousarray(values, dtype=np.float64)
+            dt = TSFA_F64
+        offsets = np.ascontiguousarray(offsets, dtype=np.int64)
+        n_series = offsets.shape[0] - 1
+        if matrix.shape[0] != n_series or col0 < 0 or col0 + self.n_cols > matrix.shape[1]:
+            raise ValueError("the device matrix does not hold [n_series, col0 + n_cols] cells")
+        if n_series == 0 or self.n_cols == 0:
+            return
+        if values.size == 0:
+            raise ValueError("every series must hold at least one sample")
+        bufs = [_DeviceBuffer(self._lib, values, matrix.device), _DeviceBuffer(self._lib, offsets, matrix.device)]
+        try:
+            tptr = None
+            if times is not None:
+                times = np.ascontiguousarray(times, dtype=np.float64)
+                if times.shape != values.shape:
+                    raise ValueError("times must have one entry per sample")
+                bufs.append(_DeviceBuffer(self._lib, times, matrix.device))
+                tptr = ctypes.c_void_p(bufs[2].ptr)
+            _check(self._lib, self._lib.tsfa_extract_timed(
+                self._h, ctypes.c_void_p(bufs[0].ptr), dt, tptr, ctypes.c_void_p(bufs[1].ptr), n_series,
+                ctypes.c_void_p(matrix.ptr + 8 * col0), matrix.ld, TSFA_DEVICE, None))
+        finally:
+            for bf in bufs:
+                bf.free()
+
     def extract_device(self, values_ptr, dtype, offsets_ptr, n_series, out_ptr, ld_out, stream=None):
         """Raw device-pointer entry (ints): used with torch tensors (`.data_ptr()`) by bench.py / the sharded path."""
         _check(self._lib, self._lib.tsfa_extract(
@@ -351,14 +388,105 @@ class Plan:
             ctypes.c_void_p(out_ptr), int(ld_out), TSFA_DEVICE, ctypes.c_void_p(stream) if stream else None))
 
 
+class DeviceMatrix:
+    """Row-major float64 [n_rows, n_cols] in the HBM of one device (tsfa_device_alloc): the feature matrix of the chain
+    extract -> impute -> select when it never leaves the GPU (convenience.extract_relevant_features(device_resident=True)).
+    Owns its memory; `to_host(cols)` fetches the named column indices (tsfa_gather_columns) or everything."""
+
+    def __init__(self, n_rows, n_cols, device=0):
+        self._lib = load()
+        self.shape = (int(n_rows), int(n_cols))
+        self.device = int(device)
+        self._ptr = ctypes.c_void_p()
+        _bind_device_api(self._lib)
+        _check(self._lib, self._lib.tsfa_device_alloc(ctypes.byref(self._ptr), max(1, 8 * self.shape[0] * self.shape[1]),
+                                                      self.device))
+
+    @property
+    def ptr(self):
+        return self._ptr.value
+
+    @property
+    def ld(self):
+        return self.shape[1]
+
+    def free(self):
+        if getattr(self, "_ptr", None) is not None and self._ptr.value:
+            self._lib.tsfa_device_free(self._ptr, self.device)
+            self._ptr = ctypes.c_void_p()
+
+    def __del__(self):
+        import sys
+        if sys is not None and not sys.is_finalizing():
+            try:
+                self.free()
+            except Exception:
+                pass
+
+    def to_host(self, cols=None):
+        n, m = self.shape
+        if cols is None:
+            out = np.empty((n, m), dtype=np.float64)
+            _check(self._lib, self._lib.tsfa_device_copy(out.ctypes.data_as(ctypes.c_void_p), self._ptr, out.nbytes, 0,
+                                                         self.device))
+            return out
+        cols = np.ascontiguousarray(cols, dtype=np.int32)
+        out = np.empty((n, cols.shape[0]), dtype=np.float64)
+        _check(self._lib, self._lib.tsfa_gather_columns(self._ptr, n, m, cols.ctypes.data_as(ctypes.c_void_p),
+                                                        cols.shape[0], out.ctypes.data_as(ctypes.c_void_p), self.device))
+        return out
+
+
+def _bind_device_api(lib):
+    if getattr(lib, "_tsfa_device_api_bound", False):
+        return
+    lib.tsfa_device_alloc.restype = ctypes.c_int32
+    lib.tsfa_device_alloc.argtypes = [ctypes.POINTER(ctypes.c_void_p), ctypes.c_size_t, ctypes.c_int32]
+    lib.tsfa_device_free.restype = ctypes.c_int32
+    lib.tsfa_device_free.argtypes = [ctypes.c_void_p, ctypes.c_int32]
+    lib.tsfa_device_copy.restype = ctypes.c_int32
+    lib.tsfa_device_copy.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int32, ctypes.c_int32]
+    lib.tsfa_gather_columns.restype = ctypes.c_int32
+    lib.tsfa_gather_columns.argtypes = [ctypes.c_void_p, ctypes.c_int64, ctypes.c_int64, ctypes.c_void_p, ctypes.c_int64,
+                                        ctypes.c_void_p, ctypes.c_int32]
+    lib._tsfa_device_api_bound = True
+
+
+class _DeviceBuffer:
+    """A transient device copy of a host array (inputs of Plan.extract_into)."""
+
+    def __init__(self, lib, array, device):
+        self._lib, self.device = lib, device
+        self._ptr = ctypes.c_void_p()
+        _bind_device_api(lib)
+        _check(lib, lib.tsfa_device_alloc(ctypes.byref(self._ptr), max(1, array.nbytes), device))
+        _check(lib, lib.tsfa_device_copy(self._ptr, array.ctypes.data_as(ctypes.c_void_p), array.nbytes, 1, device))
+
+    @property
+    def ptr(self):
+        return self._ptr.value
+
+    def free(self):
+        if self._ptr.value:
+            self._lib.tsfa_device_free(self._ptr, self.device)
+            self._ptr = ctypes.c_void_p()
+
+
+def _matrix_args(X):
+    """(pointer, n_rows, n_cols, ld, space, keepalive) of a host ndarray or a DeviceMatrix."""
+    if isinstance(X, DeviceMatrix):
+        return ctypes.c_void_p(X.ptr), X.shape[0], X.shape[1], X.ld, TSFA_DEVICE, X
+    X = np.ascontiguousarray(X, dtype=np.float64)
+    if X.ndim != 2:
+        raise ValueError("X must be two-dimensional")
+    return X.ctypes.data_as(ctypes.c_void_p), X.shape[0], X.shape[1], X.shape[1], TSFA_HOST, X
+
+
 def relevance_classes(X, y_codes, n_classes, device=0, with_ks=False):
     """Per-column relevance statistics of the row-major float64 matrix X against class codes (tsfa_relevance_classes).
     -> (n_unique int64[m], v_lo[m], v_hi[m], tie_term[m], rank_sums[m, C], hi_counts[m, C]) (+ ks_d[m, C] with_ks)."""
     lib = load()
-    X = np.ascontiguousarray(X, dtype=np.float64)
-    if X.ndim != 2:
-        raise ValueError("X must be two-dimensional")
-    n, m = X.shape
+    xptr, n, m, ld, space, _keep = _matrix_args(X)
     y_codes = np.ascontiguousarray(y_codes, dtype=np.int32)
     if y_codes.shape != (n,):
         raise ValueError("one class code per row")
@@ -373,12 +501,12 @@ def relevance_classes(X, y_codes, n_classes, device=0, with_ks=False):
         ks_d = np.zeros((m, n_classes), dtype=np.float64)
         lib.tsfa_relevance_classes_ks.restype = ctypes.c_int32
         lib.tsfa_relevance_classes_ks.argtypes = lib.tsfa_relevance_classes.argtypes + [ctypes.c_void_p]
-        _check(lib, lib.tsfa_relevance_classes_ks(X.ctypes.data_as(ctypes.c_void_p), n, m, m, TSFA_HOST,
+        _check(lib, lib.tsfa_relevance_classes_ks(xptr, n, m, ld, space,
                                                   y_codes.ctypes.data_as(ctypes.c_void_p), int(n_classes), int(device),
                                                   ctypes.cast(cols, ctypes.c_void_p), rank_sums.ctypes.data_as(ctypes.c_void_p),
                                                   hi_counts.ctypes.data_as(ctypes.c_void_p), ks_d.ctypes.data_as(ctypes.c_void_p)))
     else:
-        _check(lib, lib.tsfa_relevance_classes(X.ctypes.data_as(ctypes.c_void_p), n, m, m, TSFA_HOST,
+        _check(lib, lib.tsfa_relevance_classes(xptr, n, m, ld, space,
                                                y_codes.ctypes.data_as(ctypes.c_void_p), int(n_classes), int(device),
                                                ctypes.cast(cols, ctypes.c_void_p), rank_sums.ctypes.data_as(ctypes.c_void_p),
                                                hi_counts.ctypes.data_as(ctypes.c_void_p)))
@@ -395,8 +523,7 @@ def relevance_real(X, y, device=0):
     """Per-column statistics of the row-major float64 matrix X against a real-valued target (tsfa_relevance_real).
     -> (structured array with the fields of tsfa_relevance_real_col, dense ranks of y)."""
     lib = load()
-    X = np.ascontiguousarray(X, dtype=np.float64)
-    n, m = X.shape
+    xptr, n, m, ld, space, _keep = _matrix_args(X)
     y = np.ascontiguousarray(y, dtype=np.float64)
     if y.shape != (n,):
         raise ValueError("one target value per row")
@@ -412,7 +539,7 @@ def relevance_real(X, y, device=0):
     lib.tsfa_relevance_real.restype = ctypes.c_int32
     lib.tsfa_relevance_real.argtypes = [ctypes.c_void_p, ctypes.c_int64, ctypes.c_int64, ctypes.c_int64, ctypes.c_int32,
                                         ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int32, ctypes.c_void_p]
-    _check(lib, lib.tsfa_relevance_real(X.ctypes.data_as(ctypes.c_void_p), n, m, m, TSFA_HOST,
+    _check(lib, lib.tsfa_relevance_real(xptr, n, m, ld, space,
                                         y_rank.ctypes.data_as(ctypes.c_void_p), y_perm.ctypes.data_as(ctypes.c_void_p),
                                         y_end.ctypes.data_as(ctypes.c_void_p), int(device),
                                         cols.ctypes.data_as(ctypes.c_void_p)))
@@ -423,16 +550,21 @@ def impute_matrix(X, device=0):
     """In-place impute of the C-contiguous-row float64 matrix X on the device (tsfa_impute).
     -> (col_max, col_min, col_median of the finite values, number of finite cells per column)."""
     lib = load()
-    if not (isinstance(X, np.ndarray) and X.dtype == np.float64 and X.ndim == 2 and X.flags.writeable
-            and (X.shape[1] == 0 or X.strides[1] == 8) and X.strides[0] % 8 == 0 and X.strides[0] >= 8 * X.shape[1]):
-        raise ValueError("impute_matrix needs a writeable float64 matrix with contiguous rows")
-    n, m = X.shape
+    if isinstance(X, DeviceMatrix):
+        xptr, (n, m), ld, space = ctypes.c_void_p(X.ptr), X.shape, X.ld, TSFA_DEVICE
+        device = X.device
+    else:
+        if not (isinstance(X, np.ndarray) and X.dtype == np.float64 and X.ndim == 2 and X.flags.writeable
+                and (X.shape[1] == 0 or X.strides[1] == 8) and X.strides[0] % 8 == 0 and X.strides[0] >= 8 * X.shape[1]):
+            raise ValueError("impute_matrix needs a writeable float64 matrix with contiguous rows")
+        n, m = X.shape
+        xptr, ld, space = X.ctypes.data_as(ctypes.c_void_p), (X.strides[0] // 8 if n else m), TSFA_HOST
     cmax, cmin, cmed = (np.zeros(m) for _ in range(3))
     cnt = np.zeros(m, dtype=np.int32)
     lib.tsfa_impute.restype = ctypes.c_int32
     lib.tsfa_impute.argtypes = [ctypes.c_void_p, ctypes.c_int64, ctypes.c_int64, ctypes.c_int64, ctypes.c_int32, ctypes.c_int32,
                                 ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]
-    _check(lib, lib.tsfa_impute(X.ctypes.data_as(ctypes.c_void_p), n, m, X.strides[0] // 8 if n else m, TSFA_HOST, int(device),
+    _check(lib, lib.tsfa_impute(xptr, n, m, ld, space, int(device),
                                 cmax.ctypes.data_as(ctypes.c_void_p), cmin.ctypes.data_as(ctypes.c_void_p),
                                 cmed.ctypes.data_as(ctypes.c_void_p), cnt.ctypes.data_as(ctypes.c_void_p)))
     return cmax, cmin, cmed, cnt

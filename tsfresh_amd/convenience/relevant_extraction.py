@@ -34,8 +34,14 @@ def extract_relevant_features(timeseries_container, y, X=None, default_fc_parame
                               test_for_binary_target_binary_feature="fisher", test_for_binary_target_real_feature="mann",
                               test_for_real_target_binary_feature="mann", test_for_real_target_real_feature="kendall",
                               fdr_level=0.05, hypotheses_independent=False, n_jobs=None, distributor=None, chunksize=None,
-                              ml_task="auto", device=None):
-    """Arguments, checks and result of the reference (relevant_extraction.py:150-221)."""
+                              ml_task="auto", device=None, device_resident=False):
+    """Arguments, checks and result of the reference (relevant_extraction.py:150-221).
+
+    device_resident=True keeps the feature matrix in HBM for the whole chain: the kinds' feature blocks
+    are extracted into one device matrix (tsfa_extract with device pointers), imputed in place (tsfa_impute), ranked
+    against y (tsfa_relevance_*), and only the selected columns are fetched (tsfa_gather_columns) -- one PCIe crossing of
+    the samples in and of the relevant columns out, instead of the whole matrix out, in, out and in again.  The result
+    equals the default path's; every kind must hold the same ids (the reference joins the kinds on the id)."""
     assert isinstance(y, pd.Series), "y needs to be a pandas.Series, received type: {}.".format(type(y))
     assert len(set(y)) > 1, "Feature selection is only possible if more than 1 label/class is provided"
     if X is not None:
@@ -49,6 +55,14 @@ def extract_relevant_features(timeseries_container, y, X=None, default_fc_parame
         if len(ids_y - ids_container) > 0:
             raise ValueError("The following ids are in y but are missing inside the time series container: "
                              "{}".format(ids_y - ids_container))
+    if device_resident:
+        X_sel = _relevant_features_on_device(
+            timeseries_container, y, default_fc_parameters, kind_to_fc_parameters, column_id, column_sort, column_kind,
+            column_value, show_warnings, test_for_binary_target_real_feature, fdr_level, hypotheses_independent, ml_task,
+            device if device is not None else (distributor.device if distributor is not None else None))
+        if X is None:
+            return X_sel
+        return pd.merge(X, X_sel, left_index=True, right_index=True, how="left")
     X_ext = extract_features(timeseries_container, default_fc_parameters=default_fc_parameters,
                              kind_to_fc_parameters=kind_to_fc_parameters, show_warnings=show_warnings,
                              disable_progressbar=disable_progressbar, profile=profile, n_jobs=n_jobs, chunksize=chunksize,
@@ -63,3 +77,69 @@ def extract_relevant_features(timeseries_container, y, X=None, default_fc_parame
     if X is None:
         return X_sel
     return pd.merge(X, X_sel, left_index=True, right_index=True, how="left")
+
+
+def _relevant_features_on_device(container, y, default_fc_parameters, kind_to_fc_parameters, column_id, column_sort,
+                                 column_kind, column_value, show_warnings, test_for_binary_target_real_feature, fdr_level,
+                                 hypotheses_independent, ml_task, device):
+    import warnings
+
+    import numpy as np
+
+    from tsfresh_amd import _native
+    from tsfresh_amd.feature_extraction.data import pack_timeseries
+    from tsfresh_amd.feature_extraction.extraction import _acquire_plan, _default_device
+    from tsfresh_amd.feature_extraction.plan import compile_fc_parameters
+    from tsfresh_amd.feature_extraction.settings import ComprehensiveFCParameters
+    from tsfresh_amd.feature_selection.relevance import _relevance_table
+
+    if default_fc_parameters is None and kind_to_fc_parameters is None:
+        default_fc_parameters = ComprehensiveFCParameters()
+    elif default_fc_parameters is None:
+        default_fc_parameters = {}
+    if device is None:
+        device = _default_device()
+    packed, id_dtype, _ = pack_timeseries(container, column_id=column_id, column_kind=column_kind,
+                                          column_value=column_value, column_sort=column_sort)
+    if not packed:
+        raise ValueError("the time series container holds no series")
+    ids = np.asarray(packed[0].ids)
+    for pk in packed[1:]:
+        if len(pk.ids) != len(ids) or not np.array_equal(np.asarray(pk.ids), ids):
+            raise ValueError("device_resident=True needs the same ids in every kind (kind {!r} differs from {!r})".format(
+                pk.kind, packed[0].kind))
+    with warnings.catch_warnings():
+        warnings.simplefilter("default" if show_warnings else "ignore")
+        jobs, names = [], []
+        for pk in packed:
+            fc = kind_to_fc_parameters[pk.kind] if kind_to_fc_parameters and pk.kind in kind_to_fc_parameters \
+                else default_fc_parameters
+            fplan = compile_fc_parameters(fc, has_datetime_index=pk.times is not None)
+            if fplan.host_calls:
+                raise ValueError("device_resident=True cannot splice host-evaluated custom calculators into the device matrix")
+            if not fplan.names:
+                continue
+            jobs.append((pk, _acquire_plan(fplan, device), len(names)))
+            names.extend(pk.kind + "__" + n for n in fplan.names)
+        dm = _native.DeviceMatrix(len(ids), len(names), device)
+        try:
+            for pk, nplan, col0 in jobs:
+                nplan.extract_into(pk.values, pk.offsets, dm, col0=col0, times=pk.times)
+            _native.impute_matrix(dm)  # impute(): +-inf -> column max / min, NaN -> median of the finite values
+            index = pd.Index(ids)
+            try:
+                index = index.astype(id_dtype)  # data.py:115-116
+            except (TypeError, ValueError):
+                pass
+            assert index.is_monotonic_increasing, "the packer returns the ids in sorted order"
+            y_sorted = y.sort_index()
+            assert list(y_sorted.index) == list(index), "The index of X and y need to be the same"
+            table = _relevance_table(dm, names, y_sorted, ml_task, False, 1, show_warnings,
+                                     test_for_binary_target_real_feature, fdr_level, hypotheses_independent, device)
+            relevant = list(table[table.relevant].feature)
+            pos = {n: j for j, n in enumerate(names)}
+            block = dm.to_host([pos[f] for f in relevant]) if relevant else np.empty((len(ids), 0))
+        finally:
+            dm.free()
+    out = pd.DataFrame(block, index=index, columns=relevant)
+    return out

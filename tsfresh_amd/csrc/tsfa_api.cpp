@@ -386,7 +386,7 @@ static int host_len_stats(const int64_t *starts, const int64_t *ends, int64_t n,
 static int run_batch(tsfa_plan *plan, const void *d_values, int dtype, const double *d_times, const int64_t *d_starts,
                      const int64_t *d_ends, int64_t n_series, double *d_out, int64_t ld, const BatchShape &sh,
                      const int *d_sel, hipStream_t st, bool with_overlap) {
-    if (tsfa_launch_fill_nan(d_out, n_series * ld, st)) return fail(TSFA_ERR_HIP, "fill launch failed");
+    if (tsfa_launch_fill_nan(d_out, n_series, plan->n_cols, ld, st)) return fail(TSFA_ERR_HIP, "fill launch failed");
 
     // Launch order: longest kernels first.  With side streams (and no per-kernel timing requested) the families are
     // dealt round-robin over the streams after a fork event; the join events bring them back to `st`.

@@ -436,10 +436,18 @@ k_cwt_gemm(const T *__restrict__ values, const int64_t *__restrict__ starts, con
     }
 }
 
-__global__ void k_fill_nan(double *__restrict__ out, int64_t n) {
+// the plan's n_cols columns of every row (leading dimension ld >= n_cols: the cells beyond belong to the caller)
+__global__ void k_fill_nan(double *__restrict__ out, int64_t n_rows, int64_t n_cols, int64_t ld) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-    for (int64_t k = i; k < n; k += stride) out[k] = TSFA_NAN;
+    if (ld == n_cols) {
+        for (int64_t k = i; k < n_rows * n_cols; k += stride) out[k] = TSFA_NAN;
+    } else {
+        for (int64_t k = i; k < n_rows * n_cols; k += stride) {
+            const int64_t r = k / n_cols;
+            out[r * ld + (k - r * n_cols)] = TSFA_NAN;
+        }
+    }
 }
 
 // per-batch length statistics: [0] = max length, [1] = min length, [2] = max non-power-of-two length, then per
@@ -699,8 +707,8 @@ int tsfa_launch_cwt(const TsfaCwtLaunch &a) {
     return launch_cwt_t<double>(a, (const double *)a.values);
 }
 
-int tsfa_launch_fill_nan(double *out, int64_t n, void *stream) {
-    k_fill_nan<<<2048, 256, 0, (hipStream_t)stream>>>(out, n);
+int tsfa_launch_fill_nan(double *out, int64_t n_rows, int64_t n_cols, int64_t ld, void *stream) {
+    k_fill_nan<<<2048, 256, 0, (hipStream_t)stream>>>(out, n_rows, n_cols, ld);
     TSFA_LAUNCH_CHECK();
     return 0;
 }

@@ -82,7 +82,7 @@ int tsfa_launch_family_long(const TsfaLaunch &a);   // working set in a.long_scr
 int tsfa_launch_ar_degenerate(const TsfaLaunch &a);
 int tsfa_launch_order_stats(const TsfaLaunch &a);    // SORT family holding only median / quantile columns, maxn <= 2048  // second pass of TSFA_FAM_AR over the series the first listed
 int tsfa_launch_cwt(const TsfaCwtLaunch &a);
-int tsfa_launch_fill_nan(double *out, int64_t n, void *stream);
+int tsfa_launch_fill_nan(double *out, int64_t n_rows, int64_t n_cols, int64_t ld, void *stream);
 int tsfa_launch_len_stats(const int64_t *starts, const int64_t *ends, int64_t n_series, long long *stats, void *stream);
 int tsfa_launch_class_fill(const int64_t *starts, const int64_t *ends, int64_t n_series, const TsfaClassMap &g, int *cursor,
                            int *sel, void *stream);

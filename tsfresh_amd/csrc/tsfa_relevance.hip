@@ -655,6 +655,81 @@ done:
     return rc;
 }
 
+// ---------------------------------------------------------------------------------------------
+// Device-resident matrices: extract -> impute -> select without the feature matrix crossing PCIe
+// between the steps.  tsfa_extract / tsfa_impute / tsfa_relevance_* take TSFA_DEVICE pointers; these four entry points
+// give a host in any language the buffer, the transfers and the final gather of the selected columns.
+// ---------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) k_gather_columns(const double *__restrict__ X, int64_t n_rows, int64_t ld,
+                                                         const int32_t *__restrict__ cols, int64_t n_sel,
+                                                         double *__restrict__ out) {
+    const int64_t total = n_rows * n_sel;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t r = i / n_sel, c = i - r * n_sel;
+        out[i] = X[r * ld + cols[c]];
+    }
+}
+
+static int rel_check_device(int32_t device, const char *who) {
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1 || device < 0 || device >= ndev)
+        return tsfa_fail(TSFA_ERR_NO_DEVICE, (std::string(who) + ": no such HIP device").c_str());
+    return TSFA_OK;
+}
+
+extern "C" int tsfa_device_alloc(void **ptr, size_t bytes, int32_t device) {
+    if (!ptr) return tsfa_fail(TSFA_ERR_INVALID, "tsfa_device_alloc: ptr is NULL");
+    *ptr = nullptr;
+    int rc = rel_check_device(device, "tsfa_device_alloc");
+    if (rc) return rc;
+    REL_HIP(hipSetDevice(device));
+    REL_HIP(hipMalloc(ptr, bytes ? bytes : 1));
+done:
+    return rc;
+}
+
+extern "C" int tsfa_device_free(void *ptr, int32_t device) {
+    if (!ptr) return TSFA_OK;
+    int rc = rel_check_device(device, "tsfa_device_free");
+    if (rc) return rc;
+    REL_HIP(hipSetDevice(device));
+    REL_HIP(hipFree(ptr));
+done:
+    return rc;
+}
+
+extern "C" int tsfa_device_copy(void *dst, const void *src, size_t bytes, int32_t to_device, int32_t device) {
+    if ((!dst || !src) && bytes) return tsfa_fail(TSFA_ERR_INVALID, "tsfa_device_copy: null pointer");
+    int rc = rel_check_device(device, "tsfa_device_copy");
+    if (rc || !bytes) return rc;
+    REL_HIP(hipSetDevice(device));
+    REL_HIP(hipMemcpy(dst, src, bytes, to_device ? hipMemcpyHostToDevice : hipMemcpyDeviceToHost));
+done:
+    return rc;
+}
+
+extern "C" int tsfa_gather_columns(const double *X, int64_t n_rows, int64_t ld, const int32_t *cols, int64_t n_sel,
+                                   double *out_host, int32_t device) {
+    if (n_rows < 0 || n_sel < 0 || ((n_rows && n_sel) && (!X || !cols || !out_host)))
+        return tsfa_fail(TSFA_ERR_INVALID, "tsfa_gather_columns: null pointer or bad shape");
+    int rc = rel_check_device(device, "tsfa_gather_columns");
+    if (rc || n_rows == 0 || n_sel == 0) return rc;
+    for (int64_t c = 0; c < n_sel; ++c)
+        if (cols[c] < 0 || cols[c] >= ld) return tsfa_fail(TSFA_ERR_INVALID, "tsfa_gather_columns: column index out of range");
+    int32_t *dcols = nullptr;
+    double *dout = nullptr;
+    REL_HIP(hipSetDevice(device));
+    REL_HIP(hipMalloc((void **)&dcols, (size_t)n_sel * sizeof(int32_t)));
+    REL_HIP(hipMalloc((void **)&dout, (size_t)n_rows * n_sel * sizeof(double)));
+    REL_HIP(hipMemcpy(dcols, cols, (size_t)n_sel * sizeof(int32_t), hipMemcpyHostToDevice));
+    k_gather_columns<<<2048, 256, 0, 0>>>(X, n_rows, ld, dcols, n_sel, dout);
+    REL_HIP(hipGetLastError());
+    REL_HIP(hipMemcpy(out_host, dout, (size_t)n_rows * n_sel * sizeof(double), hipMemcpyDeviceToHost));
+done:
+    (void)hipFree(dcols); (void)hipFree(dout);
+    return rc;
+}
+
 // Pr(D >= h / lcm(m, n)) for the two-sided two-sample Kolmogorov-Smirnov statistic, m != n: the proportion of lattice
 // paths (0,0) -> (m,n) that do not stay strictly inside |x/m - y/n| < h/lcm (Hodges 1958; the column recurrence scipy
 // uses in ks_2samp(method="exact"), computed on the complement so small probabilities keep their relative accuracy).

@@ -55,6 +55,15 @@ def calculate_relevance_table(X, y, ml_task="auto", multiclass=False, n_signific
     y = y.sort_index()
     X = X.sort_index()
     assert list(y.index) == list(X.index), "The index of X and y need to be the same"
+    return _relevance_table(X, X.columns, y, ml_task, multiclass, n_significant, show_warnings,
+                            test_for_binary_target_real_feature, fdr_level, hypotheses_independent, device)
+
+
+def _relevance_table(X, columns, y, ml_task, multiclass, n_significant, show_warnings, test_for_binary_target_real_feature,
+                     fdr_level, hypotheses_independent, device):
+    """The body of calculate_relevance_table.  X: a DataFrame, or a `_native.DeviceMatrix` whose rows follow y's sorted
+    index and whose columns are named by `columns` (the device-resident chain of extract_relevant_features: imputed on
+    the device, hence free of NaN)."""
     if ml_task not in ["auto", "classification", "regression"]:
         raise ValueError("ml_task must be one of: 'auto', 'classification', 'regression'")
     elif ml_task == "auto":
@@ -70,10 +79,16 @@ def calculate_relevance_table(X, y, ml_task="auto", multiclass=False, n_signific
                          "Valid entries are 'mann' and 'smir'.")
     smir = (test_for_binary_target_real_feature == "smir")
 
-    values = np.ascontiguousarray(X.to_numpy(dtype=np.float64))
-    if np.isnan(values).any():
-        bad = X.columns[np.isnan(values).any(axis=0)][0]
-        raise ValueError("Feature {} contains NaN values".format(bad))
+    columns = pd.Index(columns)
+    if isinstance(X, _native.DeviceMatrix):
+        values = X
+        if device is None:
+            device = X.device
+    else:
+        values = np.ascontiguousarray(X.to_numpy(dtype=np.float64))
+        if np.isnan(values).any():
+            bad = columns[np.isnan(values).any(axis=0)][0]
+            raise ValueError("Feature {} contains NaN values".format(bad))
     if y.dtype.kind == "f" and np.isnan(y.to_numpy()).any():
         raise ValueError("Target contains NaN values")
     if device is None:
@@ -94,11 +109,11 @@ def calculate_relevance_table(X, y, ml_task="auto", multiclass=False, n_signific
 
     with warnings.catch_warnings():
         warnings.simplefilter("default" if show_warnings else "ignore")
-        relevance_table = pd.DataFrame(index=pd.Series(X.columns, name="feature"))
+        relevance_table = pd.DataFrame(index=pd.Series(columns, name="feature"))
         relevance_table["feature"] = relevance_table.index
         relevance_table["type"] = pd.Series(
             np.where(n_unique == 1, "constant", np.where(n_unique == 2, "binary", "real")), index=relevance_table.index)
-        pos = {f: i for i, f in enumerate(X.columns)}
+        pos = {f: i for i, f in enumerate(columns)}
         table_real = relevance_table[relevance_table.type == "real"].copy()
         table_binary = relevance_table[relevance_table.type == "binary"].copy()
         table_const = relevance_table[relevance_table.type == "constant"].copy()
