@@ -512,7 +512,9 @@ static int run_batch(tsfa_plan *plan, const void *d_values, int dtype, const dou
                 if (getenv("TSFA_ENT_SLOW")) a.ent_fast = 0;  // experiment / test hook: the general kernel
                 // series up to TSFA_ENTB_MAXN samples: the bit-matrix sweep (fam_entropy_bits.h) -- sorted ranges + bit
                 // rows instead of a distance per pair; one (strip, tolerance) task per wavefront register slot
-                if (a.ent_fast && maxn <= TSFA_ENTB_MAXN && maxn >= 3 &&
+                // (a single tolerance: the windowed pair sweep is the cheaper one -- 7.7 vs 9.0 ms per 100k x 1024 -- the sample
+                //  sort, the table and the ranges do not amortise)
+                if (a.ent_fast && a.nspecs >= 2 && maxn <= TSFA_ENTB_MAXN && maxn >= 3 &&
                     !(getenv("TSFA_ENT_PAIRS") && atoi(getenv("TSFA_ENT_PAIRS"))) &&
                     tsfa_entropy_lds_bytes(maxn, 2) <= TSFA_LDS_LIMIT / 2) {
                     a.ent_cnt = 2;

@@ -37,6 +37,11 @@ static inline TSFA_ENTB_HD int entb_waves_for(int maxn, int nk) {
     const int need = (nstrips * nk + TSFA_ENTB_MAXT - 1) / TSFA_ENTB_MAXT;
     int w = 1;
     while (w < need) w <<= 1;
+    // at most two samples per thread: the sample sort, the range bisections and the table build are per-sample work
+    // (and the register sort handles 1, 2 or 4 keys per thread), whatever the number of tolerances
+    int p2 = 1;
+    while (p2 < maxn) p2 <<= 1;
+    while (w * 128 < p2 && w < TSFA_ENTB_MAXWAVES) w <<= 1;
     return w < 1 ? 1 : w;
 }
 #endif
