@@ -740,6 +740,13 @@ TSFA_DEV void fam_sort_series(const Blk &b, const ST *xs_raw, int n, const TsfaS
                     codes[u] = (t < num) ? perm_code(xs_raw + t * tau, D, fact) : -1;
                 }
             }
+            // log(c / num) of the small counts from a table (one float64 logarithm, ~150 instructions, per lane of ONE
+            // evaluation instead of one per bin / window: for D >= 5 nearly every count is below the table's end)
+            const int LT = 64;
+            double *ltab = b.np->leaf_sum;  // the numpy-order scratch is idle here
+            blk_sync();
+            for (int c = b.tid; c < LT; c += b.nt) ltab[c] = (c > 0) ? log((double)c / (double)num) : 0.0;
+            blk_sync();
             double e = 0.0;
             for (int base = 0; base < fact; base += per_pass) {
                 const int top = (fact - base < per_pass) ? (fact - base) : per_pass;  // patterns of this pass
@@ -777,7 +784,7 @@ TSFA_DEV void fam_sort_series(const Blk &b, const ST *xs_raw, int n, const TsfaS
                         const int c = (k & 1) ? (int)(wv >> 16) : (int)(wv & 0xffffu);
                         if (c > 0) {
                             const double pr = (double)c / (double)num;
-                            e += pr * log(pr);
+                            e += pr * ((c < LT) ? ltab[c] : log(pr));
                         }
                     }
                 } else {  // more patterns than windows: sum_k c_k log(c_k / num) = sum over windows of log(c(window) / num)
@@ -789,7 +796,7 @@ TSFA_DEV void fam_sort_series(const Blk &b, const ST *xs_raw, int n, const TsfaS
                             if (codes[u] >= 0 && c >= 0 && c < top) {
                                 const unsigned wv = (unsigned)iw[c >> 1];
                                 const int cc = (c & 1) ? (int)(wv >> 16) : (int)(wv & 0xffffu);
-                                acc += log((double)cc / (double)num);
+                                acc += (cc < LT) ? ltab[cc] : log((double)cc / (double)num);
                             }
                         }
                     } else {
@@ -798,7 +805,7 @@ TSFA_DEV void fam_sort_series(const Blk &b, const ST *xs_raw, int n, const TsfaS
                             if (c >= 0 && c < top) {
                                 const unsigned wv = (unsigned)iw[c >> 1];
                                 const int cc = (c & 1) ? (int)(wv >> 16) : (int)(wv & 0xffffu);
-                                acc += log((double)cc / (double)num);
+                                acc += (cc < LT) ? ltab[cc] : log((double)cc / (double)num);
                             }
                         }
                     }
