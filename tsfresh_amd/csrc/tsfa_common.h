@@ -1120,14 +1120,28 @@ TSFA_DEV double blk_binned_entropy(const Blk &b, int m, G g, int bins, double vm
     for (int k = b.tid; k < bins; k += b.nt) cnt[k] = 0;
     blk_sync();
     const double norm = last - first;
+    // numpy: idx = int((v - first) / norm * bins), then one step down if v < edge[idx], one step up if v >= edge[idx + 1]:
+    // the two corrections make idx the bin whose edges enclose v for ANY estimate within one bin of it, so the estimate
+    // may use the reciprocal (one division per call instead of one per element), and the edges np.linspace(first, last,
+    // bins + 1)[i] = i * step + first with the step formed once (numpy's own expression; three divisions per element
+    // before -- a float64 division is ~30 instructions)
+    const double inv_norm = 1.0 / norm;
+    const double delta = last - first, step = delta / (double)bins;
+    const bool flat = (step == 0.0);
     for (int i = b.tid; i < m; i += b.nt) {
         const double v = g(i);
         if (!(v >= first && v <= last)) continue;
-        const double fidx = ((v - first) / norm) * (double)bins;
+        const double fidx = ((v - first) * inv_norm) * (double)bins;
         int idx = (int)fidx;
-        if (idx == bins) idx -= 1;
-        if (v < np_linspace_at(first, last, bins + 1, idx)) idx -= 1;
-        if (idx != bins - 1 && v >= np_linspace_at(first, last, bins + 1, idx + 1)) idx += 1;
+        if (idx >= bins) idx = bins - 1;
+        if (idx < 0) idx = 0;
+        const double e0 = flat ? np_linspace_at(first, last, bins + 1, idx) : ((idx == bins) ? last : (double)idx * step + first);
+        if (v < e0) idx -= 1;
+        if (idx != bins - 1) {
+            const double e1 = flat ? np_linspace_at(first, last, bins + 1, idx + 1)
+                                   : ((idx + 1 == bins) ? last : (double)(idx + 1) * step + first);
+            if (v >= e1) idx += 1;
+        }
 #if TSFA_GPU
         atomicAdd(&cnt[idx], 1);
 #else
