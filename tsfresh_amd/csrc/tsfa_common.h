@@ -213,17 +213,94 @@ TSFA_DEV TsfaSpec spec_fetch(const Blk &b, const TsfaSpec *specs, int nspecs, in
 
 // N sums at once: the wave reductions are independent chains (they overlap), and the cross-wave exchange costs one
 // barrier pair for all N instead of one per value.  Same summation order as N calls of blk_sum.  N * waves <= 64.
+#if TSFA_GPU
+template <int LX>
+TSFA_DEV double lane_xor_f64(double v);  // defined with the sorting networks below
+#endif
+#if TSFA_GPU
+// G (4 or 8) per-lane values -> their G wavefront totals, one per lane: a reduce-scatter inside the wavefront.  At each
+// of the first log2(G) steps a lane keeps one half of its values and hands the other half to its partner (lane xor 1, 2,
+// 4), so the values per lane halve while the lanes per sum double: G - 1 additions + G - 1 exchanges instead of G full
+// butterflies (6 G of each).  The lane then holds the partial sum of quantity rev(lane mod G) over its G-lane group
+// (rev = bit reversal), and log2(64 / G) more steps add the groups.  Returns that total.
+template <int G>
+TSFA_DEV double wave_reduce_scatter(const double *v) {
+    static_assert(G == 4 || G == 8, "groups of four or eight values");
+    const int lane = (int)(threadIdx.x & 63);
+    double t[G / 2];
+    {
+        const bool hi = (lane & 1) != 0;
+#pragma unroll
+        for (int i = 0; i < G / 2; ++i) {
+            const double keep = hi ? v[G / 2 + i] : v[i], send = hi ? v[i] : v[G / 2 + i];
+            t[i] = keep + lane_xor_f64<1>(send);
+        }
+    }
+    {
+        const bool hi = (lane & 2) != 0;
+#pragma unroll
+        for (int i = 0; i < G / 4; ++i) {
+            const double keep = hi ? t[G / 4 + i] : t[i], send = hi ? t[i] : t[G / 4 + i];
+            t[i] = keep + lane_xor_f64<2>(send);
+        }
+    }
+    double r = t[0];
+    if (G == 8) {
+        const bool hi = (lane & 4) != 0;
+        const double keep = hi ? t[1] : t[0], send = hi ? t[0] : t[1];
+        r = keep + lane_xor_f64<4>(send);
+    } else {
+        r += lane_xor_f64<4>(r);
+    }
+    r += lane_xor_f64<8>(r);
+    r += lane_xor_f64<16>(r);
+    r += lane_xor_f64<32>(r);
+    return r;
+}
+// quantity held by lane l (l < G) after wave_reduce_scatter<G>
+template <int G>
+TSFA_DEV int wave_reduce_scatter_index(int l) {
+    return (G == 8) ? (((l & 1) << 2) | (l & 2) | ((l >> 2) & 1)) : (((l & 1) << 1) | ((l >> 1) & 1));
+}
+#endif
+
 template <int N>
 TSFA_DEV void blk_sum_multi(const Blk &b, double *v) {
 #if TSFA_GPU
+    // groups of eight (and one of four) values by the wavefront reduce-scatter, the remaining ones by full butterflies
+    constexpr int N8 = (N / 8) * 8, N4 = N8 + (((N - N8) >= 4) ? 4 : 0);
+    const int lane = b.tid & 63;
+    double held[(N4 > 0) ? (N4 / 4) : 1];
+    (void)held;
 #pragma unroll
-    for (int k = 0; k < N; ++k) v[k] = wave_sum(v[k]);
+    for (int g = 0; g < N8; g += 8) held[g / 8] = wave_reduce_scatter<8>(v + g);
+    if (N4 > N8) held[N8 / 8] = wave_reduce_scatter<4>(v + N8);
+#pragma unroll
+    for (int k = N4; k < N; ++k) v[k] = wave_sum(v[k]);
+    if (b.nt <= 64) {
+#pragma unroll
+        for (int g = 0; g < N8; g += 8) {
+#pragma unroll
+            for (int k = 0; k < 8; ++k) v[g + k] = readlane_f64(held[g / 8], wave_reduce_scatter_index<8>(k));
+        }
+        if (N4 > N8) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) v[N8 + k] = readlane_f64(held[N8 / 8], wave_reduce_scatter_index<4>(k));
+        }
+    }
     if (b.nt > 64) {
         const int nw = b.nt >> 6;
         blk_sync();
-        if ((b.tid & 63) == 0) {
+        {
+            double *slot = b.red + (b.tid >> 6) * N;
 #pragma unroll
-            for (int k = 0; k < N; ++k) b.red[(b.tid >> 6) * N + k] = v[k];
+            for (int g = 0; g < N8; g += 8)
+                if (lane < 8) slot[g + wave_reduce_scatter_index<8>(lane)] = held[g / 8];
+            if (N4 > N8 && lane < 4) slot[N8 + wave_reduce_scatter_index<4>(lane)] = held[N8 / 8];
+            if (lane == 0) {
+#pragma unroll
+                for (int k = N4; k < N; ++k) slot[k] = v[k];
+            }
         }
         blk_sync();
 #pragma unroll
@@ -345,10 +422,6 @@ TSFA_DEV double np_leaf_sum(int o, int l, F f) {
     return res;
 }
 
-#if TSFA_GPU
-template <int LX>
-TSFA_DEV double lane_xor_f64(double v);  // defined with the sorting networks below
-#endif
 template <class F>
 TSFA_DEV double np_sum(const Blk &b, int n, F f) {
     NpScratch *s = b.np;
