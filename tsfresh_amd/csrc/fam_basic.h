@@ -206,8 +206,9 @@ TSFA_DEV void alt_fill_all(const Blk &b, XS xs, int n, const TsfaAltPlan &alt, d
                 if (j < ng) sy[j] += w[j * m + i];
         }
         double ym[4];
+        blk_sum_multi<4>(b, sy);
 #pragma unroll
-        for (int j = 0; j < 4; ++j) ym[j] = (j < ng) ? blk_sum(b, sy[j]) / dm : 0.0;
+        for (int j = 0; j < 4; ++j) ym[j] = (j < ng) ? sy[j] / dm : 0.0;
         double sxy[4] = {0.0, 0.0, 0.0, 0.0}, syy[4] = {0.0, 0.0, 0.0, 0.0};
         for (int i = b.tid; i < m; i += b.nt) {
             const double dx = (double)i - xmean;
@@ -220,10 +221,12 @@ TSFA_DEV void alt_fill_all(const Blk &b, XS xs, int n, const TsfaAltPlan &alt, d
                 }
             }
         }
+        double s8[8] = {sxy[0], sxy[1], sxy[2], sxy[3], syy[0], syy[1], syy[2], syy[3]};
+        blk_sum_multi<8>(b, s8);
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             if (j < ng) {
-                const double a = blk_sum(b, sxy[j]), c2 = blk_sum(b, syy[j]);
+                const double a = s8[j], c2 = s8[4 + j];
                 if (b.tid == 0) {
                     double *r = raw + 6 * (k0 + j);
                     r[0] = dm;

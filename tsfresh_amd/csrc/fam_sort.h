@@ -701,11 +701,9 @@ TSFA_DEV void fam_sort_series(const Blk &b, const ST *xs_raw, int n, const TsfaS
                     }
                     if (eq_prev || eq_next) { mp += 1.0; spn += x; }
                 }
-                n_unique = blk_sum(b, nu);
-                n_multi_vals = blk_sum(b, mv);
-                n_multi_pts = blk_sum(b, mp);
-                sum_multi_vals = blk_sum(b, sv);
-                sum_multi_pts = blk_sum(b, spn);
+                double r5[5] = {nu, mv, mp, sv, spn};  // reduced together: one barrier pair
+                blk_sum_multi<5>(b, r5);
+                n_unique = r5[0]; n_multi_vals = r5[1]; n_multi_pts = r5[2]; sum_multi_vals = r5[3]; sum_multi_pts = r5[4];
                 have_runs = true;
                 if (nloop < nspecs && b.tid == 0) {
                     ctx[TSFA_SCTX_NUNIQUE] = n_unique; ctx[TSFA_SCTX_MULTI_VALS] = n_multi_vals;

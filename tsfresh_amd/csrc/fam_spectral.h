@@ -461,11 +461,11 @@ TSFA_DEV void fam_spectral_series(const Blk &b, const ST *xs_raw, int n, const T
         s3 += a * (dk * dk * dk);
         s4 += a * (dk * dk * dk * dk);
     }
-    s0 = blk_sum(b, s0);
-    s1 = blk_sum(b, s1);
-    s2 = blk_sum(b, s2);
-    s3 = blk_sum(b, s3);
-    s4 = blk_sum(b, s4);
+    {
+        double s5[5] = {s0, s1, s2, s3, s4};  // reduced together: one barrier pair, a reduce-scatter for four of them
+        blk_sum_multi<5>(b, s5);
+        s0 = s5[0]; s1 = s5[1]; s2 = s5[2]; s3 = s5[3]; s4 = s5[4];
+    }
     const double m1 = s1 / s0, m2 = s2 / s0, m3 = s3 / s0, m4 = s4 / s0;
     const double var = m2 - m1 * m1;
     for (int s = nlead + b.tid; s < nspecs; s += b.nt) {  // one lane per column
