@@ -686,3 +686,20 @@ def test_device_output_with_a_leading_dimension_leaves_the_other_cells_alone(gpu
         assert np.array_equal(dm.to_host([2 + m - 1, 2, 0]), np.c_[want[:, m - 1], want[:, 0], np.full(n, -777.0)])
     finally:
         dm.free()
+
+
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+def test_minimal_plan_on_ragged_batches_matches_oracle(gpu, dtype):
+    """MinimalFCParameters runs as k_basic_lite (statistics + lane = column closed forms, a persistent grid that fetches
+    the next series while the current one is evaluated) + k_order_stats: every length 1 ... 1024 in one batch, and a batch
+    beyond the register prefetch (3000 samples)."""
+    rng = np.random.default_rng(5)
+    params = settings.MinimalFCParameters()
+    for hi in (40, 1024, 3000):
+        lens = list(rng.integers(1, hi + 1, size=300)) + [1, 2, hi]
+        values = np.concatenate([rng.standard_normal(n).astype(dtype) * (1 + i % 5) + (i % 3) for i, n in enumerate(lens)])
+        offsets = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
+        names, got = hip_engine(params, values, offsets)
+        onames, want = oracle_engine(params, values.astype(np.float64), offsets)
+        bad = compare(onames, _align(onames, names, got), want, _series(values.astype(np.float64), offsets))
+        assert not bad, "%d mismatches at lengths <= %d, first: %s" % (len(bad), hi, bad[:6])

@@ -636,6 +636,13 @@ TSFA_DEV void fam_basic_series(const Blk &b0, XS xs, int n, const TsfaSpec *spec
     bool have_peaks = false;
     int peaks_p = 0;  // window length of the sliding maxima currently held in w (number_peaks fast path), 0 = none
 
+    if (PART & 4) {  // k_basic_lite: every column is a closed form of the statistics (the plan has no other kind)
+        if (nloop < nspecs) {
+            blk_sync();
+            basic_epilogue(b, specs, nloop, nspecs, n, ctx, altc, out_row);
+        }
+        return;
+    }
     // the count-type columns at the front of the list (host hint) are evaluated together from registers
     const int ncnt = ((PART & 1) && n_count > 0 && n_count <= nloop) ? n_count : 0;
     if ((PART & 1) && ncnt > 0) basic_count_pass(b, xs, n, specs, ncnt, st, out_row, iw);

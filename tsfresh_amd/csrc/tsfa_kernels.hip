@@ -84,6 +84,76 @@ __global__ void __launch_bounds__(1024) k_basic(const T *__restrict__ values, co
                      n_count, n_sum TSFA_GS_ARGS);
 }
 
+// A plan whose BASIC columns are all closed forms of the per-series statistics (MinimalFCParameters: sum, mean, length,
+// std, variance, rms, max, |max|, min): statistics + lane = column epilogue only.  A fraction of k_basic's registers, so
+// twice the resident wavefronts for a kernel that waits on the numpy-order sums.
+template <typename T>
+__global__ void __launch_bounds__(256, 4) k_basic_lite(const T *__restrict__ values, const int64_t *__restrict__ starts, const int64_t *__restrict__ ends, int64_t n_series, const int *__restrict__ sel,
+                        const TsfaSpec *__restrict__ specs, int nspecs, double *__restrict__ out, int64_t ld,
+                        const double *__restrict__ dectab, int maxn, int hint_a TSFA_GS_PARAMS) {
+    TsfaAltPlan alt;
+    alt.nkeys = 0; alt.want_p = 0; alt.nq = 0;
+#if defined(TSFA_LONG)
+    basic_body<T, 5>(values, starts, ends, n_series, sel, specs, nspecs, out, ld, dectab, maxn, hint_a, 0, nullptr, alt, 0, 0, 0 TSFA_GS_ARGS);
+#else
+    // a persistent grid: the per-series work is a few thousand cycles, less than the dispatch of a workgroup costs
+    unsigned char *const tsfa_base = tsfa_smem;
+    BasicLds L;
+    L.carve(tsfa_base, maxn, blockDim.x, (int)sizeof(T), 1);
+    // ... and the samples of the NEXT series are fetched into registers while the current one is evaluated: with one
+    // series per wavefront in flight the kernel waits on HBM latency, not bandwidth (0.4 GB in 0.33 ms).
+    const bool prefetch = (maxn <= 16 * (int)blockDim.x);
+    Blk b{(int)threadIdx.x, (int)blockDim.x, L.red, L.np};
+    T *xs = (T *)L.xs;
+    T pre[16];
+    int64_t sidx_n = 0;
+    int n_n = 0;
+    if ((int64_t)blockIdx.x < n_series) {
+        sidx_n = sel ? (int64_t)sel[blockIdx.x] : (int64_t)blockIdx.x;
+        const int64_t off = starts[sidx_n];
+        n_n = (int)(ends[sidx_n] - off);
+        if (prefetch) {
+#pragma unroll
+            for (int u = 0; u < 16; ++u) {
+                const int i = b.tid + u * b.nt;
+                pre[u] = (i < n_n) ? values[off + i] : (T)0;
+            }
+        }
+    }
+    for (int64_t wi = blockIdx.x; wi < n_series; wi += gridDim.x) {
+        const int64_t sidx = sidx_n;
+        const int n = n_n;
+        if (prefetch) {
+#pragma unroll
+            for (int u = 0; u < 16; ++u) {
+                const int i = b.tid + u * b.nt;
+                if (i < n) xs[i] = pre[u];
+            }
+        } else {
+            const T *__restrict__ g = values + starts[sidx];
+            for (int i = b.tid; i < n; i += b.nt) xs[i] = g[i];
+        }
+        blk_sync();
+        const int64_t wn = wi + gridDim.x;
+        if (wn < n_series) {
+            sidx_n = sel ? (int64_t)sel[wn] : wn;
+            const int64_t off = starts[sidx_n];
+            n_n = (int)(ends[sidx_n] - off);
+            if (prefetch) {
+#pragma unroll
+                for (int u = 0; u < 16; ++u) {
+                    const int i = b.tid + u * b.nt;
+                    pre[u] = (i < n_n) ? values[off + i] : (T)0;
+                }
+            }
+        }
+        fam_basic_series<5>(b, XsView<T>{xs}, n, specs, nspecs, out + sidx * ld, L.w, L.cum, L.altc, L.iw, dectab, hint_a, 0,
+                            alt, L.stage, nullptr, 0, L.ctx, 0, 0);
+        blk_sync();
+    }
+#endif
+}
+
 template <typename T>
 __global__ void __launch_bounds__(512) k_trend(const T *__restrict__ values, const int64_t *__restrict__ starts, const int64_t *__restrict__ ends, int64_t n_series, const int *__restrict__ sel,
                         const TsfaSpec *__restrict__ specs, int nspecs, double *__restrict__ out, int64_t ld, int maxn,
@@ -542,8 +612,21 @@ static int launch_all_t(const TsfaLaunch &a, const T *values) {
     if (a.fam == TSFA_FAM_BASIC) {
         BasicLds L;
         const size_t lds = L.carve(nullptr, a.maxn, nt, (int)sizeof(T), 1);
-        TSFA_KLAUNCH(k_basic<T>, lds, values, a.starts, a.ends, a.n_series, a.sel, a.specs, a.nspecs, a.out, a.ld, a.dectab,
-                     a.maxn, a.hint_a, a.hint_c, a.hint_d, a.hint_e);
+        if (a.hint_c == 0 && nt <= 256) {  // no column of the loop / count / sum kinds: statistics + epilogue only
+#if defined(TSFA_LONG)
+            TSFA_KLAUNCH(k_basic_lite<T>, lds, values, a.starts, a.ends, a.n_series, a.sel, a.specs, a.nspecs, a.out, a.ld,
+                         a.dectab, a.maxn, a.hint_a);
+#else
+            if ((rc = set_lds(k_basic_lite<T>, lds))) return rc;
+            const int64_t resident = std::max<int64_t>(1, std::min<int64_t>(32, (int64_t)(TSFA_LDS_LIMIT / std::max<size_t>(lds, 1))));
+            const dim3 pgrid((unsigned)std::min<int64_t>(a.n_series, 256 * resident));
+            k_basic_lite<T><<<pgrid, nt, lds, st>>>(values, a.starts, a.ends, a.n_series, a.sel, a.specs, a.nspecs, a.out, a.ld,
+                                                     a.dectab, a.maxn, a.hint_a);
+#endif
+        } else {
+            TSFA_KLAUNCH(k_basic<T>, lds, values, a.starts, a.ends, a.n_series, a.sel, a.specs, a.nspecs, a.out, a.ld, a.dectab,
+                         a.maxn, a.hint_a, a.hint_c, a.hint_d, a.hint_e);
+        }
     } else if (a.fam == TSFA_FAM_TREND) {
         BasicLds L;
         const size_t lds = L.carve(nullptr, a.maxn, nt, (int)sizeof(T), 2);
