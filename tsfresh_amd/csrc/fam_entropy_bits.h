@@ -6,9 +6,10 @@
 // tolerance.  This sweep never forms a distance:
 //
 //   * Per SAMPLE a and tolerance r, the samples within r of x[a] form one contiguous range of the sorted order,
-//     [lo, hi) -- fl(|x_a - x_b|) <= r is monotone in x_b on either side of x_a, so the range is found with the
-//     reference's own float64 predicate by bisection (lo), and hi follows from lo by symmetry of the predicate
-//     (hi(q) = #{p : lo(p) <= q}, an integer bisection).  O(n log n) float64 operations per tolerance instead of O(n^2).
+//     [lo, hi) -- fl(|x_a - x_b|) <= r is monotone in x_b on either side of x_a (rounding is monotone), so both ends
+//     are found by bisection with the reference's own float64 predicate on a sorted copy padded with +inf:
+//     lo = #{p : !(x_a - x_p <= r)}, hi = #{p : x_p - x_a <= r}.  O(n log n) float64 operations per tolerance instead
+//     of O(n^2); ties, infinities and NaN tolerances fall out of the same compares.
 //   * With Pref(t) = the bit set {b : rank(x_b) < t} over the NATURAL sample index b, the row of the 0/1 matrix
 //     A[a, b] = (|x_a - x_b| <= r) is Pref(hi) xor Pref(lo): two table reads and one xor per 32 pairs.
 //   * Templates i, j of length 2 match iff A[i, j] & A[i+1, j+1]; of length 3 iff additionally A[i+2, j+2]: the
