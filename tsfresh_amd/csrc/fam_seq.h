@@ -74,12 +74,12 @@ TSFA_SEQ_HD LzTable lz_table_plan(int bins, int n) {
         // (child of node id by symbol s: id * bins + 1 + s), so "does this child exist" is one bit of a table indexed
         // by id * bins + s: no keys, no probing, a third of the LDS.  D is the largest depth whose bit table fits
         // TSFA_LZ_BITS_MAX; only phrases longer than D (at most n / (D + 1) of them) go to a small hash table.
-        // ... and no deeper than the parse can fill: it creates at most P phrases, so a level of more than 2 P nodes is
+        // ... and no deeper than the parse can fill: it creates at most P phrases, so a level of more than P nodes is
         // mostly empty -- the LDS it would take buys more resident series instead (the kernel is bound by the latency of
         // its serial parse times the series in flight; the few deeper phrases take the hash)
         long long nodes = 1, pw = 1;  // nodes of depth < D, bins^(D-1)
         int D = 1;
-        while ((nodes + pw * bins) * bins <= TSFA_LZ_BITS_MAX && pw < 2LL * P) { pw *= bins; nodes += pw; ++D; }
+        while ((nodes + pw * bins) * bins <= TSFA_LZ_BITS_MAX && pw < (long long)P) { pw *= bins; nodes += pw; ++D; }
         const int deep = n / (D + 1);
         int cap = 16, lg = 4;
         while (17LL * cap < 20LL * deep + 20) { cap <<= 1; ++lg; }  // load factor <= 0.85: probing only costs the rare deep steps
