@@ -56,7 +56,38 @@ def degenerate_series():
     return cases
 
 
-CASE_SETS = {"main": golden_series, "degenerate": degenerate_series}
+def offset_series():
+    """Series whose mean is far from zero relative to their spread (grid frequency 50 Hz +- 5 mHz, pressure
+    101 325 +- 5 Pa, float64 counters / epoch seconds): np.polyfit's rank cut (friedrich_coefficients,
+    max_langevin_fixed_point; fc.py:131-173) and statsmodels' pinv cut (ar_coefficient, augmented_dickey_fuller;
+    fc.py:1459-1508, :499-545) decide what the reference returns there."""
+    rng = np.random.default_rng(20260924)
+    cases = []
+    for q in (1e2, 1e3, 1e4, 3e4, 1e5, 1e6):
+        for sigma in (1.0, 10.0):
+            for kind in ("iid", "walk"):
+                for dt in (np.float32, np.float64):
+                    e = rng.standard_normal(300)
+                    if kind == "walk":
+                        e = np.cumsum(e) * 0.1
+                    x = (q * sigma + sigma * e).astype(dt).astype(np.float64)
+                    cases.append(("off_%g_s%g_%s_%s" % (q, sigma, kind, dt.__name__), x))
+    t = np.arange(400, dtype=np.float64)
+    cases.append(("neg_off_1e5_iid", -1e5 + rng.standard_normal(300)))
+    cases.append(("off_1e7_iid", 1e7 + rng.standard_normal(300)))
+    cases.append(("off_1e8_iid", 1e8 + rng.standard_normal(300)))
+    cases.append(("off_1e9_iid", 1e9 + rng.standard_normal(300)))
+    cases.append(("off_1e8_walk", 1e8 + np.cumsum(rng.standard_normal(400))))
+    cases.append(("epoch_seconds_400", 1.7e9 + t))
+    cases.append(("epoch_jitter_400", 1.7e9 + t + 0.01 * rng.standard_normal(400)))
+    cases.append(("grid_hz_1024", 50.0 + 0.005 * rng.standard_normal(1024)))
+    cases.append(("pressure_pa_512", 101325.0 + 5.0 * rng.standard_normal(512)))
+    cases.append(("scaled_small_300", 1e-6 * (3.0 + rng.standard_normal(300))))
+    cases.append(("scaled_big_300", 1e6 * (0.5 + rng.standard_normal(300))))
+    return cases
+
+
+CASE_SETS = {"main": golden_series, "degenerate": degenerate_series, "offset": offset_series}
 
 
 def pack(cases):

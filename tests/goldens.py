@@ -6,6 +6,7 @@ offsets, series, labels) tuples.
   main_nosimd     ref_main_nosimd.npz + ref_conda.npz             False (stable ranks: permutation_entropy ties pinned)
   degenerate      ref_main_degenerate.npz + ref_conda_degenerate  True
   degenerate_nosimd  ref_main_degenerate_nosimd.npz + ...         False
+  offset / offset_nosimd   ref_main_offset*.npz + ref_conda_offset.npz   (|mean| >> spread: the rank cuts of np.polyfit / pinv)
 """
 import os
 
@@ -18,6 +19,8 @@ PAIRS = {
     "main_nosimd": ("ref_main_nosimd.npz", "ref_conda.npz", False),
     "degenerate": ("ref_main_degenerate.npz", "ref_conda_degenerate.npz", True),
     "degenerate_nosimd": ("ref_main_degenerate_nosimd.npz", "ref_conda_degenerate.npz", False),
+    "offset": ("ref_main_offset.npz", "ref_conda_offset.npz", True),
+    "offset_nosimd": ("ref_main_offset_nosimd.npz", "ref_conda_offset.npz", False),
 }
 
 

@@ -4,6 +4,7 @@
 #define TSFA_FAM_SORT_H
 
 #include "tsfa_common.h"
+#include "fam_langevin_dd.h"
 
 // np.quantile(sorted, q, method="linear")   (numpy/lib/_function_base_impl.py: _compute_virtual_index,
 // _get_indexes, _get_gamma, _lerp -- the exact expression order matters for tie-sensitive callers)
@@ -231,13 +232,64 @@ TSFA_DEV int perm_code(const AT *a, int D, int fact) {
 #define TSFA_FRIEDRICH_MAX_R 64
 #define TSFA_FRIEDRICH_MAX_M 3
 
+// Where friedrich_coeffs leaves an ill-conditioned fit for the double-double pass (fam_langevin_dd.h).  The device
+// build records it for k_langevin_dd; the single-thread emulation (no second kernel) redoes the fit in place.
+struct FrDefer {
+    double *buf;        // the plan's buffer of deferred fits: records of slot_doubles doubles (tsfa_pf_slot_doubles)
+    int *count;         // number of records (zeroed before the launch)
+    int slot_doubles;
+    long long sidx;     // row of this series in the output matrix
+    int spec;           // index of the spec that asked for the fit (the pass reads m and r from it)
+};
+
+// Exact bin sums.  A value v with |v| < 2^E is split as v = hi 2^-S1 + lo, hi = rint(v 2^S1), S1 = 60 - bits - E (2^bits
+// >= the number of addends: the integer sum stays below 2^60), and lo -- exact in float64 -- as rint(lo 2^S2) with S2 =
+// S1 + 59 - bits.  Both parts are added as 64-bit integers (LDS atomics on the device): associative, hence independent
+// of the order in which the threads arrive, and EXACT for every addend above 2^-50 of the largest (below: to 2^-100
+// of the largest).  pandas' groupby mean adds with Kahan compensation, i.e. also returns the (nearly always correctly)
+// rounded exact sum; float atomics differed from run to run, a single 2^-50 grid lost the small deltas of a series with
+// a large offset.
+struct FxScale {
+    int s1, s2;
+};
+TSFA_DEV FxScale fx_scale(double amax, int bits) {
+    int e2 = 0;
+    (void)frexp(amax, &e2);   // amax < 2^e2
+    FxScale f;
+    f.s1 = 60 - bits - e2;
+    f.s2 = f.s1 + 59 - bits;
+    return f;
+}
+TSFA_DEV void fx_split(double v, FxScale f, long long &hi, long long &lo) {
+    const double h = rint(ldexp(v, f.s1));
+    hi = (long long)h;
+    lo = (long long)rint(ldexp(v - ldexp(h, -f.s1), f.s2));
+}
+TSFA_DEV double fx_value(long long hi, long long lo, FxScale f) {
+    // 64-bit integers do not fit a float64: 26 low bits apart, the four pieces added in double-double
+    const long long hh = hi >> 26, hl = hi - hh * 67108864LL, lh = lo >> 26, ll = lo - lh * 67108864LL;
+    const double a = ldexp((double)hh, 26 - f.s1), bq = ldexp((double)hl, -f.s1);
+    const double c = ldexp((double)lh, 26 - f.s2), d = ldexp((double)ll, -f.s2);
+    // a >> bq >> c >> d in magnitude classes: two_sum cascade, smallest first
+    double s = c + d;
+    double e = d - (s - c);
+    double s2 = bq + s;
+    double bb = s2 - bq;
+    double e2 = (bq - (s2 - bb)) + (s - bb);
+    double s3 = a + s2;
+    bb = s3 - a;
+    double e3 = (a - (s3 - bb)) + (s2 - bb);
+    return s3 + (e3 + (e2 + e));
+}
+
 // fc.py:131 _estimate_friedrich_coefficients(x, m, r) -> coeff[0..m] (highest power first), NaN on failure.
 //   srt1  : functor, the first n-1 samples sorted ascending (signal = x[:-1])
 //   fw    : LDS double scratch >= 6*r + 16 + (r)*(m+1)
-// every thread returns the coefficients in `coef`
+// every thread returns the coefficients in `coef`; an ill-conditioned fit is ALSO recorded in df for the second pass,
+// which overwrites the columns this one wrote (fam_langevin_dd.h)
 template <class XS, class S1>
 TSFA_DEV void friedrich_coeffs(const Blk &b, XS xs, int n, S1 srt1, int m, int r,
-                               double *fw, double *coef) {
+                               double *fw, double *coef, const FrDefer &df) {
     for (int k = 0; k <= m; ++k) coef[k] = TSFA_NAN;
     const int ns = n - 1;
     if (ns < 1 || r < 1 || r > TSFA_FRIEDRICH_MAX_R || m < 1 || m > TSFA_FRIEDRICH_MAX_M) return;
@@ -246,7 +298,7 @@ TSFA_DEV void friedrich_coeffs(const Blk &b, XS xs, int n, S1 srt1, int m, int r
     double *sy = sx + r;                // r
     double *cnt = sy + r;               // r
     double *flag = cnt + r;             // 1
-    double *A = flag + 1;               // r * (m+1)
+    double *A = flag + 1;               // r * (m+1)   (the low parts of the bin sums live here until the means exist)
     double *yv = A + r * (m + 1);       // r
     double *cc = yv + r;                // m + 1
     double *tmp = cc + (m + 1);         // r
@@ -256,7 +308,9 @@ TSFA_DEV void friedrich_coeffs(const Blk &b, XS xs, int n, S1 srt1, int m, int r
         const double q = np_linspace_at(0.0, 1.0, r + 1, j);
         edges[j] = pd_quantile_sorted(srt1, ns, q);
     }
-    for (int j = b.tid; j < r; j += b.nt) { sx[j] = 0.0; sy[j] = 0.0; cnt[j] = 0.0; }
+    long long *isx = (long long *)(void *)sx, *isy = (long long *)(void *)sy, *icnt = (long long *)(void *)cnt,
+              *isxl = (long long *)(void *)A, *isyl = isxl + r;
+    for (int j = b.tid; j < r; j += b.nt) { isx[j] = 0; isy[j] = 0; icnt[j] = 0; isxl[j] = 0; isyl[j] = 0; }
     if (b.tid == 0) flag[0] = 0.0;
     blk_sync();
     double bad = 0.0;
@@ -264,21 +318,12 @@ TSFA_DEV void friedrich_coeffs(const Blk &b, XS xs, int n, S1 srt1, int m, int r
     bad = blk_sum(b, bad);
     if (bad > 0.0) return;
     // bin index = #{edges < x} - 1, with x == edges[0] -> bin 0  (pandas _bins_to_cuts, right=True, include_lowest)
-#if TSFA_GPU
     {
-        // Bin sums by LDS atomics, made independent of the order in which the threads arrive: the addends are converted
-        // to 64-bit fixed point (a power-of-two scale chosen so that even the sum of all |values| stays below 2^61) and
-        // added as integers -- exact, hence associative.  The quantum is 2^-(61 - log2 n) of max|x| (1e-15 at n = 1024),
-        // the precision a float64 sum of these values has anyway; float atomics made the last bits of the Friedrich
-        // coefficients differ from run to run.
         double amax = fmax(fabs(srt1(0)), fabs(srt1(ns - 1)));
         amax = fmax(amax, fabs(xs[n - 1]));
-        int e2 = 0, bits = 1;
-        (void)frexp(amax, &e2);              // amax < 2^e2, |delta| < 2^(e2 + 1)
+        int bits = 1;
         while ((1 << bits) < n) ++bits;
-        const double scale = ldexp(1.0, 60 - bits - e2), inv_scale = ldexp(1.0, -(60 - bits - e2));
-        unsigned long long *isx = (unsigned long long *)(void *)sx, *isy = (unsigned long long *)(void *)sy,
-                           *icnt = (unsigned long long *)(void *)cnt;
+        const FxScale fx = fx_scale(amax, bits), fy = fx_scale(2.0 * amax, bits);   // |delta| <= 2 max|x|
         for (int i = b.tid; i < ns; i += b.nt) {
             const double x = xs[i];
             int lo = 0, hi = r + 1;  // count of edges < x
@@ -290,49 +335,44 @@ TSFA_DEV void friedrich_coeffs(const Blk &b, XS xs, int n, S1 srt1, int m, int r
             if (x == edges[0]) bin = 0;
             if (bin < 0 || bin >= r) continue;
             const double dlt = xs[i + 1] - xs[i];
-            atomicAdd(&isx[bin], (unsigned long long)(long long)rint(x * scale));
-            atomicAdd(&isy[bin], (unsigned long long)(long long)rint(dlt * scale));
-            atomicAdd(&icnt[bin], 1ULL);
+            long long xh, xl, yh, yl;
+            fx_split(x, fx, xh, xl);
+            fx_split(dlt, fy, yh, yl);
+#if TSFA_GPU
+            atomicAdd((unsigned long long *)&isx[bin], (unsigned long long)xh);
+            atomicAdd((unsigned long long *)&isy[bin], (unsigned long long)yh);
+            if (xl != 0) atomicAdd((unsigned long long *)&isxl[bin], (unsigned long long)xl);
+            if (yl != 0) atomicAdd((unsigned long long *)&isyl[bin], (unsigned long long)yl);
+            atomicAdd((unsigned long long *)&icnt[bin], 1ULL);
+#else
+            isx[bin] += xh; isy[bin] += yh; isxl[bin] += xl; isyl[bin] += yl; icnt[bin] += 1;
+#endif
         }
         blk_sync();
-        for (int j = b.tid; j < r; j += b.nt) {  // back to float64 sums (0.0 bit pattern == integer 0: empty bins stay 0)
-            const double vx = (double)(long long)isx[j] * inv_scale, vy = (double)(long long)isy[j] * inv_scale;
+        for (int j = b.tid; j < r; j += b.nt) {  // back to float64 sums
+            const double vx = fx_value(isx[j], isxl[j], fx), vy = fx_value(isy[j], isyl[j], fy);
             const double vc = (double)icnt[j];
             sx[j] = vx; sy[j] = vy; cnt[j] = vc;
         }
         blk_sync();
     }
-#else
-    for (int i = b.tid; i < ns; i += b.nt) {
-        const double x = xs[i];
-        int lo = 0, hi = r + 1;  // count of edges < x
-        while (lo < hi) {
-            const int mid = (lo + hi) >> 1;
-            if (edges[mid] < x) lo = mid + 1; else hi = mid;
-        }
-        int bin = lo - 1;
-        if (x == edges[0]) bin = 0;
-        if (bin < 0 || bin >= r) continue;
-        const double dlt = xs[i + 1] - xs[i];
-        sx[bin] += x; sy[bin] += dlt; cnt[bin] += 1.0;
-    }
-    blk_sync();
-#endif
+    const int rmax = (df.slot_doubles - TSFA_PF_HDR) / 2;
 #if TSFA_GPU
     // np.polyfit(x_mean, y_mean, deg=m): scaled Vandermonde + least squares.  The r <= 64 bins are the lanes of
     // wavefront 0: every lane keeps its row of the design in registers and the Householder reflections are
     // wavefront reductions (the serial LDS version below costs ~1500 dependent LDS round trips).
-    bool wave_done = false;
     if (b.tid < 64) {
         const int lane = b.tid;
         const bool has = (lane < r) && (cnt[lane < r ? lane : 0] > 0.0);
         const unsigned long long mask = __ballot(has);
         const int k = __popcll(mask);
         const int cols = m + 1;
+        const int row = has ? __popcll(mask & ((1ull << lane) - 1ull)) : 1000;
+        const double xm = has ? sx[lane] / cnt[lane] : 0.0;
+        const double ym = has ? sy[lane] / cnt[lane] : 0.0;
+        bool defer = (k < cols);    // fewer bins than coefficients: the minimum-norm fit of the second pass
         if (k >= cols) {
-            const int row = has ? __popcll(mask & ((1ull << lane) - 1ull)) : 1000;
-            const double xm = has ? sx[lane] / cnt[lane] : 0.0;
-            double yrow = has ? sy[lane] / cnt[lane] : 0.0;
+            double yrow = ym;
             double a[TSFA_FRIEDRICH_MAX_M + 1], scale[TSFA_FRIEDRICH_MAX_M + 1], R[TSFA_FRIEDRICH_MAX_M + 1][TSFA_FRIEDRICH_MAX_M + 1],
                 qy[TSFA_FRIEDRICH_MAX_M + 1];
 #pragma unroll
@@ -348,6 +388,7 @@ TSFA_DEV void friedrich_coeffs(const Blk &b, XS xs, int n, S1 srt1, int m, int r
                     if (!has) a[c] = 0.0;
                 }
             }
+            double rmin = TSFA_INF, rbig = 0.0;
 #pragma unroll
             for (int kk = 0; kk <= TSFA_FRIEDRICH_MAX_M; ++kk) {
                 if (kk < cols) {
@@ -372,6 +413,8 @@ TSFA_DEV void friedrich_coeffs(const Blk &b, XS xs, int n, S1 srt1, int m, int r
                     } else {
                         R[kk][kk] = akk;
                     }
+                    rmin = fmin(rmin, fabs(R[kk][kk]));
+                    rbig = fmax(rbig, fabs(R[kk][kk]));
 #pragma unroll
                     for (int j = 0; j <= TSFA_FRIEDRICH_MAX_M; ++j)
                         if (j > kk && j < cols) R[kk][j] = wave_sum((row == kk) ? a[j] : 0.0);
@@ -396,19 +439,29 @@ TSFA_DEV void friedrich_coeffs(const Blk &b, XS xs, int n, S1 srt1, int m, int r
                     if (c < cols) cc[c] = sol[c] / scale[c];
                 flag[0] = 1.0;
             }
-            wave_done = true;
+            defer = (rmin < TSFA_PF_FLAG * rbig);   // false for NaN: a non-finite fit stays what it is
+        }
+        if (defer && k >= 1) {
+            if (df.buf != nullptr && r <= rmax) {
+                int slot = 0;
+                if (lane == 0) slot = atomicAdd(df.count, 1);
+                slot = __shfl(slot, 0);
+                double *rec = df.buf + (size_t)slot * (size_t)df.slot_doubles;
+                if (lane == 0) { rec[0] = (double)df.sidx; rec[1] = (double)df.spec; rec[2] = (double)k; }
+                if (has) { rec[TSFA_PF_HDR + row] = xm; rec[TSFA_PF_HDR + rmax + row] = ym; }
+            }   // (no buffer: the float64 fit stands; the library always passes one)
         }
     }
-    if (b.tid == 0 && !wave_done) {
 #else
     if (b.tid == 0) {
-#endif
         // np.polyfit(x_mean, y_mean, deg=m): scaled Vandermonde + lstsq
         int k = 0;
+        double ysave[TSFA_FRIEDRICH_MAX_R];
         for (int j = 0; j < r; ++j) {
             if (cnt[j] > 0.0) {
                 tmp[k] = sx[j] / cnt[j];
                 yv[k] = sy[j] / cnt[j];
+                ysave[k] = yv[k];
                 ++k;
             }
         }
@@ -425,10 +478,31 @@ TSFA_DEV void friedrich_coeffs(const Blk &b, XS xs, int n, S1 srt1, int m, int r
             scale[c] = sqrt(ss);
             for (int i = 0; i < k; ++i) A[i + c * k] /= scale[c];
         }
-        small_lstsq(A, k, cols, yv, cc, tmp);
-        for (int c = 0; c < cols; ++c) cc[c] = cc[c] / scale[c];
-        flag[0] = 1.0;
+        bool defer = (k < cols);
+        if (k >= cols) {
+            double xsave[TSFA_FRIEDRICH_MAX_R];
+            for (int i = 0; i < k; ++i) xsave[i] = tmp[i];
+            small_lstsq(A, k, cols, yv, cc, tmp);
+            for (int c = 0; c < cols; ++c) cc[c] = cc[c] / scale[c];
+            flag[0] = 1.0;
+            double rmin = TSFA_INF, rbig = 0.0;
+            for (int c = 0; c < cols; ++c) {   // the diagonal of R
+                rmin = fmin(rmin, fabs(A[c + c * k]));
+                rbig = fmax(rbig, fabs(A[c + c * k]));
+            }
+            defer = (rmin < TSFA_PF_FLAG * rbig);
+            for (int i = 0; i < k; ++i) tmp[i] = xsave[i];
+        }
+        if (defer && k >= 1) {
+            (void)rmax;
+            double cf[TSFA_PF_MAXC];
+            const double *tx = tmp;
+            polyfit_svd_dd([=](int i) { return tx[i]; }, [=](int i) { return ysave[i]; }, k, m, cf);
+            for (int c = 0; c < cols; ++c) cc[c] = cf[c];
+            flag[0] = 1.0;
+        }
     }
+#endif
     blk_sync();
     if (flag[0] != 0.0)
         for (int c = 0; c <= m; ++c) coef[c] = cc[c];
@@ -560,7 +634,8 @@ TSFA_DEV void sort_epilogue(const Blk &b, const TsfaSpec *specs, int first, int 
 template <class ST>
 TSFA_DEV void fam_sort_series(const Blk &b, const ST *xs_raw, int n, const TsfaSpec *specs, int nspecs,
                               double *out_row, ST *srt_raw, double *w, int *iw, const TsfaCqPlan &cqplan, double *cq,
-                              TsfaSpec *stage, int n_loop = -1, double *ctx = nullptr, int w_doubles = 1280) {
+                              TsfaSpec *stage, int n_loop = -1, double *ctx = nullptr, int w_doubles = 1280,
+                              FrDefer df = FrDefer{nullptr, nullptr, TSFA_PF_HDR + 2 * TSFA_FRIEDRICH_MAX_R, 0, 0}) {
     const int hist_words = 2 * w_doubles;  // iw aliases w: 32-bit words of the ordinal-pattern histogram
     // n_loop columns go through the column loop; the rest are evaluated by sort_epilogue (lane = column)
     const int nloop = (n_loop >= 0 && ctx != nullptr) ? n_loop : nspecs;
@@ -830,7 +905,8 @@ TSFA_DEV void fam_sort_series(const Blk &b, const ST *xs_raw, int n, const TsfaS
                     pos = lo;
                 }
                 const XsView<ST> sr = srt;
-                friedrich_coeffs(b, xs, n, [=](int i) { return sr[i < pos ? i : i + 1]; }, m, r, w, fr_coef);
+                df.spec = s;
+                friedrich_coeffs(b, xs, n, [=](int i) { return sr[i < pos ? i : i + 1]; }, m, r, w, fr_coef, df);
                 fr_valid = true;
                 fr_m = m;
                 fr_r = r;

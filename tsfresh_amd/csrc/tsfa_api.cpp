@@ -76,7 +76,7 @@ struct tsfa_plan {
     int *d_cols = nullptr, *d_coeff = nullptr;
     double *d_dectab = nullptr, *d_twc = nullptr, *d_tws = nullptr;
     long long *d_stats = nullptr;
-    DevBuf values, offsets, out, gscratch, times, deg_list, sel, long_scratch;
+    DevBuf values, offsets, out, gscratch, times, deg_list, sel, long_scratch, pf_buf;
     int *d_deg_count = nullptr;
     int *d_cursor = nullptr;                    // per-launch-group fill cursors (k_class_fill)
     hipStream_t s_in = nullptr, s_out = nullptr;  // copy-in / copy-out streams of the host pipeline
@@ -151,6 +151,7 @@ void tsfa_plan_destroy(tsfa_plan *plan) {
     if (plan->d_deg_count) (void)hipFree(plan->d_deg_count);
     if (plan->d_cursor) (void)hipFree(plan->d_cursor);
     plan->deg_list.release();
+    plan->pf_buf.release();
     plan->sel.release();
     plan->long_scratch.release();
     for (int i = 0; i < TSFA_MAX_CHUNKS; ++i) {
@@ -239,7 +240,7 @@ int tsfa_plan_create(const tsfa_feature_spec *specs, int32_t n_specs, int32_t de
         ok = upload(dt, &plan->d_dectab) == 0 && upload(twc, &plan->d_twc) == 0 && upload(tws, &plan->d_tws) == 0;
     }
     if (ok) ok = hipMalloc((void **)&plan->d_stats, TSFA_LEN_STATS * sizeof(long long)) == hipSuccess;
-    if (ok) ok = hipMalloc((void **)&plan->d_deg_count, sizeof(int)) == hipSuccess;
+    if (ok) ok = hipMalloc((void **)&plan->d_deg_count, 2 * sizeof(int)) == hipSuccess;   // [k_ar_degenerate, k_langevin_dd]
     if (ok) ok = hipMalloc((void **)&plan->d_cursor, TSFA_N_LEN_CLASSES * sizeof(int)) == hipSuccess;
     if (ok) ok = hipStreamCreateWithFlags(&plan->s_in, hipStreamNonBlocking) == hipSuccess &&
                  hipStreamCreateWithFlags(&plan->s_out, hipStreamNonBlocking) == hipSuccess;
@@ -500,6 +501,12 @@ static int run_batch(tsfa_plan *plan, const void *d_values, int dtype, const dou
                 a.deg_list = (long long *)plan->deg_list.p;
                 a.deg_count = plan->d_deg_count;
                 HIP_TRY(hipMemsetAsync(plan->d_deg_count, 0, sizeof(int), fst));
+            } else if (f == TSFA_FAM_SORT && plan->hints[f].b > 0) {
+                // Langevin fits: ill-conditioned ones are recorded for the double-double pass (fam_langevin_dd.h)
+                a.pf_slot = tsfa_pf_slot_doubles(plan->hints[f].b);
+                a.pf_buf = (double *)plan->pf_buf.p;
+                a.pf_count = plan->d_deg_count + 1;
+                HIP_TRY(hipMemsetAsync(a.pf_count, 0, sizeof(int), fst));
             } else if (f == TSFA_FAM_ENTROPY) {
                 // one wavefront per 64-template row block, up to four per series; the symmetric sweep needs 12 B of
                 // LDS counters per sample
@@ -592,6 +599,7 @@ static int run_batch(tsfa_plan *plan, const void *d_values, int dtype, const dou
                 rc = use_long ? tsfa_launch_family_long(a) : tsfa_launch_family(a);
             }
             if (rc == 0 && f == TSFA_FAM_AR) rc = tsfa_launch_ar_degenerate(a);
+            if (rc == 0 && f == TSFA_FAM_SORT && a.pf_buf) rc = tsfa_launch_langevin_dd(a);
             if (rc) return fail(TSFA_ERR_HIP, std::string(fam_names[f]) + " launch failed: " +
                                                   (rc == -2 ? "no scratch slot" : hipGetErrorString((hipError_t)rc)));
         }
@@ -664,6 +672,9 @@ int tsfa_extract_windows(tsfa_plan *plan, const void *values, int32_t dtype, con
     const size_t esz = (dtype == TSFA_F32) ? 4 : 8;
     if (plan->deg_list.ensure((size_t)n_series * sizeof(long long)))
         return fail(TSFA_ERR_HIP, "hipMalloc failed for the k_ar_degenerate list");
+    if (plan->hints[TSFA_FAM_SORT].b > 0 &&
+        plan->pf_buf.ensure((size_t)n_series * (size_t)tsfa_pf_slot_doubles(plan->hints[TSFA_FAM_SORT].b) * sizeof(double)))
+        return fail(TSFA_ERR_HIP, "hipMalloc failed for the records of the Langevin second pass");
 
     if (space == TSFA_DEVICE) {
         hipStream_t st = stream ? (hipStream_t)stream : plan->stream;

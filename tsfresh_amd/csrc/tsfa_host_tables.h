@@ -158,7 +158,10 @@ static inline void tsfa_prepare_family(int fam, std::vector<TsfaSpec> &specs, Ts
             int m = 0, r = 0;
             if (s.calc == TSFA_C_FRIEDRICH_COEFFICIENTS) { m = (int)s.p[1]; r = (int)s.p[2]; }
             else if (s.calc == TSFA_C_MAX_LANGEVIN_FIXED_POINT) { m = (int)s.p[0]; r = (int)s.p[1]; }
-            if (r > 0 && r <= 64 && m >= 1 && m <= 3) h.a = std::max(h.a, 6 * r + 16 + r * (m + 1) + 8);
+            if (r > 0 && r <= 64 && m >= 1 && m <= 3) {
+                h.a = std::max(h.a, 6 * r + 16 + r * (m + 1) + 8);
+                h.b = std::max(h.b, r);   // b = largest bin count of a Langevin fit: sizes the records of the second pass
+            }
         }
         specs = loop;
         specs.insert(specs.end(), epi.begin(), epi.end());

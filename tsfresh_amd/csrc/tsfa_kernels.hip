@@ -164,7 +164,8 @@ __global__ void __launch_bounds__(512) k_trend(const T *__restrict__ values, con
 template <typename T>
 __global__ void __launch_bounds__(1024) k_sort(const T *__restrict__ values, const int64_t *__restrict__ starts, const int64_t *__restrict__ ends, int64_t n_series, const int *__restrict__ sel,
                        const TsfaSpec *__restrict__ specs, int nspecs, double *__restrict__ out, int64_t ld, int maxn,
-                       const TsfaCqPlan cqplan, int n_loop, int w_doubles TSFA_GS_PARAMS) {
+                       const TsfaCqPlan cqplan, int n_loop, int w_doubles, double *__restrict__ pf_buf,
+                       int *__restrict__ pf_count, int pf_slot TSFA_GS_PARAMS) {
     TSFA_SERIES_BEGIN
     const int64_t off = starts[sidx];
     const int n = (int)(ends[sidx] - off);
@@ -179,7 +180,7 @@ __global__ void __launch_bounds__(1024) k_sort(const T *__restrict__ values, con
         blk_sync();
     }
     fam_sort_series<T>(b, xs, n, specs, nspecs, out + sidx * ld, (T *)L.srt, L.w, L.iw, cqplan, L.cq, L.stage,
-                       n_loop, L.ctx, w_doubles);
+                       n_loop, L.ctx, w_doubles, FrDefer{pf_buf, pf_count, pf_slot, (long long)sidx, 0});
     TSFA_TICKS_END();
     TSFA_SERIES_END
 }
@@ -232,6 +233,37 @@ __global__ void __launch_bounds__(1024) k_ar(const T *__restrict__ values, const
 }
 
 #if !defined(TSFA_LONG)
+// second pass of the SORT family (fam_langevin_dd.h): one LANE per recorded fit, np.polyfit's scaled design + rank cut in
+// double-double; overwrites the friedrich_coefficients / max_langevin_fixed_point columns of the same (m, r) that k_sort
+// wrote from its float64 QR.
+__global__ void __launch_bounds__(64) k_langevin_dd(const double *__restrict__ pf_buf, const int *__restrict__ pf_count, int pf_slot,
+                     const TsfaSpec *__restrict__ specs, int nspecs, double *__restrict__ out, int64_t ld) {
+    const int cnt = *pf_count;
+    const int rmax = (pf_slot - TSFA_PF_HDR) / 2;
+    for (int i = blockIdx.x * 64 + threadIdx.x; i < cnt; i += gridDim.x * 64) {
+        const double *rec = pf_buf + (size_t)i * (size_t)pf_slot;
+        const int64_t sidx = (int64_t)rec[0];
+        const int sp0 = (int)rec[1], k = (int)rec[2];
+        const TsfaSpec s0 = specs[sp0];
+        int m, r;
+        if (s0.calc == TSFA_C_FRIEDRICH_COEFFICIENTS) { m = (int)s0.p[1]; r = (int)s0.p[2]; }
+        else { m = (int)s0.p[0]; r = (int)s0.p[1]; }
+        double coef[TSFA_PF_MAXC];
+        const double *xm = rec + TSFA_PF_HDR, *ym = rec + TSFA_PF_HDR + rmax;
+        polyfit_svd_dd([=](int j) { return xm[j]; }, [=](int j) { return ym[j]; }, k, m, coef);
+        double *row = out + sidx * ld;
+        for (int s = 0; s < nspecs; ++s) {
+            const TsfaSpec sp = specs[s];
+            if (sp.calc == TSFA_C_FRIEDRICH_COEFFICIENTS && (int)sp.p[1] == m && (int)sp.p[2] == r) {
+                const int c = (int)sp.p[0];
+                row[sp.col] = (c >= 0 && c <= m) ? coef[c] : TSFA_NAN;
+            } else if (sp.calc == TSFA_C_MAX_LANGEVIN_FIXED_POINT && (int)sp.p[0] == m && (int)sp.p[1] == r) {
+                row[sp.col] = max_real_root_deg3(coef, m + 1);
+            }
+        }
+    }
+}
+
 // second pass of the AR family (fam_ar_dd.h): the listed series, one workgroup each, double-double normal equations.
 // The list order is arbitrary (atomics); every listed series writes only its own row, so the result is not.
 template <typename T>
@@ -637,7 +669,7 @@ static int launch_all_t(const TsfaLaunch &a, const T *values) {
         const int wd = (a.hint_a >= 320) ? a.hint_a : 1280;
         const size_t lds = L.carve(nullptr, a.maxn, nt, (int)sizeof(T), wd);
         TSFA_KLAUNCH(k_sort<T>, lds, values, a.starts, a.ends, a.n_series, a.sel, a.specs, a.nspecs, a.out, a.ld, a.maxn, a.cq,
-                     a.hint_c, wd);
+                     a.hint_c, wd, a.pf_buf, a.pf_count, a.pf_slot);
     } else if (a.fam == TSFA_FAM_SPECTRAL) {
         SpectralLds L;
         const size_t lds = L.carve(nullptr, a.maxn, a.dft_n, (int)sizeof(T));
@@ -709,6 +741,16 @@ int tsfa_launch_ar_degenerate(const TsfaLaunch &a) {
     if (!(a.hint_c || a.ar_has_coef)) return 0;  // no ADF / ar_coefficient column: nothing can degenerate
     if (a.dtype == 0) return launch_ar_degenerate_t<float>(a, (const float *)a.values);
     return launch_ar_degenerate_t<double>(a, (const double *)a.values);
+}
+
+// second pass of the SORT family over the fits k_sort recorded (after tsfa_launch_family / _long of TSFA_FAM_SORT)
+int tsfa_launch_langevin_dd(const TsfaLaunch &a) {
+    if (!a.pf_buf) return 0;   // the plan holds no Langevin fit
+    hipStream_t st = (hipStream_t)a.stream;
+    const unsigned grid = (unsigned)std::min<int64_t>((a.n_series + 63) / 64, 4096);
+    k_langevin_dd<<<grid, 64, 0, st>>>(a.pf_buf, a.pf_count, a.pf_slot, a.specs, a.nspecs, a.out, a.ld);
+    TSFA_LAUNCH_CHECK();
+    return 0;
 }
 
 size_t tsfa_entropy_lds_bytes(int maxn, int with_cnt) {

@@ -52,6 +52,9 @@ struct TsfaLaunch {
     int ar_has_coef;        // AR: the plan holds ar_coefficient columns
     long long *deg_list;    // AR: series listed for the double-double second pass ((index << 2) | calculator bits) ...
     int *deg_count;         // ... and their number (device; zeroed before the launch)
+    double *pf_buf;         // SORT: records of the Langevin fits left to k_langevin_dd (fam_langevin_dd.h) ...
+    int *pf_count;          // ... their number (device; zeroed before the launch) ...
+    int pf_slot;            // ... and the doubles per record (tsfa_pf_slot_doubles)
     int cwt_rowv;           // CWT peaks: second CWT row resident in LDS
     int hint_a, hint_b, hint_c, hint_d, hint_e;  // tsfa_prepare_family (BASIC, SORT, SPECTRAL, AR)
     unsigned char *long_scratch;  // HBM scratch of the long-series build (tsfa_launch_family_long) ...
@@ -80,6 +83,7 @@ size_t tsfa_seq_lds_bytes(const TsfaSeqGroup &g);
 int tsfa_launch_family(const TsfaLaunch &a);
 int tsfa_launch_family_long(const TsfaLaunch &a);   // working set in a.long_scratch instead of LDS (any length <= 65535)
 int tsfa_launch_ar_degenerate(const TsfaLaunch &a);
+int tsfa_launch_langevin_dd(const TsfaLaunch &a);     // second pass of TSFA_FAM_SORT: the ill-conditioned Langevin fits k_sort recorded
 int tsfa_launch_order_stats(const TsfaLaunch &a);    // SORT family holding only median / quantile columns, maxn <= 2048  // second pass of TSFA_FAM_AR over the series the first listed
 int tsfa_launch_cwt(const TsfaCwtLaunch &a);
 int tsfa_launch_fill_nan(double *out, int64_t n_rows, int64_t n_cols, int64_t ld, void *stream);

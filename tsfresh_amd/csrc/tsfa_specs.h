@@ -172,4 +172,9 @@ struct TsfaSpec {
     double p[4];
 };
 
+// record of a Langevin fit that k_sort leaves to k_langevin_dd (fam_langevin_dd.h), in the plan's buffer:
+// [series index, spec index, rows k, x_mean[rmax], y_mean[rmax]] as doubles
+#define TSFA_PF_HDR 3
+static inline int tsfa_pf_slot_doubles(int rmax) { return TSFA_PF_HDR + 2 * rmax; }
+
 #endif
