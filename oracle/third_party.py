@@ -109,10 +109,13 @@ def _add_const(X, prepend):
     return np.column_stack([ones, X]) if prepend else np.column_stack([X, ones])
 
 
-def adfuller_aic(x):
+def adfuller_aic(x, perturb=None):
     """adfuller(x, autolag="AIC") -> (teststat, pvalue, usedlag); raises ValueError like statsmodels
     (stattools.py:160-380, _autolag :63-147).  AIC = -2 llf + 2 rank (linear_model.py:1827 with df_model = rank -
-    k_constant), llf of OLS.loglike (:896-903), t value = params[0] / sqrt(ssr / (nobs - rank) * ncov[0, 0])."""
+    k_constant), llf of OLS.loglike (:896-903), t value = params[0] / sqrt(ssr / (nobs - rank) * ncov[0, 0]).
+    perturb (tests/parity.py only): a function applied to every design matrix before it is solved -- the probe that
+    measures how far last-bit changes of the design move the result."""
+    perturb = perturb or (lambda X: X)
     x = np.asarray(x, dtype=np.float64)
     nobs = x.shape[0]
     ntrend = 1
@@ -134,7 +137,7 @@ def adfuller_aic(x):
     best = None
     with np.errstate(divide="ignore", invalid="ignore"):
         for lag in range(startlag, startlag + maxlag + 1):
-            _, ssr, rank, _ = _ols(y, full[:, :lag])
+            _, ssr, rank, _ = _ols(y, perturb(full[:, :lag]))
             llf = -n1 / 2.0 * np.log(2 * np.pi) - n1 / 2.0 * np.log(ssr / n1) - n1 / 2.0
             aic = -2 * llf + 2 * rank
             if best is None or (aic, lag) < best:
@@ -143,13 +146,13 @@ def adfuller_aic(x):
         Z, y = design(usedlag)
         n2 = len(y)
         X = _add_const(Z[:, : usedlag + 1], prepend=False)
-        beta, ssr, rank, ncov = _ols(y, X)
+        beta, ssr, rank, ncov = _ols(y, perturb(X))
         sigma2 = ssr / (n2 - rank)
         tstat = beta[0] / np.sqrt(sigma2 * ncov[0, 0])
     return tstat, mackinnonp_c(tstat), usedlag
 
 
-def autoreg_params(x, k):
+def autoreg_params(x, k, perturb=None):
     """AutoReg(x, lags=k, trend="c").fit().params = conditional OLS; raises ValueError/ZeroDivisionError when
     statsmodels (0.12.2) cannot estimate the model (n < 2k + 2)."""
     x = np.asarray(x, dtype=np.float64)
@@ -163,7 +166,7 @@ def autoreg_params(x, k):
         raise ZeroDivisionError("division by zero")
     rows = np.arange(k, n)
     X = np.column_stack([np.ones(nobs)] + [x[rows - j] for j in range(1, k + 1)])
-    return _ols(x[rows], X)[0]
+    return _ols(x[rows], X if perturb is None else perturb(X))[0]
 
 
 # ------------------------------------------------------------------------------------------------

@@ -18,6 +18,20 @@ from tsfresh_amd.feature_extraction import settings  # noqa: E402
 
 
 def make_series(rng, n):
+    """A structured or random series; a third of them are then moved off zero and rescaled (offset 1e2 .. 1e9 times
+    the spread, scale 1e-6 .. 1e6): the rank cuts of np.polyfit and statsmodels' pinv live there (round 2 never
+    generated a non-zero mean, which is how the Langevin fit's missing truncation got through 80 clean rounds)."""
+    x = make_base_series(rng, n)
+    u = rng.random()
+    if u < 0.33:
+        spread = float(np.std(x)) or 1.0
+        x = x + spread * 10.0 ** rng.uniform(2, 9) * rng.choice([-1.0, 1.0])
+    if u < 0.15 or u > 0.85:
+        x = x * 10.0 ** rng.uniform(-6, 6)
+    return x
+
+
+def make_base_series(rng, n):
     k = rng.integers(0, 12)
     if k == 7:  # ramp (rank-deficient regressions)
         return rng.uniform(-5, 5) + rng.uniform(-2, 2) * np.arange(n)

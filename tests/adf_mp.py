@@ -64,3 +64,53 @@ def autoreg_params_mp(x, k):
     X = [[mp.mpf(1)] + [x[t - j] for j in range(1, k + 1)] for t in range(k, n)]
     beta, _, _ = _ls(X, [x[t] for t in range(k, n)])
     return np.array([float(b) for b in beta])
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# statsmodels' pinv semantics in many digits: singular values <= 1e-15 s_max dropped, rank = #{s > s_max p eps}
+# ---------------------------------------------------------------------------------------------------------------------
+def pinv_ols_mp(X, y, dps=120):
+    """OLS(y, X).fit(method="pinv") evaluated in `dps` digits from the eigen-decomposition of X^T X (the squared
+    condition number needs the digits).  -> (beta, ssr, rank, cov00, s / s_max) as floats / float arrays."""
+    old = mp.mp.dps
+    mp.mp.dps = dps
+    try:
+        n, p = len(X), len(X[0])
+        Xm = [[mp.mpf(float(v)) for v in r] for r in X]
+        ym = [mp.mpf(float(v)) for v in y]
+        G = mp.matrix(p, p)
+        g = mp.matrix(p, 1)
+        for a in range(p):
+            for c in range(a + 1):
+                G[a, c] = G[c, a] = mp.fsum(Xm[t][a] * Xm[t][c] for t in range(n))
+            g[a] = mp.fsum(Xm[t][a] * ym[t] for t in range(n))
+        lam, V = mp.eigsy(G)
+        lmax = max(lam)
+        smax = mp.sqrt(lmax)
+        eps = mp.mpf(2) ** -52
+        beta = [mp.mpf(0)] * p
+        cov00 = mp.mpf(0)
+        rank = 0
+        ratios = []
+        for i in range(p):
+            s = mp.sqrt(lam[i]) if lam[i] > 0 else mp.mpf(0)
+            ratios.append(float(s / smax))
+            if s > smax * p * eps:
+                rank += 1
+            if s > mp.mpf("1e-15") * smax:
+                w = mp.fsum(V[a, i] * g[a] for a in range(p)) / lam[i]
+                for a in range(p):
+                    beta[a] += V[a, i] * w
+                cov00 += V[0, i] ** 2 / lam[i]
+        ssr = mp.fsum((ym[t] - mp.fsum(Xm[t][a] * beta[a] for a in range(p))) ** 2 for t in range(n))
+        return [float(v) for v in beta], float(ssr), rank, float(cov00), sorted(ratios, reverse=True)
+    finally:
+        mp.mp.dps = old
+
+
+def autoreg_params_pinv_mp(x, k):
+    x = np.asarray(x, dtype=np.float64)
+    n = len(x)
+    rows = np.arange(k, n)
+    X = np.column_stack([np.ones(n - k)] + [x[rows - j] for j in range(1, k + 1)])
+    return pinv_ols_mp(X.tolist(), x[rows].tolist())

@@ -6,7 +6,8 @@ within 1e-6 relative).
 * integer / boolean / count features (INTEGER_FEATURES) must be EXACTLY equal.
 * every other feature:  |got - want| <= 1e-6 * |want| + atol, where atol is a tiny absolute floor scaled by the
   magnitude of the series (results that are mathematically ~0, e.g. the imaginary part of a real FFT bin, have no
-  meaningful relative error):  atol = 1e-9 * scale,  scale = max(1, max|x|) ** power(feature)  (sum|x| for FFT bins).
+  meaningful relative error):  atol = 1e-9 * max|x| ** dimension(feature)  (1e-10 * sum|x| for FFT bins); dimensionless
+  features (lag coefficients, entropies, test statistics, p-values, ratios): 1e-9.
 * NaN must match NaN, +-inf must match.
 
 EXCLUSIONS.  A cell is skipped only where the REFERENCE's value is a function of round-off, i.e. where no
@@ -22,12 +23,21 @@ can bound it.
   R2  fft_coefficient "angle" of a bin whose magnitude is round-off (|X_k| < 1e-9 * sum|x|).
   R3  fourier_entropy / spkt_welch_density of a constant series (the detrended PSD is pure round-off).
   R4  ar_coefficient / augmented_dickey_fuller when the regression design (as statsmodels builds it) has a singular
-      value inside (5e-16, 1e-8) * s_max: statsmodels' pinv cuts at 1e-15 * s_max, so such a value is either LAPACK
-      round-off that gets inverted (const_1024: the reference returns -0.0754 for coefficients whose minimum-norm
-      value is 0.0091) or a genuine direction whose solution the float64 SVD resolves to eps / 1e-8 at best, measured: 3e-6 off at 1e-9
-      (tiny_noise_ramp_300: exact rational arithmetic gives usedlag 12, the reference 0 -- see DESIGN.md 4.3).
-      Exactly rank-deficient designs whose round-off stays below the cut (constant / linear / periodic series up to a
-      few hundred samples) are NOT excluded: the minimum-norm solution is well defined and must match.
+      value inside (5e-16, 3e-15) * s_max -- or, for the rank count of a wide lag-search design, within 30 % of
+      matrix_rank's tolerance p * eps: statsmodels' pinv cuts at 1e-15 * s_max, LAPACK's small singular values carry
+      an absolute error of a few eps * s_max, so whether such a direction is inverted is round-off (const_1024: the
+      reference returns -0.0754 for coefficients whose minimum-norm value is 0.0091) -- or when the rank its float64
+      singular values give differs from the rank of the same singular values computed in extended precision (a
+      constant series of 1000 samples: s_2 = 4.3e-15 s_max for a direction that does not exist).  Everything else is
+      COMPARED.
+      Designs that are merely ill-conditioned get the tolerance the reference's own arithmetic has (tolerance_for):
+      the spread of its result over six copies of the design whose entries are perturbed by 4 eps (the backward
+      error of an SVD), times 4.  `usedlag` is an argmin over AIC values and has no tolerance: it is skipped when the
+      probes disagree about it (tiny_noise_ramp_300 = t + 1e-9 noise, cond 5e11: exact rational arithmetic gives 12 --
+      what the double-double pass returns -- the reference 0, its probes anything from 0 to 16), and
+      then so are teststat / pvalue, which belong to the chosen lag.  Exactly rank-deficient designs whose round-off
+      stays below the cut (constant / linear / periodic series) and the pinv TRUNCATION regime (|mean| >> spread: 1e8 +
+      N(0,1), epoch seconds) are compared like any other.
   R5  augmented_dickey_fuller when a lag-search regression fits perfectly (ssr <= 1e-18 * yy, yy > 0): the AIC is
       n log(round-off) and the t statistic (round-off)/(round-off); the kernels return AIC = -inf and 0/0 = NaN or
       x/0 = +-inf there (tests/test_degenerate.py pins that behaviour).
@@ -61,6 +71,7 @@ INTEGER_FEATURES = {
     "number_cwt_peaks",
 }
 RTOL = 1e-6
+EPS = float(np.finfo(np.float64).eps)
 
 
 def feature_of(col):
@@ -86,14 +97,107 @@ def _has_window_ties(x, dim):
     return False
 
 
+def _singular_ratios_accurate(X):
+    """s / s_max of X by one-sided Jacobi in extended precision (x87 long double, eps 1e-19): resolves what LAPACK's
+    float64 SVD cannot -- whether a computed singular value of 4e-15 s_max belongs to a direction that exists or is the
+    round-off image of an exactly dependent column."""
+    A = np.array(X, dtype=np.longdouble)
+    p = A.shape[1]
+    for _ in range(30):
+        rotated = False
+        for i in range(p - 1):
+            for j in range(i + 1, p):
+                al, be, ga = A[:, i] @ A[:, i], A[:, j] @ A[:, j], A[:, i] @ A[:, j]
+                if not abs(ga) > np.longdouble(1e-18) * np.sqrt(al * be):
+                    continue
+                rotated = True
+                ze = (be - al) / (2 * ga)
+                t = np.sign(ze) / (abs(ze) + np.sqrt(1 + ze * ze)) if ze != 0 else np.longdouble(1)
+                c = 1 / np.sqrt(1 + t * t)
+                sn = c * t
+                ai, aj = A[:, i].copy(), A[:, j].copy()
+                A[:, i], A[:, j] = c * ai - sn * aj, sn * ai + c * aj
+        if not rotated:
+            break
+    sv = np.sort(np.sqrt((A * A).sum(axis=0)).astype(np.float64))[::-1]
+    return sv / sv[0] if sv[0] > 0 else sv
+
+
 def _pinv_unstable(X):
+    """R4: is the RANK statsmodels' pinv / matrix_rank see decided by round-off?  Either a float64 singular value lies in
+    the band around a cut, or the rank the float64 singular values give differs from the rank of the accurately
+    computed ones (a constant series of 1000 samples: LAPACK returns s_2 = 4.3e-15 s_max for a direction that does not
+    exist, pinv inverts it, the reference's coefficients are noise around the minimum-norm values)."""
     if X.size == 0 or X.shape[1] == 0:
         return False
     s = np.linalg.svd(X, compute_uv=False)
     if not np.isfinite(s).all() or s[0] == 0:
         return False
     r = s / s[0]
-    return bool(np.any((r > 5e-16) & (r < 1e-8)))
+    rank_tol = X.shape[1] * EPS     # np.linalg.matrix_rank(np.diag(s)): counted in the AIC / degrees of freedom
+    if np.any((r > 5e-16) & (r < 3e-15)) or np.any((r > rank_tol / 1.3) & (r < rank_tol * 1.3)):
+        return True
+    if np.any(r < 1e-12):
+        ra = _singular_ratios_accurate(X)
+        return bool(np.sum(ra > 1e-15) != np.sum(r > 1e-15) or np.sum(ra > rank_tol) != np.sum(r > rank_tol))
+    return False
+
+
+PROBES = 6
+PROBE_EPS = 4.0
+PROBE_FACTOR = 4.0
+
+
+def _probe(seed):
+    rng = np.random.default_rng(1000 + seed)
+    return lambda X: X * (1.0 + PROBE_EPS * EPS * rng.uniform(-1.0, 1.0, size=X.shape))
+
+
+def _cond_raw(X):
+    s = np.linalg.svd(X, compute_uv=False)
+    kept = s[s > 1e-15 * s[0]] if s[0] > 0 else s
+    return float(s[0] / kept[-1]) if len(kept) else np.inf
+
+
+def _ar_probe(x, k):
+    """-> per-coefficient spread of AutoReg's parameters over the probes (None: well conditioned, no probe needed)."""
+    from oracle import third_party as tp
+    X = _ar_design(x, k)
+    if X is None or not np.all(np.isfinite(X)) or EPS * _cond_raw(X) < 1e-9:
+        return None
+    try:
+        base = tp.autoreg_params(x, k)
+        runs = [tp.autoreg_params(x, k, perturb=_probe(i)) for i in range(PROBES)]
+    except (ValueError, ZeroDivisionError, np.linalg.LinAlgError):
+        return None
+    return np.max(np.abs(np.array(runs) - base), axis=0)
+
+
+def _adf_probe(x):
+    """-> (lag_stable, spread of teststat, spread of pvalue) over the probes, or None (well conditioned)."""
+    from oracle import third_party as tp
+    n = len(x)
+    maxlag = min(n // 2 - 2, int(np.ceil(12.0 * np.power(n / 100.0, 0.25))))
+    if maxlag < 0 or not np.all(np.isfinite(x)):
+        return None
+    d = np.diff(x)
+    rows = np.arange(maxlag, len(d))
+    full = tp._add_const(np.column_stack([x[rows]] + [d[rows - j] for j in range(1, maxlag + 1)]), prepend=True)
+    if EPS * _cond_raw(full) < 1e-9:
+        return None
+    import warnings
+    with warnings.catch_warnings(), np.errstate(all="ignore"):
+        warnings.simplefilter("ignore")
+        try:
+            base = tp.adfuller_aic(x)
+            runs = [tp.adfuller_aic(x, perturb=_probe(i)) for i in range(PROBES)]
+        except (ValueError, np.linalg.LinAlgError):
+            return None
+    stable = all(r[2] == base[2] for r in runs)
+    with np.errstate(all="ignore"):
+        ds = max(abs(r[0] - base[0]) for r in runs)
+        dp = max(abs(r[1] - base[1]) for r in runs)
+    return stable, (ds if np.isfinite(ds) else np.inf), (dp if np.isfinite(dp) else np.inf)
 
 
 def _ar_design(x, k):
@@ -119,8 +223,12 @@ def _adf_state(x):
     yy = float(y @ y)
     perfect = False
     if yy > 0:
-        beta = np.linalg.lstsq(full, y, rcond=None)[0]
-        r = y - full @ beta
+        # columns scaled to unit norm: on a raw design with a 1e9 level column the residual of a PERFECT fit is
+        # round-off of size eps * 1e9 * |beta|, not zero (epoch seconds: the diffs are exactly 1)
+        nrm = np.sqrt((full * full).sum(axis=0))
+        fs = full / np.where(nrm > 0, nrm, 1.0)
+        beta = np.linalg.lstsq(fs, y, rcond=None)[0]
+        r = y - fs @ beta
         perfect = float(r @ r) <= 1e-18 * yy
     return _pinv_unstable(full), perfect
 
@@ -280,7 +388,10 @@ def excluded(col, x, simd_golden=False, facts=None, rvalue=None):
         return X is not None and facts.get(("ar_unst", k), lambda: _pinv_unstable(X))                    # R4
     if f == "augmented_dickey_fuller":
         unstable, perfect = facts.get("adf", lambda: _adf_state(xv))
-        return unstable or perfect                                                                       # R4, R5
+        if unstable or perfect:
+            return True                                                                                   # R4, R5
+        probe = facts.get("adf_probe", lambda: _adf_probe(xv))
+        return probe is not None and not probe[0]                                                        # R4: the lag
     if f in ("max_langevin_fixed_point", "friedrich_coefficients"):
         m, r = _param(col, "m", int), _param(col, "r", float)
         r = int(r) if float(r).is_integer() else r
@@ -312,7 +423,6 @@ def excluded(col, x, simd_golden=False, facts=None, rvalue=None):
 
 
 COND_FACTOR = 2.0
-EPS = float(np.finfo(np.float64).eps)
 
 
 def tolerance_for(col, x, want, facts):
@@ -348,23 +458,69 @@ def tolerance_for(col, x, want, facts):
             if slope > 0:
                 atol += COND_FACTOR * EPS * grow * (fit["kappa"] * fit["resid"] + fit["scaled_norm"]) / slope
         return RTOL, atol
+    if f == "ar_coefficient":
+        k, j = _param(col, "k", int), _param(col, "coeff", int)
+        spread = facts.get(("ar_probe", k), lambda: _ar_probe(facts.x, k))
+        extra = PROBE_FACTOR * float(spread[j]) if spread is not None and 0 <= j < len(spread) else 0.0
+        return RTOL, atol_for(col, x) + extra
+    if f == "augmented_dickey_fuller" and 'attr_"usedlag"' not in col:
+        probe = facts.get("adf_probe", lambda: _adf_probe(facts.x))
+        extra = 0.0 if probe is None else PROBE_FACTOR * (probe[1] if 'attr_"teststat"' in col else probe[2])
+        return RTOL, atol_for(col, x) + extra
     return RTOL, atol_for(col, x)
 
 
+# Physical dimension of a feature value as a power of the unit of x (0: dimensionless).  Everything not listed has the
+# dimension of x itself.
+_DIMENSIONLESS = {
+    "variation_coefficient", "skewness", "kurtosis", "last_location_of_maximum", "first_location_of_maximum",
+    "last_location_of_minimum", "first_location_of_minimum", "percentage_of_reoccurring_values_to_all_values",
+    "percentage_of_reoccurring_datapoints_to_all_datapoints", "ratio_value_number_to_time_series_length",
+    "sample_entropy", "approximate_entropy", "benford_correlation", "autocorrelation", "agg_autocorrelation",
+    "partial_autocorrelation", "binned_entropy", "index_mass_quantile", "fft_aggregated", "augmented_dickey_fuller",
+    "energy_ratio_by_chunks", "ratio_beyond_r_sigma", "count_above", "count_below", "lempel_ziv_complexity",
+    "fourier_entropy", "permutation_entropy",
+}
+_SQUARED = {"abs_energy", "variance", "spkt_welch_density"}
+_CUBED = {"c3", "time_reversal_asymmetry_statistic"}
+
+
+def dimension_of(col):
+    f = feature_of(col)
+    if f in _DIMENSIONLESS:
+        return 0
+    if f in _SQUARED:
+        return 2
+    if f in _CUBED:
+        return 3
+    if f == "ar_coefficient":
+        return 1 if _param(col, "coeff", int) == 0 else 0            # intercept : lag coefficients
+    if f == "cid_ce":
+        return 0 if "normalize_True" in col else 1
+    if f == "change_quantiles":
+        return 2 if 'f_agg_"var"' in col else 1
+    if f in ("linear_trend", "agg_linear_trend", "linear_trend_timewise"):
+        return 0 if ('attr_"pvalue"' in col or 'attr_"rvalue"' in col) else 1
+    return 1
+
+
 def atol_for(col, x):
+    """Absolute floor of a comparison: 1e-9 of the feature's natural scale, max|x| ** dimension (results that are
+    mathematically ~0 -- the mean of a symmetric series, the imaginary part of a real FFT bin -- have no meaningful
+    relative error).  Dimensionless columns: 1e-9."""
     f = feature_of(col)
     ax = np.abs(np.asarray(x, dtype=np.float64))
-    amax = max(1.0, float(ax.max()) if len(ax) else 1.0)
-    if f in ("fft_coefficient", "fft_aggregated"):
-        return 1e-10 * max(1.0, float(ax.sum()))
-    if f in ("c3", "time_reversal_asymmetry_statistic"):
-        return 1e-9 * amax ** 3
-    if f in ("abs_energy", "variance", "spkt_welch_density"):
-        return 1e-9 * amax ** 2
-    if f in ("skewness", "kurtosis", "autocorrelation", "agg_autocorrelation", "partial_autocorrelation",
-             "approximate_entropy", "sample_entropy", "linear_trend", "agg_linear_trend"):
-        return 1e-9
-    return 1e-9 * amax
+    amax = float(ax.max()) if len(ax) else 0.0
+    if not np.isfinite(amax) or amax == 0.0:
+        amax = 1.0
+    if f in ("fft_coefficient",):
+        return 1e-10 * max(float(ax.sum()), 1e-300)
+    if f == "ar_coefficient" and dimension_of(col) == 1:
+        # the intercept: mean * (1 - sum of the lag coefficients) -- of the size of the spread for a stationary series,
+        # and tiny in the pinv truncation regime (1e-10 for 1e9 + N(0, 1)), where max|x| would forgive anything
+        sd = float(np.std(np.asarray(x, dtype=np.float64)))
+        return 1e-9 * (sd if sd > 0 else amax)
+    return 1e-9 * amax ** dimension_of(col)
 
 
 def _rvalue_lookup(names, want_row):

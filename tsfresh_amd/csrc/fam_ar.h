@@ -85,12 +85,15 @@ TSFA_DEV void blk_chol_solve(const Blk &b, const double *L, int p, int ld, const
 // worse than ~3e4, where float64 normal equations lose the digits the reference's SVD still has.  Such series are
 // listed for the double-double second pass (fam_ar_dd.h); an absolute `d > 0` test lets round-off pass for a pivot.
 #define TSFA_AR_PIVOT_TOL 1e-9
-TSFA_DEV bool blk_chol_factor(const Blk &b, double *G, int p, int ld, double *diag0) {
+TSFA_DEV bool blk_chol_factor(const Blk &b, double *G, int p, int ld, double *diag0, double *dmin = nullptr) {
     for (int a = b.tid; a < p; a += b.nt) diag0[a] = G[a + a * ld];
+    double dm = TSFA_INF;
     for (int j = 0; j < p; ++j) {
         blk_sync();
         const double d = G[j + j * ld];
         if (!(d > TSFA_AR_PIVOT_TOL * diag0[j])) return false;
+        dm = fmin(dm, d);
+        if (dmin) *dmin = dm;   // uniform: the smallest pivot so far
         const double sd = sqrt(d);
         blk_sync();
         for (int i = j + b.tid; i < p; i += b.nt) G[i + j * ld] = (i == j) ? sd : G[i + j * ld] / sd;
@@ -211,6 +214,17 @@ TSFA_DEV int ar_scratch_doubles(int P) { return 2 * P * P + 7 * P + 64 + 16 + 48
 //   aw   : LDS, ar_scratch_doubles(P) doubles;  P >= max(adf_maxlag_for(n) + 3, max AR order + 2)
 // The series stays in LDS in its INPUT precision ST (float32 samples: half the LDS, one more resident series per CU);
 // the mean-centred value is formed where it is read -- (double)x - mean is the very expression that used to be stored.
+// statsmodels' pinv drops singular values <= 1e-15 s_max of the RAW design (fam_ar_dd.h).  The first pass works on the
+// centred series, whose design X_c is well conditioned however large the mean is; the raw one is X_c S with S = I +
+// e_const mu^T, so  s_min(raw) >= s_min(X_c) / (1 + |mu|)  and  s_max(raw)^2 <= trace.  With s_min(X_c) ~ the square
+// root of the smallest Cholesky pivot this bounds the raw ratio from below; a series whose bound is within 1000x of
+// the cut is listed for the second pass, which measures the ratio and takes the eigen route if it has to
+// (1e6 + N(0, 1) is listed, 1e5 + N(0, 1) is not).
+#define TSFA_AR_RAW_RATIO 1e-12
+TSFA_DEV bool ar_raw_design_suspect(double dmin, double mu_norm, double trace_raw) {
+    return sqrt(dmin) < TSFA_AR_RAW_RATIO * (1.0 + mu_norm) * sqrt(trace_raw);
+}
+
 template <class ST>
 struct ArCentred {
     const ST *p;
@@ -363,8 +377,15 @@ TSFA_DEV int fam_ar_series(const Blk &b, X xv, int n, const TsfaSpec *specs, int
             TSFA_TICK(tk, b, 123);
             {
                 // all nested fits from one factorization: w = L^-1 g, SSR_p = yy - sum_{i<p} w_i^2
-                const bool okf = blk_chol_factor(b, G, p1, P, diag0);
+                double dmin1 = 0.0;
+                const bool okf = blk_chol_factor(b, G, p1, P, diag0, &dmin1);
                 if (!okf) degenerate |= 2;
+                else {
+                    // raw level column: sum (xc + mean)^2 over the rows; the lag columns are differences (no offset)
+                    const double mu = xcc.mean;
+                    const double tr = nobs + (sxx + 2.0 * mu * sx + nobs * mu * mu) + (double)maxlag * yy;
+                    if (ar_raw_design_suspect(dmin1, fabs(mu), tr)) degenerate |= 2;
+                }
                 if (okf) {
                     for (int a = b.tid; a < p1; a += b.nt) tmp1[a] = g[a];
                     blk_chol_forward(b, G, p1, P, tmp1);
@@ -601,8 +622,15 @@ TSFA_DEV int fam_ar_series(const Blk &b, X xv, int n, const TsfaSpec *specs, int
                 }
                 for (int a = b.tid; a < p; a += b.nt) g[a] = (a == 0) ? C[0] : T[a];
                 blk_sync();
-                ar_ok = blk_chol_factor(b, G, p, P, diag0);
+                double dmin_ar = 0.0;
+                ar_ok = blk_chol_factor(b, G, p, P, diag0, &dmin_ar);
                 if (!ar_ok) degenerate |= 1;
+                else {
+                    const double mu = xcc.mean, rows = (double)(n - k);
+                    double tr = rows;
+                    for (int a = 1; a < p; ++a) tr += diag0[a] + 2.0 * mu * C[a] + rows * mu * mu;
+                    if (ar_raw_design_suspect(dmin_ar, sqrt((double)k) * fabs(mu), tr)) degenerate |= 1;
+                }
                 if (ar_ok) blk_chol_solve(b, G, p, P, g, beta);
                 blk_sync();
                 if (ar_ok) {

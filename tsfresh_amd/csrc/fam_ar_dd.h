@@ -54,8 +54,9 @@ TSFA_DEV dd blk_sum_dd(const Blk &b, dd v) {
 // Cholesky in natural column order, skipping dependent columns (right-looking; rows of a column are dealt over the
 // threads).  On exit kept[j] tells whether column j entered the factor; for a kept j, G[i + j*ld] (i >= j) = L(i, j)
 // for EVERY row i (dependent rows included: they are the columns of R beyond its triangle).  `mask` (optional)
-// pre-excludes columns.  Returns the rank, or -1 if a non-masked pivot is not positive although tol == 0.
-TSFA_DEV int dd_chol_skip(const Blk &b, dd *G, int p, int ld, int *kept, const int *mask, double tol, dd *diag0) {
+// pre-excludes columns; `skip_rel` (optional) receives |pivot| / diagonal of every skipped column.  Returns the rank, or -1 if a non-masked pivot is not positive although tol == 0.
+TSFA_DEV int dd_chol_skip(const Blk &b, dd *G, int p, int ld, int *kept, const int *mask, double tol, dd *diag0,
+                         double *skip_rel = nullptr) {
     blk_sync();
     for (int a = b.tid; a < p; a += b.nt) diag0[a] = G[a + a * ld];
     int rank = 0;
@@ -69,7 +70,10 @@ TSFA_DEV int dd_chol_skip(const Blk &b, dd *G, int p, int ld, int *kept, const i
             if (tol > 0.0) keep = (d0 > 0.0) && (d.hi > tol * d0);
             else if (!(d.hi > 0.0)) { keep = false; bad = true; }
         }
-        if (b.tid == 0) kept[j] = keep ? 1 : 0;
+        if (b.tid == 0) {
+            kept[j] = keep ? 1 : 0;
+            if (skip_rel) skip_rel[j] = (keep || !(d0 > 0.0)) ? 0.0 : fabs(d.hi) / d0;   // pivot a skipped column was left with
+        }
         if (!keep) continue;
         ++rank;
         const dd sd = dd_sqrt(d);
@@ -163,6 +167,206 @@ TSFA_DEV bool dd_min_norm(const Blk &b, const dd *L, int p, int ld, const int *k
     return true;
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// The pseudo-inverse TRUNCATION regime.  statsmodels' pinv drops singular values <= 1e-15 s_max of the RAW design and
+// counts rank = matrix_rank(diag(s)), tolerance s_max * p * eps.  A series with |mean| = mu >> spread gives the design
+// [1, x_{t-1}, ...] a smallest singular value ~ s_max * sigma / (k mu^2): from mu / sigma ~ 1e7 on (epoch seconds, 1e8 +
+// noise, any float64 counter) the reference solves a problem of lower rank although no column is dependent, and the
+// skipping Cholesky above (which only recognises DEPENDENT columns) returns the full-rank least-squares solution
+// instead -- 1e17 x off in the intercept.  Such designs take the SVD route:
+//   * the Gram matrix of the design in SHIFTED coordinates x' = x - c (c = the series mean, so x' is the size of the
+//     spread and nothing cancels): G' = X'^T X' = L L^T by the skipping Cholesky; the raw design is X = X' S with
+//     S = I + c e_const d^T (d marks the shifted columns), hence X = Q (L^T S) and the singular values / right
+//     singular vectors of X are those of the small matrix M = L^T S;
+//   * one-sided (Hestenes) Jacobi on the columns of A = M^T = L + c d L[const, :] in double-double: on exit column i of
+//     A is s_i v_i, and the same rotations turn w = L^-1 X'^T y into u_i . y.  One-sided Jacobi works on the factor,
+//     not on a Gram matrix, so a singular value 1e-12 of the largest still carries ~20 digits (an eigen-decomposition
+//     of X^T X would leave it 8, and none to the intercept of 6.6e8 +- 0.01);
+//   * keep s_i > 1e-15 s_max:  beta = sum_kept v_i (u_i . y) / s_i,  ssr = ssr_full + sum_dropped (u_i . y)^2,
+//     rank = #{s_i > p eps s_max},  (X^T X)^+[0, 0] = sum_kept v_i[0]^2 / s_i^2.
+// Exactly dependent columns never enter the factor (zero singular values), so this route is a superset of the skipping
+// one; it is taken when s_min / s_max of the raw design, estimated by inverse iteration on the raw factor, is within
+// 20x of the cuts (dd_needs_svd).
+
+#define TSFA_DD_PINV_RCOND 1e-15
+#define TSFA_DD_SVD_TRIGGER 1e-13   // estimated s_min / s_max below which the SVD route decides
+#define TSFA_DD_JACOBI_SWEEPS 20
+
+// x = L^-T w over the kept columns, in place
+TSFA_DEV void dd_backward_kept(const Blk &b, const dd *L, int p, int ld, const int *kept, dd *w) {
+    for (int j = p - 1; j >= 0; --j) {
+        blk_sync();
+        if (!kept[j]) {
+            if (b.tid == 0) w[j] = dd_from(0.0);
+            continue;
+        }
+        const dd wj = dd_div(w[j], L[j + j * ld]);
+        blk_sync();
+        if (b.tid == 0) w[j] = wj;
+        for (int i = b.tid; i < j; i += b.nt)
+            if (kept[i]) w[i] = dd_sub(w[i], dd_mul(L[j + i * ld], wj));
+    }
+    blk_sync();
+}
+
+// Does the design behind the skipping factor L (diag0 = the Gram diagonal) need the SVD route?  Yes if a skipped
+// column is not an EXACT dependency (its pivot is not at the arithmetic's noise floor), or if s_min / s_max of the kept
+// block -- l_min by three steps of inverse iteration, l_max <= trace -- is below TSFA_DD_SVD_TRIGGER.
+TSFA_DEV bool dd_needs_svd(const Blk &b, const dd *L, int p, int ld, const int *kept, const dd *diag0, const double *skipped_rel,
+                           dd *v) {
+    blk_sync();
+    double trace = 0.0;
+    bool soft_skip = false;
+    int nk = 0;
+    for (int a = 0; a < p; ++a) {
+        if (kept[a]) { trace += diag0[a].hi; ++nk; }
+        else if (skipped_rel[a] > 1e-29) soft_skip = true;
+    }
+    if (soft_skip) return true;
+    if (nk == 0 || !(trace > 0.0)) return false;
+    for (int a = b.tid; a < p; a += b.nt) v[a] = dd_from(kept[a] ? 1.0 / sqrt(diag0[a].hi) : 0.0);
+    double lmin = trace;
+    for (int it = 0; it < 3; ++it) {
+        dd_forward_kept(b, L, p, ld, kept, v);
+        dd_backward_kept(b, L, p, ld, kept, v);
+        double nrm2 = 0.0;
+        for (int a = 0; a < p; ++a) nrm2 += v[a].hi * v[a].hi;   // uniform: every thread reads the same LDS values
+        const double nrm = sqrt(nrm2);
+        blk_sync();
+        if (!(nrm > 0.0) || isinf(nrm)) return true;
+        lmin = 1.0 / nrm;   // |v| was 1 (first step: ~1): l_min ~ |v| / |G^-1 v|
+        for (int a = b.tid; a < p; a += b.nt) v[a] = dd{v[a].hi / nrm, v[a].lo / nrm};
+        blk_sync();
+    }
+    return lmin < TSFA_DD_SVD_TRIGGER * TSFA_DD_SVD_TRIGGER * trace;
+}
+
+// One-sided (Hestenes) Jacobi: plane rotations from the right orthogonalise the r columns (length p) of A (column-major,
+// leading dimension ld); the row vector wv (r entries) takes the same rotations.  On exit A = V diag(s) up to column
+// order: column i has norm s_i and direction v_i.
+TSFA_DEV void dd_hestenes(const Blk &b, dd *A, int p, int r, int ld, dd *wv) {
+    for (int sweep = 0; sweep < TSFA_DD_JACOBI_SWEEPS; ++sweep) {
+        bool any = false;
+        for (int i = 0; i < r - 1; ++i) {
+            for (int j = i + 1; j < r; ++j) {
+                blk_sync();
+                dd al = dd_from(0.0), be = dd_from(0.0), ga = dd_from(0.0);
+                for (int k = b.tid; k < p; k += b.nt) {
+                    const dd ai = A[k + i * ld], aj = A[k + j * ld];
+                    al = dd_add(al, dd_mul(ai, ai));
+                    be = dd_add(be, dd_mul(aj, aj));
+                    ga = dd_add(ga, dd_mul(ai, aj));
+                }
+                al = blk_sum_dd(b, al);
+                be = blk_sum_dd(b, be);
+                ga = blk_sum_dd(b, ga);
+                if (!(fabs(ga.hi) > 1e-31 * sqrt(al.hi * be.hi))) continue;   // uniform (also: a zero column)
+                any = true;
+                const dd ze = dd_div(dd_sub(be, al), dd_mul_d(ga, 2.0));
+                dd t;
+                if (fabs(ze.hi) > 1e150) {
+                    t = dd_div(dd_from(0.5), ze);
+                } else {
+                    const dd az = (ze.hi < 0.0) ? dd_neg(ze) : ze;
+                    t = dd_div(dd_from(1.0), dd_add(az, dd_sqrt(dd_add(dd_mul(ze, ze), dd_from(1.0)))));
+                    if (ze.hi < 0.0) t = dd_neg(t);
+                }
+                const dd c = dd_div(dd_from(1.0), dd_sqrt(dd_add(dd_mul(t, t), dd_from(1.0))));
+                const dd sn = dd_mul(t, c);
+                blk_sync();
+                for (int k = b.tid; k < p; k += b.nt) {
+                    const dd ai = A[k + i * ld], aj = A[k + j * ld];
+                    A[k + i * ld] = dd_sub(dd_mul(c, ai), dd_mul(sn, aj));
+                    A[k + j * ld] = dd_add(dd_mul(sn, ai), dd_mul(c, aj));
+                }
+                if (b.tid == 0 && wv) {
+                    const dd wi = wv[i], wj = wv[j];
+                    wv[i] = dd_sub(dd_mul(c, wi), dd_mul(sn, wj));
+                    wv[j] = dd_add(dd_mul(sn, wi), dd_mul(c, wj));
+                }
+            }
+        }
+        if (!any) break;
+    }
+    blk_sync();
+}
+
+struct DdPinvFit {
+    double dropped;  // sum over the dropped directions of (u_i . y)^2: what truncation adds to the residual sum
+    int rank;        // matrix_rank(diag(s)): #{s_i > s_max pcols eps}
+    double cov0;     // ((X^T X)^+)[row0, row0]
+    dd beta0;        // coefficient of design column row0
+};
+// statsmodels OLS(...).fit(method="pinv") quantities from the orthogonalised columns A = V diag(s) (p x r) and the
+// rotated wv = U^T y.  s2 (r entries of scratch) receives s_i^2.  If beta != nullptr it receives all p coefficients.
+TSFA_DEV DdPinvFit dd_pinv_from_svd(const Blk &b, const dd *A, int p, int r, int ld, const dd *wv, int pcols, int row0,
+                                    dd *s2, dd *beta) {
+    blk_sync();
+    for (int i = b.tid; i < r; i += b.nt) {
+        dd acc = dd_from(0.0);
+        for (int k = 0; k < p; ++k) acc = dd_add(acc, dd_mul(A[k + i * ld], A[k + i * ld]));
+        s2[i] = acc;
+    }
+    blk_sync();
+    double lmax = 0.0;
+    for (int i = 0; i < r; ++i) lmax = fmax(lmax, s2[i].hi);
+    const double cut = TSFA_DD_PINV_RCOND * TSFA_DD_PINV_RCOND * lmax;
+    const double rtol = (double)pcols * 2.220446049250313e-16;
+    const double rcut = rtol * rtol * lmax;
+    DdPinvFit f;
+    f.rank = 0;
+    dd dropped = dd_from(0.0), c0 = dd_from(0.0), b0 = dd_from(0.0);
+    for (int i = 0; i < r; ++i) {    // uniform
+        const dd l = s2[i];
+        if (l.hi > rcut) ++f.rank;
+        if (!(l.hi > cut) || !(l.hi > 0.0)) {
+            dropped = dd_add(dropped, dd_mul(wv[i], wv[i]));
+            continue;
+        }
+        const dd a0 = A[row0 + i * ld];
+        b0 = dd_add(b0, dd_div(dd_mul(a0, wv[i]), l));
+        c0 = dd_add(c0, dd_div(dd_mul(a0, a0), dd_mul(l, l)));
+    }
+    f.dropped = dropped.hi;
+    f.cov0 = c0.hi;
+    f.beta0 = b0;
+    if (beta) {
+        for (int a = b.tid; a < p; a += b.nt) {
+            dd acc = dd_from(0.0);
+            for (int i = 0; i < r; ++i) {
+                const dd l = s2[i];
+                if (!(l.hi > cut) || !(l.hi > 0.0)) continue;
+                acc = dd_add(acc, dd_div(dd_mul(A[a + i * ld], wv[i]), l));
+            }
+            beta[a] = acc;
+        }
+        blk_sync();
+    }
+    return f;
+}
+
+// A = M^T = L + c d L[crow, :] over the kept columns of the leading m x m block of the skipping factor L (see above):
+// row a of A belongs to design column a, column i to the i-th KEPT factor column; shifted(a) tells whether design column
+// a was shifted by c.  wv receives the kept entries of w.  Returns the number of columns r.
+template <class SH>
+TSFA_DEV int dd_build_mt(const Blk &b, const dd *L, int m, int ld, const int *kept, double c, int crow, SH shifted,
+                         const dd *w, dd *A, dd *wv) {
+    blk_sync();
+    int r = 0;
+    for (int i = 0; i < m; ++i) {
+        if (!kept[i]) continue;
+        for (int a = b.tid; a < m; a += b.nt) {
+            dd v = (a >= i) ? L[a + i * ld] : dd_from(0.0);
+            if (crow >= 0 && crow >= i && shifted(a)) v = dd_add(v, dd_mul_d(L[crow + i * ld], c));
+            A[a + r * ld] = v;
+        }
+        if (b.tid == 0) wv[r] = w[i];
+        ++r;
+    }
+    blk_sync();
+    return r;
+}
+
 // Lag products of sequence s over rows t in [t0, t1) in double-double: T[i + j*ld] = sum_t s(t-i) s(t-j) (lower
 // triangle, 0 <= j <= i <= Lg) and C[j] = sum_t s(t-j).  Requires t0 >= Lg.
 template <class S>
@@ -193,14 +397,14 @@ TSFA_DEV void dd_lag_products(const Blk &b, S s, int Lg, int t0, int t1, dd *T, 
     blk_sync();
 }
 
-// LDS scratch of the second pass, in doubles (ArDdLds::scratch_doubles): 2 matrices of P*P dd + 7 vectors of (P+1) dd
-// + 2 P ints, rounded up
+// LDS scratch of the second pass, in doubles (ArDdLds::scratch_doubles): 2 matrices of P*P dd + 8 vectors of (P+1) dd
+// + (P+1) doubles + 2 P ints, rounded up
 
 // flags: bit 0 = ar_coefficient, bit 1 = augmented_dickey_fuller (which calculators the first pass gave up on)
 template <class X>
 TSFA_DEV void fam_ar_degenerate_series(const Blk &b, X xv, int n, const TsfaSpec *specs, int nspecs, double *out_row,
                                        double *scratch, int P, int flags) {
-    dd *T = (dd *)(void *)scratch;        // lag products, later R R^T
+    dd *T = (dd *)(void *)scratch;        // lag products; later R R^T (skipping route) or A = M^T (SVD route)
     dd *G = T + P * P;                    // Gram matrix -> skipping factor
     dd *C = G + P * P;                    // column sums
     dd *V = C + (P + 1);                  // level products (ADF)
@@ -211,6 +415,18 @@ TSFA_DEV void fam_ar_degenerate_series(const Blk &b, X xv, int n, const TsfaSpec
     dd *misc = diag0 + (P + 1);           // P + 1
     int *kept = (int *)(void *)(misc + (P + 1));
     int *kept2 = kept + P;
+    dd *ev = (dd *)(void *)(kept2 + P + (P & 1));   // P + 1: inverse-iteration vector / rotated w of the SVD route
+    double *skip_rel = (double *)(void *)(ev + (P + 1));   // P + 1
+
+    // the series mean (any constant of that size would do): the shift of the SVD route
+    double xmean;
+    {
+        dd acc = dd_from(0.0);
+        for (int t = b.tid; t < n; t += b.nt) acc = dd_add(acc, dd_from(xv(t)));
+        acc = blk_sum_dd(b, acc);
+        xmean = acc.hi / (double)n;
+        if (!(xmean == xmean) || isinf(xmean)) xmean = 0.0;
+    }
 
     // ---------------------------------------------------------------------------------------------------------
     // augmented Dickey-Fuller, regression="c", autolag="AIC" (stattools.adfuller)
@@ -235,21 +451,27 @@ TSFA_DEV void fam_ar_degenerate_series(const Blk &b, X xv, int n, const TsfaSpec
                 return blk_sum(b, cnt) > 0.0;
             };
             const int hasc = const_cols(M, t0) ? 0 : 1;
-            dd_lag_products(b, dif, M, t0, t1, T, P, C);
-            for (int j = 0; j <= M; ++j) {
-                dd a = dd_from(0.0);
-                for (int t = t0 + b.tid; t < t1; t += b.nt) a = dd_add_prod(a, xv(t), dif(t - j));
-                a = blk_sum_dd(b, a);
-                if (b.tid == 0) V[j] = a;
-            }
+            // sums over the rows [t0, t1) with the level column shifted by `shift` (0: the raw design)
             dd sx = dd_from(0.0), sxx = dd_from(0.0);
-            for (int t = t0 + b.tid; t < t1; t += b.nt) {
-                sx = dd_add(sx, dd_from(xv(t)));
-                sxx = dd_add_prod(sxx, xv(t), xv(t));
-            }
-            sx = blk_sum_dd(b, sx);
-            sxx = blk_sum_dd(b, sxx);
-            blk_sync();
+            auto assemble = [&](double shift) {
+                blk_sync();
+                dd_lag_products(b, dif, M, t0, t1, T, P, C);
+                for (int j = 0; j <= M; ++j) {
+                    dd a = dd_from(0.0);
+                    for (int t = t0 + b.tid; t < t1; t += b.nt) a = dd_add_prod(a, xv(t) - shift, dif(t - j));
+                    a = blk_sum_dd(b, a);
+                    if (b.tid == 0) V[j] = a;
+                }
+                dd s1 = dd_from(0.0), s2 = dd_from(0.0);
+                for (int t = t0 + b.tid; t < t1; t += b.nt) {
+                    const double l = xv(t) - shift;
+                    s1 = dd_add(s1, dd_from(l));
+                    s2 = dd_add_prod(s2, l, l);
+                }
+                sx = blk_sum_dd(b, s1);
+                sxx = blk_sum_dd(b, s2);
+                blk_sync();
+            };
             // column kinds of the lag-search design: -1 const, 0 level, j >= 1 lag j
             const int p1 = M + 1 + hasc;
             auto kind1 = [=](int a) { return hasc ? (a == 0 ? -1 : a - 1) : a; };
@@ -261,36 +483,71 @@ TSFA_DEV void fam_ar_degenerate_series(const Blk &b, X xv, int n, const TsfaSpec
                 if (kc == 0) return V[ka];
                 return T[ka + kc * P];
             };
-            for (int e = b.tid; e < p1 * p1; e += b.nt) {
-                const int a = e / p1, c = e % p1;
-                if (c > a) continue;
-                G[a + c * P] = gram(kind1(a), kind1(c));
-            }
-            for (int a = b.tid; a < p1; a += b.nt) {
-                const int ka = kind1(a);
-                g[a] = (ka == -1) ? C[0] : (ka == 0 ? V[0] : T[ka]);
-            }
+            auto build_search = [&]() {
+                for (int e = b.tid; e < p1 * p1; e += b.nt) {
+                    const int a = e / p1, c = e % p1;
+                    if (c > a) continue;
+                    G[a + c * P] = gram(kind1(a), kind1(c));
+                }
+                for (int a = b.tid; a < p1; a += b.nt) {
+                    const int ka = kind1(a);
+                    g[a] = (ka == -1) ? C[0] : (ka == 0 ? V[0] : T[ka]);
+                }
+                blk_sync();
+            };
+            assemble(0.0);
+            build_search();
             const dd yy = T[0];
-            blk_sync();
-            dd_chol_skip(b, G, p1, P, kept, nullptr, TSFA_DD_SKIP_TOL, diag0);
-            dd_forward_kept(b, G, p1, P, kept, g);
-            if (b.tid == 0) {
-                // nested fits: `lag` leading columns, lag = startlag .. startlag + M (stattools._autolag)
-                const int startlag = hasc + 1;
-                dd acc = dd_from(0.0);
-                int rank = 0, best = -1;
+            const int startlag = hasc + 1;
+            const double dn = (double)nobs;
+            dd_chol_skip(b, G, p1, P, kept, nullptr, TSFA_DD_SKIP_TOL, diag0, skip_rel);
+            const bool svd1 = dd_needs_svd(b, G, p1, P, kept, diag0, skip_rel, ev);
+            // the shift needs the constant column inside the design (column 0 of the lag search, the last one of the
+            // final regression); a design whose constant is another exactly constant column stays unshifted
+            const double shift = hasc ? xmean : 0.0;
+            if (svd1) {
+                // pinv truncation regime: every nested fit from the SVD of its own leading block (uniform control flow)
+                if (shift != 0.0) {
+                    assemble(shift);
+                    build_search();
+                    dd_chol_skip(b, G, p1, P, kept, nullptr, TSFA_DD_SKIP_TOL, diag0, skip_rel);
+                }
+                dd_forward_kept(b, G, p1, P, kept, g);
+                int best = -1;
                 double best_aic = 0.0;
-                const double dn = (double)nobs;
-                for (int m = 1; m <= p1; ++m) {
-                    if (kept[m - 1]) { acc = dd_add(acc, dd_mul(g[m - 1], g[m - 1])); ++rank; }
-                    if (m < startlag) continue;
-                    double ssr = dd_sub(yy, acc).hi;
+                for (int m = startlag; m <= p1; ++m) {
+                    const int r = dd_build_mt(b, G, m, P, kept, shift, hasc ? 0 : -1, [=](int a) { return kind1(a) == 0; }, g, T, ev);
+                    dd full = dd_from(0.0);
+                    for (int i = 0; i < r; ++i) full = dd_add(full, dd_mul(ev[i], ev[i]));   // uniform: explained by the full fit
+                    dd_hestenes(b, T, m, r, P, ev);
+                    const DdPinvFit f = dd_pinv_from_svd(b, T, m, r, P, ev, m, 0, z, nullptr);
+                    double ssr = dd_sub(yy, full).hi + f.dropped;
                     if (!(ssr > TSFA_DD_ZERO_SSR * yy.hi)) ssr = 0.0;
                     const double llf = -0.5 * dn * log(2.0 * M_PI) - 0.5 * dn * log(ssr / dn) - 0.5 * dn;
-                    const double aic = -2.0 * llf + 2.0 * (double)rank;
+                    const double aic = -2.0 * llf + 2.0 * (double)f.rank;
                     if (best < 0 || aic < best_aic) { best = m; best_aic = aic; }
                 }
-                misc[0] = dd_from((double)(best - startlag));
+                blk_sync();
+                if (b.tid == 0) misc[0] = dd_from((double)(best - startlag));
+                assemble(0.0);   // T held the work matrices: the final regression starts from the raw sums again
+            } else {
+                dd_forward_kept(b, G, p1, P, kept, g);
+                if (b.tid == 0) {
+                    // nested fits: `lag` leading columns, lag = startlag .. startlag + M (stattools._autolag)
+                    dd acc = dd_from(0.0);
+                    int rank = 0, best = -1;
+                    double best_aic = 0.0;
+                    for (int m = 1; m <= p1; ++m) {
+                        if (kept[m - 1]) { acc = dd_add(acc, dd_mul(g[m - 1], g[m - 1])); ++rank; }
+                        if (m < startlag) continue;
+                        double ssr = dd_sub(yy, acc).hi;
+                        if (!(ssr > TSFA_DD_ZERO_SSR * yy.hi)) ssr = 0.0;
+                        const double llf = -0.5 * dn * log(2.0 * M_PI) - 0.5 * dn * log(ssr / dn) - 0.5 * dn;
+                        const double aic = -2.0 * llf + 2.0 * (double)rank;
+                        if (best < 0 || aic < best_aic) { best = m; best_aic = aic; }
+                    }
+                    misc[0] = dd_from((double)(best - startlag));
+                }
             }
             blk_sync();
             const int U = (int)misc[0].hi;
@@ -301,46 +558,73 @@ TSFA_DEV void fam_ar_degenerate_series(const Blk &b, X xv, int n, const TsfaSpec
             const int hasc2 = const_cols(U, u0) ? 0 : 1;
             const int p2 = U + 1 + hasc2;
             auto kind2 = [=](int a) { return (a <= U) ? a : -1; };
-            auto colv = [=](int k, int t) { return k == -1 ? 1.0 : (k == 0 ? xv(t) : dif(t - k)); };
-            for (int e = b.tid; e < p2 * p2 + p2 + 1; e += b.nt) {
-                const bool is_yy = (e == p2 * p2 + p2), is_rhs = (e >= p2 * p2) && !is_yy;
-                const int a = is_yy ? 0 : (is_rhs ? e - p2 * p2 : e / p2);
-                const int c = (is_rhs || is_yy) ? 0 : e % p2;
-                if (!is_rhs && !is_yy && c > a) continue;
-                const int ka = kind2(a), kc = kind2(c);
-                dd v;
-                if (is_yy) v = yy;
-                else if (is_rhs) v = (ka == -1) ? C[0] : (ka == 0 ? V[0] : T[ka]);
-                else v = gram(ka, kc);
-                for (int t = u0; t < t0; ++t) {  // the rows the lag search had trimmed
-                    const double l = is_yy ? dif(t) : colv(ka, t);
-                    const double r = (is_rhs || is_yy) ? dif(t) : colv(kc, t);
-                    v = dd_add_prod(v, l, r);
+            // (T, C, V, sx, sxx hold the sums of the rows [t0, t1) for the level column shifted by `sh`)
+            auto build_final = [&](double sh) {
+                auto colv = [=](int k, int t) { return k == -1 ? 1.0 : (k == 0 ? xv(t) - sh : dif(t - k)); };
+                for (int e = b.tid; e < p2 * p2 + p2 + 1; e += b.nt) {
+                    const bool is_yy = (e == p2 * p2 + p2), is_rhs = (e >= p2 * p2) && !is_yy;
+                    const int a = is_yy ? 0 : (is_rhs ? e - p2 * p2 : e / p2);
+                    const int c = (is_rhs || is_yy) ? 0 : e % p2;
+                    if (!is_rhs && !is_yy && c > a) continue;
+                    const int ka = kind2(a), kc = kind2(c);
+                    dd v;
+                    if (is_yy) v = yy;
+                    else if (is_rhs) v = (ka == -1) ? C[0] : (ka == 0 ? V[0] : T[ka]);
+                    else v = gram(ka, kc);
+                    for (int t = u0; t < t0; ++t) {  // the rows the lag search had trimmed
+                        const double l = is_yy ? dif(t) : colv(ka, t);
+                        const double r = (is_rhs || is_yy) ? dif(t) : colv(kc, t);
+                        v = dd_add_prod(v, l, r);
+                    }
+                    if (is_yy) misc[1] = v;
+                    else if (is_rhs) g[a] = v;
+                    else G[a + c * P] = v;
                 }
-                if (is_yy) misc[1] = v;
-                else if (is_rhs) g[a] = v;
-                else G[a + c * P] = v;
-            }
-            blk_sync();
+                blk_sync();
+            };
+            build_final(0.0);
             const dd yy2 = misc[1];
             const double lev2 = G[0].hi;  // squared norm of the level column
-            const int rank2 = dd_chol_skip(b, G, p2, P, kept, nullptr, TSFA_DD_SKIP_TOL, diag0);
-            dd_forward_kept(b, G, p2, P, kept, g);
-            double cov0 = 0.0;
-            const bool ok = dd_min_norm(b, G, p2, P, kept, g, T, z, diag0, kept2, beta, true, &cov0);
-            if (ok) {
-                dd acc = dd_from(0.0);
-                for (int a = 0; a < p2; ++a)
-                    if (kept[a]) acc = dd_add(acc, dd_mul(g[a], g[a]));
-                double ssr = dd_sub(yy2, acc).hi;
+            const int rank2 = dd_chol_skip(b, G, p2, P, kept, nullptr, TSFA_DD_SKIP_TOL, diag0, skip_rel);
+            if (dd_needs_svd(b, G, p2, P, kept, diag0, skip_rel, ev)) {
+                const double sh2 = hasc2 ? xmean : 0.0;
+                if (sh2 != 0.0) {
+                    assemble(sh2);
+                    build_final(sh2);
+                    dd_chol_skip(b, G, p2, P, kept, nullptr, TSFA_DD_SKIP_TOL, diag0, skip_rel);
+                }
+                dd_forward_kept(b, G, p2, P, kept, g);
+                const int r = dd_build_mt(b, G, p2, P, kept, sh2, hasc2 ? p2 - 1 : -1, [=](int a) { return a == 0; }, g, T, ev);
+                dd full = dd_from(0.0);
+                for (int i = 0; i < r; ++i) full = dd_add(full, dd_mul(ev[i], ev[i]));
+                dd_hestenes(b, T, p2, r, P, ev);
+                const DdPinvFit f = dd_pinv_from_svd(b, T, p2, r, P, ev, p2, 0, z, nullptr);
+                double ssr = dd_sub(yy2, full).hi + f.dropped;
                 if (!(ssr > TSFA_DD_ZERO_SSR * yy2.hi)) ssr = 0.0;
-                const double sigma2 = ssr / ((double)nobs2 - (double)rank2);
-                double b0 = beta[0].hi;
-                // a perfect fit whose level coefficient is zero in exact arithmetic: 0 / 0, not (round-off) / 0
+                const double sigma2 = ssr / ((double)nobs2 - (double)f.rank);
+                double b0 = f.beta0.hi;
                 if (ssr == 0.0 && fabs(b0) * sqrt(lev2) <= 1e-12 * sqrt(yy2.hi)) b0 = 0.0;
-                r_stat = b0 / sqrt(sigma2 * cov0);
+                r_stat = b0 / sqrt(sigma2 * f.cov0);
                 r_p = (r_stat != r_stat) ? TSFA_NAN : mackinnon_p_c1(r_stat);
                 r_lag = (double)U;
+            } else {
+                dd_forward_kept(b, G, p2, P, kept, g);
+                double cov0 = 0.0;
+                const bool ok = dd_min_norm(b, G, p2, P, kept, g, T, z, diag0, kept2, beta, true, &cov0);
+                if (ok) {
+                    dd acc = dd_from(0.0);
+                    for (int a = 0; a < p2; ++a)
+                        if (kept[a]) acc = dd_add(acc, dd_mul(g[a], g[a]));
+                    double ssr = dd_sub(yy2, acc).hi;
+                    if (!(ssr > TSFA_DD_ZERO_SSR * yy2.hi)) ssr = 0.0;
+                    const double sigma2 = ssr / ((double)nobs2 - (double)rank2);
+                    double b0 = beta[0].hi;
+                    // a perfect fit whose level coefficient is zero in exact arithmetic: 0 / 0, not (round-off) / 0
+                    if (ssr == 0.0 && fabs(b0) * sqrt(lev2) <= 1e-12 * sqrt(yy2.hi)) b0 = 0.0;
+                    r_stat = b0 / sqrt(sigma2 * cov0);
+                    r_p = (r_stat != r_stat) ? TSFA_NAN : mackinnon_p_c1(r_stat);
+                    r_lag = (double)U;
+                }
             }
         }
         for (int s = b.tid; s < nspecs; s += b.nt) {
@@ -364,19 +648,38 @@ TSFA_DEV void fam_ar_degenerate_series(const Blk &b, X xv, int n, const TsfaSpec
             const int coeff = (int)sp.p[0], k = (int)sp.p[1];
             if (coeff > k || n < 2 * k + 2 || k + 2 > P || k < 1 || k + 1 > 40) continue;  // the first pass's answer stands
             if (done_k != k) {
-                dd_lag_products(b, [=](int u) { return xv(u); }, k, k, n, T, P, C);
                 const int p = k + 1;
-                for (int e = b.tid; e < p * p; e += b.nt) {
-                    const int a = e / p, c = e % p;
-                    if (c > a) continue;
-                    G[a + c * P] = (a == 0) ? dd_from((double)(n - k)) : (c == 0 ? C[a] : T[a + c * P]);
+                auto build_ar = [&](double sh) {   // Gram matrix and rhs of [1, x'[t-1..t-k]] -> x'[t], x' = x - sh
+                    blk_sync();
+                    dd_lag_products(b, [=](int u) { return xv(u) - sh; }, k, k, n, T, P, C);
+                    for (int e = b.tid; e < p * p; e += b.nt) {
+                        const int a = e / p, c = e % p;
+                        if (c > a) continue;
+                        G[a + c * P] = (a == 0) ? dd_from((double)(n - k)) : (c == 0 ? C[a] : T[a + c * P]);
+                    }
+                    for (int a = b.tid; a < p; a += b.nt) g[a] = (a == 0) ? C[0] : T[a];
+                    blk_sync();
+                };
+                build_ar(0.0);
+                dd_chol_skip(b, G, p, P, kept, nullptr, TSFA_DD_SKIP_TOL, diag0, skip_rel);
+                if (dd_needs_svd(b, G, p, P, kept, diag0, skip_rel, ev)) {
+                    // pinv truncation regime (see dd_hestenes): shifted design, target x[t] = x'[t] + c
+                    build_ar(xmean);
+                    dd_chol_skip(b, G, p, P, kept, nullptr, TSFA_DD_SKIP_TOL, diag0, skip_rel);
+                    dd_forward_kept(b, G, p, P, kept, g);
+                    blk_sync();
+                    for (int i = b.tid; i < p; i += b.nt)
+                        if (kept[i]) g[i] = dd_add(g[i], dd_mul_d(G[0 + i * P], (i == 0) ? xmean : 0.0));   // + c Q^T 1 = c L[0, :]
+                    blk_sync();
+                    const int r = dd_build_mt(b, G, p, P, kept, xmean, 0, [=](int a) { return a >= 1; }, g, T, ev);
+                    dd_hestenes(b, T, p, r, P, ev);
+                    (void)dd_pinv_from_svd(b, T, p, r, P, ev, p, 0, z, beta);
+                    ok = true;
+                } else {
+                    dd_forward_kept(b, G, p, P, kept, g);
+                    double unused = 0.0;
+                    ok = dd_min_norm(b, G, p, P, kept, g, T, z, diag0, kept2, beta, false, &unused);
                 }
-                for (int a = b.tid; a < p; a += b.nt) g[a] = (a == 0) ? C[0] : T[a];
-                blk_sync();
-                dd_chol_skip(b, G, p, P, kept, nullptr, TSFA_DD_SKIP_TOL, diag0);
-                dd_forward_kept(b, G, p, P, kept, g);
-                double unused = 0.0;
-                ok = dd_min_norm(b, G, p, P, kept, g, T, z, diag0, kept2, beta, false, &unused);
                 done_k = k;
             }
             if (b.tid == 0) out_row[sp.col] = ok ? beta[coeff].hi : TSFA_NAN;

@@ -135,7 +135,7 @@ struct ArLds {
 // second pass of the AR family (fam_ar_dd.h): one workgroup per listed series, matrices in double-double
 struct ArDdLds {
     double *red; double *scratch;
-    TSFA_HD static int scratch_doubles(int P) { return 4 * P * P + 16 * (P + 1) + P + 8; }
+    TSFA_HD static int scratch_doubles(int P) { return 4 * P * P + 19 * (P + 1) + P + 10; }
     TSFA_HD size_t carve(unsigned char *base, int P) {
         LdsCarve c{base, 0};
         red = c.take<double>(TSFA_RED_DOUBLES);
