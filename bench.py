@@ -175,6 +175,11 @@ def main():
     ap.add_argument("--params", default="comprehensive", choices=["comprehensive", "efficient", "minimal"])
     ap.add_argument("--ragged", default="", help="LO:HI -> series lengths uniform on [LO, HI] (configs[4] shape); "
                                                  "--length is ignored")
+    ap.add_argument("--walk", action="store_true", help="random walks (randn().cumsum(), the recipe of the reference's "
+                    "tests/benchmark.py:22) instead of i.i.d. N(0,1): the data-dependent kernels (LZ parse, CWT peaks, pair "
+                    "sweep) see long runs and smooth ridges")
+    ap.add_argument("--offset", type=float, default=0.0, help="add OFFSET to every sample (|mean| >> spread: the "
+                    "double-double second passes of the Langevin fit and of AR / ADF take every series)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-e2e", action="store_true", help="skip the host-buffer / DataFrame boundary timings")
     ap.add_argument("--chunks", type=int, default=0,
@@ -224,6 +229,10 @@ def main():
     else:
         values = torch.randn(n * L, device=dev, dtype=torch.float32, generator=gen)  # i.i.d. N(0,1) float32 series
         offsets = torch.arange(0, (n + 1) * L, L, device=dev, dtype=torch.int64)
+        if args.walk:
+            values = torch.cumsum(values.view(n, L).double(), dim=1).float().reshape(-1).contiguous()
+    if args.offset:
+        values = (values.double() + args.offset).float().contiguous()
     # The product pipeline (tsfresh_amd/distributed.py: ShardPipeline): the shard is extracted in row chunks on two
     # alternating launch streams (a plan each); with N > 1 every finished chunk is exchanged (RCCL all-gather into a
     # staging block + device scatter into the rank-major matrix) while the next chunk is being extracted, so only the
@@ -319,9 +328,10 @@ def main():
             "value": value, "unit": "series/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f64", "data": "synthetic",
-            "config": {"workload": "%d series/GPU x len %d float32 i.i.d. N(0,1), %sFCParameters (%d columns), "
+            "config": {"workload": "%d series/GPU x len %d float32 %s%s, %sFCParameters (%d columns), "
                                    "inputs and outputs resident in HBM%s" % (
-                                       n, L, args.params.capitalize(), n_cols,
+                                       n, L, "random walks (cumsum of N(0,1))" if args.walk else "i.i.d. N(0,1)",
+                                       (" + %g" % args.offset) if args.offset else "", args.params.capitalize(), n_cols,
                                        ", id-sharded + RCCL all-gather of the feature matrix" if world > 1 else ""),
                        "n_series_per_gpu": n, "length": L, "n_cols": n_cols, "parallelism": "ids%d" % world,
                        "row_chunks_per_step": n_chunks},

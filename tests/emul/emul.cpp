@@ -139,7 +139,7 @@ extern "C" int tsfa_emul_extract_timed(const tsfa_feature_spec *specs, int n_spe
                           (int)fam[TSFA_FAM_AR].size(), row, (void *)xc.data(), aw.data(), P, hints[TSFA_FAM_AR].a,
                           hints[TSFA_FAM_AR].b, hints[TSFA_FAM_AR].c, (s % 2) ? -1 : hints[TSFA_FAM_AR].d);
             if (flags) {  // the second pass of the family (k_ar_degenerate)
-                std::vector<double> sc(ArDdLds::scratch_doubles(P));
+                std::vector<double> sc(ArDdLds::scratch_doubles(P), TSFA_NAN);  // poisoned: LDS is not zero-initialised on the device
                 fam_ar_degenerate_series(b, [=](int i) { return xp[i]; }, n, fam[TSFA_FAM_AR].data(),
                                          (int)fam[TSFA_FAM_AR].size(), row, sc.data(), P, flags);
             }

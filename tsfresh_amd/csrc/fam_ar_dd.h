@@ -668,8 +668,7 @@ TSFA_DEV void fam_ar_degenerate_series(const Blk &b, X xv, int n, const TsfaSpec
                     dd_chol_skip(b, G, p, P, kept, nullptr, TSFA_DD_SKIP_TOL, diag0, skip_rel);
                     dd_forward_kept(b, G, p, P, kept, g);
                     blk_sync();
-                    for (int i = b.tid; i < p; i += b.nt)
-                        if (kept[i]) g[i] = dd_add(g[i], dd_mul_d(G[0 + i * P], (i == 0) ? xmean : 0.0));   // + c Q^T 1 = c L[0, :]
+                    if (b.tid == 0 && kept[0]) g[0] = dd_add(g[0], dd_mul_d(G[0], xmean));   // + c Q^T 1 = c L[0, :] (row 0 of L: one entry)
                     blk_sync();
                     const int r = dd_build_mt(b, G, p, P, kept, xmean, 0, [=](int a) { return a >= 1; }, g, T, ev);
                     dd_hestenes(b, T, p, r, P, ev);
