@@ -46,12 +46,9 @@ def load():
     return lib
 
 
-def emul_extract(fc_parameters, values, offsets, kind="value", times=None):
-    """-> (column names, float64 matrix) using the same plan compiler as the product."""
-    from tsfresh_amd.feature_extraction.plan import compile_fc_parameters
+def emul_extract_specs(specs, values, offsets, times=None):
+    """specs: [(calculator id of the EMULATION library, p[4])] -> float64 matrix [n_series x len(specs)]."""
     lib = load()
-    plan = compile_fc_parameters(fc_parameters, has_datetime_index=times is not None)
-    specs = plan.native_specs(lambda name: lib.tsfa_emul_calc_id(name.encode()))
     arr = (_Spec * max(len(specs), 1))()
     for i, (cid, p) in enumerate(specs):
         arr[i].calc = cid
@@ -68,4 +65,25 @@ def emul_extract(fc_parameters, values, offsets, kind="value", times=None):
                                      offsets.ctypes.data, n, out.ctypes.data, len(specs), err, 512)
     if rc != 0:
         raise RuntimeError("emul: %d %s" % (rc, err.value.decode()))
-    return [kind + "__" + nm for nm in plan.names], out
+    return out
+
+
+def emul_extract(fc_parameters, values, offsets, kind="value", times=None):
+    """-> (column names, float64 matrix) using the same plan compiler as the product."""
+    from tsfresh_amd.feature_extraction.plan import compile_fc_parameters
+    lib = load()
+    plan = compile_fc_parameters(fc_parameters, has_datetime_index=times is not None)
+    specs = plan.native_specs(lambda name: lib.tsfa_emul_calc_id(name.encode()))
+    return [kind + "__" + nm for nm in plan.names], emul_extract_specs(specs, values, offsets, times=times)
+
+
+class EmulPlan:
+    """Stands in for tsfresh_amd._native.Plan in CPU tests of the DataFrame-level code (tests/test_frames.py): the same
+    `extract_host` contract, the g++ build of the kernel sources behind it."""
+
+    def __init__(self, fplan):
+        lib = load()
+        self.specs = fplan.native_specs(lambda name: lib.tsfa_emul_calc_id(name.encode()))
+
+    def extract_host(self, values, offsets, times=None):
+        return emul_extract_specs(self.specs, values, offsets, times=times)

@@ -109,11 +109,18 @@ TSFA_DEV void blk_rfft(const Blk &b, int n, G g, double *Xr, double *Xi, double 
         blk_sync();
         return;
     }
-    // Both O(n^2) routes below transform x - x_0: a constant only feeds bin 0 (added back there), and without it the
+    // Both O(n^2) routes below transform x - mean: a constant only feeds bin 0 (added back there), and without it the
     // round-off of the other bins scales with the spread of the series instead of with its offset -- Goertzel's error
     // grows like n eps |x| / th, 3e-4 absolute on bin 1 of 300 samples at 1e7 +- 1 where numpy's mixed-radix FFT has 1e-6
-    // (found by the offset fixtures of the real reference, tests/golden/ref_*_offset.npz).
-    const double x_first = g(0);
+    // (found by the offset fixtures of the real reference, tests/golden/ref_*_offset.npz).  Any constant near the mean
+    // serves; a plain strided sum finds one.
+    double x_first;
+    {
+        double acc = 0.0;
+        for (int j = b.tid; j < n; j += b.nt) acc += g(j);
+        x_first = blk_sum(b, acc) / (double)n;
+        if (!(x_first == x_first) || isinf(x_first)) x_first = 0.0;
+    }
     if (n >= TSFA_GOERTZEL_MIN) {
         blk_sync();
         for (int k0 = 4 * b.tid; k0 <= nh; k0 += 4 * b.nt) {

@@ -21,6 +21,7 @@ The full matrix is rank-major: rows [starts[r], starts[r + 1]) belong to rank r.
   * unequal heights: grouped point-to-point `isend` / `irecv` straight between the rank slices -- on the fully
     connected xGMI mesh every block crosses exactly one link, no padding, no staging.
 """
+import collections
 import threading
 
 import numpy as np
@@ -203,6 +204,44 @@ def extract_sharded(extract_fn, values, offsets, n_cols, dist=None, torch_device
     return full.cpu().numpy()
 
 
+# Plans of extract_on_devices, kept across calls: (shard slot, device, specs) -> (plan, lock).  The workers are fresh
+# threads on every call, so the per-thread cache of feature_extraction/extraction.py never hits for them: round 2 built
+# len(devices) plans per call (8 ms each) and never released them -- device memory grew with every call.  A slot's
+# plan is driven by one thread at a time (its lock); the LRU closes what it evicts.
+_DEVICE_PLANS = collections.OrderedDict()
+_DEVICE_PLANS_LOCK = threading.Lock()
+_DEVICE_PLANS_MAX = 32
+
+
+def _device_plan(slot, device, specs):
+    from tsfresh_amd import _native
+    key = (int(slot), int(device), tuple((cid, tuple(float(v) for v in p)) for cid, p in specs))
+    evicted = []
+    with _DEVICE_PLANS_LOCK:
+        entry = _DEVICE_PLANS.get(key)
+        if entry is None:
+            entry = _DEVICE_PLANS[key] = (_native.Plan(specs, device=device), threading.Lock())
+            while len(_DEVICE_PLANS) > _DEVICE_PLANS_MAX:
+                old_key = next(k for k in _DEVICE_PLANS if k != key)
+                evicted.append(_DEVICE_PLANS.pop(old_key))
+        else:
+            _DEVICE_PLANS.move_to_end(key)
+    for plan, lock in evicted:
+        with lock:  # wait for a worker that may still be inside it
+            plan.close()
+    return entry
+
+
+def clear_device_plans():
+    """Release the plans extract_on_devices keeps (and the device memory they hold)."""
+    with _DEVICE_PLANS_LOCK:
+        entries = list(_DEVICE_PLANS.values())
+        _DEVICE_PLANS.clear()
+    for plan, lock in entries:
+        with lock:
+            plan.close()
+
+
 def extract_on_devices(specs, values, offsets, devices, times=None, n_cols=None):
     """One process, several GPUs: the ragged batch is cut into sum(len^2)-balanced contiguous shards, one per device;
     every device runs its chunked host pipeline (tsfa_extract, TSFA_HOST) from its own host thread and writes its rows
@@ -226,11 +265,11 @@ def extract_on_devices(specs, values, offsets, devices, times=None, n_cols=None)
         if hi <= lo:
             return
         try:
-            from tsfresh_amd.feature_extraction.extraction import _acquire_plan_specs
-            plan = _acquire_plan_specs(specs, dev)
+            plan, lock = _device_plan(k, dev, specs)
             sub = offsets[lo:hi + 1]
-            plan.extract_host(values[sub[0]:sub[-1]], sub - sub[0],
-                              times=None if times is None else times[sub[0]:sub[-1]], out=out[lo:hi])
+            with lock:
+                plan.extract_host(values[sub[0]:sub[-1]], sub - sub[0],
+                                  times=None if times is None else times[sub[0]:sub[-1]], out=out[lo:hi])
         except BaseException as e:  # surfaced in the calling thread
             errors.append(e)
 

@@ -41,17 +41,14 @@ def _default_device():
 # tsfa_extract), so every thread keeps its OWN small LRU: no thread can evict -- and destroy -- a plan another thread
 # is running, and no lock is held across the native call.
 _PLAN_CACHE_SIZE = 6
+_BATCH_KINDS_MAX_SAMPLES = 4_000_000   # kinds sharing a plan are concatenated into one native call up to this size
 _TLS = threading.local()
-_ALL_CACHES = []  # weak bookkeeping for clear_plan_cache(): (thread ident, cache)
-_ALL_CACHES_LOCK = threading.Lock()
 
 
 def _thread_cache():
     cache = getattr(_TLS, "plans", None)
     if cache is None:
-        cache = _TLS.plans = collections.OrderedDict()
-        with _ALL_CACHES_LOCK:
-            _ALL_CACHES.append((threading.get_ident(), cache))
+        cache = _TLS.plans = collections.OrderedDict()   # dies with the thread; the plans close in Plan.__del__
     return cache
 
 
@@ -156,6 +153,7 @@ def extract_features(
 
         blocks = []  # (PackedKind, column names, matrix)
         plan_cache = {}
+        jobs = []    # (PackedKind, FeaturePlan, native plan or None)
         for pk in packed:
             if kind_to_fc_parameters and pk.kind in kind_to_fc_parameters:
                 fc_parameters = kind_to_fc_parameters[pk.kind]
@@ -170,9 +168,41 @@ def extract_features(
             fplan, nplan = plan_cache[key]
             if len(fplan) == 0:
                 continue
-            if not fplan.names:
+            jobs.append((pk, fplan, nplan))
+
+        # Kinds that share a plan and a sample dtype travel in ONE native call while the batch is small: a frame of 6
+        # kinds x 88 series x 15 samples (BASELINE configs[0]) is one upload / launch set / download instead of six.
+        # Beyond _BATCH_KINDS_MAX_SAMPLES the concatenation copy costs more than the launches it saves.
+        matrices = {}
+        multi = devices is not None and len(devices) > 1
+        groups = collections.OrderedDict()
+        for j, (pk, fplan, nplan) in enumerate(jobs):
+            if nplan is not None and not multi:
+                groups.setdefault((id(nplan), pk.values.dtype.str, pk.times is not None), []).append(j)
+        for members in groups.values():
+            total = sum(len(jobs[j][0].values) for j in members)
+            if len(members) < 2 or total > _BATCH_KINDS_MAX_SAMPLES:
+                continue
+            pks = [jobs[j][0] for j in members]
+            nplan = jobs[members[0]][2]
+            values = np.concatenate([pk.values for pk in pks])
+            times = np.concatenate([pk.times for pk in pks]) if pks[0].times is not None else None
+            offs, base = [np.zeros(1, dtype=np.int64)], 0
+            for pk in pks:
+                offs.append(np.asarray(pk.offsets[1:], dtype=np.int64) + base)
+                base += int(pk.offsets[-1])
+            big = nplan.extract_host(values, np.concatenate(offs), times=times)
+            r0 = 0
+            for j, pk in zip(members, pks):
+                matrices[j] = big[r0:r0 + pk.n_series]
+                r0 += pk.n_series
+
+        for j, (pk, fplan, nplan) in enumerate(jobs):
+            if j in matrices:
+                matrix = matrices[j]
+            elif not fplan.names:
                 matrix = np.empty((pk.n_series, 0))
-            elif devices is not None and len(devices) > 1:
+            elif multi:
                 from tsfresh_amd.distributed import extract_on_devices
                 matrix = extract_on_devices(fplan.native_specs(_native.calc_id), pk.values, pk.offsets, devices,
                                             times=pk.times)
