@@ -33,7 +33,7 @@ typedef enum tsfa_status {
     TSFA_ERR_UNSUPPORTED = -2, /* calculator / parameter not implemented natively */
     TSFA_ERR_NO_DEVICE = -3,   /* no HIP device: the library never falls back to the CPU */
     TSFA_ERR_HIP = -4,         /* HIP runtime error */
-    TSFA_ERR_TOO_LONG = -5     /* a series exceeds the per-workgroup LDS budget */
+    TSFA_ERR_TOO_LONG = -5     /* a series holds more than 65 535 samples (the 16-bit sample indices of the kernels) */
 } tsfa_status;
 
 /* element type of the ragged value buffer */

@@ -1,0 +1,209 @@
+// Design lab for the fused MinimalFCParameters kernel: standalone timing of the candidate pieces on
+// 100 000 x 1024 float32 series.  hipcc --offload-arch=gfx950 -O3 -o /tmp/lab profiles/lab/minimal_fused_lab.hip && /tmp/lab
+#include <hip/hip_runtime.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <math.h>
+#include <vector>
+#include <algorithm>
+
+#define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e_), __LINE__); exit(1); } } while (0)
+
+__device__ __forceinline__ unsigned enc(float v) { unsigned u = __float_as_uint(v); return (u & 0x80000000u) ? ~u : (u | 0x80000000u); }
+__device__ __forceinline__ float dec(unsigned k) { unsigned u = (k & 0x80000000u) ? (k & 0x7FFFFFFFu) : ~k; return __uint_as_float(u); }
+
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+__device__ __forceinline__ float wave_min(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fminf(v, __shfl_xor(v, o));
+    return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o));
+    return v;
+}
+
+template <int E>
+__device__ __forceinline__ unsigned bit_select(const unsigned (&key)[E], int k) {
+    unsigned prefix = 0;
+#pragma unroll 1
+    for (int bit = 31; bit >= 0; --bit) {
+        const unsigned cand = prefix | (1u << bit);
+        int c = 0;
+#pragma unroll
+        for (int e = 0; e < E; ++e) c += __popcll(__ballot(key[e] < cand));
+        if (c <= k) prefix = cand;
+    }
+    return prefix;
+}
+
+// mode 0: load + sum; 1: stats; 2: bit-select median; 3: stats + bit-select; 4: stats + window-select (fallback bit-select)
+template <int MODE>
+__global__ void __launch_bounds__(256) k_lab(const float *__restrict__ x, int n_series, int L, double *__restrict__ out, int ld,
+                                               int *__restrict__ fallbacks) {
+    const int lane = threadIdx.x & 63;
+    const int wi = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (wi >= n_series) return;
+    const float *g = x + (size_t)wi * L;
+    float v[16];
+#pragma unroll
+    for (int e = 0; e < 16; ++e) v[e] = g[e * 64 + lane];
+    double *row = out + (size_t)wi * ld;
+    double s = 0.0;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) s += (double)v[e];
+    s = wave_sum(s);
+    const double mean = s / (double)L;
+    if (MODE == 0) { if (lane == 0) row[0] = s; return; }
+    double var = 0.0, ss = 0.0;
+    float mn = v[0], mx = v[0];
+    if (MODE == 1 || MODE >= 3) {
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            const double d = (double)v[e] - mean;
+            var += d * d;
+            ss += (double)v[e] * (double)v[e];
+            mn = fminf(mn, v[e]);
+            mx = fmaxf(mx, v[e]);
+        }
+        var = wave_sum(var) / (double)L;
+        ss = wave_sum(ss);
+        mn = wave_min(mn);
+        mx = wave_max(mx);
+    }
+    double med = 0.0;
+    if (MODE == 2 || MODE == 3) {
+        unsigned key[16];
+#pragma unroll
+        for (int e = 0; e < 16; ++e) key[e] = enc(v[e]);
+        const unsigned k0 = bit_select<16>(key, L / 2 - 1);
+        int cle = 0;
+        unsigned nxt = 0xFFFFFFFFu;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            cle += __popcll(__ballot(key[e] <= k0));
+            if (key[e] > k0 && key[e] < nxt) nxt = key[e];
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) { const unsigned t = (unsigned)__shfl_xor((int)nxt, o); nxt = (t < nxt) ? t : nxt; }
+        const double a0 = dec(k0), a1 = (cle >= L / 2 + 1) ? a0 : (double)dec(nxt);
+        med = (a0 + a1) / 2.0;
+    }
+    if (MODE == 4) {
+        // window select: samples within [lo, hi] around the mean, expected ~40 of 1024 for a bell-shaped series
+        __shared__ unsigned win[4][64];
+        unsigned *w = win[threadIdx.x >> 6];
+        const float sd = (float)sqrt(var);
+        const int k = L / 2 - 1;   // need order statistics k and k + 1
+        const float lo = (float)mean - 0.05f * sd, hi = (float)mean + 0.05f * sd;
+        int below = 0, inwin = 0;
+        unsigned long long m[16];
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            below += __popcll(__ballot(v[e] < lo));
+            m[e] = __ballot(v[e] >= lo && v[e] <= hi);
+            inwin += __popcll(m[e]);
+        }
+        bool ok = (inwin <= 64) && (k >= below) && (k + 1 < below + inwin);
+        if (ok) {
+            int base = 0;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const bool in = (m[e] >> lane) & 1ull;
+                const int pos = base + __popcll(m[e] & ((1ull << lane) - 1ull));
+                if (in) w[pos] = enc(v[e]);
+                base += __popcll(m[e]);
+            }
+            __builtin_amdgcn_wave_barrier();
+            unsigned key = (lane < inwin) ? w[lane] : 0xFFFFFFFFu;
+            // bitonic sort of 64 keys across the lanes
+#pragma unroll
+            for (int kk = 2; kk <= 64; kk <<= 1) {
+#pragma unroll
+                for (int j = kk >> 1; j > 0; j >>= 1) {
+                    const unsigned o = (unsigned)__shfl_xor((int)key, j);
+                    const bool up = ((lane & kk) == 0);
+                    const bool lower = ((lane & j) == 0);
+                    const unsigned mnk = key < o ? key : o, mxk = key < o ? o : key;
+                    key = (lower == up) ? mnk : mxk;
+                }
+            }
+            const unsigned k0 = (unsigned)__shfl((int)key, k - below), k1 = (unsigned)__shfl((int)key, k + 1 - below);
+            med = ((double)dec(k0) + (double)dec(k1)) / 2.0;
+        } else {
+            if (lane == 0) atomicAdd(fallbacks, 1);
+            unsigned key[16];
+#pragma unroll
+            for (int e = 0; e < 16; ++e) key[e] = enc(v[e]);
+            const unsigned k0 = bit_select<16>(key, k);
+            int cle = 0;
+            unsigned nxt = 0xFFFFFFFFu;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                cle += __popcll(__ballot(key[e] <= k0));
+                if (key[e] > k0 && key[e] < nxt) nxt = key[e];
+            }
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) { const unsigned t = (unsigned)__shfl_xor((int)nxt, o); nxt = (t < nxt) ? t : nxt; }
+            const double a0 = dec(k0), a1 = (cle >= k + 2) ? a0 : (double)dec(nxt);
+            med = (a0 + a1) / 2.0;
+        }
+    }
+    // lane = column epilogue: 10 columns, one 8-byte store each from lanes 0..9 (one 80-byte segment)
+    double r = 0.0;
+    switch (lane) {
+    case 0: r = s; break;
+    case 1: r = med; break;
+    case 2: r = mean; break;
+    case 3: r = (double)L; break;
+    case 4: r = sqrt(var); break;
+    case 5: r = var; break;
+    case 6: r = sqrt(ss / (double)L); break;
+    case 7: r = mx; break;
+    case 8: r = fmax(fabs((double)mn), fabs((double)mx)); break;
+    case 9: r = mn; break;
+    default: break;
+    }
+    if (lane < 10) row[lane] = r;
+}
+
+int main() {
+    const int n = 100000, L = 1024, ld = 10;
+    std::vector<float> h((size_t)n * L);
+    srand(1);
+    for (auto &v : h) { float a = 0; for (int i = 0; i < 12; ++i) a += rand() / (float)RAND_MAX; v = a - 6.0f; }
+    float *dx; double *dout; int *dfb;
+    CK(hipMalloc(&dx, h.size() * 4)); CK(hipMalloc(&dout, (size_t)n * ld * 8)); CK(hipMalloc(&dfb, 4));
+    CK(hipMemcpy(dx, h.data(), h.size() * 4, hipMemcpyHostToDevice));
+    hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+    auto time = [&](const char *name, auto launch) {
+        CK(hipMemset(dfb, 0, 4));
+        launch(); CK(hipDeviceSynchronize());
+        CK(hipEventRecord(e0));
+        for (int r = 0; r < 10; ++r) launch();
+        CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
+        float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+        int fb; CK(hipMemcpy(&fb, dfb, 4, hipMemcpyDeviceToHost));
+        printf("%-28s %.3f ms  (%.2f TB/s)  fallbacks/launch %d\n", name, ms / 10, (double)n * L * 4 / (ms / 10 * 1e-3) / 1e12, fb / 11);
+    };
+    const dim3 grid((n + 3) / 4);
+    time("load + sum", [&] { k_lab<0><<<grid, 256>>>(dx, n, L, dout, ld, dfb); });
+    time("stats", [&] { k_lab<1><<<grid, 256>>>(dx, n, L, dout, ld, dfb); });
+    time("bit-select median", [&] { k_lab<2><<<grid, 256>>>(dx, n, L, dout, ld, dfb); });
+    time("stats + bit-select", [&] { k_lab<3><<<grid, 256>>>(dx, n, L, dout, ld, dfb); });
+    time("stats + window-select", [&] { k_lab<4><<<grid, 256>>>(dx, n, L, dout, ld, dfb); });
+    // check medians of mode 3 against mode 4 and the host
+    std::vector<double> o3((size_t)n * ld), o4((size_t)n * ld);
+    k_lab<3><<<grid, 256>>>(dx, n, L, dout, ld, dfb); CK(hipMemcpy(o3.data(), dout, o3.size() * 8, hipMemcpyDeviceToHost));
+    k_lab<4><<<grid, 256>>>(dx, n, L, dout, ld, dfb); CK(hipMemcpy(o4.data(), dout, o4.size() * 8, hipMemcpyDeviceToHost));
+    int bad = 0;
+    for (int i = 0; i < n; ++i) if (o3[(size_t)i * ld + 1] != o4[(size_t)i * ld + 1]) ++bad;
+    std::vector<float> t(h.begin(), h.begin() + L); std::sort(t.begin(), t.end());
+    printf("median mismatches window vs bit-select: %d; series 0: host %.9g gpu %.9g\n", bad, ((double)t[L / 2 - 1] + t[L / 2]) / 2, o3[1]);
+    return 0;
+}

@@ -109,10 +109,20 @@ extern "C" int tsfa_emul_extract_timed(const tsfa_feature_spec *specs, int n_spe
         }
         if (!fam[TSFA_FAM_SORT].empty()) {
             std::vector<double> srt(tsfa_pow2_ceil(maxn) + 8), w(1280), cq(5 * TSFA_CQ_MAX), sctx(8);
+            // every third series: the sorted copy as a gather through the sample order another family left behind
+            // (k_entropy_bits -> k_sort on the device)
+            std::vector<unsigned short> order;
+            if (s % 3 == 0 && n >= 3 && n <= 65535) {
+                order.resize(n);
+                for (int i = 0; i < n; ++i) order[i] = (unsigned short)i;
+                std::stable_sort(order.begin(), order.end(), [&](unsigned short a, unsigned short c) { return xs[a] < xs[c]; });
+            }
             fam_sort_series(b, xs.data(), n, fam[TSFA_FAM_SORT].data(), (int)fam[TSFA_FAM_SORT].size(), row, srt.data(),
                             w.data(), (int *)w.data(), hints[TSFA_FAM_SORT].cq, cq.data(), nullptr,
                             (s % 2) ? -1 : hints[TSFA_FAM_SORT].c, sctx.data(),
-                            (s % 4 >= 2) ? hints[TSFA_FAM_SORT].a : 1280);  // plan-sized scratch: multi-pass pattern histogram
+                            (s % 4 >= 2) ? hints[TSFA_FAM_SORT].a : 1280,  // plan-sized scratch: multi-pass pattern histogram
+                            FrDefer{nullptr, nullptr, TSFA_PF_HDR + 2 * TSFA_FRIEDRICH_MAX_R, 0, 0},
+                            order.empty() ? nullptr : order.data());
         }
         if (!fam[TSFA_FAM_SPECTRAL].empty()) {
             const int nx = (maxn / 2 + 2 > 260) ? maxn / 2 + 2 : 260;

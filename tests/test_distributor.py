@@ -160,9 +160,84 @@ def test_partition_binding_returns_the_reference_long_rows(gpu):
     except ImportError:
         with pytest.raises(ImportError, match="needs dask"):
             dask_feature_extraction_on_chunk(df, "id", "kind", "v", "t", MinimalFCParameters())
+
+
+@pytest.mark.gpu
+def test_map_reduce_over_comprehensive_parameters_matches_the_oracle(gpu):
+    """N4 on the device: the reference's chunk tuples through GPUDistributor.map_reduce with
+    ComprehensiveFCParameters, every (id, column) value against the oracle by column NAME."""
+    from engines import oracle_engine
+    from parity import compare
+    from tsfresh_amd import ComprehensiveFCParameters
+    rng = np.random.default_rng(17)
+    Chunk = type(_chunks()[0])
+    chunks, series = [], {}
+    for sid in range(5):
+        for kind, n in (("a", 300), ("b", 128)):
+            x = rng.standard_normal(n) if kind == "a" else np.cumsum(rng.standard_normal(n))
+            chunks.append(Chunk(sid, kind, pd.Series(x)))
+            series[(sid, kind)] = x
+    params = ComprehensiveFCParameters()
+    tuples = GPUDistributor().map_reduce(None, data=iter(chunks), function_kwargs={"default_fc_parameters": params,
+                                                                                   "kind_to_fc_parameters": None})
+    got = {(t[0], t[1]): float(t[2]) for t in tuples}
+    for kind in ("a", "b"):
+        ids = sorted({c.id for c in chunks})
+        xs = [series[(i, kind)] for i in ids]
+        values = np.concatenate(xs)
+        offsets = np.concatenate([[0], np.cumsum([len(x) for x in xs])]).astype(np.int64)
+        names, want = oracle_engine(params, values, offsets, kind=kind)
+        assert all((i, n) in got for i in ids for n in names), "a column is missing from the tuples"
+        mat = np.array([[got[(i, n)] for n in names] for i in ids])
+        bad = compare(["value__" + n.split("__", 1)[1] for n in names], mat, want, xs)
+        assert not bad, bad[:8]
+    assert len(got) == 10 * 783
+
+
+class _StandInDaskFrame:
+    """What dask_feature_extraction_on_chunk needs of a dask DataFrame: column access for the meta frame and
+    map_partitions(fn, **kwargs, meta=...) -- applied eagerly to a list of pandas partitions here."""
+
+    def __init__(self, partitions):
+        self.partitions = partitions
+
+    def __getitem__(self, col):
+        return self.partitions[0][col]
+
+    def map_partitions(self, fn, meta=None, **kwargs):
+        out = pd.concat([fn(p, **kwargs) for p in self.partitions], ignore_index=True)
+        assert list(out.columns) == list(meta.columns) and all(out.dtypes == meta.dtypes)
+        return out
+
+
+@pytest.mark.gpu
+def test_dask_binding_wiring(gpu, monkeypatch):
+    """bindings.py:9-60 at partition grain.  dask is not in this image: the wrapper's wiring (meta frame, keyword
+    plumbing, one extraction per partition) runs against a stand-in frame; with dask installed the second half builds and
+    computes a real graph."""
+    import sys
+    import types
+    from tsfresh_amd import MinimalFCParameters
+    from tsfresh_amd.convenience.bindings import dask_feature_extraction_on_chunk, feature_extraction_on_partition
+    chunks = _chunks()
+    df = pd.concat([pd.DataFrame({"id": c.id, "kind": c.kind, "t": np.arange(len(c.data)), "v": c.data.to_numpy()})
+                    for c in chunks], ignore_index=True)
+    want = feature_extraction_on_partition(df, "id", "kind", "v", "t", MinimalFCParameters())
+    ids = sorted(df["id"].unique())
+    parts = [df[df["id"].isin(ids[:1])], df[df["id"].isin(ids[1:])]]
     try:
-        import pyspark  # noqa: F401
+        import dask.dataframe as dd
+        real = True
     except ImportError:
-        from tsfresh_amd.convenience.bindings import spark_feature_extraction_on_chunk
-        with pytest.raises(ImportError, match="needs pyspark"):
-            spark_feature_extraction_on_chunk(df, "id", "kind", "v", "t", MinimalFCParameters())
+        real = False
+        fake = types.ModuleType("dask")
+        fake.dataframe = types.ModuleType("dask.dataframe")
+        monkeypatch.setitem(sys.modules, "dask", fake)
+        monkeypatch.setitem(sys.modules, "dask.dataframe", fake.dataframe)
+    got = dask_feature_extraction_on_chunk(_StandInDaskFrame(parts), "id", "kind", "v", "t", MinimalFCParameters())
+    key = ["id", "variable"]
+    assert got.sort_values(key).reset_index(drop=True).equals(want.sort_values(key).reset_index(drop=True))
+    if real:
+        ddf = dd.from_pandas(df.sort_values("id"), npartitions=2)
+        out = dask_feature_extraction_on_chunk(ddf, "id", "kind", "v", "t", MinimalFCParameters()).compute()
+        assert out.sort_values(key).reset_index(drop=True).equals(want.sort_values(key).reset_index(drop=True))

@@ -1,4 +1,4 @@
-"""dask / spark partition bindings (reference: tsfresh/convenience/bindings.py:9-60, :62-162, :164-264).
+"""dask partition binding (reference: tsfresh/convenience/bindings.py:9-60, :62-162).
 
 The reference hands dask one `(id, kind)` group at a time: `df.groupby([id, kind]).apply(_feature_extraction_on_chunk_
 helper)` runs the Python dispatcher per series and returns long `(id, variable, value)` rows.  One series per call is
@@ -7,11 +7,10 @@ the wrong grain for a GPU: here the unit of work is a whole PARTITION -- `featur
 rows; `dask_feature_extraction_on_chunk` maps it over the partitions of a dask DataFrame (which must be partitioned
 so that no id is split across partitions, e.g. `df.set_index(column_id)` or `shuffle(on=column_id)`).
 
-`spark_feature_extraction_on_chunk` does the same for a Spark DataFrame (`repartition(column_id)`, then one grouped-map
-pandas call per Spark partition).
+The reference's Spark entry point (bindings.py:164-264) is out of scope (SURVEY.md section 2 / 8f name only the dask
+binding): a Spark job calls `feature_extraction_on_partition` from its own grouped-map function.
 
-Neither dask nor pyspark is a dependency of this package: the entry points import them lazily and say so when they
-are missing.
+dask is not a dependency of this package: the entry point imports it lazily and says so when it is missing.
 """
 import numpy as np
 import pandas as pd
@@ -65,40 +64,3 @@ def dask_feature_extraction_on_chunk(df, column_id, column_kind, column_value, c
                                 column_value=column_value, column_sort=column_sort,
                                 default_fc_parameters=default_fc_parameters, kind_to_fc_parameters=kind_to_fc_parameters,
                                 device=device, meta=meta)
-
-
-def spark_feature_extraction_on_chunk(df, column_id, column_kind, column_value, column_sort=None,
-                                      default_fc_parameters=None, kind_to_fc_parameters=None, device=None):
-    """The reference's Spark entry point (bindings.py:164) at partition grain.
-
-    The reference registers `_feature_extraction_on_chunk_helper` as a GROUPED_MAP pandas UDF and applies it to every
-    (id, kind) group (bindings.py:252-264).  Here the frame is repartitioned by `column_id` (every id in ONE partition)
-    and each Spark partition is extracted in one pass on the executor's GPU.
-
-    :param df: a `pyspark.sql.DataFrame` in long format with the columns `column_id`, `column_kind`, `column_value`
-        (and `column_sort`).  (The reference takes `df.groupby([id, kind])`; a `GroupedData` cannot be un-grouped, so
-        pass the frame itself.)
-    :return: `pyspark.sql.DataFrame[column_id, variable: string, value: double]`, as the reference returns; pivot it
-        with `.groupby(column_id).pivot("variable").sum("value")`."""
-    try:
-        from pyspark.sql import functions as F
-        from pyspark.sql.types import DoubleType, StringType, StructField, StructType
-    except ImportError as e:  # pragma: no cover - pyspark is not installed in the build image
-        raise ImportError("spark_feature_extraction_on_chunk needs pyspark; for a pandas frame call "
-                          "feature_extraction_on_partition directly") from e
-    if not hasattr(df, "repartition"):
-        raise TypeError("pass the Spark DataFrame itself (not df.groupby(...)): the partitions are formed by column_id here")
-    id_field = [f for f in df.schema.fields if f.name == column_id]
-    if not id_field:
-        raise ValueError("column {!r} is not in the Spark DataFrame".format(column_id))
-    schema = StructType([StructField(column_id, id_field[0].dataType), StructField("variable", StringType()),
-                         StructField("value", DoubleType())])
-
-    def on_partition(pdf):
-        return feature_extraction_on_partition(pdf.drop(columns=["__tsfa_part"]), column_id=column_id,
-                                               column_kind=column_kind, column_value=column_value, column_sort=column_sort,
-                                               default_fc_parameters=default_fc_parameters,
-                                               kind_to_fc_parameters=kind_to_fc_parameters, device=device)
-
-    parts = df.repartition(column_id).withColumn("__tsfa_part", F.spark_partition_id())
-    return parts.groupby("__tsfa_part").applyInPandas(on_partition, schema=schema)

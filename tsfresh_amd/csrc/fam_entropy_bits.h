@@ -625,7 +625,8 @@ TSFA_DEVN void entb_sort_merge(const Blk b, const double *xs, int n, unsigned sh
 // next_pow2(n) + 32 entries; work: entb_work_words(maxn) words (may alias b.np: the numpy-order sums finish first).
 template <bool F32>
 TSFA_DEV void fam_entropy_series_bits(const Blk &b, double *xs, int n, const TsfaSpec *specs, int nspecs, double *out_row,
-                                      double *thr, unsigned short *perm, unsigned int *work) {
+                                      double *thr, unsigned short *perm, unsigned int *work,
+                                      unsigned short *perm_out = nullptr) {
     TSFA_TICKER(tk, 0);
     const double dn = (double)n;
     const double mean = np_sum(b, n, [=](int i) { return xs[i]; }) / dn;
@@ -645,6 +646,9 @@ TSFA_DEV void fam_entropy_series_bits(const Blk &b, double *xs, int n, const Tsf
         }
 #endif
         if (!sorted) entropy_sort_templates(b, xs, n + 1, perm, np2, F32);  // all n samples (a "template" per sample)
+        if (perm_out != nullptr) {  // the sample order, for the SORT family of the same plan (fam_sort.h: perm_in)
+            for (int i = b.tid; i < n; i += b.nt) perm_out[i] = perm[i];
+        }
         TSFA_TICK(tk, b, 131);
     }
     double *racc = thr + TSFA_ENTB_MAXK;

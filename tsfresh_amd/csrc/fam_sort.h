@@ -635,7 +635,8 @@ template <class ST>
 TSFA_DEV void fam_sort_series(const Blk &b, const ST *xs_raw, int n, const TsfaSpec *specs, int nspecs,
                               double *out_row, ST *srt_raw, double *w, int *iw, const TsfaCqPlan &cqplan, double *cq,
                               TsfaSpec *stage, int n_loop = -1, double *ctx = nullptr, int w_doubles = 1280,
-                              FrDefer df = FrDefer{nullptr, nullptr, TSFA_PF_HDR + 2 * TSFA_FRIEDRICH_MAX_R, 0, 0}) {
+                              FrDefer df = FrDefer{nullptr, nullptr, TSFA_PF_HDR + 2 * TSFA_FRIEDRICH_MAX_R, 0, 0},
+                              const unsigned short *perm_in = nullptr) {
     const int hist_words = 2 * w_doubles;  // iw aliases w: 32-bit words of the ordinal-pattern histogram
     // n_loop columns go through the column loop; the rest are evaluated by sort_epilogue (lane = column)
     const int nloop = (n_loop >= 0 && ctx != nullptr) ? n_loop : nspecs;
@@ -644,6 +645,13 @@ TSFA_DEV void fam_sort_series(const Blk &b, const ST *xs_raw, int n, const TsfaS
     const int np2 = next_pow2(n);
     TSFA_TICKER(tk, 0);
     blk_sync();
+    // perm_in: the sample order another family of the same plan already established (k_entropy_bits sorts the samples
+    // for its ranges and leaves the permutation in HBM, 2 bytes per sample): the sorted copy is then a gather from the
+    // resident series instead of a second sort of the same keys (62 k of this kernel's cycles per series)
+    if (perm_in != nullptr && n >= 3) {
+        for (int i = b.tid; i < np2; i += b.nt) srt_raw[i] = (i < n) ? xs_raw[perm_in[i]] : (ST)TSFA_INF;
+        blk_sync();
+    } else
 #if TSFA_GPU
     if (!blk_sorted_copy_regs(b, xs_raw, n, srt_raw, np2))
 #endif

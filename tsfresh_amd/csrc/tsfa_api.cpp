@@ -76,7 +76,7 @@ struct tsfa_plan {
     int *d_cols = nullptr, *d_coeff = nullptr;
     double *d_dectab = nullptr, *d_twc = nullptr, *d_tws = nullptr;
     long long *d_stats = nullptr;
-    DevBuf values, offsets, out, gscratch, times, deg_list, sel, long_scratch, pf_buf;
+    DevBuf values, offsets, out, gscratch, times, deg_list, sel, long_scratch, pf_buf, perm_buf;
     int *d_deg_count = nullptr;
     int *d_cursor = nullptr;                    // per-launch-group fill cursors (k_class_fill)
     hipStream_t s_in = nullptr, s_out = nullptr;  // copy-in / copy-out streams of the host pipeline
@@ -152,6 +152,7 @@ void tsfa_plan_destroy(tsfa_plan *plan) {
     if (plan->d_cursor) (void)hipFree(plan->d_cursor);
     plan->deg_list.release();
     plan->pf_buf.release();
+    plan->perm_buf.release();
     plan->sel.release();
     plan->long_scratch.release();
     for (int i = 0; i < TSFA_MAX_CHUNKS; ++i) {
@@ -400,6 +401,12 @@ static int run_batch(tsfa_plan *plan, const void *d_values, int dtype, const dou
     }
     size_t slot = 0;
     int dealt = 0;
+    // the sample order k_entropy_bits establishes is handed to k_sort through plan->perm_buf (2 bytes per sample): one
+    // sort per series instead of two.  Per launch group: only where the bit-matrix sweep ran (float32 or float64 series
+    // of 3 .. 1024 samples, LDS build), and only on one stream (the entropy family is launched first).
+    bool perm_valid[TSFA_N_LEN_CLASSES + 1];
+    for (int g = 0; g <= TSFA_N_LEN_CLASSES; ++g) perm_valid[g] = false;
+    const bool perm_share = plan->perm_buf.p != nullptr && !overlap && !(getenv("TSFA_NO_PERM_SHARE") && atoi(getenv("TSFA_NO_PERM_SHARE")));
     for (int fi = 0; fi < TSFA_N_FAMILIES; ++fi) {
         const int f = order[fi];
         if (plan->fam_specs[f].empty()) continue;
@@ -582,6 +589,16 @@ static int run_batch(tsfa_plan *plan, const void *d_values, int dtype, const dou
                 a.long_scratch = (unsigned char *)plan->long_scratch.p;
                 a.long_bytes = (size_t)n_slots * slot_bytes;
             }
+            if (perm_share && !use_long && g <= TSFA_N_LEN_CLASSES) {
+                if (f == TSFA_FAM_ENTROPY && a.ent_cnt == 2) {
+                    a.perm_buf = (unsigned short *)plan->perm_buf.p;
+                    a.perm_stride = TSFA_ENTB_MAXN;
+                    perm_valid[g] = true;
+                } else if (f == TSFA_FAM_SORT && perm_valid[g]) {
+                    a.perm_buf = (unsigned short *)plan->perm_buf.p;
+                    a.perm_stride = TSFA_ENTB_MAXN;
+                }
+            }
             int rc = 0;
             if (f == TSFA_FAM_SORT && plan->sort_only_order_stats && maxn <= 2048 && !use_long &&
                 !(getenv("TSFA_NO_SELECT") && atoi(getenv("TSFA_NO_SELECT")))) {
@@ -672,6 +689,9 @@ int tsfa_extract_windows(tsfa_plan *plan, const void *values, int32_t dtype, con
     const size_t esz = (dtype == TSFA_F32) ? 4 : 8;
     if (plan->deg_list.ensure((size_t)n_series * sizeof(long long)))
         return fail(TSFA_ERR_HIP, "hipMalloc failed for the k_ar_degenerate list");
+    if (!plan->fam_specs[TSFA_FAM_SORT].empty() && !plan->fam_specs[TSFA_FAM_ENTROPY].empty() && !plan->sort_only_order_stats &&
+        plan->perm_buf.ensure((size_t)n_series * (size_t)TSFA_ENTB_MAXN * sizeof(unsigned short)))
+        return fail(TSFA_ERR_HIP, "hipMalloc failed for the shared sample order");
     if (plan->hints[TSFA_FAM_SORT].b > 0 &&
         plan->pf_buf.ensure((size_t)n_series * (size_t)tsfa_pf_slot_doubles(plan->hints[TSFA_FAM_SORT].b) * sizeof(double)))
         return fail(TSFA_ERR_HIP, "hipMalloc failed for the records of the Langevin second pass");

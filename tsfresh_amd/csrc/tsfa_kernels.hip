@@ -165,7 +165,7 @@ template <typename T>
 __global__ void __launch_bounds__(1024) k_sort(const T *__restrict__ values, const int64_t *__restrict__ starts, const int64_t *__restrict__ ends, int64_t n_series, const int *__restrict__ sel,
                        const TsfaSpec *__restrict__ specs, int nspecs, double *__restrict__ out, int64_t ld, int maxn,
                        const TsfaCqPlan cqplan, int n_loop, int w_doubles, double *__restrict__ pf_buf,
-                       int *__restrict__ pf_count, int pf_slot TSFA_GS_PARAMS) {
+                       int *__restrict__ pf_count, int pf_slot, const unsigned short *__restrict__ perm_buf, int perm_stride TSFA_GS_PARAMS) {
     TSFA_SERIES_BEGIN
     const int64_t off = starts[sidx];
     const int n = (int)(ends[sidx] - off);
@@ -180,7 +180,8 @@ __global__ void __launch_bounds__(1024) k_sort(const T *__restrict__ values, con
         blk_sync();
     }
     fam_sort_series<T>(b, xs, n, specs, nspecs, out + sidx * ld, (T *)L.srt, L.w, L.iw, cqplan, L.cq, L.stage,
-                       n_loop, L.ctx, w_doubles, FrDefer{pf_buf, pf_count, pf_slot, (long long)sidx, 0});
+                       n_loop, L.ctx, w_doubles, FrDefer{pf_buf, pf_count, pf_slot, (long long)sidx, 0},
+                       perm_buf ? perm_buf + (size_t)sidx * (size_t)perm_stride : nullptr);
     TSFA_TICKS_END();
     TSFA_SERIES_END
 }
@@ -311,7 +312,8 @@ __global__ void __launch_bounds__(1024) k_entropy(const T *__restrict__ values, 
 // (shorter ones take the closed forms); workgroup = entb_waves_for(maxn, nspecs) wavefronts.
 template <typename T>
 __global__ void __launch_bounds__(1024) k_entropy_bits(const T *__restrict__ values, const int64_t *__restrict__ starts, const int64_t *__restrict__ ends, int64_t n_series, const int *__restrict__ sel,
-                          const TsfaSpec *__restrict__ specs, int nspecs, double *__restrict__ out, int64_t ld, int maxn) {
+                          const TsfaSpec *__restrict__ specs, int nspecs, double *__restrict__ out, int64_t ld, int maxn,
+                          unsigned short *__restrict__ perm_buf, int perm_stride) {
     TSFA_SERIES_BEGIN
     const int64_t off = starts[sidx];
     const int n = (int)(ends[sidx] - off);
@@ -320,7 +322,8 @@ __global__ void __launch_bounds__(1024) k_entropy_bits(const T *__restrict__ val
     TSFA_TICKS_BEGIN();
     Blk b{(int)threadIdx.x, (int)blockDim.x, L.red, L.np};
     stage_series(b, values + off, n, L.xs);
-    fam_entropy_series_bits<sizeof(T) == 4>(b, L.xs, n, specs, nspecs, out + sidx * ld, L.thr, L.perm, L.cnt);
+    fam_entropy_series_bits<sizeof(T) == 4>(b, L.xs, n, specs, nspecs, out + sidx * ld, L.thr, L.perm, L.cnt,
+                                            perm_buf ? perm_buf + (size_t)sidx * (size_t)perm_stride : nullptr);
     TSFA_TICKS_END();
     TSFA_SERIES_END
 }
@@ -669,7 +672,7 @@ static int launch_all_t(const TsfaLaunch &a, const T *values) {
         const int wd = (a.hint_a >= 320) ? a.hint_a : 1280;
         const size_t lds = L.carve(nullptr, a.maxn, nt, (int)sizeof(T), wd);
         TSFA_KLAUNCH(k_sort<T>, lds, values, a.starts, a.ends, a.n_series, a.sel, a.specs, a.nspecs, a.out, a.ld, a.maxn, a.cq,
-                     a.hint_c, wd, a.pf_buf, a.pf_count, a.pf_slot);
+                     a.hint_c, wd, a.pf_buf, a.pf_count, a.pf_slot, a.perm_buf, a.perm_stride);
     } else if (a.fam == TSFA_FAM_SPECTRAL) {
         SpectralLds L;
         const size_t lds = L.carve(nullptr, a.maxn, a.dft_n, (int)sizeof(T));
@@ -686,7 +689,8 @@ static int launch_all_t(const TsfaLaunch &a, const T *values) {
 #if !defined(TSFA_LONG)
         if (a.ent_cnt == 2) {
             auto kfn = k_entropy_bits<T>;
-            TSFA_KLAUNCH(kfn, lds, values, a.starts, a.ends, a.n_series, a.sel, a.specs, a.nspecs, a.out, a.ld, a.maxn);
+            TSFA_KLAUNCH(kfn, lds, values, a.starts, a.ends, a.n_series, a.sel, a.specs, a.nspecs, a.out, a.ld, a.maxn,
+                         a.perm_buf, a.perm_stride);
         } else
 #endif
         if (a.ent_fast) {

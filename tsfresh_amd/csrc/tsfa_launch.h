@@ -55,6 +55,8 @@ struct TsfaLaunch {
     double *pf_buf;         // SORT: records of the Langevin fits left to k_langevin_dd (fam_langevin_dd.h) ...
     int *pf_count;          // ... their number (device; zeroed before the launch) ...
     int pf_slot;            // ... and the doubles per record (tsfa_pf_slot_doubles)
+    unsigned short *perm_buf;  // ENTROPY (bit-matrix sweep) writes / SORT reads: sample order of every series, perm_stride entries each
+    int perm_stride;
     int cwt_rowv;           // CWT peaks: second CWT row resident in LDS
     int hint_a, hint_b, hint_c, hint_d, hint_e;  // tsfa_prepare_family (BASIC, SORT, SPECTRAL, AR)
     unsigned char *long_scratch;  // HBM scratch of the long-series build (tsfa_launch_family_long) ...
