@@ -154,6 +154,84 @@ __global__ void __launch_bounds__(256) k_lab(const float *__restrict__ x, int n_
             med = (a0 + a1) / 2.0;
         }
     }
+    if (MODE == 5) {
+        __shared__ unsigned win5[4][64];
+        unsigned *w = win5[threadIdx.x >> 6];
+        const float sd = (float)sqrt(var);
+        const int k = L / 2 - 1;
+        float lo = (float)mean - 0.06f * sd, hi = (float)mean + 0.06f * sd;
+        int c_lo = 0, c_hi = 0;   // #{v < lo}, #{v <= hi}
+        bool ok = false;
+#pragma unroll 1
+        for (int it = 0; it < 4; ++it) {
+            c_lo = 0; c_hi = 0;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                c_lo += __popcll(__ballot(v[e] < lo));
+                c_hi += __popcll(__ballot(v[e] <= hi));
+            }
+            const int inwin = c_hi - c_lo;
+            if (k >= c_lo && k + 1 < c_hi) {
+                if (inwin <= 64) { ok = true; break; }
+                // too many samples in the window: keep the half that holds the two order statistics (or give up)
+                const float mid = 0.5f * (lo + hi);
+                int c_mid = 0;
+#pragma unroll
+                for (int e = 0; e < 16; ++e) c_mid += __popcll(__ballot(v[e] <= mid));
+                if (k + 1 < c_mid) hi = mid; else if (k >= c_mid) lo = nextafterf(mid, INFINITY); else break;
+            } else if (k < c_lo) {   // both order statistics must lie in one window: slide it, overlapping by its width
+                const float wdt = hi - lo;
+                hi = lo + 0.5f * wdt; lo = hi - 2.0f * wdt;
+            } else {
+                const float wdt = hi - lo;
+                lo = hi - 0.5f * wdt; hi = lo + 2.0f * wdt;
+            }
+        }
+        if (ok) {
+            int base = 0;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const unsigned long long m = __ballot(v[e] >= lo && v[e] <= hi);
+                const bool in = (m >> lane) & 1ull;
+                const int pos = base + __popcll(m & ((1ull << lane) - 1ull));
+                if (in) w[pos] = enc(v[e]);
+                base += __popcll(m);
+            }
+            const int inwin = c_hi - c_lo;
+            __builtin_amdgcn_wave_barrier();
+            unsigned key = (lane < inwin) ? w[lane] : 0xFFFFFFFFu;
+#pragma unroll
+            for (int kk = 2; kk <= 64; kk <<= 1) {
+#pragma unroll
+                for (int j = kk >> 1; j > 0; j >>= 1) {
+                    const unsigned o = (unsigned)__shfl_xor((int)key, j);
+                    const bool up = ((lane & kk) == 0);
+                    const bool lower = ((lane & j) == 0);
+                    const unsigned mnk = key < o ? key : o, mxk = key < o ? o : key;
+                    key = (lower == up) ? mnk : mxk;
+                }
+            }
+            const unsigned k0 = (unsigned)__shfl((int)key, k - c_lo), k1 = (unsigned)__shfl((int)key, k + 1 - c_lo);
+            med = ((double)dec(k0) + (double)dec(k1)) / 2.0;
+        } else {
+            if (lane == 0) atomicAdd(fallbacks, 1);
+            unsigned key[16];
+#pragma unroll
+            for (int e = 0; e < 16; ++e) key[e] = enc(v[e]);
+            const unsigned k0 = bit_select<16>(key, k);
+            int cle = 0;
+            unsigned nxt = 0xFFFFFFFFu;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                cle += __popcll(__ballot(key[e] <= k0));
+                if (key[e] > k0 && key[e] < nxt) nxt = key[e];
+            }
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) { const unsigned t = (unsigned)__shfl_xor((int)nxt, o); nxt = (t < nxt) ? t : nxt; }
+            const double a0 = dec(k0), a1 = (cle >= k + 2) ? a0 : (double)dec(nxt);
+            med = (a0 + a1) / 2.0;
+        }
+    }
     // lane = column epilogue: 10 columns, one 8-byte store each from lanes 0..9 (one 80-byte segment)
     double r = 0.0;
     switch (lane) {
@@ -197,12 +275,17 @@ int main() {
     time("bit-select median", [&] { k_lab<2><<<grid, 256>>>(dx, n, L, dout, ld, dfb); });
     time("stats + bit-select", [&] { k_lab<3><<<grid, 256>>>(dx, n, L, dout, ld, dfb); });
     time("stats + window-select", [&] { k_lab<4><<<grid, 256>>>(dx, n, L, dout, ld, dfb); });
+    time("stats + window-select/retry", [&] { k_lab<5><<<grid, 256>>>(dx, n, L, dout, ld, dfb); });
     // check medians of mode 3 against mode 4 and the host
     std::vector<double> o3((size_t)n * ld), o4((size_t)n * ld);
     k_lab<3><<<grid, 256>>>(dx, n, L, dout, ld, dfb); CK(hipMemcpy(o3.data(), dout, o3.size() * 8, hipMemcpyDeviceToHost));
     k_lab<4><<<grid, 256>>>(dx, n, L, dout, ld, dfb); CK(hipMemcpy(o4.data(), dout, o4.size() * 8, hipMemcpyDeviceToHost));
     int bad = 0;
     for (int i = 0; i < n; ++i) if (o3[(size_t)i * ld + 1] != o4[(size_t)i * ld + 1]) ++bad;
+    k_lab<5><<<grid, 256>>>(dx, n, L, dout, ld, dfb); CK(hipMemcpy(o4.data(), dout, o4.size() * 8, hipMemcpyDeviceToHost));
+    int bad5 = 0;
+    for (int i = 0; i < n; ++i) if (o3[(size_t)i * ld + 1] != o4[(size_t)i * ld + 1]) ++bad5;
+    printf("median mismatches retry-window vs bit-select: %d\n", bad5);
     std::vector<float> t(h.begin(), h.begin() + L); std::sort(t.begin(), t.end());
     printf("median mismatches window vs bit-select: %d; series 0: host %.9g gpu %.9g\n", bad, ((double)t[L / 2 - 1] + t[L / 2]) / 2, o3[1]);
     return 0;

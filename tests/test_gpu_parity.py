@@ -722,3 +722,38 @@ def test_minimal_plan_on_ragged_batches_matches_oracle(gpu, dtype):
         onames, want = oracle_engine(params, values.astype(np.float64), offsets)
         bad = compare(onames, _align(onames, names, got), want, _series(values.astype(np.float64), offsets))
         assert not bad, "%d mismatches at lengths <= %d, first: %s" % (len(bad), hi, bad[:6])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+def test_streaming_kernel_medians_are_exact_on_hostile_series(gpu, dtype, monkeypatch):
+    """k_stream (MinimalFCParameters: statistics + window-selected median from one read of the samples): the median must be
+    THE order statistic -- bit-equal to numpy's -- whatever route found it: window hit, slid window, halved window, or
+    the bit-by-bit fallback (ties, constants, two-valued, heavy tails, offsets, lengths 1 ... 2048, odd and even)."""
+    rng = np.random.default_rng(77)
+    series = []
+    for n in (1, 2, 3, 4, 5, 63, 64, 65, 127, 128, 129, 255, 256, 257, 511, 512, 513, 1000, 1023, 1024, 1025, 2047, 2048):
+        series.append(rng.standard_normal(n))
+        series.append(np.round(rng.standard_normal(n), 1))                       # heavy ties around the median
+        series.append(rng.integers(0, 2, n).astype(float))                        # two-valued
+        series.append(np.full(n, 0.1))                                            # constant
+        series.append(1e6 + rng.standard_normal(n))                               # offset
+        series.append(rng.standard_cauchy(n))                                     # median far from the mean in sigma units
+        series.append(np.concatenate([np.zeros(n // 2), rng.standard_normal(n - n // 2) * 1e-3 + 5.0]))  # bimodal
+        series.append(np.exp(3.0 * rng.standard_normal(n)))                       # log-normal: skewed
+    series = [s.astype(dtype) for s in series]
+    values = np.concatenate(series)
+    offsets = np.concatenate([[0], np.cumsum([len(s) for s in series])]).astype(np.int64)
+    params = settings.MinimalFCParameters()
+    names, got = hip_engine(params, values, offsets)
+    med = got[:, names.index("value__median")]
+    want = np.array([np.median(s.astype(np.float64)) for s in series])
+    assert np.array_equal(med, want), np.flatnonzero(med != want)[:10]
+    onames, owant = oracle_engine(params, values.astype(np.float64), offsets)
+    bad = compare(onames, _align(onames, names, got), owant, _series(values.astype(np.float64), offsets))
+    assert not bad, bad[:8]
+    # the two-kernel route (k_basic_lite + k_order_stats) gives the same medians and statistics within the bar
+    monkeypatch.setenv("TSFA_NO_STREAM", "1")
+    names2, got2 = hip_engine(params, values, offsets)
+    assert np.array_equal(got2[:, names2.index("value__median")], med)
+    assert not compare(names, got, got2, _series(values.astype(np.float64), offsets))

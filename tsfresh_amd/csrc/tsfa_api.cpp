@@ -84,6 +84,7 @@ struct tsfa_plan {
     std::vector<int64_t> h_rel;                 // offsets relative to the staged span
     bool needs_times = false;  // the plan holds linear_trend_timewise columns
     bool sort_only_order_stats = false;  // the SORT family holds only median / quantile columns
+    bool stream_ok = false;              // BASIC + SORT are served by the fused streaming kernel (k_stream)
     // side streams: the family kernels are independent (each writes its own columns), so they may overlap
     int n_streams = 1;
     hipStream_t aux[TSFA_MAX_AUX] = {nullptr};
@@ -228,6 +229,13 @@ int tsfa_plan_create(const tsfa_feature_spec *specs, int32_t n_specs, int32_t de
     plan->sort_only_order_stats = !plan->fam_specs[TSFA_FAM_SORT].empty();
     for (const auto &sp : plan->fam_specs[TSFA_FAM_SORT])
         if (sp.calc != TSFA_C_MEDIAN && sp.calc != TSFA_C_QUANTILE) plan->sort_only_order_stats = false;
+    // streaming plans (MinimalFCParameters): BASIC float closed forms + median only -> one kernel, one read
+    plan->stream_ok = !plan->fam_specs[TSFA_FAM_BASIC].empty() && plan->hints[TSFA_FAM_BASIC].c == 0;
+    for (const auto &sp : plan->fam_specs[TSFA_FAM_BASIC])
+        if (!tsfa_stream_calc_ok(sp.calc) || sp.calc == TSFA_C_MEDIAN) plan->stream_ok = false;
+    for (const auto &sp : plan->fam_specs[TSFA_FAM_SORT])
+        if (sp.calc != TSFA_C_MEDIAN) plan->stream_ok = false;
+    if (getenv("TSFA_NO_STREAM") && atoi(getenv("TSFA_NO_STREAM"))) plan->stream_ok = false;
     bool ok = hipStreamCreateWithFlags(&plan->stream, hipStreamNonBlocking) == hipSuccess;
     for (int f = 0; ok && f < TSFA_N_FAMILIES; ++f) ok = upload(plan->fam_specs[f], &plan->d_specs[f]) == 0;
     if (ok && !cwt_coef.empty()) {
@@ -407,9 +415,16 @@ static int run_batch(tsfa_plan *plan, const void *d_values, int dtype, const dou
     bool perm_valid[TSFA_N_LEN_CLASSES + 1];
     for (int g = 0; g <= TSFA_N_LEN_CLASSES; ++g) perm_valid[g] = false;
     const bool perm_share = plan->perm_buf.p != nullptr && !overlap && !(getenv("TSFA_NO_PERM_SHARE") && atoi(getenv("TSFA_NO_PERM_SHARE")));
+    bool stream_done[TSFA_N_LEN_CLASSES + 1];   // launch groups whose BASIC (+ SORT) columns k_stream has written
+    for (int g = 0; g <= TSFA_N_LEN_CLASSES; ++g) stream_done[g] = false;
     for (int fi = 0; fi < TSFA_N_FAMILIES; ++fi) {
         const int f = order[fi];
         if (plan->fam_specs[f].empty()) continue;
+        if (f == TSFA_FAM_BASIC && plan->stream_ok) {
+            bool all = true;
+            for (int g = 0; g < sh.n_groups; ++g) all = all && stream_done[g];
+            if (all) continue;   // every group went through k_stream at the SORT (or this) family's turn
+        }
         hipStream_t fst = st;
         if (overlap) {
             const int k = dealt++ % plan->n_streams;
@@ -600,6 +615,16 @@ static int run_batch(tsfa_plan *plan, const void *d_values, int dtype, const dou
                 }
             }
             int rc = 0;
+            if (plan->stream_ok && (f == TSFA_FAM_SORT || f == TSFA_FAM_BASIC) && maxn <= 2048 && g <= TSFA_N_LEN_CLASSES) {
+                if (stream_done[g]) continue;   // BASIC's turn after the SORT family's launch served both
+                TsfaLaunch sa = a;
+                sa.specs = plan->d_specs[TSFA_FAM_SORT];
+                sa.nspecs = (int)plan->fam_specs[TSFA_FAM_SORT].size();
+                sa.bspecs = plan->d_specs[TSFA_FAM_BASIC];
+                sa.nbspecs = (int)plan->fam_specs[TSFA_FAM_BASIC].size();
+                rc = tsfa_launch_stream(sa);
+                stream_done[g] = true;
+            } else
             if (f == TSFA_FAM_SORT && plan->sort_only_order_stats && maxn <= 2048 && !use_long &&
                 !(getenv("TSFA_NO_SELECT") && atoi(getenv("TSFA_NO_SELECT")))) {
                 // a plan that only asks the sort family for median / quantile columns (MinimalFCParameters): selection

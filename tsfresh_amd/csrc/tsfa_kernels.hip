@@ -487,6 +487,176 @@ __global__ void __launch_bounds__(256) k_order_stats(const T *__restrict__ value
 }
 
 // ---------------------------------------------------------------------------------------------
+// Streaming plans (MinimalFCParameters): ONE read of the samples.  A plan whose BASIC columns are float closed forms of
+// the per-series statistics (sum / mean / length / std / variance / rms / max / |max| / min / abs_energy / variation
+// coefficient) and whose SORT columns are `median` only runs entirely from registers: one wavefront per series, the
+// samples coalesced into E registers per lane (E * 64 >= n), statistics by in-register sums + wave butterflies, the
+// median by WINDOW SELECTION, the row written by lane = column.  No LDS staging of the series, no barrier.
+//   * Window selection: the two middle order statistics lie near the mean; count the samples below lo and up to hi for
+//     [lo, hi] = mean -+ 0.06 std (counts are popcounts of compare masks: 2 v_cmp per register, the rest on the scalar
+//     ALU).  If both ranks fall inside and the window holds <= 64 samples they are compacted to one per lane (LDS, 256
+//     B per wavefront) and sorted across the lanes; a window that misses is slid towards the ranks, a crowded one is
+//     halved, and after four tries the exact bit-by-bit selection of k_order_stats takes over (ties, heavy tails).
+//     Measured on 100 000 x 1024 float32 (profiles/lab/minimal_fused_lab.hip): load + statistics 0.067 ms (6.1 TB/s),
+//     + bit-by-bit selection 0.25 ms, + window selection 0.14 ms with 46 series falling back.
+//   * The sums are plain tree sums, not numpy's pairwise order (fam_basic.h reproduces that order from an LDS copy, which
+//     is what k_basic_lite spent its time on): none of the columns served here is compared against another quantity,
+//     so the 1e-6 bar holds with margin (differences ~1e-16 relative).
+// Replaces k_basic_lite + k_order_stats (0.23 + 0.25 ms, two reads of the samples).
+// ---------------------------------------------------------------------------------------------
+template <typename T, int E>
+__global__ void __launch_bounds__(256) k_stream(const T *__restrict__ values, const int64_t *__restrict__ starts, const int64_t *__restrict__ ends, int64_t n_series,
+                                                const int *__restrict__ sel, const TsfaSpec *__restrict__ bspecs, int nb,
+                                                const TsfaSpec *__restrict__ sspecs, int ns, int want_median,
+                                                double *__restrict__ out, int64_t ld) {
+    typedef OsKey<T> KC;
+    typedef typename KC::key_t K;
+    __shared__ K win[4][64];
+    const int lane = threadIdx.x & 63;
+    const int64_t wi = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (wi >= n_series) return;  // wave-uniform
+    const int64_t sidx = sel ? (int64_t)sel[wi] : wi;
+    const int64_t off = starts[sidx];
+    const int n = (int)(ends[sidx] - off);
+    const T *__restrict__ g = values + off;
+    T v[E];
+#pragma unroll
+    for (int e = 0; e < E; ++e) {
+        const int i = e * 64 + lane;
+        v[e] = (i < n) ? g[i] : (T)TSFA_INF;   // pads sort behind every sample and are masked out of the sums
+    }
+    const double dn = (double)n;
+    double s = 0.0;
+#pragma unroll
+    for (int e = 0; e < E; ++e) s += (e * 64 + lane < n) ? (double)v[e] : 0.0;
+    s = wave_sum(s);
+    const double mean = s / dn;
+    double ssd = 0.0, sq = 0.0, mn = TSFA_INF, mx = -TSFA_INF;
+#pragma unroll
+    for (int e = 0; e < E; ++e) {
+        const bool in = (e * 64 + lane < n);
+        const double x = (double)v[e], d = x - mean;
+        ssd += in ? d * d : 0.0;
+        sq += in ? x * x : 0.0;
+        mn = in ? fmin(mn, x) : mn;
+        mx = in ? fmax(mx, x) : mx;
+    }
+    ssd = wave_sum(ssd);
+    sq = wave_sum(sq);
+    mn = wave_min(mn);
+    mx = wave_max(mx);
+    const double var = ssd / dn, sd = sqrt(var);
+
+    double med = TSFA_NAN;
+    if (want_median) {
+        // order statistics k and k1 (k1 == k for odd n)
+        const int k = (n - 1) / 2, k1 = n / 2;
+        K *w = win[threadIdx.x >> 6];
+        T lo = (T)(mean - 0.06 * sd), hi = (T)(mean + 0.06 * sd);
+        int c_lo = 0, c_hi = 0;   // #{v < lo}, #{v <= hi}
+        bool ok = false;
+        if (sd > 0.0 && sd < TSFA_INF) {
+#pragma unroll 1
+            for (int it = 0; it < 4; ++it) {
+                c_lo = 0; c_hi = 0;
+#pragma unroll
+                for (int e = 0; e < E; ++e) {
+                    c_lo += __popcll(__ballot(v[e] < lo));
+                    c_hi += __popcll(__ballot(v[e] <= hi));
+                }
+                if (k >= c_lo && k1 < c_hi) {
+                    if (c_hi - c_lo <= 64) { ok = true; break; }
+                    // crowded: keep the half that holds both ranks (a rank pair straddling the cut gives up)
+                    const T mid = (T)(0.5 * ((double)lo + (double)hi));
+                    int c_mid = 0;
+#pragma unroll
+                    for (int e = 0; e < E; ++e) c_mid += __popcll(__ballot(v[e] <= mid));
+                    if (k1 < c_mid) hi = mid;
+                    else if (k >= c_mid) lo = mid;   // (mid itself is then counted on the low side: c_lo is recounted)
+                    else break;
+                    if (k >= c_mid) {  // samples equal to mid belong to the upper half's "below" count only if < lo: use the next value
+                        lo = (sizeof(T) == 4) ? (T)nextafterf((float)mid, INFINITY) : (T)nextafter((double)mid, (double)INFINITY);
+                    }
+                } else {
+                    const double wd = (double)hi - (double)lo;   // slide towards the ranks, overlapping the old window
+                    if (k < c_lo) { hi = (T)((double)lo + 0.5 * wd); lo = (T)((double)hi - 2.0 * wd); }
+                    else { lo = (T)((double)hi - 0.5 * wd); hi = (T)((double)lo + 2.0 * wd); }
+                }
+            }
+        }
+        if (ok) {
+            int base = 0;
+#pragma unroll
+            for (int e = 0; e < E; ++e) {
+                const unsigned long long m = __ballot(v[e] >= lo && v[e] <= hi);
+                const bool in = (m >> lane) & 1ull;
+                const int pos = base + __popcll(m & ((1ull << lane) - 1ull));
+                if (in) w[pos] = KC::enc(v[e]);
+                base += __popcll(m);
+            }
+            __builtin_amdgcn_wave_barrier();
+            K key = (lane < c_hi - c_lo) ? w[lane] : KC::maxkey();
+#pragma unroll
+            for (int kk = 2; kk <= 64; kk <<= 1) {
+#pragma unroll
+                for (int j = kk >> 1; j > 0; j >>= 1) {
+                    const K o = (K)__shfl_xor(key, j);
+                    const bool up = ((lane & kk) == 0), lower = ((lane & j) == 0);
+                    const K a = key < o ? key : o, c = key < o ? o : key;
+                    key = (lower == up) ? a : c;
+                }
+            }
+            const K q0 = (K)__shfl(key, k - c_lo), q1 = (K)__shfl(key, k1 - c_lo);
+            med = (n & 1) ? KC::dec(q0) : (0.0 + KC::dec(q0) + KC::dec(q1)) / 2.0;   // np.median
+        } else {
+            K key[E];
+#pragma unroll
+            for (int e = 0; e < E; ++e) key[e] = (e * 64 + lane < n) ? KC::enc(v[e]) : KC::maxkey();
+            const K q0 = os_select<K, E, KC::BITS>(key, k);
+            double a0 = KC::dec(q0), a1 = a0;
+            if (k1 != k) {
+                int cle = 0;
+                K nxt = KC::maxkey();
+#pragma unroll
+                for (int e = 0; e < E; ++e) {
+                    cle += __popcll(__ballot(key[e] <= q0));
+                    if (key[e] > q0 && key[e] < nxt) nxt = key[e];
+                }
+#pragma unroll
+                for (int o = 32; o > 0; o >>= 1) {
+                    const K t = (K)__shfl_xor(nxt, o);
+                    nxt = (t < nxt) ? t : nxt;
+                }
+                a1 = (cle >= k1 + 1) ? a0 : KC::dec(nxt);
+            }
+            med = (n & 1) ? a0 : (0.0 + a0 + a1) / 2.0;
+        }
+    }
+    // lane = column
+    double *row = out + sidx * ld;
+    for (int c = lane; c < nb + ns; c += 64) {
+        const TsfaSpec sp = (c < nb) ? bspecs[c] : sspecs[c - nb];
+        double r = TSFA_NAN;
+        switch (sp.calc) {
+        case TSFA_C_SUM_VALUES: r = s; break;
+        case TSFA_C_MEAN: r = mean; break;
+        case TSFA_C_LENGTH: r = dn; break;
+        case TSFA_C_STANDARD_DEVIATION: r = sd; break;
+        case TSFA_C_VARIANCE: r = var; break;
+        case TSFA_C_ROOT_MEAN_SQUARE: r = sqrt(sq / dn); break;
+        case TSFA_C_MAXIMUM: r = mx; break;
+        case TSFA_C_ABSOLUTE_MAXIMUM: r = fmax(fabs(mx), fabs(mn)); break;
+        case TSFA_C_MINIMUM: r = mn; break;
+        case TSFA_C_ABS_ENERGY: r = sq; break;
+        case TSFA_C_VARIATION_COEFFICIENT: r = (mean == 0.0) ? TSFA_NAN : sd / mean; break;
+        case TSFA_C_MEDIAN: r = med; break;
+        default: break;
+        }
+        row[sp.col] = r;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
 // cwt_coefficients (fc.py:1370): pywt.cwt(x, widths, "mexh")[i, coeff] only ever reads output positions
 // coeff < ~15, i.e. a dot product of the first S samples with a fixed filter column.  For a batch that is the
 // dense contraction  X[n_series x S] . W[S x C]  -> float64 MFMA (v_mfma_f64_16x16x4_f64), one wavefront per
@@ -800,6 +970,36 @@ static int launch_order_stats_t(const TsfaLaunch &a, const T *values) {
     TSFA_LAUNCH_CHECK();
     return 0;
 }
+// the fused streaming kernel: a.specs / a.nspecs = the SORT family's (median) columns, a.bspecs / a.nbspecs the BASIC ones
+template <typename T>
+static int launch_stream_t(const TsfaLaunch &a, const T *values) {
+    hipStream_t st = (hipStream_t)a.stream;
+    const dim3 grid((unsigned)((a.n_series + 3) / 4));
+    const int wm = a.nspecs > 0 ? 1 : 0;
+#define TSFA_STREAM_CASE(EE) k_stream<T, EE><<<grid, 256, 0, st>>>(values, a.starts, a.ends, a.n_series, a.sel, a.bspecs, a.nbspecs, a.specs, a.nspecs, wm, a.out, a.ld)
+    if (a.maxn <= 256) TSFA_STREAM_CASE(4);
+    else if (a.maxn <= 512) TSFA_STREAM_CASE(8);
+    else if (a.maxn <= 1024) TSFA_STREAM_CASE(16);
+    else if (a.maxn <= 2048) TSFA_STREAM_CASE(32);
+    else return -1;
+#undef TSFA_STREAM_CASE
+    TSFA_LAUNCH_CHECK();
+    return 0;
+}
+int tsfa_launch_stream(const TsfaLaunch &a) {
+    if (a.dtype == 0) return launch_stream_t<float>(a, (const float *)a.values);
+    return launch_stream_t<double>(a, (const double *)a.values);
+}
+int tsfa_stream_calc_ok(int calc) {
+    switch (calc) {
+    case TSFA_C_SUM_VALUES: case TSFA_C_MEAN: case TSFA_C_LENGTH: case TSFA_C_STANDARD_DEVIATION: case TSFA_C_VARIANCE:
+    case TSFA_C_ROOT_MEAN_SQUARE: case TSFA_C_MAXIMUM: case TSFA_C_ABSOLUTE_MAXIMUM: case TSFA_C_MINIMUM:
+    case TSFA_C_ABS_ENERGY: case TSFA_C_VARIATION_COEFFICIENT: case TSFA_C_QUERY_SIMILARITY_COUNT: case TSFA_C_MEDIAN:
+        return 1;
+    default: return 0;
+    }
+}
+
 int tsfa_launch_order_stats(const TsfaLaunch &a) {
     if (a.dtype == 0) return launch_order_stats_t<float>(a, (const float *)a.values);
     return launch_order_stats_t<double>(a, (const double *)a.values);

@@ -33,6 +33,8 @@ struct TsfaLaunch {
     const int *sel;         // device: the series of this launch (indices into starts/ends/out rows), or null = 0..n-1
     const TsfaSpec *specs;  // device
     int nspecs;
+    const TsfaSpec *bspecs; // device: the BASIC family's specs next to the SORT family's in `specs` (tsfa_launch_stream only)
+    int nbspecs;
     double *out;
     int64_t ld;
     int maxn;   // longest series of the batch (LDS is sized for it)
@@ -86,6 +88,8 @@ int tsfa_launch_family(const TsfaLaunch &a);
 int tsfa_launch_family_long(const TsfaLaunch &a);   // working set in a.long_scratch instead of LDS (any length <= 65535)
 int tsfa_launch_ar_degenerate(const TsfaLaunch &a);
 int tsfa_launch_langevin_dd(const TsfaLaunch &a);     // second pass of TSFA_FAM_SORT: the ill-conditioned Langevin fits k_sort recorded
+int tsfa_launch_stream(const TsfaLaunch &a);         // BASIC closed forms + median in one read of the samples (k_stream), maxn <= 2048
+int tsfa_stream_calc_ok(int calc);                   // is the calculator one of those k_stream serves?
 int tsfa_launch_order_stats(const TsfaLaunch &a);    // SORT family holding only median / quantile columns, maxn <= 2048  // second pass of TSFA_FAM_AR over the series the first listed
 int tsfa_launch_cwt(const TsfaCwtLaunch &a);
 int tsfa_launch_fill_nan(double *out, int64_t n_rows, int64_t n_cols, int64_t ld, void *stream);
