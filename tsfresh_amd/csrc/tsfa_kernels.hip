@@ -504,54 +504,43 @@ __global__ void __launch_bounds__(256) k_order_stats(const T *__restrict__ value
 //     so the 1e-6 bar holds with margin (differences ~1e-16 relative).
 // Replaces k_basic_lite + k_order_stats (0.23 + 0.25 ms, two reads of the samples).
 // ---------------------------------------------------------------------------------------------
-template <typename T, int E>
-__global__ void __launch_bounds__(256) k_stream(const T *__restrict__ values, const int64_t *__restrict__ starts, const int64_t *__restrict__ ends, int64_t n_series,
-                                                const int *__restrict__ sel, const TsfaSpec *__restrict__ bspecs, int nb,
-                                                const TsfaSpec *__restrict__ sspecs, int ns, int want_median,
-                                                double *__restrict__ out, int64_t ld) {
+// FULL: the series fills all E * 64 register slots (n == E * 64: no pads to mask out of the sums)
+template <typename T, int E, bool FULL>
+__device__ __forceinline__ void stream_body(const T (&v)[E], int n, int lane, typename OsKey<T>::key_t *w,
+                                            const TsfaSpec *__restrict__ bspecs, int nb, const TsfaSpec *__restrict__ sspecs, int ns,
+                                            int want_median, double *__restrict__ row) {
+#pragma clang fp contract(fast)   // nothing here is compared against another quantity: fused multiply-adds are fine
     typedef OsKey<T> KC;
     typedef typename KC::key_t K;
-    __shared__ K win[4][64];
-    const int lane = threadIdx.x & 63;
-    const int64_t wi = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
-    if (wi >= n_series) return;  // wave-uniform
-    const int64_t sidx = sel ? (int64_t)sel[wi] : wi;
-    const int64_t off = starts[sidx];
-    const int n = (int)(ends[sidx] - off);
-    const T *__restrict__ g = values + off;
-    T v[E];
-#pragma unroll
-    for (int e = 0; e < E; ++e) {
-        const int i = e * 64 + lane;
-        v[e] = (i < n) ? g[i] : (T)TSFA_INF;   // pads sort behind every sample and are masked out of the sums
-    }
     const double dn = (double)n;
     double s = 0.0;
-#pragma unroll
-    for (int e = 0; e < E; ++e) s += (e * 64 + lane < n) ? (double)v[e] : 0.0;
-    s = wave_sum(s);
-    const double mean = s / dn;
-    double ssd = 0.0, sq = 0.0, mn = TSFA_INF, mx = -TSFA_INF;
+    T tmn = (T)TSFA_INF, tmx = (T)-TSFA_INF;
 #pragma unroll
     for (int e = 0; e < E; ++e) {
-        const bool in = (e * 64 + lane < n);
+        const bool in = FULL || (e * 64 + lane < n);
+        s += in ? (double)v[e] : 0.0;
+        tmn = in ? (v[e] < tmn ? v[e] : tmn) : tmn;
+        tmx = in ? (v[e] > tmx ? v[e] : tmx) : tmx;
+    }
+    s = wave_sum(s);
+    const double mean = s / dn;
+    double ssd = 0.0, sq = 0.0;
+#pragma unroll
+    for (int e = 0; e < E; ++e) {
+        const bool in = FULL || (e * 64 + lane < n);
         const double x = (double)v[e], d = x - mean;
         ssd += in ? d * d : 0.0;
         sq += in ? x * x : 0.0;
-        mn = in ? fmin(mn, x) : mn;
-        mx = in ? fmax(mx, x) : mx;
     }
     ssd = wave_sum(ssd);
     sq = wave_sum(sq);
-    mn = wave_min(mn);
-    mx = wave_max(mx);
+    const double mn = wave_min((double)tmn), mx = wave_max((double)tmx);
     const double var = ssd / dn, sd = sqrt(var);
 
     double med = TSFA_NAN;
     if (want_median) {
         // order statistics k and k1 (k1 == k for odd n)
         const int k = (n - 1) / 2, k1 = n / 2;
-        K *w = win[threadIdx.x >> 6];
         T lo = (T)(mean - 0.06 * sd), hi = (T)(mean + 0.06 * sd);
         int c_lo = 0, c_hi = 0;   // #{v < lo}, #{v <= hi}
         bool ok = false;
@@ -572,11 +561,9 @@ __global__ void __launch_bounds__(256) k_stream(const T *__restrict__ values, co
 #pragma unroll
                     for (int e = 0; e < E; ++e) c_mid += __popcll(__ballot(v[e] <= mid));
                     if (k1 < c_mid) hi = mid;
-                    else if (k >= c_mid) lo = mid;   // (mid itself is then counted on the low side: c_lo is recounted)
-                    else break;
-                    if (k >= c_mid) {  // samples equal to mid belong to the upper half's "below" count only if < lo: use the next value
+                    else if (k >= c_mid)   // both ranks above mid: the window restarts at the next value after it
                         lo = (sizeof(T) == 4) ? (T)nextafterf((float)mid, INFINITY) : (T)nextafter((double)mid, (double)INFINITY);
-                    }
+                    else break;
                 } else {
                     const double wd = (double)hi - (double)lo;   // slide towards the ranks, overlapping the old window
                     if (k < c_lo) { hi = (T)((double)lo + 0.5 * wd); lo = (T)((double)hi - 2.0 * wd); }
@@ -611,7 +598,7 @@ __global__ void __launch_bounds__(256) k_stream(const T *__restrict__ values, co
         } else {
             K key[E];
 #pragma unroll
-            for (int e = 0; e < E; ++e) key[e] = (e * 64 + lane < n) ? KC::enc(v[e]) : KC::maxkey();
+            for (int e = 0; e < E; ++e) key[e] = (FULL || e * 64 + lane < n) ? KC::enc(v[e]) : KC::maxkey();
             const K q0 = os_select<K, E, KC::BITS>(key, k);
             double a0 = KC::dec(q0), a1 = a0;
             if (k1 != k) {
@@ -633,7 +620,6 @@ __global__ void __launch_bounds__(256) k_stream(const T *__restrict__ values, co
         }
     }
     // lane = column
-    double *row = out + sidx * ld;
     for (int c = lane; c < nb + ns; c += 64) {
         const TsfaSpec sp = (c < nb) ? bspecs[c] : sspecs[c - nb];
         double r = TSFA_NAN;
@@ -653,6 +639,38 @@ __global__ void __launch_bounds__(256) k_stream(const T *__restrict__ values, co
         default: break;
         }
         row[sp.col] = r;
+    }
+}
+
+template <typename T, int E>
+__global__ void __launch_bounds__(256) k_stream(const T *__restrict__ values, const int64_t *__restrict__ starts, const int64_t *__restrict__ ends, int64_t n_series,
+                                                const int *__restrict__ sel, const TsfaSpec *__restrict__ bspecs, int nb,
+                                                const TsfaSpec *__restrict__ sspecs, int ns, int want_median,
+                                                double *__restrict__ out, int64_t ld) {
+    typedef OsKey<T> KC;
+    typedef typename KC::key_t K;
+    __shared__ K win[4][64];
+    const int lane = threadIdx.x & 63;
+    const int64_t wi = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (wi >= n_series) return;  // wave-uniform
+    const int64_t sidx = sel ? (int64_t)sel[wi] : wi;
+    const int64_t off = starts[sidx];
+    const int n = (int)(ends[sidx] - off);
+    const T *__restrict__ g = values + off;
+    T v[E];
+    K *w = win[threadIdx.x >> 6];
+    double *row = out + sidx * ld;
+    if (n == E * 64) {
+#pragma unroll
+        for (int e = 0; e < E; ++e) v[e] = g[e * 64 + lane];
+        stream_body<T, E, true>(v, n, lane, w, bspecs, nb, sspecs, ns, want_median, row);
+    } else {
+#pragma unroll
+        for (int e = 0; e < E; ++e) {
+            const int i = e * 64 + lane;
+            v[e] = (i < n) ? g[i] : (T)TSFA_INF;   // pads sort behind every sample and are masked out of the sums
+        }
+        stream_body<T, E, false>(v, n, lane, w, bspecs, nb, sspecs, ns, want_median, row);
     }
 }
 
