@@ -165,11 +165,18 @@ extern "C" int tsfa_emul_extract_timed(const tsfa_feature_spec *specs, int n_spe
             for (const auto &sp : fam[TSFA_FAM_ENTROPY])
                 if (sp.calc == TSFA_C_APPROXIMATE_ENTROPY && (int)sp.p[0] != 2) all_m2 = false;
             const char *force = getenv("TSFA_EMUL_ENTROPY");  // "bits" / "pairs": one sweep for every series
-            const bool bits = all_m2 && n <= TSFA_ENTB_MAXN && (force ? !strcmp(force, "bits") : (s % 4 == 2));
-            if (bits) {  // the bit-matrix sweep (k_entropy_bits)
+            const bool bits = all_m2 && n <= TSFA_ENTB_MAXN_LONG && (force ? !strcmp(force, "bits") : (s % 4 == 2 || n > TSFA_ENTB_MAXN));
+            if (bits && n <= TSFA_ENTB_MAXN) {  // the bit-matrix sweep (k_entropy_bits)
                 std::vector<unsigned int> work(entb_work_words(n) + 64);
                 fam_entropy_series_bits<false>(b, xe.data(), n, fam[TSFA_FAM_ENTROPY].data(), (int)fam[TSFA_FAM_ENTROPY].size(),
                                                row, thr.data(), perm.data(), work.data());
+            } else if (bits) {  // ... with 16-byte table entries and tolerance rounds (series of 1025 .. 4096 samples)
+                const int nk = std::min((int)fam[TSFA_FAM_ENTROPY].size(), TSFA_ENTB_MAXK);
+                std::vector<unsigned int> work(entb_work_words(n, TSFA_ENTB_QW_LONG + 1, entb_kround(n, nk, TSFA_ENTB_MAXWAVES)) + 64,
+                                               0xFFFFFFFFu);
+                fam_entropy_series_bits<false, TSFA_ENTB_QW_LONG>(b, xe.data(), n, fam[TSFA_FAM_ENTROPY].data(),
+                                                                 (int)fam[TSFA_FAM_ENTROPY].size(), row, thr.data(), perm.data(),
+                                                                 work.data());
             } else
             fam_entropy_series<double>(b, xe.data(), n, fam[TSFA_FAM_ENTROPY].data(), (int)fam[TSFA_FAM_ENTROPY].size(),
                                        row, thr.data(), perm.data(), refs.data(), (s % 2) ? nullptr : cnt.data(),

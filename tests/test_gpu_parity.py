@@ -757,3 +757,40 @@ def test_streaming_kernel_medians_are_exact_on_hostile_series(gpu, dtype, monkey
     names2, got2 = hip_engine(params, values, offsets)
     assert np.array_equal(got2[:, names2.index("value__median")], med)
     assert not compare(names, got, got2, _series(values.astype(np.float64), offsets))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+def test_entropy_bit_matrix_sweep_on_long_series_equals_the_pair_sweep(gpu, dtype, monkeypatch):
+    """Series of 1025 ... 4096 samples take the bit-matrix sweep with 16-byte table entries and the tolerances in rounds
+    (k_entropy_bits<T, 3>); beyond 4096 the pair sweep remains.  Same integer counts as the pair sweep
+    (TSFA_ENT_PAIRS=1) on lengths around the part / strip / round boundaries, with ties, walks and a constant run, one
+    ragged batch that also holds short series (length classes) -- and the oracle on the shorter ones."""
+    rng = np.random.default_rng(78)
+    lens = [1025, 1026, 1055, 1056, 1057, 1500, 2047, 2048, 2049, 3071, 3072, 3073, 4000, 4095, 4096, 4097, 5000, 700, 64]
+    chunks = []
+    for i, n in enumerate(lens):
+        kind = i % 4
+        if kind == 0: x = rng.standard_normal(n)
+        elif kind == 1: x = np.round(rng.standard_normal(n) * 3)
+        elif kind == 2: x = np.cumsum(rng.standard_normal(n))
+        else: x = np.r_[np.full(n // 3, 0.25), rng.standard_normal(n - n // 3)]
+        chunks.append(x.astype(dtype))
+    values = np.concatenate(chunks)
+    offsets = np.concatenate([[0], np.cumsum([len(c) for c in chunks])]).astype(np.int64)
+    params = {"sample_entropy": None,
+              "approximate_entropy": [{"m": 2, "r": r} for r in (0.1, 0.3, 0.5, 0.7, 0.9, 0.05, 1.7)]}  # 8 specs: two batches
+    names, bits = hip_engine(params, values, offsets)
+    monkeypatch.setenv("TSFA_ENT_PAIRS", "1")
+    names2, pairs = hip_engine(params, values, offsets)
+    monkeypatch.delenv("TSFA_ENT_PAIRS")
+    assert names == names2
+    assert np.array_equal(np.isnan(bits), np.isnan(pairs)) and np.array_equal(np.isinf(bits), np.isinf(pairs))
+    ok = np.isfinite(bits)
+    assert np.allclose(bits[ok], pairs[ok], rtol=1e-12, atol=1e-13), np.abs(bits[ok] - pairs[ok]).max()
+    short = [i for i, n in enumerate(lens) if n <= 2049]
+    sub_vals = np.concatenate([chunks[i] for i in short])
+    sub_offs = np.concatenate([[0], np.cumsum([lens[i] for i in short])]).astype(np.int64)
+    onames, want = oracle_engine(params, sub_vals.astype(np.float64), sub_offs)
+    bad = compare(onames, _align(onames, names, bits[short]), want, _series(sub_vals.astype(np.float64), sub_offs))
+    assert not bad, "%d mismatches, first: %s" % (len(bad), bad[:12])

@@ -74,6 +74,7 @@ TSFA_DEV Blk entb_opaque(const Blk &b0) {
 // index: rng[k * n + a] = (lo * S) | (hi * S) << 16 -- word offsets of the two table entries (lo == hi: empty).
 // lo16: scratch, nk * n unsigned shorts.
 // ---------------------------------------------------------------------------------------------------------------
+template <int S_>
 TSFA_DEV void entb_ranges(const Blk &b0, const double *xs, int n, const double *thr, int nk, const unsigned short *perm,
                           double *xsrt, unsigned int *rng) {
     const Blk b = entb_opaque(b0);
@@ -110,7 +111,7 @@ TSFA_DEV void entb_ranges(const Blk &b0, const double *xs, int n, const double *
             // infinite sample / negative or NaN tolerance: matches nothing (not even itself)
             const bool any = (fabs(xq - xq) <= r[k]) && pl[k] < ph[k];
             const unsigned int lo = any ? (unsigned int)pl[k] : 0u, hi = any ? (unsigned int)ph[k] : 0u;  // 8 * rank
-            if (k < nk) rng[k * n + a] = ((lo >> 3) * (unsigned int)TSFA_ENTB_S) | (((hi >> 3) * (unsigned int)TSFA_ENTB_S) << 16);
+            if (k < nk) rng[k * n + a] = ((lo >> 3) * (unsigned int)S_) | (((hi >> 3) * (unsigned int)S_) << 16);
         }
     }
     blk_sync();
@@ -120,17 +121,18 @@ TSFA_DEV void entb_ranges(const Blk &b0, const double *xs, int n, const double *
 // Table of one column part: entry t (0 .. n), word u (0 .. S-1) = bits of the columns of word (w0 + u) mod NW whose
 // rank is below t.  wtot: TSFA_ENTB_MAXWAVES * S words of cross-wavefront scratch.
 // ---------------------------------------------------------------------------------------------------------------
+template <int S_>
 TSFA_DEV void entb_build_table(const Blk &b0, int n, const unsigned short *perm, int w0, int NW, unsigned int *table,
                                unsigned int *wtot) {
     const Blk b = entb_opaque(b0);
-    const int S = TSFA_ENTB_S;
-    int target[TSFA_ENTB_S];  // wave-uniform: the row word each entry word mirrors
+    const int S = S_;
+    int target[S_];  // wave-uniform: the row word each entry word mirrors
 #pragma unroll
     for (int u = 0; u < S; ++u) target[u] = (w0 + u) % NW;
 #if TSFA_GPU
     const int E = (n + b.nt - 1) / b.nt;
     const int p0 = b.tid * E;
-    unsigned int tot[TSFA_ENTB_S];
+    unsigned int tot[S_];
 #pragma unroll
     for (int u = 0; u < S; ++u) tot[u] = 0u;
     for (int e = 0; e < E; ++e) {
@@ -143,7 +145,7 @@ TSFA_DEV void entb_build_table(const Blk &b0, int n, const unsigned short *perm,
             for (int u = 0; u < S; ++u) tot[u] |= (jw == target[u]) ? bit : 0u;
         }
     }
-    unsigned int run[TSFA_ENTB_S];
+    unsigned int run[S_];
     const int lane = b.tid & 63, wave = b.tid >> 6;
 #pragma unroll
     for (int u = 0; u < S; ++u) {
@@ -174,7 +176,7 @@ TSFA_DEV void entb_build_table(const Blk &b0, int n, const unsigned short *perm,
     }
 #else
     (void)b; (void)wtot;
-    unsigned int run[TSFA_ENTB_S];
+    unsigned int run[S_];
     for (int u = 0; u < S; ++u) run[u] = 0u;
     for (int p = 0; p <= n; ++p) {
         for (int u = 0; u < S; ++u) table[p * S + u] = run[u];
@@ -193,28 +195,28 @@ TSFA_DEV void entb_build_table(const Blk &b0, int n, const unsigned short *perm,
 #if TSFA_GPU
 #define TSFA_ENTB_DPP " wave_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
 // FULL: all QW diagonal words of the part exist (every part of a series with NW % QW == 0)
-template <bool FULL>
+template <int QW_, bool FULL>
 TSFA_DEV unsigned int entb_task_part(unsigned int pl_addr, unsigned int ph_addr, unsigned int sh, int nq) {
-    static_assert(TSFA_ENTB_S % 4 == 0, "entries are read as 16-byte vectors");
+    static_assert((QW_ + 1) % 4 == 0, "entries are read as 16-byte vectors");
     typedef unsigned int entb_u4 __attribute__((ext_vector_type(4)));
     typedef __attribute__((address_space(3))) const entb_u4 *entb_lds_cv4;
     const entb_lds_cv4 pl = (entb_lds_cv4)pl_addr, ph = (entb_lds_cv4)ph_addr;
-    unsigned int A[TSFA_ENTB_S];
+    unsigned int A[QW_ + 1];
 #pragma unroll
-    for (int v = 0; v < TSFA_ENTB_S / 4; ++v) {
+    for (int v = 0; v < (QW_ + 1) / 4; ++v) {
         const entb_u4 l4 = pl[v], h4 = ph[v];
         A[4 * v + 0] = h4.x ^ l4.x; A[4 * v + 1] = h4.y ^ l4.y; A[4 * v + 2] = h4.z ^ l4.z; A[4 * v + 3] = h4.w ^ l4.w;
     }
-    unsigned int e[TSFA_ENTB_QW], m[TSFA_ENTB_QW];
+    unsigned int e[QW_], m[QW_];
 #pragma unroll
-    for (int t = 0; t < TSFA_ENTB_QW; ++t) {
+    for (int t = 0; t < QW_; ++t) {
         e[t] = __builtin_amdgcn_alignbit(A[t + 1], A[t], sh);  // the row rotated left by the lane index
         if (!FULL) e[t] = (t < nq) ? e[t] : 0u;
     }
     // M2 = E & E(lane + 1), M3 = M2 & M2(lane + 1), the neighbour's word as the DPP operand of the AND; the words are
     // interleaved so that no DPP read follows the write of its source by less than the two required wait states
     unsigned int c2 = 0u, c3 = 0u;
-#if TSFA_ENTB_QW == 11
+    if constexpr (QW_ == 11) {
     asm("s_nop 1\n\t"
         "v_and_b32_dpp %2, %13, %13" TSFA_ENTB_DPP
         "v_and_b32_dpp %3, %14, %14" TSFA_ENTB_DPP
@@ -262,7 +264,7 @@ TSFA_DEV unsigned int entb_task_part(unsigned int pl_addr, unsigned int ph_addr,
         "v_bcnt_u32_b32 %1, %12, %1"
         : "+v"(c2), "+v"(c3), "=&v"(m[0]), "=&v"(m[1]), "=&v"(m[2]), "=&v"(m[3]), "=&v"(m[4]), "=&v"(m[5]), "=&v"(m[6]), "=&v"(m[7]), "=&v"(m[8]), "=&v"(m[9]), "=&v"(m[10])
         : "v"(e[0]), "v"(e[1]), "v"(e[2]), "v"(e[3]), "v"(e[4]), "v"(e[5]), "v"(e[6]), "v"(e[7]), "v"(e[8]), "v"(e[9]), "v"(e[10]));
-#elif TSFA_ENTB_QW == 7
+    } else if constexpr (QW_ == 7) {
     asm("s_nop 1\n\t"
         "v_and_b32_dpp %2, %9, %9" TSFA_ENTB_DPP
         "v_and_b32_dpp %3, %10, %10" TSFA_ENTB_DPP
@@ -294,9 +296,24 @@ TSFA_DEV unsigned int entb_task_part(unsigned int pl_addr, unsigned int ph_addr,
         "v_bcnt_u32_b32 %1, %8, %1"
         : "+v"(c2), "+v"(c3), "=&v"(m[0]), "=&v"(m[1]), "=&v"(m[2]), "=&v"(m[3]), "=&v"(m[4]), "=&v"(m[5]), "=&v"(m[6])
         : "v"(e[0]), "v"(e[1]), "v"(e[2]), "v"(e[3]), "v"(e[4]), "v"(e[5]), "v"(e[6]));
-#else
-#error "write the DPP block for this TSFA_ENTB_QW"
-#endif
+    } else {
+    static_assert(QW_ == 11 || QW_ == 7 || QW_ == 3, "write the DPP block for this part width");
+    asm("s_nop 1\n\t"
+        "v_and_b32_dpp %2, %5, %5" TSFA_ENTB_DPP
+        "v_and_b32_dpp %3, %6, %6" TSFA_ENTB_DPP
+        "v_and_b32_dpp %4, %7, %7" TSFA_ENTB_DPP
+        "v_bcnt_u32_b32 %0, %2, %0\n\t"
+        "v_bcnt_u32_b32 %0, %3, %0\n\t"
+        "v_bcnt_u32_b32 %0, %4, %0\n\t"
+        "v_and_b32_dpp %2, %2, %2" TSFA_ENTB_DPP
+        "v_and_b32_dpp %3, %3, %3" TSFA_ENTB_DPP
+        "v_and_b32_dpp %4, %4, %4" TSFA_ENTB_DPP
+        "v_bcnt_u32_b32 %1, %2, %1\n\t"
+        "v_bcnt_u32_b32 %1, %3, %1\n\t"
+        "v_bcnt_u32_b32 %1, %4, %1"
+        : "+v"(c2), "+v"(c3), "=&v"(m[0]), "=&v"(m[1]), "=&v"(m[2])
+        : "v"(e[0]), "v"(e[1]), "v"(e[2]));
+    }
     return c2 | (c3 << 16);
 }
 #endif
@@ -356,10 +373,10 @@ TSFA_DEV void entb_totals(const Blk &b, int kn, int k0, double *pm, double *pm1,
         const int k = b.tid >> 1, odd = b.tid & 1;
         double a = 0.0;
         for (int r = 0; r < nrows; ++r) a += part[b.tid * nrows + r];
-        unsigned int tot = 0u;
-        for (int w = 0; w < nw; ++w) tot += islot[w * 2 * K + b.tid];
+        unsigned int tot_c = 0u, tot_n = 0u;   // a wavefront's packed word holds sum C < 2^21 and #rows < 2^11; the block's may not
+        for (int w = 0; w < nw; ++w) { const unsigned int t = islot[w * 2 * K + b.tid]; tot_c += t & 0x1FFFFFu; tot_n += t >> 21; }
         double *d = racc + 4 * (k0 + k);
-        const double v = a - (double)(tot >> 21) * (odd ? ldm1 : ldm), c = (double)(tot & 0x1FFFFFu);
+        const double v = a - (double)tot_n * (odd ? ldm1 : ldm), c = (double)tot_c;
         if (accumulate) { d[odd] += v; d[2 + odd] += c; }
         else { d[odd] = v; d[2 + odd] = c; }
     }
@@ -382,10 +399,11 @@ TSFA_DEV void entb_totals(const Blk &b, int kn, int k0, double *pm, double *pm1,
 // sum log(C_3 / (n-2)), sum C_2, sum C_3 of tolerance k -- the totals the pair sweeps deliver.
 // perm: all n samples sorted; work: entb_work_words(n) words of LDS.
 // ---------------------------------------------------------------------------------------------------------------
+template <int QW_>
 TSFA_DEV void entropy_bits_batch(const Blk &b_in, const double *xs, int n, const double *thr, int nk,
                                  const unsigned short *perm, unsigned int *work, double *racc) {
     const Blk b = entb_opaque(b_in);
-    const int S = TSFA_ENTB_S, QW = TSFA_ENTB_QW;
+    const int S = QW_ + 1, QW = QW_;
     const int nrow_m = n - 1, nrow_m1 = n - 2;
     const int NW = (n + 32) >> 5;  // row words: at least one zero guard column
     const int nparts = (NW + QW - 1) / QW;
@@ -396,8 +414,6 @@ TSFA_DEV void entropy_bits_batch(const Blk &b_in, const double *xs, int n, const
     unsigned int *cnt = work;
     TSFA_TICKER(tk, 0);
     blk_sync();
-    entb_ranges(b, xs, n, thr, nk, perm, (double *)(void *)work, rng);
-    TSFA_TICK(tk, b, 132);
 #if TSFA_GPU
     const int lane = b.tid & 63, wave = __builtin_amdgcn_readfirstlane(b.tid >> 6), nw = b.nt >> 6;
     const unsigned int tbase = entb_lds_addr(table);
@@ -406,6 +422,7 @@ TSFA_DEV void entropy_bits_batch(const Blk &b_in, const double *xs, int n, const
     if (kround > nk) kround = nk;
     if (kround < 1) kround = 1;  // (the host never selects this sweep for such a shape; the counts below stay correct
                                  //  only for nstrips <= MAXT * nw)
+    const int kcap = kround;     // tolerances per round: the ranges / counters of ONE round live in the work region
     for (int k0 = 0; k0 < nk; k0 += kround) {
         const int kn = (nk - k0 < kround) ? (nk - k0) : kround;
         const int ntask = nstrips * kn;
@@ -413,10 +430,9 @@ TSFA_DEV void entropy_bits_batch(const Blk &b_in, const double *xs, int n, const
         const unsigned int lane_off = tbase, sh = (unsigned int)(lane & 31);
         const int lane_row = (lane >> 5) * TSFA_ENTB_STRIP + (lane & 31);  // template of the lane within its pair of half-strips
         const unsigned int kmagic = 65536u / (unsigned int)kn + 1u;  // id / kn == (id * kmagic) >> 16 for id < 10 000
-        if (k0 > 0) {  // the ranges were overwritten by the table of the previous round
-            blk_sync();
-            entb_ranges(b, xs, n, thr, nk, perm, (double *)(void *)work, rng);
-        }
+        blk_sync();   // the work region held the previous round's counters
+        entb_ranges<QW_ + 1>(b, xs, n, thr + k0, kn, perm, (double *)(void *)work, rng);
+        TSFA_TICK(tk, b, 132);
 #pragma unroll
         for (int tt = 0; tt < TSFA_ENTB_MAXT; ++tt) {
             const int id = wave + tt * nw;
@@ -424,7 +440,7 @@ TSFA_DEV void entropy_bits_batch(const Blk &b_in, const double *xs, int n, const
             rh[tt] = lane_off;
             ct[tt] = 0u;
             if (id < ntask) {
-                const int s = (int)(((unsigned int)id * kmagic) >> 16), k = k0 + (id - s * kn);
+                const int s = (int)(((unsigned int)id * kmagic) >> 16), k = id - s * kn;   // tolerance within the round
                 const int i = s * (2 * TSFA_ENTB_STRIP) + lane_row;
                 const unsigned int r = (i < n) ? rng[k * n + i] : 0u;
                 rl[tt] = lane_off + 4u * (r & 0xFFFFu);
@@ -434,18 +450,18 @@ TSFA_DEV void entropy_bits_batch(const Blk &b_in, const double *xs, int n, const
         blk_sync();
         TSFA_TICK(tk, b, 138);
         for (int part = 0; part < nparts; ++part) {
-            entb_build_table(b, n, perm, part * QW, NW, table, wtot);
+            entb_build_table<QW_ + 1>(b, n, perm, part * QW, NW, table, wtot);
             TSFA_TICK(tk, b, 139);
             const int nq = (NW - part * QW < QW) ? (NW - part * QW) : QW;
             if (nq == QW) {
 #pragma unroll
                 for (int tt = 0; tt < TSFA_ENTB_MAXT; ++tt) {
-                    if (wave + tt * nw < ntask) ct[tt] += entb_task_part<true>(rl[tt], rh[tt], sh, nq);
+                    if (wave + tt * nw < ntask) ct[tt] += entb_task_part<QW_, true>(rl[tt], rh[tt], sh, nq);
                 }
             } else {
 #pragma unroll
                 for (int tt = 0; tt < TSFA_ENTB_MAXT; ++tt) {
-                    if (wave + tt * nw < ntask) ct[tt] += entb_task_part<false>(rl[tt], rh[tt], sh, nq);
+                    if (wave + tt * nw < ntask) ct[tt] += entb_task_part<QW_, false>(rl[tt], rh[tt], sh, nq);
                 }
             }
             TSFA_TICK(tk, b, 136);
@@ -457,7 +473,7 @@ TSFA_DEV void entropy_bits_batch(const Blk &b_in, const double *xs, int n, const
         for (int tt = 0; tt < TSFA_ENTB_MAXT; ++tt) {
             const int id = wave + tt * nw;
             if (id < ntask) {
-                const int s = (int)(((unsigned int)id * kmagic) >> 16), k = k0 + (id - s * kn);
+                const int s = (int)(((unsigned int)id * kmagic) >> 16), k = id - s * kn;
                 const int i = s * (2 * TSFA_ENTB_STRIP) + lane_row;
                 if ((lane & 31) < TSFA_ENTB_STRIP && i < nrow_m) cnt[k * n + i] = ct[tt];
             }
@@ -465,21 +481,25 @@ TSFA_DEV void entropy_bits_batch(const Blk &b_in, const double *xs, int n, const
         blk_sync();
         TSFA_TICK(tk, b, 133);
 #else
-    {
-        const int k0 = 0, kn = nk;
+    // the emulation runs the rounds a 16-wavefront workgroup would (entb_kround): ranges and counters of ONE round at a time
+    const int kround = entb_kround(n, nk, TSFA_ENTB_MAXWAVES), kcap = kround;
+    for (int k0 = 0; k0 < nk; k0 += kround) {
+        const int kn = (nk - k0 < kround) ? (nk - k0) : kround;
+        entb_ranges<QW_ + 1>(b, xs, n, thr + k0, kn, perm, (double *)(void *)work, rng);
         // single-thread emulation of the same strips: 64 "lanes", lanes 62 / 63 only supply their neighbours
-        static thread_local unsigned int rg[TSFA_ENTB_MAXK * (TSFA_ENTB_MAXN + 64)], ct[TSFA_ENTB_MAXK * (TSFA_ENTB_MAXN + 64)];
-        for (int k = 0; k < nk; ++k)
-            for (int i = 0; i < n + 64; ++i) { rg[k * (TSFA_ENTB_MAXN + 64) + i] = (i < n) ? rng[k * n + i] : 0u; ct[k * (TSFA_ENTB_MAXN + 64) + i] = 0u; }
+        const int RS = TSFA_ENTB_MAXN_LONG + 64;
+        static thread_local unsigned int rg[TSFA_ENTB_MAXK * (TSFA_ENTB_MAXN_LONG + 64)], ct[TSFA_ENTB_MAXK * (TSFA_ENTB_MAXN_LONG + 64)];
+        for (int k = 0; k < kn; ++k)
+            for (int i = 0; i < n + 64; ++i) { rg[k * RS + i] = (i < n) ? rng[k * n + i] : 0u; ct[k * RS + i] = 0u; }
         for (int part = 0; part < nparts; ++part) {
-            entb_build_table(b, n, perm, part * QW, NW, table, wtot);
+            entb_build_table<QW_ + 1>(b, n, perm, part * QW, NW, table, wtot);
             const int nq = (NW - part * QW < QW) ? (NW - part * QW) : QW;
-            for (int k = 0; k < nk; ++k) {
+            for (int k = 0; k < kn; ++k) {
                 for (int s = 0; s < nstrips; ++s) {
-                    unsigned int e[66][TSFA_ENTB_QW], m2[66][TSFA_ENTB_QW];
+                    unsigned int e[66][QW_], m2[66][QW_];
                     for (int l = 0; l < 64; ++l) {
                         const int row = s * (2 * TSFA_ENTB_STRIP) + (l >> 5) * TSFA_ENTB_STRIP + (l & 31);
-                        const unsigned int r = rg[k * (TSFA_ENTB_MAXN + 64) + row];
+                        const unsigned int r = rg[k * RS + row];
                         const unsigned int *pl = table + (r & 0xFFFFu), *ph = table + (r >> 16);
                         const unsigned int sh = (unsigned int)(l & 31);
                         for (int t = 0; t < QW; ++t) {
@@ -498,13 +518,13 @@ TSFA_DEV void entropy_bits_batch(const Blk &b_in, const double *xs, int n, const
                             c2 += (unsigned int)__builtin_popcount(m2[l][t]);
                             c3 += (unsigned int)__builtin_popcount(m2[l][t] & m2[l + 1][t]);
                         }
-                        ct[k * (TSFA_ENTB_MAXN + 64) + row] += c2 | (c3 << 16);
+                        ct[k * RS + row] += c2 | (c3 << 16);
                     }
                 }
             }
         }
-        for (int k = 0; k < nk; ++k)
-            for (int i = 0; i < nrow_m; ++i) cnt[k * n + i] = ct[k * (TSFA_ENTB_MAXN + 64) + i];
+        for (int k = 0; k < kn; ++k)
+            for (int i = 0; i < nrow_m; ++i) cnt[k * n + i] = ct[k * RS + i];
 #endif
         // ---- totals of the round's tolerances: sum_i log(C_i / N) = log(prod_i C_i) - (#rows) log N.  The counts are
         //      integers <= 2^11, so a thread multiplies its rows' counts, the 16 lanes of a DPP row multiply theirs
@@ -516,7 +536,7 @@ TSFA_DEV void entropy_bits_batch(const Blk &b_in, const double *xs, int n, const
             const int K = TSFA_ENTB_MAXK;
             double pm[TSFA_ENTB_MAXK], pm1[TSFA_ENTB_MAXK];
             int sc[TSFA_ENTB_MAXK], sc1[TSFA_ENTB_MAXK], nm[TSFA_ENTB_MAXK], nm1[TSFA_ENTB_MAXK];
-            double *part = (double *)(void *)(cnt + (((size_t)TSFA_ENTB_MAXK * n + 1) & ~(size_t)1));  // [2 K][nt / 16]
+            double *part = (double *)(void *)(cnt + (((size_t)kcap * n + 1) & ~(size_t)1));  // [2 K][nt / 16]
             // (a thread multiplies at most four counts before the lanes combine theirs: longer rows go in chunks)
             for (int c0 = 0; c0 < nrow_m; c0 += 4 * b.nt) {
 #pragma unroll
@@ -526,7 +546,7 @@ TSFA_DEV void entropy_bits_batch(const Blk &b_in, const double *xs, int n, const
 #pragma unroll
                     for (int k = 0; k < K; ++k) {
                         if (k < kn && i < nrow_m) {
-                            const unsigned int cc = cnt[(k0 + k) * n + i];
+                            const unsigned int cc = cnt[k * n + i];
                             const int t2 = (int)(cc & 0xFFFFu), t3 = (int)(cc >> 16);
                             sc[k] += t2;
                             if (t2 != nrow_m) { pm[k] *= (double)t2; ++nm[k]; }
@@ -623,7 +643,7 @@ TSFA_DEVN void entb_sort_merge(const Blk b, const double *xs, int n, unsigned sh
 // The ENTROPY specs of one series by the bit-matrix sweep (every spec has m = 2; 3 <= n <= TSFA_ENTB_MAXN is decided
 // on the host, shorter series take the closed forms below).  xs: n + 4 doubles; thr: >= 56 doubles; perm:
 // next_pow2(n) + 32 entries; work: entb_work_words(maxn) words (may alias b.np: the numpy-order sums finish first).
-template <bool F32>
+template <bool F32, int QW_ = TSFA_ENTB_QW>
 TSFA_DEV void fam_entropy_series_bits(const Blk &b, double *xs, int n, const TsfaSpec *specs, int nspecs, double *out_row,
                                       double *thr, unsigned short *perm, unsigned int *work,
                                       unsigned short *perm_out = nullptr) {
@@ -660,7 +680,7 @@ TSFA_DEV void fam_entropy_series_bits(const Blk &b, double *xs, int n, const Tsf
             thr[k] = (sp.calc == TSFA_C_SAMPLE_ENTROPY) ? 0.2 * sd : sp.p[1] * sd;
         }
         blk_sync();
-        if (n >= 3) entropy_bits_batch(b, xs, n, thr, nk, perm, work, racc);
+        if (n >= 3) entropy_bits_batch<QW_>(b, xs, n, thr, nk, perm, work, racc);
         for (int k = 0; k < nk; ++k) {
             const TsfaSpec sp = specs[first + k];
             EntAcc a;

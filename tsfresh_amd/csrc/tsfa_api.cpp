@@ -552,6 +552,15 @@ static int run_batch(tsfa_plan *plan, const void *d_values, int dtype, const dou
                     snprintf(key, sizeof key, "TSFA_NT_%d", f);
                     const char *e = getenv(key);
                     if (e && atoi(e) >= 64) a.nt = atoi(e);
+                } else if (a.ent_fast && a.nspecs >= 2 && maxn > TSFA_ENTB_MAXN && maxn <= TSFA_ENTB_MAXN_LONG &&
+                           !(getenv("TSFA_ENT_PAIRS") && atoi(getenv("TSFA_ENT_PAIRS"))) &&
+                           tsfa_entropy_lds_bytes(maxn, 3) <= TSFA_LDS_LIMIT) {
+                    // 1025 .. 4096 samples: the same sweep with 16-byte table entries (a column part of 96 columns still
+                    // fits LDS) and the tolerances in rounds of as many as 16 wavefronts hold in registers; one
+                    // workgroup per CU.  The pair sweep is O(n^2) float64 operations per tolerance: 101.6 ms per
+                    // 10 000 series of 4096 samples (profiles/r03_shapes.txt) against ... for this one.
+                    a.ent_cnt = 3;
+                    a.nt = 64 * TSFA_ENTB_MAXWAVES;
                 }
             }
             // SEQ: one launch parses up to TSFA_LZ_MAX_GROUP `bins` values side by side -- as many as LDS allows

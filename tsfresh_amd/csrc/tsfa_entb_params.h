@@ -9,21 +9,34 @@
 #define TSFA_ENTB_HD
 #endif
 
-#define TSFA_ENTB_QW 11                   // diagonal words per column part
+#define TSFA_ENTB_QW 11                   // diagonal words per column part, series up to TSFA_ENTB_MAXN samples
 #define TSFA_ENTB_S (TSFA_ENTB_QW + 1)    // words per table entry (one halo word: the rotation by up to 31 bits); 48 B: three ds_read_b128
+#define TSFA_ENTB_QW_LONG 3               // ... and for longer series (TSFA_ENTB_MAXN_LONG): 16-byte entries, so that the table of one
+                                          // column part -- (n + 1) entries -- still fits LDS: 64 KB at 4096 samples
 #define TSFA_ENTB_MAXT 14                 // tasks (strip x tolerance) per wavefront: register-resident ranges + counters
 #define TSFA_ENTB_MAXK 6                  // tolerances per batch
 #define TSFA_ENTB_STRIP 30                // templates per half-strip (32 lanes, two halo lanes); a wavefront sweeps two
 #define TSFA_ENTB_MAXN 1024
+#define TSFA_ENTB_MAXN_LONG 4096          // beyond: the series, its sorted copy and the ranges of one tolerance exceed a CU's LDS
 #define TSFA_ENTB_MAXWAVES 16
 
+// tolerances per round: the (strip, tolerance) tasks of a round live in the wavefronts' registers
+static inline TSFA_ENTB_HD int entb_kround(int maxn, int nk, int nw) {
+    const int nstrips = ((maxn - 1 + TSFA_ENTB_STRIP - 1) / TSFA_ENTB_STRIP + 1) / 2;
+    int kr = (TSFA_ENTB_MAXT * nw) / (nstrips > 0 ? nstrips : 1);
+    if (kr > nk) kr = nk;
+    if (kr > TSFA_ENTB_MAXK) kr = TSFA_ENTB_MAXK;
+    return kr < 1 ? 1 : kr;
+}
+
 // words of the LDS work region (ranges / table / counters take turns in it)
-static inline TSFA_ENTB_HD size_t entb_work_words(int maxn) {
+//   S: words per table entry (QW + 1); kcap: tolerances per round (entb_kround)
+static inline TSFA_ENTB_HD size_t entb_work_words(int maxn, int S = TSFA_ENTB_S, int kcap = TSFA_ENTB_MAXK) {
     size_t p2 = 1;
     while (p2 < (size_t)maxn) p2 <<= 1;
-    const size_t ranges = 2 * p2 + (size_t)TSFA_ENTB_MAXK * maxn;  // sorted copy (float64, padded) + packed ranges
-    const size_t table = (size_t)(maxn + 1) * TSFA_ENTB_S + (size_t)TSFA_ENTB_MAXWAVES * TSFA_ENTB_S;
-    const size_t counts = (size_t)TSFA_ENTB_MAXK * maxn + 2 * (2 * TSFA_ENTB_MAXK * TSFA_ENTB_MAXWAVES * 4) + 2 * TSFA_ENTB_MAXK * TSFA_ENTB_MAXWAVES + 4;  // + partial products, integer slots
+    const size_t ranges = 2 * p2 + (size_t)kcap * maxn;  // sorted copy (float64, padded) + packed ranges of a round
+    const size_t table = (size_t)(maxn + 1) * S + (size_t)TSFA_ENTB_MAXWAVES * S;
+    const size_t counts = (size_t)kcap * maxn + 2 * (2 * TSFA_ENTB_MAXK * TSFA_ENTB_MAXWAVES * 4) + 2 * TSFA_ENTB_MAXK * TSFA_ENTB_MAXWAVES + 4;  // + partial products, integer slots
     size_t w = ranges > table ? ranges : table;
     if (counts > w) w = counts;
     return w + 8;

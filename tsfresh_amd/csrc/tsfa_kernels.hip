@@ -310,7 +310,7 @@ __global__ void __launch_bounds__(1024) k_entropy(const T *__restrict__ values, 
 #if !defined(TSFA_LONG)
 // Bit-matrix sweep (fam_entropy_bits.h): every spec has m = 2 and every series of the launch 3 .. TSFA_ENTB_MAXN samples
 // (shorter ones take the closed forms); workgroup = entb_waves_for(maxn, nspecs) wavefronts.
-template <typename T>
+template <typename T, int QW_>
 __global__ void __launch_bounds__(1024) k_entropy_bits(const T *__restrict__ values, const int64_t *__restrict__ starts, const int64_t *__restrict__ ends, int64_t n_series, const int *__restrict__ sel,
                           const TsfaSpec *__restrict__ specs, int nspecs, double *__restrict__ out, int64_t ld, int maxn,
                           unsigned short *__restrict__ perm_buf, int perm_stride) {
@@ -318,11 +318,11 @@ __global__ void __launch_bounds__(1024) k_entropy_bits(const T *__restrict__ val
     const int64_t off = starts[sidx];
     const int n = (int)(ends[sidx] - off);
     EntropyLds L;
-    L.carve(tsfa_base, maxn, 2);
+    L.carve(tsfa_base, maxn, QW_ == TSFA_ENTB_QW ? 2 : 3);
     TSFA_TICKS_BEGIN();
     Blk b{(int)threadIdx.x, (int)blockDim.x, L.red, L.np};
     stage_series(b, values + off, n, L.xs);
-    fam_entropy_series_bits<sizeof(T) == 4>(b, L.xs, n, specs, nspecs, out + sidx * ld, L.thr, L.perm, L.cnt,
+    fam_entropy_series_bits<sizeof(T) == 4, QW_>(b, L.xs, n, specs, nspecs, out + sidx * ld, L.thr, L.perm, L.cnt,
                                             perm_buf ? perm_buf + (size_t)sidx * (size_t)perm_stride : nullptr);
     TSFA_TICKS_END();
     TSFA_SERIES_END
@@ -875,8 +875,12 @@ static int launch_all_t(const TsfaLaunch &a, const T *values) {
         EntropyLds L;
         const size_t lds = L.carve(nullptr, a.maxn, a.ent_cnt);
 #if !defined(TSFA_LONG)
-        if (a.ent_cnt == 2) {
-            auto kfn = k_entropy_bits<T>;
+        if (a.ent_cnt == 3) {
+            auto kfn = k_entropy_bits<T, TSFA_ENTB_QW_LONG>;
+            TSFA_KLAUNCH(kfn, lds, values, a.starts, a.ends, a.n_series, a.sel, a.specs, a.nspecs, a.out, a.ld, a.maxn,
+                         (unsigned short *)nullptr, 0);
+        } else if (a.ent_cnt == 2) {
+            auto kfn = k_entropy_bits<T, TSFA_ENTB_QW>;
             TSFA_KLAUNCH(kfn, lds, values, a.starts, a.ends, a.n_series, a.sel, a.specs, a.nspecs, a.out, a.ld, a.maxn,
                          a.perm_buf, a.perm_stride);
         } else

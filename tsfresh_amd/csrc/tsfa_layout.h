@@ -156,9 +156,11 @@ struct EntropyLds {
         const int np2 = tsfa_pow2_ceil(maxn);
         const int nperm = ((np2 > 64) ? np2 : 64) + 32;
         perm = c.take<unsigned short>(nperm);
-        if (with_cnt == 2) {  // the numpy-order scratch is dead before the ranges are computed: share its storage
+        if (with_cnt == 2 || with_cnt == 3) {  // the numpy-order scratch is dead before the ranges are computed: share its storage
+            // (3: the long-series variant -- 16-byte table entries, as many tolerances per round as 16 wavefronts hold)
             refs = nullptr;
-            const size_t cb = entb_work_words(maxn) * sizeof(unsigned int);
+            const size_t cb = (with_cnt == 2 ? entb_work_words(maxn)
+                                             : entb_work_words(maxn, TSFA_ENTB_QW_LONG + 1, entb_kround(maxn, TSFA_ENTB_MAXK, TSFA_ENTB_MAXWAVES))) * sizeof(unsigned int);
             unsigned char *u = c.take<unsigned char>(cb > sizeof(NpScratch) ? cb : sizeof(NpScratch));
             np = (NpScratch *)u;
             cnt = (unsigned int *)u;
