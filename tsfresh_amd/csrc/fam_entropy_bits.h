@@ -29,9 +29,6 @@
 // tasks stay in registers across the parts.
 #ifndef TSFA_FAM_ENTROPY_BITS_H
 #define TSFA_FAM_ENTROPY_BITS_H
-#ifndef TSFA_ENTB_OLD_SORT
-#define TSFA_ENTB_OLD_SORT 0   // 1: the packed (value, index) sort + merge by ranking of round 2 (A/B measurements)
-#endif
 
 #include "tsfa_entb_params.h"
 
@@ -643,40 +640,6 @@ TSFA_DEVN void entb_sort_merge(const Blk b, const double *xs, int n, unsigned sh
 }
 #endif
 
-#if TSFA_GPU
-// ---------------------------------------------------------------------------------------------------------------
-// The sample order without sorting (value, index) pairs: the VALUES are sorted by the register-blocked float64 network
-// of the SORT family (v_min_f64 / v_max_f64 compare-exchanges: 2 instructions where a packed 64-bit key + index needs a
-// compare and four selects), then every sample finds its place by one bisection for its lower bound in the sorted
-// values; samples of equal value take consecutive places in the order an LDS counter hands out (which of two equal
-// samples comes first changes no range and no prefix set).  srt: np2 doubles + n words of LDS (the work region).
-// Returns false when the workgroup shape has no register-blocked variant here (np2 must be 2 or 4 x nt).
-// ---------------------------------------------------------------------------------------------------------------
-TSFA_DEV bool entb_order_by_rank(const Blk &b0, const double *xs, int n, int np2, unsigned short *perm, unsigned int *work) {
-    const Blk b = entb_opaque(b0);
-    double *srt = (double *)(void *)work;
-    // (the shapes this kernel is launched with: 2 keys per thread up to 2048 samples at 8 / 16 wavefronts, 4 at 4096)
-    if (np2 == 2 * b.nt) blk_sorted_copy_regs_e<2>(b, xs, n, srt);
-    else if (np2 == 4 * b.nt) blk_sorted_copy_regs_e<4>(b, xs, n, srt);
-    else return false;
-    unsigned int *taken = work + 2 * (size_t)np2;   // taken[p]: samples already placed from lower bound p
-    for (int p = b.tid; p < n; p += b.nt) taken[p] = 0u;
-    for (int p = n + b.tid; p < np2; p += b.nt) perm[p] = (unsigned short)0xFFFFu;
-    blk_sync();
-    const char *xb = (const char *)srt;
-    for (int a = b.tid; a < n; a += b.nt) {
-        const double x = xs[a];
-        int lb = 0;   // byte offset of #{p : srt[p] < x}
-        for (int step = (np2 >> 1) * 8; step >= 8; step >>= 1) lb += (*(const double *)(xb + lb + step - 8) < x) ? step : 0;
-        lb >>= 3;
-        const unsigned int t = atomicAdd(&taken[lb], 1u);
-        perm[lb + (int)t] = (unsigned short)a;
-    }
-    blk_sync();
-    return true;
-}
-#endif
-
 // The ENTROPY specs of one series by the bit-matrix sweep (every spec has m = 2; 3 <= n <= TSFA_ENTB_MAXN is decided
 // on the host, shorter series take the closed forms below).  xs: n + 4 doubles; thr: >= 56 doubles; perm:
 // next_pow2(n) + 32 entries; work: entb_work_words(maxn) words (may alias b.np: the numpy-order sums finish first).
@@ -695,8 +658,7 @@ TSFA_DEV void fam_entropy_series_bits(const Blk &b, double *xs, int n, const Tsf
         const int np2 = next_pow2(n);
         bool sorted = false;
 #if TSFA_GPU
-        if (b.nt >= 64 && !(TSFA_ENTB_OLD_SORT)) sorted = entb_order_by_rank(b, xs, n, np2, perm, work);
-        if (!sorted && F32 && b.nt >= 64) {  // wavefront-local bitonic sort + merge by ranking (work: 2 * np2 64-bit words)
+        if (F32 && b.nt >= 64) {  // wavefront-local bitonic sort + merge by ranking (work: 2 * np2 64-bit words)
             unsigned long long *buf = (unsigned long long *)(void *)work;
             if (np2 == b.nt) { entb_sort_merge<1>(b, xs, n, perm, buf); sorted = true; }
             else if (np2 == 2 * b.nt) { entb_sort_merge<2>(b, xs, n, perm, buf); sorted = true; }
