@@ -69,6 +69,44 @@ def measured_hbm_traffic(kernel, cfg):
     return doc.get("kernels", {}).get(kernel, {}).get("hbm_bytes_per_launch")
 
 
+def measured_valu_issue(cfg):
+    """Vector-instruction issue of the whole step from the committed PMC pass (profiles/pmc_issue.sh ->
+    profiles/valu_issue.json: SQ_INSTS_VALU, SQ_ACTIVE_INST_VALU, GRBM_GUI_ACTIVE per kernel, separate rocprofv3 --pmc
+    runs of this command).  This -- not HBM bandwidth -- is the roof ComprehensiveFCParameters runs against (DESIGN.md
+    section 3.1): `ms_at_full_issue` = wave-instructions / (1024 SIMDs x 2.4 GHz / 4 cycles per wave64 instruction)."""
+    path = os.path.join(ROOT, "profiles", "valu_issue.json")
+    try:
+        doc = json.load(open(path))
+    except (OSError, ValueError):
+        return None
+    w = doc.get("workload", {})
+    if any(w.get(k) != cfg.get(k) for k in ("n_series_per_gpu", "length", "n_cols")):
+        return None
+    return doc.get("step")
+
+
+def physical_cores():
+    """(physical cores, logical CPUs) of this box."""
+    logical = os.cpu_count() or 1
+    try:
+        seen = set()
+        phys = core = None
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("physical id"):
+                phys = line.split(":")[1].strip()
+            elif line.startswith("core id"):
+                core = line.split(":")[1].strip()
+            elif not line.strip():
+                if phys is not None and core is not None:
+                    seen.add((phys, core))
+                phys = core = None
+        if seen:
+            return len(seen), logical
+    except OSError:
+        pass
+    return logical, logical
+
+
 def cpu_baseline(pool, workers, length, params_name, seed, per_worker=32, repeats=3):
     """The CPU path beside the GPU number, on the host cores of this box (rank 0, N = 1 only).
 
@@ -92,7 +130,9 @@ def cpu_baseline(pool, workers, length, params_name, seed, per_worker=32, repeat
         walls.append(time.perf_counter() - t0)
     n = workers * per_worker
     wall = statistics.median(walls)
+    phys, logical = physical_cores()
     doc = {"value": n / wall, "unit": "series/sec", "cores": workers, "kind": "port",
+           "physical_cores": phys, "logical_cpus": logical,
            "series_per_sec_per_core": n / wall / workers,
            "sample": "%d series x len %d, %s, oracle/ (numpy port of the reference calculators, all 75), %d warm worker "
                      "processes x %d series, median of %d runs (%s s), pool start outside the clock" % (
@@ -280,6 +320,31 @@ def main():
         dist.all_reduce(lo, op=dist.ReduceOp.MIN)
         assert bool((hi == lo).all().item()), "exchange: ranks disagree on the gathered matrix"
 
+    # ---- N > 1: what the exchange costs on top of the extraction (outside the timed region) ----
+    multi = None
+    if dist is not None and world > 1:
+        local = ShardPipeline(fplan.native_specs(_native.calc_id), n_cols, local_rank, dist=None, n_chunks=n_chunks,
+                              length_hint=None if args.ragged else (L, L))
+        local.run(values, offsets, [n], out, _native.TSFA_F32)   # a world of one: this rank's rows into its own block
+        barrier()
+        t1 = time.perf_counter()
+        for _ in range(args.steps):
+            local.run(values, offsets, [n], out, _native.TSFA_F32)
+        barrier()
+        t_local = torch.tensor([time.perf_counter() - t1], device=dev, dtype=torch.float64)
+        dist.all_reduce(t_local, op=dist.ReduceOp.MAX)
+        compute_ms = 1000.0 * float(t_local.item()) / max(args.steps, 1)
+        local.close()
+        try:
+            rccl = ".".join(str(v) for v in torch.cuda.nccl.version())
+        except Exception:  # noqa: BLE001
+            rccl = None
+        gathered = (world - 1) * n * n_cols * 8
+        multi = {"world": world, "backend": "nccl (RCCL %s)" % rccl, "row_chunks": n_chunks,
+                 "compute_only_ms_per_step": compute_ms, "exchange_ms_exposed": ms_per_step - compute_ms,
+                 "bytes_received_per_rank_per_step": gathered,
+                 "exchange_gbs_per_rank_if_fully_exposed": gathered / max((ms_per_step - compute_ms) * 1e-3, 1e-9) / 1e9}
+
     # ---- per-kernel HIP-event timings (events recorded on the launch stream), 2 profiled passes ----
     plan.set_profiling(True)
     kt = {}
@@ -321,7 +386,8 @@ def main():
                     "traffic": measured_hbm_traffic(kname, {"n_series_per_gpu": n, "length": L, "n_cols": n_cols}),
                     "kernel_ms": kt[dom],
                     "algorithmic_bytes_per_launch": alg_bytes,
-                    "note": notes.get(kname, "compute-side bound: see DESIGN.md roofline section")}
+                    "note": notes.get(kname, "compute-side bound: see DESIGN.md roofline section"),
+                    "valu": measured_valu_issue({"n_series_per_gpu": n, "length": L, "n_cols": n_cols})}
         line = {
             "metric": "series/sec (ComprehensiveFCParameters, len=1024)" if args.params == "comprehensive" and L == 1024
                       else "series/sec (%s, %s)" % (args.params, ("ragged len %s" % args.ragged) if args.ragged else "len=%d" % L),
@@ -337,6 +403,8 @@ def main():
                        "row_chunks_per_step": n_chunks},
             "kernel_ms": kt, "outputs_finite": finite, "roofline": roof,
         }
+        if multi is not None:
+            line["multi_gpu"] = multi
         line["nonfinite_columns"] = nonfinite_cols
         params_name = args.params.capitalize() + "FCParameters"
         pool = None
@@ -344,7 +412,7 @@ def main():
             import multiprocessing as mp
             for v in ("OMP_NUM_THREADS", "MKL_NUM_THREADS", "OPENBLAS_NUM_THREADS"):
                 os.environ[v] = "1"  # the reference's own advice (docs/text/tsfresh_on_a_cluster.rst:216-231)
-            workers = min(os.cpu_count() or 1, 64)
+            workers = min(physical_cores()[0], 64)   # one worker per PHYSICAL core: SMT siblings halve the per-core rate
             pool = mp.get_context("spawn").Pool(workers)
             pool.map(_cpu_warm, range(4 * workers))
         if world == 1 and not args.ragged:
@@ -360,6 +428,17 @@ def main():
             line["cpu_baseline"] = cpu_baseline(pool, workers, L, params_name, seed=42)
             pool.close()
             pool.join()
+            # the reference's DEFAULT: n_jobs = cpu_count() // 2 worker processes (tsfresh/defaults.py:7), one run
+            half = max(1, min((os.cpu_count() or 2) // 2, 64))
+            if half != workers:
+                pool2 = mp.get_context("spawn").Pool(half)
+                pool2.map(_cpu_warm, range(4 * half))
+                d2 = cpu_baseline(pool2, half, L, params_name, seed=43, repeats=1)
+                pool2.close()
+                pool2.join()
+                line["cpu_baseline"]["default_n_jobs"] = {"workers": half, "value": d2["value"], "unit": "series/sec",
+                                                          "series_per_sec_per_core": d2["series_per_sec_per_core"],
+                                                          "sample": d2["sample"]}
         print(json.dumps(line))
     if dist is not None:
         dist.barrier()

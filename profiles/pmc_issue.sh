@@ -1,30 +1,65 @@
 #!/bin/bash
 # Issue-side counters of every kernel of the default bench workload (separate --pmc passes, no tracing next to them):
-# how busy the VALU / LDS / scalar pipes are per family.  Writes gpurun_out/pmc_issue/summary.md
+# how busy the VALU / LDS / scalar pipes are per family, and the MFMA pipe for k_cwt_gemm.
+# Writes gpurun_out/pmc_issue/summary.md and gpurun_out/pmc_issue/valu_issue.json (bench.py reads the committed copy
+# profiles/valu_issue.json for its roofline.valu field).
 export TMPDIR=/tmp
 rm -rf gpurun_out/pmc_issue; mkdir -p gpurun_out/pmc_issue
 i=0
-for set in "GRBM_GUI_ACTIVE SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES" "SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_INSTS_SALU SQ_ACTIVE_INST_SCA" "SQ_INSTS_LDS SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT" "SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_SMEM"; do
+for set in "GRBM_GUI_ACTIVE SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES" "SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_INSTS_SALU SQ_ACTIVE_INST_SCA" "SQ_INSTS_LDS SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT" "SQ_VALU_MFMA_BUSY_CYCLES" "SQ_INSTS_VALU_MFMA_MOPS_F64"; do
   i=$((i+1))
   timeout 600 rocprofv3 --pmc $set -d gpurun_out/pmc_issue/p$i -o p --output-format csv -- python bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-e2e > gpurun_out/pmc_issue/p$i.log 2>&1
 done
-python - <<'PY' > gpurun_out/pmc_issue/summary.md
-import csv, glob, collections
+python - <<'PY'
+import csv, glob, collections, json
+# one dict per kernel NAME and counter; every pass is aggregated by the kernel name of ITS OWN rows (round 2's table
+# printed k_sort's GRBM_GUI_ACTIVE in the k_trend row: the template arguments were cut at the first '<' of 'void k<..>')
+def kname(raw):
+    raw = raw.strip()
+    if raw.startswith("void "):
+        raw = raw[5:]
+    return raw.split("<")[0].split("(")[0]
 agg = collections.defaultdict(lambda: collections.defaultdict(list))
 for f in sorted(glob.glob("gpurun_out/pmc_issue/*/*counter_collection.csv")):
     for r in csv.DictReader(open(f)):
-        k = r["Kernel_Name"].split("(")[0].replace("void ", "").split("<")[0]
-        if k.startswith("k_"):
+        k = kname(r["Kernel_Name"])
+        if k.startswith("k_") or k.startswith("kl_"):
             agg[k][r["Counter_Name"]].append(float(r["Counter_Value"]))
 cols = ["GRBM_GUI_ACTIVE", "SQ_WAVES", "SQ_WAVE_CYCLES", "SQ_BUSY_CYCLES", "SQ_INSTS_VALU", "SQ_ACTIVE_INST_VALU", "SQ_INSTS_SALU",
-        "SQ_ACTIVE_INST_SCA", "SQ_INSTS_LDS", "SQ_ACTIVE_INST_LDS", "SQ_WAIT_INST_LDS", "SQ_LDS_BANK_CONFLICT", "SQ_WAIT_ANY",
-        "SQ_WAIT_INST_ANY", "SQ_ACTIVE_INST_ANY", "SQ_INSTS_SMEM"]
-print("per-launch means (rocprofv3 --pmc, bench.py default workload); SQ_* cycle counters are summed over all SIMDs/waves in quad-cycles\n")
-print("| kernel | " + " | ".join(cols) + " | VALU busy = ACTIVE_INST_VALU*4 / (GUI_ACTIVE/8 XCDs * 1024 SIMDs) |")
-print("|---|" + "---|" * (len(cols) + 1))
-for k, v in agg.items():
-    m = {c: (sum(v[c]) / len(v[c]) if v.get(c) else float("nan")) for c in cols}
-    busy = m["SQ_ACTIVE_INST_VALU"] * 4.0 / (m["GRBM_GUI_ACTIVE"] / 8.0 * 1024.0)  # GUI_ACTIVE is summed over the 8 XCDs if m["GRBM_GUI_ACTIVE"] == m["GRBM_GUI_ACTIVE"] else float("nan")
-    print("| %s | " % k + " | ".join("%.4g" % m[c] for c in cols) + " | %.3f |" % busy)
+        "SQ_ACTIVE_INST_SCA", "SQ_INSTS_LDS", "SQ_ACTIVE_INST_LDS", "SQ_WAIT_INST_LDS", "SQ_LDS_BANK_CONFLICT",
+        "SQ_VALU_MFMA_BUSY_CYCLES", "SQ_INSTS_VALU_MFMA_MOPS_F64"]
+line = json.loads([l for l in open("gpurun_out/pmc_issue/p1.log") if l.startswith('{"metric"')][-1])
+SIMDS, CLOCK = 1024.0, 2.4e9
+doc = {"workload": line["config"], "units": "per-launch sums over the step's launches of each kernel; SQ_* instruction counters are "
+       "wave-instructions, *ACTIVE* / *BUSY* counters quad-cycles summed over the SIMDs; GRBM_GUI_ACTIVE cycles summed over the 8 XCDs",
+       "kernels": {}, "step": None}
+with open("gpurun_out/pmc_issue/summary.md", "w") as out:
+    out.write("per-step sums per kernel (rocprofv3 --pmc, bench.py default workload, one pass per counter set)\n\n")
+    out.write("| kernel | launches | " + " | ".join(cols) + " | VALU busy | ms at full VALU issue | MFMA busy |\n")
+    out.write("|---|---|" + "---|" * (len(cols) + 3) + "\n")
+    tot_insts = tot_active = tot_gui = 0.0
+    for k, v in sorted(agg.items()):
+        n_launch = max(len(x) for x in v.values())
+        m = {c: (sum(v[c]) if v.get(c) else float("nan")) for c in cols}
+        gui = m["GRBM_GUI_ACTIVE"] / 8.0
+        busy = m["SQ_ACTIVE_INST_VALU"] * 4.0 / (gui * SIMDS) if gui == gui and gui > 0 else float("nan")
+        full_ms = m["SQ_INSTS_VALU"] * 4.0 / (SIMDS * CLOCK) * 1e3
+        # MfmaUtil as rocprofv3's gfx94x formula: MFMA-busy cycles (counted in cycles per SIMD) over all SIMD-cycles of the kernel
+        mfma = m["SQ_VALU_MFMA_BUSY_CYCLES"] / (gui * SIMDS) if gui == gui and gui > 0 else float("nan")
+        out.write("| %s | %d | " % (k, n_launch) + " | ".join("%.4g" % m[c] for c in cols) + " | %.3f | %.3f | %.4f |\n" % (busy, full_ms, mfma))
+        doc["kernels"][k] = {"launches": n_launch, "insts_valu": m["SQ_INSTS_VALU"], "active_inst_valu_quadcycles": m["SQ_ACTIVE_INST_VALU"],
+                             "gui_active_cycles_per_xcd": gui, "valu_busy": busy, "ms_at_full_issue": full_ms,
+                             "mfma_busy_quadcycles": m["SQ_VALU_MFMA_BUSY_CYCLES"], "mfma_mops_f64": m["SQ_INSTS_VALU_MFMA_MOPS_F64"],
+                             "mfma_busy_frac": mfma}
+        if m["SQ_INSTS_VALU"] == m["SQ_INSTS_VALU"]:
+            tot_insts += m["SQ_INSTS_VALU"]; tot_active += m["SQ_ACTIVE_INST_VALU"]; tot_gui += gui
+    doc["step"] = {"insts": tot_insts, "busy": tot_active * 4.0 / (tot_gui * SIMDS) if tot_gui else None,
+                   "ms_at_full_issue": tot_insts * 4.0 / (SIMDS * CLOCK) * 1e3,
+                   "basis": "SQ_INSTS_VALU / SQ_ACTIVE_INST_VALU / GRBM_GUI_ACTIVE summed over the kernels of one step; full issue = one "
+                            "wave64 VALU instruction per 4 cycles on each of 1024 SIMDs at 2.4 GHz"}
+    out.write("\nstep: %.4g VALU wave-instructions, %.3f ms at full issue, time-weighted VALU busy %.3f\n" % (
+        tot_insts, doc["step"]["ms_at_full_issue"], doc["step"]["busy"] or float("nan")))
+json.dump(doc, open("gpurun_out/pmc_issue/valu_issue.json", "w"), indent=1)
+print(open("gpurun_out/pmc_issue/summary.md").read())
 PY
-cat gpurun_out/pmc_issue/summary.md
+rm -rf gpurun_out/pmc_issue/p*/

@@ -321,13 +321,16 @@ def test_config5_ragged_8192_efficient(gpu):
     walk = np.cumsum(rng.standard_normal(int(lens.max()) + n, dtype=np.float32)).astype(np.float32)
     series = [walk[i:i + lens[i]].copy() for i in range(n)]  # rolled windows over one random walk
     series[2] = rng.standard_normal(lens[2], dtype=np.float32)
+    series[4] = np.round(rng.standard_normal(lens[4]) * 2).astype(np.float32)             # tie-heavy: 15 distinct values
+    series[5] = np.full(lens[5], np.float32(0.1))                                          # a stuck sensor, 4096+ samples
+    series[6] = (np.arange(lens[6]) % 7).astype(np.float32)                                # exactly periodic integers
     values = np.concatenate(series)
     offsets = np.zeros(n + 1, dtype=np.int64)
     np.cumsum(lens, out=offsets[1:])
     params = settings.EfficientFCParameters()
     names, got = hip_engine(params, values, offsets)
     assert got.shape == (n, 777)
-    rows = [0, 1, 2, 3]
+    rows = [0, 1, 2, 3, 4, 5, 6]
     onames, want = _sample_parity(params, series, rows)
     bad = compare(onames, _align(onames, names, got[rows]), want, [series[i].astype(np.float64) for i in rows])
     assert not bad, "%d mismatches, first: %s" % (len(bad), bad[:12])

@@ -430,7 +430,9 @@ static int run_batch(tsfa_plan *plan, const void *d_values, int dtype, const dou
             const int k = dealt++ % plan->n_streams;
             if (k > 0) fst = plan->aux[k - 1];
         }
-        if (record(plan, fst, slot, fam_names[f], true)) return fail(TSFA_ERR_HIP, "event record failed");
+        const char *slot_name = (plan->stream_ok && (f == TSFA_FAM_SORT || (f == TSFA_FAM_BASIC && plan->fam_specs[TSFA_FAM_SORT].empty())))
+                                    ? "k_stream" : fam_names[f];
+        if (record(plan, fst, slot, slot_name, true)) return fail(TSFA_ERR_HIP, "event record failed");
         for (int g = sh.n_groups - 1; g >= 0; --g) {  // longest series first
             const int maxn = sh.g_maxn[g];
             const long long max_np2 = sh.g_np2[g];
@@ -654,7 +656,7 @@ static int run_batch(tsfa_plan *plan, const void *d_values, int dtype, const dou
             if (rc) return fail(TSFA_ERR_HIP, std::string(fam_names[f]) + " launch failed: " +
                                                   (rc == -2 ? "no scratch slot" : hipGetErrorString((hipError_t)rc)));
         }
-        if (record(plan, fst, slot, fam_names[f], false)) return fail(TSFA_ERR_HIP, "event record failed");
+        if (record(plan, fst, slot, slot_name, false)) return fail(TSFA_ERR_HIP, "event record failed");
         ++slot;
     }
     if (overlap) {
