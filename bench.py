@@ -429,11 +429,11 @@ def main():
             pool.close()
             pool.join()
             # the reference's DEFAULT: n_jobs = cpu_count() // 2 worker processes (tsfresh/defaults.py:7), one run
-            half = max(1, min((os.cpu_count() or 2) // 2, 64))
+            half = max(1, (os.cpu_count() or 2) // 2)
             if half != workers:
                 pool2 = mp.get_context("spawn").Pool(half)
                 pool2.map(_cpu_warm, range(4 * half))
-                d2 = cpu_baseline(pool2, half, L, params_name, seed=43, repeats=1)
+                d2 = cpu_baseline(pool2, half, L, params_name, seed=43, per_worker=16, repeats=1)
                 pool2.close()
                 pool2.join()
                 line["cpu_baseline"]["default_n_jobs"] = {"workers": half, "value": d2["value"], "unit": "series/sec",

@@ -30,17 +30,17 @@ cols = ["GRBM_GUI_ACTIVE", "SQ_WAVES", "SQ_WAVE_CYCLES", "SQ_BUSY_CYCLES", "SQ_I
         "SQ_VALU_MFMA_BUSY_CYCLES", "SQ_INSTS_VALU_MFMA_MOPS_F64"]
 line = json.loads([l for l in open("gpurun_out/pmc_issue/p1.log") if l.startswith('{"metric"')][-1])
 SIMDS, CLOCK = 1024.0, 2.4e9
-doc = {"workload": line["config"], "units": "per-launch sums over the step's launches of each kernel; SQ_* instruction counters are "
+doc = {"workload": line["config"], "units": "means per launch (= per step) of each kernel; SQ_* instruction counters are "
        "wave-instructions, *ACTIVE* / *BUSY* counters quad-cycles summed over the SIMDs; GRBM_GUI_ACTIVE cycles summed over the 8 XCDs",
        "kernels": {}, "step": None}
 with open("gpurun_out/pmc_issue/summary.md", "w") as out:
-    out.write("per-step sums per kernel (rocprofv3 --pmc, bench.py default workload, one pass per counter set)\n\n")
+    out.write("means per launch of each kernel = per step (rocprofv3 --pmc, bench.py default workload: 4 launches per pass, one pass per counter set)\n\n")
     out.write("| kernel | launches | " + " | ".join(cols) + " | VALU busy | ms at full VALU issue | MFMA busy |\n")
     out.write("|---|---|" + "---|" * (len(cols) + 3) + "\n")
     tot_insts = tot_active = tot_gui = 0.0
     for k, v in sorted(agg.items()):
         n_launch = max(len(x) for x in v.values())
-        m = {c: (sum(v[c]) if v.get(c) else float("nan")) for c in cols}
+        m = {c: (sum(v[c]) / len(v[c]) if v.get(c) else float("nan")) for c in cols}   # mean per launch
         gui = m["GRBM_GUI_ACTIVE"] / 8.0
         busy = m["SQ_ACTIVE_INST_VALU"] * 4.0 / (gui * SIMDS) if gui == gui and gui > 0 else float("nan")
         full_ms = m["SQ_INSTS_VALU"] * 4.0 / (SIMDS * CLOCK) * 1e3

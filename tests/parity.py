@@ -21,7 +21,8 @@ can bound it.
       *_nosimd.npz, gen_golden_main.py --nosimd) ranks ties stably, as the kernels and the oracle do, and is compared
       without exclusion.
   R2  fft_coefficient "angle" of a bin whose magnitude is round-off (|X_k| < 1e-9 * sum|x|).
-  R3  fourier_entropy / spkt_welch_density of a constant series (the detrended PSD is pure round-off).
+  R3  fourier_entropy / spkt_welch_density / fft_aggregated of a constant series: the detrended PSD, and every FFT bin but
+      bin 0, is pure round-off (the spectral moments weight those bins by k^2: 4e-8 for 6 000 samples of 0.1).
   R4  ar_coefficient / augmented_dickey_fuller when the regression design (as statsmodels builds it) has a singular
       value inside (5e-16, 3e-15) * s_max -- or, for the rank count of a wide lag-search design, within 30 % of
       matrix_rank's tolerance p * eps: statsmodels' pinv cuts at 1e-15 * s_max, LAPACK's small singular values carry
@@ -375,9 +376,11 @@ def excluded(col, x, simd_golden=False, facts=None, rvalue=None):
     xv = facts.x
     if f == "permutation_entropy":
         return simd_golden and _has_window_ties(xv, _param(col, "dimension", int))                       # R1
-    if f in ("fourier_entropy", "spkt_welch_density"):
+    if f in ("fourier_entropy", "spkt_welch_density", "fft_aggregated"):
         if len(xv) > 0 and np.ptp(xv) == 0:
             return True                                                                                   # R3
+        if f == "fft_aggregated":
+            return False
         if f == "fourier_entropy":
             bins = _param(col, "bins", int)
             return facts.get(("fe_edge", bins), lambda: _psd_on_bin_edge(xv, bins))                      # R10
