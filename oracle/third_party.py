@@ -79,14 +79,29 @@ def mackinnonp_c(teststat):
     return stats.norm.cdf(np.polyval(coef[::-1], teststat))
 
 
-def _ols(y, X):
+def _ols(y, X, probe=None):
     """statsmodels OLS(y, X).fit(method="pinv") (regression/linear_model.py:300-338, tools/tools.py:398 pinv_extended):
     params = pinv(X) y with singular values <= 1e-15 * s_max zeroed; rank = matrix_rank(diag(s)) (tolerance
     s_max * p * eps); normalized_cov_params = pinv(X) pinv(X)^T; ssr from the residuals.
-    -> (params, ssr, rank, normalized_cov_params)"""
+    -> (params, ssr, rank, normalized_cov_params)
+    probe (tests/parity.py only; .rng, .relative_eps): the rows (observations) and columns (regressors) are permuted
+    before the solve and the result is mapped back -- mathematically the same regression, numerically another run of
+    the same LAPACK routine: the spread over a few probes IS the reference's round-off on this design."""
     X = np.asarray(X, dtype=np.float64)
     if X.shape[1] == 0:
         return np.zeros(0), float(y @ y), 0, np.zeros((0, 0))
+    if probe is not None and getattr(probe, "relative_eps", 0.0):
+        # ... or the design with every entry moved by a few ulp (the reference's answer for an input that differs from
+        # the real one by less than its own representation error)
+        X = X * (1.0 + probe.relative_eps * probe.rng.uniform(-1.0, 1.0, size=X.shape))
+    elif probe is not None:
+        rows, cols = probe.rng.permutation(X.shape[0]), probe.rng.permutation(X.shape[1])
+        b2, ssr, rank, nc2 = _ols(np.asarray(y)[rows], X[rows][:, cols])
+        beta = np.empty_like(b2)
+        beta[cols] = b2
+        ncov = np.empty_like(nc2)
+        ncov[np.ix_(cols, cols)] = nc2
+        return beta, ssr, rank, ncov
     u, s, vt = np.linalg.svd(X, False)
     s_orig = s.copy()
     cutoff = 1e-15 * s.max()
@@ -109,13 +124,12 @@ def _add_const(X, prepend):
     return np.column_stack([ones, X]) if prepend else np.column_stack([X, ones])
 
 
-def adfuller_aic(x, perturb=None):
+def adfuller_aic(x, probe=None):
     """adfuller(x, autolag="AIC") -> (teststat, pvalue, usedlag); raises ValueError like statsmodels
     (stattools.py:160-380, _autolag :63-147).  AIC = -2 llf + 2 rank (linear_model.py:1827 with df_model = rank -
     k_constant), llf of OLS.loglike (:896-903), t value = params[0] / sqrt(ssr / (nobs - rank) * ncov[0, 0]).
-    perturb (tests/parity.py only): a function applied to every design matrix before it is solved -- the probe that
-    measures how far last-bit changes of the design move the result."""
-    perturb = perturb or (lambda X: X)
+    probe (tests/parity.py only): a random generator handed to every `_ols` call (row / column permutations of the same
+    regression: how far the reference's own round-off moves the result)."""
     x = np.asarray(x, dtype=np.float64)
     nobs = x.shape[0]
     ntrend = 1
@@ -137,7 +151,7 @@ def adfuller_aic(x, perturb=None):
     best = None
     with np.errstate(divide="ignore", invalid="ignore"):
         for lag in range(startlag, startlag + maxlag + 1):
-            _, ssr, rank, _ = _ols(y, perturb(full[:, :lag]))
+            _, ssr, rank, _ = _ols(y, full[:, :lag], probe)
             llf = -n1 / 2.0 * np.log(2 * np.pi) - n1 / 2.0 * np.log(ssr / n1) - n1 / 2.0
             aic = -2 * llf + 2 * rank
             if best is None or (aic, lag) < best:
@@ -146,13 +160,13 @@ def adfuller_aic(x, perturb=None):
         Z, y = design(usedlag)
         n2 = len(y)
         X = _add_const(Z[:, : usedlag + 1], prepend=False)
-        beta, ssr, rank, ncov = _ols(y, perturb(X))
+        beta, ssr, rank, ncov = _ols(y, X, probe)
         sigma2 = ssr / (n2 - rank)
         tstat = beta[0] / np.sqrt(sigma2 * ncov[0, 0])
     return tstat, mackinnonp_c(tstat), usedlag
 
 
-def autoreg_params(x, k, perturb=None):
+def autoreg_params(x, k, probe=None):
     """AutoReg(x, lags=k, trend="c").fit().params = conditional OLS; raises ValueError/ZeroDivisionError when
     statsmodels (0.12.2) cannot estimate the model (n < 2k + 2)."""
     x = np.asarray(x, dtype=np.float64)
@@ -166,7 +180,7 @@ def autoreg_params(x, k, perturb=None):
         raise ZeroDivisionError("division by zero")
     rows = np.arange(k, n)
     X = np.column_stack([np.ones(nobs)] + [x[rows - j] for j in range(1, k + 1)])
-    return _ols(x[rows], X if perturb is None else perturb(X))[0]
+    return _ols(x[rows], X, probe)[0]
 
 
 # ------------------------------------------------------------------------------------------------
