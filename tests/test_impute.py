@@ -88,3 +88,31 @@ def test_device_impute_matches_the_reference_and_the_numpy_path(gpu):
         ours.impute_dataframe_range(df_cpu, mx, mn, med)
     assert np.isfinite(df_dev.to_numpy()).all()
     assert np.array_equal(df_dev.to_numpy(), df_cpu.to_numpy())
+
+
+@pytest.mark.gpu
+def test_device_impute_on_a_row_strided_view_touches_only_its_own_cells(gpu):
+    """a row-strided host view (ld > n_cols) that ENDS with its last row -- tsfa_impute used to copy
+    n_rows * ld doubles in both directions: out of bounds behind the last row, and stale data over the cells between
+    the rows.  Now the rows are staged dense (hipMemcpy2D)."""
+    from tsfresh_amd import _native
+    rng = np.random.default_rng(9)
+    n_rows, n_cols, ld = 300, 7, 12
+    buf = np.full((n_rows - 1) * ld + n_cols, 777.0)
+    view = np.lib.stride_tricks.as_strided(buf, shape=(n_rows, n_cols), strides=(8 * ld, 8))
+    data = rng.standard_normal((n_rows, n_cols))
+    data[rng.random(data.shape) < 0.05] = np.nan
+    data[rng.random(data.shape) < 0.03] = np.inf
+    data[rng.random(data.shape) < 0.03] = -np.inf
+    view[:] = data
+    want = pd.DataFrame(data.copy())
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        mx, mn, med = ours.get_range_values_per_column(want)
+        ours.impute_dataframe_range(want, mx, mn, med)
+    _native.impute_matrix(view, device=0)
+    assert np.array_equal(view, want.to_numpy())
+    between = np.ones(len(buf), dtype=bool)
+    for r in range(n_rows):
+        between[r * ld:r * ld + n_cols] = False
+    assert np.all(buf[between] == 777.0)

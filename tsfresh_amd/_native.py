@@ -138,7 +138,7 @@ def calc_id(name):
 # caller's DataFrame dies.
 _PIN_POOL = {}
 _PIN_POOL_BYTES = [0]
-_PIN_LOCK = __import__("threading").Lock()
+_PIN_LOCK = __import__("threading").RLock()   # re-entrant: a cyclic GC pass under the lock may finalize another _PinnedBlock
 
 
 def _pin_pool_cap():

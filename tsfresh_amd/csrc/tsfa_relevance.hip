@@ -443,10 +443,16 @@ static int relevance_classes_impl(const double *X, int64_t n_rows, int64_t n_col
     int64_t *dhc = nullptr;
     tsfa_relevance_col *dcols = nullptr;
     const double *Xd = X;
+    int64_t ldd = ld;   // leading dimension of the matrix the kernels work on (a host matrix is staged dense)
     REL_HIP(hipSetDevice(device));
+    // a host matrix may be a row-strided VIEW (ld > n_cols) that ends with its last row: only the n_cols-wide rows are
+    // the caller's -- the device copy is dense (leading dimension n_cols) and the columns between the rows are never
+    // read nor written back
     if (space == TSFA_HOST) {
-        REL_HIP(hipMalloc((void **)&dX, (size_t)n_rows * ld * sizeof(double)));
-        REL_HIP(hipMemcpy(dX, X, (size_t)n_rows * ld * sizeof(double), hipMemcpyHostToDevice));
+        ldd = n_cols;
+        REL_HIP(hipMalloc((void **)&dX, (size_t)n_rows * n_cols * sizeof(double)));
+        REL_HIP(hipMemcpy2D(dX, (size_t)n_cols * sizeof(double), X, (size_t)ld * sizeof(double), (size_t)n_cols * sizeof(double),
+                            (size_t)n_rows, hipMemcpyHostToDevice));
         Xd = dX;
     }
     REL_HIP(hipMalloc((void **)&dkeys, (size_t)batch * np2 * sizeof(double)));
@@ -462,7 +468,7 @@ static int relevance_classes_impl(const double *X, int64_t n_rows, int64_t n_col
         REL_HIP(hipFuncSetAttribute((const void *)k_rel_sort, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         for (int64_t c0 = 0; c0 < n_cols; c0 += batch) {
             const int64_t nb = (n_cols - c0 < batch) ? (n_cols - c0) : batch;
-            k_rel_stage<<<dim3((unsigned)nb), REL_NT, 0, 0>>>(Xd, n_rows, ld, c0, dkeys, didx, np2);
+            k_rel_stage<<<dim3((unsigned)nb), REL_NT, 0, 0>>>(Xd, n_rows, ldd, c0, dkeys, didx, np2);
             k_rel_sort<<<dim3((unsigned)nb), REL_NT, lds, 0>>>(dkeys, didx, np2, tile);
             k_rel_stats<<<dim3((unsigned)nb), REL_NT, 0, 0>>>(dkeys, didx, np2, n_rows, dy, n_classes, c0, dcols, drs, dhc);
             if (ks_d) k_rel_ks_classes<<<dim3((unsigned)nb), REL_NT, 0, 0>>>(dkeys, didx, np2, n_rows, dy, n_classes, c0, dks);
@@ -500,10 +506,16 @@ extern "C" int tsfa_relevance_real(const double *X, int64_t n_rows, int64_t n_co
     unsigned char *dye = nullptr;
     tsfa_relevance_real_col *dcols = nullptr;
     const double *Xd = X;
+    int64_t ldd = ld;   // leading dimension of the matrix the kernels work on (a host matrix is staged dense)
     REL_HIP(hipSetDevice(device));
+    // a host matrix may be a row-strided VIEW (ld > n_cols) that ends with its last row: only the n_cols-wide rows are
+    // the caller's -- the device copy is dense (leading dimension n_cols) and the columns between the rows are never
+    // read nor written back
     if (space == TSFA_HOST) {
-        REL_HIP(hipMalloc((void **)&dX, (size_t)n_rows * ld * sizeof(double)));
-        REL_HIP(hipMemcpy(dX, X, (size_t)n_rows * ld * sizeof(double), hipMemcpyHostToDevice));
+        ldd = n_cols;
+        REL_HIP(hipMalloc((void **)&dX, (size_t)n_rows * n_cols * sizeof(double)));
+        REL_HIP(hipMemcpy2D(dX, (size_t)n_cols * sizeof(double), X, (size_t)ld * sizeof(double), (size_t)n_cols * sizeof(double),
+                            (size_t)n_rows, hipMemcpyHostToDevice));
         Xd = dX;
     }
     REL_HIP(hipMalloc((void **)&dkeys, (size_t)batch * np2 * sizeof(double)));
@@ -522,7 +534,7 @@ extern "C" int tsfa_relevance_real(const double *X, int64_t n_rows, int64_t n_co
         REL_HIP(hipFuncSetAttribute((const void *)k_rel_inversions, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_inv));
         for (int64_t c0 = 0; c0 < n_cols; c0 += batch) {
             const int64_t nb = (n_cols - c0 < batch) ? (n_cols - c0) : batch;
-            k_rel_stage_real<<<dim3((unsigned)nb), REL_NT, 0, 0>>>(Xd, n_rows, ld, c0, dyr, dkeys, didx, np2);
+            k_rel_stage_real<<<dim3((unsigned)nb), REL_NT, 0, 0>>>(Xd, n_rows, ldd, c0, dyr, dkeys, didx, np2);
             k_rel_sort<<<dim3((unsigned)nb), REL_NT, lds_sort, 0>>>(dkeys, didx, np2, tile);
             k_rel_xties<<<dim3((unsigned)nb), REL_NT, 0, 0>>>(dkeys, didx, np2, n_rows, c0, dcols);
             // the sorted values are dead now: their storage is the second buffer of the merge sort (np2 words per column
@@ -530,7 +542,7 @@ extern "C" int tsfa_relevance_real(const double *X, int64_t n_rows, int64_t n_co
             k_rel_inversions<<<dim3((unsigned)nb), REL_NT, lds_inv, 0>>>(didx, (uint32_t *)dkeys, np2, tile, c0, dcols);
             REL_HIP(hipGetLastError());
         }
-        k_rel_ks<<<dim3((unsigned)n_cols), REL_NT, 0, 0>>>(Xd, n_rows, ld, dyp, dye, dcols);
+        k_rel_ks<<<dim3((unsigned)n_cols), REL_NT, 0, 0>>>(Xd, n_rows, ldd, dyp, dye, dcols);
         REL_HIP(hipGetLastError());
     }
     REL_HIP(hipMemcpy(cols, dcols, (size_t)n_cols * sizeof(tsfa_relevance_real_col), hipMemcpyDeviceToHost));
@@ -621,10 +633,16 @@ extern "C" int tsfa_impute(double *X, int64_t n_rows, int64_t n_cols, int64_t ld
     uint32_t *didx = nullptr;
     int *dcnt = nullptr;
     double *Xd = X;
+    int64_t ldd = ld;   // leading dimension of the matrix the kernels work on
     REL_HIP(hipSetDevice(device));
+    // a host matrix may be a row-strided VIEW (ld > n_cols) that ends with its last row: only the n_cols-wide rows are
+    // the caller's -- the device copy is dense (leading dimension n_cols) and the columns between the rows are never
+    // read nor written back
     if (space == TSFA_HOST) {
-        REL_HIP(hipMalloc((void **)&dX, (size_t)n_rows * ld * sizeof(double)));
-        REL_HIP(hipMemcpy(dX, X, (size_t)n_rows * ld * sizeof(double), hipMemcpyHostToDevice));
+        ldd = n_cols;
+        REL_HIP(hipMalloc((void **)&dX, (size_t)n_rows * n_cols * sizeof(double)));
+        REL_HIP(hipMemcpy2D(dX, (size_t)n_cols * sizeof(double), X, (size_t)ld * sizeof(double), (size_t)n_cols * sizeof(double),
+                            (size_t)n_rows, hipMemcpyHostToDevice));
         Xd = dX;
     }
     REL_HIP(hipMalloc((void **)&dkeys, (size_t)batch * np2 * sizeof(double)));
@@ -636,19 +654,21 @@ extern "C" int tsfa_impute(double *X, int64_t n_rows, int64_t n_cols, int64_t ld
         REL_HIP(hipFuncSetAttribute((const void *)k_rel_sort, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         for (int64_t c0 = 0; c0 < n_cols; c0 += batch) {
             const int64_t nb = (n_cols - c0 < batch) ? (n_cols - c0) : batch;
-            k_imp_stage<<<dim3((unsigned)nb), REL_NT, 0, 0>>>(Xd, n_rows, ld, c0, dkeys, didx, np2, dcnt);
+            k_imp_stage<<<dim3((unsigned)nb), REL_NT, 0, 0>>>(Xd, n_rows, ldd, c0, dkeys, didx, np2, dcnt);
             k_rel_sort<<<dim3((unsigned)nb), REL_NT, lds, 0>>>(dkeys, didx, np2, tile);
             k_imp_stats<<<dim3((unsigned)((nb + 63) / 64)), 64, 0, 0>>>(dkeys, np2, dcnt, c0, nb, dstat, dstat + n_cols, dstat + 2 * n_cols);
             REL_HIP(hipGetLastError());
         }
-        k_imp_apply<<<2048, 256, 0, 0>>>(Xd, n_rows, ld, n_cols, dstat, dstat + n_cols, dstat + 2 * n_cols);
+        k_imp_apply<<<2048, 256, 0, 0>>>(Xd, n_rows, ldd, n_cols, dstat, dstat + n_cols, dstat + 2 * n_cols);
         REL_HIP(hipGetLastError());
     }
     if (col_max) REL_HIP(hipMemcpy(col_max, dstat, (size_t)n_cols * sizeof(double), hipMemcpyDeviceToHost));
     if (col_min) REL_HIP(hipMemcpy(col_min, dstat + n_cols, (size_t)n_cols * sizeof(double), hipMemcpyDeviceToHost));
     if (col_median) REL_HIP(hipMemcpy(col_median, dstat + 2 * n_cols, (size_t)n_cols * sizeof(double), hipMemcpyDeviceToHost));
     if (finite_count) REL_HIP(hipMemcpy(finite_count, dcnt, (size_t)n_cols * sizeof(int), hipMemcpyDeviceToHost));
-    if (space == TSFA_HOST) REL_HIP(hipMemcpy(X, dX, (size_t)n_rows * ld * sizeof(double), hipMemcpyDeviceToHost));
+    if (space == TSFA_HOST)
+        REL_HIP(hipMemcpy2D(X, (size_t)ld * sizeof(double), dX, (size_t)n_cols * sizeof(double), (size_t)n_cols * sizeof(double),
+                            (size_t)n_rows, hipMemcpyDeviceToHost));
     REL_HIP(hipDeviceSynchronize());
 done:
     (void)hipFree(dX); (void)hipFree(dkeys); (void)hipFree(didx); (void)hipFree(dcnt); (void)hipFree(dstat);
