@@ -92,9 +92,13 @@ def main():
         assert names == names_o, (names[:3], names_o[:3])
         bad = compare(names, got, want, [values[offsets[i]:offsets[i + 1]].astype(np.float64) for i in range(len(series))])
         total_bad += len(bad)
+        dump = os.environ.get("TSFA_FUZZ_DUMP")   # directory: the offending series as .npy, for adjudication
         for bmsg in bad[:3]:
             si = int(bmsg.split()[1])
             print("   offending series", si, repr(values[offsets[si]:offsets[si + 1]].astype(np.float64).tolist()[:60]))
+            if dump:
+                os.makedirs(dump, exist_ok=True)
+                np.save(os.path.join(dump, "round%d_series%d.npy" % (r, si)), values[offsets[si]:offsets[si + 1]])
         print("round", r, "calcs", len(pick), "cols", len(names), "series", len(lens), "maxlen", maxlen, dtype.__name__,
               "mismatches", len(bad), bad[:4])
     print("TOTAL mismatches", total_bad)

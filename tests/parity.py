@@ -59,9 +59,10 @@ can bound it.
       s_max / the smallest kept singular value (measured against 60-digit arithmetic: the reference deviates by up to
       1.2 eps kappa (...), the kernels' double-double pass by < 1e-2 of that; tests/test_offset.py).  The largest real root
       moves with the well-conditioned VALUES of the cubic, not with its monomial coefficients.
-  R8  number_cwt_peaks when a CWT row has two neighbouring values on top of a hump that are equal up to round-off
-      (1e-12 of the row's magnitude; symmetric integer-valued or periodic data): which one is the STRICT relative
-      maximum that starts a ridge line depends on the summation order of scipy's convolution.
+  R8  number_cwt_peaks when a CWT row has two neighbouring values that are equal up to round-off (1e-12 of the row's
+      magnitude; symmetric integer-valued, periodic or piecewise-constant data) next to a lower neighbour: which of them
+      -- or neither -- is the STRICT relative maximum that starts a ridge line depends on the summation order of
+      scipy's convolution ([a, a+1, a+1, a+1, a+1] at a = -1.1e7: 1 ulp apart in scipy, a ridge line more or less).
 """
 import numpy as np
 
@@ -165,9 +166,10 @@ def _probe(seed):
 
 
 def _cond_raw(X):
+    """s_max / s_min over ALL singular values (inf for a rank-deficient design): a direction pinv truncates is exactly
+    where the reference's answer hangs on round-off, so it must not make the design look harmless."""
     s = np.linalg.svd(X, compute_uv=False)
-    kept = s[s > 1e-15 * s[0]] if s[0] > 0 else s
-    return float(s[0] / kept[-1]) if len(kept) else np.inf
+    return float(s[0] / s[-1]) if s[0] > 0 and s[-1] > 0 else np.inf
 
 
 def _ar_probe(x, k):
@@ -236,8 +238,14 @@ def _adf_state(x):
     if yy > 0:
         # columns scaled to unit norm: on a raw design with a 1e9 level column the residual of a PERFECT fit is
         # round-off of size eps * 1e9 * |beta|, not zero (epoch seconds: the diffs are exactly 1)
-        nrm = np.sqrt((full * full).sum(axis=0))
-        fs = full / np.where(nrm > 0, nrm, 1.0)
+        fs = np.array(full, dtype=np.float64)
+        const = [j for j in range(fs.shape[1]) if np.ptp(fs[:, j]) == 0 and fs[0, j] != 0]
+        if const:   # a constant column is in the span: the other columns may be centred without changing the fit
+            for j in range(fs.shape[1]):
+                if j not in const:
+                    fs[:, j] -= fs[:, j].mean()
+        nrm = np.sqrt((fs * fs).sum(axis=0))
+        fs = fs / np.where(nrm > 0, nrm, 1.0)
         beta = np.linalg.lstsq(fs, y, rcond=None)[0]
         r = y - fs @ beta
         perfect = float(r @ r) <= 1e-18 * yy
@@ -305,9 +313,9 @@ def _cwt_peaks_ambiguous(x, n):
     for c in rows:
         tol = 1e-12 * np.max(np.abs(c))
         near = np.abs(c[1:] - c[:-1]) <= tol                       # c[i] ~ c[i+1]
-        left = np.concatenate([[True], c[1:-1] >= c[:-2] - tol])   # c[i] >= c[i-1]
-        right = np.concatenate([c[1:-1] >= c[2:] - tol, [True]])   # c[i+1] >= c[i+2]
-        if np.any(near & left & right):
+        left = np.concatenate([[True], c[1:-1] >= c[:-2] - tol])   # c[i] >= c[i-1]: c[i] is a strict maximum iff it beats c[i+1]
+        right = np.concatenate([c[1:-1] >= c[2:] - tol, [True]])   # c[i+1] >= c[i+2]: c[i+1] is one iff it beats c[i]
+        if np.any(near & (left | right)):                          # (a tie on a slope decides a maximum just as one on a hump)
             return True
     return False
 
@@ -441,9 +449,9 @@ COND_FACTOR = 2.0
 def tolerance_for(col, x, want, facts):
     """-> (rtol, atol) of one cell: 1e-6 and a tiny dimension-aware floor, except where the reference's own float64
     arithmetic is measurably worse than that (R11): a least-squares solution computed by a backward-stable float64
-    solver deviates from the exact one by  eps * kappa * (|c| + kappa * |resid| * |v_min|)  (Wedin; measured against
-    60-digit arithmetic on 600 random offset series: at most 1.2 x that, tests/polyfit_mp.py) -- v_min the right singular
-    vector of the smallest kept singular value.  The values of the fitted cubic move by eps * (kappa |resid| + |c_scaled|)
+    solver deviates from the exact one by  eps * kappa * (|c| + (|c_scaled| + kappa * |resid|) * |v_min|)  (Wedin; measured
+    against 60-digit arithmetic on 600 random offset series: at most 1.2 x that, tests/polyfit_mp.py) -- v_min the right
+    singular vector of the smallest kept singular value, c_scaled the solution in numpy's column-scaled basis.  The values of the fitted cubic move by eps * (kappa |resid| + |c_scaled|)
     on the range of the bin means and by the Chebyshev factor T_m(d / halfwidth) beyond it; a simple root moves by that
     over |p'(root)|."""
     f = feature_of(col)
@@ -460,7 +468,9 @@ def tolerance_for(col, x, want, facts):
             amax = max(float(np.max(np.abs(facts.x))), 1e-300)
             atol = 1e-9 * fit["dmax"] / amax ** max(m - j, 0)
             if 0 <= j <= m:
-                atol += noise * fit["kappa"] * fit["resid"] * fit["noise_dir"][j]
+                # the error ALONG v_min is normwise: eps kappa (|c_scaled| + kappa |resid|) -- a coefficient that is exactly
+                # zero (the cubic of an exact ramp's constant drift) still receives it through its component of v_min
+                atol += noise * (fit["scaled_norm"] + fit["kappa"] * fit["resid"]) * fit["noise_dir"][j]
             return max(RTOL, noise), atol
         atol = atol_for(col, x)
         if np.isfinite(want):

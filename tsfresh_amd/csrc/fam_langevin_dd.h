@@ -11,7 +11,7 @@
 // 101 325 +- 5 Pa, any float64 counter).
 //
 // k_sort solves the scaled design by Householder QR in float64, which is the same polynomial while the design is well
-// conditioned (error ~ eps * cond).  When the diagonal of R spans more than TSFA_PF_FLAG (or there are fewer bins than
+// conditioned (error ~ eps * cond^2 * |resid|).  When the diagonal of R spans more than TSFA_PF_FLAG (or there are fewer bins than
 // coefficients) it hands the bin means to this pass: ONE LANE PER LISTED SERIES (k_langevin_dd), serial code in
 // double-double arithmetic:
 //   * the scaled design A exactly as numpy forms it (float64 running products, float64 column norms and divisions);
@@ -29,7 +29,8 @@
 #include "tsfa_dd.h"
 
 #define TSFA_PF_MAXC 4          // coefficients of the largest fit (TSFA_FRIEDRICH_MAX_M + 1)
-#define TSFA_PF_FLAG 1e-5       // min |R_kk| / max |R_kk| of the float64 QR below which a fit is redone here
+#define TSFA_PF_FLAG 1e-3       // min |R_kk| / max |R_kk| of the float64 QR below which a fit is redone here: the float64 solve
+                                // errs by ~eps cond^2 |resid|, 2e-10 at the threshold (1e-5 left 2e-6 -- found by the fuzz)
 #define TSFA_PF_SWEEPS 12
 
 // (record layout of a deferred fit: TSFA_PF_HDR / tsfa_pf_slot_doubles in tsfa_specs.h)
