@@ -433,7 +433,7 @@ def main():
             if half != workers:
                 pool2 = mp.get_context("spawn").Pool(half)
                 pool2.map(_cpu_warm, range(4 * half))
-                d2 = cpu_baseline(pool2, half, L, params_name, seed=43, per_worker=16, repeats=1)
+                d2 = cpu_baseline(pool2, half, L, params_name, seed=43, per_worker=8, repeats=1)
                 pool2.close()
                 pool2.join()
                 line["cpu_baseline"]["default_n_jobs"] = {"workers": half, "value": d2["value"], "unit": "series/sec",

@@ -49,6 +49,8 @@ can bound it.
       (scipy's sqrt((1 - r^2) ...) cancels).
   R9  partial_autocorrelation from the lag at which the Levinson-Durbin innovation variance has dropped below
       1e-9 * acov[0] (an exactly predictable series: periodic, linear): the next coefficient divides by round-off.
+      Above that floor the lags are compared with rtol = max(1e-6, 100 eps / the smallest innovation variance divided by
+      so far, relative to acov[0]) -- the recursion's own conditioning (tolerance_for).
   R10 fourier_entropy when a normalised Welch density lies on an edge of np.histogram's bins up to round-off (exactly
       periodic series: a Hann-leaked bin of exactly 1/4 of the peak sits on the edge 0.25 of 100 bins).
   R11 friedrich_coefficients / max_langevin_fixed_point when a singular value of np.polyfit's scaled Vandermonde design
@@ -349,6 +351,41 @@ def _r2_cancels(rvalue):
     return rvalue is not None and np.isfinite(rvalue) and 1.0 - rvalue * rvalue < 1e-9
 
 
+def _pacf_min_innovation(x):
+    """-> array m[k] = min over j < k of |sig_j| / acov[0]: the smallest innovation variance the Levinson-Durbin recursion
+    has divided by before it produces lag k.  The recursion's relative error at lag k is ~eps / m[k] (its numerator
+    cancels to that size): a two-valued +-1 series with pacf[2] = -1.0000000006 leaves m = 1.2e-9 and every later
+    coefficient -- 28 439, -614.7, ... -- good to 1e-6 at best, in the reference as anywhere."""
+    from oracle.third_party import acovf_adjusted
+    n = len(x)
+    nlags = min(40, n // 2 - 1)
+    out = np.ones(max(nlags, 0) + 2)
+    if nlags < 1:
+        return out
+    acv = acovf_adjusted(x, nlags)
+    if not acv[0] > 0:
+        return out
+    phi_prev = np.zeros(nlags + 1)
+    phi_prev[1] = acv[1] / acv[0]
+    sig = acv[0] - phi_prev[1] * acv[1]
+    cur_min = 1.0
+    k = 1
+    for k in range(2, nlags + 1):
+        cur_min = min(cur_min, abs(sig) / acv[0])
+        out[k] = cur_min
+        if sig == 0:
+            break
+        pkk = (acv[k] - np.dot(phi_prev[1:k], acv[1:k][::-1])) / sig
+        cur = phi_prev.copy()
+        for j in range(1, k):
+            cur[j] = phi_prev[j] - pkk * phi_prev[k - j]
+        cur[k] = pkk
+        sig = sig * (1 - pkk * pkk)
+        phi_prev = cur
+    out[k:] = np.minimum(out[k:], cur_min)
+    return out
+
+
 def _pacf_noise_lag(x):
     """First lag whose Levinson-Durbin step divides by an innovation variance at round-off level (or a large number)."""
     from oracle.third_party import acovf_adjusted
@@ -481,6 +518,11 @@ def tolerance_for(col, x, want, facts):
             if slope > 0:
                 atol += COND_FACTOR * EPS * grow * (fit["kappa"] * fit["resid"] + fit["scaled_norm"]) / slope
         return RTOL, atol
+    if f == "partial_autocorrelation":
+        lag = _param(col, "lag", int)
+        m = facts.get("pacf_min", lambda: _pacf_min_innovation(facts.x))
+        worst = float(m[min(lag, len(m) - 1)]) if lag >= 2 else 1.0
+        return max(RTOL, 100.0 * EPS / max(worst, 1e-300)), atol_for(col, x)
     if f == "ar_coefficient":
         k, j = _param(col, "k", int), _param(col, "coeff", int)
         spread = facts.get(("ar_probe", k), lambda: _ar_probe(facts.x, k))

@@ -82,9 +82,10 @@ TSFA_DEV void blk_chol_solve(const Blk &b, const double *L, int p, int ld, const
 // serial.
 // Returns false (uniformly) when a pivot keeps less than TSFA_AR_PIVOT_TOL of its column's squared norm (diag0
 // receives the diagonal of G): the design is rank-deficient (constant / linear / periodic series) or conditioned
-// worse than ~3e4, where float64 normal equations lose the digits the reference's SVD still has.  Such series are
+// worse than ~1e3, where float64 normal equations lose the digits the reference's SVD still has.  Such series are
 // listed for the double-double second pass (fam_ar_dd.h); an absolute `d > 0` test lets round-off pass for a pivot.
-#define TSFA_AR_PIVOT_TOL 1e-9
+#define TSFA_AR_PIVOT_TOL 1e-6   // (1e-9 until round 3: a noiseless float32 sine + offset keeps 16 pivots at 1.5e-9 of their columns,
+                                 //  the float64 factor then loses the ADF statistic's 4th digit -- found by the fuzz, adjudicated in 60 digits)
 TSFA_DEV bool blk_chol_factor(const Blk &b, double *G, int p, int ld, double *diag0, double *dmin = nullptr) {
     for (int a = b.tid; a < p; a += b.nt) diag0[a] = G[a + a * ld];
     double dm = TSFA_INF;
