@@ -42,15 +42,16 @@ can bound it.
   R5  augmented_dickey_fuller when a lag-search regression fits perfectly (ssr <= 1e-18 * yy, yy > 0): the AIC is
       n log(round-off) and the t statistic (round-off)/(round-off); the kernels return AIC = -inf and 0/0 = NaN or
       x/0 = +-inf there (tests/test_degenerate.py pins that behaviour).
-  R6  max_langevin_fixed_point when the fitted cubic's leading coefficient is round-off (a perfectly linear drift):
-      np.roots then returns a root near -c2/c3.
+  R6  max_langevin_fixed_point when the fitted cubic's leading coefficient is round-off (a perfectly linear drift:
+      np.roots then returns a root near -c2/c3) -- relative to the other terms, or within the noise of its own fit (R11's
+      tolerance: an exact ramp far from zero has a constant drift and the reference's cubic is that constant + noise).
   R7  agg_linear_trend: slope-type attributes when the chunk aggregates differ by round-off only
       (0 < ptp <= 1e-12 * max|agg|), and "stderr" of linear_trend / agg_linear_trend when 1 - r^2 < 1e-9
       (scipy's sqrt((1 - r^2) ...) cancels).
   R9  partial_autocorrelation from the lag at which the Levinson-Durbin innovation variance has dropped below
       1e-9 * acov[0] (an exactly predictable series: periodic, linear): the next coefficient divides by round-off.
-      Above that floor the lags are compared with rtol = max(1e-6, 100 eps / the smallest innovation variance divided by
-      so far, relative to acov[0]) -- the recursion's own conditioning (tolerance_for).
+      Above that floor the lags are compared with a tolerance of 1000 eps / (the smallest innovation variance divided by so
+      far, relative to acov[0]), relative and absolute -- the recursion's own conditioning (tolerance_for).
   R10 fourier_entropy when a normalised Welch density lies on an edge of np.histogram's bins up to round-off (exactly
       periodic series: a Hann-leaked bin of exactly 1/4 of the peak sits on the edge 0.25 of 100 bins).
   R11 friedrich_coefficients / max_langevin_fixed_point when a singular value of np.polyfit's scaled Vandermonde design
@@ -254,14 +255,21 @@ def _adf_state(x):
     return _pinv_unstable(full), perfect
 
 
-def _langevin_noise_cubic(x, m, r):
+def _langevin_noise_cubic(x, m, r, fit=None):
     from oracle.calculators import friedrich_coefficients_of
     c = friedrich_coefficients_of(np.asarray(x, dtype=np.float64), m, r)
     if c is None or not np.all(np.isfinite(c)):
         return False
     s = max(float(np.max(np.abs(x))), 1e-300)
     mag = np.abs(c) * s ** np.arange(len(c) - 1, -1, -1)
-    return bool(mag[0] <= 1e-8 * mag.max())
+    if mag[0] <= 1e-8 * mag.max():
+        return True
+    # ... or when the leading coefficient is within the noise its own least-squares fit has (tolerance_for): an exact ramp
+    # far from zero has a CONSTANT drift, the reference's cubic there is c_3 + round-off and its roots are roots of noise
+    if fit is not None and np.isfinite(fit["kappa"]):
+        noise0 = COND_FACTOR * EPS * fit["kappa"] * ((fit["scaled_norm"] + fit["kappa"] * fit["resid"]) * fit["noise_dir"][0] + abs(c[0]))
+        return bool(abs(c[0]) <= noise0)
+    return False
 
 
 def _langevin_fit_facts(x, m, r):
@@ -458,7 +466,7 @@ def excluded(col, x, simd_golden=False, facts=None, rvalue=None):
             return True                                                                                   # R11
         if f == "friedrich_coefficients":
             return False
-        return facts.get(("lang", m, r), lambda: _langevin_noise_cubic(xv, m, r))                        # R6
+        return facts.get(("lang", m, r), lambda: _langevin_noise_cubic(xv, m, r, fit))                   # R6
     if f == "agg_linear_trend":
         attr = col.split('attr_"')[1].split('"')[0]
         f_agg, cl = col.split('f_agg_"')[1].split('"')[0], _param(col, "chunk_len", int)
@@ -522,7 +530,10 @@ def tolerance_for(col, x, want, facts):
         lag = _param(col, "lag", int)
         m = facts.get("pacf_min", lambda: _pacf_min_innovation(facts.x))
         worst = float(m[min(lag, len(m) - 1)]) if lag >= 2 else 1.0
-        return max(RTOL, 100.0 * EPS / max(worst, 1e-300)), atol_for(col, x)
+        # the recursion's coefficients are O(1) quantities: the error is absolute as well as relative (a lag coefficient
+        # of 0.018 behind an innovation variance of 1.7e-6: 2.9e-8 off in the reference, 220 eps / m)
+        noise = 1000.0 * EPS / max(worst, 1e-300)
+        return max(RTOL, noise), atol_for(col, x) + (noise if noise > 1e-9 else 0.0)
     if f == "ar_coefficient":
         k, j = _param(col, "k", int), _param(col, "coeff", int)
         spread = facts.get(("ar_probe", k), lambda: _ar_probe(facts.x, k))
