@@ -323,27 +323,30 @@ def main():
     # ---- N > 1: what the exchange costs on top of the extraction (outside the timed region) ----
     multi = None
     if dist is not None and world > 1:
-        local = ShardPipeline(fplan.native_specs(_native.calc_id), n_cols, local_rank, dist=None, n_chunks=n_chunks,
-                              length_hint=None if args.ragged else (L, L))
-        local.run(values, offsets, [n], out, _native.TSFA_F32)   # a world of one: this rank's rows into its own block
-        barrier()
-        t1 = time.perf_counter()
-        for _ in range(args.steps):
-            local.run(values, offsets, [n], out, _native.TSFA_F32)
-        barrier()
-        t_local = torch.tensor([time.perf_counter() - t1], device=dev, dtype=torch.float64)
-        dist.all_reduce(t_local, op=dist.ReduceOp.MAX)
-        compute_ms = 1000.0 * float(t_local.item()) / max(args.steps, 1)
-        local.close()
-        try:
-            rccl = ".".join(str(v) for v in torch.cuda.nccl.version())
-        except Exception:  # noqa: BLE001
-            rccl = None
-        gathered = (world - 1) * n * n_cols * 8
-        multi = {"world": world, "backend": "nccl (RCCL %s)" % rccl, "row_chunks": n_chunks,
-                 "compute_only_ms_per_step": compute_ms, "exchange_ms_exposed": ms_per_step - compute_ms,
-                 "bytes_received_per_rank_per_step": gathered,
-                 "exchange_gbs_per_rank_if_fully_exposed": gathered / max((ms_per_step - compute_ms) * 1e-3, 1e-9) / 1e9}
+        try:   # diagnostics only: a failure here (the same on every rank) must not cost the bench line
+            local = ShardPipeline(fplan.native_specs(_native.calc_id), n_cols, local_rank, dist=None, n_chunks=n_chunks,
+                                  length_hint=None if args.ragged else (L, L))
+            local.run(values, offsets, [n], out, _native.TSFA_F32)   # a world of one: this rank's rows into its own block
+            barrier()
+            t1 = time.perf_counter()
+            for _ in range(args.steps):
+                local.run(values, offsets, [n], out, _native.TSFA_F32)
+            barrier()
+            t_local = torch.tensor([time.perf_counter() - t1], device=dev, dtype=torch.float64)
+            dist.all_reduce(t_local, op=dist.ReduceOp.MAX)
+            compute_ms = 1000.0 * float(t_local.item()) / max(args.steps, 1)
+            local.close()
+            try:
+                rccl = ".".join(str(v) for v in torch.cuda.nccl.version())
+            except Exception:  # noqa: BLE001
+                rccl = None
+            gathered = (world - 1) * n * n_cols * 8
+            multi = {"world": world, "backend": "nccl (RCCL %s)" % rccl, "row_chunks": n_chunks,
+                     "compute_only_ms_per_step": compute_ms, "exchange_ms_exposed": ms_per_step - compute_ms,
+                     "bytes_received_per_rank_per_step": gathered,
+                     "exchange_gbs_per_rank_if_fully_exposed": gathered / max((ms_per_step - compute_ms) * 1e-3, 1e-9) / 1e9}
+        except Exception as e:  # noqa: BLE001
+            multi = {"world": world, "error": repr(e)}
 
     # ---- per-kernel HIP-event timings (events recorded on the launch stream), 2 profiled passes ----
     plan.set_profiling(True)
