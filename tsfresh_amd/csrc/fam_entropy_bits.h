@@ -658,7 +658,12 @@ TSFA_DEV void fam_entropy_series_bits(const Blk &b, double *xs, int n, const Tsf
         const int np2 = next_pow2(n);
         bool sorted = false;
 #if TSFA_GPU
-        if (F32 && b.nt >= 64) {  // wavefront-local bitonic sort + merge by ranking (work: 2 * np2 64-bit words)
+#if defined(TSFA_EXPERIMENT_NO_ENTB_SORT)   // cost experiment only (profiles/r03_i.sh): identity order, wrong results
+        for (int i = b.tid; i < np2; i += b.nt) perm[i] = (unsigned short)(i < n ? i : 0xFFFF);
+        blk_sync();
+        sorted = true;
+#endif
+        if (!sorted && F32 && b.nt >= 64) {  // wavefront-local bitonic sort + merge by ranking (work: 2 * np2 64-bit words)
             unsigned long long *buf = (unsigned long long *)(void *)work;
             if (np2 == b.nt) { entb_sort_merge<1>(b, xs, n, perm, buf); sorted = true; }
             else if (np2 == 2 * b.nt) { entb_sort_merge<2>(b, xs, n, perm, buf); sorted = true; }
