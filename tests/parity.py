@@ -65,7 +65,9 @@ can bound it.
   R8  number_cwt_peaks when a CWT row has two neighbouring values that are equal up to round-off (1e-12 of the row's
       magnitude; symmetric integer-valued, periodic or piecewise-constant data) next to a lower neighbour: which of them
       -- or neither -- is the STRICT relative maximum that starts a ridge line depends on the summation order of
-      scipy's convolution ([a, a+1, a+1, a+1, a+1] at a = -1.1e7: 1 ulp apart in scipy, a ridge line more or less).
+      scipy's convolution ([a, a+1, a+1, a+1, a+1] at a = -1.1e7: 1 ulp apart in scipy, a ridge line more or less);
+      or when a ridge line's signal-to-noise ratio equals the threshold 1 up to 1e-9 (exactly periodic data: the noise
+      percentile of the window is minus the peak value, `snr < 1` is decided by the last bit).
 """
 import numpy as np
 
@@ -320,6 +322,26 @@ def _cwt_peaks_ambiguous(x, n):
     if len(x) < 4 or np.ptp(x) == 0:
         return False
     rows = _cwt(x, _ricker, np.arange(1, n + 1))
+    # ... or a ridge line's signal-to-noise ratio sits ON the threshold min_snr = 1 up to round-off: on exactly periodic data
+    # (0, 2, -2, 0, ...) the 10th percentile of the width-1 row in a window IS minus the peak value, |signal / noise| = 1.0
+    # exactly in scipy, and a last-bit difference between two "equal" peaks decides `snr < 1` (24 peaks or 2)
+    from scipy.signal._peak_finding import _identify_ridge_lines
+    from scipy.stats import scoreatpercentile
+    widths = np.arange(1, n + 1)
+    try:
+        lines = _identify_ridge_lines(rows, widths / 4.0, np.ceil(widths[0]))
+    except Exception:  # noqa: BLE001
+        lines = []
+    if lines:
+        num_points = rows.shape[1]
+        hf, odd = divmod(int(np.ceil(num_points / 20)), 2)
+        row_one = rows[0]
+        for line in lines:
+            r, c0 = line[0][0], line[1][0]
+            noise = scoreatpercentile(row_one[max(c0 - hf, 0):min(c0 + hf + odd, num_points)], per=10)
+            sig = rows[r, c0]
+            if noise != 0 and abs(abs(sig / noise) - 1.0) < 1e-9:
+                return True
     for c in rows:
         tol = 1e-12 * np.max(np.abs(c))
         near = np.abs(c[1:] - c[:-1]) <= tol                       # c[i] ~ c[i+1]
@@ -591,6 +613,11 @@ def atol_for(col, x):
         amax = 1.0
     if f in ("fft_coefficient",):
         return 1e-10 * max(float(ax.sum()), 1e-300)
+    if f == "fft_aggregated":
+        # moments of the spectrum over the bin index 0 .. n/2: the centroid is of the size of n/2, the variance (m2 -
+        # centroid^2, a cancellation: exactly 0 for a series of period 2) of its square
+        half = max(len(ax) / 2.0, 1.0)
+        return 1e-9 * (half if 'aggtype_"centroid"' in col else half * half if 'aggtype_"variance"' in col else 1.0)
     if f == "ar_coefficient" and dimension_of(col) == 1:
         # the intercept: mean * (1 - sum of the lag coefficients) -- of the size of the spread for a stationary series,
         # and tiny in the pinv truncation regime (1e-10 for 1e9 + N(0, 1)), where max|x| would forgive anything
