@@ -88,7 +88,11 @@ def main():
             warnings.simplefilter("ignore")
             engine = emul_engine if os.environ.get("TSFA_FUZZ_ENGINE") == "emul" else hip_engine
             names, got = engine(params, values, offsets)
-            names_o, want = oracle_engine(params, values.astype(np.float64), offsets)
+            try:
+                names_o, want = oracle_engine(params, values.astype(np.float64), offsets)
+            except ValueError as e:   # the REFERENCE raises here (np.histogram: "Too many bins for data range" ...): no value to compare
+                print("round", r, "skipped: the oracle raises as the reference does:", str(e)[:80])
+                continue
         assert names == names_o, (names[:3], names_o[:3])
         bad = compare(names, got, want, [values[offsets[i]:offsets[i + 1]].astype(np.float64) for i in range(len(series))])
         total_bad += len(bad)

@@ -319,7 +319,7 @@ def _cwt_peaks_ambiguous(x, n):
     from scipy.signal._wavelets import _cwt
     from oracle.calculators import _ricker
     x = np.asarray(x, dtype=np.float64)
-    if len(x) < 4 or np.ptp(x) == 0:
+    if len(x) < 4 or not np.any(x):   # (a NON-zero constant has a flat CWT interior: every neighbour pair is a tie)
         return False
     rows = _cwt(x, _ricker, np.arange(1, n + 1))
     # ... or a ridge line's signal-to-noise ratio sits ON the threshold min_snr = 1 up to round-off: on exactly periodic data
