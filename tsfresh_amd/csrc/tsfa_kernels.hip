@@ -547,6 +547,7 @@ __device__ __forceinline__ void stream_body(const T (&v)[E], int n, int lane, ty
         if (sd > 0.0 && sd < TSFA_INF) {
 #pragma unroll 1
             for (int it = 0; it < 4; ++it) {
+                if (!((double)hi < TSFA_INF) || !((double)lo > -TSFA_INF)) break;   // (the +inf pads must stay outside the window)
                 c_lo = 0; c_hi = 0;
 #pragma unroll
                 for (int e = 0; e < E; ++e) {
