@@ -221,6 +221,23 @@ TSFA_DEV int ar_scratch_doubles(int P) { return 2 * P * P + 7 * P + 64 + 16 + 48
 // root of the smallest Cholesky pivot this bounds the raw ratio from below; a series whose bound is within 1000x of
 // the cut is listed for the second pass, which measures the ratio and takes the eigen route if it has to
 // (1e6 + N(0, 1) is listed, 1e5 + N(0, 1) is not).
+// A factorization without pivoting does not reveal rank: a design can keep every relative pivot above 1e-2 and still have
+// cond(X) = 2e7 (a stuck sensor after a noisy start: the lag columns differ from the constant in their first rows only;
+// eleven pivots of ~0.05 each multiply to a determinant of 1e-11).  The float64 normal equations then lose eps cond^2 --
+// the intercept came out 4e-7 off where the reference's SVD is good to 4e-9 (found by the fuzz).  What does reveal it is
+// the refinement step both regressions take anyway: its correction IS the error of the first solve.  A correction above
+// 1e-8 of the solution (both weighted by the column norms) lists the series for the double-double pass.
+#define TSFA_AR_REFINE_TOL 1e-8
+TSFA_DEV bool ar_refinement_suspect(const double *beta, const double *corr, const double *diag0, int p) {
+    double mb = 0.0, mc = 0.0;
+    for (int a = 0; a < p; ++a) {   // uniform: every thread reads the same LDS values
+        const double w = sqrt(diag0[a]);
+        mb = fmax(mb, fabs(beta[a]) * w);
+        mc = fmax(mc, fabs(corr[a]) * w);
+    }
+    return mc > TSFA_AR_REFINE_TOL * mb;
+}
+
 #define TSFA_AR_RAW_RATIO 1e-12
 TSFA_DEV bool ar_raw_design_suspect(double dmin, double mu_norm, double trace_raw) {
     return sqrt(dmin) < TSFA_AR_RAW_RATIO * (1.0 + mu_norm) * sqrt(trace_raw);
@@ -486,6 +503,8 @@ TSFA_DEV int fam_ar_series(const Blk &b, X xv, int n, const TsfaSpec *specs, int
                     blk_sync();
                     blk_chol_solve(b, G, p2, P, tmp1, tmp2);
                     blk_sync();
+                    if (ar_refinement_suspect(beta, tmp2, diag0, p2)) degenerate |= 2;
+                    blk_sync();
                     for (int a = b.tid; a < p2; a += b.nt) beta[a] += tmp2[a];
                     blk_sync();
                     double ssr = 0.0;
@@ -660,6 +679,8 @@ TSFA_DEV int fam_ar_series(const Blk &b, X xv, int n, const TsfaSpec *specs, int
                     }
                     blk_sync();
                     blk_chol_solve(b, G, p, P, tmp1, tmp2);
+                    blk_sync();
+                    if (ar_refinement_suspect(beta, tmp2, diag0, p)) degenerate |= 1;
                     blk_sync();
                     if (b.tid == 0) {
                         double sphi = 0.0;
