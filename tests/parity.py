@@ -41,7 +41,9 @@ can bound it.
       N(0,1), epoch seconds) are compared like any other.
   R5  augmented_dickey_fuller when a lag-search regression fits perfectly (ssr <= 1e-18 * yy, yy > 0): the AIC is
       n log(round-off) and the t statistic (round-off)/(round-off); the kernels return AIC = -inf and 0/0 = NaN or
-      x/0 = +-inf there (tests/test_degenerate.py pins that behaviour).
+      x/0 = +-inf there (tests/test_degenerate.py pins that behaviour) -- or fits so nearly perfectly that its residual
+      sum lies below the round-off of the reference's float64 solve of the raw design, ssr <= (10 eps cond(X))^2 yy (then the
+      kernels return what exact arithmetic returns, the reference a deterministic function of its round-off).
   R6  max_langevin_fixed_point when the fitted cubic's leading coefficient is round-off (a perfectly linear drift:
       np.roots then returns a root near -c2/c3) -- relative to the other terms, or within the noise of its own fit (R11's
       tolerance: an exact ramp far from zero has a constant drift and the reference's cubic is that constant + noise).
@@ -227,17 +229,33 @@ def _ar_design(x, k):
 
 
 def _adf_state(x):
-    """-> (unstable, perfect): properties of the lag-search design of statsmodels.adfuller(x, autolag="AIC")."""
-    from oracle.third_party import _add_const
+    """-> (unstable, perfect): properties of the regressions of statsmodels.adfuller(x, autolag="AIC") -- the lag-search
+    design and the final regression at the lag the reference's algorithm picks."""
+    from oracle import third_party as tp
     n = len(x)
     maxlag = min(n // 2 - 2, int(np.ceil(12.0 * np.power(n / 100.0, 0.25))))
     if maxlag < 0:
         return False, False
     d = np.diff(x)
-    rows = np.arange(maxlag, len(d))
-    Z = np.column_stack([x[rows]] + [d[rows - j] for j in range(1, maxlag + 1)])
+    unstable, perfect = _adf_design_state(x, d, maxlag, prepend=True)
+    if not perfect:
+        try:
+            with np.errstate(all="ignore"):
+                used = int(tp.adfuller_aic(x)[2])
+        except (ValueError, np.linalg.LinAlgError):
+            used = None
+        if used is not None and 0 <= used <= maxlag:
+            u2, p2 = _adf_design_state(x, d, used, prepend=False)   # x = [a + 1, a, a, ...]: two points, a perfect line
+            unstable, perfect = unstable or u2, p2
+    return unstable, perfect
+
+
+def _adf_design_state(x, d, lags, prepend):
+    from oracle.third_party import _add_const
+    rows = np.arange(lags, len(d))
+    Z = np.column_stack([x[rows]] + [d[rows - j] for j in range(1, lags + 1)])
     y = d[rows]
-    full = _add_const(Z, prepend=True)
+    full = _add_const(Z, prepend=prepend)
     yy = float(y @ y)
     perfect = False
     if yy > 0:
@@ -254,6 +272,16 @@ def _adf_state(x):
         beta = np.linalg.lstsq(fs, y, rcond=None)[0]
         r = y - fs @ beta
         perfect = float(r @ r) <= 1e-18 * yy
+        # ... or NEARLY perfectly, below what the reference's own solve of the RAW design resolves: it computes pinv(X) y in
+        # float64, so its fitted values carry ~eps cond(X) |y| of round-off; a lag search whose residual sums are smaller
+        # than that compares round-off (a noiseless sinusoid, rounded to float32 and moved to -1.55 +- 3e-6: cond 1e14, the
+        # residual of the exact fit is 1e-7 of |y| -- 60-digit arithmetic and the double-double pass say usedlag 11,
+        # teststat -6.83; every float64 run of the reference's algorithm says usedlag 1, -7.6e6)
+        sv = np.linalg.svd(full, compute_uv=False)
+        kept = sv[sv > 1e-15 * sv[0]] if sv[0] > 0 else sv
+        cond_kept = float(sv[0] / kept[-1]) if len(kept) else np.inf
+        if not perfect and np.isfinite(cond_kept):
+            perfect = float(r @ r) <= (10.0 * EPS * cond_kept) ** 2 * yy
     return _pinv_unstable(full), perfect
 
 
