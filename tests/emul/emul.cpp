@@ -143,7 +143,7 @@ extern "C" int tsfa_emul_extract_timed(const tsfa_feature_spec *specs, int n_spe
                 if (sp.calc == TSFA_C_AUGMENTED_DICKEY_FULLER) P = std::max(P, adf_maxlag_for(maxn) + 3);
                 else if (sp.calc == TSFA_C_AR_COEFFICIENT) P = std::max(P, (int)sp.p[1] + 2);
             }
-            std::vector<double> xc(maxn + 8), aw(ArLds::scratch_doubles(P));
+            std::vector<double> xc(maxn + TSFA_AR_PADL + TSFA_AR_PADR, TSFA_NAN), aw(ArLds::scratch_doubles(P));
             const double *xp = xs.data();
             const int flags = fam_ar_series<double>(b, [=](int i) { return xp[i]; }, n, fam[TSFA_FAM_AR].data(),
                           (int)fam[TSFA_FAM_AR].size(), row, (void *)xc.data(), aw.data(), P, hints[TSFA_FAM_AR].a,

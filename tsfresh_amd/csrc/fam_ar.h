@@ -124,63 +124,164 @@ TSFA_DEV void blk_chol_forward(const Blk &b, const double *L, int p, int ld, dou
     blk_sync();
 }
 
-// s8[j] = sum over t in [t0, t1) of fa(t) * fb(t, j), j < nj <= 8 (the caller reduces s8 over the workgroup).
-// With <= 8 time points per thread they stay in registers, every operand read of the 8 x nj products is issued
-// unconditionally on an in-range index (fb must accept any t in [t0, t1) and j < 8), and the lane sums run in the same
-// order as the plain loop: the loop form waits for an LDS round trip in each of its iterations.
-template <class FA, class FB>
-TSFA_DEV void blk_dots8(const Blk &b, int t0, int t1, int nj, FA fa, FB fb, double (&s8)[8]) {
-#pragma unroll
-    for (int j = 0; j < 8; ++j) s8[j] = 0.0;
-    if (t1 <= t0) return;
+// ---------------------------------------------------------------------------------------------
+// Lagged sums on register tiles.  Every sum of the family has the form  S[j] = sum_t A(t) B(t - j)  over a row range,
+// j = 0 .. 60.  A thread owns EIGHT CONSECUTIVE rows (a tile: A(tb .. tb+7) in registers); the eight lags of a sweep then
+// need B(tb - j0 - 8 .. tb - j0 + 7), two aligned blocks of eight, of which the upper one is the previous sweep's lower
+// one.  A sweep is 64 fused multiply-adds on registers plus ONE block load (two 128-bit LDS reads for float32 samples);
+// the strided form it replaces (row = tid + u nt) spent ten instructions per product on index clamps, conversions,
+// centring and selects.  The series sits in LDS between TSFA_AR_PADL zero samples and TSFA_AR_PADR zero samples, so every
+// block a tile can ask for exists and is finite: rows outside the sum are masked in A alone.
+// ---------------------------------------------------------------------------------------------
+#define TSFA_AR_PADL 64   // >= 8 * ceil((max lag + 1) / 8): ADF maxlag <= 61 at n = 65 535, agg_autocorrelation <= 60
+#define TSFA_AR_PADR 16   // tiles cover [0, 8 ceil(n / 8)); a block of differences reads one sample more
+
+template <class ST>
+TSFA_DEV void ar_load8(const ST *p, double (&r)[8]) {   // p: block of eight samples, index a multiple of 8
 #if TSFA_GPU
-    if (t1 - t0 <= 8 * b.nt) {
-        double a[8];
-        int tc[8];
+    p = (const ST *)__builtin_assume_aligned(p, 16);
+#endif
 #pragma unroll
-        for (int u = 0; u < 8; ++u) {
-            const int t = t0 + b.tid + u * b.nt;
-            tc[u] = (t < t1) ? t : t0;
-            const double av = fa(tc[u]);
-            a[u] = (t < t1) ? av : 0.0;
-        }
+    for (int q = 0; q < 8; ++q) r[q] = (double)p[q];
+}
+
+// the resident series as blocks: y = centred samples (double)x - mean, d = first differences x[i + 1] - x[i] of the RAW
+// samples (np.diff(x): the mean cancels, and for float32 input the difference of two samples is exact in float64)
+template <class ST>
+struct ArBlocks {
+    const ST *xs;   // sample 0 (TSFA_AR_PADL zero samples before it)
+    double mean;
+    TSFA_MEM void y8(int i0, double (&r)[8]) const {
+        ar_load8(xs + i0, r);
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            if (j < nj) {
+        for (int q = 0; q < 8; ++q) r[q] -= mean;
+    }
+    TSFA_MEM void d8(int i0, double (&r)[8]) const {
+        double v[8];
+        ar_load8(xs + i0, v);
+        const double nx = (double)xs[i0 + 8];
 #pragma unroll
-                for (int u = 0; u < 8; ++u) s8[j] += a[u] * fb(tc[u], j);
+        for (int q = 0; q < 7; ++q) r[q] = v[q + 1] - v[q];
+        r[7] = nx - v[7];
+    }
+};
+
+// rows outside [r0, r1) of the tile starting at tb read as zero
+TSFA_DEV void tile_mask_rows(double (&A)[8], int tb, int r0, int r1) {
+#pragma unroll
+    for (int u = 0; u < 8; ++u) A[u] = (tb + u >= r0 && tb + u < r1) ? A[u] : 0.0;
+}
+
+// s[j] += sum_u A[u] B(tb + u - j0 - j), j < 8:  hi = B(tb - j0 ..), lo = B(tb - j0 - 8 ..)
+TSFA_DEV void tile_dots8(const double (&A)[8], const double (&lo)[8], const double (&hi)[8], double (&s)[8]) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+#pragma unroll
+        for (int u = 0; u < 8; ++u) s[j] = fma(A[u], (u >= j) ? hi[u - j] : lo[u - j + 8], s[j]);
+    }
+}
+// r[u] -= sum_j cf[j] B(tb + u - j0 - j): the same window, transposed (residuals of a lagged regression)
+TSFA_DEV void tile_axpy8(const double (&cf)[8], const double (&lo)[8], const double (&hi)[8], double (&r)[8]) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+#pragma unroll
+        for (int u = 0; u < 8; ++u) r[u] = fma(-cf[j], (u >= j) ? hi[u - j] : lo[u - j + 8], r[u]);
+    }
+}
+
+// store(j, sum_t A(t) B(t - j)) for j < nlags, rows t in [0, nrows):
+//   loadA(tb, A): A(tb .. tb + 7), zero on the rows that are not part of the sum
+//   loadB(i0, B): B(i0 .. i0 + 7), i0 a multiple of 8, >= -TSFA_AR_PADL
+//   sums (or null): sums[0] = sum_t A(t), sums[1] = sum_t A(t)^2  (every thread receives them)
+//   part (or null): LDS scratch of part_doubles doubles.  With it the wavefronts leave their partial sums of ALL sweeps
+//                   there and meet once (two barriers per call instead of two per sweep; lane = lag adds them up).
+// store() is called by one thread per lag; the caller provides the barrier before anybody else reads what it wrote.
+// One tile per thread (n <= 8 nt, the short-series launch): A and the upper block stay in registers across the sweeps.
+#define TSFA_AR_PART_STRIDE 72   // 64 lags + the two row sums, per wavefront
+template <class LA, class LB, class SF>
+TSFA_DEV void blk_tile_lagdots(const Blk &b, int nrows, int nlags, LA loadA, LB loadB, SF store, double *sums = nullptr,
+                               double *part = nullptr, int part_doubles = 0) {
+    const int ntiles = (nrows + 7) >> 3;
+    const bool single = ntiles <= b.nt;
+#if TSFA_GPU
+    const int nwv = (b.nt + 63) >> 6, wv = b.tid >> 6, lane = b.tid & 63;
+#else
+    const int nwv = 1, wv = 0;
+#endif
+    const bool deferred = (part != nullptr) && (nwv * TSFA_AR_PART_STRIDE <= part_doubles) && (nlags <= 64);
+    if (deferred) blk_sync();   // the previous user of `part`
+    double A[8], lo[8], hi[8];
+    for (int j0 = 0; j0 < nlags; j0 += 8) {
+        double s[8], sa[2] = {0.0, 0.0};
+#pragma unroll
+        for (int j = 0; j < 8; ++j) s[j] = 0.0;
+        for (int tile = b.tid; tile < ntiles; tile += b.nt) {
+            const int tb = tile << 3;
+            if (single && j0 > 0) {
+#pragma unroll
+                for (int q = 0; q < 8; ++q) hi[q] = lo[q];
+            } else {
+                loadA(tb, A);
+                loadB(tb - j0, hi);
+            }
+            loadB(tb - j0 - 8, lo);
+            tile_dots8(A, lo, hi, s);
+            if (sums != nullptr && j0 == 0) {
+#pragma unroll
+                for (int u = 0; u < 8; ++u) { sa[0] += A[u]; sa[1] = fma(A[u], A[u], sa[1]); }
             }
         }
-        return;
-    }
-#endif
-    for (int t = t0 + b.tid; t < t1; t += b.nt) {
-        const double at = fa(t);
+        if (deferred) {
+            double *slot = part + wv * TSFA_AR_PART_STRIDE;
+#if TSFA_GPU
+            const double held = wave_reduce_scatter<8>(s);
+            if (lane < 8) slot[j0 + wave_reduce_scatter_index<8>(lane)] = held;
+            if (sums != nullptr && j0 == 0) {
+                sa[0] = wave_sum(sa[0]);
+                sa[1] = wave_sum(sa[1]);
+                if (lane == 0) { slot[64] = sa[0]; slot[65] = sa[1]; }
+            }
+#else
 #pragma unroll
-        for (int j = 0; j < 8; ++j)
-            if (j < nj) s8[j] += at * fb(t, j);
+            for (int j = 0; j < 8; ++j) slot[j0 + j] = s[j];
+            if (sums != nullptr && j0 == 0) { slot[64] = sa[0]; slot[65] = sa[1]; }
+#endif
+            continue;
+        }
+        blk_sum_multi<8>(b, s);
+        if (b.tid == 0) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j)
+                if (j0 + j < nlags) store(j0 + j, s[j]);
+        }
+        if (sums != nullptr && j0 == 0) {
+            blk_sum_multi<2>(b, sa);
+            sums[0] = sa[0];
+            sums[1] = sa[1];
+        }
+    }
+    if (deferred) {
+        blk_sync();
+        for (int j = b.tid; j < nlags; j += b.nt) {
+            double v = part[j];
+            for (int w = 1; w < nwv; ++w) v += part[w * TSFA_AR_PART_STRIDE + j];
+            store(j, v);
+        }
+        if (sums != nullptr) {
+            double v0 = part[64], v1 = part[65];
+            for (int w = 1; w < nwv; ++w) { v0 += part[w * TSFA_AR_PART_STRIDE + 64]; v1 += part[w * TSFA_AR_PART_STRIDE + 65]; }
+            sums[0] = v0;
+            sums[1] = v1;
+        }
     }
 }
 
 // Lag-product matrix of sequence s over rows t in [t0, t1):  T[i + j*ld] = sum_t s(t-i) s(t-j), 0 <= j <= i <= Lg,
-// and column sums C[j] = sum_t s(t-j).  Requires t0 >= Lg.  S(u) returns s[u].
+// and column sums C[j] = sum_t s(t-j), from the first column T[0 .. Lg] and C[0] (blk_tile_lagdots; thread 0 wrote
+// them).  Requires t0 >= Lg.  S(u) returns s[u].
 template <class S>
-TSFA_DEV void blk_lag_products(const Blk &b, S s, int Lg, int t0, int t1, double *T, int ld, double *C) {
-    for (int j0 = 0; j0 <= Lg; j0 += 8) {  // first column by reduction, eight lags per sweep
-        double a8[8];
-        blk_dots8(b, t0, t1, Lg - j0 + 1, [=](int t) { return s(t); }, [=](int t, int j) { return s(t - j0 - j); }, a8);
-        blk_sum_multi<8>(b, a8);
-        if (b.tid == 0) {
-#pragma unroll
-            for (int j = 0; j < 8; ++j)
-                if (j0 + j <= Lg) T[j0 + j] = a8[j];
-        }
-    }
-    double c0 = 0.0;
-    for (int t = t0 + b.tid; t < t1; t += b.nt) c0 += s(t);
-    c0 = blk_sum(b, c0);
+TSFA_DEV void blk_lag_products_rest(const Blk &b, S s, int Lg, int t0, int t1, double *T, int ld, double *C) {
     if (b.tid == 0) {
-        C[0] = c0;
         for (int j = 0; j < Lg; ++j) C[j + 1] = C[j] + s(t0 - 1 - j) - s(t1 - 1 - j);
     }
     blk_sync();
@@ -261,9 +362,13 @@ TSFA_DEV int fam_ar_series(const Blk &b, X xv, int n, const TsfaSpec *specs, int
     // autocovariances are pure round-off of x - x.mean(), so the order decides what comes out
     const double mean = np_sum(b, n, [=](int i) { return xv(i); }) / dn;
     blk_sync();
-    ST *xs_lds = (ST *)xc_raw;
-    for (int i = b.tid; i < n; i += b.nt) xs_lds[i] = (ST)xv(i);
+    ST *xs_lds = (ST *)xc_raw + TSFA_AR_PADL;   // zero samples on either side: the blocks of the register tiles
+    for (int i = b.tid; i < n + TSFA_AR_PADL + TSFA_AR_PADR; i += b.nt) {
+        const int j = i - TSFA_AR_PADL;
+        ((ST *)xc_raw)[i] = (j >= 0 && j < n) ? (ST)xv(j) : (ST)0;
+    }
     const ArCentred<ST> xc{xs_lds, mean};
+    const ArBlocks<ST> blk{xs_lds, mean};
     blk_sync();
     double v0 = 0.0;
     for (int i = b.tid; i < n; i += b.nt) v0 += xc[i] * xc[i];
@@ -300,20 +405,16 @@ TSFA_DEV int fam_ar_series(const Blk &b, X xv, int n, const TsfaSpec *specs, int
     int nacv = -1;
     if (max_acf_lag >= 0) nacv = (max_acf_lag < n - 1) ? max_acf_lag : (n - 1);
     if (pacf_maxlag > nacv) nacv = pacf_maxlag;
-    for (int k0 = 0; k0 <= nacv; k0 += 8) {  // eight lags per sweep: x[t] is read once, the sums are reduced together
-        double s8[8];
-        blk_dots8(b, 0, n - k0, 8, [=](int t) { return xcc[t]; },
-                  [=](int t, int j) {
-                      const int i = t + k0 + j;
-                      const double v = xcc[(i < n) ? i : (n - 1)];
-                      return (i < n) ? v : 0.0;
-                  }, s8);
-        blk_sum_multi<8>(b, s8);
-        if (b.tid == 0) {
+    if (nacv >= 0) {
+        // sum_t y(t) y(t - k) over t in [0, n) with y = 0 before the series: the blocks below sample 0 read as zeros
+        blk_tile_lagdots(b, n, nacv + 1,
+                         [=](int tb, double (&A)[8]) { blk.y8(tb, A); tile_mask_rows(A, tb, 0, n); },
+                         [=](int i0, double (&B)[8]) {
+                             blk.y8(i0, B);
 #pragma unroll
-            for (int j = 0; j < 8; ++j)
-                if (k0 + j <= nacv) acv[k0 + j] = s8[j] / (double)(n - k0 - j);
-        }
+                             for (int q = 0; q < 8; ++q) B[q] = (i0 >= 0) ? B[q] : 0.0;
+                         },
+                         [=](int k, double v) { acv[k] = v / (double)(n - k); }, nullptr, G, P * P);
     }
     blk_sync();
 
@@ -352,27 +453,21 @@ TSFA_DEV int fam_ar_series(const Blk &b, X xv, int n, const TsfaSpec *specs, int
     if (need_adf) {
         const int maxlag = adf_maxlag_for(n);
         if (maxlag >= 0 && maxlag + 3 <= P) {
-            auto dif = [=](int t) { return xcc[t + 1] - xcc[t]; };
+            auto dif = [=](int t) { return (double)xs_lds[t + 1] - (double)xs_lds[t]; };
             const int t0 = maxlag, t1 = n - 1;
             const double nobs = (double)(t1 - t0);
-            // lag products of d (lag 0 = the target) and level products
-            blk_lag_products(b, dif, maxlag, t0, t1, T, P, C);
-            for (int j0 = 0; j0 <= maxlag; j0 += 8) {  // eight lags per sweep, reduced together
-                double a8[8];
-                blk_dots8(b, t0, t1, maxlag - j0 + 1, [=](int t) { return xcc[t]; },
-                          [=](int t, int j) { return dif(t - j0 - j); }, a8);
-                blk_sum_multi<8>(b, a8);
-                if (b.tid == 0) {
-#pragma unroll
-                    for (int j = 0; j < 8; ++j)
-                        if (j0 + j <= maxlag) V[j0 + j] = a8[j];
-                }
-            }
-            double sxs[2] = {0.0, 0.0};
-            for (int t = t0 + b.tid; t < t1; t += b.nt) { sxs[0] += xcc[t]; sxs[1] += xcc[t] * xcc[t]; }
-            blk_sum_multi<2>(b, sxs);
-            const double sx = sxs[0], sxx = sxs[1];
-            blk_sync();
+            // lag products of d (lag 0 = the target) and level products: first columns on register tiles
+            auto d_blocks = [=](int i0, double (&B)[8]) { blk.d8(i0, B); };
+            double sd[2], sl[2];
+            blk_tile_lagdots(b, n, maxlag + 1,
+                             [=](int tb, double (&A)[8]) { blk.d8(tb, A); tile_mask_rows(A, tb, t0, t1); }, d_blocks,
+                             [=](int j, double v) { T[j] = v; }, sd, G, P * P);
+            blk_tile_lagdots(b, n, maxlag + 1,
+                             [=](int tb, double (&A)[8]) { blk.y8(tb, A); tile_mask_rows(A, tb, t0, t1); }, d_blocks,
+                             [=](int j, double v) { V[j] = v; }, sl, G, P * P);
+            if (b.tid == 0) C[0] = sd[0];
+            blk_lag_products_rest(b, dif, maxlag, t0, t1, T, P, C);
+            const double sx = sl[0], sxx = sl[1];
             // assemble the normal matrix in the autolag column order [const, level, d-lag1 .. d-lag maxlag]
             const int p1 = maxlag + 2;
             for (int e = b.tid; e < 64 * p1; e += b.nt) {  // (a, c) = (e % 64, e / 64): p1 <= 63 for n <= 65535
@@ -633,7 +728,13 @@ TSFA_DEV int fam_ar_series(const Blk &b, X xv, int n, const TsfaSpec *specs, int
             if (ar_cached_k != k) {
                 // regressors: const, xc[t-1..t-k]; target xc[t]; rows t in [k, n)
                 auto sx = [=](int u) { return xcc[u]; };
-                blk_lag_products(b, sx, k, k, n, T, P, C);
+                auto y_blocks = [=](int i0, double (&B)[8]) { blk.y8(i0, B); };
+                double sy[2];
+                blk_tile_lagdots(b, n, k + 1,
+                                 [=](int tb, double (&A)[8]) { blk.y8(tb, A); tile_mask_rows(A, tb, k, n); }, y_blocks,
+                                 [=](int j, double v) { T[j] = v; }, sy, G, P * P);
+                if (b.tid == 0) C[0] = sy[0];
+                blk_lag_products_rest(b, sx, k, k, n, T, P, C);
                 const int p = k + 1;
                 for (int e = b.tid; e < p * p; e += b.nt) {
                     const int a = e % p, c = e / p;
@@ -654,29 +755,32 @@ TSFA_DEV int fam_ar_series(const Blk &b, X xv, int n, const TsfaSpec *specs, int
                 if (ar_ok) blk_chol_solve(b, G, p, P, g, beta);
                 blk_sync();
                 if (ar_ok) {
-                    auto reg = [=](int a, int t) { return a == 0 ? 1.0 : xcc[t - a]; };
-                    auto resid = [=](int t) {
-                        double r = xcc[t];
-                        for (int c = 0; c < p; ++c) r -= reg(c, t) * beta[c];
-                        return r;
-                    };
-                    for (int a0 = 0; a0 < p; a0 += 8) {  // X^T r, eight regressors per sweep
-                        double s8[8];
+                    // X^T r of the refinement step: r(t) = y(t) - beta_0 - sum_c beta_c y(t - c) on the tile, then the same
+                    // lagged sums with A = r  (lag 0 is the constant's entry: sum_t r(t))
+                    double sr[2];
+                    blk_tile_lagdots(b, n, k + 1,
+                                     [=](int tb, double (&A)[8]) {
+                                         blk.y8(tb, A);
+                                         const double b0 = beta[0];
 #pragma unroll
-                        for (int j = 0; j < 8; ++j) s8[j] = 0.0;
-                        for (int t = k + b.tid; t < n; t += b.nt) {
-                            const double rt = resid(t);
+                                         for (int u = 0; u < 8; ++u) A[u] -= b0;
+                                         double lo[8], hi[8], cf[8];
+                                         blk.y8(tb, hi);
+                                         for (int c0 = 0; c0 <= k; c0 += 8) {
+                                             blk.y8(tb - c0 - 8, lo);
 #pragma unroll
-                            for (int j = 0; j < 8; ++j)
-                                if (a0 + j < p) s8[j] += reg(a0 + j, t) * rt;
-                        }
-                        blk_sum_multi<8>(b, s8);
-                        if (b.tid == 0) {
+                                             for (int j = 0; j < 8; ++j) {
+                                                 const int c = c0 + j;
+                                                 cf[j] = (c >= 1 && c <= k) ? beta[(c <= k) ? c : 0] : 0.0;
+                                             }
+                                             tile_axpy8(cf, lo, hi, A);
 #pragma unroll
-                            for (int j = 0; j < 8; ++j)
-                                if (a0 + j < p) tmp1[a0 + j] = s8[j];
-                        }
-                    }
+                                             for (int q = 0; q < 8; ++q) hi[q] = lo[q];
+                                         }
+                                         tile_mask_rows(A, tb, k, n);
+                                     },
+                                     y_blocks, [=](int a, double v) { if (a > 0) tmp1[a] = v; }, sr, T, P * P);
+                    if (b.tid == 0) tmp1[0] = sr[0];
                     blk_sync();
                     blk_chol_solve(b, G, p, P, tmp1, tmp2);
                     blk_sync();

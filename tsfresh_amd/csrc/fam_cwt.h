@@ -59,71 +59,123 @@ struct CwtPeaksLds {
 #define TSFA_LI_ROW(v) (((v) >> 9) & 15)
 #define TSFA_LI_PACK(len, gap, dead, row) ((unsigned short)(((len) & 63) | (((gap) & 3) << 6) | (((dead) & 1) << 8) | (((row) & 15) << 9)))
 
-// value of rank i0 and i0 + 1 (0-based, ascending) among v(0..m-1); i0 + 1 < 8: running list of the 8 smallest
-template <class V>
-TSFA_DEV void smallest8_select(V v, int m, int i0, double *s0, double *s1) {
-    double t0 = TSFA_INF, t1 = TSFA_INF, t2 = TSFA_INF, t3 = TSFA_INF, t4 = TSFA_INF, t5 = TSFA_INF, t6 = TSFA_INF,
-           t7 = TSFA_INF;
-    for (int a = 0; a < m; ++a) {
-        double e = v(a);
-        if (!(e < t7)) continue;
-        double u;
-#define TSFA_CSWAP(t) u = fmin(t, e); e = fmax(t, e); t = u;
-        TSFA_CSWAP(t0) TSFA_CSWAP(t1) TSFA_CSWAP(t2) TSFA_CSWAP(t3) TSFA_CSWAP(t4) TSFA_CSWAP(t5) TSFA_CSWAP(t6) TSFA_CSWAP(t7)
-#undef TSFA_CSWAP
-    }
-    const double arr[8] = {t0, t1, t2, t3, t4, t5, t6, t7};
-    double a0 = t0, a1 = t1;
+// ascending sort of eight values: the 19-comparator network
+TSFA_DEV void sort8_f64(double (&v)[8]) {
+    ce_f64(v[0], v[1]); ce_f64(v[2], v[3]); ce_f64(v[4], v[5]); ce_f64(v[6], v[7]);
+    ce_f64(v[0], v[2]); ce_f64(v[1], v[3]); ce_f64(v[4], v[6]); ce_f64(v[5], v[7]);
+    ce_f64(v[1], v[2]); ce_f64(v[5], v[6]); ce_f64(v[0], v[4]); ce_f64(v[3], v[7]);
+    ce_f64(v[1], v[5]); ce_f64(v[2], v[6]);
+    ce_f64(v[1], v[4]); ce_f64(v[3], v[6]);
+    ce_f64(v[2], v[4]); ce_f64(v[3], v[5]);
+    ce_f64(v[3], v[4]);
+}
+// r <- the eight smallest of r and g, ascending (both ascending on entry): min(r[i], g[7 - i]) is a bitonic sequence
+// holding exactly those eight; three half-cleaner stages sort it
+TSFA_DEV void merge_low8_f64(double (&r)[8], const double (&g)[8]) {
 #pragma unroll
-    for (int k = 0; k < 7; ++k)
-        if (k == i0) { a0 = arr[k]; a1 = arr[k + 1]; }
+    for (int i = 0; i < 8; ++i) r[i] = min_f64(r[i], g[7 - i]);
+    ce_f64(r[0], r[4]); ce_f64(r[1], r[5]); ce_f64(r[2], r[6]); ce_f64(r[3], r[7]);
+    ce_f64(r[0], r[2]); ce_f64(r[1], r[3]); ce_f64(r[4], r[6]); ce_f64(r[5], r[7]);
+    ce_f64(r[0], r[1]); ce_f64(r[2], r[3]); ce_f64(r[4], r[5]); ce_f64(r[6], r[7]);
+}
+
+// value of rank i0 and i0 + 1 (0-based, ascending) among r0[0 .. m-1], i0 + 1 < 8 (nmax: readable elements of r0).
+// The window is taken in groups of eight (the last one padded with +inf), each sorted by the network and merged into
+// the running eight smallest: 70 minimum / maximum instructions per group, against ~25 per ELEMENT for an insertion
+// list -- this selection (one per ridge-line end point) is the largest part of the kernel after the convolutions.
+TSFA_DEV void lowest8_select(const double *r0, int m, int nmax, int i0, double *s0, double *s1) {
+    double r[8], g[8];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+        const double e = r0[(q < nmax) ? q : (nmax - 1)];
+        r[q] = (q < m) ? e : TSFA_INF;
+    }
+    sort8_f64(r);
+    for (int a = 8; a < m; a += 8) {
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            const double e = r0[(a + q < nmax) ? a + q : (nmax - 1)];
+            g[q] = (a + q < m) ? e : TSFA_INF;
+        }
+        sort8_f64(g);
+        merge_low8_f64(r, g);
+    }
+    double a0 = r[0], a1 = r[1];
+#pragma unroll
+    for (int k = 1; k < 7; ++k)
+        if (k == i0) { a0 = r[k]; a1 = r[k + 1]; }
     *s0 = a0;
     *s1 = a1;
 }
 
+// Four consecutive outputs of one width's convolution in registers: out[c0 + j] = sum_t hh[t] x[u0 + j + t], t ascending
+// (the accumulation order of conv_same_at: ascending sample).  The seven-sample window slides by four taps per trip, so a
+// trip is 16 fused multiply-adds, four conversions and three register moves -- the kernel is VALU-issue bound and the
+// multiply-adds are the only instructions that have to be there.
+template <class XA>
+TSFA_DEV void cwt_tile4(XA xat, const double *hh, int nw, int u0, double &r0, double &r1, double &r2, double &r3) {
+    double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
+    double x0 = xat(u0), x1 = xat(u0 + 1), x2 = xat(u0 + 2);
+    int t = 0;
+    for (; t + 4 <= nw; t += 4) {
+        const double h0 = hh[t], h1 = hh[t + 1], h2 = hh[t + 2], h3 = hh[t + 3];
+        const double x3 = xat(u0 + t + 3), x4 = xat(u0 + t + 4), x5 = xat(u0 + t + 5), x6 = xat(u0 + t + 6);
+        // explicit fused multiply-adds: the fused form is the more accurate one, and the reference's own convolution
+        // (np.convolve) leaves the contraction to the CPU's BLAS-style inner loop anyway
+        a0 = fma(x0, h0, a0); a1 = fma(x1, h0, a1); a2 = fma(x2, h0, a2); a3 = fma(x3, h0, a3);
+        a0 = fma(x1, h1, a0); a1 = fma(x2, h1, a1); a2 = fma(x3, h1, a2); a3 = fma(x4, h1, a3);
+        a0 = fma(x2, h2, a0); a1 = fma(x3, h2, a1); a2 = fma(x4, h2, a2); a3 = fma(x5, h2, a3);
+        a0 = fma(x3, h3, a0); a1 = fma(x4, h3, a1); a2 = fma(x5, h3, a2); a3 = fma(x6, h3, a3);
+        x0 = x4; x1 = x5; x2 = x6;
+    }
+    for (; t < nw; ++t) {
+        const double h = hh[t];
+        const double x3 = xat(u0 + t + 3);
+        a0 = fma(x0, h, a0); a1 = fma(x1, h, a1); a2 = fma(x2, h, a2); a3 = fma(x3, h, a3);
+        x0 = x1; x1 = x2; x2 = x3;
+    }
+    r0 = a0; r1 = a1; r2 = a2; r3 = a3;
+}
+
 // CWT rows for widths 1..W by direct convolution with the Ricker taps, relative-maximum bit mask, row 0 kept.
 // xat(i) = sample i, 0 outside [0, n): every output runs the full tap range without bounds (the padded products are
-// exact zeros).  A thread owns four consecutive columns plus one neighbour on either side: the six running sums share
-// each sample it reads (a sliding window in registers), and the relative-maximum test needs no stored row.  Same
-// accumulation order as conv_same_at (ascending sample).
+// exact zeros).  A thread owns four consecutive columns (cwt_tile4); the relative-maximum test of its first and last
+// column needs the neighbouring threads' outer values, which travel through `edge` (two values per four columns,
+// L.lcol / L.linf are idle until phase B): the bit is set on the thread's own evidence and withdrawn after the barrier if
+// the neighbour is not smaller.  No output is computed twice and no CWT row is stored.
 template <class XA>
 TSFA_DEV void cwt_rows_tiled(const Blk &b, XA xat, int n, int W, const CwtPeaksLds &L) {
+    double *edge = (double *)L.lcol;   // edge[2 g] / edge[2 g + 1]: first / last output of columns 4 g .. 4 g + 3
     for (int w = 1; w <= W; ++w) {
         const int nw = (10 * w < n) ? 10 * w : n;
+        for (int k = b.tid; k < nw; k += b.nt) L.taps[k] = ricker_tap(nw, (double)w, k);  // tap of sample offset k
         blk_sync();
-        for (int k = b.tid; k < nw; k += b.nt) L.taps[k] = ricker_tap(nw, (double)w, nw - 1 - k);  // reversed
-        blk_sync();
-        const double *h = L.taps;
-        const int half = (nw - 1) / 2;
+        const int lead = (nw - 1) - (nw - 1) / 2;  // out[c] = sum_t taps[t] x[c - lead + t]
+        const unsigned short bit = (unsigned short)(1u << (w - 1));
         for (int c0 = 4 * b.tid; c0 < n; c0 += 4 * b.nt) {
-            // outputs c0-1 .. c0+4;  out[c] = sum_k h[k] x[c + half - k]: with u = c0 - 1 + half - k (sample of the
-            // first output), output j reads sample u + j.  k runs nw-1 .. 0, i.e. u ascends.
-            double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0, a4 = 0.0, a5 = 0.0;
-            const int u0 = c0 - 1 + half - (nw - 1);
-            double x0 = xat(u0), x1 = xat(u0 + 1), x2 = xat(u0 + 2), x3 = xat(u0 + 3), x4 = xat(u0 + 4);
-            for (int t = 0; t < nw; ++t) {  // k = nw - 1 - t
-                const double hk = h[nw - 1 - t];
-                const double x5 = xat(u0 + t + 5);
-                // explicit fused multiply-adds: the kernel is VALU-issue bound (95 % busy) and these are 90 % of its
-                // arithmetic; the fused form is the more accurate one, and the reference's own convolution
-                // (np.convolve) leaves the contraction to the CPU's BLAS-style inner loop anyway
-                a0 = fma(x0, hk, a0); a1 = fma(x1, hk, a1); a2 = fma(x2, hk, a2);
-                a3 = fma(x3, hk, a3); a4 = fma(x4, hk, a4); a5 = fma(x5, hk, a5);
-                x0 = x1; x1 = x2; x2 = x3; x3 = x4; x4 = x5;
-            }
+            double a0, a1, a2, a3;
+            cwt_tile4(xat, L.taps, nw, c0 - lead, a0, a1, a2, a3);
+            edge[c0 >> 1] = a0;
+            edge[(c0 >> 1) + 1] = a3;
             // _boolrelextrema(order=1, mode="clip"): strict, never at the ends
-            const unsigned short bit = (unsigned short)(1u << (w - 1));
-            if (c0 >= 1 && c0 < n - 1 && a1 > a0 && a1 > a2) L.mask[c0] |= bit;
-            if (c0 + 1 < n - 1 && a2 > a1 && a2 > a3) L.mask[c0 + 1] |= bit;
-            if (c0 + 2 < n - 1 && a3 > a2 && a3 > a4) L.mask[c0 + 2] |= bit;
-            if (c0 + 3 < n - 1 && a4 > a3 && a4 > a5) L.mask[c0 + 3] |= bit;
+            if (c0 >= 1 && c0 < n - 1 && a0 > a1) L.mask[c0] |= bit;                 // pending: the left neighbour
+            if (c0 + 1 < n - 1 && a1 > a0 && a1 > a2) L.mask[c0 + 1] |= bit;
+            if (c0 + 2 < n - 1 && a2 > a1 && a2 > a3) L.mask[c0 + 2] |= bit;
+            if (c0 + 3 < n - 1 && a3 > a2) L.mask[c0 + 3] |= bit;                    // pending: the right neighbour
             if (w == 1) {
-                L.row0[c0] = a1;
-                if (c0 + 1 < n) L.row0[c0 + 1] = a2;
-                if (c0 + 2 < n) L.row0[c0 + 2] = a3;
-                if (c0 + 3 < n) L.row0[c0 + 3] = a4;
+                L.row0[c0] = a0;
+                if (c0 + 1 < n) L.row0[c0 + 1] = a1;
+                if (c0 + 2 < n) L.row0[c0 + 2] = a2;
+                if (c0 + 3 < n) L.row0[c0 + 3] = a3;
             }
         }
+        blk_sync();
+        for (int c0 = 4 * b.tid; c0 < n; c0 += 4 * b.nt) {
+            const int g2 = c0 >> 1;
+            if (c0 >= 1 && c0 < n - 1 && !(edge[g2] > edge[g2 - 1])) L.mask[c0] &= (unsigned short)~bit;
+            if (c0 + 3 < n - 1 && !(edge[g2 + 1] > edge[g2 + 2])) L.mask[c0 + 3] &= (unsigned short)~bit;
+        }
+        blk_sync();  // the next width's taps and edges
     }
 }
 
@@ -188,7 +240,7 @@ TSFA_DEV double cwt_filter_list(const Blk &b, X xv, int n, const CwtPeaksLds &L,
         } else if (live) {
             const double *r0 = L.row0 + ws;
             if (i0 + 1 < 8) {
-                smallest8_select([=](int a) { return r0[a]; }, m, i0, &s0, &s1);
+                lowest8_select(r0, m, n - ws, i0, &s0, &s1);
             } else {
                 for (int a = 0; a < m; ++a) {
                     const double ea = r0[a];
@@ -267,27 +319,35 @@ TSFA_DEV double number_cwt_peaks_one(const Blk &b, X xv, int n, int W, const Cwt
     blk_sync();
     TSFA_TICK(tk, b, 151);
     // ---- phase B ----
+    // A thread owns CT consecutive columns: the maxima of a row that start new lines get their indices from ONE
+    // workgroup scan of per-thread counts (ascending column order = the reference's order of creation).
+    const int CT = (n + b.nt - 1) / b.nt;
+    int ctbits = 1;
+    while ((1 << ctbits) <= CT) ++ctbits;
+    const int cbeg = CT * b.tid, cend = (cbeg + CT < n) ? cbeg + CT : n;
+    unsigned anyrow = 0;
+    for (int c = cbeg; c < cend; ++c) anyrow |= L.mask[c];
+    anyrow = blk_or16(b, anyrow) & ((1u << W) - 1u);
     int start_row = -1;
-    for (int r = 0; r < W; ++r) {
-        double cnt = 0.0;
-        for (int c = b.tid; c < n; c += b.nt) cnt += (L.mask[c] >> r) & 1;
-        if (blk_sum(b, cnt) > 0.0) start_row = r;
-    }
+    for (int r = 0; r < W; ++r)
+        if ((anyrow >> r) & 1u) start_row = r;
     int nlines = 0, overflow = 0;
     if (start_row >= 0) {
         const unsigned sbit = 1u << start_row;
-        for (int c0 = 0; c0 < n; c0 += b.nt) {  // initial lines, ascending column order
-            const int c = c0 + b.tid;
-            const bool f = (c < n) && (L.mask[c] & sbit);
+        {   // initial lines, ascending column order
+            int mine = 0;
+            for (int c = cbeg; c < cend; ++c) mine += (L.mask[c] & sbit) ? 1 : 0;
             int tot;
-            const int idx = nlines + blk_excl_count(b, f, &tot);
-            if (f) {
+            int idx = blk_excl_sum_small(b, mine, ctbits, &tot);
+            for (int c = cbeg; c < cend; ++c) {
+                if (!(L.mask[c] & sbit)) continue;
                 if (idx < cap) {
                     L.lcol[idx] = (unsigned short)c;
                     L.linf[idx] = TSFA_LI_PACK(1, 0, 0, start_row);
                 }
+                ++idx;
             }
-            nlines += tot;
+            nlines = tot;
         }
         if (nlines > cap) { overflow = 1; nlines = cap; }
         const int gap_thresh = 1;  // ceil(widths[0])
@@ -301,31 +361,33 @@ TSFA_DEV double number_cwt_peaks_one(const Blk &b, X xv, int n, int W, const Cwt
                 if (!TSFA_LI_DEAD(L.linf[l])) L.colmap[L.lcol[l]] = (unsigned short)(l + 1);
             blk_sync();
             // every maximum of this row picks the nearest live line (earliest line wins a distance tie)
-            for (int c0 = 0; c0 < n; c0 += b.nt) {
-                const int c = c0 + b.tid;
-                const bool is_max = (c < n) && (L.mask[c] & bit);
+            int fresh = 0;
+            for (int c = cbeg; c < cend; ++c) {
+                if (!(L.mask[c] & bit)) continue;
                 int line = 0;
-                if (is_max) {
-                    for (int d = 0; d <= D && line == 0; ++d) {
-                        int best = 0;
-                        if (c - d >= 0 && L.colmap[c - d]) best = L.colmap[c - d];
-                        if (d > 0 && c + d < n && L.colmap[c + d]) {
-                            const int o = L.colmap[c + d];
-                            if (best == 0 || o < best) best = o;
-                        }
-                        line = best;
+                for (int d = 0; d <= D && line == 0; ++d) {
+                    int best = 0;
+                    if (c - d >= 0 && L.colmap[c - d]) best = L.colmap[c - d];
+                    if (d > 0 && c + d < n && L.colmap[c + d]) {
+                        const int o = L.colmap[c + d];
+                        if (best == 0 || o < best) best = o;
                     }
-                    L.mline[c] = (unsigned short)line;
+                    line = best;
                 }
-                const bool fresh = is_max && line == 0;
-                int tot;
-                const int idx = nlines + blk_excl_count(b, fresh, &tot);
-                if (fresh && idx < cap) {
+                L.mline[c] = (unsigned short)line;
+                fresh += (line == 0) ? 1 : 0;
+            }
+            int tot;
+            int idx = nlines + blk_excl_sum_small(b, fresh, ctbits, &tot);
+            for (int c = cbeg; c < cend; ++c) {
+                if (!(L.mask[c] & bit) || L.mline[c] != 0) continue;
+                if (idx < cap) {
                     L.lcol[idx] = (unsigned short)c;
                     L.linf[idx] = TSFA_LI_PACK(1, 0, 0, row);
                 }
-                nlines += tot;
+                ++idx;
             }
+            nlines += tot;
             if (nlines > cap) { overflow = 1; nlines = cap; }
             blk_sync();
             // every previously live line collects the maxima that chose it (ascending: the last one is its new column)
@@ -390,36 +452,73 @@ TSFA_DEV double number_cwt_peaks_one(const Blk &b, X xv, int n, int W, const Cwt
     const unsigned short bit_a = (unsigned short)(1u << (W + 1));
     int cnt_a = 0;
     blk_sync();
-    for (int base = 0; base < nlines; base += b.nt) {
-        const int l = base + b.tid;
-        const unsigned short v = (l < nlines) ? L.linf[l] : 0;
-        const bool qual = (l < nlines) && (TSFA_LI_LEN(v) >= min_length);
-        const int col = (l < nlines) ? (int)L.lcol[l] : 0, row = TSFA_LI_ROW(v);
-        const bool defer = derive_w1 && qual && row == 0;
-        if (defer) L.mask[col] |= bit_a;
-        const bool take = qual && !defer;
-        int tot;
-        const int idx = cnt_a + blk_excl_count(b, take, &tot);
-        if (take) {
-            L.lcol[idx] = (unsigned short)col;
-            L.linf[idx] = (unsigned short)row;
+    {   // a thread owns LT consecutive lines; the marks first
+        const int LT = (nlines + b.nt - 1) / b.nt;
+        int ltbits = 1;
+        while ((1 << ltbits) <= LT) ++ltbits;
+        const int lbeg = LT * b.tid, lend = (lbeg + LT < nlines) ? lbeg + LT : nlines;
+        int mine = 0;
+        for (int l = lbeg; l < lend; ++l) {
+            const unsigned short v = L.linf[l];
+            const bool qual = TSFA_LI_LEN(v) >= min_length;
+            const bool defer = derive_w1 && qual && TSFA_LI_ROW(v) == 0;
+            if (defer) L.mask[L.lcol[l]] |= bit_a;
+            mine += (qual && !defer) ? 1 : 0;
         }
-        cnt_a += tot;
+        if (!long_windows) {
+            // one scan; the entries are staged in (mline, colmap) -- dead by now -- because entry k may land on a line
+            // another thread has not read yet, then copied to the front of (lcol, linf)
+            int idx = blk_excl_sum_small(b, mine, ltbits, &cnt_a);
+            for (int l = lbeg; l < lend; ++l) {
+                const unsigned short v = L.linf[l];
+                const int row = TSFA_LI_ROW(v);
+                if (TSFA_LI_LEN(v) < min_length || (derive_w1 && row == 0)) continue;
+                L.mline[idx] = L.lcol[l];
+                L.colmap[idx] = (unsigned short)row;
+                ++idx;
+            }
+            blk_sync();
+            for (int k = b.tid; k < cnt_a; k += b.nt) {
+                L.lcol[k] = L.mline[k];
+                L.linf[k] = L.colmap[k];
+            }
+        } else {
+            // (mline, colmap) hold the argsort: compaction in place, a chunk of nt lines at a time
+            for (int base = 0; base < nlines; base += b.nt) {
+                const int l = base + b.tid;
+                const unsigned short v = (l < nlines) ? L.linf[l] : 0;
+                const int col = (l < nlines) ? (int)L.lcol[l] : 0, row = TSFA_LI_ROW(v);
+                const bool take = (l < nlines) && (TSFA_LI_LEN(v) >= min_length) && !(derive_w1 && row == 0);
+                int tot;
+                const int k = cnt_a + blk_excl_count(b, take, &tot);
+                if (take) {
+                    L.lcol[k] = (unsigned short)col;
+                    L.linf[k] = (unsigned short)row;
+                }
+                cnt_a += tot;
+                blk_sync();
+            }
+        }
         blk_sync();
     }
     double unused = 0.0;
-    double kept = cwt_filter_list(b, xv, n, L, L.lcol, L.linf, cnt_a, hf, odd, taps_cached, order, 0, &unused);
+    double kept;
+    const ST *xp0 = (L.xpad != nullptr) ? (const ST *)L.xpad + TSFA_CWTP_HALO : nullptr;
+    // the re-evaluated signal reads the staged copy of the series (LDS) where there is one
+    if (xp0 != nullptr)
+        kept = cwt_filter_list(b, [=](int i) { return (double)xp0[i]; }, n, L, L.lcol, L.linf, cnt_a, hf, odd, taps_cached, order, 0, &unused);
+    else
+        kept = cwt_filter_list(b, xv, n, L, L.lcol, L.linf, cnt_a, hf, odd, taps_cached, order, 0, &unused);
     TSFA_TICK(tk, b, 153);
     if (derive_w1) {
         int cnt_b = 0;
         blk_sync();
-        for (int base = 0; base < n; base += b.nt) {
-            const int c = base + b.tid;
-            const bool take = (c < n) && (L.mask[c < n ? c : 0] & 1u);
-            int tot;
-            const int idx = cnt_b + blk_excl_count(b, take, &tot);
-            if (take) L.lcol[idx] = (unsigned short)c;
-            cnt_b += tot;
+        {
+            int mine = 0;
+            for (int c = cbeg; c < cend; ++c) mine += (L.mask[c] & 1u) ? 1 : 0;
+            int idx = blk_excl_sum_small(b, mine, ctbits, &cnt_b);
+            for (int c = cbeg; c < cend; ++c)
+                if (L.mask[c] & 1u) L.lcol[idx++] = (unsigned short)c;
             blk_sync();
         }
         double marked = 0.0;

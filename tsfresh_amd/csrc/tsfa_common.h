@@ -372,6 +372,84 @@ TSFA_DEV int blk_excl_count(const Blk &b, bool flag, int *total) {
 #endif
 }
 
+// Exclusive prefix of a small per-thread count (0 <= cnt < 2^bits) over the lower-numbered threads, and the workgroup
+// total: a thread that owns several consecutive items hands out indices for all of them with ONE scan.
+TSFA_DEV int blk_excl_sum_small(const Blk &b, int cnt, int bits, int *total) {
+#if TSFA_GPU
+    const int lane = b.tid & 63;
+    const unsigned long long below = (1ull << lane) - 1ull;
+    int pre = 0, tot = 0;
+    for (int k = 0; k < bits; ++k) {
+        const unsigned long long m = __ballot((cnt >> k) & 1);
+        pre += __popcll(m & below) << k;
+        tot += __popcll(m) << k;
+    }
+    if (b.nt > 64) {
+        const int nw = b.nt >> 6, w = b.tid >> 6;
+        int *ir = (int *)(b.red + 32);
+        blk_sync();
+        if (lane == 0) ir[w] = tot;
+        blk_sync();
+        int base = 0, all = 0;
+        for (int k = 0; k < nw; ++k) {
+            if (k < w) base += ir[k];
+            all += ir[k];
+        }
+        pre += base;
+        tot = all;
+    }
+    *total = tot;
+    return pre;
+#else
+    *total = cnt;
+    return 0;
+#endif
+}
+
+// bitwise OR of a 16-bit value over the workgroup (every thread receives it)
+TSFA_DEV unsigned blk_or16(const Blk &b, unsigned v) {
+#if TSFA_GPU
+    unsigned r = 0;
+    for (int k = 0; k < 16; ++k) r |= (__ballot((v >> k) & 1u) != 0ull) ? (1u << k) : 0u;
+    if (b.nt > 64) {
+        const int nw = b.nt >> 6;
+        int *ir = (int *)(b.red + 32);
+        blk_sync();
+        if ((b.tid & 63) == 0) ir[b.tid >> 6] = (int)r;
+        blk_sync();
+        r = 0;
+        for (int k = 0; k < nw; ++k) r |= (unsigned)ir[k];
+    }
+    return r;
+#else
+    return v;
+#endif
+}
+
+// compare-exchange: a <- min, b <- max.  The hardware minimum / maximum directly: the compiler's fmin / fmax spend a
+// third instruction per pair on canonicalising an operand
+TSFA_DEV void ce_f64(double &a, double &b2) {
+#if TSFA_GPU
+    double lo, hi;
+    asm("v_min_f64 %0, %2, %3\n\tv_max_f64 %1, %2, %3" : "=&v"(lo), "=&v"(hi) : "v"(a), "v"(b2));
+    a = lo;
+    b2 = hi;
+#else
+    const double lo = fmin(a, b2), hi = fmax(a, b2);
+    a = lo;
+    b2 = hi;
+#endif
+}
+TSFA_DEV double min_f64(double a, double b2) {
+#if TSFA_GPU
+    double lo;
+    asm("v_min_f64 %0, %1, %2" : "=v"(lo) : "v"(a), "v"(b2));
+    return lo;
+#else
+    return fmin(a, b2);
+#endif
+}
+
 // broadcast a value computed by thread 0 to the whole workgroup
 TSFA_DEV double blk_bcast0(const Blk &b, double v) {
 #if TSFA_GPU

@@ -347,7 +347,7 @@ __global__ void __launch_bounds__(256) k_seq(const T *__restrict__ values, const
 
 // MAXT: 256 for series up to 2048 samples (register allocation for 4-wave workgroups), 1024 beyond
 template <typename T, int MAXT>
-__global__ void __launch_bounds__(MAXT) k_cwtpeaks(const T *__restrict__ values, const int64_t *__restrict__ starts, const int64_t *__restrict__ ends, int64_t n_series, const int *__restrict__ sel,
+__global__ void __launch_bounds__(MAXT, (MAXT == 256) ? 6 : 4) k_cwtpeaks(const T *__restrict__ values, const int64_t *__restrict__ starts, const int64_t *__restrict__ ends, int64_t n_series, const int *__restrict__ sel,
                            const TsfaSpec *__restrict__ specs, int nspecs, double *__restrict__ out, int64_t ld,
                            int maxn, int with_rowv TSFA_GS_PARAMS) {
     TSFA_SERIES_BEGIN

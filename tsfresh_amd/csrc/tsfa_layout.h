@@ -122,7 +122,7 @@ struct ArLds {
     TSFA_HD size_t carve(unsigned char *base, int maxn, int P, int xs_bytes = 8) {
         LdsCarve c{base, 0};
         red = c.take<double>(TSFA_RED_DOUBLES);
-        xc = (double *)(void *)c.take<unsigned char>((size_t)(maxn + 2) * xs_bytes);
+        xc = (double *)(void *)c.take<unsigned char>((size_t)(maxn + 64 + 16) * xs_bytes);  // TSFA_AR_PADL + n + TSFA_AR_PADR (fam_ar.h)
         // the numpy-order scratch is only used for x.mean(), before the matrices exist: it shares their storage
         const size_t ab = (size_t)scratch_doubles(P) * sizeof(double);
         unsigned char *u = c.take<unsigned char>(ab > sizeof(NpScratch) ? ab : sizeof(NpScratch));
@@ -206,8 +206,8 @@ struct CwtPeaksLayout {
         p.xpad = mode ? (void *)c.take<unsigned char>((size_t)(maxn + 2 * TSFA_CWTP_HALO + 8) * xs_bytes) : nullptr;
         p.taps = c.take<double>(TSFA_CWTP_MAXTAPS + 16);
         p.mask = c.take<unsigned short>(maxn);
-        p.lcol = c.take<unsigned short>(maxn);
-        p.linf = c.take<unsigned short>(maxn);
+        p.lcol = c.take<unsigned short>(2 * (size_t)maxn + 8);  // lcol | linf, contiguous: phase A's edge values (16 B per 4 columns)
+        p.linf = p.lcol + maxn;
         p.colmap = c.take<unsigned short>(2 * (size_t)maxn);  // colmap | mline, contiguous: phase C argsorts into both
         p.mline = p.colmap + maxn;
         p.misc = c.take<int>(8);
