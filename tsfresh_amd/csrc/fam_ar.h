@@ -41,12 +41,12 @@ TSFA_DEV void chol_solve(const double *L, int p, int ld, const double *rhs, doub
     for (int i = 0; i < p; ++i) {
         double s = rhs[i];
         for (int k = 0; k < i; ++k) s -= L[i + k * ld] * x[k];
-        x[i] = s / L[i + i * ld];
+        x[i] = s * (1.0 / L[i + i * ld]);   // reciprocal pivots, as in blk_chol_solve: one division per pivot, not per use
     }
     for (int i = p - 1; i >= 0; --i) {
         double s = x[i];
         for (int k = i + 1; k < p; ++k) s -= L[k + i * ld] * x[k];
-        x[i] = s / L[i + i * ld];
+        x[i] = s * (1.0 / L[i + i * ld]);
     }
 }
 
@@ -59,14 +59,15 @@ TSFA_DEV void blk_chol_solve(const Blk &b, const double *L, int p, int ld, const
     const int lane = b.tid & 63;
     const bool live = lane < p;
     double s = live ? rhs[lane] : 0.0;
-    const double dg = live ? L[lane + lane * ld] : 1.0;
+    // a float64 division is ~30 instructions and the family is issue bound: one reciprocal per pivot (lane), then products
+    const double dg = live ? 1.0 / L[lane + lane * ld] : 1.0;
     for (int k = 0; k < p; ++k) {  // forward: L w = rhs
-        const double wk = readlane_f64(s, k) / readlane_f64(dg, k);
+        const double wk = readlane_f64(s, k) * readlane_f64(dg, k);
         if (lane == k) s = wk;
         else if (live && lane > k) s -= L[lane + k * ld] * wk;
     }
     for (int k = p - 1; k >= 0; --k) {  // backward: L^T x = w
-        const double xk = readlane_f64(s, k) / readlane_f64(dg, k);
+        const double xk = readlane_f64(s, k) * readlane_f64(dg, k);
         if (lane == k) s = xk;
         else if (live && lane < k) s -= L[k + lane * ld] * xk;
     }
@@ -97,7 +98,8 @@ TSFA_DEV bool blk_chol_factor(const Blk &b, double *G, int p, int ld, double *di
         if (dmin) *dmin = dm;   // uniform: the smallest pivot so far
         const double sd = sqrt(d);
         blk_sync();
-        for (int i = j + b.tid; i < p; i += b.nt) G[i + j * ld] = (i == j) ? sd : G[i + j * ld] / sd;
+        const double rsd = 1.0 / sd;
+        for (int i = j + b.tid; i < p; i += b.nt) G[i + j * ld] = (i == j) ? sd : G[i + j * ld] * rsd;
         blk_sync();
         // trailing update, (row, column) = (tid % 32, tid / 32) strides: shifts instead of an integer division and a
         // modulo per element (the family is VALU-issue bound, and those two cost ~80 instructions)
@@ -112,16 +114,101 @@ TSFA_DEV bool blk_chol_factor(const Blk &b, double *G, int p, int ld, double *di
     return true;
 }
 // w = L^-1 rhs by column-oriented forward substitution (same subtraction order as the serial row loop).
-// `w` is overwritten in place: pass a copy of rhs.
+// `w` is overwritten in place: pass a copy of rhs.  GPU (p <= 64): lane i of every wavefront holds w_i, w_j travels by
+// readlane -- p dependent steps without a barrier (every wavefront computes the same values, thread i < p stores).
 TSFA_DEV void blk_chol_forward(const Blk &b, const double *L, int p, int ld, double *w) {
+#if TSFA_GPU
+    if (p <= 64) {
+        const int lane = b.tid & 63;
+        const bool live = lane < p;
+        double s = live ? w[lane] : 0.0;
+        const double dg = live ? 1.0 / L[lane + lane * ld] : 1.0;
+        for (int k = 0; k < p; ++k) {
+            const double wk = readlane_f64(s, k) * readlane_f64(dg, k);
+            if (lane == k) s = wk;
+            else if (live && lane > k) s = s - L[lane + k * ld] * wk;
+        }
+        blk_sync();
+        if (b.tid < p) w[b.tid] = s;
+        blk_sync();
+        return;
+    }
+#endif
     for (int i = 0; i < p; ++i) {
         blk_sync();
-        const double wi = w[i] / L[i + i * ld];
+        const double wi = w[i] * (1.0 / L[i + i * ld]);
         blk_sync();
         if (b.tid == 0) w[i] = wi;
         for (int k = i + 1 + b.tid; k < p; k += b.nt) w[k] = w[k] - L[k + i * ld] * wi;
     }
     blk_sync();
+}
+
+#if TSFA_GPU
+// The factorization of blk_chol_factor by ONE wavefront with the matrix in registers: lane i holds row i of the lower
+// triangle, column j of the factor travels by readlane.  No barrier, no LDS round trip inside the p dependent steps;
+// every entry receives the same subtractions in the same order (j ascending), so the factor is bit-identical.
+// Returns false at the first pivot below TSFA_AR_PIVOT_TOL of its original diagonal (uniform over the wavefront).
+template <int PM>
+__device__ __attribute__((noinline)) bool wave_chol_regs(double *G, int p, int ld, double *diag0, double *dmin) {
+    const int lane = (int)(threadIdx.x & 63);
+    double a[PM];
+#pragma unroll
+    for (int k = 0; k < PM; ++k) a[k] = (k < p && lane < p && k <= lane) ? G[lane + k * ld] : 0.0;
+    const double dg0 = (lane < p) ? G[lane + lane * ld] : 1.0;
+    if (lane < p) diag0[lane] = dg0;
+    double dm = TSFA_INF;
+    bool ok = true;
+#pragma unroll
+    for (int j = 0; j < PM; ++j) {
+        if (j < p && ok) {
+            const double d = readlane_f64(a[j], j);
+            if (!(d > TSFA_AR_PIVOT_TOL * readlane_f64(dg0, j))) {
+                ok = false;
+            } else {
+                dm = fmin(dm, d);
+                const double sd = sqrt(d), rsd = 1.0 / sd;
+                a[j] = (lane == j) ? sd : a[j] * rsd;
+#pragma unroll
+                for (int k = j + 1; k < PM; ++k) {
+                    if (k < p) a[k] = a[k] - a[j] * readlane_f64(a[j], k);
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < PM; ++k)
+        if (k < p && lane < p && k <= lane) G[lane + k * ld] = a[k];
+    *dmin = dm;
+    return ok;
+}
+#endif
+
+// blk_chol_factor, the register form where the matrix fits (p <= 32: every ADF design up to ~3400 samples, every AR
+// order of the library's parameter sets): wavefront 0 factors, the others wait at the barrier.
+#ifndef TSFA_AR_CHOL_REGS
+#define TSFA_AR_CHOL_REGS 1
+#endif
+TSFA_DEV bool blk_chol_factor_fast(const Blk &b, double *G, int p, int ld, double *diag0, double *dmin = nullptr) {
+#if TSFA_GPU && TSFA_AR_CHOL_REGS
+    if (p <= 32) {
+        blk_sync();
+        if (b.tid < 64) {
+            double dm = TSFA_INF;
+            const bool ok = wave_chol_regs<32>(G, p, ld, diag0, &dm);   // one out-of-line body (~3000 instructions) for the three call sites
+            if (b.tid == 0) {
+                b.red[TSFA_RED_DOUBLES - 2] = ok ? 1.0 : 0.0;
+                b.red[TSFA_RED_DOUBLES - 3] = dm;
+            }
+        }
+        blk_sync();
+        if (dmin) *dmin = b.red[TSFA_RED_DOUBLES - 3];
+        const bool ok = b.red[TSFA_RED_DOUBLES - 2] != 0.0;
+        blk_sync();
+        return ok;
+    }
+#endif
+    return blk_chol_factor(b, G, p, ld, diag0, dmin);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -421,6 +508,37 @@ TSFA_DEV int fam_ar_series(const Blk &b, X xv, int n, const TsfaSpec *specs, int
     TSFA_TICK(tk, b, 121);
     // ---- PACF by Levinson-Durbin (stattools.levinson_durbin, isacov=True) ----
     if (max_pacf_lag >= 0) {
+#if TSFA_GPU
+        {
+            // lane j holds phi[j] of the current order (j <= 40): the products of the dot are formed in parallel and
+            // added in the serial order (readlane), phi[k - j] comes through the LDS crossbar; every wavefront computes
+            // the same values, bit-identical to the serial recursion below.  (Serial on one lane: 21 k cycles per series.)
+            const int lane = b.tid & 63;
+            for (int k = b.tid; k <= max_pacf_lag; k += b.nt) pac[k] = TSFA_NAN;
+            blk_sync();
+            if (n > 1 && pacf_maxlag > 0) {
+                const int ord = pacf_maxlag;
+                const double a0 = acv[0], a1 = acv[1];
+                const double p1v = a1 / a0;
+                double phi = (lane == 1) ? p1v : 0.0;
+                double sig = a0 - p1v * a1;
+                if (b.tid == 0) pac[1] = p1v;
+                for (int k = 2; k <= ord; ++k) {
+                    const int back = k - lane;
+                    const double ak = acv[(back >= 0 && back <= ord) ? back : 0];
+                    const double prod = phi * ak;
+                    double dot = 0.0;
+                    for (int j = 1; j < k; ++j) dot += readlane_f64(prod, j);
+                    const double pkk = (acv[k] - dot) / sig;
+                    const double rev = __shfl(phi, (back >= 0 && back < 64) ? back : 0);
+                    phi = (lane >= 1 && lane < k) ? phi - pkk * rev : ((lane == k) ? pkk : phi);
+                    sig = sig * (1.0 - pkk * pkk);
+                    if (b.tid == 0) pac[k] = pkk;
+                }
+                if (b.tid == 0) pac[0] = 1.0;
+            }
+        }
+#else
         if (b.tid == 0) {
             for (int k = 0; k <= max_pacf_lag; ++k) pac[k] = TSFA_NAN;
             if (n > 1 && pacf_maxlag > 0) {
@@ -443,6 +561,7 @@ TSFA_DEV int fam_ar_series(const Blk &b, X xv, int n, const TsfaSpec *specs, int
                 pac[0] = 1.0;
             }
         }
+#endif
         blk_sync();
     }
 
@@ -491,7 +610,7 @@ TSFA_DEV int fam_ar_series(const Blk &b, X xv, int n, const TsfaSpec *specs, int
             {
                 // all nested fits from one factorization: w = L^-1 g, SSR_p = yy - sum_{i<p} w_i^2
                 double dmin1 = 0.0;
-                const bool okf = blk_chol_factor(b, G, p1, P, diag0, &dmin1);
+                const bool okf = blk_chol_factor_fast(b, G, p1, P, diag0, &dmin1);
                 if (!okf) degenerate |= 2;
                 else {
                     // raw level column: sum (xc + mean)^2 over the rows; the lag columns are differences (no offset)
@@ -565,7 +684,7 @@ TSFA_DEV int fam_ar_series(const Blk &b, X xv, int n, const TsfaSpec *specs, int
                     if (is_rhs) g[a] = v; else G[a + c * P] = v;
                 }
                 blk_sync();
-                const bool ok2 = blk_chol_factor(b, G, p2, P, diag0);
+                const bool ok2 = blk_chol_factor_fast(b, G, p2, P, diag0);
                 if (!ok2) degenerate |= 2;
                 if (ok2) blk_chol_solve(b, G, p2, P, g, beta);
                 blk_sync();
@@ -744,7 +863,7 @@ TSFA_DEV int fam_ar_series(const Blk &b, X xv, int n, const TsfaSpec *specs, int
                 for (int a = b.tid; a < p; a += b.nt) g[a] = (a == 0) ? C[0] : T[a];
                 blk_sync();
                 double dmin_ar = 0.0;
-                ar_ok = blk_chol_factor(b, G, p, P, diag0, &dmin_ar);
+                ar_ok = blk_chol_factor_fast(b, G, p, P, diag0, &dmin_ar);
                 if (!ar_ok) degenerate |= 1;
                 else {
                     const double mu = xcc.mean, rows = (double)(n - k);
