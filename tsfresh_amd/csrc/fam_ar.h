@@ -144,72 +144,9 @@ TSFA_DEV void blk_chol_forward(const Blk &b, const double *L, int p, int ld, dou
     blk_sync();
 }
 
-#if TSFA_GPU
-// The factorization of blk_chol_factor by ONE wavefront with the matrix in registers: lane i holds row i of the lower
-// triangle, column j of the factor travels by readlane.  No barrier, no LDS round trip inside the p dependent steps;
-// every entry receives the same subtractions in the same order (j ascending), so the factor is bit-identical.
-// Returns false at the first pivot below TSFA_AR_PIVOT_TOL of its original diagonal (uniform over the wavefront).
-template <int PM>
-__device__ __attribute__((noinline)) bool wave_chol_regs(double *G, int p, int ld, double *diag0, double *dmin) {
-    const int lane = (int)(threadIdx.x & 63);
-    double a[PM];
-#pragma unroll
-    for (int k = 0; k < PM; ++k) a[k] = (k < p && lane < p && k <= lane) ? G[lane + k * ld] : 0.0;
-    const double dg0 = (lane < p) ? G[lane + lane * ld] : 1.0;
-    if (lane < p) diag0[lane] = dg0;
-    double dm = TSFA_INF;
-    bool ok = true;
-#pragma unroll
-    for (int j = 0; j < PM; ++j) {
-        if (j < p && ok) {
-            const double d = readlane_f64(a[j], j);
-            if (!(d > TSFA_AR_PIVOT_TOL * readlane_f64(dg0, j))) {
-                ok = false;
-            } else {
-                dm = fmin(dm, d);
-                const double sd = sqrt(d), rsd = 1.0 / sd;
-                a[j] = (lane == j) ? sd : a[j] * rsd;
-#pragma unroll
-                for (int k = j + 1; k < PM; ++k) {
-                    if (k < p) a[k] = a[k] - a[j] * readlane_f64(a[j], k);
-                }
-            }
-        }
-    }
-#pragma unroll
-    for (int k = 0; k < PM; ++k)
-        if (k < p && lane < p && k <= lane) G[lane + k * ld] = a[k];
-    *dmin = dm;
-    return ok;
-}
-#endif
-
-// blk_chol_factor, the register form where the matrix fits (p <= 32: every ADF design up to ~3400 samples, every AR
-// order of the library's parameter sets): wavefront 0 factors, the others wait at the barrier.
-#ifndef TSFA_AR_CHOL_REGS
-#define TSFA_AR_CHOL_REGS 1
-#endif
-TSFA_DEV bool blk_chol_factor_fast(const Blk &b, double *G, int p, int ld, double *diag0, double *dmin = nullptr) {
-#if TSFA_GPU && TSFA_AR_CHOL_REGS
-    if (p <= 32) {
-        blk_sync();
-        if (b.tid < 64) {
-            double dm = TSFA_INF;
-            const bool ok = wave_chol_regs<32>(G, p, ld, diag0, &dm);   // one out-of-line body (~3000 instructions) for the three call sites
-            if (b.tid == 0) {
-                b.red[TSFA_RED_DOUBLES - 2] = ok ? 1.0 : 0.0;
-                b.red[TSFA_RED_DOUBLES - 3] = dm;
-            }
-        }
-        blk_sync();
-        if (dmin) *dmin = b.red[TSFA_RED_DOUBLES - 3];
-        const bool ok = b.red[TSFA_RED_DOUBLES - 2] != 0.0;
-        blk_sync();
-        return ok;
-    }
-#endif
-    return blk_chol_factor(b, G, p, ld, diag0, dmin);
-}
+// (Measured and dropped, round 3: the same factorization by ONE wavefront with the matrix in registers -- lane = row,
+//  columns by readlane, no barrier.  Fewer instructions, but the other wavefront of the workgroup idles through p
+//  dependent sqrt / reciprocal chains: k_ar 5.90 -> 6.56 ms per 100 000 series.)
 
 // ---------------------------------------------------------------------------------------------
 // Lagged sums on register tiles.  Every sum of the family has the form  S[j] = sum_t A(t) B(t - j)  over a row range,
@@ -610,7 +547,7 @@ TSFA_DEV int fam_ar_series(const Blk &b, X xv, int n, const TsfaSpec *specs, int
             {
                 // all nested fits from one factorization: w = L^-1 g, SSR_p = yy - sum_{i<p} w_i^2
                 double dmin1 = 0.0;
-                const bool okf = blk_chol_factor_fast(b, G, p1, P, diag0, &dmin1);
+                const bool okf = blk_chol_factor(b, G, p1, P, diag0, &dmin1);
                 if (!okf) degenerate |= 2;
                 else {
                     // raw level column: sum (xc + mean)^2 over the rows; the lag columns are differences (no offset)
@@ -684,7 +621,7 @@ TSFA_DEV int fam_ar_series(const Blk &b, X xv, int n, const TsfaSpec *specs, int
                     if (is_rhs) g[a] = v; else G[a + c * P] = v;
                 }
                 blk_sync();
-                const bool ok2 = blk_chol_factor_fast(b, G, p2, P, diag0);
+                const bool ok2 = blk_chol_factor(b, G, p2, P, diag0);
                 if (!ok2) degenerate |= 2;
                 if (ok2) blk_chol_solve(b, G, p2, P, g, beta);
                 blk_sync();
@@ -863,7 +800,7 @@ TSFA_DEV int fam_ar_series(const Blk &b, X xv, int n, const TsfaSpec *specs, int
                 for (int a = b.tid; a < p; a += b.nt) g[a] = (a == 0) ? C[0] : T[a];
                 blk_sync();
                 double dmin_ar = 0.0;
-                ar_ok = blk_chol_factor_fast(b, G, p, P, diag0, &dmin_ar);
+                ar_ok = blk_chol_factor(b, G, p, P, diag0, &dmin_ar);
                 if (!ar_ok) degenerate |= 1;
                 else {
                     const double mu = xcc.mean, rows = (double)(n - k);
