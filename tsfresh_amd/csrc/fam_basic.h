@@ -331,6 +331,101 @@ TSFA_DEV void basic_epilogue(const Blk &b, const TsfaSpec *specs, int first, int
     }
 }
 
+// index_mass_quantile (fc.py:1275) for all q of the plan WITHOUT the serial cumulative sum.
+// The reference takes the first i with np.cumsum(|x|)[i] / S >= q; np.cumsum rounds after every addend, so its values c_i
+// can only be reproduced by one lane adding n terms in a row (that chain was 30 % of k_trend).  But the decision rarely
+// depends on the rounding: any other summation order p_i of the same non-negative terms differs from c_i by less than
+// 2 n u S, so  p_i < (q - delta) S  implies  c_i / S < q  and  p_i >= (q + delta) S  implies  c_i / S >= q  with
+// delta = (2 n + 64) 2^-52.  p_i = o_j + s_i: thread j owns E consecutive samples, s_i its running sum, o_{j+1} =
+// o_j + t_j the offsets (64 dependent adds instead of n) -- non-decreasing in i by construction.  Lane (q, bound) counts
+// the i below its bound by bisection over the offsets and a walk through ONE thread's samples; where the two counts of a
+// q agree, no c_i lies in the band and the count is the reference's index.  Otherwise (a prefix sum that hits q S to
+// within 5e-13: integer-valued series do) the function returns false and the caller takes the serial route.
+// cum: LDS scratch, >= nt + 2 * nq + 2 doubles.  Writes altc[8 k + 7] for every q.
+template <class XS>
+TSFA_DEV bool imq_banded(const Blk &b, XS xs, int n, double S, const TsfaAltPlan &alt, double *cum, double *altc) {
+    const int nq = alt.nq;
+    if (!(S > 0.0) || !(S < TSFA_INF) || n < 1) return false;  // uniform
+    const double dn = (double)n;
+    const int E = (n + b.nt - 1) / b.nt;
+    const int nown = (n + E - 1) / E;  // threads that own samples
+    if (nown + 1 + 2 * nq > n) return false;  // the scratch is the n-double buffer of the serial route (short series: short chain)
+    const int beg = E * b.tid, end = (beg + E < n) ? beg + E : n;
+    double t = 0.0;
+    for (int i = beg; i < end; ++i) t += fabs(xs[i]);
+    blk_sync();
+#if TSFA_GPU
+    if (b.nt == 64) {
+        double o = 0.0, mine = 0.0;
+        for (int j = 0; j < nown; ++j) {
+            if ((b.tid & 63) == j) mine = o;
+            o += readlane_f64(t, j);
+        }
+        if (b.tid < nown) cum[b.tid] = mine;
+        if (b.tid == 0) cum[nown] = o;
+    } else
+#endif
+    {
+        if (b.tid < nown) cum[b.tid] = t;
+        blk_sync();
+        if (b.tid == 0) {
+            double o = 0.0;
+            for (int j = 0; j < nown; ++j) {
+                const double tj = cum[j];
+                cum[j] = o;
+                o += tj;
+            }
+            cum[nown] = o;
+        }
+    }
+    blk_sync();
+    const double delta = (double)(2 * n + 64) * 2.220446049250313e-16;
+    double *cnt = cum + nown + 1;
+    for (int l = b.tid; l < 2 * nq; l += b.nt) {
+        const int k = l >> 1;
+        double q = 0.0;
+#pragma unroll
+        for (int u = 0; u < TSFA_ALT_MAXKEYS; ++u)
+            if (u == k) q = alt.q[u];
+        const double T = (l & 1) ? (q + delta) * S : (q - delta) * S;
+        int lo = 0, hi = nown;  // first thread whose offset is >= T: every sample from there on is >= T
+        while (lo < hi) {
+            const int mid = (lo + hi) >> 1;
+            if (cum[mid] >= T) hi = mid;
+            else lo = mid + 1;
+        }
+        int count = 0;
+        if (lo > 0) {
+            const int j = lo - 1;   // o_j < T <= o_{j+1} (or j is the last thread): the threads before j lie below T entirely
+            const double oj = cum[j];
+            double sacc = 0.0;
+            count = E * j;
+            for (int e = 0; e < E; ++e) {
+                const int i = E * j + e;
+                if (i < n) {
+                    sacc += fabs(xs[i]);
+                    count += (oj + sacc < T) ? 1 : 0;
+                }
+            }
+        }
+        cnt[l] = (double)count;
+    }
+    blk_sync();
+    unsigned amb = 0;
+    for (int k = b.tid; k < nq; k += b.nt) {
+        const double ca = cnt[2 * k], cb = cnt[2 * k + 1];
+        if (ca == cb) {
+            const int idx = ((int)ca < n) ? (int)ca : 0;  // np.argmax of an all-False mask is 0
+            altc[8 * k + 7] = (double)(idx + 1) / dn;
+        } else {
+            amb = 1;
+        }
+    }
+    amb = blk_or16(b, amb);
+    blk_sync();
+    return amb == 0;
+}
+
 // Count-type columns (ratio_beyond_r_sigma, count_above/below(_mean), value_count, range_count, number_crossing_m):
 // the host moves them to the front of the spec list (tsfa_prepare_family, hint d = their number) and they are
 // evaluated together here.  A wavefront keeps 1024 samples in registers (16 per lane); a predicate then costs one
@@ -1056,13 +1151,22 @@ TSFA_DEV void fam_basic_series(const Blk &b0, XS xs, int n, const TsfaSpec *spec
                 v = altc[8 * ((int)p1 & 127) + 7];
                 break;
             }
+            bool imq_decided = false;
             if (!have_cumsum) {
-                // np.cumsum is a serial accumulation: one lane builds it once (in numpy's order, so that the >= q
-                // comparison is bit-identical), every q then scans it in parallel
                 have_peaks = false;  // cum may alias the peak distances
                 peaks_p = 0;
                 imq_sabs = np_sum(b, n, [=](int i) { return fabs(xs[i]); });
                 blk_sync();
+                // all q of the plan from banded prefix sums where the rounding of np.cumsum cannot matter (imq_banded)
+                if (imq_indexed) imq_decided = imq_banded(b, xs, n, imq_sabs, alt, cum, altc);
+            }
+            if (imq_decided) {
+                v = altc[8 * ((int)p1 & 127) + 7];
+                break;
+            }
+            if (!have_cumsum) {
+                // np.cumsum is a serial accumulation: one lane builds it once (in numpy's order, so that the >= q
+                // comparison is bit-identical), every q then scans it in parallel
                 if (b.tid == 0) {
                     double acc = 0.0;
                     int i = 0;
