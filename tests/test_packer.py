@@ -79,7 +79,7 @@ def test_arrow_tables_pack_like_frames():
 
 
 @pytest.mark.parametrize("case", ["sorted", "ragged", "float_ids", "unsorted_within", "unsorted_ids", "datetime_sort",
-                                  "int32", "no_sort"])
+                                  "int32", "no_sort", "int_values", "int_values_unsorted", "float64_values"])
 def test_native_scan_equals_numpy_passes(case, monkeypatch):
     """tsfa_pack_scan (one multi-threaded C++ pass: layout proof + group boundaries + NaN check) against the numpy
     passes it replaces, on frames large enough to split over several scan threads."""
@@ -100,6 +100,12 @@ def test_native_scan_equals_numpy_passes(case, monkeypatch):
     if case == "int32":
         df["id"] = df["id"].astype(np.int32)
         df["time"] = df["time"].astype(np.int32)
+    if case.startswith("int_values"):   # no NaN check to run, converted only once the layout is proven
+        df["value"] = rng.integers(-50, 50, size=len(df))
+        if case.endswith("unsorted"):
+            df = df.iloc[::-1].reset_index(drop=True)
+    if case == "float64_values":        # taken as they are: no copy
+        df["value"] = df["value"].astype(np.float64)
     kw = dict(column_id="id") if case == "no_sort" else dict(column_id="id", column_sort="time")
     if case == "no_sort":
         df = df.drop(columns="time")

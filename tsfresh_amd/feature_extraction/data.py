@@ -66,8 +66,8 @@ def _get_value_columns(df, *other_columns):
 
 def _as_values(column):
     arr = np.asarray(column)
-    if arr.dtype == np.float32:
-        return arr
+    if arr.dtype == np.float32 or arr.dtype == np.float64:
+        return arr   # read only from here on: no copy
     return arr.astype(np.float64)
 
 
@@ -89,15 +89,19 @@ def _pack_presorted(kind, ids, values, sort_values, index, nan_name=None):
         return None
     if len(ids) >= _NATIVE_SCAN_MIN_ROWS:
         # one multi-threaded native pass: layout proof + group boundaries + the NaN check of the value column
-        vals = _as_values(values)
+        # (a float column as it is; any other element type cannot hold a NaN and is only converted -- a full copy --
+        # once the layout is proven, so an unsorted integer frame is not converted twice)
+        raw = np.asarray(values)
+        scanned = raw if raw.dtype.kind == "f" and raw.dtype.itemsize in (4, 8) else None
         sv = None if sort_values is None else np.asarray(sort_values)
-        res = _native.pack_scan(ids, sv, vals)
+        res = _native.pack_scan(ids, sv, scanned)
         if res is not None:
             flags, offsets = res
             if flags & _native.TSFA_PACK_VALUE_NAN and nan_name is not None:
                 raise ValueError("Column must not contain NaN values: {}".format(nan_name))
             if offsets is None:
                 return None
+            vals = scanned if scanned is not None else _as_values(raw)
             times = _hours_since_first(index, slice(None), offsets) if index is not None else None
             return PackedKind(str(kind), ids[offsets[:-1]], np.ascontiguousarray(vals), offsets, times, sv)
     if not bool(np.all(ids[1:] >= ids[:-1])):  # also False for NaN ids
