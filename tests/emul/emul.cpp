@@ -100,7 +100,8 @@ extern "C" int tsfa_emul_extract_timed(const tsfa_feature_spec *specs, int n_spe
                                 (s % 4 == 1) ? 0 : hints[TSFA_FAM_BASIC].d);
         }
         if (!fam[TSFA_FAM_TREND].empty()) {
-            std::vector<double> w(maxn + 8), cum(maxn + 8), altc(8 * 16), ctx(32);
+            // (BasicLds: with TsfaAltPlan::small_w the work array is nt + 2 * 16 + 8 doubles whatever the length)
+            std::vector<double> w(maxn + 48, TSFA_NAN), cum(maxn + 48, TSFA_NAN), altc(8 * 16), ctx(32);
             std::vector<int> iw(512);
             fam_basic_series<2>(b, xs.data(), n, fam[TSFA_FAM_TREND].data(), (int)fam[TSFA_FAM_TREND].size(), row, w.data(),
                                 (s % 2) ? w.data() : cum.data(), altc.data(), iw.data(), dectab.data(), 0,

@@ -410,8 +410,9 @@ def _r2_cancels(rvalue):
 
 
 def _pacf_min_innovation(x):
-    """-> array m[k] = min over j < k of |sig_j| / acov[0]: the smallest innovation variance the Levinson-Durbin recursion
-    has divided by before it produces lag k.  The recursion's relative error at lag k is ~eps / m[k] (its numerator
+    """-> array m[k] = (min over j < k of |sig_j| / acov[0]) / max(1, max over j < k of |pacf_j|): the smallest innovation
+    variance the Levinson-Durbin recursion has divided by before it produces lag k, over the largest coefficient it has
+    multiplied by.  The recursion's relative error at lag k is ~eps / m[k] (its numerator
     cancels to that size): a two-valued +-1 series with pacf[2] = -1.0000000006 leaves m = 1.2e-9 and every later
     coefficient -- 28 439, -614.7, ... -- good to 1e-6 at best, in the reference as anywhere."""
     from oracle.third_party import acovf_adjusted
@@ -427,10 +428,11 @@ def _pacf_min_innovation(x):
     phi_prev[1] = acv[1] / acv[0]
     sig = acv[0] - phi_prev[1] * acv[1]
     cur_min = 1.0
-    k = 1
-    for k in range(2, nlags + 1):
+    gain = max(1.0, abs(phi_prev[1]))   # the ADJUSTED autocovariances need not be positive definite: a period-3 series has
+    k = 1                               # pacf[2] = -1.0001, a negative innovation variance and pacf[4] = -4016; the error
+    for k in range(2, nlags + 1):       # of a coefficient is carried into the later ones multiplied by those magnitudes
         cur_min = min(cur_min, abs(sig) / acv[0])
-        out[k] = cur_min
+        out[k] = cur_min / gain
         if sig == 0:
             break
         pkk = (acv[k] - np.dot(phi_prev[1:k], acv[1:k][::-1])) / sig
@@ -440,7 +442,9 @@ def _pacf_min_innovation(x):
         cur[k] = pkk
         sig = sig * (1 - pkk * pkk)
         phi_prev = cur
-    out[k:] = np.minimum(out[k:], cur_min)
+        if np.isfinite(pkk):
+            gain = max(gain, abs(pkk))
+    out[k:] = np.minimum(out[k:], cur_min / gain)
     return out
 
 
@@ -576,6 +580,19 @@ def tolerance_for(col, x, want, facts):
             if slope > 0:
                 atol += COND_FACTOR * EPS * grow * (fit["kappa"] * fit["resid"] + fit["scaled_norm"]) / slope
         return RTOL, atol
+    if f in ("linear_trend", "agg_linear_trend") and 'attr_"pvalue"' in col:
+        # t = r sqrt(df / ((1 - r)(1 + r))): 1 - r^2 is known to ~4 eps, and p ~ t^-df for the large t of a near-perfect
+        # line (three float32 samples on a line: 1 - r = 5e-16, p = 1.9e-8 or 2.3e-8 by the last bit of r)
+        if f == "linear_trend":
+            y = facts.x
+        else:
+            f_agg, cl = col.split('f_agg_"')[1].split('"')[0], _param(col, "chunk_len", int)
+            y = facts.get(("agg", f_agg, cl), lambda: _chunk_aggs(facts.x, f_agg, cl))
+        r = _r_of_chunks(y)
+        if r is not None and np.isfinite(r) and len(y) > 2:
+            gap = max(1.0 - r * r, EPS)
+            return max(RTOL, 8.0 * EPS * (len(y) - 2) / gap), atol_for(col, x)
+        return RTOL, atol_for(col, x)
     if f == "partial_autocorrelation":
         lag = _param(col, "lag", int)
         m = facts.get("pacf_min", lambda: _pacf_min_innovation(facts.x))

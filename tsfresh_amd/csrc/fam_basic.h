@@ -154,12 +154,16 @@ TSFA_DEV void alt_fill_all(const Blk &b, XS xs, int n, const TsfaAltPlan &alt, d
     const int nkeys = alt.nkeys;
     int k0 = 0;
     TSFA_TICKER(tka, 0);
+    // The chunk aggregates are not stored: a chunk is cl consecutive samples of the LDS-resident series, its (up to four)
+    // aggregates cost a handful of instructions, and the regression reads every aggregate exactly twice (the mean, then
+    // the centred products).  Recomputing them in the second sweep instead of keeping 4 m doubles per series lets the
+    // kernel run without an n-double work array (TsfaAltPlan::small_w): 15 -> 8 KB of LDS per series.  `w` is unused.
+    (void)w;
     while (k0 < nkeys) {
         const int cl = alt.cl[k0];
         int k1 = k0 + 1;
         while (k1 < nkeys && alt.cl[k1] == cl && k1 - k0 < 4) ++k1;
         const int m = (n + cl - 1) / cl;
-        if (cl >= n || (k1 - k0) * m > n) k1 = k0 + 1;  // no room for several aggregate rows: one key at a time
         const int ng = k1 - k0;
         if (cl >= n) {  // fc.py: chunk_len >= len(x) -> NaN
             blk_sync();
@@ -170,18 +174,18 @@ TSFA_DEV void alt_fill_all(const Blk &b, XS xs, int n, const TsfaAltPlan &alt, d
         int ag[4];
 #pragma unroll
         for (int j = 0; j < 4; ++j) ag[j] = (j < ng) ? alt.agg[k0 + j] : -1;
-        blk_sync();
-        for (int c = b.tid; c < m; c += b.nt) {  // fc.py:176 _aggregate_on_chunks
+        bool need_max = false, need_min = false, need_mean = false, need_var = false;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            need_max |= (ag[j] == TSFA_AGG_MAX);
+            need_min |= (ag[j] == TSFA_AGG_MIN);
+            need_mean |= (ag[j] == TSFA_AGG_MEAN) || (ag[j] == TSFA_AGG_VAR);
+            need_var |= (ag[j] == TSFA_AGG_VAR);
+        }
+        // fc.py:176 _aggregate_on_chunks: the aggregates of chunk c, in the order of the group's keys
+        auto chunk_aggs = [=](int c, double (&r)[4]) {
             const int lo = c * cl;
             const int hi = (lo + cl < n) ? lo + cl : n;
-            bool need_max = false, need_min = false, need_mean = false, need_var = false;
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                need_max |= (ag[j] == TSFA_AGG_MAX);
-                need_min |= (ag[j] == TSFA_AGG_MIN);
-                need_mean |= (ag[j] == TSFA_AGG_MEAN) || (ag[j] == TSFA_AGG_VAR);
-                need_var |= (ag[j] == TSFA_AGG_VAR);
-            }
             double vmx = xs[lo], vmn = xs[lo], vmean = 0.0, vvar = 0.0;
             if (need_max || need_min)
                 for (int i = lo + 1; i < hi; ++i) { const double x = xs[i]; vmx = fmax(vmx, x); vmn = fmin(vmn, x); }
@@ -189,33 +193,39 @@ TSFA_DEV void alt_fill_all(const Blk &b, XS xs, int n, const TsfaAltPlan &alt, d
             if (need_var)
                 vvar = np_leaf_sum(lo, hi - lo, [=](int i) { const double d = xs[i] - vmean; return d * d; }) / (double)(hi - lo);
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                if (j >= ng) continue;
-                const double r = (ag[j] == TSFA_AGG_MAX) ? vmx : (ag[j] == TSFA_AGG_MIN) ? vmn : (ag[j] == TSFA_AGG_MEAN) ? vmean : vvar;
-                w[j * m + c] = r;
-            }
-        }
+            for (int j = 0; j < 4; ++j)
+                r[j] = (ag[j] == TSFA_AGG_MAX) ? vmx : (ag[j] == TSFA_AGG_MIN) ? vmn : (ag[j] == TSFA_AGG_MEAN) ? vmean : vvar;
+        };
         blk_sync();
-        TSFA_TICK(tka, b, 200);
         const double dm = (double)m;
         const double xmean = (dm - 1.0) * 0.5;
         double sy[4] = {0.0, 0.0, 0.0, 0.0};
-        for (int i = b.tid; i < m; i += b.nt) {
+        for (int c = b.tid; c < m; c += b.nt) {
+            double r[4];
+            chunk_aggs(c, r);
 #pragma unroll
             for (int j = 0; j < 4; ++j)
-                if (j < ng) sy[j] += w[j * m + i];
+                if (j < ng) sy[j] += r[j];
+            if (c < 2) {   // linregress of two points reads the two values themselves
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    if (j < ng) raw[6 * (k0 + j) + 4 + c] = r[j];
+            }
         }
+        TSFA_TICK(tka, b, 200);
         double ym[4];
         blk_sum_multi<4>(b, sy);
 #pragma unroll
         for (int j = 0; j < 4; ++j) ym[j] = (j < ng) ? sy[j] / dm : 0.0;
         double sxy[4] = {0.0, 0.0, 0.0, 0.0}, syy[4] = {0.0, 0.0, 0.0, 0.0};
-        for (int i = b.tid; i < m; i += b.nt) {
-            const double dx = (double)i - xmean;
+        for (int c = b.tid; c < m; c += b.nt) {
+            double r[4];
+            chunk_aggs(c, r);
+            const double dx = (double)c - xmean;
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 if (j < ng) {
-                    const double dy = w[j * m + i] - ym[j];
+                    const double dy = r[j] - ym[j];
                     sxy[j] += dx * dy;
                     syy[j] += dy * dy;
                 }
@@ -233,8 +243,7 @@ TSFA_DEV void alt_fill_all(const Blk &b, XS xs, int n, const TsfaAltPlan &alt, d
                     r[1] = ym[j];
                     r[2] = a;
                     r[3] = c2;
-                    r[4] = w[j * m];
-                    r[5] = (m > 1) ? w[j * m + 1] : 0.0;
+                    if (m < 2) r[5] = 0.0;
                 }
             }
         }
@@ -349,7 +358,9 @@ TSFA_DEV bool imq_banded(const Blk &b, XS xs, int n, double S, const TsfaAltPlan
     const double dn = (double)n;
     const int E = (n + b.nt - 1) / b.nt;
     const int nown = (n + E - 1) / E;  // threads that own samples
-    if (nown + 1 + 2 * nq > n) return false;  // the scratch is the n-double buffer of the serial route (short series: short chain)
+    // scratch: nown + 1 + 2 nq doubles -- the small work array of the kernel holds that by construction, the n-double
+    // buffer of the serial route only for series longer than it (short series: short chain)
+    if (!alt.small_w && nown + 1 + 2 * nq > n) return false;
     const int beg = E * b.tid, end = (beg + E < n) ? beg + E : n;
     double t = 0.0;
     for (int i = beg; i < end; ++i) t += fabs(xs[i]);
@@ -424,6 +435,38 @@ TSFA_DEV bool imq_banded(const Blk &b, XS xs, int n, double S, const TsfaAltPlan
     amb = blk_or16(b, amb);
     blk_sync();
     return amb == 0;
+}
+
+// The serial route without the n-double array (TsfaAltPlan::small_w): lane = q, every lane adds the samples in a row
+// (the rounding of np.cumsum) and notes the first i with c_i / S >= q.  fl(c / S) is monotone in c, so far below
+// q S the answer is no and far above it is yes without dividing; the division decides only within 1e-15 of q S.
+template <class XS>
+TSFA_DEV void imq_serial_walk(const Blk &b, XS xs, int n, double S, const TsfaAltPlan &alt, double *altc) {
+    const double dn = (double)n;
+    for (int k = b.tid; k < alt.nq; k += b.nt) {
+        double q = 0.0;
+#pragma unroll
+        for (int u = 0; u < TSFA_ALT_MAXKEYS; ++u)
+            if (u == k) q = alt.q[u];
+        double res = TSFA_NAN;
+        if (S != 0.0) {
+            const double lo = q * S * (1.0 - 1e-15), hi = q * S * (1.0 + 1e-15);
+            const bool banded = (S > 0.0) && (S < TSFA_INF) && (q > 0.0);   // otherwise every step divides
+            double acc = 0.0;
+            int idx = -1;
+            for (int i = 0; i < n; ++i) {
+                acc += fabs(xs[i]);
+                if (idx < 0) {
+                    const bool yes = banded ? (acc > hi || (acc >= lo && acc / S >= q)) : (acc / S >= q);
+                    if (yes) idx = i;
+                }
+            }
+            if (idx < 0) idx = 0;  // np.argmax of an all-False mask is 0
+            res = (double)(idx + 1) / dn;
+        }
+        altc[8 * k + 7] = res;
+    }
+    blk_sync();
 }
 
 // Count-type columns (ratio_beyond_r_sigma, count_above/below(_mean), value_count, range_count, number_crossing_m):
@@ -1159,6 +1202,10 @@ TSFA_DEV void fam_basic_series(const Blk &b0, XS xs, int n, const TsfaSpec *spec
                 blk_sync();
                 // all q of the plan from banded prefix sums where the rounding of np.cumsum cannot matter (imq_banded)
                 if (imq_indexed) imq_decided = imq_banded(b, xs, n, imq_sabs, alt, cum, altc);
+            }
+            if (!imq_decided && imq_indexed && alt.small_w && !have_cumsum) {
+                imq_serial_walk(b, xs, n, imq_sabs, alt, altc);   // no n-double array in this launch
+                imq_decided = true;
             }
             if (imq_decided) {
                 v = altc[8 * ((int)p1 & 127) + 7];

@@ -487,6 +487,7 @@ static int run_batch(tsfa_plan *plan, const void *d_values, int dtype, const dou
             a.alt = plan->hints[f].alt;
             a.cq = plan->hints[f].cq;
             int aux = 0;
+            if (f == TSFA_FAM_TREND) aux = a.alt.small_w;   // no n-double work array in LDS (TsfaAltPlan::small_w)
             if (f == TSFA_FAM_SPECTRAL) {
                 // only non-power-of-two lengths <= 256 use the table-driven DFT (longer ones: Goertzel, no table)
                 a.dft_n = (int)std::min<long long>(max_np2, 256);

@@ -278,6 +278,19 @@ static inline void tsfa_prepare_family_impl(int fam, std::vector<TsfaSpec> &spec
                 }
             }
         }
+        {   // no column left that needs the n-double work array?  (per-column index_mass_quantile / agg_linear_trend do)
+            bool imq_plain = false, has_alt = false;
+            std::vector<std::pair<int, int>> akeys;
+            for (const auto &s : specs) {
+                if (s.calc == TSFA_C_INDEX_MASS_QUANTILE && s.p[2] != 1.0) imq_plain = true;
+                if (s.calc == TSFA_C_AGG_LINEAR_TREND) {
+                    has_alt = true;
+                    const std::pair<int, int> k((int)s.p[1], (int)s.p[2]);
+                    if (std::find(akeys.begin(), akeys.end(), k) == akeys.end()) akeys.push_back(k);
+                }
+            }
+            h.alt.small_w = (!imq_plain && (!has_alt || akeys.size() <= TSFA_ALT_MAXKEYS)) ? 1 : 0;
+        }
         // preferred: all distinct (chunk_len, f_agg) keys at once (TsfaAltPlan); p[3] = key index, + 128 on the first
         // agg_linear_trend column, which computes them all
         {

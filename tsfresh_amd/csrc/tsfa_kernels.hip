@@ -59,7 +59,7 @@ __device__ __forceinline__ void basic_body(const T *__restrict__ values, const i
     const int64_t off = starts[sidx];
     const int n = (int)(ends[sidx] - off);
     BasicLds L;
-    L.carve(tsfa_base, maxn, blockDim.x, (int)sizeof(T), PART);
+    L.carve(tsfa_base, maxn, blockDim.x, (int)sizeof(T), PART, (PART == 2) ? alt.small_w : 0);
     TSFA_TICKS_BEGIN();
     Blk b{(int)threadIdx.x, (int)blockDim.x, L.red, L.np};
     T *xs = (T *)L.xs;  // resident in the input precision (half the LDS for float32), read as float64
@@ -79,7 +79,7 @@ __global__ void __launch_bounds__(1024) k_basic(const T *__restrict__ values, co
                         const TsfaSpec *__restrict__ specs, int nspecs, double *__restrict__ out, int64_t ld,
                         const double *__restrict__ dectab, int maxn, int hint_a, int n_loop, int n_count, int n_sum TSFA_GS_PARAMS) {
     TsfaAltPlan alt;
-    alt.nkeys = 0; alt.want_p = 0; alt.nq = 0;
+    alt.nkeys = 0; alt.want_p = 0; alt.nq = 0; alt.small_w = 0;
     basic_body<T, 1>(values, starts, ends, n_series, sel, specs, nspecs, out, ld, dectab, maxn, hint_a, 0, nullptr, alt, n_loop,
                      n_count, n_sum TSFA_GS_ARGS);
 }
@@ -92,7 +92,7 @@ __global__ void __launch_bounds__(256, 4) k_basic_lite(const T *__restrict__ val
                         const TsfaSpec *__restrict__ specs, int nspecs, double *__restrict__ out, int64_t ld,
                         const double *__restrict__ dectab, int maxn, int hint_a TSFA_GS_PARAMS) {
     TsfaAltPlan alt;
-    alt.nkeys = 0; alt.want_p = 0; alt.nq = 0;
+    alt.nkeys = 0; alt.want_p = 0; alt.nq = 0; alt.small_w = 0;
 #if defined(TSFA_LONG)
     basic_body<T, 5>(values, starts, ends, n_series, sel, specs, nspecs, out, ld, dectab, maxn, hint_a, 0, nullptr, alt, 0, 0, 0 TSFA_GS_ARGS);
 #else
@@ -155,7 +155,7 @@ __global__ void __launch_bounds__(256, 4) k_basic_lite(const T *__restrict__ val
 }
 
 template <typename T>
-__global__ void __launch_bounds__(512) k_trend(const T *__restrict__ values, const int64_t *__restrict__ starts, const int64_t *__restrict__ ends, int64_t n_series, const int *__restrict__ sel,
+__global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4))) k_trend(const T *__restrict__ values, const int64_t *__restrict__ starts, const int64_t *__restrict__ ends, int64_t n_series, const int *__restrict__ sel,
                         const TsfaSpec *__restrict__ specs, int nspecs, double *__restrict__ out, int64_t ld, int maxn,
                         int hint_b, const double *__restrict__ times, const TsfaAltPlan alt, int n_loop TSFA_GS_PARAMS) {
     basic_body<T, 2>(values, starts, ends, n_series, sel, specs, nspecs, out, ld, nullptr, maxn, 0, hint_b, times, alt, n_loop, 0, 0 TSFA_GS_ARGS);
@@ -853,7 +853,7 @@ static int launch_all_t(const TsfaLaunch &a, const T *values) {
         }
     } else if (a.fam == TSFA_FAM_TREND) {
         BasicLds L;
-        const size_t lds = L.carve(nullptr, a.maxn, nt, (int)sizeof(T), 2);
+        const size_t lds = L.carve(nullptr, a.maxn, nt, (int)sizeof(T), 2, a.alt.small_w);
         TSFA_KLAUNCH(k_trend<T>, lds, values, a.starts, a.ends, a.n_series, a.sel, a.specs, a.nspecs, a.out, a.ld, a.maxn,
                      a.hint_b, a.times, a.alt, a.hint_c);
     } else if (a.fam == TSFA_FAM_SORT) {
@@ -963,7 +963,7 @@ size_t tsfa_seq_lds_bytes(const TsfaSeqGroup &g) {
 size_t tsfa_family_lds_bytes(int fam, int maxn, int nt, int aux) {
     switch (fam) {
     case TSFA_FAM_BASIC: { BasicLds L; return L.carve(nullptr, maxn, nt, 8, 1); }
-    case TSFA_FAM_TREND: { BasicLds L; return L.carve(nullptr, maxn, nt, 8, 2); }
+    case TSFA_FAM_TREND: { BasicLds L; return L.carve(nullptr, maxn, nt, 8, 2, aux); }
     case TSFA_FAM_SORT: { SortLds L; return L.carve(nullptr, maxn, nt); }
     case TSFA_FAM_SPECTRAL: { SpectralLds L; return L.carve(nullptr, maxn, aux); }
     case TSFA_FAM_AR: { ArLds L; return L.carve(nullptr, maxn, aux); }

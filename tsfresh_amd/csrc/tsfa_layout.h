@@ -43,11 +43,14 @@ struct BasicLds {
     // part: 1 = k_basic (w holds the sliding maxima of number_peaks / the distance codes: maxn elements of the input
     //       precision, at least maxn shorts), 2 = k_trend (w = maxn float64: cumulative |x|, chunk aggregates), 3 = both
     // The numpy-order scratch (np_sum: the statistics / sum |x|, always finished before w is written) shares w.
-    TSFA_HD size_t carve(unsigned char *base, int maxn, int nt, int xs_bytes = 8, int part = 3) {
+    // small_w (k_trend, TsfaAltPlan::small_w): the plan's calculators need no n-double array -- w holds the scratch of
+    //       the banded index_mass_quantile (nt offsets + 2 counts per q) only: half the LDS per series at n = 1024
+    TSFA_HD size_t carve(unsigned char *base, int maxn, int nt, int xs_bytes = 8, int part = 3, int small_w = 0) {
         LdsCarve c{base, 0};
         red = c.take<double>(TSFA_RED_DOUBLES);
         xs = c.take<unsigned char>((size_t)maxn * xs_bytes);
         size_t wb = (part & 2) ? (size_t)maxn * sizeof(double) : (size_t)maxn * xs_bytes;
+        if ((part & 2) && small_w) wb = (size_t)(nt + 2 * 16 + 8) * sizeof(double);
         if (wb < sizeof(NpScratch)) wb = sizeof(NpScratch);
         unsigned char *u = c.take<unsigned char>(wb);
         w = (double *)u;   // chunk aggregates (agg_linear_trend) ...

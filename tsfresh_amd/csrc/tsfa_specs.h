@@ -150,7 +150,8 @@ struct TsfaAltPlan {
     // index_mass_quantile (fc.py:1275): the distinct q of the plan; an indexed column has p[2] == 1 and its q's index
     // in p[1] (+ 128 on the column that evaluates them all).  nq == 0: more than TSFA_ALT_MAXKEYS -> per column.
     int nq;
-    int pad;
+    int small_w;  // TREND: every agg_linear_trend column is keyed and every index_mass_quantile column indexed (or absent):
+                  // no calculator of the plan needs an n-double work array, the kernel's LDS holds a small scratch instead
     double q[TSFA_ALT_MAXKEYS];
 };
 
