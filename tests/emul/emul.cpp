@@ -102,7 +102,7 @@ extern "C" int tsfa_emul_extract_timed(const tsfa_feature_spec *specs, int n_spe
         if (!fam[TSFA_FAM_TREND].empty()) {
             // (BasicLds: with TsfaAltPlan::small_w the work array is nt + 2 * 16 + 8 doubles whatever the length)
             std::vector<double> w(maxn + 48, TSFA_NAN), cum(maxn + 48, TSFA_NAN), altc(8 * 16), ctx(32);
-            std::vector<int> iw(512);
+            std::vector<int> iw(512, 0x3fe00000);   // poisoned with finite values: LDS keeps the previous series' contents
             fam_basic_series<2>(b, xs.data(), n, fam[TSFA_FAM_TREND].data(), (int)fam[TSFA_FAM_TREND].size(), row, w.data(),
                                 (s % 2) ? w.data() : cum.data(), altc.data(), iw.data(), dectab.data(), 0,
                                 hints[TSFA_FAM_TREND].b, hints[TSFA_FAM_TREND].alt, nullptr,
@@ -172,12 +172,25 @@ extern "C" int tsfa_emul_extract_timed(const tsfa_feature_spec *specs, int n_spe
                 fam_entropy_series_bits<false>(b, xe.data(), n, fam[TSFA_FAM_ENTROPY].data(), (int)fam[TSFA_FAM_ENTROPY].size(),
                                                row, thr.data(), perm.data(), work.data());
             } else if (bits) {  // ... with 16-byte table entries and tolerance rounds (series of 1025 .. 4096 samples)
-                const int nk = std::min((int)fam[TSFA_FAM_ENTROPY].size(), TSFA_ENTB_MAXK);
-                std::vector<unsigned int> work(entb_work_words(n, TSFA_ENTB_QW_LONG + 1, entb_kround(n, nk, TSFA_ENTB_MAXWAVES)) + 64,
-                                               0xFFFFFFFFu);
+                // the work region as the DEVICE sizes it: for the longest series of the launch (here: of the call), which may
+                // hold fewer tolerances per round than this series' registers would; canary words behind it
+                int lmax = n;
+                for (int64_t q = 0; q < n_series; ++q) {
+                    const int nq_ = (int)(offsets[q + 1] - offsets[q]);
+                    if (nq_ <= TSFA_ENTB_MAXN_LONG && nq_ > lmax) lmax = nq_;
+                }
+                const int kcap = entb_kround(lmax, TSFA_ENTB_MAXK, TSFA_ENTB_MAXWAVES);
+                const size_t words = entb_work_words(lmax, TSFA_ENTB_QW_LONG + 1, kcap);
+                std::vector<unsigned int> work(words + 64, 0xFFFFFFFFu);
+                for (size_t q = words; q < words + 64; ++q) work[q] = 0xC0FFEE00u + (unsigned int)(q - words);
                 fam_entropy_series_bits<false, TSFA_ENTB_QW_LONG>(b, xe.data(), n, fam[TSFA_FAM_ENTROPY].data(),
                                                                  (int)fam[TSFA_FAM_ENTROPY].size(), row, thr.data(), perm.data(),
-                                                                 work.data());
+                                                                 work.data(), nullptr, kcap);
+                for (size_t q = words; q < words + 64; ++q)
+                    if (work[q] != 0xC0FFEE00u + (unsigned int)(q - words)) {
+                        snprintf(err, errlen, "entropy work region overrun (series of %d samples in a launch of up to %d)", n, lmax);
+                        return TSFA_ERR_INVALID;
+                    }
             } else
             fam_entropy_series<double>(b, xe.data(), n, fam[TSFA_FAM_ENTROPY].data(), (int)fam[TSFA_FAM_ENTROPY].size(),
                                        row, thr.data(), perm.data(), refs.data(), (s % 2) ? nullptr : cnt.data(),

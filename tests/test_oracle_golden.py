@@ -66,3 +66,43 @@ def test_emul_matches_oracle_on_config3_rows(dtype):
     bad = compare(onames, got[:, [names.index(n) for n in onames]], want, rows, skipped=skipped)
     assert not bad, "%d mismatches, first: %s" % (len(bad), bad[:10])
     assert len(skipped) <= 0.01 * want.size, len(skipped)
+
+
+def test_emul_agg_linear_trend_on_series_no_longer_than_the_chunk():
+    """chunk_len >= len(x): every aggregate of that chunk length is NaN (fc.py:2171) -- the keyed evaluation handles up to
+    four aggregates of one chunk length per sweep and has to clear all of them (a fuzz find: 'min' kept a stale value
+    next to a NaN 'max'); lengths around the chunk lengths of ComprehensiveFCParameters."""
+    from parity import compare
+    rng = np.random.default_rng(77)
+    lens = [1, 2, 3, 5, 5, 6, 10, 11, 49, 50, 51, 120]
+    rows = [np.full(5, -1062.46435546875) if i == 4 else rng.standard_normal(n) for i, n in enumerate(lens)]
+    values = np.concatenate(rows)
+    offsets = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
+    params = {"agg_linear_trend": ComprehensiveFCParameters()["agg_linear_trend"],
+              "index_mass_quantile": ComprehensiveFCParameters()["index_mass_quantile"],
+              "linear_trend": ComprehensiveFCParameters()["linear_trend"]}
+    names, got = emul_engine(params, values, offsets)
+    onames, want = oracle_engine(params, values, offsets)
+    assert names == onames
+    assert np.array_equal(np.isnan(got), np.isnan(want))
+    bad = compare(names, got, want, rows)
+    assert not bad, bad[:10]
+
+
+def test_emul_long_entropy_sweep_in_a_ragged_launch():
+    """Series of 1025 .. 4096 samples share a launch whose work region is sized for the LONGEST of them (fewer
+    tolerances per round); a shorter series must not take more tolerances per round than that region holds
+    (a GPU fuzz find: 2192 samples next to 2500, six tolerances -> NaN for the last one).  The emulation sizes the region
+    the device's way and checks canary words behind it."""
+    from parity import compare
+    rng = np.random.default_rng(41)
+    lens = [1065, 2192, 2500]
+    rows = [rng.standard_normal(n) for n in lens]
+    values = np.concatenate(rows)
+    offsets = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
+    params = {"approximate_entropy": ComprehensiveFCParameters()["approximate_entropy"], "sample_entropy": None}
+    names, got = emul_engine(params, values, offsets)
+    onames, want = oracle_engine(params, values, offsets)
+    assert names == onames
+    bad = compare(names, got, want, rows)
+    assert not bad, bad[:10]

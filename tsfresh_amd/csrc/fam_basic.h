@@ -165,9 +165,10 @@ TSFA_DEV void alt_fill_all(const Blk &b, XS xs, int n, const TsfaAltPlan &alt, d
         while (k1 < nkeys && alt.cl[k1] == cl && k1 - k0 < 4) ++k1;
         const int m = (n + cl - 1) / cl;
         const int ng = k1 - k0;
-        if (cl >= n) {  // fc.py: chunk_len >= len(x) -> NaN
+        if (cl >= n) {  // fc.py: chunk_len >= len(x) -> NaN, for every key of this chunk length
             blk_sync();
-            if (b.tid == 0) raw[6 * k0] = 0.0;
+            if (b.tid == 0)
+                for (int j = 0; j < ng; ++j) raw[6 * (k0 + j)] = 0.0;
             k0 = k1;
             continue;
         }

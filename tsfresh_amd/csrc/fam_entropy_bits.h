@@ -401,7 +401,7 @@ TSFA_DEV void entb_totals(const Blk &b, int kn, int k0, double *pm, double *pm1,
 // ---------------------------------------------------------------------------------------------------------------
 template <int QW_>
 TSFA_DEV void entropy_bits_batch(const Blk &b_in, const double *xs, int n, const double *thr, int nk,
-                                 const unsigned short *perm, unsigned int *work, double *racc) {
+                                 const unsigned short *perm, unsigned int *work, double *racc, int kcap_max = TSFA_ENTB_MAXK) {
     const Blk b = entb_opaque(b_in);
     const int S = QW_ + 1, QW = QW_;
     const int nrow_m = n - 1, nrow_m1 = n - 2;
@@ -420,6 +420,10 @@ TSFA_DEV void entropy_bits_batch(const Blk &b_in, const double *xs, int n, const
     // tolerances per round: all of them when the tasks fit the wavefronts' registers
     int kround = (TSFA_ENTB_MAXT * nw) / nstrips;
     if (kround > nk) kround = nk;
+    // ... and no more than the work region was sized for: the layout takes entb_kround of the LONGEST series of the
+    // launch (5 at 2500 samples), a shorter series of the same launch could fit 6 in its registers -- and wrote its sixth
+    // row of ranges past the region (found by the fuzz on a ragged batch: NaN for the last tolerance)
+    if (kround > kcap_max) kround = kcap_max;
     if (kround < 1) kround = 1;  // (the host never selects this sweep for such a shape; the counts below stay correct
                                  //  only for nstrips <= MAXT * nw)
     const int kcap = kround;     // tolerances per round: the ranges / counters of ONE round live in the work region
@@ -482,7 +486,9 @@ TSFA_DEV void entropy_bits_batch(const Blk &b_in, const double *xs, int n, const
         TSFA_TICK(tk, b, 133);
 #else
     // the emulation runs the rounds a 16-wavefront workgroup would (entb_kround): ranges and counters of ONE round at a time
-    const int kround = entb_kround(n, nk, TSFA_ENTB_MAXWAVES), kcap = kround;
+    int kround = entb_kround(n, nk, TSFA_ENTB_MAXWAVES);
+    if (kround > kcap_max) kround = kcap_max;
+    const int kcap = kround;
     for (int k0 = 0; k0 < nk; k0 += kround) {
         const int kn = (nk - k0 < kround) ? (nk - k0) : kround;
         entb_ranges<QW_ + 1>(b, xs, n, thr + k0, kn, perm, (double *)(void *)work, rng);
@@ -646,7 +652,7 @@ TSFA_DEVN void entb_sort_merge(const Blk b, const double *xs, int n, unsigned sh
 template <bool F32, int QW_ = TSFA_ENTB_QW>
 TSFA_DEV void fam_entropy_series_bits(const Blk &b, double *xs, int n, const TsfaSpec *specs, int nspecs, double *out_row,
                                       double *thr, unsigned short *perm, unsigned int *work,
-                                      unsigned short *perm_out = nullptr) {
+                                      unsigned short *perm_out = nullptr, int kcap_max = TSFA_ENTB_MAXK) {
     TSFA_TICKER(tk, 0);
     const double dn = (double)n;
     const double mean = np_sum(b, n, [=](int i) { return xs[i]; }) / dn;
@@ -685,7 +691,7 @@ TSFA_DEV void fam_entropy_series_bits(const Blk &b, double *xs, int n, const Tsf
             thr[k] = (sp.calc == TSFA_C_SAMPLE_ENTROPY) ? 0.2 * sd : sp.p[1] * sd;
         }
         blk_sync();
-        if (n >= 3) entropy_bits_batch<QW_>(b, xs, n, thr, nk, perm, work, racc);
+        if (n >= 3) entropy_bits_batch<QW_>(b, xs, n, thr, nk, perm, work, racc, kcap_max);
         for (int k = 0; k < nk; ++k) {
             const TsfaSpec sp = specs[first + k];
             EntAcc a;

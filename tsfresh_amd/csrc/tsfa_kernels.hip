@@ -322,8 +322,10 @@ __global__ void __launch_bounds__(1024) k_entropy_bits(const T *__restrict__ val
     TSFA_TICKS_BEGIN();
     Blk b{(int)threadIdx.x, (int)blockDim.x, L.red, L.np};
     stage_series(b, values + off, n, L.xs);
+    // tolerances per round: what EntropyLds sized the work region for (the longest series of the launch)
+    const int kcap = (QW_ == TSFA_ENTB_QW) ? TSFA_ENTB_MAXK : entb_kround(maxn, TSFA_ENTB_MAXK, TSFA_ENTB_MAXWAVES);
     fam_entropy_series_bits<sizeof(T) == 4, QW_>(b, L.xs, n, specs, nspecs, out + sidx * ld, L.thr, L.perm, L.cnt,
-                                            perm_buf ? perm_buf + (size_t)sidx * (size_t)perm_stride : nullptr);
+                                            perm_buf ? perm_buf + (size_t)sidx * (size_t)perm_stride : nullptr, kcap);
     TSFA_TICKS_END();
     TSFA_SERIES_END
 }
