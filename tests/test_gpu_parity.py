@@ -797,3 +797,50 @@ def test_entropy_bit_matrix_sweep_on_long_series_equals_the_pair_sweep(gpu, dtyp
     onames, want = oracle_engine(params, sub_vals.astype(np.float64), sub_offs)
     bad = compare(onames, _align(onames, names, bits[short]), want, _series(sub_vals.astype(np.float64), sub_offs))
     assert not bad, "%d mismatches, first: %s" % (len(bad), bad[:12])
+
+
+@pytest.mark.gpu
+def test_entropy_long_sweep_in_a_ragged_launch_keeps_to_its_work_region(gpu, monkeypatch):
+    """A launch of the long bit-matrix sweep sizes its work region for the longest series (2500 samples: five
+    tolerances per round); a shorter series of the same launch would fit six in its registers and used to write the
+    sixth row of ranges past the region: NaN for approximate_entropy(r = 0.9) on the 2192- and 2176-sample series
+    (found by profiles/fuzz_parity.py seed 41 on the device; the emulation now sizes the region the same way)."""
+    rng = np.random.default_rng(41)
+    lens = [1065, 2192, 2500, 1785, 2176]
+    chunks = [(79018.0 + 1.5 * rng.standard_normal(n) if i == 1 else rng.standard_normal(n)).astype(np.float32)
+              for i, n in enumerate(lens)]
+    values = np.concatenate(chunks)
+    offsets = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
+    params = {"sample_entropy": None, "approximate_entropy": [{"m": 2, "r": r} for r in (0.1, 0.3, 0.5, 0.7, 0.9)]}
+    names, bits = hip_engine(params, values, offsets)
+    assert np.all(np.isfinite(bits)), bits
+    monkeypatch.setenv("TSFA_ENT_PAIRS", "1")
+    names2, pairs = hip_engine(params, values, offsets)
+    monkeypatch.delenv("TSFA_ENT_PAIRS")
+    assert names == names2
+    assert np.allclose(bits, pairs, rtol=1e-12, atol=1e-13), np.abs(bits - pairs).max()
+    sub = [1, 4]
+    sub_vals = np.concatenate([chunks[i] for i in sub]).astype(np.float64)
+    sub_offs = np.concatenate([[0], np.cumsum([lens[i] for i in sub])]).astype(np.int64)
+    onames, want = oracle_engine(params, sub_vals, sub_offs)
+    bad = compare(onames, _align(onames, names, bits[sub]), want, _series(sub_vals, sub_offs))
+    assert not bad, bad[:12]
+
+
+@pytest.mark.gpu
+def test_trend_family_on_series_no_longer_than_the_chunk(gpu):
+    """chunk_len >= len(x): NaN for EVERY aggregate of that chunk length (the keyed evaluation clears up to four per
+    sweep; LDS keeps the previous series' values) -- and the short-series routes of index_mass_quantile next to it."""
+    rng = np.random.default_rng(77)
+    lens = [120, 1, 2, 3, 5, 5, 6, 10, 11, 49, 50, 51, 120, 5, 1024, 4]
+    rows = [np.full(5, -1062.46435546875) if i == 5 else rng.standard_normal(n) for i, n in enumerate(lens)]
+    values = np.concatenate(rows)
+    offsets = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
+    full = settings.ComprehensiveFCParameters()
+    params = {k: full[k] for k in ("agg_linear_trend", "index_mass_quantile", "linear_trend")}
+    names, got = hip_engine(params, values, offsets)
+    onames, want = oracle_engine(params, values, offsets)
+    got = _align(onames, names, got)
+    assert np.array_equal(np.isnan(got), np.isnan(want))
+    bad = compare(onames, got, want, rows)
+    assert not bad, bad[:12]
