@@ -7,6 +7,7 @@
 #include <stdint.h>
 #include <stdio.h>
 #include <string.h>
+#include <stdlib.h>
 
 #include <algorithm>
 #include <string>
@@ -23,6 +24,28 @@
 #include "../../tsfresh_amd/csrc/fam_spectral.h"
 #include "../../tsfresh_amd/csrc/tsfa_host_tables.h"
 #include "../../tsfresh_amd/csrc/tsfa_layout.h"
+
+// TSFA_EMUL_POISON=<1|2|3>: every scratch buffer of the emulation (the stand-ins for LDS, which the device never
+// clears between series) starts out as NaN / a large finite value / a small negative one instead of zeros.  The outputs
+// must not depend on it (tests/test_oracle_golden.py): a kernel that reads scratch it has not written reads the PREVIOUS
+// series' values on the device.
+static int emul_poison_mode() {
+    const char *e = getenv("TSFA_EMUL_POISON");
+    return e ? atoi(e) : 0;
+}
+static void poison(std::vector<double> &v, size_t from = 0) {
+    const int m = emul_poison_mode();
+    if (!m) return;
+    const double val = (m == 1) ? TSFA_NAN : (m == 2) ? 1.0e30 : -0.75;
+    for (size_t i = from; i < v.size(); ++i) v[i] = val;
+}
+template <class I>
+static void poison_int(std::vector<I> &v) {
+    const int m = emul_poison_mode();
+    if (!m) return;
+    const unsigned long long pat = (m == 1) ? 0x7ff800007ff80000ull : (m == 2) ? 0x3fe000003fe00000ull : 0xfffffff9fffffff9ull;
+    for (size_t i = 0; i < v.size(); ++i) v[i] = (I)pat;
+}
 
 extern "C" int tsfa_emul_calc_id(const char *name) {
     for (int i = 0; i < TSFA_N_CALCS; ++i)
@@ -75,6 +98,10 @@ extern "C" int tsfa_emul_extract_timed(const tsfa_feature_spec *specs, int n_spe
     tsfa_build_dectab(dectab);
     tsfa_build_twiddles(twc, tws);
 
+    // the device sizes a launch's LDS layout, table plans and matrix dimensions for the LONGEST series of the launch
+    // (a length class); the emulation does the same with the longest series of the call
+    int call_maxn = 1;
+    for (int64_t s = 0; s < n_series; ++s) call_maxn = std::max(call_maxn, (int)(offsets[s + 1] - offsets[s]));
     for (int64_t s = 0; s < n_series; ++s) {
         const int n = (int)(offsets[s + 1] - offsets[s]);
         const double *x = values + offsets[s];
@@ -84,15 +111,19 @@ extern "C" int tsfa_emul_extract_timed(const tsfa_feature_spec *specs, int n_spe
             snprintf(err, errlen, "empty series");
             return TSFA_ERR_INVALID;
         }
-        const int maxn = n;
+        const int maxn = (s % 3 == 1) ? n : call_maxn;   // every third series: a launch of its own
         std::vector<double> red(TSFA_RED_DOUBLES);
+        poison(red);
         NpScratch nps;
+        if (emul_poison_mode()) memset(&nps, 0x7f, sizeof nps);
         Blk b{0, 1, red.data(), &nps};
         std::vector<double> xs(x, x + n);
         xs.resize(n + 8, 0.0);
+        poison(xs, (size_t)n);
         if (!fam[TSFA_FAM_BASIC].empty()) {
             std::vector<double> w(maxn + 8), cum(maxn + 8), altc(8 * 16), ctx(32);
             std::vector<int> iw(512);
+            poison(w); poison(cum); poison(altc); poison(ctx); poison_int(iw);
             fam_basic_series<1>(b, xs.data(), n, fam[TSFA_FAM_BASIC].data(), (int)fam[TSFA_FAM_BASIC].size(), row, w.data(),
                                 (s % 2) ? w.data() : cum.data(), altc.data(), iw.data(), dectab.data(),
                                 hints[TSFA_FAM_BASIC].a, 0, hints[TSFA_FAM_BASIC].alt, nullptr, nullptr,
@@ -103,6 +134,7 @@ extern "C" int tsfa_emul_extract_timed(const tsfa_feature_spec *specs, int n_spe
             // (BasicLds: with TsfaAltPlan::small_w the work array is nt + 2 * 16 + 8 doubles whatever the length)
             std::vector<double> w(maxn + 48, TSFA_NAN), cum(maxn + 48, TSFA_NAN), altc(8 * 16), ctx(32);
             std::vector<int> iw(512, 0x3fe00000);   // poisoned with finite values: LDS keeps the previous series' contents
+            poison(w); poison(cum); poison(altc); poison(ctx); poison_int(iw);
             fam_basic_series<2>(b, xs.data(), n, fam[TSFA_FAM_TREND].data(), (int)fam[TSFA_FAM_TREND].size(), row, w.data(),
                                 (s % 2) ? w.data() : cum.data(), altc.data(), iw.data(), dectab.data(), 0,
                                 hints[TSFA_FAM_TREND].b, hints[TSFA_FAM_TREND].alt, nullptr,
@@ -110,6 +142,7 @@ extern "C" int tsfa_emul_extract_timed(const tsfa_feature_spec *specs, int n_spe
         }
         if (!fam[TSFA_FAM_SORT].empty()) {
             std::vector<double> srt(tsfa_pow2_ceil(maxn) + 8), w(1280), cq(5 * TSFA_CQ_MAX), sctx(8);
+            poison(srt); poison(w); poison(cq); poison(sctx);
             // every third series: the sorted copy as a gather through the sample order another family left behind
             // (k_entropy_bits -> k_sort on the device)
             std::vector<unsigned short> order;
@@ -130,9 +163,11 @@ extern "C" int tsfa_emul_extract_timed(const tsfa_feature_spec *specs, int n_spe
             const int nd = (maxn > 256) ? maxn : 256;
             std::vector<double> Xr(nx), Xi(nx), tc(nd), ts(nd), win(256), pxx(132);
             std::vector<int> iw(128);
+            poison(Xr); poison(Xi); poison(tc); poison(ts); poison(win); poison(pxx); poison_int(iw);
             // even series take the Bluestein route where it applies (HBM scratch on the device), odd ones the Goertzel sweep
             std::vector<double> gsv((s % 2 == 0 && n >= TSFA_BLUESTEIN_MIN && bluestein_m(n) <= TSFA_BLUESTEIN_MAXM)
                                         ? 4 * (size_t)bluestein_m(n) : 0);
+            poison(gsv);
             fam_spectral_series(b, xs.data(), n, fam[TSFA_FAM_SPECTRAL].data(), (int)fam[TSFA_FAM_SPECTRAL].size(), row,
                                 Xr.data(), Xi.data(), tc.data(), ts.data(), win.data(), pxx.data(), iw.data(),
                                 twc.data(), tws.data(), hints[TSFA_FAM_SPECTRAL].a, hints[TSFA_FAM_SPECTRAL].b,
@@ -145,6 +180,7 @@ extern "C" int tsfa_emul_extract_timed(const tsfa_feature_spec *specs, int n_spe
                 else if (sp.calc == TSFA_C_AR_COEFFICIENT) P = std::max(P, (int)sp.p[1] + 2);
             }
             std::vector<double> xc(maxn + TSFA_AR_PADL + TSFA_AR_PADR, TSFA_NAN), aw(ArLds::scratch_doubles(P));
+            poison(xc); poison(aw);
             const double *xp = xs.data();
             const int flags = fam_ar_series<double>(b, [=](int i) { return xp[i]; }, n, fam[TSFA_FAM_AR].data(),
                           (int)fam[TSFA_FAM_AR].size(), row, (void *)xc.data(), aw.data(), P, hints[TSFA_FAM_AR].a,
@@ -160,6 +196,7 @@ extern "C" int tsfa_emul_extract_timed(const tsfa_feature_spec *specs, int n_spe
             xe.resize(n + 8, 0.0);
             std::vector<unsigned short> perm(tsfa_pow2_ceil(maxn) + 96);
             std::vector<unsigned int> cnt((size_t)(maxn + 16) * 4), refs(perm.size());
+            poison(thr); poison(xe, (size_t)n); poison_int(perm); poison_int(cnt); poison_int(refs);
             // odd series exercise the ordered-pair sweep (no LDS counters), every fourth the grouped symmetric sweep
             // instead of the staged one
             bool all_m2 = true;
@@ -169,6 +206,7 @@ extern "C" int tsfa_emul_extract_timed(const tsfa_feature_spec *specs, int n_spe
             const bool bits = all_m2 && n <= TSFA_ENTB_MAXN_LONG && (force ? !strcmp(force, "bits") : (s % 4 == 2 || n > TSFA_ENTB_MAXN));
             if (bits && n <= TSFA_ENTB_MAXN) {  // the bit-matrix sweep (k_entropy_bits)
                 std::vector<unsigned int> work(entb_work_words(n) + 64);
+                poison_int(work);
                 fam_entropy_series_bits<false>(b, xe.data(), n, fam[TSFA_FAM_ENTROPY].data(), (int)fam[TSFA_FAM_ENTROPY].size(),
                                                row, thr.data(), perm.data(), work.data());
             } else if (bits) {  // ... with 16-byte table entries and tolerance rounds (series of 1025 .. 4096 samples)
@@ -205,6 +243,7 @@ extern "C" int tsfa_emul_extract_timed(const tsfa_feature_spec *specs, int n_spe
                 lz_build_group(fam[TSFA_FAM_SEQ].data() + s0, std::min(group, nsq - s0), maxn, &g);
                 std::vector<uint32_t> seqw(((size_t)g.stride + 16) / 4 + 1), tab((size_t)g.ttotal + 4);
                 std::vector<double> edges(g.etotal + 4);
+                poison_int(seqw); poison_int(tab); poison(edges);
                 fam_seq_series(b, [=](int i) { return xp[i]; }, n, g, row, (unsigned char *)seqw.data(), tab.data(),
                                edges.data());
             }
@@ -212,6 +251,7 @@ extern "C" int tsfa_emul_extract_timed(const tsfa_feature_spec *specs, int n_spe
         if (!fam[TSFA_FAM_CWT].empty()) {
             const int with_rowv = (s % 2 == 0) ? 1 : 0;  // exercise both variants
             std::vector<unsigned char> lds(CwtPeaksLayout().carve(nullptr, maxn, with_rowv) + 64);
+            poison_int(lds);
             CwtPeaksLayout L;
             unsigned char *basep = lds.data();
             basep += (16 - ((uintptr_t)basep & 15)) & 15;

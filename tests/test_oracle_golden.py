@@ -106,3 +106,28 @@ def test_emul_long_entropy_sweep_in_a_ragged_launch():
     assert names == onames
     bad = compare(names, got, want, rows)
     assert not bad, bad[:10]
+
+
+def test_emul_outputs_do_not_depend_on_what_the_scratch_held(monkeypatch):
+    """The device never clears LDS between the series a CU works through: whatever a kernel reads from its scratch
+    before writing it is the PREVIOUS series' data.  The emulation's stand-in buffers start as zeros, NaN, a huge and a
+    small negative number in turn (TSFA_EMUL_POISON); every one of the 783 columns must come out bit-identical."""
+    rng = np.random.default_rng(5)
+    lens = [1, 2, 3, 4, 5, 7, 9, 12, 17, 30, 33, 64, 100, 255, 256, 257, 300, 777, 1024, 1500]
+    rows = []
+    for i, n in enumerate(lens):
+        k = i % 5
+        rows.append(rng.standard_normal(n) if k == 0 else np.round(rng.standard_normal(n) * 2) if k == 1
+                    else np.cumsum(rng.standard_normal(n)) if k == 2 else np.full(n, 0.5) if k == 3
+                    else 1e6 + rng.standard_normal(n))
+    values = np.concatenate(rows)
+    offsets = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
+    outs = []
+    for mode in ("0", "1", "2", "3"):
+        monkeypatch.setenv("TSFA_EMUL_POISON", mode)
+        names, got = emul_engine(ComprehensiveFCParameters(), values, offsets)
+        outs.append(got)
+    for mode, got in enumerate(outs[1:], 1):
+        same = (got == outs[0]) | (np.isnan(got) & np.isnan(outs[0]))
+        bad = np.argwhere(~same)
+        assert len(bad) == 0, [(lens[r], names[c], outs[0][r, c], got[r, c]) for r, c in bad[:8]]
