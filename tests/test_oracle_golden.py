@@ -131,3 +131,17 @@ def test_emul_outputs_do_not_depend_on_what_the_scratch_held(monkeypatch):
         same = (got == outs[0]) | (np.isnan(got) & np.isnan(outs[0]))
         bad = np.argwhere(~same)
         assert len(bad) == 0, [(lens[r], names[c], outs[0][r, c], got[r, c]) for r, c in bad[:8]]
+
+
+def test_fuzz_rounds_on_the_emulated_kernel_sources():
+    """Six rounds of profiles/fuzz_parity.py (random calculator / parameter subsets on ragged batches of structured,
+    offset and rescaled series) through the g++ build of the kernel sources, its scratch poisoned: what the GPU box
+    runs with the HIP library and what found this round's defects, kept alive in the CPU suite."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, TSFA_FUZZ_ENGINE="emul", TSFA_EMUL_POISON="2")
+    out = subprocess.run([sys.executable, os.path.join(root, "profiles", "fuzz_parity.py"), "6", "2026"], env=env,
+                         capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stderr[-2000:]
+    assert "TOTAL mismatches 0" in out.stdout, out.stdout[-3000:]
