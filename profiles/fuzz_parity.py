@@ -78,7 +78,8 @@ def main():
             else:
                 sub = [p for p in pl if rng.random() < 0.6] or [pl[0]]
                 params[nm] = sub
-        maxlen = int(rng.choice([40, 300, 1024, 1024, 2500]))
+        # TSFA_FUZZ_MAXLENS="40,300,1024,1024,2500,4500": other length mixes (the default keeps a round within seconds)
+        maxlen = int(rng.choice([int(v) for v in os.environ.get("TSFA_FUZZ_MAXLENS", "40,300,1024,1024,2500").split(",")]))
         lens = rng.integers(1, maxlen + 1, size=int(rng.integers(3, 14)))
         dtype = np.float32 if rng.random() < 0.6 else np.float64
         series = [make_series(rng, int(n)).astype(dtype) for n in lens]
