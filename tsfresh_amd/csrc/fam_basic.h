@@ -1302,7 +1302,6 @@ TSFA_DEV void fam_basic_series(const Blk &b0, XS xs, int n, const TsfaSpec *spec
                 if (((int)sp.p[3]) >= 128) {
                     have_cumsum = false;  // w may alias cum ...
                     have_peaks = false;   // ... and holds the peak distances
-                peaks_p = 0;
                     peaks_p = 0;
                     alt_fill_all(b, xs, n, alt, w, (double *)(void *)iw, altc);
                 }
