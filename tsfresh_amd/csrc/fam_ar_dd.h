@@ -238,9 +238,6 @@ TSFA_DEV bool dd_needs_svd(const Blk &b, const dd *L, int p, int ld, const int *
         for (int a = b.tid; a < p; a += b.nt) v[a] = dd{v[a].hi / nrm, v[a].lo / nrm};
         blk_sync();
     }
-#if !TSFA_GPU
-    if (getenv("TSFA_DBG")) fprintf(stderr, "needs_svd p=%d lmin=%g trace=%g ratio=%g\n", p, lmin, trace, sqrt(lmin / trace));
-#endif
     return lmin < TSFA_DD_SVD_TRIGGER * TSFA_DD_SVD_TRIGGER * trace;
 }
 
