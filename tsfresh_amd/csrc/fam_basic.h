@@ -1158,9 +1158,11 @@ TSFA_DEV void fam_basic_series(const Blk &b0, XS xs, int n, const TsfaSpec *spec
             blk_sync();
             double r = TSFA_NAN;
             if (b.tid == 0) {  // np.corrcoef(benford, data)[0, 1]
-                double bd[9], dd[9], mb = 0.0, md = 0.0;
+                // np.log10(1 + 1 / d), d = 1 .. 9, as numpy returns them (fc.py:2356): nine float64 logarithms on one lane
+                // were ~1400 instructions per series in an issue-bound kernel
+                const double bd[9] = {0.3010299956639812, 0.17609125905568124, 0.12493873660829993, 0.09691001300805642, 0.07918124604762482, 0.06694678963061322, 0.05799194697768673, 0.05115252244738129, 0.04575749056067514};
+                double dd[9], mb = 0.0, md = 0.0;
                 for (int k = 0; k < 9; ++k) {
-                    bd[k] = log10(1.0 + 1.0 / (double)(k + 1));
                     dd[k] = (double)iw[k + 1] / dn;
                     mb += bd[k];
                     md += dd[k];
