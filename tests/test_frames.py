@@ -105,7 +105,7 @@ def _run(case):
 def emul_plans(monkeypatch):
     from emul_lib import EmulPlan
     from tsfresh_amd.feature_extraction import extraction
-    monkeypatch.setattr(extraction, "_acquire_plan", lambda fplan, device: EmulPlan(fplan))
+    monkeypatch.setattr(extraction, "_acquire_plan", lambda fplan, device, pins=None: EmulPlan(fplan))
 
 
 @pytest.mark.parametrize("case", CASES, ids=[c["name"] for c in CASES])
@@ -136,3 +136,58 @@ def test_shuffled_rows_give_the_same_frame(emul_plans):
     a = _run(next(c for c in CASES if c["name"] == "reference_test_data_sample"))
     b = _run(next(c for c in CASES if c["name"] == "reference_test_data_sample_shuffled"))
     pd.testing.assert_frame_equal(a, b[a.columns])
+
+
+def test_more_distinct_per_kind_plans_than_the_cache_holds(monkeypatch):
+    """A frame whose kinds compile to more distinct native plans than the per-thread LRU holds (the usual from_columns /
+    extract_relevant_features output): every plan acquired by the running call stays open until the call has used it;
+    the cache is trimmed afterwards.  (Round-3 ADVICE: the 7th acquire closed the 1st plan before it ran.)"""
+    from tsfresh_amd import _native, extract_features
+    from tsfresh_amd.feature_extraction import extraction
+
+    log = {"open": 0, "closed": 0, "ran_closed": 0}
+
+    class FakePlan:
+        def __init__(self, specs, device=0):
+            self.specs, self.closed = list(specs), False
+            log["open"] += 1
+
+        def extract_host(self, values, offsets, times=None):
+            if self.closed:
+                log["ran_closed"] += 1
+                raise RuntimeError("plan is NULL")
+            from emul_lib import emul_extract_specs
+            return emul_extract_specs(self.specs, values, offsets, times=times)
+
+        def close(self):
+            if not self.closed:
+                self.closed = True
+                log["closed"] += 1
+
+    from emul_lib import load
+    lib = load()
+    monkeypatch.setattr(_native, "Plan", FakePlan)
+    monkeypatch.setattr(_native, "calc_id", lambda name: lib.tsfa_emul_calc_id(name.encode()))  # the emulation's table
+    extraction.clear_plan_cache()
+    n_kinds = extraction._PLAN_CACHE_SIZE + 3
+    rng = np.random.default_rng(3)
+    frames = []
+    for k in range(n_kinds):
+        frames.append(pd.DataFrame({"id": np.repeat(np.arange(4), 12), "time": np.tile(np.arange(12), 4),
+                                    "kind": "k%d" % k, "value": rng.standard_normal(48)}))
+    df = pd.concat(frames, ignore_index=True)
+    k2fc = {"k%d" % k: {"quantile": [{"q": 0.1 + 0.05 * k}], "mean": None} for k in range(n_kinds)}
+    try:
+        got = extract_features(df, column_id="id", column_sort="time", column_kind="kind", column_value="value",
+                               kind_to_fc_parameters=k2fc)
+        assert log["ran_closed"] == 0 and log["open"] == n_kinds
+        assert got.shape == (4, 2 * n_kinds)
+        for k in range(n_kinds):
+            x = df[df.kind == "k%d" % k].groupby("id")["value"]
+            np.testing.assert_allclose(got["k%d__mean" % k].to_numpy(), x.mean().to_numpy(), rtol=1e-12)
+            np.testing.assert_allclose(got["k%d__quantile__q_%s" % (k, 0.1 + 0.05 * k)].to_numpy(),
+                                       x.quantile(0.1 + 0.05 * k).to_numpy(), rtol=1e-12)
+        # trimmed back after the call: only the newest _PLAN_CACHE_SIZE plans stay open
+        assert log["closed"] == 3 and len(extraction._thread_cache()) == extraction._PLAN_CACHE_SIZE
+    finally:
+        extraction.clear_plan_cache()

@@ -108,3 +108,61 @@ def test_truncation_regime_is_not_hidden_by_an_exclusion():
         x = off + rng.standard_normal(300)
         names, _ = oracle_engine(AR_ADF, x, np.array([0, len(x)]))
         assert not any(excluded(n, x) for n in names), off
+
+
+# Round-3 ADVICE (high): a plan with several Langevin fits, listed ALTERNATELY -- the kernel keeps one fit's coefficients,
+# so the plan makes the columns of one (m, r) neighbours; the records of the second pass are sized n_series x #fits.
+LANGEVIN_TWO_FITS = {
+    "friedrich_coefficients": [{"coeff": 0, "m": 3, "r": 30}, {"coeff": 0, "m": 3, "r": 20}, {"coeff": 1, "m": 3, "r": 30},
+                               {"coeff": 1, "m": 3, "r": 20}, {"coeff": 2, "m": 2, "r": 30}, {"coeff": 3, "m": 3, "r": 30},
+                               {"coeff": 2, "m": 3, "r": 20}],
+    "max_langevin_fixed_point": [{"m": 3, "r": 20}, {"m": 3, "r": 30}, {"m": 2, "r": 30}]}
+
+
+def _two_fit_series():
+    rng = np.random.default_rng(11)
+    series = []
+    for off in (0.0, 50.0, 1e3, 1e4):      # |mean| / std >= ~10: the float64 QR defers to the double-double pass
+        for n in (40, 300, 1000):
+            series.append(off + rng.standard_normal(n))
+            series.append(off + np.cumsum(rng.standard_normal(n)) * 0.1)
+    return series
+
+
+def _check_two_fits(engine):
+    series = _two_fit_series()
+    values, offsets = _pack(series)
+    names, got = engine(LANGEVIN_TWO_FITS, values, offsets)
+    onames, want = oracle_engine(LANGEVIN_TWO_FITS, values, offsets)
+    assert list(names) == list(onames)
+    bad = compare(names, got, want, series)
+    assert not bad, bad[:5]
+    # and each column equals the same column of a plan holding ONE (m, r): the grouping changes no value
+    for m, r in ((3, 30), (3, 20), (2, 30)):
+        single = {"friedrich_coefficients": [p for p in LANGEVIN_TWO_FITS["friedrich_coefficients"] if (p["m"], p["r"]) == (m, r)],
+                  "max_langevin_fixed_point": [{"m": m, "r": r}]}
+        sn, sg = engine(single, values, offsets)
+        for j, nm in enumerate(sn):
+            np.testing.assert_array_equal(sg[:, j], got[:, list(names).index(nm)], err_msg=nm)
+
+
+def test_alternating_langevin_fits_emulated():
+    _check_two_fits(emul_engine)
+
+
+@pytest.mark.gpu
+def test_alternating_langevin_fits_on_the_device(gpu):
+    """Every offset series defers all three fits: 3 records per series reach k_langevin_dd (one per distinct (m, r))."""
+    from engines import hip_engine
+    _check_two_fits(hip_engine)
+    # a batch large enough that n_series records would not have held the 3 n_series written (the old sizing)
+    rng = np.random.default_rng(12)
+    big = [1e3 + rng.standard_normal(200) for _ in range(3000)]
+    values, offsets = _pack(big)
+    names, got = hip_engine(LANGEVIN_TWO_FITS, values, offsets)
+    pick = [0, 1, 1500, 2998, 2999]
+    v2, o2 = _pack([big[i] for i in pick])
+    _, want = oracle_engine(LANGEVIN_TWO_FITS, v2, o2)
+    bad = compare(names, got[pick], want, [big[i] for i in pick])
+    assert not bad, bad[:5]
+    assert np.isfinite(got).all()

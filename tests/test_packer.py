@@ -127,6 +127,21 @@ def test_native_scan_reports_nan_values_like_the_reference():
         D.pack_timeseries(small, column_id="id", column_sort="time")
 
 
+@pytest.mark.parametrize("dtype", [np.float16, np.longdouble])
+def test_native_scan_sees_nan_in_float16_and_longdouble_columns(dtype):
+    """Round-3 ADVICE (low): element types other than float32 / float64 that CAN hold a NaN are converted before the
+    native scan, so a large frame raises the reference's ValueError (data.py:124-178) instead of yielding NaN features."""
+    n = D._NATIVE_SCAN_MIN_ROWS + 10
+    v = np.zeros(n, dtype=dtype)
+    v[n - 3] = np.nan
+    df = pd.DataFrame({"id": np.arange(n) // 100, "time": np.arange(n) % 100, "value": v})
+    with pytest.raises(ValueError, match="Column must not contain NaN values: value"):
+        D.pack_timeseries(df, column_id="id", column_sort="time")
+    df.loc[n - 3, "value"] = 1.5
+    packed, _, _ = D.pack_timeseries(df, column_id="id", column_sort="time")
+    assert packed[0].values.dtype == np.float64 and packed[0].values[n - 3] == 1.5
+
+
 def test_arrow_wide_table_is_packed_without_a_dataframe(monkeypatch):
     pa = pytest.importorskip("pyarrow")
     rng = np.random.default_rng(9)

@@ -88,7 +88,7 @@ def _relevant_features_on_device(container, y, default_fc_parameters, kind_to_fc
 
     from tsfresh_amd import _native
     from tsfresh_amd.feature_extraction.data import pack_timeseries
-    from tsfresh_amd.feature_extraction.extraction import _acquire_plan, _default_device
+    from tsfresh_amd.feature_extraction.extraction import _acquire_plan, _default_device, _thread_cache, _trim_cache
     from tsfresh_amd.feature_extraction.plan import compile_fc_parameters
     from tsfresh_amd.feature_extraction.settings import ComprehensiveFCParameters
     from tsfresh_amd.feature_selection.relevance import _relevance_table
@@ -110,7 +110,7 @@ def _relevant_features_on_device(container, y, default_fc_parameters, kind_to_fc
                 pk.kind, packed[0].kind))
     with warnings.catch_warnings():
         warnings.simplefilter("default" if show_warnings else "ignore")
-        jobs, names = [], []
+        jobs, names, pins = [], [], set()   # pins: plans held until the matrix is filled (never evicted meanwhile)
         for pk in packed:
             fc = kind_to_fc_parameters[pk.kind] if kind_to_fc_parameters and pk.kind in kind_to_fc_parameters \
                 else default_fc_parameters
@@ -119,12 +119,13 @@ def _relevant_features_on_device(container, y, default_fc_parameters, kind_to_fc
                 raise ValueError("device_resident=True cannot splice host-evaluated custom calculators into the device matrix")
             if not fplan.names:
                 continue
-            jobs.append((pk, _acquire_plan(fplan, device), len(names)))
+            jobs.append((pk, _acquire_plan(fplan, device, pins), len(names)))
             names.extend(pk.kind + "__" + n for n in fplan.names)
         dm = _native.DeviceMatrix(len(ids), len(names), device)
         try:
             for pk, nplan, col0 in jobs:
                 nplan.extract_into(pk.values, pk.offsets, dm, col0=col0, times=pk.times)
+            _trim_cache(_thread_cache())
             _native.impute_matrix(dm)  # impute(): +-inf -> column max / min, NaN -> median of the finite values
             index = pd.Index(ids)
             try:

@@ -240,6 +240,7 @@ struct FrDefer {
     int slot_doubles;
     long long sidx;     // row of this series in the output matrix
     int spec;           // index of the spec that asked for the fit (the pass reads m and r from it)
+    int cap;            // records the buffer holds (n_series x distinct (m, r) fits of the plan); a record beyond it is dropped
 };
 
 // Exact bin sums.  A value v with |v| < 2^E is split as v = hi 2^-S1 + lo, hi = rint(v 2^S1), S1 = 60 - bits - E (2^bits
@@ -446,9 +447,11 @@ TSFA_DEV void friedrich_coeffs(const Blk &b, XS xs, int n, S1 srt1, int m, int r
                 int slot = 0;
                 if (lane == 0) slot = atomicAdd(df.count, 1);
                 slot = __shfl(slot, 0);
-                double *rec = df.buf + (size_t)slot * (size_t)df.slot_doubles;
-                if (lane == 0) { rec[0] = (double)df.sidx; rec[1] = (double)df.spec; rec[2] = (double)k; }
-                if (has) { rec[TSFA_PF_HDR + row] = xm; rec[TSFA_PF_HDR + rmax + row] = ym; }
+                if (slot < df.cap) {   // (cannot fail: the plan evaluates each distinct (m, r) once per series)
+                    double *rec = df.buf + (size_t)slot * (size_t)df.slot_doubles;
+                    if (lane == 0) { rec[0] = (double)df.sidx; rec[1] = (double)df.spec; rec[2] = (double)k; }
+                    if (has) { rec[TSFA_PF_HDR + row] = xm; rec[TSFA_PF_HDR + rmax + row] = ym; }
+                }
             }   // (no buffer: the float64 fit stands; the library always passes one)
         }
     }

@@ -531,6 +531,7 @@ static int run_batch(tsfa_plan *plan, const void *d_values, int dtype, const dou
                 a.pf_slot = tsfa_pf_slot_doubles(plan->hints[f].b);
                 a.pf_buf = (double *)plan->pf_buf.p;
                 a.pf_count = plan->d_deg_count + 1;
+                a.pf_cap = (int)std::min<long long>((long long)n_series * std::max(1, plan->hints[f].e), 2147483647LL);
                 HIP_TRY(hipMemsetAsync(a.pf_count, 0, sizeof(int), fst));
             } else if (f == TSFA_FAM_ENTROPY) {
                 // one wavefront per 64-template row block, up to four per series; the symmetric sweep needs 12 B of
@@ -730,7 +731,8 @@ int tsfa_extract_windows(tsfa_plan *plan, const void *values, int32_t dtype, con
         plan->perm_buf.ensure((size_t)n_series * (size_t)TSFA_ENTB_MAXN * sizeof(unsigned short)))
         return fail(TSFA_ERR_HIP, "hipMalloc failed for the shared sample order");
     if (plan->hints[TSFA_FAM_SORT].b > 0 &&
-        plan->pf_buf.ensure((size_t)n_series * (size_t)tsfa_pf_slot_doubles(plan->hints[TSFA_FAM_SORT].b) * sizeof(double)))
+        plan->pf_buf.ensure((size_t)n_series * (size_t)std::max(1, plan->hints[TSFA_FAM_SORT].e) *
+                            (size_t)tsfa_pf_slot_doubles(plan->hints[TSFA_FAM_SORT].b) * sizeof(double)))
         return fail(TSFA_ERR_HIP, "hipMalloc failed for the records of the Langevin second pass");
 
     if (space == TSFA_DEVICE) {

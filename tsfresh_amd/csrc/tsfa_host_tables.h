@@ -150,6 +150,29 @@ static inline void tsfa_prepare_family(int fam, std::vector<TsfaSpec> &specs, Ts
                 s.calc == TSFA_C_SUM_REOCC_DATA_POINTS) { e = seen_runs; seen_runs = true; }
             (e ? epi : loop).push_back(s);
         }
+        // Langevin fits: fam_sort_series keeps the LAST fit's coefficients, so the columns of one (m, r) are made
+        // neighbours (in their own slots of the column loop; a spec carries its output column) -- every distinct (m, r)
+        // is then fitted once per series, and at most e = #distinct records per series reach the second pass
+        {
+            auto is_lv = [](const TsfaSpec &s) { return s.calc == TSFA_C_FRIEDRICH_COEFFICIENTS || s.calc == TSFA_C_MAX_LANGEVIN_FIXED_POINT; };
+            auto key = [](const TsfaSpec &s) {
+                return s.calc == TSFA_C_FRIEDRICH_COEFFICIENTS ? std::make_pair((int)s.p[1], (int)s.p[2]) : std::make_pair((int)s.p[0], (int)s.p[1]);
+            };
+            std::vector<std::pair<int, int>> order;   // distinct (m, r) by first appearance
+            std::vector<TsfaSpec> lv;
+            for (const auto &s : loop)
+                if (is_lv(s)) {
+                    lv.push_back(s);
+                    if (std::find(order.begin(), order.end(), key(s)) == order.end()) order.push_back(key(s));
+                }
+            std::stable_sort(lv.begin(), lv.end(), [&](const TsfaSpec &x, const TsfaSpec &y) {
+                return std::find(order.begin(), order.end(), key(x)) < std::find(order.begin(), order.end(), key(y));
+            });
+            size_t k = 0;
+            for (auto &s : loop)
+                if (is_lv(s)) s = lv[k++];
+            h.e = (int)order.size();
+        }
         h.c = (int)loop.size();
         // a = doubles of LDS scratch the plan needs (fam_sort.h friedrich_coeffs: 6 r + 16 + r (m + 1)), at least 320:
         // the ordinal-pattern histogram adapts to it

@@ -165,7 +165,7 @@ template <typename T>
 __global__ void __launch_bounds__(1024) k_sort(const T *__restrict__ values, const int64_t *__restrict__ starts, const int64_t *__restrict__ ends, int64_t n_series, const int *__restrict__ sel,
                        const TsfaSpec *__restrict__ specs, int nspecs, double *__restrict__ out, int64_t ld, int maxn,
                        const TsfaCqPlan cqplan, int n_loop, int w_doubles, double *__restrict__ pf_buf,
-                       int *__restrict__ pf_count, int pf_slot, const unsigned short *__restrict__ perm_buf, int perm_stride TSFA_GS_PARAMS) {
+                       int *__restrict__ pf_count, int pf_slot, int pf_cap, const unsigned short *__restrict__ perm_buf, int perm_stride TSFA_GS_PARAMS) {
     TSFA_SERIES_BEGIN
     const int64_t off = starts[sidx];
     const int n = (int)(ends[sidx] - off);
@@ -180,7 +180,7 @@ __global__ void __launch_bounds__(1024) k_sort(const T *__restrict__ values, con
         blk_sync();
     }
     fam_sort_series<T>(b, xs, n, specs, nspecs, out + sidx * ld, (T *)L.srt, L.w, L.iw, cqplan, L.cq, L.stage,
-                       n_loop, L.ctx, w_doubles, FrDefer{pf_buf, pf_count, pf_slot, (long long)sidx, 0},
+                       n_loop, L.ctx, w_doubles, FrDefer{pf_buf, pf_count, pf_slot, (long long)sidx, 0, pf_cap},
                        perm_buf ? perm_buf + (size_t)sidx * (size_t)perm_stride : nullptr);
     TSFA_TICKS_END();
     TSFA_SERIES_END
@@ -237,9 +237,9 @@ __global__ void __launch_bounds__(1024) k_ar(const T *__restrict__ values, const
 // second pass of the SORT family (fam_langevin_dd.h): one LANE per recorded fit, np.polyfit's scaled design + rank cut in
 // double-double; overwrites the friedrich_coefficients / max_langevin_fixed_point columns of the same (m, r) that k_sort
 // wrote from its float64 QR.
-__global__ void __launch_bounds__(64) k_langevin_dd(const double *__restrict__ pf_buf, const int *__restrict__ pf_count, int pf_slot,
+__global__ void __launch_bounds__(64) k_langevin_dd(const double *__restrict__ pf_buf, const int *__restrict__ pf_count, int pf_slot, int pf_cap,
                      const TsfaSpec *__restrict__ specs, int nspecs, double *__restrict__ out, int64_t ld) {
-    const int cnt = *pf_count;
+    const int cnt = min(*pf_count, pf_cap);
     const int rmax = (pf_slot - TSFA_PF_HDR) / 2;
     for (int i = blockIdx.x * 64 + threadIdx.x; i < cnt; i += gridDim.x * 64) {
         const double *rec = pf_buf + (size_t)i * (size_t)pf_slot;
@@ -863,7 +863,7 @@ static int launch_all_t(const TsfaLaunch &a, const T *values) {
         const int wd = (a.hint_a >= 320) ? a.hint_a : 1280;
         const size_t lds = L.carve(nullptr, a.maxn, nt, (int)sizeof(T), wd);
         TSFA_KLAUNCH(k_sort<T>, lds, values, a.starts, a.ends, a.n_series, a.sel, a.specs, a.nspecs, a.out, a.ld, a.maxn, a.cq,
-                     a.hint_c, wd, a.pf_buf, a.pf_count, a.pf_slot, a.perm_buf, a.perm_stride);
+                     a.hint_c, wd, a.pf_buf, a.pf_count, a.pf_slot, a.pf_cap, a.perm_buf, a.perm_stride);
     } else if (a.fam == TSFA_FAM_SPECTRAL) {
         SpectralLds L;
         const size_t lds = L.carve(nullptr, a.maxn, a.dft_n, (int)sizeof(T));
@@ -947,7 +947,7 @@ int tsfa_launch_langevin_dd(const TsfaLaunch &a) {
     if (!a.pf_buf) return 0;   // the plan holds no Langevin fit
     hipStream_t st = (hipStream_t)a.stream;
     const unsigned grid = (unsigned)std::min<int64_t>((a.n_series + 63) / 64, 4096);
-    k_langevin_dd<<<grid, 64, 0, st>>>(a.pf_buf, a.pf_count, a.pf_slot, a.specs, a.nspecs, a.out, a.ld);
+    k_langevin_dd<<<grid, 64, 0, st>>>(a.pf_buf, a.pf_count, a.pf_slot, a.pf_cap, a.specs, a.nspecs, a.out, a.ld);
     TSFA_LAUNCH_CHECK();
     return 0;
 }

@@ -56,7 +56,8 @@ struct TsfaLaunch {
     int *deg_count;         // ... and their number (device; zeroed before the launch)
     double *pf_buf;         // SORT: records of the Langevin fits left to k_langevin_dd (fam_langevin_dd.h) ...
     int *pf_count;          // ... their number (device; zeroed before the launch) ...
-    int pf_slot;            // ... and the doubles per record (tsfa_pf_slot_doubles)
+    int pf_slot;            // ... the doubles per record (tsfa_pf_slot_doubles) ...
+    int pf_cap;             // ... and the records the buffer holds (n_series x distinct (m, r) fits, hints[SORT].e)
     unsigned short *perm_buf;  // ENTROPY (bit-matrix sweep) writes / SORT reads: sample order of every series, perm_stride entries each
     int perm_stride;
     int cwt_rowv;           // CWT peaks: second CWT row resident in LDS

@@ -204,42 +204,63 @@ def extract_sharded(extract_fn, values, offsets, n_cols, dist=None, torch_device
     return full.cpu().numpy()
 
 
-# Plans of extract_on_devices, kept across calls: (shard slot, device, specs) -> (plan, lock).  The workers are fresh
+# Plans of extract_on_devices, kept across calls: (shard slot, device, specs) -> _PlanEntry.  The workers are fresh
 # threads on every call, so the per-thread cache of feature_extraction/extraction.py never hits for them: round 2 built
 # len(devices) plans per call (8 ms each) and never released them -- device memory grew with every call.  A slot's
-# plan is driven by one thread at a time (its lock); the LRU closes what it evicts.
+# plan is driven by one thread at a time (the entry's lock, under which it is also CREATED: the global lock is never held
+# across the ~8 ms of a plan build, so the devices build theirs concurrently).  An entry counts its users; the LRU only
+# evicts -- and closes -- entries nobody holds, so a worker can never be handed a plan that is closed before it runs.
+class _PlanEntry:
+    __slots__ = ("plan", "lock", "users")
+
+    def __init__(self):
+        self.plan, self.lock, self.users = None, threading.Lock(), 0
+
+
 _DEVICE_PLANS = collections.OrderedDict()
 _DEVICE_PLANS_LOCK = threading.Lock()
 _DEVICE_PLANS_MAX = 32
 
 
-def _device_plan(slot, device, specs):
-    from tsfresh_amd import _native
+def _device_plan_acquire(slot, device, specs):
+    """-> the entry of (slot, device, specs) with its user count raised; pair with _device_plan_release."""
     key = (int(slot), int(device), tuple((cid, tuple(float(v) for v in p)) for cid, p in specs))
     evicted = []
     with _DEVICE_PLANS_LOCK:
         entry = _DEVICE_PLANS.get(key)
         if entry is None:
-            entry = _DEVICE_PLANS[key] = (_native.Plan(specs, device=device), threading.Lock())
-            while len(_DEVICE_PLANS) > _DEVICE_PLANS_MAX:
-                old_key = next(k for k in _DEVICE_PLANS if k != key)
-                evicted.append(_DEVICE_PLANS.pop(old_key))
+            entry = _DEVICE_PLANS[key] = _PlanEntry()
         else:
             _DEVICE_PLANS.move_to_end(key)
-    for plan, lock in evicted:
-        with lock:  # wait for a worker that may still be inside it
-            plan.close()
+        entry.users += 1
+        if len(_DEVICE_PLANS) > _DEVICE_PLANS_MAX:
+            for old_key in [k for k, e in _DEVICE_PLANS.items() if e.users == 0]:
+                if len(_DEVICE_PLANS) <= _DEVICE_PLANS_MAX:
+                    break
+                evicted.append(_DEVICE_PLANS.pop(old_key))   # unreachable from here on, and nobody is inside it
+    for old in evicted:
+        with old.lock:
+            if old.plan is not None:
+                old.plan.close()
+                old.plan = None
     return entry
 
 
-def clear_device_plans():
-    """Release the plans extract_on_devices keeps (and the device memory they hold)."""
+def _device_plan_release(entry):
     with _DEVICE_PLANS_LOCK:
-        entries = list(_DEVICE_PLANS.values())
-        _DEVICE_PLANS.clear()
-    for plan, lock in entries:
-        with lock:
-            plan.close()
+        entry.users -= 1
+
+
+def clear_device_plans():
+    """Release the idle plans extract_on_devices keeps (and the device memory they hold)."""
+    with _DEVICE_PLANS_LOCK:
+        keys = [k for k, e in _DEVICE_PLANS.items() if e.users == 0]
+        entries = [_DEVICE_PLANS.pop(k) for k in keys]
+    for e in entries:
+        with e.lock:
+            if e.plan is not None:
+                e.plan.close()
+                e.plan = None
 
 
 def extract_on_devices(specs, values, offsets, devices, times=None, n_cols=None):
@@ -264,14 +285,20 @@ def extract_on_devices(specs, values, offsets, devices, times=None, n_cols=None)
         lo, hi = int(bounds[k]), int(bounds[k + 1])
         if hi <= lo:
             return
+        entry = None
         try:
-            plan, lock = _device_plan(k, dev, specs)
+            entry = _device_plan_acquire(k, dev, specs)
             sub = offsets[lo:hi + 1]
-            with lock:
-                plan.extract_host(values[sub[0]:sub[-1]], sub - sub[0],
-                                  times=None if times is None else times[sub[0]:sub[-1]], out=out[lo:hi])
+            with entry.lock:
+                if entry.plan is None:
+                    entry.plan = _native.Plan(specs, device=dev)
+                entry.plan.extract_host(values[sub[0]:sub[-1]], sub - sub[0],
+                                        times=None if times is None else times[sub[0]:sub[-1]], out=out[lo:hi])
         except BaseException as e:  # surfaced in the calling thread
             errors.append(e)
+        finally:
+            if entry is not None:
+                _device_plan_release(entry)
 
     threads = [threading.Thread(target=work, args=(k, d), name="tsfresh_amd-dev%d" % d) for k, d in enumerate(devices)]
     for t in threads:

@@ -89,9 +89,12 @@ def _pack_presorted(kind, ids, values, sort_values, index, nan_name=None):
         return None
     if len(ids) >= _NATIVE_SCAN_MIN_ROWS:
         # one multi-threaded native pass: layout proof + group boundaries + the NaN check of the value column
-        # (a float column as it is; any other element type cannot hold a NaN and is only converted -- a full copy --
-        # once the layout is proven, so an unsorted integer frame is not converted twice)
+        # (a float32 / float64 column as it is; float16 / longdouble -- which CAN hold a NaN -- converted first, so that
+        # the scan sees them; integer and bool columns cannot hold one and are only converted -- a full copy -- once the
+        # layout is proven, so an unsorted integer frame is not converted twice)
         raw = np.asarray(values)
+        if raw.dtype.kind == "f" and raw.dtype.itemsize not in (4, 8):
+            raw = _as_values(raw)
         scanned = raw if raw.dtype.kind == "f" and raw.dtype.itemsize in (4, 8) else None
         sv = None if sort_values is None else np.asarray(sort_values)
         res = _native.pack_scan(ids, sv, scanned)

@@ -52,23 +52,36 @@ def _thread_cache():
     return cache
 
 
-def _acquire_plan(fplan, device):
-    return _acquire_plan_specs(fplan.native_specs(_native.calc_id), device)
+def _acquire_plan(fplan, device, pins=None):
+    return _acquire_plan_specs(fplan.native_specs(_native.calc_id), device, pins)
 
 
-def _acquire_plan_specs(specs, device):
+def _trim_cache(cache, pins=()):
+    """Close the oldest plans beyond _PLAN_CACHE_SIZE, never one whose key is in `pins` (the plans the running call
+    still holds: a frame of more than _PLAN_CACHE_SIZE kinds with distinct settings keeps them all until it returns)."""
+    if len(cache) <= _PLAN_CACHE_SIZE:
+        return
+    for key in [k for k in cache if k not in pins]:
+        if len(cache) <= _PLAN_CACHE_SIZE:
+            break
+        cache.pop(key).close()  # this thread's own, idle plan
+
+
+def _acquire_plan_specs(specs, device, pins=None):
+    """The calling thread's cached native plan for `specs` on `device`.  `pins`: a set the caller owns for the duration
+    of ONE extract call; every key acquired through it is exempt from eviction until the caller trims the cache."""
     specs = list(specs)
     key = (int(device), tuple((cid, tuple(float(v) for v in p)) for cid, p in specs))
     cache = _thread_cache()
+    if pins is not None:
+        pins.add(key)
     plan = cache.get(key)
     if plan is not None:
         cache.move_to_end(key)
         return plan
     plan = _native.Plan(specs, device=device)
     cache[key] = plan
-    while len(cache) > _PLAN_CACHE_SIZE:
-        _, old = cache.popitem(last=False)  # this thread's own, idle plan
-        old.close()
+    _trim_cache(cache, pins if pins is not None else (key,))
     return plan
 
 
@@ -153,6 +166,7 @@ def extract_features(
 
         blocks = []  # (PackedKind, column names, matrix)
         plan_cache = {}
+        pins = set()  # native plans this call holds: not evictable before it returns
         jobs = []    # (PackedKind, FeaturePlan, native plan or None)
         for pk in packed:
             if kind_to_fc_parameters and pk.kind in kind_to_fc_parameters:
@@ -163,7 +177,8 @@ def extract_features(
             key = (id(fc_parameters), kind_has_dt)
             if key not in plan_cache:
                 fplan = compile_fc_parameters(fc_parameters, has_datetime_index=kind_has_dt)
-                nplan = _acquire_plan(fplan, device) if fplan.names else None
+                multi_dev = devices is not None and len(devices) > 1   # extract_on_devices keeps its own plans
+                nplan = _acquire_plan(fplan, device, pins) if fplan.names and not multi_dev else None
                 plan_cache[key] = (fplan, nplan)
             fplan, nplan = plan_cache[key]
             if len(fplan) == 0:
@@ -211,6 +226,7 @@ def extract_features(
             # user-defined calculators (callable keys): per series on the host, spliced in at their dict position
             names, matrix = fplan.finish(matrix, lambda i, pk=pk: pk.values[pk.offsets[i]:pk.offsets[i + 1]], pk.n_series)
             blocks.append((pk, [pk.kind + "__" + name for name in names], matrix))
+        _trim_cache(_thread_cache())
 
     return _assemble(blocks, id_dtype, pivot, impute_function)
 
@@ -292,7 +308,7 @@ def extract_rolled_features(timeseries_container, column_id=None, column_sort=No
     # container is rolled entry by entry (:430-445), each entry with the longest series of its own frame
     per_kind_steps = isinstance(timeseries_container, dict)
     steps_all = max(int(np.diff(pk.offsets).max()) for pk in packed if pk.n_series)
-    blocks, plan_cache = [], {}
+    blocks, plan_cache, pins = [], {}, set()
     with warnings.catch_warnings():
         warnings.simplefilter("default" if show_warnings else "ignore")
         for pk in packed:
@@ -306,7 +322,7 @@ def extract_rolled_features(timeseries_container, column_id=None, column_sort=No
                     from tsfresh_amd.feature_extraction.registry import UnsupportedFeature
                     raise UnsupportedFeature("custom (callable) calculators are evaluated per series on the host: roll the "
                                              "frame with roll_time_series and call extract_features on it")
-                plan_cache[key] = (fplan, _acquire_plan(fplan, device) if len(fplan) else None)
+                plan_cache[key] = (fplan, _acquire_plan(fplan, device, pins) if len(fplan) else None)
             fplan, nplan = plan_cache[key]
             if nplan is None:
                 continue
@@ -330,4 +346,5 @@ def extract_rolled_features(timeseries_container, column_id=None, column_sort=No
             matrix = nplan.extract_windows_host(pk.values, starts, ends, times=pk.times)
             order = sorted(range(len(ids)), key=lambda i: ids[i])
             blocks.append((_WindowBlock(pk.kind, ids[order]), [pk.kind + "__" + n for n in fplan.names], matrix[order]))
+        _trim_cache(_thread_cache())
     return _assemble(blocks, np.dtype(object), pivot, impute_function)
