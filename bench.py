@@ -1,7 +1,7 @@
 #!/usr/bin/env python
 """Headline benchmark: series/sec of the feature-extraction hot path (BASELINE.json metric).
 
-    python bench.py --gpus 1 --steps K --warmup W
+    python bench.py --gpus N --steps K --warmup W          (N > 1 without a launcher: bench.py starts its own ranks)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
         bench.py --gpus N --steps K --warmup W
 
@@ -168,10 +168,10 @@ def parity_sample(pool, rows_in, rows_out, names, params_name):
     return "ok" if not bad else "fail: %d of %d cells, first %s" % (len(bad), want.size, bad[:3])
 
 
-def e2e_block(plan, fplan, params_cls, n, L):
+def e2e_block(plan, fplan, params_cls, n, L, calls=4):
     """Boundary timings beside the HBM-resident `value`: the same plan on HOST buffers (PCIe-inclusive:
     chunked H2D / kernels / D2H pipeline of tsfa_extract(TSFA_HOST)) and DataFrame in -> DataFrame out through
-    extract_features (packer + host path + frame construction).  Best of 3 after one warm call."""
+    extract_features (packer + host path + frame construction).  Best of `calls - 1` after one warm call."""
     import warnings
 
     import pandas as pd
@@ -182,7 +182,7 @@ def e2e_block(plan, fplan, params_cls, n, L):
     plan.set_length_hint(0, 0)
     res = {"n_series": n, "length": L}
     best = None
-    for _ in range(4):
+    for _ in range(calls):
         t0 = time.perf_counter()
         m = plan.extract_host(x.reshape(-1), offsets)
         dt = time.perf_counter() - t0
@@ -193,7 +193,7 @@ def e2e_block(plan, fplan, params_cls, n, L):
     best = None
     with warnings.catch_warnings():
         warnings.simplefilter("ignore")
-        for _ in range(4):
+        for _ in range(calls):
             t0 = time.perf_counter()
             f = extract_features(df, column_id="id", column_sort="time", default_fc_parameters=params_cls())
             dt = time.perf_counter() - t0
@@ -203,6 +203,27 @@ def e2e_block(plan, fplan, params_cls, n, L):
     res["dataframe"] = {"seconds": best, "series_per_sec": n / best, "rows_in": int(n * L),
                         "equals_host_buffer_result": bool(same)}
     return res
+
+
+def free_port():
+    import socket
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as sk:
+        sk.bind(("127.0.0.1", 0))
+        return sk.getsockname()[1]
+
+
+def self_launch_command(n_ranks, argv, port):
+    """argv and environment that run this file as `n_ranks` processes, one per GPU, on this node -- what the driver's
+    launcher form does (`python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1
+    --master-port P bench.py ...`).  The reference's counterpart is the worker pool of its MultiprocessingDistributor
+    (tsfresh/utilities/distribution.py:438-494)."""
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(int(n_ranks)),
+           "--master-addr", "127.0.0.1", "--master-port", str(int(port)), os.path.abspath(__file__)] + list(argv)
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC: RCCL's P2P buffers across processes need it here
+    env.setdefault("OMP_NUM_THREADS", "1")
+    env["TSFA_BENCH_LAUNCHED"] = "1"
+    return cmd, env
 
 
 def main():
@@ -227,6 +248,13 @@ def main():
                          "being extracted (0 = 8 when N > 1, else 1)")
     args = ap.parse_args()
 
+    # `python bench.py --gpus N` (no launcher): start N ranks of this file and hand back their exit code; rank 0 of the
+    # child job prints the one JSON line.  Under a launcher (WORLD_SIZE set) this is skipped.
+    if "WORLD_SIZE" not in os.environ and (args.gpus > 1 or os.environ.get("TSFA_BENCH_SELF_LAUNCH")):
+        import subprocess
+        cmd, env = self_launch_command(args.gpus, sys.argv[1:], free_port())
+        raise SystemExit(subprocess.call(cmd, env=env))
+
     import torch
     from tsfresh_amd import _native
     from tsfresh_amd.feature_extraction import settings
@@ -245,7 +273,16 @@ def main():
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         dist_mod.init_process_group(backend="nccl", device_id=dev)
         dist = dist_mod
-    assert world == args.gpus, "launch with --nproc-per-node equal to --gpus"
+    if world != args.gpus:
+        raise SystemExit("bench.py: --gpus %d but the launcher started %d ranks (use --nproc-per-node %d, or run "
+                         "`python bench.py --gpus %d` without a launcher)" % (args.gpus, world, args.gpus, args.gpus))
+    ranks_seen = None
+    if dist is not None:
+        # "did RCCL see N ranks": a sum of ones over the communicator, next to torch's own world size
+        ones = torch.ones(1, device=dev, dtype=torch.int32)
+        dist.all_reduce(ones)
+        ranks_seen = int(ones.item())
+        assert ranks_seen == dist.get_world_size() == world, (ranks_seen, dist.get_world_size(), world)
 
     cls = {"comprehensive": settings.ComprehensiveFCParameters, "efficient": settings.EfficientFCParameters,
            "minimal": settings.MinimalFCParameters}[args.params]
@@ -255,24 +292,29 @@ def main():
         fplan = compile_fc_parameters(cls())
     n_cols = len(fplan)
 
+    # BASELINE.md 3.4's recipe: np.random.default_rng(seed).standard_normal((n, L), dtype=float32), seed = 42 (+ rank:
+    # every rank its own shard), drawn on the host and copied to the device BEFORE the clock
     n, L = args.n_series, args.length
-    gen = torch.Generator(device=dev)
-    gen.manual_seed(42 + rank)
+    rng = np.random.default_rng(42 + rank)
     if args.ragged:
         lo, hi = (int(t) for t in args.ragged.split(":"))
-        lens = torch.randint(lo, hi + 1, (n,), device=dev, generator=gen, dtype=torch.int64)
-        offsets = torch.zeros(n + 1, device=dev, dtype=torch.int64)
-        offsets[1:] = torch.cumsum(lens, 0)
-        total = int(offsets[-1].item())
+        lens = rng.integers(lo, hi + 1, size=n, dtype=np.int64)
+        h_offsets = np.zeros(n + 1, dtype=np.int64)
+        np.cumsum(lens, out=h_offsets[1:])
+        total = int(h_offsets[-1])
         L = total // n  # mean length, for the byte accounting below
-        values = torch.randn(total, device=dev, dtype=torch.float32, generator=gen)
+        h_values = rng.standard_normal(total, dtype=np.float32)
     else:
-        values = torch.randn(n * L, device=dev, dtype=torch.float32, generator=gen)  # i.i.d. N(0,1) float32 series
-        offsets = torch.arange(0, (n + 1) * L, L, device=dev, dtype=torch.int64)
-        if args.walk:
-            values = torch.cumsum(values.view(n, L).double(), dim=1).float().reshape(-1).contiguous()
+        h_values = rng.standard_normal((n, L), dtype=np.float32)  # i.i.d. N(0,1) float32 series
+        h_offsets = np.arange(n + 1, dtype=np.int64) * L
+        if args.walk:   # tests/benchmark.py:22 of the reference: randn().cumsum()
+            h_values = np.cumsum(h_values.astype(np.float64), axis=1).astype(np.float32)
+        h_values = h_values.reshape(-1)
     if args.offset:
-        values = (values.double() + args.offset).float().contiguous()
+        h_values = (h_values.astype(np.float64) + args.offset).astype(np.float32)
+    values = torch.from_numpy(np.ascontiguousarray(h_values)).to(dev)
+    offsets = torch.from_numpy(h_offsets).to(dev)
+    del h_values
     # The product pipeline (tsfresh_amd/distributed.py: ShardPipeline): the shard is extracted in row chunks on two
     # alternating launch streams (a plan each); with N > 1 every finished chunk is exchanged (RCCL all-gather into a
     # staging block + device scatter into the rank-major matrix) while the next chunk is being extracted, so only the
@@ -341,12 +383,13 @@ def main():
             except Exception:  # noqa: BLE001
                 rccl = None
             gathered = (world - 1) * n * n_cols * 8
-            multi = {"world": world, "backend": "nccl (RCCL %s)" % rccl, "row_chunks": n_chunks,
+            multi = {"world": dist.get_world_size(), "ranks_seen_by_rccl": ranks_seen,
+                     "backend": "nccl (RCCL %s)" % rccl, "row_chunks": n_chunks,
                      "compute_only_ms_per_step": compute_ms, "exchange_ms_exposed": ms_per_step - compute_ms,
                      "bytes_received_per_rank_per_step": gathered,
                      "exchange_gbs_per_rank_if_fully_exposed": gathered / max((ms_per_step - compute_ms) * 1e-3, 1e-9) / 1e9}
         except Exception as e:  # noqa: BLE001
-            multi = {"world": world, "error": repr(e)}
+            multi = {"world": dist.get_world_size(), "ranks_seen_by_rccl": ranks_seen, "error": repr(e)}
 
     # ---- per-kernel HIP-event timings (events recorded on the launch stream), 2 profiled passes ----
     plan.set_profiling(True)
@@ -387,6 +430,8 @@ def main():
             roof = {"bound": "hbm", "kernel": kname, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": achieved / HBM_PEAK_GBS,
                     "traffic": measured_hbm_traffic(kname, {"n_series_per_gpu": n, "length": L, "n_cols": n_cols}),
+                    "traffic_source": "profiles/hbm_traffic.json (builder-measured: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE "
+                                      "passes of this command, profiles/pmc_hbm.sh; replayed, not re-measured in this run)",
                     "kernel_ms": kt[dom],
                     "algorithmic_bytes_per_launch": alg_bytes,
                     "note": notes.get(kname, "compute-side bound: see DESIGN.md roofline section"),
@@ -406,7 +451,10 @@ def main():
                        "row_chunks_per_step": n_chunks},
             "kernel_ms": kt, "outputs_finite": finite, "roofline": roof,
         }
+        if multi is None and dist is not None:   # a world of one through the distributed code path
+            multi = {"world": dist.get_world_size(), "ranks_seen_by_rccl": ranks_seen, "row_chunks": n_chunks}
         if multi is not None:
+            multi["self_launched"] = bool(os.environ.get("TSFA_BENCH_LAUNCHED"))
             line["multi_gpu"] = multi
         line["nonfinite_columns"] = nonfinite_cols
         params_name = args.params.capitalize() + "FCParameters"
@@ -427,6 +475,9 @@ def main():
             line["parity_sample"] = parity_sample(pool, rows_in, rows_out, fplan.names, params_name)
         if world == 1 and not args.ragged and not args.no_e2e:
             line["e2e"] = e2e_block(plan, fplan, cls, min(n, 20_000), L)
+            if n > 20_000 and n * L <= 110_000_000:
+                # the headline shape itself: configs[2] as a long frame is 102 M rows
+                line["e2e_headline"] = e2e_block(plan, fplan, cls, n, L, calls=3)
         if pool is not None:
             line["cpu_baseline"] = cpu_baseline(pool, workers, L, params_name, seed=42)
             pool.close()
