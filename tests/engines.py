@@ -13,6 +13,43 @@ def oracle_engine(fc_parameters, values, offsets, kind="value", times=None):
     return oracle_matrix(np.asarray(values, dtype=np.float64), offsets, fc_parameters, kind=kind, times=times)
 
 
+_PARALLEL_CACHE = {}
+
+
+def _oracle_one(job):
+    fc_parameters, x, kind = job
+    return oracle_engine(fc_parameters, x, np.array([0, len(x)], dtype=np.int64), kind=kind)
+
+
+def oracle_engine_parallel(fc_parameters, values, offsets, kind="value", times=None, workers=None):
+    """oracle_engine with the series dealt over worker processes (longest first): the reference's own arithmetic is
+    O(n^2) in memory and time for the entropies, so a handful of 4096 .. 8192-sample series is minutes on one core."""
+    import hashlib
+    import multiprocessing as mp
+    import os
+    assert times is None
+    values = np.asarray(values, dtype=np.float64)
+    n = len(offsets) - 1
+    # the fixture pairs `long` and `long_nosimd` hold the same series: the oracle runs once per session for both
+    key = (hashlib.sha1(values.tobytes() + np.asarray(offsets, dtype=np.int64).tobytes()).hexdigest(), kind,
+           repr(sorted((k, repr(v)) for k, v in dict(fc_parameters).items())))
+    if key in _PARALLEL_CACHE:
+        names, out = _PARALLEL_CACHE[key]
+        return list(names), out.copy()
+    order = sorted(range(n), key=lambda i: -(offsets[i + 1] - offsets[i]))
+    jobs = [(fc_parameters, values[offsets[i]:offsets[i + 1]], kind) for i in order]
+    workers = workers or min(os.cpu_count() or 1, 8, max(n, 1))
+    with mp.get_context("spawn").Pool(workers) as pool:
+        res = pool.map(_oracle_one, jobs, chunksize=1)
+    names = res[0][0]
+    out = np.empty((n, len(names)))
+    for i, (nm, row) in zip(order, res):
+        assert list(nm) == list(names)
+        out[i] = row[0]
+    _PARALLEL_CACHE[key] = (list(names), out.copy())
+    return names, out
+
+
 def emul_engine(fc_parameters, values, offsets, kind="value", times=None):
     from emul_lib import emul_extract
     return emul_extract(fc_parameters, values, offsets, kind=kind, times=times)

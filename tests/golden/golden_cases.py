@@ -87,7 +87,43 @@ def offset_series():
     return cases
 
 
-CASE_SETS = {"main": golden_series, "degenerate": degenerate_series, "offset": offset_series}
+def long_series():
+    """Series beyond 1024 samples (BASELINE configs[4] is 4096 .. 8192): the reference changes algorithm there --
+    agg_autocorrelation switches to an FFT autocorrelation past 1250 samples (fc.py:421-429), ADF's maxlag grows with n
+    (fc.py:499-545: 12 (n / 100)^(1/4)), the CWT-peak noise window grows with n (fc.py:1320-1340), the entropy sweeps
+    leave the kernels' 1024- and 4096-sample classes, the FFTs leave the power-of-two path.  Lengths just past every
+    switch; iid / walk / tie-heavy / constant / periodic; float32 and float64; and three windows of ONE walk, the rolled
+    layout of configs[4] (dataframe_functions.py:340-372)."""
+    rng = np.random.default_rng(20260925)
+    f32 = lambda x: np.asarray(x, dtype=np.float32).astype(np.float64)   # noqa: E731
+    cases = [
+        ("randn_f32_1025", f32(rng.standard_normal(1025))),
+        ("randn_f32_1251", f32(rng.standard_normal(1251))),
+        ("walk_f64_1251", np.cumsum(rng.standard_normal(1251))),
+        ("const_1300", np.full(1300, 2.5)),
+        ("randn_f32_2048", f32(rng.standard_normal(2048))),
+        ("walk_f32_2048", f32(np.cumsum(rng.standard_normal(2048)))),
+        ("ties_1dec_3000", np.round(rng.standard_normal(3000), 1)),
+        ("sine_noise_3000", np.sin(np.arange(3000) * 0.02) + 0.05 * rng.standard_normal(3000)),
+        ("randn_f64_4096", rng.standard_normal(4096)),
+        ("walk_f32_4096", f32(np.cumsum(rng.standard_normal(4096)) * 0.1)),
+        ("randn_f32_4097", f32(rng.standard_normal(4097))),
+        ("ints_dup_5000", rng.integers(-3, 4, size=5000).astype(np.float64)),
+        ("randn_f32_8192", f32(rng.standard_normal(8192))),
+        ("walk_f64_8192", np.cumsum(rng.standard_normal(8192))),
+        ("ar1_f32_6000", None),
+    ]
+    e = rng.standard_normal(6000)
+    for t in range(1, 6000):
+        e[t] += 0.9 * e[t - 1]
+    cases[-1] = ("ar1_f32_6000", f32(e))
+    walk = f32(np.cumsum(rng.standard_normal(5200)) * 0.05 + 20.0)
+    for lo, hi in ((0, 4096), (1000, 5096), (1104, 5200)):   # windows of one series, as roll_time_series cuts them
+        cases.append(("rolled_walk_%d_%d" % (lo, hi), walk[lo:hi].copy()))
+    return cases
+
+
+CASE_SETS = {"main": golden_series, "degenerate": degenerate_series, "offset": offset_series, "long": long_series}
 
 
 def pack(cases):

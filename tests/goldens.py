@@ -7,6 +7,7 @@ offsets, series, labels) tuples.
   degenerate      ref_main_degenerate.npz + ref_conda_degenerate  True
   degenerate_nosimd  ref_main_degenerate_nosimd.npz + ...         False
   offset / offset_nosimd   ref_main_offset*.npz + ref_conda_offset.npz   (|mean| >> spread: the rank cuts of np.polyfit / pinv)
+  long            ref_main_long.npz + ref_conda_long.npz          True  (1025 .. 8192 samples, rolled windows of one walk)
 """
 import os
 
@@ -21,6 +22,10 @@ PAIRS = {
     "degenerate_nosimd": ("ref_main_degenerate_nosimd.npz", "ref_conda_degenerate.npz", False),
     "offset": ("ref_main_offset.npz", "ref_conda_offset.npz", True),
     "offset_nosimd": ("ref_main_offset_nosimd.npz", "ref_conda_offset.npz", False),
+    # series of 1025 .. 8192 samples (BASELINE configs[4]; golden_cases.long_series): past the reference's FFT switch of
+    # agg_autocorrelation, ADF's growing maxlag, the growing CWT-peak noise window, the kernels' length classes
+    "long": ("ref_main_long.npz", "ref_conda_long.npz", True),
+    "long_nosimd": ("ref_main_long_nosimd.npz", "ref_conda_long.npz", False),
 }
 
 
