@@ -14,6 +14,7 @@ from tsfresh_amd.feature_extraction import settings
 
 pytestmark = pytest.mark.gpu
 G = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def _series(values, offsets):
@@ -315,7 +316,7 @@ def test_config5_ragged_8192_efficient(gpu):
     """configs[4] shape: ragged rolled windows, lengths uniform on [4096, 8192], EfficientFCParameters.
     The longest series switches every kernel to multi-wavefront workgroups with the LDS carved for 8192 samples."""
     rng = np.random.default_rng(44)
-    n = 96
+    n = 2000      # (configs[4] is 50 000 over 4 GPUs = 12 500 per GPU; 2 000 ragged series = 12 M samples fill every CU several times)
     lens = rng.integers(4096, 8193, size=n)
     lens[0], lens[1] = 8192, 4096
     walk = np.cumsum(rng.standard_normal(int(lens.max()) + n, dtype=np.float32)).astype(np.float32)
@@ -330,8 +331,11 @@ def test_config5_ragged_8192_efficient(gpu):
     params = settings.EfficientFCParameters()
     names, got = hip_engine(params, values, offsets)
     assert got.shape == (n, 777)
-    rows = [0, 1, 2, 3, 4, 5, 6]
-    onames, want = _sample_parity(params, series, rows)
+    rows = [0, 1, 2, 3, 4, 5, 6] + [7 + 79 * k for k in range(25)]     # 32 rows: the special ones + a spread over the launch groups
+    from engines import oracle_engine_parallel
+    vals = np.concatenate([series[i] for i in rows]).astype(np.float64)
+    offs = np.concatenate([[0], np.cumsum([len(series[i]) for i in rows])]).astype(np.int64)
+    onames, want = oracle_engine_parallel(params, vals, offs)
     bad = compare(onames, _align(onames, names, got[rows]), want, [series[i].astype(np.float64) for i in rows])
     assert not bad, "%d mismatches, first: %s" % (len(bad), bad[:12])
     col = {nm: i for i, nm in enumerate(names)}
@@ -844,3 +848,22 @@ def test_trend_family_on_series_no_longer_than_the_chunk(gpu):
     assert np.array_equal(np.isnan(got), np.isnan(want))
     bad = compare(onames, got, want, rows)
     assert not bad, bad[:12]
+
+
+@pytest.mark.gpu
+def test_every_cell_is_written_by_a_kernel(gpu, monkeypatch):
+    """The feature matrix is not pre-filled with NaN (k_fill_nan rewrote 0.63 GB per step): every kernel
+    writes every one of its columns for every series.  Audit with a sentinel pre-fill (TSFA_DEBUG_FILL) over lengths
+    0 .. 4097, Comprehensive + a stress set of parameters + Minimal, float32 / float64, iid / walk / constant / zero /
+    non-finite series: no cell may keep the sentinel; and the control -- a family whose launch is skipped keeps it."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("fill_audit", os.path.join(ROOT, "profiles", "fill_audit.py"))
+    fa = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(fa)          # sets TSFA_DEBUG_FILL for the plans it creates
+    try:
+        assert fa.positive_control()
+        lengths = [0, 1, 2, 3, 4, 5, 7, 10, 16, 21, 22, 23, 33, 64, 100, 255, 256, 257, 1000, 1024, 1025, 2049, 4097]
+        kept = fa.audit(lengths)
+        assert not kept, kept
+    finally:
+        os.environ.pop("TSFA_DEBUG_FILL", None)

@@ -92,6 +92,17 @@ struct tsfa_plan {
     bool profiling = false;
     std::vector<Timing> timings;
     long long hint_min_len = 0, hint_max_len = 0;  // tsfa_plan_set_length_hint: skip the length scan (and its host sync)
+    // Every family kernel writes every one of its columns for every series (NaN where the reference yields NaN): audited
+    // with a sentinel pre-fill over lengths 1 .. 8192, three parameter sets, both sample types, constant / non-finite
+    // series (profiles/fill_audit.py, tests/test_gpu_parity.py::test_every_cell_is_written_by_a_kernel), so the matrix is
+    // NOT pre-filled (round 3 rewrote all of it, 0.63 GB per 100 000 x 783, for nothing).  fill_all (TSFA_FILL_ALL=1, or
+    // a TSFA_DEBUG_FILL sentinel) restores the pre-fill; d_fill_cols would list single columns should a kernel ever
+    // need them.
+    bool fill_all = false;
+    int *d_fill_cols = nullptr;
+    int n_fill_cols = 0;
+    int debug_skip_fam = -1;             // TSFA_DEBUG_SKIP_FAM=<family>: the audit's positive control
+    double fill_value = __builtin_nan("");   // TSFA_DEBUG_FILL=<value>: a sentinel instead (profiles/fill_audit.py)
 };
 
 static const char *fam_names[TSFA_N_FAMILIES] = {"k_basic", "k_sort", "k_spectral", "k_ar", "k_entropy", "k_cwtpeaks", "k_seq", "k_trend"};
@@ -264,6 +275,9 @@ int tsfa_plan_create(const tsfa_feature_spec *specs, int32_t n_specs, int32_t de
                  hipEventCreateWithFlags(&plan->ev_join[i], hipEventDisableTiming) == hipSuccess;
         if (ok && plan->n_streams > 1) ok = hipEventCreateWithFlags(&plan->ev_fork, hipEventDisableTiming) == hipSuccess;
     }
+    if (const char *e = getenv("TSFA_DEBUG_FILL")) { plan->fill_value = atof(e); plan->fill_all = true; }
+    if (const char *e = getenv("TSFA_FILL_ALL")) plan->fill_all = plan->fill_all || atoi(e) != 0;
+    if (const char *e = getenv("TSFA_DEBUG_SKIP_FAM")) plan->debug_skip_fam = atoi(e);
     if (!ok) {
         tsfa_plan_destroy(plan);
         return fail(TSFA_ERR_HIP, "device allocation/upload failed while creating the plan");
@@ -396,7 +410,10 @@ static int host_len_stats(const int64_t *starts, const int64_t *ends, int64_t n,
 static int run_batch(tsfa_plan *plan, const void *d_values, int dtype, const double *d_times, const int64_t *d_starts,
                      const int64_t *d_ends, int64_t n_series, double *d_out, int64_t ld, const BatchShape &sh,
                      const int *d_sel, hipStream_t st, bool with_overlap) {
-    if (tsfa_launch_fill_nan(d_out, n_series, plan->n_cols, ld, st)) return fail(TSFA_ERR_HIP, "fill launch failed");
+    if ((plan->fill_all || plan->n_fill_cols > 0) &&
+        tsfa_launch_fill_nan(d_out, n_series, plan->n_cols, ld, st, plan->fill_value, plan->fill_all ? nullptr : plan->d_fill_cols,
+                             plan->n_fill_cols))
+        return fail(TSFA_ERR_HIP, "fill launch failed");
 
     // Launch order: longest kernels first.  With side streams (and no per-kernel timing requested) the families are
     // dealt round-robin over the streams after a fork event; the join events bring them back to `st`.
@@ -420,6 +437,7 @@ static int run_batch(tsfa_plan *plan, const void *d_values, int dtype, const dou
     for (int fi = 0; fi < TSFA_N_FAMILIES; ++fi) {
         const int f = order[fi];
         if (plan->fam_specs[f].empty()) continue;
+        if (plan->debug_skip_fam == f) continue;   // diagnostics (profiles/fill_audit.py): this family's cells keep the fill
         if (f == TSFA_FAM_BASIC && plan->stream_ok) {
             bool all = true;
             for (int g = 0; g < sh.n_groups; ++g) all = all && stream_done[g];

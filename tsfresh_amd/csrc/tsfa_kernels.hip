@@ -733,16 +733,24 @@ k_cwt_gemm(const T *__restrict__ values, const int64_t *__restrict__ starts, con
 }
 
 // the plan's n_cols columns of every row (leading dimension ld >= n_cols: the cells beyond belong to the caller)
-__global__ void k_fill_nan(double *__restrict__ out, int64_t n_rows, int64_t n_cols, int64_t ld) {
+__global__ void k_fill_nan(double *__restrict__ out, int64_t n_rows, int64_t n_cols, int64_t ld, double value) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
     if (ld == n_cols) {
-        for (int64_t k = i; k < n_rows * n_cols; k += stride) out[k] = TSFA_NAN;
+        for (int64_t k = i; k < n_rows * n_cols; k += stride) out[k] = value;
     } else {
         for (int64_t k = i; k < n_rows * n_cols; k += stride) {
             const int64_t r = k / n_cols;
-            out[r * ld + (k - r * n_cols)] = TSFA_NAN;
+            out[r * ld + (k - r * n_cols)] = value;
         }
+    }
+}
+// the listed columns only (a plan whose kernels write every other cell themselves)
+__global__ void k_fill_cols(double *__restrict__ out, int64_t n_rows, const int *__restrict__ cols, int n_fill, int64_t ld, double value) {
+    const int64_t total = n_rows * (int64_t)n_fill;
+    for (int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; k < total; k += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t r = k / n_fill;
+        out[r * ld + cols[k - r * n_fill]] = value;
     }
 }
 
@@ -1061,8 +1069,13 @@ int tsfa_launch_cwt(const TsfaCwtLaunch &a) {
     return launch_cwt_t<double>(a, (const double *)a.values);
 }
 
-int tsfa_launch_fill_nan(double *out, int64_t n_rows, int64_t n_cols, int64_t ld, void *stream) {
-    k_fill_nan<<<2048, 256, 0, (hipStream_t)stream>>>(out, n_rows, n_cols, ld);
+int tsfa_launch_fill_nan(double *out, int64_t n_rows, int64_t n_cols, int64_t ld, void *stream, double value,
+                         const int *cols, int n_fill) {
+    if (cols == nullptr) k_fill_nan<<<2048, 256, 0, (hipStream_t)stream>>>(out, n_rows, n_cols, ld, value);
+    else if (n_fill > 0) {
+        const int64_t total = n_rows * (int64_t)n_fill;
+        k_fill_cols<<<(unsigned)std::min<int64_t>((total + 255) / 256, 2048), 256, 0, (hipStream_t)stream>>>(out, n_rows, cols, n_fill, ld, value);
+    }
     TSFA_LAUNCH_CHECK();
     return 0;
 }

@@ -93,7 +93,10 @@ int tsfa_launch_stream(const TsfaLaunch &a);         // BASIC closed forms + med
 int tsfa_stream_calc_ok(int calc);                   // is the calculator one of those k_stream serves?
 int tsfa_launch_order_stats(const TsfaLaunch &a);    // SORT family holding only median / quantile columns, maxn <= 2048  // second pass of TSFA_FAM_AR over the series the first listed
 int tsfa_launch_cwt(const TsfaCwtLaunch &a);
-int tsfa_launch_fill_nan(double *out, int64_t n_rows, int64_t n_cols, int64_t ld, void *stream);
+// value: NaN (a diagnostics run may ask for a sentinel: TSFA_DEBUG_FILL).  cols / n_fill: only these columns (device list);
+// cols == nullptr: every column of the plan
+int tsfa_launch_fill_nan(double *out, int64_t n_rows, int64_t n_cols, int64_t ld, void *stream, double value,
+                         const int *cols, int n_fill);
 int tsfa_launch_len_stats(const int64_t *starts, const int64_t *ends, int64_t n_series, long long *stats, void *stream);
 int tsfa_launch_class_fill(const int64_t *starts, const int64_t *ends, int64_t n_series, const TsfaClassMap &g, int *cursor,
                            int *sel, void *stream);
