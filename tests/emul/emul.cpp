@@ -97,6 +97,8 @@ extern "C" int tsfa_emul_extract_timed(const tsfa_feature_spec *specs, int n_spe
     std::vector<double> dectab, twc, tws;
     tsfa_build_dectab(dectab);
     tsfa_build_twiddles(twc, tws);
+    std::vector<double> consts;
+    tsfa_build_consts(consts);
 
     // the device sizes a launch's LDS layout, table plans and matrix dimensions for the LONGEST series of the launch
     // (a length class); the emulation does the same with the longest series of the call
@@ -171,7 +173,7 @@ extern "C" int tsfa_emul_extract_timed(const tsfa_feature_spec *specs, int n_spe
             fam_spectral_series(b, xs.data(), n, fam[TSFA_FAM_SPECTRAL].data(), (int)fam[TSFA_FAM_SPECTRAL].size(), row,
                                 Xr.data(), Xi.data(), tc.data(), ts.data(), win.data(), pxx.data(), iw.data(),
                                 twc.data(), tws.data(), hints[TSFA_FAM_SPECTRAL].a, hints[TSFA_FAM_SPECTRAL].b,
-                                gsv.empty() ? nullptr : gsv.data());
+                                gsv.empty() ? nullptr : gsv.data(), (s % 2 == 0) ? consts.data() + TSFA_CONSTS_HANN : nullptr);
         }
         if (!fam[TSFA_FAM_AR].empty()) {
             int P = 8;
@@ -256,6 +258,7 @@ extern "C" int tsfa_emul_extract_timed(const tsfa_feature_spec *specs, int n_spe
             unsigned char *basep = lds.data();
             basep += (16 - ((uintptr_t)basep & 15)) & 15;
             L.carve(basep, maxn, with_rowv);
+            L.p.rk = (s % 2 == 0) ? consts.data() + TSFA_CONSTS_RICKER : nullptr;   // every other series from the plan's table
             const double *xp = xs.data();
             fam_cwtpeaks_series<double>(b, [=](int i) { return xp[i]; }, n, fam[TSFA_FAM_CWT].data(), (int)fam[TSFA_FAM_CWT].size(),
                                 row, L.p);

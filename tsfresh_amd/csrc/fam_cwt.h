@@ -28,6 +28,13 @@ TSFA_DEV double ricker_tap(int points, double a, int k) {
     return A * mod * gauss;
 }
 
+// the same tap from the plan's table (rk: Ricker part of tsfa_build_consts, or null) when the width has its full 10 w
+// points -- every width of a series longer than 10 W; shorter series truncate the wavelet and evaluate it
+TSFA_DEV double ricker_tap_t(const double *rk, int points, int w, int k) {
+    if (rk != nullptr && points == 10 * w && w <= 16) return rk[5 * w * (w - 1) + k];
+    return ricker_tap(points, (double)w, k);
+}
+
 // scipy.signal.convolve(x, h, mode="same")[c] for len(h) = nw <= n: full[c + (nw-1)/2], full[m] = sum_k h[k] x[m-k]
 template <class X>
 TSFA_DEV double conv_same_at(X xv, int n, const double *h, int nw, int c) {
@@ -50,6 +57,7 @@ TSFA_DEV double conv_same_at(X xv, int n, const double *h, int nw, int c) {
 struct CwtPeaksLds {
     double *red; double *row0; double *rowv; double *taps; void *xpad; unsigned short *mask; unsigned short *lcol;
     unsigned short *linf; unsigned short *colmap; unsigned short *mline; int *misc;
+    const double *rk = nullptr;   // the plan's Ricker tap table (tsfa_build_consts + TSFA_CONSTS_RICKER; global memory), or null
 };
 
 // linf packing: length (6 bits, saturating), gap (2 bits), retired flag, last row (4 bits)
@@ -148,7 +156,7 @@ TSFA_DEV void cwt_rows_tiled(const Blk &b, XA xat, int n, int W, const CwtPeaksL
     double *edge = (double *)L.lcol;   // edge[2 g] / edge[2 g + 1]: first / last output of columns 4 g .. 4 g + 3
     for (int w = 1; w <= W; ++w) {
         const int nw = (10 * w < n) ? 10 * w : n;
-        for (int k = b.tid; k < nw; k += b.nt) L.taps[k] = ricker_tap(nw, (double)w, k);  // tap of sample offset k
+        for (int k = b.tid; k < nw; k += b.nt) L.taps[k] = ricker_tap_t(L.rk, nw, w, k);  // tap of sample offset k
         blk_sync();
         const int lead = (nw - 1) - (nw - 1) / 2;  // out[c] = sum_t taps[t] x[c - lead + t]
         const unsigned short bit = (unsigned short)(1u << (w - 1));
@@ -278,7 +286,7 @@ TSFA_DEV double cwt_filter_list(const Blk &b, X xv, int n, const CwtPeaksLds &L,
                 const double *tw = L.taps + 5 * (w - 2) * (w + 1);  // sum_{v=2}^{w-1} 10 v
                 for (int kk = kk1; kk >= kk0; --kk) acc += xv(m2 - kk) * tw[kk];
             } else {
-                for (int kk = kk1; kk >= kk0; --kk) acc += xv(m2 - kk) * ricker_tap(nw, (double)w, nw - 1 - kk);
+                for (int kk = kk1; kk >= kk0; --kk) acc += xv(m2 - kk) * ricker_tap_t(L.rk, nw, w, nw - 1 - kk);
             }
             sig = acc;
         }
@@ -427,7 +435,7 @@ TSFA_DEV double number_cwt_peaks_one(const Blk &b, X xv, int n, int W, const Cwt
         for (int w = 2; w <= W; ++w) {
             const int nw = 10 * w;
             double *tw = L.taps + 5 * (w - 2) * (w + 1);
-            for (int k = b.tid; k < nw; k += b.nt) tw[k] = ricker_tap(nw, (double)w, nw - 1 - k);
+            for (int k = b.tid; k < nw; k += b.nt) tw[k] = ricker_tap_t(L.rk, nw, w, nw - 1 - k);
         }
         blk_sync();
     }

@@ -325,7 +325,8 @@ TSFA_DEV void blk_rfft_bluestein(const Blk &b, int n, G g, double *Xr, double *X
 //   xcap : doubles available in Xr and in Xi (the parallel form needs a 256-double slice per wavefront)
 template <class ST>
 TSFA_DEV int blk_welch(const Blk &b, const ST *xs, int n, double *win, double *pxx, double *Xr, double *Xi,
-                       double *tc, double *ts, const double *twc, const double *tws, int xcap = 0) {
+                       double *tc, double *ts, const double *twc, const double *tws, int xcap = 0,
+                       const double *hann256 = nullptr) {
     const int nper = (n < 256) ? n : 256;
     const int nover = nper / 2;
     const int step = nper - nover;
@@ -335,8 +336,13 @@ TSFA_DEV int blk_welch(const Blk &b, const ST *xs, int n, double *win, double *p
     double w2 = 0.0;
     for (int j = b.tid; j < nper; j += b.nt) {
         // scipy.signal.windows.general_cosine(M, [0.5, 0.5], sym=False): fac = linspace(-pi, pi, M + 1)[:M]
-        const double fac = np_linspace_at(-M_PI, M_PI, nper + 1, j);
-        const double wv = (nper <= 1) ? 1.0 : (0.5 + 0.5 * cos(fac));  // _len_guards: M <= 1 -> ones
+        // (the 256-sample window -- every series of 256 samples or more -- comes from the plan's table: tsfa_build_consts)
+        double wv;
+        if (nper == 256 && hann256 != nullptr) wv = hann256[j];
+        else {
+            const double fac = np_linspace_at(-M_PI, M_PI, nper + 1, j);
+            wv = (nper <= 1) ? 1.0 : (0.5 + 0.5 * cos(fac));  // _len_guards: M <= 1 -> ones
+        }
         win[j] = wv;
         w2 += wv * wv;
     }
@@ -409,7 +415,7 @@ template <class ST>
 TSFA_DEV void fam_spectral_series(const Blk &b, const ST *xs_raw, int n, const TsfaSpec *specs, int nspecs,
                                   double *out_row, double *Xr, double *Xi, double *tc, double *ts, double *win,
                                   double *pxx, int *iw, const double *twc, const double *tws, int flags, int nlead,
-                                  double *gs = nullptr) {
+                                  double *gs = nullptr, const double *hann256 = nullptr) {
     const XsView<ST> xs{xs_raw};
     // flags / nlead come from tsfa_prepare_family (host): the Welch-based specs are the first nlead of the list
     const bool need_fft = (flags & 1) != 0, need_welch = (flags & 2) != 0;
@@ -421,7 +427,7 @@ TSFA_DEV void fam_spectral_series(const Blk &b, const ST *xs_raw, int n, const T
     double pmax = 0.0, pmin = 0.0;
     bool pnan = false;
     if (need_welch) {
-        npx = blk_welch(b, xs_raw, n, win, pxx, Xr, Xi, tc, ts, twc, tws, (n / 2 + 2 > 260) ? n / 2 + 2 : 260);
+        npx = blk_welch(b, xs_raw, n, win, pxx, Xr, Xi, tc, ts, twc, tws, (n / 2 + 2 > 260) ? n / 2 + 2 : 260, hann256);
         double mx = -TSFA_INF, mn = TSFA_INF, nn = 0.0;
         for (int k = b.tid; k < npx; k += b.nt) {
             mx = fmax(mx, pxx[k]);

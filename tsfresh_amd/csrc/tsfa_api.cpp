@@ -74,7 +74,7 @@ struct tsfa_plan {
     TsfaCwtBank bank;  // cwt_coefficients
     double *d_W = nullptr;
     int *d_cols = nullptr, *d_coeff = nullptr;
-    double *d_dectab = nullptr, *d_twc = nullptr, *d_tws = nullptr;
+    double *d_dectab = nullptr, *d_twc = nullptr, *d_tws = nullptr, *d_consts = nullptr;
     long long *d_stats = nullptr;
     DevBuf values, offsets, out, gscratch, times, deg_list, sel, long_scratch, pf_buf, perm_buf;
     int *d_deg_count = nullptr;
@@ -159,6 +159,7 @@ void tsfa_plan_destroy(tsfa_plan *plan) {
     if (plan->d_dectab) (void)hipFree(plan->d_dectab);
     if (plan->d_twc) (void)hipFree(plan->d_twc);
     if (plan->d_tws) (void)hipFree(plan->d_tws);
+    if (plan->d_consts) (void)hipFree(plan->d_consts);
     if (plan->d_stats) (void)hipFree(plan->d_stats);
     if (plan->d_deg_count) (void)hipFree(plan->d_deg_count);
     if (plan->d_cursor) (void)hipFree(plan->d_cursor);
@@ -258,6 +259,9 @@ int tsfa_plan_create(const tsfa_feature_spec *specs, int32_t n_specs, int32_t de
         tsfa_build_dectab(dt);
         tsfa_build_twiddles(twc, tws);
         ok = upload(dt, &plan->d_dectab) == 0 && upload(twc, &plan->d_twc) == 0 && upload(tws, &plan->d_tws) == 0;
+        std::vector<double> consts;
+        tsfa_build_consts(consts);
+        ok = ok && upload(consts, &plan->d_consts) == 0;
     }
     if (ok) ok = hipMalloc((void **)&plan->d_stats, TSFA_LEN_STATS * sizeof(long long)) == hipSuccess;
     if (ok) ok = hipMalloc((void **)&plan->d_deg_count, 2 * sizeof(int)) == hipSuccess;   // [k_ar_degenerate, k_langevin_dd]
@@ -496,6 +500,7 @@ static int run_batch(tsfa_plan *plan, const void *d_values, int dtype, const dou
             a.dectab = plan->d_dectab;
             a.times = d_times;
             a.twc = plan->d_twc;
+            a.consts = plan->d_consts;
             a.tws = plan->d_tws;
             a.hint_a = plan->hints[f].a;
             a.hint_b = plan->hints[f].b;

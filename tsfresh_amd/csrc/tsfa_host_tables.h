@@ -40,6 +40,32 @@ static inline void tsfa_build_dectab(std::vector<double> &tab) {
         }
 }
 
+// Per-plan constants the kernels used to recompute for every series (~4 % of k_spectral and of k_cwtpeaks):
+//   [0, 256)                 the periodic Hann window of scipy.signal.welch's 256-sample segments
+//                            (scipy.signal.windows.general_cosine(256, [0.5, 0.5], sym=False))
+//   [256 + 5 w (w - 1) + k]  Ricker tap k of width w with 10 w points (fc.py:1307 _ricker), w = 1 .. TSFA_CONSTS_MAXW
+//   (offsets: TSFA_CONSTS_* in tsfa_specs.h)
+static inline void tsfa_build_consts(std::vector<double> &c) {
+    c.assign(TSFA_CONSTS_N, 0.0);
+    for (int j = 0; j < 256; ++j) {
+        // fac = np.linspace(-pi, pi, 257)[j] = j * step + start (numpy's expression)
+        const double step = (M_PI - (-M_PI)) / 256.0;
+        const double fac = (double)j * step + (-M_PI);
+        c[TSFA_CONSTS_HANN + j] = 0.5 + 0.5 * cos(fac);
+    }
+    for (int w = 1; w <= TSFA_CONSTS_MAXW; ++w) {
+        const int points = 10 * w;
+        const double a = (double)w;
+        const double A = 2.0 / (sqrt(3.0 * a) * pow(M_PI, 0.25));
+        const double wsq = a * a;
+        for (int k = 0; k < points; ++k) {
+            const double vec = (double)k - ((double)points - 1.0) / 2.0;
+            const double xsq = vec * vec;
+            c[TSFA_CONSTS_RICKER + 5 * w * (w - 1) + k] = A * (1.0 - xsq / wsq) * exp(-xsq / (2.0 * wsq));
+        }
+    }
+}
+
 // twc[j] = cos(2 pi j / N), tws[j] = -sin(2 pi j / N), j < N/2, N = 65536; octant symmetry keeps the table exact
 // under the symmetries a radix-2 FFT relies on
 static inline void tsfa_build_twiddles(std::vector<double> &twc, std::vector<double> &tws) {

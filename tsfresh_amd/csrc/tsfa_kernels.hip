@@ -190,7 +190,8 @@ template <typename T>
 __global__ void __launch_bounds__(1024) k_spectral(const T *__restrict__ values, const int64_t *__restrict__ starts, const int64_t *__restrict__ ends, int64_t n_series, const int *__restrict__ sel,
                            const TsfaSpec *__restrict__ specs, int nspecs, double *__restrict__ out, int64_t ld,
                            int maxn, int dft_n, double *__restrict__ gscratch, int gscratch_n,
-                           const double *__restrict__ twc, const double *__restrict__ tws, int hint_a, int hint_b TSFA_GS_PARAMS) {
+                           const double *__restrict__ twc, const double *__restrict__ tws, int hint_a, int hint_b,
+                           const double *__restrict__ consts TSFA_GS_PARAMS) {
     TSFA_SERIES_BEGIN
     const int64_t off = starts[sidx];
     const int n = (int)(ends[sidx] - off);
@@ -207,7 +208,7 @@ __global__ void __launch_bounds__(1024) k_spectral(const T *__restrict__ values,
     // gscratch: one slot of gscratch_n doubles per workgroup for the Bluestein FFTs of long series (or null)
     double *gs = gscratch ? gscratch + (size_t)blockIdx.x * (size_t)gscratch_n : nullptr;
     fam_spectral_series<T>(b, xs, n, specs, nspecs, out + sidx * ld, L.Xr, L.Xi, L.tc, L.ts, L.win, L.pxx, L.iw, twc, tws,
-                        hint_a, hint_b, gs);
+                        hint_a, hint_b, gs, consts ? consts + TSFA_CONSTS_HANN : nullptr);
     TSFA_TICKS_END();
     TSFA_SERIES_END
 }
@@ -351,12 +352,13 @@ __global__ void __launch_bounds__(256) k_seq(const T *__restrict__ values, const
 template <typename T, int MAXT>
 __global__ void __launch_bounds__(MAXT, (MAXT == 256) ? 6 : 4) k_cwtpeaks(const T *__restrict__ values, const int64_t *__restrict__ starts, const int64_t *__restrict__ ends, int64_t n_series, const int *__restrict__ sel,
                            const TsfaSpec *__restrict__ specs, int nspecs, double *__restrict__ out, int64_t ld,
-                           int maxn, int with_rowv TSFA_GS_PARAMS) {
+                           int maxn, int with_rowv, const double *__restrict__ consts TSFA_GS_PARAMS) {
     TSFA_SERIES_BEGIN
     const int64_t off = starts[sidx];
     const int n = (int)(ends[sidx] - off);
     CwtPeaksLayout L;
     L.carve(tsfa_base, maxn, with_rowv, (int)sizeof(T));
+    L.p.rk = consts ? consts + TSFA_CONSTS_RICKER : nullptr;
     TSFA_TICKS_BEGIN();
     Blk b{(int)threadIdx.x, (int)blockDim.x, L.p.red, nullptr};
     const T *g = values + off;
@@ -876,7 +878,7 @@ static int launch_all_t(const TsfaLaunch &a, const T *values) {
         SpectralLds L;
         const size_t lds = L.carve(nullptr, a.maxn, a.dft_n, (int)sizeof(T));
         TSFA_KLAUNCH(k_spectral<T>, lds, values, a.starts, a.ends, a.n_series, a.sel, a.specs, a.nspecs, a.out, a.ld, a.maxn,
-                     a.dft_n, a.gscratch, a.gscratch_n, a.twc, a.tws, a.hint_a, a.hint_b);
+                     a.dft_n, a.gscratch, a.gscratch_n, a.twc, a.tws, a.hint_a, a.hint_b, a.consts);
     } else if (a.fam == TSFA_FAM_AR) {
         ArLds L;
         const size_t lds = L.carve(nullptr, a.maxn, a.ar_P, (int)sizeof(T));
@@ -912,10 +914,10 @@ static int launch_all_t(const TsfaLaunch &a, const T *values) {
         const size_t lds = L.carve(nullptr, a.maxn, a.cwt_rowv, (int)sizeof(T));
         if (nt <= 256) {
             auto kfn = k_cwtpeaks<T, 256>;
-            TSFA_KLAUNCH(kfn, lds, values, a.starts, a.ends, a.n_series, a.sel, a.specs, a.nspecs, a.out, a.ld, a.maxn, a.cwt_rowv);
+            TSFA_KLAUNCH(kfn, lds, values, a.starts, a.ends, a.n_series, a.sel, a.specs, a.nspecs, a.out, a.ld, a.maxn, a.cwt_rowv, a.consts);
         } else {
             auto kfn = k_cwtpeaks<T, 1024>;
-            TSFA_KLAUNCH(kfn, lds, values, a.starts, a.ends, a.n_series, a.sel, a.specs, a.nspecs, a.out, a.ld, a.maxn, a.cwt_rowv);
+            TSFA_KLAUNCH(kfn, lds, values, a.starts, a.ends, a.n_series, a.sel, a.specs, a.nspecs, a.out, a.ld, a.maxn, a.cwt_rowv, a.consts);
         }
     } else {
         return -1;

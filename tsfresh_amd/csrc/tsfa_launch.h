@@ -54,6 +54,7 @@ struct TsfaLaunch {
     int ar_has_coef;        // AR: the plan holds ar_coefficient columns
     long long *deg_list;    // AR: series listed for the double-double second pass ((index << 2) | calculator bits) ...
     int *deg_count;         // ... and their number (device; zeroed before the launch)
+    const double *consts;   // SPECTRAL / CWT peaks: the plan's constant tables (tsfa_build_consts), device memory
     double *pf_buf;         // SORT: records of the Langevin fits left to k_langevin_dd (fam_langevin_dd.h) ...
     int *pf_count;          // ... their number (device; zeroed before the launch) ...
     int pf_slot;            // ... the doubles per record (tsfa_pf_slot_doubles) ...

@@ -178,4 +178,10 @@ struct TsfaSpec {
 #define TSFA_PF_HDR 3
 static inline int tsfa_pf_slot_doubles(int rmax) { return TSFA_PF_HDR + 2 * rmax; }
 
+// offsets into the plan's constant tables (tsfa_host_tables.h: tsfa_build_consts)
+#define TSFA_CONSTS_HANN 0
+#define TSFA_CONSTS_RICKER 256
+#define TSFA_CONSTS_MAXW 16
+#define TSFA_CONSTS_N (256 + 5 * TSFA_CONSTS_MAXW * (TSFA_CONSTS_MAXW + 1))
+
 #endif
