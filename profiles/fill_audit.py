@@ -21,7 +21,7 @@ from tsfresh_amd import _native  # noqa: E402
 from tsfresh_amd.feature_extraction import settings  # noqa: E402
 from tsfresh_amd.feature_extraction.plan import compile_fc_parameters  # noqa: E402
 
-LENGTHS = [0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 15, 16, 17, 20, 21, 22, 23, 24, 31, 32, 33, 45, 63, 64, 65, 100, 127, 128, 129,
+LENGTHS = [1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 15, 16, 17, 20, 21, 22, 23, 24, 31, 32, 33, 45, 63, 64, 65, 100, 127, 128, 129,
            200, 255, 256, 257, 300, 511, 512, 513, 1000, 1023, 1024, 1025, 1251, 2047, 2048, 2049, 3000, 4096, 4097, 5000, 8192]
 
 

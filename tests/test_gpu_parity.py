@@ -854,7 +854,7 @@ def test_trend_family_on_series_no_longer_than_the_chunk(gpu):
 def test_every_cell_is_written_by_a_kernel(gpu, monkeypatch):
     """The feature matrix is not pre-filled with NaN (k_fill_nan rewrote 0.63 GB per step): every kernel
     writes every one of its columns for every series.  Audit with a sentinel pre-fill (TSFA_DEBUG_FILL) over lengths
-    0 .. 4097, Comprehensive + a stress set of parameters + Minimal, float32 / float64, iid / walk / constant / zero /
+    1 .. 4097 (the API rejects empty series), Comprehensive + a stress set of parameters + Minimal, float32 / float64, iid / walk / constant / zero /
     non-finite series: no cell may keep the sentinel; and the control -- a family whose launch is skipped keeps it."""
     import importlib.util
     spec = importlib.util.spec_from_file_location("fill_audit", os.path.join(ROOT, "profiles", "fill_audit.py"))
@@ -862,7 +862,7 @@ def test_every_cell_is_written_by_a_kernel(gpu, monkeypatch):
     spec.loader.exec_module(fa)          # sets TSFA_DEBUG_FILL for the plans it creates
     try:
         assert fa.positive_control()
-        lengths = [0, 1, 2, 3, 4, 5, 7, 10, 16, 21, 22, 23, 33, 64, 100, 255, 256, 257, 1000, 1024, 1025, 2049, 4097]
+        lengths = [1, 2, 3, 4, 5, 7, 10, 16, 21, 22, 23, 33, 64, 100, 255, 256, 257, 1000, 1024, 1025, 2049, 4097]
         kept = fa.audit(lengths)
         assert not kept, kept
     finally:

@@ -152,8 +152,7 @@ inline void lz_build_group(const TsfaSpec *specs, int nb, int maxn, TsfaSeqGroup
     }
     g->stride = sbytes;
     g->ttotal = t;
-    g->etotal = 0;   // no edge table: the edges are evaluated in closed form (lz_symbol)
-    (void)e;
+    g->etotal = e;
 }
 
 // Lockstep parse of the calling lane's chain with a DIRECT16 table.  All lanes of the wavefront that call this walk the
@@ -314,41 +313,6 @@ TSFA_DEV int lz_parse_bits(const unsigned char *sq, int n, int bins, int nbt, in
     return count;
 }
 
-// ---------------------------------------------------------------------------------------------------------------
-// Symbols without an edge table.  edges = np.linspace(vmin, vmax, bins + 1)[1:] is a closed form of its index, so
-// np.searchsorted(edges, x, side="left") = #{j : edge_j < x} comes from an estimate and two corrections instead of a
-// bisection over a table in LDS: no edge array (1 KB per series at bins 2 / 3 / 5 / 10 / 100: LDS is what caps the series
-// in flight, and the series in flight are what the latency-bound parse lives on), ~3 edge evaluations per symbol
-// instead of log2(bins) + 1 dependent LDS reads.
-// ---------------------------------------------------------------------------------------------------------------
-// np.linspace(vmin, vmax, bins + 1)[j + 1]: the j-th edge (np_linspace_at with the step formed once)
-TSFA_DEV double lz_edge(double vmin, double vmax, int bins, double step, int j) {
-    if (j + 1 == bins) return vmax;
-    if (step == 0.0) return ((double)(j + 1) / (double)bins) * (vmax - vmin) + vmin;
-    return (double)(j + 1) * step + vmin;
-}
-// (j + 1) * step + vmin is non-decreasing in j (rounding is monotone); only the last edge -- vmax itself -- could break
-// the order, if the one before it rounded above vmax.  On sorted edges the count below IS numpy's bisection result;
-// otherwise the bisection is replayed on the closed-form edges (the same probes, the same edge values).
-TSFA_DEV bool lz_edges_sorted(double vmin, double vmax, int bins, double step) {
-    return bins < 2 || lz_edge(vmin, vmax, bins, step, bins - 2) <= vmax;
-}
-TSFA_DEV int lz_symbol(double x, double vmin, double vmax, int bins, double step, double inv, bool sorted) {
-    if (sorted) {
-        const double est = (x - vmin) * inv;   // any estimate is corrected below (inv = bins / (vmax - vmin), may be inf / NaN)
-        int c = (est >= 0.0) ? ((est < (double)bins) ? (int)est : bins) : 0;   // NaN: 0
-        while (c > 0 && !(lz_edge(vmin, vmax, bins, step, c - 1) < x)) --c;
-        while (c < bins && lz_edge(vmin, vmax, bins, step, c) < x) ++c;
-        return c;
-    }
-    int lo = 0, hi = bins;
-    while (lo < hi) {
-        const int mid = (lo + hi) >> 1;
-        if (lz_edge(vmin, vmax, bins, step, mid) < x) lo = mid + 1; else hi = mid;
-    }
-    return lo;
-}
-
 // Evaluate one group of SEQ specs for one series.
 //   x(i)   : sample accessor (the kernel reads HBM directly: the series is only touched twice)
 //   seq    : LDS bytes,   >= g.stride, 4-byte aligned
@@ -368,28 +332,36 @@ TSFA_DEV void fam_seq_series(const Blk &b, X xv, int n, const TsfaSeqGroup &g, d
     const int nb = g.nb;
     blk_sync();
     TSFA_TICK(tk, b, 160);
-    for (int k = b.tid; k < g.ttotal; k += b.nt) tab[k] = 0u;
-    TSFA_TICK(tk, b, 161);
-    // symbols: np.searchsorted(np.linspace(min, max, bins + 1)[1:], x, side="left"), edges in closed form (lz_symbol)
-    // a thread bins two neighbouring samples (a 4-bit row packs them into one byte)
-    (void)edges;
-#pragma unroll 1
-    for (int t = 0; t < nb; ++t) {
+    // bin edges: np.linspace(min, max, bins + 1)[1:]
+#pragma unroll
+    for (int t = 0; t < TSFA_LZ_MAX_GROUP; ++t) {
+        if (t >= nb) continue;
         const int bins = g.bins[t];
-        const double step = (vmax - vmin) / (double)bins;
-        const double inv = (double)bins / (vmax - vmin);
-        const bool sorted = lz_edges_sorted(vmin, vmax, bins, step);
-        unsigned char *row = seq + g.soff[t];
-        const bool packed = (g.sbits[t] == 4);
-        for (int i = 2 * b.tid; i < n; i += 2 * b.nt) {
-            const bool two = (i + 1 < n);
-            const int s0 = lz_symbol(xv(i), vmin, vmax, bins, step, inv, sorted);
-            const int s1 = two ? lz_symbol(xv(i + 1), vmin, vmax, bins, step, inv, sorted) : 0;
-            if (packed) {
-                row[i >> 1] = (unsigned char)(s0 | (s1 << 4));
+        for (int k = b.tid; k < bins; k += b.nt) edges[g.eoff[t] + k] = np_linspace_at(vmin, vmax, bins + 1, k + 1);
+    }
+    for (int k = b.tid; k < g.ttotal; k += b.nt) tab[k] = 0u;
+    blk_sync();
+    TSFA_TICK(tk, b, 161);
+    // symbols: np.searchsorted(edges, x, side="left") = #{edges < x}
+    // a thread bins two neighbouring samples (a 4-bit row packs them into one byte)
+    for (int i = 2 * b.tid; i < n; i += 2 * b.nt) {
+        const bool two = (i + 1 < n);
+        const double x0 = xv(i), x1 = two ? xv(i + 1) : x0;
+#pragma unroll
+        for (int t = 0; t < TSFA_LZ_MAX_GROUP; ++t) {
+            if (t >= nb) continue;
+            const double *ed = edges + g.eoff[t];
+            int lo0 = 0, hi0 = g.bins[t], lo1 = 0, hi1 = g.bins[t];
+            while (lo0 < hi0 || lo1 < hi1) {
+                if (lo0 < hi0) { const int mid = (lo0 + hi0) >> 1; if (ed[mid] < x0) lo0 = mid + 1; else hi0 = mid; }
+                if (lo1 < hi1) { const int mid = (lo1 + hi1) >> 1; if (ed[mid] < x1) lo1 = mid + 1; else hi1 = mid; }
+            }
+            unsigned char *row = seq + g.soff[t];
+            if (g.sbits[t] == 4) {
+                row[i >> 1] = (unsigned char)(lo0 | (two ? (lo1 << 4) : 0));
             } else {
-                row[i] = (unsigned char)s0;
-                if (two) row[i + 1] = (unsigned char)s1;
+                row[i] = (unsigned char)lo0;
+                if (two) row[i + 1] = (unsigned char)lo1;
             }
         }
     }
