@@ -191,3 +191,19 @@ def test_more_distinct_per_kind_plans_than_the_cache_holds(monkeypatch):
         assert log["closed"] == 3 and len(extraction._thread_cache()) == extraction._PLAN_CACHE_SIZE
     finally:
         extraction.clear_plan_cache()
+
+
+def test_long_series_with_entropy_columns_warn_about_their_run_time(emul_plans):
+    """VERDICT r3 'long-series cliff': beyond 4096 samples the O(n^2) entropies leave the LDS sweep; the call still works
+    but says so -- even with show_warnings=False, which only silences the calculators' own domain warnings."""
+    import warnings as w
+    from tsfresh_amd import extract_features
+    from tsfresh_amd.feature_extraction import extraction
+    n = extraction.ENTROPY_FAST_MAX_LEN + 1
+    df = pd.DataFrame({"id": 0, "time": np.arange(n), "value": np.sin(np.arange(n) * 0.01)})
+    with pytest.warns(UserWarning, match="O\\(n\\^2\\)"):
+        extract_features(df, column_id="id", column_sort="time", default_fc_parameters={"sample_entropy": None, "mean": None})
+    with w.catch_warnings():
+        w.simplefilter("error")    # no warning without the quadratic calculators, nor at the limit itself
+        extract_features(df, column_id="id", column_sort="time", default_fc_parameters={"mean": None, "median": None})
+        extract_features(df.iloc[:-1], column_id="id", column_sort="time", default_fc_parameters={"sample_entropy": None})

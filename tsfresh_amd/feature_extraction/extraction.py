@@ -43,6 +43,28 @@ def _default_device():
 _PLAN_CACHE_SIZE = 6
 _BATCH_KINDS_MAX_SAMPLES = 4_000_000   # kinds sharing a plan are concatenated into one native call up to this size
 _TLS = threading.local()
+# sample_entropy / approximate_entropy are O(n^2): up to this length the bit-matrix sweep keeps a series' working set in a
+# CU's LDS (fam_entropy_bits.h: 13 ms per 100 000 series of 1024 samples, 2.3 ms per 1 000 of 4096); beyond it the pair
+# sweep runs from HBM scratch (profiles/r04_long_entropy.md: seconds per series at 16 384 samples) -- the call still
+# returns the right values, but the caller should know why it takes that long
+ENTROPY_FAST_MAX_LEN = 4096
+_QUADRATIC = ("sample_entropy", "approximate_entropy")
+
+
+def _warn_long_entropy(fc_parameters, pk):
+    try:
+        quadratic = any(name in fc_parameters for name in _QUADRATIC)
+    except TypeError:
+        quadratic = False
+    if pk.n_series == 0 or not quadratic:
+        return
+    longest = int(np.diff(pk.offsets).max())
+    if longest > ENTROPY_FAST_MAX_LEN:
+        warnings.warn("kind {!r}: series of up to {} samples with sample_entropy / approximate_entropy in the settings: these "
+                      "calculators are O(n^2) and beyond {} samples run from HBM scratch instead of LDS (minutes for thousands "
+                      "of such series; see profiles/r04_long_entropy.md).  EfficientFCParameters() leaves them out, as the "
+                      "reference recommends for long series.".format(pk.kind, longest, ENTROPY_FAST_MAX_LEN),
+                      UserWarning, stacklevel=3)
 
 
 def _thread_cache():
@@ -157,6 +179,9 @@ def extract_features(
             device = devices[0]
     if device is None:
         device = _default_device()
+    for pk in packed:   # outside the filter below: this one is about run time, not about a calculator's domain
+        _warn_long_entropy(kind_to_fc_parameters[pk.kind] if kind_to_fc_parameters and pk.kind in kind_to_fc_parameters
+                           else default_fc_parameters, pk)
 
     with warnings.catch_warnings():
         if not show_warnings:
