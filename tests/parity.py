@@ -682,6 +682,21 @@ def _rvalue_lookup(names, want_row):
     return find
 
 
+# Per test and calculator: how many cells the exclusions above skipped, of how many compared (a predicate that
+# quietly grows must be visible).  tests/conftest.py writes the table at session end when TSFA_PARITY_SKIPS_MD names a file.
+SKIP_LOG = {}
+
+
+def _log_skips(names, n_series, skipped_cells):
+    import os
+    test = os.environ.get("PYTEST_CURRENT_TEST", "(no test)").split(" (")[0]
+    entry = SKIP_LOG.setdefault(test, {"cells": 0, "skipped": {}})
+    entry["cells"] += n_series * len(names)
+    for _, col in skipped_cells:
+        f = feature_of(col)
+        entry["skipped"][f] = entry["skipped"].get(f, 0) + 1
+
+
 def compare(names, got, want, series, rtol=RTOL, check_excluded=False, simd_golden=False, skipped=None):
     """names: list[str]; got, want: [n_series, n_cols]; series: list of 1-D arrays.  -> list[str] of mismatches.
     skipped: optional list that receives (series index, column) of every excluded cell."""
@@ -689,6 +704,16 @@ def compare(names, got, want, series, rtol=RTOL, check_excluded=False, simd_gold
     got = np.asarray(got, dtype=np.float64)
     want = np.asarray(want, dtype=np.float64)
     assert got.shape == want.shape == (len(series), len(names)), (got.shape, want.shape, len(series), len(names))
+    if skipped is None:
+        skipped = []
+    n_before = len(skipped)
+    try:
+        return _compare(names, got, want, series, rtol, check_excluded, simd_golden, skipped, bad)
+    finally:
+        _log_skips(names, len(series), skipped[n_before:])
+
+
+def _compare(names, got, want, series, rtol, check_excluded, simd_golden, skipped, bad):
     for i, x in enumerate(series):
         absum = float(np.abs(np.asarray(x, dtype=np.float64)).sum())
         spectrum = None

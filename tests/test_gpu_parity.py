@@ -66,7 +66,9 @@ def test_hip_offset_fuzz(gpu):
     skipped = []
     bad = compare(names, got, want, series, skipped=skipped)
     assert not bad, bad[:10]
-    assert len(skipped) <= 0.12 * got.size, (len(skipped), got.size)
+    # measured 2.4 % (29 of 1216 cells: profiles/r04_parity_skips.md); the predicates read the series only, so the share is a
+    # property of this input set -- a bound two points above it catches a predicate that grows
+    assert len(skipped) <= 0.044 * got.size, (len(skipped), got.size)
     _, again = hip_engine(params, values, offsets)
     assert np.array_equal(got, again, equal_nan=True)
 
@@ -100,8 +102,9 @@ def test_hip_second_pass_handles_a_batch_of_stuck_sensors(gpu, dtype):
     bad = compare(onames, _align(onames, names, got), want, _series(values.astype(np.float64), offsets), skipped=skipped)
     assert not bad, "%d mismatches, first: %s" % (len(bad), bad[:12])
     # skipped: the perfect-fit ADF cells of ramps / periodic patterns (parity.py R5) and the AR cells of long constant
-    # series, where the reference inverts LAPACK round-off (R4)
-    assert len(skipped) < 0.3 * want.size
+    # series, where the reference inverts LAPACK round-off (R4): measured 15.8 % (float32) / 22.5 % (float64, which adds the
+    # exact ramps) of this batch, bound = measured + 2 points
+    assert len(skipped) <= (0.178 if dtype == np.float32 else 0.245) * want.size, (len(skipped), want.size)
 
 
 @pytest.mark.parametrize("dtype", [np.float32, np.float64])
