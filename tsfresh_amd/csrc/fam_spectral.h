@@ -34,15 +34,17 @@ TSFA_DEV void blk_fft_pow2(const Blk &b, double *re, double *im, int M, const do
             im[j] = ti;
         }
     }
-    int lh = 0;  // log2(half): the butterfly index splits by shifts, not by an integer division per butterfly
-    for (int len = 2; len <= M; len <<= 1, ++lh) {
-        const int half = len >> 1;
-        const int stride = TSFA_TW_N / len;
+    // Radix-2 stages taken TWO AT A TIME: the four elements i0 + {0, h, 2h, 3h} of two consecutive stages (half-lengths h
+    // and 2h) meet only each other, so a thread carries them through both stages in registers -- the same butterflies
+    // with the same twiddles in the same order as one stage per pass (bit-identical results), with half the LDS reads,
+    // writes and barriers: the stages were what the kernel waited on (54 % issue, SQ_WAIT_INST_LDS).  An odd number of
+    // stages starts with one single stage.
+    int st = 0;   // stages done; stage st has half-length 1 << st
+    if (logM & 1) {
         blk_sync();
-        for (int t = b.tid; t < (M >> 1); t += b.nt) {
-            const int grp = t >> lh, k = t & (half - 1);
-            const int i0 = grp * len + k, i1 = i0 + half;
-            const double wr = twc[k * stride], wi = tws[k * stride];
+        for (int t = b.tid; t < (M >> 1); t += b.nt) {   // len = 2: twiddle 1
+            const int i0 = 2 * t, i1 = i0 + 1;
+            const double wr = twc[0], wi = tws[0];
             const double xr = re[i1], xi = im[i1];
             const double tr = xr * wr - xi * wi;
             const double ti = xr * wi + xi * wr;
@@ -51,6 +53,40 @@ TSFA_DEV void blk_fft_pow2(const Blk &b, double *re, double *im, int M, const do
             im[i1] = ui - ti;
             re[i0] = ur + tr;
             im[i0] = ui + ti;
+        }
+        st = 1;
+    }
+    for (; st + 1 < logM; st += 2) {
+        const int h = 1 << st;
+        const int strideA = TSFA_TW_N / (2 * h), strideB = TSFA_TW_N / (4 * h);
+        blk_sync();
+        for (int t = b.tid; t < (M >> 2); t += b.nt) {
+            const int grp = t >> st, k = t & (h - 1);
+            const int i0 = grp * 4 * h + k, i1 = i0 + h, i2 = i0 + 2 * h, i3 = i0 + 3 * h;
+            const double war = twc[k * strideA], wai = tws[k * strideA];
+            const double wbr0 = twc[k * strideB], wbi0 = tws[k * strideB];
+            const double wbr1 = twc[(k + h) * strideB], wbi1 = tws[(k + h) * strideB];
+            const double x0r = re[i0], x0i = im[i0], x1r = re[i1], x1i = im[i1];
+            const double x2r = re[i2], x2i = im[i2], x3r = re[i3], x3i = im[i3];
+            // stage A (half-length h): (i0, i1) and (i2, i3), twiddle w_A(k)
+            double tr = x1r * war - x1i * wai, ti = x1r * wai + x1i * war;
+            const double a1r = x0r - tr, a1i = x0i - ti, a0r = x0r + tr, a0i = x0i + ti;
+            tr = x3r * war - x3i * wai;
+            ti = x3r * wai + x3i * war;
+            const double a3r = x2r - tr, a3i = x2i - ti, a2r = x2r + tr, a2i = x2i + ti;
+            // stage B (half-length 2h): (i0, i2) with w_B(k), (i1, i3) with w_B(k + h)
+            tr = a2r * wbr0 - a2i * wbi0;
+            ti = a2r * wbi0 + a2i * wbr0;
+            re[i2] = a0r - tr;
+            im[i2] = a0i - ti;
+            re[i0] = a0r + tr;
+            im[i0] = a0i + ti;
+            tr = a3r * wbr1 - a3i * wbi1;
+            ti = a3r * wbi1 + a3i * wbr1;
+            re[i3] = a1r - tr;
+            im[i3] = a1i - ti;
+            re[i1] = a1r + tr;
+            im[i1] = a1i + ti;
         }
     }
     blk_sync();

@@ -45,8 +45,9 @@ _BATCH_KINDS_MAX_SAMPLES = 4_000_000   # kinds sharing a plan are concatenated i
 _TLS = threading.local()
 # sample_entropy / approximate_entropy are O(n^2): up to this length the bit-matrix sweep keeps a series' working set in a
 # CU's LDS (fam_entropy_bits.h: 13 ms per 100 000 series of 1024 samples, 2.3 ms per 1 000 of 4096); beyond it the pair
-# sweep runs from HBM scratch (profiles/r04_long_entropy.md: seconds per series at 16 384 samples) -- the call still
-# returns the right values, but the caller should know why it takes that long
+# sweep takes over (profiles/r04_long_entropy.md: 0.18 ms per series at 8192 samples, 0.45 ms at 16 384 with the GPU
+# full -- 2 000 x 16 384 Comprehensive: 0.98 s -- and four times that per doubling) -- the call returns the right values,
+# but these two calculators are then 90 % of its time and the caller should know
 ENTROPY_FAST_MAX_LEN = 4096
 _QUADRATIC = ("sample_entropy", "approximate_entropy")
 
@@ -61,9 +62,9 @@ def _warn_long_entropy(fc_parameters, pk):
     longest = int(np.diff(pk.offsets).max())
     if longest > ENTROPY_FAST_MAX_LEN:
         warnings.warn("kind {!r}: series of up to {} samples with sample_entropy / approximate_entropy in the settings: these "
-                      "calculators are O(n^2) and beyond {} samples run from HBM scratch instead of LDS (minutes for thousands "
-                      "of such series; see profiles/r04_long_entropy.md).  EfficientFCParameters() leaves them out, as the "
-                      "reference recommends for long series.".format(pk.kind, longest, ENTROPY_FAST_MAX_LEN),
+                      "calculators are O(n^2) and beyond {} samples leave the LDS-resident sweep (about 0.5 ms per series at "
+                      "16 384 samples on a full MI355X, four times that per doubling: 90 % of the extraction).  "
+                      "EfficientFCParameters() leaves them out, as the reference recommends for long series.".format(pk.kind, longest, ENTROPY_FAST_MAX_LEN),
                       UserWarning, stacklevel=3)
 
 
