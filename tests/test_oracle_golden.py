@@ -147,3 +147,22 @@ def test_fuzz_rounds_on_the_emulated_kernel_sources():
                          capture_output=True, text=True, timeout=900)
     assert out.returncode == 0, out.stderr[-2000:]
     assert "TOTAL mismatches 0" in out.stdout, out.stdout[-3000:]
+
+
+def test_emul_welch_segment_batches_on_very_long_series():
+    """The 256-sample Welch segments are transformed in batches (fam_spectral.h: blk_fft_pow2_batch); the batch size is
+    capped by the reduction scratch that carries the segment means -- a 20 000-sample series (156 segments) used to
+    overflow it on the device (found by test_series_longer_than_lds_match_oracle)."""
+    from parity import compare
+    rng = np.random.default_rng(8)
+    lens = [20000, 300, 9001, 1024, 640]
+    series = [rng.standard_normal(n) if i % 2 == 0 else np.cumsum(rng.standard_normal(n)) for i, n in enumerate(lens)]
+    values = np.concatenate(series)
+    offsets = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
+    params = {"spkt_welch_density": [{"coeff": c} for c in (2, 5, 8)], "fourier_entropy": [{"bins": b} for b in (2, 3, 5, 10, 100)],
+              "fft_aggregated": [{"aggtype": a} for a in ("centroid", "variance", "skew", "kurtosis")]}
+    names, got = emul_engine(params, values, offsets)
+    onames, want = oracle_engine(params, values, offsets)
+    assert list(names) == list(onames)
+    bad = compare(names, got, want, series)
+    assert not bad, bad[:6]

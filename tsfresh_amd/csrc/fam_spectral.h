@@ -92,6 +92,86 @@ TSFA_DEV void blk_fft_pow2(const Blk &b, double *re, double *im, int M, const do
     blk_sync();
 }
 
+// The same transform on nb blocks of M contiguous elements at once (re / im hold nb * M doubles): one butterfly index space
+// over all blocks, so a stage keeps every thread busy when M / 4 is smaller than the workgroup (the 256-sample Welch
+// segments: M = 128, 32 four-element groups per stage).  Per block the operations are those of blk_fft_pow2.
+TSFA_DEV void blk_fft_pow2_batch(const Blk &b, double *re, double *im, int M, int nb, const double *twc, const double *tws) {
+    int logM = 0;
+    while ((1 << logM) < M) ++logM;
+    blk_sync();
+    for (int ii = b.tid; ii < nb * M; ii += b.nt) {
+        const int base = ii & ~(M - 1), i = ii & (M - 1);
+#if TSFA_GPU
+        const int j = (logM > 0) ? (int)(__builtin_bitreverse32((unsigned)i) >> (32 - logM)) : 0;
+#else
+        unsigned r = 0, x = (unsigned)i;
+        for (int k = 0; k < logM; ++k) {
+            r = (r << 1) | (x & 1u);
+            x >>= 1;
+        }
+        const int j = (int)r;
+#endif
+        if (j > i) {
+            const double tr = re[base + i], ti = im[base + i];
+            re[base + i] = re[base + j];
+            im[base + i] = im[base + j];
+            re[base + j] = tr;
+            im[base + j] = ti;
+        }
+    }
+    int st = 0;
+    if (logM & 1) {
+        blk_sync();
+        for (int t = b.tid; t < nb * (M >> 1); t += b.nt) {
+            const int i0 = 2 * t, i1 = i0 + 1;   // (pairs never straddle a block: M is even)
+            const double wr = twc[0], wi = tws[0];
+            const double xr = re[i1], xi = im[i1];
+            const double tr = xr * wr - xi * wi;
+            const double ti = xr * wi + xi * wr;
+            const double ur = re[i0], ui = im[i0];
+            re[i1] = ur - tr;
+            im[i1] = ui - ti;
+            re[i0] = ur + tr;
+            im[i0] = ui + ti;
+        }
+        st = 1;
+    }
+    const int lq = logM - 2;   // log2(M / 4)
+    for (; st + 1 < logM; st += 2) {
+        const int h = 1 << st;
+        const int strideA = TSFA_TW_N / (2 * h), strideB = TSFA_TW_N / (4 * h);
+        blk_sync();
+        for (int tt = b.tid; tt < nb * (M >> 2); tt += b.nt) {
+            const int blk = tt >> lq, t = tt & ((M >> 2) - 1);
+            const int grp = t >> st, k = t & (h - 1);
+            const int i0 = blk * M + grp * 4 * h + k, i1 = i0 + h, i2 = i0 + 2 * h, i3 = i0 + 3 * h;
+            const double war = twc[k * strideA], wai = tws[k * strideA];
+            const double wbr0 = twc[k * strideB], wbi0 = tws[k * strideB];
+            const double wbr1 = twc[(k + h) * strideB], wbi1 = tws[(k + h) * strideB];
+            const double x0r = re[i0], x0i = im[i0], x1r = re[i1], x1i = im[i1];
+            const double x2r = re[i2], x2i = im[i2], x3r = re[i3], x3i = im[i3];
+            double tr = x1r * war - x1i * wai, ti = x1r * wai + x1i * war;
+            const double a1r = x0r - tr, a1i = x0i - ti, a0r = x0r + tr, a0i = x0i + ti;
+            tr = x3r * war - x3i * wai;
+            ti = x3r * wai + x3i * war;
+            const double a3r = x2r - tr, a3i = x2i - ti, a2r = x2r + tr, a2i = x2i + ti;
+            tr = a2r * wbr0 - a2i * wbi0;
+            ti = a2r * wbi0 + a2i * wbr0;
+            re[i2] = a0r - tr;
+            im[i2] = a0i - ti;
+            re[i0] = a0r + tr;
+            im[i0] = a0i + ti;
+            tr = a3r * wbr1 - a3i * wbi1;
+            ti = a3r * wbi1 + a3i * wbr1;
+            re[i3] = a1r - tr;
+            im[i3] = a1i - ti;
+            re[i1] = a1r + tr;
+            im[i1] = a1i + ti;
+        }
+    }
+    blk_sync();
+}
+
 #define TSFA_GOERTZEL_MIN 257  // non-power-of-two lengths from here on use the Goertzel sweep
 
 // rfft of G(i), i < n, into Xr/Xi[0 .. n/2].
@@ -385,42 +465,90 @@ TSFA_DEV int blk_welch(const Blk &b, const ST *xs, int n, double *win, double *p
     for (int k = b.tid; k < nf; k += b.nt) pxx[k] = 0.0;
     w2 = blk_sum(b, w2);
     const double scale = 1.0 / w2;
+    // The 256-sample segments in BATCHES of up to four (as many half-size transforms of 128 complex points as Xr / Xi
+    // hold): one butterfly index space over the batch (blk_fft_pow2_batch) instead of one segment per wavefront, whose
+    // 32 four-element groups per stage left half the lanes idle and whose rounds (four for seven segments on two
+    // wavefronts) each paid every stage's barrier.  The real-input split and the periodogram are taken straight from the
+    // half-size spectrum, pair (k, 128 - k) by pair, in place; the periodograms are added to pxx in SEGMENT order -- the
+    // additions of the sequential loop below, in the same order, on the same values.
+    // (the segment means travel through b.red: at most TSFA_RED_DOUBLES / 2 segments per batch)
+    const int nbmax = (xcap / 128 < TSFA_RED_DOUBLES / 2) ? xcap / 128 : TSFA_RED_DOUBLES / 2;
+    if (nper == 256 && nseg > 1 && nbmax >= 2) {
+        const int M = 128;
+        const int stride_tw = TSFA_TW_N / 256;
+        for (int s0 = 0; s0 < nseg; s0 += nbmax) {
+            const int nb = (nseg - s0 < nbmax) ? (nseg - s0) : nbmax;
+            blk_sync();
+            // segment means: one WAVEFRONT per segment (lane-strided partial sums + the wave butterfly: the summation
+            // order of the one-segment-per-wavefront form this replaces)
 #if TSFA_GPU
-    // Several 256-sample segments at a time, one per WAVEFRONT: the half-size FFT of a segment keeps 64 lanes busy, the
-    // other wavefronts of the workgroup used to wait at its barriers.  Every wavefront transforms its own segment in its
-    // own slice of Xr / Xi (the barriers inside blk_rfft stay workgroup barriers: all wavefronts run the same stages),
-    // leaves the segment's periodogram there, and the periodograms are added to pxx in SEGMENT order -- the additions of
-    // the sequential loop below, in the same order.
-    const int nwav = b.nt >> 6;
-    if (nper == 256 && nseg > 1 && nwav > 1 && 256 * (nwav - 1) + 130 <= xcap) {
-        const int lane = b.tid & 63, wave = b.tid >> 6;
-        const Blk wb{lane, 64, b.red, nullptr};
-        double *xr = Xr + 256 * wave, *xi = Xi + 256 * wave;
-        for (int s0 = 0; s0 < nseg; s0 += nwav) {
-            const int sgi = s0 + wave;
-            const bool act = sgi < nseg;
-            const XsView<ST> seg{xs + (act ? sgi : 0) * step};  // idle wavefronts redo segment 0 and discard it
-            double sm = 0.0;
-            for (int j = lane; j < nper; j += 64) sm += seg[j];
-            const double mu = wave_sum(sm) / (double)nper;
-            const double *wn = win;
-            blk_rfft(wb, nper, [=](int j) { return (seg[j] - mu) * wn[j]; }, xr, xi, tc, ts, twc, tws);
-            for (int k = lane; k < nf; k += 64) {
-                double pw = (xr[k] * xr[k] + xi[k] * xi[k]) * scale;
-                const bool edge = (k == 0) || (k == nf - 1);
-                if (!edge) pw *= 2.0;
-                xr[k] = act ? pw : 0.0;
+            {
+                const int lane = b.tid & 63, wave = b.tid >> 6, nwav = (b.nt + 63) >> 6;
+                for (int q = wave; q < nb; q += nwav) {
+                    const XsView<ST> seg{xs + (s0 + q) * step};
+                    double sm = 0.0;
+                    for (int j = lane; j < nper; j += 64) sm += seg[j];
+                    const double mu = wave_sum(sm) / (double)nper;
+                    if (lane == 0) b.red[q] = mu;
+                }
+            }
+#else
+            for (int q = b.tid; q < nb; q += b.nt) {
+                const XsView<ST> seg{xs + (s0 + q) * step};
+                double sm = 0.0;
+                for (int j = 0; j < nper; ++j) sm += seg[j];
+                b.red[q] = sm / (double)nper;
+            }
+#endif
+            blk_sync();
+            for (int i = b.tid; i < nb * M; i += b.nt) {
+                const int q = i >> 7, k = i & (M - 1);
+                const XsView<ST> seg{xs + (s0 + q) * step};
+                const double mu = b.red[q];
+                Xr[i] = (seg[2 * k] - mu) * win[2 * k];
+                Xi[i] = (seg[2 * k + 1] - mu) * win[2 * k + 1];
+            }
+            blk_fft_pow2_batch(b, Xr, Xi, M, nb, twc, tws);
+            // split + periodogram: thread = (segment, pair k <= 64); pw of bin k -> Xr[q M + k], of bin 128 -> Xi[q M]
+            for (int i = b.tid; i < nb * (M / 2 + 1); i += b.nt) {
+                const int q = i / (M / 2 + 1), k = i - q * (M / 2 + 1);
+                double *zr = Xr + q * M, *zi = Xi + q * M;
+                if (k == 0) {
+                    const double a0 = zr[0], b0 = zi[0];
+                    const double x0 = a0 + b0, xm = a0 - b0;       // X[0], X[128] (both real)
+                    zr[0] = (x0 * x0 + 0.0 * 0.0) * scale;
+                    zi[0] = (xm * xm + 0.0 * 0.0) * scale;
+                } else {
+                    const int k2 = M - k;
+                    const double ar = zr[k], ai = zi[k], br = zr[k2], bi = zi[k2];
+                    double pk, pk2 = 0.0;
+                    {
+                        const double er = 0.5 * (ar + br), ei = 0.5 * (ai - bi);
+                        const double orr = 0.5 * (ai + bi), oi = -0.5 * (ar - br);
+                        const double wr = twc[k * stride_tw], wi = tws[k * stride_tw];
+                        const double xr = er + (orr * wr - oi * wi), xi = ei + (orr * wi + oi * wr);
+                        pk = (xr * xr + xi * xi) * scale * 2.0;
+                    }
+                    if (k2 != k) {
+                        const double er = 0.5 * (br + ar), ei = 0.5 * (bi - ai);
+                        const double orr = 0.5 * (bi + ai), oi = -0.5 * (br - ar);
+                        const double wr = twc[k2 * stride_tw], wi = tws[k2 * stride_tw];
+                        const double xr = er + (orr * wr - oi * wi), xi = ei + (orr * wi + oi * wr);
+                        pk2 = (xr * xr + xi * xi) * scale * 2.0;
+                    }
+                    zr[k] = pk;
+                    if (k2 != k) zr[k2] = pk2;
+                }
             }
             blk_sync();
             for (int k = b.tid; k < nf; k += b.nt) {
                 double acc = pxx[k];
-                for (int w = 0; w < nwav && s0 + w < nseg; ++w) acc += Xr[256 * w + k];
+                for (int q = 0; q < nb; ++q) acc += (k < M) ? Xr[q * M + k] : Xi[q * M];
                 pxx[k] = acc;
             }
             blk_sync();
         }
     } else
-#endif
     for (int sgi = 0; sgi < nseg; ++sgi) {
         const XsView<ST> seg{xs + sgi * step};
         double sm = 0.0;

@@ -688,34 +688,47 @@ __global__ void __launch_bounds__(256) k_stream(const T *__restrict__ values, co
 // ---------------------------------------------------------------------------------------------
 typedef double tsfa_d4 __attribute__((ext_vector_type(4)));
 
-template <typename T, int CT>
+// MT 16-series row tiles per wavefront share every filter load: per k-step MT + CT loads feed MT * CT MFMAs (round 3:
+// one tile, 1 + CT loads per CT MFMAs, matrix pipe 13.6 % busy).
+template <typename T, int CT, int MT>
 __global__ void __launch_bounds__(64)
 k_cwt_gemm(const T *__restrict__ values, const int64_t *__restrict__ starts, const int64_t *__restrict__ ends, int64_t n_series,
            const double *__restrict__ W, int S4, int C, const int *__restrict__ cols,
            const int *__restrict__ coeff_idx, double *__restrict__ out, int64_t ld) {
-    __shared__ int lens[16];
+    __shared__ int lens[16 * MT];
     const int lane = threadIdx.x;
     const int r = lane & 15, kq = lane >> 4;
-    const int64_t s = (int64_t)blockIdx.x * 16 + r;
-    int64_t off = 0;
-    int len = 0;
-    if (s < n_series) {
-        off = starts[s];
-        len = (int)(ends[s] - off);
-    }
-    if (lane < 16) lens[lane] = len;
-    __syncthreads();
-    tsfa_d4 acc[CT];
+    const int64_t base = (int64_t)blockIdx.x * (16 * MT);
+    const T *g[MT];
+    int len[MT];
 #pragma unroll
-    for (int ct = 0; ct < CT; ++ct) acc[ct] = (tsfa_d4){0.0, 0.0, 0.0, 0.0};
-    const T *g = values + off;
+    for (int m = 0; m < MT; ++m) {
+        const int64_t s = base + m * 16 + r;
+        int64_t off = 0;
+        len[m] = 0;
+        if (s < n_series) {
+            off = starts[s];
+            len[m] = (int)(ends[s] - off);
+        }
+        g[m] = values + off;
+        if (lane < 16) lens[m * 16 + lane] = len[m];
+    }
+    __syncthreads();
+    tsfa_d4 acc[MT][CT];
+#pragma unroll
+    for (int m = 0; m < MT; ++m)
+#pragma unroll
+        for (int ct = 0; ct < CT; ++ct) acc[m][ct] = (tsfa_d4){0.0, 0.0, 0.0, 0.0};
     for (int k0 = 0; k0 < S4; k0 += 4) {
         const int k = k0 + kq;
-        const double a = (k < len) ? (double)g[k] : 0.0;  // A[i = r][k = kq]
+        double a[MT];
+#pragma unroll
+        for (int m = 0; m < MT; ++m) a[m] = (k < len[m]) ? (double)g[m][k] : 0.0;  // A[i = r][k = kq] of tile m
 #pragma unroll
         for (int ct = 0; ct < CT; ++ct) {
             const double bv = W[(size_t)(ct * 16 + r) * S4 + k];  // B[k = kq][j = r]
-            acc[ct] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, bv, acc[ct], 0, 0, 0);
+#pragma unroll
+            for (int m = 0; m < MT; ++m) acc[m][ct] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[m], bv, acc[m][ct], 0, 0, 0);
         }
     }
     // D[i = 4*v + kq][j = r]: the f64 16x16x4 accumulator interleaves rows across the four 16-lane groups
@@ -726,10 +739,13 @@ k_cwt_gemm(const T *__restrict__ values, const int64_t *__restrict__ starts, con
         if (c >= C) continue;
         const int col = cols[c], ci = coeff_idx[c];
 #pragma unroll
-        for (int v = 0; v < 4; ++v) {
-            const int i = 4 * v + kq;
-            const int64_t srow = (int64_t)blockIdx.x * 16 + i;
-            if (srow < n_series) out[srow * ld + col] = (ci < lens[i]) ? acc[ct][v] : TSFA_NAN;
+        for (int m = 0; m < MT; ++m) {
+#pragma unroll
+            for (int v = 0; v < 4; ++v) {
+                const int i = 4 * v + kq;
+                const int64_t srow = base + m * 16 + i;
+                if (srow < n_series) out[srow * ld + col] = (ci < lens[m * 16 + i]) ? acc[m][ct][v] : TSFA_NAN;
+            }
         }
     }
 }
@@ -1043,12 +1059,14 @@ int tsfa_launch_order_stats(const TsfaLaunch &a) {
 template <typename T>
 static int launch_cwt_t(const TsfaCwtLaunch &a, const T *values) {
     hipStream_t st = (hipStream_t)a.stream;
-    const dim3 grid((unsigned)((a.n_series + 15) / 16));
+    // MT row tiles per wavefront: 4 (64 series) while the accumulators fit (CT <= 4: 4 x 4 x 4 doubles), else 2
     const int ct = (a.C + 15) / 16;
+    const int mt = (ct <= 4) ? 4 : 2;
+    const dim3 grid((unsigned)((a.n_series + 16 * mt - 1) / (16 * mt)));
 #define TSFA_CWT_CASE(N)                                                                                         \
     case N:                                                                                                      \
-        k_cwt_gemm<T, N><<<grid, 64, 0, st>>>(values, a.starts, a.ends, a.n_series, a.W, a.S4, a.C, a.cols, a.coeff_idx, \
-                                              a.out, a.ld);                                                      \
+        k_cwt_gemm<T, N, (N <= 4 ? 4 : 2)><<<grid, 64, 0, st>>>(values, a.starts, a.ends, a.n_series, a.W, a.S4, a.C, a.cols, \
+                                                               a.coeff_idx, a.out, a.ld);                        \
         break;
     switch (ct) {
         TSFA_CWT_CASE(1)
