@@ -95,7 +95,11 @@ TSFA_DEV void entb_ranges(const Blk &b0, const double *xs, int n, const double *
         int pl[TSFA_ENTB_MAXK], ph[TSFA_ENTB_MAXK];  // byte offsets into xsrt
 #pragma unroll
         for (int k = 0; k < K; ++k) { pl[k] = 0; ph[k] = 0; }
+#if defined(TSFA_EXPERIMENT_RANGE_STEPS)   // cost experiment only (profiles/r04_i.sh): fewer bisection steps, wrong ranges
+        for (int step = (P >> 1) * 8; step >= 8 * (P >> TSFA_EXPERIMENT_RANGE_STEPS); step >>= 1) {
+#else
         for (int step = (P >> 1) * 8; step >= 8; step >>= 1) {
+#endif
             const char *at = xb + (step - 8);
 #pragma unroll
             for (int k = 0; k < K; ++k) {
@@ -454,19 +458,27 @@ TSFA_DEV void entropy_bits_batch(const Blk &b_in, const double *xs, int n, const
         blk_sync();
         TSFA_TICK(tk, b, 138);
         for (int part = 0; part < nparts; ++part) {
+#if !defined(TSFA_EXPERIMENT_NO_ENTB_TABLE)   // cost experiments only (profiles/r04_i.sh): timing with a phase left out, wrong results
             entb_build_table<QW_ + 1>(b, n, perm, part * QW, NW, table, wtot);
+#endif
             TSFA_TICK(tk, b, 139);
             const int nq = (NW - part * QW < QW) ? (NW - part * QW) : QW;
+#if defined(TSFA_EXPERIMENT_NO_ENTB_SWEEP)
+            if (false) {
+#else
             if (nq == QW) {
+#endif
 #pragma unroll
                 for (int tt = 0; tt < TSFA_ENTB_MAXT; ++tt) {
                     if (wave + tt * nw < ntask) ct[tt] += entb_task_part<QW_, true>(rl[tt], rh[tt], sh, nq);
                 }
             } else {
+#if !defined(TSFA_EXPERIMENT_NO_ENTB_SWEEP)
 #pragma unroll
                 for (int tt = 0; tt < TSFA_ENTB_MAXT; ++tt) {
                     if (wave + tt * nw < ntask) ct[tt] += entb_task_part<QW_, false>(rl[tt], rh[tt], sh, nq);
                 }
+#endif
             }
             TSFA_TICK(tk, b, 136);
             blk_sync();
@@ -544,7 +556,11 @@ TSFA_DEV void entropy_bits_batch(const Blk &b_in, const double *xs, int n, const
             int sc[TSFA_ENTB_MAXK], sc1[TSFA_ENTB_MAXK], nm[TSFA_ENTB_MAXK], nm1[TSFA_ENTB_MAXK];
             double *part = (double *)(void *)(cnt + (((size_t)kcap * n + 1) & ~(size_t)1));  // [2 K][nt / 16]
             // (a thread multiplies at most four counts before the lanes combine theirs: longer rows go in chunks)
+#if defined(TSFA_EXPERIMENT_NO_ENTB_TOTALS)
+            for (int c0 = 0; c0 < 0; c0 += 4 * b.nt) {
+#else
             for (int c0 = 0; c0 < nrow_m; c0 += 4 * b.nt) {
+#endif
 #pragma unroll
                 for (int k = 0; k < K; ++k) { pm[k] = 1.0; pm1[k] = 1.0; sc[k] = 0; sc1[k] = 0; nm[k] = 0; nm1[k] = 0; }
                 for (int ib = c0; ib < nrow_m && ib < c0 + 4 * b.nt; ib += b.nt) {
