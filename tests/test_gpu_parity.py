@@ -870,3 +870,42 @@ def test_every_cell_is_written_by_a_kernel(gpu, monkeypatch):
         assert not kept, kept
     finally:
         os.environ.pop("TSFA_DEBUG_FILL", None)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+def test_shared_series_statistics_change_no_bit(gpu, dtype, monkeypatch):
+    """k_basic leaves numpy-order mean / variance and the extrema of every series for the ENTROPY, AR and SEQ families of
+    the same extraction (plan->stats_buf); with the sharing switched off (TSFA_NO_STATS_SHARE=1) every family computes its
+    own -- the same sums in the same order, so all 783 columns must agree bit for bit: ragged lengths (several launch
+    groups), nice decimals (where one ulp of the mean flips counts), constants, offsets."""
+    rng = np.random.default_rng(17)
+    lens = list(rng.integers(5, 1200, size=300)) + [1024] * 40 + [3000, 4096, 2500, 64, 3, 4, 5]
+    series = []
+    for i, n in enumerate(lens):
+        kind = i % 5
+        if kind == 0:
+            x = rng.standard_normal(n)
+        elif kind == 1:
+            x = np.cumsum(rng.standard_normal(n))
+        elif kind == 2:
+            x = np.round(rng.standard_normal(n), 1)
+        elif kind == 3:
+            x = 1e4 + rng.standard_normal(n)
+        else:
+            x = np.full(n, 0.1)
+        series.append(x.astype(dtype))
+    values = np.concatenate(series)
+    offsets = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
+    params = settings.ComprehensiveFCParameters()
+    names, shared = hip_engine(params, values, offsets)
+    monkeypatch.setenv("TSFA_NO_STATS_SHARE", "1")
+    names2, own = hip_engine(params, values, offsets)
+    monkeypatch.delenv("TSFA_NO_STATS_SHARE")
+    assert names == names2
+    assert np.array_equal(shared, own, equal_nan=True), [names[j] for j in np.nonzero(~((shared == own) | (np.isnan(shared) & np.isnan(own))).all(axis=0))[0]][:8]
+    # a plan WITHOUT the BASIC family has nobody to share with and still works
+    only = {"sample_entropy": None, "lempel_ziv_complexity": [{"bins": 5}], "ar_coefficient": [{"coeff": 1, "k": 10}]}
+    n3, got = hip_engine(only, values, offsets)
+    cols = [names.index(c) for c in n3]
+    assert np.array_equal(got, shared[:, cols], equal_nan=True)

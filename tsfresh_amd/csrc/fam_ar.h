@@ -378,13 +378,15 @@ struct ArCentred {
 // augmented_dickey_fuller); their columns are left NaN for the second pass (fam_ar_dd.h).
 template <class ST, class X>
 TSFA_DEV int fam_ar_series(const Blk &b, X xv, int n, const TsfaSpec *specs, int nspecs, double *out_row, void *xc_raw,
-                            double *aw, int P, int hint_acf, int hint_pacf, int hint_adf, int n_loop = -1) {
+                            double *aw, int P, int hint_acf, int hint_pacf, int hint_adf, int n_loop = -1,
+                            const double *stats = nullptr) {
     const int nloop = (n_loop >= 0) ? n_loop : nspecs;  // columns [nloop, nspecs): lane = column epilogue
     const double dn = (double)n;
     TSFA_TICKER(tk, 0);
     // x.mean() in numpy's summation order: statsmodels demeans with it, and on (near-)constant series the
     // autocovariances are pure round-off of x - x.mean(), so the order decides what comes out
-    const double mean = np_sum(b, n, [=](int i) { return xv(i); }) / dn;
+    // (stats: the record k_basic left for this series, TSFA_STATS_*: the same sum in the same order)
+    const double mean = stats ? stats[TSFA_STATS_MEAN] : np_sum(b, n, [=](int i) { return xv(i); }) / dn;
     blk_sync();
     ST *xs_lds = (ST *)xc_raw + TSFA_AR_PADL;   // zero samples on either side: the blocks of the register tiles
     for (int i = b.tid; i < n + TSFA_AR_PADL + TSFA_AR_PADR; i += b.nt) {

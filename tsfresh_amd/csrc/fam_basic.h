@@ -739,7 +739,7 @@ TSFA_DEV void fam_basic_series(const Blk &b0, XS xs, int n, const TsfaSpec *spec
                                double *out_row, double *w, double *cum, double *altc, int *iw, const double *dectab,
                                int peaks_hint, int alt_want_p, const TsfaAltPlan &alt, TsfaSpec *stage,
                                const double *times = nullptr, int n_loop = -1, double *ctx = nullptr,
-                               int n_count = 0, int n_sum = 0) {
+                               int n_count = 0, int n_sum = 0, double *stats_out = nullptr) {
     const Blk &b = b0;
     TSFA_TICKER(tk, 0);
     BasicStats st;
@@ -747,6 +747,12 @@ TSFA_DEV void fam_basic_series(const Blk &b0, XS xs, int n, const TsfaSpec *spec
     const bool want_loc = ((peaks_hint >> 16) & 1) == 0;  // ... and bit 16: no column reads the extrema's positions
     if (PART & 1) {
         basic_stats(b, xs, n, st, want_loc);
+        // the series' statistics for the families launched after this one (TSFA_STATS_*: numpy-order mean and variance,
+        // extrema): k_entropy_bits / k_entropy, k_ar and k_seq used to recompute them -- 0.7 + 0.3 + 0.1 ms per 100 000 series
+        if (stats_out != nullptr && b.tid == 0) {
+            stats_out[TSFA_STATS_MEAN] = st.mean; stats_out[TSFA_STATS_VAR] = st.var;
+            stats_out[TSFA_STATS_MIN] = st.vmin; stats_out[TSFA_STATS_MAX] = st.vmax;
+        }
     } else {
         st.n = n; st.sum = 0.0; st.mean = 0.0; st.var = 0.0; st.std = 0.0; st.vmin = 0.0; st.vmax = 0.0; st.sumsq = 0.0;
         st.first_max = 0; st.last_max = 0; st.first_min = 0; st.last_min = 0; st.cnt_max = 0; st.cnt_min = 0;

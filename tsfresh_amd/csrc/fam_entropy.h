@@ -672,13 +672,13 @@ TSFA_DEV double sampen_from_acc(const EntAcc &a, int n, int m) {
 template <typename XT, bool FAST = false, bool F32 = false>
 TSFA_DEV void fam_entropy_series(const Blk &b0, XT *xs, int n, const TsfaSpec *specs, int nspecs, double *out_row,
                                  double *thr, unsigned short *perm, ent_ref *refs, unsigned int *cnt,
-                                 int staged_ok = 1) {
+                                 int staged_ok = 1, const double *stats = nullptr) {
     const Blk &b = b0;
-    // np.std(x), numpy summation order (the tolerances are c * np.std(x))
+    // np.std(x), numpy summation order (the tolerances are c * np.std(x)); stats: the record k_basic left (TSFA_STATS_*)
     TSFA_TICKER(tk, 0);
     const double dn = (double)n;
-    const double mean = np_sum(b, n, [=](int i) { return (double)xs[i]; }) / dn;
-    const double var = np_sum(b, n, [=](int i) { const double d = (double)xs[i] - mean; return d * d; }) / dn;
+    const double mean = stats ? stats[TSFA_STATS_MEAN] : np_sum(b, n, [=](int i) { return (double)xs[i]; }) / dn;
+    const double var = stats ? stats[TSFA_STATS_VAR] : np_sum(b, n, [=](int i) { const double d = (double)xs[i] - mean; return d * d; }) / dn;
     const double sd = sqrt(var);
     blk_sync();
     if (b.tid == 0) { xs[n] = (XT)TSFA_INF; xs[n + 1] = (XT)TSFA_INF; xs[n + 2] = (XT)TSFA_INF; xs[n + 3] = (XT)TSFA_INF; }

@@ -447,7 +447,11 @@ TSFA_DEV void entropy_bits_batch(const Blk &b_in, const double *xs, int n, const
             rl[tt] = lane_off;
             rh[tt] = lane_off;
             ct[tt] = 0u;
+#if defined(TSFA_EXPERIMENT_NO_ENTB_TASKSETUP)
+            if (false) {
+#else
             if (id < ntask) {
+#endif
                 const int s = (int)(((unsigned int)id * kmagic) >> 16), k = id - s * kn;   // tolerance within the round
                 const int i = s * (2 * TSFA_ENTB_STRIP) + lane_row;
                 const unsigned int r = (i < n) ? rng[k * n + i] : 0u;
@@ -668,11 +672,17 @@ TSFA_DEVN void entb_sort_merge(const Blk b, const double *xs, int n, unsigned sh
 template <bool F32, int QW_ = TSFA_ENTB_QW>
 TSFA_DEV void fam_entropy_series_bits(const Blk &b, double *xs, int n, const TsfaSpec *specs, int nspecs, double *out_row,
                                       double *thr, unsigned short *perm, unsigned int *work,
-                                      unsigned short *perm_out = nullptr, int kcap_max = TSFA_ENTB_MAXK) {
+                                      unsigned short *perm_out = nullptr, int kcap_max = TSFA_ENTB_MAXK,
+                                      const double *stats = nullptr) {
     TSFA_TICKER(tk, 0);
     const double dn = (double)n;
-    const double mean = np_sum(b, n, [=](int i) { return xs[i]; }) / dn;
-    const double var = np_sum(b, n, [=](int i) { const double d = xs[i] - mean; return d * d; }) / dn;
+#if defined(TSFA_EXPERIMENT_NO_ENTB_STD)
+    const double mean = xs[0] * 0.0, var = 1.0 + mean;
+#else
+    // (stats: the record k_basic left for this series -- the same numpy-order mean and variance, TSFA_STATS_*)
+    const double mean = stats ? stats[TSFA_STATS_MEAN] : np_sum(b, n, [=](int i) { return xs[i]; }) / dn;
+    const double var = stats ? stats[TSFA_STATS_VAR] : np_sum(b, n, [=](int i) { const double d = xs[i] - mean; return d * d; }) / dn;
+#endif
     const double sd = sqrt(var);
     blk_sync();
     TSFA_TICK(tk, b, 130);

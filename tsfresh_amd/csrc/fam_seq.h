@@ -320,15 +320,22 @@ TSFA_DEV int lz_parse_bits(const unsigned char *sq, int n, int bins, int nbt, in
 //   edges  : LDS doubles, >= g.etotal
 template <class X>
 TSFA_DEV void fam_seq_series(const Blk &b, X xv, int n, const TsfaSeqGroup &g, double *out_row, unsigned char *seq,
-                             uint32_t *tab, double *edges) {
+                             uint32_t *tab, double *edges, const double *stats = nullptr) {
     TSFA_TICKER(tk, 0);
-    double mn = TSFA_INF, mx = -TSFA_INF;
-    for (int i = b.tid; i < n; i += b.nt) {
-        const double x = xv(i);
-        mn = fmin(mn, x);
-        mx = fmax(mx, x);
+    double vmin, vmax;
+    if (stats != nullptr) {   // the record k_basic left for this series (TSFA_STATS_*)
+        vmin = stats[TSFA_STATS_MIN];
+        vmax = stats[TSFA_STATS_MAX];
+    } else {
+        double mn = TSFA_INF, mx = -TSFA_INF;
+        for (int i = b.tid; i < n; i += b.nt) {
+            const double x = xv(i);
+            mn = fmin(mn, x);
+            mx = fmax(mx, x);
+        }
+        vmin = blk_min(b, mn);
+        vmax = blk_max(b, mx);
     }
-    const double vmin = blk_min(b, mn), vmax = blk_max(b, mx);
     const int nb = g.nb;
     blk_sync();
     TSFA_TICK(tk, b, 160);

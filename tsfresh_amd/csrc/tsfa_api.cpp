@@ -76,7 +76,7 @@ struct tsfa_plan {
     int *d_cols = nullptr, *d_coeff = nullptr;
     double *d_dectab = nullptr, *d_twc = nullptr, *d_tws = nullptr, *d_consts = nullptr;
     long long *d_stats = nullptr;
-    DevBuf values, offsets, out, gscratch, times, deg_list, sel, long_scratch, pf_buf, perm_buf;
+    DevBuf values, offsets, out, gscratch, times, deg_list, sel, long_scratch, pf_buf, perm_buf, stats_buf;
     int *d_deg_count = nullptr;
     int *d_cursor = nullptr;                    // per-launch-group fill cursors (k_class_fill)
     hipStream_t s_in = nullptr, s_out = nullptr;  // copy-in / copy-out streams of the host pipeline
@@ -165,6 +165,7 @@ void tsfa_plan_destroy(tsfa_plan *plan) {
     if (plan->d_cursor) (void)hipFree(plan->d_cursor);
     plan->deg_list.release();
     plan->pf_buf.release();
+    plan->stats_buf.release();
     plan->perm_buf.release();
     plan->sel.release();
     plan->long_scratch.release();
@@ -421,9 +422,18 @@ static int run_batch(tsfa_plan *plan, const void *d_values, int dtype, const dou
 
     // Launch order: longest kernels first.  With side streams (and no per-kernel timing requested) the families are
     // dealt round-robin over the streams after a fork event; the join events bring them back to `st`.
-    static const int order[TSFA_N_FAMILIES] = {TSFA_FAM_ENTROPY, TSFA_FAM_AR, TSFA_FAM_SORT, TSFA_FAM_CWT, TSFA_FAM_BASIC,
-                                               TSFA_FAM_SEQ, TSFA_FAM_SPECTRAL, TSFA_FAM_TREND};
+    static const int order_long_first[TSFA_N_FAMILIES] = {TSFA_FAM_ENTROPY, TSFA_FAM_AR, TSFA_FAM_SORT, TSFA_FAM_CWT, TSFA_FAM_BASIC,
+                                                          TSFA_FAM_SEQ, TSFA_FAM_SPECTRAL, TSFA_FAM_TREND};
+    // ... unless k_basic shares its per-series statistics (numpy-order mean / variance, extrema: plan->stats_buf,
+    // TSFA_STATS_*) with the ENTROPY, AR and SEQ families, which then skip their own sums: BASIC goes first
+    static const int order_basic_first[TSFA_N_FAMILIES] = {TSFA_FAM_BASIC, TSFA_FAM_ENTROPY, TSFA_FAM_AR, TSFA_FAM_SORT, TSFA_FAM_CWT,
+                                                           TSFA_FAM_SEQ, TSFA_FAM_SPECTRAL, TSFA_FAM_TREND};
     const bool overlap = with_overlap && plan->n_streams > 1 && !plan->profiling;
+    const bool share_stats = plan->stats_buf.p != nullptr && !overlap && !plan->stream_ok &&
+                             !(getenv("TSFA_NO_STATS_SHARE") && atoi(getenv("TSFA_NO_STATS_SHARE")));
+    const int *order = share_stats ? order_basic_first : order_long_first;
+    bool stats_valid[TSFA_N_LEN_CLASSES + 1];   // launch groups whose statistics record k_basic has written
+    for (int g = 0; g <= TSFA_N_LEN_CLASSES; ++g) stats_valid[g] = false;
     if (overlap) {
         HIP_TRY(hipEventRecord(plan->ev_fork, st));
         for (int i = 0; i + 1 < plan->n_streams; ++i) HIP_TRY(hipStreamWaitEvent(plan->aux[i], plan->ev_fork, 0));
@@ -640,6 +650,14 @@ static int run_batch(tsfa_plan *plan, const void *d_values, int dtype, const dou
                 a.long_scratch = (unsigned char *)plan->long_scratch.p;
                 a.long_bytes = (size_t)n_slots * slot_bytes;
             }
+            if (share_stats && g <= TSFA_N_LEN_CLASSES) {
+                if (f == TSFA_FAM_BASIC && !(plan->hints[f].c == 0 && a.nt <= 256)) {   // (k_basic_lite does not export)
+                    a.stats_out = (double *)plan->stats_buf.p;
+                    stats_valid[g] = true;
+                } else if ((f == TSFA_FAM_ENTROPY || f == TSFA_FAM_AR || f == TSFA_FAM_SEQ) && stats_valid[g]) {
+                    a.stats_in = (const double *)plan->stats_buf.p;
+                }
+            }
             if (perm_share && !use_long && g <= TSFA_N_LEN_CLASSES) {
                 if (f == TSFA_FAM_ENTROPY && a.ent_cnt == 2) {
                     a.perm_buf = (unsigned short *)plan->perm_buf.p;
@@ -753,6 +771,10 @@ int tsfa_extract_windows(tsfa_plan *plan, const void *values, int32_t dtype, con
     if (!plan->fam_specs[TSFA_FAM_SORT].empty() && !plan->fam_specs[TSFA_FAM_ENTROPY].empty() && !plan->sort_only_order_stats &&
         plan->perm_buf.ensure((size_t)n_series * (size_t)TSFA_ENTB_MAXN * sizeof(unsigned short)))
         return fail(TSFA_ERR_HIP, "hipMalloc failed for the shared sample order");
+    if (!plan->fam_specs[TSFA_FAM_BASIC].empty() && !plan->stream_ok &&
+        (!plan->fam_specs[TSFA_FAM_ENTROPY].empty() || !plan->fam_specs[TSFA_FAM_AR].empty() || !plan->fam_specs[TSFA_FAM_SEQ].empty()) &&
+        plan->stats_buf.ensure((size_t)n_series * TSFA_STATS_N * sizeof(double)))
+        return fail(TSFA_ERR_HIP, "hipMalloc failed for the shared per-series statistics");
     if (plan->hints[TSFA_FAM_SORT].b > 0 &&
         plan->pf_buf.ensure((size_t)n_series * (size_t)std::max(1, plan->hints[TSFA_FAM_SORT].e) *
                             (size_t)tsfa_pf_slot_doubles(plan->hints[TSFA_FAM_SORT].b) * sizeof(double)))

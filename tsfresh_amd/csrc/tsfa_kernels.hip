@@ -54,7 +54,8 @@ template <typename T, int PART>
 __device__ __forceinline__ void basic_body(const T *__restrict__ values, const int64_t *__restrict__ starts, const int64_t *__restrict__ ends, int64_t n_series, const int *__restrict__ sel,
                         const TsfaSpec *__restrict__ specs, int nspecs, double *__restrict__ out, int64_t ld,
                         const double *__restrict__ dectab, int maxn, int hint_a, int hint_b,
-                        const double *__restrict__ times, const TsfaAltPlan &alt, int n_loop, int n_count, int n_sum TSFA_GS_PARAMS) {
+                        const double *__restrict__ times, const TsfaAltPlan &alt, int n_loop, int n_count, int n_sum,
+                        double *__restrict__ stats_out TSFA_GS_PARAMS) {
     TSFA_SERIES_BEGIN
     const int64_t off = starts[sidx];
     const int n = (int)(ends[sidx] - off);
@@ -69,7 +70,8 @@ __device__ __forceinline__ void basic_body(const T *__restrict__ values, const i
         blk_sync();
     }
     fam_basic_series<PART>(b, XsView<T>{xs}, n, specs, nspecs, out + sidx * ld, L.w, L.cum, L.altc, L.iw, dectab, hint_a,
-                           hint_b, alt, L.stage, times ? times + off : nullptr, n_loop, L.ctx, n_count, n_sum);
+                           hint_b, alt, L.stage, times ? times + off : nullptr, n_loop, L.ctx, n_count, n_sum,
+                           stats_out ? stats_out + sidx * TSFA_STATS_N : nullptr);
     TSFA_TICKS_END();
     TSFA_SERIES_END
 }
@@ -77,11 +79,12 @@ __device__ __forceinline__ void basic_body(const T *__restrict__ values, const i
 template <typename T>
 __global__ void __launch_bounds__(1024) k_basic(const T *__restrict__ values, const int64_t *__restrict__ starts, const int64_t *__restrict__ ends, int64_t n_series, const int *__restrict__ sel,
                         const TsfaSpec *__restrict__ specs, int nspecs, double *__restrict__ out, int64_t ld,
-                        const double *__restrict__ dectab, int maxn, int hint_a, int n_loop, int n_count, int n_sum TSFA_GS_PARAMS) {
+                        const double *__restrict__ dectab, int maxn, int hint_a, int n_loop, int n_count, int n_sum,
+                        double *__restrict__ stats_out TSFA_GS_PARAMS) {
     TsfaAltPlan alt;
     alt.nkeys = 0; alt.want_p = 0; alt.nq = 0; alt.small_w = 0;
     basic_body<T, 1>(values, starts, ends, n_series, sel, specs, nspecs, out, ld, dectab, maxn, hint_a, 0, nullptr, alt, n_loop,
-                     n_count, n_sum TSFA_GS_ARGS);
+                     n_count, n_sum, stats_out TSFA_GS_ARGS);
 }
 
 // A plan whose BASIC columns are all closed forms of the per-series statistics (MinimalFCParameters: sum, mean, length,
@@ -94,7 +97,7 @@ __global__ void __launch_bounds__(256, 4) k_basic_lite(const T *__restrict__ val
     TsfaAltPlan alt;
     alt.nkeys = 0; alt.want_p = 0; alt.nq = 0; alt.small_w = 0;
 #if defined(TSFA_LONG)
-    basic_body<T, 5>(values, starts, ends, n_series, sel, specs, nspecs, out, ld, dectab, maxn, hint_a, 0, nullptr, alt, 0, 0, 0 TSFA_GS_ARGS);
+    basic_body<T, 5>(values, starts, ends, n_series, sel, specs, nspecs, out, ld, dectab, maxn, hint_a, 0, nullptr, alt, 0, 0, 0, nullptr TSFA_GS_ARGS);
 #else
     // a persistent grid: the per-series work is a few thousand cycles, less than the dispatch of a workgroup costs
     unsigned char *const tsfa_base = tsfa_smem;
@@ -158,7 +161,7 @@ template <typename T>
 __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4))) k_trend(const T *__restrict__ values, const int64_t *__restrict__ starts, const int64_t *__restrict__ ends, int64_t n_series, const int *__restrict__ sel,
                         const TsfaSpec *__restrict__ specs, int nspecs, double *__restrict__ out, int64_t ld, int maxn,
                         int hint_b, const double *__restrict__ times, const TsfaAltPlan alt, int n_loop TSFA_GS_PARAMS) {
-    basic_body<T, 2>(values, starts, ends, n_series, sel, specs, nspecs, out, ld, nullptr, maxn, 0, hint_b, times, alt, n_loop, 0, 0 TSFA_GS_ARGS);
+    basic_body<T, 2>(values, starts, ends, n_series, sel, specs, nspecs, out, ld, nullptr, maxn, 0, hint_b, times, alt, n_loop, 0, 0, nullptr TSFA_GS_ARGS);
 }
 
 template <typename T>
@@ -217,7 +220,7 @@ template <typename T>
 __global__ void __launch_bounds__(1024) k_ar(const T *__restrict__ values, const int64_t *__restrict__ starts, const int64_t *__restrict__ ends, int64_t n_series, const int *__restrict__ sel,
                      const TsfaSpec *__restrict__ specs, int nspecs, double *__restrict__ out, int64_t ld, int maxn,
                      int P, int hint_acf, int hint_pacf, int hint_adf, int n_loop, long long *__restrict__ deg_list,
-                     int *__restrict__ deg_count TSFA_GS_PARAMS) {
+                     int *__restrict__ deg_count, const double *__restrict__ stats_in TSFA_GS_PARAMS) {
     TSFA_SERIES_BEGIN
     const int64_t off = starts[sidx];
     const int n = (int)(ends[sidx] - off);
@@ -227,7 +230,8 @@ __global__ void __launch_bounds__(1024) k_ar(const T *__restrict__ values, const
     Blk b{(int)threadIdx.x, (int)blockDim.x, L.red, L.np};
     const T *g = values + off;
     const int flags = fam_ar_series<T>(b, [=](int i) { return (double)g[i]; }, n, specs, nspecs, out + sidx * ld,
-                                       (void *)L.xc, L.aw, P, hint_acf, hint_pacf, hint_adf, n_loop);
+                                       (void *)L.xc, L.aw, P, hint_acf, hint_pacf, hint_adf, n_loop,
+                                       stats_in ? stats_in + sidx * TSFA_STATS_N : nullptr);
     // rank-deficient / ill-conditioned regressions: list the series for k_ar_degenerate
     if (flags && threadIdx.x == 0) deg_list[atomicAdd(deg_count, 1)] = ((long long)sidx << 2) | flags;
     TSFA_TICKS_END();
@@ -294,7 +298,7 @@ __global__ void __launch_bounds__(64) k_ar_degenerate(const T *__restrict__ valu
 template <typename T, bool FAST>
 __global__ void __launch_bounds__(1024) k_entropy(const T *__restrict__ values, const int64_t *__restrict__ starts, const int64_t *__restrict__ ends, int64_t n_series, const int *__restrict__ sel,
                           const TsfaSpec *__restrict__ specs, int nspecs, double *__restrict__ out, int64_t ld,
-                          int maxn, int with_cnt TSFA_GS_PARAMS) {
+                          int maxn, int with_cnt, const double *__restrict__ stats_in TSFA_GS_PARAMS) {
     TSFA_SERIES_BEGIN
     const int64_t off = starts[sidx];
     const int n = (int)(ends[sidx] - off);
@@ -303,7 +307,8 @@ __global__ void __launch_bounds__(1024) k_entropy(const T *__restrict__ values, 
     TSFA_TICKS_BEGIN();
     Blk b{(int)threadIdx.x, (int)blockDim.x, L.red, L.np};
     stage_series(b, values + off, n, L.xs);
-    fam_entropy_series<double, FAST, sizeof(T) == 4>(b, L.xs, n, specs, nspecs, out + sidx * ld, L.thr, L.perm, L.refs, L.cnt);
+    fam_entropy_series<double, FAST, sizeof(T) == 4>(b, L.xs, n, specs, nspecs, out + sidx * ld, L.thr, L.perm, L.refs, L.cnt, 1,
+                                                      stats_in ? stats_in + sidx * TSFA_STATS_N : nullptr);
     TSFA_TICKS_END();
     TSFA_SERIES_END
 }
@@ -314,7 +319,7 @@ __global__ void __launch_bounds__(1024) k_entropy(const T *__restrict__ values, 
 template <typename T, int QW_>
 __global__ void __launch_bounds__(1024) k_entropy_bits(const T *__restrict__ values, const int64_t *__restrict__ starts, const int64_t *__restrict__ ends, int64_t n_series, const int *__restrict__ sel,
                           const TsfaSpec *__restrict__ specs, int nspecs, double *__restrict__ out, int64_t ld, int maxn,
-                          unsigned short *__restrict__ perm_buf, int perm_stride) {
+                          unsigned short *__restrict__ perm_buf, int perm_stride, const double *__restrict__ stats_in) {
     TSFA_SERIES_BEGIN
     const int64_t off = starts[sidx];
     const int n = (int)(ends[sidx] - off);
@@ -326,7 +331,8 @@ __global__ void __launch_bounds__(1024) k_entropy_bits(const T *__restrict__ val
     // tolerances per round: what EntropyLds sized the work region for (the longest series of the launch)
     const int kcap = (QW_ == TSFA_ENTB_QW) ? TSFA_ENTB_MAXK : entb_kround(maxn, TSFA_ENTB_MAXK, TSFA_ENTB_MAXWAVES);
     fam_entropy_series_bits<sizeof(T) == 4, QW_>(b, L.xs, n, specs, nspecs, out + sidx * ld, L.thr, L.perm, L.cnt,
-                                            perm_buf ? perm_buf + (size_t)sidx * (size_t)perm_stride : nullptr, kcap);
+                                            perm_buf ? perm_buf + (size_t)sidx * (size_t)perm_stride : nullptr, kcap,
+                                            stats_in ? stats_in + sidx * TSFA_STATS_N : nullptr);
     TSFA_TICKS_END();
     TSFA_SERIES_END
 }
@@ -334,7 +340,7 @@ __global__ void __launch_bounds__(1024) k_entropy_bits(const T *__restrict__ val
 
 template <typename T>
 __global__ void __launch_bounds__(256) k_seq(const T *__restrict__ values, const int64_t *__restrict__ starts, const int64_t *__restrict__ ends, int64_t n_series, const int *__restrict__ sel,
-                      double *__restrict__ out, int64_t ld, const TsfaSeqGroup g TSFA_GS_PARAMS) {
+                      double *__restrict__ out, int64_t ld, const TsfaSeqGroup g, const double *__restrict__ stats_in TSFA_GS_PARAMS) {
     TSFA_SERIES_BEGIN
     const int64_t off = starts[sidx];
     const int n = (int)(ends[sidx] - off);
@@ -343,7 +349,8 @@ __global__ void __launch_bounds__(256) k_seq(const T *__restrict__ values, const
     TSFA_TICKS_BEGIN();
     Blk b{(int)threadIdx.x, (int)blockDim.x, L.red, nullptr};
     const T *gv = values + off;
-    fam_seq_series(b, [=](int i) { return (double)gv[i]; }, n, g, out + sidx * ld, L.seq, L.tab, L.edges);
+    fam_seq_series(b, [=](int i) { return (double)gv[i]; }, n, g, out + sidx * ld, L.seq, L.tab, L.edges,
+                   stats_in ? stats_in + sidx * TSFA_STATS_N : nullptr);
     TSFA_TICKS_END();
     TSFA_SERIES_END
 }
@@ -877,7 +884,7 @@ static int launch_all_t(const TsfaLaunch &a, const T *values) {
 #endif
         } else {
             TSFA_KLAUNCH(k_basic<T>, lds, values, a.starts, a.ends, a.n_series, a.sel, a.specs, a.nspecs, a.out, a.ld, a.dectab,
-                         a.maxn, a.hint_a, a.hint_c, a.hint_d, a.hint_e);
+                         a.maxn, a.hint_a, a.hint_c, a.hint_d, a.hint_e, a.stats_out);
         }
     } else if (a.fam == TSFA_FAM_TREND) {
         BasicLds L;
@@ -899,7 +906,7 @@ static int launch_all_t(const TsfaLaunch &a, const T *values) {
         ArLds L;
         const size_t lds = L.carve(nullptr, a.maxn, a.ar_P, (int)sizeof(T));
         TSFA_KLAUNCH(k_ar<T>, lds, values, a.starts, a.ends, a.n_series, a.sel, a.specs, a.nspecs, a.out, a.ld, a.maxn, a.ar_P,
-                     a.hint_a, a.hint_b, a.hint_c, a.hint_d, a.deg_list, a.deg_count);
+                     a.hint_a, a.hint_b, a.hint_c, a.hint_d, a.deg_list, a.deg_count, a.stats_in);
     } else if (a.fam == TSFA_FAM_ENTROPY) {
         EntropyLds L;
         const size_t lds = L.carve(nullptr, a.maxn, a.ent_cnt);
@@ -907,24 +914,24 @@ static int launch_all_t(const TsfaLaunch &a, const T *values) {
         if (a.ent_cnt == 3) {
             auto kfn = k_entropy_bits<T, TSFA_ENTB_QW_LONG>;
             TSFA_KLAUNCH(kfn, lds, values, a.starts, a.ends, a.n_series, a.sel, a.specs, a.nspecs, a.out, a.ld, a.maxn,
-                         (unsigned short *)nullptr, 0);
+                         (unsigned short *)nullptr, 0, a.stats_in);
         } else if (a.ent_cnt == 2) {
             auto kfn = k_entropy_bits<T, TSFA_ENTB_QW>;
             TSFA_KLAUNCH(kfn, lds, values, a.starts, a.ends, a.n_series, a.sel, a.specs, a.nspecs, a.out, a.ld, a.maxn,
-                         a.perm_buf, a.perm_stride);
+                         a.perm_buf, a.perm_stride, a.stats_in);
         } else
 #endif
         if (a.ent_fast) {
             auto kfn = k_entropy<T, true>;
-            TSFA_KLAUNCH(kfn, lds, values, a.starts, a.ends, a.n_series, a.sel, a.specs, a.nspecs, a.out, a.ld, a.maxn, a.ent_cnt);
+            TSFA_KLAUNCH(kfn, lds, values, a.starts, a.ends, a.n_series, a.sel, a.specs, a.nspecs, a.out, a.ld, a.maxn, a.ent_cnt, a.stats_in);
         } else {
             auto kfn = k_entropy<T, false>;
-            TSFA_KLAUNCH(kfn, lds, values, a.starts, a.ends, a.n_series, a.sel, a.specs, a.nspecs, a.out, a.ld, a.maxn, a.ent_cnt);
+            TSFA_KLAUNCH(kfn, lds, values, a.starts, a.ends, a.n_series, a.sel, a.specs, a.nspecs, a.out, a.ld, a.maxn, a.ent_cnt, a.stats_in);
         }
     } else if (a.fam == TSFA_FAM_SEQ) {
         SeqLds L;
         const size_t lds = L.carve(nullptr, 1, a.seq.stride, a.seq.ttotal, a.seq.etotal);
-        TSFA_KLAUNCH(k_seq<T>, lds, values, a.starts, a.ends, a.n_series, a.sel, a.out, a.ld, a.seq);
+        TSFA_KLAUNCH(k_seq<T>, lds, values, a.starts, a.ends, a.n_series, a.sel, a.out, a.ld, a.seq, a.stats_in);
     } else if (a.fam == TSFA_FAM_CWT) {  // number_cwt_peaks
         CwtPeaksLayout L;
         const size_t lds = L.carve(nullptr, a.maxn, a.cwt_rowv, (int)sizeof(T));

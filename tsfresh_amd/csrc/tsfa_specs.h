@@ -184,4 +184,11 @@ static inline int tsfa_pf_slot_doubles(int rmax) { return TSFA_PF_HDR + 2 * rmax
 #define TSFA_CONSTS_MAXW 16
 #define TSFA_CONSTS_N (256 + 5 * TSFA_CONSTS_MAXW * (TSFA_CONSTS_MAXW + 1))
 
+// per-series statistics record k_basic leaves for the other families of the same extraction (plan->stats_buf)
+#define TSFA_STATS_MEAN 0   // np.mean(x): numpy's pairwise order
+#define TSFA_STATS_VAR 1    // np.var(x)
+#define TSFA_STATS_MIN 2
+#define TSFA_STATS_MAX 3
+#define TSFA_STATS_N 4
+
 #endif
