@@ -1,7 +1,7 @@
 #!/bin/bash
 # round 4, the measurement set from ONE build: gpu tests, the bench line (with cpu_baseline), rocprofv3 kernel stats of
 # the same command, issue / MFMA / HBM counters, the other BASELINE configs as bench lines.   usage: bash profiles/r04_final.sh TAG
-TAG=${1:-r04_g}
+TAG=${1:-r04_z}
 export TMPDIR=/tmp
 O=gpurun_out/$TAG; rm -rf $O; mkdir -p $O
 TSFA_PARITY_SKIPS_MD=$O/parity_skips.md timeout 1800 python -m pytest tests -m gpu -q > $O/pytest_gpu.log 2>&1; echo "pytest rc=$?" >> $O/pytest_gpu.log; tail -3 $O/pytest_gpu.log
@@ -22,5 +22,7 @@ for l in open("$O/configs.jsonl"):
     print(d["config"]["workload"][:90], "|", round(d["ms_per_step"], 3), "ms |", round(d["value"]), "series/s | roofline", d["roofline"]["kernel"], round(d["roofline"]["frac"], 4), d.get("parity_sample"))
 PY
 rm -rf $O/prof gpurun_out/hbm/*/
+# parity fuzz on the device with the final build: random calculator subsets x random ragged batches against the oracle
+( timeout 900 python profiles/fuzz_parity.py 40 4101; timeout 600 python profiles/fuzz_parity.py 30 4102 ) > $O/fuzz_gpu.log 2>&1; tail -3 $O/fuzz_gpu.log
 # the long-series check of VERDICT r3 #8: 2 000 x 16 384 Comprehensive (the run that "did not finish in 600 s")
 ( time timeout 900 python bench.py --n-series 2000 --length 16384 --steps 1 --warmup 0 --no-cpu-baseline --no-e2e ) > $O/long_2000x16384.json 2> $O/long_2000x16384.err; tail -c 600 $O/long_2000x16384.json; tail -4 $O/long_2000x16384.err

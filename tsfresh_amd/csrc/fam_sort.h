@@ -639,7 +639,7 @@ TSFA_DEV void fam_sort_series(const Blk &b, const ST *xs_raw, int n, const TsfaS
                               double *out_row, ST *srt_raw, double *w, int *iw, const TsfaCqPlan &cqplan, double *cq,
                               TsfaSpec *stage, int n_loop = -1, double *ctx = nullptr, int w_doubles = 1280,
                               FrDefer df = FrDefer{nullptr, nullptr, TSFA_PF_HDR + 2 * TSFA_FRIEDRICH_MAX_R, 0, 0},
-                              const unsigned short *perm_in = nullptr) {
+                              const unsigned short *perm_in = nullptr, const double *stats = nullptr) {
     const int hist_words = 2 * w_doubles;  // iw aliases w: 32-bit words of the ordinal-pattern histogram
     // n_loop columns go through the column loop; the rest are evaluated by sort_epilogue (lane = column)
     const int nloop = (n_loop >= 0 && ctx != nullptr) ? n_loop : nspecs;
@@ -689,7 +689,8 @@ TSFA_DEV void fam_sort_series(const Blk &b, const ST *xs_raw, int n, const TsfaS
             break;
         case TSFA_C_SYMMETRY_LOOKING: {                                  // fc.py:299
             if (!have_sym) {
-                const double mean = np_sum(b, n, [=](int i) { return xs[i]; }) / dn;
+                // (stats: the record k_basic left for this series, TSFA_STATS_*: the same numpy-order mean)
+                const double mean = stats ? stats[TSFA_STATS_MEAN] : np_sum(b, n, [=](int i) { return xs[i]; }) / dn;
                 const double med = (n & 1) ? srt[(n - 1) / 2] : (0.0 + srt[n / 2 - 1] + srt[n / 2]) / 2.0;
                 sym_dist = fabs(mean - med);
                 have_sym = true;

@@ -654,7 +654,7 @@ static int run_batch(tsfa_plan *plan, const void *d_values, int dtype, const dou
                 if (f == TSFA_FAM_BASIC && !(plan->hints[f].c == 0 && a.nt <= 256)) {   // (k_basic_lite does not export)
                     a.stats_out = (double *)plan->stats_buf.p;
                     stats_valid[g] = true;
-                } else if ((f == TSFA_FAM_ENTROPY || f == TSFA_FAM_AR || f == TSFA_FAM_SEQ) && stats_valid[g]) {
+                } else if ((f == TSFA_FAM_ENTROPY || f == TSFA_FAM_AR || f == TSFA_FAM_SEQ || f == TSFA_FAM_SORT) && stats_valid[g]) {
                     a.stats_in = (const double *)plan->stats_buf.p;
                 }
             }
@@ -772,7 +772,8 @@ int tsfa_extract_windows(tsfa_plan *plan, const void *values, int32_t dtype, con
         plan->perm_buf.ensure((size_t)n_series * (size_t)TSFA_ENTB_MAXN * sizeof(unsigned short)))
         return fail(TSFA_ERR_HIP, "hipMalloc failed for the shared sample order");
     if (!plan->fam_specs[TSFA_FAM_BASIC].empty() && !plan->stream_ok &&
-        (!plan->fam_specs[TSFA_FAM_ENTROPY].empty() || !plan->fam_specs[TSFA_FAM_AR].empty() || !plan->fam_specs[TSFA_FAM_SEQ].empty()) &&
+        (!plan->fam_specs[TSFA_FAM_ENTROPY].empty() || !plan->fam_specs[TSFA_FAM_AR].empty() || !plan->fam_specs[TSFA_FAM_SEQ].empty() ||
+         !plan->fam_specs[TSFA_FAM_SORT].empty()) &&
         plan->stats_buf.ensure((size_t)n_series * TSFA_STATS_N * sizeof(double)))
         return fail(TSFA_ERR_HIP, "hipMalloc failed for the shared per-series statistics");
     if (plan->hints[TSFA_FAM_SORT].b > 0 &&

@@ -168,7 +168,8 @@ template <typename T>
 __global__ void __launch_bounds__(1024) k_sort(const T *__restrict__ values, const int64_t *__restrict__ starts, const int64_t *__restrict__ ends, int64_t n_series, const int *__restrict__ sel,
                        const TsfaSpec *__restrict__ specs, int nspecs, double *__restrict__ out, int64_t ld, int maxn,
                        const TsfaCqPlan cqplan, int n_loop, int w_doubles, double *__restrict__ pf_buf,
-                       int *__restrict__ pf_count, int pf_slot, int pf_cap, const unsigned short *__restrict__ perm_buf, int perm_stride TSFA_GS_PARAMS) {
+                       int *__restrict__ pf_count, int pf_slot, int pf_cap, const unsigned short *__restrict__ perm_buf, int perm_stride,
+                       const double *__restrict__ stats_in TSFA_GS_PARAMS) {
     TSFA_SERIES_BEGIN
     const int64_t off = starts[sidx];
     const int n = (int)(ends[sidx] - off);
@@ -184,7 +185,8 @@ __global__ void __launch_bounds__(1024) k_sort(const T *__restrict__ values, con
     }
     fam_sort_series<T>(b, xs, n, specs, nspecs, out + sidx * ld, (T *)L.srt, L.w, L.iw, cqplan, L.cq, L.stage,
                        n_loop, L.ctx, w_doubles, FrDefer{pf_buf, pf_count, pf_slot, (long long)sidx, 0, pf_cap},
-                       perm_buf ? perm_buf + (size_t)sidx * (size_t)perm_stride : nullptr);
+                       perm_buf ? perm_buf + (size_t)sidx * (size_t)perm_stride : nullptr,
+                       stats_in ? stats_in + sidx * TSFA_STATS_N : nullptr);
     TSFA_TICKS_END();
     TSFA_SERIES_END
 }
@@ -896,7 +898,7 @@ static int launch_all_t(const TsfaLaunch &a, const T *values) {
         const int wd = (a.hint_a >= 320) ? a.hint_a : 1280;
         const size_t lds = L.carve(nullptr, a.maxn, nt, (int)sizeof(T), wd);
         TSFA_KLAUNCH(k_sort<T>, lds, values, a.starts, a.ends, a.n_series, a.sel, a.specs, a.nspecs, a.out, a.ld, a.maxn, a.cq,
-                     a.hint_c, wd, a.pf_buf, a.pf_count, a.pf_slot, a.pf_cap, a.perm_buf, a.perm_stride);
+                     a.hint_c, wd, a.pf_buf, a.pf_count, a.pf_slot, a.pf_cap, a.perm_buf, a.perm_stride, a.stats_in);
     } else if (a.fam == TSFA_FAM_SPECTRAL) {
         SpectralLds L;
         const size_t lds = L.carve(nullptr, a.maxn, a.dft_n, (int)sizeof(T));
