@@ -340,7 +340,9 @@ TSFA_DEV int entb_wave_sum_i32(int v) {
 TSFA_DEV void entb_totals(const Blk &b, int kn, int k0, double *pm, double *pm1, int *sc, int *sc1, int *nm, int *nm1,
                           int nrow_m, int nrow_m1, double *part, double *racc, bool accumulate) {
     const int K = TSFA_ENTB_MAXK;
+#if !TSFA_GPU
     const double ldm = log((double)nrow_m), ldm1 = log((double)nrow_m1);
+#endif
 #if TSFA_GPU
     const int lane = b.tid & 63, wave = b.tid >> 6, nrows = b.nt >> 4;  // DPP rows of 16 lanes
     // products over the 16 lanes of a row (xor butterflies inside the row), sums over the wavefront
@@ -374,6 +376,9 @@ TSFA_DEV void entb_totals(const Blk &b, int kn, int k0, double *pm, double *pm1,
     if (b.tid < 2 * kn * nrows) part[b.tid] = log(part[b.tid]);
     blk_sync();
     if (b.tid < 2 * kn) {  // value j = 2 k + (0: m, 1: m + 1)
+        // log N of the two template counts, by the dozen lanes that use them (a float64 logarithm is ~150 instructions:
+        // evaluated at the top of the function it was paid by all eight wavefronts, 2.4 k wave-instructions per series)
+        const double ldm = log((double)nrow_m), ldm1 = log((double)nrow_m1);
         const int k = b.tid >> 1, odd = b.tid & 1;
         double a = 0.0;
         for (int r = 0; r < nrows; ++r) a += part[b.tid * nrows + r];
@@ -718,7 +723,9 @@ TSFA_DEV void fam_entropy_series_bits(const Blk &b, double *xs, int n, const Tsf
         }
         blk_sync();
         if (n >= 3) entropy_bits_batch<QW_>(b, xs, n, thr, nk, perm, work, racc, kcap_max);
-        for (int k = 0; k < nk; ++k) {
+        // lane = column: the closing divisions and sample_entropy's logarithm once per column, not once per column AND
+        // wavefront (every thread used to evaluate all six tails for thread 0 to store: 3.8 k wave-instructions per series)
+        for (int k = b.tid; k < nk; k += b.nt) {
             const TsfaSpec sp = specs[first + k];
             EntAcc a;
             a.sum_log_m = racc[4 * k + 0];
@@ -728,7 +735,7 @@ TSFA_DEV void fam_entropy_series_bits(const Blk &b, double *xs, int n, const Tsf
             double v;
             if (sp.calc == TSFA_C_APPROXIMATE_ENTROPY) v = (n <= 3) ? 0.0 : apen_from_acc(a, n, 2);
             else v = (n < 3) ? TSFA_NAN : sampen_from_acc(a, n, 2);
-            if (b.tid == 0) out_row[sp.col] = v;
+            out_row[sp.col] = v;
         }
         blk_sync();
     }

@@ -102,6 +102,13 @@ struct tsfa_plan {
     int *d_fill_cols = nullptr;
     int n_fill_cols = 0;
     int debug_skip_fam = -1;             // TSFA_DEBUG_SKIP_FAM=<family>: the audit's positive control
+    // Side lane (TSFA_PAIR=<families>, e.g. "seq" or "seq,spectral"): the named families run on a LOW-priority stream beside
+    // the others -- the dispatcher gives the main lane's workgroups every slot they can use and the side lane's the LDS /
+    // register / wavefront slots they leave (k_entropy_bits holds 122 of 160 KB of LDS and 448 of 512 VGPRs per SIMD: two
+    // k_seq workgroups fit beside it), so a latency-bound kernel fills issue slots an issue-bound one leaves idle.
+    hipStream_t side = nullptr;
+    hipEvent_t ev_side_fork = nullptr, ev_side_join = nullptr;
+    unsigned side_mask = 0;              // bit f: family f runs on the side lane
     double fill_value = __builtin_nan("");   // TSFA_DEBUG_FILL=<value>: a sentinel instead (profiles/fill_audit.py)
 };
 
@@ -189,6 +196,9 @@ void tsfa_plan_destroy(tsfa_plan *plan) {
         if (plan->ev_join[i]) (void)hipEventDestroy(plan->ev_join[i]);
     }
     if (plan->ev_fork) (void)hipEventDestroy(plan->ev_fork);
+    if (plan->side) (void)hipStreamDestroy(plan->side);
+    if (plan->ev_side_fork) (void)hipEventDestroy(plan->ev_side_fork);
+    if (plan->ev_side_join) (void)hipEventDestroy(plan->ev_side_join);
     if (plan->stream) (void)hipStreamDestroy(plan->stream);
     delete plan;
 }
@@ -279,6 +289,18 @@ int tsfa_plan_create(const tsfa_feature_spec *specs, int32_t n_specs, int32_t de
             ok = hipStreamCreateWithFlags(&plan->aux[i], hipStreamNonBlocking) == hipSuccess &&
                  hipEventCreateWithFlags(&plan->ev_join[i], hipEventDisableTiming) == hipSuccess;
         if (ok && plan->n_streams > 1) ok = hipEventCreateWithFlags(&plan->ev_fork, hipEventDisableTiming) == hipSuccess;
+    }
+    if (const char *e = getenv("TSFA_PAIR")) {
+        static const char *nm[TSFA_N_FAMILIES] = {"basic", "sort", "spectral", "ar", "entropy", "cwt", "seq", "trend"};
+        for (int f = 0; f < TSFA_N_FAMILIES; ++f)
+            if (f != TSFA_FAM_BASIC && f != TSFA_FAM_SORT && f != TSFA_FAM_ENTROPY && strstr(e, nm[f])) plan->side_mask |= 1u << f;   // (SORT reads ENTROPY's sample order: both stay on the main lane)
+        if (plan->side_mask) {
+            int least = 0, greatest = 0;
+            (void)hipDeviceGetStreamPriorityRange(&least, &greatest);
+            ok = ok && hipStreamCreateWithPriority(&plan->side, hipStreamNonBlocking, least) == hipSuccess &&
+                 hipEventCreateWithFlags(&plan->ev_side_fork, hipEventDisableTiming) == hipSuccess &&
+                 hipEventCreateWithFlags(&plan->ev_side_join, hipEventDisableTiming) == hipSuccess;
+        }
     }
     if (const char *e = getenv("TSFA_DEBUG_FILL")) { plan->fill_value = atof(e); plan->fill_all = true; }
     if (const char *e = getenv("TSFA_FILL_ALL")) plan->fill_all = plan->fill_all || atoi(e) != 0;
@@ -438,6 +460,10 @@ static int run_batch(tsfa_plan *plan, const void *d_values, int dtype, const dou
         HIP_TRY(hipEventRecord(plan->ev_fork, st));
         for (int i = 0; i + 1 < plan->n_streams; ++i) HIP_TRY(hipStreamWaitEvent(plan->aux[i], plan->ev_fork, 0));
     }
+    // side lane: forked after the first family of the order (BASIC when it shares its statistics), joined at the end
+    bool pair = plan->side != nullptr && plan->side_mask != 0 && !overlap && !plan->profiling && with_overlap;
+    for (int g = 0; g < sh.n_groups; ++g) pair = pair && sh.g_maxn[g] <= 4096;   // (the HBM-scratch build shares one scratch region)
+    bool side_forked = false, side_used = false;
     size_t slot = 0;
     int dealt = 0;
     // the sample order k_entropy_bits establishes is handed to k_sort through plan->perm_buf (2 bytes per sample): one
@@ -461,6 +487,15 @@ static int run_batch(tsfa_plan *plan, const void *d_values, int dtype, const dou
         if (overlap) {
             const int k = dealt++ % plan->n_streams;
             if (k > 0) fst = plan->aux[k - 1];
+        }
+        if (pair && fi > 0 && ((plan->side_mask >> f) & 1u)) {
+            if (!side_forked) {   // everything launched so far (k_basic and its statistics record) precedes the side lane
+                HIP_TRY(hipEventRecord(plan->ev_side_fork, st));
+                HIP_TRY(hipStreamWaitEvent(plan->side, plan->ev_side_fork, 0));
+                side_forked = true;
+            }
+            fst = plan->side;
+            side_used = true;
         }
         const char *slot_name = (plan->stream_ok && (f == TSFA_FAM_SORT || (f == TSFA_FAM_BASIC && plan->fam_specs[TSFA_FAM_SORT].empty())))
                                     ? "k_stream" : fam_names[f];
@@ -707,6 +742,10 @@ static int run_batch(tsfa_plan *plan, const void *d_values, int dtype, const dou
             HIP_TRY(hipEventRecord(plan->ev_join[i], plan->aux[i]));
             HIP_TRY(hipStreamWaitEvent(st, plan->ev_join[i], 0));
         }
+    }
+    if (side_used) {
+        HIP_TRY(hipEventRecord(plan->ev_side_join, plan->side));
+        HIP_TRY(hipStreamWaitEvent(st, plan->ev_side_join, 0));
     }
     if (plan->bank.C > 0) {
         TsfaCwtLaunch c;
