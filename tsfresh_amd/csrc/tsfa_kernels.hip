@@ -697,48 +697,86 @@ __global__ void __launch_bounds__(256) k_stream(const T *__restrict__ values, co
 // ---------------------------------------------------------------------------------------------
 typedef double tsfa_d4 __attribute__((ext_vector_type(4)));
 
-// MT 16-series row tiles per wavefront share every filter load: per k-step MT + CT loads feed MT * CT MFMAs (round 3:
-// one tile, 1 + CT loads per CT MFMAs, matrix pipe 13.6 % busy).
-template <typename T, int CT, int MT>
-__global__ void __launch_bounds__(64)
+// Workgroup = 4 wavefronts = 64 series (one 16-series row tile per wavefront); K in chunks of 16: the sample chunk
+// [64 x 16] (coalesced 64-byte rows, converted to float64 on the way) and the filter chunk [16 x 16 CT] are staged in LDS,
+// double buffered, and every wavefront feeds 4 CT MFMAs per chunk from 4 + 4 CT conflict-free ds_read_b64.  (Rounds 1-3:
+// one wavefront per 16 series reading A and B straight from global memory, one 4- or 8-byte load per lane and MFMA
+// operand: matrix pipe 13.6 % busy.)
+#define TSFA_CWT_KC 16
+template <typename T, int CT>
+__global__ void __launch_bounds__(256)
 k_cwt_gemm(const T *__restrict__ values, const int64_t *__restrict__ starts, const int64_t *__restrict__ ends, int64_t n_series,
            const double *__restrict__ W, int S4, int C, const int *__restrict__ cols,
            const int *__restrict__ coeff_idx, double *__restrict__ out, int64_t ld) {
-    __shared__ int lens[16 * MT];
-    const int lane = threadIdx.x;
+    constexpr int KC = TSFA_CWT_KC, NC = CT * 16;
+    __shared__ double sA[2][64][KC + 1];
+    __shared__ double sB[2][KC][NC + 2];
+    __shared__ int lens[64];
+    __shared__ long long offs[64];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int r = lane & 15, kq = lane >> 4;
-    const int64_t base = (int64_t)blockIdx.x * (16 * MT);
-    const T *g[MT];
-    int len[MT];
-#pragma unroll
-    for (int m = 0; m < MT; ++m) {
-        const int64_t s = base + m * 16 + r;
-        int64_t off = 0;
-        len[m] = 0;
+    const int64_t base = (int64_t)blockIdx.x * 64;
+    if (tid < 64) {
+        const int64_t s = base + tid;
+        long long off = 0;
+        int len = 0;
         if (s < n_series) {
             off = starts[s];
-            len[m] = (int)(ends[s] - off);
+            len = (int)(ends[s] - off);
         }
-        g[m] = values + off;
-        if (lane < 16) lens[m * 16 + lane] = len[m];
+        lens[tid] = len;
+        offs[tid] = off;
     }
     __syncthreads();
-    tsfa_d4 acc[MT][CT];
+    // a thread's share of a chunk: 4 samples (A: 16 consecutive samples of a series per 16 threads) and CT filter taps (B: W
+    // is [Cpad][S4], column c contiguous in k); fetched into registers BEFORE the MFMAs of the current chunk and written to
+    // the other LDS buffer AFTER them, so the global-memory latency hides behind the matrix pipe
+    double ra[4], rb[CT];
+    auto fetch = [&](int k0) {
 #pragma unroll
-    for (int m = 0; m < MT; ++m)
-#pragma unroll
-        for (int ct = 0; ct < CT; ++ct) acc[m][ct] = (tsfa_d4){0.0, 0.0, 0.0, 0.0};
-    for (int k0 = 0; k0 < S4; k0 += 4) {
-        const int k = k0 + kq;
-        double a[MT];
-#pragma unroll
-        for (int m = 0; m < MT; ++m) a[m] = (k < len[m]) ? (double)g[m][k] : 0.0;  // A[i = r][k = kq] of tile m
-#pragma unroll
-        for (int ct = 0; ct < CT; ++ct) {
-            const double bv = W[(size_t)(ct * 16 + r) * S4 + k];  // B[k = kq][j = r]
-#pragma unroll
-            for (int m = 0; m < MT; ++m) acc[m][ct] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[m], bv, acc[m][ct], 0, 0, 0);
+        for (int u = 0; u < 4; ++u) {
+            const int i = tid + u * 256, m = i / KC, kk = i - m * KC, k = k0 + kk;
+            ra[u] = (k < lens[m]) ? (double)values[offs[m] + k] : 0.0;
         }
+#pragma unroll
+        for (int u = 0; u < CT; ++u) {
+            const int i = tid + u * 256, c = i / KC, kk = i - c * KC, k = k0 + kk;
+            rb[u] = (k < S4) ? W[(size_t)c * S4 + k] : 0.0;
+        }
+    };
+    auto put = [&](int buf) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int i = tid + u * 256, m = i / KC, kk = i - m * KC;
+            sA[buf][m][kk] = ra[u];
+        }
+#pragma unroll
+        for (int u = 0; u < CT; ++u) {
+            const int i = tid + u * 256, c = i / KC, kk = i - c * KC;
+            sB[buf][kk][c] = rb[u];
+        }
+    };
+    tsfa_d4 acc[CT];
+#pragma unroll
+    for (int ct = 0; ct < CT; ++ct) acc[ct] = (tsfa_d4){0.0, 0.0, 0.0, 0.0};
+    const int nchunks = (S4 + KC - 1) / KC;
+    fetch(0);
+    put(0);
+    __syncthreads();
+    for (int ch = 0; ch < nchunks; ++ch) {
+        const int buf = ch & 1;
+        if (ch + 1 < nchunks) fetch((ch + 1) * KC);
+#pragma unroll
+        for (int ks = 0; ks < KC; ks += 4) {
+            const double a = sA[buf][wave * 16 + r][ks + kq];         // A[i = r][k = kq]
+#pragma unroll
+            for (int ct = 0; ct < CT; ++ct) {
+                const double bv = sB[buf][ks + kq][ct * 16 + r];      // B[k = kq][j = r]
+                acc[ct] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, bv, acc[ct], 0, 0, 0);
+            }
+        }
+        if (ch + 1 < nchunks) put(buf ^ 1);
+        __syncthreads();
     }
     // D[i = 4*v + kq][j = r]: the f64 16x16x4 accumulator interleaves rows across the four 16-lane groups
     // (composable_kernel xdlops_gemm.hpp mfma_f64_16x16x4f64: group_size 1, 4 groups), unlike the f32 shapes
@@ -748,13 +786,10 @@ k_cwt_gemm(const T *__restrict__ values, const int64_t *__restrict__ starts, con
         if (c >= C) continue;
         const int col = cols[c], ci = coeff_idx[c];
 #pragma unroll
-        for (int m = 0; m < MT; ++m) {
-#pragma unroll
-            for (int v = 0; v < 4; ++v) {
-                const int i = 4 * v + kq;
-                const int64_t srow = base + m * 16 + i;
-                if (srow < n_series) out[srow * ld + col] = (ci < lens[m * 16 + i]) ? acc[m][ct][v] : TSFA_NAN;
-            }
+        for (int v = 0; v < 4; ++v) {
+            const int i = wave * 16 + 4 * v + kq;
+            const int64_t srow = base + i;
+            if (srow < n_series) out[srow * ld + col] = (ci < lens[i]) ? acc[ct][v] : TSFA_NAN;
         }
     }
 }
@@ -1068,14 +1103,12 @@ int tsfa_launch_order_stats(const TsfaLaunch &a) {
 template <typename T>
 static int launch_cwt_t(const TsfaCwtLaunch &a, const T *values) {
     hipStream_t st = (hipStream_t)a.stream;
-    // MT row tiles per wavefront: 4 (64 series) while the accumulators fit (CT <= 4: 4 x 4 x 4 doubles), else 2
     const int ct = (a.C + 15) / 16;
-    const int mt = (ct <= 4) ? 4 : 2;
-    const dim3 grid((unsigned)((a.n_series + 16 * mt - 1) / (16 * mt)));
+    const dim3 grid((unsigned)((a.n_series + 63) / 64));
 #define TSFA_CWT_CASE(N)                                                                                         \
     case N:                                                                                                      \
-        k_cwt_gemm<T, N, (N <= 4 ? 4 : 2)><<<grid, 64, 0, st>>>(values, a.starts, a.ends, a.n_series, a.W, a.S4, a.C, a.cols, \
-                                                               a.coeff_idx, a.out, a.ld);                        \
+        k_cwt_gemm<T, N><<<grid, 256, 0, st>>>(values, a.starts, a.ends, a.n_series, a.W, a.S4, a.C, a.cols, a.coeff_idx, \
+                                               a.out, a.ld);                                                     \
         break;
     switch (ct) {
         TSFA_CWT_CASE(1)
