@@ -347,7 +347,7 @@ __global__ void __launch_bounds__(256) k_seq(const T *__restrict__ values, const
     const int64_t off = starts[sidx];
     const int n = (int)(ends[sidx] - off);
     SeqLds L;
-    L.carve(tsfa_base, 1, g.stride, g.ttotal, g.etotal);
+    L.carve(tsfa_base, 1, g.stride, g.ttotal, g.etotal, (int)(blockDim.x + 63) >> 6);
     TSFA_TICKS_BEGIN();
     Blk b{(int)threadIdx.x, (int)blockDim.x, L.red, nullptr};
     const T *gv = values + off;
@@ -967,7 +967,7 @@ static int launch_all_t(const TsfaLaunch &a, const T *values) {
         }
     } else if (a.fam == TSFA_FAM_SEQ) {
         SeqLds L;
-        const size_t lds = L.carve(nullptr, 1, a.seq.stride, a.seq.ttotal, a.seq.etotal);
+        const size_t lds = L.carve(nullptr, 1, a.seq.stride, a.seq.ttotal, a.seq.etotal, (nt + 63) >> 6);
         TSFA_KLAUNCH(k_seq<T>, lds, values, a.starts, a.ends, a.n_series, a.sel, a.out, a.ld, a.seq, a.stats_in);
     } else if (a.fam == TSFA_FAM_CWT) {  // number_cwt_peaks
         CwtPeaksLayout L;

@@ -47,7 +47,9 @@ struct BasicLds {
     //       the banded index_mass_quantile (nt offsets + 2 counts per q) only: half the LDS per series at n = 1024
     TSFA_HD size_t carve(unsigned char *base, int maxn, int nt, int xs_bytes = 8, int part = 3, int small_w = 0) {
         LdsCarve c{base, 0};
-        red = c.take<double>(TSFA_RED_DOUBLES);
+        // a one-wavefront workgroup never touches the cross-wavefront scratch (every blk_* reduction and blk_bcast0 test
+        // nt > 64 first): 16 bytes instead of 512 -- k_trend at 1024 samples was 16 bytes above 160 KB / 16
+        red = c.take<double>(nt <= 64 ? 2 : TSFA_RED_DOUBLES);
         xs = c.take<unsigned char>((size_t)maxn * xs_bytes);
         size_t wb = (part & 2) ? (size_t)maxn * sizeof(double) : (size_t)maxn * xs_bytes;
         if ((part & 2) && small_w) wb = (size_t)(nt + 2 * 16 + 8) * sizeof(double);
@@ -112,7 +114,9 @@ struct SpectralLds {
         ts = c.take<double>(nd);
         win = c.take<double>(256);
         pxx = c.take<double>(132);
-        iw = c.take<int>(128);
+        // the bin counters of fourier_entropy (<= 128 ints) live in the Hann window's storage: the window is dead once
+        // blk_welch has returned, and the 512 bytes are what kept a tenth workgroup off a CU at 1024 samples (16 480 B)
+        iw = (int *)(void *)win;
         return c.off;
     }
 };
@@ -185,9 +189,12 @@ struct EntropyLds {
 struct SeqLds {
     double *red; unsigned char *seq; uint32_t *tab; double *edges;
     // group: chains parsed side by side; stride: bytes per symbol row; tab_words / edge_doubles: TsfaSeqGroup totals
-    TSFA_HD size_t carve(unsigned char *base, int group, int stride, int tab_words, int edge_doubles) {
+    // nwaves: wavefronts of the workgroup -- the kernel's only use of `red` is one slot per wavefront (blk_min / blk_max):
+    // 16 bytes instead of 512 for the 128-thread workgroups of series up to 2048 samples, which is what takes a series from
+    // 13 720 to 13 224 bytes of LDS: TWELVE series per CU instead of eleven (160 KB / 12 = 13 653)
+    TSFA_HD size_t carve(unsigned char *base, int group, int stride, int tab_words, int edge_doubles, int nwaves = 16) {
         LdsCarve c{base, 0};
-        red = c.take<double>(TSFA_RED_DOUBLES);
+        red = c.take<double>(nwaves < 2 ? 2 : (nwaves + 1) & ~1);
         edges = c.take<double>(edge_doubles + 2);
         tab = c.take<uint32_t>((size_t)tab_words);
         seq = c.take<unsigned char>((size_t)group * stride + 16);
