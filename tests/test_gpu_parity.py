@@ -909,3 +909,21 @@ def test_shared_series_statistics_change_no_bit(gpu, dtype, monkeypatch):
     n3, got = hip_engine(only, values, offsets)
     cols = [names.index(c) for c in n3]
     assert np.array_equal(got, shared[:, cols], equal_nan=True)
+
+
+@pytest.mark.gpu
+def test_side_lane_changes_no_bit(gpu, monkeypatch):
+    """TSFA_PAIR (opt-in): the named families run on a low-priority side stream beside the others, forked after k_basic and
+    joined (the main stream waits for the side lane's last kernel) before the results are copied out -- same kernels on the
+    same data, so the matrix must be bit-identical."""
+    rng = np.random.default_rng(23)
+    lens = list(rng.integers(20, 1100, size=500)) + [1024] * 100
+    series = [rng.standard_normal(n).astype(np.float32) if i % 2 else np.cumsum(rng.standard_normal(n)).astype(np.float32)
+              for i, n in enumerate(lens)]
+    values = np.concatenate(series)
+    offsets = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
+    params = settings.ComprehensiveFCParameters()
+    names, one_lane = hip_engine(params, values, offsets)
+    monkeypatch.setenv("TSFA_PAIR", "seq,spectral,cwt,trend,ar")
+    names2, two_lanes = hip_engine(params, values, offsets)
+    assert names == names2 and np.array_equal(one_lane, two_lanes, equal_nan=True)

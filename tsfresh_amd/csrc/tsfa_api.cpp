@@ -447,7 +447,7 @@ static int run_batch(tsfa_plan *plan, const void *d_values, int dtype, const dou
     static const int order_long_first[TSFA_N_FAMILIES] = {TSFA_FAM_ENTROPY, TSFA_FAM_AR, TSFA_FAM_SORT, TSFA_FAM_CWT, TSFA_FAM_BASIC,
                                                           TSFA_FAM_SEQ, TSFA_FAM_SPECTRAL, TSFA_FAM_TREND};
     // ... unless k_basic shares its per-series statistics (numpy-order mean / variance, extrema: plan->stats_buf,
-    // TSFA_STATS_*) with the ENTROPY, AR and SEQ families, which then skip their own sums: BASIC goes first
+    // TSFA_STATS_*) with the ENTROPY, AR, SEQ and SORT families, which then skip their own sums: BASIC goes first
     static const int order_basic_first[TSFA_N_FAMILIES] = {TSFA_FAM_BASIC, TSFA_FAM_ENTROPY, TSFA_FAM_AR, TSFA_FAM_SORT, TSFA_FAM_CWT,
                                                            TSFA_FAM_SEQ, TSFA_FAM_SPECTRAL, TSFA_FAM_TREND};
     const bool overlap = with_overlap && plan->n_streams > 1 && !plan->profiling;

@@ -55,7 +55,7 @@ struct TsfaLaunch {
     long long *deg_list;    // AR: series listed for the double-double second pass ((index << 2) | calculator bits) ...
     int *deg_count;         // ... and their number (device; zeroed before the launch)
     double *stats_out;      // BASIC (k_basic): where to leave the per-series statistics record (TSFA_STATS_N doubles per series), or null
-    const double *stats_in; // ENTROPY / AR / SEQ: that record, when k_basic of the same extraction ran before (or null: compute)
+    const double *stats_in; // ENTROPY / AR / SEQ / SORT: that record, when k_basic of the same extraction ran before (or null: compute)
     const double *consts;   // SPECTRAL / CWT peaks: the plan's constant tables (tsfa_build_consts), device memory
     double *pf_buf;         // SORT: records of the Langevin fits left to k_langevin_dd (fam_langevin_dd.h) ...
     int *pf_count;          // ... their number (device; zeroed before the launch) ...
