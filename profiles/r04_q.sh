@@ -1,0 +1,7 @@
+#!/bin/bash
+# round 4, call Q: permutation_entropy, all dimensions from one sweep (out-of-line, LDS pointers declared); parity + steps
+export TMPDIR=/tmp
+O=gpurun_out/r04_q; rm -rf $O; mkdir -p $O
+timeout 600 python -m pytest tests -m gpu -q -x -k "perm or golden" > $O/pytest_some.log 2>&1; echo "pytest rc=$?" >> $O/pytest_some.log; tail -3 $O/pytest_some.log
+q() { timeout 300 python bench.py --steps 6 --warmup 2 --no-cpu-baseline --no-e2e $2 2>/dev/null | tail -1 | python -c "import json,sys; d=json.loads(sys.stdin.read()); print('$1', round(d['ms_per_step'],2), {k: round(v,2) for k,v in d['kernel_ms'].items()}, d.get('parity_sample'))"; }
+{ q "headline"; q "256" "--n-series 125000 --length 256"; } > $O/quick.txt 2>&1; cat $O/quick.txt

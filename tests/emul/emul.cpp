@@ -19,6 +19,7 @@
 #include "../../tsfresh_amd/csrc/fam_basic.h"
 #include "../../tsfresh_amd/csrc/fam_cwt.h"
 #include "../../tsfresh_amd/csrc/fam_entropy.h"
+#include "../../tsfresh_amd/csrc/fam_perm.h"
 #include "../../tsfresh_amd/csrc/fam_seq.h"
 #include "../../tsfresh_amd/csrc/fam_sort.h"
 #include "../../tsfresh_amd/csrc/fam_spectral.h"
@@ -158,7 +159,16 @@ extern "C" int tsfa_emul_extract_timed(const tsfa_feature_spec *specs, int n_spe
                             (s % 2) ? -1 : hints[TSFA_FAM_SORT].c, sctx.data(),
                             (s % 4 >= 2) ? hints[TSFA_FAM_SORT].a : 1280,  // plan-sized scratch: multi-pass pattern histogram
                             FrDefer{nullptr, nullptr, TSFA_PF_HDR + 2 * TSFA_FRIEDRICH_MAX_R, 0, 0},
-                            order.empty() ? nullptr : order.data());
+                            order.empty() ? nullptr : order.data(), nullptr,
+                            (s % 2 == 0) ? hints[TSFA_FAM_SORT].d : 0);   // every other series: permutation_entropy left to k_perm's code ...
+            if (s % 2 == 0 && hints[TSFA_FAM_SORT].d != 0) {                    // ... all dimensions from one sweep (fam_perm.h)
+                std::vector<int> hist(TSFA_PE_HIST_WORDS + 4);
+                std::vector<double> ltab(TSFA_PE_LOGS + TSFA_PE_MAXD + 1);
+                for (auto &v : hist) v = 0x5a5a5a5a;
+                poison(ltab);
+                fam_perm_series(b, xs.data(), n, fam[TSFA_FAM_SORT].data(), (int)fam[TSFA_FAM_SORT].size(), row,
+                                hints[TSFA_FAM_SORT].d >> 8, hist.data(), ltab.data());
+            }
         }
         if (!fam[TSFA_FAM_SPECTRAL].empty()) {
             const int nx = (maxn / 2 + 2 > 260) ? maxn / 2 + 2 : 260;

@@ -639,7 +639,7 @@ TSFA_DEV void fam_sort_series(const Blk &b, const ST *xs_raw, int n, const TsfaS
                               double *out_row, ST *srt_raw, double *w, int *iw, const TsfaCqPlan &cqplan, double *cq,
                               TsfaSpec *stage, int n_loop = -1, double *ctx = nullptr, int w_doubles = 1280,
                               FrDefer df = FrDefer{nullptr, nullptr, TSFA_PF_HDR + 2 * TSFA_FRIEDRICH_MAX_R, 0, 0},
-                              const unsigned short *perm_in = nullptr, const double *stats = nullptr) {
+                              const unsigned short *perm_in = nullptr, const double *stats = nullptr, int pe_hint = 0) {
     const int hist_words = 2 * w_doubles;  // iw aliases w: 32-bit words of the ordinal-pattern histogram
     // n_loop columns go through the column loop; the rest are evaluated by sort_epilogue (lane = column)
     const int nloop = (n_loop >= 0 && ctx != nullptr) ? n_loop : nspecs;
@@ -807,6 +807,8 @@ TSFA_DEV void fam_sort_series(const Blk &b, const ST *xs_raw, int n, const TsfaS
         } break;
         case TSFA_C_PERMUTATION_ENTROPY: {                               // fc.py:1866
             const int tau = (int)p0, D = (int)p1;
+            // pe_hint: the launch left every permutation_entropy column of the plan to k_perm (fam_perm.h)
+            if (pe_hint != 0) { TSFA_TICK(tk, b, sp.calc); continue; }
             const int num = (n >= D) ? ((n - D) / tau + 1) : 0;
             if (num <= 0) { v = TSFA_NAN; break; }
             int fact = 1;
@@ -817,6 +819,7 @@ TSFA_DEV void fam_sort_series(const Blk &b, const ST *xs_raw, int n, const TsfaS
             // computed ONCE and stay in registers for all passes (the code of a D = 7 window is 21 compares).
             const int per_pass = 2 * hist_words;
             const bool in_regs = (num <= 8 * b.nt);
+            TSFA_TICKER(tp, 0);
             int codes[8];
             if (in_regs) {
 #pragma unroll
@@ -827,11 +830,13 @@ TSFA_DEV void fam_sort_series(const Blk &b, const ST *xs_raw, int n, const TsfaS
             }
             // log(c / num) of the small counts from a table (one float64 logarithm, ~150 instructions, per lane of ONE
             // evaluation instead of one per bin / window: for D >= 5 nearly every count is below the table's end)
+            TSFA_TICK(tp, b, 236);
             const int LT = 64;
             double *ltab = b.np->leaf_sum;  // the numpy-order scratch is idle here
             blk_sync();
             for (int c = b.tid; c < LT; c += b.nt) ltab[c] = (c > 0) ? log((double)c / (double)num) : 0.0;
             blk_sync();
+            TSFA_TICK(tp, b, 237);
             double e = 0.0;
             for (int base = 0; base < fact; base += per_pass) {
                 const int top = (fact - base < per_pass) ? (fact - base) : per_pass;  // patterns of this pass
@@ -897,7 +902,9 @@ TSFA_DEV void fam_sort_series(const Blk &b, const ST *xs_raw, int n, const TsfaS
                     e += acc / (double)num;
                 }
             }
+            TSFA_TICK(tp, b, 238);
             v = -blk_sum(b, e);
+            TSFA_TICK(tp, b, 239);
         } break;
         case TSFA_C_FRIEDRICH_COEFFICIENTS:                              // fc.py:2082
         case TSFA_C_MAX_LANGEVIN_FIXED_POINT: {                          // fc.py:2134

@@ -500,6 +500,7 @@ static int run_batch(tsfa_plan *plan, const void *d_values, int dtype, const dou
         const char *slot_name = (plan->stream_ok && (f == TSFA_FAM_SORT || (f == TSFA_FAM_BASIC && plan->fam_specs[TSFA_FAM_SORT].empty())))
                                     ? "k_stream" : fam_names[f];
         if (record(plan, fst, slot, slot_name, true)) return fail(TSFA_ERR_HIP, "event record failed");
+        std::vector<TsfaLaunch> perm_launches;   // SORT: the groups whose permutation_entropy columns go to k_perm (fam_perm.h)
         for (int g = sh.n_groups - 1; g >= 0; --g) {  // longest series first
             const int maxn = sh.g_maxn[g];
             const long long max_np2 = sh.g_np2[g];
@@ -703,6 +704,23 @@ static int run_batch(tsfa_plan *plan, const void *d_values, int dtype, const dou
                     a.perm_stride = TSFA_ENTB_MAXN;
                 }
             }
+            if (f == TSFA_FAM_SORT) {
+                // every permutation_entropy column of the plan from one sweep, in a kernel of its own (hints.d: one stride,
+                // the dimensions 3 .. 7): where the series and the histogram of all patterns fit LDS -- also beside the
+                // HBM-scratch build of k_sort -- with at most eight windows per thread; k_sort then skips those columns
+                a.hint_d = 0;
+                if (plan->hints[f].d != 0) {
+                    const int pnt = (maxn <= 2048) ? std::min(256, std::max(64, ((maxn / 4 + 63) / 64) * 64))
+                                                   : std::min(1024, ((maxn / 8 + 63) / 64) * 64);
+                    if (tsfa_perm_lds_bytes(maxn, pnt, dtype == TSFA_F32 ? 4 : 8) <= TSFA_LDS_LIMIT) {
+                        a.hint_d = plan->hints[f].d;
+                        TsfaLaunch pa = a;
+                        pa.nt = pnt;
+                        pa.long_scratch = nullptr;
+                        perm_launches.push_back(pa);
+                    }
+                }
+            }
             int rc = 0;
             if (plan->stream_ok && (f == TSFA_FAM_SORT || f == TSFA_FAM_BASIC) && maxn <= 2048 && g <= TSFA_N_LEN_CLASSES) {
                 if (stream_done[g]) continue;   // BASIC's turn after the SORT family's launch served both
@@ -736,6 +754,15 @@ static int run_batch(tsfa_plan *plan, const void *d_values, int dtype, const dou
         }
         if (record(plan, fst, slot, slot_name, false)) return fail(TSFA_ERR_HIP, "event record failed");
         ++slot;
+        if (!perm_launches.empty()) {
+            if (record(plan, fst, slot, "k_perm", true)) return fail(TSFA_ERR_HIP, "event record failed");
+            for (const auto &pa : perm_launches) {
+                const int rc = tsfa_launch_perm(pa);
+                if (rc) return fail(TSFA_ERR_HIP, std::string("k_perm launch failed: ") + hipGetErrorString((hipError_t)rc));
+            }
+            if (record(plan, fst, slot, "k_perm", false)) return fail(TSFA_ERR_HIP, "event record failed");
+            ++slot;
+        }
     }
     if (overlap) {
         for (int i = 0; i + 1 < plan->n_streams; ++i) {

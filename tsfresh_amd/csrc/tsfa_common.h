@@ -29,6 +29,13 @@
 #define TSFA_DEVN static
 #define TSFA_MEM inline
 #endif
+// p points into LDS (for out-of-line device functions, whose pointer arguments are generic: InferAddressSpaces turns the
+// accesses behind such an assumption into ds_* instructions)
+#if defined(__HIP_DEVICE_COMPILE__)
+#define TSFA_ASSUME_LDS(p) __builtin_assume(__builtin_amdgcn_is_shared((const void *)(p)))
+#else
+#define TSFA_ASSUME_LDS(p) ((void)0)
+#endif
 
 #define TSFA_NAN (__builtin_nan(""))
 #define TSFA_INF (__builtin_inf())

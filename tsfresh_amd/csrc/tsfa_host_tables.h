@@ -199,6 +199,23 @@ static inline void tsfa_prepare_family(int fam, std::vector<TsfaSpec> &specs, Ts
                 if (is_lv(s)) s = lv[k++];
             h.e = (int)order.size();
         }
+        // d = (stride << 8) | set of dimensions, when every permutation_entropy column of the plan has the same stride and
+        // the dimensions are exactly 3 .. 7 (ComprehensiveFCParameters, fam_perm.h TSFA_PE_MASK): k_perm evaluates them all
+        // from one sweep of the windows and k_sort skips them
+        {
+            int tau = -1, n_pe = 0;
+            unsigned mask = 0;
+            bool ok = true;
+            for (const auto &s : loop)
+                if (s.calc == TSFA_C_PERMUTATION_ENTROPY) {
+                    const int t = (int)s.p[0], D = (int)s.p[1];
+                    if (tau < 0) tau = t;
+                    if (t != tau || D < 2 || D > 7 || t < 1 || t > 0x7FFF) ok = false;
+                    else mask |= 1u << D;
+                    ++n_pe;
+                }
+            h.d = (ok && n_pe >= 2 && mask == 0xF8u && !getenv("TSFA_NO_PE_FUSED")) ? (int)((unsigned)tau << 8 | mask) : 0;   // (fam_perm.h TSFA_PE_MASK)
+        }
         h.c = (int)loop.size();
         // a = doubles of LDS scratch the plan needs (fam_sort.h friedrich_coeffs: 6 r + 16 + r (m + 1)), at least 320:
         // the ordinal-pattern histogram adapts to it

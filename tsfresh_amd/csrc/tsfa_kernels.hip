@@ -7,6 +7,7 @@
 #include "fam_cwt.h"
 #include "fam_entropy.h"
 #include "fam_seq.h"
+#include "fam_perm.h"
 #include "fam_sort.h"
 #include "fam_spectral.h"
 #include "tsfa_launch.h"
@@ -169,7 +170,7 @@ __global__ void __launch_bounds__(1024) k_sort(const T *__restrict__ values, con
                        const TsfaSpec *__restrict__ specs, int nspecs, double *__restrict__ out, int64_t ld, int maxn,
                        const TsfaCqPlan cqplan, int n_loop, int w_doubles, double *__restrict__ pf_buf,
                        int *__restrict__ pf_count, int pf_slot, int pf_cap, const unsigned short *__restrict__ perm_buf, int perm_stride,
-                       const double *__restrict__ stats_in TSFA_GS_PARAMS) {
+                       const double *__restrict__ stats_in, int pe_hint TSFA_GS_PARAMS) {
     TSFA_SERIES_BEGIN
     const int64_t off = starts[sidx];
     const int n = (int)(ends[sidx] - off);
@@ -186,10 +187,34 @@ __global__ void __launch_bounds__(1024) k_sort(const T *__restrict__ values, con
     fam_sort_series<T>(b, xs, n, specs, nspecs, out + sidx * ld, (T *)L.srt, L.w, L.iw, cqplan, L.cq, L.stage,
                        n_loop, L.ctx, w_doubles, FrDefer{pf_buf, pf_count, pf_slot, (long long)sidx, 0, pf_cap},
                        perm_buf ? perm_buf + (size_t)sidx * (size_t)perm_stride : nullptr,
-                       stats_in ? stats_in + sidx * TSFA_STATS_N : nullptr);
+                       stats_in ? stats_in + sidx * TSFA_STATS_N : nullptr, pe_hint);
     TSFA_TICKS_END();
     TSFA_SERIES_END
 }
+
+#if !defined(TSFA_LONG)
+// every permutation_entropy column of the plan (fam_perm.h): the SORT family's spec list, its other columns left to k_sort
+template <typename T>
+__global__ void __launch_bounds__(1024) k_perm(const T *__restrict__ values, const int64_t *__restrict__ starts, const int64_t *__restrict__ ends, int64_t n_series, const int *__restrict__ sel,
+                       const TsfaSpec *__restrict__ specs, int nspecs, double *__restrict__ out, int64_t ld, int maxn, int tau) {
+    TSFA_SERIES_BEGIN
+    const int64_t off = starts[sidx];
+    const int n = (int)(ends[sidx] - off);
+    PermLds L;
+    L.carve(tsfa_base, maxn, blockDim.x, (int)sizeof(T), TSFA_PE_HIST_WORDS, TSFA_PE_LOGS + TSFA_PE_MAXD + 1);
+    TSFA_TICKS_BEGIN();
+    Blk b{(int)threadIdx.x, (int)blockDim.x, L.red, nullptr};
+    T *xs = (T *)L.xs;
+    {
+        const T *__restrict__ g = values + off;
+        for (int i = b.tid; i < n; i += b.nt) xs[i] = g[i];
+        blk_sync();
+    }
+    fam_perm_series<T>(b, xs, n, specs, nspecs, out + sidx * ld, tau, L.iw, L.ltab);
+    TSFA_TICKS_END();
+    TSFA_SERIES_END
+}
+#endif
 
 template <typename T>
 __global__ void __launch_bounds__(1024) k_spectral(const T *__restrict__ values, const int64_t *__restrict__ starts, const int64_t *__restrict__ ends, int64_t n_series, const int *__restrict__ sel,
@@ -933,7 +958,7 @@ static int launch_all_t(const TsfaLaunch &a, const T *values) {
         const int wd = (a.hint_a >= 320) ? a.hint_a : 1280;
         const size_t lds = L.carve(nullptr, a.maxn, nt, (int)sizeof(T), wd);
         TSFA_KLAUNCH(k_sort<T>, lds, values, a.starts, a.ends, a.n_series, a.sel, a.specs, a.nspecs, a.out, a.ld, a.maxn, a.cq,
-                     a.hint_c, wd, a.pf_buf, a.pf_count, a.pf_slot, a.pf_cap, a.perm_buf, a.perm_stride, a.stats_in);
+                     a.hint_c, wd, a.pf_buf, a.pf_count, a.pf_slot, a.pf_cap, a.perm_buf, a.perm_stride, a.stats_in, a.hint_d);
     } else if (a.fam == TSFA_FAM_SPECTRAL) {
         SpectralLds L;
         const size_t lds = L.carve(nullptr, a.maxn, a.dft_n, (int)sizeof(T));
@@ -1093,6 +1118,28 @@ int tsfa_stream_calc_ok(int calc) {
         return 1;
     default: return 0;
     }
+}
+
+size_t tsfa_perm_lds_bytes(int maxn, int nt, int elem_bytes) {
+    PermLds L;
+    return L.carve(nullptr, maxn, nt, elem_bytes, TSFA_PE_HIST_WORDS, TSFA_PE_LOGS + TSFA_PE_MAXD + 1);
+}
+template <typename T>
+static int launch_perm_t(const TsfaLaunch &a, const T *values) {
+    hipStream_t st = (hipStream_t)a.stream;
+    const dim3 grid((unsigned)a.n_series);
+    const int nt = a.nt;
+    const size_t lds = tsfa_perm_lds_bytes(a.maxn, nt, (int)sizeof(T));
+    int rc = 0;
+    if ((rc = set_lds(k_perm<T>, lds))) return rc;
+    k_perm<T><<<grid, nt, lds, st>>>(values, a.starts, a.ends, a.n_series, a.sel, a.specs, a.nspecs, a.out, a.ld, a.maxn, a.hint_d >> 8);
+    TSFA_LAUNCH_CHECK();
+    return 0;
+}
+int tsfa_launch_perm(const TsfaLaunch &a) {
+    if (((unsigned)a.hint_d & 0xFFu) != TSFA_PE_MASK || (a.hint_d >> 8) < 1) return -1;
+    if (a.dtype == 0) return launch_perm_t<float>(a, (const float *)a.values);
+    return launch_perm_t<double>(a, (const double *)a.values);
 }
 
 int tsfa_launch_order_stats(const TsfaLaunch &a) {

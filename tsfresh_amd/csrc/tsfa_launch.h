@@ -92,6 +92,8 @@ int tsfa_launch_family(const TsfaLaunch &a);
 int tsfa_launch_family_long(const TsfaLaunch &a);   // working set in a.long_scratch instead of LDS (any length <= 65535)
 int tsfa_launch_ar_degenerate(const TsfaLaunch &a);
 int tsfa_launch_langevin_dd(const TsfaLaunch &a);     // second pass of TSFA_FAM_SORT: the ill-conditioned Langevin fits k_sort recorded
+int tsfa_launch_perm(const TsfaLaunch &a);            // beside TSFA_FAM_SORT: every permutation_entropy column (k_perm, fam_perm.h); a.hint_d = (stride << 8) | dimensions, a.nt threads
+size_t tsfa_perm_lds_bytes(int maxn, int nt, int elem_bytes);
 int tsfa_launch_stream(const TsfaLaunch &a);         // BASIC closed forms + median in one read of the samples (k_stream), maxn <= 2048
 int tsfa_stream_calc_ok(int calc);                   // is the calculator one of those k_stream serves?
 int tsfa_launch_order_stats(const TsfaLaunch &a);    // SORT family holding only median / quantile columns, maxn <= 2048  // second pass of TSFA_FAM_AR over the series the first listed

@@ -203,6 +203,21 @@ struct SeqLds {
 };
 
 
+// k_perm (fam_perm.h): the series in the input precision, one histogram of every ordinal pattern of the set of dimensions,
+// the table of logarithms.  nwaves x 5 doubles of reduction scratch (blk_sum_multi).
+struct PermLds {
+    double *red; double *ltab; int *iw; void *xs;
+    TSFA_HD size_t carve(unsigned char *base, int maxn, int nt, int elem_bytes, int hist_words, int log_doubles) {
+        LdsCarve c{base, 0};
+        const int nwaves = (nt + 63) >> 6;
+        red = c.take<double>(nwaves * 8 < 16 ? 16 : nwaves * 8);
+        ltab = c.take<double>((size_t)log_doubles);
+        iw = c.take<int>((size_t)hist_words + 4);
+        xs = (void *)c.take<unsigned char>((size_t)(maxn + 8) * elem_bytes);
+        return c.off;
+    }
+};
+
 struct CwtPeaksLayout {
     CwtPeaksLds p;
     // mode 1: the series is staged between zero halos (register-tiled convolutions, no second row needed);
