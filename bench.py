@@ -17,7 +17,7 @@ ComprehensiveFCParameters (783 columns) -- the configuration the metric/target i
 The JSON line also carries
   roofline     : dominant kernel's algorithmic HBM bytes per launch / its HIP-event duration vs 8 TB/s
   cpu_baseline : the numpy oracle (a port of the reference's calculators) timed on a bounded sample of the same
-                 workload on the host cores (warm pool, >= 32 series per worker, median of 3) -- a reported baseline,
+                 workload on the host cores (warm pool, >= 32 series per worker; one run, --cpu-baseline-full: median of 3) -- a reported baseline,
                  not the target; `reference_estimate` scales it by the port/reference ratio measured in the build
                  container (profiles/r02_reference_cpu.json)
   parity_sample: 8 rows of the timed output against the oracle (tests/parity.py), outside the timed region
@@ -242,6 +242,9 @@ def main():
     ap.add_argument("--offset", type=float, default=0.0, help="add OFFSET to every sample (|mean| >> spread: the "
                     "double-double second passes of the Langevin fit and of AR / ADF take every series)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-baseline-full", action="store_true",
+                    help="three runs of the CPU protocol (median) and the reference's default n_jobs = cpu_count() // 2 as a "
+                         "second leg (~4 min of wall clock) instead of one run (~1 min): profiles/r04_z_bench.json was taken so")
     ap.add_argument("--no-e2e", action="store_true", help="skip the host-buffer / DataFrame boundary timings")
     ap.add_argument("--chunks", type=int, default=0,
                     help="N > 1: row chunks per step; the all-gather of chunk c runs on RCCL's stream while chunk c + 1 is "
@@ -481,12 +484,12 @@ def main():
                 # the headline shape itself: configs[2] as a long frame is 102 M rows
                 line["e2e_headline"] = e2e_block(plan, fplan, cls, n, L, calls=3)
         if pool is not None:
-            line["cpu_baseline"] = cpu_baseline(pool, workers, L, params_name, seed=42)
+            line["cpu_baseline"] = cpu_baseline(pool, workers, L, params_name, seed=42, repeats=3 if args.cpu_baseline_full else 1)
             pool.close()
             pool.join()
             # the reference's DEFAULT: n_jobs = cpu_count() // 2 worker processes (tsfresh/defaults.py:7), one run
             half = max(1, (os.cpu_count() or 2) // 2)
-            if half != workers:
+            if half != workers and args.cpu_baseline_full:
                 pool2 = mp.get_context("spawn").Pool(half)
                 pool2.map(_cpu_warm, range(4 * half))
                 d2 = cpu_baseline(pool2, half, L, params_name, seed=43, per_worker=8, repeats=1)

@@ -1,7 +1,7 @@
-"""permutation_entropy (fc.py:1866-1916): all dimensions of one stride from ONE sweep of the windows (fam_sort.h:
-perm_entropy_fused -- prefix inversion-table codes, the histograms of the lower dimensions side by side in one pass)
-against the one-dimension-at-a-time path and the oracle.  The emulation takes the fused path on the even series of a
-batch and the other on the odd ones, so every input appears twice in a row."""
+"""permutation_entropy (fc.py:1866-1916): all dimensions of one stride from ONE sweep of the windows (fam_perm.h, k_perm:
+prefix inversion-table codes, every histogram side by side in one LDS table) against the one-dimension-at-a-time path
+in k_sort (fam_sort.h) and the oracle.  The emulation takes k_perm's code on the even series of a batch and k_sort's on
+the odd ones, so every input appears twice in a row."""
 import numpy as np
 import pytest
 
@@ -52,7 +52,9 @@ def test_fused_dimensions_equal_the_oracle_emulated(name):
 @pytest.mark.parametrize("dtype", [np.float32, np.float64])
 def test_fused_dimensions_equal_the_oracle_on_the_device(gpu, dtype):
     from engines import hip_engine
-    series = [s.astype(dtype).astype(np.float64) for s in pe_series()]
+    rng = np.random.default_rng(92)
+    # (beyond 8 x 1024 windows the codes are recomputed per pass instead of held in registers)
+    series = [s.astype(dtype).astype(np.float64) for s in pe_series() + [rng.standard_normal(3000), rng.standard_normal(9000)]]
     values = np.concatenate(series).astype(dtype)
     offsets = np.concatenate([[0], np.cumsum([len(s) for s in series])]).astype(np.int64)
     for name in sorted(SETS):
@@ -62,3 +64,16 @@ def test_fused_dimensions_equal_the_oracle_on_the_device(gpu, dtype):
         assert list(names) == list(onames)
         bad = compare(names, got, want, series)
         assert not bad, (name, bad[:6])
+
+
+@pytest.mark.gpu
+def test_the_kernel_of_its_own_and_the_columns_in_k_sort_agree(gpu, monkeypatch):
+    """TSFA_NO_PE_FUSED (read when the plan is built) leaves the columns to k_sort, one dimension at a time."""
+    from engines import hip_engine
+    series = [s.astype(np.float32) for s in pe_series()]
+    values = np.concatenate(series)
+    offsets = np.concatenate([[0], np.cumsum([len(s) for s in series])]).astype(np.int64)
+    _, own = hip_engine(ALL5, values, offsets)
+    monkeypatch.setenv("TSFA_NO_PE_FUSED", "1")
+    _, in_sort = hip_engine(ALL5, values, offsets)
+    np.testing.assert_allclose(own, in_sort, rtol=1e-13, atol=1e-14, equal_nan=True)
