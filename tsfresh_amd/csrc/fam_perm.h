@@ -12,9 +12,10 @@
 //      Dm-code divided by Dm! / D!: 21 comparisons per window serve every dimension (55 one by one); the codes of up to
 //      eight windows per thread stay in registers;
 //   2. one pass of LDS atomics over the windows, all histograms side by side;
-//   3. per dimension sum_k p_k log p_k over the patterns (or, where there are more patterns than windows, over the
-//      windows: sum_k c_k log(c_k / num) = sum over the windows of log(c(window) / num)), logarithms of the small counts
-//      from ONE table (log c, and log num per dimension: log(c / num) = log c - log num, 1 ulp from the quotient's);
+//   3. per dimension the number G[c] of windows whose pattern occurs c times -- from the patterns, or from the windows where
+//      those are fewer -- again LDS atomics; -sum_k p_k log p_k = -(1 / num) sum_c G[c] (log c - log num) with the logarithms
+//      from ONE table (log c, log num per dimension), lane c of the first wavefront holding term c: integers up to the
+//      last 64 multiplications, so the value depends neither on the thread count nor on the order of anything;
 //   4. one block reduction for all dimensions.
 // The codes differ from fam_sort.h's perm_code (another bijection of the same stable pattern): only the histogram
 // matters.  Windows near the end of the series hold fewer than Dm elements: their missing digits are 0 and they only
@@ -43,7 +44,8 @@ struct PeSet {
     // code(D) = code(Dm) / div = (code(Dm) * magic) >> 24 with magic = ceil(2^24 / div): exact for code < 2^13
     static constexpr int magic(int D) { const int div = fact(dm()) / fact(D); return (1 << 24) / div + (((1 << 24) % div) ? 1 : 0); }
 };
-#define TSFA_PE_HIST_WORDS ((PeSet<TSFA_PE_MASK>::bins() + 1) / 2)   // 32-bit words of the histogram (2955)
+// 32-bit words of LDS: the histogram (2955, rounded to 2956) + per dimension TSFA_PE_LOGS + 1 counters of windows by their pattern's count
+#define TSFA_PE_HIST_WORDS ((((PeSet<TSFA_PE_MASK>::bins() + 1) / 2 + 3) & ~3) + PeSet<TSFA_PE_MASK>::count() * (TSFA_PE_LOGS + 1))
 
 template <class AT>
 TSFA_DEV int perm_prefix_code(const AT *a, int L, int Dm, int last) {
@@ -69,12 +71,13 @@ TSFA_DEV int pe_div(int code, int magic) {
 }
 
 // res[D] for every D of the set: the entropy, NaN where the series is shorter than D.
-// iw: TSFA_PE_HIST_WORDS words of LDS; ltab: TSFA_PE_LOGS + TSFA_PE_MAXD + 1 doubles of LDS.
+// iw: TSFA_PE_HIST_WORDS words of LDS (histogram + counters); ltab: TSFA_PE_LOGS + TSFA_PE_MAXD + 1 doubles of LDS.
 template <unsigned dmask, class ST>
 TSFA_DEV void perm_entropy_all(const Blk &b, const ST *xs_raw, int n, int tau, int *iw, double *ltab,
                                double (&res)[TSFA_PE_MAXD + 1]) {
     typedef PeSet<dmask> S;
-    constexpr int Dm = S::dm(), Dmin = S::dmin(), LT = TSFA_PE_LOGS;
+    constexpr int Dm = S::dm(), Dmin = S::dmin(), LT = TSFA_PE_LOGS, GW = LT + 1, GOFF = ((S::bins() + 1) / 2 + 3) & ~3;
+    int *const G = iw + GOFF;
     static_assert(Dm >= 3 && Dmin < Dm && S::fact(Dm) <= 8192, "at least two dimensions, the largest at most 7");
     int num[TSFA_PE_MAXD + 1];                                         // (indexed by unrolled constants only)
 #pragma unroll
@@ -106,7 +109,7 @@ TSFA_DEV void perm_entropy_all(const Blk &b, const ST *xs_raw, int n, int tau, i
             if (c == LT + D) arg = num[D];
         ltab[c] = (arg > 0) ? log((double)arg) : 0.0;
     }
-    for (int k = b.tid; k < (S::bins() + 1) / 2; k += b.nt) iw[k] = 0;
+    for (int k = b.tid; k < GOFF + S::count() * GW; k += b.nt) iw[k] = 0;
     blk_sync();
     TSFA_TICK(tk, b, 231);
     auto bump = [=](int bin) {
@@ -137,46 +140,76 @@ TSFA_DEV void perm_entropy_all(const Blk &b, const ST *xs_raw, int n, int tau, i
     });
     blk_sync();
     TSFA_TICK(tk, b, 232);
+    // G[D][c] = number of WINDOWS whose pattern occurs c times (c < LT; G[D][LT] != 0: some pattern occurs LT times or more),
+    // from the patterns (+ c each) where they are fewer than the windows, else from the windows (+ 1 each): integers,
+    // whichever way they are counted and however many threads count them
+    auto add = [=](int *p, int v) {
+#if TSFA_GPU
+        atomicAdd(p, v);
+#else
+        *p += v;
+#endif
+    };
+#pragma unroll
+    for (int D = 2; D <= Dm; ++D) {
+        if (!S::has(D) || num[D] <= 0) continue;
+        int *g = G + S::index(D) * GW;
+        if (S::fact(D) <= num[D]) {
+            for (int k = b.tid; k < S::fact(D); k += b.nt) {
+                const int c = count_of(S::off(D) + k);
+                if (c > 0) add(&g[c < LT ? c : LT], c);
+            }
+        } else {
+            windows([&](int code, int t) {
+                const bool live = t < num[D];
+                const int c = live ? count_of(bin_of(code, D)) : 0;
+#if TSFA_GPU
+                // (most patterns of a large dimension occur once: one atomic per wavefront for those instead of one per lane
+                // on the same LDS word -- k_perm 0.88 -> 0.75 ms per 100k x 1024, profiles/r04_v_*)
+                const unsigned long long once = __ballot(live && c == 1);
+                if (live && c == 1) {
+                    if ((int)__ffsll((long long)once) - 1 == (b.tid & 63)) atomicAdd(&g[1], (int)__popcll(once));
+                } else if (live) {
+                    atomicAdd(&g[c < LT ? c : LT], 1);
+                }
+#else
+                if (live) add(&g[c < LT ? c : LT], 1);
+#endif
+            });
+        }
+    }
+    blk_sync();
+    TSFA_TICK(tk, b, 233);
+    // -sum_k p_k log p_k = -(1 / num) sum_c G[c] (log c - log num): lane c of the FIRST wavefront holds the c-th term (and
+    // its share of the rare patterns beyond the table), the other wavefronts hold exact zeros, so the value does not depend
+    // on the number of threads the launch gave the series (it did while every thread summed its own windows: the same
+    // series in another launch group -- another shard of a multi-device call -- came out one ulp off)
+    const int st = (b.nt < 64) ? b.nt : 64;
     double e[S::count()];
 #pragma unroll
     for (int D = 2; D <= Dm; ++D) {
         if (!S::has(D)) continue;
         double acc = 0.0;
-        const double dnum = (double)num[D], lnum = ltab[LT + D];
-        if (num[D] <= 0) {
-        } else if (S::fact(D) <= num[D]) {
-            // no more patterns than windows: sum over the patterns
-            for (int k = b.tid; k < S::fact(D); k += b.nt) {
-                const int c = count_of(S::off(D) + k);
-                if (c > 0) {
-                    const double pr = (double)c / dnum;
-                    acc += pr * ((c < LT) ? (ltab[c] - lnum) : log(pr));
-                }
+        if (num[D] > 0 && b.tid < st) {
+            const int *g = G + S::index(D) * GW;
+            const double lnum = ltab[LT + D];
+            for (int c = b.tid; c < LT; c += st) {
+                const int gc = g[c];
+                if (gc != 0) acc += (double)gc * (ltab[c] - lnum);
             }
-        } else {
-            // ... or over the windows (counts beyond the table -- a constant stretch -- in a second, rolled sweep: one
-            // inlined logarithm per dimension instead of nine)
-            bool big = false;
-            windows([&](int code, int t) {
-                if (t < num[D]) {
-                    const int cc = count_of(bin_of(code, D));
-                    if (cc < LT) acc += ltab[cc] - lnum; else big = true;
+            if (g[LT] != 0)
+                for (int k = b.tid; k < S::fact(D); k += st) {
+                    const int c = count_of(S::off(D) + k);
+                    if (c >= LT) acc += (double)c * (log((double)c) - lnum);
                 }
-            });
-            if (big)
-                for (int t = b.tid; t < num[D]; t += b.nt) {
-                    const int cc = count_of(bin_of(code_at(t), D));
-                    if (cc >= LT) acc += log((double)cc / dnum);
-                }
-            acc /= dnum;
         }
         e[S::index(D)] = acc;
     }
-    TSFA_TICK(tk, b, 233);
+    TSFA_TICK(tk, b, 234);
     blk_sum_multi<S::count()>(b, e);
 #pragma unroll
     for (int D = 2; D <= Dm; ++D)
-        if (S::has(D) && num[D] > 0) res[D] = -e[S::index(D)];
+        if (S::has(D) && num[D] > 0) res[D] = -e[S::index(D)] / (double)num[D];
     TSFA_TICK(tk, b, 235);
 }
 
