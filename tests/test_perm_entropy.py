@@ -2,35 +2,30 @@
 prefix inversion-table codes, every histogram side by side in one LDS table) against the one-dimension-at-a-time path
 in k_sort (fam_sort.h) and the oracle.  The emulation takes k_perm's code on the even series of a batch and k_sort's on
 the odd ones, so every input appears twice in a row."""
+import json
+import os
+import re
+import sys
+
 import numpy as np
 import pytest
 
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden"))
 from engines import emul_engine, oracle_engine
 from parity import compare
+from perm_cases import ALL5, SETS, pe_series
 
-ALL5 = {"permutation_entropy": [{"tau": 1, "dimension": d} for d in (3, 4, 5, 6, 7)]}        # ComprehensiveFCParameters
-SETS = {
-    "comprehensive": ALL5,                                                                                   # fused
-    "comprehensive_stride3": {"permutation_entropy": [{"tau": 3, "dimension": d} for d in (7, 3, 5, 4, 6)]},  # fused, any order
-    "subset": {"permutation_entropy": [{"tau": 2, "dimension": d} for d in (7, 3, 5)]},                       # other sets: not fused
-    "low": {"permutation_entropy": [{"tau": 3, "dimension": d} for d in (2, 3, 4)]},
-    "two_dims": {"permutation_entropy": [{"tau": 1, "dimension": 6}, {"tau": 1, "dimension": 2}]},
-    "mixed_strides": {"permutation_entropy": [{"tau": 1, "dimension": 3}, {"tau": 2, "dimension": 4}, {"tau": 1, "dimension": 5}]},  # not fused
-    "single": {"permutation_entropy": [{"tau": 1, "dimension": 7}]},                                                                  # not fused
-}
+REF = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "ref_perm.json")))
 
 
-def pe_series():
-    rng = np.random.default_rng(91)
-    out = [rng.standard_normal(n) for n in (1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 12, 20, 50, 129, 300, 1000, 1024, 1500, 2049)]
-    out.append(np.round(rng.standard_normal(400), 1))                    # ties inside the windows: stable ranks
-    out.append(rng.integers(0, 3, size=700).astype(np.float64))          # three distinct values
-    out.append(np.full(90, 2.5))                                         # one pattern
-    out.append(np.arange(300, dtype=np.float64))                         # one pattern
-    out.append(np.tile([1.0, 3.0, 2.0], 200))                            # three patterns
-    out.append(np.cumsum(rng.standard_normal(1024)))
-    out.append(rng.standard_normal(1024).astype(np.float32).astype(np.float64))
-    return out
+def reference_matrix(name, names):
+    """The real reference's values (tests/golden/gen_golden_perm.py) in the engine's column order."""
+    cols = {(c["dimension"], c["tau"]): c["values"] for c in REF["sets"][name]}
+    out = []
+    for nm in names:
+        m = re.search(r"permutation_entropy__dimension_(\d+)__tau_(\d+)$", nm)
+        out.append([np.nan if v is None else v for v in cols[(int(m.group(1)), int(m.group(2)))]])
+    return np.array(out, dtype=np.float64).T
 
 
 @pytest.mark.parametrize("name", sorted(SETS))
@@ -43,6 +38,9 @@ def test_fused_dimensions_equal_the_oracle_emulated(name):
     onames, want = oracle_engine(params, values, offsets)
     assert list(names) == list(onames)
     bad = compare(names, got, want, twice)          # (stable ranks: the oracle's, parity.py R1 only applies to SIMD fixtures)
+    assert not bad, bad[:6]
+    ref = reference_matrix(name, names)             # the real reference under numpy's scalar (stable) sort
+    bad = compare(names, want[0::2], ref, pe_series()) + compare(names, got[0::2], ref, pe_series()) + compare(names, got[1::2], ref, pe_series())
     assert not bad, bad[:6]
     # fused sweep vs one dimension at a time: the same counts, logarithms taken as log c - log num instead of log(c / num)
     np.testing.assert_allclose(got[0::2], got[1::2], rtol=1e-13, atol=1e-14, equal_nan=True)
@@ -64,6 +62,10 @@ def test_fused_dimensions_equal_the_oracle_on_the_device(gpu, dtype):
         assert list(names) == list(onames)
         bad = compare(names, got, want, series)
         assert not bad, (name, bad[:6])
+        if dtype == np.float64:   # (the fixture's series are float64; the last two of this batch are not in it)
+            k = REF["n_series"]
+            bad = compare(names, got[:k], reference_matrix(name, names), series[:k])
+            assert not bad, (name, bad[:6])
 
 
 @pytest.mark.gpu
