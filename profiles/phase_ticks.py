@@ -17,8 +17,8 @@ os.environ.setdefault("TSFA_LIB", os.path.join(ROOT, "tsfresh_amd", "libtsfresh_
 
 NAMED = {213: "basic: count pass (all count-type columns)", 214: "basic: sum pass (all sum-type columns)", 220: "sort/change_quantiles: corridor edges (quantiles)", 221: "sort/change_quantiles: pass 1",
          222: "sort/change_quantiles: reduce 12", 223: "sort/change_quantiles: pass 2", 224: "sort/change_quantiles: reduce 8",
-         230: "sort/permutation_entropy: window codes", 231: "sort/permutation_entropy: logarithm table + clear", 232: "sort/permutation_entropy: lower dimensions, histogram pass",
-         233: "sort/permutation_entropy: lower dimensions, sums", 234: "sort/permutation_entropy: largest dimension (range passes)", 235: "sort/permutation_entropy: block sums",
+         230: "perm: window codes", 231: "perm: logarithm table + clear", 232: "perm: histogram pass (all dimensions)",
+         233: "perm: windows by pattern count (G)", 234: "perm: terms (first wavefront)", 235: "perm: block sum",
          236: "sort/permutation_entropy one by one: window codes", 237: "sort/permutation_entropy one by one: logarithm table", 238: "sort/permutation_entropy one by one: histogram passes + sums", 239: "sort/permutation_entropy one by one: block sum",
          225: "basic/number_peaks: near pass (L/R up to 10)", 226: "basic/number_peaks: far candidates", 210: "basic: spec fetch (all columns)", 211: "basic: column bodies (all columns)",
          212: "basic: output stores (all columns)", 200: "basic/agg_linear_trend: chunk aggregates", 201: "basic/agg_linear_trend: regression sums",
