@@ -2,7 +2,7 @@
 run through the REAL reference code (feature_calculators.py read from /root/reference) with the REAL libraries of
 the second interpreter of the build container:
 
-    /opt/conda/bin/python3.9 tests/golden/gen_golden_conda.py
+    /opt/conda/bin/python3.9 tests/golden/gen_golden_conda.py [--set S] [--params sweep]
         numpy 1.26.4, scipy 1.7.1, pandas 2.3.3, pywt 1.1.1, statsmodels 0.12.2
 
 statsmodels 0.12.2 does not import against that numpy/pandas as shipped (np.MachAr and pd.Int64Index are gone);
@@ -55,6 +55,10 @@ def main():
     case_set = sys.argv[sys.argv.index("--set") + 1] if "--set" in sys.argv else "main"
     cases = CASE_SETS[case_set]()
     full = ref_settings.ComprehensiveFCParameters()
+    sweep = "--params" in sys.argv and sys.argv[sys.argv.index("--params") + 1] == "sweep"
+    if sweep:   # parameters away from the Comprehensive grids (param_cases.py) -> ref_conda_sweep.npz
+        from param_cases import sweep_parameters
+        full = sweep_parameters()
     params = {k: full[k] for k in CALCS}
     names, rows = None, []
     for label, x in cases:
@@ -65,7 +69,7 @@ def main():
         assert cols == names
         rows.append([float(r[2]) for r in res])
     values, offsets = pack(cases)
-    out = os.path.join(HERE, "ref_conda.npz" if case_set == "main" else "ref_conda_%s.npz" % case_set)
+    out = os.path.join(HERE, ("ref_conda.npz" if case_set == "main" else "ref_conda_%s.npz" % case_set).replace(".npz", "_sweep.npz" if sweep else ".npz"))
     np.savez_compressed(out, values=values, offsets=offsets, labels=np.array([c[0] for c in cases]),
                         names=np.array(names), matrix=np.asarray(rows, dtype=np.float64),
                         versions=np.array(["numpy " + np.__version__, "pandas " + pd.__version__,

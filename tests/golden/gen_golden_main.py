@@ -10,6 +10,7 @@ removed from the FCParameters and covered by gen_golden_conda.py instead.  Every
     python tests/golden/gen_golden_main.py        # needs /root/reference; writes tests/golden/ref_main.npz
     python tests/golden/gen_golden_main.py --set degenerate             # ref_main_degenerate.npz
     python tests/golden/gen_golden_main.py [--set S] --nosimd           # ref_main[_S]_nosimd.npz
+    python tests/golden/gen_golden_main.py --params sweep               # ref_main_sweep.npz (param_cases.py)
 
 --nosimd re-executes the interpreter with NPY_DISABLE_CPU_FEATURES set, so numpy's runtime dispatch falls back to its
 scalar loops.  It exists for ONE calculator: permutation_entropy ranks every window with np.argsort's default kind
@@ -65,6 +66,10 @@ def main():
     case_set = sys.argv[sys.argv.index("--set") + 1] if "--set" in sys.argv else "main"
     cases = CASE_SETS[case_set]()
     params = ref_settings.ComprehensiveFCParameters()
+    sweep = "--params" in sys.argv and sys.argv[sys.argv.index("--params") + 1] == "sweep"
+    if sweep:   # parameters away from the Comprehensive grids (param_cases.py) -> ref_main_sweep.npz
+        from param_cases import sweep_parameters
+        params = sweep_parameters()
     full_names = {}
     for cls in ("ComprehensiveFCParameters", "EfficientFCParameters", "MinimalFCParameters"):
         p = getattr(ref_settings, cls)()
@@ -74,6 +79,8 @@ def main():
         full_names[cls + "_keys"] = list(p.keys())
     for k in NEED_THIRD_PARTY:
         del params[k]
+    if sweep:
+        full_names = {}
     names, rows = None, []
     with warnings.catch_warnings():
         warnings.simplefilter("ignore")
@@ -85,7 +92,7 @@ def main():
             assert cols == names
             rows.append([float(r[2]) for r in res])
     values, offsets = pack(cases)
-    suffix = ("" if case_set == "main" else "_" + case_set) + ("_nosimd" if NOSIMD else "")
+    suffix = ("" if case_set == "main" else "_" + case_set) + ("_sweep" if sweep else "") + ("_nosimd" if NOSIMD else "")
     out = os.path.join(HERE, "ref_main%s.npz" % suffix)
     np.savez_compressed(
         out, values=values, offsets=offsets, labels=np.array([c[0] for c in cases]), names=np.array(names),

@@ -29,8 +29,15 @@ PAIRS = {
 }
 
 
+# fixtures of OTHER parameter sets than ComprehensiveFCParameters (not part of the PAIRS the golden tests iterate over)
+EXTRA = {
+    # tests/golden/param_cases.py: parameters away from the Comprehensive grids, the `main` series
+    "sweep": ("ref_main_sweep.npz", "ref_conda_sweep.npz", True),
+}
+
+
 def load(pair):
-    f1, f2, simd = PAIRS[pair]
+    f1, f2, simd = PAIRS[pair] if pair in PAIRS else EXTRA[pair]
     g1 = np.load(os.path.join(G, f1))
     g2 = np.load(os.path.join(G, f2))
     assert np.array_equal(g1["values"], g2["values"]) and np.array_equal(g1["offsets"], g2["offsets"])
