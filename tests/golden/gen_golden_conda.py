@@ -69,9 +69,26 @@ def main():
         assert cols == names
         rows.append([float(r[2]) for r in res])
     values, offsets = pack(cases)
+    extra = {}
+    if sweep:
+        # Singular values of every AR(k) design [1, x[t-1] .. x[t-k]] AS THIS INTERPRETER'S LAPACK RETURNS THEM: the
+        # reference's pinv cuts at 1e-15 s_max, and for an exactly rank-deficient design (a constant series) whether a
+        # direction that does not exist comes back above that cut is round-off of the LAPACK build -- tests/parity.py R4
+        # asks that question of the test interpreter's LAPACK, these rows let it ask the reference's own
+        for k in sorted({p["k"] for p in params["ar_coefficient"]}):
+            sv = np.full((len(cases), k + 1), np.nan)
+            for i, (_, x) in enumerate(cases):
+                x = np.asarray(x, dtype=np.float64)
+                n = len(x)
+                if n < 2 * k + 2 or not np.all(np.isfinite(x)):
+                    continue
+                tt = np.arange(k, n)
+                X = np.column_stack([np.ones(n - k)] + [x[tt - j] for j in range(1, k + 1)])
+                sv[i] = np.linalg.svd(X, compute_uv=False)
+            extra["ar_sv_k%d" % k] = sv
     out = os.path.join(HERE, ("ref_conda.npz" if case_set == "main" else "ref_conda_%s.npz" % case_set).replace(".npz", "_sweep.npz" if sweep else ".npz"))
     np.savez_compressed(out, values=values, offsets=offsets, labels=np.array([c[0] for c in cases]),
-                        names=np.array(names), matrix=np.asarray(rows, dtype=np.float64),
+                        names=np.array(names), matrix=np.asarray(rows, dtype=np.float64), **extra,
                         versions=np.array(["numpy " + np.__version__, "pandas " + pd.__version__,
                                            "pywt " + pywt.__version__, "statsmodels " + statsmodels.__version__,
                                            "python " + sys.version.split()[0]]))

@@ -33,6 +33,12 @@ PAIRS = {
 EXTRA = {
     # tests/golden/param_cases.py: parameters away from the Comprehensive grids, the `main` series
     "sweep": ("ref_main_sweep.npz", "ref_conda_sweep.npz", True),
+    # the same parameters on the rank-deficient / far-from-zero series: the second passes (k_ar_degenerate, k_langevin_dd)
+    # with other AR orders and Langevin (m, r) than the Comprehensive ones
+    "degenerate_sweep": ("ref_main_degenerate_sweep.npz", "ref_conda_degenerate_sweep.npz", True),
+    "offset_sweep": ("ref_main_offset_sweep.npz", "ref_conda_offset_sweep.npz", True),
+    # ... and on the 1025 .. 8192-sample series: lags, peak supports and coefficient indices that only exist there
+    "long_sweep": ("ref_main_long_sweep.npz", "ref_conda_long_sweep.npz", True),
 }
 
 
@@ -45,8 +51,9 @@ def load(pair):
     matrix = np.concatenate([g1["matrix"], g2["matrix"]], axis=1)
     values, offsets = g1["values"], g1["offsets"]
     series = [values[offsets[i]:offsets[i + 1]] for i in range(len(offsets) - 1)]
+    ar_sv = {int(k[len("ar_sv_k"):]): g2[k] for k in g2.files if k.startswith("ar_sv_k")}
     return dict(names=names, matrix=matrix, values=values, offsets=offsets, series=series,
-                labels=[str(l) for l in g1["labels"]], simd=simd)
+                labels=[str(l) for l in g1["labels"]], simd=simd, ar_sv=ar_sv)
 
 
 def align(names_want, names_got, got):
@@ -63,4 +70,31 @@ def check_engine(engine, pair, fc_parameters):
     skipped = []
     bad = compare(g["names"], align(g["names"], got_names, got), g["matrix"], g["series"], simd_golden=g["simd"],
                   skipped=skipped)
+    bad = [b for b in bad if not _r4_under_the_reference_lapack(b, g, skipped)]
     return bad, skipped, g["matrix"].size
+
+
+def _r4_under_the_reference_lapack(line, g, skipped):
+    """tests/parity.py R4 for ar_coefficient -- "the rank the float64 singular values give at statsmodels' pinv cut (1e-15
+    s_max) differs from the rank of the same singular values computed accurately" -- asked of the singular values the
+    REFERENCE's interpreter computed (fixtures made with --params sweep store them, gen_golden_conda.py): for an exactly
+    rank-deficient design, whether LAPACK returns a non-existent direction above the cut differs between LAPACK builds
+    (a constant 1 000 000.25 x 1024, AR(5): the conda build inverts one and returns -0.116 / 1.44 for coefficients whose
+    minimum-norm value -- the oracle's, with this interpreter's LAPACK, and the kernels' -- is 0.2).  A property of the
+    series and of the reference's arithmetic, not of the value compared."""
+    import re
+
+    from parity import _ar_design, _singular_ratios_accurate
+    m = re.match(r"series (\d+) (\S*ar_coefficient__coeff_\d+__k_(\d+)):", line)
+    if not m or int(m.group(3)) not in g.get("ar_sv", {}):
+        return False
+    i, col, k = int(m.group(1)), m.group(2), int(m.group(3))
+    s_ref = g["ar_sv"][k][i]
+    X = _ar_design(np.asarray(g["series"][i], dtype=np.float64), k)
+    if X is None or not np.all(np.isfinite(s_ref)) or s_ref[0] <= 0:
+        return False
+    accurate = _singular_ratios_accurate(X)
+    if int(np.sum(s_ref / s_ref[0] > 1e-15)) == int(np.sum(accurate > 1e-15)):
+        return False
+    skipped.append((i, col))
+    return True

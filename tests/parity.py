@@ -332,6 +332,7 @@ def _langevin_fit_facts(x, m, r):
     return {"kappa": float(1.0 / ratio[kept[-1]]), "in_band": in_band, "resid": resid, "coef": coef, "centre": c0,
             "shifted": shifted, "halfwidth": float(np.max(np.abs(xm - c0))), "scaled_norm": float(np.linalg.norm(coef * scale)),
             "noise_dir": np.abs(Vt[kept[-1]]) / scale,      # |v_min| in coefficient units
+            "scale": np.asarray(scale, dtype=np.float64),
             "dmax": float(np.max(np.abs(np.diff(x))))}
 
 
@@ -570,6 +571,11 @@ def tolerance_for(col, x, want, facts):
                 # the error ALONG v_min is normwise: eps kappa (|c_scaled| + kappa |resid|) -- a coefficient that is exactly
                 # zero (the cubic of an exact ramp's constant drift) still receives it through its component of v_min
                 atol += noise * (fit["scaled_norm"] + fit["kappa"] * fit["resid"]) * fit["noise_dir"][j]
+                # ... and the plain normwise bound of a backward-stable solver, |dc_scaled| <= eps kappa |c_scaled|, for the
+                # components v_min does not reach (m = 2, r = 5 on 1e8 + N(0, 1): v_min has no linear component, the
+                # reference's linear coefficient is 1.79e-9, the 60-digit truncated solution -- and the double-double
+                # pass -- -2.74e-10, this bound 4e-8; tests/golden/param_cases.py, offset_sweep series 50-52)
+                atol += noise * fit["scaled_norm"] / fit["scale"][j]
             return max(RTOL, noise), atol
         atol = atol_for(col, x)
         if np.isfinite(want):

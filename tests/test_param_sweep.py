@@ -24,11 +24,17 @@ def test_fixture_has_every_column_of_the_sweep():
     assert len(g["names"]) == 229
 
 
+# skipped cells (tests/parity.py R1-R11) per set: the sweep is MADE of the calculators those exclusions are about, and the
+# degenerate set of the series they are about
+SETS = {"sweep": 0.015, "degenerate_sweep": 0.045, "offset_sweep": 0.005}
+
+
+@pytest.mark.parametrize("pair", sorted(SETS))
 @pytest.mark.parametrize("engine", [oracle_engine, emul_engine], ids=["oracle", "emul"])
-def test_engine_matches_the_reference_on_other_parameters(engine):
-    bad, skipped, cells = goldens.check_engine(engine, "sweep", sweep_parameters())
+def test_engine_matches_the_reference_on_other_parameters(engine, pair):
+    bad, skipped, cells = goldens.check_engine(engine, pair, sweep_parameters())
     assert not bad, "%d mismatches, first: %s" % (len(bad), bad[:10])
-    assert len(skipped) <= 0.015 * cells, (len(skipped), cells)   # (71 of 5496: the set is made of the calculators the exclusions of tests/parity.py are about)
+    assert len(skipped) <= SETS[pair] * cells, (len(skipped), cells)
 
 
 @pytest.mark.gpu
@@ -36,7 +42,20 @@ def test_hip_matches_the_reference_on_other_parameters(gpu):
     from engines import hip_engine
     bad, skipped, cells = goldens.check_engine(hip_engine, "sweep", sweep_parameters())
     assert not bad, "%d mismatches, first: %s" % (len(bad), bad[:10])
-    assert len(skipped) <= 0.015 * cells, (len(skipped), cells)   # (71 of 5496: the set is made of the calculators the exclusions of tests/parity.py are about)
+    assert len(skipped) <= SETS["sweep"] * cells, (len(skipped), cells)
+
+
+@pytest.mark.gpu
+@pytest.mark.skipif(not os.environ.get("TSFA_TEST_NEW_ON_HARDWARE"),
+                    reason="written after round 4's GPU minutes were spent: oracle and emulation are green on these two sets, "
+                           "the HIP path has not run them yet (set TSFA_TEST_NEW_ON_HARDWARE=1; drop this mark once it has)")
+@pytest.mark.parametrize("pair", ["degenerate_sweep", "offset_sweep"])
+def test_hip_second_passes_match_the_reference_on_other_parameters(gpu, pair):
+    """k_ar_degenerate with AR orders 3 / 5 / 12, k_langevin_dd with five (m, r) fits in one plan."""
+    from engines import hip_engine
+    bad, skipped, cells = goldens.check_engine(hip_engine, pair, sweep_parameters())
+    assert not bad, "%d mismatches, first: %s" % (len(bad), bad[:10])
+    assert len(skipped) <= SETS[pair] * cells, (len(skipped), cells)
 
 
 @pytest.mark.parametrize("params, needle", [
