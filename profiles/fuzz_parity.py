@@ -2,7 +2,9 @@
 """Ad-hoc parity fuzz on the GPU box: random subsets of ComprehensiveFCParameters (random parameter sub-lists, random
 order of appearance is the reference's dict order) on random ragged batches of mixed structured / random series, HIP
 path against the oracle.    python profiles/fuzz_parity.py [rounds] [seed]
-TSFA_FUZZ_ENGINE=emul runs the g++ build of the kernel sources instead (no GPU needed)."""
+TSFA_FUZZ_ENGINE=emul runs the g++ build of the kernel sources instead (no GPU needed).
+TSFA_FUZZ_PARAMS=random draws every parameter at random inside the range the kernels serve instead of
+from the Comprehensive grids: lags, chunk lengths, bin counts and coefficient indices beyond the series length included."""
 import os
 import sys
 import warnings
@@ -62,6 +64,64 @@ def make_base_series(rng, n):
     return rng.standard_normal(n) * 10.0 ** float(rng.integers(-3, 4))
 
 
+def random_params(rng):
+    """One random parameter list per parameterised calculator (a random 45 % of them per round)."""
+    ri = lambda lo, hi: int(rng.integers(lo, hi + 1))   # noqa: E731
+    rf = lambda lo, hi: float(np.round(rng.uniform(lo, hi), 3))   # noqa: E731
+    several = lambda f: [f() for _ in range(ri(1, 3))]   # noqa: E731
+    gen = {
+        "ratio_beyond_r_sigma": lambda: {"r": rf(0.1, 12)},
+        "large_standard_deviation": lambda: {"r": rf(0.0, 1.0)},
+        "symmetry_looking": lambda: {"r": rf(0.0, 1.0)},
+        "cid_ce": lambda: {"normalize": bool(rng.integers(0, 2))},
+        "fft_coefficient": lambda: {"coeff": ri(0, 600), "attr": str(rng.choice(["real", "imag", "abs", "angle"]))},
+        "fft_aggregated": lambda: {"aggtype": str(rng.choice(["centroid", "variance", "skew", "kurtosis"]))},
+        "number_peaks": lambda: {"n": ri(1, 70)},
+        "index_mass_quantile": lambda: {"q": rf(0.0, 1.0)},
+        "number_cwt_peaks": lambda: {"n": ri(1, 16)},
+        "linear_trend": lambda: {"attr": str(rng.choice(["pvalue", "rvalue", "intercept", "slope", "stderr"]))},
+        "spkt_welch_density": lambda: {"coeff": ri(0, 200)},
+        "change_quantiles": lambda: (lambda a, b: {"ql": min(a, b), "qh": max(a, b), "isabs": bool(rng.integers(0, 2)),
+                                                   "f_agg": str(rng.choice(["mean", "var"]))})(rf(0, 1), rf(0, 1)),
+        "time_reversal_asymmetry_statistic": lambda: {"lag": ri(0, 60)},
+        "c3": lambda: {"lag": ri(0, 60)},
+        "mean_n_absolute_max": lambda: {"number_of_maxima": ri(1, 400)},
+        "binned_entropy": lambda: {"max_bins": ri(1, 256)},
+        "approximate_entropy": lambda: {"m": ri(1, 3), "r": rf(0.0, 1.5)},
+        "fourier_entropy": lambda: {"bins": ri(1, 128)},
+        "lempel_ziv_complexity": lambda: {"bins": ri(1, 255)},
+        "permutation_entropy": lambda: {"tau": ri(1, 4), "dimension": ri(2, 7)},
+        "autocorrelation": lambda: {"lag": ri(0, 400)},
+        "quantile": lambda: {"q": rf(0.0, 1.0)},
+        "number_crossing_m": lambda: {"m": rf(-3, 3)},
+        "value_count": lambda: {"value": float(rng.integers(-3, 4)) * 0.25},
+        "range_count": lambda: {"min": rf(-2, 1), "max": rf(-1, 2)},
+        "friedrich_coefficients": lambda: (lambda m: {"coeff": ri(0, m), "m": m, "r": ri(2, 64)})(ri(1, 3)),
+        "max_langevin_fixed_point": lambda: {"m": ri(1, 3), "r": ri(2, 64)},
+        "agg_linear_trend": lambda: {"attr": str(rng.choice(["rvalue", "intercept", "slope", "stderr"])), "chunk_len": ri(1, 120),
+                                     "f_agg": str(rng.choice(["max", "min", "mean", "var"]))},
+        "energy_ratio_by_chunks": lambda: (lambda k: {"num_segments": k, "segment_focus": ri(0, k - 1)})(ri(1, 20)),
+        "count_above": lambda: {"t": rf(-2, 2)},
+        "count_below": lambda: {"t": rf(-2, 2)},
+        "agg_autocorrelation": lambda: {"f_agg": str(rng.choice(["mean", "median", "var"])), "maxlag": ri(1, 60)},
+        "partial_autocorrelation": lambda: {"lag": ri(0, 40)},
+        "ar_coefficient": lambda: (lambda k: {"coeff": ri(0, k + 1), "k": k})(ri(1, 31)),
+        "cwt_coefficients": lambda: (lambda ws: {"widths": ws, "coeff": ri(0, 40), "w": int(rng.choice(ws))})(
+            tuple(sorted(set(int(v) for v in rng.integers(1, 24, size=ri(1, 4)))))),
+    }
+    params = {}
+    for nm, g in gen.items():
+        if rng.random() < 0.45:
+            seen, lst = set(), []
+            for p in several(g):
+                key = repr(sorted(p.items()))
+                if key not in seen:
+                    seen.add(key)
+                    lst.append(p)
+            params[nm] = lst
+    return params or {"quantile": [{"q": 0.5}]}
+
+
 def main():
     rounds = int(sys.argv[1]) if len(sys.argv) > 1 else 12
     rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
@@ -71,7 +131,10 @@ def main():
     for r in range(rounds):
         pick = [nm for nm in names_all if rng.random() < 0.45]
         params = {}
-        for nm in pick:
+        if os.environ.get("TSFA_FUZZ_PARAMS") == "random":
+            params = random_params(rng)
+            pick = list(params)
+        for nm in ([] if os.environ.get("TSFA_FUZZ_PARAMS") == "random" else pick):
             pl = full[nm]
             if pl is None:
                 params[nm] = None
