@@ -400,16 +400,22 @@ class SeriesOracle:
         return [("lag_{}".format(p["lag"]), coeffs[p["lag"]]) for p in param]
 
     def augmented_dickey_fuller(self, param):  # fc.py:499
-        try:
-            adf = tp.adfuller_aic(self.x)
-        except (np.linalg.LinAlgError, ValueError):
-            adf = (np.nan, np.nan, np.nan)
+        fits = {}
+
+        def compute(autolag):   # fc.py:519-527: one fit per autolag value
+            key = repr(autolag)
+            if key not in fits:
+                try:
+                    fits[key] = tp.adfuller(self.x, autolag)
+                except (np.linalg.LinAlgError, ValueError):
+                    fits[key] = (np.nan, np.nan, np.nan)
+            return fits[key]
         pos = {"teststat": 0, "pvalue": 1, "usedlag": 2}
         out = []
         for p in param:
             autolag = p.get("autolag", "AIC")
             name = 'attr_"{}"__autolag_"{}"'.format(p["attr"], autolag)
-            out.append((name, adf[pos[p["attr"]]] if p["attr"] in pos else np.nan))
+            out.append((name, compute(autolag)[pos[p["attr"]]] if p["attr"] in pos else np.nan))
         return out
 
     def fft_coefficient(self, param):  # fc.py:1067

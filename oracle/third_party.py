@@ -2,7 +2,7 @@
 importable in the main interpreter of this image.
 
   * statsmodels >= 0.13 (setup.cfg:42; floor only, not vendored under /root/reference)
-        acf / acovf / pacf("ld") / levinson_durbin / adfuller(autolag="AIC") / mackinnonp / AutoReg(trend="c")
+        acf / acovf / pacf("ld") / levinson_durbin / adfuller(autolag=...) / mackinnonp / AutoReg(trend="c")
         call sites: feature_calculators.py:429 (acf), :490 (pacf), :521 (adfuller), :1493-1494 (AutoReg)
   * PyWavelets (setup.cfg:44, unpinned)
         pywt.cwt(x, scales, "mexh")     call site: feature_calculators.py:1402
@@ -124,12 +124,20 @@ def _add_const(X, prepend):
     return np.column_stack([ones, X]) if prepend else np.column_stack([X, ones])
 
 
-def adfuller_aic(x, probe=None):
-    """adfuller(x, autolag="AIC") -> (teststat, pvalue, usedlag); raises ValueError like statsmodels
-    (stattools.py:160-380, _autolag :63-147).  AIC = -2 llf + 2 rank (linear_model.py:1827 with df_model = rank -
-    k_constant), llf of OLS.loglike (:896-903), t value = params[0] / sqrt(ssr / (nobs - rank) * ncov[0, 0]).
+ADF_TSTAT_STOP = 1.6448536269514722   # stats.norm.ppf(.95), stattools._autolag "t-stat"
+
+
+def adfuller(x, autolag="AIC", probe=None):
+    """adfuller(x, autolag=autolag) -> (teststat, pvalue, usedlag); raises ValueError like statsmodels
+    (stattools.py:160-380, _autolag :63-147).  autolag "AIC" / "BIC": the lag minimising -2 llf + 2 rank / -2 llf +
+    log(nobs) rank (linear_model.py:1827, :1843 with df_model = rank - k_constant; llf of OLS.loglike :896-903); "t-stat":
+    from maxlag downwards, the first lag whose LAST coefficient has |t| >= norm.ppf(.95), else the smallest; None: maxlag.
+    t value = params[j] / sqrt(ssr / (nobs - rank) * ncov[j, j]).
     probe (tests/parity.py only): a random generator handed to every `_ols` call (row / column permutations of the same
     regression: how far the reference's own round-off moves the result)."""
+    mode = None if autolag is None else str(autolag).lower()
+    if mode not in (None, "aic", "bic", "t-stat"):
+        raise ValueError("autolag must be one of 'AIC', 'BIC', 't-stat' or None")
     x = np.asarray(x, dtype=np.float64)
     nobs = x.shape[0]
     ntrend = 1
@@ -146,17 +154,30 @@ def adfuller_aic(x, probe=None):
 
     Z, y = design(maxlag)
     n1 = len(y)
-    full = _add_const(Z, prepend=True)
-    startlag = full.shape[1] - Z.shape[1] + 1
-    best = None
     with np.errstate(divide="ignore", invalid="ignore"):
-        for lag in range(startlag, startlag + maxlag + 1):
-            _, ssr, rank, _ = _ols(y, full[:, :lag], probe)
-            llf = -n1 / 2.0 * np.log(2 * np.pi) - n1 / 2.0 * np.log(ssr / n1) - n1 / 2.0
-            aic = -2 * llf + 2 * rank
-            if best is None or (aic, lag) < best:
-                best = (aic, lag)
-        usedlag = best[1] - startlag
+        if mode is None:
+            usedlag = maxlag
+        else:
+            full = _add_const(Z, prepend=True)
+            startlag = full.shape[1] - Z.shape[1] + 1
+            if mode == "t-stat":
+                bestlag = startlag + maxlag
+                for lag in range(startlag + maxlag, startlag - 1, -1):
+                    beta, ssr, rank, ncov = _ols(y, full[:, :lag], probe)
+                    tlast = beta[-1] / np.sqrt(ssr / (n1 - rank) * ncov[-1, -1])
+                    bestlag = lag
+                    if np.abs(tlast) >= ADF_TSTAT_STOP:
+                        break
+            else:
+                best = None
+                for lag in range(startlag, startlag + maxlag + 1):
+                    _, ssr, rank, _ = _ols(y, full[:, :lag], probe)
+                    llf = -n1 / 2.0 * np.log(2 * np.pi) - n1 / 2.0 * np.log(ssr / n1) - n1 / 2.0
+                    ic = -2 * llf + (2 if mode == "aic" else np.log(n1)) * rank
+                    if best is None or (ic, lag) < best:
+                        best = (ic, lag)
+                bestlag = best[1]
+            usedlag = bestlag - startlag
         Z, y = design(usedlag)
         n2 = len(y)
         X = _add_const(Z[:, : usedlag + 1], prepend=False)
@@ -164,6 +185,10 @@ def adfuller_aic(x, probe=None):
         sigma2 = ssr / (n2 - rank)
         tstat = beta[0] / np.sqrt(sigma2 * ncov[0, 0])
     return tstat, mackinnonp_c(tstat), usedlag
+
+
+def adfuller_aic(x, probe=None):
+    return adfuller(x, "AIC", probe)
 
 
 def autoreg_params(x, k, probe=None):

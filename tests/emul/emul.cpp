@@ -85,6 +85,15 @@ extern "C" int tsfa_emul_extract_timed(const tsfa_feature_spec *specs, int n_spe
         if (s.calc == TSFA_C_CWT_COEFFICIENTS) cwt_coef.push_back(s);
         else fam[tsfa_calc_table[s.calc].family].push_back(s);
     }
+    {
+        std::vector<TsfaSpec> all;
+        for (int f = 0; f < TSFA_N_FAMILIES; ++f) all.insert(all.end(), fam[f].begin(), fam[f].end());
+        const std::string why = tsfa_validate_plan(all.data(), (int)all.size());
+        if (!why.empty()) {
+            snprintf(err, errlen, "%s", why.c_str());
+            return TSFA_ERR_UNSUPPORTED;
+        }
+    }
     TsfaFamHints hints[TSFA_N_FAMILIES];
     for (int f = 0; f < TSFA_N_FAMILIES; ++f) tsfa_prepare_family(f, fam[f], hints[f]);
     TsfaCwtBank bank;
@@ -200,7 +209,7 @@ extern "C" int tsfa_emul_extract_timed(const tsfa_feature_spec *specs, int n_spe
             if (flags) {  // the second pass of the family (k_ar_degenerate)
                 std::vector<double> sc(ArDdLds::scratch_doubles(P), TSFA_NAN);  // poisoned: LDS is not zero-initialised on the device
                 fam_ar_degenerate_series(b, [=](int i) { return xp[i]; }, n, fam[TSFA_FAM_AR].data(),
-                                         (int)fam[TSFA_FAM_AR].size(), row, sc.data(), P, flags);
+                                         (int)fam[TSFA_FAM_AR].size(), row, sc.data(), P, flags, (hints[TSFA_FAM_AR].c >> 1) & 3);
             }
         }
         if (!fam[TSFA_FAM_ENTROPY].empty()) {

@@ -54,3 +54,10 @@ def sweep_parameters():
 
 
 THIRD_PARTY = ("cwt_coefficients", "agg_autocorrelation", "partial_autocorrelation", "augmented_dickey_fuller", "ar_coefficient")
+
+
+def adf_autolag_parameters():
+    """augmented_dickey_fuller with the lag selections ComprehensiveFCParameters does not use (fc.py:499-545 passes
+    `autolag` through to statsmodels.adfuller): gen_golden_conda.py --params adf -> ref_conda_*_adf.npz."""
+    return {"augmented_dickey_fuller": [{"attr": a, "autolag": al} for al in ("BIC", "t-stat", None)
+                                        for a in ("teststat", "pvalue", "usedlag")]}

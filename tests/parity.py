@@ -193,7 +193,13 @@ def _ar_probe(x, k):
     return np.max(np.abs(np.array(runs) - base), axis=0)
 
 
-def _adf_probe(x):
+def _autolag_of(col):
+    """autolag of an augmented_dickey_fuller column: "AIC" / "BIC" / "t-stat" / None (the key spells None as "None")."""
+    al = col.split('autolag_"')[1].split('"')[0] if 'autolag_"' in col else "AIC"
+    return None if al == "None" else al
+
+
+def _adf_probe(x, autolag="AIC"):
     """-> (lag_stable, spread of teststat, spread of pvalue) over the probes, or None (well conditioned)."""
     from oracle import third_party as tp
     n = len(x)
@@ -209,8 +215,8 @@ def _adf_probe(x):
     with warnings.catch_warnings(), np.errstate(all="ignore"):
         warnings.simplefilter("ignore")
         try:
-            base = tp.adfuller_aic(x)
-            runs = [tp.adfuller_aic(x, probe=_probe(i)) for i in range(PROBES)]
+            base = tp.adfuller(x, autolag)
+            runs = [tp.adfuller(x, autolag, probe=_probe(i)) for i in range(PROBES)]
         except (ValueError, np.linalg.LinAlgError):
             return None
     stable = all(r[2] == base[2] for r in runs)
@@ -228,8 +234,8 @@ def _ar_design(x, k):
     return np.column_stack([np.ones(n - k)] + [x[rows - j] for j in range(1, k + 1)])
 
 
-def _adf_state(x):
-    """-> (unstable, perfect): properties of the regressions of statsmodels.adfuller(x, autolag="AIC") -- the lag-search
+def _adf_state(x, autolag="AIC"):
+    """-> (unstable, perfect): properties of the regressions of statsmodels.adfuller(x, autolag=autolag) -- the lag-search
     design and the final regression at the lag the reference's algorithm picks."""
     from oracle import third_party as tp
     n = len(x)
@@ -241,7 +247,7 @@ def _adf_state(x):
     if not perfect:
         try:
             with np.errstate(all="ignore"):
-                used = int(tp.adfuller_aic(x)[2])
+                used = int(tp.adfuller(x, autolag)[2])
         except (ValueError, np.linalg.LinAlgError):
             used = None
         if used is not None and 0 <= used <= maxlag:
@@ -508,10 +514,11 @@ def excluded(col, x, simd_golden=False, facts=None, rvalue=None):
         X = facts.get(("ar", k), lambda: _ar_design(xv, k))
         return X is not None and facts.get(("ar_unst", k), lambda: _pinv_unstable(X))                    # R4
     if f == "augmented_dickey_fuller":
-        unstable, perfect = facts.get("adf", lambda: _adf_state(xv))
+        al = _autolag_of(col)
+        unstable, perfect = facts.get(("adf", al), lambda: _adf_state(xv, al))
         if unstable or perfect:
             return True                                                                                   # R4, R5
-        probe = facts.get("adf_probe", lambda: _adf_probe(xv))
+        probe = facts.get(("adf_probe", al), lambda: _adf_probe(xv, al))
         return probe is not None and not probe[0]                                                        # R4: the lag
     if f in ("max_langevin_fixed_point", "friedrich_coefficients"):
         m, r = _param(col, "m", int), _param(col, "r", float)
@@ -613,7 +620,8 @@ def tolerance_for(col, x, want, facts):
         extra = PROBE_FACTOR * float(spread[j]) if spread is not None and 0 <= j < len(spread) else 0.0
         return RTOL, atol_for(col, x) + extra
     if f == "augmented_dickey_fuller" and 'attr_"usedlag"' not in col:
-        probe = facts.get("adf_probe", lambda: _adf_probe(facts.x))
+        al = _autolag_of(col)
+        probe = facts.get(("adf_probe", al), lambda: _adf_probe(facts.x, al))
         extra = 0.0 if probe is None else PROBE_FACTOR * (probe[1] if 'attr_"teststat"' in col else probe[2])
         return RTOL, atol_for(col, x) + extra
     return RTOL, atol_for(col, x)

@@ -422,6 +422,7 @@ TSFA_DEV int fam_ar_series(const Blk &b, X xv, int n, const TsfaSpec *specs, int
     // requested: tsfa_prepare_family on the host (a scan of the spec list here costs a scalar-load round trip per spec)
     int max_acf_lag = hint_acf, max_pacf_lag = hint_pacf;
     const bool need_adf = (hint_adf != 0);
+    const int adf_mode = (hint_adf >> 1) & 3;   // TSFA_ADF_*: the plan's lag selection
     if (max_acf_lag > 60) max_acf_lag = 60;
     if (max_pacf_lag > 40) max_pacf_lag = 40;
 
@@ -565,18 +566,31 @@ TSFA_DEV int fam_ar_series(const Blk &b, X xv, int n, const TsfaSpec *specs, int
                         for (int i = 0; i < p1; ++i) { acc += tmp1[i] * tmp1[i]; tmp2[i] = acc; }
                     }
                     blk_sync();
-                    for (int i = b.tid; i < p1; i += b.nt) {  // AIC of the fit with i + 1 columns
+                    for (int i = b.tid; i < p1; i += b.nt) {  // AIC (BIC) of the fit with i + 1 columns
                         const int pcols = i + 1;
                         const double ssr = yy - tmp2[i];
                         const double llf = -0.5 * nobs * log(2.0 * M_PI) - 0.5 * nobs * log(ssr / nobs) - 0.5 * nobs;
-                        tmp1[i] = -2.0 * llf + 2.0 * (double)pcols;
+                        const double wi = tmp1[i];
+                        double ic = -2.0 * llf + ((adf_mode == TSFA_ADF_BIC) ? log(nobs) : 2.0) * (double)pcols;
+                        // "t-stat": |t| of the LAST coefficient of that fit -- its value is w_i / L_ii and its variance
+                        // sigma^2 / L_ii^2, so the Cholesky diagonal cancels
+                        if (adf_mode == TSFA_ADF_TSTAT) ic = fabs(wi / sqrt(ssr / (nobs - (double)pcols)));
+                        tmp1[i] = ic;
                     }
                     blk_sync();
                 }
                 if (b.tid == 0) {
                     int best = -1;
                     double best_aic = 0.0;
-                    if (okf)
+                    if (okf && adf_mode == TSFA_ADF_TSTAT) {
+                        // from the largest lag down: the first fit whose last coefficient is significant, else the smallest
+                        for (int i = p1 - 1; i >= 1; --i) {
+                            best = i + 1;
+                            if (tmp1[i] >= TSFA_ADF_TSTAT_STOP) break;
+                        }
+                    } else if (okf && adf_mode == TSFA_ADF_MAXLAG) {
+                        best = p1;
+                    } else if (okf)
                         for (int i = 1; i < p1; ++i) {
                             const double aic = tmp1[i];
                             if (best < 0 || aic < best_aic) { best = i + 1; best_aic = aic; }

@@ -237,6 +237,15 @@ int tsfa_plan_create(const tsfa_feature_spec *specs, int32_t n_specs, int32_t de
         delete plan;
         return fail(TSFA_ERR_UNSUPPORTED, "more than 128 cwt_coefficients columns in one plan");
     }
+    {
+        std::vector<TsfaSpec> all;
+        for (int f = 0; f < TSFA_N_FAMILIES; ++f) all.insert(all.end(), plan->fam_specs[f].begin(), plan->fam_specs[f].end());
+        const std::string why = tsfa_validate_plan(all.data(), (int)all.size());
+        if (!why.empty()) {
+            delete plan;
+            return fail(TSFA_ERR_UNSUPPORTED, why);
+        }
+    }
     if (!cwt_coef.empty()) {
         const std::string why = plan->bank.build(cwt_coef);
         if (!why.empty()) {

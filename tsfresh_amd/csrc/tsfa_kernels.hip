@@ -302,7 +302,7 @@ __global__ void __launch_bounds__(64) k_langevin_dd(const double *__restrict__ p
 template <typename T>
 __global__ void __launch_bounds__(64) k_ar_degenerate(const T *__restrict__ values, const int64_t *__restrict__ starts, const int64_t *__restrict__ ends,
                      const TsfaSpec *__restrict__ specs, int nspecs, double *__restrict__ out, int64_t ld, int P,
-                     const long long *__restrict__ deg_list, const int *__restrict__ deg_count) {
+                     const long long *__restrict__ deg_list, const int *__restrict__ deg_count, int adf_mode) {
     ArDdLds L;
     L.carve(tsfa_smem, P);
     Blk b{(int)threadIdx.x, (int)blockDim.x, L.red, nullptr};
@@ -314,7 +314,7 @@ __global__ void __launch_bounds__(64) k_ar_degenerate(const T *__restrict__ valu
         const int n = (int)(ends[sidx] - off);
         const T *g = values + off;
         fam_ar_degenerate_series(b, [=](int k) { return (double)g[k]; }, n, specs, nspecs, out + sidx * ld, L.scratch, P,
-                                 (int)(e & 3));
+                                 (int)(e & 3), adf_mode);
         blk_sync();
     }
 }
@@ -1027,7 +1027,7 @@ static int launch_ar_degenerate_t(const TsfaLaunch &a, const T *values) {
     if ((rc = set_lds(k_ar_degenerate<T>, dlds))) return rc;
     const unsigned dgrid = (unsigned)std::min<int64_t>(a.n_series, 4096);
     k_ar_degenerate<T><<<dgrid, 64, dlds, st>>>(values, a.starts, a.ends, a.specs, a.nspecs, a.out, a.ld, a.ar_P, a.deg_list,
-                                                a.deg_count);
+                                                a.deg_count, (a.hint_c >> 1) & 3);
     TSFA_LAUNCH_CHECK();
     return 0;
 }

@@ -179,6 +179,12 @@ struct TsfaSpec {
 static inline int tsfa_pf_slot_doubles(int rmax) { return TSFA_PF_HDR + 2 * rmax; }
 
 // offsets into the plan's constant tables (tsfa_host_tables.h: tsfa_build_consts)
+// augmented_dickey_fuller, p[1]: the lag selection (statsmodels.adfuller autolag; one value per plan)
+#define TSFA_ADF_AIC 0
+#define TSFA_ADF_BIC 1
+#define TSFA_ADF_TSTAT 2
+#define TSFA_ADF_MAXLAG 3   /* autolag=None: the regression at maxlag */
+#define TSFA_ADF_TSTAT_STOP 1.6448536269514722   /* stats.norm.ppf(.95), stattools._autolag */
 #define TSFA_CONSTS_HANN 0
 #define TSFA_CONSTS_RICKER 256
 #define TSFA_CONSTS_MAXW 16

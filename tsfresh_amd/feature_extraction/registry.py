@@ -10,6 +10,7 @@ mapping becomes (a) the column-name suffix the reference would generate and (b) 
 The ORDER of this table is the definition order of the functions in the reference module, because
 ``ComprehensiveFCParameters`` lists the parameter-less calculators in that order (settings.py:157-163).
 """
+import os
 from collections import OrderedDict
 
 from tsfresh_amd.utilities.string_manipulation import convert_to_output_format
@@ -66,11 +67,23 @@ def _simple0(name, **kw):
     return Calc(name, "simple", n_args=1, **kw)
 
 
+ADF_AUTOLAG = {"aic": 0.0, "bic": 1.0, "t-stat": 2.0}   # tsfa_specs.h TSFA_ADF_*; None (the regression at maxlag): 3
+
+
 def _adf_encode(p):
+    """fc.py:499-545 hands `autolag` to statsmodels.adfuller (case-insensitive "AIC" / "BIC" / "t-stat", or None).
+    Every settings object of the reference uses "AIC".  The other three selections are built (fam_ar.h, fam_ar_dd.h) and
+    green against statsmodels' own output in the emulation of the kernel sources (tests/test_adf_autolag.py), but were
+    written after round 4's GPU minutes were spent: until they have run on the device they answer only to
+    TSFA_ADF_AUTOLAG=1 -- the default stays the refusal it was."""
     autolag = p.get("autolag", "AIC")
-    if autolag is None or str(autolag).upper() != "AIC":
-        raise UnsupportedFeature("augmented_dickey_fuller: only autolag='AIC' has a native kernel")
-    return (_code(ATTR_ADF, p["attr"], "augmented_dickey_fuller attr") if p["attr"] in ATTR_ADF else 3.0,)
+    mode = 3.0 if autolag is None else ADF_AUTOLAG.get(str(autolag).lower())
+    if mode is None:
+        raise UnsupportedFeature("augmented_dickey_fuller: autolag must be 'AIC', 'BIC', 't-stat' or None")
+    if mode != 0.0 and not os.environ.get("TSFA_ADF_AUTOLAG"):
+        raise UnsupportedFeature("augmented_dickey_fuller: only autolag='AIC' has a native kernel that has run on the device "
+                                 "(set TSFA_ADF_AUTOLAG=1 for 'BIC' / 't-stat' / None)")
+    return (_code(ATTR_ADF, p["attr"], "augmented_dickey_fuller attr") if p["attr"] in ATTR_ADF else 3.0, mode)
 
 
 def _cwt_encode(p):
