@@ -75,3 +75,13 @@ def test_one_autolag_value_per_plan():
 def test_hip_matches_statsmodels(gpu, set_name, mode):
     from engines import hip_engine
     _check(hip_engine, set_name, mode)
+
+
+@pytest.mark.parametrize("engine", [oracle_engine, emul_engine], ids=["oracle", "emul"])
+def test_an_unknown_attr_is_nan_as_in_the_reference(engine):
+    """fc.py:543: any other `attr` yields NaN (the column exists, under the name the caller gave it)."""
+    rng = np.random.default_rng(3)
+    x = rng.standard_normal(200)
+    names, got = engine({"augmented_dickey_fuller": [{"attr": "teststat"}, {"attr": "no_such_attr"}]}, x, np.array([0, 200], dtype=np.int64))
+    assert names[1] == 'value__augmented_dickey_fuller__attr_"no_such_attr"__autolag_"AIC"'
+    assert np.isfinite(got[0, 0]) and np.isnan(got[0, 1])

@@ -422,7 +422,7 @@ TSFA_DEV int fam_ar_series(const Blk &b, X xv, int n, const TsfaSpec *specs, int
     // requested: tsfa_prepare_family on the host (a scan of the spec list here costs a scalar-load round trip per spec)
     int max_acf_lag = hint_acf, max_pacf_lag = hint_pacf;
     const bool need_adf = (hint_adf != 0);
-    const int adf_mode = (hint_adf >> 1) & 3;   // TSFA_ADF_*: the plan's lag selection
+    const int adf_mode = (hint_adf >> 1) & 3;   // TSFA_AUTOLAG_*: the plan's lag selection
     if (max_acf_lag > 60) max_acf_lag = 60;
     if (max_pacf_lag > 40) max_pacf_lag = 40;
 
@@ -571,10 +571,10 @@ TSFA_DEV int fam_ar_series(const Blk &b, X xv, int n, const TsfaSpec *specs, int
                         const double ssr = yy - tmp2[i];
                         const double llf = -0.5 * nobs * log(2.0 * M_PI) - 0.5 * nobs * log(ssr / nobs) - 0.5 * nobs;
                         const double wi = tmp1[i];
-                        double ic = -2.0 * llf + ((adf_mode == TSFA_ADF_BIC) ? log(nobs) : 2.0) * (double)pcols;
+                        double ic = -2.0 * llf + ((adf_mode == TSFA_AUTOLAG_BIC) ? log(nobs) : 2.0) * (double)pcols;
                         // "t-stat": |t| of the LAST coefficient of that fit -- its value is w_i / L_ii and its variance
                         // sigma^2 / L_ii^2, so the Cholesky diagonal cancels
-                        if (adf_mode == TSFA_ADF_TSTAT) ic = fabs(wi / sqrt(ssr / (nobs - (double)pcols)));
+                        if (adf_mode == TSFA_AUTOLAG_TSTAT) ic = fabs(wi / sqrt(ssr / (nobs - (double)pcols)));
                         tmp1[i] = ic;
                     }
                     blk_sync();
@@ -582,13 +582,13 @@ TSFA_DEV int fam_ar_series(const Blk &b, X xv, int n, const TsfaSpec *specs, int
                 if (b.tid == 0) {
                     int best = -1;
                     double best_aic = 0.0;
-                    if (okf && adf_mode == TSFA_ADF_TSTAT) {
+                    if (okf && adf_mode == TSFA_AUTOLAG_TSTAT) {
                         // from the largest lag down: the first fit whose last coefficient is significant, else the smallest
                         for (int i = p1 - 1; i >= 1; --i) {
                             best = i + 1;
-                            if (tmp1[i] >= TSFA_ADF_TSTAT_STOP) break;
+                            if (tmp1[i] >= TSFA_AUTOLAG_TSTAT_STOP) break;
                         }
-                    } else if (okf && adf_mode == TSFA_ADF_MAXLAG) {
+                    } else if (okf && adf_mode == TSFA_AUTOLAG_NONE) {
                         best = p1;
                     } else if (okf)
                         for (int i = 1; i < p1; ++i) {

@@ -403,7 +403,7 @@ TSFA_DEV void dd_lag_products(const Blk &b, S s, int Lg, int t0, int t1, dd *T, 
 // flags: bit 0 = ar_coefficient, bit 1 = augmented_dickey_fuller (which calculators the first pass gave up on)
 template <class X>
 TSFA_DEV void fam_ar_degenerate_series(const Blk &b, X xv, int n, const TsfaSpec *specs, int nspecs, double *out_row,
-                                       double *scratch, int P, int flags, int adf_mode = TSFA_ADF_AIC) {
+                                       double *scratch, int P, int flags, int adf_mode = TSFA_AUTOLAG_AIC) {
     dd *T = (dd *)(void *)scratch;        // lag products; later R R^T (skipping route) or A = M^T (SVD route)
     dd *G = T + P * P;                    // Gram matrix -> skipping factor
     dd *C = G + P * P;                    // column sums
@@ -503,7 +503,7 @@ TSFA_DEV void fam_ar_degenerate_series(const Blk &b, X xv, int n, const TsfaSpec
             dd_chol_skip(b, G, p1, P, kept, nullptr, TSFA_DD_SKIP_TOL, diag0, skip_rel);
             // ("t-stat" reads a coefficient and its variance of every nested fit: always from the SVD of its block, the
             // skipping factor only knows residual sums and ranks)
-            const bool svd1 = dd_needs_svd(b, G, p1, P, kept, diag0, skip_rel, ev) || adf_mode == TSFA_ADF_TSTAT;
+            const bool svd1 = dd_needs_svd(b, G, p1, P, kept, diag0, skip_rel, ev) || adf_mode == TSFA_AUTOLAG_TSTAT;
             // the shift needs the constant column inside the design (column 0 of the lag search, the last one of the
             // final regression); a design whose constant is another exactly constant column stays unshifted
             const double shift = hasc ? xmean : 0.0;
@@ -518,27 +518,27 @@ TSFA_DEV void fam_ar_degenerate_series(const Blk &b, X xv, int n, const TsfaSpec
                 int best = -1;
                 double best_aic = 0.0;
                 bool stop = false;
-                const int nfits = (adf_mode == TSFA_ADF_MAXLAG) ? 0 : (p1 - startlag + 1);
-                if (adf_mode == TSFA_ADF_MAXLAG) best = p1;
+                const int nfits = (adf_mode == TSFA_AUTOLAG_NONE) ? 0 : (p1 - startlag + 1);
+                if (adf_mode == TSFA_AUTOLAG_NONE) best = p1;
                 for (int q = 0; q < nfits && !stop; ++q) {
                     // AIC / BIC: every nested fit, smallest first; "t-stat": from the largest down to the first whose last
                     // coefficient is significant
-                    const int m = (adf_mode == TSFA_ADF_TSTAT) ? p1 - q : startlag + q;
+                    const int m = (adf_mode == TSFA_AUTOLAG_TSTAT) ? p1 - q : startlag + q;
                     const int r = dd_build_mt(b, G, m, P, kept, shift, hasc ? 0 : -1, [=](int a) { return kind1(a) == 0; }, g, T, ev);
                     dd full = dd_from(0.0);
                     for (int i = 0; i < r; ++i) full = dd_add(full, dd_mul(ev[i], ev[i]));   // uniform: explained by the full fit
                     dd_hestenes(b, T, m, r, P, ev);
-                    const DdPinvFit f = dd_pinv_from_svd(b, T, m, r, P, ev, m, (adf_mode == TSFA_ADF_TSTAT) ? m - 1 : 0, z, nullptr);
+                    const DdPinvFit f = dd_pinv_from_svd(b, T, m, r, P, ev, m, (adf_mode == TSFA_AUTOLAG_TSTAT) ? m - 1 : 0, z, nullptr);
                     double ssr = dd_sub(yy, full).hi + f.dropped;
                     if (!(ssr > TSFA_DD_ZERO_SSR * yy.hi)) ssr = 0.0;
-                    if (adf_mode == TSFA_ADF_TSTAT) {
+                    if (adf_mode == TSFA_AUTOLAG_TSTAT) {
                         const double tl = f.beta0.hi / sqrt(ssr / (dn - (double)f.rank) * f.cov0);
                         best = m;
-                        if (fabs(tl) >= TSFA_ADF_TSTAT_STOP) stop = true;   // (uniform: every thread holds the same fit)
+                        if (fabs(tl) >= TSFA_AUTOLAG_TSTAT_STOP) stop = true;   // (uniform: every thread holds the same fit)
                         continue;
                     }
                     const double llf = -0.5 * dn * log(2.0 * M_PI) - 0.5 * dn * log(ssr / dn) - 0.5 * dn;
-                    const double aic = -2.0 * llf + ((adf_mode == TSFA_ADF_BIC) ? log(dn) : 2.0) * (double)f.rank;
+                    const double aic = -2.0 * llf + ((adf_mode == TSFA_AUTOLAG_BIC) ? log(dn) : 2.0) * (double)f.rank;
                     if (best < 0 || aic < best_aic) { best = m; best_aic = aic; }
                 }
                 blk_sync();
@@ -557,10 +557,10 @@ TSFA_DEV void fam_ar_degenerate_series(const Blk &b, X xv, int n, const TsfaSpec
                         double ssr = dd_sub(yy, acc).hi;
                         if (!(ssr > TSFA_DD_ZERO_SSR * yy.hi)) ssr = 0.0;
                         const double llf = -0.5 * dn * log(2.0 * M_PI) - 0.5 * dn * log(ssr / dn) - 0.5 * dn;
-                        const double aic = -2.0 * llf + ((adf_mode == TSFA_ADF_BIC) ? log(dn) : 2.0) * (double)rank;
+                        const double aic = -2.0 * llf + ((adf_mode == TSFA_AUTOLAG_BIC) ? log(dn) : 2.0) * (double)rank;
                         if (best < 0 || aic < best_aic) { best = m; best_aic = aic; }
                     }
-                    if (adf_mode == TSFA_ADF_MAXLAG) best = p1;
+                    if (adf_mode == TSFA_AUTOLAG_NONE) best = p1;
                     misc[0] = dd_from((double)(best - startlag));
                 }
             }

@@ -287,7 +287,7 @@ static inline void tsfa_prepare_family_impl(int fam, std::vector<TsfaSpec> &spec
         for (const auto &s : specs) {
             if (s.calc == TSFA_C_AGG_AUTOCORRELATION && (int)s.p[1] > h.a) h.a = (int)s.p[1];
             if (s.calc == TSFA_C_PARTIAL_AUTOCORRELATION && (int)s.p[0] > h.b) h.b = (int)s.p[0];
-            if (s.calc == TSFA_C_AUGMENTED_DICKEY_FULLER) h.c = 1 + 2 * (int)s.p[1];   // bit 0: requested; bits 1-2: TSFA_ADF_* (tsfa_validate_plan: one per plan)
+            if (s.calc == TSFA_C_AUGMENTED_DICKEY_FULLER) h.c = 1 + 2 * (int)s.p[1];   // bit 0: requested; bits 1-2: TSFA_AUTOLAG_* (tsfa_validate_plan: one per plan)
         }
     }
     if (fam == TSFA_FAM_SORT) {
@@ -565,8 +565,8 @@ static inline std::string tsfa_validate_spec(const TsfaSpec &s) {
         if (!(is_int(p[1]) && p[1] >= 1 && p[1] <= 31)) return "ar_coefficient: k must be in [1, 31]";
         break;
     case TSFA_C_AUGMENTED_DICKEY_FULLER:
-        if (!(p[0] >= 0 && p[0] <= 2)) return "augmented_dickey_fuller: unknown attr";
-        if (!(is_int(p[1]) && p[1] >= TSFA_ADF_AIC && p[1] <= TSFA_ADF_MAXLAG)) return "augmented_dickey_fuller: autolag must be AIC, BIC, t-stat or None";
+        if (!(is_int(p[0]) && p[0] >= 0 && p[0] <= 3)) return "augmented_dickey_fuller: unknown attr code";   // (3: a name the reference answers with NaN, fc.py:543)
+        if (!(is_int(p[1]) && p[1] >= TSFA_AUTOLAG_AIC && p[1] <= TSFA_AUTOLAG_NONE)) return "augmented_dickey_fuller: autolag must be AIC, BIC, t-stat or None";
         break;
     case TSFA_C_APPROXIMATE_ENTROPY:
         if (!(is_int(p[0]) && p[0] >= 1)) return "approximate_entropy: m must be >= 1";

@@ -27,7 +27,7 @@
 //   agg_autocorrelation             : p0 = f_agg (mean/median/var), p1 = maxlag
 //   partial_autocorrelation         : p0 = lag
 //   ar_coefficient                  : p0 = coeff, p1 = k
-//   augmented_dickey_fuller         : p0 = attr (TSFA_ADF_*)   (autolag "AIC" only)
+//   augmented_dickey_fuller         : p0 = attr (TSFA_ADF_*), p1 = lag selection (TSFA_AUTOLAG_*, one value per plan)
 //   approximate_entropy             : p0 = m, p1 = r
 //   cwt_coefficients                : p0 = w (the width), p1 = coeff
 #ifndef TSFA_SPECS_H
@@ -180,11 +180,11 @@ static inline int tsfa_pf_slot_doubles(int rmax) { return TSFA_PF_HDR + 2 * rmax
 
 // offsets into the plan's constant tables (tsfa_host_tables.h: tsfa_build_consts)
 // augmented_dickey_fuller, p[1]: the lag selection (statsmodels.adfuller autolag; one value per plan)
-#define TSFA_ADF_AIC 0
-#define TSFA_ADF_BIC 1
-#define TSFA_ADF_TSTAT 2
-#define TSFA_ADF_MAXLAG 3   /* autolag=None: the regression at maxlag */
-#define TSFA_ADF_TSTAT_STOP 1.6448536269514722   /* stats.norm.ppf(.95), stattools._autolag */
+#define TSFA_AUTOLAG_AIC 0
+#define TSFA_AUTOLAG_BIC 1
+#define TSFA_AUTOLAG_TSTAT 2
+#define TSFA_AUTOLAG_NONE 3   /* autolag=None: the regression at maxlag */
+#define TSFA_AUTOLAG_TSTAT_STOP 1.6448536269514722   /* stats.norm.ppf(.95), stattools._autolag */
 #define TSFA_CONSTS_HANN 0
 #define TSFA_CONSTS_RICKER 256
 #define TSFA_CONSTS_MAXW 16

@@ -67,7 +67,7 @@ def _simple0(name, **kw):
     return Calc(name, "simple", n_args=1, **kw)
 
 
-ADF_AUTOLAG = {"aic": 0.0, "bic": 1.0, "t-stat": 2.0}   # tsfa_specs.h TSFA_ADF_*; None (the regression at maxlag): 3
+ADF_AUTOLAG = {"aic": 0.0, "bic": 1.0, "t-stat": 2.0}   # tsfa_specs.h TSFA_AUTOLAG_*; None (the regression at maxlag): 3
 
 
 def _adf_encode(p):
