@@ -48,7 +48,8 @@ can bound it.
       np.roots then returns a root near -c2/c3) -- relative to the other terms, or within the noise of its own fit (R11's
       tolerance: an exact ramp far from zero has a constant drift and the reference's cubic is that constant + noise).
   R7  agg_linear_trend: slope-type attributes when the chunk aggregates differ by round-off only
-      (0 < ptp <= 1e-12 * max|agg|), and "stderr" of linear_trend / agg_linear_trend when 1 - r^2 < 1e-9
+      (0 < ptp <= 1e-12 * max|agg|), "stderr" of linear_trend / agg_linear_trend when 1 - r^2 < 1e-9, and "pvalue" when
+      1 - r^2 <= 16 eps (three points on a line: scipy's p is then a function of its 1e-20 guard)
       (scipy's sqrt((1 - r^2) ...) cancels).
   R9  partial_autocorrelation from the lag at which the Levinson-Durbin innovation variance has dropped below
       1e-9 * acov[0] (an exactly predictable series: periodic, linear): the next coefficient divides by round-off.
@@ -209,7 +210,20 @@ def _adf_probe(x, autolag="AIC"):
     d = np.diff(x)
     rows = np.arange(maxlag, len(d))
     full = tp._add_const(np.column_stack([x[rows]] + [d[rows - j] for j in range(1, maxlag + 1)]), prepend=True)
-    if EPS * _cond_raw(full) < 1e-9:
+    # ... times how much of y the fit explains: statsmodels forms resid = y - X b in float64, so |resid| -- and through it the
+    # standard error under the statistic -- carries eps cond |y| / |resid| (seven samples of 3.7e-6 sin(t): cond 1.8e6 alone
+    # looks harmless, |y| / |resid| is 2e6: the reference says -2310901.09, its probes move it by 8, 60-digit arithmetic
+    # (tests/adf_mp.py) and the kernels say -2310909.12)
+    amp = 1.0
+    y = d[rows]
+    yy = float(y @ y)
+    if yy > 0 and np.all(np.isfinite(full)):
+        nrm = np.sqrt((full * full).sum(axis=0))
+        fs = full / np.where(nrm > 0, nrm, 1.0)
+        r = y - fs @ np.linalg.lstsq(fs, y, rcond=None)[0]
+        rr = float(r @ r)
+        amp = np.sqrt(yy / rr) if rr > 0 else np.inf
+    if EPS * _cond_raw(full) * max(1.0, amp) < 1e-9:
         return None
     import warnings
     with warnings.catch_warnings(), np.errstate(all="ignore"):
@@ -354,7 +368,9 @@ def _cwt_peaks_ambiguous(x, n):
     from scipy.signal._wavelets import _cwt
     from oracle.calculators import _ricker
     x = np.asarray(x, dtype=np.float64)
-    if len(x) < 4 or not np.any(x):   # (a NON-zero constant has a flat CWT interior: every neighbour pair is a tie)
+    # (three samples suffice: [0, a, a] -- the width-2 row holds a and a up to the last bit of np.convolve, scipy finds a
+    #  strict maximum at column 1 for n = 2 .. 4 and a ridge line of length 1 passes; the kernels see an exact tie)
+    if len(x) < 3 or not np.any(x):   # (a NON-zero constant has a flat CWT interior: every neighbour pair is a tie)
         return False
     rows = _cwt(x, _ricker, np.arange(1, n + 1))
     # ... or a ridge line's signal-to-noise ratio sits ON the threshold min_snr = 1 up to round-off: on exactly periodic data
@@ -414,6 +430,13 @@ def _r_of_chunks(agg):
 def _r2_cancels(rvalue):
     # two-point fits are exact (r = +-1, stderr = 0 by scipy's special case) and stay compared
     return rvalue is not None and np.isfinite(rvalue) and 1.0 - rvalue * rvalue < 1e-9
+
+
+def _r2_is_one(r):
+    """pvalue of a fit whose r^2 is 1 to the last bits: scipy evaluates t = r sqrt(df / ((1 - r + 1e-20)(1 + r + 1e-20))), so
+    for r == +-1.0 EXACTLY the p-value is a function of that 1e-20 (9.0e-11 for three points on a line), and of the last
+    bit of r otherwise (9.5e-9 one ulp away): not a number to compare."""
+    return r is not None and np.isfinite(r) and 1.0 - r * r <= 16.0 * EPS
 
 
 def _pacf_min_innovation(x):
@@ -535,10 +558,14 @@ def excluded(col, x, simd_golden=False, facts=None, rvalue=None):
         agg = facts.get(("agg", f_agg, cl), lambda: _chunk_aggs(xv, f_agg, cl))
         if attr != "intercept" and len(agg) > 1 and 0 < np.ptp(agg) <= 1e-12 * np.max(np.abs(agg)):
             return True                                                                                   # R7
+        if attr == "pvalue" and len(agg) > 2 and _r2_is_one(_r_of_chunks(agg)):
+            return True                                                                                   # R7
         if attr == "stderr" and len(agg) > 2 and rvalue is None:  # the plan does not hold the sibling column
             rvalue = _r_of_chunks(agg)
         return attr == "stderr" and len(agg) > 2 and _r2_cancels(rvalue)
     if f == "linear_trend":
+        if 'attr_"pvalue"' in col and len(xv) > 2 and _r2_is_one(_r_of_chunks(xv)):
+            return True                                                                                   # R7
         if 'attr_"stderr"' in col and len(xv) > 2 and rvalue is None:
             rvalue = _r_of_chunks(xv)
         return 'attr_"stderr"' in col and len(xv) > 2 and _r2_cancels(rvalue)

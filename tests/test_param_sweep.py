@@ -87,3 +87,22 @@ def test_parameters_beyond_the_tables_are_refused_by_name(params, needle):
     with pytest.raises(RuntimeError) as e:
         emul_engine(params, np.arange(50.0), np.array([0, 50], dtype=np.int64))
     assert needle in str(e.value) and list(params)[0] in str(e.value)
+
+
+def test_an_ar_column_beyond_the_order_does_not_starve_the_others():
+    """ar_coefficient coeff > k is NaN without a fit (fc.py:1500).  The columns behind the first one read the fit the first one
+    cached: a plan whose FIRST column was such a NaN left the cache empty (a random-parameter fuzz find; the device always
+    takes that path, the emulation on its even series)."""
+    import numpy as np
+    from parity import compare
+    rng = np.random.default_rng(5)
+    series = [rng.standard_normal(n) for n in (68, 25, 58, 55, 66, 31, 97, 77)]
+    values = np.concatenate(series)
+    offsets = np.concatenate([[0], np.cumsum([len(s) for s in series])]).astype(np.int64)
+    params = {"ar_coefficient": [{"coeff": 16, "k": 15}, {"coeff": 9, "k": 15}, {"coeff": 0, "k": 15}]}
+    names, got = emul_engine(params, values, offsets)
+    onames, want = oracle_engine(params, values, offsets)
+    assert names == onames
+    assert np.isnan(got[:, 0]).all() and np.isfinite(got[np.array([len(s) >= 32 for s in series]), 1]).all()
+    bad = compare(names, got, want, series)
+    assert not bad, bad[:6]

@@ -152,7 +152,9 @@ static inline void tsfa_prepare_family(int fam, std::vector<TsfaSpec> &specs, Ts
         bool seen_ar = false;
         for (const auto &s : specs) {
             bool e = (s.calc == TSFA_C_PARTIAL_AUTOCORRELATION || s.calc == TSFA_C_AUGMENTED_DICKEY_FULLER);
-            if (s.calc == TSFA_C_AR_COEFFICIENT) { e = one_k && seen_ar; seen_ar = true; }
+            // (the fit is made -- and cached for the epilogue -- by the first column that READS it: coeff > k is NaN without
+            //  one, fc.py:1500; a plan whose first column was such a one left the cache empty for the others -- a fuzz find)
+            if (s.calc == TSFA_C_AR_COEFFICIENT) { e = one_k && seen_ar; if ((int)s.p[0] <= (int)s.p[1]) seen_ar = true; }
             (e ? epi : loop).push_back(s);
         }
         h.d = (int)loop.size();
