@@ -85,3 +85,17 @@ def test_an_unknown_attr_is_nan_as_in_the_reference(engine):
     names, got = engine({"augmented_dickey_fuller": [{"attr": "teststat"}, {"attr": "no_such_attr"}]}, x, np.array([0, 200], dtype=np.int64))
     assert names[1] == 'value__augmented_dickey_fuller__attr_"no_such_attr"__autolag_"AIC"'
     assert np.isfinite(got[0, 0]) and np.isnan(got[0, 1])
+
+
+@pytest.mark.parametrize("engine", [oracle_engine, emul_engine], ids=["oracle", "emul"])
+def test_the_string_none_is_not_none(engine):
+    """settings.from_columns turns autolag_"None" into the STRING "None"; statsmodels raises ValueError for it and
+    fc.py:523 answers (nan, nan, nan) -- verified against the real libraries: NaN for "None", -4.4378 for None."""
+    x = np.random.default_rng(1).standard_normal(200)
+    o = np.array([0, 200], dtype=np.int64)
+    names, got = engine({"augmented_dickey_fuller": [{"attr": "teststat", "autolag": "None"}]}, x, o)
+    assert names == ['value__augmented_dickey_fuller__attr_"teststat"__autolag_"None"'] and np.isnan(got[0, 0])
+    _, got = engine({"augmented_dickey_fuller": [{"attr": "teststat", "autolag": None}]}, x, o)
+    assert abs(got[0, 0] - (-4.437821986643767)) < 1e-9
+    _, got = engine({"augmented_dickey_fuller": [{"attr": "teststat", "autolag": "bic"}]}, x, o)
+    assert abs(got[0, 0] - (-13.046525438501202)) < 1e-8

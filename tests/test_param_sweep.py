@@ -106,3 +106,24 @@ def test_an_ar_column_beyond_the_order_does_not_starve_the_others():
     assert np.isnan(got[:, 0]).all() and np.isfinite(got[np.array([len(s) >= 32 for s in series]), 1]).all()
     bad = compare(names, got, want, series)
     assert not bad, bad[:6]
+
+
+def test_from_columns_round_trips_every_name_of_the_sweep(monkeypatch):
+    """settings.from_columns (the reference's settings.py:24-84: what feature selection hands back) on the 229 names of the
+    sweep, the permutation_entropy sets and the ADF lag selections: tuples, negative and exponent-form numbers, None."""
+    import warnings
+    from perm_cases import SETS as PERM_SETS
+    from param_cases import adf_autolag_parameters
+    from tsfresh_amd.feature_extraction import settings
+    from tsfresh_amd.feature_extraction.plan import compile_fc_parameters
+    monkeypatch.setenv("TSFA_ADF_AUTOLAG", "1")
+    sets = [sweep_parameters()] + list(PERM_SETS.values())
+    sets += [{"augmented_dickey_fuller": [p for p in adf_autolag_parameters()["augmented_dickey_fuller"] if p["autolag"] == al]}
+             for al in ("BIC", "t-stat", None)]
+    for params in sets:
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            names = ["value__" + n for n in compile_fc_parameters(params).names]
+            back = settings.from_columns(names)["value"]
+            again = ["value__" + n for n in compile_fc_parameters(back).names]
+        assert sorted(again) == sorted(names)

@@ -79,7 +79,9 @@ def _adf_encode(p):
     autolag = p.get("autolag", "AIC")
     mode = 3.0 if autolag is None else ADF_AUTOLAG.get(str(autolag).lower())
     if mode is None:
-        raise UnsupportedFeature("augmented_dickey_fuller: autolag must be 'AIC', 'BIC', 't-stat' or None")
+        # any other value (the STRING "None" that from_columns makes of autolag_"None" included): statsmodels raises
+        # ValueError, fc.py:523 turns that into (nan, nan, nan) -- a NaN column under the name the caller gave it
+        return (3.0, 0.0)
     if mode != 0.0 and not os.environ.get("TSFA_ADF_AUTOLAG"):
         raise UnsupportedFeature("augmented_dickey_fuller: only autolag='AIC' has a native kernel that has run on the device "
                                  "(set TSFA_ADF_AUTOLAG=1 for 'BIC' / 't-stat' / None)")
