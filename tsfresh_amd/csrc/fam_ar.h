@@ -363,6 +363,7 @@ TSFA_DEV bool ar_refinement_suspect(const double *beta, const double *corr, cons
     return mc > TSFA_AR_REFINE_TOL * mb;
 }
 
+#define TSFA_AR_COND_CHECK_K 12   // AR orders above this also get a condition estimate (fam_ar_series, ar_coefficient)
 #define TSFA_AR_RAW_RATIO 1e-12
 TSFA_DEV bool ar_raw_design_suspect(double dmin, double mu_norm, double trace_raw) {
     return sqrt(dmin) < TSFA_AR_RAW_RATIO * (1.0 + mu_norm) * sqrt(trace_raw);
@@ -823,6 +824,34 @@ TSFA_DEV int fam_ar_series(const Blk &b, X xv, int n, const TsfaSpec *specs, int
                     double tr = rows;
                     for (int a = 1; a < p; ++a) tr += diag0[a] + 2.0 * mu * C[a] + rows * mu * mu;
                     if (ar_raw_design_suspect(dmin_ar, sqrt((double)k) * fabs(mu), tr)) degenerate |= 1;
+                }
+                if (ar_ok && k > TSFA_AR_COND_CHECK_K) {
+                    // The pivots of a Cholesky in the natural column order do not reveal a design that is singular to working
+                    // precision WITHOUT an exact dependency among leading columns (k + 1 noisy samples, then a stuck sensor:
+                    // smallest singular value 1e-21 s_max, every pivot above 1e-3 of its diagonal): the float64 factor then
+                    // "solves" a perturbed problem, the refinement step agrees with it, and the coefficients are wrong in the
+                    // first digit (a random-parameter fuzz find: ~10 % of such series from AR(16) on; none seen at AR(10) /
+                    // AR(12), which is why the orders of ComprehensiveFCParameters do not pay for this).  Two steps of inverse
+                    // iteration through the factor estimate the smallest eigenvalue; below 1e-12 of the trace (singular value
+                    // ratio 1e-6) the series goes to the double-double pass, which orders the columns by pivoting.
+                    double tr0 = 0.0, s0 = 0.0;
+                    for (int a = 0; a < p; ++a) { tr0 += diag0[a]; s0 += 1.0 / diag0[a]; }   // uniform
+                    for (int a = b.tid; a < p; a += b.nt) tmp1[a] = 1.0 / sqrt(diag0[a] * s0);
+                    blk_sync();
+                    double lmin = tr0;
+                    for (int it = 0; it < 2; ++it) {
+                        blk_chol_solve(b, G, p, P, tmp1, tmp2);
+                        blk_sync();
+                        double nrm2 = 0.0;
+                        for (int a = 0; a < p; ++a) nrm2 += tmp2[a] * tmp2[a];   // uniform: every thread reads the same LDS values
+                        const double nrm = sqrt(nrm2);
+                        if (!(nrm > 0.0) || isinf(nrm) || nrm != nrm) { lmin = 0.0; break; }
+                        lmin = 1.0 / nrm;
+                        blk_sync();
+                        for (int a = b.tid; a < p; a += b.nt) tmp1[a] = tmp2[a] / nrm;
+                        blk_sync();
+                    }
+                    if (!(lmin >= 1e-12 * tr0)) degenerate |= 1;
                 }
                 if (ar_ok) blk_chol_solve(b, G, p, P, g, beta);
                 blk_sync();

@@ -676,10 +676,73 @@ TSFA_DEV void fam_ar_degenerate_series(const Blk &b, X xv, int n, const TsfaSpec
                     blk_sync();
                 };
                 build_ar(0.0);
+                // The skipping Cholesky is not rank revealing in the natural column order: a design whose smallest singular
+                // value is 5e-24 s_max WITHOUT any column depending exactly on its predecessors (32 noisy samples, then a
+                // stuck sensor, AR(30): every exact pivot is above 6e-4 of its diagonal, the Gram matrix has condition 1e47)
+                // breaks the factorisation down in double-double -- a pivot of -1.6e-3 -- and the fit came out as a rank-28
+                // truncation (a random-parameter fuzz find; ~10 % of such series from AR(16) on, none at the AR(10) of
+                // ComprehensiveFCParameters).  So the lag columns are first put in the order of a diagonally PIVOTED
+                // Cholesky (float64 dry run, the constant stays first): whatever is dependent to working precision comes
+                // last and meets a clean, tiny pivot.  perm[a] = design column at position a.
+                int *perm = kept2;   // (kept2 is only used inside dd_min_norm, after the order is applied)
+                auto order_columns = [&]() {
+                    blk_sync();
+                    double *S = (double *)(void *)T;   // T is free between build_ar and the routes: p x p doubles
+                    for (int e = b.tid; e < p * p; e += b.nt) {
+                        const int a = e / p, c = e % p;
+                        S[a + c * p] = (c <= a) ? G[a + c * P].hi : G[c + a * P].hi;
+                    }
+                    blk_sync();
+                    if (b.tid == 0) {
+                        for (int a = 0; a < p; ++a) perm[a] = a;
+                        double dmax = 0.0;
+                        for (int a = 1; a < p; ++a) dmax = fmax(dmax, S[a + a * p]);
+                        for (int j = 0; j < p; ++j) {
+                            if (j >= 1) {   // largest remaining diagonal among the lag columns
+                                int best = j;
+                                for (int a = j + 1; a < p; ++a)
+                                    if (S[a + a * p] > S[best + best * p]) best = a;
+                                if (!(S[best + best * p] > 1e-13 * dmax)) break;   // float64 noise: the rest in the order it has
+                                if (best != j) {
+                                    for (int c = 0; c < p; ++c) { const double t = S[j + c * p]; S[j + c * p] = S[best + c * p]; S[best + c * p] = t; }
+                                    for (int c = 0; c < p; ++c) { const double t = S[c + j * p]; S[c + j * p] = S[c + best * p]; S[c + best * p] = t; }
+                                    const int t = perm[j]; perm[j] = perm[best]; perm[best] = t;
+                                }
+                            }
+                            const double d = S[j + j * p];
+                            if (!(d > 0.0)) break;
+                            const double sd = sqrt(d);
+                            for (int i = j + 1; i < p; ++i) S[i + j * p] /= sd;
+                            for (int i = j + 1; i < p; ++i)
+                                for (int c = j + 1; c <= i; ++c) { S[i + c * p] -= S[i + j * p] * S[c + j * p]; S[c + i * p] = S[i + c * p]; }
+                        }
+                    }
+                    blk_sync();
+                };
+                auto apply_order = [&]() {   // G, g (natural order) -> the order of perm
+                    blk_sync();
+                    for (int e = b.tid; e < p * p; e += b.nt) {
+                        const int a = e / p, c = e % p;
+                        if (c <= a) T[a + c * P] = G[a + c * P];
+                    }
+                    for (int a = b.tid; a < p; a += b.nt) z[a] = g[a];
+                    blk_sync();
+                    for (int e = b.tid; e < p * p; e += b.nt) {
+                        const int a = e / p, c = e % p;
+                        if (c > a) continue;
+                        const int pa = perm[a], pc = perm[c];
+                        G[a + c * P] = (pa >= pc) ? T[pa + pc * P] : T[pc + pa * P];
+                    }
+                    for (int a = b.tid; a < p; a += b.nt) g[a] = z[perm[a]];
+                    blk_sync();
+                };
+                order_columns();
+                apply_order();
                 dd_chol_skip(b, G, p, P, kept, nullptr, TSFA_DD_SKIP_TOL, diag0, skip_rel);
                 if (dd_needs_svd(b, G, p, P, kept, diag0, skip_rel, ev)) {
                     // pinv truncation regime (see dd_hestenes): shifted design, target x[t] = x'[t] + c
                     build_ar(xmean);
+                    apply_order();
                     dd_chol_skip(b, G, p, P, kept, nullptr, TSFA_DD_SKIP_TOL, diag0, skip_rel);
                     dd_forward_kept(b, G, p, P, kept, g);
                     blk_sync();
@@ -692,8 +755,21 @@ TSFA_DEV void fam_ar_degenerate_series(const Blk &b, X xv, int n, const TsfaSpec
                 } else {
                     dd_forward_kept(b, G, p, P, kept, g);
                     double unused = 0.0;
+                    // (dd_min_norm uses kept2 as scratch: the order moves to skip_rel's place first)
+                    blk_sync();
+                    if (b.tid == 0) for (int a = 0; a < p; ++a) skip_rel[a] = (double)perm[a];
+                    blk_sync();
                     ok = dd_min_norm(b, G, p, P, kept, g, T, z, diag0, kept2, beta, false, &unused);
+                    blk_sync();
+                    if (b.tid == 0) for (int a = 0; a < p; ++a) perm[a] = (int)skip_rel[a];
+                    blk_sync();
                 }
+                // coefficients back to the design's column order
+                blk_sync();
+                for (int a = b.tid; a < p; a += b.nt) z[a] = beta[a];
+                blk_sync();
+                for (int a = b.tid; a < p; a += b.nt) beta[perm[a]] = z[a];
+                blk_sync();
                 done_k = k;
             }
             if (b.tid == 0) out_row[sp.col] = ok ? beta[coeff].hi : TSFA_NAN;
