@@ -432,6 +432,14 @@ def _r2_cancels(rvalue):
     return rvalue is not None and np.isfinite(rvalue) and 1.0 - rvalue * rvalue < 1e-9
 
 
+def _max_real_root(coef):
+    c = np.trim_zeros(np.asarray(coef, dtype=np.float64), "f")
+    if len(c) < 2 or not np.all(np.isfinite(c)):
+        return None
+    r = np.roots(c)
+    return float(np.max(np.real(r))) if len(r) else None
+
+
 def _r2_is_one(r):
     """pvalue of a fit whose r^2 is 1 to the last bits: scipy evaluates t = r sqrt(df / ((1 - r + 1e-20)(1 + r + 1e-20))), so
     for r == +-1.0 EXACTLY the p-value is a function of that 1e-20 (9.0e-11 for three points on a line), and of the last
@@ -619,6 +627,20 @@ def tolerance_for(col, x, want, facts):
             grow = float(np.polynomial.chebyshev.Chebyshev.basis(m)(t))
             if slope > 0:
                 atol += COND_FACTOR * EPS * grow * (fit["kappa"] * fit["resid"] + fit["scaled_norm"]) / slope
+            # ... and how far the plain normwise noise of the coefficients (eps kappa |c_scaled| each, as above) moves the
+            # largest real part itself: the slope argument is about a simple REAL root; a ramp's drift is a constant plus
+            # noise coefficients, its roots a complex pair 8.5 +- 552 065 i whose real part -c1 / (2 c0) is a quotient of two
+            # numbers known to 1e-6 (reference 8.514211, 60-digit fit 8.514215, the kernels 8.514224)
+            dc = noise * fit["scaled_norm"] / fit["scale"]
+            base = _max_real_root(fit["coef"])
+            if base is not None:
+                import itertools
+                worst = 0.0
+                for sg in itertools.product((-1.0, 1.0), repeat=len(dc)):
+                    r = _max_real_root(fit["coef"] + np.array(sg) * dc)
+                    if r is not None:
+                        worst = max(worst, abs(r - base))
+                atol += worst
         return RTOL, atol
     if f in ("linear_trend", "agg_linear_trend") and 'attr_"pvalue"' in col:
         # t = r sqrt(df / ((1 - r)(1 + r))): 1 - r^2 is known to ~4 eps, and p ~ t^-df for the large t of a near-perfect
