@@ -54,35 +54,49 @@ def _cpu_warm(_):
     return 0
 
 
-def measured_hbm_traffic(kernel, cfg):
-    """HBM bytes per launch of `kernel` from the committed PMC pass (profiles/pmc_hbm.sh -> profiles/hbm_traffic.json:
-    rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate runs of this same command, FETCH_SIZE doubled as
-    MI355X_MICROARCH.md prescribes for gfx950).  None when the file is absent or was taken on another workload."""
-    path = os.path.join(ROOT, "profiles", "hbm_traffic.json")
+def lib_sha16():
+    """Build id of the library this process loaded: the first 16 hex digits of sha256(libtsfresh_amd.so).  The counter
+    scripts (profiles/pmc_hbm.sh, pmc_issue.sh) record the same figure next to what they measure."""
+    import hashlib
+    from tsfresh_amd import _native
     try:
-        doc = json.load(open(path))
-    except (OSError, ValueError):
+        return hashlib.sha256(open(_native.LIB_PATH, "rb").read()).hexdigest()[:16]
+    except OSError:
         return None
+
+
+def _replayed_counters(fname, cfg):
+    """-> (document, stale): a committed PMC document is replayed only when it was taken on THIS workload and on THIS
+    build of the library (VERDICT r4 #3); a document of another build is refused and reported as stale."""
+    try:
+        doc = json.load(open(os.path.join(ROOT, "profiles", fname)))
+    except (OSError, ValueError):
+        return None, False
     w = doc.get("workload", {})
     if any(w.get(k) != cfg.get(k) for k in ("n_series_per_gpu", "length", "n_cols")):
-        return None
-    return doc.get("kernels", {}).get(kernel, {}).get("hbm_bytes_per_launch")
+        return None, False
+    if doc.get("lib_sha16") != lib_sha16():
+        return None, True
+    return doc, False
+
+
+def measured_hbm_traffic(kernel, cfg):
+    """-> (HBM bytes per launch of `kernel`, stale) from the committed PMC pass (profiles/pmc_hbm.sh ->
+    profiles/hbm_traffic.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate runs of this same command, FETCH_SIZE
+    doubled as MI355X_MICROARCH.md prescribes for gfx950).  None when the file is absent, was taken on another workload
+    or on another build of the library."""
+    doc, stale = _replayed_counters("hbm_traffic.json", cfg)
+    return (doc.get("kernels", {}).get(kernel, {}).get("hbm_bytes_per_launch") if doc else None), stale
 
 
 def measured_valu_issue(cfg):
-    """Vector-instruction issue of the whole step from the committed PMC pass (profiles/pmc_issue.sh ->
+    """-> (vector-instruction issue of the whole step, stale) from the committed PMC pass (profiles/pmc_issue.sh ->
     profiles/valu_issue.json: SQ_INSTS_VALU, SQ_ACTIVE_INST_VALU, GRBM_GUI_ACTIVE per kernel, separate rocprofv3 --pmc
     runs of this command).  This -- not HBM bandwidth -- is the roof ComprehensiveFCParameters runs against (DESIGN.md
-    section 3.1): `ms_at_full_issue` = wave-instructions / (1024 SIMDs x 2.4 GHz / 4 cycles per wave64 instruction)."""
-    path = os.path.join(ROOT, "profiles", "valu_issue.json")
-    try:
-        doc = json.load(open(path))
-    except (OSError, ValueError):
-        return None
-    w = doc.get("workload", {})
-    if any(w.get(k) != cfg.get(k) for k in ("n_series_per_gpu", "length", "n_cols")):
-        return None
-    return doc.get("step")
+    section 3.1): `ms_at_full_issue` = sum over kernels of wave-instructions x the measured cycles per instruction of the
+    kernel's mix / (1024 SIMDs x the measured shader clock)."""
+    doc, stale = _replayed_counters("valu_issue.json", cfg)
+    return (doc.get("step") if doc else None), stale
 
 
 def physical_cores():
@@ -430,15 +444,21 @@ def main():
             notes = {"k_entropy_bits": "sorted ranges + bit-matrix sweep of all template pairs: VALU / LDS-issue bound, not "
                                        "HBM-bound (DESIGN.md roofline section)",
                      "k_entropy": "O(L^2) template-pair sweep: VALU(fp64)-bound, not HBM-bound (DESIGN.md roofline section)"}
+            wl = {"n_series_per_gpu": n, "length": L, "n_cols": n_cols}
+            traffic, stale_t = measured_hbm_traffic(kname, wl)
+            valu, stale_v = measured_valu_issue(wl)
             roof = {"bound": "hbm", "kernel": kname, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": achieved / HBM_PEAK_GBS,
-                    "traffic": measured_hbm_traffic(kname, {"n_series_per_gpu": n, "length": L, "n_cols": n_cols}),
+                    "traffic": traffic,
                     "traffic_source": "profiles/hbm_traffic.json (builder-measured: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE "
-                                      "passes of this command, profiles/pmc_hbm.sh; replayed, not re-measured in this run)",
+                                      "passes of this command, profiles/pmc_hbm.sh; replayed, not re-measured in this run; "
+                                      "refused when its lib_sha16 is not the loaded library's)",
+                    "lib_sha16": lib_sha16(),
+                    "stale": bool(stale_t or stale_v),
                     "kernel_ms": kt[dom],
                     "algorithmic_bytes_per_launch": alg_bytes,
                     "note": notes.get(kname, "compute-side bound: see DESIGN.md roofline section"),
-                    "valu": measured_valu_issue({"n_series_per_gpu": n, "length": L, "n_cols": n_cols})}
+                    "valu": valu}
         line = {
             "metric": "series/sec (ComprehensiveFCParameters, len=1024)" if args.params == "comprehensive" and L == 1024
                       else "series/sec (%s, %s)" % (args.params, ("ragged len %s" % args.ragged) if args.ragged else "len=%d" % L),

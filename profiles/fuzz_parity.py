@@ -109,9 +109,8 @@ def random_params(rng):
         "cwt_coefficients": lambda: (lambda ws: {"widths": ws, "coeff": ri(0, 40), "w": int(rng.choice(ws))})(
             tuple(sorted(set(int(v) for v in rng.integers(1, 24, size=ri(1, 4)))))),
     }
-    if os.environ.get("TSFA_ADF_AUTOLAG"):   # one lag selection per plan (registry.py: gated until its first device run)
-        al = [None, "AIC", "BIC", "t-stat"][ri(0, 3)]
-        gen["augmented_dickey_fuller"] = lambda: {"attr": str(rng.choice(["teststat", "pvalue", "usedlag"])), "autolag": al}
+    al = [None, "AIC", "BIC", "t-stat"][ri(0, 3)]   # one lag selection per plan (tsfa_validate_plan)
+    gen["augmented_dickey_fuller"] = lambda: {"attr": str(rng.choice(["teststat", "pvalue", "usedlag"])), "autolag": al}
     params = {}
     for nm, g in gen.items():
         if rng.random() < 0.45:

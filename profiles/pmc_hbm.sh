@@ -10,7 +10,8 @@ for c in FETCH_SIZE WRITE_SIZE; do
   timeout 600 rocprofv3 --pmc $c -d gpurun_out/hbm/$c -o p --output-format csv -- python bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-e2e > gpurun_out/hbm/$c.log 2>&1
 done
 python - <<'PY'
-import csv, glob, collections, json
+import csv, glob, collections, json, hashlib
+LIBSHA = hashlib.sha256(open('tsfresh_amd/libtsfresh_amd.so', 'rb').read()).hexdigest()[:16]
 out = collections.defaultdict(dict)
 for f in sorted(glob.glob("gpurun_out/hbm/*/*counter_collection.csv")):
     agg = collections.defaultdict(list)
@@ -25,6 +26,7 @@ for k, v in out.items():
 line = json.loads([l for l in open("gpurun_out/hbm/FETCH_SIZE.log") if l.startswith('{"metric"')][-1])
 doc = {"workload": line["config"], "units": "FETCH_SIZE / WRITE_SIZE means in KiB per launch as rocprofv3 reports them; "
        "hbm_bytes_per_launch = 2 * FETCH_SIZE + WRITE_SIZE in bytes (gfx950 read correction)", "kernels": out}
+doc["lib_sha16"] = LIBSHA   # bench.py replays this document only for the library it was measured on
 json.dump(doc, open("gpurun_out/hbm/traffic.json", "w"), indent=1)
 for k, v in out.items():
     print(k, {c: (round(x["mean"], 1) if isinstance(x, dict) else round(x / 1e6, 1)) for c, x in v.items()})

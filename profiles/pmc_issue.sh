@@ -11,7 +11,8 @@ for set in "GRBM_GUI_ACTIVE SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES" "SQ_INSTS_VA
   timeout 600 rocprofv3 --pmc $set -d gpurun_out/pmc_issue/p$i -o p --output-format csv -- python bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-e2e > gpurun_out/pmc_issue/p$i.log 2>&1
 done
 python - <<'PY'
-import csv, glob, collections, json
+import csv, glob, collections, json, hashlib
+LIBSHA = hashlib.sha256(open('tsfresh_amd/libtsfresh_amd.so', 'rb').read()).hexdigest()[:16]
 # one dict per kernel NAME and counter; every pass is aggregated by the kernel name of ITS OWN rows (round 2's table
 # printed k_sort's GRBM_GUI_ACTIVE in the k_trend row: the template arguments were cut at the first '<' of 'void k<..>')
 def kname(raw):
@@ -75,6 +76,7 @@ with open("gpurun_out/pmc_issue/summary.md", "w") as out:
                              "replayed, not re-measured in this run)"}
     out.write("\nstep: %.4g VALU wave-instructions, %.3f ms at full issue, time-weighted VALU busy %.3f\n" % (
         tot_insts, doc["step"]["ms_at_full_issue"], doc["step"]["busy"] or float("nan")))
+doc["lib_sha16"] = LIBSHA   # bench.py replays this document only for the library it was measured on
 json.dump(doc, open("gpurun_out/pmc_issue/valu_issue.json", "w"), indent=1)
 print(open("gpurun_out/pmc_issue/summary.md").read())
 PY

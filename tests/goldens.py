@@ -69,32 +69,5 @@ def check_engine(engine, pair, fc_parameters):
     got_names, got = engine(fc_parameters, g["values"], g["offsets"])
     skipped = []
     bad = compare(g["names"], align(g["names"], got_names, got), g["matrix"], g["series"], simd_golden=g["simd"],
-                  skipped=skipped)
-    bad = [b for b in bad if not _r4_under_the_reference_lapack(b, g, skipped)]
+                  skipped=skipped, ar_sv=g["ar_sv"] or None)
     return bad, skipped, g["matrix"].size
-
-
-def _r4_under_the_reference_lapack(line, g, skipped):
-    """tests/parity.py R4 for ar_coefficient -- "the rank the float64 singular values give at statsmodels' pinv cut (1e-15
-    s_max) differs from the rank of the same singular values computed accurately" -- asked of the singular values the
-    REFERENCE's interpreter computed (fixtures made with --params sweep store them, gen_golden_conda.py): for an exactly
-    rank-deficient design, whether LAPACK returns a non-existent direction above the cut differs between LAPACK builds
-    (a constant 1 000 000.25 x 1024, AR(5): the conda build inverts one and returns -0.116 / 1.44 for coefficients whose
-    minimum-norm value -- the oracle's, with this interpreter's LAPACK, and the kernels' -- is 0.2).  A property of the
-    series and of the reference's arithmetic, not of the value compared."""
-    import re
-
-    from parity import _ar_design, _singular_ratios_accurate
-    m = re.match(r"series (\d+) (\S*ar_coefficient__coeff_\d+__k_(\d+)):", line)
-    if not m or int(m.group(3)) not in g.get("ar_sv", {}):
-        return False
-    i, col, k = int(m.group(1)), m.group(2), int(m.group(3))
-    s_ref = g["ar_sv"][k][i]
-    X = _ar_design(np.asarray(g["series"][i], dtype=np.float64), k)
-    if X is None or not np.all(np.isfinite(s_ref)) or s_ref[0] <= 0:
-        return False
-    accurate = _singular_ratios_accurate(X)
-    if int(np.sum(s_ref / s_ref[0] > 1e-15)) == int(np.sum(accurate > 1e-15)):
-        return False
-    skipped.append((i, col))
-    return True

@@ -20,11 +20,6 @@ SKIP_BOUND = {"main": 0.05, "degenerate": 0.55, "offset": 0.07, "long": 0.0}
 MODES = ["BIC", "t-stat", None]
 
 
-@pytest.fixture(autouse=True)
-def _enable(monkeypatch):
-    monkeypatch.setenv("TSFA_ADF_AUTOLAG", "1")
-
-
 def _params(mode):
     return {"augmented_dickey_fuller": [{"attr": a, "autolag": mode} for a in ("teststat", "pvalue", "usedlag")]}
 
@@ -49,13 +44,32 @@ def test_engine_matches_statsmodels(engine, set_name, mode):
     _check(engine, set_name, mode)
 
 
-def test_the_default_is_still_a_refusal(monkeypatch):
+def test_every_lag_selection_compiles_by_default():
+    """Round 5: the selections other than "AIC" ran on the device (profiles/r05_a_pytest_new.log); no gate is left."""
     from tsfresh_amd.feature_extraction.plan import compile_fc_parameters
-    from tsfresh_amd.feature_extraction.registry import UnsupportedFeature
-    monkeypatch.delenv("TSFA_ADF_AUTOLAG")
-    with pytest.raises(UnsupportedFeature):
-        compile_fc_parameters(_params("BIC"))
+    for mode in MODES + ["AIC", "aic", "bic"]:
+        compile_fc_parameters(_params(mode))
     compile_fc_parameters({"augmented_dickey_fuller": [{"attr": "teststat", "autolag": "AIC"}, {"attr": "pvalue"}]})
+
+
+def test_autolag_values_statsmodels_rejects():
+    """A string statsmodels does not know -> ValueError inside adfuller -> fc.py:523 returns NaNs: a NaN column, also
+    BESIDE columns with a valid lag selection (round-4 ADVICE: it was refused as 'one autolag value per plan'); a
+    non-string (5) -> statsmodels' TypeError, which the reference does not catch."""
+    from tsfresh_amd.feature_extraction.plan import compile_fc_parameters
+    x = np.cumsum(np.random.default_rng(3).standard_normal(200))
+    params = {"augmented_dickey_fuller": [{"attr": "teststat", "autolag": "BIC"}, {"attr": "teststat", "autolag": "nonsense"},
+                                          {"attr": "usedlag", "autolag": "BIC"}, {"attr": "pvalue", "autolag": "None"}]}
+    names, got = emul_engine(params, x, np.array([0, 200], dtype=np.int64))
+    _, want = oracle_engine({"augmented_dickey_fuller": [{"attr": "teststat", "autolag": "BIC"}, {"attr": "usedlag", "autolag": "BIC"}]},
+                            x, np.array([0, 200], dtype=np.int64))
+    by = dict(zip(names, got[0]))
+    assert np.isnan(by['value__augmented_dickey_fuller__attr_"teststat"__autolag_"nonsense"'])
+    assert np.isnan(by['value__augmented_dickey_fuller__attr_"pvalue"__autolag_"None"'])
+    assert abs(by['value__augmented_dickey_fuller__attr_"teststat"__autolag_"BIC"'] - want[0, 0]) <= 1e-6 * abs(want[0, 0])
+    assert by['value__augmented_dickey_fuller__attr_"usedlag"__autolag_"BIC"'] == want[0, 1]
+    with pytest.raises(TypeError):
+        compile_fc_parameters({"augmented_dickey_fuller": [{"attr": "teststat", "autolag": 5}]})
 
 
 def test_one_autolag_value_per_plan():
@@ -66,10 +80,6 @@ def test_one_autolag_value_per_plan():
 
 
 @pytest.mark.gpu
-@pytest.mark.skipif(not os.environ.get("TSFA_TEST_NEW_ON_HARDWARE"),
-                    reason="written after round 4's GPU minutes were spent: oracle and emulation are green, the HIP path has not "
-                           "run these yet (set TSFA_TEST_NEW_ON_HARDWARE=1; drop this mark -- and the TSFA_ADF_AUTOLAG gate in "
-                           "registry.py -- once it has)")
 @pytest.mark.parametrize("mode", MODES, ids=[str(m) for m in MODES])
 @pytest.mark.parametrize("set_name", sorted(FILES))
 def test_hip_matches_statsmodels(gpu, set_name, mode):

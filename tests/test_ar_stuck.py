@@ -43,9 +43,6 @@ def test_stuck_sensor_designs_match_statsmodels(engine):
 
 
 @pytest.mark.gpu
-@pytest.mark.skipif(not os.environ.get("TSFA_TEST_NEW_ON_HARDWARE"),
-                    reason="written after round 4's GPU minutes were spent: oracle and emulation are green, the HIP path has not "
-                           "run these yet (set TSFA_TEST_NEW_ON_HARDWARE=1; drop this mark once it has)")
 def test_hip_stuck_sensor_designs_match_statsmodels(gpu):
     from engines import hip_engine
     _check(hip_engine)

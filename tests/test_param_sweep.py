@@ -56,9 +56,6 @@ def test_hip_matches_the_reference_on_other_parameters(gpu):
 
 
 @pytest.mark.gpu
-@pytest.mark.skipif(not os.environ.get("TSFA_TEST_NEW_ON_HARDWARE"),
-                    reason="written after round 4's GPU minutes were spent: oracle and emulation are green on these two sets, "
-                           "the HIP path has not run them yet (set TSFA_TEST_NEW_ON_HARDWARE=1; drop this mark once it has)")
 @pytest.mark.parametrize("pair", ["degenerate_sweep", "offset_sweep", "long_sweep"])
 def test_hip_second_passes_match_the_reference_on_other_parameters(gpu, pair):
     """k_ar_degenerate with AR orders 3 / 5 / 12, k_langevin_dd with five (m, r) fits in one plan; the long series."""
@@ -116,7 +113,6 @@ def test_from_columns_round_trips_every_name_of_the_sweep(monkeypatch):
     from param_cases import adf_autolag_parameters
     from tsfresh_amd.feature_extraction import settings
     from tsfresh_amd.feature_extraction.plan import compile_fc_parameters
-    monkeypatch.setenv("TSFA_ADF_AUTOLAG", "1")
     sets = [sweep_parameters()] + list(PERM_SETS.values())
     sets += [{"augmented_dickey_fuller": [p for p in adf_autolag_parameters()["augmented_dickey_fuller"] if p["autolag"] == al]}
              for al in ("BIC", "t-stat", None)]

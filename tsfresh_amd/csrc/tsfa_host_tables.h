@@ -289,7 +289,10 @@ static inline void tsfa_prepare_family_impl(int fam, std::vector<TsfaSpec> &spec
         for (const auto &s : specs) {
             if (s.calc == TSFA_C_AGG_AUTOCORRELATION && (int)s.p[1] > h.a) h.a = (int)s.p[1];
             if (s.calc == TSFA_C_PARTIAL_AUTOCORRELATION && (int)s.p[0] > h.b) h.b = (int)s.p[0];
-            if (s.calc == TSFA_C_AUGMENTED_DICKEY_FULLER) h.c = 1 + 2 * (int)s.p[1];   // bit 0: requested; bits 1-2: TSFA_AUTOLAG_* (tsfa_validate_plan: one per plan)
+            // bit 0: requested; bits 1-2: TSFA_AUTOLAG_* (tsfa_validate_plan: one per plan).  A column whose attr code is 3
+            // is NaN whatever the fit (an unknown attr, or an autolag value statsmodels rejects): it names no lag selection
+            if (s.calc == TSFA_C_AUGMENTED_DICKEY_FULLER && (int)s.p[0] != 3) h.c = 1 + 2 * (int)s.p[1];
+            if (s.calc == TSFA_C_AUGMENTED_DICKEY_FULLER && (int)s.p[0] == 3 && h.c == 0) h.c = 1;
         }
     }
     if (fam == TSFA_FAM_SORT) {
@@ -502,7 +505,7 @@ struct TsfaCwtBank {
 static inline std::string tsfa_validate_plan(const TsfaSpec *specs, int n) {
     int adf_mode = -1;
     for (int i = 0; i < n; ++i)
-        if (specs[i].calc == TSFA_C_AUGMENTED_DICKEY_FULLER) {
+        if (specs[i].calc == TSFA_C_AUGMENTED_DICKEY_FULLER && (int)specs[i].p[0] != 3) {   // code 3: a NaN column, no fit
             if (adf_mode >= 0 && (int)specs[i].p[1] != adf_mode)
                 return "augmented_dickey_fuller: one autolag value per plan (the kernels hold one fit per series)";
             adf_mode = (int)specs[i].p[1];

@@ -10,7 +10,6 @@ mapping becomes (a) the column-name suffix the reference would generate and (b) 
 The ORDER of this table is the definition order of the functions in the reference module, because
 ``ComprehensiveFCParameters`` lists the parameter-less calculators in that order (settings.py:157-163).
 """
-import os
 from collections import OrderedDict
 
 from tsfresh_amd.utilities.string_manipulation import convert_to_output_format
@@ -72,19 +71,19 @@ ADF_AUTOLAG = {"aic": 0.0, "bic": 1.0, "t-stat": 2.0}   # tsfa_specs.h TSFA_AUTO
 
 def _adf_encode(p):
     """fc.py:499-545 hands `autolag` to statsmodels.adfuller (case-insensitive "AIC" / "BIC" / "t-stat", or None).
-    Every settings object of the reference uses "AIC".  The other three selections are built (fam_ar.h, fam_ar_dd.h) and
-    green against statsmodels' own output in the emulation of the kernel sources (tests/test_adf_autolag.py), but were
-    written after round 4's GPU minutes were spent: until they have run on the device they answer only to
-    TSFA_ADF_AUTOLAG=1 -- the default stays the refusal it was."""
+    Every settings object of the reference uses "AIC"; the other three selections are served by the same kernels
+    (fam_ar.h, fam_ar_dd.h; one autolag value per plan) and pinned on statsmodels' own output on the device
+    (tests/test_adf_autolag.py, first device run: profiles/r05_a_pytest_new.log)."""
     autolag = p.get("autolag", "AIC")
-    mode = 3.0 if autolag is None else ADF_AUTOLAG.get(str(autolag).lower())
+    if autolag is not None and not isinstance(autolag, str):
+        # statsmodels.tools.validation.string_like raises TypeError, which fc.py:521-527 does not catch: it propagates
+        raise TypeError("autolag must be a string or None")
+    mode = 3.0 if autolag is None else ADF_AUTOLAG.get(autolag.lower())
     if mode is None:
-        # any other value (the STRING "None" that from_columns makes of autolag_"None" included): statsmodels raises
+        # any other string (the STRING "None" that from_columns makes of autolag_"None" included): statsmodels raises
         # ValueError, fc.py:523 turns that into (nan, nan, nan) -- a NaN column under the name the caller gave it
+        # (attr code 3 = "always NaN": exempt from the one-autolag-value-per-plan rule, tsfa_validate_plan)
         return (3.0, 0.0)
-    if mode != 0.0 and not os.environ.get("TSFA_ADF_AUTOLAG"):
-        raise UnsupportedFeature("augmented_dickey_fuller: only autolag='AIC' has a native kernel that has run on the device "
-                                 "(set TSFA_ADF_AUTOLAG=1 for 'BIC' / 't-stat' / None)")
     return (_code(ATTR_ADF, p["attr"], "augmented_dickey_fuller attr") if p["attr"] in ATTR_ADF else 3.0, mode)
 
 
