@@ -187,6 +187,159 @@ TSFA_DEV void cwt_rows_tiled(const Blk &b, XA xat, int n, int W, const CwtPeaksL
     }
 }
 
+#if TSFA_GPU && !defined(TSFA_LONG)
+// ---- phase A on the matrix cores (v_mfma_f64_16x16x4_f64): the contraction BASELINE.json's north_star names ----
+// The Ricker convolution of one width, out[c] = sum_t taps_w[t] x[c - 5 w + t] (t < 10 w), is a GEMM once the output
+// OFFSET inside a block of 16 goes on N:  c = 16 i + j,
+//     out[16 i + j] = sum_k' A[i][k'] B_w[k'][j],   A[i][k'] = x[16 i + k' - 5 w]   (overlapping rows of the padded LDS copy)
+//                                                   B_w[k'][j] = taps_w[k' - j]     (banded Toeplitz, zero outside the taps)
+// k' < 10 w + 15, in steps of 4: (10 w + 18) / 4 MFMAs per tile of 16 x 16 = 256 consecutive outputs -- 59 per tile for widths
+// 1..5, 64 % of the multiply-adds useful (padding the five widths to N = 16 would waste 3 x).  A wavefront owns whole
+// (tile, width) items; the accumulator layout D[i = 4 v + (lane >> 4)][j = lane & 15] puts output 256 tile + 64 v + lane into
+// register v of a lane, so the strict-maximum test reads its neighbours with wave-shift DPP moves and only the first / last
+// output of a tile travel through LDS (`edge`, as in the register-tiled form).  The float64 matrix pipe has the VALU's own
+// multiply-add rate on gfx950 (64 cycles per 16x16x4 = 16 MAC / cycle / SIMD: SQ_VALU_MFMA_BUSY_CYCLES of k_cwt_gemm); what
+// it buys is ISSUE: one instruction per 1024 multiply-adds in a kernel that is VALU-issue bound, on a pipe that runs beside
+// the other workgroups' ridge-line phases.  The summation order differs from np.convolve's (as the FMA tiles' did): a pair
+// of neighbours equal to 1e-12 is R8's business (tests/parity.py).
+typedef double cwt_d4 __attribute__((ext_vector_type(4)));
+#define TSFA_CWTM_TBL(w) (10 * (w) + 33)   /* band table of a width: [15 zeros][10 w taps][18 zeros] */
+
+// can phase A of a series of n samples, widths 1..W, run here?  (full 10 w taps for every width, the widest band table in
+// the colmap | mline block, two or more K steps)
+TSFA_DEV bool cwt_mfma_fits(int n, int W) { return W <= TSFA_CWTP_MAXW && 10 * W < n && 2 * TSFA_CWTM_TBL(W) <= n && 16 * ((n + 255) >> 8) <= (n >> 1); }
+
+template <int CTRL>
+TSFA_DEV double dpp_mov_old_f64(double old, double v) {   // lanes the DPP pattern gives no source keep `old`
+    union { double d; int i[2]; } a, o, r;
+    a.d = v;
+    o.d = old;
+    r.i[0] = __builtin_amdgcn_update_dpp(o.i[0], a.i[0], CTRL, 0xf, 0xf, false);
+    r.i[1] = __builtin_amdgcn_update_dpp(o.i[1], a.i[1], CTRL, 0xf, 0xf, false);
+    return r.d;
+}
+
+// One (tile, width) item: ksteps MFMAs over two accumulator chains (even / odd K steps: a dependent MFMA would wait out the
+// pipe's latency).  KS > 0: the step count as a constant -- the loop unrolls, the LDS operands sit at immediate offsets and
+// the scheduler hoists the reads over the matrix instructions; KS == 0: any width, operands of the NEXT pair fetched before
+// the current pair issues.
+template <class ST, int KS>
+TSFA_DEV void cwt_mfma_item(const ST *xa, const double *tb, int ksteps, cwt_d4 &acc0, cwt_d4 &acc1) {
+    acc0 = (cwt_d4){0.0, 0.0, 0.0, 0.0};
+    acc1 = (cwt_d4){0.0, 0.0, 0.0, 0.0};
+    if (KS > 0) {
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            const double a = (double)xa[4 * ks], bv = tb[4 * ks];
+            if (ks & 1) acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(a, bv, acc1, 0, 0, 0);
+            else acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(a, bv, acc0, 0, 0, 0);
+        }
+    } else {
+        double a0 = (double)xa[0], a1 = (double)xa[4], b0 = tb[0], b1 = tb[4];
+        int ks = 0;
+        for (; ks + 4 <= ksteps; ks += 2) {
+            const double na0 = (double)xa[4 * ks + 8], na1 = (double)xa[4 * ks + 12], nb0 = tb[4 * ks + 8], nb1 = tb[4 * ks + 12];
+            acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b0, acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b1, acc1, 0, 0, 0);
+            a0 = na0; a1 = na1; b0 = nb0; b1 = nb1;
+        }
+        acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b0, acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b1, acc1, 0, 0, 0);
+        ks += 2;
+        if (ks < ksteps) acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64((double)xa[4 * ks], tb[4 * ks], acc0, 0, 0, 0);
+    }
+}
+
+template <class ST>
+TSFA_DEV void cwt_rows_mfma(const Blk &b, const ST *xpad, int n, int W, const CwtPeaksLds &L) {
+    const int lane = b.tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(b.tid >> 6), nwaves = (b.nt + 63) >> 6;   // scalar: the item loop is SALU
+    const int r = lane & 15, kq = lane >> 4;
+    const int ntiles = (n + 255) >> 8, nchunks = 4 * ntiles;   // a chunk = 64 consecutive outputs = one accumulator register
+    double *tbl = (double *)L.colmap;          // colmap | mline: 4 n bytes, re-zeroed below
+    const int tbl_cap = n >> 1;
+    double *edge = (double *)L.lcol;           // lcol | linf: edge[2 e] / edge[2 e + 1] = first / last output of chunk e
+    unsigned *maskw = (unsigned *)L.mask;
+    const int xlast = n + 2 * TSFA_CWTP_HALO + 7;   // last initialised (zero) entry of the padded copy
+    const double ninf = -TSFA_INF;
+    int w0 = 1;
+    while (w0 <= W) {
+        int w1 = w0, used = 0;
+        while (w1 <= W && used + TSFA_CWTM_TBL(w1) <= tbl_cap && 2 * (w1 - w0 + 1) * nchunks <= tbl_cap) { used += TSFA_CWTM_TBL(w1); ++w1; }
+        const int gw = w1 - w0;   // >= 1 by cwt_mfma_fits
+        {   // the band tables of the group, one pass over their concatenation
+            int w = w0, base = 0;
+            for (int q0 = 0; q0 < used; q0 += b.nt) {
+                const int q = q0 + b.tid;
+                while (w < w1 - 1 && q0 >= base + TSFA_CWTM_TBL(w)) { base += TSFA_CWTM_TBL(w); ++w; }   // uniform lower bound
+                int wq = w, bq = base;
+                while (wq < w1 - 1 && q >= bq + TSFA_CWTM_TBL(wq)) { bq += TSFA_CWTM_TBL(wq); ++wq; }
+                const int t = q - bq - 15;
+                if (q < used) tbl[q] = (t >= 0 && t < 10 * wq) ? L.rk[5 * wq * (wq - 1) + t] : 0.0;
+            }
+        }
+        blk_sync();
+        int k = 0, pass = 0;   // item p = (wi, tile) -> wave (pass odd ? nwaves - 1 - k : k), k = p mod nwaves: snake order
+        for (int wi = 0; wi < gw; ++wi) {
+            const int w = w1 - 1 - wi;   // the widest widths go out first
+            const int toff = 5 * (w * (w - 1) - w0 * (w0 - 1)) + 33 * (w - w0);
+            const int ksteps = (10 * w + 18) >> 2;
+            const unsigned bit = 1u << (w - 1);
+            for (int tile = 0; tile < ntiles; ++tile) {
+                const int owner = pass ? nwaves - 1 - k : k;
+                if (++k == nwaves) { k = 0; pass ^= 1; }
+                if (owner != wave) continue;
+                const double *tb = tbl + toff + (kq - r + 15);
+                // rows of a tile hanging over the end of the series would read past the padded copy: every output of such a
+                // row lies beyond n (16 i > n + 72), so the row reads the head of the buffer instead -- finite, never used
+                int xi0 = TSFA_CWTP_HALO + 16 * (16 * tile + r) + kq - 5 * w;
+                xi0 = (xi0 + 4 * (ksteps - 1) <= xlast) ? xi0 : 0;
+                const ST *xa = xpad + xi0;
+                cwt_d4 acc0, acc1;
+                switch (ksteps) {   // widths 1 .. 5 (the settings objects): K loop unrolled, operands at immediate offsets
+                case 7: cwt_mfma_item<ST, 7>(xa, tb, 7, acc0, acc1); break;
+                case 9: cwt_mfma_item<ST, 9>(xa, tb, 9, acc0, acc1); break;
+                case 12: cwt_mfma_item<ST, 12>(xa, tb, 12, acc0, acc1); break;
+                case 14: cwt_mfma_item<ST, 14>(xa, tb, 14, acc0, acc1); break;
+                case 17: cwt_mfma_item<ST, 17>(xa, tb, 17, acc0, acc1); break;
+                default: cwt_mfma_item<ST, 0>(xa, tb, ksteps, acc0, acc1); break;
+                }
+                const int e0 = 2 * (wi * nchunks + 4 * tile);
+#pragma unroll
+                for (int v = 0; v < 4; ++v) {
+                    const double o = acc0[v] + acc1[v];
+                    const int c = 256 * tile + 64 * v + lane;
+                    // the neighbours inside the chunk by wave shifts; lane 0 / lane 63 see -inf (the bit is set on the lane's
+                    // own evidence and withdrawn below against the neighbouring chunk's edge value)
+                    const double left = dpp_mov_old_f64<0x138 /* wave_shr:1 */>(ninf, o);
+                    const double right = dpp_mov_old_f64<0x130 /* wave_shl:1 */>(ninf, o);
+                    if (lane == 0) edge[e0 + 2 * v] = o;
+                    if (lane == 63) edge[e0 + 2 * v + 1] = o;
+                    // _boolrelextrema(order=1, mode="clip"): strict, never at the ends
+                    if (c >= 1 && c < n - 1 && o > left && o > right) atomicOr(&maskw[c >> 1], bit << ((c & 1) * 16));
+                    if (w == 1 && c < n) L.row0[c] = o;
+                }
+            }
+        }
+        blk_sync();
+        // the chunk boundaries: column 64 q - 1 (last of chunk q - 1) against column 64 q (first of chunk q)
+        for (int q = b.tid; q < gw * nchunks; q += b.nt) {
+            const int wi = q / nchunks, ch = q - wi * nchunks;
+            if (ch == 0) continue;
+            const unsigned bit = 1u << (w1 - 2 - wi);   // width w1 - 1 - wi
+            const double lastp = edge[2 * (q - 1) + 1], first = edge[2 * q];
+            const int c = 64 * ch;
+            if (!(first > lastp)) atomicAnd(&maskw[c >> 1], ~(bit << ((c & 1) * 16)));
+            if (!(lastp > first)) atomicAnd(&maskw[(c - 1) >> 1], ~(bit << (((c - 1) & 1) * 16)));
+        }
+        blk_sync();
+        w0 = w1;
+    }
+    for (int c = b.tid; c < n; c += b.nt) { L.colmap[c] = 0; L.mline[c] = 0; }
+    blk_sync();
+}
+#endif
+
 // Length / signal-to-noise filter of scipy.signal._peak_finding._filter_ridge_lines over a list of ridge-line end points:
 // entry k = (cols[k], rows ? rows[k] : 0).  signal = cwt[row, col], noise = the 10th percentile
 // (scipy.stats.scoreatpercentile) of |...| row 0 in the window [col - hf, col + hf + odd) clipped to the series.
@@ -303,7 +456,7 @@ TSFA_DEV double cwt_filter_list(const Blk &b, X xv, int n, const CwtPeaksLds &L,
 
 // ST: element type of the padded LDS copy of the series (the input precision: float32 samples stay float32)
 // derive_w1 / kept_w1: also return number_cwt_peaks(n = 1) of the same series (phase C), W <= 14
-template <class ST, class X>
+template <class ST, bool MFMA = false, class X>
 TSFA_DEV double number_cwt_peaks_one(const Blk &b, X xv, int n, int W, const CwtPeaksLds &L, bool derive_w1 = false,
                                      double *kept_w1 = nullptr) {
     const int cap = n;  // line capacity
@@ -315,11 +468,22 @@ TSFA_DEV double number_cwt_peaks_one(const Blk &b, X xv, int n, int W, const Cwt
     if (L.xpad != nullptr) {
         blk_sync();
         ST *xpad = (ST *)L.xpad;
+        bool finite = true;
         for (int i = b.tid; i < n + 2 * TSFA_CWTP_HALO + 8; i += b.nt) {
             const int j = i - TSFA_CWTP_HALO;
-            xpad[i] = (j >= 0 && j < n) ? (ST)xv(j) : (ST)0;
+            const ST v = (j >= 0 && j < n) ? (ST)xv(j) : (ST)0;
+            xpad[i] = v;
+            if (MFMA) finite = finite && (fabs((double)v) < TSFA_INF);
         }
         const ST *xp0 = xpad + TSFA_CWTP_HALO;
+        (void)finite;
+#if TSFA_GPU && !defined(TSFA_LONG)
+        // the opt-in instantiation (TSFA_CWT_MFMA=1; measured slower): a non-finite sample would poison
+        // the 15 other outputs of its MFMA row (inf x 0), those series keep the tiles
+        if (MFMA && L.rk != nullptr && cwt_mfma_fits(n, W) && !__syncthreads_or(finite ? 0 : 1))
+            cwt_rows_mfma<ST>(b, xpad, n, W, L);
+        else
+#endif
         cwt_rows_tiled(b, [=](int i) { return (double)xp0[i]; }, n, W, L);
     } else {  // no room for the padded copy (very long series): the same tiles, samples straight from HBM / L2
         cwt_rows_tiled(b, [=](int i) { return (i >= 0 && i < n) ? xv(i) : 0.0; }, n, W, L);
@@ -537,7 +701,7 @@ TSFA_DEV double number_cwt_peaks_one(const Blk &b, X xv, int n, int W, const Cwt
     return overflow ? TSFA_NAN : kept;
 }
 
-template <class ST, class X>
+template <class ST, bool MFMA = false, class X>
 TSFA_DEV void fam_cwtpeaks_series(const Blk &b, X xv, int n, const TsfaSpec *specs, int nspecs, double *out_row,
                                   const CwtPeaksLds &L) {
     // n = 1 rides along with the widest other width of the plan (<= 14): its ridge lines are the maxima of row 0, which
@@ -557,14 +721,14 @@ TSFA_DEV void fam_cwtpeaks_series(const Blk &b, X xv, int n, const TsfaSpec *spe
         if (fuse && s == s_w1) continue;
         if (fuse && s == s_host) {
             double k1 = 0.0;
-            const double v = number_cwt_peaks_one<ST>(b, xv, n, (int)sp.p[0], L, true, &k1);
+            const double v = number_cwt_peaks_one<ST, MFMA>(b, xv, n, (int)sp.p[0], L, true, &k1);
             if (b.tid == 0) {
                 out_row[sp.col] = v;
                 out_row[specs[s_w1].col] = k1;
             }
             continue;
         }
-        const double v = number_cwt_peaks_one<ST>(b, xv, n, (int)sp.p[0], L);
+        const double v = number_cwt_peaks_one<ST, MFMA>(b, xv, n, (int)sp.p[0], L);
         if (b.tid == 0) out_row[sp.col] = v;
     }
 }

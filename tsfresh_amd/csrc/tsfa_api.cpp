@@ -586,6 +586,9 @@ static int run_batch(tsfa_plan *plan, const void *d_values, int dtype, const dou
             } else if (f == TSFA_FAM_CWT) {
                 a.cwt_rowv = tsfa_family_lds_bytes(f, maxn, a.nt, 1) <= 96 * 1024 ? 1 : 0;
                 aux = a.cwt_rowv;
+                // bit 1: the Ricker convolutions on the float64 matrix cores (opt-in: measured 4 % slower than the FMA tiles,
+                // DESIGN.md section 9; tests/test_cwt_peaks_mfma.py compares both forms)
+                if (getenv("TSFA_CWT_MFMA") && atoi(getenv("TSFA_CWT_MFMA"))) a.cwt_rowv |= 2;
             } else if (f == TSFA_FAM_AR) {
                 // leading dimension of the normal matrices: ADF needs maxlag(n) + 3, AR(k) needs k + 2
                 int P = 8;
@@ -676,7 +679,7 @@ static int run_batch(tsfa_plan *plan, const void *d_values, int dtype, const dou
             if (use_long) {
                 a.nt = 256;
                 if (f == TSFA_FAM_ENTROPY) { a.ent_cnt = 0; a.ent_fast = 0; lds = tsfa_entropy_lds_bytes(maxn, 0); }
-                if (f == TSFA_FAM_CWT) { a.cwt_rowv = 0; lds = tsfa_family_lds_bytes(f, maxn, a.nt, 0); }
+                if (f == TSFA_FAM_CWT) { a.cwt_rowv &= 2; lds = tsfa_family_lds_bytes(f, maxn, a.nt, 0); }
                 if (f == TSFA_FAM_SEQ) {
                     seq_group = std::min(a.nspecs, TSFA_LZ_MAX_GROUP);
                     lds = 0;

@@ -383,7 +383,8 @@ __global__ void __launch_bounds__(256) k_seq(const T *__restrict__ values, const
 }
 
 // MAXT: 256 for series up to 2048 samples (register allocation for 4-wave workgroups), 1024 beyond
-template <typename T, int MAXT>
+// MFMA: phase A on the float64 matrix cores (fam_cwt.h cwt_rows_mfma), the opt-in instantiation of TSFA_CWT_MFMA=1
+template <typename T, int MAXT, bool MFMA>
 __global__ void __launch_bounds__(MAXT, (MAXT == 256) ? 6 : 4) k_cwtpeaks(const T *__restrict__ values, const int64_t *__restrict__ starts, const int64_t *__restrict__ ends, int64_t n_series, const int *__restrict__ sel,
                            const TsfaSpec *__restrict__ specs, int nspecs, double *__restrict__ out, int64_t ld,
                            int maxn, int with_rowv, const double *__restrict__ consts TSFA_GS_PARAMS) {
@@ -391,12 +392,12 @@ __global__ void __launch_bounds__(MAXT, (MAXT == 256) ? 6 : 4) k_cwtpeaks(const 
     const int64_t off = starts[sidx];
     const int n = (int)(ends[sidx] - off);
     CwtPeaksLayout L;
-    L.carve(tsfa_base, maxn, with_rowv, (int)sizeof(T));
+    L.carve(tsfa_base, maxn, with_rowv & 1, (int)sizeof(T));
     L.p.rk = consts ? consts + TSFA_CONSTS_RICKER : nullptr;
     TSFA_TICKS_BEGIN();
     Blk b{(int)threadIdx.x, (int)blockDim.x, L.p.red, nullptr};
     const T *g = values + off;
-    fam_cwtpeaks_series<T>(b, [=](int i) { return (double)g[i]; }, n, specs, nspecs, out + sidx * ld, L.p);
+    fam_cwtpeaks_series<T, MFMA>(b, [=](int i) { return (double)g[i]; }, n, specs, nspecs, out + sidx * ld, L.p);
     TSFA_TICKS_END();
     TSFA_SERIES_END
 }
@@ -996,12 +997,23 @@ static int launch_all_t(const TsfaLaunch &a, const T *values) {
         TSFA_KLAUNCH(k_seq<T>, lds, values, a.starts, a.ends, a.n_series, a.sel, a.out, a.ld, a.seq, a.stats_in);
     } else if (a.fam == TSFA_FAM_CWT) {  // number_cwt_peaks
         CwtPeaksLayout L;
-        const size_t lds = L.carve(nullptr, a.maxn, a.cwt_rowv, (int)sizeof(T));
+        const size_t lds = L.carve(nullptr, a.maxn, a.cwt_rowv & 1, (int)sizeof(T));
+#if !defined(TSFA_LONG)
+        if (a.cwt_rowv & 2) {   // TSFA_CWT_MFMA=1
+            if (nt <= 256) {
+                auto kfn = k_cwtpeaks<T, 256, true>;
+                TSFA_KLAUNCH(kfn, lds, values, a.starts, a.ends, a.n_series, a.sel, a.specs, a.nspecs, a.out, a.ld, a.maxn, a.cwt_rowv, a.consts);
+            } else {
+                auto kfn = k_cwtpeaks<T, 1024, true>;
+                TSFA_KLAUNCH(kfn, lds, values, a.starts, a.ends, a.n_series, a.sel, a.specs, a.nspecs, a.out, a.ld, a.maxn, a.cwt_rowv, a.consts);
+            }
+        } else
+#endif
         if (nt <= 256) {
-            auto kfn = k_cwtpeaks<T, 256>;
+            auto kfn = k_cwtpeaks<T, 256, false>;
             TSFA_KLAUNCH(kfn, lds, values, a.starts, a.ends, a.n_series, a.sel, a.specs, a.nspecs, a.out, a.ld, a.maxn, a.cwt_rowv, a.consts);
         } else {
-            auto kfn = k_cwtpeaks<T, 1024>;
+            auto kfn = k_cwtpeaks<T, 1024, false>;
             TSFA_KLAUNCH(kfn, lds, values, a.starts, a.ends, a.n_series, a.sel, a.specs, a.nspecs, a.out, a.ld, a.maxn, a.cwt_rowv, a.consts);
         }
     } else {

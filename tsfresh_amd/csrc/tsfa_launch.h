@@ -63,7 +63,7 @@ struct TsfaLaunch {
     int pf_cap;             // ... and the records the buffer holds (n_series x distinct (m, r) fits, hints[SORT].e)
     unsigned short *perm_buf;  // ENTROPY (bit-matrix sweep) writes / SORT reads: sample order of every series, perm_stride entries each
     int perm_stride;
-    int cwt_rowv;           // CWT peaks: second CWT row resident in LDS
+    int cwt_rowv;           // CWT peaks: bit 0: the series is staged in LDS between zero halos; bit 1: phase A on the matrix cores (TSFA_CWT_MFMA=1)
     int hint_a, hint_b, hint_c, hint_d, hint_e;  // tsfa_prepare_family (BASIC, SORT, SPECTRAL, AR)
     unsigned char *long_scratch;  // HBM scratch of the long-series build (tsfa_launch_family_long) ...
     size_t long_bytes;            // ... and its size: slots of one working set each, one per resident workgroup
