@@ -255,6 +255,9 @@ def main():
                     "sweep) see long runs and smooth ridges")
     ap.add_argument("--offset", type=float, default=0.0, help="add OFFSET to every sample (|mean| >> spread: the "
                     "double-double second passes of the Langevin fit and of AR / ADF take every series)")
+    ap.add_argument("--strong", action="store_true",
+                    help="strong scaling: --n-series is the TOTAL of the job, split evenly over the N ranks (configs[3]: "
+                         "`--strong --n-series 1000000 --length 256 --gpus N`); the default is weak (series per GPU fixed)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-baseline-full", action="store_true",
                     help="three runs of the CPU protocol (median) and the reference's default n_jobs = cpu_count() // 2 as a "
@@ -312,6 +315,10 @@ def main():
     # BASELINE.md 3.4's recipe: np.random.default_rng(seed).standard_normal((n, L), dtype=float32), seed = 42 (+ rank:
     # every rank its own shard), drawn on the host and copied to the device BEFORE the clock
     n, L = args.n_series, args.length
+    if args.strong:
+        if args.n_series % world:
+            raise SystemExit("bench.py --strong: --n-series %d is not a multiple of the %d ranks" % (args.n_series, world))
+        n = args.n_series // world
     rng = np.random.default_rng(42 + rank)
     if args.ragged:
         lo, hi = (int(t) for t in args.ragged.split(":"))
@@ -463,7 +470,7 @@ def main():
             "metric": "series/sec (ComprehensiveFCParameters, len=1024)" if args.params == "comprehensive" and L == 1024
                       else "series/sec (%s, %s)" % (args.params, ("ragged len %s" % args.ragged) if args.ragged else "len=%d" % L),
             "value": value, "unit": "series/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "strong" if args.strong else "weak", "vs_baseline": None,
             "dtype": "f64", "data": "synthetic",
             "config": {"workload": "%d series/GPU x len %d float32 %s%s, %sFCParameters (%d columns), "
                                    "inputs and outputs resident in HBM%s" % (

@@ -1,0 +1,61 @@
+"""Worker of tests/test_distributed_rccl.py: one rank on one GPU, backend "nccl" (= RCCL).  Runs the point-to-point form
+of tsfresh_amd.distributed.exchange_rows -- the form ranks with shards of UNEQUAL height use -- through RCCL's self send /
+receive, for every chunk of a chunked extraction, and checks the bytes."""
+import json
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+from tsfresh_amd import _native  # noqa: E402
+from tsfresh_amd.distributed import chunk_cuts, exchange_rows, finish_exchange  # noqa: E402
+from tsfresh_amd.feature_extraction.plan import compile_fc_parameters  # noqa: E402
+from tsfresh_amd.feature_extraction.settings import EfficientFCParameters  # noqa: E402
+
+
+def main():
+    dev = torch.device("cuda", int(os.environ.get("LOCAL_RANK", "0")))
+    torch.cuda.set_device(dev)
+    dist.init_process_group(backend="nccl", device_id=dev)
+    assert dist.get_world_size() == 1
+    import warnings
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        fplan = compile_fc_parameters(EfficientFCParameters())
+    n_cols = len(fplan)
+    rng = np.random.default_rng(3)
+    lens = rng.integers(40, 300, size=301)            # ragged shard, a height no chunk count divides
+    offsets = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
+    values = torch.from_numpy(rng.standard_normal(int(offsets[-1])).astype(np.float32)).to(dev)
+    d_off = torch.from_numpy(offsets).to(dev)
+    n = len(lens)
+    plan = _native.Plan(fplan.native_specs(_native.calc_id), device=dev.index)
+    full = torch.full((n, n_cols), -7.0, device=dev, dtype=torch.float64)
+    mirror = torch.full((n, n_cols), -9.0, device=dev, dtype=torch.float64)   # receives every chunk through RCCL
+    cuts = chunk_cuts(n, 5)
+    handles = []
+    stream = torch.cuda.current_stream(dev)
+    for c in range(5):
+        lo, hi = cuts[c], cuts[c + 1]
+        plan.extract_device(values.data_ptr(), _native.TSFA_F32, d_off.data_ptr() + 8 * lo, hi - lo,
+                            full.data_ptr() + 8 * n_cols * lo, n_cols, stream.cuda_stream)
+        handles.append(exchange_rows(full, [0, n], 0, [(lo, hi)], dist, None, loopback=mirror[lo:hi]))
+    for hs in handles:
+        assert hs, "the loopback exchange must issue work"
+        finish_exchange(full, [0, n], 0, hs)
+    torch.cuda.synchronize(dev)
+    same = bool(torch.equal(torch.nan_to_num(full, nan=123.0), torch.nan_to_num(mirror, nan=123.0)))
+    untouched = bool((full == -7.0).any().item())
+    print(json.dumps({"same": same, "untouched_cells": untouched, "rows": n, "cols": n_cols,
+                      "rccl": ".".join(str(v) for v in torch.cuda.nccl.version())}))
+    plan.close()
+    dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

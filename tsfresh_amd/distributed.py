@@ -47,8 +47,13 @@ def chunk_cuts(n_rows, n_chunks):
     return [int(n_rows) * c // n_chunks for c in range(n_chunks + 1)]
 
 
-def exchange_rows(full, starts, rank, lo_hi, dist, stage=None):
+def exchange_rows(full, starts, rank, lo_hi, dist, stage=None, loopback=None):
     """Exchange one row chunk of every rank's slice of `full` (torch tensor [sum(counts), n_cols], rank-major).
+
+    loopback: test hook for a box with one GPU -- this rank's own rows ALSO travel through the grouped isend / irecv form,
+    from `mine` to `loopback[: rows]` over RCCL's self send / receive, so the point-to-point path (row slices of a larger
+    tensor as P2POp buffers, batch_isend_irecv, the wait in finish_exchange) executes at a world size of one
+    (tests/test_distributed_rccl.py).
 
     lo_hi[r] = (lo, hi): the rows of rank r's shard that belong to this chunk (shard-relative).  This rank's own rows
     must already be in place (or enqueued on the current stream).  Returns the list of async work handles; the caller
@@ -57,6 +62,9 @@ def exchange_rows(full, starts, rank, lo_hi, dist, stage=None):
     world = dist.get_world_size()
     heights = [hi - lo for lo, hi in lo_hi]
     mine = full[starts[rank] + lo_hi[rank][0]: starts[rank] + lo_hi[rank][1]]
+    if loopback is not None and heights[rank] > 0:
+        ops = [dist.P2POp(dist.isend, mine, rank), dist.P2POp(dist.irecv, loopback[: heights[rank]], rank)]
+        return [("p2p", w, None, None) for w in dist.batch_isend_irecv(ops)]
     if world == 1:
         return []
     if stage is not None and len(set(heights)) == 1:
