@@ -124,8 +124,15 @@ def random_params(rng):
     return params or {"quantile": [{"q": 0.5}]}
 
 
+SENTINEL = 123456.789
+
+
 def main():
     rounds = int(sys.argv[1]) if len(sys.argv) > 1 else 12
+    # every plan of the fuzz pre-fills the matrix with a sentinel (read when the plan is built): a cell no kernel wrote
+    # shows up as SENTINEL instead of a stale value of an earlier round (round-4 ADVICE)
+    if os.environ.get("TSFA_FUZZ_ENGINE") != "emul":
+        os.environ.setdefault("TSFA_DEBUG_FILL", repr(SENTINEL))
     rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
     full = settings.ComprehensiveFCParameters()
     names_all = list(full.keys())
@@ -160,6 +167,10 @@ def main():
                 print("round", r, "skipped: the oracle raises as the reference does:", str(e)[:80])
                 continue
         assert names == names_o, (names[:3], names_o[:3])
+        unwritten = np.argwhere(got == SENTINEL)
+        if len(unwritten):
+            total_bad += len(unwritten)
+            print("round", r, "UNWRITTEN CELLS", [(int(i), names[int(j)]) for i, j in unwritten[:6]])
         bad = compare(names, got, want, [values[offsets[i]:offsets[i + 1]].astype(np.float64) for i in range(len(series))])
         total_bad += len(bad)
         dump = os.environ.get("TSFA_FUZZ_DUMP")   # directory: the offending series as .npy, for adjudication

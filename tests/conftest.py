@@ -29,6 +29,43 @@ def gpu():
     return True
 
 
+SENTINEL = 123456.789   # profiles/fill_audit.py uses the same value
+
+
+@pytest.fixture(scope="session", autouse=True)
+def _sentinel_audit_of_every_gpu_extraction():
+    """The feature matrix is not pre-filled: a kernel path that skipped a cell would hand back whatever
+    the buffer held.  On a box with a GPU EVERY plan the tests create pre-fills with a sentinel (TSFA_DEBUG_FILL, read
+    when a plan is built) and every host-side result is checked for it -- the parameter sweep, the fuzz-style batches, rolled
+    windows, the long-series build and the second passes included (round-4 ADVICE: the audit covered three parameter
+    sets).  TSFA_TEST_NO_SENTINEL=1 switches it off; TSFA_DEBUG_SKIP_FAM (the audit's positive control) suspends the check."""
+    if os.environ.get("TSFA_TEST_NO_SENTINEL") or not _have_gpu():
+        yield
+        return
+    from tsfresh_amd import _native
+    os.environ["TSFA_DEBUG_FILL"] = repr(SENTINEL)
+    originals = {}
+
+    def checked(name):
+        fn = getattr(_native.Plan, name)
+        originals[name] = fn
+
+        def wrapper(self, *a, **k):
+            out = fn(self, *a, **k)
+            if out is not None and not os.environ.get("TSFA_DEBUG_SKIP_FAM") and os.environ.get("TSFA_DEBUG_FILL"):
+                import numpy as np
+                kept = np.argwhere(np.asarray(out) == SENTINEL)
+                assert len(kept) == 0, "%d cells were written by no kernel, first (row, column): %s" % (len(kept), kept[:5].tolist())
+            return out
+        setattr(_native.Plan, name, wrapper)
+    for name in ("extract_host", "extract_windows_host"):
+        checked(name)
+    yield
+    for name, fn in originals.items():
+        setattr(_native.Plan, name, fn)
+    os.environ.pop("TSFA_DEBUG_FILL", None)
+
+
 def pytest_sessionfinish(session, exitstatus):
     """TSFA_PARITY_SKIPS_MD=<file>: per test, the cells tests/parity.py excluded, by calculator."""
     path = os.environ.get("TSFA_PARITY_SKIPS_MD")

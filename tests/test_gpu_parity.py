@@ -860,6 +860,7 @@ def test_every_cell_is_written_by_a_kernel(gpu, monkeypatch):
     1 .. 4097 (the API rejects empty series), Comprehensive + a stress set of parameters + Minimal, float32 / float64, iid / walk / constant / zero /
     non-finite series: no cell may keep the sentinel; and the control -- a family whose launch is skipped keeps it."""
     import importlib.util
+    before = os.environ.get("TSFA_DEBUG_FILL")   # tests/conftest.py runs the whole gpu session with the same sentinel
     spec = importlib.util.spec_from_file_location("fill_audit", os.path.join(ROOT, "profiles", "fill_audit.py"))
     fa = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(fa)          # sets TSFA_DEBUG_FILL for the plans it creates
@@ -870,6 +871,8 @@ def test_every_cell_is_written_by_a_kernel(gpu, monkeypatch):
         assert not kept, kept
     finally:
         os.environ.pop("TSFA_DEBUG_FILL", None)
+        if before is not None:
+            os.environ["TSFA_DEBUG_FILL"] = before
 
 
 @pytest.mark.gpu
