@@ -201,8 +201,15 @@ def test_long_series_with_entropy_columns_warn_about_their_run_time(emul_plans):
     from tsfresh_amd.feature_extraction import extraction
     n = extraction.ENTROPY_FAST_MAX_LEN + 1
     df = pd.DataFrame({"id": 0, "time": np.arange(n), "value": np.sin(np.arange(n) * 0.01)})
+    extraction._LONG_ENTROPY_WARNED = False
     with pytest.warns(UserWarning, match="O\\(n\\^2\\)"):
         extract_features(df, column_id="id", column_sort="time", default_fc_parameters={"sample_entropy": None, "mean": None})
+    with w.catch_warnings():       # once per process under the default show_warnings=False (round-4 ADVICE) ...
+        w.simplefilter("error")
+        extract_features(df, column_id="id", column_sort="time", default_fc_parameters={"sample_entropy": None, "mean": None})
+    with pytest.warns(UserWarning, match="O\\(n\\^2\\)"):   # ... every call with show_warnings=True
+        extract_features(df, column_id="id", column_sort="time", default_fc_parameters={"sample_entropy": None, "mean": None},
+                         show_warnings=True)
     with w.catch_warnings():
         w.simplefilter("error")    # no warning without the quadratic calculators, nor at the limit itself
         extract_features(df, column_id="id", column_sort="time", default_fc_parameters={"mean": None, "median": None})

@@ -10,6 +10,8 @@
 
 TSFA_DEV bool is_pow2(int n) { return n > 0 && (n & (n - 1)) == 0; }
 
+TSFA_DEV void blk_fft_stages_dit(const Blk &b, double *re, double *im, int M, const double *twc, const double *tws);
+
 // in-place radix-2 complex FFT (forward, e^{-i...}) of size M = 2^logM on LDS arrays
 TSFA_DEV void blk_fft_pow2(const Blk &b, double *re, double *im, int M, const double *twc, const double *tws) {
     int logM = 0;
@@ -34,6 +36,14 @@ TSFA_DEV void blk_fft_pow2(const Blk &b, double *re, double *im, int M, const do
             im[j] = ti;
         }
     }
+    blk_fft_stages_dit(b, re, im, M, twc, tws);
+}
+
+// The butterfly stages of a decimation-in-time FFT of M = 2^logM points whose input already sits in bit-reversed order
+// (natural-order output).
+TSFA_DEV void blk_fft_stages_dit(const Blk &b, double *re, double *im, int M, const double *twc, const double *tws) {
+    int logM = 0;
+    while ((1 << logM) < M) ++logM;
     // Radix-2 stages taken TWO AT A TIME: the four elements i0 + {0, h, 2h, 3h} of two consecutive stages (half-lengths h
     // and 2h) meet only each other, so a thread carries them through both stages in registers -- the same butterflies
     // with the same twiddles in the same order as one stage per pass (bit-identical results), with half the LDS reads,
@@ -320,14 +330,120 @@ TSFA_DEV int tsfa_bitrev(int i, int bits) {
 #endif
 }
 
-// dre/dim[0 .. M) (HBM scratch, natural order) = forward FFT of the M points src(j, &re, &im), j in natural order.
-// lre / lim: LDS tile buffers of T doubles each (T a power of two <= M).
-template <class SRC>
-TSFA_DEV void gfft_pow2(const Blk &b, SRC src, double *dre, double *dim, int M, double *lre, double *lim, int T,
-                        const double *twc, const double *tws) {
+// The butterfly stages of a decimation-in-FREQUENCY FFT of M = 2^logM points: natural-order input, bit-reversed output
+// (element i holds frequency bitrev(i)).  Stages two at a time like blk_fft_stages_dit: the four elements
+// i0 + {0, h, 2h, 3h} pass the stage of half-length 2h and then the one of half-length h in registers.
+TSFA_DEV void blk_fft_stages_dif(const Blk &b, double *re, double *im, int M, const double *twc, const double *tws) {
     int logM = 0;
     while ((1 << logM) < M) ++logM;
-    if (T > M) T = M;
+    int st = logM;   // stages left; the next one has half-length 1 << (st - 1)
+    for (; st >= 2; st -= 2) {
+        const int h = 1 << (st - 2);
+        const int strideA = TSFA_TW_N / (4 * h), strideB = TSFA_TW_N / (2 * h);
+        blk_sync();
+        for (int t = b.tid; t < (M >> 2); t += b.nt) {
+            const int grp = t >> (st - 2), k = t & (h - 1);
+            const int i0 = grp * 4 * h + k, i1 = i0 + h, i2 = i0 + 2 * h, i3 = i0 + 3 * h;
+            const double wa0r = twc[k * strideA], wa0i = tws[k * strideA];
+            const double wa1r = twc[(k + h) * strideA], wa1i = tws[(k + h) * strideA];
+            const double wbr = twc[k * strideB], wbi = tws[k * strideB];
+            const double x0r = re[i0], x0i = im[i0], x1r = re[i1], x1i = im[i1];
+            const double x2r = re[i2], x2i = im[i2], x3r = re[i3], x3i = im[i3];
+            // stage A (half-length 2h): (i0, i2) with w_A(k), (i1, i3) with w_A(k + h):  a' = a + b, b' = (a - b) w
+            const double a0r = x0r + x2r, a0i = x0i + x2i, d0r = x0r - x2r, d0i = x0i - x2i;
+            const double a2r = d0r * wa0r - d0i * wa0i, a2i = d0r * wa0i + d0i * wa0r;
+            const double a1r = x1r + x3r, a1i = x1i + x3i, d1r = x1r - x3r, d1i = x1i - x3i;
+            const double a3r = d1r * wa1r - d1i * wa1i, a3i = d1r * wa1i + d1i * wa1r;
+            // stage B (half-length h): (i0, i1) and (i2, i3), both with w_B(k)
+            re[i0] = a0r + a1r;
+            im[i0] = a0i + a1i;
+            const double e0r = a0r - a1r, e0i = a0i - a1i;
+            re[i1] = e0r * wbr - e0i * wbi;
+            im[i1] = e0r * wbi + e0i * wbr;
+            re[i2] = a2r + a3r;
+            im[i2] = a2i + a3i;
+            const double e1r = a2r - a3r, e1i = a2i - a3i;
+            re[i3] = e1r * wbr - e1i * wbi;
+            im[i3] = e1r * wbi + e1i * wbr;
+        }
+    }
+    if (st == 1) {
+        blk_sync();
+        for (int t = b.tid; t < (M >> 1); t += b.nt) {   // half-length 1: twiddle 1
+            const int i0 = 2 * t, i1 = i0 + 1;
+            const double ur = re[i0], ui = im[i0], xr = re[i1], xi = im[i1];
+            re[i0] = ur + xr;
+            im[i0] = ui + xi;
+            re[i1] = ur - xr;
+            im[i1] = ui - xi;
+        }
+    }
+    blk_sync();
+}
+
+// The P = log2(R) stages of an FFT of M = R T points that cross its R tiles of T contiguous points, as ONE pass over the
+// HBM-resident array: position t of every tile (elements t + T q, q < R: coalesced over t) passes all P stages in
+// registers.  DIF = false: the LAST stages of a decimation-in-time transform (lengths 2 T .. M, after the tiles' own);
+// DIF = true: the FIRST stages of a decimation-in-frequency transform (lengths M .. 2 T, before the tiles' own).
+// post(i, re, im) receives every finished element of the DIT form instead of a store (the DIF form stores in place).
+template <int P, bool DIF, class POST>
+TSFA_DEV void gfft_cross_pass(const Blk &b, double *dre, double *dim, int T, const double *twc, const double *tws, POST post) {
+    constexpr int R = 1 << P;
+    for (int t = b.tid; t < T; t += b.nt) {
+        double vr[R], vi[R];
+#pragma unroll
+        for (int q = 0; q < R; ++q) { vr[q] = dre[t + T * q]; vi[q] = dim[t + T * q]; }
+#pragma unroll
+        for (int ss = 0; ss < P; ++ss) {
+            const int sq = DIF ? (P - 1 - ss) : ss;     // half-length of the stage in tiles: 1 << sq; its length: 2 T << sq
+            const int hq = 1 << sq;
+            const int stride = TSFA_TW_N / (2 * T * hq);
+#pragma unroll
+            for (int u = 0; u < R / 2; ++u) {
+                const int kq = u & (hq - 1), q0 = ((u >> sq) << (sq + 1)) + kq, q1 = q0 + hq;
+                const int ti = (t + T * kq) * stride;
+                const double wr = twc[ti], wi = tws[ti];
+                if (DIF) {
+                    const double ar = vr[q0], ai = vi[q0], dr = ar - vr[q1], di = ai - vi[q1];
+                    vr[q0] = ar + vr[q1];
+                    vi[q0] = ai + vi[q1];
+                    vr[q1] = dr * wr - di * wi;
+                    vi[q1] = dr * wi + di * wr;
+                } else {
+                    const double xr = vr[q1], xi = vi[q1];
+                    const double tr = xr * wr - xi * wi, tj = xr * wi + xi * wr;
+                    vr[q1] = vr[q0] - tr;
+                    vi[q1] = vi[q0] - tj;
+                    vr[q0] = vr[q0] + tr;
+                    vi[q0] = vi[q0] + tj;
+                }
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < R; ++q) {
+            if (DIF) { dre[t + T * q] = vr[q]; dim[t + T * q] = vi[q]; }
+            else post(t + T * q, vr[q], vi[q]);
+        }
+    }
+}
+
+template <bool DIF, class POST>
+TSFA_DEV void gfft_cross(const Blk &b, int P, double *dre, double *dim, int T, const double *twc, const double *tws, POST post) {
+    if (P == 1) gfft_cross_pass<1, DIF>(b, dre, dim, T, twc, tws, post);
+    else if (P == 2) gfft_cross_pass<2, DIF>(b, dre, dim, T, twc, tws, post);
+    else if (P == 3) gfft_cross_pass<3, DIF>(b, dre, dim, T, twc, tws, post);
+    else gfft_cross_pass<4, DIF>(b, dre, dim, T, twc, tws, post);
+}
+
+// Forward FFT (decimation in time) of the M points src(j, &re, &im), j in natural order, through the HBM scratch dre / dim:
+// tile by tile (T points, the input fetched in bit-reversed order -- src is a computation, not a gather) the first
+// log2(T) stages in LDS (lre / lim), then the cross-tile stages in one pass whose finished elements go to post(i, re, im).
+template <class SRC, class POST>
+TSFA_DEV void gfft_forward(const Blk &b, SRC src, POST post, double *dre, double *dim, int M, double *lre, double *lim, int T,
+                           const double *twc, const double *tws) {
+    int logM = 0, P = 0;
+    while ((1 << logM) < M) ++logM;
+    while ((T << P) < M) ++P;
     for (int t0 = 0; t0 < M; t0 += T) {
         blk_sync();
         for (int i = b.tid; i < T; i += b.nt) {
@@ -336,47 +452,14 @@ TSFA_DEV void gfft_pow2(const Blk &b, SRC src, double *dre, double *dim, int M, 
             lre[i] = re;
             lim[i] = im;
         }
-        int lh = 0;
-        for (int len = 2; len <= T; len <<= 1, ++lh) {
-            const int half = len >> 1, stride = TSFA_TW_N / len;
-            blk_sync();
-            for (int t = b.tid; t < (T >> 1); t += b.nt) {
-                const int grp = t >> lh, k = t & (half - 1);
-                const int i0 = grp * len + k, i1 = i0 + half;
-                const double wr = twc[k * stride], wi = tws[k * stride];
-                const double xr = lre[i1], xi = lim[i1];
-                const double tr = xr * wr - xi * wi, ti = xr * wi + xi * wr;
-                const double ur = lre[i0], ui = lim[i0];
-                lre[i1] = ur - tr;
-                lim[i1] = ui - ti;
-                lre[i0] = ur + tr;
-                lim[i0] = ui + ti;
-            }
-        }
-        blk_sync();
+        blk_fft_stages_dit(b, lre, lim, T, twc, tws);
         for (int i = b.tid; i < T; i += b.nt) {
             dre[t0 + i] = lre[i];
             dim[t0 + i] = lim[i];
         }
     }
-    int lh = 0;
-    while ((1 << lh) < T) ++lh;  // log2(half) of the first global stage
-    for (int len = 2 * T; len <= M; len <<= 1, ++lh) {
-        const int half = len >> 1, stride = TSFA_TW_N / len;
-        blk_sync_all();
-        for (int t = b.tid; t < (M >> 1); t += b.nt) {
-            const int grp = t >> lh, k = t & (half - 1);
-            const int i0 = grp * len + k, i1 = i0 + half;
-            const double wr = twc[k * stride], wi = tws[k * stride];
-            const double xr = dre[i1], xi = dim[i1];
-            const double tr = xr * wr - xi * wi, ti = xr * wi + xi * wr;
-            const double ur = dre[i0], ui = dim[i0];
-            dre[i1] = ur - tr;
-            dim[i1] = ui - ti;
-            dre[i0] = ur + tr;
-            dim[i0] = ui + ti;
-        }
-    }
+    blk_sync_all();
+    gfft_cross<false>(b, P, dre, dim, T, twc, tws, post);
     blk_sync_all();
 }
 
@@ -386,45 +469,101 @@ TSFA_DEV int bluestein_m(int n) {
     return M;
 }
 
-// rfft of G(i), i < n, into Xr/Xi[0 .. n/2] through gs (4 * bluestein_m(n) doubles of HBM scratch)
+// doubles of HBM scratch blk_rfft_bluestein needs for a series of n samples
+TSFA_HD long long bluestein_scratch_doubles(long long n) {
+    long long M = 1;
+    while (M < 2 * n - 1) M <<= 1;
+    return 4 * M;
+}
+
+// rfft of G(i), i < n, into Xr/Xi[0 .. n/2] through gs (bluestein_scratch_doubles(n) doubles of HBM scratch).
+// Bluestein: X_k = c_k sum_j (x_j c_j) conj(c_{k-j}), c_j = exp(-i pi j^2 / n): a circular convolution of length
+// M = 2^ceil(log2(2n - 1)) = three power-of-two FFTs.  Round 5 (0.38 ns per sample against 0.023 on the
+// radix-2 path -- the workgroup spent its time in 321 barrier intervals, three HBM passes per transform, a 64-bit modulo
+// and a sincospi per chirp value and a bit-reversed GATHER of the whole product):
+//   * the two forward transforms (chirp filter, modulated series) run decimation-in-time from COMPUTED inputs, the tiles'
+//     stages two at a time in LDS, the cross-tile stages as ONE radix-R pass (R = M / T = 4 or 8); the pass of the
+//     series' transform multiplies by the filter's and conjugates on the way out;
+//   * the inverse runs decimation-in-FREQUENCY on that natural-order product -- the cross-tile pass first, then tile by
+//     tile with contiguous loads -- and only the n/2 + 1 wanted bins are picked out of the bit-reversed result;
+//   * chirp values exp(i pi r / n), r = j^2 mod 2n < 65536, are products of two table entries, r = 256 a + b: 2 x 256
+//     sincospi per series (tab: 1024 doubles of LDS) instead of one per use, j^2 mod 2n in float64 (exact below 2^53).
+// tab: cos / sin of pi 256 a / n (a < 256) and of pi b / n (b < 256): 4 x 256 doubles.
 template <class G>
-TSFA_DEV void blk_rfft_bluestein(const Blk &b, int n, G g, double *Xr, double *Xi, double *gs, const double *twc,
-                                 const double *tws) {
+TSFA_DEV void blk_rfft_bluestein(const Blk &b, int n, G g, double *Xr, double *Xi, double *gs, double *tab,
+                                 const double *twc, const double *tws) {
     const int M = bluestein_m(n);
     int T = 1;
     while (2 * T <= n / 2 + 1) T <<= 1;  // Xr / Xi hold n/2 + 2 doubles each
+    if (T > M) T = M;
+    int logM = 0;
+    while ((1 << logM) < M) ++logM;
     double *Are = gs, *Aim = gs + M, *Bre = gs + 2 * (size_t)M, *Bim = gs + 3 * (size_t)M;
-    const double dn = (double)n;
-    // conj(c_j) = exp(+i pi j^2 / n), phase reduced in integers: j^2 mod 2n
+    const double dn = (double)n, two_n = 2.0 * dn, inv_two_n = 1.0 / two_n;
+    double *cA = tab, *sA = tab + 256, *cB = tab + 512, *sB = tab + 768;
+    blk_sync();
+    for (int a = b.tid; a < 512; a += b.nt) {
+        double sv, cv;
+        const int e = a & 255;
+        // exp(i pi 256 e / n): the angle reduced to [0, 2) in integers first (256 e < 2^16 <= 2n may not hold: mod 2n)
+        const long long num = (a < 256) ? ((long long)256 * e) % (2LL * n) : (long long)e;
+        tsfa_sincospi((double)num / dn, &sv, &cv);
+        if (a < 256) { cA[e] = cv; sA[e] = sv; } else { cB[e] = cv; sB[e] = sv; }
+    }
+    blk_sync();
+    // conj(c_j) = exp(+i pi j^2 / n)
     auto chirp = [=](int j, double *c, double *s) {
-        const unsigned long long jj = ((unsigned long long)j * (unsigned long long)j) % (2ull * (unsigned long long)n);
-        tsfa_sincospi((double)jj / dn, s, c);
+        const double jj = (double)j * (double)j;                 // exact: j < 2^15
+        double r = jj - floor(jj * inv_two_n) * two_n;           // j^2 mod 2n, up to one wrap either way
+        r = (r < 0.0) ? r + two_n : r;
+        r = (r >= two_n) ? r - two_n : r;
+        const int ri = (int)r, a = ri >> 8, e = ri & 255;
+        const double ca = cA[a], sa = sA[a], cb = cB[e], sb = sB[e];
+        *c = ca * cb - sa * sb;
+        *s = sa * cb + ca * sb;
     };
-    gfft_pow2(b, [=](int j, double *re, double *im) {
+    // B = FFT of the chirp filter conj(c_j), j in (-n, n) wrapped into [0, M)
+    gfft_forward(b, [=](int j, double *re, double *im) {
         const int jj = (j < n) ? j : ((M - j < n) ? M - j : -1);
         if (jj < 0) { *re = 0.0; *im = 0.0; return; }
-        double c, s;
-        chirp(jj, &c, &s);
-        *re = c;
-        *im = s;
-    }, Bre, Bim, M, Xr, Xi, T, twc, tws);
-    gfft_pow2(b, [=](int j, double *re, double *im) {
+        chirp(jj, re, im);
+    }, [=](int i, double re, double im) { Bre[i] = re; Bim[i] = im; }, Bre, Bim, M, Xr, Xi, T, twc, tws);
+    // A = conj(FFT(x_j c_j) B): the inverse transform below is conj(FFT(conj(.))) / M
+    gfft_forward(b, [=](int j, double *re, double *im) {
         if (j >= n) { *re = 0.0; *im = 0.0; return; }
         double c, s;
         chirp(j, &c, &s);
         const double x = g(j);
         *re = x * c;
         *im = -(x * s);
+    }, [=](int i, double ar, double ai) {
+        const double br = Bre[i], bi = Bim[i];
+        Are[i] = ar * br - ai * bi;
+        Aim[i] = -(ar * bi + ai * br);
     }, Are, Aim, M, Xr, Xi, T, twc, tws);
-    for (int j = b.tid; j < M; j += b.nt) {  // A <- conj(A B): the inverse transform is conj(FFT(conj(.))) / M
-        const double ar = Are[j], ai = Aim[j], br = Bre[j], bi = Bim[j];
-        Are[j] = ar * br - ai * bi;
-        Aim[j] = -(ar * bi + ai * br);
+    // decimation in frequency on the natural-order product: cross-tile stages, then the tiles; element i of the result
+    // holds bin bitrev(i), and only bins 0 .. n/2 are kept (in Bre / Bim: the filter's transform is spent)
+    int P = 0;
+    while ((T << P) < M) ++P;
+    gfft_cross<true>(b, P, Are, Aim, T, twc, tws, [](int, double, double) {});
+    blk_sync_all();
+    const int nh = n / 2;
+    for (int t0 = 0; t0 < M; t0 += T) {
+        blk_sync();
+        for (int i = b.tid; i < T; i += b.nt) {
+            Xr[i] = Are[t0 + i];
+            Xi[i] = Aim[t0 + i];
+        }
+        blk_fft_stages_dif(b, Xr, Xi, T, twc, tws);
+        // (tile-local position i) -> global position t0 + bitrev_T(i)-th ... : the DIF stages of the tile leave ITS result
+        // in the tile's own bit-reversed order, the cross pass left the tiles themselves in bit-reversed order
+        for (int i = b.tid; i < T; i += b.nt) {
+            const int k = tsfa_bitrev(t0 + i, logM);
+            if (k <= nh) { Bre[k] = Xr[i]; Bim[k] = Xi[i]; }
+        }
     }
     blk_sync_all();
-    gfft_pow2(b, [=](int j, double *re, double *im) { *re = Are[j]; *im = Aim[j]; }, Bre, Bim, M, Xr, Xi, T, twc, tws);
     const double inv_m = 1.0 / (double)M;
-    const int nh = n / 2;
     for (int k = b.tid; k <= nh; k += b.nt) {
         double c, s;
         chirp(k, &c, &s);

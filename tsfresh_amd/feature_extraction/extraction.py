@@ -52,7 +52,15 @@ ENTROPY_FAST_MAX_LEN = 4096
 _QUADRATIC = ("sample_entropy", "approximate_entropy")
 
 
-def _warn_long_entropy(fc_parameters, pk):
+_LONG_ENTROPY_WARNED = False
+
+
+def _warn_long_entropy(fc_parameters, pk, show_warnings=False):
+    """A run-time warning, not a calculator's: with show_warnings=False (the reference's default, which silences what the
+    calculators emit) it is raised ONCE per process instead of on every call (round-4 ADVICE); show_warnings=True: every call."""
+    global _LONG_ENTROPY_WARNED
+    if _LONG_ENTROPY_WARNED and not show_warnings:
+        return
     try:
         quadratic = any(name in fc_parameters for name in _QUADRATIC)
     except TypeError:
@@ -61,6 +69,7 @@ def _warn_long_entropy(fc_parameters, pk):
         return
     longest = int(np.diff(pk.offsets).max())
     if longest > ENTROPY_FAST_MAX_LEN:
+        _LONG_ENTROPY_WARNED = True
         warnings.warn("kind {!r}: series of up to {} samples with sample_entropy / approximate_entropy in the settings: these "
                       "calculators are O(n^2) and beyond {} samples leave the LDS-resident sweep (about 0.5 ms per series at "
                       "16 384 samples on a full MI355X, four times that per doubling: 90 % of the extraction).  "
@@ -182,7 +191,7 @@ def extract_features(
         device = _default_device()
     for pk in packed:   # outside the filter below: this one is about run time, not about a calculator's domain
         _warn_long_entropy(kind_to_fc_parameters[pk.kind] if kind_to_fc_parameters and pk.kind in kind_to_fc_parameters
-                           else default_fc_parameters, pk)
+                           else default_fc_parameters, pk, show_warnings)
 
     with warnings.catch_warnings():
         if not show_warnings:
