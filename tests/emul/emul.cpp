@@ -30,6 +30,18 @@
 // clears between series) starts out as NaN / a large finite value / a small negative one instead of zeros.  The outputs
 // must not depend on it (tests/test_oracle_golden.py): a kernel that reads scratch it has not written reads the PREVIOUS
 // series' values on the device.
+// non-power-of-two lengths from here on take the chirp-z transform on even series (TSFA_EMUL_BLUESTEIN_MIN: the tests
+// lower it to reach every tile / cross-pass shape on short series)
+static int emul_bluestein_min() {
+    const char *e = getenv("TSFA_EMUL_BLUESTEIN_MIN");
+    return e ? std::max(atoi(e), 3) : TSFA_BLUESTEIN_MIN_EVEN;   // (the smaller of the two crossovers: scratch for both)
+}
+static int emul_bluestein_pack() {
+    const char *e = getenv("TSFA_EMUL_BLUESTEIN_MIN");
+    const int v = e ? std::max(atoi(e), 3) : 0;
+    return e ? TSFA_BLUESTEIN_PACK(v, v) : TSFA_BLUESTEIN_PACK(TSFA_BLUESTEIN_MIN, TSFA_BLUESTEIN_MIN_EVEN);
+}
+
 static int emul_poison_mode() {
     const char *e = getenv("TSFA_EMUL_POISON");
     return e ? atoi(e) : 0;
@@ -182,17 +194,19 @@ extern "C" int tsfa_emul_extract_timed(const tsfa_feature_spec *specs, int n_spe
         if (!fam[TSFA_FAM_SPECTRAL].empty()) {
             const int nx = (maxn / 2 + 2 > 260) ? maxn / 2 + 2 : 260;
             const int nd = (maxn > 256) ? maxn : 256;
-            std::vector<double> Xr(nx), Xi(nx), tc(nd), ts(nd), win(256), pxx(132);
+            std::vector<double> Xr(nx), Xi(nx), tc(nd), ts(nd), win(256), pxx(132), chirp_tab(1024);
+            poison(chirp_tab);
             std::vector<int> iw(128);
             poison(Xr); poison(Xi); poison(tc); poison(ts); poison(win); poison(pxx); poison_int(iw);
             // even series take the Bluestein route where it applies (HBM scratch on the device), odd ones the Goertzel sweep
-            std::vector<double> gsv((s % 2 == 0 && n >= TSFA_BLUESTEIN_MIN && bluestein_m(n) <= TSFA_BLUESTEIN_MAXM)
+            std::vector<double> gsv((s % 2 == 0 && n >= emul_bluestein_min() && bluestein_m(n) <= TSFA_BLUESTEIN_MAXM)
                                         ? 4 * (size_t)bluestein_m(n) : 0);
             poison(gsv);
             fam_spectral_series(b, xs.data(), n, fam[TSFA_FAM_SPECTRAL].data(), (int)fam[TSFA_FAM_SPECTRAL].size(), row,
                                 Xr.data(), Xi.data(), tc.data(), ts.data(), win.data(), pxx.data(), iw.data(),
                                 twc.data(), tws.data(), hints[TSFA_FAM_SPECTRAL].a, hints[TSFA_FAM_SPECTRAL].b,
-                                gsv.empty() ? nullptr : gsv.data(), (s % 2 == 0) ? consts.data() + TSFA_CONSTS_HANN : nullptr);
+                                gsv.empty() ? nullptr : gsv.data(), (s % 2 == 0) ? consts.data() + TSFA_CONSTS_HANN : nullptr,
+                                chirp_tab.data(), emul_bluestein_pack());
         }
         if (!fam[TSFA_FAM_AR].empty()) {
             int P = 8;

@@ -8,7 +8,7 @@ import pandas as pd
 import pytest
 
 import goldens
-from engines import hip_engine, oracle_engine
+from engines import hip_engine, oracle_engine, oracle_engine_parallel
 from parity import compare
 from tsfresh_amd.feature_extraction import settings
 
@@ -930,3 +930,47 @@ def test_side_lane_changes_no_bit(gpu, monkeypatch):
     monkeypatch.setenv("TSFA_PAIR", "seq,spectral,cwt,trend,ar")
     names2, two_lanes = hip_engine(params, values, offsets)
     assert names == names2 and np.array_equal(one_lane, two_lanes, equal_nan=True)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+@pytest.mark.parametrize("batch", ["lds", "long"])
+def test_chirp_z_transform_on_every_tile_shape_and_in_several_launches(gpu, dtype, batch, monkeypatch):
+    """fft_coefficient / fft_aggregated of non-power-of-two lengths from the crossover (TSFA_BLUESTEIN_MIN, lowered here so
+    that short series reach every shape) up to 32 767 samples: even lengths (n / 2 complex points, M / T = 2 or 4), odd
+    lengths (M / T = 4 or 8), next to powers of two; against numpy's rfft to 1e-13 of sum|x| (the Goertzel sweep it
+    replaces: 6e-10) and against the oracle.  Batch "lds" (series a CU's LDS holds) is also extracted with ONE scratch slot
+    -- a launch per series: the chunked form configs[4] takes when 12 500 series x 512 KB exceed the plan's scratch -- and
+    must agree bit for bit; batch "long" runs from the long-series build (a small batch is one launch group: its longest
+    series decides the build for all of it)."""
+    rng = np.random.default_rng(31)
+    lens = ([257, 258, 300, 301, 510, 511, 513, 514, 1022, 1023, 1025, 1026, 1281, 1500, 2046, 2047, 2049, 2050, 3001, 4094, 4095,
+             4097, 4098, 6000, 6001, 8190, 8191, 8193, 8194] if batch == "lds" else [300, 2050, 12001, 16382, 16385, 20000, 32766, 32767])
+    series = [(np.cumsum(rng.standard_normal(n)) if i % 3 == 0 else rng.standard_normal(n) + (5.0 if i % 3 == 1 else 0.0)).astype(dtype)
+              for i, n in enumerate(lens)]
+    values = np.concatenate(series)
+    offsets = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
+    params = {"fft_coefficient": [{"attr": a, "coeff": k} for a in ("real", "imag", "abs", "angle") for k in (0, 1, 2, 5, 33, 99)],
+              "fft_aggregated": [{"aggtype": t} for t in ("centroid", "variance", "skew", "kurtosis")]}
+    monkeypatch.setenv("TSFA_BLUESTEIN_MIN", "257")
+    names, got = hip_engine(params, values, offsets)
+    if batch == "lds":
+        monkeypatch.setenv("TSFA_GSCRATCH_SLOTS", "1")
+        names2, one_slot = hip_engine(params, values, offsets)
+        monkeypatch.delenv("TSFA_GSCRATCH_SLOTS")
+        assert names == names2 and np.array_equal(got, one_slot, equal_nan=True)
+    monkeypatch.delenv("TSFA_BLUESTEIN_MIN")
+    for i, x in enumerate(series):
+        X = np.fft.rfft(x.astype(np.float64))
+        scale = float(np.abs(x.astype(np.float64)).sum())
+        for j, nm in enumerate(names):
+            if "fft_coefficient" not in nm or "angle" in nm:
+                continue
+            k = int(nm.split("coeff_")[1])
+            a = nm.split('attr_"')[1].split('"')[0]
+            want = {"real": X[k].real, "imag": X[k].imag, "abs": abs(X[k])}[a]
+            assert abs(got[i, j] - want) <= 1e-13 * scale, (lens[i], nm, got[i, j], want)
+    onames, want = oracle_engine_parallel(params, values.astype(np.float64), offsets)
+    assert onames == names
+    bad = compare(names, got, want, [s.astype(np.float64) for s in series])
+    assert not bad, bad[:8]

@@ -61,8 +61,7 @@ def test_unsupported_features_raise_instead_of_falling_back():
         compile_fc_parameters({"matrix_profile": [{"threshold": 0.98, "feature": "min"}]})
     with pytest.raises(UnsupportedFeature):
         compile_fc_parameters({"query_similarity_count": [{"query": [1.0, 2.0, 3.0], "threshold": 0.0}]})
-    with pytest.raises(UnsupportedFeature):
-        compile_fc_parameters({"augmented_dickey_fuller": [{"attr": "teststat", "autolag": "BIC"}]})
+    compile_fc_parameters({"augmented_dickey_fuller": [{"attr": "teststat", "autolag": "BIC"}]})   # served since round 5
     with pytest.raises(AttributeError):
         compile_fc_parameters({"not_a_calculator": None})
 

@@ -317,7 +317,7 @@ TSFA_DEV void blk_rfft(const Blk &b, int n, G g, double *Xr, double *Xi, double 
 // result only occupies at the very end) and the last log2(M / T) stages in place in the scratch.  The chirp phases come
 // from j^2 mod 2n in integer arithmetic, so they stay accurate to the last bit for every n.
 // ---------------------------------------------------------------------------------------------------------------
-#define TSFA_BLUESTEIN_MIN 4097     // measured (5 000 series): 4096..8192 samples 16.7 -> 14.1 ms, 2049..4096 samples 4.1 -> 5.5 ms
+// TSFA_BLUESTEIN_MIN (tsfa_specs.h): the crossover against the Goertzel sweep
 #define TSFA_BLUESTEIN_MAXM 65536   // the shared twiddle table (TSFA_TW_N) serves FFTs up to this size: n <= 32768
 
 TSFA_DEV int tsfa_bitrev(int i, int bits) {
@@ -381,69 +381,77 @@ TSFA_DEV void blk_fft_stages_dif(const Blk &b, double *re, double *im, int M, co
     blk_sync();
 }
 
-// The P = log2(R) stages of an FFT of M = R T points that cross its R tiles of T contiguous points, as ONE pass over the
-// HBM-resident array: position t of every tile (elements t + T q, q < R: coalesced over t) passes all P stages in
-// registers.  DIF = false: the LAST stages of a decimation-in-time transform (lengths 2 T .. M, after the tiles' own);
-// DIF = true: the FIRST stages of a decimation-in-frequency transform (lengths M .. 2 T, before the tiles' own).
-// post(i, re, im) receives every finished element of the DIT form instead of a store (the DIF form stores in place).
-template <int P, bool DIF, class POST>
-TSFA_DEV void gfft_cross_pass(const Blk &b, double *dre, double *dim, int T, const double *twc, const double *tws, POST post) {
+// One stage of the P = log2(R) stages of an FFT of M = R T points that cross its R tiles of T contiguous points, on the R
+// elements t + T q (q < R) of position t held in registers.  sq: half-length of the stage in tiles = 1 << sq (its length:
+// 2 T << sq).  DIF: a' = a + b, b' = (a - b) w; else (decimation in time): a' = a + w b, b' = a - w b.
+template <int P, bool DIF>
+TSFA_DEV void gfft_cross_stage(double (&vr)[1 << P], double (&vi)[1 << P], int sq, int t, int T, const double *twc, const double *tws) {
     constexpr int R = 1 << P;
-    for (int t = b.tid; t < T; t += b.nt) {
-        double vr[R], vi[R];
+    const int hq = 1 << sq;
+    const int stride = TSFA_TW_N / (2 * T * hq);
 #pragma unroll
-        for (int q = 0; q < R; ++q) { vr[q] = dre[t + T * q]; vi[q] = dim[t + T * q]; }
-#pragma unroll
-        for (int ss = 0; ss < P; ++ss) {
-            const int sq = DIF ? (P - 1 - ss) : ss;     // half-length of the stage in tiles: 1 << sq; its length: 2 T << sq
-            const int hq = 1 << sq;
-            const int stride = TSFA_TW_N / (2 * T * hq);
-#pragma unroll
-            for (int u = 0; u < R / 2; ++u) {
-                const int kq = u & (hq - 1), q0 = ((u >> sq) << (sq + 1)) + kq, q1 = q0 + hq;
-                const int ti = (t + T * kq) * stride;
-                const double wr = twc[ti], wi = tws[ti];
-                if (DIF) {
-                    const double ar = vr[q0], ai = vi[q0], dr = ar - vr[q1], di = ai - vi[q1];
-                    vr[q0] = ar + vr[q1];
-                    vi[q0] = ai + vi[q1];
-                    vr[q1] = dr * wr - di * wi;
-                    vi[q1] = dr * wi + di * wr;
-                } else {
-                    const double xr = vr[q1], xi = vi[q1];
-                    const double tr = xr * wr - xi * wi, tj = xr * wi + xi * wr;
-                    vr[q1] = vr[q0] - tr;
-                    vi[q1] = vi[q0] - tj;
-                    vr[q0] = vr[q0] + tr;
-                    vi[q0] = vi[q0] + tj;
-                }
-            }
-        }
-#pragma unroll
-        for (int q = 0; q < R; ++q) {
-            if (DIF) { dre[t + T * q] = vr[q]; dim[t + T * q] = vi[q]; }
-            else post(t + T * q, vr[q], vi[q]);
+    for (int u = 0; u < R / 2; ++u) {
+        const int kq = u & (hq - 1), q0 = ((u >> sq) << (sq + 1)) + kq, q1 = q0 + hq;
+        const int ti = (t + T * kq) * stride;
+        const double wr = twc[ti], wi = tws[ti];
+        if (DIF) {
+            const double ar = vr[q0], ai = vi[q0], dr = ar - vr[q1], di = ai - vi[q1];
+            vr[q0] = ar + vr[q1];
+            vi[q0] = ai + vi[q1];
+            vr[q1] = dr * wr - di * wi;
+            vi[q1] = dr * wi + di * wr;
+        } else {
+            const double xr = vr[q1], xi = vi[q1];
+            const double tr = xr * wr - xi * wi, tj = xr * wi + xi * wr;
+            vr[q1] = vr[q0] - tr;
+            vi[q1] = vi[q0] - tj;
+            vr[q0] = vr[q0] + tr;
+            vi[q0] = vi[q0] + tj;
         }
     }
 }
 
-template <bool DIF, class POST>
-TSFA_DEV void gfft_cross(const Blk &b, int P, double *dre, double *dim, int T, const double *twc, const double *tws, POST post) {
-    if (P == 1) gfft_cross_pass<1, DIF>(b, dre, dim, T, twc, tws, post);
-    else if (P == 2) gfft_cross_pass<2, DIF>(b, dre, dim, T, twc, tws, post);
-    else if (P == 3) gfft_cross_pass<3, DIF>(b, dre, dim, T, twc, tws, post);
-    else gfft_cross_pass<4, DIF>(b, dre, dim, T, twc, tws, post);
+// The cross-tile stages of BOTH forward transforms, the product and the cross-tile stages of the inverse in ONE pass over
+// the HBM-resident arrays: position t of every tile of A (the modulated series) and of B (the chirp filter), each already
+// through its own tiles' decimation-in-time stages, pass the last P stages in registers (lengths 2 T .. M); the product
+// conj(A B) of the two finished spectra -- natural order, same positions -- passes the FIRST P stages of the
+// decimation-in-frequency inverse (lengths M .. 2 T) and is stored over A.  Elements t + T q are coalesced over t.
+// (Round 5: separate passes moved 10 M complex values per series through HBM scratch, this form 6 M -- the transform is
+// bound by that traffic: 512 KB of scratch per resident workgroup is far beyond the L2.)
+template <int P>
+TSFA_DEV void gfft_fused_cross(const Blk &b, double *Are, double *Aim, const double *Bre, const double *Bim, int T,
+                               const double *twc, const double *tws) {
+    constexpr int R = 1 << P;
+    for (int t = b.tid; t < T; t += b.nt) {
+        double ar[R], ai[R], br[R], bi[R];
+#pragma unroll
+        for (int q = 0; q < R; ++q) { ar[q] = Are[t + T * q]; ai[q] = Aim[t + T * q]; br[q] = Bre[t + T * q]; bi[q] = Bim[t + T * q]; }
+#pragma unroll
+        for (int sq = 0; sq < P; ++sq) {
+            gfft_cross_stage<P, false>(ar, ai, sq, t, T, twc, tws);
+            gfft_cross_stage<P, false>(br, bi, sq, t, T, twc, tws);
+        }
+#pragma unroll
+        for (int q = 0; q < R; ++q) {   // conj(A B): the inverse transform is conj(FFT(conj(.))) / M
+            const double pr = ar[q] * br[q] - ai[q] * bi[q], pi = -(ar[q] * bi[q] + ai[q] * br[q]);
+            ar[q] = pr;
+            ai[q] = pi;
+        }
+#pragma unroll
+        for (int sq = P - 1; sq >= 0; --sq) gfft_cross_stage<P, true>(ar, ai, sq, t, T, twc, tws);
+#pragma unroll
+        for (int q = 0; q < R; ++q) { Are[t + T * q] = ar[q]; Aim[t + T * q] = ai[q]; }
+    }
 }
 
-// Forward FFT (decimation in time) of the M points src(j, &re, &im), j in natural order, through the HBM scratch dre / dim:
-// tile by tile (T points, the input fetched in bit-reversed order -- src is a computation, not a gather) the first
-// log2(T) stages in LDS (lre / lim), then the cross-tile stages in one pass whose finished elements go to post(i, re, im).
-template <class SRC, class POST>
-TSFA_DEV void gfft_forward(const Blk &b, SRC src, POST post, double *dre, double *dim, int M, double *lre, double *lim, int T,
-                           const double *twc, const double *tws) {
-    int logM = 0, P = 0;
+// The tiles' own stages of a decimation-in-time FFT of the M points src(j, &re, &im) (j in natural order): tile by tile
+// (T points, the input fetched in bit-reversed order -- src is a computation, not a gather) log2(T) stages in LDS
+// (lre / lim), the result to dre / dim; the cross-tile stages are gfft_fused_cross's.
+template <class SRC>
+TSFA_DEV void gfft_tiles_dit(const Blk &b, SRC src, double *dre, double *dim, int M, double *lre, double *lim, int T,
+                             const double *twc, const double *tws) {
+    int logM = 0;
     while ((1 << logM) < M) ++logM;
-    while ((T << P) < M) ++P;
     for (int t0 = 0; t0 < M; t0 += T) {
         blk_sync();
         for (int i = b.tid; i < T; i += b.nt) {
@@ -458,96 +466,104 @@ TSFA_DEV void gfft_forward(const Blk &b, SRC src, POST post, double *dre, double
             dim[t0 + i] = lim[i];
         }
     }
-    blk_sync_all();
-    gfft_cross<false>(b, P, dre, dim, T, twc, tws, post);
-    blk_sync_all();
 }
 
-TSFA_DEV int bluestein_m(int n) {
+TSFA_DEV int bluestein_pow2(int len) {   // convolution length of a chirp-z transform of `len` points
     int M = 1;
-    while (M < 2 * n - 1) M <<= 1;
+    while (M < 2 * len - 1) M <<= 1;
     return M;
 }
-
-// doubles of HBM scratch blk_rfft_bluestein needs for a series of n samples
-TSFA_HD long long bluestein_scratch_doubles(long long n) {
-    long long M = 1;
-    while (M < 2 * n - 1) M <<= 1;
-    return 4 * M;
+// The transform of an EVEN n runs on the n / 2 complex points x[2j] + i x[2j + 1] (half the convolution length, half the
+// traffic) and is split afterwards like the power-of-two path's; an odd n on its n real points.
+TSFA_DEV int bluestein_points(int n) { return (n & 1) ? n : n / 2; }
+TSFA_DEV int bluestein_m(int n) { return bluestein_pow2(bluestein_points(n)); }
+// the tile of blk_rfft_bluestein: the largest power of two the n/2 + 2 doubles of Xr / Xi hold
+TSFA_DEV int bluestein_tile(int n) {
+    int T = 1;
+    while (2 * T <= n / 2 + 1) T <<= 1;
+    return T;
+}
+// M / T is 4 or 8 for odd n, 2 or 4 for even n (T = 2^k <= n/2 + 1 < 2^(k+1)): the cross passes exist for 2, 4 and 8
+TSFA_DEV bool bluestein_tiles_ok(int n) {
+    const int M = bluestein_m(n), T = bluestein_tile(n);
+    return n >= 16 && (M == 2 * T || M == 4 * T || M == 8 * T) && M <= TSFA_BLUESTEIN_MAXM && n <= 32768;
 }
 
-// rfft of G(i), i < n, into Xr/Xi[0 .. n/2] through gs (bluestein_scratch_doubles(n) doubles of HBM scratch).
-// Bluestein: X_k = c_k sum_j (x_j c_j) conj(c_{k-j}), c_j = exp(-i pi j^2 / n): a circular convolution of length
-// M = 2^ceil(log2(2n - 1)) = three power-of-two FFTs.  Round 5 (0.38 ns per sample against 0.023 on the
-// radix-2 path -- the workgroup spent its time in 321 barrier intervals, three HBM passes per transform, a 64-bit modulo
-// and a sincospi per chirp value and a bit-reversed GATHER of the whole product):
+// rfft of G(i), i < n, into Xr/Xi[0 .. n/2] through gs (4 * bluestein_m(n) doubles of HBM scratch).
+// Bluestein: Z_k = c_k sum_j (z_j c_j) conj(c_{k-j}), c_j = exp(-i pi j^2 / N) over the N = bluestein_points(n) points:
+// a circular convolution of length M = 2^ceil(log2(2N - 1)) = three power-of-two FFTs.  Round 5 (0.38 ns
+// per sample against 0.023 on the radix-2 path -- 321 barrier intervals, three HBM passes per transform, a 64-bit modulo
+// and a sincospi per chirp value, a bit-reversed GATHER of the whole product; 11.98 ms per 5 000 series of 4096..8192):
 //   * the two forward transforms (chirp filter, modulated series) run decimation-in-time from COMPUTED inputs, the tiles'
-//     stages two at a time in LDS, the cross-tile stages as ONE radix-R pass (R = M / T = 4 or 8); the pass of the
-//     series' transform multiplies by the filter's and conjugates on the way out;
-//   * the inverse runs decimation-in-FREQUENCY on that natural-order product -- the cross-tile pass first, then tile by
-//     tile with contiguous loads -- and only the n/2 + 1 wanted bins are picked out of the bit-reversed result;
-//   * chirp values exp(i pi r / n), r = j^2 mod 2n < 65536, are products of two table entries, r = 256 a + b: 2 x 256
-//     sincospi per series (tab: 1024 doubles of LDS) instead of one per use, j^2 mod 2n in float64 (exact below 2^53).
+//     stages two at a time in LDS; their cross-tile stages, the product and the cross-tile stages of the inverse are ONE
+//     pass over the scratch (gfft_fused_cross);
+//   * the inverse runs decimation-in-FREQUENCY on that natural-order product, tile by tile with contiguous loads, and only
+//     the wanted bins are picked out of the bit-reversed result;
+//   * an even n is transformed as n / 2 complex points and split;
+//   * chirp values exp(i pi r / n), r < 2n <= 65536, are products of two table entries, r = 256 a + b: 2 x 256 sincospi
+//     per series (tab: 1024 doubles of LDS) instead of one per use; j^2 mod 2N in float64 (exact: j < 2^15).
+// Accuracy: 4e-16 sum|x| on 9 .. 32 767 samples (the Goertzel sweep: 6e-10).
 // tab: cos / sin of pi 256 a / n (a < 256) and of pi b / n (b < 256): 4 x 256 doubles.
 template <class G>
 TSFA_DEV void blk_rfft_bluestein(const Blk &b, int n, G g, double *Xr, double *Xi, double *gs, double *tab,
                                  const double *twc, const double *tws) {
-    const int M = bluestein_m(n);
-    int T = 1;
-    while (2 * T <= n / 2 + 1) T <<= 1;  // Xr / Xi hold n/2 + 2 doubles each
-    if (T > M) T = M;
-    int logM = 0;
+    const bool half = (n & 1) == 0;
+    const int N = bluestein_points(n), M = bluestein_m(n), T = bluestein_tile(n);
+    int logM = 0, P = 0;
     while ((1 << logM) < M) ++logM;
+    while ((T << P) < M) ++P;
     double *Are = gs, *Aim = gs + M, *Bre = gs + 2 * (size_t)M, *Bim = gs + 3 * (size_t)M;
-    const double dn = (double)n, two_n = 2.0 * dn, inv_two_n = 1.0 / two_n;
+    const double dn = (double)n, two_N = 2.0 * (double)N, inv_two_N = 1.0 / two_N;
     double *cA = tab, *sA = tab + 256, *cB = tab + 512, *sB = tab + 768;
     blk_sync();
     for (int a = b.tid; a < 512; a += b.nt) {
         double sv, cv;
         const int e = a & 255;
-        // exp(i pi 256 e / n): the angle reduced to [0, 2) in integers first (256 e < 2^16 <= 2n may not hold: mod 2n)
-        const long long num = (a < 256) ? ((long long)256 * e) % (2LL * n) : (long long)e;
+        // exp(i pi 256 e / n): the angle reduced to [0, 2) in integers first (256 e may exceed 2n)
+        const int num = (a < 256) ? (256 * e) % (2 * n) : e;
         tsfa_sincospi((double)num / dn, &sv, &cv);
         if (a < 256) { cA[e] = cv; sA[e] = sv; } else { cB[e] = cv; sB[e] = sv; }
     }
     blk_sync();
-    // conj(c_j) = exp(+i pi j^2 / n)
-    auto chirp = [=](int j, double *c, double *s) {
-        const double jj = (double)j * (double)j;                 // exact: j < 2^15
-        double r = jj - floor(jj * inv_two_n) * two_n;           // j^2 mod 2n, up to one wrap either way
-        r = (r < 0.0) ? r + two_n : r;
-        r = (r >= two_n) ? r - two_n : r;
-        const int ri = (int)r, a = ri >> 8, e = ri & 255;
+    // exp(+i pi r / n), 0 <= r < 2n
+    auto unit = [=](int ri, double *c, double *s) {
+        const int a = ri >> 8, e = ri & 255;
         const double ca = cA[a], sa = sA[a], cb = cB[e], sb = sB[e];
         *c = ca * cb - sa * sb;
         *s = sa * cb + ca * sb;
     };
-    // B = FFT of the chirp filter conj(c_j), j in (-n, n) wrapped into [0, M)
-    gfft_forward(b, [=](int j, double *re, double *im) {
-        const int jj = (j < n) ? j : ((M - j < n) ? M - j : -1);
+    // conj(c_j) = exp(+i pi j^2 / N) = exp(+i pi r / n) with r = (j^2 mod 2N) * (n / N)
+    const int rmul = half ? 2 : 1;
+    auto chirp = [=](int j, double *c, double *s) {
+        const double jj = (double)j * (double)j;                 // exact: j < 2^15
+        double r = jj - floor(jj * inv_two_N) * two_N;           // j^2 mod 2N, up to one wrap either way
+        r = (r < 0.0) ? r + two_N : r;
+        r = (r >= two_N) ? r - two_N : r;
+        unit((int)r * rmul, c, s);
+    };
+    // B: the chirp filter conj(c_j), j in (-N, N) wrapped into [0, M)
+    gfft_tiles_dit(b, [=](int j, double *re, double *im) {
+        const int jj = (j < N) ? j : ((M - j < N) ? M - j : -1);
         if (jj < 0) { *re = 0.0; *im = 0.0; return; }
         chirp(jj, re, im);
-    }, [=](int i, double re, double im) { Bre[i] = re; Bim[i] = im; }, Bre, Bim, M, Xr, Xi, T, twc, tws);
-    // A = conj(FFT(x_j c_j) B): the inverse transform below is conj(FFT(conj(.))) / M
-    gfft_forward(b, [=](int j, double *re, double *im) {
-        if (j >= n) { *re = 0.0; *im = 0.0; return; }
+    }, Bre, Bim, M, Xr, Xi, T, twc, tws);
+    // A: z_j c_j
+    gfft_tiles_dit(b, [=](int j, double *re, double *im) {
+        if (j >= N) { *re = 0.0; *im = 0.0; return; }
         double c, s;
         chirp(j, &c, &s);
-        const double x = g(j);
-        *re = x * c;
-        *im = -(x * s);
-    }, [=](int i, double ar, double ai) {
-        const double br = Bre[i], bi = Bim[i];
-        Are[i] = ar * br - ai * bi;
-        Aim[i] = -(ar * bi + ai * br);
+        const double zr = half ? g(2 * j) : g(j), zi = half ? g(2 * j + 1) : 0.0;
+        *re = zr * c + zi * s;   // (zr + i zi)(c - i s)
+        *im = zi * c - zr * s;
     }, Are, Aim, M, Xr, Xi, T, twc, tws);
-    // decimation in frequency on the natural-order product: cross-tile stages, then the tiles; element i of the result
-    // holds bin bitrev(i), and only bins 0 .. n/2 are kept (in Bre / Bim: the filter's transform is spent)
-    int P = 0;
-    while ((T << P) < M) ++P;
-    gfft_cross<true>(b, P, Are, Aim, T, twc, tws, [](int, double, double) {});
     blk_sync_all();
-    const int nh = n / 2;
+    if (P == 1) gfft_fused_cross<1>(b, Are, Aim, Bre, Bim, T, twc, tws);
+    else if (P == 2) gfft_fused_cross<2>(b, Are, Aim, Bre, Bim, T, twc, tws);
+    else gfft_fused_cross<3>(b, Are, Aim, Bre, Bim, T, twc, tws);
+    blk_sync_all();
+    // the tiles of the decimation-in-frequency inverse; element i of the whole result holds bin bitrev(i), and only the
+    // wanted bins are kept (in Bre / Bim: the filter's transform is spent): all N of a half-length transform, 0 .. n/2 else
+    const int keep = half ? N : n / 2 + 1;
     for (int t0 = 0; t0 < M; t0 += T) {
         blk_sync();
         for (int i = b.tid; i < T; i += b.nt) {
@@ -555,21 +571,65 @@ TSFA_DEV void blk_rfft_bluestein(const Blk &b, int n, G g, double *Xr, double *X
             Xi[i] = Aim[t0 + i];
         }
         blk_fft_stages_dif(b, Xr, Xi, T, twc, tws);
-        // (tile-local position i) -> global position t0 + bitrev_T(i)-th ... : the DIF stages of the tile leave ITS result
-        // in the tile's own bit-reversed order, the cross pass left the tiles themselves in bit-reversed order
         for (int i = b.tid; i < T; i += b.nt) {
             const int k = tsfa_bitrev(t0 + i, logM);
-            if (k <= nh) { Bre[k] = Xr[i]; Bim[k] = Xi[i]; }
+            if (k < keep) { Bre[k] = Xr[i]; Bim[k] = Xi[i]; }
         }
     }
     blk_sync_all();
     const double inv_m = 1.0 / (double)M;
-    for (int k = b.tid; k <= nh; k += b.nt) {
+    // Z_k = conj(conv_k) / M * c_k
+    auto zbin = [=](int k, double *zr, double *zi) {
         double c, s;
         chirp(k, &c, &s);
         const double cr = Bre[k] * inv_m, ci = -(Bim[k] * inv_m);
-        Xr[k] = cr * c + ci * s;  // (cr + i ci)(c - i s)
-        Xi[k] = (k == 0 || 2 * k == n) ? 0.0 : (ci * c - cr * s);
+        *zr = cr * c + ci * s;  // (cr + i ci)(c - i s)
+        *zi = ci * c - cr * s;
+    };
+    const int nh = n / 2;
+    if (!half) {
+        for (int k = b.tid; k <= nh; k += b.nt) {
+            double zr, zi;
+            zbin(k, &zr, &zi);
+            Xr[k] = zr;
+            Xi[k] = (k == 0) ? 0.0 : zi;
+        }
+    } else {
+        // split of the half-length transform (pairs k, N - k): X_k = E + w^k O, E = (Z_k + conj(Z_{N-k})) / 2,
+        // O = -i (Z_k - conj(Z_{N-k})) / 2, w^k = exp(-2 pi i k / n) = conj(unit(2 k))
+        for (int k = b.tid; k <= N / 2; k += b.nt) {
+            if (k == 0) {
+                double zr, zi;
+                zbin(0, &zr, &zi);
+                Xr[0] = zr + zi;
+                Xi[0] = 0.0;
+                Xr[N] = zr - zi;
+                Xi[N] = 0.0;
+            } else {
+                const int k2 = N - k;
+                double ar, ai, br, bi;
+                zbin(k, &ar, &ai);
+                zbin(k2, &br, &bi);
+                {
+                    const double er = 0.5 * (ar + br), ei = 0.5 * (ai - bi);
+                    const double orr = 0.5 * (ai + bi), oi = -0.5 * (ar - br);
+                    double c, s;
+                    unit(2 * k, &c, &s);
+                    const double wr = c, wi = -s;
+                    Xr[k] = er + (orr * wr - oi * wi);
+                    Xi[k] = ei + (orr * wi + oi * wr);
+                }
+                if (k2 != k) {
+                    const double er = 0.5 * (br + ar), ei = 0.5 * (bi - ai);
+                    const double orr = 0.5 * (bi + ai), oi = -0.5 * (br - ar);
+                    double c, s;
+                    unit(2 * k2, &c, &s);
+                    const double wr = c, wi = -s;
+                    Xr[k2] = er + (orr * wr - oi * wi);
+                    Xi[k2] = ei + (orr * wi + oi * wr);
+                }
+            }
+        }
     }
     blk_sync();
 }
@@ -714,11 +774,13 @@ TSFA_DEV int blk_welch(const Blk &b, const ST *xs, int n, double *win, double *p
 //   tc, ts : per-series DFT twiddles, >= n doubles each when n is not a power of two (LDS or global scratch)
 //   win    : LDS >= 256;  pxx : LDS >= 132;  iw : LDS ints >= 128
 // ST: element type of the LDS-resident series (the input precision; read as float64)
-template <class ST>
+// BL: the instantiation that holds the chirp-z transform (launches with HBM scratch; the others stay lean)
+template <class ST, bool BL = true>
 TSFA_DEV void fam_spectral_series(const Blk &b, const ST *xs_raw, int n, const TsfaSpec *specs, int nspecs,
                                   double *out_row, double *Xr, double *Xi, double *tc, double *ts, double *win,
                                   double *pxx, int *iw, const double *twc, const double *tws, int flags, int nlead,
-                                  double *gs = nullptr, const double *hann256 = nullptr) {
+                                  double *gs = nullptr, const double *hann256 = nullptr, double *chirp_tab = nullptr,
+                                  int bl_min = TSFA_BLUESTEIN_PACK(TSFA_BLUESTEIN_MIN, TSFA_BLUESTEIN_MIN_EVEN)) {
     const XsView<ST> xs{xs_raw};
     // flags / nlead come from tsfa_prepare_family (host): the Welch-based specs are the first nlead of the list
     const bool need_fft = (flags & 1) != 0, need_welch = (flags & 2) != 0;
@@ -767,8 +829,8 @@ TSFA_DEV void fam_spectral_series(const Blk &b, const ST *xs_raw, int n, const T
     // ---- full-length rfft ----
     // gs: 4 * bluestein_m(n) doubles of HBM scratch (or null: long lengths of arbitrary factorisation fall back on the
     // O(n^2) Goertzel sweep of blk_rfft)
-    if (gs != nullptr && n >= TSFA_BLUESTEIN_MIN && !is_pow2(n) && bluestein_m(n) <= TSFA_BLUESTEIN_MAXM)
-        blk_rfft_bluestein(b, n, [=](int j) { return xs[j]; }, Xr, Xi, gs, twc, tws);
+    if (BL && gs != nullptr && chirp_tab != nullptr && n >= ((n & 1) ? (bl_min & 0xFFFF) : (bl_min >> 16)) && !is_pow2(n) && bluestein_tiles_ok(n))
+        blk_rfft_bluestein(b, n, [=](int j) { return xs[j]; }, Xr, Xi, gs, chirp_tab, twc, tws);
     else
         blk_rfft(b, n, [=](int j) { return xs[j]; }, Xr, Xi, tc, ts, twc, tws);
     TSFA_TICK(tk, b, 172);

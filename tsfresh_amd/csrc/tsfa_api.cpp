@@ -572,15 +572,26 @@ static int run_batch(tsfa_plan *plan, const void *d_values, int dtype, const dou
                 aux = a.dft_n;
                 // long series of non-power-of-two length: three power-of-two FFTs through HBM scratch (Bluestein,
                 // fam_spectral.h) instead of the O(n^2) Goertzel sweep; 32 M bytes per workgroup, at most 6 GB per launch
-                if (max_np2 >= 4097 && max_np2 <= 32768 && !(getenv("TSFA_NO_BLUESTEIN") && atoi(getenv("TSFA_NO_BLUESTEIN")))) {
+                int bl_odd = TSFA_BLUESTEIN_MIN, bl_even = TSFA_BLUESTEIN_MIN_EVEN;
+                if (const char *e = getenv("TSFA_BLUESTEIN_MIN")) bl_odd = bl_even = std::min(std::max(atoi(e), 17), 65535);   // A/B of the crossover, tests
+                a.bluestein_min = TSFA_BLUESTEIN_PACK(bl_odd, bl_even);
+                if (max_np2 >= std::min(bl_odd, bl_even) && max_np2 <= 32768 && !(getenv("TSFA_NO_BLUESTEIN") && atoi(getenv("TSFA_NO_BLUESTEIN")))) {
                     long long M = 1;
                     while (M < 2 * max_np2 - 1) M <<= 1;
-                    const int64_t wgs = std::min<int64_t>(a.n_series, 512 * 64);
-                    const size_t bytes = (size_t)a.n_series * (size_t)(4 * M) * sizeof(double);
-                    (void)wgs;
-                    if (bytes <= (6ull << 30) && plan->gscratch.ensure(bytes) == 0) {
+                    // one slot per workgroup of a launch; at most 4 GB (and at least the 2048 workgroups of the long-series
+                    // build's persistent grid, 2 MB each at the longest length): a larger group goes out in several launches
+                    const size_t slot_bytes = (size_t)(4 * M) * sizeof(double);
+                    int64_t slots = std::min<int64_t>(a.n_series, std::max<int64_t>((int64_t)((4ull << 30) / slot_bytes), 2048));
+                    if (const char *e = getenv("TSFA_GSCRATCH_SLOTS")) slots = std::min<int64_t>(slots, std::max(atoi(e), 1));   // test hook: several launches per group
+                    const size_t bytes = (size_t)slots * slot_bytes;
+                    if (plan->gscratch.ensure(bytes) == 0) {
                         a.gscratch = (double *)plan->gscratch.p;
                         a.gscratch_n = (int)(4 * M);
+                        a.gscratch_slots = slots;
+                        // the transform's passes over its HBM scratch want more wavefronts than the LDS-resident phases
+                        // (profiles/r05_j: 1025..2048 samples 1.76 -> 1.59 ms at 256 threads, 2049..4096 2.36 -> 2.28 at 512)
+                        // (up to 1280 samples -- even lengths from 897 -- the family's own 128 stay: 20 000 x 1000 1.47 -> 1.23 ms)
+                        if (!getenv("TSFA_NT_2") && maxn > 1280) a.nt = (maxn <= 2048) ? 256 : 512;
                     }
                 }
             } else if (f == TSFA_FAM_CWT) {
@@ -676,8 +687,13 @@ static int run_batch(tsfa_plan *plan, const void *d_values, int dtype, const dou
             // (tsfa_kernels_long.hip): the working set in a slot of HBM scratch per resident workgroup, a persistent
             // grid walking the group's series.  Slower per sample, but every length up to 65 535 extracts.
             const bool use_long = lds > TSFA_LDS_LIMIT || (getenv("TSFA_FORCE_LONG") && atoi(getenv("TSFA_FORCE_LONG")));
+            if (f == TSFA_FAM_SPECTRAL && getenv("TSFA_DEBUG_SPECTRAL"))
+                fprintf(stderr, "[tsfa] spectral group %d: n_series %lld maxn %d max_np2 %lld lds %zu long %d chirp-z %d slots %lld nt %d\n", g,
+                        (long long)a.n_series, maxn, max_np2, lds, (int)use_long, (int)(a.gscratch != nullptr), (long long)a.gscratch_slots, a.nt);
             if (use_long) {
                 a.nt = 256;
+                // the long-series build's persistent grid indexes the chirp-z scratch by workgroup: a slot for each, or none
+                if (a.gscratch != nullptr && a.gscratch_slots < std::min<int64_t>(a.n_series, 2048)) a.gscratch = nullptr;
                 if (f == TSFA_FAM_ENTROPY) { a.ent_cnt = 0; a.ent_fast = 0; lds = tsfa_entropy_lds_bytes(maxn, 0); }
                 if (f == TSFA_FAM_CWT) { a.cwt_rowv &= 2; lds = tsfa_family_lds_bytes(f, maxn, a.nt, 0); }
                 if (f == TSFA_FAM_SEQ) {

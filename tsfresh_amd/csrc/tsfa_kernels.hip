@@ -216,10 +216,11 @@ __global__ void __launch_bounds__(1024) k_perm(const T *__restrict__ values, con
 }
 #endif
 
-template <typename T>
+// BL: with the chirp-z transform of long non-power-of-two series (launched when the plan gave the group HBM scratch)
+template <typename T, bool BL>
 __global__ void __launch_bounds__(1024) k_spectral(const T *__restrict__ values, const int64_t *__restrict__ starts, const int64_t *__restrict__ ends, int64_t n_series, const int *__restrict__ sel,
                            const TsfaSpec *__restrict__ specs, int nspecs, double *__restrict__ out, int64_t ld,
-                           int maxn, int dft_n, double *__restrict__ gscratch, int gscratch_n,
+                           int maxn, int dft_n, double *__restrict__ gscratch, int gscratch_n, int bl_min,
                            const double *__restrict__ twc, const double *__restrict__ tws, int hint_a, int hint_b,
                            const double *__restrict__ consts TSFA_GS_PARAMS) {
     TSFA_SERIES_BEGIN
@@ -237,8 +238,8 @@ __global__ void __launch_bounds__(1024) k_spectral(const T *__restrict__ values,
     }
     // gscratch: one slot of gscratch_n doubles per workgroup for the Bluestein FFTs of long series (or null)
     double *gs = gscratch ? gscratch + (size_t)blockIdx.x * (size_t)gscratch_n : nullptr;
-    fam_spectral_series<T>(b, xs, n, specs, nspecs, out + sidx * ld, L.Xr, L.Xi, L.tc, L.ts, L.win, L.pxx, L.iw, twc, tws,
-                        hint_a, hint_b, gs, consts ? consts + TSFA_CONSTS_HANN : nullptr);
+    fam_spectral_series<T, BL>(b, xs, n, specs, nspecs, out + sidx * ld, L.Xr, L.Xi, L.tc, L.ts, L.win, L.pxx, L.iw, twc, tws,
+                        hint_a, hint_b, gs, consts ? consts + TSFA_CONSTS_HANN : nullptr, L.chirp_tab(), bl_min);
     TSFA_TICKS_END();
     TSFA_SERIES_END
 }
@@ -963,8 +964,30 @@ static int launch_all_t(const TsfaLaunch &a, const T *values) {
     } else if (a.fam == TSFA_FAM_SPECTRAL) {
         SpectralLds L;
         const size_t lds = L.carve(nullptr, a.maxn, a.dft_n, (int)sizeof(T));
-        TSFA_KLAUNCH(k_spectral<T>, lds, values, a.starts, a.ends, a.n_series, a.sel, a.specs, a.nspecs, a.out, a.ld, a.maxn,
-                     a.dft_n, a.gscratch, a.gscratch_n, a.twc, a.tws, a.hint_a, a.hint_b, a.consts);
+        if (a.gscratch != nullptr) {
+            auto kfn = k_spectral<T, true>;
+#if defined(TSFA_LONG)
+            // (a persistent grid of at most 2048 workgroups: the plan allocated a scratch slot for each)
+            TSFA_KLAUNCH(kfn, lds, values, a.starts, a.ends, a.n_series, a.sel, a.specs, a.nspecs, a.out, a.ld, a.maxn,
+                         a.dft_n, a.gscratch, a.gscratch_n, a.bluestein_min, a.twc, a.tws, a.hint_a, a.hint_b, a.consts);
+#else
+            // one workgroup per series, one scratch slot per workgroup: the group goes out in launches of as many series as
+            // the plan's scratch has slots (configs[4] per GPU: 12 500 series x 512 KB would be 6.4 GB in one launch)
+            if ((rc = set_lds(kfn, lds))) return rc;
+            const int64_t slots = std::max<int64_t>(a.gscratch_slots, 1);
+            for (int64_t c0 = 0; c0 < a.n_series; c0 += slots) {
+                const int64_t nc = std::min<int64_t>(slots, a.n_series - c0);
+                const int64_t s0 = a.sel ? 0 : c0;   // without a series list the workgroup index IS the series
+                kfn<<<dim3((unsigned)nc), nt, lds, st>>>(values, a.starts + s0, a.ends + s0, nc, a.sel ? a.sel + c0 : nullptr, a.specs,
+                                                        a.nspecs, a.out + s0 * a.ld, a.ld, a.maxn, a.dft_n, a.gscratch,
+                                                        a.gscratch_n, a.bluestein_min, a.twc, a.tws, a.hint_a, a.hint_b, a.consts);
+            }
+#endif
+        } else {
+            auto kfn = k_spectral<T, false>;
+            TSFA_KLAUNCH(kfn, lds, values, a.starts, a.ends, a.n_series, a.sel, a.specs, a.nspecs, a.out, a.ld, a.maxn,
+                         a.dft_n, a.gscratch, a.gscratch_n, a.bluestein_min, a.twc, a.tws, a.hint_a, a.hint_b, a.consts);
+        }
     } else if (a.fam == TSFA_FAM_AR) {
         ArLds L;
         const size_t lds = L.carve(nullptr, a.maxn, a.ar_P, (int)sizeof(T));

@@ -63,6 +63,8 @@ struct TsfaLaunch {
     int pf_cap;             // ... and the records the buffer holds (n_series x distinct (m, r) fits, hints[SORT].e)
     unsigned short *perm_buf;  // ENTROPY (bit-matrix sweep) writes / SORT reads: sample order of every series, perm_stride entries each
     int perm_stride;
+    int64_t gscratch_slots; // SPECTRAL: slots of gscratch_n doubles in gscratch (one per workgroup of a launch)
+    int bluestein_min;      // SPECTRAL: non-power-of-two lengths from here on take the chirp-z transform (with gscratch)
     int cwt_rowv;           // CWT peaks: bit 0: the series is staged in LDS between zero halos; bit 1: phase A on the matrix cores (TSFA_CWT_MFMA=1)
     int hint_a, hint_b, hint_c, hint_d, hint_e;  // tsfa_prepare_family (BASIC, SORT, SPECTRAL, AR)
     unsigned char *long_scratch;  // HBM scratch of the long-series build (tsfa_launch_family_long) ...

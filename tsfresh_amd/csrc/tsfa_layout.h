@@ -113,12 +113,17 @@ struct SpectralLds {
         tc = c.take<double>(nd);
         ts = c.take<double>(nd);
         win = c.take<double>(256);
-        pxx = c.take<double>(132);
+        // tc | ts | win | pxx are contiguous; with nd = 256 and pxx padded to 260 they are also the 1024-double chirp table
+        // of blk_rfft_bluestein (all four are dead by the time the full-length transform runs): chirp_tab()
+        pxx = c.take<double>(dft_n > 0 ? 260 : 132);
         // the bin counters of fourier_entropy (<= 128 ints) live in the Hann window's storage: the window is dead once
         // blk_welch has returned, and the 512 bytes are what kept a tenth workgroup off a CU at 1024 samples (16 480 B)
         iw = (int *)(void *)win;
+        has_chirp_tab = (nd == 256 && dft_n > 0);
         return c.off;
     }
+    bool has_chirp_tab = false;
+    TSFA_HD double *chirp_tab() const { return has_chirp_tab ? tc : nullptr; }
 };
 
 struct ArLds {

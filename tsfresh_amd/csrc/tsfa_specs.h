@@ -186,6 +186,16 @@ static inline int tsfa_pf_slot_doubles(int rmax) { return TSFA_PF_HDR + 2 * rmax
 #define TSFA_AUTOLAG_NONE 3   /* autolag=None: the regression at maxlag */
 #define TSFA_AUTOLAG_TSTAT_STOP 1.6448536269514722   /* stats.norm.ppf(.95), stattools._autolag */
 #define TSFA_CONSTS_HANN 0
+// SPECTRAL: non-power-of-two lengths from here on take the chirp-z transform through HBM scratch (fam_spectral.h), shorter
+// ones the O(n^2) Goertzel sweep.  Round 4's form paid from 4097 samples on (4096..8192: 16.7 -> 14.1 ms per 5 000 series);
+// round 5's (fused cross pass, even lengths as n / 2 complex points) from ~1300: 10 000 series of 1025..2048 samples
+// 1.94 ms with the crossover at 2049, 1.65 at 1793, 1.59 at 1281 (profiles/r05_j_spectral_nt.txt)
+#define TSFA_BLUESTEIN_MIN 1281
+// ... an EVEN length (transformed as n / 2 complex points: half the convolution length) from ~860: 20 000 series of 1000
+// samples 1.56 -> 1.23 ms, 40 000 of 500 samples 1.15 -> 1.99 (profiles/r05_l_spectral_crossover.txt)
+#define TSFA_BLUESTEIN_MIN_EVEN 897
+// both crossovers travel as one kernel argument: odd | even << 16
+#define TSFA_BLUESTEIN_PACK(odd, even) ((odd) | ((even) << 16))
 #define TSFA_CONSTS_RICKER 256
 #define TSFA_CONSTS_MAXW 16
 #define TSFA_CONSTS_N (256 + 5 * TSFA_CONSTS_MAXW * (TSFA_CONSTS_MAXW + 1))
