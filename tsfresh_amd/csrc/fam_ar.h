@@ -512,7 +512,11 @@ TSFA_DEV int fam_ar_series(const Blk &b, X xv, int n, const TsfaSpec *specs, int
     double adf_stat = TSFA_NAN, adf_p = TSFA_NAN, adf_lag = TSFA_NAN;
     if (need_adf) {
         const int maxlag = adf_maxlag_for(n);
-        if (maxlag >= 0 && maxlag + 3 <= P) {
+        // The float64 fit holds one matrix entry per lane (p1 = maxlag + 2 <= 64: series up to 75 969 samples).  Longer series
+        // -- maxlag = ceil(12 (n / 100)^(1/4)) keeps growing -- go to the second pass, whose double-double normal equations
+        // take any p (fam_ar_dd.h; its matrices move to HBM beyond P = 64: tsfa_api.cpp).
+        if (maxlag + 2 > 64) degenerate |= 2;
+        else if (maxlag >= 0 && maxlag + 3 <= P) {
             auto dif = [=](int t) { return (double)xs_lds[t + 1] - (double)xs_lds[t]; };
             const int t0 = maxlag, t1 = n - 1;
             const double nobs = (double)(t1 - t0);

@@ -54,9 +54,19 @@ TSFA_DEV double conv_same_at(X xv, int n, const double *h, int nw, int c) {
 #endif
 #define TSFA_CWTP_HALO ((TSFA_CWTP_MAXTAPS + 1) / 2 + 2)   // zero padding of the staged series on either side
 
+// column / ridge-line indices: 16 bits where a series fits a CU's LDS, 32 bits in the long-series build (series beyond
+// 65 535 samples; the mask stays 16 bits per column: one bit per width + the two marks)
+#if defined(TSFA_LONG)
+typedef unsigned int cwt_idx_t;
+#define TSFA_CWT_IDX_NONE 0xFFFFFFFFu
+#else
+typedef unsigned short cwt_idx_t;
+#define TSFA_CWT_IDX_NONE 0xFFFFu
+#endif
+
 struct CwtPeaksLds {
-    double *red; double *row0; double *rowv; double *taps; void *xpad; unsigned short *mask; unsigned short *lcol;
-    unsigned short *linf; unsigned short *colmap; unsigned short *mline; int *misc;
+    double *red; double *row0; double *rowv; double *taps; void *xpad; unsigned short *mask; cwt_idx_t *lcol;
+    cwt_idx_t *linf; cwt_idx_t *colmap; cwt_idx_t *mline; int *misc;
     const double *rk = nullptr;   // the plan's Ricker tap table (tsfa_build_consts + TSFA_CONSTS_RICKER; global memory), or null
 };
 
@@ -65,7 +75,7 @@ struct CwtPeaksLds {
 #define TSFA_LI_GAP(v) (((v) >> 6) & 3)
 #define TSFA_LI_DEAD(v) (((v) >> 8) & 1)
 #define TSFA_LI_ROW(v) (((v) >> 9) & 15)
-#define TSFA_LI_PACK(len, gap, dead, row) ((unsigned short)(((len) & 63) | (((gap) & 3) << 6) | (((dead) & 1) << 8) | (((row) & 15) << 9)))
+#define TSFA_LI_PACK(len, gap, dead, row) ((cwt_idx_t)(((len) & 63) | (((gap) & 3) << 6) | (((dead) & 1) << 8) | (((row) & 15) << 9)))
 
 // ascending sort of eight values: the 19-comparator network
 TSFA_DEV void sort8_f64(double (&v)[8]) {
@@ -352,9 +362,9 @@ TSFA_DEV void cwt_rows_mfma(const Blk &b, const ST *xpad, int n, int W, const Cw
 //                      per lane) and count the entries whose column falls into their own window until they have seen
 //                      the i0-th and (i0 + 1)-th: ~0.1 n entries for 64 end points at once.
 template <class X>
-TSFA_DEV double cwt_filter_list(const Blk &b, X xv, int n, const CwtPeaksLds &L, const unsigned short *cols,
-                                const unsigned short *rows, int cnt, int hf, int odd, bool taps_cached,
-                                const unsigned short *order, unsigned short extra_bit, double *extra) {
+TSFA_DEV double cwt_filter_list(const Blk &b, X xv, int n, const CwtPeaksLds &L, const cwt_idx_t *cols,
+                                const cwt_idx_t *rows, int cnt, int hf, int odd, bool taps_cached,
+                                const cwt_idx_t *order, unsigned short extra_bit, double *extra) {
     double kept = 0.0, ext = 0.0;
 #if TSFA_GPU
     const int lane = b.tid & 63;
@@ -375,7 +385,7 @@ TSFA_DEV double cwt_filter_list(const Blk &b, X xv, int n, const CwtPeaksLds &L,
             for (int base = 0; base < n; base += 64) {
                 if (!__ballot(count <= i0 + 1)) break;
                 const int e = base + lane;
-                const int pe = (e < n) ? (int)order[e] : 0xFFFF;
+                const int pe = (e < n) ? (int)order[e] : (int)TSFA_CWT_IDX_NONE;   // (beyond every window: 65 535 >= n, or -1)
                 const int lim = (n - base < 64) ? n - base : 64;
                 for (int j = 0; j < lim; ++j) {
                     const int p = __builtin_amdgcn_readlane(pe, j);
@@ -514,7 +524,7 @@ TSFA_DEV double number_cwt_peaks_one(const Blk &b, X xv, int n, int W, const Cwt
             for (int c = cbeg; c < cend; ++c) {
                 if (!(L.mask[c] & sbit)) continue;
                 if (idx < cap) {
-                    L.lcol[idx] = (unsigned short)c;
+                    L.lcol[idx] = (cwt_idx_t)c;
                     L.linf[idx] = TSFA_LI_PACK(1, 0, 0, start_row);
                 }
                 ++idx;
@@ -530,7 +540,7 @@ TSFA_DEV double number_cwt_peaks_one(const Blk &b, X xv, int n, int W, const Cwt
             blk_sync();
             // snapshot: column -> live line (no two live lines share a last column)
             for (int l = b.tid; l < nprev; l += b.nt)
-                if (!TSFA_LI_DEAD(L.linf[l])) L.colmap[L.lcol[l]] = (unsigned short)(l + 1);
+                if (!TSFA_LI_DEAD(L.linf[l])) L.colmap[L.lcol[l]] = (cwt_idx_t)(l + 1);
             blk_sync();
             // every maximum of this row picks the nearest live line (earliest line wins a distance tie)
             int fresh = 0;
@@ -546,7 +556,7 @@ TSFA_DEV double number_cwt_peaks_one(const Blk &b, X xv, int n, int W, const Cwt
                     }
                     line = best;
                 }
-                L.mline[c] = (unsigned short)line;
+                L.mline[c] = (cwt_idx_t)line;
                 fresh += (line == 0) ? 1 : 0;
             }
             int tot;
@@ -554,7 +564,7 @@ TSFA_DEV double number_cwt_peaks_one(const Blk &b, X xv, int n, int W, const Cwt
             for (int c = cbeg; c < cend; ++c) {
                 if (!(L.mask[c] & bit) || L.mline[c] != 0) continue;
                 if (idx < cap) {
-                    L.lcol[idx] = (unsigned short)c;
+                    L.lcol[idx] = (cwt_idx_t)c;
                     L.linf[idx] = TSFA_LI_PACK(1, 0, 0, row);
                 }
                 ++idx;
@@ -564,7 +574,7 @@ TSFA_DEV double number_cwt_peaks_one(const Blk &b, X xv, int n, int W, const Cwt
             blk_sync();
             // every previously live line collects the maxima that chose it (ascending: the last one is its new column)
             for (int l = b.tid; l < nprev; l += b.nt) {
-                const unsigned short v = L.linf[l];
+                const cwt_idx_t v = L.linf[l];
                 if (TSFA_LI_DEAD(v)) continue;
                 const int prev = L.lcol[l];
                 L.colmap[prev] = 0;
@@ -577,7 +587,7 @@ TSFA_DEV double number_cwt_peaks_one(const Blk &b, X xv, int n, int W, const Cwt
                     int len = TSFA_LI_LEN(v) + cnt;
                     if (len > 63) len = 63;
                     L.linf[l] = TSFA_LI_PACK(len, 0, 0, row);
-                    L.lcol[l] = (unsigned short)last;
+                    L.lcol[l] = (cwt_idx_t)last;
                 } else {
                     const int g = TSFA_LI_GAP(v) + 1;
                     L.linf[l] = TSFA_LI_PACK(TSFA_LI_LEN(v), g > 3 ? 3 : g, g > gap_thresh ? 1 : 0, TSFA_LI_ROW(v));
@@ -606,12 +616,12 @@ TSFA_DEV double number_cwt_peaks_one(const Blk &b, X xv, int n, int W, const Cwt
     // Long series: the noise window holds hundreds of samples and its 10th percentile is no longer among the eight
     // smallest: the width-1 row is argsorted ONCE and every entry walks that global order (cwt_filter_list).
     const bool long_windows = ((int)(0.1 * (double)(window - 1)) + 1 >= 8);
-    const unsigned short *order = nullptr;
+    const cwt_idx_t *order = nullptr;
     if (__builtin_expect(long_windows, 0)) {
-        unsigned short *ord = L.colmap;  // colmap and mline are contiguous and dead by now: 2 * maxn >= pow2(n)
+        cwt_idx_t *ord = L.colmap;  // colmap and mline are contiguous and dead by now: 2 * maxn >= pow2(n)
         int np2 = 1;
         while (np2 < n) np2 <<= 1;
-        blk_argsort_u16(b, L.row0, n, ord, np2);
+        blk_argsort_idx<cwt_idx_t>(b, L.row0, n, ord, np2);
         order = ord;
         TSFA_TICK(tk, b, 154);
     }
@@ -631,7 +641,7 @@ TSFA_DEV double number_cwt_peaks_one(const Blk &b, X xv, int n, int W, const Cwt
         const int lbeg = LT * b.tid, lend = (lbeg + LT < nlines) ? lbeg + LT : nlines;
         int mine = 0;
         for (int l = lbeg; l < lend; ++l) {
-            const unsigned short v = L.linf[l];
+            const cwt_idx_t v = L.linf[l];
             const bool qual = TSFA_LI_LEN(v) >= min_length;
             const bool defer = derive_w1 && qual && TSFA_LI_ROW(v) == 0;
             if (defer) L.mask[L.lcol[l]] |= bit_a;
@@ -642,11 +652,11 @@ TSFA_DEV double number_cwt_peaks_one(const Blk &b, X xv, int n, int W, const Cwt
             // another thread has not read yet, then copied to the front of (lcol, linf)
             int idx = blk_excl_sum_small(b, mine, ltbits, &cnt_a);
             for (int l = lbeg; l < lend; ++l) {
-                const unsigned short v = L.linf[l];
+                const cwt_idx_t v = L.linf[l];
                 const int row = TSFA_LI_ROW(v);
                 if (TSFA_LI_LEN(v) < min_length || (derive_w1 && row == 0)) continue;
                 L.mline[idx] = L.lcol[l];
-                L.colmap[idx] = (unsigned short)row;
+                L.colmap[idx] = (cwt_idx_t)row;
                 ++idx;
             }
             blk_sync();
@@ -658,14 +668,14 @@ TSFA_DEV double number_cwt_peaks_one(const Blk &b, X xv, int n, int W, const Cwt
             // (mline, colmap) hold the argsort: compaction in place, a chunk of nt lines at a time
             for (int base = 0; base < nlines; base += b.nt) {
                 const int l = base + b.tid;
-                const unsigned short v = (l < nlines) ? L.linf[l] : 0;
+                const cwt_idx_t v = (l < nlines) ? L.linf[l] : 0;
                 const int col = (l < nlines) ? (int)L.lcol[l] : 0, row = TSFA_LI_ROW(v);
                 const bool take = (l < nlines) && (TSFA_LI_LEN(v) >= min_length) && !(derive_w1 && row == 0);
                 int tot;
                 const int k = cnt_a + blk_excl_count(b, take, &tot);
                 if (take) {
-                    L.lcol[k] = (unsigned short)col;
-                    L.linf[k] = (unsigned short)row;
+                    L.lcol[k] = (cwt_idx_t)col;
+                    L.linf[k] = (cwt_idx_t)row;
                 }
                 cnt_a += tot;
                 blk_sync();
@@ -690,7 +700,7 @@ TSFA_DEV double number_cwt_peaks_one(const Blk &b, X xv, int n, int W, const Cwt
             for (int c = cbeg; c < cend; ++c) mine += (L.mask[c] & 1u) ? 1 : 0;
             int idx = blk_excl_sum_small(b, mine, ctbits, &cnt_b);
             for (int c = cbeg; c < cend; ++c)
-                if (L.mask[c] & 1u) L.lcol[idx++] = (unsigned short)c;
+                if (L.mask[c] & 1u) L.lcol[idx++] = (cwt_idx_t)c;
             blk_sync();
         }
         double marked = 0.0;

@@ -76,7 +76,7 @@ struct tsfa_plan {
     int *d_cols = nullptr, *d_coeff = nullptr;
     double *d_dectab = nullptr, *d_twc = nullptr, *d_tws = nullptr, *d_consts = nullptr;
     long long *d_stats = nullptr;
-    DevBuf values, offsets, out, gscratch, times, deg_list, sel, long_scratch, pf_buf, perm_buf, stats_buf;
+    DevBuf values, offsets, out, gscratch, times, deg_list, sel, long_scratch, pf_buf, perm_buf, stats_buf, dd_scratch;
     int *d_deg_count = nullptr;
     int *d_cursor = nullptr;                    // per-launch-group fill cursors (k_class_fill)
     hipStream_t s_in = nullptr, s_out = nullptr;  // copy-in / copy-out streams of the host pipeline
@@ -187,6 +187,7 @@ void tsfa_plan_destroy(tsfa_plan *plan) {
     plan->offsets.release();
     plan->out.release();
     plan->gscratch.release();
+    plan->dd_scratch.release();
     for (auto &t : plan->timings) {
         if (t.e0) (void)hipEventDestroy(t.e0);
         if (t.e1) (void)hipEventDestroy(t.e1);
@@ -327,7 +328,7 @@ int32_t tsfa_plan_n_cols(const tsfa_plan *plan) { return plan ? plan->n_cols : -
 int tsfa_plan_set_length_hint(tsfa_plan *plan, int64_t min_len, int64_t max_len) {
     if (!plan) return fail(TSFA_ERR_INVALID, "null plan");
     if (max_len == 0 && min_len == 0) { plan->hint_min_len = plan->hint_max_len = 0; return TSFA_OK; }
-    if (min_len < 1 || max_len < min_len || max_len > 65535) return fail(TSFA_ERR_INVALID, "length hint must satisfy 1 <= min <= max <= 65535");
+    if (min_len < 1 || max_len < min_len || max_len > 2147483647LL / 64) return fail(TSFA_ERR_INVALID, "length hint must satisfy 1 <= min <= max <= 33554431");
     plan->hint_min_len = min_len;
     plan->hint_max_len = max_len;
     return TSFA_OK;
@@ -615,6 +616,16 @@ static int run_batch(tsfa_plan *plan, const void *d_values, int dtype, const dou
                 }
                 a.ar_P = P;
                 aux = P;
+                {   // second pass (k_ar_degenerate): double-double normal equations in LDS up to P = 64 (65 535 samples), HBM beyond
+                    ArDdLds D;
+                    if (D.carve(nullptr, P) > TSFA_LDS_LIMIT - 2048) {
+                        const int slots = (int)std::min<int64_t>(a.n_series, 256);
+                        if (plan->dd_scratch.ensure((size_t)slots * (size_t)ArDdLds::scratch_doubles(P) * sizeof(double)))
+                            return fail(TSFA_ERR_HIP, "hipMalloc failed for the second AR pass");
+                        a.dd_scratch = (double *)plan->dd_scratch.p;
+                        a.dd_slots = slots;
+                    }
+                }
                 a.deg_list = (long long *)plan->deg_list.p;
                 a.deg_count = plan->d_deg_count;
                 HIP_TRY(hipMemsetAsync(plan->d_deg_count, 0, sizeof(int), fst));
@@ -828,9 +839,15 @@ static int run_batch(tsfa_plan *plan, const void *d_values, int dtype, const dou
     return TSFA_OK;
 }
 
-static int check_shape(const BatchShape &sh) {
+// Series of any length extract (beyond a CU's LDS from the long-series build: 32-bit indices, working set in HBM) -- except
+// under sample_entropy / approximate_entropy, whose O(n^2) pair sweep keeps 16-bit sample indices: the reference's own
+// approximate_entropy allocates an n x n x m float64 array there (160 GB at 100 000 samples: MemoryError).
+static int check_shape(const tsfa_plan *plan, const BatchShape &sh) {
     if (sh.min_len < 1) return fail(TSFA_ERR_INVALID, "every series must hold at least one sample");
-    if (sh.max_len > 65535) return fail(TSFA_ERR_TOO_LONG, "series longer than 65535 samples are not supported");
+    if (sh.max_len > 65535 && !plan->fam_specs[TSFA_FAM_ENTROPY].empty())
+        return fail(TSFA_ERR_TOO_LONG, "sample_entropy / approximate_entropy: series longer than 65535 samples are not supported "
+                                       "(O(n^2); every other calculator takes any length)");
+    if (sh.max_len > 2147483647LL / 64) return fail(TSFA_ERR_TOO_LONG, "series longer than 33 554 431 samples are not supported");
     return TSFA_OK;
 }
 
@@ -904,7 +921,7 @@ int tsfa_extract_windows(tsfa_plan *plan, const void *values, int32_t dtype, con
             HIP_TRY(hipStreamSynchronize(st));
             shape_from_stats(h_stats, n_series, sh);
         }
-        int rc = check_shape(sh);
+        int rc = check_shape(plan, sh);
         if (rc) return rc;
         int *d_sel = nullptr;
         if (sh.n_groups > 1) {
@@ -939,7 +956,7 @@ int tsfa_extract_windows(tsfa_plan *plan, const void *values, int32_t dtype, con
     {
         BatchShape whole;
         shape_from_stats(h_stats, n_series, whole);
-        const int rc = check_shape(whole);
+        const int rc = check_shape(plan, whole);
         if (rc) return rc;
     }
     int64_t base = starts[0], top = ends[0];

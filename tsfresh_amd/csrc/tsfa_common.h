@@ -735,11 +735,14 @@ TSFA_DEV void blk_bitonic_sort(const Blk &b, K *a, int npow2) {
     blk_sync();
 }
 
-// perm[0 .. np2) = indices 0 .. n-1 sorted ascending by key[index] (ties by index), padded with 0xFFFF (key +inf).
-// In-LDS bitonic network on the indices; np2 = power of two >= n.
-TSFA_DEV void blk_argsort_u16(const Blk &b, const double *key, int n, unsigned short *perm, int np2) {
+// perm[0 .. np2) = indices 0 .. n-1 sorted ascending by key[index] (ties by index), padded with the index type's largest
+// value (key +inf).  In-LDS bitonic network on the indices; np2 = power of two >= n.  IDX: unsigned short (n <= 65 535) or
+// unsigned int (the long-series build).
+template <class IDX>
+TSFA_DEV void blk_argsort_idx(const Blk &b, const double *key, int n, IDX *perm, int np2) {
+    const IDX none = (IDX)~(IDX)0;
     blk_sync();
-    for (int i = b.tid; i < np2; i += b.nt) perm[i] = (unsigned short)((i < n) ? i : 0xFFFF);
+    for (int i = b.tid; i < np2; i += b.nt) perm[i] = (i < n) ? (IDX)i : none;
     for (int k = 2; k <= np2; k <<= 1) {
         for (int j = k >> 1; j > 0; j >>= 1) {
             blk_sync();
@@ -747,8 +750,8 @@ TSFA_DEV void blk_argsort_u16(const Blk &b, const double *key, int n, unsigned s
                 const int i = ((t & ~(j - 1)) << 1) | (t & (j - 1));
                 const int l = i | j;
                 const bool up = ((i & k) == 0);
-                const unsigned short a = perm[i], c = perm[l];
-                const double ka = (a == 0xFFFF) ? TSFA_INF : key[a], kc = (c == 0xFFFF) ? TSFA_INF : key[c];
+                const IDX a = perm[i], c = perm[l];
+                const double ka = (a == none) ? TSFA_INF : key[a], kc = (c == none) ? TSFA_INF : key[c];
                 const bool gt = (ka > kc) || (ka == kc && a > c);
                 if (gt == up) {
                     perm[i] = c;
@@ -758,6 +761,9 @@ TSFA_DEV void blk_argsort_u16(const Blk &b, const double *key, int n, unsigned s
         }
     }
     blk_sync();
+}
+TSFA_DEV void blk_argsort_u16(const Blk &b, const double *key, int n, unsigned short *perm, int np2) {
+    blk_argsort_idx<unsigned short>(b, key, n, perm, np2);
 }
 
 #if TSFA_GPU

@@ -303,9 +303,13 @@ __global__ void __launch_bounds__(64) k_langevin_dd(const double *__restrict__ p
 template <typename T>
 __global__ void __launch_bounds__(64) k_ar_degenerate(const T *__restrict__ values, const int64_t *__restrict__ starts, const int64_t *__restrict__ ends,
                      const TsfaSpec *__restrict__ specs, int nspecs, double *__restrict__ out, int64_t ld, int P,
-                     const long long *__restrict__ deg_list, const int *__restrict__ deg_count, int adf_mode) {
+                     const long long *__restrict__ deg_list, const int *__restrict__ deg_count, int adf_mode,
+                     double *__restrict__ gscratch) {
     ArDdLds L;
     L.carve(tsfa_smem, P);
+    // matrices beyond a CU's LDS (ADF's maxlag grows with the length: P = 71 at 100 000 samples is 173 KB of double-double
+    // normal equations): a slot of HBM scratch per workgroup instead, the reduction scratch stays in LDS
+    if (gscratch != nullptr) L.scratch = gscratch + (size_t)blockIdx.x * (size_t)ArDdLds::scratch_doubles(P);
     Blk b{(int)threadIdx.x, (int)blockDim.x, L.red, nullptr};
     const int cnt = *deg_count;
     for (int i = blockIdx.x; i < cnt; i += gridDim.x) {
@@ -915,6 +919,9 @@ static int set_lds(K kern, size_t bytes) {
         const int64_t slots_ = (int64_t)(a.long_bytes / slot_);                                            \
         if (!a.long_scratch || slots_ < 1) return -2;                                                      \
         const dim3 lgrid_((unsigned)std::min<int64_t>(a.n_series, std::min<int64_t>(slots_, 2048)));       \
+        if (getenv("TSFA_DEBUG_LAUNCH"))                                                                   \
+            fprintf(stderr, "[tsfa] long launch fam %d: grid %u nt %d slot %zu bytes, scratch %zu, pending error %d\n", a.fam, \
+                    lgrid_.x, nt, slot_, a.long_bytes, (int)hipPeekAtLastError());                         \
         kern<<<lgrid_, nt, 0, st>>>(__VA_ARGS__, a.long_scratch, slot_);                                   \
     } while (0)
 #else
@@ -1058,11 +1065,15 @@ static int launch_ar_degenerate_t(const TsfaLaunch &a, const T *values) {
     hipStream_t st = (hipStream_t)a.stream;
     int rc;
     ArDdLds D;
-    const size_t dlds = D.carve(nullptr, a.ar_P);
+    size_t dlds = D.carve(nullptr, a.ar_P);
+    unsigned dgrid = (unsigned)std::min<int64_t>(a.n_series, 4096);
+    if (a.dd_scratch != nullptr) {   // the plan found the matrices too large for LDS (tsfa_api.cpp): one HBM slot per workgroup
+        dlds = (size_t)TSFA_RED_DOUBLES * sizeof(double) + 64;
+        dgrid = (unsigned)std::max<int64_t>(1, std::min<int64_t>(a.n_series, a.dd_slots));
+    }
     if ((rc = set_lds(k_ar_degenerate<T>, dlds))) return rc;
-    const unsigned dgrid = (unsigned)std::min<int64_t>(a.n_series, 4096);
     k_ar_degenerate<T><<<dgrid, 64, dlds, st>>>(values, a.starts, a.ends, a.specs, a.nspecs, a.out, a.ld, a.ar_P, a.deg_list,
-                                                a.deg_count, (a.hint_c >> 1) & 3);
+                                                a.deg_count, (a.hint_c >> 1) & 3, a.dd_scratch);
     TSFA_LAUNCH_CHECK();
     return 0;
 }
@@ -1099,7 +1110,11 @@ size_t tsfa_family_lds_bytes(int fam, int maxn, int nt, int aux) {
     case TSFA_FAM_SORT: { SortLds L; return L.carve(nullptr, maxn, nt); }
     case TSFA_FAM_SPECTRAL: { SpectralLds L; return L.carve(nullptr, maxn, aux); }
     case TSFA_FAM_AR: { ArLds L; return L.carve(nullptr, maxn, aux); }
-    case TSFA_FAM_CWT: { CwtPeaksLayout L; return L.carve(nullptr, maxn, aux); }
+    case TSFA_FAM_CWT: {   // beyond a CU's LDS the long-series build runs, with 32-bit column indices
+        CwtPeaksLayout L;
+        const size_t lds16 = L.carve(nullptr, maxn, aux, 8, 2);
+        return lds16 > TSFA_LDS_LIMIT ? L.carve(nullptr, maxn, aux, 8, 4) : lds16;
+    }
     default: return 0;
     }
 }

@@ -51,6 +51,8 @@ struct TsfaLaunch {
     int gscratch_n;
     TsfaSeqGroup seq;       // SEQ: the (<= TSFA_LZ_MAX_GROUP) specs this launch parses side by side
     int ar_P;               // AR: leading dimension of the normal matrices
+    double *dd_scratch;     // AR second pass: HBM slots for double-double matrices beyond LDS (or null), dd_slots of them
+    int dd_slots;
     int ar_has_coef;        // AR: the plan holds ar_coefficient columns
     long long *deg_list;    // AR: series listed for the double-double second pass ((index << 2) | calculator bits) ...
     int *deg_count;         // ... and their number (device; zeroed before the launch)

@@ -228,7 +228,8 @@ struct CwtPeaksLayout {
     // mode 1: the series is staged between zero halos (register-tiled convolutions, no second row needed);
     // mode 0: no staging (very long series): the CWT rows are evaluated column by column from HBM
     // xs_bytes: element size of the padded copy (4: float32 input kept as float32, 8: float64)
-    TSFA_HD size_t carve(unsigned char *base, int maxn, int mode, int xs_bytes = 8) {
+    // idx_bytes: size of a column / line index (cwt_idx_t of the build that runs; the host asks with 4 for the long-series build)
+    TSFA_HD size_t carve(unsigned char *base, int maxn, int mode, int xs_bytes = 8, int idx_bytes = (int)sizeof(cwt_idx_t)) {
         LdsCarve c{base, 0};
         p.red = c.take<double>(TSFA_RED_DOUBLES);
         p.row0 = c.take<double>(maxn + 4);
@@ -236,9 +237,9 @@ struct CwtPeaksLayout {
         p.xpad = mode ? (void *)c.take<unsigned char>((size_t)(maxn + 2 * TSFA_CWTP_HALO + 8) * xs_bytes) : nullptr;
         p.taps = c.take<double>(TSFA_CWTP_MAXTAPS + 16);
         p.mask = c.take<unsigned short>(maxn);
-        p.lcol = c.take<unsigned short>(2 * (size_t)maxn + 8);  // lcol | linf, contiguous: phase A's edge values (16 B per 4 columns)
+        p.lcol = (cwt_idx_t *)(void *)c.take<unsigned char>((2 * (size_t)maxn + 8) * idx_bytes);  // lcol | linf, contiguous: phase A's edge values (16 B per 4 columns)
         p.linf = p.lcol + maxn;
-        p.colmap = c.take<unsigned short>(2 * (size_t)maxn);  // colmap | mline, contiguous: phase C argsorts into both
+        p.colmap = (cwt_idx_t *)(void *)c.take<unsigned char>(2 * (size_t)maxn * idx_bytes);  // colmap | mline, contiguous: phase C argsorts into both
         p.mline = p.colmap + maxn;
         p.misc = c.take<int>(8);
         return c.off;
