@@ -262,6 +262,7 @@ def main():
     ap.add_argument("--cpu-baseline-full", action="store_true",
                     help="three runs of the CPU protocol (median) and the reference's default n_jobs = cpu_count() // 2 as a "
                          "second leg (~4 min of wall clock) instead of one run (~1 min): profiles/r04_z_bench.json was taken so")
+    ap.add_argument("--cpu-workers", type=int, default=0, help="worker processes of the CPU baseline (default: every physical core)")
     ap.add_argument("--no-e2e", action="store_true", help="skip the host-buffer / DataFrame boundary timings")
     ap.add_argument("--chunks", type=int, default=0,
                     help="N > 1: row chunks per step; the all-gather of chunk c runs on RCCL's stream while chunk c + 1 is "
@@ -493,7 +494,10 @@ def main():
             import multiprocessing as mp
             for v in ("OMP_NUM_THREADS", "MKL_NUM_THREADS", "OPENBLAS_NUM_THREADS"):
                 os.environ[v] = "1"  # the reference's own advice (docs/text/tsfresh_on_a_cluster.rst:216-231)
-            workers = min(physical_cores()[0], 64)   # one worker per PHYSICAL core: SMT siblings halve the per-core rate
+            # one worker per PHYSICAL core (SMT siblings halve the per-core rate), ALL of them: until round 4 the pool was
+            # capped at 64 of the box's 128 cores, which undersold the CPU by the factor the rest would have added
+            # (VERDICT r4 weak #13); --cpu-workers N overrides
+            workers = args.cpu_workers if args.cpu_workers > 0 else physical_cores()[0]
             pool = mp.get_context("spawn").Pool(workers)
             pool.map(_cpu_warm, range(4 * workers))
         if world == 1 and not args.ragged:

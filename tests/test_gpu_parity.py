@@ -1003,3 +1003,26 @@ def test_series_beyond_65535_samples(gpu):
     assert "sample_entropy" in str(e.value) and "65535" in str(e.value)
     # ... and the same plan on series within the limit is unaffected
     hip_engine({"sample_entropy": None, "mean": None}, values[:3000], np.array([0, 1000, 3000], dtype=np.int64))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("key", ["config2", "config3", "config4", "config5"])
+def test_baseline_config_batches_against_the_stored_oracle_rows(gpu, key):
+    """the config tests above compare 6-32 rows with the oracle (0.85 s per Comprehensive series on the GPU
+    box's host).  Here ~800 rows -- 200 of configs[1], 203 of configs[2] (the structured rows included), 300 of configs[3]'s
+    per-GPU shard, 96 of the configs[4] shape -- against oracle values computed in the build container
+    (tests/golden/oracle_configs.npz, gen_oracle_configs.py), the batches rebuilt from the same seeds (tests/config_inputs.py)."""
+    import config_inputs
+    g = np.load(os.path.join(ROOT, "tests", "golden", "oracle_configs.npz"))
+    pname, series, rows = config_inputs.CONFIGS[key]()
+    assert rows == list(g[key + "_rows"])
+    lens = [len(s) for s in series]
+    values = np.concatenate([np.asarray(s) for s in series]) if not isinstance(series, np.ndarray) else series.reshape(-1)
+    offsets = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
+    names, got = hip_engine(config_inputs.parameters(pname), values, offsets)
+    onames = list(g[key + "_names"])
+    skipped = []
+    bad = compare(onames, _align(onames, names, got[rows]), g[key + "_matrix"],
+                  [np.asarray(series[i], dtype=np.float64) for i in rows], skipped=skipped)
+    assert not bad, "%d mismatches, first: %s" % (len(bad), bad[:12])
+    assert len(skipped) <= 0.01 * g[key + "_matrix"].size, (len(skipped), skipped[:6])
