@@ -494,10 +494,11 @@ def main():
             import multiprocessing as mp
             for v in ("OMP_NUM_THREADS", "MKL_NUM_THREADS", "OPENBLAS_NUM_THREADS"):
                 os.environ[v] = "1"  # the reference's own advice (docs/text/tsfresh_on_a_cluster.rst:216-231)
-            # one worker per PHYSICAL core (SMT siblings halve the per-core rate), ALL of them: until round 4 the pool was
-            # capped at 64 of the box's 128 cores, which undersold the CPU by the factor the rest would have added
-            # (VERDICT r4 weak #13); --cpu-workers N overrides
-            workers = args.cpu_workers if args.cpu_workers > 0 else physical_cores()[0]
+            # one worker per PHYSICAL core (SMT siblings halve the per-core rate), at most 64: measured on the 128-core box of
+            # round 5 (profiles/r05_z_bench.json vs r05_zz), 128 workers give the CPU a LOWER total -- 31.3 series/s in 131 s
+            # against 37.4 in 55 s with 64 (memory bandwidth: the numpy port streams n x n / 2 intermediate arrays) -- so 64
+            # is the CPU's best showing here, and it keeps the default run within minutes; --cpu-workers N overrides
+            workers = args.cpu_workers if args.cpu_workers > 0 else min(physical_cores()[0], 64)
             pool = mp.get_context("spawn").Pool(workers)
             pool.map(_cpu_warm, range(4 * workers))
         if world == 1 and not args.ragged:

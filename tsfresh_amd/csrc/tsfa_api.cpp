@@ -590,9 +590,11 @@ static int run_batch(tsfa_plan *plan, const void *d_values, int dtype, const dou
                         a.gscratch_n = (int)(4 * M);
                         a.gscratch_slots = slots;
                         // the transform's passes over its HBM scratch want more wavefronts than the LDS-resident phases
-                        // (profiles/r05_j: 1025..2048 samples 1.76 -> 1.59 ms at 256 threads, 2049..4096 2.36 -> 2.28 at 512)
-                        // (up to 1280 samples -- even lengths from 897 -- the family's own 128 stay: 20 000 x 1000 1.47 -> 1.23 ms)
-                        if (!getenv("TSFA_NT_2") && maxn > 1280) a.nt = (maxn <= 2048) ? 256 : 512;
+                        // (profiles/r05_j: 2049..4096 samples 2.36 -> 2.28 ms at 512 threads).  Up to 2048 samples the family's
+                        // own 128 stay although 256 measured faster on 1025..2048 (1.76 -> 1.59 ms): there the workgroup size
+                        // is the same for every launch group, and the Welch sums depend on it in the last bit -- a series must
+                        // give the same bits in whatever shard it lands (test_extract_features_on_several_devices_from_one_process)
+                        if (!getenv("TSFA_NT_2") && maxn > 2048) a.nt = 512;
                     }
                 }
             } else if (f == TSFA_FAM_CWT) {
