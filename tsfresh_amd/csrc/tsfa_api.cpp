@@ -753,7 +753,9 @@ static int run_batch(tsfa_plan *plan, const void *d_values, int dtype, const dou
                 if (plan->hints[f].d != 0) {
                     const int pnt = (maxn <= 2048) ? std::min(256, std::max(64, ((maxn / 4 + 63) / 64) * 64))
                                                    : std::min(1024, ((maxn / 8 + 63) / 64) * 64);
-                    if (tsfa_perm_lds_bytes(maxn, pnt, dtype == TSFA_F32 ? 4 : 8) <= TSFA_LDS_LIMIT) {
+                    // (k_perm packs two 16-bit counters per word: safe while a series holds at most 65 535 windows -- LDS
+                    //  admits 40 960 float32 samples; asserted here rather than implied, round-4 ADVICE)
+                    if (maxn <= 65535 && tsfa_perm_lds_bytes(maxn, pnt, dtype == TSFA_F32 ? 4 : 8) <= TSFA_LDS_LIMIT) {
                         a.hint_d = plan->hints[f].d;
                         TsfaLaunch pa = a;
                         pa.nt = pnt;
