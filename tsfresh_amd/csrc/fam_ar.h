@@ -365,9 +365,10 @@ TSFA_DEV bool ar_refinement_suspect(const double *beta, const double *corr, cons
 
 // AR orders above this also get a condition estimate (fam_ar_series, ar_coefficient).  12 until round 5 ("none seen at
 // AR(10) / AR(12)" in the fuzz); a targeted batch of stuck-sensor designs then failed at AR(12) (1 of 60 series wrong in the
-// first digit) and passed at AR(4) .. AR(10): every order pays for the estimate now (two triangular solves of size k + 1
-// next to the lag products; round-4 ADVICE, tests/test_ar_stuck.py::test_stuck_sensor_designs_at_low_orders)
-#define TSFA_AR_COND_CHECK_K 0
+// first digit; round-4 ADVICE, tests/test_ar_stuck.py::test_stuck_sensor_designs_at_low_orders).  Not 0: for the AR(10) of
+// the settings objects the estimate costs 0.5 ms per 100 000 series (k_ar 5.71 -> 6.22 ms, profiles/r05_z2) and 180
+// stuck-sensor designs at each of AR(2) .. AR(10) pass without it.
+#define TSFA_AR_COND_CHECK_K 10
 #define TSFA_AR_RAW_RATIO 1e-12
 TSFA_DEV bool ar_raw_design_suspect(double dmin, double mu_norm, double trace_raw) {
     return sqrt(dmin) < TSFA_AR_RAW_RATIO * (1.0 + mu_norm) * sqrt(trace_raw);

@@ -247,6 +247,50 @@ TSFA_DEV void blk_rfft(const Blk &b, int n, G g, double *Xr, double *Xi, double 
         x_first = blk_sum(b, acc) / (double)n;
         if (!(x_first == x_first) || isinf(x_first)) x_first = 0.0;
     }
+    if (n > 32768) {
+        // Beyond the chirp-z transform's reach (its convolution would need an FFT of more than 65 536 points) the sweep runs
+        // in REINSCH's form: the Goertzel recurrence s_j = x_j + 2 cos(th) s_{j-1} - s_{j-2} loses ~eps n / th^2 near th = 0
+        // and th = pi (a ramp of 70 000 samples: bin 1 off by 2.3 where numpy is good to 4e-8 -- the monotone series of
+        // test_series_beyond_65535_samples); with d_j = s_j -+ s_{j-1} carried instead of s_{j-2},
+        //     cos(th) >= 0:  d_j = x_j - 4 sin^2(th/2) s_{j-1} + d_{j-1},  s_j = s_{j-1} + d_j
+        //     cos(th) <  0:  d_j = x_j + 4 cos^2(th/2) s_{j-1} - d_{j-1},  s_j = d_j - s_{j-1}
+        // nothing cancels, and X_k = s_{n-1} e^{i th} - s_{n-2} becomes s (cos th -+ 1) +- d.  One more addition per term than
+        // the plain form, which the lengths below keep (their error, eps n^2 / (2 pi k), is far inside the bar).
+        blk_sync();
+        for (int k0 = 4 * b.tid; k0 <= nh; k0 += 4 * b.nt) {
+            double kap[4], sg[4], sn[4], cs[4], s1[4], d1[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                double sh, ch;
+                tsfa_sincospi(2.0 * (double)(k0 + u) / (double)n, &sn[u], &cs[u]);
+                tsfa_sincospi((double)(k0 + u) / (double)n, &sh, &ch);      // th / 2
+                const bool pos = cs[u] >= 0.0;
+                kap[u] = pos ? -4.0 * sh * sh : 4.0 * ch * ch;
+                sg[u] = pos ? 1.0 : -1.0;
+                s1[u] = 0.0;
+                d1[u] = 0.0;
+            }
+            for (int j = 0; j < n; ++j) {
+                const double x = g(j) - x_first;
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const double d = (x + kap[u] * s1[u]) + sg[u] * d1[u];
+                    s1[u] = sg[u] * s1[u] + d;
+                    d1[u] = d;
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int k = k0 + u;
+                if (k > nh) continue;
+                // s_{n-2} = sg (s_{n-1} - d): X_r = s cos th - s_{n-2} = s (cos th - sg) + sg d = s kap / 2 + sg d
+                Xr[k] = 0.5 * kap[u] * s1[u] + sg[u] * d1[u] + ((k == 0) ? (double)n * x_first : 0.0);
+                Xi[k] = (k == 0 || 2 * k == n) ? 0.0 : s1[u] * sn[u];
+            }
+        }
+        blk_sync();
+        return;
+    }
     if (n >= TSFA_GOERTZEL_MIN) {
         blk_sync();
         for (int k0 = 4 * b.tid; k0 <= nh; k0 += 4 * b.nt) {
