@@ -58,6 +58,15 @@ def test_without_a_launcher_gpus_n_spawns_n_ranks(monkeypatch):
     assert cmd[cmd.index("--nproc-per-node") + 1] == "4" and cmd[-4:] == ["--gpus", "4", "--steps", "3"]
 
 
+def test_strong_scaling_flag_reaches_the_ranks_unchanged():
+    """`--strong --n-series TOTAL` (configs[3]: 1 M x 256 split over N): the self-launch hands the flag to every rank; a rank
+    derives its share from WORLD_SIZE (bench.py main)."""
+    import bench
+    argv = ["--gpus", "8", "--strong", "--n-series", "1000000", "--length", "256"]
+    cmd, _ = bench.self_launch_command(8, argv, 29999)
+    assert cmd[-len(argv):] == argv
+
+
 @pytest.mark.gpu
 def test_bench_self_launch_path_on_one_gpu(gpu):
     """`python bench.py --gpus 1` THROUGH the self-launch path (torch.distributed.run, one rank, RCCL communicator of
