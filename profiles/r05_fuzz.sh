@@ -4,6 +4,6 @@
 TAG=${1:-r05_y}
 export TMPDIR=/tmp
 O=gpurun_out/$TAG; mkdir -p $O
-( timeout 500 python profiles/fuzz_parity.py 40 5101; TSFA_FUZZ_PARAMS=random timeout 500 python profiles/fuzz_parity.py 40 5102;
-  TSFA_FUZZ_MAXLENS="300,1024,2500,4500,9000" timeout 500 python profiles/fuzz_parity.py 16 5103 ) > $O/fuzz_gpu.log 2>&1
+( timeout 500 python profiles/fuzz_parity.py 36 ${SEED:-5101}; TSFA_FUZZ_PARAMS=random timeout 500 python profiles/fuzz_parity.py 36 $((${SEED:-5101}+1));
+  TSFA_FUZZ_MAXLENS="300,1024,2500,4500,9000" timeout 500 python profiles/fuzz_parity.py 12 $((${SEED:-5101}+2)) ) > $O/fuzz_gpu.log 2>&1
 grep -c "^round" $O/fuzz_gpu.log; grep "TOTAL\|UNWRITTEN" $O/fuzz_gpu.log
