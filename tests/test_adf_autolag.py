@@ -109,3 +109,64 @@ def test_the_string_none_is_not_none(engine):
     assert abs(got[0, 0] - (-4.437821986643767)) < 1e-9
     _, got = engine({"augmented_dickey_fuller": [{"attr": "teststat", "autolag": "bic"}]}, x, o)
     assert abs(got[0, 0] - (-13.046525438501202)) < 1e-8
+
+
+def test_several_autolag_values_in_one_settings_object(monkeypatch):
+    """fc.py:499-545 evaluates every dict of the list on its own, so a settings object may mix lag selections; a native plan
+    holds one (tsfa_validate_plan).  extract_features splits such a plan into one native plan per value and scatters the
+    columns back (feature_extraction/extraction.py: _CompositePlan) -- here with the emulated kernels behind the parts."""
+    import pandas as pd
+    from emul_lib import emul_extract_specs
+    from tsfresh_amd import extract_features
+    from tsfresh_amd.feature_extraction import extraction
+
+    class _Part:
+        def __init__(self, specs):
+            self.specs = list(specs)
+
+        def extract_host(self, values, offsets, times=None):
+            return emul_extract_specs(self.specs, values, offsets, times=times)
+
+    made = []
+    monkeypatch.setattr(extraction, "_acquire_plan_specs", lambda specs, device, pins=None: made.append(len(list(specs))) or _Part(specs))
+    rng = np.random.default_rng(8)
+    lens = [120, 300, 75]
+    df = pd.DataFrame({"id": np.repeat(np.arange(3), lens), "time": np.concatenate([np.arange(m) for m in lens]),
+                       "value": np.concatenate([np.cumsum(rng.standard_normal(m)) for m in lens])})
+    params = {"mean": None,
+              "augmented_dickey_fuller": [{"attr": "teststat", "autolag": "BIC"}, {"attr": "pvalue", "autolag": "AIC"},
+                                          {"attr": "usedlag", "autolag": None}, {"attr": "teststat", "autolag": "AIC"},
+                                          {"attr": "teststat", "autolag": "bogus"}, {"attr": "usedlag", "autolag": "t-stat"}],
+              "median": None}
+    got = extract_features(df, column_id="id", column_sort="time", default_fc_parameters=params, device=0)
+    assert made == [4, 2, 1, 1]          # mean + BIC + the NaN column + median | AIC x 2 | None | t-stat
+    values = df["value"].to_numpy()
+    offsets = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
+    onames, want = oracle_engine(params, values, offsets)
+    assert list(got.columns) == onames
+    bad = compare(onames, got.to_numpy(), want, [values[offsets[i]:offsets[i + 1]] for i in range(3)])
+    assert not bad, bad
+    assert got['value__augmented_dickey_fuller__attr_"teststat"__autolag_"bogus"'].isna().all()
+
+
+@pytest.mark.gpu
+def test_hip_several_autolag_values_in_one_settings_object(gpu):
+    """The same through the real native plans (one per lag selection), also for rolled windows."""
+    import pandas as pd
+    from tsfresh_amd import extract_features
+    rng = np.random.default_rng(8)
+    lens = [120, 300, 75, 1024]
+    df = pd.DataFrame({"id": np.repeat(np.arange(4), lens), "time": np.concatenate([np.arange(m) for m in lens]),
+                       "value": np.concatenate([np.cumsum(rng.standard_normal(m)) for m in lens])})
+    params = {"mean": None,
+              "augmented_dickey_fuller": [{"attr": "teststat", "autolag": "BIC"}, {"attr": "pvalue", "autolag": "AIC"},
+                                          {"attr": "usedlag", "autolag": None}, {"attr": "teststat", "autolag": "AIC"},
+                                          {"attr": "teststat", "autolag": "bogus"}, {"attr": "usedlag", "autolag": "t-stat"}],
+              "median": None}
+    got = extract_features(df, column_id="id", column_sort="time", default_fc_parameters=params, device=0)
+    values = df["value"].to_numpy()
+    offsets = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
+    onames, want = oracle_engine(params, values, offsets)
+    assert list(got.columns) == onames
+    bad = compare(onames, got.to_numpy(), want, [values[offsets[i]:offsets[i + 1]] for i in range(4)])
+    assert not bad, bad

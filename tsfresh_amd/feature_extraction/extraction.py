@@ -84,8 +84,54 @@ def _thread_cache():
     return cache
 
 
+class _CompositePlan:
+    """Several native plans behind one plan's `extract_host` / `extract_windows_host`: the columns of a settings object that
+    one native plan cannot hold together.  Today that is `augmented_dickey_fuller` with more than one `autolag` value
+    (fc.py:499-545 evaluates every dict of the list on its own; the kernels hold ONE lag-search fit per series, so
+    `tsfa_plan_create` takes one value per plan): the first part carries every other column + the first value's, the
+    others one value each; results are scattered into the caller's column order."""
+
+    def __init__(self, parts, n_cols):
+        self.parts = parts          # [(native plan, column indices in the full matrix)]
+        self.n_cols = int(n_cols)
+
+    def _gather(self, n_rows, run):
+        out = _native._result_matrix(n_rows, self.n_cols)
+        for plan, cols in self.parts:
+            out[:, cols] = run(plan)
+        return out
+
+    def extract_host(self, values, offsets, times=None):
+        return self._gather(len(offsets) - 1, lambda pl: pl.extract_host(values, offsets, times=times))
+
+    def extract_windows_host(self, values, starts, ends, times=None):
+        return self._gather(len(starts), lambda pl: pl.extract_windows_host(values, starts, ends, times=times))
+
+
+def _split_native_specs(specs):
+    """-> [(sub-list of specs, their column indices)]: one part unless augmented_dickey_fuller columns name several lag
+    selections (p[1]; attr code 3 -- a column that is NaN whatever the fit -- belongs to any part)."""
+    adf = _native.calc_id("augmented_dickey_fuller")
+    modes = []
+    for cid, p in specs:
+        if cid == adf and int(p[0]) != 3 and float(p[1]) not in modes:
+            modes.append(float(p[1]))
+    if len(modes) <= 1:
+        return [(list(specs), list(range(len(specs))))]
+    parts = [([], []) for _ in modes]
+    for j, (cid, p) in enumerate(specs):
+        k = modes.index(float(p[1])) if (cid == adf and int(p[0]) != 3) else 0
+        parts[k][0].append((cid, p))
+        parts[k][1].append(j)
+    return parts
+
+
 def _acquire_plan(fplan, device, pins=None):
-    return _acquire_plan_specs(fplan.native_specs(_native.calc_id), device, pins)
+    specs = list(fplan.native_specs(_native.calc_id))
+    parts = _split_native_specs(specs)
+    if len(parts) == 1:
+        return _acquire_plan_specs(specs, device, pins)
+    return _CompositePlan([(_acquire_plan_specs(sub, device, pins), cols) for sub, cols in parts], len(specs))
 
 
 def _trim_cache(cache, pins=()):
