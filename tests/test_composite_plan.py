@@ -1,0 +1,60 @@
+"""Settings objects one native plan cannot hold together are split by extract_features into several native plans whose
+columns are scattered back (feature_extraction/extraction.py: _CompositePlan): more than 128 cwt_coefficients columns
+(fc.py:1370 takes any list), several augmented_dickey_fuller lag selections (tests/test_adf_autolag.py)."""
+import numpy as np
+import pandas as pd
+import pytest
+
+from engines import oracle_engine
+from parity import compare
+
+WIDTHS = (1, 2, 3, 4, 5, 6, 8, 10, 12, 20)
+PARAMS = {"mean": None,
+          "cwt_coefficients": [{"widths": WIDTHS, "coeff": c, "w": w} for w in WIDTHS for c in range(15)],   # 150 columns
+          "median": None}
+
+
+def _frame():
+    rng = np.random.default_rng(4)
+    lens = [64, 200, 31]
+    df = pd.DataFrame({"id": np.repeat(np.arange(3), lens), "time": np.concatenate([np.arange(m) for m in lens]),
+                       "value": np.concatenate([rng.standard_normal(m) for m in lens])})
+    return df, lens
+
+
+def _check(got, df, lens):
+    values = df["value"].to_numpy()
+    offsets = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
+    onames, want = oracle_engine(PARAMS, values, offsets)
+    assert list(got.columns) == onames and got.shape == (3, 152)
+    bad = compare(onames, got.to_numpy(), want, [values[offsets[i]:offsets[i + 1]] for i in range(3)])
+    assert not bad, bad[:6]
+
+
+def test_more_cwt_columns_than_one_native_plan_holds(monkeypatch):
+    from emul_lib import emul_extract_specs
+    from tsfresh_amd import _native, extract_features
+    from tsfresh_amd.feature_extraction import extraction
+
+    class _Part:
+        def __init__(self, specs):
+            self.specs = list(specs)
+
+        def extract_host(self, values, offsets, times=None):
+            return emul_extract_specs(self.specs, values, offsets, times=times)
+
+    made = []
+    cwt = _native.calc_id("cwt_coefficients")
+    monkeypatch.setattr(extraction, "_acquire_plan_specs",
+                        lambda specs, device, pins=None: made.append(sum(1 for c, _ in specs if c == cwt)) or _Part(specs))
+    df, lens = _frame()
+    got = extract_features(df, column_id="id", column_sort="time", default_fc_parameters=PARAMS, device=0)
+    assert made == [128, 22]
+    _check(got, df, lens)
+
+
+@pytest.mark.gpu
+def test_hip_more_cwt_columns_than_one_native_plan_holds(gpu):
+    from tsfresh_amd import extract_features
+    df, lens = _frame()
+    _check(extract_features(df, column_id="id", column_sort="time", default_fc_parameters=PARAMS, device=0), df, lens)

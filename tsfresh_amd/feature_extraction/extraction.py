@@ -84,12 +84,16 @@ def _thread_cache():
     return cache
 
 
+_CWT_COLUMNS_PER_PLAN = 128   # tsfa_api.cpp: "more than 128 cwt_coefficients columns in one plan"
+
+
 class _CompositePlan:
     """Several native plans behind one plan's `extract_host` / `extract_windows_host`: the columns of a settings object that
-    one native plan cannot hold together.  Today that is `augmented_dickey_fuller` with more than one `autolag` value
-    (fc.py:499-545 evaluates every dict of the list on its own; the kernels hold ONE lag-search fit per series, so
-    `tsfa_plan_create` takes one value per plan): the first part carries every other column + the first value's, the
-    others one value each; results are scattered into the caller's column order."""
+    one native plan cannot hold together: `augmented_dickey_fuller` with more than one `autolag` value (fc.py:499-545
+    evaluates every dict of the list on its own; the kernels hold ONE lag-search fit per series, so `tsfa_plan_create` takes
+    one value per plan) and more than 128 `cwt_coefficients` columns (the filter bank of one plan).  The first part carries
+    every other column + the first lag selection's + the first 128 CWT columns, the others one lag selection / 128 CWT
+    columns each; results are scattered into the caller's column order."""
 
     def __init__(self, parts, n_cols):
         self.parts = parts          # [(native plan, column indices in the full matrix)]
@@ -110,20 +114,32 @@ class _CompositePlan:
 
 def _split_native_specs(specs):
     """-> [(sub-list of specs, their column indices)]: one part unless augmented_dickey_fuller columns name several lag
-    selections (p[1]; attr code 3 -- a column that is NaN whatever the fit -- belongs to any part)."""
+    selections (p[1]; attr code 3 -- a column that is NaN whatever the fit -- belongs to any part) or the plan holds more
+    cwt_coefficients columns than one native plan takes."""
     adf = _native.calc_id("augmented_dickey_fuller")
     modes = []
     for cid, p in specs:
         if cid == adf and int(p[0]) != 3 and float(p[1]) not in modes:
             modes.append(float(p[1]))
-    if len(modes) <= 1:
-        return [(list(specs), list(range(len(specs))))]
-    parts = [([], []) for _ in modes]
+    parts = [([], []) for _ in (modes or [0.0])]
+    cwt = _native.calc_id("cwt_coefficients")
+    n_cwt, overflow = 0, []
     for j, (cid, p) in enumerate(specs):
+        if cid == cwt:
+            # the MFMA filter bank of one plan holds _CWT_COLUMNS_PER_PLAN columns (tsfa_plan_create refuses more): the rest
+            # goes to plans of its own (15 coefficients x 10 widths is already 150 columns)
+            n_cwt += 1
+            if n_cwt > _CWT_COLUMNS_PER_PLAN:
+                k = (n_cwt - 1) // _CWT_COLUMNS_PER_PLAN - 1
+                while len(overflow) <= k:
+                    overflow.append(([], []))
+                overflow[k][0].append((cid, p))
+                overflow[k][1].append(j)
+                continue
         k = modes.index(float(p[1])) if (cid == adf and int(p[0]) != 3) else 0
         parts[k][0].append((cid, p))
         parts[k][1].append(j)
-    return parts
+    return [pt for pt in parts + overflow if pt[0]]
 
 
 def _acquire_plan(fplan, device, pins=None):
