@@ -58,3 +58,27 @@ def test_hip_more_cwt_columns_than_one_native_plan_holds(gpu):
     from tsfresh_amd import extract_features
     df, lens = _frame()
     _check(extract_features(df, column_id="id", column_sort="time", default_fc_parameters=PARAMS, device=0), df, lens)
+
+
+@pytest.mark.gpu
+def test_hip_rolled_windows_through_a_composite_plan(gpu):
+    """extract_rolled_features (window views, tsfa_extract_windows) with a settings object that needs two native plans equals
+    extract_features on the materialised rolled frame."""
+    import warnings
+
+    from tsfresh_amd import extract_features, extract_rolled_features
+    from tsfresh_amd.utilities.dataframe_functions import roll_time_series
+    rng = np.random.default_rng(5)
+    df = pd.concat([pd.DataFrame({"id": sid, "time": np.arange(L), "value": np.cumsum(rng.standard_normal(L))})
+                    for sid, L in enumerate([90, 70, 120])], ignore_index=True)
+    params = {"mean": None, "augmented_dickey_fuller": [{"attr": "teststat", "autolag": "AIC"}, {"attr": "usedlag", "autolag": "BIC"},
+                                                        {"attr": "pvalue", "autolag": None}], "maximum": None}
+    kw = dict(max_timeshift=60, min_timeshift=40)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        rolled = roll_time_series(df, "id", "time", **kw)
+        want = extract_features(rolled, column_id="id", column_sort="time", default_fc_parameters=params)
+        got = extract_rolled_features(df, column_id="id", column_sort="time", default_fc_parameters=params, **kw)
+    assert list(got.index) == list(want.index) and list(got.columns) == list(want.columns) and got.shape[1] == 5
+    a, b = got.to_numpy(), want.to_numpy()
+    assert np.array_equal(np.isnan(a), np.isnan(b)) and np.array_equal(np.nan_to_num(a), np.nan_to_num(b))
