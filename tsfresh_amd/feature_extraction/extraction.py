@@ -316,8 +316,14 @@ def extract_features(
                 matrix = np.empty((pk.n_series, 0))
             elif multi:
                 from tsfresh_amd.distributed import extract_on_devices
-                matrix = extract_on_devices(fplan.native_specs(_native.calc_id), pk.values, pk.offsets, devices,
-                                            times=pk.times)
+                specs = list(fplan.native_specs(_native.calc_id))
+                parts = _split_native_specs(specs)   # (one part unless the settings need several native plans)
+                if len(parts) == 1:
+                    matrix = extract_on_devices(specs, pk.values, pk.offsets, devices, times=pk.times)
+                else:
+                    matrix = _native._result_matrix(pk.n_series, len(specs))
+                    for sub, cols in parts:
+                        matrix[:, cols] = extract_on_devices(sub, pk.values, pk.offsets, devices, times=pk.times)
             else:
                 matrix = nplan.extract_host(pk.values, pk.offsets, times=pk.times)
             # user-defined calculators (callable keys): per series on the host, spliced in at their dict position
