@@ -100,3 +100,9 @@ def test_hip_several_devices_through_several_native_plans(gpu):
     #  cell when this test first ran)
     pd.testing.assert_frame_equal(one, two, check_exact=False, rtol=1e-12, atol=0.0)
     assert one.shape == (6, 4) and not one.isna().any().any()
+
+
+def test_device_resident_extraction_names_what_it_cannot_hold():
+    from tsfresh_amd.feature_extraction.extraction import _CompositePlan
+    with pytest.raises(ValueError, match="ONE native plan"):
+        _CompositePlan([], 0).extract_into(None, None, None)

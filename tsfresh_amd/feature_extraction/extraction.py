@@ -111,6 +111,12 @@ class _CompositePlan:
     def extract_windows_host(self, values, starts, ends, times=None):
         return self._gather(len(starts), lambda pl: pl.extract_windows_host(values, starts, ends, times=times))
 
+    def extract_into(self, values, offsets, matrix, col0=0, times=None):
+        # the parts' columns interleave in the caller's order; a device matrix is filled block by block
+        raise ValueError("device_resident=True needs a settings object that ONE native plan holds (a single "
+                         "augmented_dickey_fuller autolag value, at most {} cwt_coefficients columns); extract with "
+                         "device_resident=False instead".format(_CWT_COLUMNS_PER_PLAN))
+
 
 def _split_native_specs(specs):
     """-> [(sub-list of specs, their column indices)]: one part unless augmented_dickey_fuller columns name several lag
