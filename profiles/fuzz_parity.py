@@ -19,11 +19,32 @@ from parity import compare  # noqa: E402
 from tsfresh_amd.feature_extraction import settings  # noqa: E402
 
 
-def make_series(rng, n):
+def make_series(rng, n, dtype=np.float64):
     """A structured or random series; a third of them are then moved off zero and rescaled (offset 1e2 .. 1e9 times
     the spread, scale 1e-6 .. 1e6): the rank cuts of np.polyfit and statsmodels' pinv live there (round 2 never
     generated a non-zero mean, which is how the Langevin fit's missing truncation got through 80 clean rounds)."""
     x = make_base_series(rng, n)
+    if os.environ.get("TSFA_FUZZ_EXTREME"):
+        # round 6 (VERDICT r5 weak #1): the magnitudes the ordinary families never leave [1e-3, 1e9] for -- 1e+-300, subnormal
+        # ranges, signed zeros, integers at 2^53 (TSFA_FUZZ_EXTREME=1: half of the series; float32 batches clip at 1e+-38)
+        e = rng.integers(0, 8)
+        f32 = (dtype == np.float32)
+        hi, lo, sub, mant = ((30, 36), (-36, -30), (-44, -38), 24) if f32 else ((290, 300), (-300, -290), (-322, -308), 53)
+        if e == 0:
+            return x * 10.0 ** rng.uniform(*hi)
+        if e == 1:
+            return x * 10.0 ** rng.uniform(*lo)
+        if e == 2:
+            return x * 10.0 ** rng.uniform(*sub)              # subnormal in the batch's dtype
+        if e == 3:
+            z = np.where(rng.random(n) < 0.5, 0.0, -0.0)         # signed zeros among a few values
+            m = rng.random(n) < 0.3
+            z[m] = np.round(x[m], 1)
+            return z
+        if e == 4:
+            return np.float64(2.0 ** mant) + rng.integers(-4, 5, n).astype(np.float64) * 2.0   # exactly representable neighbours
+        if e == 5:
+            return np.round(x) * 2.0 ** (mant - 1)
     u = rng.random()
     if u < 0.33:
         spread = float(np.std(x)) or 1.0
@@ -154,7 +175,7 @@ def main():
         maxlen = int(rng.choice([int(v) for v in os.environ.get("TSFA_FUZZ_MAXLENS", "40,300,1024,1024,2500").split(",")]))
         lens = rng.integers(1, maxlen + 1, size=int(rng.integers(3, 14)))
         dtype = np.float32 if rng.random() < 0.6 else np.float64
-        series = [make_series(rng, int(n)).astype(dtype) for n in lens]
+        series = [make_series(rng, int(n), dtype).astype(dtype) for n in lens]
         values = np.concatenate(series)
         offsets = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
         with warnings.catch_warnings():
@@ -163,7 +184,7 @@ def main():
             names, got = engine(params, values, offsets)
             try:
                 names_o, want = oracle_engine(params, values.astype(np.float64), offsets)
-            except ValueError as e:   # the REFERENCE raises here (np.histogram: "Too many bins for data range" ...): no value to compare
+            except (ValueError, TypeError) as e:   # (TypeError: np.polyfit on the empty frame friedrich_coefficients is left with when every bin mean overflowed)   # the REFERENCE raises here (np.histogram: "Too many bins for data range" ...): no value to compare
                 print("round", r, "skipped: the oracle raises as the reference does:", str(e)[:80])
                 continue
         assert names == names_o, (names[:3], names_o[:3])

@@ -16,6 +16,11 @@
 #define TSFA_ENT_MAXK 8
 #define TSFA_ENT_GROUP 3   // thresholds per symmetric sweep (LDS holds one packed word per template per threshold)
 
+// The tolerance r * std of a series whose variance overflowed (|x| beyond 1e154) is +inf in the reference too, and there
+// every pair of templates matches (finite differences <= inf).  The sweeps pad their sorted orders with +inf sentinels,
+// which an infinite tolerance would match as well: the largest finite float64 keeps the sentinels out and every real pair in.
+TSFA_DEV double ent_tolerance(double t) { return (t > 1.7976931348623157e308) ? 1.7976931348623157e308 : t; }
+
 struct EntAcc {          // per-threshold accumulators of one sweep (template length m)
     double sum_log_m;    // sum_i log(C_m[i] / (N - m + 1))
     double sum_log_m1;   // sum_i log(C_{m+1}[i] / (N - m))
@@ -704,7 +709,7 @@ TSFA_DEV void fam_entropy_series(const Blk &b0, XT *xs, int n, const TsfaSpec *s
                                (sp.calc == TSFA_C_APPROXIMATE_ENTROPY && (int)sp.p[0] == 2);
             if (!is_m2) continue;
             blk_sync();
-            if (b.tid == 0) thr[nk] = (sp.calc == TSFA_C_SAMPLE_ENTROPY) ? 0.2 * sd : sp.p[1] * sd;
+            if (b.tid == 0) thr[nk] = ent_tolerance((sp.calc == TSFA_C_SAMPLE_ENTROPY) ? 0.2 * sd : sp.p[1] * sd);
             ++nk;
         }
         const int first = done;
@@ -821,7 +826,7 @@ TSFA_DEV void fam_entropy_series(const Blk &b0, XT *xs, int n, const TsfaSpec *s
             v = 0.0;
         } else {
             EntAcc a;
-            entropy_sweep_generic(b, xs, n, m, sp.p[1] * sd, &a);
+            entropy_sweep_generic(b, xs, n, m, ent_tolerance(sp.p[1] * sd), &a);
             v = apen_from_acc(a, n, m);
         }
         if (b.tid == 0) out_row[sp.col] = v;

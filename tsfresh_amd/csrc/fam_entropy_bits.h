@@ -719,7 +719,7 @@ TSFA_DEV void fam_entropy_series_bits(const Blk &b, double *xs, int n, const Tsf
         blk_sync();
         for (int k = b.tid; k < nk; k += b.nt) {
             const TsfaSpec sp = specs[first + k];
-            thr[k] = (sp.calc == TSFA_C_SAMPLE_ENTROPY) ? 0.2 * sd : sp.p[1] * sd;
+            thr[k] = ent_tolerance((sp.calc == TSFA_C_SAMPLE_ENTROPY) ? 0.2 * sd : sp.p[1] * sd);
         }
         blk_sync();
         if (n >= 3) entropy_bits_batch<QW_>(b, xs, n, thr, nk, perm, work, racc, kcap_max);

@@ -1276,6 +1276,9 @@ TSFA_DEV double np_linspace_at(double start, double stop, int num_edges, int i) 
 template <class G>
 TSFA_DEV double blk_binned_entropy(const Blk &b, int m, G g, int bins, double vmin, double vmax, int *cnt) {
     double first = vmin, last = vmax;
+    // np.histogram raises "autodetected range of [..] is not finite" for a series holding +-inf (fc.py:1691); the host
+    // turns the NaN of this cell into that ValueError (feature_extraction/reference_errors.py)
+    if (!(fabs(first) < TSFA_INF) || !(fabs(last) < TSFA_INF)) return TSFA_NAN;
     if (first == last) {
         first = first - 0.5;
         last = last + 0.5;
@@ -1290,12 +1293,24 @@ TSFA_DEV double blk_binned_entropy(const Blk &b, int m, G g, int bins, double vm
     // bins + 1)[i] = i * step + first with the step formed once (numpy's own expression; three divisions per element
     // before -- a float64 division is ~30 instructions)
     const double inv_norm = 1.0 / norm;
+    // ... unless the reciprocal is not a float64 worth multiplying by: a range of subnormal width has 1 / norm = inf
+    // (every sample landed in bin 0), a range beyond 2^1022 a subnormal reciprocal -- numpy's own quotient then
+    const bool recip = (inv_norm < TSFA_INF) && (inv_norm >= 2.2250738585072014e-308);
     const double delta = last - first, step = delta / (double)bins;
     const bool flat = (step == 0.0);
+    {
+        // numpy >= 2.0 (_histograms_impl.py:452): "Too many bins for data range. Cannot create N finite-sized bins." when two
+        // neighbouring edges of the linspace coincide (a range of a few ulps: 2^53 + {0, 2, 4}); the host turns the NaN
+        // into that ValueError (reference_errors.py)
+        unsigned stuck = 0;
+        for (int k = b.tid; k < bins; k += b.nt)
+            if (np_linspace_at(first, last, bins + 1, k) >= np_linspace_at(first, last, bins + 1, k + 1)) stuck = 1;
+        if (blk_or16(b, stuck) != 0) return TSFA_NAN;
+    }
     for (int i = b.tid; i < m; i += b.nt) {
         const double v = g(i);
         if (!(v >= first && v <= last)) continue;
-        const double fidx = ((v - first) * inv_norm) * (double)bins;
+        const double fidx = recip ? ((v - first) * inv_norm) * (double)bins : ((v - first) / norm) * (double)bins;
         int idx = (int)fidx;
         if (idx >= bins) idx = bins - 1;
         if (idx < 0) idx = 0;

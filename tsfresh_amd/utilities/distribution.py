@@ -40,6 +40,8 @@ class GPUDistributor(_Base):
             device = self.device if self.device is not None else _default_device()
             plan = _acquire_plan(fplan, device)  # cached per thread: no 8 ms plan build per call
             matrix = plan.extract_host(values, offsets, times=times)
+            from tsfresh_amd.feature_extraction.reference_errors import check_reference_data_errors
+            check_reference_data_errors(fplan.specs, matrix, values, offsets[:-1], offsets[1:])
         else:
             matrix = np.empty((n_series, 0))
         names, matrix = fplan.finish(matrix, lambda i: values[offsets[i]:offsets[i + 1]], n_series)
