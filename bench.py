@@ -447,7 +447,7 @@ def main():
             achieved = alg_bytes / (kt[dom] * 1e-3) / 1e9
             # the entropy family runs as k_entropy_bits for series up to 1024 samples (fam_entropy_bits.h), as k_entropy beyond
             kname = dom
-            if dom == "k_entropy" and L <= 1024 and not args.ragged and not os.environ.get("TSFA_ENT_PAIRS"):
+            if dom == "k_entropy" and L <= 1024 and not args.ragged:
                 kname = "k_entropy_bits"
             notes = {"k_entropy_bits": "sorted ranges + bit-matrix sweep of all template pairs: VALU / LDS-issue bound, not "
                                        "HBM-bound (DESIGN.md roofline section)",

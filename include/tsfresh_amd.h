@@ -139,6 +139,28 @@ int tsfa_extract_windows(tsfa_plan *plan, const void *values, int32_t dtype, con
 int tsfa_plan_set_profiling(tsfa_plan *plan, int32_t enable);
 int32_t tsfa_plan_last_timings(const tsfa_plan *plan, const char **names, float *ms, int32_t cap);
 
+/*
+ * Launch options of one plan, set by the caller who owns it.  The library reads NO environment variable that can change a
+ * result; what used to be debugging switches of the environment are named options here, each an alternative ROUTE to the same
+ * numbers (the tests compare both ways) or a diagnostic pre-fill:
+ *   "length_classes" 0|1   launch a batch whose lengths span more than 2x class by class (default 1)
+ *   "stats_share"    0|1   k_basic's per-series statistics serve the other families (1)
+ *   "perm_share"     0|1   the entropy kernel's sample order serves k_sort (1)
+ *   "select"         0|1   median / quantile-only plans by selection instead of a sort (1)
+ *   "fused_minimal"  0     MinimalFCParameters-shaped plans through the family kernels instead of k_stream
+ *   "perm_fused"     0     permutation_entropy inside k_sort instead of k_perm
+ *   "bluestein"      0|1   chirp-z transform for long spectra of non-power-of-two length (1); "bluestein_min" n: its crossover
+ *   "gscratch_slots" n     cap of the chirp-z scratch slots (several launches per group)
+ *   "cwt_mfma"       0|1   number_cwt_peaks' convolutions on the float64 matrix cores (0: measured 4 % slower)
+ *   "entropy_route"  0|1|2 bit-matrix sweep | windowed pair sweep | general kernel
+ *   "force_long"     0|1   the HBM-scratch build of the family kernels whatever the length
+ *   "host_chunks"    n     row chunks of the TSFA_HOST pipeline (0: by batch size)
+ *   "fill" v / "fill_off"  pre-fill the result matrix with v before the kernels run (audits: every cell is written anyway)
+ * plan == NULL: library-wide options ("relevance_batch" n: columns per sort batch of tsfa_relevance_*).
+ * Unknown names return TSFA_ERR_INVALID.  The reference has no counterpart (its knobs are n_jobs / chunksize).
+ */
+int tsfa_plan_set_option(tsfa_plan *plan, const char *name, double value);
+
 /* Optional: promise that every series of the following tsfa_extract* calls on this plan has min_len <= length <=
  * max_len.  The calls then skip their length scan and the host synchronisation it needs, so device-pointer calls on one
  * stream (e.g. the row chunks of a shard whose results are exchanged chunk by chunk) are enqueued back to back.  A batch

@@ -1,9 +1,10 @@
 #!/usr/bin/env python
-"""Which cells does NO kernel write?  Runs plans with the pre-fill value replaced by a sentinel (TSFA_DEBUG_FILL) over
-series of many lengths and lists, per calculator, the lengths at which a column kept the sentinel -- those calculators
-need the NaN pre-fill (k_fill_nan); every other column is written by its kernel for every series.
+"""Which cells does NO kernel write?  Runs plans with a sentinel pre-fill (plan option "fill") over series of many lengths
+and lists, per calculator, the lengths at which a column kept the sentinel -- those calculators would need the NaN
+pre-fill (k_fill_nan); every other column is written by its kernel for every series.
 
-    TSFA_DEBUG_FILL=123456.789 python profiles/fill_audit.py > gpurun_out/fill_audit.json
+    python profiles/fill_audit.py > gpurun_out/fill_audit.json
+    TSFA_LIB=tsfresh_amd/libtsfresh_amd_lab.so python profiles/fill_audit.py --control   # the positive control (lab build)
 """
 import json
 import os
@@ -15,7 +16,6 @@ import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 SENT = 123456.789
-os.environ["TSFA_DEBUG_FILL"] = repr(SENT)
 
 from tsfresh_amd import _native  # noqa: E402
 from tsfresh_amd.feature_extraction import settings  # noqa: E402
@@ -25,11 +25,14 @@ LENGTHS = [1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 15, 16, 17, 20, 21, 22, 23, 24
            200, 255, 256, 257, 300, 511, 512, 513, 1000, 1023, 1024, 1025, 1251, 2047, 2048, 2049, 3000, 4096, 4097, 5000, 8192]
 
 
-def run(params, series, dtype):
+def run(params, series, dtype, options=None):
     with warnings.catch_warnings():
         warnings.simplefilter("ignore")
         fplan = compile_fc_parameters(params)
     plan = _native.Plan(fplan.native_specs(_native.calc_id), device=0)
+    plan.set_option("fill", SENT)
+    for name, value in (options or {}).items():
+        plan.set_option(name, value)
     values = np.concatenate(series).astype(dtype)
     offsets = np.concatenate([[0], np.cumsum([len(s) for s in series])]).astype(np.int64)
     out = plan.extract_host(values, offsets)
@@ -38,14 +41,12 @@ def run(params, series, dtype):
 
 
 def positive_control():
-    """The sentinel really is what an unwritten cell shows: with one family's launch skipped (TSFA_DEBUG_SKIP_FAM) its
-    columns -- and only its columns -- keep it."""
+    """The sentinel really is what an unwritten cell shows: with one family's launch skipped (option "skip_family", which only
+    the LAB build of the library has: TSFA_LIB=.../libtsfresh_amd_lab.so) its columns -- and only its columns -- keep it."""
     rng = np.random.default_rng(2)
     series = [rng.standard_normal(300) for _ in range(4)]
     params = {"lempel_ziv_complexity": [{"bins": 10}], "mean": None, "median": None}
-    os.environ["TSFA_DEBUG_SKIP_FAM"] = "6"    # TSFA_FAM_SEQ
-    names, out = run(params, series, np.float32)
-    del os.environ["TSFA_DEBUG_SKIP_FAM"]
+    names, out = run(params, series, np.float32, options={"skip_family": 6})    # TSFA_FAM_SEQ
     col = {n.split("__")[0]: i for i, n in enumerate(names)}
     ok = bool((out[:, col["lempel_ziv_complexity"]] == SENT).all() and (out[:, col["mean"]] != SENT).all()
               and (out[:, col["median"]] != SENT).all())
@@ -102,7 +103,11 @@ def audit(lengths=LENGTHS, sets=("comprehensive", "extra", "minimal")):
 
 
 def main():
-    control = positive_control()
+    if "--control" in sys.argv:
+        ok = positive_control()
+        print("positive control ok" if ok else "positive control FAILED")
+        sys.exit(0 if ok else 1)
+    control = None   # (needs the lab build: run with --control under TSFA_LIB)
     sys.stderr.write("positive control (a skipped family keeps the sentinel): %s\n" % control)
     doc = audit()
     print(json.dumps({"sentinel": SENT, "positive_control_ok": control, "lengths_tried": LENGTHS, "calculators_that_leave_cells": doc}, indent=1))

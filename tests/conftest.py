@@ -35,16 +35,22 @@ SENTINEL = 123456.789   # profiles/fill_audit.py uses the same value
 @pytest.fixture(scope="session", autouse=True)
 def _sentinel_audit_of_every_gpu_extraction():
     """The feature matrix is not pre-filled: a kernel path that skipped a cell would hand back whatever
-    the buffer held.  On a box with a GPU EVERY plan the tests create pre-fills with a sentinel (TSFA_DEBUG_FILL, read
-    when a plan is built) and every host-side result is checked for it -- the parameter sweep, the fuzz-style batches, rolled
+    the buffer held.  On a box with a GPU EVERY plan the tests create pre-fills with a sentinel (plan option "fill",
+    set right after the plan is built) and every host-side result is checked for it -- the parameter sweep, the fuzz-style batches, rolled
     windows, the long-series build and the second passes included (round-4 ADVICE: the audit covered three parameter
-    sets).  TSFA_TEST_NO_SENTINEL=1 switches it off; TSFA_DEBUG_SKIP_FAM (the audit's positive control) suspends the check."""
+    sets).  TSFA_TEST_NO_SENTINEL=1 switches it off."""
     if os.environ.get("TSFA_TEST_NO_SENTINEL") or not _have_gpu():
         yield
         return
     from tsfresh_amd import _native
-    os.environ["TSFA_DEBUG_FILL"] = repr(SENTINEL)
     originals = {}
+    create = _native.Plan.__init__
+    originals["__init__"] = create
+
+    def create_with_fill(self, *a, **k):
+        create(self, *a, **k)
+        self.set_option("fill", SENTINEL)   # tsfa_plan_set_option: the matrix is pre-filled before the kernels run
+    _native.Plan.__init__ = create_with_fill
 
     def checked(name):
         fn = getattr(_native.Plan, name)
@@ -52,7 +58,7 @@ def _sentinel_audit_of_every_gpu_extraction():
 
         def wrapper(self, *a, **k):
             out = fn(self, *a, **k)
-            if out is not None and not os.environ.get("TSFA_DEBUG_SKIP_FAM") and os.environ.get("TSFA_DEBUG_FILL"):
+            if out is not None:
                 import numpy as np
                 kept = np.argwhere(np.asarray(out) == SENTINEL)
                 assert len(kept) == 0, "%d cells were written by no kernel, first (row, column): %s" % (len(kept), kept[:5].tolist())
@@ -63,7 +69,6 @@ def _sentinel_audit_of_every_gpu_extraction():
     yield
     for name, fn in originals.items():
         setattr(_native.Plan, name, fn)
-    os.environ.pop("TSFA_DEBUG_FILL", None)
 
 
 def pytest_sessionfinish(session, exitstatus):

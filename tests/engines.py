@@ -55,12 +55,15 @@ def emul_engine(fc_parameters, values, offsets, kind="value", times=None):
     return emul_extract(fc_parameters, values, offsets, kind=kind, times=times)
 
 
-def hip_engine(fc_parameters, values, offsets, kind="value", device=0, times=None):
-    """times: float64 hours since each series' first timestamp (DatetimeIndex data) -> linear_trend_timewise"""
+def hip_engine(fc_parameters, values, offsets, kind="value", device=0, times=None, options=None):
+    """times: float64 hours since each series' first timestamp (DatetimeIndex data) -> linear_trend_timewise
+    options: {name: value} for tsfa_plan_set_option (an alternative route to the same numbers: the A/B tests)"""
     from tsfresh_amd import _native
     from tsfresh_amd.feature_extraction.plan import compile_fc_parameters
     fplan = compile_fc_parameters(fc_parameters, has_datetime_index=times is not None)
     plan = _native.Plan(fplan.native_specs(_native.calc_id), device=device)
+    for name, value in (options or {}).items():
+        plan.set_option(name, value)
     try:
         out = plan.extract_host(values, np.asarray(offsets, dtype=np.int64), times=times)
     finally:

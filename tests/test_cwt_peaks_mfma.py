@@ -1,5 +1,5 @@
 """number_cwt_peaks (fc.py:1320): the Ricker convolutions on the float64 matrix cores (fam_cwt.h: cwt_rows_mfma, the opt-in
-instantiation of TSFA_CWT_MFMA=1 -- measured slower than the float64 FMA tiles on gfx950) against the
+instantiation of the plan option "cwt_mfma" -- measured slower than the float64 FMA tiles on gfx950) against the
 register-tiled default and against the oracle (scipy.signal.find_peaks_cwt)."""
 import numpy as np
 import pytest
@@ -33,9 +33,7 @@ def _batch(dtype, seed):
 def test_mfma_phase_a_equals_the_tiles_and_the_oracle(gpu, dtype, monkeypatch):
     chunks, values, offsets = _batch(dtype, 5)
     names2, tiles = hip_engine(PARAMS, values, offsets)
-    monkeypatch.setenv("TSFA_CWT_MFMA", "1")
-    names, got = hip_engine(PARAMS, values, offsets)
-    monkeypatch.delenv("TSFA_CWT_MFMA")
+    names, got = hip_engine(PARAMS, values, offsets, options={"cwt_mfma": 1})
     assert names == names2
     assert np.array_equal(got, tiles), np.argwhere(got != tiles)[:10]
     onames, want = oracle_engine_parallel(PARAMS, values.astype(np.float64), offsets)
@@ -57,9 +55,7 @@ def test_mfma_phase_a_uniform_batch_and_nonfinite_samples(gpu, monkeypatch):
     offsets = np.arange(25, dtype=np.int64) * 1024
     params = {"number_cwt_peaks": [{"n": 1}, {"n": 5}]}
     _, tiles = hip_engine(params, values, offsets)
-    monkeypatch.setenv("TSFA_CWT_MFMA", "1")
-    names, got = hip_engine(params, values, offsets)
-    monkeypatch.delenv("TSFA_CWT_MFMA")
+    names, got = hip_engine(params, values, offsets, options={"cwt_mfma": 1})
     assert np.array_equal(got, tiles, equal_nan=True), np.argwhere(got != tiles)[:10]
     onames, want = oracle_engine_parallel(params, values.astype(np.float64), offsets)
     assert names == onames

@@ -1,6 +1,7 @@
 """`-m gpu`: the HIP path (through the C-ABI) against the reference golden vectors, the oracle, and -- at
 BASELINE sizes -- size-independent properties."""
 import os
+import sys
 import warnings
 
 import numpy as np
@@ -515,7 +516,7 @@ def test_shard_pipeline_chunks_and_lanes_equal_one_pass(gpu):
 
 def test_length_classes_give_identical_results_and_do_not_pay_for_the_longest(gpu, monkeypatch):
     """A ragged batch is launched by length class (each class with its own LDS carve / workgroup size): same numbers as
-    the single-launch form (TSFA_NO_LENGTH_CLASSES=1), for host and device-resident inputs."""
+    the single-launch form (option "length_classes" 0), for host and device-resident inputs."""
     rng = np.random.default_rng(23)
     lens = np.concatenate([rng.integers(8, 64, size=1500), rng.integers(200, 260, size=1500), rng.integers(900, 1100, size=600),
                            [4000, 3000, 7000]])
@@ -524,9 +525,7 @@ def test_length_classes_give_identical_results_and_do_not_pay_for_the_longest(gp
     offsets = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
     params = settings.EfficientFCParameters()
     names, classed = hip_engine(params, values, offsets)
-    monkeypatch.setenv("TSFA_NO_LENGTH_CLASSES", "1")
-    names2, single = hip_engine(params, values, offsets)
-    monkeypatch.delenv("TSFA_NO_LENGTH_CLASSES")
+    names2, single = hip_engine(params, values, offsets, options={"length_classes": 0})
     assert names == names2
     assert np.array_equal(np.isnan(classed), np.isnan(single))
     # the workgroup size of a class decides the association of its reductions: equal to 1e-12, not bit for bit
@@ -583,7 +582,7 @@ def test_series_longer_than_lds_match_oracle(gpu):
 
 
 def test_forced_long_build_equals_the_lds_build(gpu, monkeypatch):
-    """TSFA_FORCE_LONG=1 sends every family through the HBM-scratch build, also for ordinary lengths: all 783
+    """Option "force_long" sends every family through the HBM-scratch build, also for ordinary lengths: all 783
     Comprehensive columns (the general entropy sweep included) must agree with the LDS build and with the oracle."""
     rng = np.random.default_rng(42)
     lens = list(rng.integers(4, 600, size=40)) + [1024, 700, 64, 1, 2, 3]
@@ -593,9 +592,7 @@ def test_forced_long_build_equals_the_lds_build(gpu, monkeypatch):
     offsets = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
     params = settings.ComprehensiveFCParameters()
     names, lds_build = hip_engine(params, values, offsets)
-    monkeypatch.setenv("TSFA_FORCE_LONG", "1")
-    names2, long_build = hip_engine(params, values, offsets)
-    monkeypatch.delenv("TSFA_FORCE_LONG")
+    names2, long_build = hip_engine(params, values, offsets, options={"force_long": 1})
     assert names == names2 and np.array_equal(np.isnan(lds_build), np.isnan(long_build))
     onames, want = oracle_engine(params, values.astype(np.float64), offsets)
     bad = compare(onames, _align(onames, names2, long_build), want, _series(values.astype(np.float64), offsets))
@@ -634,9 +631,7 @@ def test_order_statistics_by_selection_equal_numpy(gpu, dtype, monkeypatch):
     offsets = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
     params = {"median": None, "quantile": [{"q": q} for q in (0.1, 0.2, 0.3, 0.4, 0.6, 0.7, 0.8, 0.9, 0.0, 1.0, 0.5)]}
     names, got = hip_engine(params, values, offsets)
-    monkeypatch.setenv("TSFA_NO_SELECT", "1")
-    names2, sorted_path = hip_engine(params, values, offsets)
-    monkeypatch.delenv("TSFA_NO_SELECT")
+    names2, sorted_path = hip_engine(params, values, offsets, options={"select": 0})
     assert names == names2 and np.array_equal(got, sorted_path)
     for i in range(len(lens)):
         x = values[offsets[i]:offsets[i + 1]].astype(np.float64)
@@ -648,7 +643,7 @@ def test_order_statistics_by_selection_equal_numpy(gpu, dtype, monkeypatch):
 @pytest.mark.parametrize("dtype", [np.float32, np.float64])
 def test_entropy_bit_matrix_sweep_equals_the_pair_sweep_and_the_oracle(gpu, dtype, monkeypatch):
     """k_entropy_bits (sorted ranges + prefix bit sets, fam_entropy_bits.h) counts the same neighbours as the float64
-    pair sweep of k_entropy (TSFA_ENT_PAIRS=1): the counts are integers, so the six columns agree to the rounding of the
+    pair sweep of k_entropy (option "entropy_route" 1): the counts are integers, so the six columns agree to the rounding of the
     log sums -- on every length 1 ... 1024 around the strip / word / part boundaries (30, 32, 60, 352, 1023, 1024 ...),
     with ties, constant runs, two-valued and heavy-tailed series, tolerances given by the caller, and against the
     oracle (feature_calculators.py:1701-1805)."""
@@ -674,9 +669,7 @@ def test_entropy_bit_matrix_sweep_equals_the_pair_sweep_and_the_oracle(gpu, dtyp
     params = {"sample_entropy": None,
               "approximate_entropy": [{"m": 2, "r": r} for r in (0.1, 0.3, 0.5, 0.7, 0.9, 0.05, 1.7, 0.0)]}  # 9 specs: two batches
     names, bits = hip_engine(params, values, offsets)
-    monkeypatch.setenv("TSFA_ENT_PAIRS", "1")
-    names2, pairs = hip_engine(params, values, offsets)
-    monkeypatch.delenv("TSFA_ENT_PAIRS")
+    names2, pairs = hip_engine(params, values, offsets, options={"entropy_route": 1})
     assert names == names2
     assert np.array_equal(np.isnan(bits), np.isnan(pairs)) and np.array_equal(np.isinf(bits), np.isinf(pairs))
     ok = np.isfinite(bits)
@@ -763,8 +756,7 @@ def test_streaming_kernel_medians_are_exact_on_hostile_series(gpu, dtype, monkey
     bad = compare(onames, _align(onames, names, got), owant, _series(values.astype(np.float64), offsets))
     assert not bad, bad[:8]
     # the two-kernel route (k_basic_lite + k_order_stats) gives the same medians and statistics within the bar
-    monkeypatch.setenv("TSFA_NO_STREAM", "1")
-    names2, got2 = hip_engine(params, values, offsets)
+    names2, got2 = hip_engine(params, values, offsets, options={"fused_minimal": 0})
     assert np.array_equal(got2[:, names2.index("value__median")], med)
     assert not compare(names, got, got2, _series(values.astype(np.float64), offsets))
 
@@ -774,7 +766,7 @@ def test_streaming_kernel_medians_are_exact_on_hostile_series(gpu, dtype, monkey
 def test_entropy_bit_matrix_sweep_on_long_series_equals_the_pair_sweep(gpu, dtype, monkeypatch):
     """Series of 1025 ... 4096 samples take the bit-matrix sweep with 16-byte table entries and the tolerances in rounds
     (k_entropy_bits<T, 3>); beyond 4096 the pair sweep remains.  Same integer counts as the pair sweep
-    (TSFA_ENT_PAIRS=1) on lengths around the part / strip / round boundaries, with ties, walks and a constant run, one
+    (option "entropy_route" 1) on lengths around the part / strip / round boundaries, with ties, walks and a constant run, one
     ragged batch that also holds short series (length classes) -- and the oracle on the shorter ones."""
     rng = np.random.default_rng(78)
     lens = [1025, 1026, 1055, 1056, 1057, 1500, 2047, 2048, 2049, 3071, 3072, 3073, 4000, 4095, 4096, 4097, 5000, 700, 64]
@@ -791,9 +783,7 @@ def test_entropy_bit_matrix_sweep_on_long_series_equals_the_pair_sweep(gpu, dtyp
     params = {"sample_entropy": None,
               "approximate_entropy": [{"m": 2, "r": r} for r in (0.1, 0.3, 0.5, 0.7, 0.9, 0.05, 1.7)]}  # 8 specs: two batches
     names, bits = hip_engine(params, values, offsets)
-    monkeypatch.setenv("TSFA_ENT_PAIRS", "1")
-    names2, pairs = hip_engine(params, values, offsets)
-    monkeypatch.delenv("TSFA_ENT_PAIRS")
+    names2, pairs = hip_engine(params, values, offsets, options={"entropy_route": 1})
     assert names == names2
     assert np.array_equal(np.isnan(bits), np.isnan(pairs)) and np.array_equal(np.isinf(bits), np.isinf(pairs))
     ok = np.isfinite(bits)
@@ -821,9 +811,7 @@ def test_entropy_long_sweep_in_a_ragged_launch_keeps_to_its_work_region(gpu, mon
     params = {"sample_entropy": None, "approximate_entropy": [{"m": 2, "r": r} for r in (0.1, 0.3, 0.5, 0.7, 0.9)]}
     names, bits = hip_engine(params, values, offsets)
     assert np.all(np.isfinite(bits)), bits
-    monkeypatch.setenv("TSFA_ENT_PAIRS", "1")
-    names2, pairs = hip_engine(params, values, offsets)
-    monkeypatch.delenv("TSFA_ENT_PAIRS")
+    names2, pairs = hip_engine(params, values, offsets, options={"entropy_route": 1})
     assert names == names2
     assert np.allclose(bits, pairs, rtol=1e-12, atol=1e-13), np.abs(bits - pairs).max()
     sub = [1, 4]
@@ -860,26 +848,53 @@ def test_every_cell_is_written_by_a_kernel(gpu, monkeypatch):
     1 .. 4097 (the API rejects empty series), Comprehensive + a stress set of parameters + Minimal, float32 / float64, iid / walk / constant / zero /
     non-finite series: no cell may keep the sentinel; and the control -- a family whose launch is skipped keeps it."""
     import importlib.util
-    before = os.environ.get("TSFA_DEBUG_FILL")   # tests/conftest.py runs the whole gpu session with the same sentinel
+    import subprocess
     spec = importlib.util.spec_from_file_location("fill_audit", os.path.join(ROOT, "profiles", "fill_audit.py"))
     fa = importlib.util.module_from_spec(spec)
-    spec.loader.exec_module(fa)          # sets TSFA_DEBUG_FILL for the plans it creates
-    try:
-        assert fa.positive_control()
-        lengths = [1, 2, 3, 4, 5, 7, 10, 16, 21, 22, 23, 33, 64, 100, 255, 256, 257, 1000, 1024, 1025, 2049, 4097]
-        kept = fa.audit(lengths)
-        assert not kept, kept
-    finally:
-        os.environ.pop("TSFA_DEBUG_FILL", None)
-        if before is not None:
-            os.environ["TSFA_DEBUG_FILL"] = before
+    spec.loader.exec_module(fa)          # every plan it creates: set_option("fill", sentinel)
+    # the control needs a launch LEFT OUT: that switch exists only in the lab build of the library (make lab), loaded by a
+    # process of its own -- this one keeps running on the shipped library
+    lab = os.path.join(ROOT, "tsfresh_amd", "libtsfresh_amd_lab.so")
+    assert os.path.exists(lab), "build the lab library: make -C tsfresh_amd/csrc lab (__graft_entry__.build() does)"
+    env = dict(os.environ, TSFA_LIB=lab)
+    res = subprocess.run([sys.executable, os.path.join(ROOT, "profiles", "fill_audit.py"), "--control"], env=env,
+                         capture_output=True, text=True, timeout=600)
+    assert res.returncode == 0 and "positive control ok" in res.stdout, (res.stdout[-500:], res.stderr[-1500:])
+    lengths = [1, 2, 3, 4, 5, 7, 10, 16, 21, 22, 23, 33, 64, 100, 255, 256, 257, 1000, 1024, 1025, 2049, 4097]
+    kept = fa.audit(lengths)
+    assert not kept, kept
+
+
+@pytest.mark.gpu
+def test_the_environment_cannot_change_a_number(gpu, monkeypatch):
+    """Round-5 VERDICT #7: the shipped library read 25 environment variables on its launch path, one of which left a whole
+    family's launch out.  With every one of the old switches set the oracle's numbers still come back, bit-identical to
+    a run without them; the three variables the library does read (streams, side lane, host chunks) move work, not bits."""
+    rng = np.random.default_rng(77)
+    lens = [5, 64, 300, 1024, 1500]
+    series = [rng.standard_normal(n).astype(np.float32) for n in lens]
+    values = np.concatenate(series)
+    offsets = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
+    params = settings.EfficientFCParameters()
+    names, clean = hip_engine(params, values, offsets)
+    for var, val in (("TSFA_DEBUG_SKIP_FAM", "0"), ("TSFA_DEBUG_SKIP_FAM", "3"), ("TSFA_ENT_SLOW", "1"), ("TSFA_NO_SELECT", "1"), ("TSFA_FORCE_LONG", "1"),
+                     ("TSFA_NO_STATS_SHARE", "1"), ("TSFA_NO_PERM_SHARE", "1"), ("TSFA_NO_LENGTH_CLASSES", "1"), ("TSFA_NO_STREAM", "1"),
+                     ("TSFA_NO_BLUESTEIN", "1"), ("TSFA_ENT_PAIRS", "1"), ("TSFA_CWT_MFMA", "1"), ("TSFA_NO_PE_FUSED", "1"),
+                     ("TSFA_BLUESTEIN_MIN", "17"), ("TSFA_GSCRATCH_SLOTS", "1"), ("TSFA_NT_0", "256"), ("TSFA_NT_3", "512"),
+                     ("TSFA_DEBUG_FILL", "7.0"), ("TSFA_FILL_ALL", "1")):
+        monkeypatch.setenv(var, val)
+    names2, noisy = hip_engine(params, values, offsets)
+    assert names == names2 and np.array_equal(clean, noisy, equal_nan=True)
+    onames, want = oracle_engine(params, values.astype(np.float64), offsets)
+    bad = compare(onames, _align(onames, names, noisy), want, _series(values.astype(np.float64), offsets))
+    assert not bad, bad[:8]
 
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("dtype", [np.float32, np.float64])
 def test_shared_series_statistics_change_no_bit(gpu, dtype, monkeypatch):
     """k_basic leaves numpy-order mean / variance and the extrema of every series for the ENTROPY, AR and SEQ families of
-    the same extraction (plan->stats_buf); with the sharing switched off (TSFA_NO_STATS_SHARE=1) every family computes its
+    the same extraction (plan->stats_buf); with the sharing switched off (option "stats_share" 0) every family computes its
     own -- the same sums in the same order, so all 783 columns must agree bit for bit: ragged lengths (several launch
     groups), nice decimals (where one ulp of the mean flips counts), constants, offsets."""
     rng = np.random.default_rng(17)
@@ -902,9 +917,7 @@ def test_shared_series_statistics_change_no_bit(gpu, dtype, monkeypatch):
     offsets = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
     params = settings.ComprehensiveFCParameters()
     names, shared = hip_engine(params, values, offsets)
-    monkeypatch.setenv("TSFA_NO_STATS_SHARE", "1")
-    names2, own = hip_engine(params, values, offsets)
-    monkeypatch.delenv("TSFA_NO_STATS_SHARE")
+    names2, own = hip_engine(params, values, offsets, options={"stats_share": 0})
     assert names == names2
     assert np.array_equal(shared, own, equal_nan=True), [names[j] for j in np.nonzero(~((shared == own) | (np.isnan(shared) & np.isnan(own))).all(axis=0))[0]][:8]
     # a plan WITHOUT the BASIC family has nobody to share with and still works
@@ -936,7 +949,7 @@ def test_side_lane_changes_no_bit(gpu, monkeypatch):
 @pytest.mark.parametrize("dtype", [np.float32, np.float64])
 @pytest.mark.parametrize("batch", ["lds", "long"])
 def test_chirp_z_transform_on_every_tile_shape_and_in_several_launches(gpu, dtype, batch, monkeypatch):
-    """fft_coefficient / fft_aggregated of non-power-of-two lengths from the crossover (TSFA_BLUESTEIN_MIN, lowered here so
+    """fft_coefficient / fft_aggregated of non-power-of-two lengths from the crossover (option "bluestein_min", lowered here so
     that short series reach every shape) up to 32 767 samples: even lengths (n / 2 complex points, M / T = 2 or 4), odd
     lengths (M / T = 4 or 8), next to powers of two; against numpy's rfft to 1e-13 of sum|x| (the Goertzel sweep it
     replaces: 6e-10) and against the oracle.  Batch "lds" (series a CU's LDS holds) is also extracted with ONE scratch slot
@@ -952,14 +965,10 @@ def test_chirp_z_transform_on_every_tile_shape_and_in_several_launches(gpu, dtyp
     offsets = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
     params = {"fft_coefficient": [{"attr": a, "coeff": k} for a in ("real", "imag", "abs", "angle") for k in (0, 1, 2, 5, 33, 99)],
               "fft_aggregated": [{"aggtype": t} for t in ("centroid", "variance", "skew", "kurtosis")]}
-    monkeypatch.setenv("TSFA_BLUESTEIN_MIN", "257")
-    names, got = hip_engine(params, values, offsets)
+    names, got = hip_engine(params, values, offsets, options={"bluestein_min": 257})
     if batch == "lds":
-        monkeypatch.setenv("TSFA_GSCRATCH_SLOTS", "1")
-        names2, one_slot = hip_engine(params, values, offsets)
-        monkeypatch.delenv("TSFA_GSCRATCH_SLOTS")
+        names2, one_slot = hip_engine(params, values, offsets, options={"bluestein_min": 257, "gscratch_slots": 1})
         assert names == names2 and np.array_equal(got, one_slot, equal_nan=True)
-    monkeypatch.delenv("TSFA_BLUESTEIN_MIN")
     for i, x in enumerate(series):
         X = np.fft.rfft(x.astype(np.float64))
         scale = float(np.abs(x.astype(np.float64)).sum())

@@ -70,12 +70,11 @@ def test_fused_dimensions_equal_the_oracle_on_the_device(gpu, dtype):
 
 @pytest.mark.gpu
 def test_the_kernel_of_its_own_and_the_columns_in_k_sort_agree(gpu, monkeypatch):
-    """TSFA_NO_PE_FUSED (read when the plan is built) leaves the columns to k_sort, one dimension at a time."""
+    """Option "perm_fused" 0 leaves the columns to k_sort, one dimension at a time."""
     from engines import hip_engine
     series = [s.astype(np.float32) for s in pe_series()]
     values = np.concatenate(series)
     offsets = np.concatenate([[0], np.cumsum([len(s) for s in series])]).astype(np.int64)
     _, own = hip_engine(ALL5, values, offsets)
-    monkeypatch.setenv("TSFA_NO_PE_FUSED", "1")
-    _, in_sort = hip_engine(ALL5, values, offsets)
+    _, in_sort = hip_engine(ALL5, values, offsets, options={"perm_fused": 0})
     np.testing.assert_allclose(own, in_sort, rtol=1e-13, atol=1e-14, equal_nan=True)

@@ -280,12 +280,15 @@ def test_gpu_relevance_column_batches(monkeypatch):
     X[:, 7] = np.round(X[:, 7], 1)
     yc = rng.integers(0, 3, n).astype(np.int32)
     yr = np.round(rng.standard_normal(n), 2)
-    monkeypatch.delenv("TSFA_REL_BATCH", raising=False)
+    _native.set_library_option("relevance_batch", 0)
     a = _native.relevance_classes(X, yc, 3, with_ks=True)
     ar, _ = _native.relevance_real(X, yr)
-    monkeypatch.setenv("TSFA_REL_BATCH", "3")
-    b = _native.relevance_classes(X, yc, 3, with_ks=True)
-    br, _ = _native.relevance_real(X, yr)
+    _native.set_library_option("relevance_batch", 3)
+    try:
+        b = _native.relevance_classes(X, yc, 3, with_ks=True)
+        br, _ = _native.relevance_real(X, yr)
+    finally:
+        _native.set_library_option("relevance_batch", 0)
     for u, v in zip(a, b):
         assert np.array_equal(u, v)
     for f in ar.dtype.names:

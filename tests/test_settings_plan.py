@@ -96,3 +96,27 @@ def test_custom_callable_calculators_are_spliced_in_at_their_dict_position():
     only_host = compile_fc_parameters({spread: None})
     names, matrix = only_host.finish(np.empty((2, 0)), lambda i: rows[i], 2)
     assert names == ["spread"] and matrix.tolist() == [[5.0], [0.5]]
+
+
+def test_settings_pickle_with_callable_keys():
+    """The reference's own test (tests/units/feature_extraction/test_settings.py:329-352): lambdas and nested functions as
+    keys survive pickle because the keys travel cloudpickled."""
+    import pickle
+
+    from tsfresh_amd.feature_extraction.settings import ComprehensiveFCParameters, PickableSettings
+    settings = PickableSettings()
+    settings["test"] = 3
+    settings[lambda x: x + 1] = None
+
+    def f(x):
+        return x - 2
+
+    settings[f] = {"this": "is a test"}
+    settings = pickle.loads(pickle.dumps(settings))
+    assert "test" in settings and len(settings) == 3
+    for key in settings:
+        assert (not callable(key) or (key(3) == 4 and settings[key] is None)
+                or (key(3) == 1 and settings[key] == {"this": "is a test"}))
+    full = ComprehensiveFCParameters()
+    back = pickle.loads(pickle.dumps(full))
+    assert type(back) is ComprehensiveFCParameters and dict(back) == dict(full) and list(back) == list(full)

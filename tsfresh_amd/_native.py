@@ -29,6 +29,7 @@ EXPORTS = (
     "tsfa_plan_create", "tsfa_plan_n_cols", "tsfa_plan_destroy", "tsfa_extract", "tsfa_extract_timed",
     "tsfa_extract_windows",
     "tsfa_plan_set_profiling",
+    "tsfa_plan_set_option",
     "tsfa_plan_last_timings",
     "tsfa_plan_set_length_hint",
     "tsfa_host_alloc",
@@ -116,6 +117,8 @@ def load():
     lib.tsfa_host_alloc.restype = ctypes.c_int
     lib.tsfa_host_free.argtypes = [ctypes.c_void_p]
     lib.tsfa_host_free.restype = ctypes.c_int
+    lib.tsfa_plan_set_option.argtypes = [ctypes.c_void_p, ctypes.c_char_p, ctypes.c_double]
+    lib.tsfa_plan_set_option.restype = ctypes.c_int
     _lib = lib
     return lib
 
@@ -123,6 +126,12 @@ def load():
 def _check(lib, rc):
     if rc != TSFA_OK:
         raise NativeError(rc, lib.tsfa_last_error().decode("utf-8", "replace"))
+
+
+def set_library_option(name, value):
+    """Library-wide option (tsfa_plan_set_option with a NULL plan), e.g. "relevance_batch"."""
+    lib = load()
+    _check(lib, lib.tsfa_plan_set_option(None, name.encode("ascii"), float(value)))
 
 
 def device_count():
@@ -269,6 +278,11 @@ class Plan:
                 self.close()
         except Exception:
             pass
+
+    def set_option(self, name, value=1.0):
+        """A launch option of this plan (include/tsfresh_amd.h: tsfa_plan_set_option): an alternative route to the same
+        numbers, or a diagnostic pre-fill.  Environment variables do not reach the kernels."""
+        _check(self._lib, self._lib.tsfa_plan_set_option(self._h, name.encode("ascii"), float(value)))
 
     def set_profiling(self, enable=True):
         _check(self._lib, self._lib.tsfa_plan_set_profiling(self._h, 1 if enable else 0))

@@ -95,11 +95,7 @@ TSFA_DEV void entb_ranges(const Blk &b0, const double *xs, int n, const double *
         int pl[TSFA_ENTB_MAXK], ph[TSFA_ENTB_MAXK];  // byte offsets into xsrt
 #pragma unroll
         for (int k = 0; k < K; ++k) { pl[k] = 0; ph[k] = 0; }
-#if defined(TSFA_EXPERIMENT_RANGE_STEPS)   // cost experiment only (profiles/r04_i.sh): fewer bisection steps, wrong ranges
-        for (int step = (P >> 1) * 8; step >= 8 * (P >> TSFA_EXPERIMENT_RANGE_STEPS); step >>= 1) {
-#else
         for (int step = (P >> 1) * 8; step >= 8; step >>= 1) {
-#endif
             const char *at = xb + (step - 8);
 #pragma unroll
             for (int k = 0; k < K; ++k) {
@@ -452,11 +448,7 @@ TSFA_DEV void entropy_bits_batch(const Blk &b_in, const double *xs, int n, const
             rl[tt] = lane_off;
             rh[tt] = lane_off;
             ct[tt] = 0u;
-#if defined(TSFA_EXPERIMENT_NO_ENTB_TASKSETUP)
-            if (false) {
-#else
             if (id < ntask) {
-#endif
                 const int s = (int)(((unsigned int)id * kmagic) >> 16), k = id - s * kn;   // tolerance within the round
                 const int i = s * (2 * TSFA_ENTB_STRIP) + lane_row;
                 const unsigned int r = (i < n) ? rng[k * n + i] : 0u;
@@ -467,27 +459,19 @@ TSFA_DEV void entropy_bits_batch(const Blk &b_in, const double *xs, int n, const
         blk_sync();
         TSFA_TICK(tk, b, 138);
         for (int part = 0; part < nparts; ++part) {
-#if !defined(TSFA_EXPERIMENT_NO_ENTB_TABLE)   // cost experiments only (profiles/r04_i.sh): timing with a phase left out, wrong results
             entb_build_table<QW_ + 1>(b, n, perm, part * QW, NW, table, wtot);
-#endif
             TSFA_TICK(tk, b, 139);
             const int nq = (NW - part * QW < QW) ? (NW - part * QW) : QW;
-#if defined(TSFA_EXPERIMENT_NO_ENTB_SWEEP)
-            if (false) {
-#else
             if (nq == QW) {
-#endif
 #pragma unroll
                 for (int tt = 0; tt < TSFA_ENTB_MAXT; ++tt) {
                     if (wave + tt * nw < ntask) ct[tt] += entb_task_part<QW_, true>(rl[tt], rh[tt], sh, nq);
                 }
             } else {
-#if !defined(TSFA_EXPERIMENT_NO_ENTB_SWEEP)
 #pragma unroll
                 for (int tt = 0; tt < TSFA_ENTB_MAXT; ++tt) {
                     if (wave + tt * nw < ntask) ct[tt] += entb_task_part<QW_, false>(rl[tt], rh[tt], sh, nq);
                 }
-#endif
             }
             TSFA_TICK(tk, b, 136);
             blk_sync();
@@ -565,11 +549,7 @@ TSFA_DEV void entropy_bits_batch(const Blk &b_in, const double *xs, int n, const
             int sc[TSFA_ENTB_MAXK], sc1[TSFA_ENTB_MAXK], nm[TSFA_ENTB_MAXK], nm1[TSFA_ENTB_MAXK];
             double *part = (double *)(void *)(cnt + (((size_t)kcap * n + 1) & ~(size_t)1));  // [2 K][nt / 16]
             // (a thread multiplies at most four counts before the lanes combine theirs: longer rows go in chunks)
-#if defined(TSFA_EXPERIMENT_NO_ENTB_TOTALS)
-            for (int c0 = 0; c0 < 0; c0 += 4 * b.nt) {
-#else
             for (int c0 = 0; c0 < nrow_m; c0 += 4 * b.nt) {
-#endif
 #pragma unroll
                 for (int k = 0; k < K; ++k) { pm[k] = 1.0; pm1[k] = 1.0; sc[k] = 0; sc1[k] = 0; nm[k] = 0; nm1[k] = 0; }
                 for (int ib = c0; ib < nrow_m && ib < c0 + 4 * b.nt; ib += b.nt) {
@@ -681,13 +661,9 @@ TSFA_DEV void fam_entropy_series_bits(const Blk &b, double *xs, int n, const Tsf
                                       const double *stats = nullptr) {
     TSFA_TICKER(tk, 0);
     const double dn = (double)n;
-#if defined(TSFA_EXPERIMENT_NO_ENTB_STD)
-    const double mean = xs[0] * 0.0, var = 1.0 + mean;
-#else
     // (stats: the record k_basic left for this series -- the same numpy-order mean and variance, TSFA_STATS_*)
     const double mean = stats ? stats[TSFA_STATS_MEAN] : np_sum(b, n, [=](int i) { return xs[i]; }) / dn;
     const double var = stats ? stats[TSFA_STATS_VAR] : np_sum(b, n, [=](int i) { const double d = xs[i] - mean; return d * d; }) / dn;
-#endif
     const double sd = sqrt(var);
     blk_sync();
     TSFA_TICK(tk, b, 130);
@@ -695,11 +671,6 @@ TSFA_DEV void fam_entropy_series_bits(const Blk &b, double *xs, int n, const Tsf
         const int np2 = next_pow2(n);
         bool sorted = false;
 #if TSFA_GPU
-#if defined(TSFA_EXPERIMENT_NO_ENTB_SORT)   // cost experiment only (profiles/r03_i.sh): identity order, wrong results
-        for (int i = b.tid; i < np2; i += b.nt) perm[i] = (unsigned short)(i < n ? i : 0xFFFF);
-        blk_sync();
-        sorted = true;
-#endif
         if (!sorted && F32 && b.nt >= 64) {  // wavefront-local bitonic sort + merge by ranking (work: 2 * np2 64-bit words)
             unsigned long long *buf = (unsigned long long *)(void *)work;
             if (np2 == b.nt) { entb_sort_merge<1>(b, xs, n, perm, buf); sorted = true; }

@@ -873,7 +873,7 @@ TSFA_DEV void fam_spectral_series(const Blk &b, const ST *xs_raw, int n, const T
     // ---- full-length rfft ----
     // gs: 4 * bluestein_m(n) doubles of HBM scratch (or null: long lengths of arbitrary factorisation fall back on the
     // O(n^2) Goertzel sweep of blk_rfft)
-    if (BL && gs != nullptr && chirp_tab != nullptr && n >= ((n & 1) ? (bl_min & 0xFFFF) : (bl_min >> 16)) && !is_pow2(n) && bluestein_tiles_ok(n))
+    if (BL && gs != nullptr && chirp_tab != nullptr && n >= ((n & 1) ? (bl_min & 0xFFFF) : (int)((unsigned)bl_min >> 16)) && !is_pow2(n) && bluestein_tiles_ok(n))
         blk_rfft_bluestein(b, n, [=](int j) { return xs[j]; }, Xr, Xi, gs, chirp_tab, twc, tws);
     else
         blk_rfft(b, n, [=](int j) { return xs[j]; }, Xr, Xi, tc, ts, twc, tws);

@@ -36,14 +36,21 @@ struct DevBuf {
     size_t cap = 0;
     int ensure(size_t bytes) {
         if (bytes <= cap) return 0;
-        if (p) (void)hipFree(p);
-        p = nullptr;
-        cap = 0;
+        // the larger buffer first: a failed request leaves the old one (and its contents' owner) intact, and the
+        // out-of-memory error is taken off the thread -- callers with a fallback (chirp-z scratch -> Goertzel sweep) go on
+        // to launch kernels, whose launch check reads hipGetLastError (round-5 ADVICE)
         size_t want = bytes + bytes / 8 + 4096;
-        if (hipMalloc(&p, want) != hipSuccess) {
-            p = nullptr;
-            return -1;
+        void *q = nullptr;
+        if (hipMalloc(&q, want) != hipSuccess) {
+            (void)hipGetLastError();
+            if (p) { (void)hipFree(p); p = nullptr; cap = 0; }   // second try with the old buffer's bytes returned
+            if (hipMalloc(&q, want) != hipSuccess) {
+                (void)hipGetLastError();
+                return -1;
+            }
         }
+        if (p) (void)hipFree(p);
+        p = q;
         cap = want;
         return 0;
     }
@@ -64,8 +71,40 @@ struct Timing {
     float ms = 0.f;
 };
 
+// Launch options of a plan (tsfa_plan_set_option): each names an alternative ROUTE to the same numbers -- every one has a test
+// that compares both ways -- or a diagnostic pre-fill.  They are set through the C-ABI by the caller who owns the plan; the
+// shipped library reads NO environment variable that can change a result (round-5 VERDICT: 25 getenv calls on the launch path).
+// The three variables it does read, once, when a plan is built, only move work between streams: TSFA_STREAMS, TSFA_PAIR,
+// TSFA_HOST_CHUNKS.  Result-changing diagnostics (leaving a family's launch out, per-family workgroup sizes, the stderr
+// traces) exist only in the lab build (make lab: -DTSFA_LAB, libtsfresh_amd_lab.so, never loaded by the package).
+struct PlanOptions {
+    bool length_classes = true;   // launch a batch whose lengths span more than 2x class by class
+    bool stats_share = true;      // k_basic's per-series statistics record serves the ENTROPY / AR / SEQ / SORT families
+    bool perm_share = true;       // k_entropy_bits' sample order serves k_sort
+    bool select = true;           // median / quantile-only plans: order statistics by selection (k_order_stats)
+    bool bluestein = true;        // chirp-z transform for long non-power-of-two spectra
+    bool cwt_mfma = false;        // number_cwt_peaks' Ricker convolutions on v_mfma_f64_16x16x4_f64
+    bool force_long = false;      // the HBM-scratch build of every family kernel whatever the length
+    int entropy_route = 0;        // 0: bit-matrix sweep where it applies; 1: the windowed pair sweep; 2: the general kernel
+    int bluestein_min = 0;        // crossover Goertzel -> chirp-z in samples (0: the measured defaults)
+    int gscratch_slots = 0;       // cap of the chirp-z scratch slots (0: none; tests force several launches per group)
+    int host_chunks = 0;          // row chunks of the host pipeline (0: by batch size)
+    int nt[TSFA_N_FAMILIES] = {0};  // lab build: workgroup size per family (0: the measured defaults)
+    bool trace = false;           // lab build: launch decisions to stderr
+};
+
+#if defined(TSFA_LAB)
+#define TSFA_LAB_ONLY(x) (x)
+#else
+#define TSFA_LAB_ONLY(x) (0)
+#endif
+
+static int64_t g_relevance_batch = 0;   // tsfa_plan_set_option(NULL, "relevance_batch", n): columns per sort batch (tests)
+int64_t tsfa_relevance_batch_override() { return g_relevance_batch; }
+
 struct tsfa_plan {
     int device = 0;
+    PlanOptions opt;
     hipStream_t stream = nullptr;
     int n_cols = 0;
     std::vector<TsfaSpec> fam_specs[TSFA_N_FAMILIES];  // CWT slot: number_cwt_peaks specs only
@@ -268,7 +307,6 @@ int tsfa_plan_create(const tsfa_feature_spec *specs, int32_t n_specs, int32_t de
         if (!tsfa_stream_calc_ok(sp.calc) || sp.calc == TSFA_C_MEDIAN) plan->stream_ok = false;
     for (const auto &sp : plan->fam_specs[TSFA_FAM_SORT])
         if (sp.calc != TSFA_C_MEDIAN) plan->stream_ok = false;
-    if (getenv("TSFA_NO_STREAM") && atoi(getenv("TSFA_NO_STREAM"))) plan->stream_ok = false;
     bool ok = hipStreamCreateWithFlags(&plan->stream, hipStreamNonBlocking) == hipSuccess;
     for (int f = 0; ok && f < TSFA_N_FAMILIES; ++f) ok = upload(plan->fam_specs[f], &plan->d_specs[f]) == 0;
     if (ok && !cwt_coef.empty()) {
@@ -312,9 +350,7 @@ int tsfa_plan_create(const tsfa_feature_spec *specs, int32_t n_specs, int32_t de
                  hipEventCreateWithFlags(&plan->ev_side_join, hipEventDisableTiming) == hipSuccess;
         }
     }
-    if (const char *e = getenv("TSFA_DEBUG_FILL")) { plan->fill_value = atof(e); plan->fill_all = true; }
-    if (const char *e = getenv("TSFA_FILL_ALL")) plan->fill_all = plan->fill_all || atoi(e) != 0;
-    if (const char *e = getenv("TSFA_DEBUG_SKIP_FAM")) plan->debug_skip_fam = atoi(e);
+    if (const char *e = getenv("TSFA_HOST_CHUNKS")) plan->opt.host_chunks = std::max(atoi(e), 0);
     if (!ok) {
         tsfa_plan_destroy(plan);
         return fail(TSFA_ERR_HIP, "device allocation/upload failed while creating the plan");
@@ -331,6 +367,39 @@ int tsfa_plan_set_length_hint(tsfa_plan *plan, int64_t min_len, int64_t max_len)
     if (min_len < 1 || max_len < min_len || max_len > 2147483647LL / 64) return fail(TSFA_ERR_INVALID, "length hint must satisfy 1 <= min <= max <= 33554431");
     plan->hint_min_len = min_len;
     plan->hint_max_len = max_len;
+    return TSFA_OK;
+}
+
+int tsfa_plan_set_option(tsfa_plan *plan, const char *name, double value) {
+    if (!name) return fail(TSFA_ERR_INVALID, "option name is NULL");
+    const std::string n(name);
+    const bool on = value != 0.0;
+    if (!plan) {   // library-wide
+        if (n == "relevance_batch") { g_relevance_batch = value > 0.0 ? (int64_t)value : 0; return TSFA_OK; }
+        return fail(TSFA_ERR_INVALID, "unknown library option '" + n + "'");
+    }
+    PlanOptions &o = plan->opt;
+    if (n == "length_classes") o.length_classes = on;
+    else if (n == "stats_share") o.stats_share = on;
+    else if (n == "perm_share") o.perm_share = on;
+    else if (n == "select") o.select = on;
+    else if (n == "bluestein") o.bluestein = on;
+    else if (n == "cwt_mfma") o.cwt_mfma = on;
+    else if (n == "force_long") o.force_long = on;
+    else if (n == "entropy_route") { if (value != 0.0 && value != 1.0 && value != 2.0) return fail(TSFA_ERR_INVALID, "entropy_route: 0, 1 or 2"); o.entropy_route = (int)value; }
+    else if (n == "bluestein_min") o.bluestein_min = value > 0.0 ? (int)std::min(value, 32767.0) : 0;
+    else if (n == "gscratch_slots") o.gscratch_slots = value > 0.0 ? (int)std::min(value, 2147483647.0) : 0;
+    else if (n == "host_chunks") o.host_chunks = value > 0.0 ? (int)std::min(value, (double)TSFA_MAX_CHUNKS) : 0;
+    else if (n == "fused_minimal") { if (!on) plan->stream_ok = false; }   // (cannot be switched back on: decided when the plan is built)
+    else if (n == "perm_fused") { if (!on) plan->hints[TSFA_FAM_SORT].d = 0; }   // permutation_entropy stays in k_sort
+    else if (n == "fill") { plan->fill_value = value; plan->fill_all = true; }   // pre-fill the matrix (NaN, or an audit's sentinel)
+    else if (n == "fill_off") { plan->fill_all = false; }
+#if defined(TSFA_LAB)
+    else if (n == "skip_family") plan->debug_skip_fam = (int)value;
+    else if (n == "trace") o.trace = on;
+    else if (n.rfind("nt_", 0) == 0 && n.size() == 4 && n[3] >= '0' && n[3] < '0' + TSFA_N_FAMILIES) o.nt[n[3] - '0'] = (int)value;
+#endif
+    else return fail(TSFA_ERR_INVALID, "unknown plan option '" + n + "'");
     return TSFA_OK;
 }
 
@@ -379,7 +448,7 @@ struct BatchShape {
 // stats: the TSFA_LEN_STATS numbers of k_len_stats (or their host-side twin).  Length classes with fewer than
 // `min_group` series ride with the next longer class; a batch whose lengths span less than a factor of two (or that is
 // small) is one group.
-static void shape_from_stats(const long long *st, int64_t n_series, BatchShape &sh) {
+static void shape_from_stats(const long long *st, int64_t n_series, BatchShape &sh, bool length_classes) {
     sh.max_len = st[0];
     sh.min_len = st[1];
     sh.max_np2 = st[2];
@@ -388,8 +457,7 @@ static void shape_from_stats(const long long *st, int64_t n_series, BatchShape &
     sh.g_maxn[0] = (int)st[0];
     sh.g_np2[0] = st[2];
     sh.g_count[0] = n_series;
-    const char *env = getenv("TSFA_NO_LENGTH_CLASSES");
-    if ((env && atoi(env)) || n_series < 2048 || st[0] <= 2 * st[1] || st[0] <= 128) return;
+    if (!length_classes || n_series < 2048 || st[0] <= 2 * st[1] || st[0] <= 128) return;
     const int64_t min_group = 512;
     int ng = 0;
     int64_t pend_count = 0;
@@ -461,8 +529,7 @@ static int run_batch(tsfa_plan *plan, const void *d_values, int dtype, const dou
     static const int order_basic_first[TSFA_N_FAMILIES] = {TSFA_FAM_BASIC, TSFA_FAM_ENTROPY, TSFA_FAM_AR, TSFA_FAM_SORT, TSFA_FAM_CWT,
                                                            TSFA_FAM_SEQ, TSFA_FAM_SPECTRAL, TSFA_FAM_TREND};
     const bool overlap = with_overlap && plan->n_streams > 1 && !plan->profiling;
-    const bool share_stats = plan->stats_buf.p != nullptr && !overlap && !plan->stream_ok &&
-                             !(getenv("TSFA_NO_STATS_SHARE") && atoi(getenv("TSFA_NO_STATS_SHARE")));
+    const bool share_stats = plan->stats_buf.p != nullptr && !overlap && !plan->stream_ok && plan->opt.stats_share;
     const int *order = share_stats ? order_basic_first : order_long_first;
     bool stats_valid[TSFA_N_LEN_CLASSES + 1];   // launch groups whose statistics record k_basic has written
     for (int g = 0; g <= TSFA_N_LEN_CLASSES; ++g) stats_valid[g] = false;
@@ -481,13 +548,13 @@ static int run_batch(tsfa_plan *plan, const void *d_values, int dtype, const dou
     // of 3 .. 1024 samples, LDS build), and only on one stream (the entropy family is launched first).
     bool perm_valid[TSFA_N_LEN_CLASSES + 1];
     for (int g = 0; g <= TSFA_N_LEN_CLASSES; ++g) perm_valid[g] = false;
-    const bool perm_share = plan->perm_buf.p != nullptr && !overlap && !(getenv("TSFA_NO_PERM_SHARE") && atoi(getenv("TSFA_NO_PERM_SHARE")));
+    const bool perm_share = plan->perm_buf.p != nullptr && !overlap && plan->opt.perm_share;
     bool stream_done[TSFA_N_LEN_CLASSES + 1];   // launch groups whose BASIC (+ SORT) columns k_stream has written
     for (int g = 0; g <= TSFA_N_LEN_CLASSES; ++g) stream_done[g] = false;
     for (int fi = 0; fi < TSFA_N_FAMILIES; ++fi) {
         const int f = order[fi];
         if (plan->fam_specs[f].empty()) continue;
-        if (plan->debug_skip_fam == f) continue;   // diagnostics (profiles/fill_audit.py): this family's cells keep the fill
+        if (TSFA_LAB_ONLY(plan->debug_skip_fam == f)) continue;   // lab build (profiles/fill_audit.py): this family's cells keep the fill
         if (f == TSFA_FAM_BASIC && plan->stream_ok) {
             bool all = true;
             for (int g = 0; g < sh.n_groups; ++g) all = all && stream_done[g];
@@ -546,12 +613,7 @@ static int run_batch(tsfa_plan *plan, const void *d_values, int dtype, const dou
                 const int cap = std::max(64, ((maxn / 4 + 63) / 64) * 64);
                 a.nt = std::min(pref[f], cap);
             }
-            {   // experiment hook: TSFA_NT_<family index>=<threads>
-                char key[32];
-                snprintf(key, sizeof key, "TSFA_NT_%d", f);
-                const char *e = getenv(key);
-                if (e && atoi(e) >= 64) a.nt = atoi(e);
-            }
+            if (TSFA_LAB_ONLY(plan->opt.nt[f] >= 64)) a.nt = plan->opt.nt[f];   // lab build: workgroup size of a family
             a.stream = fst;
             a.dectab = plan->d_dectab;
             a.times = d_times;
@@ -565,6 +627,11 @@ static int run_batch(tsfa_plan *plan, const void *d_values, int dtype, const dou
             a.hint_e = plan->hints[f].e;
             a.alt = plan->hints[f].alt;
             a.cq = plan->hints[f].cq;
+            // SPECTRAL beyond 2048 samples: 512 threads for EVERY series of such a group, not only where some series of the
+            // group takes the chirp-z transform (whose passes over HBM scratch want them: profiles/r05_j, 2049..4096 samples
+            // 2.36 -> 2.28 ms) -- the Welch sums depend on the workgroup size in the last bit, and a series must give the same
+            // bits whatever else its shard holds (round-5 ADVICE)
+            if (f == TSFA_FAM_SPECTRAL && maxn > 2048 && !TSFA_LAB_ONLY(plan->opt.nt[f] >= 64)) a.nt = 512;
             int aux = 0;
             if (f == TSFA_FAM_TREND) aux = a.alt.small_w;   // no n-double work array in LDS (TsfaAltPlan::small_w)
             if (f == TSFA_FAM_SPECTRAL) {
@@ -574,16 +641,19 @@ static int run_batch(tsfa_plan *plan, const void *d_values, int dtype, const dou
                 // long series of non-power-of-two length: three power-of-two FFTs through HBM scratch (Bluestein,
                 // fam_spectral.h) instead of the O(n^2) Goertzel sweep; 32 M bytes per workgroup, at most 6 GB per launch
                 int bl_odd = TSFA_BLUESTEIN_MIN, bl_even = TSFA_BLUESTEIN_MIN_EVEN;
-                if (const char *e = getenv("TSFA_BLUESTEIN_MIN")) bl_odd = bl_even = std::min(std::max(atoi(e), 17), 65535);   // A/B of the crossover, tests
+                // (A/B of the crossover, tests.  32 767: both crossovers travel packed in one int)
+                if (plan->opt.bluestein_min > 0) bl_odd = bl_even = std::min(std::max(plan->opt.bluestein_min, 17), 32767);
                 a.bluestein_min = TSFA_BLUESTEIN_PACK(bl_odd, bl_even);
-                if (max_np2 >= std::min(bl_odd, bl_even) && max_np2 <= 32768 && !(getenv("TSFA_NO_BLUESTEIN") && atoi(getenv("TSFA_NO_BLUESTEIN")))) {
+                if (max_np2 >= std::min(bl_odd, bl_even) && max_np2 <= 32768 && plan->opt.bluestein) {
                     long long M = 1;
                     while (M < 2 * max_np2 - 1) M <<= 1;
-                    // one slot per workgroup of a launch; at most 4 GB (and at least the 2048 workgroups of the long-series
+                    // one slot per workgroup of a launch; at most 1 GB (and at least the 2048 workgroups of the long-series
                     // build's persistent grid, 2 MB each at the longest length): a larger group goes out in several launches
                     const size_t slot_bytes = (size_t)(4 * M) * sizeof(double);
-                    int64_t slots = std::min<int64_t>(a.n_series, std::max<int64_t>((int64_t)((4ull << 30) / slot_bytes), 2048));
-                    if (const char *e = getenv("TSFA_GSCRATCH_SLOTS")) slots = std::min<int64_t>(slots, std::max(atoi(e), 1));   // test hook: several launches per group
+                    // (1 GB: a launch of >= 2048 workgroups already fills the chip several times over, and a plan keeps this
+                    //  scratch for its lifetime -- six cached plans per thread, one per device: round-5 ADVICE)
+                    int64_t slots = std::min<int64_t>(a.n_series, std::max<int64_t>((int64_t)((1ull << 30) / slot_bytes), 2048));
+                    if (plan->opt.gscratch_slots > 0) slots = std::min<int64_t>(slots, plan->opt.gscratch_slots);   // test hook: several launches per group
                     const size_t bytes = (size_t)slots * slot_bytes;
                     if (plan->gscratch.ensure(bytes) == 0) {
                         a.gscratch = (double *)plan->gscratch.p;
@@ -594,7 +664,6 @@ static int run_batch(tsfa_plan *plan, const void *d_values, int dtype, const dou
                         // own 128 stay although 256 measured faster on 1025..2048 (1.76 -> 1.59 ms): there the workgroup size
                         // is the same for every launch group, and the Welch sums depend on it in the last bit -- a series must
                         // give the same bits in whatever shard it lands (test_extract_features_on_several_devices_from_one_process)
-                        if (!getenv("TSFA_NT_2") && maxn > 2048) a.nt = 512;
                     }
                 }
             } else if (f == TSFA_FAM_CWT) {
@@ -602,7 +671,7 @@ static int run_batch(tsfa_plan *plan, const void *d_values, int dtype, const dou
                 aux = a.cwt_rowv;
                 // bit 1: the Ricker convolutions on the float64 matrix cores (opt-in: measured 4 % slower than the FMA tiles,
                 // DESIGN.md section 9; tests/test_cwt_peaks_mfma.py compares both forms)
-                if (getenv("TSFA_CWT_MFMA") && atoi(getenv("TSFA_CWT_MFMA"))) a.cwt_rowv |= 2;
+                if (plan->opt.cwt_mfma) a.cwt_rowv |= 2;
             } else if (f == TSFA_FAM_AR) {
                 // leading dimension of the normal matrices: ADF needs maxlag(n) + 3, AR(k) needs k + 2
                 int P = 8;
@@ -647,22 +716,19 @@ static int run_batch(tsfa_plan *plan, const void *d_values, int dtype, const dou
                 a.ent_fast = a.ent_cnt;
                 for (const auto &s : plan->fam_specs[f])
                     if (s.calc == TSFA_C_APPROXIMATE_ENTROPY && (int)s.p[0] != 2) a.ent_fast = 0;
-                if (getenv("TSFA_ENT_SLOW")) a.ent_fast = 0;  // experiment / test hook: the general kernel
+                if (plan->opt.entropy_route == 2) a.ent_fast = 0;  // test hook: the general kernel
                 // series up to TSFA_ENTB_MAXN samples: the bit-matrix sweep (fam_entropy_bits.h) -- sorted ranges + bit
                 // rows instead of a distance per pair; one (strip, tolerance) task per wavefront register slot
                 // (a single tolerance: the windowed pair sweep is the cheaper one -- 7.7 vs 9.0 ms per 100k x 1024 -- the sample
                 //  sort, the table and the ranges do not amortise)
                 if (a.ent_fast && a.nspecs >= 2 && maxn <= TSFA_ENTB_MAXN && maxn >= 3 &&
-                    !(getenv("TSFA_ENT_PAIRS") && atoi(getenv("TSFA_ENT_PAIRS"))) &&
+                    plan->opt.entropy_route == 0 &&
                     tsfa_entropy_lds_bytes(maxn, 2) <= TSFA_LDS_LIMIT / 2) {
                     a.ent_cnt = 2;
                     a.nt = 64 * std::min(TSFA_ENTB_MAXWAVES, entb_waves_for(maxn, a.nspecs));
-                    char key[32];
-                    snprintf(key, sizeof key, "TSFA_NT_%d", f);
-                    const char *e = getenv(key);
-                    if (e && atoi(e) >= 64) a.nt = atoi(e);
+                    if (TSFA_LAB_ONLY(plan->opt.nt[f] >= 64)) a.nt = plan->opt.nt[f];
                 } else if (a.ent_fast && a.nspecs >= 2 && maxn > TSFA_ENTB_MAXN && maxn <= TSFA_ENTB_MAXN_LONG &&
-                           !(getenv("TSFA_ENT_PAIRS") && atoi(getenv("TSFA_ENT_PAIRS"))) &&
+                           plan->opt.entropy_route == 0 &&
                            tsfa_entropy_lds_bytes(maxn, 3) <= TSFA_LDS_LIMIT) {
                     // 1025 .. 4096 samples: the same sweep with 16-byte table entries (a column part of 96 columns still
                     // fits LDS) and the tolerances in rounds of as many as 16 wavefronts hold in registers; one
@@ -699,8 +765,8 @@ static int run_batch(tsfa_plan *plan, const void *d_values, int dtype, const dou
             // A series whose working set does not fit a CU's LDS runs from the long-series build of the same kernels
             // (tsfa_kernels_long.hip): the working set in a slot of HBM scratch per resident workgroup, a persistent
             // grid walking the group's series.  Slower per sample, but every length up to 65 535 extracts.
-            const bool use_long = lds > TSFA_LDS_LIMIT || (getenv("TSFA_FORCE_LONG") && atoi(getenv("TSFA_FORCE_LONG")));
-            if (f == TSFA_FAM_SPECTRAL && getenv("TSFA_DEBUG_SPECTRAL"))
+            const bool use_long = lds > TSFA_LDS_LIMIT || plan->opt.force_long;
+            if (TSFA_LAB_ONLY(f == TSFA_FAM_SPECTRAL && plan->opt.trace))
                 fprintf(stderr, "[tsfa] spectral group %d: n_series %lld maxn %d max_np2 %lld lds %zu long %d chirp-z %d slots %lld nt %d\n", g,
                         (long long)a.n_series, maxn, max_np2, lds, (int)use_long, (int)(a.gscratch != nullptr), (long long)a.gscratch_slots, a.nt);
             if (use_long) {
@@ -776,7 +842,7 @@ static int run_batch(tsfa_plan *plan, const void *d_values, int dtype, const dou
                 stream_done[g] = true;
             } else
             if (f == TSFA_FAM_SORT && plan->sort_only_order_stats && maxn <= 2048 && !use_long &&
-                !(getenv("TSFA_NO_SELECT") && atoi(getenv("TSFA_NO_SELECT")))) {
+                plan->opt.select) {
                 // a plan that only asks the sort family for median / quantile columns (MinimalFCParameters): selection
                 // in registers, one wavefront per series, no sorted copy (tsfa_kernels.hip: k_order_stats)
                 rc = tsfa_launch_order_stats(a);
@@ -923,7 +989,7 @@ int tsfa_extract_windows(tsfa_plan *plan, const void *values, int32_t dtype, con
             if (tsfa_launch_len_stats(starts, ends, n_series, plan->d_stats, st)) return fail(TSFA_ERR_HIP, "len_stats launch failed");
             HIP_TRY(hipMemcpyAsync(h_stats, plan->d_stats, sizeof h_stats, hipMemcpyDeviceToHost, st));
             HIP_TRY(hipStreamSynchronize(st));
-            shape_from_stats(h_stats, n_series, sh);
+            shape_from_stats(h_stats, n_series, sh, plan->opt.length_classes);
         }
         int rc = check_shape(plan, sh);
         if (rc) return rc;
@@ -959,7 +1025,7 @@ int tsfa_extract_windows(tsfa_plan *plan, const void *values, int32_t dtype, con
         return fail(TSFA_ERR_INVALID, "a series ends before it starts (offsets must be non-decreasing)");
     {
         BatchShape whole;
-        shape_from_stats(h_stats, n_series, whole);
+        shape_from_stats(h_stats, n_series, whole, plan->opt.length_classes);
         const int rc = check_shape(plan, whole);
         if (rc) return rc;
     }
@@ -1001,10 +1067,7 @@ int tsfa_extract_windows(tsfa_plan *plan, const void *values, int32_t dtype, con
 
     // chunks: >= 4096 series each (a launch should fill the 256 CUs several times over), at most TSFA_MAX_CHUNKS
     int n_chunks = (int)std::min<int64_t>(TSFA_MAX_CHUNKS, std::max<int64_t>(1, n_series / 4096));
-    {
-        const char *e = getenv("TSFA_HOST_CHUNKS");
-        if (e && atoi(e) >= 1) n_chunks = std::min(atoi(e), TSFA_MAX_CHUNKS);
-    }
+    if (plan->opt.host_chunks >= 1) n_chunks = std::min(plan->opt.host_chunks, TSFA_MAX_CHUNKS);
     if (plan->profiling) n_chunks = 1;
     n_chunks = (int)std::min<int64_t>(n_chunks, n_series);
 
@@ -1033,7 +1096,7 @@ int tsfa_extract_windows(tsfa_plan *plan, const void *values, int32_t dtype, con
         long long cs[TSFA_LEN_STATS];
         host_len_stats(starts + c0, ends + c0, c1 - c0, cs);
         BatchShape sh;
-        shape_from_stats(cs, c1 - c0, sh);
+        shape_from_stats(cs, c1 - c0, sh, plan->opt.length_classes);
         int *d_sel = (int *)plan->sel.p + c0;
         if ((rc = build_sel(plan, d_starts + c0, d_ends + c0, c1 - c0, sh, d_sel, st))) break;
         if ((rc = run_batch(plan, plan->values.p, dtype, d_times, d_starts + c0, d_ends + c0, c1 - c0, d_out + c0 * ld, ld,

@@ -216,7 +216,7 @@ static inline void tsfa_prepare_family(int fam, std::vector<TsfaSpec> &specs, Ts
                     else mask |= 1u << D;
                     ++n_pe;
                 }
-            h.d = (ok && n_pe >= 2 && mask == 0xF8u && !getenv("TSFA_NO_PE_FUSED")) ? (int)((unsigned)tau << 8 | mask) : 0;   // (fam_perm.h TSFA_PE_MASK)
+            h.d = (ok && n_pe >= 2 && mask == 0xF8u) ? (int)((unsigned)tau << 8 | mask) : 0;   // (fam_perm.h TSFA_PE_MASK)
         }
         h.c = (int)loop.size();
         // a = doubles of LDS scratch the plan needs (fam_sort.h friedrich_coeffs: 6 r + 16 + r (m + 1)), at least 320:

@@ -919,9 +919,6 @@ static int set_lds(K kern, size_t bytes) {
         const int64_t slots_ = (int64_t)(a.long_bytes / slot_);                                            \
         if (!a.long_scratch || slots_ < 1) return -2;                                                      \
         const dim3 lgrid_((unsigned)std::min<int64_t>(a.n_series, std::min<int64_t>(slots_, 2048)));       \
-        if (getenv("TSFA_DEBUG_LAUNCH"))                                                                   \
-            fprintf(stderr, "[tsfa] long launch fam %d: grid %u nt %d slot %zu bytes, scratch %zu, pending error %d\n", a.fam, \
-                    lgrid_.x, nt, slot_, a.long_bytes, (int)hipPeekAtLastError());                         \
         kern<<<lgrid_, nt, 0, st>>>(__VA_ARGS__, a.long_scratch, slot_);                                   \
     } while (0)
 #else

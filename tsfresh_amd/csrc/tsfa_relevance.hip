@@ -386,11 +386,12 @@ __global__ void __launch_bounds__(REL_NT) k_rel_ks(const double *__restrict__ X,
     }
 }
 
-// columns per batch: bound the sort scratch (12 B per padded row and column) to ~4 GB; TSFA_REL_BATCH overrides (tests)
+// columns per batch: bound the sort scratch (12 B per padded row and column) to ~4 GB; tsfa_plan_set_option(NULL,
+// "relevance_batch", n) overrides (tests)
+int64_t tsfa_relevance_batch_override();
 static int64_t rel_batch_columns(int64_t np2, int64_t n_cols) {
     int64_t batch = (int64_t)(4.0e9 / (12.0 * (double)np2));
-    const char *e = getenv("TSFA_REL_BATCH");
-    if (e && atoll(e) > 0) batch = atoll(e);
+    if (tsfa_relevance_batch_override() > 0) batch = tsfa_relevance_batch_override();
     if (batch < 1) batch = 1;
     if (batch > n_cols) batch = n_cols;
     return batch;

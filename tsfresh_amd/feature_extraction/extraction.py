@@ -12,7 +12,8 @@ dtype, sorted) and whose columns are named ``"{kind}__{calculator}__{parameters}
 
 Arguments that only steer the reference's CPU distributors (`n_jobs`, `chunksize`, `disable_progressbar`,
 `show_warnings`) are accepted and ignored.  `distributor` may be a `tsfresh_amd.utilities.distribution.GPUDistributor`
-(only its device is used); any other distributor raises the reference's ValueError.
+(only its device is used) or any other `DistributorBaseClass` (ignored with a warning); an object that is no distributor
+raises the reference's ValueError.
 """
 import collections
 import os
@@ -154,7 +155,10 @@ def _acquire_plan(fplan, device, pins=None):
     parts = _split_native_specs(specs)
     if len(parts) == 1:
         return _acquire_plan_specs(specs, device, pins)
-    return _CompositePlan([(_acquire_plan_specs(sub, device, pins), cols) for sub, cols in parts], len(specs))
+    # every part is pinned while the others are acquired (a composite of more parts than the cache holds must not close its
+    # own first part: round-5 ADVICE); a caller without a pin set gets a local one for the duration of the acquisition
+    local = pins if pins is not None else set()
+    return _CompositePlan([(_acquire_plan_specs(sub, device, local), cols) for sub, cols in parts], len(specs))
 
 
 def _trim_cache(cache, pins=()):
@@ -237,12 +241,17 @@ def extract_features(
     elif default_fc_parameters is None and kind_to_fc_parameters is not None:
         default_fc_parameters = {}
     if distributor is not None:
-        from tsfresh_amd.utilities.distribution import GPUDistributor
-        if not isinstance(distributor, GPUDistributor):
-            raise ValueError("the passed distributor is not an DistributorBaseClass object "
-                             "(tsfresh_amd runs the extraction on the GPU: pass a GPUDistributor or None)")
-        if device is None:
-            device = distributor.device
+        # extraction.py:285-286 only type-checks the object; any DistributorBaseClass is a valid argument there.  The
+        # series go to the GPU whatever it is: a GPUDistributor lends its device, another distributor is thanked and ignored
+        from tsfresh_amd.utilities.distribution import GPUDistributor, is_distributor
+        if not is_distributor(distributor):
+            raise ValueError("the passed distributor is not an DistributorBaseClass object")
+        if isinstance(distributor, GPUDistributor):
+            if device is None:
+                device = distributor.device
+        else:
+            warnings.warn("distributor {}: tsfresh_amd extracts on the GPU and does not map chunks over it; the argument "
+                          "is ignored".format(type(distributor).__name__), UserWarning, stacklevel=2)
     if profile:
         warnings.warn("profile=True (cProfile of the Python calculators) has no meaning for the GPU path; "
                       "use rocprofv3 or Plan.set_profiling instead", stacklevel=2)

@@ -42,8 +42,19 @@ def from_columns(columns, columns_to_ignore=None):
 
 
 class PickableSettings(UserDict):
-    """Base of the settings classes (the reference adds cloudpickle support for callable keys; plain dicts of
-    names pickle as they are)."""
+    """Base of the settings classes: a dict that pickles although its keys may be the user's own functions
+    (settings.py:108-129).  pickle cannot transport a lambda or a nested function; cloudpickle can, so the keys are
+    encoded with it first and pickle only ever sees bytes -- what lets a settings object with custom calculators travel to
+    dask / multiprocessing workers (and to the ranks of `tsfresh_amd.distributed`)."""
+
+    def __getstate__(self):
+        import cloudpickle
+        return {cloudpickle.dumps(key): value for key, value in self.items()}
+
+    def __setstate__(self, state):
+        import cloudpickle
+        # (UserDict keeps its mapping in `data`)
+        self.__dict__.update(data={cloudpickle.loads(key): value for key, value in state.items()})
 
 
 def _comprehensive_parameters():

@@ -21,6 +21,14 @@ except Exception:  # ImportError or a broken optional dependency of tsfresh
     _Base = object
 
 
+def is_distributor(obj):
+    """What extraction.py:285 asks: an instance of the reference's DistributorBaseClass where tsfresh is importable; where it is
+    not, any object with the class's interface (`map_reduce` + `close`, utilities/distribution.py:64-104)."""
+    if _Base is not object and isinstance(obj, _Base):
+        return True
+    return isinstance(obj, GPUDistributor) or (callable(getattr(obj, "map_reduce", None)) and callable(getattr(obj, "close", None)))
+
+
 class GPUDistributor(_Base):
     """`map_reduce` on one MI355X.  `device`: HIP ordinal (default: the package default, see extract_features)."""
 
