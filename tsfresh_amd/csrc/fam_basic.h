@@ -40,8 +40,8 @@ struct BasicStats {
 
 // want_loc: some column needs the positions / multiplicities of the extrema (first / last_location_of_*,
 // has_duplicate_*); a plan without them (MinimalFCParameters) skips that sweep and its six reductions
-template <class XS>
-TSFA_DEV void basic_stats(const Blk &b, XS xs, int n, BasicStats &st, bool want_loc = true) {
+template <class BT, class XS>
+TSFA_DEV void basic_stats(const BT &b, XS xs, int n, BasicStats &st, bool want_loc = true) {
     st.n = n;
     st.sum = np_sum(b, n, [=](int i) { return xs[i]; });          // np.sum
     st.mean = st.sum / (double)n;                                   // np.mean = add.reduce / n
@@ -84,8 +84,8 @@ TSFA_DEV void basic_stats(const Blk &b, XS xs, int n, BasicStats &st, bool want_
 }
 
 // longest run of `true` of pred(i), i in [0, n)  (fc.py:102 _get_length_sequences_where + max)
-template <class P>
-TSFA_DEV double blk_longest_run(const Blk &b, int n, P pred, int *iw) {
+template <class BT, class P>
+TSFA_DEV double blk_longest_run(const BT &b, int n, P pred, int *iw) {
     // each thread scans a contiguous segment; segments are stitched by thread 0
     const int chunk = (n + b.nt - 1) / b.nt;
     const int lo = b.tid * chunk;
@@ -107,9 +107,10 @@ TSFA_DEV double blk_longest_run(const Blk &b, int n, P pred, int *iw) {
     // (pre, suf, best, len) of adjacent segments combine associatively ("all true" <=> pre == len), so the wavefront
     // stitches its 64 segments with an ordered butterfly (6 shuffle steps) instead of a serial walk by thread 0
     int len = (hi > lo) ? (hi - lo) : 0;
-    const int lane = b.tid & 63;
+    constexpr int LN = BlkLanes<BT>::n;   // lanes that stitch without LDS: the wavefront, or the 16-lane row of the row form
+    const int lane = b.tid & (LN - 1);
 #pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
+    for (int d = 1; d < LN; d <<= 1) {
         const int opre = __shfl_xor(pre, d), osuf = __shfl_xor(suf, d), obest = __shfl_xor(best, d), olen = __shfl_xor(len, d);
         const bool left = ((lane & d) == 0);  // this lane's aggregate lies to the left of its partner's
         const int Lpre = left ? pre : opre, Lsuf = left ? suf : osuf, Lbest = left ? best : obest, Llen = left ? len : olen;
@@ -121,7 +122,7 @@ TSFA_DEV double blk_longest_run(const Blk &b, int n, P pred, int *iw) {
         best = nb;
         len = Llen + Rlen;
     }
-    if (b.nt == 64) return (double)best;
+    if (b.nt == LN) return (double)best;
     const int nw = b.nt >> 6, wv = b.tid >> 6;
     blk_sync();
     if (lane == 0) { iw[4 * wv + 0] = pre; iw[4 * wv + 1] = suf; iw[4 * wv + 2] = best; iw[4 * wv + 3] = len; }
@@ -148,8 +149,8 @@ TSFA_DEV double blk_longest_run(const Blk &b, int n, P pred, int *iw) {
 //   * the scalar tail of linregress (a dozen dependent float64 divisions / square roots, ~4k cycles) runs ONCE with
 //     lane = regression instead of once per regression on every lane.
 // raw: LDS, 6 doubles per key (m, mean, sxy, syy, y0, y1); w: LDS, >= n doubles; altc[8 * key + 2 + attr] = results.
-template <class XS>
-TSFA_DEV void alt_fill_all(const Blk &b, XS xs, int n, const TsfaAltPlan &alt, double *w, double *raw,
+template <class BT, class XS>
+TSFA_DEV void alt_fill_all(const BT &b, XS xs, int n, const TsfaAltPlan &alt, double *w, double *raw,
                            double *altc) {
     const int nkeys = alt.nkeys;
     int k0 = 0;
@@ -303,7 +304,8 @@ enum { TSFA_CTX_SUM = 0, TSFA_CTX_MEAN, TSFA_CTX_VAR, TSFA_CTX_STD, TSFA_CTX_VMI
 // Columns [first, nspecs): closed forms of the statistics in ctx and reads of the caches (altc, ctx), lane = column.
 // Every lane fetches its own spec (one coalesced vector load for the whole group instead of a scalar-load round trip
 // per column) and stores its own value.
-TSFA_DEV void basic_epilogue(const Blk &b, const TsfaSpec *specs, int first, int nspecs, int n, const double *ctx,
+template <class BT>
+TSFA_DEV void basic_epilogue(const BT &b, const TsfaSpec *specs, int first, int nspecs, int n, const double *ctx,
                              const double *altc, double *out_row) {
     const double dn = (double)n;
     for (int s = first + b.tid; s < nspecs; s += b.nt) {
@@ -352,8 +354,8 @@ TSFA_DEV void basic_epilogue(const Blk &b, const TsfaSpec *specs, int first, int
 // q agree, no c_i lies in the band and the count is the reference's index.  Otherwise (a prefix sum that hits q S to
 // within 5e-13: integer-valued series do) the function returns false and the caller takes the serial route.
 // cum: LDS scratch, >= nt + 2 * nq + 2 doubles.  Writes altc[8 k + 7] for every q.
-template <class XS>
-TSFA_DEV bool imq_banded(const Blk &b, XS xs, int n, double S, const TsfaAltPlan &alt, double *cum, double *altc) {
+template <class BT, class XS>
+TSFA_DEV bool imq_banded(const BT &b, XS xs, int n, double S, const TsfaAltPlan &alt, double *cum, double *altc) {
     const int nq = alt.nq;
     if (!(S > 0.0) || !(S < TSFA_INF) || n < 1) return false;  // uniform
     const double dn = (double)n;
@@ -367,7 +369,7 @@ TSFA_DEV bool imq_banded(const Blk &b, XS xs, int n, double S, const TsfaAltPlan
     for (int i = beg; i < end; ++i) t += fabs(xs[i]);
     blk_sync();
 #if TSFA_GPU
-    if (b.nt == 64) {
+    if (!BlkIsRow<BT>::v && b.nt == 64) {
         double o = 0.0, mine = 0.0;
         for (int j = 0; j < nown; ++j) {
             if ((b.tid & 63) == j) mine = o;
@@ -441,8 +443,8 @@ TSFA_DEV bool imq_banded(const Blk &b, XS xs, int n, double S, const TsfaAltPlan
 // The serial route without the n-double array (TsfaAltPlan::small_w): lane = q, every lane adds the samples in a row
 // (the rounding of np.cumsum) and notes the first i with c_i / S >= q.  fl(c / S) is monotone in c, so far below
 // q S the answer is no and far above it is yes without dividing; the division decides only within 1e-15 of q S.
-template <class XS>
-TSFA_DEV void imq_serial_walk(const Blk &b, XS xs, int n, double S, const TsfaAltPlan &alt, double *altc) {
+template <class BT, class XS>
+TSFA_DEV void imq_serial_walk(const BT &b, XS xs, int n, double S, const TsfaAltPlan &alt, double *altc) {
     const double dn = (double)n;
     for (int k = b.tid; k < alt.nq; k += b.nt) {
         double q = 0.0;
@@ -479,11 +481,65 @@ TSFA_DEV void imq_serial_walk(const Blk &b, XS xs, int n, double S, const TsfaAl
 TSFA_DEV bool basic_count_scaled(int calc) {  // count / n instead of the count
     return calc == TSFA_C_RATIO_BEYOND_R_SIGMA || calc == TSFA_C_COUNT_ABOVE || calc == TSFA_C_COUNT_BELOW;
 }
-template <class XS>
-TSFA_DEV void basic_count_pass(const Blk &b, XS xs, int n, const TsfaSpec *specs, int ncount, const BasicStats &st,
+template <class BT, class XS>
+TSFA_DEV void basic_count_pass(const BT &b, XS xs, int n, const TsfaSpec *specs, int ncount, const BasicStats &st,
                                double *out_row, int *iw) {
     const double mean = st.mean, dn = (double)n;
 #if TSFA_GPU
+    if constexpr (BlkIsRow<BT>::v) {
+        // row form (n <= 256 = 16 samples per lane): a predicate is a compare and an add-with-carry per register, the count one
+        // integer DPP tree inside the row; the columns' spec loads and dispatch are shared by the four rows of the wavefront
+        (void)iw;
+        const int lane = b.tid;
+        double xr[16];
+#pragma unroll
+        for (int u = 0; u < 16; ++u) {
+            const int i = u * 16 + lane;
+            xr[u] = (i < n) ? xs[i] : TSFA_NAN;  // NaN: every ordered comparison below is false
+        }
+        TsfaSpec nxt = specs[0];
+        for (int e = 0; e < ncount; ++e) {
+            const TsfaSpec sp = nxt;
+            nxt = specs[(e + 1 < ncount) ? e + 1 : e];
+            const double p0 = sp.p[0], p1 = sp.p[1];
+            int c = 0;
+            int ln = lane;
+            asm volatile("" : "+v"(ln));
+#pragma unroll
+            for (int u = 0; u < 16; ++u) asm volatile("" : "+v"(xr[u]));
+#define TSFA_ROWCOUNT_LOOP(PRED) \
+    _Pragma("unroll") for (int u = 0; u < 16; ++u) { const double x = xr[u]; c += (PRED) ? 1 : 0; }
+            switch (sp.calc) {
+            case TSFA_C_RATIO_BEYOND_R_SIGMA: { const double thr = p0 * st.std; TSFA_ROWCOUNT_LOOP(fabs(x - mean) > thr) } break;
+            case TSFA_C_COUNT_ABOVE_MEAN: TSFA_ROWCOUNT_LOOP(x > mean) break;
+            case TSFA_C_COUNT_BELOW_MEAN: TSFA_ROWCOUNT_LOOP(x < mean) break;
+            case TSFA_C_COUNT_ABOVE: TSFA_ROWCOUNT_LOOP(x >= p0) break;
+            case TSFA_C_COUNT_BELOW: TSFA_ROWCOUNT_LOOP(x <= p0) break;
+            case TSFA_C_RANGE_COUNT: TSFA_ROWCOUNT_LOOP(x >= p0 && x < p1) break;
+            case TSFA_C_VALUE_COUNT:
+                if (p0 != p0) {
+#pragma unroll
+                    for (int u = 0; u < 16; ++u) { const double x = xr[u]; c += (u * 16 + ln < n && x != x) ? 1 : 0; }
+                } else {
+                    TSFA_ROWCOUNT_LOOP(x == p0)
+                }
+                break;
+            case TSFA_C_NUMBER_CROSSING_M: {
+#pragma unroll
+                for (int u = 0; u < 16; ++u) {
+                    const int i = u * 16 + ln + 1;
+                    const double y = xs[(i < n) ? i : (n - 1)];
+                    c += (i < n && ((xr[u] > p0) != (y > p0))) ? 1 : 0;
+                }
+            } break;
+            default: break;
+            }
+#undef TSFA_ROWCOUNT_LOOP
+            c = row_sum_i32(c);
+            if (lane == 0) out_row[sp.col] = basic_count_scaled(sp.calc) ? (double)c / dn : (double)c;
+        }
+        return;
+    }
     const int lane = b.tid & 63, wave = b.tid >> 6, nwave = b.nt >> 6;
     blk_sync();
     for (int e = b.tid; e < ncount; e += b.nt) iw[e] = 0;
@@ -581,23 +637,24 @@ TSFA_DEV void basic_count_pass(const Blk &b, XS xs, int n, const TsfaSpec *specs
 // per lane), the lagged operands of a column are fetched from LDS all at once (16 independent reads in flight instead
 // of a read -> multiply -> add round trip per loop iteration) and the lane sums run in the same order as the column
 // loop's (identical results).  Other shapes leave these columns to the column loop.
-template <class XS>
-TSFA_DEV bool basic_sum_pass(const Blk &b, XS xs, int n, const TsfaSpec *specs, int first, int nsum, const BasicStats &st,
+template <class BT, class XS>
+TSFA_DEV bool basic_sum_pass(const BT &b, XS xs, int n, const TsfaSpec *specs, int first, int nsum, const BasicStats &st,
                              double *out_row) {
 #if TSFA_GPU
-    if (b.nt != 64 || n > 1024 || nsum <= 0) return false;
+    constexpr int LN = BlkLanes<BT>::n;   // 64: one wavefront owns <= 1024 samples; 16: the row form (<= 256)
+    if (b.nt != LN || n > 16 * LN || nsum <= 0) return false;
     const int lane0 = b.tid;
     const double mean = st.mean, dn = (double)n;
     double xr[16];
 #pragma unroll
     for (int u = 0; u < 16; ++u) {
-        const int i = u * 64 + lane0;
+        const int i = u * LN + lane0;
         xr[u] = xs[(i < n) ? i : (n - 1)];  // unconditional reads (clamped index): every use below is masked
     }
 #define TSFA_LOAD_LAG(Y, LAG)                                                                         \
     double Y[16];                                                                                     \
     _Pragma("unroll") for (int u = 0; u < 16; ++u) {                                                  \
-        const int i = u * 64 + lane + (LAG);                                                          \
+        const int i = u * LN + lane + (LAG);                                                          \
         Y[u] = xs[(i < n) ? i : (n - 1)];                                                             \
     }
     TsfaSpec nxt = specs[first];
@@ -620,7 +677,7 @@ TSFA_DEV bool basic_sum_pass(const Blk &b, XS xs, int n, const TsfaSpec *specs, 
 #pragma unroll
             for (int u = 0; u < 16; ++u) {
                 const double t = (xr[u] - mean) * (y[u] - mean);
-                a += (u * 64 + lane < n - lag) ? t : 0.0;
+                a += (u * LN + lane < n - lag) ? t : 0.0;
             }
             a = blk_sum(b, a);
             if (!(fabs(st.var) <= 1e-8)) v = a / ((double)(n - lag) * st.var);  // np.isclose(v, 0) -> NaN
@@ -635,12 +692,12 @@ TSFA_DEV bool basic_sum_pass(const Blk &b, XS xs, int n, const TsfaSpec *specs, 
             double a = 0.0;
             if (sp.calc == TSFA_C_C3) {
 #pragma unroll
-                for (int u = 0; u < 16; ++u) { const double t = y2[u] * y1[u] * xr[u]; a += (u * 64 + lane < m) ? t : 0.0; }
+                for (int u = 0; u < 16; ++u) { const double t = y2[u] * y1[u] * xr[u]; a += (u * LN + lane < m) ? t : 0.0; }
             } else {
 #pragma unroll
                 for (int u = 0; u < 16; ++u) {
                     const double t = y2[u] * y2[u] * y1[u] - y1[u] * xr[u] * xr[u];
-                    a += (u * 64 + lane < m) ? t : 0.0;
+                    a += (u * LN + lane < m) ? t : 0.0;
                 }
             }
             v = blk_sum(b, a) / (double)m;
@@ -652,7 +709,7 @@ TSFA_DEV bool basic_sum_pass(const Blk &b, XS xs, int n, const TsfaSpec *specs, 
             const int hi = lo + q + (foc < rem ? 1 : 0);
             double a = 0.0;
 #pragma unroll
-            for (int u = 0; u < 16; ++u) { const int i = u * 64 + lane; a += (i >= lo && i < hi) ? xr[u] * xr[u] : 0.0; }
+            for (int u = 0; u < 16; ++u) { const int i = u * LN + lane; a += (i >= lo && i < hi) ? xr[u] * xr[u] : 0.0; }
             a = blk_sum(b, a);
             v = (st.sumsq == 0.0) ? TSFA_NAN : a / st.sumsq;
         } break;
@@ -665,7 +722,7 @@ TSFA_DEV bool basic_sum_pass(const Blk &b, XS xs, int n, const TsfaSpec *specs, 
 #pragma unroll
             for (int u = 0; u < 16; ++u) {
                 const double d = normalize ? ((y[u] - mean) / sd - (xr[u] - mean) / sd) : (y[u] - xr[u]);
-                a += (u * 64 + lane < n - 1) ? d * d : 0.0;
+                a += (u * LN + lane < n - 1) ? d * d : 0.0;
             }
             v = sqrt(blk_sum(b, a));
         } break;
@@ -674,7 +731,7 @@ TSFA_DEV bool basic_sum_pass(const Blk &b, XS xs, int n, const TsfaSpec *specs, 
             TSFA_LOAD_LAG(y, 1)
             double a = 0.0;
 #pragma unroll
-            for (int u = 0; u < 16; ++u) a += (u * 64 + lane < n - 1) ? fabs(y[u] - xr[u]) : 0.0;
+            for (int u = 0; u < 16; ++u) a += (u * LN + lane < n - 1) ? fabs(y[u] - xr[u]) : 0.0;
             a = blk_sum(b, a);
             if (sp.calc == TSFA_C_MEAN_ABS_CHANGE) v = (n > 1) ? a / (double)(n - 1) : TSFA_NAN;
             else v = a;
@@ -687,7 +744,7 @@ TSFA_DEV bool basic_sum_pass(const Blk &b, XS xs, int n, const TsfaSpec *specs, 
             for (int u = 0; u < 16; ++u) {
                 const double a = xr[u] - mean;
                 const double a2 = a * a;
-                const bool in = (u * 64 + lane < n);
+                const bool in = (u * LN + lane < n);
                 m2 += in ? a2 : 0.0;
                 mh += in ? (skew ? a2 * a : a2 * a2) : 0.0;
             }
@@ -734,13 +791,13 @@ TSFA_DEV bool basic_sum_pass(const Blk &b, XS xs, int n, const TsfaSpec *specs, 
 // agg_linear_trend -- the calculators that need a float64 work array of n entries), 3 = both.  Two kernels instead
 // of one: each half needs far fewer registers and less LDS than the union, and both are latency-bound (the resident
 // wavefronts per CU are what they gain from).
-template <int PART, class XS>
-TSFA_DEV void fam_basic_series(const Blk &b0, XS xs, int n, const TsfaSpec *specs, int nspecs,
+template <int PART, class BT, class XS>
+TSFA_DEV void fam_basic_series(const BT &b0, XS xs, int n, const TsfaSpec *specs, int nspecs,
                                double *out_row, double *w, double *cum, double *altc, int *iw, const double *dectab,
                                int peaks_hint, int alt_want_p, const TsfaAltPlan &alt, TsfaSpec *stage,
                                const double *times = nullptr, int n_loop = -1, double *ctx = nullptr,
                                int n_count = 0, int n_sum = 0, double *stats_out = nullptr) {
-    const Blk &b = b0;
+    const BT &b = b0;
     TSFA_TICKER(tk, 0);
     BasicStats st;
     const int peaks_maxsup = peaks_hint & 0xFFFF;         // tsfa_prepare_family: largest number_peaks support
@@ -804,7 +861,7 @@ TSFA_DEV void fam_basic_series(const Blk &b0, XS xs, int n, const TsfaSpec *spec
         // all the other columns and spilled
         int tid_opaque = b0.tid;
         asm volatile("" : "+v"(tid_opaque));
-        const Blk b{tid_opaque, b0.nt, b0.red, b0.np};
+        const BT b = blk_rebind(b0, tid_opaque);
 #endif
         TSFA_TICKER(tkc, 0);
         const TsfaSpec sp = nxt;

@@ -91,6 +91,7 @@ struct PlanOptions {
     int host_chunks = 0;          // row chunks of the host pipeline (0: by batch size)
     int nt[TSFA_N_FAMILIES] = {0};  // lab build: workgroup size per family (0: the measured defaults)
     bool trace = false;           // lab build: launch decisions to stderr
+    bool row_form = true;         // BASIC / TREND: series of <= 256 samples four to a wavefront (k_basic_rows / k_trend_rows)
 };
 
 #if defined(TSFA_LAB)
@@ -386,6 +387,7 @@ int tsfa_plan_set_option(tsfa_plan *plan, const char *name, double value) {
     else if (n == "bluestein") o.bluestein = on;
     else if (n == "cwt_mfma") o.cwt_mfma = on;
     else if (n == "force_long") o.force_long = on;
+    else if (n == "row_form") o.row_form = on;
     else if (n == "entropy_route") { if (value != 0.0 && value != 1.0 && value != 2.0) return fail(TSFA_ERR_INVALID, "entropy_route: 0, 1 or 2"); o.entropy_route = (int)value; }
     else if (n == "bluestein_min") o.bluestein_min = value > 0.0 ? (int)std::min(value, 32767.0) : 0;
     else if (n == "gscratch_slots") o.gscratch_slots = value > 0.0 ? (int)std::min(value, 2147483647.0) : 0;
@@ -442,6 +444,7 @@ struct BatchShape {
     int g_maxn[TSFA_N_LEN_CLASSES] = {0};
     long long g_np2[TSFA_N_LEN_CLASSES] = {0};
     int64_t g_count[TSFA_N_LEN_CLASSES] = {0};
+    bool g_has_short[TSFA_N_LEN_CLASSES] = {false};   // the group holds series of <= TSFA_ROW_MAXN samples (the row form's)
     TsfaClassMap map;
 };
 
@@ -457,6 +460,7 @@ static void shape_from_stats(const long long *st, int64_t n_series, BatchShape &
     sh.g_maxn[0] = (int)st[0];
     sh.g_np2[0] = st[2];
     sh.g_count[0] = n_series;
+    sh.g_has_short[0] = st[1] <= TSFA_ROW_MAXN;
     if (!length_classes || n_series < 2048 || st[0] <= 2 * st[1] || st[0] <= 128) return;
     const int64_t min_group = 512;
     int ng = 0;
@@ -474,7 +478,11 @@ static void shape_from_stats(const long long *st, int64_t n_series, BatchShape &
             sh.g_maxn[ng] = (int)st[3 + TSFA_N_LEN_CLASSES + c];
             sh.g_np2[ng] = pend_np2;
             sh.g_count[ng] = pend_count;
-            for (int d = first_of_group; d <= c; ++d) sh.map.group_of[d] = ng;
+            sh.g_has_short[ng] = false;
+            for (int d = first_of_group; d <= c; ++d) {   // classes 0 .. 2 end at 64, 128, 256 samples
+                sh.map.group_of[d] = ng;
+                if ((64LL << d) <= TSFA_ROW_MAXN && st[3 + d] > 0) sh.g_has_short[ng] = true;
+            }
             first_of_group = c + 1;
             pend_count = 0;
             pend_np2 = 0;
@@ -854,7 +862,20 @@ static int run_batch(tsfa_plan *plan, const void *d_values, int dtype, const dou
                     rc = use_long ? tsfa_launch_family_long(a) : tsfa_launch_family(a);
                 }
             } else {
-                rc = use_long ? tsfa_launch_family_long(a) : tsfa_launch_family(a);
+                // BASIC / TREND: a series of at most TSFA_ROW_MAXN samples is evaluated by the row form (four series per
+                // wavefront, tsfa_common.h BlkRow) whatever else its launch group holds -- its length alone decides, so it
+                // gives the same bits in every batch and shard; the family kernel skips those series
+                bool rows_any = false, rows_all = false;
+                const bool lite = (f == TSFA_FAM_BASIC && plan->hints[f].c == 0 && a.nt <= 256);   // (k_basic_lite: closed forms only)
+                if ((f == TSFA_FAM_BASIC || f == TSFA_FAM_TREND) && plan->opt.row_form && !lite && g <= TSFA_N_LEN_CLASSES) {
+                    rows_any = sh.g_has_short[g];
+                    rows_all = maxn <= TSFA_ROW_MAXN;
+                }
+                if (rows_any) {
+                    a.skip_le = TSFA_ROW_MAXN;
+                    rc = tsfa_launch_rows(a);
+                }
+                if (rc == 0 && !rows_all) rc = use_long ? tsfa_launch_family_long(a) : tsfa_launch_family(a);
             }
             if (rc == 0 && f == TSFA_FAM_AR) rc = tsfa_launch_ar_degenerate(a);
             if (rc == 0 && f == TSFA_FAM_SORT && a.pf_buf) rc = tsfa_launch_langevin_dd(a);
@@ -983,6 +1004,7 @@ int tsfa_extract_windows(tsfa_plan *plan, const void *values, int32_t dtype, con
             sh.g_maxn[0] = (int)h_stats[0];
             sh.g_np2[0] = h_stats[2];
             sh.g_count[0] = n_series;
+            sh.g_has_short[0] = plan->hint_min_len <= TSFA_ROW_MAXN;
             memset(&sh.map, 0, sizeof sh.map);
         } else {
             HIP_TRY(hipMemcpyAsync(plan->d_stats, h_stats, sizeof h_stats, hipMemcpyHostToDevice, st));

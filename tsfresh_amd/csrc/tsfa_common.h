@@ -72,6 +72,25 @@ struct Blk {
     NpScratch *np;  // LDS
 };
 
+// ROW FORM (round 6): a series of at most TSFA_ROW_MAXN samples is owned by ONE 16-lane DPP row of a wavefront, four series
+// per wavefront.  At 256 samples a 64-lane workgroup holds four samples per lane and spends its time on what is per COLUMN --
+// the scalar spec fetch and dispatch, a cross-lane reduction with its v_readlane stage, the closing float64 divisions, the
+// store (k_basic: 3.14 ms per 125 000 x 256 against 3.09 ms per 100 000 x 1024).  In the row form those
+// instructions are issued once for four series; a reduction is the four DPP steps inside the row and ends there.
+// A BlkRow is a Blk whose `tid` / `nt` are the lane within the row and 16; the overloads below (chosen by the static type,
+// so every function between the kernel and a primitive is a template on the block type) never leave the row.  Which form
+// evaluates a series depends on ITS length alone (n <= TSFA_ROW_MAXN: always the row form), never on what else the launch
+// group or the shard holds: a series gives the same bits wherever it lands.
+#define TSFA_ROW_MAXN 256
+#define TSFA_ROW_LANES 16
+struct BlkRow : Blk {};
+template <class BT> struct BlkLanes { static constexpr int n = 64; };
+template <> struct BlkLanes<BlkRow> { static constexpr int n = TSFA_ROW_LANES; };
+template <class BT> struct BlkIsRow { static constexpr bool v = false; };
+template <> struct BlkIsRow<BlkRow> { static constexpr bool v = true; };
+TSFA_DEV Blk blk_rebind(const Blk &b, int tid) { return Blk{tid, b.nt, b.red, b.np}; }
+TSFA_DEV BlkRow blk_rebind(const BlkRow &b, int tid) { BlkRow r; r.tid = tid; r.nt = b.nt; r.red = b.red; r.np = b.np; return r; }
+
 // Phase clocks (diagnostics build only: make ticks -> libtsfresh_amd_ticks.so, read with tsfa_debug_ticks).
 // Thread 0 of every workgroup adds the shader-clock cycles since its previous mark to a global counter per phase id,
 // so one bench pass yields the per-phase latency breakdown of every kernel (rocprofv3 only sees whole kernels).
@@ -469,6 +488,57 @@ TSFA_DEV double blk_bcast0(const Blk &b, double v) {
     return v;
 }
 
+#if TSFA_GPU
+// ---------------------------------------------------------------------------------------------
+// row form: every lane of the 16-lane row receives the result; nothing crosses a row
+// ---------------------------------------------------------------------------------------------
+TSFA_DEV double row_sum_f64(double v) {
+    v += dpp_mov_f64<TSFA_DPP_QUAD_XOR1>(v);
+    v += dpp_mov_f64<TSFA_DPP_QUAD_XOR2>(v);
+    v += dpp_mov_f64<TSFA_DPP_ROW_HALF_MIRROR>(v);
+    v += dpp_mov_f64<TSFA_DPP_ROW_MIRROR>(v);
+    return v;
+}
+template <int CTRL>
+TSFA_DEV int dpp_mov_i32(int v) { return __builtin_amdgcn_update_dpp(v, v, CTRL, 0xf, 0xf, false); }
+TSFA_DEV int row_sum_i32(int v) {
+    v += dpp_mov_i32<TSFA_DPP_QUAD_XOR1>(v);
+    v += dpp_mov_i32<TSFA_DPP_QUAD_XOR2>(v);
+    v += dpp_mov_i32<TSFA_DPP_ROW_HALF_MIRROR>(v);
+    v += dpp_mov_i32<TSFA_DPP_ROW_MIRROR>(v);
+    return v;
+}
+TSFA_DEV double blk_sum(const BlkRow &, double v) { return row_sum_f64(v); }
+TSFA_DEV double blk_min(const BlkRow &, double v) {
+    v = fmin(v, dpp_mov_f64<TSFA_DPP_QUAD_XOR1>(v));
+    v = fmin(v, dpp_mov_f64<TSFA_DPP_QUAD_XOR2>(v));
+    v = fmin(v, dpp_mov_f64<TSFA_DPP_ROW_HALF_MIRROR>(v));
+    return fmin(v, dpp_mov_f64<TSFA_DPP_ROW_MIRROR>(v));
+}
+TSFA_DEV double blk_max(const BlkRow &, double v) {
+    v = fmax(v, dpp_mov_f64<TSFA_DPP_QUAD_XOR1>(v));
+    v = fmax(v, dpp_mov_f64<TSFA_DPP_QUAD_XOR2>(v));
+    v = fmax(v, dpp_mov_f64<TSFA_DPP_ROW_HALF_MIRROR>(v));
+    return fmax(v, dpp_mov_f64<TSFA_DPP_ROW_MIRROR>(v));
+}
+template <int N>
+TSFA_DEV void blk_sum_multi(const BlkRow &, double *v) {
+#pragma unroll
+    for (int k = 0; k < N; ++k) v[k] = row_sum_f64(v[k]);
+}
+TSFA_DEV unsigned blk_or16(const BlkRow &, unsigned v) {
+    int r = (int)v;
+    r |= dpp_mov_i32<TSFA_DPP_QUAD_XOR1>(r);
+    r |= dpp_mov_i32<TSFA_DPP_QUAD_XOR2>(r);
+    r |= dpp_mov_i32<TSFA_DPP_ROW_HALF_MIRROR>(r);
+    r |= dpp_mov_i32<TSFA_DPP_ROW_MIRROR>(r);
+    return (unsigned)r;
+}
+// the value of the row's lane `src` (0 .. 15) in every lane of the row
+TSFA_DEV double row_bcast_f64(double v, int src) { return __shfl(v, src, TSFA_ROW_LANES); }
+TSFA_DEV double blk_bcast0(const BlkRow &, double v) { return row_bcast_f64(v, 0); }
+#endif
+
 // ---------------------------------------------------------------------------------------------
 // numpy-order summation.
 //
@@ -704,6 +774,66 @@ TSFA_DEV double np_sum(const Blk &b, int n, F f) {
     blk_sync();
     return total;
 }
+
+#if TSFA_GPU
+// np.sum's order for a series of at most TSFA_ROW_MAXN = 256 samples on ONE 16-lane row: the pairwise tree of such a length
+// has at most three leaves (129 .. 256 samples: a left half rounded down to a multiple of eight, <= 128, and a right part
+// that is split once more when it exceeds 128 -- 255 samples are 120 + (64 + 71)), a leaf is eight strided accumulators
+// combined as ((r0 + r1) + (r2 + r3)) + ((r4 + r5) + (r6 + r7)) plus a serial tail: eight lanes per leaf, two leaves side by
+// side, a second turn for the third.  The same additions in the same order as the general path above; no LDS, no barrier.
+template <class F>
+TSFA_DEV double np_row_leaves(int lane, int o, int l, F f) {   // lanes 0-7: leaf (o, l) -> its sum in lane 0 of the group of eight
+    const int k = lane & 7;
+    double r = 0.0;
+    if (l >= 8) {
+        const int lim = l - (l % 8);
+        r = f(o + k);
+        for (int i = 8; i < lim; i += 8) r += f(o + i + k);
+    }
+    r += dpp_mov_f64<TSFA_DPP_QUAD_XOR1>(r);
+    r += dpp_mov_f64<TSFA_DPP_QUAD_XOR2>(r);
+    r += dpp_mov_f64<TSFA_DPP_ROW_HALF_MIRROR>(r);
+    if (k == 0) {
+        if (l < 8) {
+            r = 0.0;
+            for (int i = 0; i < l; ++i) r += f(o + i);
+        } else {
+            for (int i = l - (l % 8); i < l; ++i) r += f(o + i);
+        }
+    }
+    return r;
+}
+template <class F>
+TSFA_DEV double np_sum(const BlkRow &b, int n, F f) {
+    if (n <= 0) return 0.0;
+    const int lane = b.tid;
+    // leaves, left to right
+    int o1 = 0, l1 = 0, o2 = 0, l2 = 0, l0 = n, nleaf = 1;
+    if (n > 128) {
+        int h = n / 2;
+        h -= h % 8;
+        l0 = h;
+        o1 = h;
+        l1 = n - h;
+        nleaf = 2;
+        if (l1 > 128) {
+            int h2 = l1 / 2;
+            h2 -= h2 % 8;
+            o2 = o1 + h2;
+            l2 = l1 - h2;
+            l1 = h2;
+            nleaf = 3;
+        }
+    }
+    const bool second = lane >= 8;
+    const double a = np_row_leaves(lane, second ? o1 : 0, second ? l1 : l0, f);
+    const double s0 = row_bcast_f64(a, 0), s1 = row_bcast_f64(a, 8);
+    double s2 = 0.0;
+    // (rows of one wavefront may differ in their leaf count: the third turn is taken by the rows that have one)
+    if (nleaf == 3) s2 = row_bcast_f64(np_row_leaves(lane, o2, second ? 0 : l2, f), 0);
+    return (nleaf == 1) ? s0 : (nleaf == 2) ? (s0 + s1) : (s0 + (s1 + s2));
+}
+#endif
 
 // ---------------------------------------------------------------------------------------------
 // in-LDS bitonic sort (ascending) of a power-of-two padded array
@@ -1153,8 +1283,8 @@ TSFA_DEV double tsfa_norm_cdf(double x) { return 0.5 * erfc(-x * 0.7071067811865
 // out[0..4] = pvalue, rvalue, intercept, slope, stderr       (scipy/stats/_stats_py.py, linregress)
 // ---------------------------------------------------------------------------------------------
 // want_p: the p-value costs a continued fraction (incomplete beta); agg_linear_trend never asks for it
-template <class G>
-TSFA_DEV void blk_linregress_index(const Blk &b, int m, G g, double *out5, bool want_p = true) {
+template <class BT, class G>
+TSFA_DEV void blk_linregress_index(const BT &b, int m, G g, double *out5, bool want_p = true) {
     const double dm = (double)m;
     double sy = 0.0;
     for (int i = b.tid; i < m; i += b.nt) sy += g(i);
@@ -1205,8 +1335,8 @@ TSFA_DEV void blk_linregress_index(const Blk &b, int m, G g, double *out5, bool 
 // scipy.stats.linregress(x, y) for an arbitrary abscissa (fc.py:2274 linear_trend_timewise: x = hours since the
 // first timestamp).  Centred sums as np.cov(x, y, bias=1) forms them.  All x identical: scipy raises ValueError
 // ("Cannot calculate a linear regression if all x values are identical"); here every attribute is NaN.
-template <class GX, class GY>
-TSFA_DEV void blk_linregress_xy(const Blk &b, int m, GX gx, GY gy, double *out5) {
+template <class BT, class GX, class GY>
+TSFA_DEV void blk_linregress_xy(const BT &b, int m, GX gx, GY gy, double *out5) {
     const double dm = (double)m;
     double sx = 0.0, sy = 0.0;
     for (int i = b.tid; i < m; i += b.nt) { sx += gx(i); sy += gy(i); }
@@ -1273,8 +1403,8 @@ TSFA_DEV double np_linspace_at(double start, double stop, int num_edges, int i) 
     return (double)i * step + start;
 }
 
-template <class G>
-TSFA_DEV double blk_binned_entropy(const Blk &b, int m, G g, int bins, double vmin, double vmax, int *cnt) {
+template <class BT, class G>
+TSFA_DEV double blk_binned_entropy(const BT &b, int m, G g, int bins, double vmin, double vmax, int *cnt) {
     double first = vmin, last = vmax;
     // np.histogram raises "autodetected range of [..] is not finite" for a series holding +-inf (fc.py:1691); the host
     // turns the NaN of this cell into that ValueError (feature_extraction/reference_errors.py)
@@ -1302,10 +1432,15 @@ TSFA_DEV double blk_binned_entropy(const Blk &b, int m, G g, int bins, double vm
         // numpy >= 2.0 (_histograms_impl.py:452): "Too many bins for data range. Cannot create N finite-sized bins." when two
         // neighbouring edges of the linspace coincide (a range of a few ulps: 2^53 + {0, 2, 4}); the host turns the NaN
         // into that ValueError (reference_errors.py)
-        unsigned stuck = 0;
-        for (int k = b.tid; k < bins; k += b.nt)
-            if (np_linspace_at(first, last, bins + 1, k) >= np_linspace_at(first, last, bins + 1, k + 1)) stuck = 1;
-        if (blk_or16(b, stuck) != 0) return TSFA_NAN;
+        // (two edges k step + first can only round to the same float64 where the step is within a few ulps of the larger
+        //  end of the range: everywhere else the test -- a sweep over the bins and a workgroup OR -- is skipped)
+        const double amax = fmax(fabs(first), fabs(last));
+        if (!(step > 8.9e-16 * amax)) {
+            unsigned stuck = 0;
+            for (int k = b.tid; k < bins; k += b.nt)
+                if (np_linspace_at(first, last, bins + 1, k) >= np_linspace_at(first, last, bins + 1, k + 1)) stuck = 1;
+            if (blk_or16(b, stuck) != 0) return TSFA_NAN;
+        }
     }
     for (int i = b.tid; i < m; i += b.nt) {
         const double v = g(i);

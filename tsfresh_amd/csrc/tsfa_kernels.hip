@@ -30,6 +30,7 @@
 #define TSFA_SERIES_END \
         __syncthreads(); \
     }
+#define TSFA_SERIES_SKIP continue
 #else
 extern __shared__ __attribute__((aligned(16))) unsigned char tsfa_smem[];
 #define TSFA_GS_PARAMS
@@ -40,6 +41,7 @@ extern __shared__ __attribute__((aligned(16))) unsigned char tsfa_smem[];
     {                                                                                                                       \
         const int64_t sidx = sel ? (int64_t)sel[blockIdx.x] : (int64_t)blockIdx.x; /* length-class launch: its series list */
 #define TSFA_SERIES_END }
+#define TSFA_SERIES_SKIP return
 #endif
 
 template <typename T>
@@ -56,10 +58,11 @@ __device__ __forceinline__ void basic_body(const T *__restrict__ values, const i
                         const TsfaSpec *__restrict__ specs, int nspecs, double *__restrict__ out, int64_t ld,
                         const double *__restrict__ dectab, int maxn, int hint_a, int hint_b,
                         const double *__restrict__ times, const TsfaAltPlan &alt, int n_loop, int n_count, int n_sum,
-                        double *__restrict__ stats_out TSFA_GS_PARAMS) {
+                        double *__restrict__ stats_out, int skip_le TSFA_GS_PARAMS) {
     TSFA_SERIES_BEGIN
     const int64_t off = starts[sidx];
     const int n = (int)(ends[sidx] - off);
+    if (n <= skip_le) TSFA_SERIES_SKIP;   // evaluated by the row form (k_basic_rows / k_trend_rows), whatever the launch group
     BasicLds L;
     L.carve(tsfa_base, maxn, blockDim.x, (int)sizeof(T), PART, (PART == 2) ? alt.small_w : 0);
     TSFA_TICKS_BEGIN();
@@ -81,11 +84,11 @@ template <typename T>
 __global__ void __launch_bounds__(1024) k_basic(const T *__restrict__ values, const int64_t *__restrict__ starts, const int64_t *__restrict__ ends, int64_t n_series, const int *__restrict__ sel,
                         const TsfaSpec *__restrict__ specs, int nspecs, double *__restrict__ out, int64_t ld,
                         const double *__restrict__ dectab, int maxn, int hint_a, int n_loop, int n_count, int n_sum,
-                        double *__restrict__ stats_out TSFA_GS_PARAMS) {
+                        double *__restrict__ stats_out, int skip_le TSFA_GS_PARAMS) {
     TsfaAltPlan alt;
     alt.nkeys = 0; alt.want_p = 0; alt.nq = 0; alt.small_w = 0;
     basic_body<T, 1>(values, starts, ends, n_series, sel, specs, nspecs, out, ld, dectab, maxn, hint_a, 0, nullptr, alt, n_loop,
-                     n_count, n_sum, stats_out TSFA_GS_ARGS);
+                     n_count, n_sum, stats_out, skip_le TSFA_GS_ARGS);
 }
 
 // A plan whose BASIC columns are all closed forms of the per-series statistics (MinimalFCParameters: sum, mean, length,
@@ -98,7 +101,7 @@ __global__ void __launch_bounds__(256, 4) k_basic_lite(const T *__restrict__ val
     TsfaAltPlan alt;
     alt.nkeys = 0; alt.want_p = 0; alt.nq = 0; alt.small_w = 0;
 #if defined(TSFA_LONG)
-    basic_body<T, 5>(values, starts, ends, n_series, sel, specs, nspecs, out, ld, dectab, maxn, hint_a, 0, nullptr, alt, 0, 0, 0, nullptr TSFA_GS_ARGS);
+    basic_body<T, 5>(values, starts, ends, n_series, sel, specs, nspecs, out, ld, dectab, maxn, hint_a, 0, nullptr, alt, 0, 0, 0, nullptr, 0 TSFA_GS_ARGS);
 #else
     // a persistent grid: the per-series work is a few thousand cycles, less than the dispatch of a workgroup costs
     unsigned char *const tsfa_base = tsfa_smem;
@@ -161,9 +164,63 @@ __global__ void __launch_bounds__(256, 4) k_basic_lite(const T *__restrict__ val
 template <typename T>
 __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4))) k_trend(const T *__restrict__ values, const int64_t *__restrict__ starts, const int64_t *__restrict__ ends, int64_t n_series, const int *__restrict__ sel,
                         const TsfaSpec *__restrict__ specs, int nspecs, double *__restrict__ out, int64_t ld, int maxn,
-                        int hint_b, const double *__restrict__ times, const TsfaAltPlan alt, int n_loop TSFA_GS_PARAMS) {
-    basic_body<T, 2>(values, starts, ends, n_series, sel, specs, nspecs, out, ld, nullptr, maxn, 0, hint_b, times, alt, n_loop, 0, 0, nullptr TSFA_GS_ARGS);
+                        int hint_b, const double *__restrict__ times, const TsfaAltPlan alt, int n_loop, int skip_le TSFA_GS_PARAMS) {
+    basic_body<T, 2>(values, starts, ends, n_series, sel, specs, nspecs, out, ld, nullptr, maxn, 0, hint_b, times, alt, n_loop, 0, 0, nullptr, skip_le TSFA_GS_ARGS);
 }
+
+#if !defined(TSFA_LONG)
+// Row form of the two kernels above (tsfa_common.h: BlkRow): the series of at most TSFA_ROW_MAXN samples, one per 16-lane row,
+// four per one-wavefront workgroup; longer series of the launch leave their row idle (k_basic / k_trend evaluate them).
+template <typename T, int PART>
+__device__ __forceinline__ void basic_rows_body(const T *__restrict__ values, const int64_t *__restrict__ starts, const int64_t *__restrict__ ends, int64_t n_series, const int *__restrict__ sel,
+                        const TsfaSpec *__restrict__ specs, int nspecs, double *__restrict__ out, int64_t ld,
+                        const double *__restrict__ dectab, int maxn, int hint_a, int hint_b,
+                        const double *__restrict__ times, const TsfaAltPlan &alt, int n_loop, int n_count, int n_sum,
+                        double *__restrict__ stats_out, int row_bytes) {
+    const int row = (int)(threadIdx.x >> 4);
+    const int64_t wi = (int64_t)blockIdx.x * (64 / TSFA_ROW_LANES) + row;
+    if (wi >= n_series) return;
+    const int64_t sidx = sel ? (int64_t)sel[wi] : wi;
+    const int64_t off = starts[sidx];
+    const int n = (int)(ends[sidx] - off);
+    if (n > TSFA_ROW_MAXN) return;
+    BasicRowLds L;
+    L.carve(tsfa_smem + (size_t)row * (size_t)row_bytes, maxn, (int)sizeof(T), PART, (PART == 2) ? alt.small_w : 0);
+    BlkRow b;
+    b.tid = (int)(threadIdx.x & (TSFA_ROW_LANES - 1));
+    b.nt = TSFA_ROW_LANES;
+    b.red = L.red;
+    b.np = nullptr;
+    T *xs = (T *)L.xs;
+    {
+        const T *__restrict__ g = values + off;
+        for (int i = b.tid; i < n; i += TSFA_ROW_LANES) xs[i] = g[i];
+        blk_sync();
+    }
+    fam_basic_series<PART>(b, XsView<T>{xs}, n, specs, nspecs, out + sidx * ld, L.w, L.cum, L.altc, L.iw, dectab, hint_a,
+                           hint_b, alt, (TsfaSpec *)nullptr, times ? times + off : nullptr, n_loop, L.ctx, n_count, n_sum,
+                           stats_out ? stats_out + sidx * TSFA_STATS_N : nullptr);
+}
+
+template <typename T>
+__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4))) k_basic_rows(const T *__restrict__ values, const int64_t *__restrict__ starts, const int64_t *__restrict__ ends, int64_t n_series, const int *__restrict__ sel,
+                        const TsfaSpec *__restrict__ specs, int nspecs, double *__restrict__ out, int64_t ld,
+                        const double *__restrict__ dectab, int maxn, int hint_a, int n_loop, int n_count, int n_sum,
+                        double *__restrict__ stats_out, int row_bytes) {
+    TsfaAltPlan alt;
+    alt.nkeys = 0; alt.want_p = 0; alt.nq = 0; alt.small_w = 0;
+    basic_rows_body<T, 1>(values, starts, ends, n_series, sel, specs, nspecs, out, ld, dectab, maxn, hint_a, 0, nullptr, alt, n_loop,
+                          n_count, n_sum, stats_out, row_bytes);
+}
+
+template <typename T>
+__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4))) k_trend_rows(const T *__restrict__ values, const int64_t *__restrict__ starts, const int64_t *__restrict__ ends, int64_t n_series, const int *__restrict__ sel,
+                        const TsfaSpec *__restrict__ specs, int nspecs, double *__restrict__ out, int64_t ld, int maxn,
+                        int hint_b, const double *__restrict__ times, const TsfaAltPlan alt, int n_loop, int row_bytes) {
+    basic_rows_body<T, 2>(values, starts, ends, n_series, sel, specs, nspecs, out, ld, nullptr, maxn, 0, hint_b, times, alt, n_loop, 0, 0,
+                          nullptr, row_bytes);
+}
+#endif
 
 template <typename T>
 __global__ void __launch_bounds__(1024) k_sort(const T *__restrict__ values, const int64_t *__restrict__ starts, const int64_t *__restrict__ ends, int64_t n_series, const int *__restrict__ sel,
@@ -952,13 +1009,13 @@ static int launch_all_t(const TsfaLaunch &a, const T *values) {
 #endif
         } else {
             TSFA_KLAUNCH(k_basic<T>, lds, values, a.starts, a.ends, a.n_series, a.sel, a.specs, a.nspecs, a.out, a.ld, a.dectab,
-                         a.maxn, a.hint_a, a.hint_c, a.hint_d, a.hint_e, a.stats_out);
+                         a.maxn, a.hint_a, a.hint_c, a.hint_d, a.hint_e, a.stats_out, a.skip_le);
         }
     } else if (a.fam == TSFA_FAM_TREND) {
         BasicLds L;
         const size_t lds = L.carve(nullptr, a.maxn, nt, (int)sizeof(T), 2, a.alt.small_w);
         TSFA_KLAUNCH(k_trend<T>, lds, values, a.starts, a.ends, a.n_series, a.sel, a.specs, a.nspecs, a.out, a.ld, a.maxn,
-                     a.hint_b, a.times, a.alt, a.hint_c);
+                     a.hint_b, a.times, a.alt, a.hint_c, a.skip_le);
     } else if (a.fam == TSFA_FAM_SORT) {
         SortLds L;
         const int wd = (a.hint_a >= 320) ? a.hint_a : 1280;
@@ -1049,6 +1106,36 @@ static int launch_all_t(const TsfaLaunch &a, const T *values) {
     TSFA_LAUNCH_CHECK();
     return 0;
 }
+
+#if !defined(TSFA_LONG)
+template <typename T>
+static int launch_rows_t(const TsfaLaunch &a, const T *values) {
+    hipStream_t st = (hipStream_t)a.stream;
+    const int per = 64 / TSFA_ROW_LANES;
+    const dim3 grid((unsigned)((a.n_series + per - 1) / per));
+    const int maxn = std::min(a.maxn, TSFA_ROW_MAXN);
+    int rc = 0;
+    if (a.fam == TSFA_FAM_BASIC) {
+        const size_t rb = BasicRowLds::row_bytes(maxn, (int)sizeof(T), 1, 0);
+        if ((rc = set_lds(k_basic_rows<T>, rb * per))) return rc;
+        k_basic_rows<T><<<grid, 64, rb * per, st>>>(values, a.starts, a.ends, a.n_series, a.sel, a.specs, a.nspecs, a.out, a.ld, a.dectab,
+                                                    maxn, a.hint_a, a.hint_c, a.hint_d, a.hint_e, a.stats_out, (int)rb);
+    } else if (a.fam == TSFA_FAM_TREND) {
+        const size_t rb = BasicRowLds::row_bytes(maxn, (int)sizeof(T), 2, a.alt.small_w);
+        if ((rc = set_lds(k_trend_rows<T>, rb * per))) return rc;
+        k_trend_rows<T><<<grid, 64, rb * per, st>>>(values, a.starts, a.ends, a.n_series, a.sel, a.specs, a.nspecs, a.out, a.ld, maxn,
+                                                    a.hint_b, a.times, a.alt, a.hint_c, (int)rb);
+    } else {
+        return -1;
+    }
+    TSFA_LAUNCH_CHECK();
+    return 0;
+}
+int tsfa_launch_rows(const TsfaLaunch &a) {
+    if (a.dtype == 0) return launch_rows_t<float>(a, (const float *)a.values);
+    return launch_rows_t<double>(a, (const double *)a.values);
+}
+#endif
 
 #if defined(TSFA_LONG)
 int tsfa_launch_family_long(const TsfaLaunch &a) {

@@ -38,6 +38,7 @@ struct TsfaLaunch {
     double *out;
     int64_t ld;
     int maxn;   // longest series of the batch (LDS is sized for it)
+    int skip_le;  // BASIC / TREND: series of at most this many samples are left to the row form (tsfa_launch_rows); 0: none
     int nt;     // workgroup size
     void *stream;
     // family extras
@@ -93,6 +94,7 @@ size_t tsfa_family_lds_bytes(int fam, int maxn, int nt, int aux);
 size_t tsfa_entropy_lds_bytes(int maxn, int with_cnt);
 size_t tsfa_seq_lds_bytes(const TsfaSeqGroup &g);
 int tsfa_launch_family(const TsfaLaunch &a);
+int tsfa_launch_rows(const TsfaLaunch &a);          // BASIC / TREND: the series of at most TSFA_ROW_MAXN samples, four per wavefront (k_basic_rows / k_trend_rows)
 int tsfa_launch_family_long(const TsfaLaunch &a);   // working set in a.long_scratch instead of LDS (any length <= 65535)
 int tsfa_launch_ar_degenerate(const TsfaLaunch &a);
 int tsfa_launch_langevin_dd(const TsfaLaunch &a);     // second pass of TSFA_FAM_SORT: the ill-conditioned Langevin fits k_sort recorded

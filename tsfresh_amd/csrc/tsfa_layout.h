@@ -70,6 +70,33 @@ struct BasicLds {
     }
 };
 
+// Row form of the BASIC / TREND families (tsfa_common.h: BlkRow): four series of at most TSFA_ROW_MAXN samples per wavefront,
+// each with a carve of its own.  No numpy-order scratch (np_sum's row form keeps its three leaves in registers), no
+// cross-wavefront scratch.  The stride between the rows' carves is 64 bytes past a multiple of 128: a ds_read_b32 serves lanes
+// 0-31 in one cycle from 32 banks, so rows 0 / 1 (and 2 / 3), reading 16 consecutive dwords each, must start 16 banks apart.
+struct BasicRowLds {
+    double *red; void *xs; double *w; double *cum; double *altc; int *iw; double *ctx;
+    TSFA_HD static size_t row_bytes(int maxn, int xs_bytes, int part, int small_w) {
+        BasicRowLds L;
+        const size_t used = L.carve(nullptr, maxn, xs_bytes, part, small_w);
+        return ((used + 127) & ~(size_t)127) + 64;
+    }
+    TSFA_HD size_t carve(unsigned char *base, int maxn, int xs_bytes, int part, int small_w) {
+        LdsCarve c{base, 0};
+        red = c.take<double>(2);
+        xs = c.take<unsigned char>((size_t)maxn * xs_bytes);
+        size_t wb = (part & 2) ? (size_t)maxn * sizeof(double) : (size_t)maxn * xs_bytes;
+        if ((part & 2) && small_w) wb = (size_t)(TSFA_ROW_LANES + 2 * 16 + 8) * sizeof(double);
+        if (wb < 64) wb = 64;
+        w = (double *)c.take<unsigned char>(wb);
+        cum = w;
+        altc = (part & 2) ? c.take<double>(8 * 16) : nullptr;
+        ctx = c.take<double>(32);
+        iw = c.take<int>(256);
+        return c.off;
+    }
+};
+
 struct SortLds {
     double *red; NpScratch *np; void *xs; void *srt; double *w; int *iw; double *cq; TsfaSpec *stage; double *ctx;
     // xs_bytes: element size of the resident series and its sorted copy (4: float32 input kept as float32, 8: float64)
