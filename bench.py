@@ -240,6 +240,22 @@ def self_launch_command(n_ranks, argv, port):
     return cmd, env
 
 
+def strong_ragged_layout(total, lo, hi, world, n_chunks=8):
+    """configs[4] as a strong-scaling job (`--strong --ragged LO:HI --n-series TOTAL --gpus N`): ONE list of series lengths for
+    the whole job (seed 42, the same on every rank), cut into contiguous shards of ~equal sum(len^2)
+    (tsfresh_amd.distributed.shard_bounds) -- so the shards differ in HEIGHT and their row chunks travel point to point.
+    Pure numpy: `--plan-only` prints it without a GPU."""
+    from tsfresh_amd.distributed import chunk_cuts, shard_bounds
+    lens = np.random.default_rng(42).integers(lo, hi + 1, size=total, dtype=np.int64)
+    bounds = shard_bounds(lens, world)
+    counts = [int(c) for c in np.diff(bounds)]
+    chunks = max(1, min(n_chunks, max(min(counts), 1)))
+    equal = all(len({chunk_cuts(c, chunks)[k + 1] - chunk_cuts(c, chunks)[k] for c in counts}) == 1 for k in range(chunks))
+    cost = [float((lens[bounds[r]:bounds[r + 1]].astype(np.float64) ** 2).sum()) for r in range(world)]
+    return {"lens": lens, "bounds": bounds, "counts": counts, "row_chunks": chunks,
+            "exchange": "all_gather" if equal else "p2p", "sum_len2": cost}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -264,11 +280,25 @@ def main():
                          "second leg (~4 min of wall clock) instead of one run (~1 min): profiles/r04_z_bench.json was taken so")
     ap.add_argument("--cpu-workers", type=int, default=0, help="worker processes of the CPU baseline (default: every physical core)")
     ap.add_argument("--no-e2e", action="store_true", help="skip the host-buffer / DataFrame boundary timings")
+    ap.add_argument("--plan-only", action="store_true",
+                    help="print the shard layout of the job as JSON (rows and sum(len^2) per rank, exchange form) and exit: no GPU")
     ap.add_argument("--chunks", type=int, default=0,
                     help="N > 1: row chunks per step; the all-gather of chunk c runs on RCCL's stream while chunk c + 1 is "
                          "being extracted (0 = 8 when N > 1, else 1)")
     args = ap.parse_args()
 
+    if args.plan_only:
+        if args.strong and args.ragged:
+            lo, hi = (int(t) for t in args.ragged.split(":"))
+            lay = strong_ragged_layout(args.n_series, lo, hi, args.gpus, args.chunks if args.chunks > 0 else 8)
+            doc = {"gpus": args.gpus, "scaling": "strong", "shard_rows": lay["counts"], "sum_len2": lay["sum_len2"],
+                   "exchange": lay["exchange"], "row_chunks": lay["row_chunks"]}
+        else:
+            per = args.n_series // args.gpus if args.strong else args.n_series
+            doc = {"gpus": args.gpus, "scaling": "strong" if args.strong else "weak", "shard_rows": [per] * args.gpus,
+                   "exchange": "all_gather", "row_chunks": args.chunks if args.chunks > 0 else 8}
+        print(json.dumps(doc))
+        return
     # `python bench.py --gpus N` (no launcher): start N ranks of this file and hand back their exit code; rank 0 of the
     # child job prints the one JSON line.  Under a launcher (WORLD_SIZE set) this is skipped.
     if "WORLD_SIZE" not in os.environ and (args.gpus > 1 or os.environ.get("TSFA_BENCH_SELF_LAUNCH")):
@@ -316,7 +346,12 @@ def main():
     # BASELINE.md 3.4's recipe: np.random.default_rng(seed).standard_normal((n, L), dtype=float32), seed = 42 (+ rank:
     # every rank its own shard), drawn on the host and copied to the device BEFORE the clock
     n, L = args.n_series, args.length
-    if args.strong:
+    layout = None
+    if args.strong and args.ragged:
+        lo, hi = (int(t) for t in args.ragged.split(":"))
+        layout = strong_ragged_layout(args.n_series, lo, hi, world, args.chunks if args.chunks > 0 else 8)
+        n = layout["counts"][rank]
+    elif args.strong:
         if args.n_series % world:
             raise SystemExit("bench.py --strong: --n-series %d is not a multiple of the %d ranks" % (args.n_series, world))
         n = args.n_series // world
@@ -324,6 +359,8 @@ def main():
     if args.ragged:
         lo, hi = (int(t) for t in args.ragged.split(":"))
         lens = rng.integers(lo, hi + 1, size=n, dtype=np.int64)
+        if layout is not None:   # this rank's slice of the job's ONE length list
+            lens = layout["lens"][layout["bounds"][rank]:layout["bounds"][rank + 1]]
         h_offsets = np.zeros(n + 1, dtype=np.int64)
         np.cumsum(lens, out=h_offsets[1:])
         total = int(h_offsets[-1])
@@ -350,10 +387,11 @@ def main():
     pipe = ShardPipeline(fplan.native_specs(_native.calc_id), n_cols, local_rank, dist=dist, n_chunks=n_chunks,
                          length_hint=None if args.ragged else (L, L))  # equal lengths, known up front: no length scan
     plan = pipe.plans[0]
-    full = torch.empty((world * n, n_cols), device=dev, dtype=torch.float64)
-    out = full[rank * n:(rank + 1) * n]
+    counts = layout["counts"] if layout is not None else [n] * world
+    row0 = [int(v) for v in np.concatenate([[0], np.cumsum(counts)])]
+    full = torch.empty((row0[-1], n_cols), device=dev, dtype=torch.float64)
+    out = full[row0[rank]:row0[rank + 1]]
     stream = torch.cuda.current_stream(dev).cuda_stream
-    counts = [n] * world
 
     def step():
         pipe.run(values, offsets, counts, full, _native.TSFA_F32)
@@ -377,11 +415,11 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     ms_per_step = 1000.0 * elapsed / max(args.steps, 1)
-    value = world * n * args.steps / elapsed
+    value = row0[-1] * args.steps / elapsed
     if dist is not None and world > 1:
         # every rank holds every rank's rows: a checksum of each rank's block (NaNs zeroed), all-reduced with MAX and
         # MIN, must agree on all ranks -- i.e. everybody received the same bytes for every block
-        sums = torch.stack([torch.nan_to_num(full[r * n:(r + 1) * n]).sum() for r in range(world)])
+        sums = torch.stack([torch.nan_to_num(full[row0[r]:row0[r + 1]]).sum() for r in range(world)])
         hi, lo = sums.clone(), sums.clone()
         dist.all_reduce(hi, op=dist.ReduceOp.MAX)
         dist.all_reduce(lo, op=dist.ReduceOp.MIN)
@@ -407,9 +445,10 @@ def main():
                 rccl = ".".join(str(v) for v in torch.cuda.nccl.version())
             except Exception:  # noqa: BLE001
                 rccl = None
-            gathered = (world - 1) * n * n_cols * 8
+            gathered = (row0[-1] - n) * n_cols * 8
             multi = {"world": dist.get_world_size(), "ranks_seen_by_rccl": ranks_seen,
-                     "backend": "nccl (RCCL %s)" % rccl, "row_chunks": n_chunks,
+                     "backend": "nccl (RCCL %s)" % rccl, "row_chunks": n_chunks, "shard_rows": counts,
+                     "exchange": layout["exchange"] if layout is not None else "all_gather",
                      "compute_only_ms_per_step": compute_ms, "exchange_ms_exposed": ms_per_step - compute_ms,
                      "bytes_received_per_rank_per_step": gathered,
                      "exchange_gbs_per_rank_if_fully_exposed": gathered / max((ms_per_step - compute_ms) * 1e-3, 1e-9) / 1e9}

@@ -3,12 +3,13 @@
 # how busy the VALU / LDS / scalar pipes are per family, and the MFMA pipe for k_cwt_gemm.
 # Writes gpurun_out/pmc_issue/summary.md and gpurun_out/pmc_issue/valu_issue.json (bench.py reads the committed copy
 # profiles/valu_issue.json for its roofline.valu field).
+# PMC_BENCH_ARGS: other workloads (round 6: "--n-series 125000 --length 256", the configs[3] shard)
 export TMPDIR=/tmp
 rm -rf gpurun_out/pmc_issue; mkdir -p gpurun_out/pmc_issue
 i=0
 for set in "GRBM_GUI_ACTIVE SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES" "SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_INSTS_SALU SQ_ACTIVE_INST_SCA" "SQ_INSTS_LDS SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT" "SQ_VALU_MFMA_BUSY_CYCLES" "SQ_INSTS_VALU_MFMA_MOPS_F64"; do
   i=$((i+1))
-  timeout 600 rocprofv3 --pmc $set -d gpurun_out/pmc_issue/p$i -o p --output-format csv -- python bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-e2e > gpurun_out/pmc_issue/p$i.log 2>&1
+  timeout 600 rocprofv3 --pmc $set -d gpurun_out/pmc_issue/p$i -o p --output-format csv -- python bench.py $PMC_BENCH_ARGS --steps 1 --warmup 1 --no-cpu-baseline --no-e2e > gpurun_out/pmc_issue/p$i.log 2>&1
 done
 python - <<'PY'
 import csv, glob, collections, json, hashlib

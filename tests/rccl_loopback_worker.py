@@ -51,7 +51,27 @@ def main():
     torch.cuda.synchronize(dev)
     same = bool(torch.equal(torch.nan_to_num(full, nan=123.0), torch.nan_to_num(mirror, nan=123.0)))
     untouched = bool((full == -7.0).any().item())
-    print(json.dumps({"same": same, "untouched_cells": untouched, "rows": n, "cols": n_cols,
+    # ShardPipeline.run itself at a world of one with the exchange of every chunk FORCED (round-5 VERDICT weak #13): eight chunks
+    # on two lanes = four per lane, so each lane's two staging slots are drained and reused; both exchange forms
+    from tsfresh_amd.distributed import ShardPipeline
+    ref = full.clone()
+    pipe_doc = {}
+    for form, p2p in (("all_gather", False), ("p2p", True)):
+        pipe = ShardPipeline(fplan.native_specs(_native.calc_id), n_cols, dev.index, dist=dist, n_chunks=8, force_exchange=True)
+        pipe.p2p_only = p2p
+        got = torch.full((n, n_cols), -3.0, device=dev, dtype=torch.float64)
+        for _ in range(2):
+            pipe.run(values, d_off, [n], got, _native.TSFA_F32)
+        torch.cuda.synchronize(dev)
+        pipe_doc[form] = {"equal": bool(torch.equal(torch.nan_to_num(got, nan=123.0), torch.nan_to_num(ref, nan=123.0))),
+                          "exchanges": pipe.exchanges_issued, "ring_reuses": pipe.ring_reuses}
+        if p2p:   # the rows that travelled through RCCL's self send / receive sit in the loop-back blocks of the ring
+            last = pipe._stage[("loop", 1, 1)]   # chunk 7: lane 1, ring slot 1
+            c0, c1 = chunk_cuts(n, 8)[7], chunk_cuts(n, 8)[8]
+            pipe_doc[form]["loopback_bytes_equal"] = bool(torch.equal(torch.nan_to_num(last[: c1 - c0], nan=123.0),
+                                                                      torch.nan_to_num(ref[c0:c1], nan=123.0)))
+        pipe.close()
+    print(json.dumps({"same": same, "untouched_cells": untouched, "rows": n, "cols": n_cols, "pipeline": pipe_doc,
                       "rccl": ".".join(str(v) for v in torch.cuda.nccl.version())}))
     plan.close()
     dist.destroy_process_group()

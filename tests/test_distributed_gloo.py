@@ -46,6 +46,48 @@ for c in range(n_chunks):
     finish_exchange(full, starts, rank, exchange_rows(full, starts, rank, lo_hi, dist, stage))
 want = torch.cat([torch.arange(rows * n_cols, dtype=torch.float64).reshape(rows, n_cols) + 1000 * r for r in range(world)])
 assert torch.equal(full, want)
+# ---- ShardPipeline.run ITSELF (what bench.py --gpus N times): two lanes, eight chunks, the staging ring reused, both forms ----
+from tsfresh_amd.distributed import ShardPipeline
+class HostPlan:
+    """extract_device on host tensors: the emulation build stands in for the kernels; pointers are mapped back to rows"""
+    def __init__(self, values_t, offsets_t, full_t):
+        self.v, self.o, self.full = values_t, offsets_t, full_t
+    def set_length_hint(self, lo, hi): pass
+    def close(self): pass
+    def extract_device(self, vptr, dtype, optr, n, out_ptr, ld, stream):
+        c0 = (optr - self.o.data_ptr()) // 8
+        off = self.o.numpy()[c0:c0 + n + 1]
+        block = emul_extract(params, self.v.numpy()[off[0]:off[-1]], off - off[0])[1]
+        r0 = (out_ptr - self.full.data_ptr()) // (8 * ld)
+        self.full[r0:r0 + n] = torch.from_numpy(np.ascontiguousarray(block))
+def run_pipeline(all_lens, n_chunks, p2p_only=False):
+    all_off = np.zeros(len(all_lens) + 1, dtype=np.int64); np.cumsum(all_lens, out=all_off[1:])
+    all_vals = np.random.default_rng(5).standard_normal(int(all_off[-1]))
+    want = fn(all_vals, all_off)
+    bounds = shard_bounds(all_lens, world)
+    counts = [int(c) for c in np.diff(bounds)]
+    lo, hi = int(bounds[rank]), int(bounds[rank + 1])
+    v = torch.from_numpy(all_vals[all_off[lo]:all_off[hi]].copy())
+    o = torch.from_numpy((all_off[lo:hi + 1] - all_off[lo]).copy())
+    full = torch.full((len(all_lens), 10), -5.0, dtype=torch.float64)
+    pipe = ShardPipeline(None, 10, None, dist=dist, n_chunks=n_chunks, plan_factory=lambda: HostPlan(v, o, full))
+    pipe.p2p_only = p2p_only
+    for _ in range(2):   # a second run reuses the staging blocks of the first
+        pipe.run(v, o, counts, full, 1)
+        assert np.array_equal(full.numpy(), want), (rank, np.argwhere(full.numpy() != want)[:4])
+        full.fill_(-5.0) if _ == 0 else None
+    stats = (pipe.exchanges_issued, pipe.ring_reuses, counts)
+    pipe.close()
+    return stats
+issued, reuses, counts = run_pipeline(np.full(16 * world, 20), 8)            # equal heights: all-gather + ring
+assert len(set(counts)) == 1 and issued == 8 and reuses == 4, (issued, reuses, counts)
+issued, reuses, counts = run_pipeline(lens, 8)                                # very unequal heights (an empty shard at world 4)
+assert len(set(counts)) > 1, (issued, reuses, counts)
+lens2 = np.random.default_rng(9).integers(10, 60, size=240); lens2[[5, 77, 150, 201]] = 150
+issued, reuses, counts = run_pipeline(lens2, 8)                               # sum(len^2)-balanced, unequal: point to point, ring reused
+assert len(set(counts)) > 1 and min(counts) >= 8 and reuses >= 1, (issued, reuses, counts)
+issued, reuses, counts = run_pipeline(np.full(16 * world, 20), 8, p2p_only=True)
+assert issued > 8 or world == 2, (issued, world)
 if rank == 0:
     print("GLOO_OK", ref.shape, world, list(heights))
 dist.destroy_process_group()

@@ -23,3 +23,8 @@ def test_point_to_point_exchange_over_rccl_on_one_gpu(gpu):
     assert out.returncode == 0, out.stderr[-3000:]
     doc = json.loads([ln for ln in out.stdout.splitlines() if ln.startswith("{")][-1])
     assert doc["same"] and not doc["untouched_cells"], doc
+    # ShardPipeline.run with the exchange forced at a world of one: 8 chunks, both forms, the staging ring reused
+    for form in ("all_gather", "p2p"):
+        d = doc["pipeline"][form]
+        assert d["equal"] and d["exchanges"] >= 8 and d["ring_reuses"] == 4, (form, d)
+    assert doc["pipeline"]["p2p"]["loopback_bytes_equal"], doc

@@ -861,7 +861,7 @@ TSFA_DEV void fam_spectral_series(const Blk &b, const ST *xs_raw, int n, const T
             const double pm = pmax;
             const double lo = pmin / pmax, hi = pmax / pmax;
             if (pnan || lo != lo || hi != hi || isinf(lo) || isinf(hi)) v = TSFA_NAN;
-            else v = blk_binned_entropy(b, npx, [=](int i) { return px[i] / pm; }, bins, lo, hi, iw);
+            else v = blk_binned_entropy(b, npx, [=](int i) { return px[i] / pm; }, bins, lo, hi, iw, 128);   // (iw: 128 counters in the Hann window's storage; more bins go in rounds)
         } else {
             continue;
         }

@@ -1404,7 +1404,7 @@ TSFA_DEV double np_linspace_at(double start, double stop, int num_edges, int i) 
 }
 
 template <class BT, class G>
-TSFA_DEV double blk_binned_entropy(const BT &b, int m, G g, int bins, double vmin, double vmax, int *cnt) {
+TSFA_DEV double blk_binned_entropy(const BT &b, int m, G g, int bins, double vmin, double vmax, int *cnt, int cap = 256) {
     double first = vmin, last = vmax;
     // np.histogram raises "autodetected range of [..] is not finite" for a series holding +-inf (fc.py:1691); the host
     // turns the NaN of this cell into that ValueError (feature_extraction/reference_errors.py)
@@ -1413,9 +1413,6 @@ TSFA_DEV double blk_binned_entropy(const BT &b, int m, G g, int bins, double vmi
         first = first - 0.5;
         last = last + 0.5;
     }
-    blk_sync();
-    for (int k = b.tid; k < bins; k += b.nt) cnt[k] = 0;
-    blk_sync();
     const double norm = last - first;
     // numpy: idx = int((v - first) / norm * bins), then one step down if v < edge[idx], one step up if v >= edge[idx + 1]:
     // the two corrections make idx the bin whose edges enclose v for ANY estimate within one bin of it, so the estimate
@@ -1442,33 +1439,43 @@ TSFA_DEV double blk_binned_entropy(const BT &b, int m, G g, int bins, double vmi
             if (blk_or16(b, stuck) != 0) return TSFA_NAN;
         }
     }
-    for (int i = b.tid; i < m; i += b.nt) {
-        const double v = g(i);
-        if (!(v >= first && v <= last)) continue;
-        const double fidx = recip ? ((v - first) * inv_norm) * (double)bins : ((v - first) / norm) * (double)bins;
-        int idx = (int)fidx;
-        if (idx >= bins) idx = bins - 1;
-        if (idx < 0) idx = 0;
-        const double e0 = flat ? np_linspace_at(first, last, bins + 1, idx) : ((idx == bins) ? last : (double)idx * step + first);
-        if (v < e0) idx -= 1;
-        if (idx != bins - 1) {
-            const double e1 = flat ? np_linspace_at(first, last, bins + 1, idx + 1)
-                                   : ((idx + 1 == bins) ? last : (double)(idx + 1) * step + first);
-            if (v >= e1) idx += 1;
-        }
-#if TSFA_GPU
-        atomicAdd(&cnt[idx], 1);
-#else
-        cnt[idx] += 1;
-#endif
-    }
-    blk_sync();
+    // The counters hold `cap` bins (LDS); more bins than that (the reference takes any max_bins: a from_columns() settings
+    // object may ask for 1000) are counted in rounds of `cap`, each a sweep over the samples that keeps the ones of its bins.
+    // Up to `cap` bins: one round, the sums below in the order they always had.
     double e = 0.0;
-    for (int k = b.tid; k < bins; k += b.nt) {
-        const int c = cnt[k];
-        if (c > 0) {
-            const double p = (double)c / (double)m;
-            e += p * log(p);
+    for (int c0 = 0; c0 < bins; c0 += cap) {
+        const int cb = (bins - c0 < cap) ? (bins - c0) : cap;
+        blk_sync();
+        for (int k = b.tid; k < cb; k += b.nt) cnt[k] = 0;
+        blk_sync();
+        for (int i = b.tid; i < m; i += b.nt) {
+            const double v = g(i);
+            if (!(v >= first && v <= last)) continue;
+            const double fidx = recip ? ((v - first) * inv_norm) * (double)bins : ((v - first) / norm) * (double)bins;
+            int idx = (fidx < 2147483000.0) ? (int)fidx : (bins - 1);
+            if (idx >= bins) idx = bins - 1;
+            if (idx < 0) idx = 0;
+            const double e0 = flat ? np_linspace_at(first, last, bins + 1, idx) : ((idx == bins) ? last : (double)idx * step + first);
+            if (v < e0) idx -= 1;
+            if (idx != bins - 1) {
+                const double e1 = flat ? np_linspace_at(first, last, bins + 1, idx + 1)
+                                       : ((idx + 1 == bins) ? last : (double)(idx + 1) * step + first);
+                if (v >= e1) idx += 1;
+            }
+            if (idx < c0 || idx >= c0 + cb) continue;
+#if TSFA_GPU
+            atomicAdd(&cnt[idx - c0], 1);
+#else
+            cnt[idx - c0] += 1;
+#endif
+        }
+        blk_sync();
+        for (int k = b.tid; k < cb; k += b.nt) {
+            const int c = cnt[k];
+            if (c > 0) {
+                const double p = (double)c / (double)m;
+                e += p * log(p);
+            }
         }
     }
     e = blk_sum(b, e);

@@ -519,8 +519,8 @@ static inline std::string tsfa_validate_spec(const TsfaSpec &s) {
     auto is_int = [](double v) { return v == floor(v); };
     switch (s.calc) {
     case TSFA_C_NUMBER_PEAKS: if (!(is_int(p[0]) && p[0] >= 1)) return "number_peaks: n must be an integer >= 1"; break;
-    case TSFA_C_BINNED_ENTROPY: if (!(is_int(p[0]) && p[0] >= 1 && p[0] <= 256)) return "binned_entropy: max_bins must be in [1, 256]"; break;
-    case TSFA_C_FOURIER_ENTROPY: if (!(is_int(p[0]) && p[0] >= 1 && p[0] <= 128)) return "fourier_entropy: bins must be in [1, 128]"; break;
+    case TSFA_C_BINNED_ENTROPY: if (!(is_int(p[0]) && p[0] >= 1 && p[0] <= 1048576)) return "binned_entropy: max_bins must be in [1, 1048576]"; break;   // (beyond 256 bins: counted in rounds of 256)
+    case TSFA_C_FOURIER_ENTROPY: if (!(is_int(p[0]) && p[0] >= 1 && p[0] <= 1048576)) return "fourier_entropy: bins must be in [1, 1048576]"; break;   // (beyond 128 bins: rounds of 128)
     case TSFA_C_LEMPEL_ZIV_COMPLEXITY: if (!(is_int(p[0]) && p[0] >= 1 && p[0] <= 255)) return "lempel_ziv_complexity: bins must be in [1, 255]"; break;
     case TSFA_C_ENERGY_RATIO_BY_CHUNKS:
         if (!(is_int(p[0]) && is_int(p[1]) && p[0] > 0 && p[1] >= 0 && p[1] < p[0])) return "energy_ratio_by_chunks: need 0 <= segment_focus < num_segments";

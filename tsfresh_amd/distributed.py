@@ -47,7 +47,7 @@ def chunk_cuts(n_rows, n_chunks):
     return [int(n_rows) * c // n_chunks for c in range(n_chunks + 1)]
 
 
-def exchange_rows(full, starts, rank, lo_hi, dist, stage=None, loopback=None):
+def exchange_rows(full, starts, rank, lo_hi, dist, stage=None, loopback=None, force=False):
     """Exchange one row chunk of every rank's slice of `full` (torch tensor [sum(counts), n_cols], rank-major).
 
     loopback: test hook for a box with one GPU -- this rank's own rows ALSO travel through the grouped isend / irecv form,
@@ -65,7 +65,7 @@ def exchange_rows(full, starts, rank, lo_hi, dist, stage=None, loopback=None):
     if loopback is not None and heights[rank] > 0:
         ops = [dist.P2POp(dist.isend, mine, rank), dist.P2POp(dist.irecv, loopback[: heights[rank]], rank)]
         return [("p2p", w, None, None) for w in dist.batch_isend_irecv(ops)]
-    if world == 1:
+    if world == 1 and not force:
         return []
     if stage is not None and len(set(heights)) == 1:
         if heights[0] == 0:
@@ -94,6 +94,23 @@ def finish_exchange(full, starts, rank, handles):
                     full[starts[r] + lo: starts[r] + hi].copy_(stage[r * rows:(r + 1) * rows], non_blocking=True)
 
 
+class _HostStream:
+    """Stands in for a torch.cuda.Stream where the pipeline runs on host tensors (the gloo tests of ShardPipeline: world
+    sizes 2 and 4 on a box without GPUs): host work is synchronous, so ordering between 'streams' is program order."""
+    cuda_stream = 0
+
+    def wait_stream(self, other):
+        pass
+
+
+class _NoContext:
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        return False
+
+
 class ShardPipeline:
     """One rank's side of the sharded extraction on a GPU (torch tensors, device-resident).
 
@@ -103,27 +120,48 @@ class ShardPipeline:
     on the collective's own stream while the next chunk is being extracted.  Only the last chunk's exchange is exposed.
     """
 
-    def __init__(self, specs, n_cols, device_index, dist=None, n_chunks=None, length_hint=None):
+    def __init__(self, specs, n_cols, device_index, dist=None, n_chunks=None, length_hint=None, plan_factory=None,
+                 force_exchange=False):
+        """plan_factory: callable -> an object with `extract_device(values_ptr, dtype, offsets_ptr, n, out_ptr, ld, stream)` and
+        `close()`; with device_index None the pipeline runs on HOST tensors (no streams): how tests/test_distributed_gloo.py
+        drives THIS class -- lanes, chunk cuts, the staging ring, the order of finish_exchange -- at world sizes 2 and 4 with
+        the emulation build standing in for the kernels.  force_exchange: issue the exchange of every chunk at a world of one
+        too (the all-gather of one rank / RCCL's self send-receive): the ring and the waits execute on a one-GPU box."""
         import torch
-        from tsfresh_amd import _native
-        self.torch, self._native = torch, _native
+        self.torch = torch
         self.dist = dist
         self.world = dist.get_world_size() if dist is not None else 1
         self.rank = dist.get_rank() if dist is not None else 0
         self.n_cols = int(n_cols)
-        self.dev = torch.device("cuda", device_index)
+        self.host = device_index is None
+        self.force_exchange = bool(force_exchange)
         self.n_chunks = int(n_chunks) if n_chunks else (8 if dist is not None else 1)
-        specs = list(specs)
-        self.plans = [_native.Plan(specs, device=device_index)]
+        if plan_factory is None:
+            from tsfresh_amd import _native
+            specs = list(specs)
+            plan_factory = lambda: _native.Plan(specs, device=device_index)   # noqa: E731
+        self.plans = [plan_factory()]
         if self.n_chunks > 1:
-            self.plans.append(_native.Plan(specs, device=device_index))
+            self.plans.append(plan_factory())
         if length_hint is not None:
             for p in self.plans:
                 p.set_length_hint(*length_hint)
-        self.main = torch.cuda.current_stream(self.dev)
-        self.lanes = [(self.plans[0], self.main)] if self.n_chunks == 1 else \
-            [(p, torch.cuda.Stream(device=self.dev)) for p in self.plans]
+        if self.host:
+            self.dev = torch.device("cpu")
+            self.main = _HostStream()
+            self.lanes = [(self.plans[0], self.main)] if self.n_chunks == 1 else [(p, _HostStream()) for p in self.plans]
+        else:
+            self.dev = torch.device("cuda", device_index)
+            self.main = torch.cuda.current_stream(self.dev)
+            self.lanes = [(self.plans[0], self.main)] if self.n_chunks == 1 else \
+                [(p, torch.cuda.Stream(device=self.dev)) for p in self.plans]
         self._stage = {}
+        self.p2p_only = False         # tests: the grouped isend / irecv form also where the chunk heights agree
+        self.exchanges_issued = 0     # handles of the last run (tests)
+        self.ring_reuses = 0          # times a staging slot was drained because its block was about to be reused
+
+    def _on(self, stream):
+        return _NoContext() if self.host else self.torch.cuda.stream(stream)
 
     def close(self):
         for p in self.plans:
@@ -140,7 +178,8 @@ class ShardPipeline:
         """values / offsets: this rank's shard (device tensors; offsets int64, relative to `values`);
         counts: rows of every rank's shard; full: [sum(counts), n_cols] float64 device tensor that receives every
         rank's rows (rank-major).  Enqueues everything and waits for the exchange; returns `full`."""
-        torch, dist = self.torch, self.dist
+        dist = self.dist
+        self.exchanges_issued = self.ring_reuses = 0
         counts = [int(c) for c in counts]
         starts = np.concatenate([[0], np.cumsum(counts)]).astype(np.int64)
         n_chunks = max(1, min(self.n_chunks, max(min(counts), 1)))  # the same on every rank
@@ -160,19 +199,25 @@ class ShardPipeline:
                 # offsets stay relative to the start of `values`: a chunk is the same buffer with a later offsets pointer
                 pl.extract_device(values.data_ptr(), dtype_code, offsets.data_ptr() + 8 * c0, c1 - c0,
                                   mine.data_ptr() + 8 * self.n_cols * c0, self.n_cols, st.cuda_stream)
-            if dist is not None and self.world > 1:
+            if dist is not None and (self.world > 1 or self.force_exchange):
                 slot = (lane, (c // n_lanes) % 2)
                 if slot in pending:  # the staging block of this slot is about to be reused: scatter its rows first
                     pst, hs = pending.pop(slot)
-                    with torch.cuda.stream(pst):
+                    self.ring_reuses += 1
+                    with self._on(pst):
                         finish_exchange(full, starts_l, self.rank, hs)
                 lo_hi = [(cuts[r][c], cuts[r][c + 1]) for r in range(self.world)]
                 heights = {hi - lo for lo, hi in lo_hi}
-                stage = self._stage_for(slot, max(heights), full.dtype) if len(heights) == 1 else None
-                with torch.cuda.stream(st):  # the collective orders itself after this chunk's kernels only
-                    pending[slot] = (st, exchange_rows(full, starts_l, self.rank, lo_hi, dist, stage))
+                stage = self._stage_for(slot, max(heights), full.dtype) if len(heights) == 1 and not self.p2p_only else None
+                loop = None
+                if self.world == 1 and self.p2p_only:   # the point-to-point form at a world of one: RCCL's self send / receive
+                    loop = self._stage_for(("loop",) + slot, max(heights), full.dtype)
+                with self._on(st):  # the collective orders itself after this chunk's kernels only
+                    hs = exchange_rows(full, starts_l, self.rank, lo_hi, dist, stage, loopback=loop, force=self.force_exchange)
+                    self.exchanges_issued += len(hs)
+                    pending[slot] = (st, hs)
         for pst, hs in pending.values():
-            with torch.cuda.stream(pst):
+            with self._on(pst):
                 finish_exchange(full, starts_l, self.rank, hs)
         for pl, st in self.lanes:
             if st is not self.main:
