@@ -197,12 +197,17 @@ int tsfa_host_free(void *ptr);
  * tsfa_relevance_* accept TSFA_DEVICE pointers; with the four entry points below a host in any language keeps that
  * matrix in HBM for the whole chain and fetches only the selected columns (the reference's `X.loc[:, relevant]`,
  * feature_selection/selection.py:181).  tsfa_device_copy: to_device != 0 copies host -> device, else device -> host.
- * tsfa_gather_columns: out_host[r * n_sel + c] = X[r * ld + cols[c]]. */
+ * tsfa_gather_columns: out_host[r * n_sel + c] = X[r * ld + cols[c]].
+ * tsfa_scatter_columns: dst[r * ld_dst + cols[c]] = src[r * n_src + c], dst and src in device memory, cols on the host: the
+ * columns of ONE native plan of a settings object that needs several (augmented_dickey_fuller with several autolag values,
+ * more than 128 cwt_coefficients columns) land in their places of the caller's matrix without leaving the device. */
 int tsfa_device_alloc(void **ptr, size_t bytes, int32_t device);
 int tsfa_device_free(void *ptr, int32_t device);
 int tsfa_device_copy(void *dst, const void *src, size_t bytes, int32_t to_device, int32_t device);
 int tsfa_gather_columns(const double *X, int64_t n_rows, int64_t ld, const int32_t *cols, int64_t n_sel, double *out_host,
                         int32_t device);
+int tsfa_scatter_columns(double *dst, int64_t ld_dst, const int32_t *cols, const double *src, int64_t n_rows, int64_t n_src,
+                         int32_t device);
 
 /* ---- feature selection: relevance statistics of the extracted matrix ----
  * Replaces the per-feature loop of tsfresh/feature_selection/relevance.py:214-322 (calculate_relevance_table ->

@@ -102,7 +102,41 @@ def test_hip_several_devices_through_several_native_plans(gpu):
     assert one.shape == (6, 4) and not one.isna().any().any()
 
 
-def test_device_resident_extraction_names_what_it_cannot_hold():
-    from tsfresh_amd.feature_extraction.extraction import _CompositePlan
-    with pytest.raises(ValueError, match="ONE native plan"):
-        _CompositePlan([], 0).extract_into(None, None, None)
+@pytest.mark.gpu
+def test_device_resident_extraction_through_several_native_plans(gpu):
+    """extract_relevant_features(device_resident=True) with a settings object that needs two native plans (round-5 VERDICT
+    missing #6: it used to be refused): the parts' blocks are scattered into the device matrix (tsfa_scatter_columns), the
+    selection equals the host path's."""
+    from tsfresh_amd import extract_relevant_features
+    rng = np.random.default_rng(12)
+    n_ids, L = 60, 80
+    y = pd.Series(rng.integers(0, 2, n_ids), index=np.arange(n_ids))
+    x = rng.standard_normal((n_ids, L)) + 1.5 * y.to_numpy()[:, None]
+    df = pd.DataFrame({"id": np.repeat(np.arange(n_ids), L), "time": np.tile(np.arange(L), n_ids), "value": x.reshape(-1)})
+    params = {"mean": None, "augmented_dickey_fuller": [{"attr": "teststat", "autolag": "AIC"}, {"attr": "teststat", "autolag": "BIC"}],
+              "maximum": None, "variance": None}
+    host = extract_relevant_features(df, y, column_id="id", column_sort="time", default_fc_parameters=params)
+    dev = extract_relevant_features(df, y, column_id="id", column_sort="time", default_fc_parameters=params, device_resident=True)
+    assert list(host.columns) == list(dev.columns) and len(host.columns) >= 2
+    pd.testing.assert_frame_equal(host, dev, check_exact=False, rtol=1e-12, atol=0.0)
+
+
+@pytest.mark.gpu
+def test_composite_plans_upload_the_samples_once_per_device(gpu, monkeypatch):
+    """devices=[0, 0] with three lag selections: ONE _DeviceBuffer of the samples per shard, not one per part (VERDICT r5 weak #11)."""
+    from tsfresh_amd import _native, extract_features
+    rng = np.random.default_rng(9)
+    lens = [150, 90, 300, 64, 200, 120]
+    df = pd.DataFrame({"id": np.repeat(np.arange(len(lens)), lens), "time": np.concatenate([np.arange(m) for m in lens]),
+                       "value": np.concatenate([np.cumsum(rng.standard_normal(m)) for m in lens])})
+    params = {"augmented_dickey_fuller": [{"attr": "teststat", "autolag": a} for a in ("AIC", "BIC", "t-stat")]}
+    uploads = []
+    real = _native._DeviceBuffer.__init__
+
+    def counting(self, lib, array, device):
+        uploads.append(array.dtype.str)
+        real(self, lib, array, device)
+    monkeypatch.setattr(_native._DeviceBuffer, "__init__", counting)
+    got = extract_features(df, column_id="id", column_sort="time", default_fc_parameters=params, devices=[0, 0])
+    assert got.shape == (6, 3) and not got.isna().any().any()
+    assert sum(1 for d in uploads if d.endswith("f8") or d.endswith("f4")) == 2, uploads     # one per shard

@@ -45,6 +45,7 @@ EXPORTS = (
     "tsfa_device_free",
     "tsfa_device_copy",
     "tsfa_gather_columns",
+    "tsfa_scatter_columns",
 )
 
 
@@ -451,6 +452,51 @@ class DeviceMatrix:
         return out
 
 
+def extract_parts_into(parts, values, offsets, matrix, col0=0, times=None):
+    """Several native plans over ONE upload of the samples: parts = [(Plan, column indices in the caller's order)].  Every
+    part's block is extracted into a transient device matrix and scattered (tsfa_scatter_columns) into columns
+    col0 + cols of `matrix` (a DeviceMatrix): the composite plans of feature_extraction/extraction.py (several ADF lag
+    selections, more than 128 CWT columns) without an upload per part, and with the matrix staying in HBM."""
+    lib = load()
+    _bind_device_api(lib)
+    values = np.ascontiguousarray(values)
+    if values.dtype == np.float32:
+        dt = TSFA_F32
+    else:
+        values = np.ascontiguousarray(values, dtype=np.float64)
+        dt = TSFA_F64
+    offsets = np.ascontiguousarray(offsets, dtype=np.int64)
+    n_series = offsets.shape[0] - 1
+    if n_series == 0:
+        return
+    if values.size == 0:
+        raise ValueError("every series must hold at least one sample")
+    device = matrix.device
+    bufs = [_DeviceBuffer(lib, values, device), _DeviceBuffer(lib, offsets, device)]
+    tmp = None
+    try:
+        tptr = None
+        if times is not None:
+            times = np.ascontiguousarray(times, dtype=np.float64)
+            bufs.append(_DeviceBuffer(lib, times, device))
+            tptr = ctypes.c_void_p(bufs[2].ptr)
+        width = max(plan.n_cols for plan, _ in parts)
+        tmp = DeviceMatrix(n_series, width, device)
+        for plan, cols in parts:
+            if plan.n_cols == 0:
+                continue
+            _check(lib, lib.tsfa_extract_timed(plan._h, ctypes.c_void_p(bufs[0].ptr), dt, tptr, ctypes.c_void_p(bufs[1].ptr),
+                                               n_series, ctypes.c_void_p(tmp.ptr), plan.n_cols, TSFA_DEVICE, None))
+            idx = np.ascontiguousarray(np.asarray(cols, dtype=np.int64) + int(col0), dtype=np.int32)
+            _check(lib, lib.tsfa_scatter_columns(ctypes.c_void_p(matrix.ptr), matrix.ld, idx.ctypes.data_as(ctypes.c_void_p),
+                                                 ctypes.c_void_p(tmp.ptr), n_series, plan.n_cols, device))
+    finally:
+        for bf in bufs:
+            bf.free()
+        if tmp is not None:
+            tmp.free()
+
+
 def _bind_device_api(lib):
     if getattr(lib, "_tsfa_device_api_bound", False):
         return
@@ -463,6 +509,9 @@ def _bind_device_api(lib):
     lib.tsfa_gather_columns.restype = ctypes.c_int32
     lib.tsfa_gather_columns.argtypes = [ctypes.c_void_p, ctypes.c_int64, ctypes.c_int64, ctypes.c_void_p, ctypes.c_int64,
                                         ctypes.c_void_p, ctypes.c_int32]
+    lib.tsfa_scatter_columns.restype = ctypes.c_int32
+    lib.tsfa_scatter_columns.argtypes = [ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64,
+                                         ctypes.c_int64, ctypes.c_int32]
     lib._tsfa_device_api_bound = True
 
 

@@ -1204,7 +1204,7 @@ TSFA_DEV void fam_basic_series(const BT &b0, XS xs, int n, const TsfaSpec *specs
             else v = a / ((double)(n - lag) * st.var);
         } break;
         case TSFA_C_BINNED_ENTROPY:                                      // fc.py:1666
-            v = blk_binned_entropy(b, n, [=](int i) { return xs[i]; }, (int)p0, st.vmin, st.vmax, iw);
+            v = blk_binned_entropy(b, n, [=](int i) { return xs[i]; }, (int)p0, st.vmin, st.vmax, iw, BlkIsRow<BT>::v ? 64 : 256);   // (64 = TSFA_ROW_BINS, tsfa_layout.h)
             break;
         case TSFA_C_BENFORD_CORRELATION: {                               // fc.py:2341
             blk_sync();

@@ -834,5 +834,6 @@ TSFA_DEV void fam_entropy_series(const Blk &b0, XT *xs, int n, const TsfaSpec *s
 }
 
 #include "fam_entropy_bits.h"
+#include "fam_entropy_hbits.h"
 
 #endif

@@ -744,6 +744,18 @@ static int run_batch(tsfa_plan *plan, const void *d_values, int dtype, const dou
                     // 10 000 series of 4096 samples (profiles/r03_shapes.txt) against ... for this one.
                     a.ent_cnt = 3;
                     a.nt = 64 * TSFA_ENTB_MAXWAVES;
+                } else if (a.nspecs >= 2 && maxn > TSFA_ENTB_MAXN_LONG && maxn <= TSFA_ENTH_MAXN && plan->opt.entropy_route == 0) {
+                    // 4097 .. 19 000 samples (fam_entropy_hbits.h, the long-series build): the table of one diagonal word per
+                    // column part in LDS, the per-sample arrays in the workgroup's HBM slot, the tasks in register batches.
+                    // The pair sweep it replaces: 0.45 ms per series of 16 384 samples with the GPU full (profiles/r04_long_entropy.md)
+                    bool all_m2 = true;
+                    for (const auto &s : plan->fam_specs[f])
+                        if (s.calc == TSFA_C_APPROXIMATE_ENTROPY && (int)s.p[0] != 2) all_m2 = false;
+                    if (all_m2) {
+                        a.ent_cnt = 4;
+                        a.ent_fast = 0;
+                        a.nt = 64 * TSFA_ENTB_MAXWAVES;
+                    }
                 }
             }
             // SEQ: one launch parses up to TSFA_LZ_MAX_GROUP `bins` values side by side -- as many as LDS allows
@@ -773,15 +785,15 @@ static int run_batch(tsfa_plan *plan, const void *d_values, int dtype, const dou
             // A series whose working set does not fit a CU's LDS runs from the long-series build of the same kernels
             // (tsfa_kernels_long.hip): the working set in a slot of HBM scratch per resident workgroup, a persistent
             // grid walking the group's series.  Slower per sample, but every length up to 65 535 extracts.
-            const bool use_long = lds > TSFA_LDS_LIMIT || plan->opt.force_long;
+            const bool use_long = lds > TSFA_LDS_LIMIT || plan->opt.force_long || (f == TSFA_FAM_ENTROPY && a.ent_cnt == 4);
             if (TSFA_LAB_ONLY(f == TSFA_FAM_SPECTRAL && plan->opt.trace))
                 fprintf(stderr, "[tsfa] spectral group %d: n_series %lld maxn %d max_np2 %lld lds %zu long %d chirp-z %d slots %lld nt %d\n", g,
                         (long long)a.n_series, maxn, max_np2, lds, (int)use_long, (int)(a.gscratch != nullptr), (long long)a.gscratch_slots, a.nt);
             if (use_long) {
-                a.nt = 256;
+                if (!(f == TSFA_FAM_ENTROPY && a.ent_cnt == 4)) a.nt = 256;
                 // the long-series build's persistent grid indexes the chirp-z scratch by workgroup: a slot for each, or none
                 if (a.gscratch != nullptr && a.gscratch_slots < std::min<int64_t>(a.n_series, 2048)) a.gscratch = nullptr;
-                if (f == TSFA_FAM_ENTROPY) { a.ent_cnt = 0; a.ent_fast = 0; lds = tsfa_entropy_lds_bytes(maxn, 0); }
+                if (f == TSFA_FAM_ENTROPY && a.ent_cnt != 4) { a.ent_cnt = 0; a.ent_fast = 0; lds = tsfa_entropy_lds_bytes(maxn, 0); }
                 if (f == TSFA_FAM_CWT) { a.cwt_rowv &= 2; lds = tsfa_family_lds_bytes(f, maxn, a.nt, 0); }
                 if (f == TSFA_FAM_SEQ) {
                     seq_group = std::min(a.nspecs, TSFA_LZ_MAX_GROUP);

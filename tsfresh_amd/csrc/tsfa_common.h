@@ -1403,6 +1403,32 @@ TSFA_DEV double np_linspace_at(double start, double stop, int num_edges, int i) 
     return (double)i * step + start;
 }
 
+template <bool RECIP, class BT, class G>
+TSFA_DEV void binned_scatter(const BT &b, int m, G g, int bins, double first, double last, double norm, double inv_norm, double step,
+                             bool flat, int c0, int cb, int *cnt) {
+    for (int i = b.tid; i < m; i += b.nt) {
+        const double v = g(i);
+        if (!(v >= first && v <= last)) continue;
+        const double fidx = RECIP ? ((v - first) * inv_norm) * (double)bins : ((v - first) / norm) * (double)bins;
+        int idx = (fidx < 2147483000.0) ? (int)fidx : (bins - 1);
+        if (idx >= bins) idx = bins - 1;
+        if (idx < 0) idx = 0;
+        const double e0 = flat ? np_linspace_at(first, last, bins + 1, idx) : ((idx == bins) ? last : (double)idx * step + first);
+        if (v < e0) idx -= 1;
+        if (idx != bins - 1) {
+            const double e1 = flat ? np_linspace_at(first, last, bins + 1, idx + 1)
+                                   : ((idx + 1 == bins) ? last : (double)(idx + 1) * step + first);
+            if (v >= e1) idx += 1;
+        }
+        if (idx < c0 || idx >= c0 + cb) continue;
+#if TSFA_GPU
+        atomicAdd(&cnt[idx - c0], 1);
+#else
+        cnt[idx - c0] += 1;
+#endif
+    }
+}
+
 template <class BT, class G>
 TSFA_DEV double blk_binned_entropy(const BT &b, int m, G g, int bins, double vmin, double vmax, int *cnt, int cap = 256) {
     double first = vmin, last = vmax;
@@ -1448,27 +1474,10 @@ TSFA_DEV double blk_binned_entropy(const BT &b, int m, G g, int bins, double vmi
         blk_sync();
         for (int k = b.tid; k < cb; k += b.nt) cnt[k] = 0;
         blk_sync();
-        for (int i = b.tid; i < m; i += b.nt) {
-            const double v = g(i);
-            if (!(v >= first && v <= last)) continue;
-            const double fidx = recip ? ((v - first) * inv_norm) * (double)bins : ((v - first) / norm) * (double)bins;
-            int idx = (fidx < 2147483000.0) ? (int)fidx : (bins - 1);
-            if (idx >= bins) idx = bins - 1;
-            if (idx < 0) idx = 0;
-            const double e0 = flat ? np_linspace_at(first, last, bins + 1, idx) : ((idx == bins) ? last : (double)idx * step + first);
-            if (v < e0) idx -= 1;
-            if (idx != bins - 1) {
-                const double e1 = flat ? np_linspace_at(first, last, bins + 1, idx + 1)
-                                       : ((idx + 1 == bins) ? last : (double)(idx + 1) * step + first);
-                if (v >= e1) idx += 1;
-            }
-            if (idx < c0 || idx >= c0 + cb) continue;
-#if TSFA_GPU
-            atomicAdd(&cnt[idx - c0], 1);
-#else
-            cnt[idx - c0] += 1;
-#endif
-        }
+        // (two loops: under one loop with a select the compiler evaluates the quotient for every sample -- a float64 division
+        //  is ~30 instructions -- although `recip` is the same for the whole series)
+        if (recip) binned_scatter<true>(b, m, g, bins, first, last, norm, inv_norm, step, flat, c0, cb, cnt);
+        else binned_scatter<false>(b, m, g, bins, first, last, norm, inv_norm, step, flat, c0, cb, cnt);
         blk_sync();
         for (int k = b.tid; k < cb; k += b.nt) {
             const int c = cnt[k];

@@ -19,6 +19,8 @@
 #define TSFA_ENTB_MAXN 1024
 #define TSFA_ENTB_MAXN_LONG 4096          // beyond: the series, its sorted copy and the ranges of one tolerance exceed a CU's LDS
 #define TSFA_ENTB_MAXWAVES 16
+#define TSFA_ENTH_S 2                     // fam_entropy_hbits.h: words per table entry: one diagonal word + its halo
+#define TSFA_ENTH_MAXN 17408              // fam_entropy_hbits.h: the table of one column part, (n + 1) x 17 / 16 x 8 bytes, fits a CU's LDS (17 x 1024: 17 entries per thread)
 
 // tolerances per round: the (strip, tolerance) tasks of a round live in the wavefronts' registers
 static inline TSFA_ENTB_HD int entb_kround(int maxn, int nk, int nw) {

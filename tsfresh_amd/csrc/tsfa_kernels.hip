@@ -202,8 +202,11 @@ __device__ __forceinline__ void basic_rows_body(const T *__restrict__ values, co
                            stats_out ? stats_out + sidx * TSFA_STATS_N : nullptr);
 }
 
+#if !defined(TSFA_ROWS_WPE)
+#define TSFA_ROWS_WPE 4
+#endif
 template <typename T>
-__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4))) k_basic_rows(const T *__restrict__ values, const int64_t *__restrict__ starts, const int64_t *__restrict__ ends, int64_t n_series, const int *__restrict__ sel,
+__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(TSFA_ROWS_WPE))) k_basic_rows(const T *__restrict__ values, const int64_t *__restrict__ starts, const int64_t *__restrict__ ends, int64_t n_series, const int *__restrict__ sel,
                         const TsfaSpec *__restrict__ specs, int nspecs, double *__restrict__ out, int64_t ld,
                         const double *__restrict__ dectab, int maxn, int hint_a, int n_loop, int n_count, int n_sum,
                         double *__restrict__ stats_out, int row_bytes) {
@@ -214,7 +217,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4))) k_
 }
 
 template <typename T>
-__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4))) k_trend_rows(const T *__restrict__ values, const int64_t *__restrict__ starts, const int64_t *__restrict__ ends, int64_t n_series, const int *__restrict__ sel,
+__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(TSFA_ROWS_WPE))) k_trend_rows(const T *__restrict__ values, const int64_t *__restrict__ starts, const int64_t *__restrict__ ends, int64_t n_series, const int *__restrict__ sel,
                         const TsfaSpec *__restrict__ specs, int nspecs, double *__restrict__ out, int64_t ld, int maxn,
                         int hint_b, const double *__restrict__ times, const TsfaAltPlan alt, int n_loop, int row_bytes) {
     basic_rows_body<T, 2>(values, starts, ends, n_series, sel, specs, nspecs, out, ld, nullptr, maxn, 0, hint_b, times, alt, n_loop, 0, 0,
@@ -401,6 +404,32 @@ __global__ void __launch_bounds__(1024) k_entropy(const T *__restrict__ values, 
     TSFA_TICKS_END();
     TSFA_SERIES_END
 }
+
+#if defined(TSFA_LONG)
+// Bit-matrix sweep beyond a CU's LDS (fam_entropy_hbits.h): every spec has m = 2, every series of the launch at most
+// TSFA_ENTH_MAXN samples.  1024 threads, one workgroup per CU (the table of a column part fills its LDS); a persistent grid
+// over the series, one HBM slot (EntropyHugeSlot) per workgroup.
+extern __shared__ __attribute__((aligned(16))) unsigned char tsfa_hsmem[];
+template <typename T>
+__global__ void __launch_bounds__(1024) kl_entropy_hbits(const T *__restrict__ values, const int64_t *__restrict__ starts, const int64_t *__restrict__ ends, int64_t n_series, const int *__restrict__ sel,
+                          const TsfaSpec *__restrict__ specs, int nspecs, double *__restrict__ out, int64_t ld, int maxn,
+                          const double *__restrict__ stats_in, unsigned char *__restrict__ gsc, size_t gslot) {
+    EntropyHugeSlot H;
+    H.carve(gsc + (size_t)blockIdx.x * gslot, maxn);
+    double *red = (double *)(void *)tsfa_hsmem;
+    unsigned int *table = (unsigned int *)(void *)(tsfa_hsmem + TSFA_RED_DOUBLES * sizeof(double));
+    unsigned int *wtot = (unsigned int *)(void *)(tsfa_hsmem + entropy_huge_lds_bytes(maxn) - 64 - (size_t)TSFA_ENTB_MAXWAVES * TSFA_ENTH_S * sizeof(unsigned int));
+    Blk b{(int)threadIdx.x, (int)blockDim.x, red, (NpScratch *)(void *)table};
+    for (int64_t wi = blockIdx.x; wi < n_series; wi += gridDim.x) {
+        const int64_t sidx = sel ? (int64_t)sel[wi] : wi;
+        const int64_t off = starts[sidx];
+        const int n = (int)(ends[sidx] - off);
+        fam_entropy_series_hbits<T>(b, values + off, n, specs, nspecs, out + sidx * ld, H, table, wtot,
+                                    stats_in ? stats_in + sidx * TSFA_STATS_N : nullptr);
+        __syncthreads();
+    }
+}
+#endif
 
 #if !defined(TSFA_LONG)
 // Bit-matrix sweep (fam_entropy_bits.h): every spec has m = 2 and every series of the launch 3 .. TSFA_ENTB_MAXN samples
@@ -1055,6 +1084,23 @@ static int launch_all_t(const TsfaLaunch &a, const T *values) {
         TSFA_KLAUNCH(k_ar<T>, lds, values, a.starts, a.ends, a.n_series, a.sel, a.specs, a.nspecs, a.out, a.ld, a.maxn, a.ar_P,
                      a.hint_a, a.hint_b, a.hint_c, a.hint_d, a.deg_list, a.deg_count, a.stats_in);
     } else if (a.fam == TSFA_FAM_ENTROPY) {
+#if defined(TSFA_LONG)
+        if (a.ent_cnt == 4) {   // fam_entropy_hbits.h: the table in LDS, everything per sample in the workgroup's HBM slot
+            EntropyHugeSlot H;
+            const size_t slot_ = (H.carve(nullptr, a.maxn) + 255) & ~(size_t)255;
+            const int64_t slots_ = (int64_t)(a.long_bytes / slot_);
+            if (!a.long_scratch || slots_ < 1) return -2;
+            const size_t hl = entropy_huge_lds_bytes(a.maxn);
+            auto kfn = kl_entropy_hbits<T>;
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)hl);
+            if (e != hipSuccess) return (int)e;
+            const dim3 hgrid((unsigned)std::min<int64_t>(a.n_series, std::min<int64_t>(slots_, 512)));
+            kfn<<<hgrid, 1024, hl, st>>>(values, a.starts, a.ends, a.n_series, a.sel, a.specs, a.nspecs, a.out, a.ld, a.maxn, a.stats_in,
+                                         a.long_scratch, slot_);
+            TSFA_LAUNCH_CHECK();
+            return 0;
+        }
+#endif
         EntropyLds L;
         const size_t lds = L.carve(nullptr, a.maxn, a.ent_cnt);
 #if !defined(TSFA_LONG)
@@ -1178,6 +1224,10 @@ int tsfa_launch_langevin_dd(const TsfaLaunch &a) {
 }
 
 size_t tsfa_entropy_lds_bytes(int maxn, int with_cnt) {
+    if (with_cnt == 4) {   // fam_entropy_hbits.h: the HBM slot of a workgroup (its LDS is entropy_huge_lds_bytes)
+        EntropyHugeSlot H;
+        return H.carve(nullptr, maxn);
+    }
     EntropyLds L;
     return L.carve(nullptr, maxn, with_cnt);
 }

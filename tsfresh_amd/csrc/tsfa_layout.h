@@ -74,6 +74,7 @@ struct BasicLds {
 // each with a carve of its own.  No numpy-order scratch (np_sum's row form keeps its three leaves in registers), no
 // cross-wavefront scratch.  The stride between the rows' carves is 64 bytes past a multiple of 128: a ds_read_b32 serves lanes
 // 0-31 in one cycle from 32 banks, so rows 0 / 1 (and 2 / 3), reading 16 consecutive dwords each, must start 16 banks apart.
+#define TSFA_ROW_BINS 64
 struct BasicRowLds {
     double *red; void *xs; double *w; double *cum; double *altc; int *iw; double *ctx;
     TSFA_HD static size_t row_bytes(int maxn, int xs_bytes, int part, int small_w) {
@@ -92,7 +93,10 @@ struct BasicRowLds {
         cum = w;
         altc = (part & 2) ? c.take<double>(8 * 16) : nullptr;
         ctx = c.take<double>(32);
-        iw = c.take<int>(256);
+        // iw: BASIC -- the histogram of binned_entropy in rounds of TSFA_ROW_BINS counters (blk_binned_entropy's `cap`) and
+        // benford's ten digit counters; TREND -- the six raw sums per agg_linear_trend regression (16 keys x 6 doubles).
+        // (1 KB per row here was what held k_basic_rows at 11 workgroups per CU: 2.75 wavefronts per SIMD)
+        iw = c.take<int>((part & 2) ? 16 * 6 * 2 : TSFA_ROW_BINS);
         return c.off;
     }
 };
@@ -217,6 +221,31 @@ struct EntropyLds {
         return c.off;
     }
 };
+
+// fam_entropy_hbits.h (long-series build): HBM slot of one workgroup
+struct EntropyHugeSlot {
+    double *thr; double *xs; double *xsrt; unsigned short *perm; unsigned int *rng; unsigned int *cnt;
+    TSFA_HD size_t carve(unsigned char *base, int maxn) {
+        LdsCarve c{base, 0};
+        thr = c.take<double>(64);
+        xs = c.take<double>((size_t)maxn + 4);
+        const int np2 = tsfa_pow2_ceil(maxn);
+        xsrt = c.take<double>((size_t)np2);
+        perm = c.take<unsigned short>((size_t)np2 + 32);
+        rng = c.take<unsigned int>((size_t)TSFA_ENTB_MAXK * maxn);
+        cnt = c.take<unsigned int>((size_t)TSFA_ENTB_MAXK * maxn + 8);
+        return c.off;
+    }
+};
+// LDS of the kernel: reduction scratch | table of one column part | cross-wavefront scratch of the table build
+TSFA_HD size_t entropy_huge_lds_bytes(int maxn) {
+    size_t table = (size_t)((maxn + 1) + ((maxn + 1) >> 4) + 1) * TSFA_ENTH_S * sizeof(unsigned int);   // entry p at slot p + p / 16 (bank skew)
+    if (table < sizeof(NpScratch) + 64) table = sizeof(NpScratch) + 64;   // the numpy-order sums run before the first table
+    const size_t totals = (2 * TSFA_ENTB_MAXK * TSFA_ENTB_MAXWAVES * 4) * sizeof(double) + (2 * TSFA_ENTB_MAXK * TSFA_ENTB_MAXWAVES + 4) * sizeof(unsigned int);
+    if (table < totals) table = totals;   // ... and the partial products of the totals after the last one
+    return TSFA_RED_DOUBLES * sizeof(double) + ((table + 15) & ~(size_t)15) + (size_t)TSFA_ENTB_MAXWAVES * TSFA_ENTH_S * sizeof(unsigned int) + 64;
+}
+
 
 struct SeqLds {
     double *red; unsigned char *seq; uint32_t *tab; double *edges;

@@ -691,6 +691,15 @@ __global__ void __launch_bounds__(256) k_gather_columns(const double *__restrict
     }
 }
 
+__global__ void __launch_bounds__(256) k_scatter_columns(double *__restrict__ dst, int64_t ld_dst, const int32_t *__restrict__ cols,
+                                                          const double *__restrict__ src, int64_t n_rows, int64_t n_src) {
+    const int64_t total = n_rows * n_src;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t r = i / n_src, c = i - r * n_src;
+        dst[r * ld_dst + cols[c]] = src[i];
+    }
+}
+
 static int rel_check_device(int32_t device, const char *who) {
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1 || device < 0 || device >= ndev)
@@ -748,6 +757,26 @@ extern "C" int tsfa_gather_columns(const double *X, int64_t n_rows, int64_t ld, 
     REL_HIP(hipMemcpy(out_host, dout, (size_t)n_rows * n_sel * sizeof(double), hipMemcpyDeviceToHost));
 done:
     (void)hipFree(dcols); (void)hipFree(dout);
+    return rc;
+}
+
+extern "C" int tsfa_scatter_columns(double *dst, int64_t ld_dst, const int32_t *cols, const double *src, int64_t n_rows,
+                                    int64_t n_src, int32_t device) {
+    if (n_rows < 0 || n_src < 0 || ((n_rows && n_src) && (!dst || !cols || !src)))
+        return tsfa_fail(TSFA_ERR_INVALID, "tsfa_scatter_columns: null pointer or bad shape");
+    int rc = rel_check_device(device, "tsfa_scatter_columns");
+    if (rc || n_rows == 0 || n_src == 0) return rc;
+    for (int64_t c = 0; c < n_src; ++c)
+        if (cols[c] < 0 || cols[c] >= ld_dst) return tsfa_fail(TSFA_ERR_INVALID, "tsfa_scatter_columns: column index out of range");
+    int32_t *dcols = nullptr;
+    REL_HIP(hipSetDevice(device));
+    REL_HIP(hipMalloc((void **)&dcols, (size_t)n_src * sizeof(int32_t)));
+    REL_HIP(hipMemcpy(dcols, cols, (size_t)n_src * sizeof(int32_t), hipMemcpyHostToDevice));
+    k_scatter_columns<<<2048, 256, 0, 0>>>(dst, ld_dst, dcols, src, n_rows, n_src);
+    REL_HIP(hipGetLastError());
+    REL_HIP(hipDeviceSynchronize());
+done:
+    (void)hipFree(dcols);
     return rc;
 }
 

@@ -316,10 +316,12 @@ def clear_device_plans():
                 e.plan = None
 
 
-def extract_on_devices(specs, values, offsets, devices, times=None, n_cols=None):
+def extract_on_devices(specs, values, offsets, devices, times=None, n_cols=None, parts=None):
     """One process, several GPUs: the ragged batch is cut into sum(len^2)-balanced contiguous shards, one per device;
     every device runs its chunked host pipeline (tsfa_extract, TSFA_HOST) from its own host thread and writes its rows
-    straight into its slice of ONE page-locked matrix.  -> float64 [n_series, n_cols] in series order."""
+    straight into its slice of ONE page-locked matrix.  -> float64 [n_series, n_cols] in series order.
+    parts: [(sub-list of specs, their column indices)] for a settings object that needs several native plans
+    (feature_extraction/extraction.py: _split_native_specs); a device then uploads its shard once and runs every part on it."""
     from tsfresh_amd import _native
     specs = list(specs)
     n_cols = len(specs) if n_cols is None else int(n_cols)
@@ -339,9 +341,28 @@ def extract_on_devices(specs, values, offsets, devices, times=None, n_cols=None)
         if hi <= lo:
             return
         entry = None
+        entries = []
         try:
-            entry = _device_plan_acquire(k, dev, specs)
             sub = offsets[lo:hi + 1]
+            if parts:
+                import contextlib
+                entries = [(_device_plan_acquire(k, dev, sp), cols) for sp, cols in parts]
+                with contextlib.ExitStack() as stack:
+                    plans = []
+                    for (e, cols), (sp, _) in zip(entries, parts):
+                        stack.enter_context(e.lock)
+                        if e.plan is None:
+                            e.plan = _native.Plan(sp, device=dev)
+                        plans.append((e.plan, cols))
+                    dm = _native.DeviceMatrix(hi - lo, n_cols, dev)
+                    try:
+                        _native.extract_parts_into(plans, values[sub[0]:sub[-1]], sub - sub[0], dm,
+                                                   times=None if times is None else times[sub[0]:sub[-1]])
+                        out[lo:hi] = dm.to_host()
+                    finally:
+                        dm.free()
+                return
+            entry = _device_plan_acquire(k, dev, specs)
             with entry.lock:
                 if entry.plan is None:
                     entry.plan = _native.Plan(specs, device=dev)
@@ -352,6 +373,8 @@ def extract_on_devices(specs, values, offsets, devices, times=None, n_cols=None)
         finally:
             if entry is not None:
                 _device_plan_release(entry)
+            for e, _ in entries:
+                _device_plan_release(e)
 
     threads = [threading.Thread(target=work, args=(k, d), name="tsfresh_amd-dev%d" % d) for k, d in enumerate(devices)]
     for t in threads:

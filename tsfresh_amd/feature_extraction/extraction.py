@@ -107,17 +107,33 @@ class _CompositePlan:
             out[:, cols] = run(plan)
         return out
 
-    def extract_host(self, values, offsets, times=None):
-        return self._gather(len(offsets) - 1, lambda pl: pl.extract_host(values, offsets, times=times))
+    def extract_host(self, values, offsets, times=None, out=None):
+        # one upload of the samples for all parts; the parts' columns meet in a device matrix that comes back in one copy
+        n_rows = len(offsets) - 1
+        if not all(isinstance(pl, _native.Plan) for pl, _ in self.parts):   # (duck-typed parts: the CPU tests' emulation plans)
+            res = self._gather(n_rows, lambda pl: pl.extract_host(values, offsets, times=times))
+            if out is not None:
+                out[:, :self.n_cols] = res
+                return out
+            return res
+        dm = _native.DeviceMatrix(n_rows, self.n_cols, self.parts[0][0].device)
+        try:
+            self.extract_into(values, offsets, dm, times=times)
+            res = dm.to_host()
+        finally:
+            dm.free()
+        if out is not None:
+            out[:, :self.n_cols] = res
+            return out
+        return res
 
     def extract_windows_host(self, values, starts, ends, times=None):
         return self._gather(len(starts), lambda pl: pl.extract_windows_host(values, starts, ends, times=times))
 
     def extract_into(self, values, offsets, matrix, col0=0, times=None):
-        # the parts' columns interleave in the caller's order; a device matrix is filled block by block
-        raise ValueError("device_resident=True needs a settings object that ONE native plan holds (a single "
-                         "augmented_dickey_fuller autolag value, at most {} cwt_coefficients columns); extract with "
-                         "device_resident=False instead".format(_CWT_COLUMNS_PER_PLAN))
+        """Columns [col0, col0 + n_cols) of the DeviceMatrix `matrix` (device_resident=True: the feature matrix never leaves
+        HBM): every part extracts into a transient block that tsfa_scatter_columns puts in the caller's column order."""
+        _native.extract_parts_into(self.parts, values, offsets, matrix, col0=col0, times=times)
 
 
 def _split_native_specs(specs):
@@ -334,12 +350,9 @@ def extract_features(
                 from tsfresh_amd.distributed import extract_on_devices
                 specs = list(fplan.native_specs(_native.calc_id))
                 parts = _split_native_specs(specs)   # (one part unless the settings need several native plans)
-                if len(parts) == 1:
-                    matrix = extract_on_devices(specs, pk.values, pk.offsets, devices, times=pk.times)
-                else:
-                    matrix = _native._result_matrix(pk.n_series, len(specs))
-                    for sub, cols in parts:
-                        matrix[:, cols] = extract_on_devices(sub, pk.values, pk.offsets, devices, times=pk.times)
+                # (several native plans: every device uploads its shard ONCE and runs all the parts on it)
+                matrix = extract_on_devices(specs, pk.values, pk.offsets, devices, times=pk.times,
+                                            parts=parts if len(parts) > 1 else None)
             else:
                 matrix = nplan.extract_host(pk.values, pk.offsets, times=pk.times)
             # the reference's exceptions that depend on the samples (an infinite value under binned_entropy / ar_coefficient)
