@@ -30,7 +30,7 @@ def _series(rng, n, kind, dtype):
 @pytest.mark.parametrize("dtype", [np.float32, np.float64])
 def test_bit_matrix_sweep_beyond_4096_samples_equals_the_pair_sweep(gpu, dtype):
     rng = np.random.default_rng(31)
-    lens = [4097, 4100, 5000, 6001, 8192, 8193, 12000, 13441, 16384, 17408, 300, 3]
+    lens = [4097, 4100, 5000, 6001, 8192, 8193, 12000, 13441, 16384, 17408, 300, 3, 31, 32, 33, 64, 1024, 2]
     chunks = [_series(rng, n, i % 5, dtype) for i, n in enumerate(lens)]
     values = np.concatenate(chunks)
     offsets = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)

@@ -16,80 +16,111 @@
 
 #if TSFA_GPU && defined(TSFA_LONG)
 
-#define TSFA_ENTH_MAXT 24                 // tasks per wavefront: three registers each (two entry addresses, the packed counts)
+#if !defined(TSFA_ENTH_MAXT)
+#define TSFA_ENTH_MAXT 16   // (20 / 24: the kernel's 128 registers no longer hold the tasks, their addresses are reloaded from scratch in the sweep)
+#endif
+//                // tasks per wavefront: three registers each (two entry addresses, the packed counts)
 
-// one task over one column part: entries of two words; sh = lane & 31
-TSFA_DEV unsigned int enth_task_part(unsigned int pl_addr, unsigned int ph_addr, unsigned int sh) {
-    typedef unsigned int enth_u2 __attribute__((ext_vector_type(2)));
-    typedef __attribute__((address_space(3))) const enth_u2 *enth_lds_cv2;
-    const enth_u2 l2 = *(enth_lds_cv2)pl_addr, h2 = *(enth_lds_cv2)ph_addr;
-    const unsigned int e = __builtin_amdgcn_alignbit(h2.y ^ l2.y, h2.x ^ l2.x, sh);  // the row rotated left by the lane index
-    unsigned int c2 = 0u, c3 = 0u, m;
-    // M2 = E & E(lane + 1), M3 = M2 & M2(lane + 1); two wait states between the write of a DPP source and its read
+// TWO tasks over one column part.  Entries of two words; sh = lane & 31.  A task without work (beyond the batch's last one)
+// points both addresses at entry 0: its row is Pref(0) xor Pref(0) = 0 and counts nothing -- no predicate, no branch.  The
+// two tasks' DPP reads interleave, so every read follows the write of its source by the two required wait states; C_2 accumulates in the low half of the packed counter by the popcount-add itself, C_3 by one shift-add.
+typedef unsigned int enth_u2 __attribute__((ext_vector_type(2)));
+typedef __attribute__((address_space(3))) const enth_u2 *enth_lds_cv2;
+TSFA_DEV void enth_sweep2(unsigned int rl0, unsigned int rh0, unsigned int rl1, unsigned int rh1, unsigned int sh, unsigned int &ct0,
+                          unsigned int &ct1) {
+    const enth_u2 l0 = *(enth_lds_cv2)rl0, h0 = *(enth_lds_cv2)rh0, l1 = *(enth_lds_cv2)rl1, h1 = *(enth_lds_cv2)rh1;
+    const unsigned int e0 = __builtin_amdgcn_alignbit(h0.y ^ l0.y, h0.x ^ l0.x, sh);  // the row rotated left by the lane index
+    const unsigned int e1 = __builtin_amdgcn_alignbit(h1.y ^ l1.y, h1.x ^ l1.x, sh);
+    unsigned int m0, m1, c30, c31;
     asm("s_nop 1\n\t"
-        "v_and_b32_dpp %2, %3, %3" TSFA_ENTB_DPP
-        "v_bcnt_u32_b32 %0, %2, %0\n\t"
-        "s_nop 1\n\t"
-        "v_and_b32_dpp %2, %2, %2" TSFA_ENTB_DPP
-        "v_bcnt_u32_b32 %1, %2, %1"
-        : "+v"(c2), "+v"(c3), "=&v"(m)
-        : "v"(e));
-    return c2 | (c3 << 16);
+        "v_and_b32_dpp %4, %6, %6" TSFA_ENTB_DPP
+        "v_and_b32_dpp %5, %7, %7" TSFA_ENTB_DPP
+        "v_bcnt_u32_b32 %0, %4, %0\n\t"
+        "v_bcnt_u32_b32 %1, %5, %1\n\t"
+        "v_and_b32_dpp %4, %4, %4" TSFA_ENTB_DPP
+        "v_and_b32_dpp %5, %5, %5" TSFA_ENTB_DPP
+        "v_bcnt_u32_b32 %2, %4, 0\n\t"
+        "v_bcnt_u32_b32 %3, %5, 0\n\t"
+        "v_lshl_add_u32 %0, %2, 16, %0\n\t"
+        "v_lshl_add_u32 %1, %3, 16, %1"
+        : "+v"(ct0), "+v"(ct1), "=&v"(c30), "=&v"(c31), "=&v"(m0), "=&v"(m1)
+        : "v"(e0), "v"(e1));
 }
 
-// Table of one column part (entb_build_table) from the thread's OWN slice of the sample order held in registers: the order
-// lives in HBM here, and the two passes over it per part -- 2 x 16 dependent global loads per thread at 16 384 samples -- were
-// 90 % of the first version's time (18 us per part against ~2 us of LDS and vector work).  pj[e] = perm[tid * E + e].
+// Table of one column part.  Thread t owns the E = ceil(n / 1024) CONSECUTIVE ranks [t E, (t + 1) E) of the sample order (the
+// running OR of a prefix needs them in order) and keeps their sample indices in registers for the whole series: the order
+// lives in HBM here, and re-reading it per part was 90 % of the first version's time.  Entry of rank p: slot
+// (p / E) * SE + p % E with SE = E | 1 -- an odd stride between the threads' blocks, so the 64-bit stores of a wavefront spread
+// over all bank pairs (blocks 128 bytes apart, E = 16, are one bank for every lane: a 32-way conflict on each of 2 E stores).
+//
+// The exclusive prefix of every thread and part -- the bits of all lower ranks in the part's two words -- does not depend on the
+// task batch: enth_prefix computes it ONCE per series (a sweep over the thread's ranks, a wavefront OR-scan and one barrier
+// per part) into the slot's `pre` array; a batch then builds a part's table from one coalesced 8-byte load per thread and one
+// sweep over its ranks.  (Recomputed per batch it was three quarters of the kernel's instructions.)
 #define TSFA_ENTH_MAXE ((TSFA_ENTH_MAXN + 1023) / 1024)
-#define TSFA_ENTH_SLOT(p) ((p) + ((p) >> 4))
-TSFA_DEV void enth_build_table(const Blk &b, int n, const int (&pj)[TSFA_ENTH_MAXE], int E, int w0, int NW, unsigned int *table,
-                               unsigned int *wtot) {
-    const int t0 = w0 % NW, t1 = (w0 + 1) % NW;   // the row words the entry's two words mirror
-    const int p0 = b.tid * E;
-    unsigned int tot0 = 0u, tot1 = 0u;
-#pragma unroll
-    for (int e = 0; e < TSFA_ENTH_MAXE; ++e) {
-        if (e < E && p0 + e < n) {
-            const int j = pj[e], jw = j >> 5;
-            const unsigned int bit = 1u << (j & 31);
-            tot0 |= (jw == t0) ? bit : 0u;
-            tot1 |= (jw == t1) ? bit : 0u;
-        }
-    }
+typedef unsigned int enth_w2 __attribute__((ext_vector_type(2)));
+// the two table words (low: word t0, high: word t0 + 1) that sample j sets; wrap: the part's second word is word 0
+// (single: the row is ONE word, n <= 31 -- it is its own halo)
+TSFA_DEV unsigned long long enth_bits(unsigned int j, unsigned int x0, bool wrap, bool single) {
+    unsigned int d = j - x0;
+    if (wrap) d = (j < 32u) ? (j + 32u) : d;
+    unsigned long long v = (unsigned long long)(d < 64u ? 1u : 0u) << (d & 63u);
+    if (single) v |= v >> 32;
+    return v;
+}
+TSFA_DEV void enth_prefix(const Blk &b, int n, const unsigned int (&pj)[TSFA_ENTH_MAXE], int NW, enth_w2 *pre, unsigned int *wtot) {
     const int lane = b.tid & 63, wave = b.tid >> 6;
-    const unsigned int inc0 = entb_wave_or_scan(tot0), inc1 = entb_wave_or_scan(tot1);
-    if (lane == 63) { wtot[wave * 2] = inc0; wtot[wave * 2 + 1] = inc1; }
-    unsigned int run0 = entb_from_prev(inc0), run1 = entb_from_prev(inc1);
+    for (int part = 0; part < NW; ++part) {
+        const unsigned int x0 = (unsigned int)part << 5;
+        const bool wrap = (part == NW - 1);
+        unsigned long long tot = 0ull;
+#pragma unroll
+        for (int e = 0; e < TSFA_ENTH_MAXE; ++e) tot |= enth_bits(pj[e], x0, wrap, NW == 1);   // (ranks beyond the thread's: index 0xFFFFFFF0, no bit)
+        const unsigned int inc0 = entb_wave_or_scan((unsigned int)tot), inc1 = entb_wave_or_scan((unsigned int)(tot >> 32));
+        unsigned int *wt = wtot + (part & 1) * 2 * TSFA_ENTB_MAXWAVES;   // two buffers: one barrier per part
+        if (lane == 63) { wt[wave * 2] = inc0; wt[wave * 2 + 1] = inc1; }
+        unsigned int run0 = entb_from_prev(inc0), run1 = entb_from_prev(inc1);
+        blk_sync();
+        for (int v = 0; v < wave; ++v) { run0 |= wt[v * 2]; run1 |= wt[v * 2 + 1]; }
+        enth_w2 w;
+        w.x = run0;
+        w.y = run1;
+        pre[(size_t)part * b.nt + b.tid] = w;
+    }
     blk_sync();
-    for (int v = 0; v < wave; ++v) { run0 |= wtot[v * 2]; run1 |= wtot[v * 2 + 1]; }
-    // A thread owns E CONSECUTIVE entries (the running OR needs them in order): at E = 16 the lanes' stores are 128 bytes
-    // apart -- one bank for the whole wavefront, a 32-way conflict on every one of 2 E stores (the first version spent more
-    // time here than in the sweep).  Entry p therefore lives at slot p + p / 16 (TSFA_ENTH_SLOT): neighbouring lanes land 17
-    // entries apart, two lanes per bank pair at worst; the sweep's gathers use the same map.
-    typedef unsigned int enth_w2 __attribute__((ext_vector_type(2)));
-    enth_w2 *t2 = (enth_w2 *)(void *)table;
+}
+TSFA_DEV void enth_build_table(const Blk &b, int n, const unsigned int (&pj)[TSFA_ENTH_MAXE], int E, int part, int NW, enth_w2 start,
+                               unsigned int *table) {
+    const unsigned int x0 = (unsigned int)part << 5;
+    const bool wrap = (part == NW - 1);
+    const int SE = E | 1;
+    enth_w2 *t2 = (enth_w2 *)(void *)table + (size_t)b.tid * SE;
+    unsigned long long run = (unsigned long long)start.x | ((unsigned long long)start.y << 32);
+    const int p0 = b.tid * E;
 #pragma unroll
     for (int e = 0; e < TSFA_ENTH_MAXE; ++e) {
         if (e < E && p0 + e < n) {
-            const int p = p0 + e;
             enth_w2 w;
-            w.x = run0;
-            w.y = run1;
-            t2[TSFA_ENTH_SLOT(p)] = w;
-            const int j = pj[e], jw = j >> 5;
-            const unsigned int bit = 1u << (j & 31);
-            run0 |= (jw == t0) ? bit : 0u;
-            run1 |= (jw == t1) ? bit : 0u;
+            w.x = (unsigned int)run;
+            w.y = (unsigned int)(run >> 32);
+            t2[e] = w;
+            run |= enth_bits(pj[e], x0, wrap, NW == 1);
         }
     }
-    if (b.tid == b.nt - 1) { enth_w2 w; w.x = run0; w.y = run1; t2[TSFA_ENTH_SLOT(n)] = w; }  // entry n: every column
+    // entry n (every column): the thread that owns rank n - 1 has the total in `run`; its slot follows that rank's
+    if (p0 < n && p0 + E >= n) {
+        enth_w2 w;
+        w.x = (unsigned int)run;
+        w.y = (unsigned int)(run >> 32);
+        ((enth_w2 *)(void *)table)[(n / E) * SE + (n % E)] = w;
+    }
     blk_sync();
 }
 
 // racc[4 k .. 4 k + 3] of the nk <= TSFA_ENTB_MAXK tolerances thr[0 .. nk) (see entropy_bits_batch)
 TSFA_DEV void entropy_hbits_batch(const Blk &b_in, const double *xs, int n, const double *thr, int nk, const unsigned short *perm,
-                                  double *xsrt, unsigned int *rng, unsigned int *cnt, unsigned int *table, unsigned int *wtot,
-                                  double *racc) {
+                                  double *xsrt, unsigned int *rng, unsigned int *cnt, enth_w2 *pre, unsigned int *table,
+                                  unsigned int *wtot, double *racc) {
     const Blk b = entb_opaque(b_in);
     const int S = TSFA_ENTH_S;
     const int nrow_m = n - 1, nrow_m1 = n - 2;
@@ -104,14 +135,15 @@ TSFA_DEV void entropy_hbits_batch(const Blk &b_in, const double *xs, int n, cons
     const unsigned int kmagic = 65536u / (unsigned int)nk + 1u;  // id / nk == (id * kmagic) >> 16 for id < 10 000
     blk_sync();
     entb_ranges<TSFA_ENTH_S>(b, xs, n, thr, nk, perm, xsrt, rng);   // every tolerance of the batch: rng[k * n + sample]
-    // this thread's slice of the sample order, for the table builds
-    const int E = (n + b.nt - 1) / b.nt;
-    int pj[TSFA_ENTH_MAXE];
+    // this thread's slice of the sample order and, from it, its exclusive prefix in every column part
+    const int E = (n + b.nt - 1) / b.nt, SE = E | 1;
+    unsigned int pj[TSFA_ENTH_MAXE];
 #pragma unroll
     for (int e = 0; e < TSFA_ENTH_MAXE; ++e) {
         const int p = b.tid * E + e;
-        pj[e] = (e < E && p < n) ? (int)perm[p] : 0;
+        pj[e] = (e < E && p < n) ? (unsigned int)perm[p] : 0xFFFFFFF0u;
     }
+    enth_prefix(b, n, pj, NW, pre, wtot);
     for (int id0 = 0; id0 < ntask; id0 += TSFA_ENTH_MAXT * nw) {
         unsigned int rl[TSFA_ENTH_MAXT], rh[TSFA_ENTH_MAXT], ct[TSFA_ENTH_MAXT];
 #pragma unroll
@@ -125,15 +157,20 @@ TSFA_DEV void entropy_hbits_batch(const Blk &b_in, const double *xs, int n, cons
                 const int i = s * (2 * TSFA_ENTB_STRIP) + lane_row;
                 const unsigned int r = (i < n) ? rng[k * n + i] : 0u;
                 const unsigned int lo = (r & 0xFFFFu) >> 1, hi = r >> 17;   // ranks (entb_ranges packs rank * S)
-                rl[tt] = lane_off + 8u * TSFA_ENTH_SLOT(lo);
-                rh[tt] = lane_off + 8u * TSFA_ENTH_SLOT(hi);
+                rl[tt] = lane_off + 8u * ((lo / (unsigned int)E) * (unsigned int)SE + lo % (unsigned int)E);
+                rh[tt] = lane_off + 8u * ((hi / (unsigned int)E) * (unsigned int)SE + hi % (unsigned int)E);
             }
         }
+        enth_w2 start = pre[b.tid];
         for (int part = 0; part < NW; ++part) {
-            enth_build_table(b, n, pj, E, part, NW, table, wtot);
+            const enth_w2 cur = start;
+            if (part + 1 < NW) start = pre[(size_t)(part + 1) * b.nt + b.tid];   // in flight while this part is built and swept
+            enth_build_table(b, n, pj, E, part, NW, cur, table);
+            {   // two tasks at a time (four, or a prefetch of the next pair's entries, want more registers than 128: the task
+                //  addresses were then spilled and reloaded from scratch one by one inside this loop -- 15 .. 70 % slower)
+                static_assert(TSFA_ENTH_MAXT % 2 == 0, "tasks are swept in pairs");
 #pragma unroll
-            for (int tt = 0; tt < TSFA_ENTH_MAXT; ++tt) {
-                if (id0 + wave + tt * nw < ntask) ct[tt] += enth_task_part(rl[tt], rh[tt], sh);
+                for (int g2 = 0; g2 < TSFA_ENTH_MAXT; g2 += 2) enth_sweep2(rl[g2], rh[g2], rl[g2 + 1], rh[g2 + 1], sh, ct[g2], ct[g2 + 1]);
             }
             blk_sync();
         }
@@ -201,7 +238,7 @@ TSFA_DEV void fam_entropy_series_hbits(const Blk &b, const T *g, int n, const Ts
             thr[k] = ent_tolerance((sp.calc == TSFA_C_SAMPLE_ENTROPY) ? 0.2 * sd : sp.p[1] * sd);
         }
         blk_sync();
-        if (n >= 3) entropy_hbits_batch(b, xs, n, thr, nk, H.perm, H.xsrt, H.rng, H.cnt, table, wtot, racc);
+        if (n >= 3) entropy_hbits_batch(b, xs, n, thr, nk, H.perm, H.xsrt, H.rng, H.cnt, (enth_w2 *)(void *)H.pre, table, wtot, racc);
         for (int k = b.tid; k < nk; k += b.nt) {
             const TsfaSpec sp = specs[first + k];
             EntAcc a;

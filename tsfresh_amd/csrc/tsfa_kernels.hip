@@ -418,7 +418,7 @@ __global__ void __launch_bounds__(1024) kl_entropy_hbits(const T *__restrict__ v
     H.carve(gsc + (size_t)blockIdx.x * gslot, maxn);
     double *red = (double *)(void *)tsfa_hsmem;
     unsigned int *table = (unsigned int *)(void *)(tsfa_hsmem + TSFA_RED_DOUBLES * sizeof(double));
-    unsigned int *wtot = (unsigned int *)(void *)(tsfa_hsmem + entropy_huge_lds_bytes(maxn) - 64 - (size_t)TSFA_ENTB_MAXWAVES * TSFA_ENTH_S * sizeof(unsigned int));
+    unsigned int *wtot = (unsigned int *)(void *)(tsfa_hsmem + entropy_huge_lds_bytes(maxn) - 64 - (size_t)2 * TSFA_ENTB_MAXWAVES * TSFA_ENTH_S * sizeof(unsigned int));
     Blk b{(int)threadIdx.x, (int)blockDim.x, red, (NpScratch *)(void *)table};
     for (int64_t wi = blockIdx.x; wi < n_series; wi += gridDim.x) {
         const int64_t sidx = sel ? (int64_t)sel[wi] : wi;

@@ -224,7 +224,7 @@ struct EntropyLds {
 
 // fam_entropy_hbits.h (long-series build): HBM slot of one workgroup
 struct EntropyHugeSlot {
-    double *thr; double *xs; double *xsrt; unsigned short *perm; unsigned int *rng; unsigned int *cnt;
+    double *thr; double *xs; double *xsrt; unsigned short *perm; unsigned int *rng; unsigned int *cnt; unsigned int *pre;
     TSFA_HD size_t carve(unsigned char *base, int maxn) {
         LdsCarve c{base, 0};
         thr = c.take<double>(64);
@@ -234,16 +234,18 @@ struct EntropyHugeSlot {
         perm = c.take<unsigned short>((size_t)np2 + 32);
         rng = c.take<unsigned int>((size_t)TSFA_ENTB_MAXK * maxn);
         cnt = c.take<unsigned int>((size_t)TSFA_ENTB_MAXK * maxn + 8);
+        pre = c.take<unsigned int>((size_t)((maxn + 32) >> 5) * 1024 * 2);   // [column part][thread]: two words (enth_prefix)
         return c.off;
     }
 };
 // LDS of the kernel: reduction scratch | table of one column part | cross-wavefront scratch of the table build
 TSFA_HD size_t entropy_huge_lds_bytes(int maxn) {
-    size_t table = (size_t)((maxn + 1) + ((maxn + 1) >> 4) + 1) * TSFA_ENTH_S * sizeof(unsigned int);   // entry p at slot p + p / 16 (bank skew)
+    const size_t e = ((size_t)maxn + 1023) / 1024;   // ranks per thread; the threads' blocks are e | 1 entries apart (bank spread)
+    size_t table = ((size_t)1024 * (e | 1) + 2) * TSFA_ENTH_S * sizeof(unsigned int);
     if (table < sizeof(NpScratch) + 64) table = sizeof(NpScratch) + 64;   // the numpy-order sums run before the first table
     const size_t totals = (2 * TSFA_ENTB_MAXK * TSFA_ENTB_MAXWAVES * 4) * sizeof(double) + (2 * TSFA_ENTB_MAXK * TSFA_ENTB_MAXWAVES + 4) * sizeof(unsigned int);
     if (table < totals) table = totals;   // ... and the partial products of the totals after the last one
-    return TSFA_RED_DOUBLES * sizeof(double) + ((table + 15) & ~(size_t)15) + (size_t)TSFA_ENTB_MAXWAVES * TSFA_ENTH_S * sizeof(unsigned int) + 64;
+    return TSFA_RED_DOUBLES * sizeof(double) + ((table + 15) & ~(size_t)15) + (size_t)2 * TSFA_ENTB_MAXWAVES * TSFA_ENTH_S * sizeof(unsigned int) + 64;
 }
 
 
