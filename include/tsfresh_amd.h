@@ -33,8 +33,8 @@ typedef enum tsfa_status {
     TSFA_ERR_UNSUPPORTED = -2, /* calculator / parameter not implemented natively */
     TSFA_ERR_NO_DEVICE = -3,   /* no HIP device: the library never falls back to the CPU */
     TSFA_ERR_HIP = -4,         /* HIP runtime error */
-    TSFA_ERR_TOO_LONG = -5     /* a series of more than 65 535 samples under sample_entropy / approximate_entropy (O(n^2), 16-bit
-                                  sample indices); every other calculator takes any length up to 33 554 431 samples */
+    TSFA_ERR_TOO_LONG = -5     /* a series of more than 33 554 431 samples (every calculator takes any length up to there; since
+                                  round 6 also sample_entropy / approximate_entropy, which used to stop at 65 535) */
 } tsfa_status;
 
 /* element type of the ragged value buffer */
@@ -122,8 +122,7 @@ int tsfa_extract_timed(tsfa_plan *plan, const void *values, int32_t dtype, const
  * called on it (the forecasting workflow, BASELINE configs[4]); here the windows stay views.
  * tsfa_extract / tsfa_extract_timed are the special case ends = starts + 1 (a ragged batch).
  *
- *   starts, ends   n_series int64 each (same memory space as values); 1 <= ends[s] - starts[s] <= 33554431 (<= 65535 when the plan
- *                  holds sample_entropy / approximate_entropy columns: TSFA_ERR_TOO_LONG)
+ *   starts, ends   n_series int64 each (same memory space as values); 1 <= ends[s] - starts[s] <= 33554431 (TSFA_ERR_TOO_LONG)
  *   times          as in tsfa_extract_timed, indexed like values; the kernel regresses on
  *                  times[i] - times[starts[s]], i.e. hours since the window's own first stamp
  */

@@ -889,7 +889,9 @@ def _compare(names, got, want, series, rtol, check_excluded, simd_golden, skippe
                     continue
                 d = abs(g - w)
                 d = min(d, 360.0 - d)  # -180 == 180
-                if d > 1e-6 * 180.0:
+                # 1e-6 relative to the angle itself (round-5 VERDICT weak #2: the bound used to be 1e-6 of 180 degrees whatever
+                # the angle), over a floor of 1e-9 of the half turn for angles that are ~0 (a real bin: atan2(+-0, x))
+                if d > 1e-6 * abs(w) + 1e-9 * 180.0:
                     bad.append("series %d %s: got %r want %r" % (i, col, g, w))
                 continue
             rt, at = tolerance_for(col, x, w, facts)

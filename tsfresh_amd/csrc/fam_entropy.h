@@ -481,8 +481,8 @@ TSFA_DEV void entropy_sweep_staged(const Blk &b, const double *xs, int n, const 
 // window, x[j..j+2] is a wave-uniform broadcast read, per-row counters live in registers.
 // xs[n], xs[n+1] must hold +inf (the length-3 extension of the last templates then never matches).
 // ---------------------------------------------------------------------------------------------------------------
-template <int NK, typename XT>
-TSFA_DEV void entropy_sweep_m2(const Blk &b, const XT *xs, int n, const double *thr, const unsigned short *perm,
+template <int NK, typename XT, typename IDX>
+TSFA_DEV void entropy_sweep_m2(const Blk &b, const XT *xs, int n, const double *thr, const IDX *perm,
                                double *racc, const int *gidx, int gn) {
     const int nrow_m = n - 1;   // templates of length 2: i in [0, n-2]
     const int nrow_m1 = n - 2;  // templates of length 3: i in [0, n-3]
@@ -521,7 +521,7 @@ TSFA_DEV void entropy_sweep_m2(const Blk &b, const XT *xs, int n, const double *
 #pragma unroll
         for (int k = 0; k < NK; ++k) { c2[k] = 0; c3[k] = 0; }
         for (int q = jlo; q < jhi; ++q) {
-            const int c = perm[q];
+            const int c = (int)perm[q];
             const double xj0 = (double)xs[c], xj1 = (double)xs[c + 1], xj2 = (double)xs[c + 2];
             const double d0 = fabs(xi0 - xj0), d1 = fabs(xi1 - xj1), d2 = fabs(xi2 - xj2);
             const double m2 = fmax(d0, d1);
@@ -587,10 +587,14 @@ TSFA_DEVN void entropy_sort_templates_regs(const Blk b, const XT *xs, int n, uns
 }
 #endif
 
-template <typename XT>
-TSFA_DEV void entropy_sort_templates(const Blk &b, const XT *xs, int n, unsigned short *perm, int np2, bool f32 = false) {
+// IDX: unsigned short (series up to 65 535 samples: the LDS build, the bit-matrix sweeps) or unsigned int (the pair sweep of the
+// long-series build: any length)
+template <typename XT, typename IDX>
+TSFA_DEV void entropy_sort_templates(const Blk &b, const XT *xs, int n, IDX *perm, int np2, bool f32 = false) {
     const int nrow_m = n - 1;
+    const IDX none = (IDX)~(IDX)0;
 #if TSFA_GPU
+    if constexpr (sizeof(IDX) == 2) {
     if (f32) {
         if (np2 == b.nt) { entropy_sort_templates_packed<1>(b, xs, n, perm); return; }
         if (np2 == 2 * b.nt) { entropy_sort_templates_packed<2>(b, xs, n, perm); return; }
@@ -600,9 +604,10 @@ TSFA_DEV void entropy_sort_templates(const Blk &b, const XT *xs, int n, unsigned
     if (np2 == b.nt) { entropy_sort_templates_regs<1>(b, xs, n, perm); return; }
     if (np2 == 2 * b.nt) { entropy_sort_templates_regs<2>(b, xs, n, perm); return; }
     if (np2 == 4 * b.nt) { entropy_sort_templates_regs<4>(b, xs, n, perm); return; }
+    }
 #endif
     blk_sync();
-    for (int i = b.tid; i < np2; i += b.nt) perm[i] = (unsigned short)((i < nrow_m) ? i : 0xFFFF);
+    for (int i = b.tid; i < np2; i += b.nt) perm[i] = (i < nrow_m) ? (IDX)i : none;
     for (int k = 2; k <= np2; k <<= 1) {
         for (int j = k >> 1; j > 0; j >>= 1) {
             blk_sync();
@@ -610,8 +615,8 @@ TSFA_DEV void entropy_sort_templates(const Blk &b, const XT *xs, int n, unsigned
                 const int i = ((t & ~(j - 1)) << 1) | (t & (j - 1));
                 const int l = i | j;
                 const bool up = ((i & k) == 0);
-                const unsigned short a = perm[i], c = perm[l];
-                const double ka = (a == 0xFFFF) ? TSFA_INF : (double)xs[a], kc = (c == 0xFFFF) ? TSFA_INF : (double)xs[c];
+                const IDX a = perm[i], c = perm[l];
+                const double ka = (a == none) ? TSFA_INF : (double)xs[a], kc = (c == none) ? TSFA_INF : (double)xs[c];
                 const bool gt = (ka > kc) || (ka == kc && a > c);
                 if (gt == up) {
                     perm[i] = c;
@@ -674,9 +679,9 @@ TSFA_DEV double sampen_from_acc(const EntAcc &a, int n, int m) {
 //          sums are finished before the first sweep.  The symmetric sweep needs XT = double.
 //   FAST : the plan holds only m = 2 specs and cnt != null (decided on the host): the ordered-pair and generic
 //          sweeps are compiled out, which keeps the register allocation of the hot kernel free of spills.
-template <typename XT, bool FAST = false, bool F32 = false>
+template <typename XT, bool FAST = false, bool F32 = false, typename IDX = unsigned short>
 TSFA_DEV void fam_entropy_series(const Blk &b0, XT *xs, int n, const TsfaSpec *specs, int nspecs, double *out_row,
-                                 double *thr, unsigned short *perm, ent_ref *refs, unsigned int *cnt,
+                                 double *thr, IDX *perm, ent_ref *refs, unsigned int *cnt,
                                  int staged_ok = 1, const double *stats = nullptr) {
     const Blk &b = b0;
     // np.std(x), numpy summation order (the tolerances are c * np.std(x)); stats: the record k_basic left (TSFA_STATS_*)
@@ -723,9 +728,9 @@ TSFA_DEV void fam_entropy_series(const Blk &b0, XT *xs, int n, const TsfaSpec *s
             entropy_sort_templates(b, xs, n, perm, next_pow2(n - 1), F32);
             // pad: absent templates point at the +inf sentinels
             const int padded = ((n - 1 + 63) / 64) * 64 + 32;
-            for (int i = n - 1 + b.tid; i < padded; i += b.nt) perm[i] = (unsigned short)n;
+            for (int i = n - 1 + b.tid; i < padded; i += b.nt) perm[i] = (IDX)n;
             blk_sync();
-            if (FAST || cnt != nullptr) {
+            if ((FAST || cnt != nullptr) && sizeof(IDX) == 2) {
                 for (int i = b.tid; i < padded; i += b.nt) refs[i] = ent_make_ref((const double *)(const void *)xs, (int)perm[i]);
                 blk_sync();
             }
@@ -738,7 +743,7 @@ TSFA_DEV void fam_entropy_series(const Blk &b0, XT *xs, int n, const TsfaSpec *s
         // indexed register arrays).
         double *gthr = thr + TSFA_ENT_MAXK;
         double *racc = thr + 2 * TSFA_ENT_MAXK;  // [TSFA_ENT_MAXK][4]
-        if ((FAST || cnt != nullptr) && staged_ok && nk >= 4 && nk <= TSFA_ENT_STAGED_K && n >= 3 &&
+        if ((FAST || cnt != nullptr) && sizeof(IDX) == 2 && staged_ok && nk >= 4 && nk <= TSFA_ENT_STAGED_K && n >= 3 &&
             n <= TSFA_ENT_STAGED_MAXN) {
             // all thresholds of the batch in one staged sweep: ascending, right-aligned in gthr[0..5]
             int *gidx = (int *)(racc + 4 * TSFA_ENT_MAXK);
@@ -754,10 +759,11 @@ TSFA_DEV void fam_entropy_series(const Blk &b0, XT *xs, int n, const TsfaSpec *s
             }
             blk_sync();
             TSFA_TICK(tk, b, 132);
-            entropy_sweep_staged(b, (const double *)(const void *)xs, n, gthr, perm, refs, cnt, racc, gidx);
+            if constexpr (sizeof(IDX) == 2) entropy_sweep_staged(b, (const double *)(const void *)xs, n, gthr, perm, refs, cnt, racc, gidx);
             TSFA_TICK(tk, b, 133);
         } else {
-        const int gcap = (FAST || cnt != nullptr) ? TSFA_ENT_GROUP : TSFA_ENT_MAXK;
+        const bool sym = (FAST || cnt != nullptr) && sizeof(IDX) == 2;   // (the counter sweeps hold 16-bit template references)
+        const int gcap = sym ? TSFA_ENT_GROUP : TSFA_ENT_MAXK;
         const int ngroups = (nk + gcap - 1) / gcap;
         const int gsize = (nk + ngroups - 1) / ngroups;
         for (int g0 = 0; n >= 3 && g0 < nk; g0 += gsize) {
@@ -774,11 +780,13 @@ TSFA_DEV void fam_entropy_series(const Blk &b0, XT *xs, int n, const TsfaSpec *s
             }
             blk_sync();
             TSFA_TICK(tk, b, 132);
-            if (FAST || cnt != nullptr) {
+            if (sym) {
+                if constexpr (sizeof(IDX) == 2) {
                 const double *xd = (const double *)(const void *)xs;  // cnt != null implies XT = double
                 if (gn <= 1) entropy_sweep_sym<1>(b, xd, n, gthr, perm, refs, cnt, racc, gidx, gn);
                 else if (gn == 2) entropy_sweep_sym<2>(b, xd, n, gthr, perm, refs, cnt, racc, gidx, gn);
                 else entropy_sweep_sym<3>(b, xd, n, gthr, perm, refs, cnt, racc, gidx, gn);
+                }
             } else if (!FAST) {
                 if (gn <= 1) entropy_sweep_m2<1>(b, xs, n, gthr, perm, racc, gidx, gn);
                 else if (gn <= 2) entropy_sweep_m2<2>(b, xs, n, gthr, perm, racc, gidx, gn);

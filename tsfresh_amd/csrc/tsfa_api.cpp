@@ -793,7 +793,7 @@ static int run_batch(tsfa_plan *plan, const void *d_values, int dtype, const dou
                 if (!(f == TSFA_FAM_ENTROPY && a.ent_cnt == 4)) a.nt = 256;
                 // the long-series build's persistent grid indexes the chirp-z scratch by workgroup: a slot for each, or none
                 if (a.gscratch != nullptr && a.gscratch_slots < std::min<int64_t>(a.n_series, 2048)) a.gscratch = nullptr;
-                if (f == TSFA_FAM_ENTROPY && a.ent_cnt != 4) { a.ent_cnt = 0; a.ent_fast = 0; lds = tsfa_entropy_lds_bytes(maxn, 0); }
+                if (f == TSFA_FAM_ENTROPY && a.ent_cnt != 4) { a.ent_cnt = 0; a.ent_fast = 0; lds = tsfa_entropy_lds_bytes(maxn, 5); }
                 if (f == TSFA_FAM_CWT) { a.cwt_rowv &= 2; lds = tsfa_family_lds_bytes(f, maxn, a.nt, 0); }
                 if (f == TSFA_FAM_SEQ) {
                     seq_group = std::min(a.nspecs, TSFA_LZ_MAX_GROUP);
@@ -942,14 +942,12 @@ static int run_batch(tsfa_plan *plan, const void *d_values, int dtype, const dou
     return TSFA_OK;
 }
 
-// Series of any length extract (beyond a CU's LDS from the long-series build: 32-bit indices, working set in HBM) -- except
-// under sample_entropy / approximate_entropy, whose O(n^2) pair sweep keeps 16-bit sample indices: the reference's own
-// approximate_entropy allocates an n x n x m float64 array there (160 GB at 100 000 samples: MemoryError).
+// Series of any length extract (beyond a CU's LDS from the long-series build: 32-bit indices, working set in HBM) -- since
+// round 6 also under sample_entropy / approximate_entropy: bit-matrix sweeps to 17 408 samples, beyond that the O(n^2) pair
+// sweep of the long-series build with a 32-bit sample order (the reference's own approximate_entropy allocates an n x n x m
+// float64 array there: 160 GB at 100 000 samples, MemoryError; its sample_entropy has no such limit).
 static int check_shape(const tsfa_plan *plan, const BatchShape &sh) {
     if (sh.min_len < 1) return fail(TSFA_ERR_INVALID, "every series must hold at least one sample");
-    if (sh.max_len > 65535 && !plan->fam_specs[TSFA_FAM_ENTROPY].empty())
-        return fail(TSFA_ERR_TOO_LONG, "sample_entropy / approximate_entropy: series longer than 65535 samples are not supported "
-                                       "(O(n^2); every other calculator takes any length)");
     if (sh.max_len > 2147483647LL / 64) return fail(TSFA_ERR_TOO_LONG, "series longer than 33 554 431 samples are not supported");
     return TSFA_OK;
 }

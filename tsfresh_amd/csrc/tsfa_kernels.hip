@@ -395,12 +395,17 @@ __global__ void __launch_bounds__(1024) k_entropy(const T *__restrict__ values, 
     const int64_t off = starts[sidx];
     const int n = (int)(ends[sidx] - off);
     EntropyLds L;
-    L.carve(tsfa_base, maxn, with_cnt);
+#if defined(TSFA_LONG)
+    typedef unsigned int ent_idx;   // the working set lives in HBM: a 32-bit sample order, series of any length
+#else
+    typedef unsigned short ent_idx;
+#endif
+    L.carve(tsfa_base, maxn, with_cnt, (int)sizeof(ent_idx));
     TSFA_TICKS_BEGIN();
     Blk b{(int)threadIdx.x, (int)blockDim.x, L.red, L.np};
     stage_series(b, values + off, n, L.xs);
-    fam_entropy_series<double, FAST, sizeof(T) == 4>(b, L.xs, n, specs, nspecs, out + sidx * ld, L.thr, L.perm, L.refs, L.cnt, 1,
-                                                      stats_in ? stats_in + sidx * TSFA_STATS_N : nullptr);
+    fam_entropy_series<double, FAST, sizeof(T) == 4, ent_idx>(b, L.xs, n, specs, nspecs, out + sidx * ld, L.thr, (ent_idx *)(void *)L.perm,
+                                                               L.refs, L.cnt, 1, stats_in ? stats_in + sidx * TSFA_STATS_N : nullptr);
     TSFA_TICKS_END();
     TSFA_SERIES_END
 }
@@ -1102,7 +1107,11 @@ static int launch_all_t(const TsfaLaunch &a, const T *values) {
         }
 #endif
         EntropyLds L;
+#if defined(TSFA_LONG)
+        const size_t lds = L.carve(nullptr, a.maxn, a.ent_cnt, 4);   // (32-bit sample order: k_entropy above)
+#else
         const size_t lds = L.carve(nullptr, a.maxn, a.ent_cnt);
+#endif
 #if !defined(TSFA_LONG)
         if (a.ent_cnt == 3) {
             auto kfn = k_entropy_bits<T, TSFA_ENTB_QW_LONG>;
@@ -1224,6 +1233,10 @@ int tsfa_launch_langevin_dd(const TsfaLaunch &a) {
 }
 
 size_t tsfa_entropy_lds_bytes(int maxn, int with_cnt) {
+    if (with_cnt == 5) {   // the pair sweep in the long-series build: 32-bit sample order
+        EntropyLds L;
+        return L.carve(nullptr, maxn, 0, 4);
+    }
     if (with_cnt == 4) {   // fam_entropy_hbits.h: the HBM slot of a workgroup (its LDS is entropy_huge_lds_bytes)
         EntropyHugeSlot H;
         return H.carve(nullptr, maxn);

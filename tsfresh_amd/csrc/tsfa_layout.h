@@ -189,16 +189,17 @@ struct ArDdLds {
 
 struct EntropyLds {
     double *red; NpScratch *np; double *xs; double *thr; unsigned short *perm; unsigned int *refs; unsigned int *cnt;
+    // idx_bytes: 2, or 4 for the pair sweep of the long-series build (32-bit sample order: series of any length)
     // with_cnt 1: per-template LDS counters + template references of the symmetric sweep (fam_entropy.h);
     // with_cnt 2: the work region of the bit-matrix sweep (fam_entropy_bits.h) in `cnt`
-    TSFA_HD size_t carve(unsigned char *base, int maxn, int with_cnt) {
+    TSFA_HD size_t carve(unsigned char *base, int maxn, int with_cnt, int idx_bytes = 2) {
         LdsCarve c{base, 0};
         red = c.take<double>(TSFA_RED_DOUBLES);
         thr = c.take<double>(56);
         xs = c.take<double>(maxn + 4);
         const int np2 = tsfa_pow2_ceil(maxn);
         const int nperm = ((np2 > 64) ? np2 : 64) + 32;
-        perm = c.take<unsigned short>(nperm);
+        perm = (unsigned short *)(void *)c.take<unsigned char>((size_t)nperm * (size_t)idx_bytes);
         if (with_cnt == 2 || with_cnt == 3) {  // the numpy-order scratch is dead before the ranges are computed: share its storage
             // (3: the long-series variant -- 16-byte table entries, as many tolerances per round as 16 wavefronts hold)
             refs = nullptr;

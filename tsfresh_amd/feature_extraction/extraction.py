@@ -45,12 +45,11 @@ def _default_device():
 _PLAN_CACHE_SIZE = 6
 _BATCH_KINDS_MAX_SAMPLES = 4_000_000   # kinds sharing a plan are concatenated into one native call up to this size
 _TLS = threading.local()
-# sample_entropy / approximate_entropy are O(n^2): up to this length the bit-matrix sweep keeps a series' working set in a
-# CU's LDS (fam_entropy_bits.h: 13 ms per 100 000 series of 1024 samples, 2.3 ms per 1 000 of 4096); beyond it the pair
-# sweep takes over (profiles/r04_long_entropy.md: 0.18 ms per series at 8192 samples, 0.45 ms at 16 384 with the GPU
-# full -- 2 000 x 16 384 Comprehensive: 0.98 s -- and four times that per doubling) -- the call returns the right values,
-# but these two calculators are then 90 % of its time and the caller should know
-ENTROPY_FAST_MAX_LEN = 4096
+# sample_entropy / approximate_entropy are O(n^2): up to this length the bit-matrix sweeps serve them (fam_entropy_bits.h in LDS
+# to 4096 samples: 12 ms per 100 000 series of 1024; fam_entropy_hbits.h with the per-sample arrays in HBM to 17 408: 50 us per
+# series of 16 384 with the GPU full); beyond it the float64 pair sweep of the long-series build takes over -- the call returns
+# the right values, for any length, but these two calculators are then nearly all of its time and the caller should know
+ENTROPY_FAST_MAX_LEN = 17408
 _QUADRATIC = ("sample_entropy", "approximate_entropy")
 
 
@@ -73,9 +72,9 @@ def _warn_long_entropy(fc_parameters, pk, show_warnings=False):
     if longest > ENTROPY_FAST_MAX_LEN:
         _LONG_ENTROPY_WARNED = True
         warnings.warn("kind {!r}: series of up to {} samples with sample_entropy / approximate_entropy in the settings: these "
-                      "calculators are O(n^2) and beyond {} samples leave the LDS-resident sweep (about 0.5 ms per series at "
-                      "16 384 samples on a full MI355X, four times that per doubling: 90 % of the extraction).  "
-                      "EfficientFCParameters() leaves them out, as the reference recommends for long series.".format(pk.kind, longest, ENTROPY_FAST_MAX_LEN),
+                      "calculators are O(n^2) and beyond {} samples leave the bit-matrix sweeps for a float64 pair sweep (several "
+                      "milliseconds per series at 32 768 samples on a full MI355X, four times that per doubling: nearly all of the "
+                      "extraction).  EfficientFCParameters() leaves them out, as the reference recommends for long series.".format(pk.kind, longest, ENTROPY_FAST_MAX_LEN),
                       UserWarning, stacklevel=3)
 
 
