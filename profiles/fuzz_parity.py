@@ -107,11 +107,11 @@ def random_params(rng):
         "time_reversal_asymmetry_statistic": lambda: {"lag": ri(0, 60)},
         "c3": lambda: {"lag": ri(0, 60)},
         "mean_n_absolute_max": lambda: {"number_of_maxima": ri(1, 400)},
-        "binned_entropy": lambda: {"max_bins": ri(1, 256)},
+        "binned_entropy": lambda: {"max_bins": ri(1, 256) if rng.random() < 0.7 else ri(257, 3000)},
         "approximate_entropy": lambda: {"m": ri(1, 3), "r": rf(0.0, 1.5)},
-        "fourier_entropy": lambda: {"bins": ri(1, 128)},
+        "fourier_entropy": lambda: {"bins": ri(1, 128) if rng.random() < 0.7 else ri(129, 600)},
         "lempel_ziv_complexity": lambda: {"bins": ri(1, 255)},
-        "permutation_entropy": lambda: {"tau": ri(1, 4), "dimension": ri(2, 7)},
+        "permutation_entropy": lambda: {"tau": ri(1, 4), "dimension": ri(2, 10)},
         "autocorrelation": lambda: {"lag": ri(0, 400)},
         "quantile": lambda: {"q": rf(0.0, 1.0)},
         "number_crossing_m": lambda: {"m": rf(-3, 3)},

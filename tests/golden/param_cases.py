@@ -24,9 +24,9 @@ def sweep_parameters():
     p["time_reversal_asymmetry_statistic"] = [{"lag": lag} for lag in (4, 10, 50)]
     p["c3"] = [{"lag": lag} for lag in (4, 9, 40)]
     p["mean_n_absolute_max"] = [{"number_of_maxima": k} for k in (1, 3, 50, 2000)]
-    p["binned_entropy"] = [{"max_bins": k} for k in (2, 7, 50, 256)]   # (the kernels hold at most 256 bins: larger values are refused when the plan is built)
+    p["binned_entropy"] = [{"max_bins": k} for k in (2, 7, 50, 256, 257, 1000)]   # (beyond 256 bins: round 6, the LDS counters are swept in rounds)
     p["approximate_entropy"] = [{"m": 2, "r": r} for r in (0.05, 0.45, 1.3)] + [{"m": 1, "r": 0.2}, {"m": 3, "r": 0.4}]
-    p["fourier_entropy"] = [{"bins": k} for k in (4, 16, 128)]
+    p["fourier_entropy"] = [{"bins": k} for k in (4, 16, 128, 129, 300)]   # (beyond 128: round 6)
     p["lempel_ziv_complexity"] = [{"bins": k} for k in (4, 7, 33, 250)]
     p["autocorrelation"] = [{"lag": lag} for lag in (0, 11, 30, 500)]
     p["quantile"] = [{"q": q} for q in (0.0, 0.05, 0.5, 0.95, 1.0)]

@@ -10,6 +10,10 @@ SETS = {
     "two_dims": {"permutation_entropy": [{"tau": 1, "dimension": 6}, {"tau": 1, "dimension": 2}]},
     "mixed_strides": {"permutation_entropy": [{"tau": 1, "dimension": 3}, {"tau": 2, "dimension": 4}, {"tau": 1, "dimension": 5}]},
     "single": {"permutation_entropy": [{"tau": 1, "dimension": 7}]},
+    # round 6: dimensions beyond the 5 040 patterns an LDS histogram sweeps (sort-and-count of the codes in k_sort)
+    "high": {"permutation_entropy": [{"tau": 1, "dimension": 8}, {"tau": 1, "dimension": 9}, {"tau": 1, "dimension": 10},
+                                     {"tau": 2, "dimension": 8}, {"tau": 5, "dimension": 10}]},
+    "high_beside_the_kernel_of_its_own": {"permutation_entropy": [{"tau": 1, "dimension": d} for d in (3, 4, 5, 6, 7, 8, 10)]},
 }
 
 

@@ -543,7 +543,7 @@ static inline std::string tsfa_validate_spec(const TsfaSpec &s) {
     case TSFA_C_QUANTILE: if (!(p[0] >= 0 && p[0] <= 1)) return "quantile: q must be in [0, 1]"; break;
     case TSFA_C_PERMUTATION_ENTROPY:
         if (!(is_int(p[0]) && p[0] >= 1)) return "permutation_entropy: tau must be >= 1";
-        if (!(is_int(p[1]) && p[1] >= 2 && p[1] <= 7)) return "permutation_entropy: dimension must be in [2, 7]";
+        if (!(is_int(p[1]) && p[1] >= 2 && p[1] <= 10)) return "permutation_entropy: dimension must be in [2, 10]";   // (8 .. 10: sort-and-count of the pattern codes, fam_sort.h)
         break;
     case TSFA_C_FRIEDRICH_COEFFICIENTS:
         if (!(is_int(p[1]) && p[1] >= 1 && p[1] <= 3)) return "friedrich_coefficients: m must be in [1, 3]";
