@@ -22,6 +22,7 @@
 #include "../../tsfresh_amd/csrc/fam_perm.h"
 #include "../../tsfresh_amd/csrc/fam_seq.h"
 #include "../../tsfresh_amd/csrc/fam_sort.h"
+#include "../../tsfresh_amd/csrc/fam_general.h"
 #include "../../tsfresh_amd/csrc/fam_spectral.h"
 #include "../../tsfresh_amd/csrc/tsfa_host_tables.h"
 #include "../../tsfresh_amd/csrc/tsfa_layout.h"
@@ -79,7 +80,9 @@ extern "C" int tsfa_emul_extract(const tsfa_feature_spec *specs, int n_specs, co
 extern "C" int tsfa_emul_extract_timed(const tsfa_feature_spec *specs, int n_specs, const double *values,
                                        const double *times, const int64_t *offsets, int64_t n_series, double *out,
                                        int64_t ld, char *err, int errlen) {
-    std::vector<TsfaSpec> fam[TSFA_N_FAMILIES], cwt_coef;
+    std::vector<TsfaSpec> fam[TSFA_N_FAMILIES], cwt_coef, gen;
+    bool general[TSFA_N_CALCS];
+    tsfa_general_calcs(specs, n_specs, general);
     for (int i = 0; i < n_specs; ++i) {
         TsfaSpec s;
         s.calc = specs[i].calc;
@@ -95,6 +98,7 @@ extern "C" int tsfa_emul_extract_timed(const tsfa_feature_spec *specs, int n_spe
             return TSFA_ERR_UNSUPPORTED;
         }
         if (s.calc == TSFA_C_CWT_COEFFICIENTS) cwt_coef.push_back(s);
+        else if (general[s.calc]) gen.push_back(s);
         else fam[tsfa_calc_table[s.calc].family].push_back(s);
     }
     {
@@ -209,11 +213,15 @@ extern "C" int tsfa_emul_extract_timed(const tsfa_feature_spec *specs, int n_spe
                                 chirp_tab.data(), emul_bluestein_pack());
         }
         if (!fam[TSFA_FAM_AR].empty()) {
-            int P = 8;
+            int P = 8, Pdd = 8;
             for (const auto &sp : fam[TSFA_FAM_AR]) {
                 if (sp.calc == TSFA_C_AUGMENTED_DICKEY_FULLER) P = std::max(P, adf_maxlag_for(maxn) + 3);
-                else if (sp.calc == TSFA_C_AR_COEFFICIENT) P = std::max(P, (int)sp.p[1] + 2);
+                else if (sp.calc == TSFA_C_AR_COEFFICIENT) {
+                    if ((int)sp.p[1] <= TSFA_AR_TABLE_K) P = std::max(P, (int)sp.p[1] + 2);
+                    Pdd = std::max(Pdd, std::min((int)sp.p[1], std::max(1, (maxn - 2) / 2)) + 2);
+                }
             }
+            Pdd = std::max(Pdd, P);
             std::vector<double> xc(maxn + TSFA_AR_PADL + TSFA_AR_PADR, TSFA_NAN), aw(ArLds::scratch_doubles(P));
             poison(xc); poison(aw);
             const double *xp = xs.data();
@@ -221,9 +229,9 @@ extern "C" int tsfa_emul_extract_timed(const tsfa_feature_spec *specs, int n_spe
                           (int)fam[TSFA_FAM_AR].size(), row, (void *)xc.data(), aw.data(), P, hints[TSFA_FAM_AR].a,
                           hints[TSFA_FAM_AR].b, hints[TSFA_FAM_AR].c, (s % 2) ? -1 : hints[TSFA_FAM_AR].d);
             if (flags) {  // the second pass of the family (k_ar_degenerate)
-                std::vector<double> sc(ArDdLds::scratch_doubles(P), TSFA_NAN);  // poisoned: LDS is not zero-initialised on the device
+                std::vector<double> sc(ArDdLds::scratch_doubles(Pdd), TSFA_NAN);  // poisoned: LDS is not zero-initialised on the device
                 fam_ar_degenerate_series(b, [=](int i) { return xp[i]; }, n, fam[TSFA_FAM_AR].data(),
-                                         (int)fam[TSFA_FAM_AR].size(), row, sc.data(), P, flags, (hints[TSFA_FAM_AR].c >> 1) & 3);
+                                         (int)fam[TSFA_FAM_AR].size(), row, sc.data(), Pdd, flags, (hints[TSFA_FAM_AR].c >> 1) & 3);
             }
         }
         if (!fam[TSFA_FAM_ENTROPY].empty()) {
@@ -295,6 +303,15 @@ extern "C" int tsfa_emul_extract_timed(const tsfa_feature_spec *specs, int n_spe
             const double *xp = xs.data();
             fam_cwtpeaks_series<double>(b, [=](int i) { return xp[i]; }, n, fam[TSFA_FAM_CWT].data(), (int)fam[TSFA_FAM_CWT].size(),
                                 row, L.p);
+        }
+        if (!gen.empty()) {   // k_general: a slot sized for the longest series of the call, poisoned
+            const TsfaGenPlan gp = tsfa_prepare_general(gen);
+            GenSlot S;
+            std::vector<double> slot(S.carve(nullptr, call_maxn, gp) + 8);
+            poison(slot);
+            S.carve(slot.data(), call_maxn, gp);
+            const double *xp = xs.data();
+            fam_general_series(b, [=](int i) { return xp[i]; }, n, gen.data(), (int)gen.size(), row, S, gp);
         }
         for (int c = 0; c < bank.C; ++c) {  // plain-loop stand-in for k_cwt_gemm
             double acc = 0.0;

@@ -2,7 +2,7 @@
 run through the REAL reference code (feature_calculators.py read from /root/reference) with the REAL libraries of
 the second interpreter of the build container:
 
-    /opt/conda/bin/python3.9 tests/golden/gen_golden_conda.py [--set S] [--params sweep | adf]
+    /opt/conda/bin/python3.9 tests/golden/gen_golden_conda.py [--set S] [--params sweep | beyond | adf]
         numpy 1.26.4, scipy 1.7.1, pandas 2.3.3, pywt 1.1.1, statsmodels 0.12.2
 
 statsmodels 0.12.2 does not import against that numpy/pandas as shipped (np.MachAr and pd.Int64Index are gone);
@@ -59,6 +59,10 @@ def main():
     if sweep:   # parameters away from the Comprehensive grids (param_cases.py) -> ref_conda_sweep.npz
         from param_cases import sweep_parameters
         full = sweep_parameters()
+    beyond = "--params" in sys.argv and sys.argv[sys.argv.index("--params") + 1] == "beyond"
+    if beyond:  # values beyond the tuned kernels' tables -> ref_conda_beyond.npz
+        from param_cases import beyond_parameters
+        full = beyond_parameters()
     adf = "--params" in sys.argv and sys.argv[sys.argv.index("--params") + 1] == "adf"
     if adf:     # the other lag selections of adfuller -> ref_conda_*_adf.npz (one fixture per autolag value: a plan holds one)
         from param_cases import adf_autolag_parameters
@@ -74,7 +78,7 @@ def main():
         rows.append([float(r[2]) for r in res])
     values, offsets = pack(cases)
     extra = {}
-    if sweep:
+    if sweep or beyond:
         # Singular values of every AR(k) design [1, x[t-1] .. x[t-k]] AS THIS INTERPRETER'S LAPACK RETURNS THEM: the
         # reference's pinv cuts at 1e-15 s_max, and for an exactly rank-deficient design (a constant series) whether a
         # direction that does not exist comes back above that cut is round-off of the LAPACK build -- tests/parity.py R4
@@ -90,7 +94,7 @@ def main():
                 X = np.column_stack([np.ones(n - k)] + [x[tt - j] for j in range(1, k + 1)])
                 sv[i] = np.linalg.svd(X, compute_uv=False)
             extra["ar_sv_k%d" % k] = sv
-    out = os.path.join(HERE, ("ref_conda.npz" if case_set == "main" else "ref_conda_%s.npz" % case_set).replace(".npz", "_sweep.npz" if sweep else "_adf.npz" if adf else ".npz"))
+    out = os.path.join(HERE, ("ref_conda.npz" if case_set == "main" else "ref_conda_%s.npz" % case_set).replace(".npz", "_sweep.npz" if sweep else "_beyond.npz" if beyond else "_adf.npz" if adf else ".npz"))
     np.savez_compressed(out, values=values, offsets=offsets, labels=np.array([c[0] for c in cases]),
                         names=np.array(names), matrix=np.asarray(rows, dtype=np.float64), **extra,
                         versions=np.array(["numpy " + np.__version__, "pandas " + pd.__version__,

@@ -11,6 +11,7 @@ removed from the FCParameters and covered by gen_golden_conda.py instead.  Every
     python tests/golden/gen_golden_main.py --set degenerate             # ref_main_degenerate.npz
     python tests/golden/gen_golden_main.py [--set S] --nosimd           # ref_main[_S]_nosimd.npz
     python tests/golden/gen_golden_main.py --params sweep               # ref_main_sweep.npz (param_cases.py)
+    python tests/golden/gen_golden_main.py --params beyond              # ref_main_beyond.npz (param_cases.beyond_parameters)
 
 --nosimd re-executes the interpreter with NPY_DISABLE_CPU_FEATURES set, so numpy's runtime dispatch falls back to its
 scalar loops.  It exists for ONE calculator: permutation_entropy ranks every window with np.argsort's default kind
@@ -70,6 +71,10 @@ def main():
     if sweep:   # parameters away from the Comprehensive grids (param_cases.py) -> ref_main_sweep.npz
         from param_cases import sweep_parameters
         params = sweep_parameters()
+    beyond = "--params" in sys.argv and sys.argv[sys.argv.index("--params") + 1] == "beyond"
+    if beyond:  # values beyond the tuned kernels' tables (param_cases.beyond_parameters) -> ref_main_beyond.npz
+        from param_cases import beyond_parameters
+        params = beyond_parameters()
     full_names = {}
     for cls in ("ComprehensiveFCParameters", "EfficientFCParameters", "MinimalFCParameters"):
         p = getattr(ref_settings, cls)()
@@ -78,8 +83,8 @@ def main():
         full_names[cls] = [r[1] for r in res]
         full_names[cls + "_keys"] = list(p.keys())
     for k in NEED_THIRD_PARTY:
-        del params[k]
-    if sweep:
+        params.pop(k, None)
+    if sweep or beyond:
         full_names = {}
     names, rows = None, []
     with warnings.catch_warnings():
@@ -92,7 +97,7 @@ def main():
             assert cols == names
             rows.append([float(r[2]) for r in res])
     values, offsets = pack(cases)
-    suffix = ("" if case_set == "main" else "_" + case_set) + ("_sweep" if sweep else "") + ("_nosimd" if NOSIMD else "")
+    suffix = ("" if case_set == "main" else "_" + case_set) + ("_sweep" if sweep else "_beyond" if beyond else "") + ("_nosimd" if NOSIMD else "")
     out = os.path.join(HERE, "ref_main%s.npz" % suffix)
     np.savez_compressed(
         out, values=values, offsets=offsets, labels=np.array([c[0] for c in cases]), names=np.array(names),

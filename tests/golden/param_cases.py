@@ -53,6 +53,24 @@ def sweep_parameters():
     return p
 
 
+def beyond_parameters():
+    """Values BEYOND the tables of the tuned kernels (round 6; tsfa_host_tables.h: tsfa_spec_beyond_tables): until then the
+    library refused such a plan, now the calculators holding one are served by k_general (fam_general.h) -- ALL their columns,
+    the in-table ones included -- and ar_coefficient orders above 31 by the double-double second pass (fam_ar_dd.h).
+    `--params beyond` of both generators -> ref_main*_beyond.npz / ref_conda*_beyond.npz."""
+    p = {}
+    p["lempel_ziv_complexity"] = [{"bins": k} for k in (3, 256, 1000, 70000)]
+    p["friedrich_coefficients"] = ([{"coeff": c, "m": 5, "r": 30} for c in range(6)] + [{"coeff": c, "m": 3, "r": 100} for c in range(4)] +
+                                   [{"coeff": c, "m": 1, "r": 65} for c in range(2)] + [{"coeff": 1, "m": 2, "r": 10}])
+    p["max_langevin_fixed_point"] = [{"m": 3, "r": 100}, {"m": 5, "r": 30}, {"m": 4, "r": 20}, {"m": 3, "r": 30}]
+    p["number_cwt_peaks"] = [{"n": n} for n in (2, 17, 30)]
+    # --- statsmodels (second interpreter) ---
+    p["agg_autocorrelation"] = [{"f_agg": f, "maxlag": m} for f in ("mean", "median", "var") for m in (5, 61, 200, 5000)]
+    p["partial_autocorrelation"] = [{"lag": lag} for lag in (0, 3, 41, 100, 700)]
+    p["ar_coefficient"] = [{"coeff": c, "k": k} for k in (32, 50) for c in (0, 1, k, k + 1)] + [{"coeff": 2, "k": 5}]
+    return p
+
+
 THIRD_PARTY = ("cwt_coefficients", "agg_autocorrelation", "partial_autocorrelation", "augmented_dickey_fuller", "ar_coefficient")
 
 

@@ -39,6 +39,11 @@ EXTRA = {
     "offset_sweep": ("ref_main_offset_sweep.npz", "ref_conda_offset_sweep.npz", True),
     # ... and on the 1025 .. 8192-sample series: lags, peak supports and coefficient indices that only exist there
     "long_sweep": ("ref_main_long_sweep.npz", "ref_conda_long_sweep.npz", True),
+    # param_cases.beyond_parameters: values beyond the tuned kernels' tables (k_general, AR orders of the second pass alone)
+    "beyond": ("ref_main_beyond.npz", "ref_conda_beyond.npz", True),
+    "degenerate_beyond": ("ref_main_degenerate_beyond.npz", "ref_conda_degenerate_beyond.npz", True),
+    "offset_beyond": ("ref_main_offset_beyond.npz", "ref_conda_offset_beyond.npz", True),
+    "long_beyond": ("ref_main_long_beyond.npz", "ref_conda_long_beyond.npz", True),
 }
 
 

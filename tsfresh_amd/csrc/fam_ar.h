@@ -803,8 +803,13 @@ TSFA_DEV int fam_ar_series(const Blk &b, X xv, int n, const TsfaSpec *specs, int
             if (coeff > k) { v = TSFA_NAN; break; }
             // AutoReg(x, lags=k, trend="c") can only be estimated with n >= 2k + 2; on failure the reference
             // substitutes [nan]*k, so coeff < k -> NaN and coeff == k -> IndexError -> 0
-            if (n < 2 * k + 2 || k + 2 > P || k < 1 || k + 1 > 40) {
+            if (n < 2 * k + 2 || k < 1) {
                 v = (coeff < k) ? TSFA_NAN : 0.0;
+                break;
+            }
+            if (k > TSFA_AR_TABLE_K || k + 2 > P) {   // beyond the float64 pass's matrices: every such fit in the second pass (fam_ar_dd.h)
+                degenerate |= 1;
+                v = TSFA_NAN;
                 break;
             }
             if (ar_cached_k != k) {
@@ -931,8 +936,8 @@ TSFA_DEV int fam_ar_series(const Blk &b, X xv, int n, const TsfaSpec *specs, int
             } else if (sp.calc == TSFA_C_AR_COEFFICIENT) {
                 const int coeff = (int)sp.p[0], k = (int)sp.p[1];
                 if (coeff > k) v = TSFA_NAN;
-                else if (n < 2 * k + 2 || k + 2 > P || k < 1 || k + 1 > 40) v = (coeff < k) ? TSFA_NAN : 0.0;
-                else v = (ar_cached_k == k && ar_ok) ? arres[coeff] : TSFA_NAN;
+                else if (n < 2 * k + 2 || k < 1) v = (coeff < k) ? TSFA_NAN : 0.0;
+                else v = (ar_cached_k == k && ar_ok && k <= TSFA_AR_TABLE_K) ? arres[coeff] : TSFA_NAN;
             }
             out_row[sp.col] = v;
         }

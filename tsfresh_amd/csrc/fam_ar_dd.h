@@ -661,7 +661,7 @@ TSFA_DEV void fam_ar_degenerate_series(const Blk &b, X xv, int n, const TsfaSpec
             const TsfaSpec sp = specs[s];
             if (sp.calc != TSFA_C_AR_COEFFICIENT) continue;
             const int coeff = (int)sp.p[0], k = (int)sp.p[1];
-            if (coeff > k || n < 2 * k + 2 || k + 2 > P || k < 1 || k + 1 > 40) continue;  // the first pass's answer stands
+            if (coeff > k || n < 2 * k + 2 || k + 2 > P || k < 1) continue;  // the first pass's answer stands
             if (done_k != k) {
                 const int p = k + 1;
                 auto build_ar = [&](double sh) {   // Gram matrix and rhs of [1, x'[t-1..t-k]] -> x'[t], x' = x - sh

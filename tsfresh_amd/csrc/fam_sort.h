@@ -283,26 +283,19 @@ TSFA_DEV double fx_value(long long hi, long long lo, FxScale f) {
     return s3 + (e3 + (e2 + e));
 }
 
-// fc.py:131 _estimate_friedrich_coefficients(x, m, r) -> coeff[0..m] (highest power first), NaN on failure.
-//   srt1  : functor, the first n-1 samples sorted ascending (signal = x[:-1])
-//   fw    : LDS double scratch >= 6*r + 16 + (r)*(m+1)
-// every thread returns the coefficients in `coef`; an ill-conditioned fit is ALSO recorded in df for the second pass,
-// which overwrites the columns this one wrote (fam_langevin_dd.h)
+// The quantile bins of fc.py:131-160 -- pd.qcut(x[:-1], r), then per bin the sums of x[t] and of x[t + 1] - x[t] and the count:
+//   fw[r + 1 ..) = sum x per bin (r), sum delta per bin (r), count per bin (r) as float64; fw[0 .. r] = the bin edges.
+//   fw: >= 6 r + 2 doubles (any pointer: LDS in k_sort, an HBM slot in k_general).  Any r.
+// Returns false (uniformly) when the series is too short or the bin edges are not unique (qcut raises, the reference returns NaN).
 template <class XS, class S1>
-TSFA_DEV void friedrich_coeffs(const Blk &b, XS xs, int n, S1 srt1, int m, int r,
-                               double *fw, double *coef, const FrDefer &df) {
-    for (int k = 0; k <= m; ++k) coef[k] = TSFA_NAN;
+TSFA_DEV bool friedrich_bin_means(const Blk &b, XS xs, int n, S1 srt1, int r, double *fw) {
     const int ns = n - 1;
-    if (ns < 1 || r < 1 || r > TSFA_FRIEDRICH_MAX_R || m < 1 || m > TSFA_FRIEDRICH_MAX_M) return;
+    if (ns < 1 || r < 1) return false;
     double *edges = fw;                 // r + 1
     double *sx = fw + (r + 1);          // r
     double *sy = sx + r;                // r
     double *cnt = sy + r;               // r
-    double *flag = cnt + r;             // 1
-    double *A = flag + 1;               // r * (m+1)   (the low parts of the bin sums live here until the means exist)
-    double *yv = A + r * (m + 1);       // r
-    double *cc = yv + r;                // m + 1
-    double *tmp = cc + (m + 1);         // r
+    double *lows = cnt + r + 1;         // 2 r: the low parts of the bin sums, until the float64 sums exist
     blk_sync();
     // pd.qcut(signal, r): edges = signal.quantile(np.linspace(0, 1, r + 1))
     for (int j = b.tid; j <= r; j += b.nt) {
@@ -310,14 +303,13 @@ TSFA_DEV void friedrich_coeffs(const Blk &b, XS xs, int n, S1 srt1, int m, int r
         edges[j] = pd_quantile_sorted(srt1, ns, q);
     }
     long long *isx = (long long *)(void *)sx, *isy = (long long *)(void *)sy, *icnt = (long long *)(void *)cnt,
-              *isxl = (long long *)(void *)A, *isyl = isxl + r;
+              *isxl = (long long *)(void *)lows, *isyl = isxl + r;
     for (int j = b.tid; j < r; j += b.nt) { isx[j] = 0; isy[j] = 0; icnt[j] = 0; isxl[j] = 0; isyl[j] = 0; }
-    if (b.tid == 0) flag[0] = 0.0;
     blk_sync();
     double bad = 0.0;
     for (int j = b.tid; j < r; j += b.nt) bad += (edges[j] < edges[j + 1]) ? 0.0 : 1.0;  // "Bin edges must be unique"
     bad = blk_sum(b, bad);
-    if (bad > 0.0) return;
+    if (bad > 0.0) return false;
     // bin index = #{edges < x} - 1, with x == edges[0] -> bin 0  (pandas _bins_to_cuts, right=True, include_lowest)
     {
         double amax = fmax(fabs(srt1(0)), fabs(srt1(ns - 1)));
@@ -357,6 +349,31 @@ TSFA_DEV void friedrich_coeffs(const Blk &b, XS xs, int n, S1 srt1, int m, int r
         }
         blk_sync();
     }
+    return true;
+}
+
+// fc.py:131 _estimate_friedrich_coefficients(x, m, r) -> coeff[0..m] (highest power first), NaN on failure.
+//   srt1  : functor, the first n-1 samples sorted ascending (signal = x[:-1])
+//   fw    : LDS double scratch >= 6*r + 16 + (r)*(m+1)
+// every thread returns the coefficients in `coef`; an ill-conditioned fit is ALSO recorded in df for the second pass,
+// which overwrites the columns this one wrote (fam_langevin_dd.h)
+template <class XS, class S1>
+TSFA_DEV void friedrich_coeffs(const Blk &b, XS xs, int n, S1 srt1, int m, int r,
+                               double *fw, double *coef, const FrDefer &df) {
+    for (int k = 0; k <= m; ++k) coef[k] = TSFA_NAN;
+    const int ns = n - 1;
+    if (ns < 1 || r < 1 || r > TSFA_FRIEDRICH_MAX_R || m < 1 || m > TSFA_FRIEDRICH_MAX_M) return;
+    double *sx = fw + (r + 1);          // r
+    double *sy = sx + r;                // r
+    double *cnt = sy + r;               // r
+    double *flag = cnt + r;             // 1
+    double *A = flag + 1;               // r * (m+1)   (the low parts of the bin sums live here until the means exist)
+    double *yv = A + r * (m + 1);       // r
+    double *cc = yv + r;                // m + 1
+    double *tmp = cc + (m + 1);         // r
+    if (!friedrich_bin_means(b, xs, n, srt1, r, fw)) return;
+    if (b.tid == 0) flag[0] = 0.0;
+    blk_sync();
     const int rmax = (df.slot_doubles - TSFA_PF_HDR) / 2;
 #if TSFA_GPU
     // np.polyfit(x_mean, y_mean, deg=m): scaled Vandermonde + least squares.  The r <= 64 bins are the lanes of

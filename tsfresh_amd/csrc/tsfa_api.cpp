@@ -116,7 +116,11 @@ struct tsfa_plan {
     int *d_cols = nullptr, *d_coeff = nullptr;
     double *d_dectab = nullptr, *d_twc = nullptr, *d_tws = nullptr, *d_consts = nullptr;
     long long *d_stats = nullptr;
-    DevBuf values, offsets, out, gscratch, times, deg_list, sel, long_scratch, pf_buf, perm_buf, stats_buf, dd_scratch;
+    DevBuf values, offsets, out, gscratch, times, deg_list, sel, long_scratch, pf_buf, perm_buf, stats_buf, dd_scratch, gen_scratch;
+    // k_general (fam_general.h): the columns of the calculators whose parameters lie beyond the tuned kernels' tables
+    std::vector<TsfaSpec> gen_specs;
+    TsfaSpec *d_gen_specs = nullptr;
+    TsfaGenPlan gen_plan;
     int *d_deg_count = nullptr;
     int *d_cursor = nullptr;                    // per-launch-group fill cursors (k_class_fill)
     hipStream_t s_in = nullptr, s_out = nullptr;  // copy-in / copy-out streams of the host pipeline
@@ -228,6 +232,8 @@ void tsfa_plan_destroy(tsfa_plan *plan) {
     plan->out.release();
     plan->gscratch.release();
     plan->dd_scratch.release();
+    plan->gen_scratch.release();
+    if (plan->d_gen_specs) (void)hipFree(plan->d_gen_specs);
     for (auto &t : plan->timings) {
         if (t.e0) (void)hipEventDestroy(t.e0);
         if (t.e1) (void)hipEventDestroy(t.e1);
@@ -256,6 +262,8 @@ int tsfa_plan_create(const tsfa_feature_spec *specs, int32_t n_specs, int32_t de
     plan->device = device;
     plan->n_cols = n_specs;
     std::vector<TsfaSpec> cwt_coef;
+    bool general[TSFA_N_CALCS];
+    tsfa_general_calcs(specs, n_specs, general);
     for (int i = 0; i < n_specs; ++i) {
         TsfaSpec s;
         s.calc = specs[i].calc;
@@ -272,8 +280,10 @@ int tsfa_plan_create(const tsfa_feature_spec *specs, int32_t n_specs, int32_t de
         }
         if (s.calc == TSFA_C_LINEAR_TREND_TIMEWISE) plan->needs_times = true;
         if (s.calc == TSFA_C_CWT_COEFFICIENTS) cwt_coef.push_back(s);
+        else if (general[s.calc]) plan->gen_specs.push_back(s);
         else plan->fam_specs[tsfa_calc_table[s.calc].family].push_back(s);
     }
+    plan->gen_plan = tsfa_prepare_general(plan->gen_specs);
     if (cwt_coef.size() > 128) {
         delete plan;
         return fail(TSFA_ERR_UNSUPPORTED, "more than 128 cwt_coefficients columns in one plan");
@@ -310,6 +320,7 @@ int tsfa_plan_create(const tsfa_feature_spec *specs, int32_t n_specs, int32_t de
         if (sp.calc != TSFA_C_MEDIAN) plan->stream_ok = false;
     bool ok = hipStreamCreateWithFlags(&plan->stream, hipStreamNonBlocking) == hipSuccess;
     for (int f = 0; ok && f < TSFA_N_FAMILIES; ++f) ok = upload(plan->fam_specs[f], &plan->d_specs[f]) == 0;
+    if (ok) ok = upload(plan->gen_specs, &plan->d_gen_specs) == 0;
     if (ok && !cwt_coef.empty()) {
         ok = upload(plan->bank.W, &plan->d_W) == 0 && upload(plan->bank.cols, &plan->d_cols) == 0 &&
              upload(plan->bank.coeff_idx, &plan->d_coeff) == 0;
@@ -682,24 +693,29 @@ static int run_batch(tsfa_plan *plan, const void *d_values, int dtype, const dou
                 if (plan->opt.cwt_mfma) a.cwt_rowv |= 2;
             } else if (f == TSFA_FAM_AR) {
                 // leading dimension of the normal matrices: ADF needs maxlag(n) + 3, AR(k) needs k + 2
-                int P = 8;
+                int P = 8, Pdd = 8;   // (Pdd: ar_coefficient orders beyond TSFA_AR_TABLE_K are fitted by the second pass alone)
                 for (const auto &s : plan->fam_specs[f]) {
                     if (s.calc == TSFA_C_AUGMENTED_DICKEY_FULLER) {
                         int ml = (int)ceil(12.0 * pow((double)maxn / 100.0, 0.25));
                         if (maxn / 2 - 2 < ml) ml = maxn / 2 - 2;
                         P = std::max(P, ml + 3);
                     } else if (s.calc == TSFA_C_AR_COEFFICIENT) {
-                        P = std::max(P, (int)s.p[1] + 2);
+                        const int k = std::min((int)s.p[1], std::max(1, (maxn - 2) / 2));   // (n < 2 k + 2: no fit, fc.py:1497)
+                        if ((int)s.p[1] <= TSFA_AR_TABLE_K) P = std::max(P, (int)s.p[1] + 2);
+                        Pdd = std::max(Pdd, k + 2);
                         a.ar_has_coef = 1;
                     }
                 }
+                Pdd = std::max(Pdd, P);
                 a.ar_P = P;
+                a.ar_P_dd = Pdd;
                 aux = P;
                 {   // second pass (k_ar_degenerate): double-double normal equations in LDS up to P = 64 (65 535 samples), HBM beyond
                     ArDdLds D;
-                    if (D.carve(nullptr, P) > TSFA_LDS_LIMIT - 2048) {
-                        const int slots = (int)std::min<int64_t>(a.n_series, 256);
-                        if (plan->dd_scratch.ensure((size_t)slots * (size_t)ArDdLds::scratch_doubles(P) * sizeof(double)))
+                    if (D.carve(nullptr, Pdd) > TSFA_LDS_LIMIT - 2048) {
+                        const size_t slot_bytes = (size_t)ArDdLds::scratch_doubles(Pdd) * sizeof(double);
+                        const int slots = (int)std::min<int64_t>(a.n_series, std::min<int64_t>(256, std::max<int64_t>(8, (int64_t)(((size_t)2 << 30) / slot_bytes))));
+                        if (plan->dd_scratch.ensure((size_t)slots * slot_bytes))
                             return fail(TSFA_ERR_HIP, "hipMalloc failed for the second AR pass");
                         a.dd_scratch = (double *)plan->dd_scratch.p;
                         a.dd_slots = slots;
@@ -936,6 +952,36 @@ static int run_batch(tsfa_plan *plan, const void *d_values, int dtype, const dou
         const int rc = tsfa_launch_cwt(c);
         if (rc) return fail(TSFA_ERR_HIP, "k_cwt_gemm launch failed");
         if (record(plan, st, slot, "k_cwt_gemm", false)) return fail(TSFA_ERR_HIP, "event record failed");
+        ++slot;
+    }
+    if (!plan->gen_specs.empty()) {
+        // one launch over every series of the batch, a slot of HBM scratch per resident workgroup (at most 1 GB in all)
+        const int maxn = (int)sh.max_len;
+        const size_t slot_doubles = tsfa_general_slot_doubles(maxn, plan->gen_plan) + 8;
+        int slots = (int)std::min<int64_t>(n_series, 2048);
+        const size_t budget = (size_t)1 << 30;
+        if ((size_t)slots * slot_doubles * sizeof(double) > budget)
+            slots = (int)std::max<size_t>(16, budget / (slot_doubles * sizeof(double)));
+        slots = (int)std::min<int64_t>(slots, n_series);
+        if (plan->gen_scratch.ensure((size_t)slots * slot_doubles * sizeof(double)))
+            return fail(TSFA_ERR_HIP, "hipMalloc failed for the scratch of k_general");
+        TsfaLaunch a;
+        memset(&a, 0, sizeof a);
+        a.dtype = dtype;
+        a.values = d_values;
+        a.starts = d_starts;
+        a.ends = d_ends;
+        a.n_series = n_series;
+        a.specs = plan->d_gen_specs;
+        a.nspecs = (int)plan->gen_specs.size();
+        a.out = d_out;
+        a.ld = ld;
+        a.maxn = maxn;
+        a.stream = st;
+        if (record(plan, st, slot, "k_general", true)) return fail(TSFA_ERR_HIP, "event record failed");
+        if (tsfa_launch_general(a, plan->gen_plan, (double *)plan->gen_scratch.p, slot_doubles, slots))
+            return fail(TSFA_ERR_HIP, "k_general launch failed");
+        if (record(plan, st, slot, "k_general", false)) return fail(TSFA_ERR_HIP, "event record failed");
         ++slot;
     }
     if (plan->profiling) plan->timings.resize(slot);

@@ -133,7 +133,11 @@ struct Ticker {
 TSFA_DEV void blk_sync() {
 #if TSFA_GPU
 #if defined(TSFA_LONG)
-    __syncthreads();  // the working set lives in HBM scratch: the barrier must order global memory too
+    // the working set lives in HBM scratch: the barrier must order global memory too.  The explicit wait is for the
+    // one-wavefront workgroups (k_general): there the compiler drops __syncthreads() to a "wave barrier" with no
+    // s_waitcnt at all, and a lane's load can pass the store of another lane of the same wavefront.
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    __syncthreads();
 #else
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
 #endif
@@ -142,6 +146,7 @@ TSFA_DEV void blk_sync() {
 // Barrier that also orders global memory within the workgroup (scratch in HBM).
 TSFA_DEV void blk_sync_all() {
 #if TSFA_GPU
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
     __syncthreads();
 #endif
 }

@@ -514,6 +514,58 @@ static inline std::string tsfa_validate_plan(const TsfaSpec *specs, int n) {
 }
 
 // validate one spec; returns "" if it can be evaluated natively, else the reason
+// ---- parameter values beyond the tables of the tuned kernels (fam_general.h) ----
+#define TSFA_GEN_MAX_M 60      // friedrich / Langevin polynomial degree (x^m of a float64 design; the reference's own fit is noise long before)
+#define TSFA_AR_MAX_K 1024     // ar_coefficient order (the normal equations of the double-double pass: (k + 2)^2 entries)
+#define TSFA_CWTP_TABLE_N 16   // number_cwt_peaks widths 1 .. n of k_cwtpeaks
+// does this column ask the tuned kernel of its calculator for more than its tables hold?
+static inline bool tsfa_spec_beyond_tables(const TsfaSpec &s) {
+    const double *p = s.p;
+    switch (s.calc) {
+    case TSFA_C_AGG_AUTOCORRELATION: return p[1] > 60;
+    case TSFA_C_PARTIAL_AUTOCORRELATION: return p[0] > 40;
+    case TSFA_C_FRIEDRICH_COEFFICIENTS: return p[1] > 3 || p[2] > 64;
+    case TSFA_C_MAX_LANGEVIN_FIXED_POINT: return p[0] > 3 || p[1] > 64;
+    case TSFA_C_LEMPEL_ZIV_COMPLEXITY: return p[0] > 255;
+    case TSFA_C_NUMBER_CWT_PEAKS: return p[0] > TSFA_CWTP_TABLE_N;
+    default: return false;
+    }
+}
+// general[c] = calculator c of this plan goes to k_general -- ALL its columns: the reference's combiners read the largest value
+// of the dict (agg_autocorrelation fc.py:428, partial_autocorrelation fc.py:470), and one route per calculator keeps a column's
+// value independent of which other columns of OTHER calculators the plan holds.  friedrich_coefficients and
+// max_langevin_fixed_point share their fits and move together.
+template <class SPEC>
+static inline void tsfa_general_calcs(const SPEC *specs, int n, bool *general) {
+    for (int c = 0; c < TSFA_N_CALCS; ++c) general[c] = false;
+    for (int i = 0; i < n; ++i) {
+        TsfaSpec s;
+        s.calc = specs[i].calc;
+        s.col = 0;
+        for (int k = 0; k < 4; ++k) s.p[k] = specs[i].p[k];
+        if (s.calc >= 0 && s.calc < TSFA_N_CALCS && tsfa_spec_beyond_tables(s)) general[s.calc] = true;
+    }
+    if (general[TSFA_C_FRIEDRICH_COEFFICIENTS] || general[TSFA_C_MAX_LANGEVIN_FIXED_POINT])
+        general[TSFA_C_FRIEDRICH_COEFFICIENTS] = general[TSFA_C_MAX_LANGEVIN_FIXED_POINT] = true;
+}
+
+static inline TsfaGenPlan tsfa_prepare_general(const std::vector<TsfaSpec> &specs) {
+    TsfaGenPlan g;
+    g.acf_maxlag = -1; g.pacf_maxlag = -1; g.fr_maxr = 0; g.fr_maxm = 0; g.lz = 0; g.cwt_maxw = 0;
+    for (const auto &s : specs) {
+        switch (s.calc) {
+        case TSFA_C_AGG_AUTOCORRELATION: g.acf_maxlag = std::max(g.acf_maxlag, (int)s.p[1]); break;
+        case TSFA_C_PARTIAL_AUTOCORRELATION: g.pacf_maxlag = std::max(g.pacf_maxlag, (int)s.p[0]); break;
+        case TSFA_C_FRIEDRICH_COEFFICIENTS: g.fr_maxm = std::max(g.fr_maxm, (int)s.p[1]); g.fr_maxr = std::max(g.fr_maxr, (int)s.p[2]); break;
+        case TSFA_C_MAX_LANGEVIN_FIXED_POINT: g.fr_maxm = std::max(g.fr_maxm, (int)s.p[0]); g.fr_maxr = std::max(g.fr_maxr, (int)s.p[1]); break;
+        case TSFA_C_LEMPEL_ZIV_COMPLEXITY: g.lz = 1; break;
+        case TSFA_C_NUMBER_CWT_PEAKS: g.cwt_maxw = std::max(g.cwt_maxw, (int)s.p[0]); break;
+        default: break;
+        }
+    }
+    return g;
+}
+
 static inline std::string tsfa_validate_spec(const TsfaSpec &s) {
     const double *p = s.p;
     auto is_int = [](double v) { return v == floor(v); };
@@ -521,7 +573,7 @@ static inline std::string tsfa_validate_spec(const TsfaSpec &s) {
     case TSFA_C_NUMBER_PEAKS: if (!(is_int(p[0]) && p[0] >= 1)) return "number_peaks: n must be an integer >= 1"; break;
     case TSFA_C_BINNED_ENTROPY: if (!(is_int(p[0]) && p[0] >= 1 && p[0] <= 1048576)) return "binned_entropy: max_bins must be in [1, 1048576]"; break;   // (beyond 256 bins: counted in rounds of 256)
     case TSFA_C_FOURIER_ENTROPY: if (!(is_int(p[0]) && p[0] >= 1 && p[0] <= 1048576)) return "fourier_entropy: bins must be in [1, 1048576]"; break;   // (beyond 128 bins: rounds of 128)
-    case TSFA_C_LEMPEL_ZIV_COMPLEXITY: if (!(is_int(p[0]) && p[0] >= 1 && p[0] <= 255)) return "lempel_ziv_complexity: bins must be in [1, 255]"; break;
+    case TSFA_C_LEMPEL_ZIV_COMPLEXITY: if (!(is_int(p[0]) && p[0] >= 1 && p[0] <= 1073741824.0)) return "lempel_ziv_complexity: bins must be in [1, 2^30]"; break;   // (beyond 255: fam_general.h)
     case TSFA_C_ENERGY_RATIO_BY_CHUNKS:
         if (!(is_int(p[0]) && is_int(p[1]) && p[0] > 0 && p[1] >= 0 && p[1] < p[0])) return "energy_ratio_by_chunks: need 0 <= segment_focus < num_segments";
         break;
@@ -546,13 +598,13 @@ static inline std::string tsfa_validate_spec(const TsfaSpec &s) {
         if (!(is_int(p[1]) && p[1] >= 2 && p[1] <= 10)) return "permutation_entropy: dimension must be in [2, 10]";   // (8 .. 10: sort-and-count of the pattern codes, fam_sort.h)
         break;
     case TSFA_C_FRIEDRICH_COEFFICIENTS:
-        if (!(is_int(p[1]) && p[1] >= 1 && p[1] <= 3)) return "friedrich_coefficients: m must be in [1, 3]";
-        if (!(is_int(p[2]) && p[2] >= 1 && p[2] <= 64)) return "friedrich_coefficients: r must be in [1, 64]";
+        if (!(is_int(p[1]) && p[1] >= 1 && p[1] <= TSFA_GEN_MAX_M)) return "friedrich_coefficients: m must be in [1, 60]";   // (m > 3, r > 64: fam_general.h; x^61 overflows float64 long before)
+        if (!(is_int(p[2]) && p[2] >= 1 && p[2] <= 1048576)) return "friedrich_coefficients: r must be in [1, 1048576]";
         if (!(is_int(p[0]) && p[0] >= 0)) return "friedrich_coefficients: coeff must be >= 0";
         break;
     case TSFA_C_MAX_LANGEVIN_FIXED_POINT:
-        if (!(is_int(p[0]) && p[0] >= 1 && p[0] <= 3)) return "max_langevin_fixed_point: m must be in [1, 3]";
-        if (!(is_int(p[1]) && p[1] >= 1 && p[1] <= 64)) return "max_langevin_fixed_point: r must be in [1, 64]";
+        if (!(is_int(p[0]) && p[0] >= 1 && p[0] <= TSFA_GEN_MAX_M)) return "max_langevin_fixed_point: m must be in [1, 60]";
+        if (!(is_int(p[1]) && p[1] >= 1 && p[1] <= 1048576)) return "max_langevin_fixed_point: r must be in [1, 1048576]";
         break;
     case TSFA_C_FFT_COEFFICIENT:
         if (!(is_int(p[0]) && p[0] >= 0)) return "fft_coefficient: coeff must be >= 0";
@@ -562,12 +614,12 @@ static inline std::string tsfa_validate_spec(const TsfaSpec &s) {
     case TSFA_C_SPKT_WELCH_DENSITY: if (!(is_int(p[0]) && p[0] >= 0)) return "spkt_welch_density: coeff must be >= 0"; break;
     case TSFA_C_AGG_AUTOCORRELATION:
         if (!(p[0] == TSFA_AGG_MEAN || p[0] == TSFA_AGG_MEDIAN || p[0] == TSFA_AGG_VAR)) return "agg_autocorrelation: f_agg must be mean/median/var";
-        if (!(is_int(p[1]) && p[1] >= 1 && p[1] <= 60)) return "agg_autocorrelation: maxlag must be in [1, 60]";
+        if (!(is_int(p[1]) && p[1] >= 1 && p[1] <= 2147483647.0)) return "agg_autocorrelation: maxlag must be a positive integer";   // (beyond 60: fam_general.h)
         break;
-    case TSFA_C_PARTIAL_AUTOCORRELATION: if (!(is_int(p[0]) && p[0] >= 0 && p[0] <= 40)) return "partial_autocorrelation: lag must be in [0, 40]"; break;
+    case TSFA_C_PARTIAL_AUTOCORRELATION: if (!(is_int(p[0]) && p[0] >= 0 && p[0] <= 2147483647.0)) return "partial_autocorrelation: lag must be a non-negative integer"; break;   // (beyond 40: fam_general.h)
     case TSFA_C_AR_COEFFICIENT:
         if (!(is_int(p[0]) && p[0] >= 0)) return "ar_coefficient: coeff must be >= 0";
-        if (!(is_int(p[1]) && p[1] >= 1 && p[1] <= 31)) return "ar_coefficient: k must be in [1, 31]";
+        if (!(is_int(p[1]) && p[1] >= 1 && p[1] <= TSFA_AR_MAX_K)) return "ar_coefficient: k must be in [1, 1024]";   // (beyond 31: every series through the double-double pass, fam_ar_dd.h)
         break;
     case TSFA_C_AUGMENTED_DICKEY_FULLER:
         if (!(is_int(p[0]) && p[0] >= 0 && p[0] <= 3)) return "augmented_dickey_fuller: unknown attr code";   // (3: a name the reference answers with NaN, fc.py:543)
@@ -577,7 +629,7 @@ static inline std::string tsfa_validate_spec(const TsfaSpec &s) {
         if (!(is_int(p[0]) && p[0] >= 1)) return "approximate_entropy: m must be >= 1";
         if (!(p[1] >= 0)) return "approximate_entropy: Parameter r must be positive.";
         break;
-    case TSFA_C_NUMBER_CWT_PEAKS: if (!(is_int(p[0]) && p[0] >= 1 && p[0] <= 16)) return "number_cwt_peaks: n must be in [1, 16]"; break;
+    case TSFA_C_NUMBER_CWT_PEAKS: if (!(is_int(p[0]) && p[0] >= 1 && p[0] <= 65536)) return "number_cwt_peaks: n must be in [1, 65536]"; break;   // (beyond 16: fam_general.h)
     default: break;
     }
     return "";

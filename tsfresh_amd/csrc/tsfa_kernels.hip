@@ -10,6 +10,7 @@
 #include "fam_perm.h"
 #include "fam_sort.h"
 #include "fam_spectral.h"
+#include "fam_general.h"
 #include "tsfa_launch.h"
 #include "tsfa_layout.h"
 
@@ -1197,6 +1198,45 @@ int tsfa_launch_family_long(const TsfaLaunch &a) {
     if (a.dtype == 0) return launch_all_t<float>(a, (const float *)a.values);
     return launch_all_t<double>(a, (const double *)a.values);
 }
+
+// k_general (fam_general.h): the calculators of a plan whose parameters lie beyond the tuned kernels' tables.  One wavefront
+// per series on a persistent grid, the series read where it lies, every working array in the workgroup's slot of HBM scratch
+// (this translation unit's blk_sync orders global memory).
+template <typename T>
+__global__ void __launch_bounds__(64) k_general(const T *__restrict__ values, const int64_t *__restrict__ starts, const int64_t *__restrict__ ends,
+                                               int64_t n_series, const TsfaSpec *__restrict__ specs, int nspecs, double *__restrict__ out, int64_t ld,
+                                               int maxn, const TsfaGenPlan g, double *__restrict__ scratch, size_t slot_doubles) {
+    __shared__ double red[TSFA_RED_DOUBLES];
+    __shared__ NpScratch nps;
+    Blk b{(int)threadIdx.x, (int)blockDim.x, red, &nps};
+    GenSlot S;
+    S.carve(scratch + (size_t)blockIdx.x * slot_doubles, maxn, g);
+    for (int64_t sidx = blockIdx.x; sidx < n_series; sidx += gridDim.x) {
+        const int64_t off = starts[sidx];
+        const int n = (int)(ends[sidx] - off);
+        const T *gv = values + off;
+        fam_general_series(b, [=](int i) { return (double)gv[i]; }, n, specs, nspecs, out + sidx * ld, S, g);
+        __syncthreads();
+    }
+}
+
+size_t tsfa_general_slot_doubles(int maxn, const TsfaGenPlan &g) {
+    GenSlot S;
+    return S.carve(nullptr, maxn, g);
+}
+
+int tsfa_launch_general(const TsfaLaunch &a, const TsfaGenPlan &g, double *scratch, size_t slot_doubles, int slots) {
+    hipStream_t st = (hipStream_t)a.stream;
+    const unsigned grid = (unsigned)std::max<int64_t>(1, std::min<int64_t>(a.n_series, slots));
+    if (a.dtype == 0)
+        k_general<float><<<grid, 64, 0, st>>>((const float *)a.values, a.starts, a.ends, a.n_series, a.specs, a.nspecs, a.out, a.ld, a.maxn, g,
+                                              scratch, slot_doubles);
+    else
+        k_general<double><<<grid, 64, 0, st>>>((const double *)a.values, a.starts, a.ends, a.n_series, a.specs, a.nspecs, a.out, a.ld, a.maxn, g,
+                                               scratch, slot_doubles);
+    TSFA_LAUNCH_CHECK();
+    return 0;
+}
 #else
 // second pass of the AR family over the series k_ar listed (after tsfa_launch_family / _long of TSFA_FAM_AR)
 template <typename T>
@@ -1204,14 +1244,15 @@ static int launch_ar_degenerate_t(const TsfaLaunch &a, const T *values) {
     hipStream_t st = (hipStream_t)a.stream;
     int rc;
     ArDdLds D;
-    size_t dlds = D.carve(nullptr, a.ar_P);
+    const int P = a.ar_P_dd > 0 ? a.ar_P_dd : a.ar_P;
+    size_t dlds = D.carve(nullptr, P);
     unsigned dgrid = (unsigned)std::min<int64_t>(a.n_series, 4096);
     if (a.dd_scratch != nullptr) {   // the plan found the matrices too large for LDS (tsfa_api.cpp): one HBM slot per workgroup
         dlds = (size_t)TSFA_RED_DOUBLES * sizeof(double) + 64;
         dgrid = (unsigned)std::max<int64_t>(1, std::min<int64_t>(a.n_series, a.dd_slots));
     }
     if ((rc = set_lds(k_ar_degenerate<T>, dlds))) return rc;
-    k_ar_degenerate<T><<<dgrid, 64, dlds, st>>>(values, a.starts, a.ends, a.specs, a.nspecs, a.out, a.ld, a.ar_P, a.deg_list,
+    k_ar_degenerate<T><<<dgrid, 64, dlds, st>>>(values, a.starts, a.ends, a.specs, a.nspecs, a.out, a.ld, P, a.deg_list,
                                                 a.deg_count, (a.hint_c >> 1) & 3, a.dd_scratch);
     TSFA_LAUNCH_CHECK();
     return 0;

@@ -52,6 +52,7 @@ struct TsfaLaunch {
     int gscratch_n;
     TsfaSeqGroup seq;       // SEQ: the (<= TSFA_LZ_MAX_GROUP) specs this launch parses side by side
     int ar_P;               // AR: leading dimension of the normal matrices
+    int ar_P_dd;            // ... and of the second pass's (ar_coefficient orders beyond the first pass's table live only there)
     double *dd_scratch;     // AR second pass: HBM slots for double-double matrices beyond LDS (or null), dd_slots of them
     int dd_slots;
     int ar_has_coef;        // AR: the plan holds ar_coefficient columns
@@ -96,6 +97,9 @@ size_t tsfa_seq_lds_bytes(const TsfaSeqGroup &g);
 int tsfa_launch_family(const TsfaLaunch &a);
 int tsfa_launch_rows(const TsfaLaunch &a);          // BASIC / TREND: the series of at most TSFA_ROW_MAXN samples, four per wavefront (k_basic_rows / k_trend_rows)
 int tsfa_launch_family_long(const TsfaLaunch &a);   // working set in a.long_scratch instead of LDS (any length <= 65535)
+// k_general (fam_general.h): a.specs / a.nspecs = the plan's GENERAL columns, every series of the batch in one launch
+size_t tsfa_general_slot_doubles(int maxn, const TsfaGenPlan &g);
+int tsfa_launch_general(const TsfaLaunch &a, const TsfaGenPlan &g, double *scratch, size_t slot_doubles, int slots);
 int tsfa_launch_ar_degenerate(const TsfaLaunch &a);
 int tsfa_launch_langevin_dd(const TsfaLaunch &a);     // second pass of TSFA_FAM_SORT: the ill-conditioned Langevin fits k_sort recorded
 int tsfa_launch_perm(const TsfaLaunch &a);            // beside TSFA_FAM_SORT: every permutation_entropy column (k_perm, fam_perm.h); a.hint_d = (stride << 8) | dimensions, a.nt threads

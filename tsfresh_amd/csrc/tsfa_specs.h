@@ -166,6 +166,20 @@ struct TsfaCqPlan {
     double qh[TSFA_CQ_MAX];
 };
 
+// what the plan's GENERAL specs (fam_general.h: parameter values beyond the tuned kernels' tables) ask for at most
+// (tsfa_host_tables.h: tsfa_prepare_general); by-value kernel argument
+struct TsfaGenPlan {
+    int acf_maxlag;    // largest agg_autocorrelation maxlag (-1: none)
+    int pacf_maxlag;   // largest partial_autocorrelation lag (-1: none)
+    int fr_maxr;       // largest r of a friedrich_coefficients / max_langevin_fixed_point column (0: none)
+    int fr_maxm;       // ... and the largest m
+    int lz;            // lempel_ziv_complexity columns
+    int cwt_maxw;      // largest n of a number_cwt_peaks column (0: none)
+};
+
+#define TSFA_AR_TABLE_K 31   // ar_coefficient orders of k_ar's float64 first pass (fam_ar.h: arres, 40 doubles); larger ones are fitted
+                             // by the double-double second pass alone (fam_ar_dd.h: any order)
+
 // device-side spec: one output column
 struct TsfaSpec {
     int32_t calc;
