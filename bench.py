@@ -280,6 +280,9 @@ def main():
                          "second leg (~4 min of wall clock) instead of one run (~1 min): profiles/r04_z_bench.json was taken so")
     ap.add_argument("--cpu-workers", type=int, default=0, help="worker processes of the CPU baseline (default: every physical core)")
     ap.add_argument("--no-e2e", action="store_true", help="skip the host-buffer / DataFrame boundary timings")
+    ap.add_argument("--plan-option", action="append", default=[], metavar="NAME=VALUE",
+                    help="tsfa_plan_set_option on every plan of the run (A/B of an alternative route to the same numbers, e.g. "
+                         "seq_rows=0); recorded in config.plan_options.  The default line sets none")
     ap.add_argument("--plan-only", action="store_true",
                     help="print the shard layout of the job as JSON (rows and sum(len^2) per rank, exchange form) and exit: no GPU")
     ap.add_argument("--chunks", type=int, default=0,
@@ -386,6 +389,10 @@ def main():
     n_chunks = max(1, min(n_chunks, n))
     pipe = ShardPipeline(fplan.native_specs(_native.calc_id), n_cols, local_rank, dist=dist, n_chunks=n_chunks,
                          length_hint=None if args.ragged else (L, L))  # equal lengths, known up front: no length scan
+    plan_options = {kv.split("=", 1)[0]: float(kv.split("=", 1)[1]) for kv in args.plan_option}
+    for pl in pipe.plans:
+        for name, value in plan_options.items():
+            pl.set_option(name, value)
     plan = pipe.plans[0]
     counts = layout["counts"] if layout is not None else [n] * world
     row0 = [int(v) for v in np.concatenate([[0], np.cumsum(counts)])]
@@ -521,6 +528,8 @@ def main():
                        "row_chunks_per_step": n_chunks},
             "kernel_ms": kt, "outputs_finite": finite, "roofline": roof,
         }
+        if plan_options:
+            line["config"]["plan_options"] = plan_options
         if multi is None and dist is not None:   # a world of one through the distributed code path
             multi = {"world": dist.get_world_size(), "ranks_seen_by_rccl": ranks_seen, "row_chunks": n_chunks}
         if multi is not None:

@@ -154,6 +154,7 @@ int32_t tsfa_plan_last_timings(const tsfa_plan *plan, const char **names, float 
  *   "entropy_route"  0|1|2 bit-matrix sweep | windowed pair sweep | general kernel
  *   "force_long"     0|1   the HBM-scratch build of the family kernels whatever the length
  *   "row_form"       0|1   BASIC / TREND columns of series of <= 256 samples four series to a wavefront (1)
+ *   "seq_rows"       -1|0|1 lempel_ziv_complexity's symbol rows in LDS (0), in HBM (1), or in HBM where that puts more series on a CU (-1, default)
  *   "host_chunks"    n     row chunks of the TSFA_HOST pipeline (0: by batch size)
  *   "fill" v / "fill_off"  pre-fill the result matrix with v before the kernels run (audits: every cell is written anyway)
  * plan == NULL: library-wide options ("relevance_batch" n: columns per sort batch of tsfa_relevance_*).

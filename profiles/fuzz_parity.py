@@ -3,7 +3,8 @@
 order of appearance is the reference's dict order) on random ragged batches of mixed structured / random series, HIP
 path against the oracle.    python profiles/fuzz_parity.py [rounds] [seed]
 TSFA_FUZZ_ENGINE=emul runs the g++ build of the kernel sources instead (no GPU needed).
-TSFA_FUZZ_PARAMS=random draws every parameter at random inside the range the kernels serve instead of
+TSFA_FUZZ_PARAMS=random draws every parameter at random inside the range the kernels serve (since round 6 also beyond the tuned
+kernels' tables: k_general, the double-double AR pass) instead of
 from the Comprehensive grids: lags, chunk lengths, bin counts and coefficient indices beyond the series length included."""
 import os
 import sys
@@ -99,7 +100,7 @@ def random_params(rng):
         "fft_aggregated": lambda: {"aggtype": str(rng.choice(["centroid", "variance", "skew", "kurtosis"]))},
         "number_peaks": lambda: {"n": ri(1, 70)},
         "index_mass_quantile": lambda: {"q": rf(0.0, 1.0)},
-        "number_cwt_peaks": lambda: {"n": ri(1, 16)},
+        "number_cwt_peaks": lambda: {"n": ri(1, 16) if rng.random() < 0.7 else ri(17, 24)},   # (beyond 16: k_general, round 6)
         "linear_trend": lambda: {"attr": str(rng.choice(["pvalue", "rvalue", "intercept", "slope", "stderr"]))},
         "spkt_welch_density": lambda: {"coeff": ri(0, 200)},
         "change_quantiles": lambda: (lambda a, b: {"ql": min(a, b), "qh": max(a, b), "isabs": bool(rng.integers(0, 2)),
@@ -110,23 +111,24 @@ def random_params(rng):
         "binned_entropy": lambda: {"max_bins": ri(1, 256) if rng.random() < 0.7 else ri(257, 3000)},
         "approximate_entropy": lambda: {"m": ri(1, 3), "r": rf(0.0, 1.5)},
         "fourier_entropy": lambda: {"bins": ri(1, 128) if rng.random() < 0.7 else ri(129, 600)},
-        "lempel_ziv_complexity": lambda: {"bins": ri(1, 255)},
+        "lempel_ziv_complexity": lambda: {"bins": ri(1, 255) if rng.random() < 0.7 else int(rng.choice([256, 300, 1000, 5000, 70000]))},
         "permutation_entropy": lambda: {"tau": ri(1, 4), "dimension": ri(2, 10)},
         "autocorrelation": lambda: {"lag": ri(0, 400)},
         "quantile": lambda: {"q": rf(0.0, 1.0)},
         "number_crossing_m": lambda: {"m": rf(-3, 3)},
         "value_count": lambda: {"value": float(rng.integers(-3, 4)) * 0.25},
         "range_count": lambda: {"min": rf(-2, 1), "max": rf(-1, 2)},
-        "friedrich_coefficients": lambda: (lambda m: {"coeff": ri(0, m), "m": m, "r": ri(2, 64)})(ri(1, 3)),
-        "max_langevin_fixed_point": lambda: {"m": ri(1, 3), "r": ri(2, 64)},
+        "friedrich_coefficients": lambda: (lambda m: {"coeff": ri(0, m), "m": m, "r": ri(2, 64) if rng.random() < 0.7 else ri(65, 150)})(
+            ri(1, 3) if rng.random() < 0.7 else ri(4, 6)),
+        "max_langevin_fixed_point": lambda: {"m": ri(1, 3) if rng.random() < 0.7 else ri(4, 6), "r": ri(2, 64) if rng.random() < 0.7 else ri(65, 150)},
         "agg_linear_trend": lambda: {"attr": str(rng.choice(["rvalue", "intercept", "slope", "stderr"])), "chunk_len": ri(1, 120),
                                      "f_agg": str(rng.choice(["max", "min", "mean", "var"]))},
         "energy_ratio_by_chunks": lambda: (lambda k: {"num_segments": k, "segment_focus": ri(0, k - 1)})(ri(1, 20)),
         "count_above": lambda: {"t": rf(-2, 2)},
         "count_below": lambda: {"t": rf(-2, 2)},
-        "agg_autocorrelation": lambda: {"f_agg": str(rng.choice(["mean", "median", "var"])), "maxlag": ri(1, 60)},
-        "partial_autocorrelation": lambda: {"lag": ri(0, 40)},
-        "ar_coefficient": lambda: (lambda k: {"coeff": ri(0, k + 1), "k": k})(ri(1, 31)),
+        "agg_autocorrelation": lambda: {"f_agg": str(rng.choice(["mean", "median", "var"])), "maxlag": ri(1, 60) if rng.random() < 0.7 else ri(61, 400)},
+        "partial_autocorrelation": lambda: {"lag": ri(0, 40) if rng.random() < 0.7 else ri(41, 200)},
+        "ar_coefficient": lambda: (lambda k: {"coeff": ri(0, k + 1), "k": k})(ri(1, 31) if rng.random() < 0.8 else ri(32, 60)),
         "cwt_coefficients": lambda: (lambda ws: {"widths": ws, "coeff": ri(0, 40), "w": int(rng.choice(ws))})(
             tuple(sorted(set(int(v) for v in rng.integers(1, 24, size=ri(1, 4)))))),
     }

@@ -283,12 +283,17 @@ extern "C" int tsfa_emul_extract_timed(const tsfa_feature_spec *specs, int n_spe
             const double *xp = xs.data();
             for (int s0 = 0; s0 < nsq; s0 += group) {
                 TsfaSeqGroup g;
-                lz_build_group(fam[TSFA_FAM_SEQ].data() + s0, std::min(group, nsq - s0), maxn, &g);
-                std::vector<uint32_t> seqw(((size_t)g.stride + 16) / 4 + 1), tab((size_t)g.ttotal + 4);
+                const int grows = (s % 2 == 1) ? 1 : 0;  // exercise both homes of the symbol rows (LDS: packed; HBM: a byte per symbol)
+                lz_build_group(fam[TSFA_FAM_SEQ].data() + s0, std::min(group, nsq - s0), maxn, &g, grows);
+                std::vector<uint32_t> seqw(((size_t)g.stride + 16) / 4 + 8), tab((size_t)g.ttotal + 4);
                 std::vector<double> edges(g.etotal + 4);
                 poison_int(seqw); poison_int(tab); poison(edges);
-                fam_seq_series(b, [=](int i) { return xp[i]; }, n, g, row, (unsigned char *)seqw.data(), tab.data(),
-                               edges.data());
+                unsigned char *seqp = (unsigned char *)seqw.data();
+                seqp += (16 - ((uintptr_t)seqp & 15)) & 15;
+                if (grows)
+                    fam_seq_series<true>(b, [=](int i) { return xp[i]; }, n, g, row, seqp, tab.data(), edges.data());
+                else
+                    fam_seq_series<false>(b, [=](int i) { return xp[i]; }, n, g, row, seqp, tab.data(), edges.data());
             }
         }
         if (!fam[TSFA_FAM_CWT].empty()) {

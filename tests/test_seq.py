@@ -65,3 +65,21 @@ def test_lempel_ziv_forms_equal_the_oracle_on_the_device(gpu, params, dtype, mon
         _, one = hip_engine(params, s.astype(dtype), np.array([0, len(s)], dtype=np.int64))
         _, ow = oracle_engine(params, s, np.array([0, len(s)], dtype=np.int64))
         np.testing.assert_array_equal(one, ow)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("params", [BINS, WIDE], ids=["comprehensive_bins", "wide_groups"])
+def test_symbol_rows_in_hbm_and_in_lds_give_the_same_counts(gpu, params):
+    """Round 6: k_seq<T, true> keeps the symbol rows in HBM (a byte per symbol, read three 16-byte blocks ahead of the chain)
+    so that LDS holds the tables alone; the library takes that form where it puts more series on a CU (long series).  Both
+    forms on every stress input, and on 4096 .. 8192-sample series where the HBM form is the default."""
+    from engines import hip_engine
+    rng = np.random.default_rng(5)
+    series = lz_series() + [rng.standard_normal(n) for n in (4096, 5000, 8191, 8192)] + [np.cumsum(rng.standard_normal(6000))]
+    values = np.concatenate(series)
+    offsets = np.concatenate([[0], np.cumsum([len(s) for s in series])]).astype(np.int64)
+    _, want = oracle_engine(params, values, offsets)
+    for rows in (0, 1, -1):
+        _, got = hip_engine(params, values, offsets, options={"seq_rows": rows})
+        np.testing.assert_array_equal(got, want, err_msg="seq_rows=%d" % rows)
+

@@ -81,12 +81,15 @@ TSFA_SEQ_HD LzTable lz_table_plan(int bins, int n) {
         int D = 1;
         while ((nodes + pw * bins) * bins <= TSFA_LZ_BITS_MAX && pw < (long long)P) { pw *= bins; nodes += pw; ++D; }
         const int deep = n / (D + 1);
-        int cap = 16, lg = 4;
-        while (17LL * cap < 20LL * deep + 20) { cap <<= 1; ++lg; }  // load factor <= 0.85: probing only costs the rare deep steps
+        // load factor <= 0.85 (probing only costs the rare deep steps), and not a slot more: the slot of a key is
+        // mulhi(hash, cap), any cap -- a power of two rounded 3212 slots up to 4096 at 8192 samples of 100 bins, and the
+        // family is bound by (series resident per CU) x (latency of a step)
+        int cap = (int)((20LL * deep + 20 + 16) / 17);
+        if (cap < 16) cap = 16;
         t.mode = TSFA_LZ_BITS;
         t.nbt = (int)nodes;
         t.cap = cap;
-        t.lg = lg;
+        t.lg = 0;
         t.words = (int)((nodes * bins + 31) / 32) + 1 + cap;  // + one dummy word (lanes that are in the hashed part)
     } else {
         int cap = 16, lg = 4;
@@ -122,9 +125,13 @@ struct TsfaSeqGroup {
     int toff[TSFA_LZ_MAX_GROUP];      // table offset in uint32 words
     int eoff[TSFA_LZ_MAX_GROUP];      // edge offset in doubles
     int col[TSFA_LZ_MAX_GROUP];       // output column
+    int grows;                        // the symbol rows live in HBM (one byte per symbol, 16-byte aligned rows): lz_parse_bits<true>
 };
-inline void lz_build_group(const TsfaSpec *specs, int nb, int maxn, TsfaSeqGroup *g) {
+// bytes of one symbol row in HBM: whole 16-byte blocks + the three blocks the parse reads ahead
+TSFA_SEQ_HD int lz_grow_bytes(int maxn) { return ((maxn + 15) & ~15) + 64; }
+inline void lz_build_group(const TsfaSpec *specs, int nb, int maxn, TsfaSeqGroup *g, int grows = 0) {
     g->nb = nb;
+    g->grows = grows;
     int sbytes = 0;
     // chains with direct tables first: they share a wavefront (lane = chain), the hashed ones share another
     int order[TSFA_LZ_MAX_GROUP], no = 0;
@@ -146,9 +153,12 @@ inline void lz_build_group(const TsfaSpec *specs, int nb, int maxn, TsfaSeqGroup
         g->toff[k] = t;
         g->eoff[k] = e;
         g->col[k] = sp ? sp->col : 0;
-        g->sbits[k] = (lt.mode == TSFA_LZ_BITS && bins <= 16) ? 4 : 8;
+        g->sbits[k] = (!grows && lt.mode == TSFA_LZ_BITS && bins <= 16) ? 4 : 8;
         g->soff[k] = sbytes;
-        if (k < nb) { t += lt.words; e += bins; sbytes += (g->sbits[k] == 4) ? lz_seq_stride((maxn + 1) / 2) : lz_seq_stride(maxn); }
+        if (k < nb) {
+            t += lt.words; e += bins;
+            sbytes += grows ? lz_grow_bytes(maxn) : (g->sbits[k] == 4) ? lz_seq_stride((maxn + 1) / 2) : lz_seq_stride(maxn);
+        }
     }
     g->stride = sbytes;
     g->ttotal = t;
@@ -222,9 +232,11 @@ TSFA_DEV int lz_parse_hash(const unsigned char *sq, int n, int cap, int lg, uint
 #if TSFA_GPU
 TSFA_DEV uint32_t lz_mad24(uint32_t a, uint32_t b, uint32_t c) { return __umul24(a, b) + c; }  // v_mad_u32_u24 (full rate)
 TSFA_DEV uint32_t lz_bit(uint32_t word, uint32_t pos) { return __builtin_amdgcn_ubfe(word, pos, 1u); }
+TSFA_DEV uint32_t lz_slot(uint32_t key, uint32_t cap) { return __umulhi(key * 2654435761u, cap); }
 #else
 TSFA_DEV uint32_t lz_mad24(uint32_t a, uint32_t b, uint32_t c) { return a * b + c; }
 TSFA_DEV uint32_t lz_bit(uint32_t word, uint32_t pos) { return (word >> pos) & 1u; }
+TSFA_DEV uint32_t lz_slot(uint32_t key, uint32_t cap) { return (uint32_t)(((unsigned long long)(key * 2654435761u) * cap) >> 32); }
 #endif
 
 // One symbol of a TSFA_LZ_BITS chain.  The dependent chain per symbol is what bounds the kernel (one lane per chain,
@@ -233,8 +245,7 @@ TSFA_DEV uint32_t lz_bit(uint32_t word, uint32_t pos) { return (word >> pos) & 1
 // the next node is child * seen instead of compare + select.
 struct LzBits {
     uint32_t *tb, *hb;
-    uint32_t ub, unb, dummy, hbase, mask;
-    int sh;
+    uint32_t ub, unb, dummy, hbase, cap;
 };
 TSFA_DEV void lz_bits_step(const LzBits &L, uint32_t sym, uint32_t &node, int &count) {
     const bool deep = (node >= L.unb);
@@ -251,10 +262,10 @@ TSFA_DEV void lz_bits_step(const LzBits &L, uint32_t sym, uint32_t &node, int &c
     {
         if (deep) {
             const uint32_t key = ((node << 8) | sym) + 1u;  // non-zero
-            uint32_t h = (key * 2654435761u) >> L.sh;
+            uint32_t h = lz_slot(key, L.cap);
             uint32_t cur = L.hb[h];
             while (cur != key && cur != 0u) {
-                h = (h + 1u) & L.mask;
+                h = (h + 1u == L.cap) ? 0u : h + 1u;
                 cur = L.hb[h];
             }
             seen = (cur == 0u) ? 0u : 1u;
@@ -268,7 +279,12 @@ TSFA_DEV void lz_bits_step(const LzBits &L, uint32_t sym, uint32_t &node, int &c
 
 // Parse with the implicit shallow trie (bit table) + a hash table for the deep phrases (TSFA_LZ_BITS).
 // tb: [ceil(nbt * bins / 32) words of child bits][dummy word][cap hash slots]
+// GROWS: the row lies in HBM, a byte per symbol (TsfaSeqGroup::grows) -- read 16 symbols at a time, three reads ahead of the
+// chain (a step is ~250 cycles, a miss to HBM ~5 000)
+struct LzU4 { uint32_t x, y, z, w; };
+template <bool GROWS = false>
 TSFA_DEV int lz_parse_bits(const unsigned char *sq, int n, int bins, int nbt, int cap, int lg, uint32_t *tb, int sbits) {
+    (void)lg;
     int count = 0;
     uint32_t node = 0u;
     const uint32_t *sw = (const uint32_t *)(const void *)sq;
@@ -283,8 +299,24 @@ TSFA_DEV int lz_parse_bits(const unsigned char *sq, int n, int bins, int nbt, in
     L.hb = tb + nbw + 1u;
     L.dummy = nbw << 5;
     L.hbase = L.dummy + 32u;  // ids of hashed nodes start above every table index (and above the dummy's)
-    L.mask = (uint32_t)cap - 1u;
-    L.sh = 32 - lg;
+    L.cap = (uint32_t)cap;
+    if (GROWS) {
+        const LzU4 *sv = (const LzU4 *)(const void *)sq;
+        LzU4 q0 = sv[0], q1 = sv[1], q2 = sv[2];
+        int pos = 0, vi = 0;
+        for (; pos + 16 <= n; pos += 16, ++vi) {
+            const LzU4 cur = q0;
+            q0 = q1; q1 = q2; q2 = sv[vi + 3];   // (the row is padded by three blocks)
+            const uint32_t wd[4] = {cur.x, cur.y, cur.z, cur.w};
+#pragma unroll
+            for (int k = 0; k < 16; ++k) lz_bits_step(L, (wd[k >> 2] >> (8 * (k & 3))) & 255u, node, count);
+        }
+        if (pos < n) {
+            const uint32_t wd[4] = {q0.x, q0.y, q0.z, q0.w};
+            for (int k = 0; pos + k < n; ++k) lz_bits_step(L, (wd[k >> 2] >> (8 * (k & 3))) & 255u, node, count);
+        }
+        return count;
+    }
     uint32_t wa = sw[0], wb = sw[1];
     int pos = 0;
     for (; pos + 8 <= n; pos += 8) {  // full groups: no per-symbol bounds
@@ -318,7 +350,8 @@ TSFA_DEV int lz_parse_bits(const unsigned char *sq, int n, int bins, int nbt, in
 //   seq    : LDS bytes,   >= g.stride, 4-byte aligned
 //   tab    : LDS uint32,  >= g.ttotal
 //   edges  : LDS doubles, >= g.etotal
-template <class X>
+//   GROWS  : seq points into HBM (g.grows: a byte per symbol, rows of lz_grow_bytes), a slot of g.stride bytes of this workgroup
+template <bool GROWS = false, class X>
 TSFA_DEV void fam_seq_series(const Blk &b, X xv, int n, const TsfaSeqGroup &g, double *out_row, unsigned char *seq,
                              uint32_t *tab, double *edges, const double *stats = nullptr) {
     TSFA_TICKER(tk, 0);
@@ -364,7 +397,9 @@ TSFA_DEV void fam_seq_series(const Blk &b, X xv, int n, const TsfaSeqGroup &g, d
                 if (lo1 < hi1) { const int mid = (lo1 + hi1) >> 1; if (ed[mid] < x1) lo1 = mid + 1; else hi1 = mid; }
             }
             unsigned char *row = seq + g.soff[t];
-            if (g.sbits[t] == 4) {
+            if (GROWS) {   // i is even, the row 16-byte aligned: one 16-bit store (the byte behind an odd n is padding)
+                *(unsigned short *)(void *)(row + i) = (unsigned short)(lo0 | (two ? (lo1 << 8) : 0));
+            } else if (g.sbits[t] == 4) {
                 row[i >> 1] = (unsigned char)(lo0 | (two ? (lo1 << 4) : 0));
             } else {
                 row[i] = (unsigned char)lo0;
@@ -372,7 +407,8 @@ TSFA_DEV void fam_seq_series(const Blk &b, X xv, int n, const TsfaSeqGroup &g, d
             }
         }
     }
-    blk_sync();
+    if (GROWS) blk_sync_all();   // the rows are global memory: the parsing wavefronts read what the others stored
+    else blk_sync();
     TSFA_TICK(tk, b, 162);
     // lane = chain: the direct chains on wavefront 0, the hashed ones on wavefront 1 (if the workgroup has one)
     {
@@ -404,7 +440,7 @@ TSFA_DEV void fam_seq_series(const Blk &b, X xv, int n, const TsfaSeqGroup &g, d
 #pragma unroll
             for (int q = 0; q < TSFA_LZ_MAX_GROUP; ++q)
                 if (q == th) { off = g.toff[q]; cap = g.cap[q]; lg = g.lg[q]; col = g.col[q]; mode = g.mode[q]; nbt = g.nbt[q]; hbins = g.bins[q]; so = g.soff[q]; sb = g.sbits[q]; }
-            const int count = (mode == TSFA_LZ_BITS) ? lz_parse_bits(seq + so, n, hbins, nbt, cap, lg, tab + off, sb)
+            const int count = (mode == TSFA_LZ_BITS) ? lz_parse_bits<GROWS>(seq + so, n, hbins, nbt, cap, lg, tab + off, sb)
                                                      : lz_parse_hash(seq + so, n, cap, lg, tab + off);
             out_row[col] = (double)count / (double)n;
         }

@@ -92,6 +92,7 @@ struct PlanOptions {
     int nt[TSFA_N_FAMILIES] = {0};  // lab build: workgroup size per family (0: the measured defaults)
     bool trace = false;           // lab build: launch decisions to stderr
     bool row_form = true;         // BASIC / TREND: series of <= 256 samples four to a wavefront (k_basic_rows / k_trend_rows)
+    int seq_rows = -1;            // lempel_ziv symbol rows: 0 in LDS, 1 in HBM, -1: in HBM where that puts more series on a CU
 };
 
 #if defined(TSFA_LAB)
@@ -116,7 +117,7 @@ struct tsfa_plan {
     int *d_cols = nullptr, *d_coeff = nullptr;
     double *d_dectab = nullptr, *d_twc = nullptr, *d_tws = nullptr, *d_consts = nullptr;
     long long *d_stats = nullptr;
-    DevBuf values, offsets, out, gscratch, times, deg_list, sel, long_scratch, pf_buf, perm_buf, stats_buf, dd_scratch, gen_scratch;
+    DevBuf values, offsets, out, gscratch, times, deg_list, sel, long_scratch, pf_buf, perm_buf, stats_buf, dd_scratch, gen_scratch, seq_rows;
     // k_general (fam_general.h): the columns of the calculators whose parameters lie beyond the tuned kernels' tables
     std::vector<TsfaSpec> gen_specs;
     TsfaSpec *d_gen_specs = nullptr;
@@ -399,6 +400,7 @@ int tsfa_plan_set_option(tsfa_plan *plan, const char *name, double value) {
     else if (n == "cwt_mfma") o.cwt_mfma = on;
     else if (n == "force_long") o.force_long = on;
     else if (n == "row_form") o.row_form = on;
+    else if (n == "seq_rows") o.seq_rows = (value < 0.0) ? -1 : (on ? 1 : 0);
     else if (n == "entropy_route") { if (value != 0.0 && value != 1.0 && value != 2.0) return fail(TSFA_ERR_INVALID, "entropy_route: 0, 1 or 2"); o.entropy_route = (int)value; }
     else if (n == "bluestein_min") o.bluestein_min = value > 0.0 ? (int)std::min(value, 32767.0) : 0;
     else if (n == "gscratch_slots") o.gscratch_slots = value > 0.0 ? (int)std::min(value, 2147483647.0) : 0;
@@ -788,11 +790,37 @@ static int run_batch(tsfa_plan *plan, const void *d_values, int dtype, const dou
                 lz_build_group(plan->fam_specs[f].data(), std::min(seq_group, a.nspecs), maxn, &a.seq);
             }
             size_t seq_lds = 0;  // the largest launch of the family at this group size
+            int seq_grows = 0;
             if (f == TSFA_FAM_SEQ) {
                 TsfaSeqGroup g;
                 for (int s0 = 0; s0 < a.nspecs; s0 += seq_group) {
                     lz_build_group(plan->fam_specs[f].data() + s0, std::min(seq_group, a.nspecs - s0), maxn, &g);
                     seq_lds = std::max(seq_lds, tsfa_seq_lds_bytes(g));
+                }
+                // The symbol rows in HBM (k_seq<T, true>): LDS then holds the tables alone, and the family is bound by
+                // (series resident per CU) x (latency of a parse step).  Taken where it puts more workgroups on a CU and the
+                // rows of the launch's workgroups fit 2 GB; every `bins` value of the plan in one launch then.
+                if (plan->opt.seq_rows != 0 && !plan->opt.force_long) {
+                    const int group_g = std::min(a.nspecs, TSFA_LZ_MAX_GROUP);
+                    size_t lds_g = 0, stride_g = 0;
+                    for (int s0 = 0; s0 < a.nspecs; s0 += group_g) {
+                        lz_build_group(plan->fam_specs[f].data() + s0, std::min(group_g, a.nspecs - s0), maxn, &g, 1);
+                        lds_g = std::max(lds_g, tsfa_seq_lds_bytes(g));
+                        stride_g = std::max(stride_g, (size_t)g.stride);
+                    }
+                    auto resident = [&](size_t lds) {
+                        if (lds > TSFA_LDS_LIMIT) return (size_t)0;
+                        return std::min<size_t>((size_t)(163840 / std::max<size_t>(lds, 1)), (size_t)(32 * 64 / a.nt));
+                    };
+                    const bool more = resident(lds_g) > resident(seq_lds);
+                    if (lds_g <= TSFA_LDS_LIMIT && (plan->opt.seq_rows == 1 || more) &&
+                        (size_t)a.n_series * stride_g <= ((size_t)2 << 30) &&
+                        plan->seq_rows.ensure((size_t)a.n_series * stride_g) == 0) {
+                        seq_grows = 1;
+                        seq_group = group_g;
+                        seq_lds = lds_g;
+                        a.seq_rows = (unsigned char *)plan->seq_rows.p;
+                    }
                 }
             }
             size_t lds = (f == TSFA_FAM_SEQ) ? seq_lds
@@ -813,6 +841,7 @@ static int run_batch(tsfa_plan *plan, const void *d_values, int dtype, const dou
                 if (f == TSFA_FAM_CWT) { a.cwt_rowv &= 2; lds = tsfa_family_lds_bytes(f, maxn, a.nt, 0); }
                 if (f == TSFA_FAM_SEQ) {
                     seq_group = std::min(a.nspecs, TSFA_LZ_MAX_GROUP);
+                    seq_grows = 0;
                     lds = 0;
                     for (int s0 = 0; s0 < a.nspecs; s0 += seq_group) {
                         lz_build_group(plan->fam_specs[f].data() + s0, std::min(seq_group, a.nspecs - s0), maxn, &a.seq);
@@ -884,7 +913,7 @@ static int run_batch(tsfa_plan *plan, const void *d_values, int dtype, const dou
                 rc = tsfa_launch_order_stats(a);
             } else if (f == TSFA_FAM_SEQ) {
                 for (int s0 = 0; rc == 0 && s0 < a.nspecs; s0 += seq_group) {
-                    lz_build_group(plan->fam_specs[f].data() + s0, std::min(seq_group, a.nspecs - s0), maxn, &a.seq);
+                    lz_build_group(plan->fam_specs[f].data() + s0, std::min(seq_group, a.nspecs - s0), maxn, &a.seq, seq_grows);
                     if (!use_long && tsfa_seq_lds_bytes(a.seq) > TSFA_LDS_LIMIT)
                         return fail(TSFA_ERR_TOO_LONG, "k_seq: a series of " + std::to_string(maxn) + " samples does not fit LDS");
                     rc = use_long ? tsfa_launch_family_long(a) : tsfa_launch_family(a);

@@ -462,19 +462,23 @@ __global__ void __launch_bounds__(1024) k_entropy_bits(const T *__restrict__ val
 }
 #endif
 
-template <typename T>
+// GROWS (LDS build only): the symbol rows in HBM -- rows + blockIdx.x * g.stride -- instead of LDS: the tables alone decide how
+// many series a CU holds (8192 samples: 75 KB -> 40 KB, four series per CU instead of two; the family is latency bound)
+template <typename T, bool GROWS>
 __global__ void __launch_bounds__(256) k_seq(const T *__restrict__ values, const int64_t *__restrict__ starts, const int64_t *__restrict__ ends, int64_t n_series, const int *__restrict__ sel,
-                      double *__restrict__ out, int64_t ld, const TsfaSeqGroup g, const double *__restrict__ stats_in TSFA_GS_PARAMS) {
+                      double *__restrict__ out, int64_t ld, const TsfaSeqGroup g, const double *__restrict__ stats_in,
+                      unsigned char *__restrict__ rows TSFA_GS_PARAMS) {
     TSFA_SERIES_BEGIN
     const int64_t off = starts[sidx];
     const int n = (int)(ends[sidx] - off);
     SeqLds L;
-    L.carve(tsfa_base, 1, g.stride, g.ttotal, g.etotal, (int)(blockDim.x + 63) >> 6);
+    L.carve(tsfa_base, GROWS ? 0 : 1, g.stride, g.ttotal, g.etotal, (int)(blockDim.x + 63) >> 6);
     TSFA_TICKS_BEGIN();
     Blk b{(int)threadIdx.x, (int)blockDim.x, L.red, nullptr};
     const T *gv = values + off;
-    fam_seq_series(b, [=](int i) { return (double)gv[i]; }, n, g, out + sidx * ld, L.seq, L.tab, L.edges,
-                   stats_in ? stats_in + sidx * TSFA_STATS_N : nullptr);
+    fam_seq_series<GROWS>(b, [=](int i) { return (double)gv[i]; }, n, g, out + sidx * ld,
+                          GROWS ? rows + (size_t)blockIdx.x * (size_t)g.stride : L.seq, L.tab, L.edges,
+                          stats_in ? stats_in + sidx * TSFA_STATS_N : nullptr);
     TSFA_TICKS_END();
     TSFA_SERIES_END
 }
@@ -1133,8 +1137,18 @@ static int launch_all_t(const TsfaLaunch &a, const T *values) {
         }
     } else if (a.fam == TSFA_FAM_SEQ) {
         SeqLds L;
-        const size_t lds = L.carve(nullptr, 1, a.seq.stride, a.seq.ttotal, a.seq.etotal, (nt + 63) >> 6);
-        TSFA_KLAUNCH(k_seq<T>, lds, values, a.starts, a.ends, a.n_series, a.sel, a.out, a.ld, a.seq, a.stats_in);
+        const size_t lds = L.carve(nullptr, a.seq.grows ? 0 : 1, a.seq.stride, a.seq.ttotal, a.seq.etotal, (nt + 63) >> 6);
+#if !defined(TSFA_LONG)
+        if (a.seq.grows) {
+            if (!a.seq_rows) return -2;
+            auto kfn = k_seq<T, true>;
+            TSFA_KLAUNCH(kfn, lds, values, a.starts, a.ends, a.n_series, a.sel, a.out, a.ld, a.seq, a.stats_in, a.seq_rows);
+        } else
+#endif
+        {
+            auto kfn = k_seq<T, false>;
+            TSFA_KLAUNCH(kfn, lds, values, a.starts, a.ends, a.n_series, a.sel, a.out, a.ld, a.seq, a.stats_in, (unsigned char *)nullptr);
+        }
     } else if (a.fam == TSFA_FAM_CWT) {  // number_cwt_peaks
         CwtPeaksLayout L;
         const size_t lds = L.carve(nullptr, a.maxn, a.cwt_rowv & 1, (int)sizeof(T));
@@ -1288,7 +1302,7 @@ size_t tsfa_entropy_lds_bytes(int maxn, int with_cnt) {
 
 size_t tsfa_seq_lds_bytes(const TsfaSeqGroup &g) {
     SeqLds L;
-    return L.carve(nullptr, 1, g.stride, g.ttotal, g.etotal);
+    return L.carve(nullptr, g.grows ? 0 : 1, g.stride, g.ttotal, g.etotal);
 }
 
 size_t tsfa_family_lds_bytes(int fam, int maxn, int nt, int aux) {

@@ -51,6 +51,7 @@ struct TsfaLaunch {
     double *gscratch;       // SPECTRAL: HBM scratch of the Bluestein FFTs, one slot of gscratch_n doubles per workgroup (or null)
     int gscratch_n;
     TsfaSeqGroup seq;       // SEQ: the (<= TSFA_LZ_MAX_GROUP) specs this launch parses side by side
+    unsigned char *seq_rows;  // SEQ, seq.grows: HBM for the symbol rows, seq.stride bytes per workgroup of the launch
     int ar_P;               // AR: leading dimension of the normal matrices
     int ar_P_dd;            // ... and of the second pass's (ar_coefficient orders beyond the first pass's table live only there)
     double *dd_scratch;     // AR second pass: HBM slots for double-double matrices beyond LDS (or null), dd_slots of them
