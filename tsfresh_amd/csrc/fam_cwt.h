@@ -350,25 +350,45 @@ TSFA_DEV void cwt_rows_mfma(const Blk &b, const ST *xpad, int n, int W, const Cw
 }
 #endif
 
+// cwt[row, col], re-evaluated for a ridge line that ended above row 0 (row 0 itself is resident: L.row0)
+template <class X>
+TSFA_DEV double cwt_signal_at(X xv, int n, const CwtPeaksLds &L, int col, int row, bool taps_cached) {
+    if (row == 0) return L.row0[col];
+    const int w = row + 1;
+    const int nw = (10 * w < n) ? 10 * w : n;
+    const int m2 = col + (nw - 1) / 2;
+    int kk0 = m2 - (n - 1);
+    if (kk0 < 0) kk0 = 0;
+    const int kk1 = (m2 < nw - 1) ? m2 : (nw - 1);
+    double acc = 0.0;
+    if (taps_cached) {
+        const double *tw = L.taps + 5 * (w - 2) * (w + 1);  // sum_{v=2}^{w-1} 10 v
+        for (int kk = kk1; kk >= kk0; --kk) acc += xv(m2 - kk) * tw[kk];
+    } else {
+        for (int kk = kk1; kk >= kk0; --kk) acc += xv(m2 - kk) * ricker_tap_t(L.rk, nw, w, nw - 1 - kk);
+    }
+    return acc;
+}
+
+// scipy.stats.scoreatpercentile(window, 10) from the two order statistics it reads (ranks i0, i0 + 1; idx = 0.1 (m - 1))
+TSFA_DEV double cwt_noise_of(double s0, double s1, double idx, int i0) {
+    if ((double)i0 == idx) return s0;
+    const double j = (double)(i0 + 1);
+    const double w0 = j - idx, w1 = idx - (double)i0;
+    return (s0 * w0 + s1 * w1) / (w0 + w1);
+}
+
 // Length / signal-to-noise filter of scipy.signal._peak_finding._filter_ridge_lines over a list of ridge-line end points:
 // entry k = (cols[k], rows ? rows[k] : 0).  signal = cwt[row, col], noise = the 10th percentile
-// (scipy.stats.scoreatpercentile) of |...| row 0 in the window [col - hf, col + hf + odd) clipped to the series.
+// (scipy.stats.scoreatpercentile) of row 0 in the window [col - hf, col + hf + odd) clipped to the series.
 // Returns the number of entries with |signal / noise| >= 1; *extra receives how many of those carry `extra_bit` in
-// mask[col] (0: none asked).
-//   order == nullptr : short windows (the percentile is among the eight smallest, or a rank count over <= 70 values),
-//                      lane = entry;
-//   order            : the argsort of row 0.  lane = entry; all lanes walk the SAME global order from the smallest value
-//                      (64 entries per load, handed round with v_readlane: the entry is wave-uniform, the window test
-//                      per lane) and count the entries whose column falls into their own window until they have seen
-//                      the i0-th and (i0 + 1)-th: ~0.1 n entries for 64 end points at once.
+// mask[col] (0: none asked).  SHORT windows (the percentile is among the eight smallest, or a rank count over <= 70 values),
+// lane = entry; long windows: cwt_filter_counts below.
 template <class X>
 TSFA_DEV double cwt_filter_list(const Blk &b, X xv, int n, const CwtPeaksLds &L, const cwt_idx_t *cols,
                                 const cwt_idx_t *rows, int cnt, int hf, int odd, bool taps_cached,
-                                const cwt_idx_t *order, unsigned short extra_bit, double *extra) {
+                                unsigned short extra_bit, double *extra) {
     double kept = 0.0, ext = 0.0;
-#if TSFA_GPU
-    const int lane = b.tid & 63;
-#endif
     for (int k0 = 0; k0 < cnt; k0 += b.nt) {  // uniform over the workgroup
         const int k = k0 + b.tid;
         const bool live = k < cnt;
@@ -379,36 +399,7 @@ TSFA_DEV double cwt_filter_list(const Blk &b, X xv, int n, const CwtPeaksLds &L,
         const double idx = 10.0 / 100.0 * (double)(m - 1);
         const int i0 = (int)idx;
         double s0 = 0.0, s1 = 0.0;
-        if (order != nullptr) {
-#if TSFA_GPU
-            int count = live ? 0 : (1 << 30), p0 = 0, p1 = 0;
-            for (int base = 0; base < n; base += 64) {
-                if (!__ballot(count <= i0 + 1)) break;
-                const int e = base + lane;
-                const int pe = (e < n) ? (int)order[e] : (int)TSFA_CWT_IDX_NONE;   // (beyond every window: 65 535 >= n, or -1)
-                const int lim = (n - base < 64) ? n - base : 64;
-                for (int j = 0; j < lim; ++j) {
-                    const int p = __builtin_amdgcn_readlane(pe, j);
-                    const bool in = (p >= ws) & (p < we);
-                    p0 = (in & (count == i0)) ? p : p0;
-                    p1 = (in & (count == i0 + 1)) ? p : p1;
-                    count += in ? 1 : 0;
-                }
-            }
-            s0 = L.row0[p0];
-            s1 = L.row0[p1];
-#else
-            int count = 0;
-            for (int e = 0; live && e < n && count <= i0 + 1; ++e) {
-                const int p = order[e];
-                if (p >= ws && p < we) {
-                    if (count == i0) s0 = L.row0[p];
-                    if (count == i0 + 1) s1 = L.row0[p];
-                    ++count;
-                }
-            }
-#endif
-        } else if (live) {
+        if (live) {
             const double *r0 = L.row0 + ws;
             if (i0 + 1 < 8) {
                 lowest8_select(r0, m, n - ws, i0, &s0, &s1);
@@ -426,33 +417,148 @@ TSFA_DEV double cwt_filter_list(const Blk &b, X xv, int n, const CwtPeaksLds &L,
             }
         }
         if (!live) continue;
-        double noise;
-        if ((double)i0 == idx) {
-            noise = s0;
-        } else {
-            const double j = (double)(i0 + 1);
-            const double w0 = j - idx, w1 = idx - (double)i0;
-            noise = (s0 * w0 + s1 * w1) / (w0 + w1);
+        const double noise = cwt_noise_of(s0, s1, idx, i0);
+        const double sig = cwt_signal_at(xv, n, L, col, row, taps_cached);
+        const double snr = fabs(sig / noise);
+        if (!(snr < 1.0)) {
+            kept += 1.0;
+            if (extra_bit && (L.mask[col] & extra_bit)) ext += 1.0;
         }
-        double sig;  // cwt[row, col]
-        if (row == 0) {
-            sig = L.row0[col];
-        } else {
-            const int w = row + 1;
-            const int nw = (10 * w < n) ? 10 * w : n;
-            const int m2 = col + (nw - 1) / 2;
-            int kk0 = m2 - (n - 1);
-            if (kk0 < 0) kk0 = 0;
-            const int kk1 = (m2 < nw - 1) ? m2 : (nw - 1);
-            double acc = 0.0;
-            if (taps_cached) {
-                const double *tw = L.taps + 5 * (w - 2) * (w + 1);  // sum_{v=2}^{w-1} 10 v
-                for (int kk = kk1; kk >= kk0; --kk) acc += xv(m2 - kk) * tw[kk];
+    }
+    kept = blk_sum(b, kept);
+    if (extra_bit) *extra = blk_sum(b, ext);
+    return kept;
+}
+
+// The same filter for LONG windows (series beyond ~1400 samples: hundreds of columns per window, the percentile is the
+// 8th .. 40th smallest).  Rounds 2-5 argsorted row 0 once and let every entry walk that global order until it had met
+// i0 + 2 columns of its own window (~0.1 n order entries per 64 end points, 12 instructions each): at 8192 samples the sort and
+// the walks were three quarters of the kernel.  The filter only needs a DECISION, |signal| against |noise|, and
+//     |x / y| >= 1  <=>  |x| >= |y|     (IEEE division: a quotient below 1 cannot round up to 1)
+// so an entry is decided by COUNTING its window against thresholds at +-|signal| -- no order at all.  With a = |signal|,
+// d = 2^-40 and the window counts
+//     A = #{x < -a (1 + d)},  B = #{x < -a (1 - d)},  C = #{x <= a (1 - d)},  D = #{x <= a (1 + d)}
+// and r1 = the larger rank the percentile reads (i0 + 1, or i0 when 0.1 (m - 1) is whole):
+//     r1 < A              both order statistics lie below -a (1 + d): |noise| > a              -> dropped
+//     i0 >= B, r1 < C     both lie in [-a (1 - d), a (1 - d)]:       |noise| < a              -> kept
+//     i0 >= D             both lie above a (1 + d)                                              -> dropped
+// (the interpolation of two values moves them by a few ulps, far inside the 2^-40 margins).  Eight instructions per window
+// column.  What is left -- a threshold falls between the two ranks, or the window holds values equal (or closer than 2^-40) to
+// +-a: ~3 % of the entries of a noisy series, every entry of a periodic one -- is compacted into a second list and decided from
+// the two order statistics themselves: in those cases both ranks lie next to a threshold, where one more sweep gives them
+// exactly -- rank A - 1 = max{x < -a (1 + d)}, ranks [A, B) = -a if that band holds one value, rank B = min{x >= -a (1 - d)},
+// and the same around +a -- then scipy's interpolation and division as written.  A band of DIFFERENT values within 2^-40 of
+// a threshold falls back to ranking the window (m^2, never seen outside constructed inputs).  amb_col / amb_row: scratch for
+// the second list, cnt entries each.
+template <class X>
+TSFA_DEV double cwt_filter_counts(const Blk &b, X xv, int n, const CwtPeaksLds &L, const cwt_idx_t *cols,
+                                  const cwt_idx_t *rows, int cnt, int hf, int odd, bool taps_cached,
+                                  unsigned short extra_bit, double *extra, cwt_idx_t *amb_col, cwt_idx_t *amb_row) {
+    double kept = 0.0, ext = 0.0;
+    const double dl = 1.0 + 0x1p-40, ds = 1.0 - 0x1p-40;
+    int namb = 0;
+    for (int k0 = 0; k0 < cnt; k0 += b.nt) {  // uniform over the workgroup
+        const int k = k0 + b.tid;
+        const bool live = k < cnt;
+        const int col = live ? (int)cols[k] : 0, row = (live && rows) ? (int)rows[k] : 0;
+        const int ws = (col - hf > 0) ? col - hf : 0;
+        const int we = (col + hf + odd < n) ? col + hf + odd : n;
+        const int m = we - ws;
+        const double idx = 10.0 / 100.0 * (double)(m - 1);
+        const int i0 = (int)idx;
+        const int r1 = ((double)i0 == idx) ? i0 : i0 + 1;
+        bool amb = false;
+        if (live) {
+            const double sig = cwt_signal_at(xv, n, L, col, row, taps_cached);
+            const double a = fabs(sig);
+            if (!(a >= 1e-290 && a <= 1e300)) {
+                amb = true;   // 0, subnormal, huge, NaN: no margins to speak of -- the order statistics decide
             } else {
-                for (int kk = kk1; kk >= kk0; --kk) acc += xv(m2 - kk) * ricker_tap_t(L.rk, nw, w, nw - 1 - kk);
+                const double tA = -a * dl, tB = -a * ds, tC = a * ds, tD = a * dl;
+                int cA = 0, cB = 0, cC = 0, cD = 0;
+                const double *r0 = L.row0 + ws;
+                for (int e = 0; e < m; ++e) {
+                    const double x = r0[e];
+                    cA += (x < tA) ? 1 : 0;
+                    cB += (x < tB) ? 1 : 0;
+                    cC += (x <= tC) ? 1 : 0;
+                    cD += (x <= tD) ? 1 : 0;
+                }
+                bool keep = false;
+                if (r1 < cA) keep = false;
+                else if (i0 >= cB && r1 < cC) keep = true;
+                else if (i0 >= cD) keep = false;
+                else amb = true;
+                if (keep) {
+                    kept += 1.0;
+                    if (extra_bit && (L.mask[col] & extra_bit)) ext += 1.0;
+                }
             }
-            sig = acc;
         }
+        int tot;
+        const int at = namb + blk_excl_count(b, amb, &tot);
+        if (amb) { amb_col[at] = (cwt_idx_t)col; amb_row[at] = (cwt_idx_t)row; }
+        namb += tot;
+    }
+    blk_sync();
+    for (int k0 = 0; k0 < namb; k0 += b.nt) {
+        const int k = k0 + b.tid;
+        if (k >= namb) continue;
+        const int col = (int)amb_col[k], row = (int)amb_row[k];
+        const int ws = (col - hf > 0) ? col - hf : 0;
+        const int we = (col + hf + odd < n) ? col + hf + odd : n;
+        const int m = we - ws;
+        const double idx = 10.0 / 100.0 * (double)(m - 1);
+        const int i0 = (int)idx;
+        const bool two = ((double)i0 != idx);
+        const double sig = cwt_signal_at(xv, n, L, col, row, taps_cached);
+        const double a = fabs(sig);
+        const double *r0 = L.row0 + ws;
+        double s0 = 0.0, s1 = 0.0;
+        bool known = false;
+        if (a >= 1e-290 && a <= 1e300) {
+            const double tA = -a * dl, tB = -a * ds, tC = a * ds, tD = a * dl;
+            int cA = 0, cB = 0, cC = 0, cD = 0;
+            double lb = -TSFA_INF, la = TSFA_INF, ub = -TSFA_INF, ua = TSFA_INF;       // ranks A - 1, B, C - 1, D
+            double minL = TSFA_INF, maxL = -TSFA_INF, minU = TSFA_INF, maxU = -TSFA_INF;   // the bands [A, B), [C, D)
+            for (int e = 0; e < m; ++e) {
+                const double x = r0[e];
+                const bool bA = x < tA, bB = x < tB, bC = x <= tC, bD = x <= tD;
+                cA += bA ? 1 : 0; cB += bB ? 1 : 0; cC += bC ? 1 : 0; cD += bD ? 1 : 0;
+                lb = fmax(lb, bA ? x : -TSFA_INF);
+                la = fmin(la, bB ? TSFA_INF : x);
+                ub = fmax(ub, bC ? x : -TSFA_INF);
+                ua = fmin(ua, bD ? TSFA_INF : x);
+                const bool inL = bB && !bA, inU = bD && !bC;
+                minL = fmin(minL, inL ? x : TSFA_INF); maxL = fmax(maxL, inL ? x : -TSFA_INF);
+                minU = fmin(minU, inU ? x : TSFA_INF); maxU = fmax(maxU, inU ? x : -TSFA_INF);
+            }
+            // value of rank r, where this sweep determines it
+            auto at_rank = [&](int r, double *v) {
+                if (r == cA - 1) { *v = lb; return true; }
+                if (r >= cA && r < cB) { *v = minL; return minL == maxL; }
+                if (r == cB && cB < m) { *v = la; return true; }
+                if (r == cC - 1 && cC >= 1) { *v = ub; return true; }
+                if (r >= cC && r < cD) { *v = minU; return minU == maxU; }
+                if (r == cD && cD < m) { *v = ua; return true; }
+                return false;
+            };
+            known = at_rank(i0, &s0);
+            if (known && two) known = at_rank(i0 + 1, &s1);
+        }
+        if (!known) {   // rank the window
+            for (int p = 0; p < m; ++p) {
+                const double ea = r0[p];
+                int rank = 0;
+                for (int c = 0; c < m; ++c) {
+                    const double ec = r0[c];
+                    rank += (ec < ea || (ec == ea && c < p)) ? 1 : 0;
+                }
+                if (rank == i0) s0 = ea;
+                if (rank == i0 + 1) s1 = ea;
+            }
+        }
+        const double noise = cwt_noise_of(s0, s1, idx, i0);
         const double snr = fabs(sig / noise);
         if (!(snr < 1.0)) {
             kept += 1.0;
@@ -614,17 +720,8 @@ TSFA_DEV double number_cwt_peaks_one(const Blk &b, X xv, int n, int W, const Cwt
         blk_sync();
     }
     // Long series: the noise window holds hundreds of samples and its 10th percentile is no longer among the eight
-    // smallest: the width-1 row is argsorted ONCE and every entry walks that global order (cwt_filter_list).
+    // smallest: every entry is decided by counting its window against thresholds at +-|signal| (cwt_filter_counts).
     const bool long_windows = ((int)(0.1 * (double)(window - 1)) + 1 >= 8);
-    const cwt_idx_t *order = nullptr;
-    if (__builtin_expect(long_windows, 0)) {
-        cwt_idx_t *ord = L.colmap;  // colmap and mline are contiguous and dead by now: 2 * maxn >= pow2(n)
-        int np2 = 1;
-        while (np2 < n) np2 <<= 1;
-        blk_argsort_idx<cwt_idx_t>(b, L.row0, n, ord, np2);
-        order = ord;
-        TSFA_TICK(tk, b, 154);
-    }
     // The filter needs (column, row) of a line's end point.  The qualifying lines are compacted to the front of
     // (lcol, linf) -- entry k = (lcol[k], row in linf[k]) -- so every lane of the evaluation below has work.
     // derive_w1 (the plan also asks for n = 1, whose ridge lines are exactly the maxima of row 0, each of length 1): the
@@ -647,7 +744,7 @@ TSFA_DEV double number_cwt_peaks_one(const Blk &b, X xv, int n, int W, const Cwt
             if (defer) L.mask[L.lcol[l]] |= bit_a;
             mine += (qual && !defer) ? 1 : 0;
         }
-        if (!long_windows) {
+        {
             // one scan; the entries are staged in (mline, colmap) -- dead by now -- because entry k may land on a line
             // another thread has not read yet, then copied to the front of (lcol, linf)
             int idx = blk_excl_sum_small(b, mine, ltbits, &cnt_a);
@@ -664,22 +761,6 @@ TSFA_DEV double number_cwt_peaks_one(const Blk &b, X xv, int n, int W, const Cwt
                 L.lcol[k] = L.mline[k];
                 L.linf[k] = L.colmap[k];
             }
-        } else {
-            // (mline, colmap) hold the argsort: compaction in place, a chunk of nt lines at a time
-            for (int base = 0; base < nlines; base += b.nt) {
-                const int l = base + b.tid;
-                const cwt_idx_t v = (l < nlines) ? L.linf[l] : 0;
-                const int col = (l < nlines) ? (int)L.lcol[l] : 0, row = TSFA_LI_ROW(v);
-                const bool take = (l < nlines) && (TSFA_LI_LEN(v) >= min_length) && !(derive_w1 && row == 0);
-                int tot;
-                const int k = cnt_a + blk_excl_count(b, take, &tot);
-                if (take) {
-                    L.lcol[k] = (cwt_idx_t)col;
-                    L.linf[k] = (cwt_idx_t)row;
-                }
-                cnt_a += tot;
-                blk_sync();
-            }
         }
         blk_sync();
     }
@@ -687,10 +768,17 @@ TSFA_DEV double number_cwt_peaks_one(const Blk &b, X xv, int n, int W, const Cwt
     double kept;
     const ST *xp0 = (L.xpad != nullptr) ? (const ST *)L.xpad + TSFA_CWTP_HALO : nullptr;
     // the re-evaluated signal reads the staged copy of the series (LDS) where there is one
-    if (xp0 != nullptr)
-        kept = cwt_filter_list(b, [=](int i) { return (double)xp0[i]; }, n, L, L.lcol, L.linf, cnt_a, hf, odd, taps_cached, order, 0, &unused);
+    // (mline, colmap): free again -- the second list of cwt_filter_counts
+    if (long_windows) {
+        blk_sync();
+        if (xp0 != nullptr)
+            kept = cwt_filter_counts(b, [=](int i) { return (double)xp0[i]; }, n, L, L.lcol, L.linf, cnt_a, hf, odd, taps_cached, 0, &unused, L.mline, L.colmap);
+        else
+            kept = cwt_filter_counts(b, xv, n, L, L.lcol, L.linf, cnt_a, hf, odd, taps_cached, 0, &unused, L.mline, L.colmap);
+    } else if (xp0 != nullptr)
+        kept = cwt_filter_list(b, [=](int i) { return (double)xp0[i]; }, n, L, L.lcol, L.linf, cnt_a, hf, odd, taps_cached, 0, &unused);
     else
-        kept = cwt_filter_list(b, xv, n, L, L.lcol, L.linf, cnt_a, hf, odd, taps_cached, order, 0, &unused);
+        kept = cwt_filter_list(b, xv, n, L, L.lcol, L.linf, cnt_a, hf, odd, taps_cached, 0, &unused);
     TSFA_TICK(tk, b, 153);
     if (derive_w1) {
         int cnt_b = 0;
@@ -704,7 +792,8 @@ TSFA_DEV double number_cwt_peaks_one(const Blk &b, X xv, int n, int W, const Cwt
             blk_sync();
         }
         double marked = 0.0;
-        *kept_w1 = cwt_filter_list(b, xv, n, L, L.lcol, nullptr, cnt_b, hf, odd, taps_cached, order, bit_a, &marked);
+        if (long_windows) *kept_w1 = cwt_filter_counts(b, xv, n, L, L.lcol, nullptr, cnt_b, hf, odd, taps_cached, bit_a, &marked, L.mline, L.colmap);
+        else *kept_w1 = cwt_filter_list(b, xv, n, L, L.lcol, nullptr, cnt_b, hf, odd, taps_cached, bit_a, &marked);
         kept += marked;
         TSFA_TICK(tk, b, 156);
     }
