@@ -79,6 +79,15 @@ int tsfa_calc_count(void);
  * offender in tsfa_last_error) for a calculator/parameter combination that has no kernel.
  */
 int tsfa_plan_create(const tsfa_feature_spec *specs, int32_t n_specs, int32_t device, tsfa_plan **out_plan);
+/*
+ * tsfa_plan_create for FCParameters whose parameter values include ARRAYS: `data` is a pool of n_data float64 (copied; the
+ * caller keeps ownership) that such specs point into.  Today one calculator has an array parameter: query_similarity_count
+ * (feature_calculators.py:2475-2519, {"query": Q, "threshold": thr, "normalize": norm}) --
+ *     p[0] = thr, p[1] = norm (0 | 1), p[2] = offset of Q in the pool, p[3] = len(Q)  (0: query=None, the column is NaN).
+ * TSFA_ERR_INVALID if a spec points outside the pool.  tsfa_plan_create is the case n_data = 0.
+ */
+int tsfa_plan_create_with_data(const tsfa_feature_spec *specs, int32_t n_specs, const double *data, int64_t n_data,
+                               int32_t device, tsfa_plan **out_plan);
 int32_t tsfa_plan_n_cols(const tsfa_plan *plan);
 void tsfa_plan_destroy(tsfa_plan *plan);
 

@@ -547,13 +547,18 @@ class SeriesOracle:
             out.append(("num_segments_{}__segment_focus_{}".format(ns, sf), v))
         return out
 
-    def query_similarity_count(self, param):  # fc.py:2475 (query=None -> NaN)
+    def query_similarity_count(self, param):  # fc.py:2475-2519
         from tsfresh_amd.utilities.string_manipulation import convert_to_output_format  # name format only
+        from oracle.third_party import stumpy_mass, stumpy_mass_absolute   # stumpy.core.mass / mass_absolute, restated
         out = {}
+        T = np.asarray(self.x).astype(float)
         for p in param:
-            if p.get("query", None) is not None:
-                raise NotImplementedError("query_similarity_count with a query needs stumpy")
-            out[convert_to_output_format(p)] = np.nan
+            Q = np.asarray(p.get("query", None)).astype(float)   # query=None -> array(nan), size 1
+            count = np.nan
+            if Q.size >= 3:
+                prof = stumpy_mass(Q, T) if p.get("normalize", True) else stumpy_mass_absolute(Q, T)
+                count = float(np.sum(prof <= p.get("threshold", 0.0)))
+            out[convert_to_output_format(p)] = count
         return list(out.items())
 
 

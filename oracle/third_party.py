@@ -7,6 +7,13 @@ importable in the main interpreter of this image.
   * PyWavelets (setup.cfg:44, unpinned)
         pywt.cwt(x, scales, "mexh")     call site: feature_calculators.py:1402
 
+  * stumpy >= 1.11.1 (setup.cfg:47; NOT installed in either interpreter of this image, not vendored)
+        stumpy.core.mass(Q, T) / stumpy.core.mass_absolute(Q, T)    call sites: feature_calculators.py:2514, :2516
+        restated from the library's published definition (core.py: _calculate_squared_distance, _mass_absolute /
+        _p_norm_distance_profile); PARITY UNPINNED against the library itself -- the only vectors are the four known
+        answers of the reference's own unit test (test_feature_calculations.py:2017-2037), checked in
+        tests/test_query_similarity.py.
+
 Pinning: tests/golden/gen_golden_conda.py runs the REAL libraries (statsmodels 0.12.2 with two import shims,
 pywt 1.1.1) under /opt/conda/bin/python3.9 in the build container and commits their outputs under tests/golden/;
 tests/test_oracle_golden.py checks this file against those vectors and against the reference's own known-answer
@@ -243,3 +250,50 @@ def cwt_mexh(data, scales):
             raise ValueError("Selected scale of {} too small.".format(scale))
         out[i] = coef
     return out
+
+
+# ------------------------------------------------------------------------------------------------
+# stumpy.core  (distance profiles of a query against every window of a series)
+# ------------------------------------------------------------------------------------------------
+STUMPY_D_SQUARED_THRESHOLD = 1e-14   # stumpy/config.py: a squared distance below it is an exact match (0.0)
+
+
+def _stumpy_windows(Q, T):
+    Q = np.asarray(Q, dtype=np.float64)
+    T = np.asarray(T, dtype=np.float64)
+    m, n = len(Q), len(T)
+    if m < 3:   # core.check_window_size
+        raise ValueError("All window sizes must be greater than or equal to three")
+    if m > n:
+        raise ValueError("The window size must be less than or equal to {}".format(n))
+    return Q, np.lib.stride_tricks.sliding_window_view(T, m), m
+
+
+def stumpy_mass(Q, T):
+    """stumpy.core.mass(Q, T): z-normalised Euclidean distance of Q to every window of T.
+    core._calculate_squared_distance: both constant -> 0; one constant -> m; else D^2 = |2 m (1 - min(rho, 1))| with rho
+    the Pearson correlation of the two subsequences; D^2 < 1e-14 -> 0; a window with a non-finite sample -> inf."""
+    Q, W, m = _stumpy_windows(Q, T)
+    mq, sq = Q.mean(), Q.std()
+    mt, st = W.mean(axis=1), W.std(axis=1)
+    qconst = Q.max() == Q.min()
+    tconst = W.max(axis=1) == W.min(axis=1)
+    with np.errstate(all="ignore"):
+        rho = ((W - mt[:, None]) * (Q - mq)[None, :]).sum(axis=1) / (m * sq * st)
+        d2 = np.abs(2.0 * m * (1.0 - np.minimum(rho, 1.0)))
+    d2 = np.where(tconst | qconst, float(m), d2)
+    d2 = np.where(tconst & qconst, 0.0, d2)
+    d2 = np.where(d2 < STUMPY_D_SQUARED_THRESHOLD, 0.0, d2)
+    bad = ~np.isfinite(W).all(axis=1) | (not np.isfinite(Q).all())
+    d2 = np.where(bad, np.inf, d2)
+    return np.sqrt(d2)
+
+
+def stumpy_mass_absolute(Q, T):
+    """stumpy.core.mass_absolute(Q, T): Euclidean distance of Q to every window of T (p = 2)."""
+    Q, W, m = _stumpy_windows(Q, T)
+    with np.errstate(all="ignore"):
+        d2 = ((W - Q[None, :]) ** 2).sum(axis=1)
+    bad = ~np.isfinite(W).all(axis=1) | (not np.isfinite(Q).all())
+    d2 = np.where(bad, np.inf, d2)
+    return np.sqrt(d2)

@@ -71,6 +71,10 @@ extern "C" int tsfa_emul_extract_timed(const tsfa_feature_spec *specs, int n_spe
                                        const double *times, const int64_t *offsets, int64_t n_series, double *out,
                                        int64_t ld, char *err, int errlen);
 
+// the float64 pool of array-valued parameters (tsfa_plan_create_with_data): set before the extract that uses it
+static std::vector<double> g_pool;
+extern "C" void tsfa_emul_set_pool(const double *data, int64_t n) { g_pool.assign(data, data + (n > 0 ? n : 0)); }
+
 extern "C" int tsfa_emul_extract(const tsfa_feature_spec *specs, int n_specs, const double *values,
                                  const int64_t *offsets, int64_t n_series, double *out, int64_t ld, char *err,
                                  int errlen) {
@@ -316,7 +320,7 @@ extern "C" int tsfa_emul_extract_timed(const tsfa_feature_spec *specs, int n_spe
             poison(slot);
             S.carve(slot.data(), call_maxn, gp);
             const double *xp = xs.data();
-            fam_general_series(b, [=](int i) { return xp[i]; }, n, gen.data(), (int)gen.size(), row, S, gp);
+            fam_general_series(b, [=](int i) { return xp[i]; }, n, gen.data(), (int)gen.size(), row, S, gp, g_pool.data());
         }
         for (int c = 0; c < bank.C; ++c) {  // plain-loop stand-in for k_cwt_gemm
             double acc = 0.0;

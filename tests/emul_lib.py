@@ -43,6 +43,8 @@ def load():
                                             ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p, ctypes.c_int64,
                                             ctypes.c_char_p, ctypes.c_int]
     lib.tsfa_emul_extract_timed.restype = ctypes.c_int
+    lib.tsfa_emul_set_pool.argtypes = [ctypes.c_void_p, ctypes.c_int64]
+    lib.tsfa_emul_set_pool.restype = None
     return lib
 
 
@@ -50,10 +52,16 @@ def emul_extract_specs(specs, values, offsets, times=None):
     """specs: [(calculator id of the EMULATION library, p[4])] -> float64 matrix [n_series x len(specs)]."""
     lib = load()
     arr = (_Spec * max(len(specs), 1))()
+    pool = []
     for i, (cid, p) in enumerate(specs):
         arr[i].calc = cid
         for k in range(4):
             arr[i].p[k] = p[k]
+        if len(p) > 4:   # an array-valued parameter (query_similarity_count): p[4:] goes to the pool, p[2] = its offset
+            arr[i].p[2] = float(len(pool))
+            pool.extend(float(v) for v in p[4:])
+    pool_arr = np.ascontiguousarray(pool, dtype=np.float64)
+    lib.tsfa_emul_set_pool(pool_arr.ctypes.data, len(pool_arr))
     values = np.ascontiguousarray(values, dtype=np.float64)
     offsets = np.ascontiguousarray(offsets, dtype=np.int64)
     n = len(offsets) - 1

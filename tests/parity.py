@@ -78,7 +78,7 @@ INTEGER_FEATURES = {
     "length", "variance_larger_than_standard_deviation", "large_standard_deviation", "symmetry_looking",
     "has_duplicate_max", "has_duplicate_min", "has_duplicate", "count_above_mean", "count_below_mean", "value_count",
     "range_count", "number_crossing_m", "longest_strike_above_mean", "longest_strike_below_mean", "number_peaks",
-    "number_cwt_peaks",
+    "number_cwt_peaks", "query_similarity_count",
 }
 RTOL = 1e-6
 EPS = float(np.finfo(np.float64).eps)

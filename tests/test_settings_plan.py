@@ -59,8 +59,9 @@ def test_param_formatting():
 def test_unsupported_features_raise_instead_of_falling_back():
     with pytest.raises(UnsupportedFeature):
         compile_fc_parameters({"matrix_profile": [{"threshold": 0.98, "feature": "min"}]})
-    with pytest.raises(UnsupportedFeature):
-        compile_fc_parameters({"query_similarity_count": [{"query": [1.0, 2.0, 3.0], "threshold": 0.0}]})
+    # served since round 6 (fam_general.h: gen_query_count): the query travels in the spec's tail to the plan's float64 pool
+    fp = compile_fc_parameters({"query_similarity_count": [{"query": [1.0, 2.0, 3.0], "threshold": 0.5}]})
+    assert fp.specs[0][1] == (0.5, 1.0, 0.0, 3.0, 1.0, 2.0, 3.0)
     compile_fc_parameters({"augmented_dickey_fuller": [{"attr": "teststat", "autolag": "BIC"}]})   # served since round 5
     with pytest.raises(AttributeError):
         compile_fc_parameters({"not_a_calculator": None})

@@ -26,7 +26,7 @@ TSFA_HOST, TSFA_DEVICE = 0, 1
 # every symbol include/tsfresh_amd.h declares
 EXPORTS = (
     "tsfa_version", "tsfa_device_count", "tsfa_last_error", "tsfa_calc_id", "tsfa_calc_name", "tsfa_calc_count",
-    "tsfa_plan_create", "tsfa_plan_n_cols", "tsfa_plan_destroy", "tsfa_extract", "tsfa_extract_timed",
+    "tsfa_plan_create", "tsfa_plan_create_with_data", "tsfa_plan_n_cols", "tsfa_plan_destroy", "tsfa_extract", "tsfa_extract_timed",
     "tsfa_extract_windows",
     "tsfa_plan_set_profiling",
     "tsfa_plan_set_option",
@@ -88,6 +88,9 @@ def load():
     lib.tsfa_plan_create.argtypes = [ctypes.POINTER(FeatureSpec), ctypes.c_int32, ctypes.c_int32,
                                      ctypes.POINTER(ctypes.c_void_p)]
     lib.tsfa_plan_create.restype = ctypes.c_int
+    lib.tsfa_plan_create_with_data.argtypes = [ctypes.POINTER(FeatureSpec), ctypes.c_int32, ctypes.c_void_p, ctypes.c_int64,
+                                               ctypes.c_int32, ctypes.POINTER(ctypes.c_void_p)]
+    lib.tsfa_plan_create_with_data.restype = ctypes.c_int
     lib.tsfa_plan_n_cols.argtypes = [ctypes.c_void_p]
     lib.tsfa_plan_n_cols.restype = ctypes.c_int32
     lib.tsfa_plan_destroy.argtypes = [ctypes.c_void_p]
@@ -251,17 +254,28 @@ class Plan:
     """Owns a `tsfa_plan*`: the compiled list of output columns of one kind on one device."""
 
     def __init__(self, specs, device=0):
-        """specs: iterable of (calc_id, (p0, p1, p2, p3))."""
+        """specs: iterable of (calc_id, (p0, p1, p2, p3)).  A parameter tuple longer than four carries an ARRAY-valued
+        parameter in p[4:] (query_similarity_count's query: registry._query_similarity_encode); those samples go to the plan's
+        float64 pool and p[2] becomes their offset (tsfa_plan_create_with_data)."""
         lib = load()
         specs = list(specs)
         arr = (FeatureSpec * max(len(specs), 1))()
+        pool = []
         for i, (cid, p) in enumerate(specs):
             arr[i].calc = int(cid)
             arr[i].reserved = 0
             for k in range(4):
                 arr[i].p[k] = float(p[k])
+            if len(p) > 4:
+                arr[i].p[2] = float(len(pool))
+                pool.extend(float(v) for v in p[4:])
         handle = ctypes.c_void_p()
-        _check(lib, lib.tsfa_plan_create(arr, len(specs), int(device), ctypes.byref(handle)))
+        if pool:
+            pool_arr = np.ascontiguousarray(pool, dtype=np.float64)
+            _check(lib, lib.tsfa_plan_create_with_data(arr, len(specs), pool_arr.ctypes.data, len(pool_arr), int(device),
+                                                       ctypes.byref(handle)))
+        else:
+            _check(lib, lib.tsfa_plan_create(arr, len(specs), int(device), ctypes.byref(handle)))
         self._lib = lib
         self._h = handle
         self.n_cols = len(specs)

@@ -15,6 +15,7 @@
 //                                                            run-time size; roots of a degree > 3 by Aberth's iteration
 //   lempel_ziv_complexity (fc.py:1825)       any bins        32-bit symbols, one open-addressing table of (node, symbol) keys
 //   number_cwt_peaks (fc.py:1320)            any n           fam_general_cwt.h
+//   query_similarity_count (fc.py:2475)      a query         lane = window; the query lives in the plan's float64 pool
 //
 // One wavefront per series, the series read from HBM / L2 where it lies, every working array in a slot of HBM scratch per
 // resident workgroup: no length limit, no table limit, and no claim on speed -- a slow path that returns the reference's numbers
@@ -410,9 +411,72 @@ struct GenIdx {
     TSFA_MEM double operator[](int i) const { return f(i); }
 };
 
+// ---------------------------------------------------------------------------------------------------------------
+// query_similarity_count (fc.py:2475-2519) with a query subsequence Q of m >= 3 samples:
+//     count = #{ i : dist(Q, T[i .. i + m)) <= threshold },  i = 0 .. n - m,
+// dist = stumpy.core.mass (z-normalised Euclidean distance, normalize=True) or stumpy.core.mass_absolute (plain Euclidean).
+// stumpy (>= 1.11.1, the reference's dependency, setup.cfg:47) is not part of the reference's tree and not installed in this
+// image; this is its PUBLISHED definition (core.py: _calculate_squared_distance / _mass_absolute), evaluated directly:
+//     normalised:  both constant -> 0;  one constant -> sqrt(m);  else  rho = sum (q - mu_Q)(t - mu_T) / (m sigma_Q sigma_T),
+//                  D^2 = |2 m (1 - min(rho, 1))|,  D^2 < 1e-14 -> 0  (stumpy's STUMPY_D_SQUARED_THRESHOLD: an exact match counts
+//                  at the default threshold 0);
+//     absolute:    D^2 = sum (q - t)^2.
+// stumpy forms the same quantities from an FFT sliding dot product and rolling moments, QT - m mu_Q mu_T; the two agree to
+// round-off, so a count can differ only where a distance equals the threshold to ~1e-7 relative (tests/parity.py R15).
+// Parity is anchored on the reference's own unit test (test_feature_calculations.py:2017-2037: 0 / 6 / 0 / 91).
+// A series shorter than the query: NaN here; the host raises the ValueError stumpy raises (reference_errors.py).
+template <class X>
+TSFA_DEV double gen_query_count(const Blk &b, X xv, int n, const double *q, int m, double thr, bool normalize) {
+    if (m < 3 || q == nullptr) return TSFA_NAN;   // fc.py:2511: Q.size >= 3, else np.nan
+    const int k = n - m + 1;
+    if (k <= 0) return TSFA_NAN;
+    double mq = 0.0, sq = 0.0, qmin = TSFA_INF, qmax = -TSFA_INF;
+    bool qfinite = true;
+    if (normalize) {   // uniform: every lane walks the (short) query
+        for (int j = 0; j < m; ++j) { const double v = q[j]; mq += v; qmin = fmin(qmin, v); qmax = fmax(qmax, v); qfinite = qfinite && (fabs(v) <= 1.7976931348623157e308); }
+        mq /= (double)m;
+        for (int j = 0; j < m; ++j) { const double d = q[j] - mq; sq += d * d; }
+        sq = sqrt(sq / (double)m);
+    } else {
+        for (int j = 0; j < m; ++j) qfinite = qfinite && (fabs(q[j]) <= 1.7976931348623157e308);
+    }
+    const bool qconst = (qmax == qmin);
+    const double dm = (double)m;
+    double cnt = 0.0;
+    for (int i = b.tid; i < k; i += b.nt) {
+        double d2;
+        if (normalize) {
+            double mt = 0.0, tmin = TSFA_INF, tmax = -TSFA_INF;
+            bool tfinite = true;
+            for (int j = 0; j < m; ++j) { const double v = xv(i + j); mt += v; tmin = fmin(tmin, v); tmax = fmax(tmax, v); tfinite = tfinite && (fabs(v) <= 1.7976931348623157e308); }
+            mt /= dm;
+            double st = 0.0, c = 0.0;
+            for (int j = 0; j < m; ++j) { const double d = xv(i + j) - mt; st += d * d; c += (q[j] - mq) * d; }
+            st = sqrt(st / dm);
+            const bool tconst = (tmax == tmin);
+            if (!tfinite || !qfinite) d2 = TSFA_INF;            // a window that holds a non-finite sample matches nothing
+            else if (qconst && tconst) d2 = 0.0;
+            else if (qconst || tconst) d2 = dm;
+            else {
+                double rho = c / (dm * sq * st);
+                rho = (rho > 1.0) ? 1.0 : rho;
+                d2 = fabs(2.0 * dm * (1.0 - rho));
+            }
+            if (d2 < 1e-14) d2 = 0.0;
+        } else {
+            d2 = 0.0;
+            bool tfinite = true;
+            for (int j = 0; j < m; ++j) { const double v = xv(i + j); const double d = q[j] - v; d2 += d * d; tfinite = tfinite && (fabs(v) <= 1.7976931348623157e308); }
+            if (!tfinite || !qfinite) d2 = TSFA_INF;
+        }
+        cnt += (sqrt(d2) <= thr) ? 1.0 : 0.0;
+    }
+    return blk_sum(b, cnt);   // integers below 2^53: exact in any order
+}
+
 template <class X>
 TSFA_DEV void fam_general_series(const Blk &b, X xv, int n, const TsfaSpec *specs, int nspecs, double *out_row,
-                                 const GenSlot &S, const TsfaGenPlan &g) {
+                                 const GenSlot &S, const TsfaGenPlan &g, const double *pool = nullptr) {
     const double dn = (double)n;
     const double mean = np_sum(b, n, [=](int i) { return xv(i); }) / dn;
     const double var = np_sum(b, n, [=](int i) { const double d = xv(i) - mean; return d * d; }) / dn;
@@ -604,6 +668,18 @@ TSFA_DEV void fam_general_series(const Blk &b, X xv, int n, const TsfaSpec *spec
                 }
                 out_row[sp.col] = (double)count / dn;
             }
+        }
+        blk_sync();
+    }
+
+    // ---- query_similarity_count (fc.py:2475) with a query: p = (threshold, normalize, offset into the pool, m) ----
+    if (g.query > 0) {
+        for (int s = 0; s < nspecs; ++s) {
+            const TsfaSpec sp = specs[s];
+            if (sp.calc != TSFA_C_QUERY_SIMILARITY_COUNT) continue;
+            const int m = (int)sp.p[3];
+            const double v = gen_query_count(b, xv, n, (pool && m > 0) ? pool + (long long)sp.p[2] : nullptr, m, sp.p[0], sp.p[1] != 0.0);
+            if (b.tid == 0) out_row[sp.col] = v;
         }
         blk_sync();
     }

@@ -534,77 +534,96 @@ TSFA_DEV void friedrich_coeffs(const Blk &b, XS xs, int n, S1 srt1, int m, int r
 //   srt  : LDS, >= next_pow2(n) doubles (sorted copy)
 //   w    : LDS, >= 768 doubles (Langevin-fit scratch)
 //   iw   : LDS, >= 2520 ints (ordinal-pattern histogram, two 16-bit counters per word); may alias w
-// change_quantiles (fc.py:1511), every corridor of the plan, four per sweep: the samples are read once per sweep and
-// the 12 + 8 partial sums of a sweep are reduced together (blk_sum_multi).  cq[5 * k ..] = count, mean, mean |.|,
-// var, var |.| of corridor k.
+// change_quantiles (fc.py:1511), every corridor of the plan, four per sweep, ONE pass over the samples per sweep.
+// cq[5 * k ..] = count, mean, mean |.|, var, var |.| of corridor k.
+//   * The corridor edges -- pd.qcut's quantiles, 2 per corridor -- are evaluated once, lane = edge (until round 6 every sweep
+//     evaluated its eight edges one after the other on all lanes: 30 dependent chains of two LDS reads, 22 k of the
+//     calculator's 115 k cycles per 1024-sample series); a sweep reads its eight back as wave-uniform values.
+//   * The variances come from the same pass as the means: sums of (d - s) and (d - s)^2 about a shift known before the pass,
+//     s = the mean change of the whole series (x[n-1] - x[0]) / (n - 1), and |s| for the absolute changes:
+//         mean = s + S1 / c,   var = S2 / c - (S1 / c)^2.
+//     The cancellation in `var` costs eps * (mean - s)^2 <= eps * (4 max|x|)^2, seven decades below the parity bar's absolute
+//     floor for a quadratic feature (tests/parity.py: 1e-9 max|x|^2); a second masked pass about each corridor's own mean
+//     (what np.var does, and what this function did until round 6) doubled the predicate evaluations and the sample reads.
 template <class XS, class SS>
 TSFA_DEV void cq_fill_all(const Blk &b, XS xs, SS srt, int n, const TsfaCqPlan &plan, double *cq) {
     TSFA_TICKER(tkq, 0);
+    // pd.qcut(x, [ql, qh], labels=False) == 0  <=>  lo <= x <= hi  (right-closed, include_lowest)
+    for (int e0 = 0; e0 < 2 * plan.n; e0 += b.nt) {
+        const int e = e0 + b.tid;
+        double q = 0.0;
+#if TSFA_GPU
+        // (the plan is a by-value kernel argument: a lane-indexed read would move it to scratch memory)
+        for (int c = 0; c < plan.n; ++c) {
+            q = (e == c) ? plan.ql[c] : q;
+            q = (e == plan.n + c) ? plan.qh[c] : q;
+        }
+#else
+        if (e < 2 * plan.n) q = (e < plan.n) ? plan.ql[e] : plan.qh[e - plan.n];
+#endif
+        if (e < 2 * plan.n) {
+            const double v = pd_quantile_sorted([=](int i) { return srt[i]; }, n, q);
+            if (e < plan.n) cq[5 * e] = v; else cq[5 * (e - plan.n) + 1] = v;
+        }
+    }
+    blk_sync();
+    double s = (n > 1) ? (xs[n - 1] - xs[0]) / (double)(n - 1) : 0.0;
+    if (!(fabs(s) <= 1.7976931348623157e308)) s = 0.0;   // an infinite end sample must not reach the corridors that exclude it
+    const double sa = fabs(s);
+    TSFA_TICK(tkq, b, 220);
     for (int k0 = 0; k0 < plan.n; k0 += 4) {
         const int ng = (plan.n - k0 < 4) ? (plan.n - k0) : 4;
         double lo[4], hi[4];
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            // pd.qcut(x, [ql, qh], labels=False) == 0  <=>  lo <= x <= hi  (right-closed, include_lowest)
-            // (evaluated uniformly: the edges stay in scalar registers for the sweeps; fetching precomputed edges
-            // from LDS into vector registers measured 20 % slower for the whole kernel)
-            lo[j] = (j < ng) ? pd_quantile_sorted([=](int i) { return srt[i]; }, n, plan.ql[k0 + j]) : TSFA_INF;
-            hi[j] = (j < ng) ? pd_quantile_sorted([=](int i) { return srt[i]; }, n, plan.qh[k0 + j]) : -TSFA_INF;
+            // (wave-uniform: the edges stay in scalar registers for the sweep; as vector operands they measured 20 % slower
+            // for the whole kernel)
+            const int k = (j < ng) ? (k0 + j) : k0;
+            double l = cq[5 * k], h = cq[5 * k + 1];
+#if TSFA_GPU
+            l = readlane_f64(l, 0);
+            h = readlane_f64(h, 0);
+#endif
+            lo[j] = (j < ng) ? l : TSFA_INF;
+            hi[j] = (j < ng) ? h : -TSFA_INF;
         }
-        TSFA_TICK(tkq, b, 220);
-        double s1[12];
+        double a[20];
 #pragma unroll
-        for (int k = 0; k < 12; ++k) s1[k] = 0.0;
+        for (int k = 0; k < 20; ++k) a[k] = 0.0;
         for (int i = b.tid; i < n - 1; i += b.nt) {
             const double x0 = xs[i], x1 = xs[i + 1];
-            const double d = x1 - x0, ad = fabs(d);
+            const double d = x1 - x0;
+            const double dd = d - s, ad = fabs(d) - sa;
+            const double dd2 = dd * dd, ad2 = ad * ad;
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 if (x0 >= lo[j] && x0 <= hi[j] && x1 >= lo[j] && x1 <= hi[j]) {
-                    s1[3 * j] += 1.0;
-                    s1[3 * j + 1] += d;
-                    s1[3 * j + 2] += ad;
+                    a[5 * j] += 1.0;
+                    a[5 * j + 1] += dd;
+                    a[5 * j + 2] += ad;
+                    a[5 * j + 3] += dd2;
+                    a[5 * j + 4] += ad2;
                 }
             }
         }
         TSFA_TICK(tkq, b, 221);
-        blk_sum_multi<12>(b, s1);
+        blk_sum_multi<20>(b, a);
         TSFA_TICK(tkq, b, 222);
-        double m1[4], m2[4];
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            m1[j] = (s1[3 * j] > 0.0) ? s1[3 * j + 1] / s1[3 * j] : 0.0;
-            m2[j] = (s1[3 * j] > 0.0) ? s1[3 * j + 2] / s1[3 * j] : 0.0;
-        }
-        double s2[8];
-#pragma unroll
-        for (int k = 0; k < 8; ++k) s2[k] = 0.0;
-        for (int i = b.tid; i < n - 1; i += b.nt) {
-            const double x0 = xs[i], x1 = xs[i + 1];
-            const double d = x1 - x0, ad = fabs(d);
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                if (x0 >= lo[j] && x0 <= hi[j] && x1 >= lo[j] && x1 <= hi[j]) {
-                    s2[2 * j] += (d - m1[j]) * (d - m1[j]);
-                    s2[2 * j + 1] += (ad - m2[j]) * (ad - m2[j]);
-                }
-            }
-        }
-        TSFA_TICK(tkq, b, 223);
-        blk_sum_multi<8>(b, s2);
-        TSFA_TICK(tkq, b, 224);
-        blk_sync();
+        blk_sync();   // every thread has read this sweep's edges
         if (b.tid == 0) {
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 if (j < ng) {
                     double *o = cq + 5 * (k0 + j);
-                    const double c = s1[3 * j];
+                    const double c = a[5 * j];
+                    const bool any = c > 0.0;
+                    const double m1 = any ? a[5 * j + 1] / c : 0.0, m2 = any ? a[5 * j + 2] / c : 0.0;
                     o[0] = c;
-                    o[1] = m1[j];
-                    o[2] = m2[j];
-                    o[3] = (c > 0.0) ? s2[2 * j] / c : 0.0;
-                    o[4] = (c > 0.0) ? s2[2 * j + 1] / c : 0.0;
+                    o[1] = any ? s + m1 : 0.0;
+                    o[2] = any ? sa + m2 : 0.0;
+                    const double v1 = a[5 * j + 3] / c - m1 * m1, v2 = a[5 * j + 4] / c - m2 * m2;
+                    o[3] = any ? ((v1 < 0.0) ? 0.0 : v1) : 0.0;   // (a NaN stays a NaN: inf - inf changes inside the corridor)
+                    o[4] = any ? ((v2 < 0.0) ? 0.0 : v2) : 0.0;
                 }
             }
         }

@@ -122,6 +122,7 @@ struct tsfa_plan {
     std::vector<TsfaSpec> gen_specs;
     TsfaSpec *d_gen_specs = nullptr;
     TsfaGenPlan gen_plan;
+    double *d_pool = nullptr;                   // array-valued parameters (tsfa_plan_create_with_data): query_similarity_count's queries
     int *d_deg_count = nullptr;
     int *d_cursor = nullptr;                    // per-launch-group fill cursors (k_class_fill)
     hipStream_t s_in = nullptr, s_out = nullptr;  // copy-in / copy-out streams of the host pipeline
@@ -235,6 +236,7 @@ void tsfa_plan_destroy(tsfa_plan *plan) {
     plan->dd_scratch.release();
     plan->gen_scratch.release();
     if (plan->d_gen_specs) (void)hipFree(plan->d_gen_specs);
+    if (plan->d_pool) (void)hipFree(plan->d_pool);
     for (auto &t : plan->timings) {
         if (t.e0) (void)hipEventDestroy(t.e0);
         if (t.e1) (void)hipEventDestroy(t.e1);
@@ -252,9 +254,15 @@ void tsfa_plan_destroy(tsfa_plan *plan) {
 }
 
 int tsfa_plan_create(const tsfa_feature_spec *specs, int32_t n_specs, int32_t device, tsfa_plan **out_plan) {
+    return tsfa_plan_create_with_data(specs, n_specs, nullptr, 0, device, out_plan);
+}
+
+int tsfa_plan_create_with_data(const tsfa_feature_spec *specs, int32_t n_specs, const double *data, int64_t n_data, int32_t device,
+                               tsfa_plan **out_plan) {
     if (!out_plan) return fail(TSFA_ERR_INVALID, "out_plan is NULL");
     *out_plan = nullptr;
     if (n_specs < 0 || (n_specs > 0 && !specs)) return fail(TSFA_ERR_INVALID, "bad specs");
+    if (n_data < 0 || (n_data > 0 && !data)) return fail(TSFA_ERR_INVALID, "bad data pool");
     const int ndev = tsfa_device_count();
     if (ndev <= 0) return fail(TSFA_ERR_NO_DEVICE, "no HIP device visible: tsfresh_amd has no CPU fallback");
     if (device < 0 || device >= ndev) return fail(TSFA_ERR_INVALID, "device ordinal out of range");
@@ -278,6 +286,10 @@ int tsfa_plan_create(const tsfa_feature_spec *specs, int32_t n_specs, int32_t de
         if (!why.empty()) {
             delete plan;
             return fail(TSFA_ERR_UNSUPPORTED, std::string("spec ") + std::to_string(i) + " (" + tsfa_calc_table[s.calc].name + "): " + why);
+        }
+        if (s.calc == TSFA_C_QUERY_SIMILARITY_COUNT && s.p[3] > 0 && !(s.p[2] + s.p[3] <= (double)n_data)) {
+            delete plan;
+            return fail(TSFA_ERR_INVALID, "spec " + std::to_string(i) + " (query_similarity_count): the query lies outside the data pool");
         }
         if (s.calc == TSFA_C_LINEAR_TREND_TIMEWISE) plan->needs_times = true;
         if (s.calc == TSFA_C_CWT_COEFFICIENTS) cwt_coef.push_back(s);
@@ -322,6 +334,7 @@ int tsfa_plan_create(const tsfa_feature_spec *specs, int32_t n_specs, int32_t de
     bool ok = hipStreamCreateWithFlags(&plan->stream, hipStreamNonBlocking) == hipSuccess;
     for (int f = 0; ok && f < TSFA_N_FAMILIES; ++f) ok = upload(plan->fam_specs[f], &plan->d_specs[f]) == 0;
     if (ok) ok = upload(plan->gen_specs, &plan->d_gen_specs) == 0;
+    if (ok && n_data > 0) ok = upload(std::vector<double>(data, data + n_data), &plan->d_pool) == 0;
     if (ok && !cwt_coef.empty()) {
         ok = upload(plan->bank.W, &plan->d_W) == 0 && upload(plan->bank.cols, &plan->d_cols) == 0 &&
              upload(plan->bank.coeff_idx, &plan->d_coeff) == 0;
@@ -1008,7 +1021,7 @@ static int run_batch(tsfa_plan *plan, const void *d_values, int dtype, const dou
         a.maxn = maxn;
         a.stream = st;
         if (record(plan, st, slot, "k_general", true)) return fail(TSFA_ERR_HIP, "event record failed");
-        if (tsfa_launch_general(a, plan->gen_plan, (double *)plan->gen_scratch.p, slot_doubles, slots))
+        if (tsfa_launch_general(a, plan->gen_plan, (double *)plan->gen_scratch.p, slot_doubles, slots, plan->d_pool))
             return fail(TSFA_ERR_HIP, "k_general launch failed");
         if (record(plan, st, slot, "k_general", false)) return fail(TSFA_ERR_HIP, "event record failed");
         ++slot;

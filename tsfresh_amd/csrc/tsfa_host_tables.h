@@ -528,6 +528,7 @@ static inline bool tsfa_spec_beyond_tables(const TsfaSpec &s) {
     case TSFA_C_MAX_LANGEVIN_FIXED_POINT: return p[0] > 3 || p[1] > 64;
     case TSFA_C_LEMPEL_ZIV_COMPLEXITY: return p[0] > 255;
     case TSFA_C_NUMBER_CWT_PEAKS: return p[0] > TSFA_CWTP_TABLE_N;
+    case TSFA_C_QUERY_SIMILARITY_COUNT: return p[3] > 0;   // a query (query=None: the constant NaN column of the BASIC family)
     default: return false;
     }
 }
@@ -551,7 +552,7 @@ static inline void tsfa_general_calcs(const SPEC *specs, int n, bool *general) {
 
 static inline TsfaGenPlan tsfa_prepare_general(const std::vector<TsfaSpec> &specs) {
     TsfaGenPlan g;
-    g.acf_maxlag = -1; g.pacf_maxlag = -1; g.fr_maxr = 0; g.fr_maxm = 0; g.lz = 0; g.cwt_maxw = 0;
+    g.acf_maxlag = -1; g.pacf_maxlag = -1; g.fr_maxr = 0; g.fr_maxm = 0; g.lz = 0; g.cwt_maxw = 0; g.query = 0;
     for (const auto &s : specs) {
         switch (s.calc) {
         case TSFA_C_AGG_AUTOCORRELATION: g.acf_maxlag = std::max(g.acf_maxlag, (int)s.p[1]); break;
@@ -560,6 +561,7 @@ static inline TsfaGenPlan tsfa_prepare_general(const std::vector<TsfaSpec> &spec
         case TSFA_C_MAX_LANGEVIN_FIXED_POINT: g.fr_maxm = std::max(g.fr_maxm, (int)s.p[0]); g.fr_maxr = std::max(g.fr_maxr, (int)s.p[1]); break;
         case TSFA_C_LEMPEL_ZIV_COMPLEXITY: g.lz = 1; break;
         case TSFA_C_NUMBER_CWT_PEAKS: g.cwt_maxw = std::max(g.cwt_maxw, (int)s.p[0]); break;
+        case TSFA_C_QUERY_SIMILARITY_COUNT: g.query += 1; break;
         default: break;
         }
     }
@@ -630,6 +632,9 @@ static inline std::string tsfa_validate_spec(const TsfaSpec &s) {
         if (!(p[1] >= 0)) return "approximate_entropy: Parameter r must be positive.";
         break;
     case TSFA_C_NUMBER_CWT_PEAKS: if (!(is_int(p[0]) && p[0] >= 1 && p[0] <= 65536)) return "number_cwt_peaks: n must be in [1, 65536]"; break;   // (beyond 16: fam_general.h)
+    case TSFA_C_QUERY_SIMILARITY_COUNT:   // (threshold, normalize, offset of the query in the plan's pool, its length; length 0: query=None)
+        if (!(is_int(p[2]) && p[2] >= 0 && is_int(p[3]) && p[3] >= 0 && p[3] <= 16777216.0)) return "query_similarity_count: bad query reference";
+        break;
     default: break;
     }
     return "";

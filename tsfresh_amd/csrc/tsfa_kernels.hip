@@ -1219,7 +1219,8 @@ int tsfa_launch_family_long(const TsfaLaunch &a) {
 template <typename T>
 __global__ void __launch_bounds__(64) k_general(const T *__restrict__ values, const int64_t *__restrict__ starts, const int64_t *__restrict__ ends,
                                                int64_t n_series, const TsfaSpec *__restrict__ specs, int nspecs, double *__restrict__ out, int64_t ld,
-                                               int maxn, const TsfaGenPlan g, double *__restrict__ scratch, size_t slot_doubles) {
+                                               int maxn, const TsfaGenPlan g, double *__restrict__ scratch, size_t slot_doubles,
+                                               const double *__restrict__ pool) {
     __shared__ double red[TSFA_RED_DOUBLES];
     __shared__ NpScratch nps;
     Blk b{(int)threadIdx.x, (int)blockDim.x, red, &nps};
@@ -1229,7 +1230,7 @@ __global__ void __launch_bounds__(64) k_general(const T *__restrict__ values, co
         const int64_t off = starts[sidx];
         const int n = (int)(ends[sidx] - off);
         const T *gv = values + off;
-        fam_general_series(b, [=](int i) { return (double)gv[i]; }, n, specs, nspecs, out + sidx * ld, S, g);
+        fam_general_series(b, [=](int i) { return (double)gv[i]; }, n, specs, nspecs, out + sidx * ld, S, g, pool);
         __syncthreads();
     }
 }
@@ -1239,15 +1240,15 @@ size_t tsfa_general_slot_doubles(int maxn, const TsfaGenPlan &g) {
     return S.carve(nullptr, maxn, g);
 }
 
-int tsfa_launch_general(const TsfaLaunch &a, const TsfaGenPlan &g, double *scratch, size_t slot_doubles, int slots) {
+int tsfa_launch_general(const TsfaLaunch &a, const TsfaGenPlan &g, double *scratch, size_t slot_doubles, int slots, const double *pool) {
     hipStream_t st = (hipStream_t)a.stream;
     const unsigned grid = (unsigned)std::max<int64_t>(1, std::min<int64_t>(a.n_series, slots));
     if (a.dtype == 0)
         k_general<float><<<grid, 64, 0, st>>>((const float *)a.values, a.starts, a.ends, a.n_series, a.specs, a.nspecs, a.out, a.ld, a.maxn, g,
-                                              scratch, slot_doubles);
+                                              scratch, slot_doubles, pool);
     else
         k_general<double><<<grid, 64, 0, st>>>((const double *)a.values, a.starts, a.ends, a.n_series, a.specs, a.nspecs, a.out, a.ld, a.maxn, g,
-                                               scratch, slot_doubles);
+                                               scratch, slot_doubles, pool);
     TSFA_LAUNCH_CHECK();
     return 0;
 }

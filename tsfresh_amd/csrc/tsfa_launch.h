@@ -100,7 +100,7 @@ int tsfa_launch_rows(const TsfaLaunch &a);          // BASIC / TREND: the series
 int tsfa_launch_family_long(const TsfaLaunch &a);   // working set in a.long_scratch instead of LDS (any length <= 65535)
 // k_general (fam_general.h): a.specs / a.nspecs = the plan's GENERAL columns, every series of the batch in one launch
 size_t tsfa_general_slot_doubles(int maxn, const TsfaGenPlan &g);
-int tsfa_launch_general(const TsfaLaunch &a, const TsfaGenPlan &g, double *scratch, size_t slot_doubles, int slots);
+int tsfa_launch_general(const TsfaLaunch &a, const TsfaGenPlan &g, double *scratch, size_t slot_doubles, int slots, const double *pool);
 int tsfa_launch_ar_degenerate(const TsfaLaunch &a);
 int tsfa_launch_langevin_dd(const TsfaLaunch &a);     // second pass of TSFA_FAM_SORT: the ill-conditioned Langevin fits k_sort recorded
 int tsfa_launch_perm(const TsfaLaunch &a);            // beside TSFA_FAM_SORT: every permutation_entropy column (k_perm, fam_perm.h); a.hint_d = (stride << 8) | dimensions, a.nt threads

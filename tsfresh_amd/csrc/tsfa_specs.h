@@ -175,6 +175,7 @@ struct TsfaGenPlan {
     int fr_maxm;       // ... and the largest m
     int lz;            // lempel_ziv_complexity columns
     int cwt_maxw;      // largest n of a number_cwt_peaks column (0: none)
+    int query;         // query_similarity_count columns that hold a query (their samples: the plan's float64 pool)
 };
 
 #define TSFA_AR_TABLE_K 31   // ar_coefficient orders of k_ar's float64 first pass (fam_ar.h: arres, 40 doubles); larger ones are fitted

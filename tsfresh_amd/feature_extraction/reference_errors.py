@@ -14,6 +14,10 @@ with +inf / -inf planted at several positions, `tests/golden/gen_golden_nonfinit
   the fit to be set up (n >= 2 k + 1; shorter series raise the ValueError that fc.py:1496 catches -> NaN).  -inf does
   not raise (statsmodels tests the column maxima, base/data.py `_handle_constant`): the columns are NaN, as here.
 
+* `query_similarity_count` with a query of m >= 3 samples (fc.py:2513-2516): `stumpy.core.mass` /  `mass_absolute` check the
+  window size first (core.check_window_size) -> ``ValueError("The window size must be less than or equal to {len(x)}")`` for
+  a series shorter than the query.  (stumpy is not installed in the build image: the text is its published one, unpinned.)
+
 The kernels never raise: `binned_entropy` writes NaN for a non-finite range (tsfa_common.h: blk_binned_entropy) and the
 AR sums of such a series are NaN.  This module looks at those cells of the finished matrix -- a few columns, no pass over
 the samples -- and only for rows that hold a NaN there goes back to the series to decide whether the reference would have
@@ -36,6 +40,28 @@ def _nan_rows(matrix, cols):
     return np.flatnonzero(np.isnan(sub).any(axis=1))
 
 
+def _query_candidates(specs, starts, ends):
+    qs = [(j, int(p[3])) for j, (name, p) in enumerate(specs) if name == "query_similarity_count" and len(p) > 3 and p[3] >= 3]
+    if not qs:
+        return []
+    lengths = np.asarray(ends, dtype=np.int64) - np.asarray(starts, dtype=np.int64)
+    out = []
+    for j, m in qs:   # per series the reference evaluates the parameter sets in list order: the first too-long query raises
+        rows = np.flatnonzero(lengths < m)
+        if len(rows):
+            r = int(rows[0])
+            out.append((r, j, ValueError("The window size must be less than or equal to {}".format(int(lengths[r])))))
+    return out
+
+
+def check_query_lengths(specs, starts, ends):
+    """query_similarity_count alone: raises for the first series that is shorter than a query of the plan."""
+    c = _query_candidates(specs, starts, ends)
+    if c:
+        c.sort(key=lambda t: (t[0], t[1]))
+        raise c[0][2]
+
+
 def check_reference_data_errors(specs, matrix, values, starts, ends):
     """specs: [(calculator name, p)] aligned with the columns of `matrix` (FeaturePlan.specs); series i =
     values[starts[i]:ends[i]].  Raises what the reference raises for the first series it cannot evaluate; else returns."""
@@ -45,9 +71,9 @@ def check_reference_data_errors(specs, matrix, values, starts, ends):
     ar = [(j, int(p[1])) for j, (name, p) in enumerate(specs) if name == "ar_coefficient"]
     # a coefficient beyond the order is NaN for every series (fc.py:1503-1506): such a column says nothing about the fit
     ar_fit = [j for j, (name, p) in enumerate(specs) if name == "ar_coefficient" and 0 <= int(p[0]) <= int(p[1])]
-    if not be_cols and not ar:
+    candidates = _query_candidates(specs, starts, ends)   # (row, first column of the calculator, exception)
+    if not be_cols and not ar and not candidates:
         return
-    candidates = []   # (row, first column of the calculator, exception)
     for r in _nan_rows(matrix, be_cols):
         x = np.asarray(values[starts[r]:ends[r]], dtype=np.float64)
         lo, hi = x.min(), x.max()

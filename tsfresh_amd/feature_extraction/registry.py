@@ -12,6 +12,8 @@ The ORDER of this table is the definition order of the functions in the referenc
 """
 from collections import OrderedDict
 
+import numpy as np
+
 from tsfresh_amd.utilities.string_manipulation import convert_to_output_format
 
 ATTR_LINREG = {"pvalue": 0, "rvalue": 1, "intercept": 2, "slope": 3, "stderr": 4}
@@ -199,10 +201,16 @@ CALCULATORS = OrderedDict((c.name, c) for c in _CALCS)
 
 
 def _query_similarity_encode(p):
+    """(threshold, normalize, 0, len(Q)) + Q: the tail is the ARRAY parameter; `_native.Plan` moves it to the plan's float64
+    pool and writes its offset to p[2] (include/tsfresh_amd.h: tsfa_plan_create_with_data).  fc.py:2475-2519:
+    Q = np.asarray(query).astype(float); fewer than three samples (or query=None) -> np.nan for every series."""
     q = p.get("query", None)
-    if q is not None:
-        raise UnsupportedFeature("query_similarity_count with a query subsequence has no native kernel")
-    return (0.0,)
+    thr = float(p.get("threshold", 0.0))
+    norm = 1.0 if p.get("normalize", True) else 0.0
+    if q is None:
+        return (thr, norm, 0.0, 0.0)
+    qa = np.asarray(q).astype(float).ravel()
+    return (thr, norm, 0.0, float(qa.size)) + tuple(float(v) for v in qa)
 
 
 CALCULATORS["query_similarity_count"]._encode = _query_similarity_encode
