@@ -368,22 +368,40 @@ TSFA_DEV void entb_totals(const Blk &b, int kn, int k0, double *pm, double *pm1,
         }
     }
     blk_sync();
-    // one logarithm per partial product -- by as many lanes as there are products (a float64 log is ~150 instructions)
-    if (b.tid < 2 * kn * nrows) part[b.tid] = log(part[b.tid]);
+    // one logarithm per partial product -- by as many lanes as there are products (a float64 log is ~150 instructions) -- and,
+    // in the same instruction stream, log N of the two template counts by the two lanes behind them (round 6: they used to
+    // be evaluated by the closing lanes, 300 instructions on the one wavefront everybody waits for)
+    double *lslot = (double *)(void *)(islot + (((size_t)nw * 2 * K + 1) & ~(size_t)1));
+    {
+        const int nlog = 2 * kn * nrows;
+        if (b.tid < nlog + 2) {
+            const double arg = (b.tid < nlog) ? part[b.tid] : (double)((b.tid == nlog) ? nrow_m : nrow_m1);
+            const double lg = log(arg);
+            if (b.tid < nlog) part[b.tid] = lg; else lslot[b.tid - nlog] = lg;
+        }
+    }
     blk_sync();
-    if (b.tid < 2 * kn) {  // value j = 2 k + (0: m, 1: m + 1)
-        // log N of the two template counts, by the dozen lanes that use them (a float64 logarithm is ~150 instructions:
-        // evaluated at the top of the function it was paid by all eight wavefronts, 2.4 k wave-instructions per series)
-        const double ldm = log((double)nrow_m), ldm1 = log((double)nrow_m1);
-        const int k = b.tid >> 1, odd = b.tid & 1;
+    for (int j0 = 0; j0 < 2 * kn; j0 += nrows) {  // value j = 2 k + (0: m, 1: m + 1) on the 16 lanes of a DPP row (nrows rows)
+        // (round 6: the row's lanes add the partial logarithms -- one lane used to walk all nt / 16 of them, a chain of
+        // dependent LDS reads at the tail of every series)
+        const int j = j0 + (b.tid >> 4), l16 = b.tid & 15;
+        if (j >= 2 * kn) continue;   // (whole rows: the DPP partners of a live lane are live)
+        const int k = j >> 1, odd = j & 1;
         double a = 0.0;
-        for (int r = 0; r < nrows; ++r) a += part[b.tid * nrows + r];
-        unsigned int tot_c = 0u, tot_n = 0u;   // a wavefront's packed word holds sum C < 2^21 and #rows < 2^11; the block's may not
-        for (int w = 0; w < nw; ++w) { const unsigned int t = islot[w * 2 * K + b.tid]; tot_c += t & 0x1FFFFFu; tot_n += t >> 21; }
-        double *d = racc + 4 * (k0 + k);
-        const double v = a - (double)tot_n * (odd ? ldm1 : ldm), c = (double)tot_c;
-        if (accumulate) { d[odd] += v; d[2 + odd] += c; }
-        else { d[odd] = v; d[2 + odd] = c; }
+        for (int r = l16; r < nrows; r += 16) a += part[j * nrows + r];
+        a += dpp_mov_f64<TSFA_DPP_QUAD_XOR1>(a);
+        a += dpp_mov_f64<TSFA_DPP_QUAD_XOR2>(a);
+        a += dpp_mov_f64<TSFA_DPP_ROW_HALF_MIRROR>(a);
+        a += dpp_mov_f64<TSFA_DPP_ROW_MIRROR>(a);
+        if (l16 == 0) {
+            const double ldm = lslot[0], ldm1 = lslot[1];
+            unsigned int tot_c = 0u, tot_n = 0u;   // a wavefront's packed word holds sum C < 2^21 and #rows < 2^11; the block's may not
+            for (int w = 0; w < nw; ++w) { const unsigned int t = islot[w * 2 * K + j]; tot_c += t & 0x1FFFFFu; tot_n += t >> 21; }
+            double *d = racc + 4 * (k0 + k);
+            const double v = a - (double)tot_n * (odd ? ldm1 : ldm), c = (double)tot_c;
+            if (accumulate) { d[odd] += v; d[2 + odd] += c; }
+            else { d[odd] = v; d[2 + odd] = c; }
+        }
     }
     blk_sync();
 #else

@@ -38,7 +38,7 @@ static inline TSFA_ENTB_HD size_t entb_work_words(int maxn, int S = TSFA_ENTB_S,
     while (p2 < (size_t)maxn) p2 <<= 1;
     const size_t ranges = 2 * p2 + (size_t)kcap * maxn;  // sorted copy (float64, padded) + packed ranges of a round
     const size_t table = (size_t)(maxn + 1) * S + (size_t)TSFA_ENTB_MAXWAVES * S;
-    const size_t counts = (size_t)kcap * maxn + 2 * (2 * TSFA_ENTB_MAXK * TSFA_ENTB_MAXWAVES * 4) + 2 * TSFA_ENTB_MAXK * TSFA_ENTB_MAXWAVES + 4;  // + partial products, integer slots
+    const size_t counts = (size_t)kcap * maxn + 2 * (2 * TSFA_ENTB_MAXK * TSFA_ENTB_MAXWAVES * 4) + 2 * TSFA_ENTB_MAXK * TSFA_ENTB_MAXWAVES + 12;  // + partial products, integer slots, log N of the two template counts
     size_t w = ranges > table ? ranges : table;
     if (counts > w) w = counts;
     return w + 8;
