@@ -28,3 +28,7 @@ for l in open("$O/configs.jsonl"):
     print(d["config"]["workload"][:90], "|", round(d["ms_per_step"], 3), "ms |", round(d["value"]), "series/s | roofline", d["roofline"]["kernel"], round(d["roofline"]["frac"], 4), d.get("parity_sample"))
 PY
 rm -rf $O/prof gpurun_out/hbm/*/
+# device fuzz of this build: standard + random parameter sets + extreme magnitudes
+timeout 900 python profiles/fuzz_parity.py 40 4242 > $O/fuzz_std.log 2>&1; tail -1 $O/fuzz_std.log
+TSFA_FUZZ_EXTREME=1 timeout 600 python profiles/fuzz_parity.py 25 777 > $O/fuzz_extreme.log 2>&1; tail -1 $O/fuzz_extreme.log
+grep -h "mismatches [1-9]\|UNWRITTEN" $O/fuzz_*.log | cut -c1-300 | head

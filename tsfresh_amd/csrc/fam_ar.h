@@ -353,13 +353,26 @@ TSFA_DEV int ar_scratch_doubles(int P) { return 2 * P * P + 7 * P + 64 + 16 + 48
 // the refinement step both regressions take anyway: its correction IS the error of the first solve.  A correction above
 // 1e-8 of the solution (both weighted by the column norms) lists the series for the double-double pass.
 #define TSFA_AR_REFINE_TOL 1e-8
-TSFA_DEV bool ar_refinement_suspect(const double *beta, const double *corr, const double *diag0, int p) {
+TSFA_DEV bool ar_refinement_suspect(const Blk &b, const double *beta, const double *corr, const double *diag0, int p) {
     double mb = 0.0, mc = 0.0;
-    for (int a = 0; a < p; ++a) {   // uniform: every thread reads the same LDS values
+#if TSFA_GPU
+    // lane = regressor, the two maxima by a wavefront reduction (a maximum does not depend on the order: the same bits as the
+    // loop below, which every lane used to walk -- a float64 square root per regressor, ~35 instructions each)
+    for (int a = b.tid & 63; a < p; a += 64) {
         const double w = sqrt(diag0[a]);
         mb = fmax(mb, fabs(beta[a]) * w);
         mc = fmax(mc, fabs(corr[a]) * w);
     }
+    mb = wave_max(mb);
+    mc = wave_max(mc);
+#else
+    (void)b;
+    for (int a = 0; a < p; ++a) {
+        const double w = sqrt(diag0[a]);
+        mb = fmax(mb, fabs(beta[a]) * w);
+        mc = fmax(mc, fabs(corr[a]) * w);
+    }
+#endif
     return mc > TSFA_AR_REFINE_TOL * mb;
 }
 
@@ -680,7 +693,7 @@ TSFA_DEV int fam_ar_series(const Blk &b, X xv, int n, const TsfaSpec *specs, int
                     blk_sync();
                     blk_chol_solve(b, G, p2, P, tmp1, tmp2);
                     blk_sync();
-                    if (ar_refinement_suspect(beta, tmp2, diag0, p2)) degenerate |= 2;
+                    if (ar_refinement_suspect(b, beta, tmp2, diag0, p2)) degenerate |= 2;
                     blk_sync();
                     for (int a = b.tid; a < p2; a += b.nt) beta[a] += tmp2[a];
                     blk_sync();
@@ -899,7 +912,7 @@ TSFA_DEV int fam_ar_series(const Blk &b, X xv, int n, const TsfaSpec *specs, int
                     blk_sync();
                     blk_chol_solve(b, G, p, P, tmp1, tmp2);
                     blk_sync();
-                    if (ar_refinement_suspect(beta, tmp2, diag0, p)) degenerate |= 1;
+                    if (ar_refinement_suspect(b, beta, tmp2, diag0, p)) degenerate |= 1;
                     blk_sync();
                     if (b.tid == 0) {
                         double sphi = 0.0;
