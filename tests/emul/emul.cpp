@@ -251,7 +251,7 @@ extern "C" int tsfa_emul_extract_timed(const tsfa_feature_spec *specs, int n_spe
                 if (sp.calc == TSFA_C_APPROXIMATE_ENTROPY && (int)sp.p[0] != 2) all_m2 = false;
             const char *force = getenv("TSFA_EMUL_ENTROPY");  // "bits" / "pairs": one sweep for every series
             const bool bits = all_m2 && n <= TSFA_ENTB_MAXN_LONG && (force ? !strcmp(force, "bits") : (s % 4 == 2 || n > TSFA_ENTB_MAXN));
-            if (bits && n <= TSFA_ENTB_MAXN) {  // the bit-matrix sweep (k_entropy_bits)
+            if (bits && n <= TSFA_ENTB_MAXN_WIDE) {  // the bit-matrix sweep (k_entropy_bits), 48-byte table entries
                 std::vector<unsigned int> work(entb_work_words(n) + 64);
                 poison_int(work);
                 fam_entropy_series_bits<false>(b, xe.data(), n, fam[TSFA_FAM_ENTROPY].data(), (int)fam[TSFA_FAM_ENTROPY].size(),

@@ -118,3 +118,26 @@ def test_extract_features_with_a_query():
     assert X.columns[0].startswith("v__query_similarity_count__query_[")
     with pytest.raises(ValueError, match="window size must be less than or equal to"):
         extract_features(df[df["t"] < 8], column_id="id", column_sort="t", default_fc_parameters=fc, disable_progressbar=True)
+
+
+@pytest.mark.gpu
+def test_a_query_outside_the_data_pool_is_refused():
+    """tsfa_plan_create_with_data (include/tsfresh_amd.h): p[2] / p[3] must lie inside the pool; tsfa_plan_create is the
+    case of an empty pool, so a spec that names a query there is refused as well."""
+    import ctypes
+    from tsfresh_amd import _native
+    lib = _native.load()
+    spec = (_native.FeatureSpec * 1)()
+    spec[0].calc = _native.calc_id("query_similarity_count")
+    for k, v in enumerate((0.0, 1.0, 2.0, 5.0)):   # offset 2, length 5
+        spec[0].p[k] = v
+    pool = np.arange(6, dtype=np.float64)           # 2 + 5 > 6
+    h = ctypes.c_void_p()
+    rc = lib.tsfa_plan_create_with_data(spec, 1, pool.ctypes.data, len(pool), 0, ctypes.byref(h))
+    assert rc == _native.TSFA_ERR_INVALID and b"outside the data pool" in lib.tsfa_last_error()
+    rc = lib.tsfa_plan_create(spec, 1, 0, ctypes.byref(h))
+    assert rc == _native.TSFA_ERR_INVALID
+    pool = np.arange(7, dtype=np.float64)
+    rc = lib.tsfa_plan_create_with_data(spec, 1, pool.ctypes.data, len(pool), 0, ctypes.byref(h))
+    assert rc == 0
+    lib.tsfa_plan_destroy(h)

@@ -417,6 +417,137 @@ TSFA_DEV void entb_totals(const Blk &b, int kn, int k0, double *pm, double *pm1,
 #endif
 }
 
+// Totals of one round's kn tolerances from the counters cnt[k * n + i] = C_2 | C_3 << 16 (see entropy_bits_batch): products of
+// the counts per thread and DPP row, one logarithm per row of lanes.  part: LDS behind the counters.
+TSFA_DEV void entb_round_totals(const Blk &b_in, const unsigned int *cnt, double *part, int n, int kn, int k0, int nrow_m,
+                                int nrow_m1, double *racc) {
+    const Blk b = entb_opaque(b_in);
+    const int K = TSFA_ENTB_MAXK;
+    double pm[TSFA_ENTB_MAXK], pm1[TSFA_ENTB_MAXK];
+    int sc[TSFA_ENTB_MAXK], sc1[TSFA_ENTB_MAXK], nm[TSFA_ENTB_MAXK], nm1[TSFA_ENTB_MAXK];
+    // (a thread multiplies at most four counts before the lanes combine theirs: longer rows go in chunks)
+    for (int c0 = 0; c0 < nrow_m; c0 += 4 * b.nt) {
+#pragma unroll
+        for (int k = 0; k < K; ++k) { pm[k] = 1.0; pm1[k] = 1.0; sc[k] = 0; sc1[k] = 0; nm[k] = 0; nm1[k] = 0; }
+        for (int ib = c0; ib < nrow_m && ib < c0 + 4 * b.nt; ib += b.nt) {
+            const int i = ib + b.tid;
+#pragma unroll
+            for (int k = 0; k < K; ++k) {
+                if (k < kn && i < nrow_m) {
+                    const unsigned int cc = cnt[k * n + i];
+                    const int t2 = (int)(cc & 0xFFFFu), t3 = (int)(cc >> 16);
+                    sc[k] += t2;
+                    if (t2 != nrow_m) { pm[k] *= (double)t2; ++nm[k]; }
+                    if (i < nrow_m1) {
+                        sc1[k] += t3;
+                        if (t3 != nrow_m1) { pm1[k] *= (double)t3; ++nm1[k]; }
+                    }
+                }
+            }
+        }
+        entb_totals(b, kn, k0, pm, pm1, sc, sc1, nm, nm1, nrow_m, nrow_m1, part, racc, c0 > 0);
+    }
+}
+
+#if TSFA_GPU
+// Series of 2049 .. 4096 samples (16-byte table entries, TSFA_ENTB_QW_LONG): the tasks of a round of three tolerances fill
+// the 14 register slots of a wavefront, so six tolerances used to take two rounds -- and every round rebuilds all 43 column
+// parts (a table build and three barriers each; one workgroup of sixteen wavefronts per CU: the barriers are what the
+// kernel waits for).  Here the ranges of TWO rounds are found one after the other (the work region holds one round's) and kept
+// in registers together -- a range as ONE packed word (two 16-bit word offsets, unpacked per part: three instructions
+// beside a sweep of ~25) -- and the parts are built and swept once for both.  Counters and totals again round by round.
+template <int QW_>
+TSFA_DEV void entropy_bits_batch_paired(const Blk &b, const double *xs, int n, const double *thr, int nk,
+                                        const unsigned short *perm, unsigned int *work, double *racc, int kround) {
+    constexpr int S = QW_ + 1, QW = QW_, MT = TSFA_ENTB_MAXT;
+    const int nrow_m = n - 1, nrow_m1 = n - 2;
+    const int NW = (n + 32) >> 5;
+    const int nparts = (NW + QW - 1) / QW;
+    const int nstrips = ((nrow_m + TSFA_ENTB_STRIP - 1) / TSFA_ENTB_STRIP + 1) / 2;
+    unsigned int *rng = work + 2 * (size_t)next_pow2(n);
+    unsigned int *table = work;
+    unsigned int *wtot = work + (size_t)(n + 1) * S;
+    unsigned int *cnt = work;
+    const int kcap = kround;
+    const int lane = b.tid & 63, wave = __builtin_amdgcn_readfirstlane(b.tid >> 6), nw = b.nt >> 6;
+    const unsigned int tbase = entb_lds_addr(table), sh = (unsigned int)(lane & 31);
+    const int lane_row = (lane >> 5) * TSFA_ENTB_STRIP + (lane & 31);
+    for (int k0 = 0; k0 < nk; k0 += 2 * kround) {
+        unsigned int rr[2 * MT], ct[2 * MT];
+        int kn_g[2], ntask_g[2];
+        unsigned int kmagic_g[2];
+#pragma unroll
+        for (int g = 0; g < 2; ++g) {
+            const int kb = k0 + g * kround;
+            int kn = nk - kb;
+            kn = (kn > kround) ? kround : kn;
+            kn = (kn < 0) ? 0 : kn;
+            kn_g[g] = kn;
+            ntask_g[g] = nstrips * kn;
+            kmagic_g[g] = 65536u / (unsigned int)(kn > 0 ? kn : 1) + 1u;
+            if (kn > 0) {
+                blk_sync();   // the work region held the other round's ranges / the previous pair's counters
+                entb_ranges<QW_ + 1>(b, xs, n, thr + kb, kn, perm, (double *)(void *)work, rng);
+            }
+#pragma unroll
+            for (int tt = 0; tt < MT; ++tt) {
+                const int id = wave + tt * nw;
+                unsigned int r = 0u;
+                if (id < ntask_g[g]) {
+                    const int s = (int)(((unsigned int)id * kmagic_g[g]) >> 16), k = id - s * kn;
+                    const int i = s * (2 * TSFA_ENTB_STRIP) + lane_row;
+                    r = (i < n) ? rng[k * n + i] : 0u;
+                }
+                rr[g * MT + tt] = r;
+                ct[g * MT + tt] = 0u;
+            }
+        }
+        blk_sync();
+        for (int part = 0; part < nparts; ++part) {
+            entb_build_table<QW_ + 1>(b, n, perm, part * QW, NW, table, wtot);
+            const int nq = (NW - part * QW < QW) ? (NW - part * QW) : QW;
+            if (nq == QW) {
+#pragma unroll
+                for (int t2 = 0; t2 < 2 * MT; ++t2) {
+                    if (wave + (t2 % MT) * nw < ntask_g[t2 / MT]) {
+                        const unsigned int r = rr[t2];
+                        ct[t2] += entb_task_part<QW_, true>(tbase + 4u * (r & 0xFFFFu), tbase + 4u * (r >> 16), sh, nq);
+                    }
+                }
+            } else {
+#pragma unroll
+                for (int t2 = 0; t2 < 2 * MT; ++t2) {
+                    if (wave + (t2 % MT) * nw < ntask_g[t2 / MT]) {
+                        const unsigned int r = rr[t2];
+                        ct[t2] += entb_task_part<QW_, false>(tbase + 4u * (r & 0xFFFFu), tbase + 4u * (r >> 16), sh, nq);
+                    }
+                }
+            }
+            blk_sync();
+        }
+#pragma unroll
+        for (int g = 0; g < 2; ++g) {
+            if (kn_g[g] > 0) {
+                const int kn = kn_g[g];
+#pragma unroll
+                for (int tt = 0; tt < MT; ++tt) {
+                    const int id = wave + tt * nw;
+                    if (id < ntask_g[g]) {
+                        const int s = (int)(((unsigned int)id * kmagic_g[g]) >> 16), k = id - s * kn;
+                        const int i = s * (2 * TSFA_ENTB_STRIP) + lane_row;
+                        if ((lane & 31) < TSFA_ENTB_STRIP && i < nrow_m) cnt[k * n + i] = ct[g * MT + tt];
+                    }
+                }
+                blk_sync();
+                entb_round_totals(b, cnt, (double *)(void *)(cnt + (((size_t)kcap * n + 1) & ~(size_t)1)), n, kn, k0 + g * kround,
+                                  nrow_m, nrow_m1, racc);
+                blk_sync();
+            }
+        }
+    }
+}
+#endif
+
 // ---------------------------------------------------------------------------------------------------------------
 // One batch of nk <= TSFA_ENTB_MAXK tolerances (thr[0 .. nk), any order): racc[4 k .. 4 k + 3] = sum log(C_2 / (n-1)),
 // sum log(C_3 / (n-2)), sum C_2, sum C_3 of tolerance k -- the totals the pair sweeps deliver.
@@ -450,6 +581,10 @@ TSFA_DEV void entropy_bits_batch(const Blk &b_in, const double *xs, int n, const
     if (kround < 1) kround = 1;  // (the host never selects this sweep for such a shape; the counts below stay correct
                                  //  only for nstrips <= MAXT * nw)
     const int kcap = kround;     // tolerances per round: the ranges / counters of ONE round live in the work region
+    if (QW_ != TSFA_ENTB_QW && nk > kround) {   // two rounds' tasks in registers, the column parts built once for both
+        entropy_bits_batch_paired<QW_>(b, xs, n, thr, nk, perm, work, racc, kround);
+        return;
+    }
     for (int k0 = 0; k0 < nk; k0 += kround) {
         const int kn = (nk - k0 < kround) ? (nk - k0) : kround;
         const int ntask = nstrips * kn;
@@ -560,35 +695,7 @@ TSFA_DEV void entropy_bits_batch(const Blk &b_in, const double *xs, int n, const
         //      (< 2^1024 up to 92 factors), and ONE logarithm is taken per row of lanes -- in a second step, by as many
         //      lanes as there are partial products (a float64 log is ~150 instructions: per thread it would cost more
         //      than the sweep of a column part).  Rows with C_i == N contribute exactly 0, as in the reference.
-        {
-            const Blk b = entb_opaque(b_in);
-            const int K = TSFA_ENTB_MAXK;
-            double pm[TSFA_ENTB_MAXK], pm1[TSFA_ENTB_MAXK];
-            int sc[TSFA_ENTB_MAXK], sc1[TSFA_ENTB_MAXK], nm[TSFA_ENTB_MAXK], nm1[TSFA_ENTB_MAXK];
-            double *part = (double *)(void *)(cnt + (((size_t)kcap * n + 1) & ~(size_t)1));  // [2 K][nt / 16]
-            // (a thread multiplies at most four counts before the lanes combine theirs: longer rows go in chunks)
-            for (int c0 = 0; c0 < nrow_m; c0 += 4 * b.nt) {
-#pragma unroll
-                for (int k = 0; k < K; ++k) { pm[k] = 1.0; pm1[k] = 1.0; sc[k] = 0; sc1[k] = 0; nm[k] = 0; nm1[k] = 0; }
-                for (int ib = c0; ib < nrow_m && ib < c0 + 4 * b.nt; ib += b.nt) {
-                    const int i = ib + b.tid;
-#pragma unroll
-                    for (int k = 0; k < K; ++k) {
-                        if (k < kn && i < nrow_m) {
-                            const unsigned int cc = cnt[k * n + i];
-                            const int t2 = (int)(cc & 0xFFFFu), t3 = (int)(cc >> 16);
-                            sc[k] += t2;
-                            if (t2 != nrow_m) { pm[k] *= (double)t2; ++nm[k]; }
-                            if (i < nrow_m1) {
-                                sc1[k] += t3;
-                                if (t3 != nrow_m1) { pm1[k] *= (double)t3; ++nm1[k]; }
-                            }
-                        }
-                    }
-                }
-                entb_totals(b, kn, k0, pm, pm1, sc, sc1, nm, nm1, nrow_m, nrow_m1, part, racc, c0 > 0);
-            }
-        }
+        entb_round_totals(b_in, cnt, (double *)(void *)(cnt + (((size_t)kcap * n + 1) & ~(size_t)1)), n, kn, k0, nrow_m, nrow_m1, racc);
         blk_sync();
     }
     TSFA_TICK(tk, b, 134);

@@ -760,9 +760,14 @@ static int run_batch(tsfa_plan *plan, const void *d_values, int dtype, const dou
                 // rows instead of a distance per pair; one (strip, tolerance) task per wavefront register slot
                 // (a single tolerance: the windowed pair sweep is the cheaper one -- 7.7 vs 9.0 ms per 100k x 1024 -- the sample
                 //  sort, the table and the ranges do not amortise)
-                if (a.ent_fast && a.nspecs >= 2 && maxn <= TSFA_ENTB_MAXN && maxn >= 3 &&
-                    plan->opt.entropy_route == 0 &&
-                    tsfa_entropy_lds_bytes(maxn, 2) <= TSFA_LDS_LIMIT / 2) {
+                // (1025 .. TSFA_ENTB_MAXN_WIDE samples, round 6: the same 48-byte-entry sweep with one workgroup per CU -- the
+                //  16-byte-entry form below builds 22 column parts at 2048 samples, this one 6, and the kernel waits for the
+                //  barriers around a build more than for its instructions: profiles/r06_w)
+                const bool entb_wide = maxn > TSFA_ENTB_MAXN && maxn <= TSFA_ENTB_MAXN_WIDE &&
+                                       tsfa_entropy_lds_bytes(maxn, 2) <= TSFA_LDS_LIMIT &&
+                                       entb_kround(maxn, std::min(a.nspecs, TSFA_ENTB_MAXK), TSFA_ENTB_MAXWAVES) >= std::min(a.nspecs, TSFA_ENTB_MAXK);
+                if (a.ent_fast && a.nspecs >= 2 && maxn >= 3 && plan->opt.entropy_route == 0 &&
+                    ((maxn <= TSFA_ENTB_MAXN && tsfa_entropy_lds_bytes(maxn, 2) <= TSFA_LDS_LIMIT / 2) || entb_wide)) {
                     a.ent_cnt = 2;
                     a.nt = 64 * std::min(TSFA_ENTB_MAXWAVES, entb_waves_for(maxn, a.nspecs));
                     if (TSFA_LAB_ONLY(plan->opt.nt[f] >= 64)) a.nt = plan->opt.nt[f];
@@ -880,7 +885,7 @@ static int run_batch(tsfa_plan *plan, const void *d_values, int dtype, const dou
                 }
             }
             if (perm_share && !use_long && g <= TSFA_N_LEN_CLASSES) {
-                if (f == TSFA_FAM_ENTROPY && a.ent_cnt == 2) {
+                if (f == TSFA_FAM_ENTROPY && a.ent_cnt == 2 && maxn <= TSFA_ENTB_MAXN) {   // (the shared order: rows of TSFA_ENTB_MAXN entries)
                     a.perm_buf = (unsigned short *)plan->perm_buf.p;
                     a.perm_stride = TSFA_ENTB_MAXN;
                     perm_valid[g] = true;

@@ -17,6 +17,8 @@
 #define TSFA_ENTB_MAXK 6                  // tolerances per batch
 #define TSFA_ENTB_STRIP 30                // templates per half-strip (32 lanes, two halo lanes); a wavefront sweeps two
 #define TSFA_ENTB_MAXN 1024
+#define TSFA_ENTB_MAXN_WIDE 2048          // ... and to here with ONE workgroup per CU (round 6): 6 column parts instead of the 22 of the
+                                          // 16-byte-entry form, every tolerance's tasks still in the registers of 16 wavefronts
 #define TSFA_ENTB_MAXN_LONG 4096          // beyond: the series, its sorted copy and the ranges of one tolerance exceed a CU's LDS
 #define TSFA_ENTB_MAXWAVES 16
 #define TSFA_ENTH_S 2                     // fam_entropy_hbits.h: words per table entry: one diagonal word + its halo
