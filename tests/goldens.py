@@ -67,12 +67,22 @@ def align(names_want, names_got, got):
     return got[:, idx]
 
 
-def check_engine(engine, pair, fc_parameters):
-    """-> (mismatches, skipped cells, total cells) of `engine` against the fixture pair."""
+def check_engine(engine, pair, fc_parameters, max_len=None):
+    """-> (mismatches, skipped cells, total cells) of `engine` against the fixture pair.
+    max_len: compare only the series of at most that many samples (the single-thread emulation of the slow general kernel on
+    8192-sample series is a minute per test; the device tests compare every row)."""
     from parity import compare
     g = load(pair)
-    got_names, got = engine(fc_parameters, g["values"], g["offsets"])
+    values, offsets, series, matrix, ar_sv = g["values"], g["offsets"], g["series"], g["matrix"], g["ar_sv"]
+    if max_len is not None:
+        keep = [i for i, x in enumerate(series) if len(x) <= max_len]
+        series = [series[i] for i in keep]
+        values = np.concatenate(series)
+        offsets = np.concatenate([[0], np.cumsum([len(x) for x in series])]).astype(np.int64)
+        matrix = matrix[keep]
+        ar_sv = {k: v[keep] for k, v in ar_sv.items()}
+    got_names, got = engine(fc_parameters, values, offsets)
     skipped = []
-    bad = compare(g["names"], align(g["names"], got_names, got), g["matrix"], g["series"], simd_golden=g["simd"],
-                  skipped=skipped, ar_sv=g["ar_sv"] or None)
-    return bad, skipped, g["matrix"].size
+    bad = compare(g["names"], align(g["names"], got_names, got), matrix, series, simd_golden=g["simd"],
+                  skipped=skipped, ar_sv=ar_sv or None)
+    return bad, skipped, matrix.size

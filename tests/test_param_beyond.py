@@ -35,7 +35,8 @@ def test_fixture_has_every_column_of_the_set():
 def test_engine_matches_the_reference_beyond_the_tables(engine, pair):
     if engine is oracle_engine and pair == "long_beyond":
         pytest.skip("the oracle's number_cwt_peaks of 30 widths on 8192-sample series: minutes per series")
-    bad, skipped, cells = goldens.check_engine(engine, pair, beyond_parameters())
+    # (the emulation of k_general on the 5000 .. 8192-sample series of the long set: a minute; the device test takes them all)
+    bad, skipped, cells = goldens.check_engine(engine, pair, beyond_parameters(), max_len=4100 if pair == "long_beyond" else None)
     assert not bad, "%d mismatches, first: %s" % (len(bad), bad[:10])
     assert len(skipped) <= SETS[pair] * cells, (len(skipped), cells)
 
